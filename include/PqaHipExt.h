@@ -1,0 +1,82 @@
+/*
+ * PqaHipExt.h -- additive exports of libPqaCore.so (MI355X build).  Nothing here exists in the reference; unchanged
+ * wrappers never need it.  It exposes (a) the deterministic outputs of the hot path, which the reference hides
+ * behind a random draw (PqaCore/CpuEngine.cpp:379), so that parity can be checked; (b) bulk KB transfer for tests and
+ * benchmarks; (c) stream-ordered (no host sync) entry points and question-axis sharding for multi-GPU hosts.
+ * Same conventions as PqaCInterop.h: void* returns are NULL or a PqaError*.
+ */
+#ifndef PQA_HIP_EXT_H
+#define PQA_HIP_EXT_H
+
+#include "PqaCInterop.h"
+
+#pragma pack(push, 8)
+typedef struct {
+  int64_t _qFirst;   /* first GLOBAL question index held by this engine */
+  int64_t _qTotal;   /* global number of questions (== _nQuestions of the definition when unsharded) */
+  int32_t _device;   /* HIP device ordinal, -1 = current device */
+  int32_t _reserved;
+} CiHipShard;
+
+typedef struct {     /* result of a stream-ordered selection; lives in device or pinned host memory */
+  double _priority;
+  int64_t _iQuestion; /* GLOBAL question index, -1 if no eligible question in this shard */
+} CiHipSelection;
+#pragma pack(pop)
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Same as PqaEngineFactory_CreateCpuEngine (which creates the HIP engine too); explicit name for new callers. */
+PQACORE_API void *PqaEngineFactory_CreateHipEngine(void *pvFactory, void **ppError, const CiEngineDefinition *pEngDef);
+/* Engine over questions [_qFirst, _qFirst + pEngDef->_nQuestions) of a KB with _qTotal questions.  Question ids in
+ * every call on such an engine are GLOBAL ids. */
+PQACORE_API void *PqaEngineFactory_CreateHipEngineSharded(void *pvFactory, void **ppError,
+                                                          const CiEngineDefinition *pEngDef, const CiHipShard *pShard);
+
+/* ---- options: "select" (0 = sampled like the reference [default], 1 = argmax), "workers" (emulated CPU worker count
+ * fixing the summation order of the prior updates, default 16), "eval_subtasks" (question subtasks of the sampled
+ * selector, default 8*workers as PqaCore/CpuEngine.cpp:339), "eval_variant" (0 = auto), "bug_compat" (reproduce
+ * PqaCore/CEUpdatePriorsSubtaskMul.cpp:53), "seed" (selector RNG seed). */
+PQACORE_API void *PqaHip_SetOption(void *pvEngine, const char *name, int64_t value);
+PQACORE_API int64_t PqaHip_GetOption(void *pvEngine, const char *name);
+PQACORE_API const char *PqaHip_EvalKernelName(void *pvEngine);
+
+/* ---- bulk KB transfer: dense host arrays without padding, A[q][k][t], D[q][t], B[t] (local questions only) */
+PQACORE_API void *PqaHip_SetKB(void *pvEngine, const double *pA, const double *pD, const double *pB);
+PQACORE_API void *PqaHip_GetKB(void *pvEngine, double *pA, double *pD, double *pB);
+/* Fill the device cube with the deterministic synthetic KB of probqa_amd/synth.py (no host transfer). */
+PQACORE_API void *PqaHip_FillSynthetic(void *pvEngine, double nTrain, double noiseAmp, uint64_t seed);
+/* Mark targets / (global) questions as gaps without going through maintenance mode (tests of gap handling). */
+PQACORE_API void *PqaHip_SetTargetGaps(void *pvEngine, int64_t n, const int64_t *pTargets);
+PQACORE_API void *PqaHip_SetQuestionGaps(void *pvEngine, int64_t n, const int64_t *pQuestions);
+
+/* ---- deterministic outputs of the hot path */
+/* priority[i] of local question i (0 for gap / asked), i < n == local question count. */
+PQACORE_API void *PqaEngine_EvalPriorities(void *pvEngine, const int64_t iQuiz, double *pOut, const int64_t n);
+/* NextQuestion with the argmax selector / with the reference's selector driven by the given 64-bit random number. */
+PQACORE_API int64_t PqaEngine_NextQuestionArgmax(void *pvEngine, void **ppError, const int64_t iQuiz);
+PQACORE_API int64_t PqaEngine_NextQuestionSampled(void *pvEngine, void **ppError, const int64_t iQuiz,
+                                                  const uint64_t rnd);
+/* Current target probabilities of a quiz (n == nTargets). */
+PQACORE_API void *PqaHip_GetPriors(void *pvEngine, const int64_t iQuiz, double *pOut, const int64_t n);
+
+/* ---- stream-ordered entry points (no host synchronisation inside) */
+PQACORE_API void *PqaHip_GetStream(void *pvEngine);                 /* hipStream_t */
+PQACORE_API void *PqaHip_SetStream(void *pvEngine, void *hipStream); /* run on the caller's stream, NULL = own */
+PQACORE_API void *PqaHip_Synchronize(void *pvEngine);
+/* Enqueue sweep + local argmax; the 16-byte CiHipSelection is written to pOut (device or pinned host pointer). */
+PQACORE_API void *PqaHip_EnqueueSelectArgmax(void *pvEngine, const int64_t iQuiz, void *pOut);
+/* Enqueue only the sweep (dominant kernel), for kernel timing. */
+PQACORE_API void *PqaHip_EnqueueEval(void *pvEngine, const int64_t iQuiz);
+/* Device pointer of the quiz's prior vector (ldT doubles, *pLdT receives ldT) for collectives between shards. */
+PQACORE_API void *PqaHip_GetPriorDevicePtr(void *pvEngine, const int64_t iQuiz, void **ppDev, int64_t *pLdT);
+/* RecordAnswer on a shard that does not own the active question: bookkeeping only; the owner's prior is expected to be
+ * broadcast into PqaHip_GetPriorDevicePtr's buffer by the caller. */
+PQACORE_API void *PqaHip_RecordAnswerRemote(void *pvEngine, const int64_t iQuiz, const int64_t iAnswer);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,383 @@
+// c_abi.cpp -- the extern "C" surface of libPqaCore.so.
+// Shims follow reference ProbQA/PqaCore/PqaCInterop.cpp:45-408 (AssignPqaError / ReturnPqaError, the three
+// GET_ENGINE_OR_* null-handle conventions); declarations are in include/PqaCInterop.h and include/PqaHipExt.h.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+
+#include "hip_engine.h"
+
+using pqa::AQ;
+using pqa::ErrCode;
+using pqa::Error;
+using pqa::HipEngine;
+
+static_assert(sizeof(CiEngineDefinition) == 48, "POD layout must match reference PqaCInterop.h:10-19");
+static_assert(offsetof(CiEngineDefinition, _precType) == 24 && offsetof(CiEngineDefinition, _precExponent) == 26 &&
+                  offsetof(CiEngineDefinition, _precMantissa) == 28 && offsetof(CiEngineDefinition, _initAmount) == 32 &&
+                  offsetof(CiEngineDefinition, _memPoolMaxBytes) == 40, "POD layout");
+static_assert(sizeof(CiAnsweredQuestion) == sizeof(AQ) && sizeof(CiRatedTarget) == 16 && sizeof(CiAddQorTParam) == 16, "POD layout");
+static_assert(sizeof(pqa::RatedTargetDev) == sizeof(CiRatedTarget) && offsetof(pqa::RatedTargetDev, prob) == offsetof(CiRatedTarget, _prob), "POD layout");
+static_assert(sizeof(CiHipSelection) == sizeof(pqa::SelectResult), "selection record");
+
+namespace {
+
+struct Factory { int unused; };
+Factory gFactory;  // process-global singleton, never freed (reference PqaCore/PqaEngineFactorySelector.cpp:11-15)
+
+void AssignErr(void **ppError, Error &err) {  // PqaCInterop.cpp:45-54
+  if (!ppError) return;
+  *ppError = err.ok() ? nullptr : new Error(std::move(err));
+}
+void *ReturnErr(Error &&err) {  // PqaCInterop.cpp:56-61
+  if (err.ok()) return nullptr;
+  return new Error(std::move(err));
+}
+Error NullEngine() { return Error::Make(ErrCode::NullArgument, "Nullptr is passed in place of IPqaEngine."); }
+Error NotImpl(const char *feature) {
+  return Error::MakeP(ErrCode::NotImplemented, std::string("Feature=") + feature,
+                      std::string(feature) + " is not built in the MI355X engine yet.");
+}
+char *DupString(const std::string &s) {
+  char *p = new char[s.size() + 1];
+  std::memcpy(p, s.c_str(), s.size() + 1);
+  return p;
+}
+
+#define GET_ENGINE_OR_RET_ERR                                   \
+  HipEngine *pEng = static_cast<HipEngine *>(pvEngine);         \
+  if (pEng == nullptr) return new Error(NullEngine());
+#define GET_ENGINE_OR_ASSIGN_ERR(retVal)                        \
+  HipEngine *pEng = static_cast<HipEngine *>(pvEngine);         \
+  if (pEng == nullptr) {                                        \
+    if (ppError) *ppError = new Error(NullEngine());            \
+    return retVal;                                              \
+  }
+#define GET_ENGINE_OR_LOG_ERR(retVal)                                               \
+  HipEngine *pEng = static_cast<HipEngine *>(pvEngine);                             \
+  if (pEng == nullptr) {                                                            \
+    std::fprintf(stderr, "PqaCore: Nullptr is passed in place of IPqaEngine.\n");   \
+    return retVal;                                                                  \
+  }
+
+void *CreateEngine(void *pvFactory, void **ppError, const CiEngineDefinition *pEngDef, const CiHipShard *pShard) {
+  if (pvFactory == nullptr) {  // PqaCInterop.cpp:93-98
+    if (ppError) *ppError = new Error(Error::Make(ErrCode::NullArgument, "Nullptr is passed in place of IPqaEngineFactory."));
+    return nullptr;
+  }
+  if (pEngDef == nullptr) {
+    if (ppError) *ppError = new Error(Error::Make(ErrCode::NullArgument, "Nullptr is passed in place of the engine definition."));
+    return nullptr;
+  }
+  Error err;
+  HipEngine *eng = HipEngine::Create(err, *pEngDef, pShard);
+  AssignErr(ppError, err);
+  return eng;
+}
+
+}  // namespace
+
+extern "C" {
+
+PQACORE_API void CiDebugBreak(void) { /* reference requests a debugger; nothing to do here */ }
+
+PQACORE_API uint8_t Logger_Init(void **ppStrErr, const char *baseName) {
+  (void)baseName;  // the MI355X engine logs anomalies to stderr; there is no file logger to initialise
+  if (ppStrErr) *ppStrErr = nullptr;
+  return 1;
+}
+
+PQACORE_API void CiReleaseString(void *pvString) { delete[] static_cast<char *>(pvString); }
+
+PQACORE_API void *CiGetPqaEngineFactory(void) { return &gFactory; }
+
+PQACORE_API void *PqaEngineFactory_CreateCpuEngine(void *pvFactory, void **ppError, const CiEngineDefinition *pEngDef) {
+  return CreateEngine(pvFactory, ppError, pEngDef, nullptr);
+}
+PQACORE_API void *PqaEngineFactory_CreateHipEngine(void *pvFactory, void **ppError, const CiEngineDefinition *pEngDef) {
+  return CreateEngine(pvFactory, ppError, pEngDef, nullptr);
+}
+PQACORE_API void *PqaEngineFactory_CreateHipEngineSharded(void *pvFactory, void **ppError,
+                                                          const CiEngineDefinition *pEngDef, const CiHipShard *pShard) {
+  return CreateEngine(pvFactory, ppError, pEngDef, pShard);
+}
+
+PQACORE_API void *PqaEngineFactory_LoadCpuEngine(void *pvFactory, void **ppError, const char *filePath,
+                                                 uint64_t memPoolMaxBytes) {
+  (void)filePath; (void)memPoolMaxBytes;
+  if (pvFactory == nullptr) {
+    if (ppError) *ppError = new Error(Error::Make(ErrCode::NullArgument, "Nullptr is passed in place of IPqaEngineFactory."));
+    return nullptr;
+  }
+  if (ppError) *ppError = new Error(NotImpl("LoadCpuEngine (.kb persistence)"));
+  return nullptr;
+}
+
+PQACORE_API void CiReleasePqaError(void *pvErr) { delete static_cast<Error *>(pvErr); }
+
+PQACORE_API void *PqaError_ToString(void *pvError, const uint8_t withParams) {
+  Error *pErr = static_cast<Error *>(pvError);
+  if (!pErr) return DupString("[Success] message=[]");
+  return DupString(pErr->ToString(withParams != 0));
+}
+
+PQACORE_API void CiReleasePqaEngine(void *pvEngine) { delete static_cast<HipEngine *>(pvEngine); }
+
+PQACORE_API void *PqaEngine_Train(void *pvEngine, int64_t nQuestions, const CiAnsweredQuestion *const pAQs,
+                                  const int64_t iTarget, const double amount) {
+  GET_ENGINE_OR_RET_ERR;
+  return ReturnErr(pEng->Train(nQuestions, reinterpret_cast<const AQ *>(pAQs), iTarget, amount));
+}
+
+PQACORE_API uint8_t PqaEngine_QuestionPermFromComp(void *pvEngine, const int64_t count, int64_t *pIds) {
+  GET_ENGINE_OR_LOG_ERR(0);
+  return pEng->QuestionIdMap(count, pIds) ? 1 : 0;
+}
+PQACORE_API uint8_t PqaEngine_QuestionCompFromPerm(void *pvEngine, const int64_t count, int64_t *pIds) {
+  GET_ENGINE_OR_LOG_ERR(0);
+  return pEng->QuestionIdMap(count, pIds) ? 1 : 0;
+}
+PQACORE_API uint8_t PqaEngine_TargetPermFromComp(void *pvEngine, const int64_t count, int64_t *pIds) {
+  GET_ENGINE_OR_LOG_ERR(0);
+  return pEng->TargetIdMap(count, pIds) ? 1 : 0;
+}
+PQACORE_API uint8_t PqaEngine_TargetCompFromPerm(void *pvEngine, const int64_t count, int64_t *pIds) {
+  GET_ENGINE_OR_LOG_ERR(0);
+  return pEng->TargetIdMap(count, pIds) ? 1 : 0;
+}
+PQACORE_API uint8_t PqaEngine_QuizPermFromComp(void *pvEngine, const int64_t count, int64_t *pIds) {
+  GET_ENGINE_OR_LOG_ERR(0);
+  return pEng->QuizIdMap(count, pIds) ? 1 : 0;
+}
+PQACORE_API uint8_t PqaEngine_QuizCompFromPerm(void *pvEngine, const int64_t count, int64_t *pIds) {
+  GET_ENGINE_OR_LOG_ERR(0);
+  return pEng->QuizIdMap(count, pIds) ? 1 : 0;
+}
+PQACORE_API uint8_t PqaEngine_EnsurePermQuizGreater(void *pvEngine, const int64_t bound) {
+  GET_ENGINE_OR_LOG_ERR(0);
+  (void)bound;
+  return 0;  // permanent quiz ids equal compact ids in this build; nothing was increased
+}
+PQACORE_API uint8_t PqaEngine_RemapQuizPermId(void *pvEngine, const int64_t srcPermId, const int64_t destPermId) {
+  GET_ENGINE_OR_LOG_ERR(0);
+  return srcPermId == destPermId ? 1 : 0;
+}
+
+PQACORE_API uint64_t PqaEngine_GetTotalQuestionsAsked(void *pvEngine, void **ppError) {
+  GET_ENGINE_OR_ASSIGN_ERR(0);
+  Error err;
+  const uint64_t n = pEng->GetTotalQuestionsAsked(err);
+  AssignErr(ppError, err);
+  return n;
+}
+
+PQACORE_API uint8_t PqaEngine_CopyDims(void *pvEngine, CiEngineDimensions *pDims) {
+  GET_ENGINE_OR_LOG_ERR(0);
+  pEng->CopyDims(pDims);
+  return 1;
+}
+
+PQACORE_API int64_t PqaEngine_StartQuiz(void *pvEngine, void **ppError) {
+  GET_ENGINE_OR_ASSIGN_ERR(-1);
+  Error err;
+  const int64_t id = pEng->StartQuiz(err);
+  AssignErr(ppError, err);
+  return id;
+}
+
+PQACORE_API int64_t PqaEngine_ResumeQuiz(void *pvEngine, void **ppError, const int64_t nAnswered,
+                                         const CiAnsweredQuestion *const pAQs) {
+  GET_ENGINE_OR_ASSIGN_ERR(-1);
+  Error err;
+  const int64_t id = pEng->ResumeQuiz(err, nAnswered, reinterpret_cast<const AQ *>(pAQs));
+  AssignErr(ppError, err);
+  return id;
+}
+
+PQACORE_API int64_t PqaEngine_NextQuestion(void *pvEngine, void **ppError, const int64_t iQuiz) {
+  GET_ENGINE_OR_ASSIGN_ERR(-1);
+  Error err;
+  const int64_t q = pEng->NextQuestion(err, iQuiz);
+  AssignErr(ppError, err);
+  return q;
+}
+
+PQACORE_API void *PqaEngine_RecordAnswer(void *pvEngine, const int64_t iQuiz, const int64_t iAnswer) {
+  GET_ENGINE_OR_RET_ERR;
+  return ReturnErr(pEng->RecordAnswer(iQuiz, iAnswer));
+}
+
+PQACORE_API void *PqaEngine_ClearOldQuizzes(void *pvEngine, const int64_t maxCount, const double maxAgeSec) {
+  GET_ENGINE_OR_RET_ERR;
+  (void)maxCount; (void)maxAgeSec;
+  return ReturnErr(NotImpl("ClearOldQuizzes"));
+}
+
+PQACORE_API int64_t PqaEngine_GetActiveQuestionId(void *pvEngine, void **ppError, const int64_t iQuiz) {
+  GET_ENGINE_OR_ASSIGN_ERR(-1);
+  Error err;
+  const int64_t q = pEng->GetActiveQuestionId(err, iQuiz);
+  AssignErr(ppError, err);
+  return q;
+}
+
+PQACORE_API void *PqaEngine_SetActiveQuestion(void *pvEngine, const int64_t iQuiz, const int64_t iQuestion) {
+  GET_ENGINE_OR_RET_ERR;
+  return ReturnErr(pEng->SetActiveQuestion(iQuiz, iQuestion));
+}
+
+PQACORE_API int64_t PqaEngine_ListTopTargets(void *pvEngine, void **ppError, const int64_t iQuiz,
+                                             const int64_t maxCount, CiRatedTarget *pDest) {
+  GET_ENGINE_OR_ASSIGN_ERR(-1);
+  Error err;
+  const int64_t n = pEng->ListTopTargets(err, iQuiz, maxCount, pDest);
+  AssignErr(ppError, err);
+  return n;
+}
+
+PQACORE_API void *PqaEngine_RecordQuizTarget(void *pvEngine, const int64_t iQuiz, const int64_t iTarget,
+                                             const double amount) {
+  GET_ENGINE_OR_RET_ERR;
+  return ReturnErr(pEng->RecordQuizTarget(iQuiz, iTarget, amount));
+}
+
+PQACORE_API void *PqaEngine_ReleaseQuiz(void *pvEngine, const int64_t iQuiz) {
+  GET_ENGINE_OR_RET_ERR;
+  return ReturnErr(pEng->ReleaseQuiz(iQuiz));
+}
+
+PQACORE_API void *PqaEngine_SaveKB(void *pvEngine, const char *const filePath, const uint8_t bDoubleBuffer) {
+  GET_ENGINE_OR_RET_ERR;
+  (void)filePath; (void)bDoubleBuffer;
+  return ReturnErr(NotImpl("SaveKB (.kb persistence)"));
+}
+
+PQACORE_API void *PqaEngine_StartMaintenance(void *pvEngine, const bool forceQuizzes) {
+  GET_ENGINE_OR_RET_ERR;
+  return ReturnErr(pEng->StartMaintenance(forceQuizzes));
+}
+PQACORE_API void *PqaEngine_FinishMaintenance(void *pvEngine) {
+  GET_ENGINE_OR_RET_ERR;
+  return ReturnErr(pEng->FinishMaintenance());
+}
+PQACORE_API void *PqaEngine_AddQsTs(void *pvEngine, const int64_t nQuestions, CiAddQorTParam *pAddQuestionParams,
+                                    const int64_t nTargets, CiAddQorTParam *pAddTargetParams) {
+  GET_ENGINE_OR_RET_ERR;
+  (void)nQuestions; (void)pAddQuestionParams; (void)nTargets; (void)pAddTargetParams;
+  return ReturnErr(NotImpl("AddQsTs"));
+}
+PQACORE_API void *PqaEngine_RemoveQuestions(void *pvEngine, const int64_t nQuestions, const int64_t *pQIds) {
+  GET_ENGINE_OR_RET_ERR;
+  (void)nQuestions; (void)pQIds;
+  return ReturnErr(NotImpl("RemoveQuestions"));
+}
+PQACORE_API void *PqaEngine_RemoveTargets(void *pvEngine, const int64_t nTargets, const int64_t *pTIds) {
+  GET_ENGINE_OR_RET_ERR;
+  (void)nTargets; (void)pTIds;
+  return ReturnErr(NotImpl("RemoveTargets"));
+}
+PQACORE_API void *PqaEngine_Compact(void *pvEngine, int64_t *pnQuestions, int64_t const **const ppOldQuestions,
+                                    int64_t *pnTargets, int64_t const **const ppOldTargets) {
+  GET_ENGINE_OR_RET_ERR;
+  (void)pnQuestions; (void)ppOldQuestions; (void)pnTargets; (void)ppOldTargets;
+  return ReturnErr(NotImpl("Compact"));
+}
+PQACORE_API void CiReleaseCompaction(const int64_t *p) { std::free(const_cast<int64_t *>(p)); }
+
+PQACORE_API void *PqaEngine_Shutdown(void *pvEngine, const char *const saveFilePath) {
+  GET_ENGINE_OR_RET_ERR;
+  return ReturnErr(pEng->Shutdown(saveFilePath));
+}
+PQACORE_API void *PqaEngine_SetLogger(void *pvEngine, void *pSRLogger) {
+  GET_ENGINE_OR_RET_ERR;
+  (void)pSRLogger;  // ISRLogger is an MSVC-ABI C++ object; it cannot be consumed here
+  return ReturnErr(NotImpl("SetLogger"));
+}
+
+// ---------------------------------------------------------------------------------------------------- PqaHipExt.h
+PQACORE_API void *PqaHip_SetOption(void *pvEngine, const char *name, int64_t value) {
+  GET_ENGINE_OR_RET_ERR;
+  return ReturnErr(pEng->SetOption(name, value));
+}
+PQACORE_API int64_t PqaHip_GetOption(void *pvEngine, const char *name) {
+  GET_ENGINE_OR_LOG_ERR(-1);
+  return pEng->GetOption(name);
+}
+PQACORE_API const char *PqaHip_EvalKernelName(void *pvEngine) {
+  GET_ENGINE_OR_LOG_ERR("");
+  return pEng->EvalKernelName();
+}
+PQACORE_API void *PqaHip_SetKB(void *pvEngine, const double *pA, const double *pD, const double *pB) {
+  GET_ENGINE_OR_RET_ERR;
+  return ReturnErr(pEng->SetKB(pA, pD, pB));
+}
+PQACORE_API void *PqaHip_GetKB(void *pvEngine, double *pA, double *pD, double *pB) {
+  GET_ENGINE_OR_RET_ERR;
+  return ReturnErr(pEng->GetKB(pA, pD, pB));
+}
+PQACORE_API void *PqaHip_FillSynthetic(void *pvEngine, double nTrain, double noiseAmp, uint64_t seed) {
+  GET_ENGINE_OR_RET_ERR;
+  return ReturnErr(pEng->FillSynthetic(nTrain, noiseAmp, seed));
+}
+PQACORE_API void *PqaHip_SetTargetGaps(void *pvEngine, int64_t n, const int64_t *pTargets) {
+  GET_ENGINE_OR_RET_ERR;
+  return ReturnErr(pEng->SetTargetGaps(n, pTargets));
+}
+PQACORE_API void *PqaHip_SetQuestionGaps(void *pvEngine, int64_t n, const int64_t *pQuestions) {
+  GET_ENGINE_OR_RET_ERR;
+  return ReturnErr(pEng->SetQuestionGaps(n, pQuestions));
+}
+PQACORE_API void *PqaEngine_EvalPriorities(void *pvEngine, const int64_t iQuiz, double *pOut, const int64_t n) {
+  GET_ENGINE_OR_RET_ERR;
+  return ReturnErr(pEng->EvalPriorities(iQuiz, pOut, n));
+}
+PQACORE_API int64_t PqaEngine_NextQuestionArgmax(void *pvEngine, void **ppError, const int64_t iQuiz) {
+  GET_ENGINE_OR_ASSIGN_ERR(-1);
+  Error err;
+  const int64_t q = pEng->NextQuestionArgmax(err, iQuiz);
+  AssignErr(ppError, err);
+  return q;
+}
+PQACORE_API int64_t PqaEngine_NextQuestionSampled(void *pvEngine, void **ppError, const int64_t iQuiz,
+                                                  const uint64_t rnd) {
+  GET_ENGINE_OR_ASSIGN_ERR(-1);
+  Error err;
+  const int64_t q = pEng->NextQuestionSampled(err, iQuiz, rnd);
+  AssignErr(ppError, err);
+  return q;
+}
+PQACORE_API void *PqaHip_GetPriors(void *pvEngine, const int64_t iQuiz, double *pOut, const int64_t n) {
+  GET_ENGINE_OR_RET_ERR;
+  return ReturnErr(pEng->GetPriors(iQuiz, pOut, n));
+}
+PQACORE_API void *PqaHip_GetStream(void *pvEngine) {
+  GET_ENGINE_OR_LOG_ERR(nullptr);
+  return pEng->GetStream();
+}
+PQACORE_API void *PqaHip_SetStream(void *pvEngine, void *hipStream) {
+  GET_ENGINE_OR_RET_ERR;
+  return ReturnErr(pEng->SetStream(static_cast<hipStream_t>(hipStream)));
+}
+PQACORE_API void *PqaHip_Synchronize(void *pvEngine) {
+  GET_ENGINE_OR_RET_ERR;
+  return ReturnErr(pEng->Synchronize());
+}
+PQACORE_API void *PqaHip_EnqueueSelectArgmax(void *pvEngine, const int64_t iQuiz, void *pOut) {
+  GET_ENGINE_OR_RET_ERR;
+  return ReturnErr(pEng->EnqueueSelectArgmax(iQuiz, pOut));
+}
+PQACORE_API void *PqaHip_EnqueueEval(void *pvEngine, const int64_t iQuiz) {
+  GET_ENGINE_OR_RET_ERR;
+  return ReturnErr(pEng->EnqueueEval(iQuiz));
+}
+PQACORE_API void *PqaHip_GetPriorDevicePtr(void *pvEngine, const int64_t iQuiz, void **ppDev, int64_t *pLdT) {
+  GET_ENGINE_OR_RET_ERR;
+  return ReturnErr(pEng->GetPriorDevicePtr(iQuiz, ppDev, pLdT));
+}
+PQACORE_API void *PqaHip_RecordAnswerRemote(void *pvEngine, const int64_t iQuiz, const int64_t iAnswer) {
+  GET_ENGINE_OR_RET_ERR;
+  return ReturnErr(pEng->RecordAnswerRemote(iQuiz, iAnswer));
+}
+
+}  // extern "C"

@@ -1,0 +1,854 @@
+// hip_engine.cpp -- see hip_engine.h.  Reference files cited are under /root/reference/ProbQA.
+#include "hip_engine.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <random>
+#include <sstream>
+
+namespace pqa {
+
+// ------------------------------------------------------------------------------------------------------------------
+// errors (reference PqaCore/PqaErrors.cpp:13-62, :128-143)
+// ------------------------------------------------------------------------------------------------------------------
+const char *ErrCodeName(ErrCode c) {
+  switch (c) {
+    case ErrCode::None: return "Success";
+    case ErrCode::NotImplemented: return "Not implemented";
+    case ErrCode::SRException: return "SRException";
+    case ErrCode::StdException: return "std::exception";
+    case ErrCode::InsufficientEngineDimensions: return "Insufficient engine dimensions";
+    case ErrCode::MaintenanceModeChangeInProgress: return "Maintenance mode change is in progress";
+    case ErrCode::MaintenanceModeAlreadyThis: return "Maintenance mode is already this";
+    case ErrCode::ObjectShutDown: return "Object is shut(ting) down";
+    case ErrCode::IndexOutOfRange: return "Index is out of range";
+    case ErrCode::Aggregate: return "Aggregate error";
+    case ErrCode::NegativeCount: return "The count is negative";
+    case ErrCode::NonPositiveAmount: return "The amount is not positive";
+    case ErrCode::AbsentId: return "The ID is absent from KB";
+    case ErrCode::WrongMode: return "An attempt to execute an operation in a wrong mode";
+    case ErrCode::UnhandledCase: return "Unhandled case";
+    case ErrCode::I64Underflow: return "Underflow of a 64-bit integer";
+    case ErrCode::QuestionsExhausted: return "Engine has run out of questions";
+    case ErrCode::NoQuizActiveQuestion: return "No active question in the quiz";
+    case ErrCode::CantOpenFile: return "Cannot open file";
+    case ErrCode::FileOp: return "File operation failed";
+    case ErrCode::QuizzesActive: return "There are still active quizzes";
+    case ErrCode::NullArgument: return "Expected non-null argument";
+    default: return nullptr;
+  }
+}
+
+std::string Error::ToString(bool withParams) const {
+  std::string s = "[";
+  const char *name = ErrCodeName(code);
+  if (name) s += name; else s += "Unhandled" + std::to_string((int64_t)code);
+  s += "] message=[" + message;
+  if (!withParams) return s + "]";
+  s += "] [";
+  s += hasParams ? params : std::string("nullptr");
+  return s + "]";
+}
+
+namespace {
+
+Error HipErr(hipError_t e, const char *what) {
+  std::string msg = std::string("HIP failure in ") + what + ": " + hipGetErrorString(e);
+  return Error::MakeP(ErrCode::Internal, std::string("Internal error at hip_engine.cpp(") + what + ")", msg);
+}
+#define HIP_TRY(expr)                                   \
+  do {                                                  \
+    const hipError_t e_ = (expr);                       \
+    if (e_ != hipSuccess) return HipErr(e_, #expr);     \
+  } while (0)
+
+std::string RangeParams(int64_t subj, int64_t lo, int64_t hi) {  // IndexOutOfRangeErrorParams::ToString
+  return "subjIndex=" + std::to_string(subj) + " not in " + std::to_string(lo) + "..." + std::to_string(hi);
+}
+
+inline bool BitTest(const std::vector<uint32_t> &bits, int64_t i) { return (bits[i >> 5] >> (i & 31)) & 1u; }
+inline void BitSet(std::vector<uint32_t> &bits, int64_t i, bool v) {
+  if (v) bits[i >> 5] |= 1u << (i & 31); else bits[i >> 5] &= ~(1u << (i & 31));
+}
+inline size_t BitWords(int64_t nBits) { return (size_t)((nBits + 63) / 64) * 2 + 2; }  // whole 64-bit packs + slack
+inline uint64_t Pack64(const std::vector<uint32_t> &bits, int64_t iPack) {
+  return (uint64_t)bits[2 * iPack] | ((uint64_t)bits[2 * iPack + 1] << 32);
+}
+
+uint64_t SplitMix64(uint64_t &x) {
+  uint64_t z = (x += 0x9E3779B97F4A7C15ULL);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+  return z ^ (z >> 31);
+}
+
+std::once_flag gTableOnce[64];
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------------------------
+// construction
+// ------------------------------------------------------------------------------------------------------------------
+HipEngine *HipEngine::Create(Error &err, const CiEngineDefinition &def, const CiHipShard *shard) {
+  std::unique_ptr<HipEngine> eng(new HipEngine());
+  err = eng->Init(def, shard);
+  if (!err.ok()) return nullptr;
+  return eng.release();
+}
+
+Error HipEngine::Init(const CiEngineDefinition &def, const CiHipShard *shard) {
+  // reference PqaCore/PqaEngineBaseFactory.cpp:29-42: minimum dimensions
+  const int64_t minA = 2, minQ = 1, minT = 2;
+  if (def._nAnswers < minA || def._nQuestions < minQ || def._nTargets < minT) {
+    std::ostringstream p;
+    p << "[nAnswers=" << def._nAnswers << " of " << minA << "] [nQuestions=" << def._nQuestions << " of " << minQ
+      << "] [nTargets=" << def._nTargets << " of " << minT << "]";
+    return Error::MakeP(ErrCode::InsufficientEngineDimensions, p.str(), "Engine dimensions are too small.");
+  }
+  if (def._precType != 3 /*Double*/) {
+    return Error::MakeP(ErrCode::NotImplemented, "Feature=HipEngine precision other than Double",
+                        "Only TPqaPrecisionType::Double is instantiated (as in the reference CPU engine, "
+                        "PqaCore/PqaEngineBaseFactory.cpp:19-27).");
+  }
+  int nDev = 0;
+  if (hipGetDeviceCount(&nDev) != hipSuccess || nDev <= 0) {
+    return Error::Make(ErrCode::NotInitialized,
+                       "No HIP device is available: libPqaCore.so (MI355X build) has no CPU fallback.");
+  }
+  _K = def._nAnswers; _Q = def._nQuestions; _T = def._nTargets;
+  _initAmount = def._initAmount;
+  _ldT = ((_T + 15) / 16) * 16;
+  _qFirst = shard ? shard->_qFirst : 0;
+  _qTotal = shard ? shard->_qTotal : _Q;
+  if (_qFirst < 0 || _qFirst + _Q > _qTotal)
+    return Error::MakeP(ErrCode::IndexOutOfRange, RangeParams(_qFirst + _Q, 0, _qTotal), "Shard exceeds the global question range.");
+  if (shard && shard->_device >= 0) {
+    if (shard->_device >= nDev)
+      return Error::MakeP(ErrCode::IndexOutOfRange, RangeParams(shard->_device, 0, nDev - 1), "No such HIP device.");
+    HIP_TRY(hipSetDevice(shard->_device));
+  }
+  HIP_TRY(hipGetDevice(&_device));
+  {
+    hipError_t tblErr = hipSuccess;
+    std::call_once(gTableOnce[_device & 63], [&] {
+      // SRVectMath::Initialize, reference SRPlatform/SRVectMath.cpp:30-44
+      std::vector<double> tbl(1024);
+      for (uint32_t i = 0; i < 1024; i++) {
+        const uint64_t iZp = 0x3FF0000000000000ULL | ((uint64_t)i << 42) | (1ULL << 41);
+        double zp;
+        std::memcpy(&zp, &iZp, 8);
+        tbl[i] = std::log2(zp);
+      }
+      tbl[0] *= 9.9999999999999927e-01;
+      tblErr = UploadLog2Table(tbl.data());
+    });
+    HIP_TRY(tblErr);
+  }
+  HIP_TRY(hipStreamCreateWithFlags(&_ownStream, hipStreamNonBlocking));
+  _stream = _ownStream;
+  const size_t cubeElems = (size_t)_Q * (size_t)(_K + 1) * (size_t)_ldT;
+  HIP_TRY(hipMalloc(&_dCube, cubeElems * sizeof(double)));
+  HIP_TRY(hipMalloc(&_dVB, (size_t)_ldT * sizeof(double)));
+  HIP_TRY(hipMalloc(&_dPriority, (size_t)_Q * sizeof(double)));
+  HIP_TRY(hipMalloc(&_dRunLength, (size_t)_Q * sizeof(double)));
+  HIP_TRY(hipMalloc(&_dExps, (size_t)_ldT * sizeof(int64_t)));
+  HIP_TRY(hipMalloc(&_dStatus, 2 * sizeof(int64_t)));
+  HIP_TRY(hipMalloc(&_dNOut, sizeof(int64_t)));
+  HIP_TRY(hipMalloc(&_dSel, sizeof(SelectResult)));
+  HIP_TRY(hipHostMalloc(&_hPinned, sizeof(Pinned), hipHostMallocDefault));
+  _hTGap.assign(BitWords(_ldT), 0);
+  _hQGap.assign(BitWords(_Q), 0);
+  for (int64_t t = _T; t < (int64_t)_hTGap.size() * 32; t++) BitSet(_hTGap, t, true);  // GapTracker.h:9-10
+  for (int64_t q = _Q; q < (int64_t)_hQGap.size() * 32; q++) BitSet(_hQGap, q, true);
+  HIP_TRY(hipMalloc(&_dTGap, _hTGap.size() * sizeof(uint32_t)));
+  HIP_TRY(hipMalloc(&_dQGap, _hQGap.size() * sizeof(uint32_t)));
+  Error e = UploadGaps();
+  if (!e.ok()) return e;
+  HIP_TRY(LaunchFillFresh(_dCube, _dVB, _K, _Q, _T, _ldT, _initAmount, _stream));
+  HIP_TRY(hipStreamSynchronize(_stream));
+  std::random_device rd;  // the reference seeds from RDRAND (SRPlatform/Interface/SRFastRandom.h:31-40)
+  uint64_t seed = ((uint64_t)rd() << 32) ^ rd();
+  _rng[0] = SplitMix64(seed);
+  _rng[1] = SplitMix64(seed);
+  return Error();
+}
+
+HipEngine::~HipEngine() {
+  hipSetDevice(_device);
+  if (_stream) hipStreamSynchronize(_stream);
+  for (Quiz *q : _quizzes) if (q) DestroyQuiz(q);
+  hipFree(_dCube); hipFree(_dVB); hipFree(_dPriority); hipFree(_dRunLength); hipFree(_dExps); hipFree(_dStatus);
+  hipFree(_dNOut); hipFree(_dSel); hipFree(_dTGap); hipFree(_dQGap); hipFree(_dAqs); hipFree(_dTop);
+  if (_hPinned) hipHostFree(_hPinned);
+  if (_ownStream) hipStreamDestroy(_ownStream);
+}
+
+Error HipEngine::UploadGaps() {
+  HIP_TRY(hipMemcpyAsync(_dTGap, _hTGap.data(), _hTGap.size() * sizeof(uint32_t), hipMemcpyHostToDevice, _stream));
+  HIP_TRY(hipMemcpyAsync(_dQGap, _hQGap.data(), _hQGap.size() * sizeof(uint32_t), hipMemcpyHostToDevice, _stream));
+  HIP_TRY(hipStreamSynchronize(_stream));
+  return Error();
+}
+
+KbView HipEngine::View() const {
+  KbView v;
+  v.cube = _dCube; v.vB = _dVB; v.tgap = _dTGap; v.qgap = _dQGap;
+  v.K = _K; v.Q = _Q; v.T = _T; v.ldT = _ldT;
+  v.nValidTargets = _T - _nTargetGaps;
+  return v;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// options
+// ------------------------------------------------------------------------------------------------------------------
+Error HipEngine::SetOption(const char *name, int64_t value) {
+  std::lock_guard<std::mutex> lk(_mu);
+  const std::string n(name ? name : "");
+  if (n == "select") { if (value != 0 && value != 1) goto bad; _optSelect = value; }
+  else if (n == "workers") { if (value < 1 || value > 4096) goto bad; _optWorkers = value; }
+  else if (n == "eval_subtasks") { if (value < 0 || value > 8192) goto bad; _optEvalSubtasks = value; }
+  else if (n == "eval_variant") { if (value < 0) goto bad; _optEvalVariant = value; }
+  else if (n == "bug_compat") { _optBugCompat = value ? 1 : 0; }
+  else if (n == "seed") { uint64_t s = (uint64_t)value; _rng[0] = SplitMix64(s); _rng[1] = SplitMix64(s); }
+  else goto bad;
+  return Error();
+bad:
+  return Error::Make(ErrCode::UnhandledCase, "Unknown option or value out of range: " + n);
+}
+
+int64_t HipEngine::GetOption(const char *name) const {
+  const std::string n(name ? name : "");
+  if (n == "select") return _optSelect;
+  if (n == "workers") return _optWorkers;
+  if (n == "eval_subtasks") return _optEvalSubtasks ? _optEvalSubtasks : 8 * _optWorkers;
+  if (n == "eval_variant") return _optEvalVariant;
+  if (n == "bug_compat") return _optBugCompat;
+  if (n == "ldT") return _ldT;
+  if (n == "device") return _device;
+  return -1;
+}
+
+const char *HipEngine::EvalKernelName() const { return EvalVariantName(View(), (int)_optEvalVariant); }
+
+uint64_t HipEngine::NextRandom() {  // xorshift128+, the generator family of SRPlatform/Interface/SRFastRandom.h:60-72
+  uint64_t s1 = _rng[0];
+  const uint64_t s0 = _rng[1];
+  _rng[0] = s0;
+  s1 ^= s1 << 23;
+  _rng[1] = s1 ^ s0 ^ (s1 >> 18) ^ (s0 >> 5);
+  return _rng[1] + s0;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// mode / quiz registry
+// ------------------------------------------------------------------------------------------------------------------
+Error HipEngine::CheckRegular(const char *what) const {
+  if (_mode == Mode::Regular) return Error();
+  return Error::Make(ErrCode::WrongMode, std::string("Can't perform regular-only mode operation (") + what +
+                                             ") because current mode is not regular (but maintenance/shutdown?).");
+}
+
+Quiz *HipEngine::UseQuiz(Error &err, int64_t iQuiz) {
+  const int64_t nQuizzes = (int64_t)_quizzes.size();
+  if (iQuiz < 0 || iQuiz >= nQuizzes) {
+    err = Error::MakeP(ErrCode::IndexOutOfRange, RangeParams(iQuiz, 0, nQuizzes - 1),
+                       "Quiz index is not in quiz registry range.");
+    return nullptr;
+  }
+  if (_quizzes[iQuiz] == nullptr) {
+    err = Error::MakeP(ErrCode::AbsentId, "id=" + std::to_string(iQuiz),
+                       "Quiz index is not in the registry (but rather at a gap).");
+    return nullptr;
+  }
+  return _quizzes[iQuiz];
+}
+
+void HipEngine::DestroyQuiz(Quiz *q) {
+  if (!q) return;
+  hipFree(q->dPrior);
+  hipFree(q->dAsked);
+  delete q;
+}
+
+int64_t HipEngine::CreateQuiz(Error &err, int64_t nAnswered, const AQ *pAQs) {
+  err = CheckRegular("Start/Resume quiz");
+  if (!err.ok()) return -1;
+  hipSetDevice(_device);
+  std::unique_ptr<Quiz> quiz(new Quiz());
+  auto fail = [&](Error e) { err = std::move(e); hipFree(quiz->dPrior); hipFree(quiz->dAsked); return (int64_t)-1; };
+  quiz->hAsked.assign(BitWords(_Q), 0);
+  // validate the answered questions and set their "asked" bits (reference PqaCore/CpuEngine.cpp:216-233)
+  bool allLocal = true;
+  for (int64_t i = 0; i < nAnswered; i++) {
+    const int64_t iq = pAQs[i].iQuestion, ia = pAQs[i].iAnswer;
+    if (iq < 0 || iq >= _qTotal)
+      return fail(Error::MakeP(ErrCode::IndexOutOfRange, RangeParams(iq, 0, _qTotal - 1), "Question index is not in KB range."));
+    if (ia < 0 || ia >= _K)
+      return fail(Error::MakeP(ErrCode::IndexOutOfRange, RangeParams(ia, 0, _K - 1), "Answer index is not in KB range."));
+    if (iq >= _qFirst && iq < _qFirst + _Q) BitSet(quiz->hAsked, iq - _qFirst, true); else allLocal = false;
+  }
+  if (!allLocal)
+    return fail(Error::MakeP(ErrCode::NotImplemented, "Feature=ResumeQuiz across shards",
+                             "ResumeQuiz on a sharded engine needs every answered question to be local."));
+  hipError_t he = hipMalloc(&quiz->dPrior, (size_t)_ldT * sizeof(double));
+  if (he == hipSuccess) he = hipMalloc(&quiz->dAsked, quiz->hAsked.size() * sizeof(uint32_t));
+  if (he == hipSuccess)
+    he = hipMemcpyAsync(quiz->dAsked, quiz->hAsked.data(), quiz->hAsked.size() * sizeof(uint32_t), hipMemcpyHostToDevice, _stream);
+  if (he != hipSuccess) return fail(HipErr(he, "quiz allocation"));
+  const KbView kb = View();
+  if (nAnswered == 0) {
+    // CECreateQuizStart::UpdateLikelihoods, reference PqaCore/CECreateQuizOperation.cpp:22-53
+    he = LaunchStartQuiz(kb, quiz->dPrior, _optWorkers, _stream);
+    if (he != hipSuccess) return fail(HipErr(he, "LaunchStartQuiz"));
+    he = hipStreamSynchronize(_stream);  // the H2D source (hAsked) must stay alive until the copy ran
+    if (he != hipSuccess) return fail(HipErr(he, "StartQuiz sync"));
+  } else {
+    // CECreateQuizResume::UpdateLikelihoods, reference PqaCore/CECreateQuizOperation.cpp:55-83
+    if (nAnswered > _aqCapacity) {
+      hipFree(_dAqs);
+      _dAqs = nullptr;
+      _aqCapacity = std::max<int64_t>(nAnswered, 64);
+      he = hipMalloc(&_dAqs, (size_t)_aqCapacity * 2 * sizeof(int64_t));
+      if (he != hipSuccess) { _aqCapacity = 0; return fail(HipErr(he, "aq buffer")); }
+    }
+    std::vector<int64_t> local(2 * (size_t)nAnswered);
+    for (int64_t i = 0; i < nAnswered; i++) { local[2 * i] = pAQs[i].iQuestion - _qFirst; local[2 * i + 1] = pAQs[i].iAnswer; }
+    he = hipMemcpyAsync(_dAqs, local.data(), local.size() * sizeof(int64_t), hipMemcpyHostToDevice, _stream);
+    if (he == hipSuccess)
+      he = LaunchResumeQuiz(kb, quiz->dPrior, _dExps, _dAqs, nAnswered, _optWorkers, (int)_optBugCompat, _dStatus, _stream);
+    if (he == hipSuccess)
+      he = hipMemcpyAsync(_hPinned->status, _dStatus, 2 * sizeof(int64_t), hipMemcpyDeviceToHost, _stream);
+    if (he == hipSuccess) he = hipStreamSynchronize(_stream);
+    if (he != hipSuccess) return fail(HipErr(he, "ResumeQuiz"));
+    if (_hPinned->status[0] != 0) {  // reference PqaCore/CpuEngine.cpp:317-321
+      const int64_t highBound = 1023 + 1023 - (int64_t)std::ceil(std::log2((double)_T)) - 2;
+      const int64_t minAllowed = INT64_MIN + highBound + 1;
+      return fail(Error::MakeP(ErrCode::I64Underflow,
+                               "actual=" + std::to_string(_hPinned->status[1]) + ", minAllowed=" + std::to_string(minAllowed),
+                               "Max exponent over the priors is too low. Are all the targets in gaps?"));
+    }
+    for (int64_t i = 0; i < nAnswered; i++) quiz->answers.push_back(pAQs[i]);
+  }
+  // AssignQuiz, reference PqaCore/BaseEngine.cpp (gap reuse, else append)
+  int64_t id;
+  if (!_quizGaps.empty()) { id = _quizGaps.back(); _quizGaps.pop_back(); _quizzes[id] = quiz.release(); }
+  else { id = (int64_t)_quizzes.size(); _quizzes.push_back(quiz.release()); }
+  return id;
+}
+
+int64_t HipEngine::StartQuiz(Error &err) {
+  std::lock_guard<std::mutex> lk(_mu);
+  return CreateQuiz(err, 0, nullptr);
+}
+
+int64_t HipEngine::ResumeQuiz(Error &err, int64_t nAnswered, const AQ *pAQs) {
+  if (nAnswered < 0) {  // reference PqaCore/BaseEngine.cpp:388-392
+    err = Error::MakeP(ErrCode::NegativeCount, "count=" + std::to_string(nAnswered), "|nAnswered| must be non-negative.");
+    return -1;
+  }
+  if (nAnswered > 0 && pAQs == nullptr) {
+    err = Error::Make(ErrCode::NullArgument, "Nullptr is passed in place of answered questions.");
+    return -1;
+  }
+  std::lock_guard<std::mutex> lk(_mu);
+  return CreateQuiz(err, nAnswered, pAQs);  // nAnswered == 0 -> StartQuiz (BaseEngine.cpp:393-395)
+}
+
+Error HipEngine::ReleaseQuiz(int64_t iQuiz) {
+  std::lock_guard<std::mutex> lk(_mu);
+  Error err = CheckRegular("release quiz");
+  if (!err.ok()) return err;
+  Quiz *q = UseQuiz(err, iQuiz);
+  if (!q) return err;
+  hipSetDevice(_device);
+  hipStreamSynchronize(_stream);
+  _quizzes[iQuiz] = nullptr;
+  _quizGaps.push_back(iQuiz);
+  DestroyQuiz(q);
+  return Error();
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// NextQuestion
+// ------------------------------------------------------------------------------------------------------------------
+bool HipEngine::QuestionUnavailable(const Quiz *q, int64_t qLocal) const {
+  return BitTest(_hQGap, qLocal) || BitTest(q->hAsked, qLocal);
+}
+
+// BaseEngine::FindNearestQuestion, reference PqaCore/BaseEngine.cpp:60-124 (over the local question range)
+int64_t HipEngine::FindNearestQuestion(int64_t iMiddle, const Quiz *q) const {
+  const uint32_t dInf = 200;
+  const int64_t iPack64 = iMiddle >> 6;
+  const uint32_t iWithin = (uint32_t)(iMiddle & 63);
+  auto avail = [&](int64_t p) { return ~(Pack64(_hQGap, p) | Pack64(q->hAsked, p)); };
+  const uint64_t available = avail(iPack64);
+  if (available != 0) {
+    const uint64_t baseMask = (1ULL << iWithin) - 1;
+    const uint64_t higher = available & ~baseMask, lower = baseMask & available;
+    const uint32_t dHigher = higher ? ((uint32_t)__builtin_ctzll(higher) - iWithin) : dInf;
+    const uint32_t dLower = lower ? (iWithin - (uint32_t)(63 - __builtin_clzll(lower))) : dInf;
+    return (dHigher < dLower) ? iMiddle + dHigher : iMiddle - dLower;
+  }
+  const int64_t limPack64 = (_Q + 63) >> 6;
+  int64_t i = 1;
+  while ((iPack64 >= i) && (iPack64 + i < limPack64)) {
+    const uint64_t availLeft = avail(iPack64 - i), availRight = avail(iPack64 + i);
+    if ((availLeft | availRight) == 0) { i++; continue; }
+    const uint32_t dHigher = availRight ? ((uint32_t)__builtin_ctzll(availRight) + 64 - iWithin) : dInf;
+    const uint32_t dLower = availLeft ? (iWithin + 64 - (uint32_t)(63 - __builtin_clzll(availLeft))) : dInf;
+    if (dHigher < dLower) return iMiddle + dHigher + ((i - 1) << 6);
+    return iMiddle - dLower - ((i - 1) << 6);
+  }
+  while (iPack64 >= i) {
+    const uint64_t availLeft = avail(iPack64 - i);
+    if (!availLeft) { i++; continue; }
+    return iMiddle - (iWithin + 64 - (uint32_t)(63 - __builtin_clzll(availLeft))) - ((i - 1) << 6);
+  }
+  while (iPack64 + i < limPack64) {
+    const uint64_t availRight = avail(iPack64 + i);
+    if (!availRight) { i++; continue; }
+    return iMiddle + ((uint32_t)__builtin_ctzll(availRight) + 64 - iWithin) + ((i - 1) << 6);
+  }
+  return -1;
+}
+
+int64_t HipEngine::FinishSelection(Error &err, Quiz *q, int64_t selLocal) {
+  // reference PqaCore/CpuEngine.cpp:403-413
+  if (selLocal >= 0 && QuestionUnavailable(q, selLocal)) selLocal = FindNearestQuestion(selLocal, q);
+  if (selLocal < 0) {
+    err = Error::Make(ErrCode::QuestionsExhausted, "Found no unasked question that is not in a gap.");
+    return -1;
+  }
+  q->activeQuestion = _qFirst + selLocal;
+  _nQuestionsAsked.fetch_add(1, std::memory_order_relaxed);
+  return q->activeQuestion;
+}
+
+Error HipEngine::EnqueueEval(int64_t iQuiz) {
+  std::lock_guard<std::mutex> lk(_mu);
+  Error err = CheckRegular("compute next question");
+  if (!err.ok()) return err;
+  Quiz *q = UseQuiz(err, iQuiz);
+  if (!q) return err;
+  HIP_TRY(LaunchEvalQuestions(View(), q->dPrior, q->dAsked, 0, _Q, _dPriority, (int)_optEvalVariant, _stream));
+  return Error();
+}
+
+Error HipEngine::EnqueueSelectArgmax(int64_t iQuiz, void *pOut) {
+  std::lock_guard<std::mutex> lk(_mu);
+  Error err = CheckRegular("compute next question");
+  if (!err.ok()) return err;
+  Quiz *q = UseQuiz(err, iQuiz);
+  if (!q) return err;
+  const KbView kb = View();
+  HIP_TRY(LaunchEvalQuestions(kb, q->dPrior, q->dAsked, 0, _Q, _dPriority, (int)_optEvalVariant, _stream));
+  // reported index = local position + qFirst, i.e. the GLOBAL question id
+  HIP_TRY(LaunchSelectArgmax(_dPriority, _dQGap, q->dAsked, 0, _Q, _qFirst, pOut ? (SelectResult *)pOut : _dSel, _stream));
+  return Error();
+}
+
+int64_t HipEngine::NextQuestionArgmax(Error &err, int64_t iQuiz) {
+  std::lock_guard<std::mutex> lk(_mu);
+  err = CheckRegular("compute next question");
+  if (!err.ok()) return -1;
+  Quiz *q = UseQuiz(err, iQuiz);
+  if (!q) return -1;
+  hipSetDevice(_device);
+  const KbView kb = View();
+  hipError_t he = LaunchEvalQuestions(kb, q->dPrior, q->dAsked, 0, _Q, _dPriority, (int)_optEvalVariant, _stream);
+  if (he == hipSuccess) he = LaunchSelectArgmax(_dPriority, _dQGap, q->dAsked, 0, _Q, 0, _dSel, _stream);
+  if (he == hipSuccess) he = hipMemcpyAsync(&_hPinned->sel, _dSel, sizeof(SelectResult), hipMemcpyDeviceToHost, _stream);
+  if (he == hipSuccess) he = hipStreamSynchronize(_stream);
+  if (he != hipSuccess) { err = HipErr(he, "NextQuestionArgmax"); return -1; }
+  return FinishSelection(err, q, _hPinned->sel.index);
+}
+
+int64_t HipEngine::NextQuestionSampled(Error &err, int64_t iQuiz, uint64_t rnd) {
+  std::lock_guard<std::mutex> lk(_mu);
+  err = CheckRegular("compute next question");
+  if (!err.ok()) return -1;
+  Quiz *q = UseQuiz(err, iQuiz);
+  if (!q) return -1;
+  hipSetDevice(_device);
+  const KbView kb = View();
+  const int64_t nSub = _optEvalSubtasks ? _optEvalSubtasks : 8 * _optWorkers;  // reference PqaCore/CpuEngine.cpp:339
+  hipError_t he = LaunchEvalQuestions(kb, q->dPrior, q->dAsked, 0, _Q, _dPriority, (int)_optEvalVariant, _stream);
+  if (he == hipSuccess) he = LaunchSelectSampled(_dPriority, _dQGap, q->dAsked, 0, _Q, nSub, rnd, _dRunLength, _dSel, _stream);
+  if (he == hipSuccess) he = hipMemcpyAsync(&_hPinned->sel, _dSel, sizeof(SelectResult), hipMemcpyDeviceToHost, _stream);
+  if (he == hipSuccess) he = hipStreamSynchronize(_stream);
+  if (he != hipSuccess) { err = HipErr(he, "NextQuestionSampled"); return -1; }
+  return FinishSelection(err, q, _hPinned->sel.index);
+}
+
+int64_t HipEngine::NextQuestion(Error &err, int64_t iQuiz) {
+  if (_optSelect == 1) return NextQuestionArgmax(err, iQuiz);
+  uint64_t rnd;
+  { std::lock_guard<std::mutex> lk(_mu); rnd = NextRandom(); }
+  return NextQuestionSampled(err, iQuiz, rnd);
+}
+
+Error HipEngine::EvalPriorities(int64_t iQuiz, double *pOut, int64_t n) {
+  std::lock_guard<std::mutex> lk(_mu);
+  Error err = CheckRegular("compute next question");
+  if (!err.ok()) return err;
+  Quiz *q = UseQuiz(err, iQuiz);
+  if (!q) return err;
+  if (!pOut) return Error::Make(ErrCode::NullArgument, "Nullptr is passed in place of the priority buffer.");
+  if (n != _Q) return Error::MakeP(ErrCode::IndexOutOfRange, RangeParams(n, _Q, _Q), "Priority buffer length must equal the local question count.");
+  hipSetDevice(_device);
+  HIP_TRY(LaunchEvalQuestions(View(), q->dPrior, q->dAsked, 0, _Q, _dPriority, (int)_optEvalVariant, _stream));
+  HIP_TRY(hipMemcpyAsync(pOut, _dPriority, (size_t)_Q * sizeof(double), hipMemcpyDeviceToHost, _stream));
+  HIP_TRY(hipStreamSynchronize(_stream));
+  return Error();
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// RecordAnswer and friends
+// ------------------------------------------------------------------------------------------------------------------
+Error HipEngine::RecordAnswerImpl(int64_t iQuiz, int64_t iAnswer, bool remote) {
+  std::lock_guard<std::mutex> lk(_mu);
+  Error err = CheckRegular("record an answer");
+  if (!err.ok()) return err;
+  if (iAnswer < 0 || iAnswer >= _K)  // reference PqaCore/BaseEngine.cpp:447-451
+    return Error::MakeP(ErrCode::IndexOutOfRange, RangeParams(iAnswer, 0, _K - 1), "Answer index is not in the answer range.");
+  Quiz *q = UseQuiz(err, iQuiz);
+  if (!q) return err;
+  // CEQuiz::RecordAnswer, reference PqaCore/CEQuiz.h:77-122
+  const int64_t aq = q->activeQuestion;
+  if (aq == -1)
+    return Error::MakeP(ErrCode::NoQuizActiveQuestion, "answerId=" + std::to_string(iAnswer),
+                        "An attempt to record an answer in a quiz that doesn't have an active question");
+  const bool local = aq >= _qFirst && aq < _qFirst + _Q;
+  if (aq < 0 || aq >= _qTotal || (local && BitTest(_hQGap, aq - _qFirst)))
+    return Error::MakeP(ErrCode::NoQuizActiveQuestion, "answerId=" + std::to_string(iAnswer),
+                        "An attempt to record an answer in a quiz that has invalid active question");
+  if (local == remote)
+    return Error::MakeP(ErrCode::IndexOutOfRange, RangeParams(aq, _qFirst, _qFirst + _Q - 1),
+                        remote ? "RecordAnswerRemote on the shard that owns the active question."
+                               : "The active question belongs to another shard: use PqaHip_RecordAnswerRemote.");
+  q->answers.push_back(AQ{aq, iAnswer});
+  q->activeQuestion = -1;
+  if (!local) return Error();
+  hipSetDevice(_device);
+  const int64_t ql = aq - _qFirst;
+  BitSet(q->hAsked, ql, true);
+  const size_t w = (size_t)(ql >> 5);
+  HIP_TRY(hipMemcpyAsync(q->dAsked + w, &q->hAsked[w], sizeof(uint32_t), hipMemcpyHostToDevice, _stream));
+  // NLooseWorkers = max(1, hw - 1): reference PqaCore/CEQuiz.h:98, PqaCore/BaseCpuEngine.cpp:22
+  const int64_t nLoose = std::max<int64_t>(1, _optWorkers - 1);
+  HIP_TRY(LaunchRecordAnswer(View(), q->dPrior, ql, iAnswer, nLoose, _stream));
+  HIP_TRY(hipStreamSynchronize(_stream));  // the 4-byte H2D source lives in hAsked; keep the call synchronous like the reference
+  return Error();
+}
+
+Error HipEngine::RecordAnswer(int64_t iQuiz, int64_t iAnswer) { return RecordAnswerImpl(iQuiz, iAnswer, false); }
+Error HipEngine::RecordAnswerRemote(int64_t iQuiz, int64_t iAnswer) { return RecordAnswerImpl(iQuiz, iAnswer, true); }
+
+int64_t HipEngine::GetActiveQuestionId(Error &err, int64_t iQuiz) {
+  std::lock_guard<std::mutex> lk(_mu);
+  err = CheckRegular("get active question ID for a quiz");
+  if (!err.ok()) return -1;
+  Quiz *q = UseQuiz(err, iQuiz);
+  if (!q) return -1;
+  return q->activeQuestion;
+}
+
+Error HipEngine::SetActiveQuestion(int64_t iQuiz, int64_t iQuestion) {
+  std::lock_guard<std::mutex> lk(_mu);
+  Error err = CheckRegular("set active question ID for a quiz");
+  if (!err.ok()) return err;
+  Quiz *q = UseQuiz(err, iQuiz);
+  if (!q) return err;
+  q->activeQuestion = iQuestion;  // unchecked, as reference PqaCore/BaseEngine.cpp:507-508
+  return Error();
+}
+
+Error HipEngine::GetPriors(int64_t iQuiz, double *pOut, int64_t n) {
+  std::lock_guard<std::mutex> lk(_mu);
+  Error err;
+  Quiz *q = UseQuiz(err, iQuiz);
+  if (!q) return err;
+  if (!pOut) return Error::Make(ErrCode::NullArgument, "Nullptr is passed in place of the prior buffer.");
+  if (n != _T) return Error::MakeP(ErrCode::IndexOutOfRange, RangeParams(n, _T, _T), "Prior buffer length must equal nTargets.");
+  hipSetDevice(_device);
+  HIP_TRY(hipMemcpyAsync(pOut, q->dPrior, (size_t)_T * sizeof(double), hipMemcpyDeviceToHost, _stream));
+  HIP_TRY(hipStreamSynchronize(_stream));
+  return Error();
+}
+
+Error HipEngine::GetPriorDevicePtr(int64_t iQuiz, void **ppDev, int64_t *pLdT) {
+  std::lock_guard<std::mutex> lk(_mu);
+  Error err;
+  Quiz *q = UseQuiz(err, iQuiz);
+  if (!q) return err;
+  if (ppDev) *ppDev = q->dPrior;
+  if (pLdT) *pLdT = _ldT;
+  return Error();
+}
+
+int64_t HipEngine::ListTopTargets(Error &err, int64_t iQuiz, int64_t maxCount, CiRatedTarget *pDest) {
+  std::lock_guard<std::mutex> lk(_mu);
+  err = CheckRegular("list top targets");
+  if (!err.ok()) return -1;
+  Quiz *q = UseQuiz(err, iQuiz);
+  if (!q) return -1;
+  if (maxCount <= 0) return 0;
+  if (!pDest) { err = Error::Make(ErrCode::NullArgument, "Nullptr is passed in place of the destination."); return -1; }
+  hipSetDevice(_device);
+  const int64_t want = std::min<int64_t>(maxCount, _T);
+  if (want <= 256) {
+    if (want > _topCapacity) {
+      hipFree(_dTop);
+      _dTop = nullptr;
+      _topCapacity = 256;
+      if (hipMalloc(&_dTop, (size_t)_topCapacity * sizeof(RatedTargetDev)) != hipSuccess) {
+        _topCapacity = 0;
+        err = Error::Make(ErrCode::Internal, "hipMalloc failed for the top-targets buffer.");
+        return -1;
+      }
+    }
+    hipError_t he = LaunchTopTargets(View(), q->dPrior, want, _dTop, _dNOut, _stream);
+    if (he == hipSuccess) he = hipMemcpyAsync(&_hPinned->nOut, _dNOut, sizeof(int64_t), hipMemcpyDeviceToHost, _stream);
+    if (he == hipSuccess) he = hipMemcpyAsync(pDest, _dTop, (size_t)want * sizeof(RatedTargetDev), hipMemcpyDeviceToHost, _stream);
+    if (he == hipSuccess) he = hipStreamSynchronize(_stream);
+    if (he != hipSuccess) { err = HipErr(he, "ListTopTargets"); return -1; }
+    return _hPinned->nOut;
+  }
+  // large lists: sort on the host (the listing is O(T log T) on 8T bytes, not a cube operation)
+  std::vector<double> pri((size_t)_T);
+  hipError_t he = hipMemcpyAsync(pri.data(), q->dPrior, (size_t)_T * sizeof(double), hipMemcpyDeviceToHost, _stream);
+  if (he == hipSuccess) he = hipStreamSynchronize(_stream);
+  if (he != hipSuccess) { err = HipErr(he, "ListTopTargets"); return -1; }
+  std::vector<int64_t> idx;
+  idx.reserve((size_t)_T);
+  for (int64_t t = 0; t < _T; t++) if (!BitTest(_hTGap, t)) idx.push_back(t);
+  const int64_t n = std::min<int64_t>(want, (int64_t)idx.size());
+  std::partial_sort(idx.begin(), idx.begin() + n, idx.end(),
+                    [&](int64_t a, int64_t b) { return pri[a] > pri[b] || (pri[a] == pri[b] && a < b); });
+  for (int64_t i = 0; i < n; i++) { pDest[i]._iTarget = idx[i]; pDest[i]._prob = pri[idx[i]]; }
+  return n;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// training (reference PqaCore/CpuEngine.cpp:102-183, :442-466; PqaCore/CETrainOperation.cpp:15-25)
+// ------------------------------------------------------------------------------------------------------------------
+Error HipEngine::Train(int64_t nQuestions, const AQ *pAQs, int64_t iTarget, double amount) {
+  if (nQuestions < 0)
+    return Error::MakeP(ErrCode::NegativeCount, "count=" + std::to_string(nQuestions), "|nQuestions| must be non-negative.");
+  if (amount <= 0)
+    return Error::MakeP(ErrCode::NonPositiveAmount, "amount=" + std::to_string(amount), "|amount| must be positive.");
+  std::lock_guard<std::mutex> lk(_mu);
+  if (_mode == Mode::Shutdown) return Error::MakeP(ErrCode::ObjectShutDown, "RejectedOperation=Train", "Engine is shut down.");
+  if (iTarget < 0 || iTarget >= _T)
+    return Error::MakeP(ErrCode::IndexOutOfRange, RangeParams(iTarget, 0, _T - 1), "Target index is not in KB range.");
+  if (BitTest(_hTGap, iTarget))
+    return Error::MakeP(ErrCode::AbsentId, "id=" + std::to_string(iTarget), "Target index is not in KB (but rather at a gap).");
+  std::vector<int64_t> local;
+  local.reserve(2 * (size_t)nQuestions);
+  bool dup = false;
+  std::vector<int64_t> seen;
+  for (int64_t i = 0; i < nQuestions; i++) {
+    const int64_t iq = pAQs[i].iQuestion, ia = pAQs[i].iAnswer;
+    // CETrainSubtaskDistrib validation (reference PqaCore/CETrainSubtaskDistrib.h)
+    if (iq < 0 || iq >= _qTotal)
+      return Error::MakeP(ErrCode::IndexOutOfRange, RangeParams(iq, 0, _qTotal - 1), "Question index is not in KB range.");
+    if (ia < 0 || ia >= _K)
+      return Error::MakeP(ErrCode::IndexOutOfRange, RangeParams(ia, 0, _K - 1), "Answer index is not in KB range.");
+    if (iq < _qFirst || iq >= _qFirst + _Q) continue;
+    if (BitTest(_hQGap, iq - _qFirst))
+      return Error::MakeP(ErrCode::AbsentId, "id=" + std::to_string(iq), "Question index is not in KB (but rather at a gap).");
+    if (std::find(seen.begin(), seen.end(), iq) != seen.end()) dup = true;
+    seen.push_back(iq);
+    local.push_back(iq - _qFirst);
+    local.push_back(ia);
+  }
+  hipSetDevice(_device);
+  const int64_t nLocal = (int64_t)local.size() / 2;
+  if (nLocal > _aqCapacity) {
+    hipFree(_dAqs);
+    _dAqs = nullptr;
+    _aqCapacity = std::max<int64_t>(nLocal, 64);
+    HIP_TRY(hipMalloc(&_dAqs, (size_t)_aqCapacity * 2 * sizeof(int64_t)));
+  }
+  if (nLocal > 0) HIP_TRY(hipMemcpyAsync(_dAqs, local.data(), local.size() * sizeof(int64_t), hipMemcpyHostToDevice, _stream));
+  if (!dup) {
+    HIP_TRY(LaunchTrain(_dCube, _dVB, _K, _ldT, _dAqs, nLocal, iTarget, amount, _stream));
+  } else {
+    // duplicate questions: apply one by one in the given order (each step is the reference's Perform1); vB once
+    for (int64_t i = 0; i < nLocal; i++)
+      HIP_TRY(LaunchTrain(_dCube, _dVB, _K, _ldT, _dAqs + 2 * i, 1, iTarget, i == 0 ? amount : 0.0, _stream));
+  }
+  HIP_TRY(hipStreamSynchronize(_stream));
+  _nQuestionsAsked.fetch_add((uint64_t)nQuestions, std::memory_order_relaxed);  // reference CpuEngine.cpp:176
+  return Error();
+}
+
+Error HipEngine::RecordQuizTarget(int64_t iQuiz, int64_t iTarget, double amount) {
+  std::vector<AQ> answers;
+  {
+    // reference PqaCore/BaseEngine.cpp:529-566
+    if (amount <= 0)
+      return Error::MakeP(ErrCode::NonPositiveAmount, "amount=" + std::to_string(amount), "|amount| must be positive.");
+    std::lock_guard<std::mutex> lk(_mu);
+    Error err = CheckRegular("record quiz target");
+    if (!err.ok()) return err;
+    if (iTarget < 0 || iTarget >= _T)
+      return Error::MakeP(ErrCode::IndexOutOfRange, RangeParams(iTarget, 0, _T - 1), "Target index is not in KB range.");
+    if (BitTest(_hTGap, iTarget))
+      return Error::MakeP(ErrCode::AbsentId, "id=" + std::to_string(iTarget), "Target index is not in KB (but rather at a gap).");
+    Quiz *q = UseQuiz(err, iQuiz);
+    if (!q) return err;
+    answers = q->answers;
+  }
+  // reference PqaCore/CpuEngine.cpp:442-466: train on the quiz's answers; the asked-questions counter is not bumped
+  const uint64_t before = _nQuestionsAsked.load();
+  Error e = Train((int64_t)answers.size(), answers.data(), iTarget, amount);
+  _nQuestionsAsked.store(before);
+  return e;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// misc
+// ------------------------------------------------------------------------------------------------------------------
+uint64_t HipEngine::GetTotalQuestionsAsked(Error &err) { err = Error(); return _nQuestionsAsked.load(std::memory_order_relaxed); }
+
+void HipEngine::CopyDims(CiEngineDimensions *pDims) const {
+  pDims->_nAnswers = _K;
+  pDims->_nQuestions = _qTotal;
+  pDims->_nTargets = _T;
+}
+
+Error HipEngine::StartMaintenance(bool forceQuizzes) {  // reference PqaCore/BaseEngine.cpp:640-690
+  std::lock_guard<std::mutex> lk(_mu);
+  if (_mode == Mode::Shutdown) return Error::MakeP(ErrCode::ObjectShutDown, "RejectedOperation=StartMaintenance", "Engine is shut down.");
+  if (_mode == Mode::Maintenance) return Error::MakeP(ErrCode::MaintenanceModeAlreadyThis, "ActiveMode=#1", "Already in maintenance mode.");
+  int64_t nActive = 0;
+  for (Quiz *q : _quizzes) nActive += q ? 1 : 0;
+  if (nActive > 0) {
+    if (!forceQuizzes)
+      return Error::MakeP(ErrCode::QuizzesActive, "nQuizzes=[" + std::to_string(nActive) + "]",
+                          "Can't switch to maintenance mode while there are active quizzes.");
+    hipSetDevice(_device);
+    hipStreamSynchronize(_stream);
+    for (size_t i = 0; i < _quizzes.size(); i++) if (_quizzes[i]) { DestroyQuiz(_quizzes[i]); _quizzes[i] = nullptr; }
+    _quizzes.clear();
+    _quizGaps.clear();
+  }
+  _mode = Mode::Maintenance;
+  return Error();
+}
+
+Error HipEngine::FinishMaintenance() {  // reference PqaCore/BaseEngine.cpp:692-712
+  std::lock_guard<std::mutex> lk(_mu);
+  if (_mode == Mode::Shutdown) return Error::MakeP(ErrCode::ObjectShutDown, "RejectedOperation=FinishMaintenance", "Engine is shut down.");
+  if (_mode == Mode::Regular) return Error::MakeP(ErrCode::MaintenanceModeAlreadyThis, "ActiveMode=#0", "Already in regular mode.");
+  _mode = Mode::Regular;
+  return Error();
+}
+
+Error HipEngine::Shutdown(const char *saveFilePath) {
+  std::lock_guard<std::mutex> lk(_mu);
+  if (_mode == Mode::Shutdown) return Error::MakeP(ErrCode::ObjectShutDown, "RejectedOperation=Shutdown", "Engine is already shut down.");
+  if (saveFilePath && *saveFilePath)
+    return Error::MakeP(ErrCode::NotImplemented, "Feature=SaveKB on Shutdown", "KB persistence is not built yet.");
+  hipSetDevice(_device);
+  hipStreamSynchronize(_stream);
+  _mode = Mode::Shutdown;
+  return Error();
+}
+
+bool HipEngine::QuestionIdMap(int64_t count, int64_t *pIds) const {
+  bool all = true;
+  for (int64_t i = 0; i < count; i++) if (pIds[i] < 0 || pIds[i] >= _qTotal) { pIds[i] = -1; all = false; }
+  return all;
+}
+bool HipEngine::TargetIdMap(int64_t count, int64_t *pIds) const {
+  bool all = true;
+  for (int64_t i = 0; i < count; i++) if (pIds[i] < 0 || pIds[i] >= _T || BitTest(_hTGap, pIds[i])) { pIds[i] = -1; all = false; }
+  return all;
+}
+bool HipEngine::QuizIdMap(int64_t count, int64_t *pIds) const {
+  std::lock_guard<std::mutex> lk(_mu);
+  bool all = true;
+  for (int64_t i = 0; i < count; i++)
+    if (pIds[i] < 0 || pIds[i] >= (int64_t)_quizzes.size() || !_quizzes[pIds[i]]) { pIds[i] = -1; all = false; }
+  return all;
+}
+
+Error HipEngine::SetStream(hipStream_t s) {
+  std::lock_guard<std::mutex> lk(_mu);
+  hipSetDevice(_device);
+  HIP_TRY(hipStreamSynchronize(_stream));
+  _stream = s ? s : _ownStream;
+  return Error();
+}
+
+Error HipEngine::Synchronize() {
+  hipSetDevice(_device);
+  HIP_TRY(hipStreamSynchronize(_stream));
+  return Error();
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// bulk KB transfer / synthetic KB / gaps
+// ------------------------------------------------------------------------------------------------------------------
+Error HipEngine::SetKB(const double *pA, const double *pD, const double *pB) {
+  std::lock_guard<std::mutex> lk(_mu);
+  if (!pA || !pD || !pB) return Error::Make(ErrCode::NullArgument, "Nullptr is passed in place of a KB array.");
+  hipSetDevice(_device);
+  const size_t rowB = (size_t)_T * sizeof(double), ldB = (size_t)_ldT * sizeof(double);
+  for (int64_t q = 0; q < _Q; q++) {
+    HIP_TRY(hipMemcpy2DAsync(_dCube + (size_t)q * (_K + 1) * _ldT, ldB, pA + (size_t)q * _K * _T, rowB, rowB, (size_t)_K,
+                             hipMemcpyHostToDevice, _stream));
+  }
+  HIP_TRY(hipMemcpy2DAsync(_dCube + (size_t)_K * _ldT, ldB * (size_t)(_K + 1), pD, rowB, rowB, (size_t)_Q, hipMemcpyHostToDevice, _stream));
+  HIP_TRY(hipMemcpyAsync(_dVB, pB, rowB, hipMemcpyHostToDevice, _stream));
+  HIP_TRY(hipStreamSynchronize(_stream));
+  return Error();
+}
+
+Error HipEngine::GetKB(double *pA, double *pD, double *pB) {
+  std::lock_guard<std::mutex> lk(_mu);
+  hipSetDevice(_device);
+  const size_t rowB = (size_t)_T * sizeof(double), ldB = (size_t)_ldT * sizeof(double);
+  if (pA)
+    for (int64_t q = 0; q < _Q; q++)
+      HIP_TRY(hipMemcpy2DAsync(pA + (size_t)q * _K * _T, rowB, _dCube + (size_t)q * (_K + 1) * _ldT, ldB, rowB, (size_t)_K,
+                               hipMemcpyDeviceToHost, _stream));
+  if (pD) HIP_TRY(hipMemcpy2DAsync(pD, rowB, _dCube + (size_t)_K * _ldT, ldB * (size_t)(_K + 1), rowB, (size_t)_Q, hipMemcpyDeviceToHost, _stream));
+  if (pB) HIP_TRY(hipMemcpyAsync(pB, _dVB, rowB, hipMemcpyDeviceToHost, _stream));
+  HIP_TRY(hipStreamSynchronize(_stream));
+  return Error();
+}
+
+Error HipEngine::FillSynthetic(double nTrain, double noiseAmp, uint64_t seed) {
+  std::lock_guard<std::mutex> lk(_mu);
+  hipSetDevice(_device);
+  HIP_TRY(LaunchFillSynthetic(_dCube, _dVB, _K, _Q, _T, _ldT, _qFirst, _qTotal, _initAmount, nTrain, noiseAmp, seed, _stream));
+  HIP_TRY(hipStreamSynchronize(_stream));
+  return Error();
+}
+
+Error HipEngine::SetTargetGaps(int64_t n, const int64_t *ids) {
+  std::lock_guard<std::mutex> lk(_mu);
+  for (int64_t i = 0; i < n; i++)
+    if (ids[i] < 0 || ids[i] >= _T) return Error::MakeP(ErrCode::IndexOutOfRange, RangeParams(ids[i], 0, _T - 1), "Target index is not in KB range.");
+  for (int64_t i = 0; i < n; i++)
+    if (!BitTest(_hTGap, ids[i])) { BitSet(_hTGap, ids[i], true); _nTargetGaps++; }
+  hipSetDevice(_device);
+  return UploadGaps();
+}
+
+Error HipEngine::SetQuestionGaps(int64_t n, const int64_t *ids) {
+  std::lock_guard<std::mutex> lk(_mu);
+  for (int64_t i = 0; i < n; i++)
+    if (ids[i] < 0 || ids[i] >= _qTotal) return Error::MakeP(ErrCode::IndexOutOfRange, RangeParams(ids[i], 0, _qTotal - 1), "Question index is not in KB range.");
+  for (int64_t i = 0; i < n; i++)
+    if (ids[i] >= _qFirst && ids[i] < _qFirst + _Q) BitSet(_hQGap, ids[i] - _qFirst, true);
+  hipSetDevice(_device);
+  return UploadGaps();
+}
+
+}  // namespace pqa

@@ -1,0 +1,145 @@
+// hip_engine.h -- host side of the MI355X engine behind the PqaCore C ABI.
+//
+// Mirrors the reference's engine interface for the hot path (reference: ProbQA/PqaCore/Interface/IPqaEngine.h:14-112;
+// behaviour of PqaCore/BaseEngine.cpp and PqaCore/CpuEngine.cpp for StartQuiz / ResumeQuiz / NextQuestion /
+// RecordAnswer / active-question bookkeeping / quiz registry / error objects).  All arithmetic runs in the gfx950
+// kernels of pqa_kernels.h; this file only owns device memory, the quiz table and the reference's error behaviour.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <atomic>
+#include <cstdint>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/PqaHipExt.h"
+#include "pqa_kernels.h"
+
+namespace pqa {
+
+// Error codes of reference PqaCore/Interface/PqaErrors.h:12-40
+enum class ErrCode : int64_t {
+  None = 0, NotImplemented = 1, SRException = 2, StdException = 3, InsufficientEngineDimensions = 4,
+  MaintenanceModeChangeInProgress = 5, MaintenanceModeAlreadyThis = 6, ObjectShutDown = 7, IndexOutOfRange = 8,
+  Internal = 9, Aggregate = 10, NegativeCount = 11, NonPositiveAmount = 12, AbsentId = 13, WrongMode = 14,
+  UnhandledCase = 15, I64Underflow = 16, QuestionsExhausted = 17, NoQuizActiveQuestion = 18, CantOpenFile = 19,
+  FileOp = 20, QuizzesActive = 21, NullArgument = 22, WrongRuntimeType = 23, NotInitialized = 24
+};
+
+// PqaError (reference PqaCore/Interface/PqaErrors.h:56-91): code + message + stringified params
+struct Error {
+  ErrCode code = ErrCode::None;
+  std::string message;
+  std::string params;   // what IPqaErrorParams::ToString() would give; empty = nullptr params
+  bool hasParams = false;
+  bool ok() const { return code == ErrCode::None; }
+  std::string ToString(bool withParams) const;  // reference PqaCore/PqaErrors.cpp:128-143
+  static Error Make(ErrCode c, std::string msg) { Error e; e.code = c; e.message = std::move(msg); return e; }
+  static Error MakeP(ErrCode c, std::string params, std::string msg) {
+    Error e; e.code = c; e.message = std::move(msg); e.params = std::move(params); e.hasParams = true; return e;
+  }
+};
+const char *ErrCodeName(ErrCode c);  // reference PqaCore/PqaErrors.cpp:13-62
+
+struct AQ { int64_t iQuestion, iAnswer; };
+
+struct Quiz {
+  double *dPrior = nullptr;            // ldT doubles, device
+  uint32_t *dAsked = nullptr;          // device bitmap over LOCAL questions
+  std::vector<uint32_t> hAsked;        // host mirror
+  std::vector<AQ> answers;             // global question ids
+  int64_t activeQuestion = -1;         // global id (reference CEQuiz::_activeQuestion)
+};
+
+class HipEngine {
+ public:
+  static HipEngine *Create(Error &err, const CiEngineDefinition &def, const CiHipShard *shard);
+  ~HipEngine();
+
+  // ---- reference IPqaEngine surface (names as in IPqaEngine.h)
+  Error Train(int64_t nQuestions, const AQ *pAQs, int64_t iTarget, double amount);
+  uint64_t GetTotalQuestionsAsked(Error &err);
+  void CopyDims(CiEngineDimensions *pDims) const;
+  int64_t StartQuiz(Error &err);
+  int64_t ResumeQuiz(Error &err, int64_t nAnswered, const AQ *pAQs);
+  int64_t NextQuestion(Error &err, int64_t iQuiz);
+  Error RecordAnswer(int64_t iQuiz, int64_t iAnswer);
+  int64_t GetActiveQuestionId(Error &err, int64_t iQuiz);
+  Error SetActiveQuestion(int64_t iQuiz, int64_t iQuestion);
+  int64_t ListTopTargets(Error &err, int64_t iQuiz, int64_t maxCount, CiRatedTarget *pDest);
+  Error RecordQuizTarget(int64_t iQuiz, int64_t iTarget, double amount);
+  Error ReleaseQuiz(int64_t iQuiz);
+  Error StartMaintenance(bool forceQuizzes);
+  Error FinishMaintenance();
+  Error Shutdown(const char *saveFilePath);
+  bool QuestionIdMap(int64_t count, int64_t *pIds) const;  // identity maps while nothing was ever removed
+  bool TargetIdMap(int64_t count, int64_t *pIds) const;
+  bool QuizIdMap(int64_t count, int64_t *pIds) const;
+
+  // ---- additive (PqaHipExt.h)
+  Error SetOption(const char *name, int64_t value);
+  int64_t GetOption(const char *name) const;
+  const char *EvalKernelName() const;
+  Error SetKB(const double *pA, const double *pD, const double *pB);
+  Error GetKB(double *pA, double *pD, double *pB);
+  Error FillSynthetic(double nTrain, double noiseAmp, uint64_t seed);
+  Error SetTargetGaps(int64_t n, const int64_t *ids);
+  Error SetQuestionGaps(int64_t n, const int64_t *ids);
+  Error EvalPriorities(int64_t iQuiz, double *pOut, int64_t n);
+  int64_t NextQuestionArgmax(Error &err, int64_t iQuiz);
+  int64_t NextQuestionSampled(Error &err, int64_t iQuiz, uint64_t rnd);
+  Error GetPriors(int64_t iQuiz, double *pOut, int64_t n);
+  hipStream_t GetStream() const { return _stream; }
+  Error SetStream(hipStream_t s);
+  Error Synchronize();
+  Error EnqueueSelectArgmax(int64_t iQuiz, void *pOut);
+  Error EnqueueEval(int64_t iQuiz);
+  Error GetPriorDevicePtr(int64_t iQuiz, void **ppDev, int64_t *pLdT);
+  Error RecordAnswerRemote(int64_t iQuiz, int64_t iAnswer);
+
+ private:
+  HipEngine() = default;
+  Error Init(const CiEngineDefinition &def, const CiHipShard *shard);
+  KbView View() const;
+  Quiz *UseQuiz(Error &err, int64_t iQuiz);                 // reference BaseEngine::UseQuiz, BaseEngine.cpp:399-419
+  Error CheckRegular(const char *what) const;               // MaintenanceSwitch gate of BaseEngine.cpp:423-427 etc.
+  int64_t CreateQuiz(Error &err, int64_t nAnswered, const AQ *pAQs);  // CpuEngine::CreateQuizInternal
+  void DestroyQuiz(Quiz *q);
+  int64_t FinishSelection(Error &err, Quiz *q, int64_t sel);  // gap/asked fallback + bookkeeping (CpuEngine.cpp:404-413)
+  int64_t FindNearestQuestion(int64_t iMiddleGlobal, const Quiz *q) const;  // BaseEngine.cpp:60-124
+  bool QuestionUnavailable(const Quiz *q, int64_t qGlobal) const;
+  Error RecordAnswerImpl(int64_t iQuiz, int64_t iAnswer, bool remote);
+  uint64_t NextRandom();
+  Error UploadGaps();
+
+  enum class Mode { Regular, Maintenance, Shutdown };
+
+  int64_t _K = 0, _Q = 0, _T = 0, _ldT = 0, _qFirst = 0, _qTotal = 0;
+  double _initAmount = 1;
+  int _device = 0;
+  hipStream_t _stream = nullptr, _ownStream = nullptr;
+  double *_dCube = nullptr, *_dVB = nullptr, *_dPriority = nullptr, *_dRunLength = nullptr;
+  uint32_t *_dTGap = nullptr, *_dQGap = nullptr;
+  int64_t *_dExps = nullptr, *_dAqs = nullptr, *_dStatus = nullptr, *_dNOut = nullptr;
+  int64_t _aqCapacity = 0;
+  RatedTargetDev *_dTop = nullptr;
+  int64_t _topCapacity = 0;
+  SelectResult *_dSel = nullptr;
+  struct Pinned { SelectResult sel; int64_t status[2]; int64_t nOut; };
+  Pinned *_hPinned = nullptr;
+  std::vector<uint32_t> _hTGap, _hQGap;   // host mirrors; qgap over local questions, bits past size set
+  int64_t _nTargetGaps = 0;
+  std::vector<Quiz *> _quizzes;
+  std::vector<int64_t> _quizGaps;
+  mutable std::mutex _mu;
+  std::atomic<uint64_t> _nQuestionsAsked{0};
+  Mode _mode = Mode::Regular;
+  // options
+  int64_t _optSelect = 0, _optWorkers = 16, _optEvalSubtasks = 0, _optEvalVariant = 0, _optBugCompat = 0;
+  uint64_t _rng[2] = {0, 0};
+};
+
+}  // namespace pqa

@@ -1,0 +1,183 @@
+// kb_kernels.hip -- knowledge-base construction / mutation and top-target listing on gfx950.
+//   fill_fresh      : CpuEngine ctor (reference: PqaCore/CpuEngine.cpp:44-84)  A = init^2, D = init^2*K, B = init
+//   fill_synthetic  : deterministic benchmark / test cube, bit-identical to probqa_amd/synth.py (numpy)
+//   train           : CETrainOperation::ProcessOne (PqaCore/CETrainOperation.cpp:15-25) for distinct questions
+//   top_targets     : ListTopTargets (PqaCore/CEListTopTargetsAlgorithm.cpp:30-95): descending probability
+#include "pqa_device.h"
+#include "pqa_kernels.h"
+
+namespace pqa {
+
+namespace {
+
+__global__ __launch_bounds__(256) void fill_fresh_kernel(double *__restrict__ cube, double *__restrict__ vB, int64_t K,
+                                                         int64_t Q, int64_t T, int64_t ldT, double initAmount) {
+  const double init1 = initAmount, initSqr = init1 * init1, initMD = initSqr * (double)K;  // CpuEngine.cpp:45-47
+  const int64_t total = Q * (K + 1) * ldT;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t t = i % ldT, r = (i / ldT) % (K + 1);
+    cube[i] = (t < T) ? (r < K ? initSqr : initMD) : (r < K ? 0.0 : 1.0);
+    if (i < ldT) vB[i] = (i < T) ? init1 : 0.0;
+  }
+}
+
+__device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
+  uint64_t z = x + 0x9E3779B97F4A7C15ULL;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+  return z ^ (z >> 31);
+}
+__device__ __forceinline__ double hash_unit(uint64_t seed, uint64_t idx) {  // uniform in [0,1), 53 bits
+  return (double)(splitmix64(seed + idx * 0x9E3779B97F4A7C15ULL) >> 11) * 0x1.0p-53;
+}
+
+// One thread per (question, target): loops over the answers so that D = sum_k A is accumulated in k order.
+__global__ __launch_bounds__(256) void fill_synth_kernel(double *__restrict__ cube, double *__restrict__ vB, int64_t K,
+                                                         int64_t Q, int64_t T, int64_t ldT, int64_t qOffset,
+                                                         int64_t qTotal, double initAmount, double nTrain,
+                                                         double noiseAmp, uint64_t seed) {
+  const int64_t total = Q * ldT;
+  const int64_t w = (32 * T) / 1000 > 1 ? (32 * T) / 1000 : 1;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t q = i / ldT, t = i % ldT;
+    double *col = cube + q * (K + 1) * ldT + t;
+    if (t >= T) {
+      for (int64_t k = 0; k < K; k++) col[k * ldT] = 0.0;
+      col[K * ldT] = 1.0;
+    } else {
+      const int64_t qg = qOffset + q;
+      const int64_t x = (qg * T) / qTotal;
+      int64_t ans;  // the +-32 "binary search" answer rule of PqaCoreTests/DichotomyTest.cpp:50-64, scaled by T/1000
+      if (t < x - w) ans = 0; else if (t < x) ans = 1; else if (t == x) ans = 2; else if (t <= x + w) ans = 3; else ans = 4;
+      if (ans > K - 1) ans = K - 1;
+      double d = 0.0;
+      for (int64_t k = 0; k < K; k++) {
+        double a = initAmount;
+        if (k == ans) a = a + nTrain;
+        a = a + noiseAmp * hash_unit(seed, (uint64_t)((qg * K + k) * T + t));
+        const double a2 = a * a;  // the cube stores squares (PqaCore/CETrainOperation.cpp:15-25)
+        col[k * ldT] = a2;
+        d = d + a2;
+      }
+      col[K * ldT] = d;
+    }
+    if (q == 0) vB[t] = (t < T) ? (initAmount + nTrain) + noiseAmp * hash_unit(seed ^ 0x5851F42D4C957F2DULL, (uint64_t)t) : 0.0;
+  }
+}
+
+__global__ void train_kernel(double *__restrict__ cube, double *__restrict__ vB, int64_t K, int64_t ldT,
+                             const int64_t *__restrict__ aqs, int64_t nAQs, int64_t iTarget, double amount) {
+  const double twoB = 2 * amount, bSquare = amount * amount;  // CETrainTaskNumSpec.h:24-32
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nAQs; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t q = aqs[2 * i], ans = aqs[2 * i + 1];
+    double *pA = cube + (q * (K + 1) + ans) * ldT + iTarget;
+    double *pD = cube + (q * (K + 1) + K) * ldT + iTarget;
+    const double a = sqrt(*pA);                                // CETrainOperation.cpp:18
+    const double addend = a * twoB + bSquare;                  // :19
+    *pA = *pA + addend;                                        // :23-24
+    *pD = *pD + addend;                                        // :25
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) vB[iTarget] += amount;  // PqaCore/CpuEngine.cpp:172
+}
+
+struct Cand {
+  double p;
+  int64_t t;
+};
+__device__ __forceinline__ bool cand_better(const Cand &a, const Cand &b) {
+  if (b.t < 0) return a.t >= 0;
+  if (a.t < 0) return false;
+  return (a.p > b.p) || (a.p == b.p && a.t < b.t);
+}
+
+// maxCount rounds of workgroup argmax with a "taken" bitmap in LDS.  Meant for small maxCount (top-1 .. top-few-100).
+__global__ __launch_bounds__(1024) void top_targets_kernel(const double *__restrict__ prior,
+                                                           const uint32_t *__restrict__ tgap, int64_t T,
+                                                           int64_t maxCount, RatedTargetDev *out, int64_t *nOut) {
+  extern __shared__ uint32_t taken[];  // ceil(T/32) words
+  __shared__ double sp[16];
+  __shared__ int64_t st[16];
+  __shared__ int64_t sWin;
+  const int64_t nWords = (T + 31) / 32;
+  for (int64_t i = threadIdx.x; i < nWords; i += blockDim.x) taken[i] = tgap[i];  // gaps are never listed
+  __syncthreads();
+  int64_t listed = 0;
+  for (int64_t r = 0; r < maxCount; r++) {
+    Cand b = {0.0, -1};
+    for (int64_t t = threadIdx.x; t < T; t += blockDim.x) {
+      if ((taken[t >> 5] >> (t & 31)) & 1u) continue;
+      const Cand c = {prior[t], t};
+      if (cand_better(c, b)) b = c;
+    }
+#pragma unroll
+    for (int m = kWave / 2; m >= 1; m >>= 1) {
+      Cand o;
+      o.p = __shfl_xor(b.p, m, kWave);
+      o.t = __shfl_xor(b.t, m, kWave);
+      if (cand_better(o, b)) b = o;
+    }
+    if (threadIdx.x % kWave == 0) {
+      sp[threadIdx.x / kWave] = b.p;
+      st[threadIdx.x / kWave] = b.t;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      Cand w = {sp[0], st[0]};
+      for (int i = 1; i < (int)(blockDim.x / kWave); i++) {
+        const Cand c = {sp[i], st[i]};
+        if (cand_better(c, w)) w = c;
+      }
+      sWin = w.t;
+      if (w.t >= 0) {
+        out[r].iTarget = w.t;
+        out[r].prob = w.p;
+        taken[w.t >> 5] |= 1u << (w.t & 31);
+      }
+    }
+    __syncthreads();
+    if (sWin < 0) break;
+    listed++;
+  }
+  if (threadIdx.x == 0) *nOut = listed;
+}
+
+unsigned grid_for(int64_t n, int threads) {
+  int64_t b = (n + threads - 1) / threads;
+  if (b > 256 * 32) b = 256 * 32;
+  if (b < 1) b = 1;
+  return (unsigned)b;
+}
+
+}  // namespace
+
+hipError_t LaunchFillFresh(double *cube, double *vB, int64_t K, int64_t Q, int64_t T, int64_t ldT, double initAmount,
+                           hipStream_t stream) {
+  hipLaunchKernelGGL(fill_fresh_kernel, dim3(grid_for(Q * (K + 1) * ldT, 256)), dim3(256), 0, stream, cube, vB, K, Q, T,
+                     ldT, initAmount);
+  return hipGetLastError();
+}
+
+hipError_t LaunchFillSynthetic(double *cube, double *vB, int64_t K, int64_t Q, int64_t T, int64_t ldT, int64_t qOffset,
+                               int64_t qTotal, double initAmount, double nTrain, double noiseAmp, uint64_t seed,
+                               hipStream_t stream) {
+  hipLaunchKernelGGL(fill_synth_kernel, dim3(grid_for(Q * ldT, 256)), dim3(256), 0, stream, cube, vB, K, Q, T, ldT,
+                     qOffset, qTotal, initAmount, nTrain, noiseAmp, seed);
+  return hipGetLastError();
+}
+
+hipError_t LaunchTrain(double *cube, double *vB, int64_t K, int64_t ldT, const int64_t *aqs, int64_t nAQs,
+                       int64_t iTarget, double amount, hipStream_t stream) {
+  hipLaunchKernelGGL(train_kernel, dim3(grid_for(nAQs, 64)), dim3(64), 0, stream, cube, vB, K, ldT, aqs, nAQs, iTarget,
+                     amount);
+  return hipGetLastError();
+}
+
+hipError_t LaunchTopTargets(const KbView &kb, const double *prior, int64_t maxCount, RatedTargetDev *out,
+                            int64_t *nOut, hipStream_t stream) {
+  const size_t shmem = (size_t)((kb.T + 31) / 32) * sizeof(uint32_t);
+  if (shmem > 60 * 1024) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(top_targets_kernel, dim3(1), dim3(1024), shmem, stream, prior, kb.tgap, kb.T, maxCount, out, nOut);
+  return hipGetLastError();
+}
+
+}  // namespace pqa

@@ -1,0 +1,76 @@
+// pqa_kernels.h -- launch wrappers for the CDNA4 (gfx950) kernels of the ProbQA question-evaluation hot path.
+// Host code (hip_engine.cpp) only sees these plain functions; everything runs on the stream it is given.
+//
+// Device layout of the knowledge base (one allocation, "cube"):
+//   cube[q][r][t],  q in [0,Q), r in [0,K] , t in [0,ldT)      -- fp64
+//     r <  K : sA[q][r][t]   squared answer counts        (reference: PqaCore/CpuEngine.decl.h:31-37 `_sA`)
+//     r == K : mD[q][t]      sum over answers of sA       (reference: `_mD`)
+//   ldT = T rounded up to 16 doubles (128 B) so every row starts on a cache line and 16-byte lane loads never straddle
+//   rows.  Padding columns t in [T,ldT) hold A=0, D=1 and are flagged as gaps in the target-gap bitmap.
+//   vB[t] (ldT doubles) is separate.  Bitmaps are uint32 words, LSB-first, bits past the size set (gap) as in
+//   PqaCore/GapTracker.h:9-15; the "asked" bitmap of a quiz has bits past Q clear.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace pqa {
+
+struct KbView {
+  const double *cube;     // [Q][K+1][ldT]
+  const double *vB;       // [ldT]
+  const uint32_t *tgap;   // target gap bits, ldT bits (+ slack), bits >= T set
+  const uint32_t *qgap;   // question gap bits, bits >= Q set
+  int64_t K, Q, T, ldT;
+  int64_t nValidTargets;  // T - #target gaps (PqaCore/CpuEngine.cpp:352)
+};
+
+struct SelectResult {     // 16 bytes, written by the select kernels
+  double priority;        // argmax: winning priority; sampled: grand total of priorities
+  int64_t index;          // selected question (global index) or -1
+};
+
+// Upload the Log2Hot table (1024 doubles, built by the host) to the device; once per process and device.
+hipError_t UploadLog2Table(const double *hostTable);
+
+// ---- a1: priority sweep.  priority[q - qFirst] for q in [qFirst,qLimit); 0 for gap / asked questions.
+// Returns hipSuccess or the launch error.  `variant`: 0 = auto, otherwise forces a kernel shape (tests/bench).
+hipError_t LaunchEvalQuestions(const KbView &kb, const double *prior, const uint32_t *asked, int64_t qFirst,
+                               int64_t qLimit, double *priority, int variant, hipStream_t stream);
+const char *EvalVariantName(const KbView &kb, int variant);
+
+// ---- selectors over priority[0..n) (questions qFirst..qFirst+n of the bitmaps); the reported index is
+// (position in priority[]) + outBase
+hipError_t LaunchSelectArgmax(const double *priority, const uint32_t *qgap, const uint32_t *asked, int64_t qFirst,
+                              int64_t n, int64_t outBase, SelectResult *out, hipStream_t stream);
+// Reference selector (PqaCore/CpuEngine.cpp:362-400): per-subtask Kahan run lengths, grand totals, upper_bound.
+// runLength: scratch of n doubles. rnd: the 64-bit random number the reference would draw.
+hipError_t LaunchSelectSampled(const double *priority, const uint32_t *qgap, const uint32_t *asked, int64_t qFirst,
+                               int64_t n, int64_t nSubtasks, uint64_t rnd, double *runLength, SelectResult *out,
+                               hipStream_t stream);
+
+// ---- prior updates (single workgroup, O(T)); nWorkers = emulated CPU worker count that fixes the summation order
+hipError_t LaunchStartQuiz(const KbView &kb, double *prior, int64_t nWorkers, hipStream_t stream);
+hipError_t LaunchRecordAnswer(const KbView &kb, double *prior, int64_t iQuestion, int64_t iAnswer, int64_t nWorkers,
+                              hipStream_t stream);
+// aqs: device array of (question, answer) int64 pairs.  exps: scratch of ldT int64.  status: device int64[2]
+// {error code (0 / 16 = I64Underflow), fullMax}.  bugCompat reproduces PqaCore/CEUpdatePriorsSubtaskMul.cpp:53.
+hipError_t LaunchResumeQuiz(const KbView &kb, double *prior, int64_t *exps, const int64_t *aqs, int64_t nAnswered,
+                            int64_t nWorkers, int bugCompat, int64_t *status, hipStream_t stream);
+
+// ---- KB construction / mutation
+hipError_t LaunchFillFresh(double *cube, double *vB, int64_t K, int64_t Q, int64_t T, int64_t ldT, double initAmount,
+                           hipStream_t stream);
+// Deterministic synthetic "binary-search trained + hash noise" cube (see probqa_amd/synth.py for the definition).
+hipError_t LaunchFillSynthetic(double *cube, double *vB, int64_t K, int64_t Q, int64_t T, int64_t ldT, int64_t qOffset,
+                               int64_t qTotal, double initAmount, double nTrain, double noiseAmp, uint64_t seed,
+                               hipStream_t stream);
+// Train / RecordQuizTarget (PqaCore/CETrainOperation.cpp:15-25): aqs device array of nAQs (q,a) pairs, distinct q.
+hipError_t LaunchTrain(double *cube, double *vB, int64_t K, int64_t ldT, const int64_t *aqs, int64_t nAQs,
+                       int64_t iTarget, double amount, hipStream_t stream);
+// ListTopTargets (PqaCore/CEListTopTargetsAlgorithm.cpp): top maxCount (prob,target) pairs, descending, gaps skipped.
+struct RatedTargetDev { int64_t iTarget; double prob; };
+hipError_t LaunchTopTargets(const KbView &kb, const double *prior, int64_t maxCount, RatedTargetDev *out,
+                            int64_t *nOut, hipStream_t stream);
+
+}  // namespace pqa

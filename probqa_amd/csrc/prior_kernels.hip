@@ -1,0 +1,208 @@
+// prior_kernels.hip -- Bayes prior / posterior updates of a quiz on CDNA4 (gfx950).
+//
+//   StartQuiz    : CESetPriorsSubtaskSum (reference: PqaCore/CESetPriorsSubtaskSum.cpp:17-40)
+//   RecordAnswer : CERecordAnswerSubtaskMul (PqaCore/CERecordAnswerSubtaskMul.cpp:15-42)
+//   ResumeQuiz   : CEUpdatePriorsSubtaskMul (PqaCore/CEUpdatePriorsSubtaskMul.cpp:16-114) +
+//                  CpuEngine::NormalizePriors (PqaCore/CpuEngine.cpp:284-335) with CENormPriorsSubtaskMax /
+//                  CENormPriorsSubtaskCorrSum
+//   all followed by Summator::ForPriors (PqaCore/Summator.h:11-21) and CEDivTargPriorsSubtask
+//   (PqaCore/CEDivTargPriorsSubtask.h:12-30).
+//
+// These are O(T) vector updates (8-80 KB): one workgroup, latency-bound, 0.04 % of the reference's profile.  They are
+// written to be BIT-IDENTICAL to the CPU engine instead of fast: element-wise steps use IEEE division / multiplication
+// and the exponent surgery of the reference, and the normalising sum reproduces the reference's summation order --
+// `nWorkers` subtasks over ceil(T/4) AVX vectors (SRPoolRunner::CalcSplit), 4 Kahan lanes per subtask
+// (lane c sums targets == c mod 4), PreciseSum per subtask, serial Kahan over the subtasks.  One GPU lane runs one
+// (subtask, AVX-lane) chain.
+#include "pqa_device.h"
+#include "pqa_kernels.h"
+
+namespace pqa {
+
+namespace {
+
+constexpr int kThreads = 1024;
+
+__device__ __forceinline__ int64_t split_bound(int64_t i, int64_t quot, int64_t rem) {  // end of subtask i
+  const int64_t n1 = (i + 1 < rem) ? (i + 1) : rem;
+  return (i + 1) * quot + n1;
+}
+
+// Sum v[0 .. 4*nVects) exactly as the CPU engine does and return the total to every thread.
+// lds: 8*nSubtasks + 1 doubles.  Must be called by all threads; contains barriers.
+__device__ double reference_order_sum(const double *__restrict__ v, int64_t nVects, int64_t nWorkers, double *lds) {
+  const int64_t quot = nVects / nWorkers, rem = nVects % nWorkers;
+  const int64_t nSubtasks = (quot == 0) ? rem : nWorkers;
+  __syncthreads();  // v was written by other threads of this workgroup
+  for (int64_t ch = threadIdx.x; ch < nSubtasks * 4; ch += blockDim.x) {
+    const int64_t s = ch >> 2;
+    const int c = (int)(ch & 3);
+    const int64_t first = (s == 0) ? 0 : split_bound(s - 1, quot, rem), limit = split_bound(s, quot, rem);
+    double sum = 0, corr = 0;  // SRAccumVectDbl256::Add, SRPlatform/Interface/SRAccumVectDbl256.h:40-46
+    for (int64_t j = first; j < limit; j++) {
+      const double y = v[4 * j + c] - corr;
+      const double t = sum + y;
+      corr = (t - sum) - y;
+      sum = t;
+    }
+    lds[8 * s + c] = sum;
+    lds[8 * s + 4 + c] = corr;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    Kahan1 acc;  // Summator::ForPriors, PqaCore/Summator.h:14-19
+    acc.init(0.0);
+    for (int64_t s = 0; s < nSubtasks; s++) acc.add(precise_sum4(lds + 8 * s, lds + 8 * s + 4));
+    lds[8 * nSubtasks] = acc.get();
+  }
+  __syncthreads();
+  return lds[8 * nSubtasks];
+}
+
+struct PriorArgs {
+  const double *cube;
+  const double *vB;
+  const uint32_t *tgap;
+  double *prior;
+  int64_t K, T, ldT, nWorkers;
+};
+
+__global__ __launch_bounds__(kThreads) void start_quiz_kernel(PriorArgs a) {
+  extern __shared__ double lds[];
+  const int64_t nVects = (a.T + 3) >> 2;
+  for (int64_t t = threadIdx.x; t < a.ldT; t += blockDim.x)
+    a.prior[t] = bit_test(a.tgap, t) ? 0.0 : a.vB[t];          // CESetPriorsSubtaskSum.cpp:28-31
+  const double total = reference_order_sum(a.prior, nVects, a.nWorkers, lds);
+  for (int64_t t = threadIdx.x; t < 4 * nVects; t += blockDim.x) a.prior[t] = a.prior[t] / total;  // CEDivTargPriors :19
+}
+
+__global__ __launch_bounds__(kThreads) void record_answer_kernel(PriorArgs a, int64_t iQuestion, int64_t iAnswer) {
+  extern __shared__ double lds[];
+  const int64_t nVects = (a.T + 3) >> 2;
+  const double *rowA = a.cube + (iQuestion * (a.K + 1) + iAnswer) * a.ldT;  // CERecordAnswerSubtaskMul.cpp:25
+  const double *rowD = a.cube + (iQuestion * (a.K + 1) + a.K) * a.ldT;      // :26
+  for (int64_t t = threadIdx.x; t < a.ldT; t += blockDim.x) {
+    const double pQaGivenT = rowA[t] / rowD[t];                // :31
+    const double product = a.prior[t] * pQaGivenT;             // :34
+    a.prior[t] = bit_test(a.tgap, t) ? 0.0 : product;          // :35-37
+  }
+  const double total = reference_order_sum(a.prior, nVects, a.nWorkers, lds);
+  for (int64_t t = threadIdx.x; t < 4 * nVects; t += blockDim.x) a.prior[t] = a.prior[t] / total;
+}
+
+__device__ __forceinline__ int ceil_log2_u64(uint64_t val) {  // SRPlatform/Interface/SRMath.h:46-51
+  if (!val) return 0;
+  const int index = 63 - __clzll((long long)val);
+  return index + ((val & (val - 1)) ? 1 : 0);
+}
+
+__global__ __launch_bounds__(kThreads) void resume_quiz_kernel(PriorArgs a, int64_t *__restrict__ exps,
+                                                               const int64_t *__restrict__ aqs, int64_t nAnswered,
+                                                               int bugCompat, int64_t *status) {
+  extern __shared__ double lds[];
+  __shared__ long long sMax[kThreads / kWave];
+  __shared__ long long sCorr;
+  const int64_t nVects = (a.T + 3) >> 2;
+  // a8: every target runs its own chain of products over the answered questions, mantissa and exponent kept apart.
+  long long myMax = INT64_MIN;
+  for (int64_t t = threadIdx.x; t < a.ldT; t += blockDim.x) {
+    double mant;
+    int64_t ex;
+    {
+      const int64_t q = aqs[0], ans = aqs[1];
+      const double pQaGivenT = a.cube[(q * (a.K + 1) + ans) * a.ldT + t] / a.cube[(q * (a.K + 1) + a.K) * a.ldT + t];
+      const double oldMant = bugCompat ? a.vB[t & 3] : a.vB[t];  // CEUpdatePriorsSubtaskMul.cpp:53 loads pvB, not pvB+j
+      const uint64_t up = d2u(oldMant * pQaGivenT);              // :54
+      mant = u2d(kExp0Up | (up & ~kExpMaskUp));                  // :56 MakeExponent0
+      ex = (int64_t)((up & kExpMaskUp) >> 52);                   // :59 ExtractExponents64<false>
+    }
+    for (int64_t i = 1; i < nAnswered; i++) {
+      const int64_t q = aqs[2 * i], ans = aqs[2 * i + 1];
+      const double pQaGivenT = a.cube[(q * (a.K + 1) + ans) * a.ldT + t] / a.cube[(q * (a.K + 1) + a.K) * a.ldT + t];
+      const uint64_t up = d2u(mant * pQaGivenT);                 // :75
+      mant = u2d(kExp0Up | (up & ~kExpMaskUp));                  // :77
+      ex += (int64_t)((up & kExpMaskUp) >> 52);                  // :80-82
+    }
+    a.prior[t] = mant;
+    exps[t] = ex;
+    // a9 part 1: CENormPriorsSubtaskMax (gap lanes retain the running maximum)
+    const long long totExp = ex + (long long)((d2u(mant) & kExpMaskUp) >> 52);
+    if (t < 4 * nVects && !bit_test(a.tgap, t) && totExp > myMax) myMax = totExp;
+  }
+#pragma unroll
+  for (int m = kWave / 2; m >= 1; m >>= 1) {
+    const long long o = __shfl_xor(myMax, m, kWave);
+    myMax = o > myMax ? o : myMax;
+  }
+  if (threadIdx.x % kWave == 0) sMax[threadIdx.x / kWave] = myMax;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    long long fullMax = sMax[0];
+    for (int w = 1; w < kThreads / kWave; w++) fullMax = sMax[w] > fullMax ? sMax[w] : fullMax;
+    const long long highBound = 1023 + 1023 - ceil_log2_u64((uint64_t)a.T) - 2;  // CpuEngine.cpp:316
+    const long long minAllowed = INT64_MIN + highBound + 1;                      // :317
+    status[1] = fullMax;
+    if (fullMax <= minAllowed) {                                                 // :318-321 I64Underflow
+      status[0] = 16;
+      sCorr = INT64_MIN;
+    } else {
+      status[0] = 0;
+      sCorr = highBound - fullMax;                                               // :322
+    }
+  }
+  __syncthreads();
+  const long long corrExp = sCorr;
+  if (corrExp == INT64_MIN) return;  // error: priors left un-normalised, the host destroys the quiz
+  // a9 part 2: CENormPriorsSubtaskCorrSum::Process (CENormPriorsSubtaskCorrSum.cpp:25-40)
+  for (int64_t t = threadIdx.x; t < a.ldT; t += blockDim.x) {
+    const uint64_t um = d2u(a.prior[t]);
+    const long long normExp = exps[t] + (long long)((um & kExpMaskUp) >> 52) + corrExp;
+    const bool assume0 = (1 > normExp) || bit_test(a.tgap, t);
+    a.prior[t] = assume0 ? 0.0 : u2d(((uint64_t)normExp << 52) | (um & ~kExpMaskUp));  // ReplaceExponents
+    exps[t] = 0;
+  }
+  const double total = reference_order_sum(a.prior, nVects, a.nWorkers, lds);
+  for (int64_t t = threadIdx.x; t < 4 * nVects; t += blockDim.x) a.prior[t] = a.prior[t] / total;
+}
+
+size_t sum_lds_bytes(int64_t nWorkers) { return (size_t)(8 * nWorkers + 1) * sizeof(double); }
+
+PriorArgs make_args(const KbView &kb, double *prior, int64_t nWorkers) {
+  PriorArgs a;
+  a.cube = kb.cube;
+  a.vB = kb.vB;
+  a.tgap = kb.tgap;
+  a.prior = prior;
+  a.K = kb.K;
+  a.T = kb.T;
+  a.ldT = kb.ldT;
+  a.nWorkers = nWorkers;
+  return a;
+}
+
+}  // namespace
+
+hipError_t LaunchStartQuiz(const KbView &kb, double *prior, int64_t nWorkers, hipStream_t stream) {
+  if (nWorkers < 1 || nWorkers > 4096) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(start_quiz_kernel, dim3(1), dim3(kThreads), sum_lds_bytes(nWorkers), stream,
+                     make_args(kb, prior, nWorkers));
+  return hipGetLastError();
+}
+
+hipError_t LaunchRecordAnswer(const KbView &kb, double *prior, int64_t iQuestion, int64_t iAnswer, int64_t nWorkers,
+                              hipStream_t stream) {
+  if (nWorkers < 1 || nWorkers > 4096) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(record_answer_kernel, dim3(1), dim3(kThreads), sum_lds_bytes(nWorkers), stream,
+                     make_args(kb, prior, nWorkers), iQuestion, iAnswer);
+  return hipGetLastError();
+}
+
+hipError_t LaunchResumeQuiz(const KbView &kb, double *prior, int64_t *exps, const int64_t *aqs, int64_t nAnswered,
+                            int64_t nWorkers, int bugCompat, int64_t *status, hipStream_t stream) {
+  if (nWorkers < 1 || nWorkers > 4096 || nAnswered < 1) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(resume_quiz_kernel, dim3(1), dim3(kThreads), sum_lds_bytes(nWorkers), stream,
+                     make_args(kb, prior, nWorkers), exps, aqs, nAnswered, bugCompat, status);
+  return hipGetLastError();
+}
+
+}  // namespace pqa

@@ -1,0 +1,104 @@
+"""Question-axis sharding of one knowledge base over the GPUs of a node (one process per GPU).
+
+The reference has no multi-device path (PqaCore/BaseCudaEngine.cpp:15 hard-wires device 0;
+PqaCore/PqaEngineBaseFactory.cpp:85-91 `CreateGridEngine` is a stub).  The path shards naturally: the priority of a
+question depends only on its own sA/mD rows plus the small replicated prior vector
+(PqaCore/CEEvalQsSubtaskConsider.cpp:53-215), so every rank sweeps its contiguous question range
+(SRPoolRunner::CalcSplit, SRPlatform/Interface/SRPoolRunner.h:96-110) and ONE tiny collective picks the global winner:
+an all-gather of 16-byte (priority, global index) records over RCCL/xGMI followed by a local pick (exact, lowest
+index on ties).  The message is 16 B per GPU, so the collective is latency-bound; ring bandwidth is irrelevant.
+RecordAnswer runs on the rank that owns the answered question and the new prior vector (8*ldT bytes) is broadcast.
+
+`torch.distributed` is plumbing only: backend "nccl" is RCCL on ROCm, "gloo" is used by the CPU tests, where the
+local selection comes from a caller-supplied function instead of the HIP engine.
+"""
+from __future__ import annotations
+
+from typing import Callable, List, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(n_questions: int, world_size: int) -> List[int]:
+    """End bound of each rank's contiguous question range; the reference's CalcSplit arithmetic."""
+    quot, rem = divmod(n_questions, world_size)
+    bounds, nxt = [], 0
+    for r in range(world_size):
+        nxt += quot + (1 if r < rem else 0)
+        bounds.append(nxt)
+    return bounds
+
+
+def shard_range(n_questions: int, world_size: int, rank: int) -> Tuple[int, int]:
+    b = shard_bounds(n_questions, world_size)
+    return (0 if rank == 0 else b[rank - 1]), b[rank]
+
+
+def pick_global(records: torch.Tensor) -> Tuple[float, int]:
+    """records: [world, 2] float64 rows (priority, index-as-bits).  Returns (priority, global question) of the
+    maximum priority, lowest index on ties, -1 if no shard had an eligible question.  NaN never wins."""
+    pri = records[:, 0].clone()
+    idx = records[:, 1].contiguous().view(torch.int64)
+    valid = idx >= 0
+    if not bool(valid.any()):
+        return float("nan"), -1
+    pri = torch.where(valid & ~torch.isnan(pri), pri, torch.full_like(pri, float("-inf")))
+    best = pri.max()
+    cand = torch.where((pri == best) & valid, idx, torch.full_like(idx, torch.iinfo(torch.int64).max))
+    return float(best), int(cand.min())
+
+
+class ShardedSelector:
+    """Global next-question selection over question shards.
+
+    local_select(out) must ENQUEUE (stream-ordered, no host sync needed) the local sweep + argmax and write the
+    16-byte record (float64 priority, int64 GLOBAL index or -1) into `out`, a 2-element float64 tensor on the
+    collective's device.  With the HIP engine this is `PqaHip_EnqueueSelectArgmax(engine, quiz, out.data_ptr())`.
+    """
+
+    def __init__(self, local_select: Callable[[torch.Tensor], None], device: torch.device,
+                 group: Optional[dist.ProcessGroup] = None):
+        self.local_select = local_select
+        self.device = device
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.local = torch.zeros(2, dtype=torch.float64, device=device)
+        self.gathered = torch.zeros(self.world, 2, dtype=torch.float64, device=device)
+
+    def enqueue(self) -> torch.Tensor:
+        """Sweep + local argmax + all-gather, all stream-ordered; returns the [world,2] device tensor."""
+        self.local_select(self.local)
+        if self.world == 1:
+            self.gathered[0].copy_(self.local)
+        else:
+            dist.all_gather_into_tensor(self.gathered.view(-1), self.local, group=self.group)
+        return self.gathered
+
+    def select(self) -> Tuple[float, int]:
+        recs = self.enqueue()
+        return pick_global(recs.cpu())
+
+
+def broadcast_prior(prior: torch.Tensor, owner_rank: int, group: Optional[dist.ProcessGroup] = None) -> None:
+    """After RecordAnswer on the owner of the answered question: replicate the new prior vector."""
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.broadcast(prior, src=owner_rank, group=group)
+
+
+def owner_of(question: int, n_questions: int, world_size: int) -> int:
+    for r, b in enumerate(shard_bounds(n_questions, world_size)):
+        if question < b:
+            return r
+    raise IndexError(question)
+
+
+def tensor_from_device_ptr(ptr: int, n_doubles: int, device: torch.device) -> torch.Tensor:
+    """Wrap engine-owned device memory (e.g. a quiz's prior vector) as a torch tensor without copying."""
+
+    class _Holder:
+        pass
+
+    h = _Holder()
+    h.__cuda_array_interface__ = {"shape": (n_doubles,), "typestr": "<f8", "data": (ptr, False), "version": 3}
+    return torch.as_tensor(h, device=device)

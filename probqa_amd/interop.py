@@ -1,0 +1,500 @@
+"""ctypes binding of libPqaCore.so (the MI355X engine) with the reference wrapper's Python API.
+
+The class and method names, argument meaning and error behaviour mirror the reference's
+``Interop/Python/ProbQAInterop/ProbQA.py`` (structs :72-116, prototypes :119-296, ``PqaEngine`` :423-741,
+``PqaEngineFactory`` :743-783) so that code written against it runs unchanged; the reference module itself cannot be
+imported on Linux (it subclasses ``ctypes.WinDLL`` and loads ``DLLs/PqaCore.dll``).  Everything below the C ABI is
+HIP; there is no CPU fallback: loading fails loudly when the library is missing, and engine creation returns an
+error when no GPU is present.
+
+Additive, MI355X-specific methods (``eval_priorities``, ``next_question_argmax`` ...) bind ``include/PqaHipExt.h``.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from enum import Enum
+from typing import List, Optional, Tuple
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.environ.get("PQACORE_LIB", os.path.join(_HERE, "libPqaCore.so"))
+
+
+class CiEngineDefinition(ctypes.Structure):  # reference PqaCInterop.h:10-19
+    _pack_ = 8
+    _fields_ = [("nAnswers", ctypes.c_int64), ("nQuestions", ctypes.c_int64), ("nTargets", ctypes.c_int64),
+                ("precType", ctypes.c_uint8), ("precExponent", ctypes.c_uint16), ("precMantissa", ctypes.c_uint32),
+                ("initAmount", ctypes.c_double), ("memPoolMaxBytes", ctypes.c_uint64)]
+
+
+class CiAnsweredQuestion(ctypes.Structure):
+    _pack_ = 8
+    _fields_ = [("iQuestion", ctypes.c_int64), ("iAnswer", ctypes.c_int64)]
+
+
+class CiEngineDimensions(ctypes.Structure):
+    _pack_ = 8
+    _fields_ = [("nAnswers", ctypes.c_int64), ("nQuestions", ctypes.c_int64), ("nTargets", ctypes.c_int64)]
+
+
+class CiRatedTarget(ctypes.Structure):
+    _pack_ = 8
+    _fields_ = [("iTarget", ctypes.c_int64), ("prob", ctypes.c_double)]
+
+
+class CiAddQorTParam(ctypes.Structure):
+    _pack_ = 8
+    _fields_ = [("index", ctypes.c_int64), ("initAmount", ctypes.c_double)]
+
+
+class CiHipShard(ctypes.Structure):  # include/PqaHipExt.h
+    _pack_ = 8
+    _fields_ = [("qFirst", ctypes.c_int64), ("qTotal", ctypes.c_int64), ("device", ctypes.c_int32),
+                ("reserved", ctypes.c_int32)]
+
+
+class CiHipSelection(ctypes.Structure):
+    _pack_ = 8
+    _fields_ = [("priority", ctypes.c_double), ("iQuestion", ctypes.c_int64)]
+
+
+_vp, _i64, _u64, _u8, _dbl = ctypes.c_void_p, ctypes.c_int64, ctypes.c_uint64, ctypes.c_uint8, ctypes.c_double
+_pvp = ctypes.POINTER(ctypes.c_void_p)
+_pi64 = ctypes.POINTER(ctypes.c_int64)
+_pdbl = ctypes.POINTER(ctypes.c_double)
+_pAQ = ctypes.POINTER(CiAnsweredQuestion)
+
+# name -> (restype, argtypes): the 40 reference exports (PqaCInterop.h:48-108) ...
+REFERENCE_EXPORTS = {
+    "CiDebugBreak": (None, []),
+    "Logger_Init": (_u8, [_pvp, ctypes.c_char_p]),
+    "CiReleaseString": (None, [_vp]),
+    "CiGetPqaEngineFactory": (_vp, []),
+    "PqaEngineFactory_CreateCpuEngine": (_vp, [_vp, _pvp, ctypes.POINTER(CiEngineDefinition)]),
+    "PqaEngineFactory_LoadCpuEngine": (_vp, [_vp, _pvp, ctypes.c_char_p, _u64]),
+    "CiReleasePqaError": (None, [_vp]),
+    "PqaError_ToString": (_vp, [_vp, _u8]),
+    "CiReleasePqaEngine": (None, [_vp]),
+    "PqaEngine_Train": (_vp, [_vp, _i64, _pAQ, _i64, _dbl]),
+    "PqaEngine_QuestionPermFromComp": (_u8, [_vp, _i64, _pi64]),
+    "PqaEngine_QuestionCompFromPerm": (_u8, [_vp, _i64, _pi64]),
+    "PqaEngine_TargetPermFromComp": (_u8, [_vp, _i64, _pi64]),
+    "PqaEngine_TargetCompFromPerm": (_u8, [_vp, _i64, _pi64]),
+    "PqaEngine_QuizPermFromComp": (_u8, [_vp, _i64, _pi64]),
+    "PqaEngine_QuizCompFromPerm": (_u8, [_vp, _i64, _pi64]),
+    "PqaEngine_EnsurePermQuizGreater": (_u8, [_vp, _i64]),
+    "PqaEngine_RemapQuizPermId": (_u8, [_vp, _i64, _i64]),
+    "PqaEngine_GetTotalQuestionsAsked": (_u64, [_vp, _pvp]),
+    "PqaEngine_CopyDims": (_u8, [_vp, ctypes.POINTER(CiEngineDimensions)]),
+    "PqaEngine_StartQuiz": (_i64, [_vp, _pvp]),
+    "PqaEngine_ResumeQuiz": (_i64, [_vp, _pvp, _i64, _pAQ]),
+    "PqaEngine_NextQuestion": (_i64, [_vp, _pvp, _i64]),
+    "PqaEngine_RecordAnswer": (_vp, [_vp, _i64, _i64]),
+    "PqaEngine_ClearOldQuizzes": (_vp, [_vp, _i64, _dbl]),
+    "PqaEngine_GetActiveQuestionId": (_i64, [_vp, _pvp, _i64]),
+    "PqaEngine_SetActiveQuestion": (_vp, [_vp, _i64, _i64]),
+    "PqaEngine_ListTopTargets": (_i64, [_vp, _pvp, _i64, _i64, ctypes.POINTER(CiRatedTarget)]),
+    "PqaEngine_RecordQuizTarget": (_vp, [_vp, _i64, _i64, _dbl]),
+    "PqaEngine_ReleaseQuiz": (_vp, [_vp, _i64]),
+    "PqaEngine_SaveKB": (_vp, [_vp, ctypes.c_char_p, _u8]),
+    "PqaEngine_StartMaintenance": (_vp, [_vp, ctypes.c_bool]),
+    "PqaEngine_FinishMaintenance": (_vp, [_vp]),
+    "PqaEngine_AddQsTs": (_vp, [_vp, _i64, ctypes.POINTER(CiAddQorTParam), _i64, ctypes.POINTER(CiAddQorTParam)]),
+    "PqaEngine_RemoveQuestions": (_vp, [_vp, _i64, _pi64]),
+    "PqaEngine_RemoveTargets": (_vp, [_vp, _i64, _pi64]),
+    "PqaEngine_Compact": (_vp, [_vp, _pi64, ctypes.POINTER(_pi64), _pi64, ctypes.POINTER(_pi64)]),
+    "CiReleaseCompaction": (None, [_pi64]),
+    "PqaEngine_Shutdown": (_vp, [_vp, ctypes.c_char_p]),
+    "PqaEngine_SetLogger": (_vp, [_vp, _vp]),
+}
+# ... and the additive ones (include/PqaHipExt.h)
+HIP_EXPORTS = {
+    "PqaEngineFactory_CreateHipEngine": (_vp, [_vp, _pvp, ctypes.POINTER(CiEngineDefinition)]),
+    "PqaEngineFactory_CreateHipEngineSharded": (_vp, [_vp, _pvp, ctypes.POINTER(CiEngineDefinition),
+                                                      ctypes.POINTER(CiHipShard)]),
+    "PqaHip_SetOption": (_vp, [_vp, ctypes.c_char_p, _i64]),
+    "PqaHip_GetOption": (_i64, [_vp, ctypes.c_char_p]),
+    "PqaHip_EvalKernelName": (ctypes.c_char_p, [_vp]),
+    "PqaHip_SetKB": (_vp, [_vp, _pdbl, _pdbl, _pdbl]),
+    "PqaHip_GetKB": (_vp, [_vp, _pdbl, _pdbl, _pdbl]),
+    "PqaHip_FillSynthetic": (_vp, [_vp, _dbl, _dbl, _u64]),
+    "PqaHip_SetTargetGaps": (_vp, [_vp, _i64, _pi64]),
+    "PqaHip_SetQuestionGaps": (_vp, [_vp, _i64, _pi64]),
+    "PqaEngine_EvalPriorities": (_vp, [_vp, _i64, _pdbl, _i64]),
+    "PqaEngine_NextQuestionArgmax": (_i64, [_vp, _pvp, _i64]),
+    "PqaEngine_NextQuestionSampled": (_i64, [_vp, _pvp, _i64, _u64]),
+    "PqaHip_GetPriors": (_vp, [_vp, _i64, _pdbl, _i64]),
+    "PqaHip_GetStream": (_vp, [_vp]),
+    "PqaHip_SetStream": (_vp, [_vp, _vp]),
+    "PqaHip_Synchronize": (_vp, [_vp]),
+    "PqaHip_EnqueueSelectArgmax": (_vp, [_vp, _i64, _vp]),
+    "PqaHip_EnqueueEval": (_vp, [_vp, _i64]),
+    "PqaHip_GetPriorDevicePtr": (_vp, [_vp, _i64, _pvp, _pi64]),
+    "PqaHip_RecordAnswerRemote": (_vp, [_vp, _i64, _i64]),
+}
+
+_lib = None
+
+
+def load_library(path: Optional[str] = None) -> ctypes.CDLL:
+    """Load libPqaCore.so and declare every prototype.  Raises OSError if the HIP library is not built."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise OSError(f"{p} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                      "(there is no CPU fallback)")
+    lib = ctypes.CDLL(p, mode=ctypes.RTLD_GLOBAL)
+    for table in (REFERENCE_EXPORTS, HIP_EXPORTS):
+        for name, (res, args) in table.items():
+            fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+    if path is None:
+        _lib = lib
+    return lib
+
+
+class PqaException(Exception):  # reference ProbQA.py:300-302
+    pass
+
+
+class PrecisionType(Enum):  # reference PqaCommon.h:17-24
+    NONE = 0
+    FLOAT = 1
+    FLOAT_PAIR = 2
+    DOUBLE = 3
+    DOUBLE_PAIR = 4
+    ARBITRARY = 5
+
+
+class AnsweredQuestion:
+    def __init__(self, i_question: int, i_answer: int):
+        self.i_question = i_question
+        self.i_answer = i_answer
+
+    def __repr__(self):
+        return f"[q={self.i_question}, a={self.i_answer}]"
+
+
+class RatedTarget:
+    def __init__(self, i_target: int, prob: float):
+        self.i_target = i_target
+        self.prob = prob
+
+    def __repr__(self):
+        return f"[t={self.i_target}, p={self.prob}]"
+
+
+class EngineDefinition:
+    DEFAULT_MEM_POOL_MAX_BYTES = 512 * 1024 * 1024
+
+    def __init__(self, n_answers: int, n_questions: int, n_targets: int, init_amount=1.0,
+                 prec_type=PrecisionType.DOUBLE, prec_exponent=11, prec_mantissa=53,
+                 mem_pool_max_bytes=DEFAULT_MEM_POOL_MAX_BYTES):
+        self.n_answers, self.n_questions, self.n_targets = n_answers, n_questions, n_targets
+        self.init_amount = init_amount
+        self.prec_type, self.prec_exponent, self.prec_mantissa = prec_type, prec_exponent, prec_mantissa
+        self.mem_pool_max_bytes = mem_pool_max_bytes
+
+    def to_c(self) -> CiEngineDefinition:
+        c = CiEngineDefinition()
+        c.nAnswers, c.nQuestions, c.nTargets = self.n_answers, self.n_questions, self.n_targets
+        c.precType, c.precExponent, c.precMantissa = self.prec_type.value, self.prec_exponent, self.prec_mantissa
+        c.initAmount, c.memPoolMaxBytes = self.init_amount, self.mem_pool_max_bytes
+        return c
+
+
+class EngineDimensions:
+    def __init__(self, n_answers: int, n_questions: int, n_targets: int):
+        self.n_answers, self.n_questions, self.n_targets = n_answers, n_questions, n_targets
+
+    def __repr__(self):
+        return f"[nAnswers={self.n_answers}, nQuestions={self.n_questions}, nTargets={self.n_targets}]"
+
+
+class PqaError:
+    """Owns a native PqaError* (reference ProbQA.py:399-420)."""
+
+    @staticmethod
+    def factor(c_err) -> Optional["PqaError"]:
+        if not c_err:
+            return None
+        return PqaError(c_err)
+
+    def __init__(self, c_err):
+        self.c_err = ctypes.c_void_p(c_err) if not isinstance(c_err, ctypes.c_void_p) else c_err
+
+    def __del__(self):
+        if self.c_err and _lib is not None:
+            _lib.CiReleasePqaError(self.c_err)
+            self.c_err = None
+
+    def __repr__(self):
+        return self.to_string(True)
+
+    def to_string(self, with_params: bool) -> str:
+        p = _lib.PqaError_ToString(self.c_err, 1 if with_params else 0)
+        try:
+            return ctypes.cast(p, ctypes.c_char_p).value.decode("utf-8", "replace")
+        finally:
+            _lib.CiReleaseString(p)
+
+
+def _check(c_err, throw: bool = True) -> Optional[PqaError]:
+    err = PqaError.factor(c_err)
+    if err and throw:
+        raise PqaException(err.to_string(True))
+    return err
+
+
+def _dptr(a: np.ndarray):
+    return a.ctypes.data_as(_pdbl)
+
+
+class PqaEngine:
+    """Reference ProbQA.py:423-741 plus the additive MI355X methods."""
+
+    def __init__(self, c_engine):
+        self.c_engine = ctypes.c_void_p(c_engine)
+
+    def __del__(self):
+        self.close()
+
+    def close(self):
+        if getattr(self, "c_engine", None) and _lib is not None:
+            _lib.CiReleasePqaEngine(self.c_engine)
+            self.c_engine = None
+
+    # ---- id mapping ---------------------------------------------------------------------------------------------
+    def __call_id_mapping(self, fn, ids: List[int]) -> List[int]:
+        arr = (ctypes.c_int64 * len(ids))(*ids)
+        fn(self.c_engine, len(ids), arr)
+        return list(arr)
+
+    def question_perm_from_comp(self, ids): return self.__call_id_mapping(_lib.PqaEngine_QuestionPermFromComp, ids)
+    def question_comp_from_perm(self, ids): return self.__call_id_mapping(_lib.PqaEngine_QuestionCompFromPerm, ids)
+    def target_perm_from_comp(self, ids): return self.__call_id_mapping(_lib.PqaEngine_TargetPermFromComp, ids)
+    def target_comp_from_perm(self, ids): return self.__call_id_mapping(_lib.PqaEngine_TargetCompFromPerm, ids)
+    def quiz_perm_from_comp(self, ids): return self.__call_id_mapping(_lib.PqaEngine_QuizPermFromComp, ids)
+    def quiz_comp_from_perm(self, ids): return self.__call_id_mapping(_lib.PqaEngine_QuizCompFromPerm, ids)
+
+    def ensure_perm_quiz_greater(self, bound: int) -> bool:
+        return _lib.PqaEngine_EnsurePermQuizGreater(self.c_engine, bound) != 0
+
+    def remap_quiz_perm_id(self, src_id: int, dest_id: int, throw: bool = True) -> bool:
+        ok = _lib.PqaEngine_RemapQuizPermId(self.c_engine, src_id, dest_id) != 0
+        if not ok and throw:
+            raise PqaException(f"Failed to remap quiz permanent ID {src_id} to {dest_id}")
+        return ok
+
+    @staticmethod
+    def to_c_answered_questions(answered_questions: List[AnsweredQuestion]):
+        n = len(answered_questions)
+        arr = (CiAnsweredQuestion * max(n, 1))()
+        for i, aq in enumerate(answered_questions):
+            arr[i].iQuestion, arr[i].iAnswer = aq.i_question, aq.i_answer
+        return arr, n
+
+    # ---- reference operations -----------------------------------------------------------------------------------
+    def train(self, answered_questions: List[AnsweredQuestion], i_target: int, amount: float = 1.0,
+              throw: bool = True) -> Optional[PqaError]:
+        arr, n = self.to_c_answered_questions(answered_questions)
+        return _check(_lib.PqaEngine_Train(self.c_engine, n, arr, i_target, amount), throw)
+
+    def get_total_questions_asked(self) -> int:
+        c_err = ctypes.c_void_p()
+        res = _lib.PqaEngine_GetTotalQuestionsAsked(self.c_engine, ctypes.byref(c_err))
+        _check(c_err.value)
+        return res
+
+    def copy_dims(self) -> EngineDimensions:
+        d = CiEngineDimensions()
+        if _lib.PqaEngine_CopyDims(self.c_engine, ctypes.byref(d)) == 0:
+            raise PqaException("PqaEngine_CopyDims() failed")
+        return EngineDimensions(d.nAnswers, d.nQuestions, d.nTargets)
+
+    def start_quiz(self) -> int:
+        c_err = ctypes.c_void_p()
+        i_quiz = _lib.PqaEngine_StartQuiz(self.c_engine, ctypes.byref(c_err))
+        _check(c_err.value)
+        return i_quiz
+
+    def resume_quiz(self, answered_questions: List[AnsweredQuestion]) -> int:
+        arr, n = self.to_c_answered_questions(answered_questions)
+        c_err = ctypes.c_void_p()
+        i_quiz = _lib.PqaEngine_ResumeQuiz(self.c_engine, ctypes.byref(c_err), n, arr)
+        _check(c_err.value)
+        return i_quiz
+
+    def next_question(self, i_quiz: int) -> int:
+        c_err = ctypes.c_void_p()
+        q = _lib.PqaEngine_NextQuestion(self.c_engine, ctypes.byref(c_err), i_quiz)
+        _check(c_err.value)
+        return q
+
+    def record_answer(self, i_quiz: int, i_answer: int, throw: bool = True) -> Optional[PqaError]:
+        return _check(_lib.PqaEngine_RecordAnswer(self.c_engine, i_quiz, i_answer), throw)
+
+    def get_active_question_id(self, i_quiz: int) -> int:
+        c_err = ctypes.c_void_p()
+        q = _lib.PqaEngine_GetActiveQuestionId(self.c_engine, ctypes.byref(c_err), i_quiz)
+        _check(c_err.value)
+        return q
+
+    def set_active_question(self, i_quiz: int, i_question: int, throw: bool = True) -> Optional[PqaError]:
+        return _check(_lib.PqaEngine_SetActiveQuestion(self.c_engine, i_quiz, i_question), throw)
+
+    def list_top_targets(self, i_quiz: int, max_count: int) -> List[RatedTarget]:
+        arr = (CiRatedTarget * max(max_count, 1))()
+        c_err = ctypes.c_void_p()
+        n = _lib.PqaEngine_ListTopTargets(self.c_engine, ctypes.byref(c_err), i_quiz, max_count, arr)
+        _check(c_err.value)
+        return [RatedTarget(arr[i].iTarget, arr[i].prob) for i in range(n)]
+
+    def record_quiz_target(self, i_quiz: int, i_target: int, amount: float = 1.0, throw: bool = True):
+        return _check(_lib.PqaEngine_RecordQuizTarget(self.c_engine, i_quiz, i_target, amount), throw)
+
+    def release_quiz(self, i_quiz: int, throw: bool = True):
+        return _check(_lib.PqaEngine_ReleaseQuiz(self.c_engine, i_quiz), throw)
+
+    def save_kb(self, file_path: str, b_double_buffer: bool, throw: bool = True):
+        return _check(_lib.PqaEngine_SaveKB(self.c_engine, file_path.encode(), 1 if b_double_buffer else 0), throw)
+
+    def start_maintenance(self, force_quizzes: bool, throw: bool = True):
+        return _check(_lib.PqaEngine_StartMaintenance(self.c_engine, force_quizzes), throw)
+
+    def finish_maintenance(self, throw: bool = True):
+        return _check(_lib.PqaEngine_FinishMaintenance(self.c_engine), throw)
+
+    def shutdown(self, save_file_path: Optional[str] = None, throw: bool = True):
+        p = save_file_path.encode() if save_file_path else None
+        return _check(_lib.PqaEngine_Shutdown(self.c_engine, p), throw)
+
+    def clear_old_quizzes(self, max_count: int, max_age_sec: float, throw: bool = True):
+        return _check(_lib.PqaEngine_ClearOldQuizzes(self.c_engine, max_count, max_age_sec), throw)
+
+    # ---- additive (include/PqaHipExt.h) -----------------------------------------------------------------------------
+    def set_option(self, name: str, value: int):
+        _check(_lib.PqaHip_SetOption(self.c_engine, name.encode(), int(value)))
+
+    def get_option(self, name: str) -> int:
+        return _lib.PqaHip_GetOption(self.c_engine, name.encode())
+
+    def eval_kernel_name(self) -> str:
+        return _lib.PqaHip_EvalKernelName(self.c_engine).decode()
+
+    def set_kb(self, A: np.ndarray, D: np.ndarray, B: np.ndarray):
+        A = np.ascontiguousarray(A, dtype=np.float64)
+        D = np.ascontiguousarray(D, dtype=np.float64)
+        B = np.ascontiguousarray(B, dtype=np.float64)
+        _check(_lib.PqaHip_SetKB(self.c_engine, _dptr(A), _dptr(D), _dptr(B)))
+
+    def get_kb(self, n_local_questions: Optional[int] = None) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+        d = self.copy_dims()
+        q = n_local_questions if n_local_questions is not None else d.n_questions
+        A = np.empty((q, d.n_answers, d.n_targets)); D = np.empty((q, d.n_targets)); B = np.empty(d.n_targets)
+        _check(_lib.PqaHip_GetKB(self.c_engine, _dptr(A), _dptr(D), _dptr(B)))
+        return A, D, B
+
+    def fill_synthetic(self, n_train: float, noise_amp: float, seed: int):
+        _check(_lib.PqaHip_FillSynthetic(self.c_engine, n_train, noise_amp, seed))
+
+    def set_target_gaps(self, targets: List[int]):
+        arr = (ctypes.c_int64 * max(len(targets), 1))(*targets)
+        _check(_lib.PqaHip_SetTargetGaps(self.c_engine, len(targets), arr))
+
+    def set_question_gaps(self, questions: List[int]):
+        arr = (ctypes.c_int64 * max(len(questions), 1))(*questions)
+        _check(_lib.PqaHip_SetQuestionGaps(self.c_engine, len(questions), arr))
+
+    def eval_priorities(self, i_quiz: int, n_local_questions: Optional[int] = None) -> np.ndarray:
+        n = n_local_questions if n_local_questions is not None else self.copy_dims().n_questions
+        out = np.empty(n, dtype=np.float64)
+        _check(_lib.PqaEngine_EvalPriorities(self.c_engine, i_quiz, _dptr(out), n))
+        return out
+
+    def next_question_argmax(self, i_quiz: int) -> int:
+        c_err = ctypes.c_void_p()
+        q = _lib.PqaEngine_NextQuestionArgmax(self.c_engine, ctypes.byref(c_err), i_quiz)
+        _check(c_err.value)
+        return q
+
+    def next_question_sampled(self, i_quiz: int, rnd: int) -> int:
+        c_err = ctypes.c_void_p()
+        q = _lib.PqaEngine_NextQuestionSampled(self.c_engine, ctypes.byref(c_err), i_quiz, rnd)
+        _check(c_err.value)
+        return q
+
+    def get_priors(self, i_quiz: int) -> np.ndarray:
+        out = np.empty(self.copy_dims().n_targets, dtype=np.float64)
+        _check(_lib.PqaHip_GetPriors(self.c_engine, i_quiz, _dptr(out), out.size))
+        return out
+
+    def get_stream(self) -> int:
+        return _lib.PqaHip_GetStream(self.c_engine) or 0
+
+    def set_stream(self, stream: int):
+        _check(_lib.PqaHip_SetStream(self.c_engine, ctypes.c_void_p(stream)))
+
+    def synchronize(self):
+        _check(_lib.PqaHip_Synchronize(self.c_engine))
+
+    def enqueue_select_argmax(self, i_quiz: int, out_ptr: int = 0):
+        _check(_lib.PqaHip_EnqueueSelectArgmax(self.c_engine, i_quiz, ctypes.c_void_p(out_ptr)))
+
+    def enqueue_eval(self, i_quiz: int):
+        _check(_lib.PqaHip_EnqueueEval(self.c_engine, i_quiz))
+
+    def prior_device_ptr(self, i_quiz: int) -> Tuple[int, int]:
+        dev = ctypes.c_void_p()
+        ld = ctypes.c_int64()
+        _check(_lib.PqaHip_GetPriorDevicePtr(self.c_engine, i_quiz, ctypes.byref(dev), ctypes.byref(ld)))
+        return dev.value or 0, ld.value
+
+    def record_answer_remote(self, i_quiz: int, i_answer: int):
+        _check(_lib.PqaHip_RecordAnswerRemote(self.c_engine, i_quiz, i_answer))
+
+
+class PqaEngineFactory:
+    """Reference ProbQA.py:743-783."""
+
+    def __init__(self):
+        load_library()
+        self.c_factory = ctypes.c_void_p(_lib.CiGetPqaEngineFactory())
+
+    def create_cpu_engine(self, eng_def: EngineDefinition) -> Tuple[Optional[PqaEngine], Optional[PqaError]]:
+        c_def = eng_def.to_c()
+        c_err = ctypes.c_void_p()
+        c_engine = _lib.PqaEngineFactory_CreateCpuEngine(self.c_factory, ctypes.byref(c_err), ctypes.byref(c_def))
+        return (PqaEngine(c_engine) if c_engine else None), PqaError.factor(c_err.value)
+
+    def create_hip_engine(self, eng_def: EngineDefinition, q_first: int = 0, q_total: Optional[int] = None,
+                          device: int = -1) -> PqaEngine:
+        c_def = eng_def.to_c()
+        shard = CiHipShard(q_first, q_total if q_total is not None else eng_def.n_questions, device, 0)
+        c_err = ctypes.c_void_p()
+        c_engine = _lib.PqaEngineFactory_CreateHipEngineSharded(self.c_factory, ctypes.byref(c_err),
+                                                                ctypes.byref(c_def), ctypes.byref(shard))
+        _check(c_err.value)
+        return PqaEngine(c_engine)
+
+    def load_cpu_engine(self, file_path: str, mem_pool_max_bytes: int = EngineDefinition.DEFAULT_MEM_POOL_MAX_BYTES):
+        c_err = ctypes.c_void_p()
+        c_engine = _lib.PqaEngineFactory_LoadCpuEngine(self.c_factory, ctypes.byref(c_err), file_path.encode(),
+                                                       mem_pool_max_bytes)
+        return (PqaEngine(c_engine) if c_engine else None), PqaError.factor(c_err.value)
+
+
+class MaintenanceLock:  # reference ProbQA.py:786-796
+    def __init__(self, engine: PqaEngine, force_quizzes: bool):
+        self.engine, self.force_quizzes = engine, force_quizzes
+
+    def __enter__(self):
+        self.engine.start_maintenance(self.force_quizzes)
+
+    def __exit__(self, exc_type, exc_value, exc_trace):
+        self.engine.finish_maintenance()

@@ -1,0 +1,77 @@
+"""Shared test scenarios: synthetic KBs + quiz scripts, run identically through the oracle and the HIP engine."""
+from __future__ import annotations
+
+import numpy as np
+
+import orclib
+from probqa_amd import interop, synth
+
+WORKERS = 16  # emulated CPU thread count (fixes the prior-update summation order on both sides)
+
+
+class Case:
+    def __init__(self, name, K, Q, T, seed, init=0.1, n_train=8.0, noise=0.5, tgaps=(), qgaps=(), answers=()):
+        self.name, self.K, self.Q, self.T, self.seed = name, K, Q, T, seed
+        self.init, self.n_train, self.noise = init, n_train, noise
+        self.tgaps, self.qgaps, self.answers = list(tgaps), list(qgaps), list(answers)
+
+    def kb(self):
+        return synth.synthetic_kb(self.K, self.Q, self.T, self.init, self.n_train, self.noise, self.seed)
+
+    def make_oracle(self) -> orclib.Oracle:
+        o = orclib.Oracle(self.K, self.Q, self.T, self.init)
+        o.set_kb(*self.kb())
+        o.set_target_gaps(self.tgaps)
+        o.set_question_gaps(self.qgaps)
+        return o
+
+    def make_engine(self, factory) -> interop.PqaEngine:
+        eng, err = factory.create_cpu_engine(interop.EngineDefinition(self.K, self.Q, self.T, init_amount=self.init))
+        assert err is None and eng is not None, err
+        eng.set_kb(*self.kb())
+        eng.set_option("workers", WORKERS)
+        if self.tgaps:
+            eng.set_target_gaps(self.tgaps)
+        if self.qgaps:
+            eng.set_question_gaps(self.qgaps)
+        return eng
+
+
+def consistent_answers(Q, T, hidden_frac=0.37, questions=(0.5, 0.25, 0.375)):
+    """Answers to a few questions consistent with a hidden target (SURVEY 8(d) quiz state)."""
+    hidden = int(hidden_frac * T)
+    w = max(1, (32 * T) // 1000)
+    out = []
+    for f in questions:
+        q = int(f * Q)
+        x = (q * T) // Q
+        if hidden < x - w:
+            a = 0
+        elif hidden < x:
+            a = 1
+        elif hidden == x:
+            a = 2
+        elif hidden <= x + w:
+            a = 3
+        else:
+            a = 4
+        out.append((q, a))
+    return out
+
+
+def small_cases():
+    rng = np.random.default_rng(5)
+    gaps101 = sorted(rng.choice(101, 5, replace=False).tolist())
+    return [
+        Case("tiny_8x3x12", 3, 8, 12, seed=11, answers=[(2, 1)]),
+        Case("gaps_37x5x101", 5, 37, 101, seed=12, tgaps=gaps101, qgaps=[3, 20], answers=[(10, 4), (30, 0)]),
+        Case("ragged_50x4x67", 4, 50, 67, seed=13, answers=[(7, 3), (8, 0), (49, 1)]),
+        Case("k7_33x7x130", 7, 33, 130, seed=14, answers=[(5, 6)]),
+        Case("mid_300x5x1000", 5, 300, 1000, seed=15, answers=consistent_answers(300, 1000)),
+    ]
+
+
+def rel_err(a, b):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    den = np.maximum(np.abs(b), 1e-300)
+    return np.abs(a - b) / den
