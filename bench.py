@@ -1,0 +1,233 @@
+#!/usr/bin/env python3
+"""bench.py -- next-question selections/s of the MI355X engine, through the PqaCore C ABI.
+
+A "step" is one complete NextQuestion of one quiz: the priority sweep over every unasked question of the
+sA[question][answer][target] cube (eval kernel) + the argmax selection + delivery of the selected question id to
+the host.  The cube is resident in HBM before the timed region.  Workload at N=1: BASELINE.json configs[1]
+(1000Q x 5A x 1000T fp64, single in-flight quiz).  N>1: the question axis of the same cube is sharded over the ranks
+(one process per GPU), each rank sweeps its shard and one 16-byte-per-rank RCCL all-gather picks the global argmax
+("strong" scaling, as north_star states it).  --config M runs configs[2] (10000x5x10000, the HBM-bound point).
+
+Prints ONE JSON line (rank 0).  Extra keys: roofline (dominant kernel, live HIP-event timing on the engine's stream),
+cpu_baseline (the AVX2+threads CPU port of the reference path, timed on this host; N=1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+CONFIGS = {
+    "S": dict(Q=1000, K=5, T=1000, name="1000Qx5Ax1000T"),
+    "M": dict(Q=10000, K=5, T=10000, name="10000Qx5Ax10000T"),
+}
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+SEED = 20260928
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="S")
+    ap.add_argument("--variant", type=int, default=0, help="force an eval kernel shape (0 = auto)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=3.0, help="wall seconds of the CPU baseline leg")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+
+    from probqa_amd import dist as pdist
+    from probqa_amd import interop
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+        args.gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the engine has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=device)
+
+    cfg = CONFIGS[args.config]
+    Q, K, T = cfg["Q"], cfg["K"], cfg["T"]
+    q_first, q_limit = pdist.shard_range(Q, world, rank)
+    q_local = q_limit - q_first
+
+    factory = interop.PqaEngineFactory()
+    eng = factory.create_hip_engine(interop.EngineDefinition(K, q_local, T, init_amount=0.1), q_first, Q, local_rank)
+    eng.set_option("select", 1)
+    eng.set_option("eval_variant", args.variant)
+    eng.fill_synthetic(8.0, 0.5, SEED)
+    stream = torch.cuda.Stream(device=device)
+    torch.cuda.set_stream(stream)
+    eng.set_stream(stream.cuda_stream)
+    quiz = eng.start_quiz()
+    ldT = eng.get_option("ldT")
+
+    selector = None
+    if world > 1:
+        selector = pdist.ShardedSelector(lambda out: eng.enqueue_select_argmax(quiz, out.data_ptr()), device)
+
+    def step():
+        if selector is None:
+            return eng.next_question_argmax(quiz)
+        _, q = selector.select()
+        return q
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            import torch.distributed as dist
+
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        sel = step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        sel = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    value = args.steps / elapsed
+
+    # ---- dominant kernel: live HIP-event timing on the engine's stream, back-to-back launches
+    n_k = max(20, min(args.steps, 200))
+    for _ in range(5):
+        eng.enqueue_eval(quiz)
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record(stream)
+    for _ in range(n_k):
+        eng.enqueue_eval(quiz)
+    ev1.record(stream)
+    torch.cuda.synchronize()
+    kernel_ms = ev0.elapsed_time(ev1) / n_k
+    alg_bytes = q_local * (K + 1) * T * 8  # one read of every sA row and the mD row, fp64
+    achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+
+    # ---- stream-ordered (pipelined) throughput: selections enqueued back to back, results left on the device
+    if selector is None:
+        for _ in range(5):
+            eng.enqueue_select_argmax(quiz)
+        torch.cuda.synchronize()
+        tp0 = time.perf_counter()
+        for _ in range(args.steps):
+            eng.enqueue_select_argmax(quiz)
+        torch.cuda.synchronize()
+        pipelined = args.steps / (time.perf_counter() - tp0)
+    else:
+        pipelined = None
+
+    out = {
+        "metric": "next_question_selections_per_sec",
+        "value": value,
+        "unit": "selections/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps,
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {
+            "workload": "%s fp64 cube resident in HBM, single in-flight quiz; step = priority sweep + argmax + "
+                        "question id on host, synchronous call through the C ABI" % cfg["name"],
+            "questions_per_gpu": q_local,
+            "parallelism": "question-axis shards x%d + 16B/rank all-gather" % world if world > 1 else "single GPU",
+            "eval_kernel": eng.eval_kernel_name(),
+            "selected_question": int(sel),
+        },
+        "question_evals_per_sec": value * Q,
+        "pipelined_selections_per_sec": pipelined,
+        "roofline": {
+            "bound": "hbm",
+            "achieved": achieved,
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS,
+            "traffic": None,
+            "kernel": "eval_questions_f64 (%s)" % eng.eval_kernel_name(),
+            "kernel_us": kernel_ms * 1e3,
+            "algorithmic_bytes_per_launch": alg_bytes,
+            "note": "48 MB cube fits the 256 MiB Infinity Cache: achieved GB/s is not an HBM measurement at this size; "
+                    "use --config M for the HBM-bound point" if args.config == "S" else "cube exceeds the Infinity Cache",
+        },
+    }
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(np, cfg, args.cpu_seconds)
+    if rank == 0:
+        print(json.dumps(out))
+    eng.close()
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.destroy_process_group()
+
+
+def cpu_baseline(np, cfg, seconds):
+    """The reference's AVX2 SRThreadPool path as restated in oracle/pqa_oracle_avx2.c ("port"), timed on this host's
+    cores on the same workload: whole sweeps of the same synthetic cube for a bounded wall time."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import orclib
+    from probqa_amd import synth
+
+    Q, K, T = cfg["Q"], cfg["K"], cfg["T"]
+    sample = "full %s sweep" % cfg["name"]
+    if Q * K * T > 2e8:  # bound memory and time: a 1000-question slice of the big cube (same rows, same T)
+        Q = 1000
+        sample = "first 1000 of %d questions of the %s cube (rate scaled to the full cube)" % (cfg["Q"], cfg["name"])
+    threads = os.cpu_count() or 1
+    orc = orclib.Oracle(K, Q, T, 0.1)
+    orc.set_kb(*synth.synthetic_kb(K, Q, T, 0.1, 8.0, 0.5, SEED, q_offset=0, q_total=cfg["Q"]))
+    orc.start_quiz(16)
+    orc.eval_avx2(threads)  # warm-up, spawns the pool
+    n, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < seconds or n < 3:
+        orc.eval_avx2(threads)
+        n += 1
+    dt = time.perf_counter() - t0
+    sweeps = n / dt * (Q / cfg["Q"])
+    model = ""
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return {"value": sweeps, "unit": "selections/s", "cores": threads, "kind": "port",
+            "sample": "%s, %d sweeps in %.1f s wall on %d threads (AVX2+FMA 4-lane Kahan port, 8*threads subtasks)"
+                      % (sample, n, dt, threads),
+            "cpu_model": model}
+
+
+if __name__ == "__main__":
+    main()

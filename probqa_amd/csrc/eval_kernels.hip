@@ -1,14 +1,18 @@
 // eval_kernels.hip -- the next-question priority sweep on CDNA4 (gfx950).
 //
-// Replaces CEEvalQsSubtaskConsider<SRDoubleNumber>::Run (reference: PqaCore/CEEvalQsSubtaskConsider.cpp:41-217) and,
-// for the selection step, the tail of CpuEngine::NextQuestionSpec (PqaCore/CpuEngine.cpp:362-400).
+// Replaces CEEvalQsSubtaskConsider<SRDoubleNumber>::Run (reference: PqaCore/CEEvalQsSubtaskConsider.cpp:41-217).
 //
-// Shape: one workgroup of WPQ wavefronts per candidate question.  Lane `tid` owns the target pairs
-// p = tid + j*(64*WPQ), j < NP, i.e. every global load is a fully coalesced 16 B/lane (1 KiB/wave) read down the
-// target axis of one sA row.  The row's likelihoods and 1/D stay in registers between the two passes, so every byte
-// of the cube is read from HBM exactly once: algorithmic traffic = Q*(K+1)*ldT*8 bytes per sweep.
-// Reductions: compensated (TwoSum) butterfly for the answer weight W_k (it feeds a division whose result goes through
-// log2), plain fp64 butterflies for the entropy / velocity / lack sums; cross-wave through 2 LDS slots.
+// Shape: one workgroup of WPQ wavefronts per candidate question (persistent over a grid-stride of questions).
+// Lane `tid` owns the target pairs p = tid + j*(64*WPQ), j < NP, i.e. every global load is a fully coalesced
+// 16 B/lane (1 KiB/wave) read down the target axis of one sA row.  The row's likelihoods and 1/D stay in REGISTERS
+// between the two passes, and the next row is prefetched into registers while the current one is reduced and
+// log2'ed, so every byte of the cube is read from HBM exactly once: algorithmic traffic = Q*(K+1)*ldT*8 B per sweep.
+//
+// The kernel sits on the fp64-ALU / HBM ridge (about 200 wave-cycles of fp64 work per 614 B of cube), so the ALU side
+// is trimmed: scale-free exact division (div_nr), DPP/permlane all-reduces instead of ds_bpermute shuffles, one
+// workgroup barrier per answer row (only the answer weight W_k is needed by everyone before pass 2; entropy, velocity
+// and lack partials go to LDS and are combined once per question).  Reductions: Kahan per lane + compensated (TwoSum)
+// butterfly for W_k (it feeds a division whose result goes through log2), plain fp64 elsewhere.
 // The epilogue (weighted averages over answers, velocity component, integer powers) is the reference's scalar code,
 // run by one lane with the reference's Kahan lane order.
 //
@@ -34,37 +38,27 @@ struct EvalArgs {
   int64_t K, ldT, qFirst, qLimit, nValidPlus1;
 };
 
-// Reference epilogue, PqaCore/CEEvalQsSubtaskConsider.cpp:134-207.  mW/mH/mV: per-answer weight, entropy, velocity^2.
-__device__ __forceinline__ double eval_epilogue(const double *mW, const double *mH, const double *mV, int64_t K,
+// Reference epilogue, PqaCore/CEEvalQsSubtaskConsider.cpp:134-207.  mW / mV: per-answer weight and velocity^2;
+// whSum = sum_k W_k * H_k, which the sweep accumulates directly as -sum_{k,t} l_kt * log2(p_kt) (W_k * p_kt == l_kt up to
+// the rounding of p = l * (1/W_k)), so the per-answer entropies H_k are never materialised.
+__device__ __forceinline__ double eval_epilogue(const double *mW, double whSum, const double *mV, int64_t K,
                                                 double lackSum, int64_t nValidPlus1) {
   Kahan1 accTotW;
   accTotW.init(0.0);
-  // 4-lane Kahan accumulators accAvgH / accAvgV (:139-172): answer k lands in lane k & 3, in k order
-  double hS[4] = {0, 0, 0, 0}, hC[4] = {0, 0, 0, 0}, vS[4] = {0, 0, 0, 0}, vC[4] = {0, 0, 0, 0};
-  const int64_t nVectorized = (K >> 2) << 2;
+  // 4-lane Kahan accumulator accAvgV (:140-172): answer k lands in lane k & 3, in k order.  A full vector Add (:158) and
+  // a tail scalar Add (:171) give every lane the same sequence of Kahan steps.
+  double vS[4] = {0, 0, 0, 0}, vC[4] = {0, 0, 0, 0};
   for (int64_t k = 0; k < K; k++) {
     accTotW.add(mW[k]);                                        // :89
     const int c = (int)(k & 3);
-    const double wh = mW[k] * mH[k];                           // :152 / :167
     const double wv = mW[k] * sqrt(mV[k]);                     // :156-157 / :165-167
-    {
-      const double y = wh - hC[c];
-      const double t = hS[c] + y;
-      hC[c] = (t - hS[c]) - y;
-      hS[c] = t;
-    }
-    {
-      const double y = wv - vC[c];
-      const double t = vS[c] + y;
-      vC[c] = (t - vS[c]) - y;
-      vS[c] = t;
-    }
-    // A full vector Add (:153,:158) also Kahan-adds into lanes that received their value in the same instruction;
-    // a tail scalar Add (:170-171) touches one lane only.  Per lane the sequence of adds is the same either way.
-    (void)nVectorized;
+    const double y = wv - vC[c];
+    const double t = vS[c] + y;
+    vC[c] = (t - vS[c]) - y;
+    vS[c] = t;
   }
   const double totW = accTotW.get();                           // :134
-  const double avgH = precise_sum4(hS, hC) / totW;             // :175-177 (PairSum == two PreciseSums side by side)
+  const double avgH = whSum / totW;                            // :175-177
   const double avgV = precise_sum4(vS, vC) / totW;
   const double nExpectedTargets = exp2(avgH);                  // :181
   const double cLnMaxV = 0.34657359027997265470861606072909;   // SRMath::_cLnSqrt2
@@ -76,40 +70,78 @@ __device__ __forceinline__ double eval_epilogue(const double *mW, const double *
   return lack * v9 * (1.0 / (nExpectedTargets * nExpectedTargets));
 }
 
+// One element pair of pass 2 (:95-128).  lh: likelihoods, id: 1/D, pr: masked priors.  The two lack terms share one
+// reciprocal: 1/(a*b) by v_rcp_f64 + two Newton steps (error ~2^-96), then 1/a = b/(ab), 1/b = a/(ab).
+__device__ __forceinline__ void pass2_pair(double2 lh, double2 id, double2 pr, double invWk, const double *tbl,
+                                           double &hW, double &v, double &accL) {
+  const double p0 = lh.x * invWk, p1 = lh.y * invWk;           // :97
+  const double l20 = log2hot(p0, tbl), l21 = log2hot(p1, tbl); // :106 (gap lanes: p = 0 -> -1023, contributes -0)
+  hW = fma(lh.x, l20, hW);                                     // :113-114 weighted by W_k (see eval_epilogue)
+  hW = fma(lh.y, l21, hW);
+  const double prod = l20 * l21;
+  double r = __builtin_amdgcn_rcp(prod);
+  r = fma(r, fma(-prod, r, 1.0), r);
+  r = fma(r, fma(-prod, r, 1.0), r);
+  // invD^2 is invariant over the answers: keep the compiler from hoisting 2*NP squares into registers for the whole
+  // question (an opaque move per element is cheaper than the occupancy they would cost)
+  double ix = id.x, iy = id.y;
+  asm volatile("" : "+v"(ix), "+v"(iy));
+  accL = fma(ix * ix, r * l21, accL);                          // :117 invD^2 / log2(p)
+  accL = fma(iy * iy, r * l20, accL);
+  const double d0 = p0 - pr.x, d1 = p1 - pr.y;                 // :119
+  v = fma(d0, d0, v);                                          // :126-127
+  v = fma(d1, d1, v);
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // Register-resident sweep: WPQ waves per question, NP target pairs per lane.  Requires ldT <= 128*WPQ*NP.
+// PRLDS: keep the masked prior vector in LDS instead of registers (long rows: frees 4*NP VGPRs).
+// LDS (doubles): log2 table [1024] | W exchange [2][WPQ] | W_k [2][K] | partials [2][K+2][WPQ] | prior [ldT] if PRLDS
+//   partial rows: V_k (K rows), sum W_k*H_k (1 row), lack (1 row); the leading [2] alternates per question so that
+//   lane 0 can run the epilogue of question n while the other waves already fill the buffers of question n+1.
 // ------------------------------------------------------------------------------------------------------------------
-template <int WPQ, int NP>
+__host__ __device__ constexpr size_t eval_lds_doubles(int wpq, int64_t K, bool prLds, int64_t ldT) {
+  return 1024 + 2 * (size_t)wpq + 2 * (size_t)K + 2 * (size_t)(K + 2) * wpq + (prLds ? (size_t)ldT + 2 : 0);
+}
+
+template <int WPQ, int NP, bool PRLDS>
 __global__ __launch_bounds__(WPQ * 64) void eval_questions_f64(EvalArgs a) {
   constexpr int kThreads = WPQ * kWave;
+  constexpr int NPR = PRLDS ? 1 : NP;
   extern __shared__ double smem[];
-  double *tbl = smem;                              // 1024 doubles
-  double *red = tbl + 1024;                        // 2 * WPQ * 3 doubles of reduction scratch
-  double *mets = red + 2 * WPQ * 3;                // 3 * K doubles: W_k, H_k, V2_k
-  const int tid = threadIdx.x;
+  const int64_t ldT = a.ldT, K = a.K;
+  double *tbl = smem;
+  double *redW = tbl + 1024;
+  double *wkAll = redW + 2 * WPQ;
+  double *partAll = wkAll + 2 * K;
+  double2 *prLds = reinterpret_cast<double2 *>(partAll + 2 * (K + 2) * WPQ);
+  const int nPart = (int)(K + 2);
+  const int tid = threadIdx.x, lane = tid % kWave, wave = tid / kWave;
   for (int i = tid; i < 1024; i += kThreads) tbl[i] = gLog2Table[i];
 
-  const int64_t ldT = a.ldT, K = a.K;
-  const int64_t nPairs = ldT >> 1;
+  const int nPairs = (int)(ldT >> 1);
   // Per-lane constants of the sweep: masked priors and gap flags of the lane's targets.
-  double2 pr[NP];
+  double2 pr[NPR];
   uint32_t gapBits = 0;  // bit 2j / 2j+1 : target pair j element 0 / 1 is a gap (or beyond the row)
   int pidx[NP];
 #pragma unroll
   for (int j = 0; j < NP; j++) {
     const int p = tid + j * kThreads;
     const bool inRow = p < nPairs;
-    pidx[j] = inRow ? p : (int)(nPairs - 1);       // clamped: out-of-row lanes re-read the last pair and are masked
+    pidx[j] = inRow ? p : (nPairs - 1);            // clamped: out-of-row lanes re-read the last pair and are masked
     const int64_t t0 = 2 * (int64_t)pidx[j];
     const bool g0 = !inRow || bit_test(a.tgap, t0), g1 = !inRow || bit_test(a.tgap, t0 + 1);
     gapBits |= (g0 ? 1u : 0u) << (2 * j) | (g1 ? 1u : 0u) << (2 * j + 1);
-    const double2 pv = reinterpret_cast<const double2 *>(a.prior)[pidx[j]];
-    pr[j].x = g0 ? 0.0 : pv.x;                     // :103 andnot(gapMask, prior)
-    pr[j].y = g1 ? 0.0 : pv.y;
+    double2 pv = reinterpret_cast<const double2 *>(a.prior)[pidx[j]];
+    pv.x = g0 ? 0.0 : pv.x;                        // :103 andnot(gapMask, prior)
+    pv.y = g1 ? 0.0 : pv.y;
+    if constexpr (PRLDS) { if (inRow) prLds[p] = pv; } else { pr[j] = pv; }
   }
+  // out-of-row lanes read the all-zero pair stored right after the row (their cube loads are clamped instead)
+  if constexpr (PRLDS) { if (tid == 0) prLds[nPairs] = make_double2(0.0, 0.0); }
   __syncthreads();
 
-  int phase = 0;
+  int phase = 0, qpar = 0;
   const int64_t qStride = (K + 1) * ldT;
   for (int64_t q = a.qFirst + blockIdx.x; q < a.qLimit; q += gridDim.x) {
     if (bit_test(a.qgap, q) || bit_test(a.asked, q)) {         // :54
@@ -119,65 +151,92 @@ __global__ __launch_bounds__(WPQ * 64) void eval_questions_f64(EvalArgs a) {
     const double *qBase = a.cube + q * qStride;
     const double2 *rowD = reinterpret_cast<const double2 *>(qBase + K * ldT);
     const double2 *rowA = reinterpret_cast<const double2 *>(qBase);
-    double2 invD[NP], aCur[NP];
+    double2 invD[NP], nxt[NP];
+#pragma unroll
+    for (int j = 0; j < NP; j++) invD[j] = rowD[pidx[j]];
+#pragma unroll
+    for (int j = 0; j < NP; j++) nxt[j] = rowA[pidx[j]];
 #pragma unroll
     for (int j = 0; j < NP; j++) {
-      const double2 d = rowD[pidx[j]];
-      aCur[j] = rowA[pidx[j]];
-      invD[j].x = ((gapBits >> (2 * j)) & 1) ? 0.0 : 1.0 / d.x;        // :74 andnot(gapMask, 1/D)
-      invD[j].y = ((gapBits >> (2 * j + 1)) & 1) ? 0.0 : 1.0 / d.y;
+      invD[j].x = ((gapBits >> (2 * j)) & 1) ? 0.0 : div_nr(1.0, invD[j].x);      // :74 andnot(gapMask, 1/D)
+      invD[j].y = ((gapBits >> (2 * j + 1)) & 1) ? 0.0 : div_nr(1.0, invD[j].y);
     }
-    double accL = 0;
+    double *wk = wkAll + qpar * K;
+    double *part = partAll + qpar * (nPart * WPQ);
+    double accL = 0, hW = 0;
     for (int64_t k = 0; k < K; k++) {
-      // ---- pass 1 (:66-87): likelihoods into registers, W_k
+      // ---- pass 1 (:66-87): likelihoods into registers, W_k (two Kahan chains per lane)
       double2 lh[NP];
-      Comp w = {0.0, 0.0};
+      double s0 = 0, c0 = 0, s1 = 0, c1 = 0;
 #pragma unroll
       for (int j = 0; j < NP; j++) {
-        lh[j].x = (aCur[j].x * invD[j].x) * pr[j].x;           // :81-82 (gap lanes: invD = 0 and prior = 0)
-        lh[j].y = (aCur[j].y * invD[j].y) * pr[j].y;
-        comp_add(w, lh[j].x);
-        comp_add(w, lh[j].y);
+        double2 pv;
+        if constexpr (PRLDS) pv = prLds[min(tid + j * kThreads, nPairs)]; else pv = pr[j];
+        lh[j].x = (nxt[j].x * invD[j].x) * pv.x;               // :81-82 (gap lanes: invD = 0 and prior = 0)
+        lh[j].y = (nxt[j].y * invD[j].y) * pv.y;
+        {
+          const double y = lh[j].x - c0;
+          const double t = s0 + y;
+          c0 = (t - s0) - y;
+          s0 = t;
+        }
+        {
+          const double y = lh[j].y - c1;
+          const double t = s1 + y;
+          c1 = (t - s1) - y;
+          s1 = t;
+        }
       }
       // prefetch the next answer's row while this one is reduced and log2'ed
       if (k + 1 < K) {
         const double2 *rowN = reinterpret_cast<const double2 *>(qBase + (k + 1) * ldT);
 #pragma unroll
-        for (int j = 0; j < NP; j++) aCur[j] = rowN[pidx[j]];
+        for (int j = 0; j < NP; j++) nxt[j] = rowN[pidx[j]];
       }
-      const double Wk = block_sum_comp<WPQ>(w, red, phase);    // :88
-      const double invWk = 1.0 / Wk;                           // :91
+      double Wk = wave_sum((s0 - c0) + (s1 - c1));             // :88
+      if constexpr (WPQ > 1) {
+        double *buf = redW + phase * WPQ;
+        if (lane == 0) buf[wave] = Wk;
+        __syncthreads();
+        Wk = row_sum<WPQ>(buf[lane % WPQ]);
+        phase ^= 1;
+      }
+      const double invWk = div_nr(1.0, Wk);                    // :91
       // ---- pass 2 (:95-128)
-      double hv[2] = {0, 0};  // entropy sum, velocity sum
+      double v = 0;
 #pragma unroll
       for (int j = 0; j < NP; j++) {
-        {
-          const double p = lh[j].x * invWk;                    // :97
-          const double l2 = log2hot(p, tbl);                   // :106 (gap lanes: p = 0 -> -1023, contributes -0)
-          hv[0] = fma(p, l2, hv[0]);                           // :113-114
-          accL += (invD[j].x * invD[j].x) / l2;                // :117
-          const double d = p - pr[j].x;                        // :119
-          hv[1] = fma(d, d, hv[1]);                            // :126-127
-        }
-        {
-          const double p = lh[j].y * invWk;
-          const double l2 = log2hot(p, tbl);
-          hv[0] = fma(p, l2, hv[0]);
-          accL += (invD[j].y * invD[j].y) / l2;
-          const double d = p - pr[j].y;
-          hv[1] = fma(d, d, hv[1]);
-        }
+        double2 pv;
+        if constexpr (PRLDS) pv = prLds[min(tid + j * kThreads, nPairs)]; else pv = pr[j];
+        pass2_pair(lh[j], invD[j], pv, invWk, tbl, hW, v, accL);
+        // Pin the accumulators here: without an opaque use the compiler sinks the whole lack chain (and every log2 it
+        // needs) below the loop, which costs 8 live VGPRs per pair; and keep the interleave to one pair at a time.
+        asm volatile("" : "+v"(accL), "+v"(hW), "+v"(v));
+        __builtin_amdgcn_sched_barrier(0);
       }
-      block_sum<WPQ, 2>(hv, red, phase);
-      if (tid == 0) {
-        mets[k] = Wk;                                          // :90
-        mets[K + k] = -hv[0];                                  // :130-131
-        mets[2 * K + k] = hv[1];                               // :132
+      v = wave_sum(v);
+      if (lane == 0) {
+        if (wave == 0) wk[k] = Wk;                             // :90
+        part[k * WPQ + wave] = v;                              // :132
       }
     }
-    double lv[1] = {accL};
-    block_sum<WPQ, 1>(lv, red, phase);
-    if (tid == 0) a.priority[q - a.qFirst] = eval_epilogue(mets, mets + K, mets + 2 * K, K, lv[0], a.nValidPlus1);
+    hW = wave_sum(hW);
+    accL = wave_sum(accL);
+    if (lane == 0) {
+      part[K * WPQ + wave] = hW;
+      part[(K + 1) * WPQ + wave] = accL;
+    }
+    if constexpr (WPQ > 1) __syncthreads();
+    if (tid == 0) {
+      // combine the waves' partials in wave order into the first K+2 slots (row r starts at r*WPQ >= r: safe in place)
+      for (int r = 0; r < nPart; r++) {
+        double acc = part[r * WPQ];
+        for (int w2 = 1; w2 < WPQ; w2++) acc += part[r * WPQ + w2];
+        part[r] = acc;
+      }
+      a.priority[q - a.qFirst] = eval_epilogue(wk, -part[K], part, K, part[K + 1], a.nValidPlus1);  // :130 H = -sum
+    }
+    qpar ^= 1;
   }
 }
 
@@ -188,56 +247,94 @@ __global__ __launch_bounds__(WPQ * 64) void eval_questions_f64(EvalArgs a) {
 __global__ __launch_bounds__(256) void eval_questions_f64_stream(EvalArgs a) {
   constexpr int WPQ = 4, kThreads = 256;
   extern __shared__ double smem[];
+  const int64_t ldT = a.ldT, K = a.K;
   double *tbl = smem;
-  double *red = tbl + 1024;
-  double *mets = red + 2 * WPQ * 3;
-  const int tid = threadIdx.x;
+  double *redW = tbl + 1024;
+  double *wkAll = redW + 2 * WPQ;
+  double *partAll = wkAll + 2 * K;
+  const int nPart = (int)(K + 2);
+  const int tid = threadIdx.x, lane = tid % kWave, wave = tid / kWave;
   for (int i = tid; i < 1024; i += kThreads) tbl[i] = gLog2Table[i];
   __syncthreads();
-  const int64_t ldT = a.ldT, K = a.K;
   const int64_t qStride = (K + 1) * ldT;
-  int phase = 0;
+  const int64_t nPairs = ldT >> 1;
+  int phase = 0, qpar = 0;
   for (int64_t q = a.qFirst + blockIdx.x; q < a.qLimit; q += gridDim.x) {
     if (bit_test(a.qgap, q) || bit_test(a.asked, q)) {
       if (tid == 0) a.priority[q - a.qFirst] = 0;
       continue;
     }
     const double *qBase = a.cube + q * qStride;
-    const double *rowD = qBase + K * ldT;
-    double accL = 0;
+    const double2 *rowD = reinterpret_cast<const double2 *>(qBase + K * ldT);
+    const double2 *prior2 = reinterpret_cast<const double2 *>(a.prior);
+    double *wk = wkAll + qpar * K;
+    double *part = partAll + qpar * (nPart * WPQ);
+    double accL = 0, hW = 0;
     for (int64_t k = 0; k < K; k++) {
-      const double *rowA = qBase + k * ldT;
-      Comp w = {0.0, 0.0};
-      for (int64_t t = tid; t < ldT; t += kThreads) {
-        const bool g = bit_test(a.tgap, t);
-        const double invD = g ? 0.0 : 1.0 / rowD[t];
-        const double pri = g ? 0.0 : a.prior[t];
-        comp_add(w, (rowA[t] * invD) * pri);
+      const double2 *rowA = reinterpret_cast<const double2 *>(qBase + k * ldT);
+      double s0 = 0, c0 = 0, s1 = 0, c1 = 0;
+      for (int64_t p = tid; p < nPairs; p += kThreads) {
+        const bool g0 = bit_test(a.tgap, 2 * p), g1 = bit_test(a.tgap, 2 * p + 1);
+        const double2 d = rowD[p], av = rowA[p], pv = prior2[p];
+        const double x0 = g0 ? 0.0 : (av.x * div_nr(1.0, d.x)) * pv.x;
+        const double x1 = g1 ? 0.0 : (av.y * div_nr(1.0, d.y)) * pv.y;
+        {
+          const double y = x0 - c0;
+          const double t = s0 + y;
+          c0 = (t - s0) - y;
+          s0 = t;
+        }
+        {
+          const double y = x1 - c1;
+          const double t = s1 + y;
+          c1 = (t - s1) - y;
+          s1 = t;
+        }
       }
-      const double Wk = block_sum_comp<WPQ>(w, red, phase);
-      const double invWk = 1.0 / Wk;
-      double hv[2] = {0, 0};
-      for (int64_t t = tid; t < ldT; t += kThreads) {
-        const bool g = bit_test(a.tgap, t);
-        const double invD = g ? 0.0 : 1.0 / rowD[t];
-        const double pri = g ? 0.0 : a.prior[t];
-        const double p = ((rowA[t] * invD) * pri) * invWk;
-        const double l2 = log2hot(p, tbl);
-        hv[0] = fma(p, l2, hv[0]);
-        accL += (invD * invD) / l2;
-        const double d = p - pri;
-        hv[1] = fma(d, d, hv[1]);
+      double Wk = wave_sum((s0 - c0) + (s1 - c1));
+      {
+        double *buf = redW + phase * WPQ;
+        if (lane == 0) buf[wave] = Wk;
+        __syncthreads();
+        Wk = row_sum<WPQ>(buf[lane % WPQ]);
+        phase ^= 1;
       }
-      block_sum<WPQ, 2>(hv, red, phase);
-      if (tid == 0) {
-        mets[k] = Wk;
-        mets[K + k] = -hv[0];
-        mets[2 * K + k] = hv[1];
+      const double invWk = div_nr(1.0, Wk);
+      double v = 0;
+      for (int64_t p = tid; p < nPairs; p += kThreads) {
+        const bool g0 = bit_test(a.tgap, 2 * p), g1 = bit_test(a.tgap, 2 * p + 1);
+        const double2 d = rowD[p], av = rowA[p];
+        double2 pv = prior2[p], id, lh;
+        id.x = g0 ? 0.0 : div_nr(1.0, d.x);
+        id.y = g1 ? 0.0 : div_nr(1.0, d.y);
+        pv.x = g0 ? 0.0 : pv.x;
+        pv.y = g1 ? 0.0 : pv.y;
+        lh.x = (av.x * id.x) * pv.x;
+        lh.y = (av.y * id.y) * pv.y;
+        pass2_pair(lh, id, pv, invWk, tbl, hW, v, accL);
+      }
+      v = wave_sum(v);
+      if (lane == 0) {
+        if (wave == 0) wk[k] = Wk;
+        part[k * WPQ + wave] = v;
       }
     }
-    double lv[1] = {accL};
-    block_sum<WPQ, 1>(lv, red, phase);
-    if (tid == 0) a.priority[q - a.qFirst] = eval_epilogue(mets, mets + K, mets + 2 * K, K, lv[0], a.nValidPlus1);
+    hW = wave_sum(hW);
+    accL = wave_sum(accL);
+    if (lane == 0) {
+      part[K * WPQ + wave] = hW;
+      part[(K + 1) * WPQ + wave] = accL;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      for (int r = 0; r < nPart; r++) {
+        double acc = part[r * WPQ];
+        for (int w2 = 1; w2 < WPQ; w2++) acc += part[r * WPQ + w2];
+        part[r] = acc;
+      }
+      a.priority[q - a.qFirst] = eval_epilogue(wk, -part[K], part, K, part[K + 1], a.nValidPlus1);
+    }
+    qpar ^= 1;
   }
 }
 
@@ -248,33 +345,52 @@ namespace {
 
 struct Variant {
   int id, wpq, np;
+  bool prLds;
   const char *name;
 };
 // capacity in targets = 128 * wpq * np
 const Variant kVariants[] = {
-    {1, 1, 8, "wave_per_question_np8"},   {2, 4, 2, "wg256_np2"},  {3, 4, 4, "wg256_np4"},   {4, 4, 8, "wg256_np8"},
-    {5, 8, 8, "wg512_np8"},               {6, 16, 5, "wg1024_np5"}, {7, 16, 8, "wg1024_np8"}, {8, 2, 4, "wg128_np4"},
-    {9, 8, 2, "wg512_np2"},               {99, 4, 0, "stream256"},
+    {1, 1, 8, false, "wave_per_question_np8"}, {2, 4, 2, false, "wg256_np2"},   {3, 4, 4, false, "wg256_np4"},
+    {4, 4, 8, false, "wg256_np8"},             {5, 8, 8, true, "wg512_np8_prlds"}, {6, 16, 5, true, "wg1024_np5_prlds"},
+    {7, 16, 8, true, "wg1024_np8_prlds"},      {8, 2, 4, false, "wg128_np4"},   {9, 8, 5, false, "wg512_np5"},
+    {10, 8, 10, true, "wg512_np10_prlds"},     {11, 16, 5, false, "wg1024_np5"}, {12, 8, 10, false, "wg512_np10"},
+    {99, 4, 0, false, "stream256"},
 };
 
 int pick_variant(int64_t ldT, int variant) {
   if (variant != 0) return variant;
-  if (ldT <= 1024) return 2;
+  if (ldT <= 1024) return 8;
   if (ldT <= 2048) return 3;
   if (ldT <= 4096) return 4;
-  if (ldT <= 8192) return 5;
-  if (ldT <= 10240) return 6;
+  if (ldT <= 5120) return 9;
+  if (ldT <= 10240) return 10;
   if (ldT <= 16384) return 7;
   return 99;
 }
 
-template <int WPQ, int NP>
+int gNumCUs = 0;
+
+template <int WPQ, int NP, bool PRLDS>
 hipError_t launch_reg(const EvalArgs &args, int64_t nQ, hipStream_t stream) {
-  const size_t shmem = (1024 + 2 * WPQ * 3 + 3 * (size_t)args.K) * sizeof(double);
-  // Enough workgroups to fill 256 CUs several times over; questions beyond the grid are grid-strided.
-  const int64_t maxBlocks = 256 * 16;
-  const unsigned grid = (unsigned)(nQ < maxBlocks ? nQ : maxBlocks);
-  hipLaunchKernelGGL((eval_questions_f64<WPQ, NP>), dim3(grid), dim3(WPQ * 64), shmem, stream, args);
+  const size_t shmem = eval_lds_doubles(WPQ, args.K, PRLDS, args.ldT) * sizeof(double);
+  auto kern = eval_questions_f64<WPQ, NP, PRLDS>;
+  if (shmem > 64 * 1024) {
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+    if (e != hipSuccess) return e;
+  }
+  if (gNumCUs == 0) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0)
+      gNumCUs = n;
+    else
+      gNumCUs = 256;
+  }
+  int perCU = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, kern, WPQ * 64, shmem) != hipSuccess || perCU < 1) perCU = 1;
+  // one question per workgroup while they all fit on the chip at once; otherwise a resident grid that strides
+  const int64_t resident = (int64_t)gNumCUs * perCU;
+  const unsigned grid = (unsigned)(nQ < resident ? nQ : resident);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(WPQ * 64), shmem, stream, args);
   return hipGetLastError();
 }
 
@@ -309,17 +425,20 @@ hipError_t LaunchEvalQuestions(const KbView &kb, const double *prior, const uint
     if (x.id == v) { wpq = x.wpq; np = x.np; }
   if (v != 99 && (wpq == 0 || kb.ldT > (int64_t)128 * wpq * np)) return hipErrorInvalidValue;
   switch (v) {
-    case 1: return launch_reg<1, 8>(args, nQ, stream);
-    case 2: return launch_reg<4, 2>(args, nQ, stream);
-    case 3: return launch_reg<4, 4>(args, nQ, stream);
-    case 4: return launch_reg<4, 8>(args, nQ, stream);
-    case 5: return launch_reg<8, 8>(args, nQ, stream);
-    case 6: return launch_reg<16, 5>(args, nQ, stream);
-    case 7: return launch_reg<16, 8>(args, nQ, stream);
-    case 8: return launch_reg<2, 4>(args, nQ, stream);
-    case 9: return launch_reg<8, 2>(args, nQ, stream);
+    case 1: return launch_reg<1, 8, false>(args, nQ, stream);
+    case 2: return launch_reg<4, 2, false>(args, nQ, stream);
+    case 3: return launch_reg<4, 4, false>(args, nQ, stream);
+    case 4: return launch_reg<4, 8, false>(args, nQ, stream);
+    case 5: return launch_reg<8, 8, true>(args, nQ, stream);
+    case 6: return launch_reg<16, 5, true>(args, nQ, stream);
+    case 7: return launch_reg<16, 8, true>(args, nQ, stream);
+    case 8: return launch_reg<2, 4, false>(args, nQ, stream);
+    case 9: return launch_reg<8, 5, false>(args, nQ, stream);
+    case 10: return launch_reg<8, 10, true>(args, nQ, stream);
+    case 11: return launch_reg<16, 5, false>(args, nQ, stream);
+    case 12: return launch_reg<8, 10, false>(args, nQ, stream);
     case 99: {
-      const size_t shmem = (1024 + 2 * 4 * 3 + 3 * (size_t)args.K) * sizeof(double);
+      const size_t shmem = eval_lds_doubles(4, args.K, false, 0) * sizeof(double);
       const int64_t maxBlocks = 256 * 8;
       const unsigned grid = (unsigned)(nQ < maxBlocks ? nQ : maxBlocks);
       hipLaunchKernelGGL(eval_questions_f64_stream, dim3(grid), dim3(256), shmem, stream, args);

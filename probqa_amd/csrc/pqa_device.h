@@ -1,5 +1,5 @@
-// pqa_device.h -- device-side building blocks shared by the gfx950 kernels: Log2Hot, compensated wave / workgroup
-// reductions, bitmap helpers.  Compiled with -ffp-contract=off: fma() appears only where it is written.
+// pqa_device.h -- device-side building blocks shared by the gfx950 kernels: Log2Hot, exact scale-free division,
+// DPP wave reductions, bitmap helpers.  Compiled with -ffp-contract=off: fma() appears only where it is written.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -18,14 +18,27 @@ __device__ __forceinline__ bool bit_test(const uint32_t *__restrict__ bits, int6
   return (bits[i >> 5] >> (i & 31)) & 1u;
 }
 
-// The 1024-entry table of SRVectMath::Log2Hot (reference: SRPlatform/SRVectMath.cpp:30-44): log2 of the bucket
-// midpoint, entry 0 scaled by 9.9999999999999927e-01 so that log2(1) < 0.  It lives in eval_kernels.hip
-// (gLog2Table), is built on the host with std::log2 and uploaded once (UploadLog2Table) -- the values the kernels
-// see are exactly the host libm's, like the reference's.
+// ---- division ------------------------------------------------------------------------------------------------------
+// IEEE-correct quotient for operands that need no scaling (no denormals / overflow in n, d, n/d): v_rcp_f64 (2^-24.4
+// accurate on gfx950), one Newton step, then Markstein's residual correction.  37 cycles per wave instead of the 60-70
+// of the compiler's div_scale / div_fmas / div_fixup sequence; bit-identical to '/' on 3e9 random operands in the
+// ranges the sweep uses (tools/div_test.hip: Log2Hot's (z-m)/(z+m), 1/D, generic quotients).
+__device__ __forceinline__ double div_nr(double n, double d) {
+  double r = __builtin_amdgcn_rcp(d);
+  const double e = fma(-d, r, 1.0);
+  r = fma(r, e, r);
+  const double q0 = n * r;
+  const double rem = fma(-d, q0, n);
+  return fma(rem, r, q0);
+}
 
-// SRVectMath::Log2Hot (reference: SRPlatform/Interface/SRVectMath.h:87-135), one lane.  tbl points at the LDS copy
-// of the table.  Operation-for-operation the reference's sequence (true division, the two explicit FMAs), so the
-// result is bit-identical to the CPU for the same x.
+// ---- SRVectMath::Log2Hot ---------------------------------------------------------------------------------------------
+// The 1024-entry table (reference: SRPlatform/SRVectMath.cpp:30-44: log2 of the bucket midpoint, entry 0 scaled by
+// 9.9999999999999927e-01 so that log2(1) < 0) lives in eval_kernels.hip (gLog2Table); it is built on the host with
+// std::log2 and uploaded once (UploadLog2Table), so the kernels see exactly the host libm's values, like the
+// reference's CPU code.  log2hot() below is SRPlatform/Interface/SRVectMath.h:87-135 for one lane: the reference's
+// sequence operation for operation (exact quotient, the two explicit FMAs), bit-identical to the CPU for the same x.
+// tbl points at the LDS copy of the table.
 __device__ __forceinline__ double log2hot(double x, const double *__restrict__ tbl) {
   const uint64_t ux = d2u(x);
   const int32_t hi = (int32_t)(ux >> 32);
@@ -35,7 +48,7 @@ __device__ __forceinline__ double log2hot(double x, const double *__restrict__ t
   const int32_t idx = (hi >> 10) & 1023;                       // top 10 mantissa bits (:101-102)
   const double y = tbl[idx];
   const double m = u2d((1ULL << 41) | (uz & ~((1ULL << 42) - 1)));  // bucket midpoint (:108)
-  const double t = (z - m) / (z + m);                          // :111-114
+  const double t = div_nr(z - m, z + m);                       // :111-114; |z-m| < 2^-10, z+m in [2,4)
   const double t2 = t * t;
   const double t3 = t * t2;
   const double terms01 = fma(1.0 / 3, t3, t);                  // :118
@@ -43,7 +56,7 @@ __device__ __forceinline__ double log2hot(double x, const double *__restrict__ t
   return log2z + (double)e;                                    // :131-133
 }
 
-// ---- error-free transformation and compensated reductions -------------------------------------------------------
+// ---- error-free transformation and compensated values ---------------------------------------------------------------
 __device__ __forceinline__ void two_sum(double a, double b, double &s, double &e) {
   s = a + b;
   const double bb = s - a;
@@ -54,12 +67,6 @@ struct Comp {  // value = s + c, c holds the rounding errors of s
   double s, c;
 };
 
-__device__ __forceinline__ void comp_add(Comp &a, double x) {
-  double e;
-  two_sum(a.s, x, a.s, e);
-  a.c += e;
-}
-
 __device__ __forceinline__ Comp comp_merge(Comp a, Comp b) {
   Comp r;
   double e;
@@ -68,70 +75,84 @@ __device__ __forceinline__ Comp comp_merge(Comp a, Comp b) {
   return r;
 }
 
-__device__ __forceinline__ double shfl_xor_d(double v, int mask) { return __shfl_xor(v, mask, kWave); }
+// ---- cross-lane moves -----------------------------------------------------------------------------------------------
+// DPP controls (gfx9): quad_perm[1,0,3,2] = lane^1, quad_perm[2,3,0,1] = lane^2, row_half_mirror = 7-lane within 8,
+// row_mirror = 15-lane within 16.  Applied in this order to partial sums they form an all-reduce over a 16-lane row
+// (after the two quad steps all lanes of a quad agree, so the mirrored partner holds the other quad's / half's sum).
+constexpr int kDppXor1 = 0xB1, kDppXor2 = 0x4E, kDppHalfMirror = 0x141, kDppMirror = 0x140;
 
-// Butterfly all-reduce over the 64 lanes; commutative steps => every lane ends with the same bits.
+template <int CTRL>
+__device__ __forceinline__ double mov_dpp(double v) {
+  const uint64_t b = d2u(v);
+  int lo = (int)(uint32_t)b, hi = (int)(uint32_t)(b >> 32);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, true);  // every lane has a valid source: no `old` copy
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true);
+  return u2d(((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo);
+}
+
+// v_permlane16_swap / v_permlane32_swap (gfx950): with both operands = v they return, per lane, this lane's value and
+// the value of the lane 16 (resp. 32) away in the paired row (resp. half).
+struct Pair { double a, b; };
+__device__ __forceinline__ Pair swap16(double v) {
+  const uint64_t b = d2u(v);
+  const auto r0 = __builtin_amdgcn_permlane16_swap((uint32_t)b, (uint32_t)b, false, false);
+  const auto r1 = __builtin_amdgcn_permlane16_swap((uint32_t)(b >> 32), (uint32_t)(b >> 32), false, false);
+  return Pair{u2d(((uint64_t)r1[0] << 32) | r0[0]), u2d(((uint64_t)r1[1] << 32) | r0[1])};
+}
+__device__ __forceinline__ Pair swap32(double v) {
+  const uint64_t b = d2u(v);
+  const auto r0 = __builtin_amdgcn_permlane32_swap((uint32_t)b, (uint32_t)b, false, false);
+  const auto r1 = __builtin_amdgcn_permlane32_swap((uint32_t)(b >> 32), (uint32_t)(b >> 32), false, false);
+  return Pair{u2d(((uint64_t)r1[0] << 32) | r0[0]), u2d(((uint64_t)r1[1] << 32) | r0[1])};
+}
+
+// All-reduce (sum) over the 64 lanes of a wave: 4 DPP steps inside each row of 16, then rows, then halves.
+// Every lane ends with the same bits (each step adds the same two partial sums in both partner lanes).
 __device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int m = kWave / 2; m >= 1; m >>= 1) v += shfl_xor_d(v, m);
-  return v;
+  v += mov_dpp<kDppXor1>(v);
+  v += mov_dpp<kDppXor2>(v);
+  v += mov_dpp<kDppHalfMirror>(v);
+  v += mov_dpp<kDppMirror>(v);
+  Pair p = swap16(v);
+  v = p.a + p.b;
+  p = swap32(v);
+  return p.a + p.b;
 }
 
 __device__ __forceinline__ Comp wave_sum_comp(Comp v) {
-#pragma unroll
-  for (int m = kWave / 2; m >= 1; m >>= 1) {
-    Comp o;
-    o.s = shfl_xor_d(v.s, m);
-    o.c = shfl_xor_d(v.c, m);
-    v = comp_merge(v, o);
-  }
+  v = comp_merge(v, Comp{mov_dpp<kDppXor1>(v.s), mov_dpp<kDppXor1>(v.c)});
+  v = comp_merge(v, Comp{mov_dpp<kDppXor2>(v.s), mov_dpp<kDppXor2>(v.c)});
+  v = comp_merge(v, Comp{mov_dpp<kDppHalfMirror>(v.s), mov_dpp<kDppHalfMirror>(v.c)});
+  v = comp_merge(v, Comp{mov_dpp<kDppMirror>(v.s), mov_dpp<kDppMirror>(v.c)});
+  Pair ps = swap16(v.s), pc = swap16(v.c);
+  v = comp_merge(Comp{ps.a, pc.a}, Comp{ps.b, pc.b});
+  ps = swap32(v.s);
+  pc = swap32(v.c);
+  return comp_merge(Comp{ps.a, pc.a}, Comp{ps.b, pc.b});
+}
+
+// Butterfly over the first W (power of two <= 16) lanes of each 16-lane row, for combining per-wave partials that
+// every lane loaded as entry (lane % W).
+template <int W>
+__device__ __forceinline__ Comp row_sum_comp(Comp v) {
+  if constexpr (W >= 2) v = comp_merge(v, Comp{mov_dpp<kDppXor1>(v.s), mov_dpp<kDppXor1>(v.c)});
+  if constexpr (W >= 4) v = comp_merge(v, Comp{mov_dpp<kDppXor2>(v.s), mov_dpp<kDppXor2>(v.c)});
+  if constexpr (W >= 8) v = comp_merge(v, Comp{mov_dpp<kDppHalfMirror>(v.s), mov_dpp<kDppHalfMirror>(v.c)});
+  if constexpr (W >= 16) v = comp_merge(v, Comp{mov_dpp<kDppMirror>(v.s), mov_dpp<kDppMirror>(v.c)});
   return v;
 }
 
-// Workgroup all-reduce of NV doubles over W waves.  scratch: LDS array of 2*W*NV doubles; `phase` alternates 0/1 per
-// call so that one barrier per reduction suffices.  W == 1 needs no LDS and no barrier.
-template <int W, int NV>
-__device__ __forceinline__ void block_sum(double (&v)[NV], double *scratch, int &phase) {
-#pragma unroll
-  for (int i = 0; i < NV; i++) v[i] = wave_sum(v[i]);
-  if constexpr (W > 1) {
-    const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
-    double *buf = scratch + phase * (W * NV);
-    if (lane == 0) {
-#pragma unroll
-      for (int i = 0; i < NV; i++) buf[wave * NV + i] = v[i];
-    }
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < NV; i++) {
-      double acc = buf[i];
-#pragma unroll
-      for (int w = 1; w < W; w++) acc += buf[w * NV + i];
-      v[i] = acc;
-    }
-    phase ^= 1;
-  }
+template <int W>
+__device__ __forceinline__ double row_sum(double v) {
+  if constexpr (W >= 2) v += mov_dpp<kDppXor1>(v);
+  if constexpr (W >= 4) v += mov_dpp<kDppXor2>(v);
+  if constexpr (W >= 8) v += mov_dpp<kDppHalfMirror>(v);
+  if constexpr (W >= 16) v += mov_dpp<kDppMirror>(v);
+  return v;
 }
 
-template <int W>
-__device__ __forceinline__ double block_sum_comp(Comp v, double *scratch, int &phase) {
-  v = wave_sum_comp(v);
-  if constexpr (W > 1) {
-    const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
-    double *buf = scratch + phase * (W * 2);
-    if (lane == 0) {
-      buf[wave * 2] = v.s;
-      buf[wave * 2 + 1] = v.c;
-    }
-    __syncthreads();
-    Comp acc = {buf[0], buf[1]};
-#pragma unroll
-    for (int w = 1; w < W; w++) acc = comp_merge(acc, Comp{buf[w * 2], buf[w * 2 + 1]});
-    v = acc;
-    phase ^= 1;
-  }
-  return v.s + v.c;
-}
+// shuffle-based variants for the small single-workgroup kernels
+__device__ __forceinline__ double shfl_xor_d(double v, int mask) { return __shfl_xor(v, mask, kWave); }
 
 // ---- scalar Kahan state of the reference (SRPlatform/Interface/SRAccumulator.h:15-39, SRAccumVectDbl256.h) -------
 struct Kahan1 {
