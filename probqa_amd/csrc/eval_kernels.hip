@@ -36,7 +36,80 @@ struct EvalArgs {
   const uint32_t *asked;
   double *priority;
   int64_t K, ldT, qFirst, qLimit, nValidPlus1;
+  FusedSelect fs;
 };
+
+// Fused argmax: the workgroup that finishes last (device-scope arrival counter) scans priority[] and publishes the
+// winner, so a selection is ONE launch and -- with out/seq in host-coherent memory -- needs no copy and no stream
+// synchronisation.  Inter-workgroup visibility follows the agent-scope release / acquire recipe of
+// cdna_hip_programming.md G16: plain stores -> barrier -> one-lane release fence + vmcnt(0) -> counter; the last
+// workgroup: one-lane acquire fence (invalidates this CU's L1) -> barrier -> plain loads.
+// Priorities are published with write-through (sc1) stores and read back with L1-bypassing (sc1) loads, the
+// fence-free hand-off form of cdna_hip_programming.md G16: payload sc1 -> s_waitcnt vmcnt(0) -> counter.
+__device__ __forceinline__ void store_priority(double *p, double v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+constexpr unsigned kCounterShards = 16;  // one hot word serialises ~12 ns per arrival; 1000 workgroups arrive together
+
+__device__ __forceinline__ void fused_select(const EvalArgs &a, double *ldsScratch) {
+  if (a.fs.counter == nullptr) return;
+  __shared__ int sIsLast;
+  if (threadIdx.x == 0) {  // the same lane stored every priority of this workgroup
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned shard = blockIdx.x % kCounterShards;
+    const unsigned expected = (gridDim.x - shard + kCounterShards - 1) / kCounterShards;
+    int last = 0;
+    if (__hip_atomic_fetch_add(a.fs.counter + shard, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == expected - 1) {
+      __hip_atomic_store(a.fs.counter + shard, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-arm
+      const unsigned nShards = gridDim.x < kCounterShards ? gridDim.x : kCounterShards;
+      unsigned *top = a.fs.counter + kCounterShards;
+      if (__hip_atomic_fetch_add(top, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nShards - 1) {
+        __hip_atomic_store(top, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        last = 1;
+      }
+    }
+    sIsLast = last;
+  }
+  __syncthreads();
+  if (!sIsLast) return;
+  const int64_t n = a.qLimit - a.qFirst;
+  double bp = 0;
+  int64_t bi = -1;
+  for (int64_t j = threadIdx.x; j < n; j += blockDim.x) {
+    const int64_t q = a.qFirst + j;
+    if (bit_test(a.qgap, q) || bit_test(a.asked, q)) continue;
+    double p = __hip_atomic_load(a.priority + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (p != p) p = -__builtin_huge_val();  // NaN never wins over a number
+    if (bi < 0 || p > bp) { bp = p; bi = j; }              // ascending j: ties keep the lowest index
+  }
+#pragma unroll
+  for (int m = kWave / 2; m >= 1; m >>= 1) {
+    const double op = __shfl_xor(bp, m, kWave);
+    const int64_t oi = __shfl_xor(bi, m, kWave);
+    if (oi >= 0 && (bi < 0 || op > bp || (op == bp && oi < bi))) { bp = op; bi = oi; }
+  }
+  const int nw = blockDim.x / kWave;
+  int64_t *ldsIdx = reinterpret_cast<int64_t *>(ldsScratch + 16);
+  if (threadIdx.x % kWave == 0) {
+    ldsScratch[threadIdx.x / kWave] = bp;
+    ldsIdx[threadIdx.x / kWave] = bi;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < nw; w++) {
+      const double op = ldsScratch[w];
+      const int64_t oi = ldsIdx[w];
+      if (oi >= 0 && (bi < 0 || op > bp || (op == bp && oi < bi))) { bp = op; bi = oi; }
+    }
+    a.fs.out->priority = bp;
+    a.fs.out->index = bi < 0 ? -1 : bi + a.fs.outBase;
+    if (a.fs.seq != nullptr) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");  // system scope: the record is visible to the host before the flag
+      __hip_atomic_store(a.fs.seq, a.fs.seqValue, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+}
 
 // Reference epilogue, PqaCore/CEEvalQsSubtaskConsider.cpp:134-207.  mW / mV: per-answer weight and velocity^2;
 // whSum = sum_k W_k * H_k, which the sweep accumulates directly as -sum_{k,t} l_kt * log2(p_kt) (W_k * p_kt == l_kt up to
@@ -80,8 +153,7 @@ __device__ __forceinline__ void pass2_pair(double2 lh, double2 id, double2 pr, d
   hW = fma(lh.y, l21, hW);
   const double prod = l20 * l21;
   double r = __builtin_amdgcn_rcp(prod);
-  r = fma(r, fma(-prod, r, 1.0), r);
-  r = fma(r, fma(-prod, r, 1.0), r);
+  r = fma(r, fma(-prod, r, 1.0), r);                           // one Newton step: 2^-48.8, below the sum's own rounding
   // invD^2 is invariant over the answers: keep the compiler from hoisting 2*NP squares into registers for the whole
   // question (an opaque move per element is cheaper than the occupancy they would cost)
   double ix = id.x, iy = id.y;
@@ -145,7 +217,7 @@ __global__ __launch_bounds__(WPQ * 64) void eval_questions_f64(EvalArgs a) {
   const int64_t qStride = (K + 1) * ldT;
   for (int64_t q = a.qFirst + blockIdx.x; q < a.qLimit; q += gridDim.x) {
     if (bit_test(a.qgap, q) || bit_test(a.asked, q)) {         // :54
-      if (tid == 0) a.priority[q - a.qFirst] = 0;
+      if (tid == 0) store_priority(a.priority + (q - a.qFirst), 0.0);
       continue;
     }
     const double *qBase = a.cube + q * qStride;
@@ -167,25 +239,15 @@ __global__ __launch_bounds__(WPQ * 64) void eval_questions_f64(EvalArgs a) {
     for (int64_t k = 0; k < K; k++) {
       // ---- pass 1 (:66-87): likelihoods into registers, W_k (two Kahan chains per lane)
       double2 lh[NP];
-      double s0 = 0, c0 = 0, s1 = 0, c1 = 0;
+      double s0 = 0, s1 = 0;
 #pragma unroll
       for (int j = 0; j < NP; j++) {
         double2 pv;
         if constexpr (PRLDS) pv = prLds[min(tid + j * kThreads, nPairs)]; else pv = pr[j];
         lh[j].x = (nxt[j].x * invD[j].x) * pv.x;               // :81-82 (gap lanes: invD = 0 and prior = 0)
         lh[j].y = (nxt[j].y * invD[j].y) * pv.y;
-        {
-          const double y = lh[j].x - c0;
-          const double t = s0 + y;
-          c0 = (t - s0) - y;
-          s0 = t;
-        }
-        {
-          const double y = lh[j].y - c1;
-          const double t = s1 + y;
-          c1 = (t - s1) - y;
-          s1 = t;
-        }
+        s0 += lh[j].x;  // <= 2*NP terms per lane: plain sums, then the butterfly -- a 64*WPQ-leaf pairwise tree
+        s1 += lh[j].y;
       }
       // prefetch the next answer's row while this one is reduced and log2'ed
       if (k + 1 < K) {
@@ -193,7 +255,7 @@ __global__ __launch_bounds__(WPQ * 64) void eval_questions_f64(EvalArgs a) {
 #pragma unroll
         for (int j = 0; j < NP; j++) nxt[j] = rowN[pidx[j]];
       }
-      double Wk = wave_sum((s0 - c0) + (s1 - c1));             // :88
+      double Wk = wave_sum(s0 + s1);                           // :88
       if constexpr (WPQ > 1) {
         double *buf = redW + phase * WPQ;
         if (lane == 0) buf[wave] = Wk;
@@ -234,10 +296,11 @@ __global__ __launch_bounds__(WPQ * 64) void eval_questions_f64(EvalArgs a) {
         for (int w2 = 1; w2 < WPQ; w2++) acc += part[r * WPQ + w2];
         part[r] = acc;
       }
-      a.priority[q - a.qFirst] = eval_epilogue(wk, -part[K], part, K, part[K + 1], a.nValidPlus1);  // :130 H = -sum
+      store_priority(a.priority + (q - a.qFirst), eval_epilogue(wk, -part[K], part, K, part[K + 1], a.nValidPlus1));  // :130
     }
     qpar ^= 1;
   }
+  fused_select(a, tbl);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -261,7 +324,7 @@ __global__ __launch_bounds__(256) void eval_questions_f64_stream(EvalArgs a) {
   int phase = 0, qpar = 0;
   for (int64_t q = a.qFirst + blockIdx.x; q < a.qLimit; q += gridDim.x) {
     if (bit_test(a.qgap, q) || bit_test(a.asked, q)) {
-      if (tid == 0) a.priority[q - a.qFirst] = 0;
+      if (tid == 0) store_priority(a.priority + (q - a.qFirst), 0.0);
       continue;
     }
     const double *qBase = a.cube + q * qStride;
@@ -332,10 +395,11 @@ __global__ __launch_bounds__(256) void eval_questions_f64_stream(EvalArgs a) {
         for (int w2 = 1; w2 < WPQ; w2++) acc += part[r * WPQ + w2];
         part[r] = acc;
       }
-      a.priority[q - a.qFirst] = eval_epilogue(wk, -part[K], part, K, part[K + 1], a.nValidPlus1);
+      store_priority(a.priority + (q - a.qFirst), eval_epilogue(wk, -part[K], part, K, part[K + 1], a.nValidPlus1));
     }
     qpar ^= 1;
   }
+  fused_select(a, tbl);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -359,7 +423,7 @@ const Variant kVariants[] = {
 
 int pick_variant(int64_t ldT, int variant) {
   if (variant != 0) return variant;
-  if (ldT <= 1024) return 8;
+  if (ldT <= 1024) return 2;
   if (ldT <= 2048) return 3;
   if (ldT <= 4096) return 4;
   if (ldT <= 5120) return 9;
@@ -404,7 +468,8 @@ const char *EvalVariantName(const KbView &kb, int variant) {
 }
 
 hipError_t LaunchEvalQuestions(const KbView &kb, const double *prior, const uint32_t *asked, int64_t qFirst,
-                               int64_t qLimit, double *priority, int variant, hipStream_t stream) {
+                               int64_t qLimit, double *priority, int variant, const FusedSelect *fused,
+                               hipStream_t stream) {
   if (qLimit <= qFirst) return hipSuccess;
   EvalArgs args;
   args.cube = kb.cube;
@@ -418,6 +483,7 @@ hipError_t LaunchEvalQuestions(const KbView &kb, const double *prior, const uint
   args.qFirst = qFirst;
   args.qLimit = qLimit;
   args.nValidPlus1 = kb.nValidTargets + 1;  // PqaCore/CEEvalQsSubtaskConsider.cpp:191
+  args.fs = fused ? *fused : FusedSelect{nullptr, nullptr, nullptr, 0, 0};
   const int64_t nQ = qLimit - qFirst;
   const int v = pick_variant(kb.ldT, variant);
   int wpq = 0, np = 0;

@@ -2,6 +2,7 @@
 #include "hip_engine.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -157,7 +158,10 @@ Error HipEngine::Init(const CiEngineDefinition &def, const CiHipShard *shard) {
   HIP_TRY(hipMalloc(&_dStatus, 2 * sizeof(int64_t)));
   HIP_TRY(hipMalloc(&_dNOut, sizeof(int64_t)));
   HIP_TRY(hipMalloc(&_dSel, sizeof(SelectResult)));
-  HIP_TRY(hipHostMalloc(&_hPinned, sizeof(Pinned), hipHostMallocDefault));
+  HIP_TRY(hipMalloc(&_dCounter, 32 * sizeof(unsigned)));  // 16 arrival shards + the top-level word (eval_kernels.hip)
+  HIP_TRY(hipMemset(_dCounter, 0, 32 * sizeof(unsigned)));
+  HIP_TRY(hipHostMalloc(&_hPinned, sizeof(Pinned), hipHostMallocMapped | hipHostMallocCoherent));
+  std::memset(_hPinned, 0, sizeof(Pinned));
   _hTGap.assign(BitWords(_ldT), 0);
   _hQGap.assign(BitWords(_Q), 0);
   for (int64_t t = _T; t < (int64_t)_hTGap.size() * 32; t++) BitSet(_hTGap, t, true);  // GapTracker.h:9-10
@@ -180,7 +184,7 @@ HipEngine::~HipEngine() {
   if (_stream) hipStreamSynchronize(_stream);
   for (Quiz *q : _quizzes) if (q) DestroyQuiz(q);
   hipFree(_dCube); hipFree(_dVB); hipFree(_dPriority); hipFree(_dRunLength); hipFree(_dExps); hipFree(_dStatus);
-  hipFree(_dNOut); hipFree(_dSel); hipFree(_dTGap); hipFree(_dQGap); hipFree(_dAqs); hipFree(_dTop);
+  hipFree(_dNOut); hipFree(_dSel); hipFree(_dCounter); hipFree(_dTGap); hipFree(_dQGap); hipFree(_dAqs); hipFree(_dTop);
   if (_hPinned) hipHostFree(_hPinned);
   if (_ownStream) hipStreamDestroy(_ownStream);
 }
@@ -432,7 +436,7 @@ Error HipEngine::EnqueueEval(int64_t iQuiz) {
   if (!err.ok()) return err;
   Quiz *q = UseQuiz(err, iQuiz);
   if (!q) return err;
-  HIP_TRY(LaunchEvalQuestions(View(), q->dPrior, q->dAsked, 0, _Q, _dPriority, (int)_optEvalVariant, _stream));
+  HIP_TRY(LaunchEvalQuestions(View(), q->dPrior, q->dAsked, 0, _Q, _dPriority, (int)_optEvalVariant, nullptr, _stream));
   return Error();
 }
 
@@ -442,10 +446,9 @@ Error HipEngine::EnqueueSelectArgmax(int64_t iQuiz, void *pOut) {
   if (!err.ok()) return err;
   Quiz *q = UseQuiz(err, iQuiz);
   if (!q) return err;
-  const KbView kb = View();
-  HIP_TRY(LaunchEvalQuestions(kb, q->dPrior, q->dAsked, 0, _Q, _dPriority, (int)_optEvalVariant, _stream));
-  // reported index = local position + qFirst, i.e. the GLOBAL question id
-  HIP_TRY(LaunchSelectArgmax(_dPriority, _dQGap, q->dAsked, 0, _Q, _qFirst, pOut ? (SelectResult *)pOut : _dSel, _stream));
+  // one launch: the sweep's last workgroup picks the argmax; reported index = local position + qFirst (GLOBAL id)
+  const FusedSelect fs{_dCounter, pOut ? (SelectResult *)pOut : _dSel, nullptr, 0, _qFirst};
+  HIP_TRY(LaunchEvalQuestions(View(), q->dPrior, q->dAsked, 0, _Q, _dPriority, (int)_optEvalVariant, &fs, _stream));
   return Error();
 }
 
@@ -456,12 +459,30 @@ int64_t HipEngine::NextQuestionArgmax(Error &err, int64_t iQuiz) {
   Quiz *q = UseQuiz(err, iQuiz);
   if (!q) return -1;
   hipSetDevice(_device);
-  const KbView kb = View();
-  hipError_t he = LaunchEvalQuestions(kb, q->dPrior, q->dAsked, 0, _Q, _dPriority, (int)_optEvalVariant, _stream);
-  if (he == hipSuccess) he = LaunchSelectArgmax(_dPriority, _dQGap, q->dAsked, 0, _Q, 0, _dSel, _stream);
-  if (he == hipSuccess) he = hipMemcpyAsync(&_hPinned->sel, _dSel, sizeof(SelectResult), hipMemcpyDeviceToHost, _stream);
-  if (he == hipSuccess) he = hipStreamSynchronize(_stream);
+  // One launch; the last workgroup writes the winner and then a sequence number straight into host-coherent pinned
+  // memory, which this thread polls: no D2H copy, no stream synchronisation on the critical path.
+  const uint64_t seq = ++_selSeq;
+  const FusedSelect fs{_dCounter, &_hPinned->sel, &_hPinned->seq, seq, 0};
+  hipError_t he = LaunchEvalQuestions(View(), q->dPrior, q->dAsked, 0, _Q, _dPriority, (int)_optEvalVariant, &fs, _stream);
   if (he != hipSuccess) { err = HipErr(he, "NextQuestionArgmax"); return -1; }
+  volatile uint64_t *flag = &_hPinned->seq;
+  const auto t0 = std::chrono::steady_clock::now();
+  uint64_t spins = 0;
+  while (*flag != seq) {
+    if ((++spins & 0xFFF) == 0) {
+      if (hipStreamQuery(_stream) == hipSuccess && *flag != seq) {  // the kernel retired without publishing
+        if ((he = hipStreamSynchronize(_stream)) != hipSuccess || *flag != seq) {
+          err = HipErr(he == hipSuccess ? hipErrorUnknown : he, "NextQuestionArgmax (result flag)");
+          return -1;
+        }
+      }
+      if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(30)) {
+        err = HipErr(hipErrorNotReady, "NextQuestionArgmax (timeout)");
+        return -1;
+      }
+    }
+  }
+  std::atomic_thread_fence(std::memory_order_acquire);
   return FinishSelection(err, q, _hPinned->sel.index);
 }
 
@@ -474,7 +495,7 @@ int64_t HipEngine::NextQuestionSampled(Error &err, int64_t iQuiz, uint64_t rnd) 
   hipSetDevice(_device);
   const KbView kb = View();
   const int64_t nSub = _optEvalSubtasks ? _optEvalSubtasks : 8 * _optWorkers;  // reference PqaCore/CpuEngine.cpp:339
-  hipError_t he = LaunchEvalQuestions(kb, q->dPrior, q->dAsked, 0, _Q, _dPriority, (int)_optEvalVariant, _stream);
+  hipError_t he = LaunchEvalQuestions(kb, q->dPrior, q->dAsked, 0, _Q, _dPriority, (int)_optEvalVariant, nullptr, _stream);
   if (he == hipSuccess) he = LaunchSelectSampled(_dPriority, _dQGap, q->dAsked, 0, _Q, nSub, rnd, _dRunLength, _dSel, _stream);
   if (he == hipSuccess) he = hipMemcpyAsync(&_hPinned->sel, _dSel, sizeof(SelectResult), hipMemcpyDeviceToHost, _stream);
   if (he == hipSuccess) he = hipStreamSynchronize(_stream);
@@ -498,7 +519,7 @@ Error HipEngine::EvalPriorities(int64_t iQuiz, double *pOut, int64_t n) {
   if (!pOut) return Error::Make(ErrCode::NullArgument, "Nullptr is passed in place of the priority buffer.");
   if (n != _Q) return Error::MakeP(ErrCode::IndexOutOfRange, RangeParams(n, _Q, _Q), "Priority buffer length must equal the local question count.");
   hipSetDevice(_device);
-  HIP_TRY(LaunchEvalQuestions(View(), q->dPrior, q->dAsked, 0, _Q, _dPriority, (int)_optEvalVariant, _stream));
+  HIP_TRY(LaunchEvalQuestions(View(), q->dPrior, q->dAsked, 0, _Q, _dPriority, (int)_optEvalVariant, nullptr, _stream));
   HIP_TRY(hipMemcpyAsync(pOut, _dPriority, (size_t)_Q * sizeof(double), hipMemcpyDeviceToHost, _stream));
   HIP_TRY(hipStreamSynchronize(_stream));
   return Error();

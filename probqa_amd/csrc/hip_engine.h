@@ -128,7 +128,9 @@ class HipEngine {
   RatedTargetDev *_dTop = nullptr;
   int64_t _topCapacity = 0;
   SelectResult *_dSel = nullptr;
-  struct Pinned { SelectResult sel; int64_t status[2]; int64_t nOut; };
+  struct Pinned { SelectResult sel; uint64_t seq; int64_t status[2]; int64_t nOut; };
+  unsigned *_dCounter = nullptr;   // arrival counter of the fused sweep+argmax launch
+  uint64_t _selSeq = 0;
   Pinned *_hPinned = nullptr;
   std::vector<uint32_t> _hTGap, _hQGap;   // host mirrors; qgap over local questions, bits past size set
   int64_t _nTargetGaps = 0;

@@ -35,8 +35,17 @@ hipError_t UploadLog2Table(const double *hostTable);
 
 // ---- a1: priority sweep.  priority[q - qFirst] for q in [qFirst,qLimit); 0 for gap / asked questions.
 // Returns hipSuccess or the launch error.  `variant`: 0 = auto, otherwise forces a kernel shape (tests/bench).
+// `fused` (optional): let the sweep's last workgroup also pick the argmax, so that a selection is one launch.
+struct FusedSelect {
+  unsigned *counter;      // device word, zero before the first launch; the kernel re-arms it
+  SelectResult *out;      // device or host-coherent memory; index = position in priority[] + outBase
+  uint64_t *seq;          // optional host-coherent flag, set to seqValue after `out` is visible
+  uint64_t seqValue;
+  int64_t outBase;
+};
 hipError_t LaunchEvalQuestions(const KbView &kb, const double *prior, const uint32_t *asked, int64_t qFirst,
-                               int64_t qLimit, double *priority, int variant, hipStream_t stream);
+                               int64_t qLimit, double *priority, int variant, const FusedSelect *fused,
+                               hipStream_t stream);
 const char *EvalVariantName(const KbView &kb, int variant);
 
 // ---- selectors over priority[0..n) (questions qFirst..qFirst+n of the bitmaps); the reported index is

@@ -1,0 +1,243 @@
+"""CPU tests of the oracle (oracle/pqa_oracle.c): the reference's own known-answer tests for the pieces it pins, internal
+consistency (AVX2 port == scalar restatement), an independent mathematical definition, selection logic, and the
+committed golden fixtures."""
+import ctypes
+import json
+import os
+
+import numpy as np
+import pytest
+
+import cases
+import orclib
+from probqa_amd import synth
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+# ---- reference SRPlatformTests/SRVectMathTest.cpp:45-103 (Log2Hot) ---------------------------------------------------
+def test_log2hot_reference_assertions(oracle_lib):
+    req_prec = 3e-12
+    f = oracle_lib.orc_log2hot
+    vals = [f(x) for x in (1.0, 0.99999, 0.9999, 0.999)]          # :49-56
+    assert all(v <= 0 for v in vals) and vals[0] >= -req_prec
+    assert all(f(x) <= -1022.5 for x in (0.0, -1.0, -2.0, -3.0))  # :57-63
+    # :65-83 mantissa x exponent sweep (every 16th point of the reference's 2^22 to keep the CPU suite short)
+    n_mant_bits, exp_range = 22, 2046
+    for i in range(0, 1 << n_mant_bits, 16):
+        cur_exp = (i % exp_range) + 1
+        bits = (cur_exp << 52) | (i << (52 - n_mant_bits))
+        x = np.array([bits], dtype=np.uint64).view(np.float64)[0]
+        if x == 1.0:
+            continue
+        exp = np.log2(x)
+        assert abs(f(float(x)) - exp) <= abs(exp) * req_prec
+    rng = np.random.default_rng(1)                                # :85-103 random uint64 -> double
+    for u in rng.integers(1, 2**63, size=20000, dtype=np.uint64):
+        x = float(u)
+        exp = np.log2(x)
+        assert abs(f(x) - exp) <= abs(exp) * req_prec
+
+
+def test_log2hot_special_values(oracle_lib):
+    f = oracle_lib.orc_log2hot
+    assert f(0.0) == -1023.0 and f(2.0 ** -1022) == -1022.0 and f(0.5) == -1.0
+    assert -1e-18 < f(1.0) < 0  # strictly negative at 1 (table[0] correction, SRVectMath.cpp:31,42)
+    tbl = np.ctypeslib.as_array(oracle_lib.orc_log2hot_table(), shape=(1024,))
+    assert np.all(np.diff(tbl) > 0) and 0 < tbl[0] < 1e-3 and tbl[-1] < 1
+
+
+# ---- reference SRPlatformTests/SRAccumulatorTest.cpp:21-35 -----------------------------------------------------------
+def test_kahan4_reference_known_answers(oracle_lib):
+    va1, va2 = orclib.OrcKahan4(), orclib.OrcKahan4()
+    va1.sum[:] = [16, 32, 64, 128]
+    va1.corr[:] = [1, 2, 4, 8]
+    va2.sum[:] = [4096, 8192, 16384, 32768]
+    va2.corr[:] = [256, 512, 1024, 2048]
+    assert oracle_lib.orc_k4_precise_sum(ctypes.byref(va1)) == 225
+    assert oracle_lib.orc_k4_full_sum(ctypes.byref(va1)) == 225
+    s2 = ctypes.c_double()
+    assert oracle_lib.orc_k4_pair_sum(ctypes.byref(va1), ctypes.byref(va2), ctypes.byref(s2)) == 225
+    assert s2.value == 57600
+    assert oracle_lib.orc_k4_full_sum(ctypes.byref(va2)) == 57600
+    assert oracle_lib.orc_k4_precise_sum(ctypes.byref(va2)) == 57600
+
+
+def test_calc_split(oracle_lib):
+    # SRPoolRunner::CalcSplit (SRPoolRunner.h:96-110)
+    b = (ctypes.c_int64 * 8)()
+    assert oracle_lib.orc_calc_split(10, 4, b) == 4 and list(b)[:4] == [3, 6, 8, 10]
+    assert oracle_lib.orc_calc_split(3, 8, b) == 3 and list(b)[:3] == [1, 2, 3]
+
+
+# ---- reference PqaCoreTests/Dimensions.cpp:60-77: fresh KB values ------------------------------------------------------
+def test_fresh_kb_values():
+    o = orclib.Oracle(4, 5, 7, 0.3)
+    assert (o.A[:, :, :7] == 0.3 * 0.3).all() and (o.D[:, :7] == 0.3 * 0.3 * 4).all() and (o.B[:7] == 0.3).all()
+    o.start_quiz(16)
+    assert abs(o.priors().sum() - 1) < 1e-15
+
+
+# ---- internal consistency ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("case", cases.small_cases(), ids=lambda c: c.name)
+def test_avx2_port_is_bit_identical_to_scalar(case):
+    if not orclib.lib().orc_have_avx2():
+        pytest.skip("no AVX2")
+    o = case.make_oracle()
+    o.start_quiz(16)
+    for q, a in case.answers:
+        o.record_answer(q, a, 15)
+    run, pri = o.eval(32)
+    for threads in (1, 4):
+        run2, pri2 = o.eval_avx2(threads, 32)
+        assert np.array_equal(pri, pri2) and np.array_equal(run, run2)
+
+
+def math_priority(A, D, prior, n_valid, gaps=()):
+    """Independent statement of the priority (README / CEEvalQsSubtaskConsider.cpp:207) in plain numpy with true log2 and
+    naive sums, in long double where it is cheap."""
+    ld = np.longdouble
+    keep = np.ones(A.shape[-1], bool)
+    keep[list(gaps)] = False
+    A, D, prior = A[..., keep].astype(ld), D[..., keep].astype(ld), prior[keep].astype(ld)
+    invD = 1 / D
+    P = A * invD[:, None, :] * prior[None, None, :]
+    W = P.sum(-1)
+    post = P / W[..., None]
+    l2 = np.log2(post)
+    H = -(post * l2).sum(-1)
+    V = np.sqrt(((post - prior) ** 2).sum(-1))
+    lack = -((invD[:, None, :] ** 2) / l2).sum((1, 2))
+    totW = W.sum(-1)
+    avgH, avgV = (W * H).sum(-1) / totW, (W * V).sum(-1) / totW
+    c = ld(0.34657359027997265470861606072909)
+    vcomp = 1 / (c - np.log(avgV) + c / ld((n_valid + 1) ** 2))
+    return (lack * vcomp ** 9 / np.exp2(avgH) ** 2).astype(np.float64)
+
+
+@pytest.mark.parametrize("case", cases.small_cases(), ids=lambda c: c.name)
+def test_priority_matches_mathematical_definition(case):
+    o = case.make_oracle()
+    o.start_quiz(16)
+    for q, a in case.answers:
+        o.record_answer(q, a, 15)
+    _, pri = o.eval(128)
+    A, D, _ = case.kb()
+    mp = math_priority(A, D, o.priors(), case.T - len(case.tgaps), case.tgaps)
+    live = pri != 0
+    assert set(np.nonzero(~live)[0]) == set(case.qgaps) | {q for q, _ in case.answers}
+    # the restatement computes the intended quantity; conditioning grows as a posterior approaches 1
+    assert cases.rel_err(pri[live], mp[live]).max() < 1e-10
+
+
+def test_posteriors_match_bayes_rule():
+    case = cases.small_cases()[4]
+    o = case.make_oracle()
+    A, D, B = case.kb()
+    o.start_quiz(16)
+    p = B / B.sum()
+    assert np.allclose(o.priors(), p, rtol=1e-14)
+    for q, a in case.answers:
+        o.record_answer(q, a, 15)
+        p = p * A[q, a] / D[q]
+        p /= p.sum()
+        assert np.allclose(o.priors(), p, rtol=1e-13)
+    # ResumeQuiz recomputes the same posterior through the mantissa/exponent split (CEUpdatePriorsSubtaskMul)
+    o2 = case.make_oracle()
+    assert o2.resume_quiz(case.answers, 16) == 0
+    assert np.allclose(o2.priors(), p, rtol=1e-13)
+
+
+def test_resume_bug_compat_switch():
+    # CEUpdatePriorsSubtaskMul.cpp:53 reads vector 0 of vB for every target vector: identical for a uniform vB,
+    # different once vB varies beyond the first four targets.
+    case = cases.small_cases()[1]
+    o1, o2 = case.make_oracle(), case.make_oracle()
+    o1.resume_quiz([(10, 4), (30, 0)], 16, False)
+    o2.resume_quiz([(10, 4), (30, 0)], 16, True)
+    assert not np.array_equal(o1.priors(), o2.priors())
+    o1.B[:] = 0.7
+    o2.B[:] = 0.7
+    o1.resume_quiz([(10, 4), (30, 0)], 16, False)
+    o2.resume_quiz([(10, 4), (30, 0)], 16, True)
+    assert np.array_equal(o1.priors(), o2.priors())
+
+
+def test_resume_all_gaps_underflows():
+    o = orclib.Oracle(3, 4, 6, 1.0)
+    o.set_target_gaps(range(6))
+    assert o.resume_quiz([(0, 1)], 4) == 16  # PqaErrorCode::I64Underflow (CpuEngine.cpp:317-321)
+
+
+# ---- selection (CpuEngine.cpp:362-406, BaseEngine.cpp:60-124) ------------------------------------------------------------
+def test_sampled_selection_follows_the_running_sums():
+    case = cases.small_cases()[1]
+    o = case.make_oracle()
+    o.start_quiz(16)
+    o.record_answer(10, 4, 15)
+    n_sub = 8
+    run, pri = o.eval(n_sub)
+    bounds = (ctypes.c_int64 * n_sub)()
+    n = orclib.lib().orc_calc_split(case.Q, n_sub, bounds)
+    tot = sum(run[bounds[i] - 1] for i in range(n))
+    cum = np.cumsum(pri)
+    assert abs(cum[-1] - tot) <= 1e-12 * tot
+    rng = np.random.default_rng(3)
+    for rnd in [0, 2**64 - 1] + [int(x) for x in rng.integers(0, 2**64 - 1, size=200, dtype=np.uint64)]:
+        sel = o.select_sampled(run, n_sub, rnd)
+        assert pri[sel] > 0  # never a gap / asked question
+        target = tot * rnd / (2**64 - 1)
+        lo = cum[sel - 1] if sel > 0 else 0.0
+        assert lo - 1e-9 * tot <= target <= cum[sel] + 1e-9 * tot or rnd == 2**64 - 1
+
+
+def test_find_nearest_question_matches_brute_force():
+    Q = 300
+    o = orclib.Oracle(3, Q, 8, 1.0)
+    rng = np.random.default_rng(9)
+    avail = rng.random(Q) < 0.05
+    avail[[0, 63, 64, 200]] = True
+    for q in range(Q):
+        if not avail[q]:
+            if rng.random() < 0.5:
+                o.set_question_gaps([q])
+            else:
+                orclib.lib()  # asked bits live in the quiz
+                o.quiz.contents.asked[q >> 3] |= 1 << (q & 7)
+    cand = np.nonzero(avail)[0]
+    for mid in range(Q):
+        got = o.find_nearest(mid)
+        d = np.abs(cand - mid)
+        assert got in cand and abs(got - mid) <= d.min() + 64  # pack-granular search: nearest within the 64-bit pack order
+        if (cand >> 6 == mid >> 6).any():  # same pack: exact nearest, ties to the lower index
+            same = cand[cand >> 6 == mid >> 6]
+            ds = np.abs(same - mid)
+            best = same[ds == ds.min()].min()
+            assert got == best
+    o2 = orclib.Oracle(3, 70, 8, 1.0)
+    o2.set_question_gaps(range(70))
+    assert o2.find_nearest(35) == -1
+
+
+def test_argmax_lowest_index_on_ties():
+    o = orclib.Oracle(3, 9, 8, 1.0)
+    o.start_quiz(4)
+    _, pri = o.eval(4)
+    assert np.ptp(pri) == 0 and o.select_argmax(pri) == 0
+    o.set_question_gaps([0])
+    _, pri = o.eval(4)
+    assert o.select_argmax(pri) == 1
+
+
+# ---- golden fixtures (generated by tests/golden/make_golden.py from this oracle; they pin it against regressions) ----------
+@pytest.mark.parametrize("name", sorted(f[:-5] for f in os.listdir(GOLDEN) if f.endswith(".json")) if os.path.isdir(GOLDEN) else [])
+def test_oracle_reproduces_golden_fixture(name):
+    import sys
+    sys.path.insert(0, GOLDEN)
+    import make_golden
+
+    meta = json.load(open(os.path.join(GOLDEN, name + ".json")))
+    data = np.load(os.path.join(GOLDEN, name + ".npz"))
+    got = make_golden.run_case(make_golden.case_from_meta(meta))
+    for key in data.files:
+        assert np.array_equal(got[key], data[key]), (name, key)
