@@ -105,13 +105,15 @@ PQACORE_API void *PqaEngineFactory_CreateHipEngineSharded(void *pvFactory, void 
 
 PQACORE_API void *PqaEngineFactory_LoadCpuEngine(void *pvFactory, void **ppError, const char *filePath,
                                                  uint64_t memPoolMaxBytes) {
-  (void)filePath; (void)memPoolMaxBytes;
+  (void)memPoolMaxBytes;  // the device engine has no host memory pool to size
   if (pvFactory == nullptr) {
     if (ppError) *ppError = new Error(Error::Make(ErrCode::NullArgument, "Nullptr is passed in place of IPqaEngineFactory."));
     return nullptr;
   }
-  if (ppError) *ppError = new Error(NotImpl("LoadCpuEngine (.kb persistence)"));
-  return nullptr;
+  Error err;
+  HipEngine *eng = HipEngine::Load(err, filePath);
+  AssignErr(ppError, err);
+  return eng;
 }
 
 PQACORE_API void CiReleasePqaError(void *pvErr) { delete static_cast<Error *>(pvErr); }
@@ -132,36 +134,35 @@ PQACORE_API void *PqaEngine_Train(void *pvEngine, int64_t nQuestions, const CiAn
 
 PQACORE_API uint8_t PqaEngine_QuestionPermFromComp(void *pvEngine, const int64_t count, int64_t *pIds) {
   GET_ENGINE_OR_LOG_ERR(0);
-  return pEng->QuestionIdMap(count, pIds) ? 1 : 0;
+  return pEng->MapIds(0, true, count, pIds) ? 1 : 0;
 }
 PQACORE_API uint8_t PqaEngine_QuestionCompFromPerm(void *pvEngine, const int64_t count, int64_t *pIds) {
   GET_ENGINE_OR_LOG_ERR(0);
-  return pEng->QuestionIdMap(count, pIds) ? 1 : 0;
+  return pEng->MapIds(0, false, count, pIds) ? 1 : 0;
 }
 PQACORE_API uint8_t PqaEngine_TargetPermFromComp(void *pvEngine, const int64_t count, int64_t *pIds) {
   GET_ENGINE_OR_LOG_ERR(0);
-  return pEng->TargetIdMap(count, pIds) ? 1 : 0;
+  return pEng->MapIds(1, true, count, pIds) ? 1 : 0;
 }
 PQACORE_API uint8_t PqaEngine_TargetCompFromPerm(void *pvEngine, const int64_t count, int64_t *pIds) {
   GET_ENGINE_OR_LOG_ERR(0);
-  return pEng->TargetIdMap(count, pIds) ? 1 : 0;
+  return pEng->MapIds(1, false, count, pIds) ? 1 : 0;
 }
 PQACORE_API uint8_t PqaEngine_QuizPermFromComp(void *pvEngine, const int64_t count, int64_t *pIds) {
   GET_ENGINE_OR_LOG_ERR(0);
-  return pEng->QuizIdMap(count, pIds) ? 1 : 0;
+  return pEng->MapIds(2, true, count, pIds) ? 1 : 0;
 }
 PQACORE_API uint8_t PqaEngine_QuizCompFromPerm(void *pvEngine, const int64_t count, int64_t *pIds) {
   GET_ENGINE_OR_LOG_ERR(0);
-  return pEng->QuizIdMap(count, pIds) ? 1 : 0;
+  return pEng->MapIds(2, false, count, pIds) ? 1 : 0;
 }
 PQACORE_API uint8_t PqaEngine_EnsurePermQuizGreater(void *pvEngine, const int64_t bound) {
   GET_ENGINE_OR_LOG_ERR(0);
-  (void)bound;
-  return 0;  // permanent quiz ids equal compact ids in this build; nothing was increased
+  return pEng->EnsurePermQuizGreater(bound) ? 1 : 0;
 }
 PQACORE_API uint8_t PqaEngine_RemapQuizPermId(void *pvEngine, const int64_t srcPermId, const int64_t destPermId) {
   GET_ENGINE_OR_LOG_ERR(0);
-  return srcPermId == destPermId ? 1 : 0;
+  return pEng->RemapQuizPermId(srcPermId, destPermId) ? 1 : 0;
 }
 
 PQACORE_API uint64_t PqaEngine_GetTotalQuestionsAsked(void *pvEngine, void **ppError) {
@@ -210,8 +211,7 @@ PQACORE_API void *PqaEngine_RecordAnswer(void *pvEngine, const int64_t iQuiz, co
 
 PQACORE_API void *PqaEngine_ClearOldQuizzes(void *pvEngine, const int64_t maxCount, const double maxAgeSec) {
   GET_ENGINE_OR_RET_ERR;
-  (void)maxCount; (void)maxAgeSec;
-  return ReturnErr(NotImpl("ClearOldQuizzes"));
+  return ReturnErr(pEng->ClearOldQuizzes(maxCount, maxAgeSec));
 }
 
 PQACORE_API int64_t PqaEngine_GetActiveQuestionId(void *pvEngine, void **ppError, const int64_t iQuiz) {
@@ -249,8 +249,7 @@ PQACORE_API void *PqaEngine_ReleaseQuiz(void *pvEngine, const int64_t iQuiz) {
 
 PQACORE_API void *PqaEngine_SaveKB(void *pvEngine, const char *const filePath, const uint8_t bDoubleBuffer) {
   GET_ENGINE_OR_RET_ERR;
-  (void)filePath; (void)bDoubleBuffer;
-  return ReturnErr(NotImpl("SaveKB (.kb persistence)"));
+  return ReturnErr(pEng->SaveKB(filePath, bDoubleBuffer != 0));
 }
 
 PQACORE_API void *PqaEngine_StartMaintenance(void *pvEngine, const bool forceQuizzes) {
@@ -264,24 +263,20 @@ PQACORE_API void *PqaEngine_FinishMaintenance(void *pvEngine) {
 PQACORE_API void *PqaEngine_AddQsTs(void *pvEngine, const int64_t nQuestions, CiAddQorTParam *pAddQuestionParams,
                                     const int64_t nTargets, CiAddQorTParam *pAddTargetParams) {
   GET_ENGINE_OR_RET_ERR;
-  (void)nQuestions; (void)pAddQuestionParams; (void)nTargets; (void)pAddTargetParams;
-  return ReturnErr(NotImpl("AddQsTs"));
+  return ReturnErr(pEng->AddQsTs(nQuestions, pAddQuestionParams, nTargets, pAddTargetParams));
 }
 PQACORE_API void *PqaEngine_RemoveQuestions(void *pvEngine, const int64_t nQuestions, const int64_t *pQIds) {
   GET_ENGINE_OR_RET_ERR;
-  (void)nQuestions; (void)pQIds;
-  return ReturnErr(NotImpl("RemoveQuestions"));
+  return ReturnErr(pEng->RemoveQuestions(nQuestions, pQIds));
 }
 PQACORE_API void *PqaEngine_RemoveTargets(void *pvEngine, const int64_t nTargets, const int64_t *pTIds) {
   GET_ENGINE_OR_RET_ERR;
-  (void)nTargets; (void)pTIds;
-  return ReturnErr(NotImpl("RemoveTargets"));
+  return ReturnErr(pEng->RemoveTargets(nTargets, pTIds));
 }
 PQACORE_API void *PqaEngine_Compact(void *pvEngine, int64_t *pnQuestions, int64_t const **const ppOldQuestions,
                                     int64_t *pnTargets, int64_t const **const ppOldTargets) {
   GET_ENGINE_OR_RET_ERR;
-  (void)pnQuestions; (void)ppOldQuestions; (void)pnTargets; (void)ppOldTargets;
-  return ReturnErr(NotImpl("Compact"));
+  return ReturnErr(pEng->Compact(pnQuestions, ppOldQuestions, pnTargets, ppOldTargets));
 }
 PQACORE_API void CiReleaseCompaction(const int64_t *p) { std::free(const_cast<int64_t *>(p)); }
 

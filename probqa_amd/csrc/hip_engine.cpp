@@ -119,6 +119,9 @@ Error HipEngine::Init(const CiEngineDefinition &def, const CiHipShard *shard) {
                        "No HIP device is available: libPqaCore.so (MI355X build) has no CPU fallback.");
   }
   _K = def._nAnswers; _Q = def._nQuestions; _T = def._nTargets;
+  _capQ = _Q;
+  _precMantissa = def._precMantissa;
+  _precExponent = def._precExponent;
   _initAmount = def._initAmount;
   _ldT = ((_T + 15) / 16) * 16;
   _qFirst = shard ? shard->_qFirst : 0;
@@ -172,6 +175,8 @@ Error HipEngine::Init(const CiEngineDefinition &def, const CiHipShard *shard) {
   if (!e.ok()) return e;
   HIP_TRY(LaunchFillFresh(_dCube, _dVB, _K, _Q, _T, _ldT, _initAmount, _stream));
   HIP_TRY(hipStreamSynchronize(_stream));
+  _pimQuestions.GrowTo(_Q);  // reference PqaCore/BaseCpuEngine.cpp:24-25
+  _pimTargets.GrowTo(_T);
   std::random_device rd;  // the reference seeds from RDRAND (SRPlatform/Interface/SRFastRandom.h:31-40)
   uint64_t seed = ((uint64_t)rd() << 32) ^ rd();
   _rng[0] = SplitMix64(seed);
@@ -266,6 +271,7 @@ Quiz *HipEngine::UseQuiz(Error &err, int64_t iQuiz) {
                        "Quiz index is not in the registry (but rather at a gap).");
     return nullptr;
   }
+  _quizzes[iQuiz]->lastUsage = time(nullptr);  // BaseQuiz::OnUsage (BaseEngine.cpp:417)
   return _quizzes[iQuiz];
 }
 
@@ -335,11 +341,8 @@ int64_t HipEngine::CreateQuiz(Error &err, int64_t nAnswered, const AQ *pAQs) {
     }
     for (int64_t i = 0; i < nAnswered; i++) quiz->answers.push_back(pAQs[i]);
   }
-  // AssignQuiz, reference PqaCore/BaseEngine.cpp (gap reuse, else append)
-  int64_t id;
-  if (!_quizGaps.empty()) { id = _quizGaps.back(); _quizGaps.pop_back(); _quizzes[id] = quiz.release(); }
-  else { id = (int64_t)_quizzes.size(); _quizzes.push_back(quiz.release()); }
-  return id;
+  quiz->lastUsage = time(nullptr);
+  return AssignQuiz(quiz.release());
 }
 
 int64_t HipEngine::StartQuiz(Error &err) {
@@ -368,8 +371,7 @@ Error HipEngine::ReleaseQuiz(int64_t iQuiz) {
   if (!q) return err;
   hipSetDevice(_device);
   hipStreamSynchronize(_stream);
-  _quizzes[iQuiz] = nullptr;
-  _quizGaps.push_back(iQuiz);
+  UnassignQuiz(iQuiz);
   DestroyQuiz(q);
   return Error();
 }
@@ -753,9 +755,8 @@ Error HipEngine::StartMaintenance(bool forceQuizzes) {  // reference PqaCore/Bas
                           "Can't switch to maintenance mode while there are active quizzes.");
     hipSetDevice(_device);
     hipStreamSynchronize(_stream);
-    for (size_t i = 0; i < _quizzes.size(); i++) if (_quizzes[i]) { DestroyQuiz(_quizzes[i]); _quizzes[i] = nullptr; }
-    _quizzes.clear();
-    _quizGaps.clear();
+    for (size_t i = 0; i < _quizzes.size(); i++)
+      if (_quizzes[i]) { Quiz *q = _quizzes[i]; UnassignQuiz((int64_t)i); DestroyQuiz(q); }
   }
   _mode = Mode::Maintenance;
   return Error();
@@ -770,32 +771,16 @@ Error HipEngine::FinishMaintenance() {  // reference PqaCore/BaseEngine.cpp:692-
 }
 
 Error HipEngine::Shutdown(const char *saveFilePath) {
+  if (saveFilePath && *saveFilePath) {  // reference PqaCore/BaseEngine.cpp:270-300: save, then shut down
+    Error e = SaveKB(saveFilePath, false);
+    if (!e.ok()) return e;
+  }
   std::lock_guard<std::mutex> lk(_mu);
   if (_mode == Mode::Shutdown) return Error::MakeP(ErrCode::ObjectShutDown, "RejectedOperation=Shutdown", "Engine is already shut down.");
-  if (saveFilePath && *saveFilePath)
-    return Error::MakeP(ErrCode::NotImplemented, "Feature=SaveKB on Shutdown", "KB persistence is not built yet.");
   hipSetDevice(_device);
   hipStreamSynchronize(_stream);
   _mode = Mode::Shutdown;
   return Error();
-}
-
-bool HipEngine::QuestionIdMap(int64_t count, int64_t *pIds) const {
-  bool all = true;
-  for (int64_t i = 0; i < count; i++) if (pIds[i] < 0 || pIds[i] >= _qTotal) { pIds[i] = -1; all = false; }
-  return all;
-}
-bool HipEngine::TargetIdMap(int64_t count, int64_t *pIds) const {
-  bool all = true;
-  for (int64_t i = 0; i < count; i++) if (pIds[i] < 0 || pIds[i] >= _T || BitTest(_hTGap, pIds[i])) { pIds[i] = -1; all = false; }
-  return all;
-}
-bool HipEngine::QuizIdMap(int64_t count, int64_t *pIds) const {
-  std::lock_guard<std::mutex> lk(_mu);
-  bool all = true;
-  for (int64_t i = 0; i < count; i++)
-    if (pIds[i] < 0 || pIds[i] >= (int64_t)_quizzes.size() || !_quizzes[pIds[i]]) { pIds[i] = -1; all = false; }
-  return all;
 }
 
 Error HipEngine::SetStream(hipStream_t s) {
@@ -857,7 +842,12 @@ Error HipEngine::SetTargetGaps(int64_t n, const int64_t *ids) {
   for (int64_t i = 0; i < n; i++)
     if (ids[i] < 0 || ids[i] >= _T) return Error::MakeP(ErrCode::IndexOutOfRange, RangeParams(ids[i], 0, _T - 1), "Target index is not in KB range.");
   for (int64_t i = 0; i < n; i++)
-    if (!BitTest(_hTGap, ids[i])) { BitSet(_hTGap, ids[i], true); _nTargetGaps++; }
+    if (!BitTest(_hTGap, ids[i])) {
+      BitSet(_hTGap, ids[i], true);
+      _nTargetGaps++;
+      _targetGapList.push_back(ids[i]);
+      _pimTargets.RemoveComp(ids[i]);
+    }
   hipSetDevice(_device);
   return UploadGaps();
 }
@@ -867,7 +857,11 @@ Error HipEngine::SetQuestionGaps(int64_t n, const int64_t *ids) {
   for (int64_t i = 0; i < n; i++)
     if (ids[i] < 0 || ids[i] >= _qTotal) return Error::MakeP(ErrCode::IndexOutOfRange, RangeParams(ids[i], 0, _qTotal - 1), "Question index is not in KB range.");
   for (int64_t i = 0; i < n; i++)
-    if (ids[i] >= _qFirst && ids[i] < _qFirst + _Q) BitSet(_hQGap, ids[i] - _qFirst, true);
+    if (ids[i] >= _qFirst && ids[i] < _qFirst + _Q && !BitTest(_hQGap, ids[i] - _qFirst)) {
+      BitSet(_hQGap, ids[i] - _qFirst, true);
+      _questionGapList.push_back(ids[i] - _qFirst);
+      _pimQuestions.RemoveComp(ids[i] - _qFirst);
+    }
   hipSetDevice(_device);
   return UploadGaps();
 }

@@ -12,7 +12,10 @@
 #include <cstdint>
 #include <memory>
 #include <mutex>
+#include <cstdio>
+#include <ctime>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/PqaHipExt.h"
@@ -46,7 +49,29 @@ const char *ErrCodeName(ErrCode c);  // reference PqaCore/PqaErrors.cpp:13-62
 
 struct AQ { int64_t iQuestion, iAnswer; };
 
+// PermanentIdManager (reference PqaCore/PermanentIdManager.{h,cpp}): compact id <-> permanent id, survives compaction
+class PermIdMgr {
+ public:
+  int64_t PermFromComp(int64_t compId) const;
+  int64_t CompFromPerm(int64_t permId) const;
+  bool Save(FILE *fpout, bool empty = false) const;
+  bool Load(FILE *fpin);
+  bool EnsurePermIdGreater(int64_t bound);
+  bool RemoveComp(int64_t compId);
+  bool RenewComp(int64_t compId);
+  bool GrowTo(int64_t nComp);
+  bool OnCompact(int64_t nNew, const int64_t *pOldIds);
+  bool RemapPermId(int64_t srcPermId, int64_t destPermId);
+  void Clear() { _comp2perm.clear(); _perm2comp.clear(); }
+
+ private:
+  int64_t _nextPermId = 0;
+  std::vector<int64_t> _comp2perm;
+  std::unordered_map<int64_t, int64_t> _perm2comp;
+};
+
 struct Quiz {
+  time_t lastUsage = 0;                // reference BaseQuiz::OnUsage
   double *dPrior = nullptr;            // ldT doubles, device
   uint32_t *dAsked = nullptr;          // device bitmap over LOCAL questions
   std::vector<uint32_t> hAsked;        // host mirror
@@ -75,9 +100,17 @@ class HipEngine {
   Error StartMaintenance(bool forceQuizzes);
   Error FinishMaintenance();
   Error Shutdown(const char *saveFilePath);
-  bool QuestionIdMap(int64_t count, int64_t *pIds) const;  // identity maps while nothing was ever removed
-  bool TargetIdMap(int64_t count, int64_t *pIds) const;
-  bool QuizIdMap(int64_t count, int64_t *pIds) const;
+  // which: 0 questions, 1 targets, 2 quizzes; toPerm: compact -> permanent (reference BaseEngine.cpp:150-215)
+  bool MapIds(int which, bool toPerm, int64_t count, int64_t *pIds);
+  bool EnsurePermQuizGreater(int64_t bound);
+  bool RemapQuizPermId(int64_t srcPermId, int64_t destPermId);
+  Error SaveKB(const char *filePath, bool doubleBuffer);
+  static HipEngine *Load(Error &err, const char *filePath);
+  Error AddQsTs(int64_t nQuestions, CiAddQorTParam *pAqps, int64_t nTargets, CiAddQorTParam *pAtps);
+  Error RemoveQuestions(int64_t n, const int64_t *pQIds);
+  Error RemoveTargets(int64_t n, const int64_t *pTIds);
+  Error Compact(int64_t *pnQuestions, const int64_t **ppOldQuestions, int64_t *pnTargets, const int64_t **ppOldTargets);
+  Error ClearOldQuizzes(int64_t maxCount, double maxAgeSec);
 
   // ---- additive (PqaHipExt.h)
   Error SetOption(const char *name, int64_t value);
@@ -114,6 +147,9 @@ class HipEngine {
   Error RecordAnswerImpl(int64_t iQuiz, int64_t iAnswer, bool remote);
   uint64_t NextRandom();
   Error UploadGaps();
+  Error ReallocKB(int64_t newQ, int64_t newT);               // grow the device cube / vB / per-question buffers
+  int64_t AssignQuiz(Quiz *q);                               // reference BaseEngine::AssignQuiz, BaseEngine.cpp:780-793
+  void UnassignQuiz(int64_t iQuiz);
 
   enum class Mode { Regular, Maintenance, Shutdown };
 
@@ -134,8 +170,14 @@ class HipEngine {
   Pinned *_hPinned = nullptr;
   std::vector<uint32_t> _hTGap, _hQGap;   // host mirrors; qgap over local questions, bits past size set
   int64_t _nTargetGaps = 0;
+  int64_t _capQ = 0;                        // questions the device buffers are allocated for (>= _Q)
+  std::vector<int64_t> _questionGapList, _targetGapList;  // LIFO, like reference PqaCore/GapTracker.h
+  PermIdMgr _pimQuestions, _pimTargets, _pimQuizzes;
+  uint32_t _precMantissa = 0;
+  uint16_t _precExponent = 0;
   std::vector<Quiz *> _quizzes;
   std::vector<int64_t> _quizGaps;
+  friend struct KbIo;
   mutable std::mutex _mu;
   std::atomic<uint64_t> _nQuestionsAsked{0};
   Mode _mode = Mode::Regular;

@@ -1,0 +1,555 @@
+// hip_engine_kb.cpp -- the parts of the engine around the hot path that change or persist the knowledge base:
+// permanent<->compact id maps, quiz registry slots, .kb files, and the maintenance-mode operations.
+// Reference: PqaCore/PermanentIdManager.cpp, PqaCore/BaseEngine.cpp:124-215,323-385,704-873,
+// PqaCore/CpuEngine.cpp:468-658,664-688, PqaCore/PqaEngineBaseFactory.cpp:44-83.  Host bookkeeping is the reference's;
+// the cube itself stays on the device and is edited there (kb_kernels.hip).
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+
+#include "hip_engine.h"
+
+namespace pqa {
+
+namespace {
+
+Error HipErr(hipError_t e, const char *what) {
+  std::string msg = std::string("HIP failure in ") + what + ": " + hipGetErrorString(e);
+  return Error::MakeP(ErrCode::Internal, std::string("Internal error at hip_engine_kb.cpp(") + what + ")", msg);
+}
+#define HIP_TRY(expr)                                   \
+  do {                                                  \
+    const hipError_t e_ = (expr);                       \
+    if (e_ != hipSuccess) return HipErr(e_, #expr);     \
+  } while (0)
+
+inline bool BitTest(const std::vector<uint32_t> &bits, int64_t i) { return (bits[i >> 5] >> (i & 31)) & 1u; }
+inline void BitSet(std::vector<uint32_t> &bits, int64_t i, bool v) {
+  if (v) bits[i >> 5] |= 1u << (i & 31); else bits[i >> 5] &= ~(1u << (i & 31));
+}
+inline size_t BitWords(int64_t nBits) { return (size_t)((nBits + 63) / 64) * 2 + 2; }
+
+Error FileErr(const char *path, const char *msg) {
+  return Error::MakeP(ErrCode::FileOp, std::string("filePath=[") + path + "]", msg);
+}
+
+struct FileCloser {
+  FILE *f;
+  ~FileCloser() { if (f) std::fclose(f); }
+};
+
+Error WrongModeErr(const char *what) {
+  return Error::Make(ErrCode::WrongMode, std::string("Can't perform maintenance-only mode operation - ") + what +
+                                             " - because current mode is not maintenance (but regular/shutdown?).");
+}
+
+// PrecisionDefinition bitfield of reference PqaCore/Interface/PqaCommon.h:26-32 (type:4, mantissa:28, exponent:16, reserved:16)
+uint64_t PackPrecision(uint64_t type, uint64_t mantissa, uint64_t exponent) {
+  return (type & 0xF) | ((mantissa & 0xFFFFFFF) << 4) | ((exponent & 0xFFFF) << 32);
+}
+
+template <typename T>
+hipError_t Upload(T **dst, const std::vector<T> &src, hipStream_t stream) {
+  *dst = nullptr;
+  if (src.empty()) return hipSuccess;
+  hipError_t e = hipMalloc(dst, src.size() * sizeof(T));
+  if (e != hipSuccess) return e;
+  return hipMemcpyAsync(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice, stream);
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------------------------
+// PermIdMgr == PermanentIdManager (reference PqaCore/PermanentIdManager.cpp)
+// ------------------------------------------------------------------------------------------------------------------
+int64_t PermIdMgr::PermFromComp(int64_t compId) const {
+  if (compId < 0 || compId >= (int64_t)_comp2perm.size()) return -1;
+  return _comp2perm[compId];
+}
+int64_t PermIdMgr::CompFromPerm(int64_t permId) const {
+  auto it = _perm2comp.find(permId);
+  return it == _perm2comp.end() ? -1 : it->second;
+}
+bool PermIdMgr::Save(FILE *fpout, bool empty) const {  // :26-38
+  const int64_t nComp = empty ? 0 : (int64_t)_comp2perm.size();
+  if (std::fwrite(&_nextPermId, sizeof(_nextPermId), 1, fpout) != 1) return false;
+  if (std::fwrite(&nComp, sizeof(nComp), 1, fpout) != 1) return false;
+  return (int64_t)std::fwrite(_comp2perm.data(), sizeof(int64_t), (size_t)nComp, fpout) == nComp;
+}
+bool PermIdMgr::Load(FILE *fpin) {  // :40-60
+  int64_t nComp;
+  if (std::fread(&_nextPermId, sizeof(_nextPermId), 1, fpin) != 1) return false;
+  if (std::fread(&nComp, sizeof(nComp), 1, fpin) != 1 || nComp < 0) return false;
+  _comp2perm.resize((size_t)nComp);
+  _perm2comp.clear();
+  if ((int64_t)std::fread(_comp2perm.data(), sizeof(int64_t), (size_t)nComp, fpin) != nComp) return false;
+  for (int64_t i = 0; i < nComp; i++)
+    if (_comp2perm[i] != -1) _perm2comp.emplace(_comp2perm[i], i);
+  return true;
+}
+bool PermIdMgr::EnsurePermIdGreater(int64_t bound) {
+  if (_nextPermId <= bound) { _nextPermId = bound + 1; return true; }
+  return false;
+}
+bool PermIdMgr::RemoveComp(int64_t compId) {
+  if (compId < 0 || compId >= (int64_t)_comp2perm.size()) return false;
+  const int64_t iPerm = _comp2perm[compId];
+  if (iPerm == -1) return false;
+  auto it = _perm2comp.find(iPerm);
+  if (it == _perm2comp.end()) return false;
+  _perm2comp.erase(it);
+  _comp2perm[compId] = -1;
+  return true;
+}
+bool PermIdMgr::RenewComp(int64_t compId) {
+  if (compId < 0 || compId >= (int64_t)_comp2perm.size() || _comp2perm[compId] != -1) return false;
+  _comp2perm[compId] = _nextPermId;
+  _perm2comp.emplace(_nextPermId, compId);
+  _nextPermId++;
+  return true;
+}
+bool PermIdMgr::GrowTo(int64_t nComp) {
+  if (nComp < (int64_t)_comp2perm.size()) return false;
+  for (int64_t i = (int64_t)_comp2perm.size(); i < nComp; i++) {
+    _comp2perm.push_back(_nextPermId);
+    _perm2comp.emplace(_nextPermId, i);
+    _nextPermId++;
+  }
+  return true;
+}
+bool PermIdMgr::OnCompact(int64_t nNew, const int64_t *pOldIds) {  // :125-169
+  if (nNew > (int64_t)_comp2perm.size() || nNew != (int64_t)_perm2comp.size()) return false;
+  for (int64_t i = 0; i < nNew; i++) {
+    const int64_t oldComp = pOldIds[i];
+    if (oldComp < 0 || oldComp >= (int64_t)_comp2perm.size()) return false;
+    const int64_t oldPerm = _comp2perm[oldComp];
+    if (oldPerm == -1) return false;
+    auto it = _perm2comp.find(oldPerm);
+    if (it == _perm2comp.end()) return false;
+    it->second = i;
+  }
+  _comp2perm.assign((size_t)nNew, -1);
+  for (const auto &m : _perm2comp) {
+    if (m.second < 0 || m.second >= nNew) return false;
+    _comp2perm[m.second] = m.first;
+  }
+  return true;
+}
+bool PermIdMgr::RemapPermId(int64_t srcPermId, int64_t destPermId) {  // :171-190
+  if (destPermId >= _nextPermId) return false;
+  if (_perm2comp.find(destPermId) != _perm2comp.end()) return false;
+  auto it = _perm2comp.find(srcPermId);
+  if (it == _perm2comp.end()) return false;
+  const int64_t comp = it->second;
+  _perm2comp.erase(it);
+  _perm2comp.emplace(destPermId, comp);
+  _comp2perm[comp] = destPermId;
+  return true;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// id maps and the quiz registry (reference PqaCore/BaseEngine.cpp:150-215, 780-802)
+// ------------------------------------------------------------------------------------------------------------------
+bool HipEngine::MapIds(int which, bool toPerm, int64_t count, int64_t *pIds) {
+  std::lock_guard<std::mutex> lk(_mu);
+  PermIdMgr &pim = which == 0 ? _pimQuestions : which == 1 ? _pimTargets : _pimQuizzes;
+  for (int64_t i = 0; i < count; i++) pIds[i] = toPerm ? pim.PermFromComp(pIds[i]) : pim.CompFromPerm(pIds[i]);
+  return true;
+}
+bool HipEngine::EnsurePermQuizGreater(int64_t bound) {
+  std::lock_guard<std::mutex> lk(_mu);
+  return _pimQuizzes.EnsurePermIdGreater(bound);
+}
+bool HipEngine::RemapQuizPermId(int64_t srcPermId, int64_t destPermId) {
+  std::lock_guard<std::mutex> lk(_mu);
+  return _pimQuizzes.RemapPermId(srcPermId, destPermId);
+}
+
+int64_t HipEngine::AssignQuiz(Quiz *q) {
+  int64_t id;
+  if (!_quizGaps.empty()) {
+    id = _quizGaps.back();
+    _quizGaps.pop_back();
+    _pimQuizzes.RenewComp(id);
+  } else {
+    id = (int64_t)_quizzes.size();
+    _quizzes.push_back(nullptr);
+    _pimQuizzes.GrowTo((int64_t)_quizzes.size());
+  }
+  _quizzes[(size_t)id] = q;
+  return id;
+}
+
+void HipEngine::UnassignQuiz(int64_t iQuiz) {
+  _quizzes[(size_t)iQuiz] = nullptr;
+  _quizGaps.push_back(iQuiz);
+  _pimQuizzes.RemoveComp(iQuiz);
+}
+
+Error HipEngine::ClearOldQuizzes(int64_t maxCount, double maxAgeSec) {  // BaseEngine.cpp:814-873
+  if (maxCount < 0)
+    return Error::MakeP(ErrCode::NegativeCount, "count=" + std::to_string(maxCount),
+                        "The number of quizzes to keep cannot be less than 0.");
+  std::lock_guard<std::mutex> lk(_mu);
+  if (_mode != Mode::Regular) return Error();  // quizzes are not expected to exist in maintenance / shutdown mode
+  hipSetDevice(_device);
+  hipStreamSynchronize(_stream);
+  struct QuizAge { int64_t iQuiz; double ageSec; bool operator<(const QuizAge &o) const { return ageSec < o.ageSec; } };
+  std::vector<QuizAge> ages;
+  const time_t callTime = time(nullptr);
+  for (int64_t i = 0; i < (int64_t)_quizzes.size(); i++) {
+    Quiz *q = _quizzes[(size_t)i];
+    if (!q) continue;
+    const double ageSec = difftime(callTime, q->lastUsage);
+    if (ageSec > maxAgeSec) { UnassignQuiz(i); DestroyQuiz(q); continue; }
+    ages.push_back(QuizAge{i, ageSec});
+  }
+  if ((int64_t)ages.size() > maxCount) {
+    std::make_heap(ages.begin(), ages.end());
+    while ((int64_t)ages.size() > maxCount) {  // the oldest quiz sits at the heap's top
+      Quiz *q = _quizzes[(size_t)ages.front().iQuiz];
+      UnassignQuiz(ages.front().iQuiz);
+      DestroyQuiz(q);
+      std::pop_heap(ages.begin(), ages.end());
+      ages.pop_back();
+    }
+  }
+  return Error();
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// .kb persistence (layout of reference PqaCore/BaseEngine.cpp:323-385 + PqaCore/CpuEngine.cpp:664-688):
+//   PrecisionDefinition (8 B) | EngineDimensions {nAnswers, nQuestions, nTargets} | u64 nQuestionsAsked |
+//   sA rows [q][a] of nTargets doubles | mD rows [q] | vB | question gaps (i64 n, n ids) | target gaps |
+//   PermanentIdManager x3 (questions, targets, quizzes saved empty)
+// ------------------------------------------------------------------------------------------------------------------
+Error HipEngine::SaveKB(const char *filePath, bool doubleBuffer) {
+  (void)doubleBuffer;  // the device copy already is the "second buffer": the file is written from a host snapshot
+  if (!filePath) return Error::Make(ErrCode::NullArgument, "Nullptr is passed in place of KB file name.");
+  std::lock_guard<std::mutex> lk(_mu);
+  if (_qTotal != _Q) return Error::MakeP(ErrCode::NotImplemented, "Feature=SaveKB of a sharded engine", "Save the shards' owner instead.");
+  FileCloser fc{std::fopen(filePath, "wb")};
+  if (!fc.f)
+    return Error::MakeP(ErrCode::CantOpenFile, std::string("filePath=[") + filePath + "]", "Can't open the file to write KB to.");
+  hipSetDevice(_device);
+  const uint64_t prec = PackPrecision(3 /*Double*/, _precMantissa, _precExponent);
+  const int64_t dims[3] = {_K, _Q, _T};
+  const uint64_t nAsked = _nQuestionsAsked.load(std::memory_order_acquire);
+  if (std::fwrite(&prec, 8, 1, fc.f) != 1) return FileErr(filePath, "Can't write precision definition header.");
+  if (std::fwrite(dims, sizeof(dims), 1, fc.f) != 1) return FileErr(filePath, "Can't write engine dimensions header.");
+  if (std::fwrite(&nAsked, 8, 1, fc.f) != 1) return FileErr(filePath, "Can't write the number of questions asked.");
+  // statistics: a bounded host staging buffer, one batch of questions at a time
+  const size_t rowB = (size_t)_T * sizeof(double), ldB = (size_t)_ldT * sizeof(double);
+  const int64_t batch = std::max<int64_t>(1, (int64_t)((64u << 20) / (rowB * (size_t)_K)));
+  std::vector<double> host((size_t)std::min(batch, _Q) * (size_t)_K * (size_t)_T);
+  for (int64_t q0 = 0; q0 < _Q; q0 += batch) {
+    const int64_t nq = std::min(batch, _Q - q0);
+    for (int64_t q = 0; q < nq; q++)
+      HIP_TRY(hipMemcpy2DAsync(host.data() + (size_t)q * _K * _T, rowB, _dCube + (size_t)(q0 + q) * (_K + 1) * _ldT, ldB, rowB,
+                               (size_t)_K, hipMemcpyDeviceToHost, _stream));
+    HIP_TRY(hipStreamSynchronize(_stream));
+    if (std::fwrite(host.data(), rowB, (size_t)(nq * _K), fc.f) != (size_t)(nq * _K))
+      return FileErr(filePath, "Can't write the target dimension of _sA weights.");
+  }
+  host.resize((size_t)std::min<int64_t>(batch * _K, _Q) * (size_t)_T);
+  for (int64_t q0 = 0; q0 < _Q; q0 += batch * _K) {
+    const int64_t nq = std::min(batch * _K, _Q - q0);
+    HIP_TRY(hipMemcpy2DAsync(host.data(), rowB, _dCube + (size_t)q0 * (_K + 1) * _ldT + (size_t)_K * _ldT, ldB * (size_t)(_K + 1), rowB,
+                             (size_t)nq, hipMemcpyDeviceToHost, _stream));
+    HIP_TRY(hipStreamSynchronize(_stream));
+    if (std::fwrite(host.data(), rowB, (size_t)nq, fc.f) != (size_t)nq)
+      return FileErr(filePath, "Can't write the target dimension of _mD weights.");
+  }
+  host.resize((size_t)_T);
+  HIP_TRY(hipMemcpyAsync(host.data(), _dVB, rowB, hipMemcpyDeviceToHost, _stream));
+  HIP_TRY(hipStreamSynchronize(_stream));
+  if (std::fwrite(host.data(), rowB, 1, fc.f) != 1) return FileErr(filePath, "Can't write the _vB weights.");
+  auto writeGaps = [&](const std::vector<int64_t> &gaps) {
+    const int64_t n = (int64_t)gaps.size();
+    return std::fwrite(&n, 8, 1, fc.f) == 1 && std::fwrite(gaps.data(), 8, (size_t)n, fc.f) == (size_t)n;
+  };
+  if (!writeGaps(_questionGapList)) return FileErr(filePath, "Can't write the question gaps.");
+  if (!writeGaps(_targetGapList)) return FileErr(filePath, "Can't write the target gaps.");
+  if (!_pimQuestions.Save(fc.f)) return FileErr(filePath, "Can't write the question permanent-compact ID mappings.");
+  if (!_pimTargets.Save(fc.f)) return FileErr(filePath, "Can't write the target permanent-compact ID mappings.");
+  if (!_pimQuizzes.Save(fc.f, true)) return FileErr(filePath, "Can't write the quiz permanent-compact ID mappings.");
+  if (std::fflush(fc.f) != 0) return FileErr(filePath, "Failed in hard flushing the KB.");
+  FILE *f = fc.f;
+  fc.f = nullptr;
+  if (std::fclose(f) != 0) return FileErr(filePath, "Failed in closing the file.");
+  return Error();
+}
+
+HipEngine *HipEngine::Load(Error &err, const char *filePath) {  // PqaEngineBaseFactory.cpp:44-83, CpuEngine.cpp:41-92
+  if (!filePath) { err = Error::Make(ErrCode::NullArgument, "Nullptr is passed in place of KB file name."); return nullptr; }
+  FileCloser fc{std::fopen(filePath, "rb")};
+  if (!fc.f) {
+    err = Error::MakeP(ErrCode::CantOpenFile, std::string("filePath=[") + filePath + "]", "Can't open the KB file to read.");
+    return nullptr;
+  }
+  uint64_t prec = 0, nAsked = 0;
+  int64_t dims[3];
+  if (std::fread(&prec, 8, 1, fc.f) != 1) { err = FileErr(filePath, "Can't read precision definition header."); return nullptr; }
+  if (std::fread(dims, sizeof(dims), 1, fc.f) != 1) { err = FileErr(filePath, "Can't read engine dimensions header."); return nullptr; }
+  if (std::fread(&nAsked, 8, 1, fc.f) != 1) { err = FileErr(filePath, "Can't read the number of questions asked."); return nullptr; }
+  CiEngineDefinition def;
+  std::memset(&def, 0, sizeof(def));
+  def._nAnswers = dims[0]; def._nQuestions = dims[1]; def._nTargets = dims[2];
+  def._precType = (uint8_t)(prec & 0xF);
+  def._precMantissa = (uint32_t)((prec >> 4) & 0xFFFFFFF);
+  def._precExponent = (uint16_t)((prec >> 32) & 0xFFFF);
+  def._initAmount = 1.0;  // not stored in the file; every count is overwritten below
+  std::unique_ptr<HipEngine> eng(HipEngine::Create(err, def, nullptr));
+  if (!eng) return nullptr;
+  HipEngine &e = *eng;
+  auto fail = [&](Error x) { err = std::move(x); return (HipEngine *)nullptr; };
+  hipSetDevice(e._device);
+  const size_t rowB = (size_t)e._T * sizeof(double), ldB = (size_t)e._ldT * sizeof(double);
+  const int64_t batch = std::max<int64_t>(1, (int64_t)((64u << 20) / (rowB * (size_t)e._K)));
+  std::vector<double> host((size_t)std::min(batch, e._Q) * (size_t)e._K * (size_t)e._T);
+  for (int64_t q0 = 0; q0 < e._Q; q0 += batch) {
+    const int64_t nq = std::min(batch, e._Q - q0);
+    if (std::fread(host.data(), rowB, (size_t)(nq * e._K), fc.f) != (size_t)(nq * e._K))
+      return fail(FileErr(filePath, "Can't read the target dimension of _sA weights."));
+    for (int64_t q = 0; q < nq; q++)
+      if (hipMemcpy2DAsync(e._dCube + (size_t)(q0 + q) * (e._K + 1) * e._ldT, ldB, host.data() + (size_t)q * e._K * e._T, rowB, rowB,
+                           (size_t)e._K, hipMemcpyHostToDevice, e._stream) != hipSuccess)
+        return fail(Error::Make(ErrCode::Internal, "HIP copy of _sA failed."));
+    if (hipStreamSynchronize(e._stream) != hipSuccess) return fail(Error::Make(ErrCode::Internal, "HIP sync failed."));
+  }
+  host.resize((size_t)std::min<int64_t>(batch * e._K, e._Q) * (size_t)e._T);
+  for (int64_t q0 = 0; q0 < e._Q; q0 += batch * e._K) {
+    const int64_t nq = std::min(batch * e._K, e._Q - q0);
+    if (std::fread(host.data(), rowB, (size_t)nq, fc.f) != (size_t)nq)
+      return fail(FileErr(filePath, "Can't read the target dimension of _mD weights."));
+    if (hipMemcpy2DAsync(e._dCube + (size_t)q0 * (e._K + 1) * e._ldT + (size_t)e._K * e._ldT, ldB * (size_t)(e._K + 1), host.data(), rowB,
+                         rowB, (size_t)nq, hipMemcpyHostToDevice, e._stream) != hipSuccess ||
+        hipStreamSynchronize(e._stream) != hipSuccess)
+      return fail(Error::Make(ErrCode::Internal, "HIP copy of _mD failed."));
+  }
+  host.resize((size_t)e._T);
+  if (std::fread(host.data(), rowB, 1, fc.f) != 1) return fail(FileErr(filePath, "Can't read the _vB weights."));
+  if (hipMemcpyAsync(e._dVB, host.data(), rowB, hipMemcpyHostToDevice, e._stream) != hipSuccess ||
+      hipStreamSynchronize(e._stream) != hipSuccess)
+    return fail(Error::Make(ErrCode::Internal, "HIP copy of _vB failed."));
+  e._nQuestionsAsked.store(nAsked);
+  auto readGaps = [&](std::vector<int64_t> &gaps, int64_t limit) {
+    int64_t n;
+    if (std::fread(&n, 8, 1, fc.f) != 1 || n < 0 || n > limit) return false;
+    gaps.resize((size_t)n);
+    if (std::fread(gaps.data(), 8, (size_t)n, fc.f) != (size_t)n) return false;
+    for (int64_t g : gaps) if (g < 0 || g >= limit) return false;
+    return true;
+  };
+  if (!readGaps(e._questionGapList, e._Q)) return fail(FileErr(filePath, "Can't read the question gaps."));
+  if (!readGaps(e._targetGapList, e._T)) return fail(FileErr(filePath, "Can't read the target gaps."));
+  for (int64_t g : e._questionGapList) BitSet(e._hQGap, g, true);
+  for (int64_t g : e._targetGapList) BitSet(e._hTGap, g, true);
+  e._nTargetGaps = (int64_t)e._targetGapList.size();
+  if (!e._pimQuestions.Load(fc.f)) return fail(FileErr(filePath, "Can't read the question permanent-compact ID mapping."));
+  if (!e._pimTargets.Load(fc.f)) return fail(FileErr(filePath, "Can't read the target permanent-compact ID mapping."));
+  if (!e._pimQuizzes.Load(fc.f)) return fail(FileErr(filePath, "Can't read the quizzes permanent-compact ID mapping."));
+  Error ue = e.UploadGaps();
+  if (!ue.ok()) return fail(std::move(ue));
+  err = Error();
+  return eng.release();
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// maintenance-mode operations
+// ------------------------------------------------------------------------------------------------------------------
+Error HipEngine::ReallocKB(int64_t newQ, int64_t newT) {
+  const int64_t newLdT = std::max(_ldT, ((newT + 15) / 16) * 16);
+  const int64_t newCap = std::max(_capQ, newQ);
+  if (newLdT != _ldT || newCap != _capQ) {
+    double *cube = nullptr, *vB = nullptr;
+    HIP_TRY(hipMalloc(&cube, (size_t)newCap * (size_t)(_K + 1) * (size_t)newLdT * sizeof(double)));
+    HIP_TRY(hipMalloc(&vB, (size_t)newLdT * sizeof(double)));
+    // old rows keep their content; new padding columns get A = 0, D = 1 from the fill of new questions / a plain fill
+    HIP_TRY(LaunchFillFresh(cube, vB, _K, newCap, 0, newLdT, 0.0, _stream));  // T = 0: every column is "padding"
+    HIP_TRY(hipMemcpy2DAsync(cube, (size_t)newLdT * sizeof(double), _dCube, (size_t)_ldT * sizeof(double), (size_t)_T * sizeof(double),
+                             (size_t)_Q * (size_t)(_K + 1), hipMemcpyDeviceToDevice, _stream));
+    HIP_TRY(hipMemcpyAsync(vB, _dVB, (size_t)_T * sizeof(double), hipMemcpyDeviceToDevice, _stream));
+    HIP_TRY(hipStreamSynchronize(_stream));
+    hipFree(_dCube); hipFree(_dVB);
+    _dCube = cube; _dVB = vB;
+    if (newLdT != _ldT) {
+      hipFree(_dExps); _dExps = nullptr;
+      HIP_TRY(hipMalloc(&_dExps, (size_t)newLdT * sizeof(int64_t)));
+    }
+    if (newCap != _capQ) {
+      hipFree(_dPriority); hipFree(_dRunLength); _dPriority = _dRunLength = nullptr;
+      HIP_TRY(hipMalloc(&_dPriority, (size_t)newCap * sizeof(double)));
+      HIP_TRY(hipMalloc(&_dRunLength, (size_t)newCap * sizeof(double)));
+    }
+    _ldT = newLdT;
+    _capQ = newCap;
+  }
+  // bitmaps: keep the old bits, new positions are not gaps, everything past the size is
+  std::vector<uint32_t> tg(BitWords(_ldT), 0), qg(BitWords(newQ), 0);
+  for (int64_t t = 0; t < _T; t++) if (BitTest(_hTGap, t)) BitSet(tg, t, true);
+  for (int64_t t = newT; t < (int64_t)tg.size() * 32; t++) BitSet(tg, t, true);
+  for (int64_t q = 0; q < _Q; q++) if (BitTest(_hQGap, q)) BitSet(qg, q, true);
+  for (int64_t q = newQ; q < (int64_t)qg.size() * 32; q++) BitSet(qg, q, true);
+  _hTGap.swap(tg);
+  _hQGap.swap(qg);
+  hipFree(_dTGap); hipFree(_dQGap); _dTGap = _dQGap = nullptr;
+  HIP_TRY(hipMalloc(&_dTGap, _hTGap.size() * sizeof(uint32_t)));
+  HIP_TRY(hipMalloc(&_dQGap, _hQGap.size() * sizeof(uint32_t)));
+  _Q = newQ;
+  _qTotal = newQ;
+  _T = newT;
+  return UploadGaps();
+}
+
+Error HipEngine::AddQsTs(int64_t nQuestions, CiAddQorTParam *pAqps, int64_t nTargets, CiAddQorTParam *pAtps) {
+  std::lock_guard<std::mutex> lk(_mu);
+  if (_mode != Mode::Maintenance) return WrongModeErr("add questions/targets");
+  if (nQuestions < 0 || nTargets < 0)
+    return Error::MakeP(ErrCode::NegativeCount, "count=" + std::to_string(std::min(nQuestions, nTargets)), "Counts must be non-negative.");
+  if ((nQuestions > 0 && !pAqps) || (nTargets > 0 && !pAtps)) return Error::Make(ErrCode::NullArgument, "Nullptr parameters array.");
+  if (_qFirst != 0 || _qTotal != _Q) return Error::MakeP(ErrCode::NotImplemented, "Feature=AddQsTs on a shard", "Not on a sharded engine.");
+  hipSetDevice(_device);
+  // CpuEngine::AddQsTsSpec, reference PqaCore/CpuEngine.cpp:468-575
+  const int64_t nQReuse = std::min<int64_t>(nQuestions, (int64_t)_questionGapList.size()), nQNew = nQuestions - nQReuse;
+  const int64_t nTReuse = std::min<int64_t>(nTargets, (int64_t)_targetGapList.size()), nTNew = nTargets - nTReuse;
+  const int64_t nQOld = _Q, nTOld = _T;
+  std::vector<int64_t> qIds, tIds;
+  std::vector<double> qInit, tInit;
+  for (int64_t i = 0; i < nQReuse; i++) {            // :476-482 gaps are reused LIFO
+    const int64_t curQ = _questionGapList.back();
+    _questionGapList.pop_back();
+    BitSet(_hQGap, curQ, false);
+    _pimQuestions.RenewComp(curQ);
+    pAqps[i]._index = curQ;
+  }
+  for (int64_t i = 0; i < nTReuse; i++) {            // :488-493
+    const int64_t curT = _targetGapList.back();
+    _targetGapList.pop_back();
+    BitSet(_hTGap, curT, false);
+    _nTargetGaps--;
+    _pimTargets.RenewComp(curT);
+    pAtps[i]._index = curT;
+  }
+  for (int64_t i = 0; i < nQNew; i++) pAqps[nQReuse + i]._index = nQOld + i;   // :500
+  // NOTE reference :516,:523,:529 index the target parameters with nQReuse + j; the evident intent nTReuse + j is used
+  for (int64_t j = 0; j < nTNew; j++) pAtps[nTReuse + j]._index = nTOld + j;    // :531
+  Error e = ReallocKB(nQOld + nQNew, nTOld + nTNew);
+  if (!e.ok()) return e;
+  _pimQuestions.GrowTo(_Q);                           // :541-542
+  _pimTargets.GrowTo(_T);
+  // initial amounts: whole questions first, then target columns over the questions not (re)initialised just now
+  std::vector<uint32_t> skip(BitWords(_Q), 0);
+  for (int64_t i = 0; i < nQuestions; i++) {
+    qIds.push_back(pAqps[i]._index);
+    qInit.push_back(pAqps[i]._initAmount);
+    if (i < nQReuse) BitSet(skip, pAqps[i]._index, true);    // :558-560 only reused questions are skipped
+  }
+  for (int64_t j = 0; j < nTargets; j++) { tIds.push_back(pAtps[j]._index); tInit.push_back(pAtps[j]._initAmount); }
+  int64_t *dQ = nullptr, *dT = nullptr;
+  double *dQi = nullptr, *dTi = nullptr;
+  uint32_t *dSkip = nullptr;
+  hipError_t he = Upload(&dQ, qIds, _stream);
+  if (he == hipSuccess) he = Upload(&dQi, qInit, _stream);
+  if (he == hipSuccess) he = Upload(&dT, tIds, _stream);
+  if (he == hipSuccess) he = Upload(&dTi, tInit, _stream);
+  if (he == hipSuccess) he = Upload(&dSkip, skip, _stream);
+  // new target columns apply to every old question (:512-527); reused target columns skip reused questions (:553-567).
+  // New questions are filled over ALL columns with their own amount (:497-510), so they are filled last.
+  if (he == hipSuccess && nTReuse > 0) he = LaunchFillTargets(_dCube, _dVB, _K, _ldT, nQOld, dSkip, dT, dTi, nTReuse, _stream);
+  if (he == hipSuccess && nTNew > 0) he = LaunchFillTargets(_dCube, _dVB, _K, _ldT, nQOld, nullptr, dT + nTReuse, dTi + nTReuse, nTNew, _stream);
+  if (he == hipSuccess && nQuestions > 0) he = LaunchFillQuestions(_dCube, _K, _T, _ldT, dQ, dQi, nQuestions, _stream);
+  if (he == hipSuccess) he = hipStreamSynchronize(_stream);
+  hipFree(dQ); hipFree(dQi); hipFree(dT); hipFree(dTi); hipFree(dSkip);
+  if (he != hipSuccess) return HipErr(he, "AddQsTs");
+  return UploadGaps();
+}
+
+Error HipEngine::RemoveQuestions(int64_t n, const int64_t *pQIds) {  // BaseEngine.cpp:722-743
+  std::lock_guard<std::mutex> lk(_mu);
+  if (_mode != Mode::Maintenance) return WrongModeErr("remove questions");
+  for (int64_t i = 0; i < n; i++) {
+    const int64_t iq = pQIds[i];
+    if (iq < 0 || iq >= _Q || BitTest(_hQGap, iq))
+      return Error::MakeP(ErrCode::AbsentId, "id=" + std::to_string(iq), "Question index is not in KB.");
+    BitSet(_hQGap, iq, true);
+    _questionGapList.push_back(iq);
+    _pimQuestions.RemoveComp(iq);
+  }
+  hipSetDevice(_device);
+  return UploadGaps();
+}
+
+Error HipEngine::RemoveTargets(int64_t n, const int64_t *pTIds) {  // BaseEngine.cpp:745-765
+  std::lock_guard<std::mutex> lk(_mu);
+  if (_mode != Mode::Maintenance) return WrongModeErr("remove targets");
+  for (int64_t i = 0; i < n; i++) {
+    const int64_t it = pTIds[i];
+    if (it < 0 || it >= _T || BitTest(_hTGap, it))
+      return Error::MakeP(ErrCode::AbsentId, "id=" + std::to_string(it), "Target index is not in KB (but rather at a gap).");
+    BitSet(_hTGap, it, true);
+    _targetGapList.push_back(it);
+    _nTargetGaps++;
+    _pimTargets.RemoveComp(it);
+  }
+  hipSetDevice(_device);
+  return UploadGaps();
+}
+
+Error HipEngine::Compact(int64_t *pnQuestions, const int64_t **ppOldQuestions, int64_t *pnTargets,
+                         const int64_t **ppOldTargets) {  // CpuEngine::CompactSpec, CpuEngine.cpp:577-658
+  std::lock_guard<std::mutex> lk(_mu);
+  if (_mode != Mode::Maintenance) return WrongModeErr("compact the KB");
+  if (!pnQuestions || !ppOldQuestions || !pnTargets || !ppOldTargets) return Error::Make(ErrCode::NullArgument, "Nullptr output.");
+  hipSetDevice(_device);
+  const int64_t nQ = _Q - (int64_t)_questionGapList.size(), nT = _T - (int64_t)_targetGapList.size();
+  int64_t *oldQ = (int64_t *)std::malloc(sizeof(int64_t) * (size_t)std::max<int64_t>(nQ, 1));
+  int64_t *oldT = (int64_t *)std::malloc(sizeof(int64_t) * (size_t)std::max<int64_t>(nT, 1));
+  // questions: a gap in the kept prefix takes the LAST surviving question (:586-601)
+  {
+    int64_t iFirst = 0, iLast = _Q - 1;
+    for (; iFirst <= iLast; iFirst++) {
+      if (!BitTest(_hQGap, iFirst)) { oldQ[iFirst] = iFirst; continue; }
+      while (BitTest(_hQGap, iLast) && iLast > iFirst) iLast--;
+      if (iFirst == iLast) break;
+      oldQ[iFirst] = iLast;
+      HIP_TRY(hipMemcpyAsync(_dCube + (size_t)iFirst * (_K + 1) * _ldT, _dCube + (size_t)iLast * (_K + 1) * _ldT,
+                             (size_t)(_K + 1) * _ldT * sizeof(double), hipMemcpyDeviceToDevice, _stream));
+      iLast--;
+    }
+  }
+  // targets: gaps of the kept prefix (ascending) take the survivors of the dropped tail (ascending) -- the pairing the
+  // reference produces when no gap lies in the tail (:604-618); with tail gaps the reference's move table is
+  // under-filled, here the pairing simply continues.
+  std::vector<int64_t> moves;
+  {
+    std::vector<int64_t> dst, src;
+    for (int64_t t = 0; t < nT; t++) if (BitTest(_hTGap, t)) dst.push_back(t); else oldT[t] = t;
+    for (int64_t t = nT; t < _T; t++) if (!BitTest(_hTGap, t)) src.push_back(t);
+    for (size_t i = 0; i < dst.size(); i++) { oldT[dst[i]] = src[i]; moves.push_back(src[i]); moves.push_back(dst[i]); }
+  }
+  int64_t *dMoves = nullptr;
+  hipError_t he = Upload(&dMoves, moves, _stream);
+  if (he == hipSuccess) he = LaunchMoveTargets(_dCube, _dVB, _K, _ldT, nQ, dMoves, (int64_t)moves.size() / 2, _stream);
+  if (he == hipSuccess) he = hipStreamSynchronize(_stream);
+  hipFree(dMoves);
+  if (he != hipSuccess) { std::free(oldQ); std::free(oldT); return HipErr(he, "Compact"); }
+  _pimQuestions.OnCompact(nQ, oldQ);
+  _pimTargets.OnCompact(nT, oldT);
+  _questionGapList.clear();
+  _targetGapList.clear();
+  _nTargetGaps = 0;
+  // shrink the logical dimensions; the allocation (capacity, ldT) stays, padding is re-flagged as gap
+  _hTGap.assign(BitWords(_ldT), 0);
+  _hQGap.assign(BitWords(nQ), 0);
+  for (int64_t t = nT; t < (int64_t)_hTGap.size() * 32; t++) BitSet(_hTGap, t, true);
+  for (int64_t q = nQ; q < (int64_t)_hQGap.size() * 32; q++) BitSet(_hQGap, q, true);
+  hipFree(_dQGap); _dQGap = nullptr;
+  HIP_TRY(hipMalloc(&_dQGap, _hQGap.size() * sizeof(uint32_t)));
+  _Q = nQ; _qTotal = nQ; _T = nT;
+  *pnQuestions = nQ; *pnTargets = nT;
+  *ppOldQuestions = oldQ; *ppOldTargets = oldT;
+  return UploadGaps();
+}
+
+}  // namespace pqa

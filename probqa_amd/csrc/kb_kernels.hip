@@ -148,7 +148,73 @@ unsigned grid_for(int64_t n, int threads) {
   return (unsigned)b;
 }
 
+// ---- maintenance (reference PqaCore/CpuEngine.cpp:468-658) ---------------------------------------------------------
+// (Re)initialise whole questions: A = init^2, D = init^2 * K on real targets; padding columns A = 0, D = 1.
+__global__ __launch_bounds__(256) void fill_questions_kernel(double *__restrict__ cube, int64_t K, int64_t T, int64_t ldT,
+                                                             const int64_t *__restrict__ qs,
+                                                             const double *__restrict__ inits, int64_t n) {
+  const int64_t per = (K + 1) * ldT, total = n * per;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t iq = i / per, r = (i % per) / ldT, t = i % ldT;
+    const double initSqr = inits[iq] * inits[iq], initMD = initSqr * (double)K;  // :503-510 / :548-555
+    cube[qs[iq] * per + r * ldT + t] = (t < T) ? (r < K ? initSqr : initMD) : (r < K ? 0.0 : 1.0);
+  }
+}
+
+// (Re)initialise target columns over questions [0,nQ) except those flagged in skipQ (already initialised as questions).
+__global__ __launch_bounds__(256) void fill_targets_kernel(double *__restrict__ cube, double *__restrict__ vB, int64_t K,
+                                                           int64_t ldT, int64_t nQ, const uint32_t *__restrict__ skipQ,
+                                                           const int64_t *__restrict__ ts,
+                                                           const double *__restrict__ inits, int64_t n) {
+  const int64_t total = nQ * n;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t q = i / n, it = i % n;
+    if (q == 0) vB[ts[it]] = inits[it];                                          // :532 / :566
+    if (skipQ && bit_test(skipQ, q)) continue;                                   // :558-560
+    const double initSqr = inits[it] * inits[it], initMD = initSqr * (double)K;  // :517,:523 / :556-557
+    double *col = cube + q * (K + 1) * ldT + ts[it];
+    for (int64_t k = 0; k < K; k++) col[k * ldT] = initSqr;
+    col[K * ldT] = initMD;
+  }
+}
+
+// Compaction of the target axis (:619-647): column dst <- column src for every kept question and for vB.
+__global__ __launch_bounds__(256) void move_targets_kernel(double *__restrict__ cube, double *__restrict__ vB, int64_t K,
+                                                           int64_t ldT, int64_t nQ, const int64_t *__restrict__ moves,
+                                                           int64_t n) {
+  const int64_t rows = nQ * (K + 1) + 1, total = rows * n;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = i / n, m = i % n;
+    double *base = (row < nQ * (K + 1)) ? cube + row * ldT : vB;
+    base[moves[2 * m + 1]] = base[moves[2 * m]];  // (src, dst) pairs; sources are never destinations (:604-618)
+  }
+}
+
 }  // namespace
+
+hipError_t LaunchFillQuestions(double *cube, int64_t K, int64_t T, int64_t ldT, const int64_t *qs, const double *inits,
+                               int64_t n, hipStream_t stream) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(fill_questions_kernel, dim3(grid_for(n * (K + 1) * ldT, 256)), dim3(256), 0, stream, cube, K, T, ldT,
+                     qs, inits, n);
+  return hipGetLastError();
+}
+
+hipError_t LaunchFillTargets(double *cube, double *vB, int64_t K, int64_t ldT, int64_t nQ, const uint32_t *skipQ,
+                             const int64_t *ts, const double *inits, int64_t n, hipStream_t stream) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(fill_targets_kernel, dim3(grid_for(nQ * n, 256)), dim3(256), 0, stream, cube, vB, K, ldT, nQ, skipQ, ts,
+                     inits, n);
+  return hipGetLastError();
+}
+
+hipError_t LaunchMoveTargets(double *cube, double *vB, int64_t K, int64_t ldT, int64_t nQ, const int64_t *moves,
+                             int64_t n, hipStream_t stream) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(move_targets_kernel, dim3(grid_for((nQ * (K + 1) + 1) * n, 256)), dim3(256), 0, stream, cube, vB, K,
+                     ldT, nQ, moves, n);
+  return hipGetLastError();
+}
 
 hipError_t LaunchFillFresh(double *cube, double *vB, int64_t K, int64_t Q, int64_t T, int64_t ldT, double initAmount,
                            hipStream_t stream) {

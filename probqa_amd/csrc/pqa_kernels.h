@@ -77,6 +77,14 @@ hipError_t LaunchFillSynthetic(double *cube, double *vB, int64_t K, int64_t Q, i
 // Train / RecordQuizTarget (PqaCore/CETrainOperation.cpp:15-25): aqs device array of nAQs (q,a) pairs, distinct q.
 hipError_t LaunchTrain(double *cube, double *vB, int64_t K, int64_t ldT, const int64_t *aqs, int64_t nAQs,
                        int64_t iTarget, double amount, hipStream_t stream);
+// Maintenance (PqaCore/CpuEngine.cpp:468-658): (re)initialise whole questions / whole target columns; compact the target
+// axis with (src,dst) column moves.  qs/ts/inits/moves are device arrays.
+hipError_t LaunchFillQuestions(double *cube, int64_t K, int64_t T, int64_t ldT, const int64_t *qs, const double *inits,
+                               int64_t n, hipStream_t stream);
+hipError_t LaunchFillTargets(double *cube, double *vB, int64_t K, int64_t ldT, int64_t nQ, const uint32_t *skipQ,
+                             const int64_t *ts, const double *inits, int64_t n, hipStream_t stream);
+hipError_t LaunchMoveTargets(double *cube, double *vB, int64_t K, int64_t ldT, int64_t nQ, const int64_t *moves,
+                             int64_t n, hipStream_t stream);
 // ListTopTargets (PqaCore/CEListTopTargetsAlgorithm.cpp): top maxCount (prob,target) pairs, descending, gaps skipped.
 struct RatedTargetDev { int64_t iTarget; double prob; };
 hipError_t LaunchTopTargets(const KbView &kb, const double *prior, int64_t maxCount, RatedTargetDev *out,

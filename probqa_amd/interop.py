@@ -216,6 +216,27 @@ class EngineDimensions:
         return f"[nAnswers={self.n_answers}, nQuestions={self.n_questions}, nTargets={self.n_targets}]"
 
 
+INVALID_PQA_ID = -1
+
+
+class AddQuestionParam:  # reference ProbQA.py:381-387
+    def __init__(self, init_amount=1.0):
+        self.i_question = INVALID_PQA_ID
+        self.init_amount = init_amount
+
+    def __repr__(self):
+        return "[i_question=%d, init_amount=%f]" % (self.i_question, self.init_amount)
+
+
+class AddTargetParam:  # reference ProbQA.py:390-396
+    def __init__(self, init_amount=1.0):
+        self.i_target = INVALID_PQA_ID
+        self.init_amount = init_amount
+
+    def __repr__(self):
+        return "[i_target=%d, init_amount=%f]" % (self.i_target, self.init_amount)
+
+
 class PqaError:
     """Owns a native PqaError* (reference ProbQA.py:399-420)."""
 
@@ -369,6 +390,40 @@ class PqaEngine:
 
     def finish_maintenance(self, throw: bool = True):
         return _check(_lib.PqaEngine_FinishMaintenance(self.c_engine), throw)
+
+    def add_qs_ts(self, add_questions: List["AddQuestionParam"], add_targets: List["AddTargetParam"],
+                  throw: bool = True) -> Optional[PqaError]:
+        cq = (CiAddQorTParam * max(len(add_questions), 1))()
+        ct = (CiAddQorTParam * max(len(add_targets), 1))()
+        for i, p in enumerate(add_questions):
+            cq[i].index, cq[i].initAmount = p.i_question, p.init_amount
+        for i, p in enumerate(add_targets):
+            ct[i].index, ct[i].initAmount = p.i_target, p.init_amount
+        err = _check(_lib.PqaEngine_AddQsTs(self.c_engine, len(add_questions), cq, len(add_targets), ct), throw)
+        for i, p in enumerate(add_questions):
+            p.i_question = cq[i].index
+        for i, p in enumerate(add_targets):
+            p.i_target = ct[i].index
+        return err
+
+    def remove_questions(self, question_ids: List[int], throw: bool = True) -> Optional[PqaError]:
+        arr = (ctypes.c_int64 * max(len(question_ids), 1))(*question_ids)
+        return _check(_lib.PqaEngine_RemoveQuestions(self.c_engine, len(question_ids), arr), throw)
+
+    def remove_targets(self, target_ids: List[int], throw: bool = True) -> Optional[PqaError]:
+        arr = (ctypes.c_int64 * max(len(target_ids), 1))(*target_ids)
+        return _check(_lib.PqaEngine_RemoveTargets(self.c_engine, len(target_ids), arr), throw)
+
+    def compact(self) -> Tuple[List[int], List[int]]:
+        n_q, n_t = ctypes.c_int64(), ctypes.c_int64()
+        p_q, p_t = _pi64(), _pi64()
+        _check(_lib.PqaEngine_Compact(self.c_engine, ctypes.byref(n_q), ctypes.byref(p_q), ctypes.byref(n_t),
+                                      ctypes.byref(p_t)))
+        try:
+            return [p_q[i] for i in range(n_q.value)], [p_t[i] for i in range(n_t.value)]
+        finally:
+            _lib.CiReleaseCompaction(p_q)
+            _lib.CiReleaseCompaction(p_t)
 
     def shutdown(self, save_file_path: Optional[str] = None, throw: bool = True):
         p = save_file_path.encode() if save_file_path else None

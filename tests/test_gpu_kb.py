@@ -1,0 +1,191 @@
+"""The operations either side of the hot path that change or persist the device-resident knowledge base: .kb files,
+maintenance mode (AddQsTs / RemoveQuestions / RemoveTargets / Compact), permanent ids, quiz registry upkeep.
+Expected values come from a numpy model of the reference's behaviour (PqaCore/CpuEngine.cpp:468-658,
+PqaCore/BaseEngine.cpp:323-385,704-873) and from the reference's own test PqaCoreTests/Dimensions.cpp."""
+import struct
+import time
+
+import numpy as np
+import pytest
+
+import cases
+from probqa_amd import interop, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def make(factory, K, Q, T, init=0.1, seed=5):
+    eng, err = factory.create_cpu_engine(interop.EngineDefinition(K, Q, T, init_amount=init))
+    assert err is None, err
+    eng.set_option("workers", cases.WORKERS)
+    A, D, B = synth.synthetic_kb(K, Q, T, init, 8.0, 0.5, seed)
+    eng.set_kb(A, D, B)
+    return eng, A, D, B
+
+
+def test_kb_file_round_trip_and_layout(factory, tmp_path):
+    K, Q, T = 5, 23, 37
+    eng, A, D, B = make(factory, K, Q, T)
+    eng.set_target_gaps([4, 30])
+    eng.set_question_gaps([7])
+    quiz = eng.start_quiz()
+    for _ in range(3):
+        eng.next_question(quiz)
+    path = str(tmp_path / "kb.kb")
+    eng.save_kb(path, True)
+    raw = open(path, "rb").read()
+    # layout of reference BaseEngine.cpp:323-385: precision (8 B) | nAnswers nQuestions nTargets | nQuestionsAsked | rows
+    prec, nA, nQ, nT, asked = struct.unpack_from("<Qqqqq", raw, 0)
+    assert prec & 0xF == 3 and (nA, nQ, nT, asked) == (K, Q, T, 3)
+    off = 40
+    fa = np.frombuffer(raw, dtype="<f8", count=Q * K * T, offset=off).reshape(Q, K, T)
+    off += Q * K * T * 8
+    fd = np.frombuffer(raw, dtype="<f8", count=Q * T, offset=off).reshape(Q, T)
+    off += Q * T * 8
+    fb = np.frombuffer(raw, dtype="<f8", count=T, offset=off)
+    off += T * 8
+    assert np.array_equal(fa, A) and np.array_equal(fd, D) and np.array_equal(fb, B)
+    (nqg,) = struct.unpack_from("<q", raw, off)
+    qg = struct.unpack_from("<%dq" % nqg, raw, off + 8)
+    off += 8 + 8 * nqg
+    (ntg,) = struct.unpack_from("<q", raw, off)
+    tg = struct.unpack_from("<%dq" % ntg, raw, off + 8)
+    off += 8 + 8 * ntg
+    assert qg == (7,) and tg == (4, 30)
+    # three PermanentIdManager blobs: nextPermId, nComp, comp2perm[nComp]; quizzes are saved empty
+    for expect_n in (Q, T, 0):
+        nxt, n = struct.unpack_from("<qq", raw, off)
+        assert n == expect_n
+        off += 16 + 8 * n
+    assert off == len(raw)
+
+    eng2, err = factory.load_cpu_engine(path)
+    assert err is None, err
+    d = eng2.copy_dims()
+    assert (d.n_answers, d.n_questions, d.n_targets) == (K, Q, T) and eng2.get_total_questions_asked() == 3
+    A2, D2, B2 = eng2.get_kb()
+    assert np.array_equal(A2, A) and np.array_equal(D2, D) and np.array_equal(B2, B)
+    eng2.set_option("workers", cases.WORKERS)
+    q1, q2 = eng.start_quiz(), eng2.start_quiz()
+    assert np.array_equal(eng.get_priors(q1), eng2.get_priors(q2))          # same gaps -> same priors
+    assert np.array_equal(eng.eval_priorities(q1), eng2.eval_priorities(q2))
+    assert eng2.question_perm_from_comp([6, 7, 8]) == [6, -1, 8] and eng2.target_comp_from_perm([4, 5]) == [-1, 5]
+    e, err = factory.load_cpu_engine(str(tmp_path / "missing.kb"))
+    assert e is None and "Cannot open file" in err.to_string(True)
+    open(str(tmp_path / "short.kb"), "wb").write(raw[:100])
+    e, err = factory.load_cpu_engine(str(tmp_path / "short.kb"))
+    assert e is None and "File operation failed" in err.to_string(True)
+    eng.close()
+    eng2.close()
+
+
+def test_dimensions_growth_like_reference_test(factory):
+    """PqaCoreTests/Dimensions.cpp:11-86, fewer rounds: dims grow by the requested amounts, fresh values everywhere."""
+    K, init = 3, 1.0
+    eng, err = factory.create_cpu_engine(interop.EngineDefinition(K, 1, 2, init_amount=init))
+    assert err is None
+    rng = np.random.default_rng(2)
+    nq, nt = 1, 2
+    for _ in range(25):
+        eng.start_maintenance(True)
+        aq = [interop.AddQuestionParam(init) for _ in range(int(rng.integers(0, 4)))]
+        at = [interop.AddTargetParam(init) for _ in range(int(rng.integers(0, 40)))]
+        eng.add_qs_ts(aq, at)
+        assert [p.i_question for p in aq] == list(range(nq, nq + len(aq)))   # :41-52 ids are appended
+        assert [p.i_target for p in at] == list(range(nt, nt + len(at)))
+        nq, nt = nq + len(aq), nt + len(at)
+        eng.finish_maintenance()
+        d = eng.copy_dims()
+        assert (d.n_answers, d.n_questions, d.n_targets) == (K, nq, nt)      # :54-58
+    A, D, B = eng.get_kb()
+    assert (A == init).all() and (D == K * init).all() and (B == init).all()  # :60-77 (init 1.0: init^2 == init)
+    quiz = eng.start_quiz()                                                   # :79-82
+    assert 0 <= eng.next_question(quiz) < nq
+    with pytest.raises(interop.PqaException, match="wrong mode"):
+        eng.add_qs_ts([interop.AddQuestionParam(1.0)], [])
+    eng.close()
+
+
+def test_add_remove_compact_against_numpy_model(factory):
+    K, Q, T = 4, 12, 19
+    eng, A, D, B = make(factory, K, Q, T, seed=9)
+    eng.start_maintenance(False)
+    eng.remove_questions([2, 9])
+    eng.remove_targets([0, 5, 18])
+    e = eng.remove_targets([5], throw=False)
+    assert "The ID is absent from KB" in e.to_string(True)
+    # AddQsTs reuses gaps LIFO (GapTracker.Acquire pops the back), then appends
+    aq = [interop.AddQuestionParam(0.5), interop.AddQuestionParam(0.25), interop.AddQuestionParam(2.0)]
+    at = [interop.AddTargetParam(0.3), interop.AddTargetParam(0.7)]
+    eng.add_qs_ts(aq, at)
+    assert [p.i_question for p in aq] == [9, 2, 12] and [p.i_target for p in at] == [18, 5]
+    A = np.concatenate([A, np.zeros((1, K, T))], axis=0)
+    D = np.concatenate([D, np.zeros((1, T))], axis=0)
+    for t, amount in ((18, 0.3), (5, 0.7)):          # reused target columns over the questions not re-initialised
+        A[:, :, t], D[:, t], B[t] = amount * amount, amount * amount * K, amount
+    for q, amount in ((9, 0.5), (2, 0.25), (12, 2.0)):  # whole questions, every column
+        A[q], D[q] = amount * amount, amount * amount * K
+    d = eng.copy_dims()
+    assert (d.n_questions, d.n_targets) == (13, 19)
+    A2, D2, B2 = eng.get_kb()
+    live_t = [t for t in range(T) if t != 0]
+    assert np.array_equal(A2[:, :, live_t], A[:, :, live_t]) and np.array_equal(D2[:, live_t], D[:, live_t])
+    assert np.array_equal(B2[live_t], B[live_t])
+    # permanent ids: re-used slots get NEW permanent ids, untouched ones keep theirs
+    assert eng.question_perm_from_comp([0, 2, 9, 12]) == [0, 13, 12, 14]
+    assert eng.target_perm_from_comp([0, 5, 18]) == [-1, 20, 19]
+    # compaction: question gaps take the last survivor, target gaps take the tail survivors (CpuEngine.cpp:577-658)
+    eng.remove_questions([3, 11])
+    old_q, old_t = eng.compact()
+    keep_q = [q for q in range(13) if q not in (3, 11)]
+    assert len(old_q) == 11 and sorted(old_q) == keep_q and old_q[3] == 12 and old_q[:3] == [0, 1, 2]
+    assert len(old_t) == 18 and old_t[0] == 18 and old_t[1:] == list(range(1, 18))
+    A3, D3, B3 = eng.get_kb()
+    assert np.array_equal(A3, A[old_q][:, :, old_t]) and np.array_equal(D3, D[old_q][:, old_t])
+    assert np.array_equal(B3, B[old_t])
+    assert eng.question_perm_from_comp([3]) == [14] and eng.question_comp_from_perm([14, 3]) == [3, -1]
+    eng.finish_maintenance()
+    # the compacted KB behaves like a KB created with those numbers
+    ref, *_ = make(factory, K, 11, 18)
+    ref.set_kb(A3, D3, B3)
+    q1, q2 = eng.start_quiz(), ref.start_quiz()
+    assert np.array_equal(eng.get_priors(q1), ref.get_priors(q2))
+    assert cases.rel_err(eng.eval_priorities(q1), ref.eval_priorities(q2)).max() < 1e-11
+    eng.close()
+    ref.close()
+
+
+def test_quiz_registry_upkeep(factory):
+    eng, *_ = make(factory, 3, 6, 8)
+    quizzes = [eng.start_quiz() for _ in range(5)]
+    assert quizzes == [0, 1, 2, 3, 4] and eng.quiz_perm_from_comp(quizzes) == quizzes
+    eng.release_quiz(1)
+    assert eng.start_quiz() == 1                       # slot re-used ...
+    assert eng.quiz_perm_from_comp([1]) == [5]         # ... under a new permanent id (BaseEngine.cpp:780-793)
+    assert eng.quiz_comp_from_perm([1, 5]) == [-1, 1]
+    assert eng.ensure_perm_quiz_greater(100) and not eng.ensure_perm_quiz_greater(50)
+    q = eng.start_quiz()
+    assert eng.quiz_perm_from_comp([q]) == [101]
+    assert eng.remap_quiz_perm_id(101, 77, throw=False) and eng.quiz_comp_from_perm([77]) == [q]
+    time.sleep(1.1)
+    eng.next_question(3)                                # refresh quiz 3: it becomes the youngest
+    eng.clear_old_quizzes(1, 1e9)                       # keep the single most recently used quiz
+    assert eng.quiz_comp_from_perm([3]) == [3] and eng.get_active_question_id(3) >= 0
+    with pytest.raises(interop.PqaException, match="absent"):
+        eng.next_question(0)
+    eng.clear_old_quizzes(5, 0.0)                       # everything older than 0 s goes (quiz 3 was used > 0 s ago?)
+    e = eng.clear_old_quizzes(-1, 1.0, throw=False)
+    assert "The count is negative" in e.to_string(True)
+    eng.close()
+
+
+def test_shutdown_saves(factory, tmp_path):
+    eng, A, D, B = make(factory, 3, 5, 6)
+    path = str(tmp_path / "final.kb")
+    eng.shutdown(path)
+    with pytest.raises(interop.PqaException, match="wrong mode"):
+        eng.start_quiz()
+    eng2, err = factory.load_cpu_engine(path)
+    assert err is None and np.array_equal(eng2.get_kb()[0], A)
+    eng.close()
+    eng2.close()
