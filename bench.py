@@ -25,6 +25,7 @@ sys.path.insert(0, ROOT)
 CONFIGS = {
     "S": dict(Q=1000, K=5, T=1000, name="1000Qx5Ax1000T"),
     "M": dict(Q=10000, K=5, T=10000, name="10000Qx5Ax10000T"),
+    "M8": dict(Q=8000, K=5, T=8000, name="8000Qx5Ax8000T"),
 }
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 SEED = 20260928
