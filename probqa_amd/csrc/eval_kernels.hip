@@ -169,12 +169,35 @@ __device__ __forceinline__ void pass2_pair(double2 lh, double2 id, double2 pr, d
 // ------------------------------------------------------------------------------------------------------------------
 // Register-resident sweep: WPQ waves per question, NP target pairs per lane.  Requires ldT <= 128*WPQ*NP.
 // PRLDS: keep the masked prior vector in LDS instead of registers (long rows: frees 4*NP VGPRs).
-// LDS (doubles): log2 table [1024] | W exchange [2][WPQ] | W_k [2][K] | partials [2][K+2][WPQ] | prior [ldT] if PRLDS
-//   partial rows: V_k (K rows), sum W_k*H_k (1 row), lack (1 row); the leading [2] alternates per question so that
-//   lane 0 can run the epilogue of question n while the other waves already fill the buffers of question n+1.
+//
+// The cube is consumed as ONE continuous stream of rows per workgroup -- mD(q), sA(q,0..K-1), mD(q'), sA(q',0) ... --
+// through a single row-sized register ring `ring`: the instant a lane has consumed its pair j of the current row it
+// re-issues the load of pair j of the NEXT row of the stream into the same registers, across answer and question
+// boundaries alike.  So a full row (16*NP*64*WPQ bytes) is always outstanding per workgroup while pass 2 runs, and the
+// memory pipe never idles at a row or question boundary.
+//
+// LDS (doubles): log2 table [1024] | W exchange [2][WPQ] | partials [2][K+2][WPQ] | pending [kPend][2K+3] |
+//                prior [ldT + 2] if PRLDS
+//   partial rows: V_k (K rows), sum W_k*H_k (1 row), lack (1 row); the leading [2] alternates per question.
+//   pending: per finished question W_k[K], V_k[K], sum WH, lack, question index.  The scalar epilogue (exp2, log,
+//   divisions: ~1 us of dependent fp64 code) is not run per question by one lane while 511 wait at the next barrier;
+//   finished questions queue up here and wave 0 runs up to kPend epilogues at once, one per lane.
 // ------------------------------------------------------------------------------------------------------------------
+constexpr int kPend = 32;
+
 __host__ __device__ constexpr size_t eval_lds_doubles(int wpq, int64_t K, bool prLds, int64_t ldT) {
-  return 1024 + 2 * (size_t)wpq + 2 * (size_t)K + 2 * (size_t)(K + 2) * wpq + (prLds ? (size_t)ldT + 2 : 0);
+  return 1024 + 2 * (size_t)wpq + 2 * (size_t)(K + 2) * wpq + (size_t)kPend * (2 * (size_t)K + 3) +
+         (prLds ? (size_t)ldT + 2 : 0);
+}
+
+// wave 0 only: one epilogue per lane over the queued questions
+__device__ __forceinline__ void flush_pending(const EvalArgs &a, const double *pend, int nPend, int lane) {
+  if (lane < nPend) {
+    const int64_t K = a.K;
+    const double *rec = pend + (size_t)lane * (2 * K + 3);
+    const int64_t q = reinterpret_cast<const int64_t *>(rec)[2 * K + 2];
+    store_priority(a.priority + (q - a.qFirst), eval_epilogue(rec, -rec[2 * K], rec + K, K, rec[2 * K + 1], a.nValidPlus1));  // :130
+  }
 }
 
 template <int WPQ, int NP, bool PRLDS>
@@ -185,10 +208,11 @@ __global__ __launch_bounds__(WPQ * 64) void eval_questions_f64(EvalArgs a) {
   const int64_t ldT = a.ldT, K = a.K;
   double *tbl = smem;
   double *redW = tbl + 1024;
-  double *wkAll = redW + 2 * WPQ;
-  double *partAll = wkAll + 2 * K;
-  double2 *prLds = reinterpret_cast<double2 *>(partAll + 2 * (K + 2) * WPQ);
+  double *partAll = redW + 2 * WPQ;
+  double *pend = partAll + 2 * (K + 2) * WPQ;
+  double2 *prLds = reinterpret_cast<double2 *>(pend + kPend * (2 * K + 3));
   const int nPart = (int)(K + 2);
+  const int recLen = (int)(2 * K + 3);
   const int tid = threadIdx.x, lane = tid % kWave, wave = tid / kWave;
   for (int i = tid; i < 1024; i += kThreads) tbl[i] = gLog2Table[i];
 
@@ -212,49 +236,63 @@ __global__ __launch_bounds__(WPQ * 64) void eval_questions_f64(EvalArgs a) {
   }
   // out-of-row lanes read the all-zero pair stored right after the row (their cube loads are clamped instead)
   if constexpr (PRLDS) { if (tid == 0) prLds[nPairs] = make_double2(0.0, 0.0); }
+
+  const int64_t qStride = (K + 1) * ldT;
+  auto next_valid = [&](int64_t q) {               // :54 gap / asked questions get priority 0 and leave the stream
+    while (q < a.qLimit && (bit_test(a.qgap, q) || bit_test(a.asked, q))) {
+      if (tid == 0) store_priority(a.priority + (q - a.qFirst), 0.0);
+      q += gridDim.x;
+    }
+    return q;
+  };
+  int64_t q = next_valid(a.qFirst + blockIdx.x);
+  double2 invD[NP], ring[NP];
+  if (q < a.qLimit) {                              // head of the stream: the first question's mD row
+    const double2 *rowD = reinterpret_cast<const double2 *>(a.cube + q * qStride + K * ldT);
+#pragma unroll
+    for (int j = 0; j < NP; j++) ring[j] = rowD[pidx[j]];
+  }
   __syncthreads();
 
-  int phase = 0, qpar = 0;
-  const int64_t qStride = (K + 1) * ldT;
-  for (int64_t q = a.qFirst + blockIdx.x; q < a.qLimit; q += gridDim.x) {
-    if (bit_test(a.qgap, q) || bit_test(a.asked, q)) {         // :54
-      if (tid == 0) store_priority(a.priority + (q - a.qFirst), 0.0);
-      continue;
-    }
+  int phase = 0, qpar = 0, nPend = 0;
+  while (q < a.qLimit) {
+    const int64_t qn = next_valid(q + gridDim.x);
     const double *qBase = a.cube + q * qStride;
-    const double2 *rowD = reinterpret_cast<const double2 *>(qBase + K * ldT);
-    const double2 *rowA = reinterpret_cast<const double2 *>(qBase);
-    double2 invD[NP], nxt[NP];
+    {
+      const double2 *rowA = reinterpret_cast<const double2 *>(qBase);
 #pragma unroll
-    for (int j = 0; j < NP; j++) invD[j] = rowD[pidx[j]];
-#pragma unroll
-    for (int j = 0; j < NP; j++) nxt[j] = rowA[pidx[j]];
-#pragma unroll
-    for (int j = 0; j < NP; j++) {
-      invD[j].x = ((gapBits >> (2 * j)) & 1) ? 0.0 : div_nr(1.0, invD[j].x);      // :74 andnot(gapMask, 1/D)
-      invD[j].y = ((gapBits >> (2 * j + 1)) & 1) ? 0.0 : div_nr(1.0, invD[j].y);
+      for (int j = 0; j < NP; j++) {
+        invD[j].x = ((gapBits >> (2 * j)) & 1) ? 0.0 : div_nr(1.0, ring[j].x);      // :74 andnot(gapMask, 1/D)
+        invD[j].y = ((gapBits >> (2 * j + 1)) & 1) ? 0.0 : div_nr(1.0, ring[j].y);
+        ring[j] = rowA[pidx[j]];
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
-    double *wk = wkAll + qpar * K;
     double *part = partAll + qpar * (nPart * WPQ);
+    double *rec = pend + nPend * recLen;
     double accL = 0, hW = 0;
     for (int64_t k = 0; k < K; k++) {
-      // ---- pass 1 (:66-87): likelihoods into registers, W_k (two Kahan chains per lane)
+      // ---- pass 1 (:66-87): likelihoods into registers, W_k; each consumed pair is refilled from the next stream row
       double2 lh[NP];
       double s0 = 0, s1 = 0;
+      // next row of the stream: the next answer, else the next question's mD row; at the very end of the stream every
+      // lane re-reads pair 0 of the current row instead (one cached line per wave) so that the refill stays
+      // unconditional -- a conditional refill makes the ring a phi and costs a full vmcnt(0) + 2*NP moves per row
+      const bool lastRow = k + 1 == K;
+      const bool more = !lastRow || qn < a.qLimit;
+      const int idxMask = more ? -1 : 0;
+      const double2 *rowN = reinterpret_cast<const double2 *>(lastRow ? a.cube + (more ? qn : q) * qStride + K * ldT
+                                                                      : qBase + (k + 1) * ldT);
 #pragma unroll
       for (int j = 0; j < NP; j++) {
         double2 pv;
         if constexpr (PRLDS) pv = prLds[min(tid + j * kThreads, nPairs)]; else pv = pr[j];
-        lh[j].x = (nxt[j].x * invD[j].x) * pv.x;               // :81-82 (gap lanes: invD = 0 and prior = 0)
-        lh[j].y = (nxt[j].y * invD[j].y) * pv.y;
+        lh[j].x = (ring[j].x * invD[j].x) * pv.x;              // :81-82 (gap lanes: invD = 0 and prior = 0)
+        lh[j].y = (ring[j].y * invD[j].y) * pv.y;
         s0 += lh[j].x;  // <= 2*NP terms per lane: plain sums, then the butterfly -- a 64*WPQ-leaf pairwise tree
         s1 += lh[j].y;
-      }
-      // prefetch the next answer's row while this one is reduced and log2'ed
-      if (k + 1 < K) {
-        const double2 *rowN = reinterpret_cast<const double2 *>(qBase + (k + 1) * ldT);
-#pragma unroll
-        for (int j = 0; j < NP; j++) nxt[j] = rowN[pidx[j]];
+        ring[j] = rowN[pidx[j] & idxMask];
+        __builtin_amdgcn_sched_barrier(0);
       }
       double Wk = wave_sum(s0 + s1);                           // :88
       if constexpr (WPQ > 1) {
@@ -279,7 +317,7 @@ __global__ __launch_bounds__(WPQ * 64) void eval_questions_f64(EvalArgs a) {
       }
       v = wave_sum(v);
       if (lane == 0) {
-        if (wave == 0) wk[k] = Wk;                             // :90
+        if (wave == 0) rec[k] = Wk;                            // :90
         part[k * WPQ + wave] = v;                              // :132
       }
     }
@@ -290,17 +328,21 @@ __global__ __launch_bounds__(WPQ * 64) void eval_questions_f64(EvalArgs a) {
       part[(K + 1) * WPQ + wave] = accL;
     }
     if constexpr (WPQ > 1) __syncthreads();
-    if (tid == 0) {
-      // combine the waves' partials in wave order into the first K+2 slots (row r starts at r*WPQ >= r: safe in place)
-      for (int r = 0; r < nPart; r++) {
+    if (wave == 0) {
+      // combine the waves' partials in wave order, one partial row per lane, and queue the question
+      for (int r = lane; r < nPart; r += kWave) {
         double acc = part[r * WPQ];
         for (int w2 = 1; w2 < WPQ; w2++) acc += part[r * WPQ + w2];
-        part[r] = acc;
+        rec[K + r] = acc;
       }
-      store_priority(a.priority + (q - a.qFirst), eval_epilogue(wk, -part[K], part, K, part[K + 1], a.nValidPlus1));  // :130
+      if (lane == 0) reinterpret_cast<int64_t *>(rec)[2 * K + 2] = q;
+      if (nPend + 1 == kPend) flush_pending(a, pend, kPend, lane);
     }
+    nPend = nPend + 1 == kPend ? 0 : nPend + 1;
     qpar ^= 1;
+    q = qn;
   }
+  if (wave == 0) flush_pending(a, pend, nPend, lane);
   fused_select(a, tbl);
 }
 
