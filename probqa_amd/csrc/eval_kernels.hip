@@ -155,12 +155,10 @@ __device__ __forceinline__ void pass2_pair(double2 lh, double2 id, double2 pr, d
   const double prod = l20 * l21;
   double r = __builtin_amdgcn_rcp(prod);
   r = fma(r, fma(-prod, r, 1.0), r);                           // one Newton step: 2^-48.8, below the sum's own rounding
-  // invD^2 is invariant over the answers: keep the compiler from hoisting 2*NP squares into registers for the whole
-  // question (an opaque move per element is cheaper than the occupancy they would cost)
-  double ix = id.x, iy = id.y;
-  asm volatile("" : "+v"(ix), "+v"(iy));
-  accL = fma(ix * ix, r * l21, accL);                          // :117 invD^2 / log2(p)
-  accL = fma(iy * iy, r * l20, accL);
+  // :117 invD^2 / log2(p), multiplied as (invD * (1/log2 p)) * invD: written as invD^2 * (...) the squares are invariant
+  // over the answers and the compiler hoists 2*NP of them into registers for the whole question
+  accL = fma(id.x * (r * l21), id.x, accL);
+  accL = fma(id.y * (r * l20), id.y, accL);
   const double d0 = p0 - pr.x, d1 = p1 - pr.y;                 // :119
   v = fma(d0, d0, v);                                          // :126-127
   v = fma(d1, d1, v);
@@ -220,16 +218,17 @@ __global__ __launch_bounds__(WPQ * 64) void eval_questions_f64(EvalArgs a) {
   // Per-lane constants of the sweep: masked priors and gap flags of the lane's targets.
   double2 pr[NPR];
   uint32_t gapBits = 0;  // bit 2j / 2j+1 : target pair j element 0 / 1 is a gap (or beyond the row)
-  int pidx[NP];
+  uint32_t poff[NP];     // byte offset of the lane's pair j within a row (see row_load)
 #pragma unroll
   for (int j = 0; j < NP; j++) {
     const int p = tid + j * kThreads;
     const bool inRow = p < nPairs;
-    pidx[j] = inRow ? p : (nPairs - 1);            // clamped: out-of-row lanes re-read the last pair and are masked
-    const int64_t t0 = 2 * (int64_t)pidx[j];
+    const int pc = inRow ? p : (nPairs - 1);       // clamped: out-of-row lanes re-read the last pair and are masked
+    poff[j] = (uint32_t)pc * 16u;
+    const int64_t t0 = 2 * (int64_t)pc;
     const bool g0 = !inRow || bit_test(a.tgap, t0), g1 = !inRow || bit_test(a.tgap, t0 + 1);
     gapBits |= (g0 ? 1u : 0u) << (2 * j) | (g1 ? 1u : 0u) << (2 * j + 1);
-    double2 pv = reinterpret_cast<const double2 *>(a.prior)[pidx[j]];
+    double2 pv = reinterpret_cast<const double2 *>(a.prior)[pc];
     pv.x = g0 ? 0.0 : pv.x;                        // :103 andnot(gapMask, prior)
     pv.y = g1 ? 0.0 : pv.y;
     if constexpr (PRLDS) { if (inRow) prLds[p] = pv; } else { pr[j] = pv; }
@@ -237,7 +236,7 @@ __global__ __launch_bounds__(WPQ * 64) void eval_questions_f64(EvalArgs a) {
   // out-of-row lanes read the all-zero pair stored right after the row (their cube loads are clamped instead)
   if constexpr (PRLDS) { if (tid == 0) prLds[nPairs] = make_double2(0.0, 0.0); }
 
-  const int64_t qStride = (K + 1) * ldT;
+  const int64_t qStride = (K + 1) * ldT, rowBytes = ldT * 8;
   auto next_valid = [&](int64_t q) {               // :54 gap / asked questions get priority 0 and leave the stream
     while (q < a.qLimit && (bit_test(a.qgap, q) || bit_test(a.asked, q))) {
       if (tid == 0) store_priority(a.priority + (q - a.qFirst), 0.0);
@@ -248,9 +247,9 @@ __global__ __launch_bounds__(WPQ * 64) void eval_questions_f64(EvalArgs a) {
   int64_t q = next_valid(a.qFirst + blockIdx.x);
   double2 invD[NP], ring[NP];
   if (q < a.qLimit) {                              // head of the stream: the first question's mD row
-    const double2 *rowD = reinterpret_cast<const double2 *>(a.cube + q * qStride + K * ldT);
+    const RowRsrc rowD = row_rsrc(a.cube + q * qStride + K * ldT, rowBytes);
 #pragma unroll
-    for (int j = 0; j < NP; j++) ring[j] = rowD[pidx[j]];
+    for (int j = 0; j < NP; j++) ring[j] = row_load(rowD, poff[j]);
   }
   __syncthreads();
 
@@ -259,12 +258,12 @@ __global__ __launch_bounds__(WPQ * 64) void eval_questions_f64(EvalArgs a) {
     const int64_t qn = next_valid(q + gridDim.x);
     const double *qBase = a.cube + q * qStride;
     {
-      const double2 *rowA = reinterpret_cast<const double2 *>(qBase);
+      const RowRsrc rowA = row_rsrc(qBase, rowBytes);
 #pragma unroll
       for (int j = 0; j < NP; j++) {
         invD[j].x = ((gapBits >> (2 * j)) & 1) ? 0.0 : div_nr(1.0, ring[j].x);      // :74 andnot(gapMask, 1/D)
         invD[j].y = ((gapBits >> (2 * j + 1)) & 1) ? 0.0 : div_nr(1.0, ring[j].y);
-        ring[j] = rowA[pidx[j]];
+        ring[j] = row_load(rowA, poff[j]);
         __builtin_amdgcn_sched_barrier(0);
       }
     }
@@ -275,14 +274,12 @@ __global__ __launch_bounds__(WPQ * 64) void eval_questions_f64(EvalArgs a) {
       // ---- pass 1 (:66-87): likelihoods into registers, W_k; each consumed pair is refilled from the next stream row
       double2 lh[NP];
       double s0 = 0, s1 = 0;
-      // next row of the stream: the next answer, else the next question's mD row; at the very end of the stream every
-      // lane re-reads pair 0 of the current row instead (one cached line per wave) so that the refill stays
-      // unconditional -- a conditional refill makes the ring a phi and costs a full vmcnt(0) + 2*NP moves per row
+      // next row of the stream: the next answer, else the next question's mD row; at the very end of the stream the
+      // (cache-resident, row-sized) prior vector stands in, so that the refill stays unconditional -- a conditional
+      // refill makes the ring a phi and costs a full vmcnt(0) + 2*NP moves per row
       const bool lastRow = k + 1 == K;
-      const bool more = !lastRow || qn < a.qLimit;
-      const int idxMask = more ? -1 : 0;
-      const double2 *rowN = reinterpret_cast<const double2 *>(lastRow ? a.cube + (more ? qn : q) * qStride + K * ldT
-                                                                      : qBase + (k + 1) * ldT);
+      const RowRsrc rowN = row_rsrc(
+          !lastRow ? qBase + (k + 1) * ldT : qn < a.qLimit ? a.cube + qn * qStride + K * ldT : a.prior, rowBytes);
 #pragma unroll
       for (int j = 0; j < NP; j++) {
         double2 pv;
@@ -291,7 +288,7 @@ __global__ __launch_bounds__(WPQ * 64) void eval_questions_f64(EvalArgs a) {
         lh[j].y = (ring[j].y * invD[j].y) * pv.y;
         s0 += lh[j].x;  // <= 2*NP terms per lane: plain sums, then the butterfly -- a 64*WPQ-leaf pairwise tree
         s1 += lh[j].y;
-        ring[j] = rowN[pidx[j] & idxMask];
+        ring[j] = row_load(rowN, poff[j]);
         __builtin_amdgcn_sched_barrier(0);
       }
       double Wk = wave_sum(s0 + s1);                           // :88

@@ -5,9 +5,23 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+#include <utility>
+
 namespace pqa {
 
 constexpr int kWave = 64;  // CDNA wavefront
+
+// Compile-time unrolled loop: f(std::integral_constant<int, 0>) ... f(std::integral_constant<int, N-1>), for bodies that
+// need the index as a constant expression (immediate operands, static ring slots).
+template <typename F, int... I>
+__device__ __forceinline__ void static_for_impl(F &&f, std::integer_sequence<int, I...>) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F &&f) {
+  static_for_impl(static_cast<F &&>(f), std::make_integer_sequence<int, N>{});
+}
 constexpr uint64_t kExpMaskUp = 0x7FF0000000000000ULL;
 constexpr uint64_t kExp0Up = 0x3FF0000000000000ULL;
 
@@ -30,6 +44,20 @@ __device__ __forceinline__ double div_nr(double n, double d) {
   const double q0 = n * r;
   const double rem = fma(-d, q0, n);
   return fma(rem, r, q0);
+}
+
+// ---- row loads through a buffer resource ------------------------------------------------------------------------------
+// buffer_load_dwordx4 v, voffset, s[rsrc], 0 offen: address = row base (in the SGPR descriptor) + the lane's 32-bit byte
+// offset.  No per-load address arithmetic on the VALU (a flat/global load needs a 64-bit add per lane per load), and the
+// per-lane state is one VGPR per pair.  Reads beyond `bytes` return 0.
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+using RowRsrc = __amdgpu_buffer_rsrc_t;
+
+__device__ __forceinline__ RowRsrc row_rsrc(const void *row, int64_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(row), (short)0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ double2 row_load(RowRsrc rs, uint32_t byteOffset) {
+  return __builtin_bit_cast(double2, __builtin_amdgcn_raw_buffer_load_b128(rs, byteOffset, 0, 0));
 }
 
 // ---- SRVectMath::Log2Hot ---------------------------------------------------------------------------------------------
