@@ -55,7 +55,10 @@ constexpr unsigned kCounterShards = 16;  // one hot word serialises ~12 ns per a
 
 __device__ __forceinline__ void fused_select(const EvalArgs &a, double *ldsScratch) {
   if (a.fs.counter == nullptr) return;
-  __shared__ int sIsLast;
+  // (the flag lives in the dynamic segment: a static __shared__ would move the log2 table off LDS address 0 and cost
+  // every table lookup of the sweep an address add)
+  volatile int &sIsLast = *reinterpret_cast<volatile int *>(ldsScratch + 40);
+  __syncthreads();  // every wave is done with the table
   if (threadIdx.x == 0) {  // the same lane stored every priority of this workgroup
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const unsigned shard = blockIdx.x % kCounterShards;
@@ -144,21 +147,21 @@ __device__ __forceinline__ double eval_epilogue(const double *mW, double whSum, 
   return lack * v9 * (1.0 / (nExpectedTargets * nExpectedTargets));
 }
 
-// One element pair of pass 2 (:95-128).  lh: likelihoods, id: 1/D, pr: masked priors.  The two lack terms share one
-// reciprocal: 1/(a*b) by v_rcp_f64 + two Newton steps (error ~2^-96), then 1/a = b/(ab), 1/b = a/(ab).
+// One element pair of pass 2 (:95-128).  lh: likelihoods, id: 1/D, pr: masked priors.
 __device__ __forceinline__ void pass2_pair(double2 lh, double2 id, double2 pr, double invWk, const double *tbl,
                                            double &hW, double &v, double &accL) {
   const double p0 = lh.x * invWk, p1 = lh.y * invWk;           // :97
   const double l20 = log2hot(p0, tbl), l21 = log2hot(p1, tbl); // :106 (gap lanes: p = 0 -> -1023, contributes -0)
   hW = fma(lh.x, l20, hW);                                     // :113-114 weighted by W_k (see eval_epilogue)
   hW = fma(lh.y, l21, hW);
+  // :117 lack += invD^2 / log2(p) for both elements over one reciprocal: (ix^2*l21 + iy^2*l20) / (l20*l21), the
+  // reciprocal by v_rcp_f64 + one Newton step (2^-48.8, below the sum's own rounding).  The squares are written
+  // (ix*l)*ix: as ix^2*l they are invariant over the answers and the compiler hoists 2*NP of them into registers.
   const double prod = l20 * l21;
   double r = __builtin_amdgcn_rcp(prod);
-  r = fma(r, fma(-prod, r, 1.0), r);                           // one Newton step: 2^-48.8, below the sum's own rounding
-  // :117 invD^2 / log2(p), multiplied as (invD * (1/log2 p)) * invD: written as invD^2 * (...) the squares are invariant
-  // over the answers and the compiler hoists 2*NP of them into registers for the whole question
-  accL = fma(id.x * (r * l21), id.x, accL);
-  accL = fma(id.y * (r * l20), id.y, accL);
+  r = fma(r, fma(-prod, r, 1.0), r);
+  const double num = fma(id.y * l20, id.y, (id.x * l21) * id.x);
+  accL = fma(num, r, accL);
   const double d0 = p0 - pr.x, d1 = p1 - pr.y;                 // :119
   v = fma(d0, d0, v);                                          // :126-127
   v = fma(d1, d1, v);
@@ -205,6 +208,7 @@ __global__ __launch_bounds__(WPQ * 64) void eval_questions_f64(EvalArgs a) {
   extern __shared__ double smem[];
   const int64_t ldT = a.ldT, K = a.K;
   double *tbl = smem;
+  if (!lds_table_at_zero(tbl)) __builtin_trap();  // log2hot addresses the table absolutely
   double *redW = tbl + 1024;
   double *partAll = redW + 2 * WPQ;
   double *pend = partAll + 2 * (K + 2) * WPQ;
@@ -352,6 +356,7 @@ __global__ __launch_bounds__(256) void eval_questions_f64_stream(EvalArgs a) {
   extern __shared__ double smem[];
   const int64_t ldT = a.ldT, K = a.K;
   double *tbl = smem;
+  if (!lds_table_at_zero(tbl)) __builtin_trap();  // log2hot addresses the table absolutely
   double *redW = tbl + 1024;
   double *wkAll = redW + 2 * WPQ;
   double *partAll = wkAll + 2 * K;

@@ -60,6 +60,10 @@ __device__ __forceinline__ double2 row_load(RowRsrc rs, uint32_t byteOffset) {
   return __builtin_bit_cast(double2, __builtin_amdgcn_raw_buffer_load_b128(rs, byteOffset, 0, 0));
 }
 
+__device__ __forceinline__ bool lds_table_at_zero(const double *tbl) {
+  return (uint32_t)(uintptr_t)tbl == 0;
+}
+
 // ---- SRVectMath::Log2Hot ---------------------------------------------------------------------------------------------
 // The 1024-entry table (reference: SRPlatform/SRVectMath.cpp:30-44: log2 of the bucket midpoint, entry 0 scaled by
 // 9.9999999999999927e-01 so that log2(1) < 0) lives in eval_kernels.hip (gLog2Table); it is built on the host with
@@ -68,14 +72,20 @@ __device__ __forceinline__ double2 row_load(RowRsrc rs, uint32_t byteOffset) {
 // sequence operation for operation (exact quotient, the two explicit FMAs), bit-identical to the CPU for the same x.
 // tbl points at the LDS copy of the table.
 __device__ __forceinline__ double log2hot(double x, const double *__restrict__ tbl) {
-  const uint64_t ux = d2u(x);
-  const int32_t hi = (int32_t)(ux >> 32);
-  const uint64_t uz = (ux & ~kExpMaskUp) | kExp0Up;            // mantissa (and sign) with exponent 0: z in [1,2)
-  const double z = u2d(uz);
-  const int32_t e = (hi >> 20) - 1023;                         // arithmetic shift; x >= 0 assumed (:96-98)
-  const int32_t idx = (hi >> 10) & 1023;                       // top 10 mantissa bits (:101-102)
-  const double y = tbl[idx];
-  const double m = u2d((1ULL << 41) | (uz & ~((1ULL << 42) - 1)));  // bucket midpoint (:108)
+  // the bit surgery is done on the high word only (the low mantissa word passes through): 32-bit VALU ops, each a
+  // single and-or
+  const uint32_t lo = (uint32_t)d2u(x);
+  const uint32_t hi = (uint32_t)(d2u(x) >> 32);
+  const uint32_t zhi = (hi & 0x800FFFFFu) | 0x3FF00000u;       // mantissa (and sign) with exponent 0: z in [1,2)
+  const double z = u2d(((uint64_t)zhi << 32) | lo);
+  const int32_t e = ((int32_t)hi >> 20) - 1023;                // arithmetic shift; x >= 0 assumed (:96-98)
+  const uint32_t tblByte = (hi >> 7) & 0x1FF8u;                // top 10 mantissa bits (:101-102), times 8
+  // the table sits at LDS address 0 (first thing in the dynamic segment of kernels without static LDS; asserted by the
+  // kernels through lds_table_at_zero): the masked byte offset IS the ds_read address, no base add
+  (void)tbl;
+  const double y = *reinterpret_cast<const __attribute__((address_space(3))) double *>((uintptr_t)tblByte);
+  const uint32_t mhi = (zhi & 0xFFFFFC00u) | 0x200u;           // bucket midpoint (:108): low 42 bits <- 100...0
+  const double m = u2d((uint64_t)mhi << 32);
   const double t = div_nr(z - m, z + m);                       // :111-114; |z-m| < 2^-10, z+m in [2,4)
   const double t2 = t * t;
   const double t3 = t * t2;
