@@ -40,74 +40,96 @@ struct EvalArgs {
   FusedSelect fs;
 };
 
-// Fused argmax: the workgroup that finishes last (device-scope arrival counter) scans priority[] and publishes the
-// winner, so a selection is ONE launch and -- with out/seq in host-coherent memory -- needs no copy and no stream
-// synchronisation.  Inter-workgroup visibility follows the agent-scope release / acquire recipe of
-// cdna_hip_programming.md G16: plain stores -> barrier -> one-lane release fence + vmcnt(0) -> counter; the last
-// workgroup: one-lane acquire fence (invalidates this CU's L1) -> barrier -> plain loads.
-// Priorities are published with write-through (sc1) stores and read back with L1-bypassing (sc1) loads, the
-// fence-free hand-off form of cdna_hip_programming.md G16: payload sc1 -> s_waitcnt vmcnt(0) -> counter.
+// Fused argmax: a selection is ONE launch and -- with out/seq in host-coherent memory -- needs no copy and no stream
+// synchronisation.  Every workgroup keeps the best of its own questions in registers while it sweeps (maximum priority,
+// lowest index on ties, NaN never wins) and publishes ONE 16-byte record {priority, launch tag : index} with a single
+// write-through store.  There is no arrival counter: the epilogue wave of workgroup 0 is the finisher -- it polls the
+// tags of all records (one coalesced load per 64 workgroups) until every one carries this launch's tag, reduces the
+// records and publishes the winner.  After the last workgroup's store lands, the tail is one poll, one read of the
+// priorities and the write to the host: device-scope round trips (each ~1 us across the XCDs' L2s) are what the tail
+// of a 19 us kernel is made of, and a counter tree costs five of them in series.
+// Never a deadlock: only the finisher waits, and it waits for workgroups that need nothing from it.
+// Visibility: records are written with sc1 (write-through past the XCD's L2) and polled with sc1 loads; the two words
+// of a record are written by one 16-byte store and the priority word is read only after its tag has been seen.
 __device__ __forceinline__ void store_priority(double *p, double v) {
   __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-constexpr unsigned kCounterShards = 16;  // one hot word serialises ~12 ns per arrival; 1000 workgroups arrive together
+struct Best {
+  double p;
+  int64_t i;  // position in priority[], < 0: none
+};
 
-__device__ __forceinline__ void fused_select(const EvalArgs &a, double *ldsScratch) {
-  if (a.fs.counter == nullptr) return;
-  // (the flag lives in the dynamic segment: a static __shared__ would move the log2 table off LDS address 0 and cost
-  // every table lookup of the sweep an address add)
-  volatile int &sIsLast = *reinterpret_cast<volatile int *>(ldsScratch + 40);
-  __syncthreads();  // every wave is done with the table
-  if (threadIdx.x == 0) {  // the same lane stored every priority of this workgroup
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const unsigned shard = blockIdx.x % kCounterShards;
-    const unsigned expected = (gridDim.x - shard + kCounterShards - 1) / kCounterShards;
-    int last = 0;
-    if (__hip_atomic_fetch_add(a.fs.counter + shard, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == expected - 1) {
-      __hip_atomic_store(a.fs.counter + shard, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-arm
-      const unsigned nShards = gridDim.x < kCounterShards ? gridDim.x : kCounterShards;
-      unsigned *top = a.fs.counter + kCounterShards;
-      if (__hip_atomic_fetch_add(top, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nShards - 1) {
-        __hip_atomic_store(top, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        last = 1;
-      }
-    }
-    sIsLast = last;
-  }
-  __syncthreads();
-  if (!sIsLast) return;
-  const int64_t n = a.qLimit - a.qFirst;
-  double bp = 0;
-  int64_t bi = -1;
-  for (int64_t j = threadIdx.x; j < n; j += blockDim.x) {
-    const int64_t q = a.qFirst + j;
-    if (bit_test(a.qgap, q) || bit_test(a.asked, q)) continue;
-    double p = __hip_atomic_load(a.priority + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (p != p) p = -__builtin_huge_val();  // NaN never wins over a number
-    if (bi < 0 || p > bp) { bp = p; bi = j; }              // ascending j: ties keep the lowest index
-  }
+__device__ __forceinline__ void best_merge(Best &b, double op, int64_t oi) {
+  if (oi >= 0 && (b.i < 0 || op > b.p || (op == b.p && oi < b.i))) { b.p = op; b.i = oi; }
+}
+__device__ __forceinline__ void best_offer(Best &b, double p, int64_t i) {
+  best_merge(b, p != p ? -__builtin_huge_val() : p, i);   // NaN never wins over a number
+}
+__device__ __forceinline__ Best wave_best(Best b) {       // every lane ends up with the wave's best
 #pragma unroll
   for (int m = kWave / 2; m >= 1; m >>= 1) {
-    const double op = __shfl_xor(bp, m, kWave);
-    const int64_t oi = __shfl_xor(bi, m, kWave);
-    if (oi >= 0 && (bi < 0 || op > bp || (op == bp && oi < bi))) { bp = op; bi = oi; }
+    const double op = __shfl_xor(b.p, m, kWave);
+    const int64_t oi = __shfl_xor(b.i, m, kWave);
+    best_merge(b, op, oi);
   }
-  const int nw = blockDim.x / kWave;
-  int64_t *ldsIdx = reinterpret_cast<int64_t *>(ldsScratch + 16);
-  if (threadIdx.x % kWave == 0) {
-    ldsScratch[threadIdx.x / kWave] = bp;
-    ldsIdx[threadIdx.x / kWave] = bi;
+  return b;
+}
+
+constexpr int kPollUnroll = 4;  // records per lane and poll round kept in flight together
+
+// Called by every lane of ONE wave per workgroup (the wave that stored the workgroup's priorities) with the lanes'
+// running bests.  Record word 1: launch tag (low 32 bits of seqValue) << 32 | index (0xFFFFFFFF: none).
+__device__ __forceinline__ void fused_select(const EvalArgs &a, Best mine) {
+  if (a.fs.scratch == nullptr) return;
+  const int lane = threadIdx.x % kWave;
+  const Best wg = wave_best(mine);
+  const uint64_t tag = (uint64_t)(uint32_t)a.fs.seqValue << 32;
+  SelectResult *rec = a.fs.scratch;
+  if (lane == 0) {
+    typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+    const uint64_t w0 = d2u(wg.p), w1 = tag | (uint32_t)(wg.i < 0 ? 0xFFFFFFFFu : (uint32_t)wg.i);
+    const u4 v = {(unsigned)w0, (unsigned)(w0 >> 32), (unsigned)w1, (unsigned)(w1 >> 32)};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(rec + blockIdx.x), "v"(v) : "memory");
   }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    for (int w = 1; w < nw; w++) {
-      const double op = ldsScratch[w];
-      const int64_t oi = ldsIdx[w];
-      if (oi >= 0 && (bi < 0 || op > bp || (op == bp && oi < bi))) { bp = op; bi = oi; }
+  if (blockIdx.x != 0) return;
+  const unsigned grid = gridDim.x;
+  for (;;) {
+    bool all = true;
+    for (unsigned w0 = lane; w0 < grid && all; w0 += kWave * kPollUnroll) {
+      uint64_t t[kPollUnroll];
+#pragma unroll
+      for (int u = 0; u < kPollUnroll; u++) {
+        const unsigned w = w0 + u * kWave;
+        t[u] = w < grid ? (uint64_t)__hip_atomic_load(&rec[w].index, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : tag;
+      }
+#pragma unroll
+      for (int u = 0; u < kPollUnroll; u++) all = all && (t[u] >> 32) == (tag >> 32);
     }
-    a.fs.out->priority = bp;
-    a.fs.out->index = bi < 0 ? -1 : bi + a.fs.outBase;
+    if (__all(all)) break;
+    __builtin_amdgcn_s_sleep(2);
+  }
+  asm volatile("" ::: "memory");  // the priority words are read after their tags
+  Best b{0.0, -1};
+  for (unsigned w0 = lane; w0 < grid; w0 += kWave * kPollUnroll) {
+    double p[kPollUnroll];
+    uint64_t t[kPollUnroll];
+#pragma unroll
+    for (int u = 0; u < kPollUnroll; u++) {
+      const unsigned w = w0 + u * kWave < grid ? w0 + u * kWave : w0;
+      p[u] = __hip_atomic_load(&rec[w].priority, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      t[u] = (uint64_t)__hip_atomic_load(&rec[w].index, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+#pragma unroll
+    for (int u = 0; u < kPollUnroll; u++) {
+      const uint32_t idx = (uint32_t)t[u];
+      best_merge(b, p[u], idx == 0xFFFFFFFFu ? -1 : (int64_t)idx);
+    }
+  }
+  b = wave_best(b);
+  if (lane == 0) {
+    a.fs.out->priority = b.i < 0 ? 0.0 : b.p;
+    a.fs.out->index = b.i < 0 ? -1 : b.i + a.fs.outBase;
     if (a.fs.seq != nullptr) {
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");  // system scope: the record is visible to the host before the flag
       __hip_atomic_store(a.fs.seq, a.fs.seqValue, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -178,7 +200,7 @@ __device__ __forceinline__ void pass2_pair(double2 lh, double2 id, double2 pr, d
 // memory pipe never idles at a row or question boundary.
 //
 // LDS (doubles): log2 table [1024] | W exchange [2][WPQ] | partials [2][K+2][WPQ] | pending [kPend][2K+3] |
-//                prior [ldT + 2] if PRLDS
+//                running argmax [64][2] | prior [ldT + 2] if PRLDS
 //   partial rows: V_k (K rows), sum W_k*H_k (1 row), lack (1 row); the leading [2] alternates per question.
 //   pending: per finished question W_k[K], V_k[K], sum WH, lack, question index.  The scalar epilogue (exp2, log,
 //   divisions: ~1 us of dependent fp64 code) is not run per question by one lane while 511 wait at the next barrier;
@@ -187,17 +209,19 @@ __device__ __forceinline__ void pass2_pair(double2 lh, double2 id, double2 pr, d
 constexpr int kPend = 32;
 
 __host__ __device__ constexpr size_t eval_lds_doubles(int wpq, int64_t K, bool prLds, int64_t ldT) {
-  return 1024 + 2 * (size_t)wpq + 2 * (size_t)(K + 2) * wpq + (size_t)kPend * (2 * (size_t)K + 3) +
+  return 1024 + 2 * (size_t)wpq + 2 * (size_t)(K + 2) * wpq + (size_t)kPend * (2 * (size_t)K + 3) + 2 * kWave +
          (prLds ? (size_t)ldT + 2 : 0);
 }
 
-// wave 0 only: one epilogue per lane over the queued questions
-__device__ __forceinline__ void flush_pending(const EvalArgs &a, const double *pend, int nPend, int lane) {
+// epilogue wave only: one epilogue per lane over the queued questions; each lane keeps the best of its own
+__device__ __forceinline__ void flush_pending(const EvalArgs &a, const double *pend, int nPend, int lane, Best &best) {
   if (lane < nPend) {
     const int64_t K = a.K;
     const double *rec = pend + (size_t)lane * (2 * K + 3);
     const int64_t q = reinterpret_cast<const int64_t *>(rec)[2 * K + 2];
-    store_priority(a.priority + (q - a.qFirst), eval_epilogue(rec, -rec[2 * K], rec + K, K, rec[2 * K + 1], a.nValidPlus1));  // :130
+    const double pri = eval_epilogue(rec, -rec[2 * K], rec + K, K, rec[2 * K + 1], a.nValidPlus1);  // :130
+    store_priority(a.priority + (q - a.qFirst), pri);
+    best_offer(best, pri, q - a.qFirst);
   }
 }
 
@@ -212,7 +236,8 @@ __global__ __launch_bounds__(WPQ * 64) void eval_questions_f64(EvalArgs a) {
   double *redW = tbl + 1024;
   double *partAll = redW + 2 * WPQ;
   double *pend = partAll + 2 * (K + 2) * WPQ;
-  double2 *prLds = reinterpret_cast<double2 *>(pend + kPend * (2 * K + 3));
+  Best *bestLds = reinterpret_cast<Best *>(pend + kPend * (2 * K + 3));  // wave 0's per-lane running argmax
+  double2 *prLds = reinterpret_cast<double2 *>(bestLds + kWave);
   const int nPart = (int)(K + 2);
   const int recLen = (int)(2 * K + 3);
   const int tid = threadIdx.x, lane = tid % kWave, wave = tid / kWave;
@@ -258,6 +283,7 @@ __global__ __launch_bounds__(WPQ * 64) void eval_questions_f64(EvalArgs a) {
   __syncthreads();
 
   int phase = 0, qpar = 0, nPend = 0;
+  if (wave == 0) bestLds[lane] = Best{0.0, -1};   // only wave 0 ever touches these
   while (q < a.qLimit) {
     const int64_t qn = next_valid(q + gridDim.x);
     const double *qBase = a.cube + q * qStride;
@@ -318,7 +344,7 @@ __global__ __launch_bounds__(WPQ * 64) void eval_questions_f64(EvalArgs a) {
       }
       v = wave_sum(v);
       if (lane == 0) {
-        if (wave == 0) rec[k] = Wk;                            // :90
+        if (wave == 0) rec[k] = Wk;                           // :90
         part[k * WPQ + wave] = v;                              // :132
       }
     }
@@ -337,14 +363,16 @@ __global__ __launch_bounds__(WPQ * 64) void eval_questions_f64(EvalArgs a) {
         rec[K + r] = acc;
       }
       if (lane == 0) reinterpret_cast<int64_t *>(rec)[2 * K + 2] = q;
-      if (nPend + 1 == kPend) flush_pending(a, pend, kPend, lane);
+      if (nPend + 1 == kPend) flush_pending(a, pend, kPend, lane, bestLds[lane]);
     }
     nPend = nPend + 1 == kPend ? 0 : nPend + 1;
     qpar ^= 1;
     q = qn;
   }
-  if (wave == 0) flush_pending(a, pend, nPend, lane);
-  fused_select(a, tbl);
+  if (wave == 0) {
+    flush_pending(a, pend, nPend, lane, bestLds[lane]);
+    fused_select(a, bestLds[lane]);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -367,6 +395,7 @@ __global__ __launch_bounds__(256) void eval_questions_f64_stream(EvalArgs a) {
   const int64_t qStride = (K + 1) * ldT;
   const int64_t nPairs = ldT >> 1;
   int phase = 0, qpar = 0;
+  Best best{0.0, -1};
   for (int64_t q = a.qFirst + blockIdx.x; q < a.qLimit; q += gridDim.x) {
     if (bit_test(a.qgap, q) || bit_test(a.asked, q)) {
       if (tid == 0) store_priority(a.priority + (q - a.qFirst), 0.0);
@@ -440,11 +469,13 @@ __global__ __launch_bounds__(256) void eval_questions_f64_stream(EvalArgs a) {
         for (int w2 = 1; w2 < WPQ; w2++) acc += part[r * WPQ + w2];
         part[r] = acc;
       }
-      store_priority(a.priority + (q - a.qFirst), eval_epilogue(wk, -part[K], part, K, part[K + 1], a.nValidPlus1));
+      const double pri = eval_epilogue(wk, -part[K], part, K, part[K + 1], a.nValidPlus1);
+      store_priority(a.priority + (q - a.qFirst), pri);
+      best_offer(best, pri, q - a.qFirst);
     }
     qpar ^= 1;
   }
-  fused_select(a, tbl);
+  if (wave == 0) fused_select(a, best);   // lane 0 carries the workgroup's best, the other lanes none
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -498,7 +529,9 @@ hipError_t launch_reg(const EvalArgs &args, int64_t nQ, hipStream_t stream) {
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, kern, WPQ * 64, shmem) != hipSuccess || perCU < 1) perCU = 1;
   // one question per workgroup while they all fit on the chip at once; otherwise a resident grid that strides
   const int64_t resident = (int64_t)gNumCUs * perCU;
-  const unsigned grid = (unsigned)(nQ < resident ? nQ : resident);
+  int64_t resGrid = nQ < resident ? nQ : resident;
+  if (args.fs.scratch != nullptr && resGrid > kFusedMaxGrid) resGrid = kFusedMaxGrid;  // one winner record per workgroup
+  const unsigned grid = (unsigned)resGrid;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(WPQ * 64), shmem, stream, args);
   return hipGetLastError();
 }

@@ -161,8 +161,8 @@ Error HipEngine::Init(const CiEngineDefinition &def, const CiHipShard *shard) {
   HIP_TRY(hipMalloc(&_dStatus, 2 * sizeof(int64_t)));
   HIP_TRY(hipMalloc(&_dNOut, sizeof(int64_t)));
   HIP_TRY(hipMalloc(&_dSel, sizeof(SelectResult)));
-  HIP_TRY(hipMalloc(&_dCounter, 32 * sizeof(unsigned)));  // 16 arrival shards + the top-level word (eval_kernels.hip)
-  HIP_TRY(hipMemset(_dCounter, 0, 32 * sizeof(unsigned)));
+  HIP_TRY(hipMalloc(&_dSelScratch, kFusedMaxGrid * sizeof(SelectResult)));
+  HIP_TRY(hipMemset(_dSelScratch, 0, kFusedMaxGrid * sizeof(SelectResult)));  // tag 0 is never used by a launch
   HIP_TRY(hipHostMalloc(&_hPinned, sizeof(Pinned), hipHostMallocMapped | hipHostMallocCoherent));
   std::memset(_hPinned, 0, sizeof(Pinned));
   _hTGap.assign(BitWords(_ldT), 0);
@@ -189,7 +189,7 @@ HipEngine::~HipEngine() {
   if (_stream) hipStreamSynchronize(_stream);
   for (Quiz *q : _quizzes) if (q) DestroyQuiz(q);
   hipFree(_dCube); hipFree(_dVB); hipFree(_dPriority); hipFree(_dRunLength); hipFree(_dExps); hipFree(_dStatus);
-  hipFree(_dNOut); hipFree(_dSel); hipFree(_dCounter); hipFree(_dTGap); hipFree(_dQGap); hipFree(_dAqs); hipFree(_dTop);
+  hipFree(_dNOut); hipFree(_dSel); hipFree(_dSelScratch); hipFree(_dTGap); hipFree(_dQGap); hipFree(_dAqs); hipFree(_dTop);
   if (_hPinned) hipHostFree(_hPinned);
   if (_ownStream) hipStreamDestroy(_ownStream);
 }
@@ -449,7 +449,7 @@ Error HipEngine::EnqueueSelectArgmax(int64_t iQuiz, void *pOut) {
   Quiz *q = UseQuiz(err, iQuiz);
   if (!q) return err;
   // one launch: the sweep's last workgroup picks the argmax; reported index = local position + qFirst (GLOBAL id)
-  const FusedSelect fs{_dCounter, pOut ? (SelectResult *)pOut : _dSel, nullptr, 0, _qFirst};
+  const FusedSelect fs{_dSelScratch, pOut ? (SelectResult *)pOut : _dSel, nullptr, NextLaunchTag(), _qFirst};
   HIP_TRY(LaunchEvalQuestions(View(), q->dPrior, q->dAsked, 0, _Q, _dPriority, (int)_optEvalVariant, &fs, _stream));
   return Error();
 }
@@ -463,8 +463,8 @@ int64_t HipEngine::NextQuestionArgmax(Error &err, int64_t iQuiz) {
   hipSetDevice(_device);
   // One launch; the last workgroup writes the winner and then a sequence number straight into host-coherent pinned
   // memory, which this thread polls: no D2H copy, no stream synchronisation on the critical path.
-  const uint64_t seq = ++_selSeq;
-  const FusedSelect fs{_dCounter, &_hPinned->sel, &_hPinned->seq, seq, 0};
+  const uint64_t seq = NextLaunchTag();
+  const FusedSelect fs{_dSelScratch, &_hPinned->sel, &_hPinned->seq, seq, 0};
   hipError_t he = LaunchEvalQuestions(View(), q->dPrior, q->dAsked, 0, _Q, _dPriority, (int)_optEvalVariant, &fs, _stream);
   if (he != hipSuccess) { err = HipErr(he, "NextQuestionArgmax"); return -1; }
   volatile uint64_t *flag = &_hPinned->seq;

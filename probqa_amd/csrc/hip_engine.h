@@ -165,8 +165,14 @@ class HipEngine {
   int64_t _topCapacity = 0;
   SelectResult *_dSel = nullptr;
   struct Pinned { SelectResult sel; uint64_t seq; int64_t status[2]; int64_t nOut; };
-  unsigned *_dCounter = nullptr;   // arrival counter of the fused sweep+argmax launch
+  SelectResult *_dSelScratch = nullptr;  // its per-shard and per-workgroup winner records
   uint64_t _selSeq = 0;
+  // Tag of the next fused launch: consecutive launches differ in the low 32 bits, and those are never 0 (the state of
+  // freshly cleared records)
+  uint64_t NextLaunchTag() {
+    if ((uint32_t)++_selSeq == 0) ++_selSeq;
+    return _selSeq;
+  }
   Pinned *_hPinned = nullptr;
   std::vector<uint32_t> _hTGap, _hQGap;   // host mirrors; qgap over local questions, bits past size set
   int64_t _nTargetGaps = 0;

@@ -36,11 +36,12 @@ hipError_t UploadLog2Table(const double *hostTable);
 // ---- a1: priority sweep.  priority[q - qFirst] for q in [qFirst,qLimit); 0 for gap / asked questions.
 // Returns hipSuccess or the launch error.  `variant`: 0 = auto, otherwise forces a kernel shape (tests/bench).
 // `fused` (optional): let the sweep's last workgroup also pick the argmax, so that a selection is one launch.
+constexpr int kFusedMaxGrid = 4096;     // workgroups of a fused launch (one record each)
 struct FusedSelect {
-  unsigned *counter;      // device word, zero before the first launch; the kernel re-arms it
+  SelectResult *scratch;  // kFusedMaxGrid device records (16-byte aligned): the workgroups' winners, tagged per launch
   SelectResult *out;      // device or host-coherent memory; index = position in priority[] + outBase
   uint64_t *seq;          // optional host-coherent flag, set to seqValue after `out` is visible
-  uint64_t seqValue;
+  uint64_t seqValue;      // launch tag: its low 32 bits must differ from those of the previous fused launch on `scratch`
   int64_t outBase;
 };
 hipError_t LaunchEvalQuestions(const KbView &kb, const double *prior, const uint32_t *asked, int64_t qFirst,
