@@ -36,7 +36,8 @@ struct EvalArgs {
   const uint32_t *qgap;
   const uint32_t *asked;
   double *priority;
-  int64_t K, ldT, qFirst, qLimit, nValidPlus1;
+  int64_t K, ldT, qFirst, qLimit;
+  double vCompTail;  // ln(sqrt 2) / (nValidTargets + 1)^2, PqaCore/CEEvalQsSubtaskConsider.cpp:191
   FusedSelect fs;
 };
 
@@ -137,11 +138,53 @@ __device__ __forceinline__ void fused_select(const EvalArgs &a, Best mine) {
   }
 }
 
-// Reference epilogue, PqaCore/CEEvalQsSubtaskConsider.cpp:134-207.  mW / mV: per-answer weight and velocity^2;
+// Natural logarithm of a positive double for the epilogue: m in [sqrt(1/2), sqrt(2)), s = (m-1)/(m+1),
+// log x = e ln2 + 2s (1 + s^2/3 + ... + s^20/21), |error| < 2 ulp.  A third of the instructions (and of the dependent
+// latency) of the library routine, and none of its register footprint, which would cost the short-row sweep a wave of
+// occupancy; the reference's std::log (MSVC CRT) is not pinned by any of its tests either.
+__device__ __forceinline__ double log_pos(double x) {
+  if (!(x < __builtin_huge_val())) return x;                   // +inf, nan
+  int e = -1023;
+  if (x < 2.2250738585072014e-308) {                           // subnormal: rescale by 2^54
+    x *= 18014398509481984.0;
+    e -= 54;
+  }
+  const uint64_t ux = d2u(x);
+  e += (int)(ux >> 52);
+  double m = u2d((ux & 0x000FFFFFFFFFFFFFULL) | kExp0Up);
+  if (m > 1.4142135623730951) { m *= 0.5; e += 1; }
+  const double s = div_nr(m - 1.0, m + 1.0);
+  const double z = s * s;
+  double p = 1.0 / 21;
+  p = fma(p, z, 1.0 / 19);
+  p = fma(p, z, 1.0 / 17);
+  p = fma(p, z, 1.0 / 15);
+  p = fma(p, z, 1.0 / 13);
+  p = fma(p, z, 1.0 / 11);
+  p = fma(p, z, 1.0 / 9);
+  p = fma(p, z, 1.0 / 7);
+  p = fma(p, z, 1.0 / 5);
+  p = fma(p, z, 1.0 / 3);
+  const double s2 = s + s;
+  const double lm = fma(s2 * z, p, s2);
+  const double de = (double)e;
+  return fma(de, 6.93147180369123816490e-01, fma(de, 1.90821492927058770002e-10, lm));
+}
+
+// exact quotient (div_nr) when the divisor is an ordinary number, the hardware's IEEE sequence otherwise
+__device__ __forceinline__ double div_fast(double n, double d) {
+  const double ad = __builtin_fabs(d);
+  return (ad > 1e-290 && ad < 1e290) ? div_nr(n, d) : n / d;
+}
+
+// Reference epilogue, PqaCore/CEEvalQsSubtaskConsider.cpp:134-207.  mW: per-answer weights W_k; mWV: W_k * sqrt(V2_k)
+// (:156-157 / :165-167; the callers form these products, lane-parallel over k where they can);
 // whSum = sum_k W_k * H_k, which the sweep accumulates directly as -sum_{k,t} l_kt * log2(p_kt) (W_k * p_kt == l_kt up to
 // the rounding of p = l * (1/W_k)), so the per-answer entropies H_k are never materialised.
-__device__ __forceinline__ double eval_epilogue(const double *mW, double whSum, const double *mV, int64_t K,
-                                                double lackSum, int64_t nValidPlus1) {
+// vCompTail = ln(sqrt 2) / (nValidTargets + 1)^2 (:191), computed once on the host with the same two operations.
+// One lane runs this per question, so it is written for latency: exact-quotient divisions, the short logarithm above.
+__device__ __forceinline__ double eval_epilogue(const double *mW, double whSum, const double *mWV, int64_t K,
+                                                double lackSum, double vCompTail) {
   Kahan1 accTotW;
   accTotW.init(0.0);
   // 4-lane Kahan accumulator accAvgV (:140-172): answer k lands in lane k & 3, in k order.  A full vector Add (:158) and
@@ -150,23 +193,21 @@ __device__ __forceinline__ double eval_epilogue(const double *mW, double whSum, 
   for (int64_t k = 0; k < K; k++) {
     accTotW.add(mW[k]);                                        // :89
     const int c = (int)(k & 3);
-    const double wv = mW[k] * sqrt(mV[k]);                     // :156-157 / :165-167
-    const double y = wv - vC[c];
+    const double y = mWV[k] - vC[c];                           // :158 / :171
     const double t = vS[c] + y;
     vC[c] = (t - vS[c]) - y;
     vS[c] = t;
   }
   const double totW = accTotW.get();                           // :134
-  const double avgH = whSum / totW;                            // :175-177
-  const double avgV = precise_sum4(vS, vC) / totW;
+  const double avgH = div_fast(whSum, totW);                   // :175-177
+  const double avgV = div_fast(precise_sum4(vS, vC), totW);
   const double nExpectedTargets = exp2(avgH);                  // :181
   const double cLnMaxV = 0.34657359027997265470861606072909;   // SRMath::_cLnSqrt2
-  const double lnV = (avgV == 0) ? -746.0 : log(avgV);         // :29
-  const double nT = (double)nValidPlus1;
-  const double vComp = 1 / (cLnMaxV - lnV + cLnMaxV / (nT * nT));  // :30-32
+  const double lnV = (avgV == 0) ? -746.0 : log_pos(avgV);     // :29
+  const double vComp = div_fast(1.0, cLnMaxV - lnV + vCompTail);   // :30-32
   const double lack = -lackSum;                                // :201
   const double v2 = vComp * vComp, v4 = v2 * v2, v8 = v4 * v4, v9 = v8 * vComp;  // :207 with integer powers (:206)
-  return lack * v9 * (1.0 / (nExpectedTargets * nExpectedTargets));
+  return lack * v9 * div_fast(1.0, nExpectedTargets * nExpectedTargets);
 }
 
 // One element pair of pass 2 (:95-128).  lh: likelihoods, id: 1/D, pr: masked priors.
@@ -219,7 +260,7 @@ __device__ __forceinline__ void flush_pending(const EvalArgs &a, const double *p
     const int64_t K = a.K;
     const double *rec = pend + (size_t)lane * (2 * K + 3);
     const int64_t q = reinterpret_cast<const int64_t *>(rec)[2 * K + 2];
-    const double pri = eval_epilogue(rec, -rec[2 * K], rec + K, K, rec[2 * K + 1], a.nValidPlus1);  // :130
+    const double pri = eval_epilogue(rec, -rec[2 * K], rec + K, K, rec[2 * K + 1], a.vCompTail);  // :130
     store_priority(a.priority + (q - a.qFirst), pri);
     best_offer(best, pri, q - a.qFirst);
   }
@@ -360,6 +401,7 @@ __global__ __launch_bounds__(WPQ * 64) void eval_questions_f64(EvalArgs a) {
       for (int r = lane; r < nPart; r += kWave) {
         double acc = part[r * WPQ];
         for (int w2 = 1; w2 < WPQ; w2++) acc += part[r * WPQ + w2];
+        if (r < K) acc = rec[r] * sqrt(acc);                   // :156-157, one answer per lane
         rec[K + r] = acc;
       }
       if (lane == 0) reinterpret_cast<int64_t *>(rec)[2 * K + 2] = q;
@@ -467,9 +509,9 @@ __global__ __launch_bounds__(256) void eval_questions_f64_stream(EvalArgs a) {
       for (int r = 0; r < nPart; r++) {
         double acc = part[r * WPQ];
         for (int w2 = 1; w2 < WPQ; w2++) acc += part[r * WPQ + w2];
-        part[r] = acc;
+        part[r] = r < K ? wk[r] * sqrt(acc) : acc;
       }
-      const double pri = eval_epilogue(wk, -part[K], part, K, part[K + 1], a.nValidPlus1);
+      const double pri = eval_epilogue(wk, -part[K], part, K, part[K + 1], a.vCompTail);
       store_priority(a.priority + (q - a.qFirst), pri);
       best_offer(best, pri, q - a.qFirst);
     }
@@ -560,7 +602,8 @@ hipError_t LaunchEvalQuestions(const KbView &kb, const double *prior, const uint
   args.ldT = kb.ldT;
   args.qFirst = qFirst;
   args.qLimit = qLimit;
-  args.nValidPlus1 = kb.nValidTargets + 1;  // PqaCore/CEEvalQsSubtaskConsider.cpp:191
+  const double nT = (double)(kb.nValidTargets + 1);  // PqaCore/CEEvalQsSubtaskConsider.cpp:191
+  args.vCompTail = 0.34657359027997265470861606072909 / (nT * nT);
   args.fs = fused ? *fused : FusedSelect{nullptr, nullptr, nullptr, 0, 0};
   const int64_t nQ = qLimit - qFirst;
   const int v = pick_variant(kb.ldT, variant);
