@@ -190,8 +190,7 @@ static struct {
 } gPool = { PTHREAD_MUTEX_INITIALIZER, PTHREAD_COND_INITIALIZER, PTHREAD_COND_INITIALIZER, NULL, 0, NULL, 0, 0 };
 
 static void *pool_worker(void *arg) {
-  (void)arg;
-  uint64_t seen = 0;
+  uint64_t seen = (uint64_t)(uintptr_t)arg;              /* the generation at which this worker was spawned */
   pthread_mutex_lock(&gPool.mu);
   for (;;) {
     while (gPool.generation == seen) pthread_cond_wait(&gPool.cvWork, &gPool.mu);
@@ -205,16 +204,19 @@ static void *pool_worker(void *arg) {
   return NULL;
 }
 
+/* The pool only grows: a request for more threads than exist spawns the difference, a request for fewer uses them all
+ * (callers that compare pool sizes go from small to large). */
 static void pool_ensure(int64_t nThreads) {
-  if (gPool.nThreads == nThreads) return;
-  /* the pool only ever grows to the first requested size in a process; a different size restarts lazily */
-  if (gPool.nThreads != 0) return;
-  gPool.threads = (pthread_t *)malloc((size_t)nThreads * sizeof(pthread_t));
-  gPool.nThreads = nThreads;
-  for (int64_t i = 0; i < nThreads; i++) {
-    pthread_create(&gPool.threads[i], NULL, pool_worker, NULL);
-    pthread_detach(gPool.threads[i]);
+  pthread_mutex_lock(&gPool.mu);
+  if (nThreads > gPool.nThreads) {
+    gPool.threads = (pthread_t *)realloc(gPool.threads, (size_t)nThreads * sizeof(pthread_t));
+    for (int64_t i = gPool.nThreads; i < nThreads; i++) {
+      pthread_create(&gPool.threads[i], NULL, pool_worker, (void *)(uintptr_t)gPool.generation);
+      pthread_detach(gPool.threads[i]);
+    }
+    gPool.nThreads = nThreads;
   }
+  pthread_mutex_unlock(&gPool.mu);
 }
 
 void orc_eval_all_avx2_mt(const OrcKB *kb, const OrcQuiz *quiz, int64_t nThreads, int64_t nSubtasks,

@@ -95,7 +95,9 @@ __device__ __forceinline__ void fused_select(const EvalArgs &a, Best mine) {
   }
   if (blockIdx.x != 0) return;
   const unsigned grid = gridDim.x;
-  for (;;) {
+  // bounded (~20 s): a record can only stay stale if a workgroup of this launch died; then the host gets index -3
+  bool complete = false;
+  for (unsigned spin = 0; spin < (1u << 24); spin++) {
     bool all = true;
     for (unsigned w0 = lane; w0 < grid && all; w0 += kWave * kPollUnroll) {
       uint64_t t[kPollUnroll];
@@ -107,7 +109,7 @@ __device__ __forceinline__ void fused_select(const EvalArgs &a, Best mine) {
 #pragma unroll
       for (int u = 0; u < kPollUnroll; u++) all = all && (t[u] >> 32) == (tag >> 32);
     }
-    if (__all(all)) break;
+    if (__all(all)) { complete = true; break; }
     __builtin_amdgcn_s_sleep(2);
   }
   asm volatile("" ::: "memory");  // the priority words are read after their tags
@@ -130,7 +132,7 @@ __device__ __forceinline__ void fused_select(const EvalArgs &a, Best mine) {
   b = wave_best(b);
   if (lane == 0) {
     a.fs.out->priority = b.i < 0 ? 0.0 : b.p;
-    a.fs.out->index = b.i < 0 ? -1 : b.i + a.fs.outBase;
+    a.fs.out->index = !complete ? -3 : b.i < 0 ? -1 : b.i + a.fs.outBase;
     if (a.fs.seq != nullptr) {
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");  // system scope: the record is visible to the host before the flag
       __hip_atomic_store(a.fs.seq, a.fs.seqValue, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);

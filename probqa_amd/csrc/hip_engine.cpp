@@ -485,6 +485,10 @@ int64_t HipEngine::NextQuestionArgmax(Error &err, int64_t iQuiz) {
     }
   }
   std::atomic_thread_fence(std::memory_order_acquire);
+  if (_hPinned->sel.index == -3) {  // the sweep's finisher gave up: some workgroup of the launch never reported
+    err = HipErr(hipErrorLaunchFailure, "NextQuestionArgmax (incomplete sweep)");
+    return -1;
+  }
   return FinishSelection(err, q, _hPinned->sel.index);
 }
 

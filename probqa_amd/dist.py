@@ -35,18 +35,22 @@ def shard_range(n_questions: int, world_size: int, rank: int) -> Tuple[int, int]
     return (0 if rank == 0 else b[rank - 1]), b[rank]
 
 
-def pick_global(records: torch.Tensor) -> Tuple[float, int]:
-    """records: [world, 2] float64 rows (priority, index-as-bits).  Returns (priority, global question) of the
-    maximum priority, lowest index on ties, -1 if no shard had an eligible question.  NaN never wins."""
-    pri = records[:, 0].clone()
-    idx = records[:, 1].contiguous().view(torch.int64)
-    valid = idx >= 0
-    if not bool(valid.any()):
-        return float("nan"), -1
-    pri = torch.where(valid & ~torch.isnan(pri), pri, torch.full_like(pri, float("-inf")))
-    best = pri.max()
-    cand = torch.where((pri == best) & valid, idx, torch.full_like(idx, torch.iinfo(torch.int64).max))
-    return float(best), int(cand.min())
+def pick_global(records) -> Tuple[float, int]:
+    """records: [world, 2] float64 rows (priority, index-as-bits), a CPU tensor or numpy array.  Returns (priority,
+    global question) of the maximum priority, lowest index on ties, -1 if no shard had an eligible question.  NaN never
+    wins.  Plain Python over <= 8 records: this sits on the latency path of every selection."""
+    arr = records.numpy() if isinstance(records, torch.Tensor) else records
+    pris = arr[:, 0].tolist()
+    idxs = arr[:, 1].copy().view("<i8").tolist()
+    best_p, best_i = float("nan"), -1
+    for p, i in zip(pris, idxs):
+        if i < 0:
+            continue
+        if p != p:
+            p = float("-inf")
+        if best_i < 0 or p > best_p or (p == best_p and i < best_i):
+            best_p, best_i = p, i
+    return best_p, best_i
 
 
 class ShardedSelector:
@@ -65,6 +69,10 @@ class ShardedSelector:
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.local = torch.zeros(2, dtype=torch.float64, device=device)
         self.gathered = torch.zeros(self.world, 2, dtype=torch.float64, device=device)
+        on_gpu = device.type == "cuda"
+        # the gathered records land here: pinned, so the D2H copy is a single async DMA followed by one stream wait
+        self.host = torch.zeros(self.world, 2, dtype=torch.float64, pin_memory=on_gpu)
+        self._host_np = self.host.numpy()
 
     def enqueue(self) -> torch.Tensor:
         """Sweep + local argmax + all-gather, all stream-ordered; returns the [world,2] device tensor."""
@@ -77,7 +85,11 @@ class ShardedSelector:
 
     def select(self) -> Tuple[float, int]:
         recs = self.enqueue()
-        return pick_global(recs.cpu())
+        if recs.device.type == "cuda":
+            self.host.copy_(recs, non_blocking=True)
+            torch.cuda.current_stream(recs.device).synchronize()
+            return pick_global(self._host_np)
+        return pick_global(recs)
 
 
 def broadcast_prior(prior: torch.Tensor, owner_rank: int, group: Optional[dist.ProcessGroup] = None) -> None:
