@@ -23,10 +23,10 @@
 
 namespace pqa {
 
-static __device__ double gLog2Table[1024];
+static __device__ double gLog2Table[kLog2TableDoubles];  // {log2(midpoint), 1/(2*midpoint)} per bucket
 
 hipError_t UploadLog2Table(const double *hostTable) {
-  return hipMemcpyToSymbol(HIP_SYMBOL(gLog2Table), hostTable, 1024 * sizeof(double));
+  return hipMemcpyToSymbol(HIP_SYMBOL(gLog2Table), hostTable, kLog2TableDoubles * sizeof(double));
 }
 
 struct EvalArgs {
@@ -242,7 +242,7 @@ __device__ __forceinline__ void pass2_pair(double2 lh, double2 id, double2 pr, d
 // boundaries alike.  So a full row (16*NP*64*WPQ bytes) is always outstanding per workgroup while pass 2 runs, and the
 // memory pipe never idles at a row or question boundary.
 //
-// LDS (doubles): log2 table [1024] | W exchange [2][WPQ] | partials [2][K+2][WPQ] | pending [kPend][2K+3] |
+// LDS (doubles): log2 table [2048] | W exchange [2][WPQ] | partials [2][K+2][WPQ] | pending [kPend][2K+3] |
 //                running argmax [64][2] | prior [ldT + 2] if PRLDS
 //   partial rows: V_k (K rows), sum W_k*H_k (1 row), lack (1 row); the leading [2] alternates per question.
 //   pending: per finished question W_k[K], V_k[K], sum WH, lack, question index.  The scalar epilogue (exp2, log,
@@ -252,7 +252,7 @@ __device__ __forceinline__ void pass2_pair(double2 lh, double2 id, double2 pr, d
 constexpr int kPend = 32;
 
 __host__ __device__ constexpr size_t eval_lds_doubles(int wpq, int64_t K, bool prLds, int64_t ldT) {
-  return 1024 + 2 * (size_t)wpq + 2 * (size_t)(K + 2) * wpq + (size_t)kPend * (2 * (size_t)K + 3) + 2 * kWave +
+  return kLog2TableDoubles + 2 * (size_t)wpq + 2 * (size_t)(K + 2) * wpq + (size_t)kPend * (2 * (size_t)K + 3) + 2 * kWave +
          (prLds ? (size_t)ldT + 2 : 0);
 }
 
@@ -276,7 +276,7 @@ __global__ __launch_bounds__(WPQ * 64) void eval_questions_f64(EvalArgs a) {
   const int64_t ldT = a.ldT, K = a.K;
   double *tbl = smem;
   if (!lds_table_at_zero(tbl)) __builtin_trap();  // log2hot addresses the table absolutely
-  double *redW = tbl + 1024;
+  double *redW = tbl + kLog2TableDoubles;
   double *partAll = redW + 2 * WPQ;
   double *pend = partAll + 2 * (K + 2) * WPQ;
   Best *bestLds = reinterpret_cast<Best *>(pend + kPend * (2 * K + 3));  // wave 0's per-lane running argmax
@@ -284,7 +284,7 @@ __global__ __launch_bounds__(WPQ * 64) void eval_questions_f64(EvalArgs a) {
   const int nPart = (int)(K + 2);
   const int recLen = (int)(2 * K + 3);
   const int tid = threadIdx.x, lane = tid % kWave, wave = tid / kWave;
-  for (int i = tid; i < 1024; i += kThreads) tbl[i] = gLog2Table[i];
+  for (int i = tid; i < kLog2TableDoubles; i += kThreads) tbl[i] = gLog2Table[i];
 
   const int nPairs = (int)(ldT >> 1);
   // Per-lane constants of the sweep: masked priors and gap flags of the lane's targets.
@@ -429,12 +429,12 @@ __global__ __launch_bounds__(256) void eval_questions_f64_stream(EvalArgs a) {
   const int64_t ldT = a.ldT, K = a.K;
   double *tbl = smem;
   if (!lds_table_at_zero(tbl)) __builtin_trap();  // log2hot addresses the table absolutely
-  double *redW = tbl + 1024;
+  double *redW = tbl + kLog2TableDoubles;
   double *wkAll = redW + 2 * WPQ;
   double *partAll = wkAll + 2 * K;
   const int nPart = (int)(K + 2);
   const int tid = threadIdx.x, lane = tid % kWave, wave = tid / kWave;
-  for (int i = tid; i < 1024; i += kThreads) tbl[i] = gLog2Table[i];
+  for (int i = tid; i < kLog2TableDoubles; i += kThreads) tbl[i] = gLog2Table[i];
   __syncthreads();
   const int64_t qStride = (K + 1) * ldT;
   const int64_t nPairs = ldT >> 1;

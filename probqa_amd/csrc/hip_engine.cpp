@@ -138,12 +138,14 @@ Error HipEngine::Init(const CiEngineDefinition &def, const CiHipShard *shard) {
     hipError_t tblErr = hipSuccess;
     std::call_once(gTableOnce[_device & 63], [&] {
       // SRVectMath::Initialize, reference SRPlatform/SRVectMath.cpp:30-44
-      std::vector<double> tbl(1024);
+      // per bucket: log2 of the midpoint, and 1/(2*midpoint) for the division-free quotient of log2hot (pqa_device.h)
+      std::vector<double> tbl(2 * 1024);
       for (uint32_t i = 0; i < 1024; i++) {
         const uint64_t iZp = 0x3FF0000000000000ULL | ((uint64_t)i << 42) | (1ULL << 41);
         double zp;
         std::memcpy(&zp, &iZp, 8);
-        tbl[i] = std::log2(zp);
+        tbl[2 * i] = std::log2(zp);
+        tbl[2 * i + 1] = 1.0 / (2.0 * zp);
       }
       tbl[0] *= 9.9999999999999927e-01;
       tblErr = UploadLog2Table(tbl.data());

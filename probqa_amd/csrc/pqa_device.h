@@ -60,37 +60,48 @@ __device__ __forceinline__ double2 row_load(RowRsrc rs, uint32_t byteOffset) {
   return __builtin_bit_cast(double2, __builtin_amdgcn_raw_buffer_load_b128(rs, byteOffset, 0, 0));
 }
 
+// ---- SRVectMath::Log2Hot ---------------------------------------------------------------------------------------------
+// Reference: SRPlatform/Interface/SRVectMath.h:87-135 with the 1024-entry table of SRPlatform/SRVectMath.cpp:30-44 (log2 of
+// the bucket midpoint m, entry 0 scaled by 9.9999999999999927e-01 so that log2(1) < 0).  The table is built on the host
+// with std::log2 and uploaded once (UploadLog2Table), so the kernels see exactly the host libm's values, like the
+// reference's CPU code; each entry carries a second double, 1/(2m).
+// log2hot() follows the reference operation for operation -- exponent / mantissa split, bucket midpoint, t = (z-m)/(z+m),
+// the two explicit FMAs, + exponent -- except for how the quotient t is formed: the reference divides; here
+// z+m = 2m(1+u), u = (z-m)/(2m), so t = u/(1+u) = u - u^2 + u^3 - u^4 (+ u^5, |u| <= 2^-12: below 2^-60 of t).
+// That is 6 fp64 operations instead of a 37-cycle exact division.  |t| <= 2^-12, so t's error (2^-52.5 relative, from the
+// rounded 1/(2m)) reaches the result below 2^-63 absolute: the value is the reference's Log2Hot(x) except where that
+// perturbation crosses a rounding boundary of the final FMA (~0.1 % of arguments, by one ulp).  The priority vector is
+// compared at 1e-9 relative (measured 4e-14, set by the summation order -- DESIGN.md section 5), not bit for bit.
+// tbl: LDS copy of the table; it sits at LDS address 0 (first thing in the dynamic segment of kernels without static
+// LDS, checked by the kernels through lds_table_at_zero), so the masked byte offset IS the ds_read address.
+constexpr int kLog2TableDoubles = 2048;
+
 __device__ __forceinline__ bool lds_table_at_zero(const double *tbl) {
   return (uint32_t)(uintptr_t)tbl == 0;
 }
 
-// ---- SRVectMath::Log2Hot ---------------------------------------------------------------------------------------------
-// The 1024-entry table (reference: SRPlatform/SRVectMath.cpp:30-44: log2 of the bucket midpoint, entry 0 scaled by
-// 9.9999999999999927e-01 so that log2(1) < 0) lives in eval_kernels.hip (gLog2Table); it is built on the host with
-// std::log2 and uploaded once (UploadLog2Table), so the kernels see exactly the host libm's values, like the
-// reference's CPU code.  log2hot() below is SRPlatform/Interface/SRVectMath.h:87-135 for one lane: the reference's
-// sequence operation for operation (exact quotient, the two explicit FMAs), bit-identical to the CPU for the same x.
-// tbl points at the LDS copy of the table.
 __device__ __forceinline__ double log2hot(double x, const double *__restrict__ tbl) {
-  // the bit surgery is done on the high word only (the low mantissa word passes through): 32-bit VALU ops, each a
-  // single and-or
+  // the bit surgery is done on the high word only (the low mantissa word passes through)
   const uint32_t lo = (uint32_t)d2u(x);
   const uint32_t hi = (uint32_t)(d2u(x) >> 32);
   const uint32_t zhi = (hi & 0x800FFFFFu) | 0x3FF00000u;       // mantissa (and sign) with exponent 0: z in [1,2)
   const double z = u2d(((uint64_t)zhi << 32) | lo);
   const int32_t e = ((int32_t)hi >> 20) - 1023;                // arithmetic shift; x >= 0 assumed (:96-98)
-  const uint32_t tblByte = (hi >> 7) & 0x1FF8u;                // top 10 mantissa bits (:101-102), times 8
-  // the table sits at LDS address 0 (first thing in the dynamic segment of kernels without static LDS; asserted by the
-  // kernels through lds_table_at_zero): the masked byte offset IS the ds_read address, no base add
+  const uint32_t tblByte = (hi >> 6) & 0x3FF0u;                // top 10 mantissa bits (:101-102), times 16
   (void)tbl;
-  const double y = *reinterpret_cast<const __attribute__((address_space(3))) double *>((uintptr_t)tblByte);
+  typedef double f64x2_t __attribute__((ext_vector_type(2)));
+  const f64x2_t yc = *reinterpret_cast<const __attribute__((address_space(3))) f64x2_t *>((uintptr_t)tblByte);
   const uint32_t mhi = (zhi & 0xFFFFFC00u) | 0x200u;           // bucket midpoint (:108): low 42 bits <- 100...0
   const double m = u2d((uint64_t)mhi << 32);
-  const double t = div_nr(z - m, z + m);                       // :111-114; |z-m| < 2^-10, z+m in [2,4)
+  const double u = (z - m) * yc.y;                             // z - m is exact (same binade, |z-m| < 2^-10)
+  double s = 1.0 - u;
+  s = fma(-u, s, 1.0);
+  s = fma(-u, s, 1.0);
+  const double t = u * s;                                      // :111-114
   const double t2 = t * t;
   const double t3 = t * t2;
   const double terms01 = fma(1.0 / 3, t3, t);                  // :118
-  const double log2z = fma(terms01, 2.8853900817779268147198493620038, y);  // :122
+  const double log2z = fma(terms01, 2.8853900817779268147198493620038, yc.x);  // :122
   return log2z + (double)e;                                    // :131-133
 }
 
