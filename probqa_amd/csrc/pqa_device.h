@@ -86,7 +86,10 @@ __device__ __forceinline__ double log2hot(double x, const double *__restrict__ t
   const uint32_t hi = (uint32_t)(d2u(x) >> 32);
   const uint32_t zhi = (hi & 0x800FFFFFu) | 0x3FF00000u;       // mantissa (and sign) with exponent 0: z in [1,2)
   const double z = u2d(((uint64_t)zhi << 32) | lo);
-  const int32_t e = ((int32_t)hi >> 20) - 1023;                // arithmetic shift; x >= 0 assumed (:96-98)
+  // exponent as a double (:96-98, :131; x >= 0 assumed): (2^52 + E) - (2^52 + 1023) with E the biased exponent field
+  // planted in the low word of 2^52 -- exact, and an integer shift + one fp64 add instead of shift, add and a
+  // quarter-rate v_cvt_f64_i32
+  const double de = u2d(0x4330000000000000ULL | (uint64_t)(hi >> 20)) - 4503599627371519.0;
   const uint32_t tblByte = (hi >> 6) & 0x3FF0u;                // top 10 mantissa bits (:101-102), times 16
   (void)tbl;
   typedef double f64x2_t __attribute__((ext_vector_type(2)));
@@ -102,7 +105,7 @@ __device__ __forceinline__ double log2hot(double x, const double *__restrict__ t
   const double t3 = t * t2;
   const double terms01 = fma(1.0 / 3, t3, t);                  // :118
   const double log2z = fma(terms01, 2.8853900817779268147198493620038, yc.x);  // :122
-  return log2z + (double)e;                                    // :131-133
+  return log2z + de;                                           // :131-133
 }
 
 // ---- error-free transformation and compensated values ---------------------------------------------------------------
