@@ -59,6 +59,10 @@ PQACORE_API void *PqaEngine_EvalPriorities(void *pvEngine, const int64_t iQuiz, 
 PQACORE_API int64_t PqaEngine_NextQuestionArgmax(void *pvEngine, void **ppError, const int64_t iQuiz);
 PQACORE_API int64_t PqaEngine_NextQuestionSampled(void *pvEngine, void **ppError, const int64_t iQuiz,
                                                   const uint64_t rnd);
+/* pOut[i] = the device's Log2Hot(pIn[i]) (host buffers): the function the sweep applies to every posterior element
+ * (replaces SRVectMath::Log2Hot, reference SRPlatform/Interface/SRVectMath.h:87-135), exposed so that it can be held to
+ * the reference's own SRVectMathTest.Log2Hot criteria (SRPlatformTests/SRVectMathTest.cpp:45-103). */
+PQACORE_API void *PqaHip_Log2Hot(void *pvEngine, const double *pIn, double *pOut, const int64_t n);
 /* Current target probabilities of a quiz (n == nTargets). */
 PQACORE_API void *PqaHip_GetPriors(void *pvEngine, const int64_t iQuiz, double *pOut, const int64_t n);
 

@@ -346,6 +346,10 @@ PQACORE_API void *PqaHip_GetPriors(void *pvEngine, const int64_t iQuiz, double *
   GET_ENGINE_OR_RET_ERR;
   return ReturnErr(pEng->GetPriors(iQuiz, pOut, n));
 }
+PQACORE_API void *PqaHip_Log2Hot(void *pvEngine, const double *pIn, double *pOut, const int64_t n) {
+  GET_ENGINE_OR_RET_ERR;
+  return ReturnErr(pEng->Log2HotArray(pIn, pOut, n));
+}
 PQACORE_API void *PqaHip_GetStream(void *pvEngine) {
   GET_ENGINE_OR_LOG_ERR(nullptr);
   return pEng->GetStream();

@@ -523,6 +523,27 @@ __global__ __launch_bounds__(256) void eval_questions_f64_stream(EvalArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// log2hot() on an array, for the tests of the device function against the reference's SRVectMathTest.Log2Hot criteria
+// and against the oracle's operation-for-operation restatement (the sweep only ever shows it through priorities).
+// ------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void log2hot_array_kernel(const double *x, double *out, int64_t n) {
+  extern __shared__ double smem[];
+  double *tbl = smem;
+  if (!lds_table_at_zero(tbl)) __builtin_trap();
+  for (int i = threadIdx.x; i < kLog2TableDoubles; i += 256) tbl[i] = gLog2Table[i];
+  __syncthreads();
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) out[i] = log2hot(x[i], tbl);
+}
+
+hipError_t LaunchLog2HotArray(const double *x, double *out, int64_t n, hipStream_t stream) {
+  if (n <= 0) return hipSuccess;
+  const int64_t blocks = (n + 255) / 256;
+  hipLaunchKernelGGL(log2hot_array_kernel, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256),
+                     kLog2TableDoubles * sizeof(double), stream, x, out, n);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // launch
 // ------------------------------------------------------------------------------------------------------------------
 namespace {

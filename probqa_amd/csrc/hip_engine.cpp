@@ -148,6 +148,25 @@ Error HipEngine::Init(const CiEngineDefinition &def, const CiHipShard *shard) {
         tbl[2 * i + 1] = 1.0 / (2.0 * zp);
       }
       tbl[0] *= 9.9999999999999927e-01;
+      // The reference scales entry 0 so that Log2Hot(1) is (just) negative, -1.08e-19: lack = -sum invD^2 / log2(p)
+      // relies on the sign, and SRVectMathTest.Log2Hot asserts it.  The device forms the quotient of log2hot by a series
+      // instead of a division (pqa_device.h), which moves the value at 1 by a few 1e-18 -- across zero.  Re-seat entry
+      // 0 on the device's own arithmetic (the same IEEE operations, replayed here): the largest table value for which
+      // the device's Log2Hot(1) is negative.  Every other argument of bucket 0 moves by the same < 3e-18.
+      {
+        const double m = 1.0 + 0x1p-11, c = tbl[1];
+        const double u = (1.0 - m) * c;
+        double sr = 1.0 - u;
+        sr = std::fma(-u, sr, 1.0);
+        sr = std::fma(-u, sr, 1.0);
+        const double t = u * sr, t3 = t * (t * t);
+        const double terms01 = std::fma(1.0 / 3, t3, t);
+        auto at1 = [&](double y0) { return std::fma(terms01, 2.8853900817779268147198493620038, y0) + 0.0; };
+        double y0 = tbl[0];
+        while (at1(y0) >= 0) y0 = std::nextafter(y0, 0.0);
+        while (at1(std::nextafter(y0, 1.0)) < 0) y0 = std::nextafter(y0, 1.0);
+        tbl[0] = y0;
+      }
       tblErr = UploadLog2Table(tbl.data());
     });
     HIP_TRY(tblErr);
@@ -604,6 +623,24 @@ Error HipEngine::GetPriors(int64_t iQuiz, double *pOut, int64_t n) {
   hipSetDevice(_device);
   HIP_TRY(hipMemcpyAsync(pOut, q->dPrior, (size_t)_T * sizeof(double), hipMemcpyDeviceToHost, _stream));
   HIP_TRY(hipStreamSynchronize(_stream));
+  return Error();
+}
+
+Error HipEngine::Log2HotArray(const double *pIn, double *pOut, int64_t n) {
+  std::lock_guard<std::mutex> lk(_mu);
+  if (n < 0 || (n > 0 && (!pIn || !pOut))) return Error::Make(ErrCode::NullArgument, "Nullptr is passed in place of a Log2Hot buffer.");
+  if (n == 0) return Error();
+  hipSetDevice(_device);
+  double *dIn = nullptr, *dOut = nullptr;
+  HIP_TRY(hipMalloc(&dIn, (size_t)n * sizeof(double)));
+  hipError_t he = hipMalloc(&dOut, (size_t)n * sizeof(double));
+  if (he == hipSuccess) he = hipMemcpyAsync(dIn, pIn, (size_t)n * sizeof(double), hipMemcpyHostToDevice, _stream);
+  if (he == hipSuccess) he = LaunchLog2HotArray(dIn, dOut, n, _stream);
+  if (he == hipSuccess) he = hipMemcpyAsync(pOut, dOut, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, _stream);
+  if (he == hipSuccess) he = hipStreamSynchronize(_stream);
+  hipFree(dIn);
+  hipFree(dOut);
+  HIP_TRY(he);
   return Error();
 }
 

@@ -125,6 +125,7 @@ class HipEngine {
   int64_t NextQuestionArgmax(Error &err, int64_t iQuiz);
   int64_t NextQuestionSampled(Error &err, int64_t iQuiz, uint64_t rnd);
   Error GetPriors(int64_t iQuiz, double *pOut, int64_t n);
+  Error Log2HotArray(const double *pIn, double *pOut, int64_t n);  // device log2hot over an array (tests)
   hipStream_t GetStream() const { return _stream; }
   Error SetStream(hipStream_t s);
   Error Synchronize();

@@ -67,11 +67,12 @@ __device__ __forceinline__ double2 row_load(RowRsrc rs, uint32_t byteOffset) {
 // reference's CPU code; each entry carries a second double, 1/(2m).
 // log2hot() follows the reference operation for operation -- exponent / mantissa split, bucket midpoint, t = (z-m)/(z+m),
 // the two explicit FMAs, + exponent -- except for how the quotient t is formed: the reference divides; here
-// z+m = 2m(1+u), u = (z-m)/(2m), so t = u/(1+u) = u - u^2 + u^3 - u^4 (+ u^5, |u| <= 2^-12: below 2^-60 of t).
-// That is 6 fp64 operations instead of a 37-cycle exact division.  |t| <= 2^-12, so t's error (2^-52.5 relative, from the
-// rounded 1/(2m)) reaches the result below 2^-63 absolute: the value is the reference's Log2Hot(x) except where that
-// perturbation crosses a rounding boundary of the final FMA (~0.1 % of arguments, by one ulp).  The priority vector is
-// compared at 1e-9 relative (measured 4e-14, set by the summation order -- DESIGN.md section 5), not bit for bit.
+// z+m = 2m(1+u), u = (z-m)/(2m), so t = u/(1+u) = u - u^2 + u^3 - u^4 (next term u^5, |u| <= 2^-12: 2^-48 of t).
+// That is 6 fp64 operations instead of a 37-cycle exact division.  |t| <= 2^-12, so the truncation reaches the result
+// below 3e-18 absolute: the value is the reference's Log2Hot(x) except where that perturbation crosses a rounding
+// boundary of the last two operations (0.06 % of arguments, by one rounding unit; tools/log2hot_stats.py).  The host
+// re-seats table entry 0 so that Log2Hot(1) stays negative under this arithmetic (hip_engine.cpp).  The priority vector
+// is compared at 1e-9 relative (measured 4e-14, set by the summation order -- DESIGN.md section 5), not bit for bit.
 // tbl: LDS copy of the table; it sits at LDS address 0 (first thing in the dynamic segment of kernels without static
 // LDS, checked by the kernels through lds_table_at_zero), so the masked byte offset IS the ds_read address.
 constexpr int kLog2TableDoubles = 2048;

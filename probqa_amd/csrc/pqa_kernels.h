@@ -30,8 +30,10 @@ struct SelectResult {     // 16 bytes, written by the select kernels
   int64_t index;          // selected question (global index) or -1
 };
 
-// Upload the Log2Hot table (1024 doubles, built by the host) to the device; once per process and device.
+// Upload the Log2Hot table (1024 x {log2 midpoint, 1/(2 midpoint)}, built by the host); once per process and device.
 hipError_t UploadLog2Table(const double *hostTable);
+// out[i] = the device log2hot(x[i]) (device pointers); test hook for the function the sweep applies per element.
+hipError_t LaunchLog2HotArray(const double *x, double *out, int64_t n, hipStream_t stream);
 
 // ---- a1: priority sweep.  priority[q - qFirst] for q in [qFirst,qLimit); 0 for gap / asked questions.
 // Returns hipSuccess or the launch error.  `variant`: 0 = auto, otherwise forces a kernel shape (tests/bench).

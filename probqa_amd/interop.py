@@ -124,6 +124,7 @@ HIP_EXPORTS = {
     "PqaHip_SetQuestionGaps": (_vp, [_vp, _i64, _pi64]),
     "PqaEngine_EvalPriorities": (_vp, [_vp, _i64, _pdbl, _i64]),
     "PqaEngine_NextQuestionArgmax": (_i64, [_vp, _pvp, _i64]),
+    "PqaHip_Log2Hot": (_vp, [_vp, _pdbl, _pdbl, _i64]),
     "PqaEngine_NextQuestionSampled": (_i64, [_vp, _pvp, _i64, _u64]),
     "PqaHip_GetPriors": (_vp, [_vp, _i64, _pdbl, _i64]),
     "PqaHip_GetStream": (_vp, [_vp]),
@@ -477,6 +478,13 @@ class PqaEngine:
         q = _lib.PqaEngine_NextQuestionArgmax(self.c_engine, ctypes.byref(c_err), i_quiz)
         _check(c_err.value)
         return q
+
+    def log2hot(self, x: np.ndarray) -> np.ndarray:
+        """The device's Log2Hot over an array (the per-element function of the sweep)."""
+        xin = np.ascontiguousarray(x, dtype=np.float64)
+        out = np.empty_like(xin)
+        _check(_lib.PqaHip_Log2Hot(self.c_engine, _dptr(xin), _dptr(out), xin.size))
+        return out
 
     def next_question_sampled(self, i_quiz: int, rnd: int) -> int:
         c_err = ctypes.c_void_p()
