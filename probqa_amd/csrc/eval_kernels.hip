@@ -284,23 +284,53 @@ __global__ __launch_bounds__(WPQ * 64) void eval_questions_f64(EvalArgs a) {
   const int nPart = (int)(K + 2);
   const int recLen = (int)(2 * K + 3);
   const int tid = threadIdx.x, lane = tid % kWave, wave = tid / kWave;
-  for (int i = tid; i < kLog2TableDoubles; i += kThreads) tbl[i] = gLog2Table[i];
-
+  // ---- prologue.  Everything it needs from memory is independent of everything else, so all of it is requested
+  // before anything is used: one memory round trip instead of a dozen dependent ones (with one question per workgroup,
+  // as at 1000 x 1000, the prologue is on the critical path of the whole launch).  That includes the mD row of the first
+  // candidate question, requested before its gap / asked bits are known (a skipped candidate costs one wasted row).
   const int nPairs = (int)(ldT >> 1);
-  // Per-lane constants of the sweep: masked priors and gap flags of the lane's targets.
-  double2 pr[NPR];
-  uint32_t gapBits = 0;  // bit 2j / 2j+1 : target pair j element 0 / 1 is a gap (or beyond the row)
+  const int64_t qStride = (K + 1) * ldT, rowBytes = ldT * 8;
   uint32_t poff[NP];     // byte offset of the lane's pair j within a row (see row_load)
+  uint32_t gapWord[NP];
+  double2 pr[NPR], prRaw[NP];
+  double2 invD[NP], ring[NP];
+  const int64_t q0 = a.qFirst + blockIdx.x;
+  const bool haveQ0 = q0 < a.qLimit;
+  const int64_t q0c = haveQ0 ? q0 : a.qLimit - 1;  // (unconditional loads: a branch here would end the batch)
+  const uint32_t q0Gap = a.qgap[q0c >> 5], q0Asked = a.asked[q0c >> 5];
+#pragma unroll
+  for (int j = 0; j < NP; j++) {
+    const int p = tid + j * kThreads;
+    const int pc = p < nPairs ? p : (nPairs - 1);  // clamped: out-of-row lanes re-read the last pair and are masked
+    poff[j] = (uint32_t)pc * 16u;
+    gapWord[j] = a.tgap[pc >> 4];                  // both bits of the pair (targets 2pc, 2pc+1) sit in one word
+    prRaw[j] = reinterpret_cast<const double2 *>(a.prior)[pc];
+  }
+  if (haveQ0) {
+    const RowRsrc rowD = row_rsrc(a.cube + q0 * qStride + K * ldT, rowBytes);
+#pragma unroll
+    for (int j = 0; j < NP; j++) ring[j] = row_load(rowD, poff[j]);
+  }
+  {
+    static_assert((kLog2TableDoubles / 2) % kThreads == 0, "the table copy is an exact number of 16-byte loads per thread");
+    constexpr int kTblPerThread = kLog2TableDoubles / 2 / kThreads;
+    double2 tv[kTblPerThread];
+    const double2 *src = reinterpret_cast<const double2 *>(gLog2Table);
+#pragma unroll
+    for (int i = 0; i < kTblPerThread; i++) tv[i] = src[tid + i * kThreads];
+#pragma unroll
+    for (int i = 0; i < kTblPerThread; i++) reinterpret_cast<double2 *>(tbl)[tid + i * kThreads] = tv[i];
+  }
+  // Per-lane constants of the sweep: masked priors and gap flags of the lane's targets.
+  uint32_t gapBits = 0;  // bit 2j / 2j+1 : target pair j element 0 / 1 is a gap (or beyond the row)
 #pragma unroll
   for (int j = 0; j < NP; j++) {
     const int p = tid + j * kThreads;
     const bool inRow = p < nPairs;
-    const int pc = inRow ? p : (nPairs - 1);       // clamped: out-of-row lanes re-read the last pair and are masked
-    poff[j] = (uint32_t)pc * 16u;
-    const int64_t t0 = 2 * (int64_t)pc;
-    const bool g0 = !inRow || bit_test(a.tgap, t0), g1 = !inRow || bit_test(a.tgap, t0 + 1);
+    const int sh = (2 * (inRow ? p : nPairs - 1)) & 31;
+    const bool g0 = !inRow || ((gapWord[j] >> sh) & 1u), g1 = !inRow || ((gapWord[j] >> (sh + 1)) & 1u);
     gapBits |= (g0 ? 1u : 0u) << (2 * j) | (g1 ? 1u : 0u) << (2 * j + 1);
-    double2 pv = reinterpret_cast<const double2 *>(a.prior)[pc];
+    double2 pv = prRaw[j];
     pv.x = g0 ? 0.0 : pv.x;                        // :103 andnot(gapMask, prior)
     pv.y = g1 ? 0.0 : pv.y;
     if constexpr (PRLDS) { if (inRow) prLds[p] = pv; } else { pr[j] = pv; }
@@ -308,7 +338,6 @@ __global__ __launch_bounds__(WPQ * 64) void eval_questions_f64(EvalArgs a) {
   // out-of-row lanes read the all-zero pair stored right after the row (their cube loads are clamped instead)
   if constexpr (PRLDS) { if (tid == 0) prLds[nPairs] = make_double2(0.0, 0.0); }
 
-  const int64_t qStride = (K + 1) * ldT, rowBytes = ldT * 8;
   auto next_valid = [&](int64_t q) {               // :54 gap / asked questions get priority 0 and leave the stream
     while (q < a.qLimit && (bit_test(a.qgap, q) || bit_test(a.asked, q))) {
       if (tid == 0) store_priority(a.priority + (q - a.qFirst), 0.0);
@@ -316,12 +345,14 @@ __global__ __launch_bounds__(WPQ * 64) void eval_questions_f64(EvalArgs a) {
     }
     return q;
   };
-  int64_t q = next_valid(a.qFirst + blockIdx.x);
-  double2 invD[NP], ring[NP];
-  if (q < a.qLimit) {                              // head of the stream: the first question's mD row
-    const RowRsrc rowD = row_rsrc(a.cube + q * qStride + K * ldT, rowBytes);
+  int64_t q = q0;
+  if (haveQ0 && (((q0Gap | q0Asked) >> (q0 & 31)) & 1u)) {     // the first candidate is skipped: restart the stream
+    q = next_valid(q0);
+    if (q < a.qLimit) {
+      const RowRsrc rowD = row_rsrc(a.cube + q * qStride + K * ldT, rowBytes);
 #pragma unroll
-    for (int j = 0; j < NP; j++) ring[j] = row_load(rowD, poff[j]);
+      for (int j = 0; j < NP; j++) ring[j] = row_load(rowD, poff[j]);
+    }
   }
   __syncthreads();
 
