@@ -77,8 +77,6 @@ __device__ __forceinline__ Best wave_best(Best b) {       // every lane ends up 
   return b;
 }
 
-constexpr int kPollUnroll = 4;  // records per lane and poll round kept in flight together
-
 // Called by every lane of ONE wave per workgroup (the wave that stored the workgroup's priorities) with the lanes'
 // running bests.  Record word 1: launch tag (low 32 bits of seqValue) << 32 | index (0xFFFFFFFF: none).
 __device__ __forceinline__ void fused_select(const EvalArgs &a, Best mine) {
@@ -95,39 +93,45 @@ __device__ __forceinline__ void fused_select(const EvalArgs &a, Best mine) {
   }
   if (blockIdx.x != 0) return;
   const unsigned grid = gridDim.x;
+  // One poll = one round trip: each lane fetches its 16 records of a 1024-record chunk with 16-byte loads (tag and
+  // priority arrive together, consistent with the 16-byte store) that are all in flight at once.
   // bounded (~20 s): a record can only stay stale if a workgroup of this launch died; then the host gets index -3
-  bool complete = false;
-  for (unsigned spin = 0; spin < (1u << 24); spin++) {
-    bool all = true;
-    for (unsigned w0 = lane; w0 < grid && all; w0 += kWave * kPollUnroll) {
-      uint64_t t[kPollUnroll];
-#pragma unroll
-      for (int u = 0; u < kPollUnroll; u++) {
-        const unsigned w = w0 + u * kWave;
-        t[u] = w < grid ? (uint64_t)__hip_atomic_load(&rec[w].index, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : tag;
-      }
-#pragma unroll
-      for (int u = 0; u < kPollUnroll; u++) all = all && (t[u] >> 32) == (tag >> 32);
-    }
-    if (__all(all)) { complete = true; break; }
-    __builtin_amdgcn_s_sleep(2);
-  }
-  asm volatile("" ::: "memory");  // the priority words are read after their tags
+  typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+  bool complete = true;
   Best b{0.0, -1};
-  for (unsigned w0 = lane; w0 < grid; w0 += kWave * kPollUnroll) {
-    double p[kPollUnroll];
-    uint64_t t[kPollUnroll];
+  for (unsigned chunk = 0; chunk < grid && complete; chunk += 16 * kWave) {
+    const SelectResult *p0 = rec + chunk + lane, *p1 = p0 + 4 * kWave, *p2 = p0 + 8 * kWave, *p3 = p0 + 12 * kWave;
+    u4 r[16];
+    bool all = false;
+    for (unsigned spin = 0; spin < (1u << 24) && !all; spin++) {
+      asm volatile(
+          "global_load_dwordx4 %0, %16, off sc1\n\tglobal_load_dwordx4 %1, %16, off offset:1024 sc1\n\t"
+          "global_load_dwordx4 %2, %16, off offset:2048 sc1\n\tglobal_load_dwordx4 %3, %16, off offset:3072 sc1\n\t"
+          "global_load_dwordx4 %4, %17, off sc1\n\tglobal_load_dwordx4 %5, %17, off offset:1024 sc1\n\t"
+          "global_load_dwordx4 %6, %17, off offset:2048 sc1\n\tglobal_load_dwordx4 %7, %17, off offset:3072 sc1\n\t"
+          "global_load_dwordx4 %8, %18, off sc1\n\tglobal_load_dwordx4 %9, %18, off offset:1024 sc1\n\t"
+          "global_load_dwordx4 %10, %18, off offset:2048 sc1\n\tglobal_load_dwordx4 %11, %18, off offset:3072 sc1\n\t"
+          "global_load_dwordx4 %12, %19, off sc1\n\tglobal_load_dwordx4 %13, %19, off offset:1024 sc1\n\t"
+          "global_load_dwordx4 %14, %19, off offset:2048 sc1\n\tglobal_load_dwordx4 %15, %19, off offset:3072 sc1\n\t"
+          "s_waitcnt vmcnt(0)"
+          : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3]), "=&v"(r[4]), "=&v"(r[5]), "=&v"(r[6]), "=&v"(r[7]),
+            "=&v"(r[8]), "=&v"(r[9]), "=&v"(r[10]), "=&v"(r[11]), "=&v"(r[12]), "=&v"(r[13]), "=&v"(r[14]), "=&v"(r[15])
+          : "v"(p0), "v"(p1), "v"(p2), "v"(p3)
+          : "memory");
+      bool mine = true;
 #pragma unroll
-    for (int u = 0; u < kPollUnroll; u++) {
-      const unsigned w = w0 + u * kWave < grid ? w0 + u * kWave : w0;
-      p[u] = __hip_atomic_load(&rec[w].priority, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      t[u] = (uint64_t)__hip_atomic_load(&rec[w].index, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (int u = 0; u < 16; u++)
+        if (chunk + lane + u * kWave < grid) mine = mine && r[u][3] == (unsigned)(tag >> 32);
+      all = __all(mine);
+      if (!all) __builtin_amdgcn_s_sleep(2);
     }
+    complete = all;
 #pragma unroll
-    for (int u = 0; u < kPollUnroll; u++) {
-      const uint32_t idx = (uint32_t)t[u];
-      best_merge(b, p[u], idx == 0xFFFFFFFFu ? -1 : (int64_t)idx);
-    }
+    for (int u = 0; u < 16; u++)
+      if (chunk + lane + u * kWave < grid) {
+        const uint64_t pw = (uint64_t)r[u][0] | ((uint64_t)r[u][1] << 32);
+        best_merge(b, u2d(pw), r[u][2] == 0xFFFFFFFFu ? -1 : (int64_t)r[u][2]);
+      }
   }
   b = wave_best(b);
   if (lane == 0) {
