@@ -594,15 +594,26 @@ const Variant kVariants[] = {
     {4, 4, 8, false, "wg256_np8"},             {5, 8, 8, true, "wg512_np8_prlds"}, {6, 16, 5, true, "wg1024_np5_prlds"},
     {7, 16, 8, true, "wg1024_np8_prlds"},      {8, 2, 4, false, "wg128_np4"},   {9, 8, 5, false, "wg512_np5"},
     {10, 8, 10, true, "wg512_np10_prlds"},     {11, 16, 5, false, "wg1024_np5"}, {12, 8, 10, false, "wg512_np10"},
-    {99, 4, 0, false, "stream256"},
+    {13, 4, 3, false, "wg256_np3"},            {14, 4, 5, false, "wg256_np5"},  {15, 4, 6, false, "wg256_np6"},
+    {16, 8, 6, false, "wg512_np6"},            {17, 8, 7, false, "wg512_np7"},  {18, 8, 8, false, "wg512_np8"},
+    {19, 8, 9, false, "wg512_np9"},            {99, 4, 0, false, "stream256"},
 };
 
+// Default shape: the smallest capacity that holds a row (idle lanes are pure loss: at 8000 targets the np10 shape wastes a
+// fifth of its lanes), 256-thread workgroups up to 4096 targets (two workgroups per CU), 512 threads beyond.
 int pick_variant(int64_t ldT, int variant) {
   if (variant != 0) return variant;
   if (ldT <= 1024) return 2;
+  if (ldT <= 1536) return 13;
   if (ldT <= 2048) return 3;
+  if (ldT <= 2560) return 14;
+  if (ldT <= 3072) return 15;
   if (ldT <= 4096) return 4;
   if (ldT <= 5120) return 9;
+  if (ldT <= 6144) return 16;
+  if (ldT <= 7168) return 17;
+  if (ldT <= 8192) return 18;
+  if (ldT <= 9216) return 19;
   if (ldT <= 10240) return 12;
   if (ldT <= 16384) return 7;
   return 99;
@@ -682,6 +693,13 @@ hipError_t LaunchEvalQuestions(const KbView &kb, const double *prior, const uint
     case 10: return launch_reg<8, 10, true>(args, nQ, stream);
     case 11: return launch_reg<16, 5, false>(args, nQ, stream);
     case 12: return launch_reg<8, 10, false>(args, nQ, stream);
+    case 13: return launch_reg<4, 3, false>(args, nQ, stream);
+    case 14: return launch_reg<4, 5, false>(args, nQ, stream);
+    case 15: return launch_reg<4, 6, false>(args, nQ, stream);
+    case 16: return launch_reg<8, 6, false>(args, nQ, stream);
+    case 17: return launch_reg<8, 7, false>(args, nQ, stream);
+    case 18: return launch_reg<8, 8, false>(args, nQ, stream);
+    case 19: return launch_reg<8, 9, false>(args, nQ, stream);
     case 99: {
       const size_t shmem = eval_lds_doubles(4, args.K, false, 0) * sizeof(double);
       const int64_t maxBlocks = 256 * 8;
