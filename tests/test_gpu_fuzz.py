@@ -1,0 +1,38 @@
+"""Seeded random cases through the same script as the fixtures (tests/test_gpu_parity.py: run_script): random dimensions
+down to the reference's minimum (2 answers, 1 question, 2 targets), random target / question gaps, random answer scripts
+that follow the engine's own argmax questions.  Posteriors bit-exact, priorities within the stated tolerance, argmax and the
+reference's sampled selector identical -- on every step of every case."""
+import numpy as np
+import pytest
+
+import cases
+from test_gpu_parity import run_script
+
+pytestmark = pytest.mark.gpu
+
+
+def random_case(i):
+    rng = np.random.default_rng(1000 + i)
+    if i < 6:   # the corners first
+        K, Q, T = [(2, 1, 2), (2, 2, 3), (9, 1, 17), (2, 40, 2), (3, 5, 64), (6, 3, 257)][i]
+    else:
+        K, Q = int(rng.integers(2, 10)), int(rng.integers(1, 60))
+        T = int(rng.integers(2, 400)) if i % 4 else int(rng.integers(400, 3300))   # every 4th crosses kernel shapes
+    n_tg = int(rng.integers(0, max(1, T // 4))) if T > 3 else 0
+    n_qg = int(rng.integers(0, max(1, Q // 4))) if Q > 3 else 0
+    tgaps = sorted(rng.choice(T, n_tg, replace=False).tolist())
+    qgaps = sorted(rng.choice(Q, n_qg, replace=False).tolist())
+    free_q = [q for q in range(Q) if q not in qgaps]
+    n_ans = int(rng.integers(0, min(len(free_q), 5) + 1))
+    qs = rng.choice(free_q, n_ans, replace=False).tolist() if n_ans else []
+    answers = [(int(q), int(rng.integers(0, K))) for q in qs]
+    return cases.Case("fuzz%02d_%dx%dx%d" % (i, Q, K, T), K, Q, T, seed=2000 + i, init=float(rng.choice([0.1, 0.5, 1.0])),
+                      n_train=float(rng.choice([0.0, 2.0, 8.0])), noise=float(rng.choice([0.1, 0.5])),
+                      tgaps=tgaps, qgaps=qgaps, answers=answers)
+
+
+@pytest.mark.parametrize("i", range(120))
+def test_random_case(i, factory):
+    case = random_case(i)
+    worst = max(run_script(case, factory))
+    assert worst < 1e-9, (case.name, worst)
