@@ -189,3 +189,39 @@ def test_shutdown_saves(factory, tmp_path):
     assert err is None and np.array_equal(eng2.get_kb()[0], A)
     eng.close()
     eng2.close()
+
+
+def test_concurrent_quizzes_from_threads(factory):
+    """The engine is thread-safe across quizzes (reference IPqaEngine.h:44: no concurrent calls on the SAME quiz).  Eight
+    threads each drive their own quiz; every transcript must equal the one the same script produces alone."""
+    import threading
+
+    K, Q, T = 5, 60, 300
+    eng, *_ = make(factory, K, Q, T, seed=31)
+    eng.set_option("select", 1)
+
+    def script(seed, out):
+        rng = np.random.default_rng(seed)
+        quiz = eng.start_quiz()
+        log = []
+        for _ in range(12):
+            q = eng.next_question(quiz)
+            a = int(rng.integers(0, K))
+            eng.record_answer(quiz, a)
+            log.append((q, a, eng.list_top_targets(quiz, 3)[0].i_target))
+        log.append(eng.get_priors(quiz).tobytes())
+        eng.release_quiz(quiz)
+        out.append((seed, log))
+
+    alone = []
+    for seed in range(8):
+        script(seed, alone)
+    together, threads = [], []
+    for seed in range(8):
+        threads.append(threading.Thread(target=script, args=(seed, together)))
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert sorted(together) == sorted(alone)
+    eng.close()
