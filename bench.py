@@ -41,6 +41,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--config", choices=sorted(CONFIGS), default="S")
     ap.add_argument("--variant", type=int, default=0, help="force an eval kernel shape (0 = auto)")
+    ap.add_argument("--batch", type=int, default=64, help="quizzes per launch of the batched-selection extra (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=3.0, help="wall seconds of the CPU baseline leg")
     args = ap.parse_args()
@@ -146,6 +147,20 @@ def main():
     else:
         pipelined = None
 
+    # ---- extra (not `value`): many quizzes in flight, one launch per batch (PqaEngine_NextQuestionArgmaxBatch)
+    batched = None
+    if selector is None and args.batch > 0:
+        quizzes = [quiz] + [eng.start_quiz() for _ in range(args.batch - 1)]
+        reps = max(3, min(200, args.steps // args.batch))
+        for _ in range(2):
+            eng.next_question_argmax_batch(quizzes)
+        torch.cuda.synchronize()
+        tb0 = time.perf_counter()
+        for _ in range(reps):
+            picks = eng.next_question_argmax_batch(quizzes)
+        batched = {"quizzes_per_launch": args.batch, "selections_per_sec": reps * args.batch / (time.perf_counter() - tb0),
+                   "launches_timed": reps, "agrees_with_single": int(picks[0]) == int(sel)}
+
     out = {
         "metric": "next_question_selections_per_sec",
         "value": value,
@@ -169,6 +184,7 @@ def main():
         },
         "question_evals_per_sec": value * Q,
         "pipelined_selections_per_sec": pipelined,
+        "batched": batched,
         "roofline": {
             "bound": "hbm",
             "achieved": achieved,

@@ -59,6 +59,11 @@ PQACORE_API void *PqaEngine_EvalPriorities(void *pvEngine, const int64_t iQuiz, 
 PQACORE_API int64_t PqaEngine_NextQuestionArgmax(void *pvEngine, void **ppError, const int64_t iQuiz);
 PQACORE_API int64_t PqaEngine_NextQuestionSampled(void *pvEngine, void **ppError, const int64_t iQuiz,
                                                   const uint64_t rnd);
+/* NextQuestion (argmax selector) for nQuizzes <= 256 distinct quizzes with ONE launch: pQuestions[i] = the selected
+ * question of pQuizzes[i], -1 if that quiz has no question left.  What a server with many quizzes in flight calls instead
+ * of nQuizzes x PqaEngine_NextQuestion (reference PqaCore/CpuEngine.cpp:337-415 serves them one sweep at a time). */
+PQACORE_API void *PqaEngine_NextQuestionArgmaxBatch(void *pvEngine, const int64_t nQuizzes, const int64_t *pQuizzes,
+                                                    int64_t *pQuestions);
 /* pOut[i] = the device's Log2Hot(pIn[i]) (host buffers): the function the sweep applies to every posterior element
  * (replaces SRVectMath::Log2Hot, reference SRPlatform/Interface/SRVectMath.h:87-135), exposed so that it can be held to
  * the reference's own SRVectMathTest.Log2Hot criteria (SRPlatformTests/SRVectMathTest.cpp:45-103). */

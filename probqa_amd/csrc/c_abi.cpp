@@ -346,6 +346,11 @@ PQACORE_API void *PqaHip_GetPriors(void *pvEngine, const int64_t iQuiz, double *
   GET_ENGINE_OR_RET_ERR;
   return ReturnErr(pEng->GetPriors(iQuiz, pOut, n));
 }
+PQACORE_API void *PqaEngine_NextQuestionArgmaxBatch(void *pvEngine, const int64_t nQuizzes, const int64_t *pQuizzes,
+                                                    int64_t *pQuestions) {
+  GET_ENGINE_OR_RET_ERR;
+  return ReturnErr(pEng->NextQuestionArgmaxBatch(nQuizzes, pQuizzes, pQuestions));
+}
 PQACORE_API void *PqaHip_Log2Hot(void *pvEngine, const double *pIn, double *pOut, const int64_t n) {
   GET_ENGINE_OR_RET_ERR;
   return ReturnErr(pEng->Log2HotArray(pIn, pOut, n));

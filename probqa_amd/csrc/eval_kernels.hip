@@ -39,7 +39,20 @@ struct EvalArgs {
   int64_t K, ldT, qFirst, qLimit;
   double vCompTail;  // ln(sqrt 2) / (nValidTargets + 1)^2, PqaCore/CEEvalQsSubtaskConsider.cpp:191
   FusedSelect fs;
+  const QuizSlot *slots;  // batched launch: per-quiz pointers, indexed by blockIdx.y (nullptr: a single quiz)
 };
+
+// batched launch: this workgroup's quiz replaces the per-quiz fields of the arguments
+__device__ __forceinline__ void select_quiz(EvalArgs &a) {
+  if (a.slots == nullptr) return;
+  const QuizSlot s = a.slots[blockIdx.y];
+  a.prior = s.prior;
+  a.asked = s.asked;
+  a.priority = s.priority;
+  a.fs.out = s.out;
+  a.fs.seq = s.seq;
+  a.fs.scratch += (size_t)blockIdx.y * (size_t)a.fs.scratchStride;
+}
 
 // Fused argmax: a selection is ONE launch and -- with out/seq in host-coherent memory -- needs no copy and no stream
 // synchronisation.  Every workgroup keeps the best of its own questions in registers while it sweeps (maximum priority,
@@ -274,6 +287,7 @@ __device__ __forceinline__ void flush_pending(const EvalArgs &a, const double *p
 
 template <int WPQ, int NP, bool PRLDS>
 __global__ __launch_bounds__(WPQ * 64) void eval_questions_f64(EvalArgs a) {
+  select_quiz(a);
   constexpr int kThreads = WPQ * kWave;
   constexpr int NPR = PRLDS ? 1 : NP;
   extern __shared__ double smem[];
@@ -459,6 +473,7 @@ __global__ __launch_bounds__(WPQ * 64) void eval_questions_f64(EvalArgs a) {
 // re-reads the sA row (served by L2 / Infinity Cache when it can).  Same arithmetic per element.
 // ------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void eval_questions_f64_stream(EvalArgs a) {
+  select_quiz(a);
   constexpr int WPQ = 4, kThreads = 256;
   extern __shared__ double smem[];
   const int64_t ldT = a.ldT, K = a.K;
@@ -622,29 +637,73 @@ int pick_variant(int64_t ldT, int variant) {
 int gNumCUs = 0;
 
 template <int WPQ, int NP, bool PRLDS>
-hipError_t launch_reg(const EvalArgs &args, int64_t nQ, hipStream_t stream) {
+hipError_t launch_reg(const EvalArgs &args, int64_t nQ, int nBatch, hipStream_t stream) {
   const size_t shmem = eval_lds_doubles(WPQ, args.K, PRLDS, args.ldT) * sizeof(double);
   auto kern = eval_questions_f64<WPQ, NP, PRLDS>;
-  if (shmem > 64 * 1024) {
-    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-    if (e != hipSuccess) return e;
+  // attribute and occupancy are properties of (kernel, LDS size): asked once, not on every launch (the engine serialises
+  // launches; a race between two engines would only repeat the query)
+  static size_t cachedShmem = ~(size_t)0;
+  static int cachedPerCU = 0;
+  if (shmem != cachedShmem) {
+    if (shmem > 64 * 1024) {
+      const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+      if (e != hipSuccess) return e;
+    }
+    if (gNumCUs == 0) {
+      int dev = 0, n = 0;
+      gNumCUs = (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
+    }
+    int perCU = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, kern, WPQ * 64, shmem) != hipSuccess || perCU < 1) perCU = 1;
+    cachedPerCU = perCU;
+    cachedShmem = shmem;
   }
-  if (gNumCUs == 0) {
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0)
-      gNumCUs = n;
-    else
-      gNumCUs = 256;
-  }
-  int perCU = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, kern, WPQ * 64, shmem) != hipSuccess || perCU < 1) perCU = 1;
   // one question per workgroup while they all fit on the chip at once; otherwise a resident grid that strides
-  const int64_t resident = (int64_t)gNumCUs * perCU;
+  const int64_t resident = (int64_t)gNumCUs * cachedPerCU;
   int64_t resGrid = nQ < resident ? nQ : resident;
-  if (args.fs.scratch != nullptr && resGrid > kFusedMaxGrid) resGrid = kFusedMaxGrid;  // one winner record per workgroup
-  const unsigned grid = (unsigned)resGrid;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(WPQ * 64), shmem, stream, args);
+  const int64_t maxRecords = args.slots != nullptr ? args.fs.scratchStride : kFusedMaxGrid;
+  if (args.fs.scratch != nullptr && resGrid > maxRecords) resGrid = maxRecords;  // one winner record per workgroup
+  hipLaunchKernelGGL(kern, dim3((unsigned)resGrid, (unsigned)nBatch), dim3(WPQ * 64), shmem, stream, args);
   return hipGetLastError();
+}
+
+hipError_t launch_variant(const EvalArgs &args, int64_t ldT, int variant, int nBatch, hipStream_t stream) {
+  const int64_t nQ = args.qLimit - args.qFirst;
+  const int v = pick_variant(ldT, variant);
+  int wpq = 0, np = 0;
+  for (const Variant &x : kVariants)
+    if (x.id == v) { wpq = x.wpq; np = x.np; }
+  if (v != 99 && (wpq == 0 || ldT > (int64_t)128 * wpq * np)) return hipErrorInvalidValue;
+  switch (v) {
+    case 1: return launch_reg<1, 8, false>(args, nQ, nBatch, stream);
+    case 2: return launch_reg<4, 2, false>(args, nQ, nBatch, stream);
+    case 3: return launch_reg<4, 4, false>(args, nQ, nBatch, stream);
+    case 4: return launch_reg<4, 8, false>(args, nQ, nBatch, stream);
+    case 5: return launch_reg<8, 8, true>(args, nQ, nBatch, stream);
+    case 6: return launch_reg<16, 5, true>(args, nQ, nBatch, stream);
+    case 7: return launch_reg<16, 8, true>(args, nQ, nBatch, stream);
+    case 8: return launch_reg<2, 4, false>(args, nQ, nBatch, stream);
+    case 9: return launch_reg<8, 5, false>(args, nQ, nBatch, stream);
+    case 10: return launch_reg<8, 10, true>(args, nQ, nBatch, stream);
+    case 11: return launch_reg<16, 5, false>(args, nQ, nBatch, stream);
+    case 12: return launch_reg<8, 10, false>(args, nQ, nBatch, stream);
+    case 13: return launch_reg<4, 3, false>(args, nQ, nBatch, stream);
+    case 14: return launch_reg<4, 5, false>(args, nQ, nBatch, stream);
+    case 15: return launch_reg<4, 6, false>(args, nQ, nBatch, stream);
+    case 16: return launch_reg<8, 6, false>(args, nQ, nBatch, stream);
+    case 17: return launch_reg<8, 7, false>(args, nQ, nBatch, stream);
+    case 18: return launch_reg<8, 8, false>(args, nQ, nBatch, stream);
+    case 19: return launch_reg<8, 9, false>(args, nQ, nBatch, stream);
+    case 99: {
+      const size_t shmem = eval_lds_doubles(4, args.K, false, 0) * sizeof(double);
+      int64_t maxBlocks = 256 * 8;
+      if (args.slots != nullptr && maxBlocks > args.fs.scratchStride) maxBlocks = args.fs.scratchStride;
+      const unsigned grid = (unsigned)(nQ < maxBlocks ? nQ : maxBlocks);
+      hipLaunchKernelGGL(eval_questions_f64_stream, dim3(grid, (unsigned)nBatch), dim3(256), shmem, stream, args);
+      return hipGetLastError();
+    }
+    default: return hipErrorInvalidValue;
+  }
 }
 
 }  // namespace
@@ -656,59 +715,42 @@ const char *EvalVariantName(const KbView &kb, int variant) {
   return "unknown";
 }
 
-hipError_t LaunchEvalQuestions(const KbView &kb, const double *prior, const uint32_t *asked, int64_t qFirst,
-                               int64_t qLimit, double *priority, int variant, const FusedSelect *fused,
-                               hipStream_t stream) {
-  if (qLimit <= qFirst) return hipSuccess;
-  EvalArgs args;
+static EvalArgs make_args(const KbView &kb, int64_t qFirst, int64_t qLimit) {
+  EvalArgs args{};
   args.cube = kb.cube;
-  args.prior = prior;
   args.tgap = kb.tgap;
   args.qgap = kb.qgap;
-  args.asked = asked;
-  args.priority = priority;
   args.K = kb.K;
   args.ldT = kb.ldT;
   args.qFirst = qFirst;
   args.qLimit = qLimit;
   const double nT = (double)(kb.nValidTargets + 1);  // PqaCore/CEEvalQsSubtaskConsider.cpp:191
   args.vCompTail = 0.34657359027997265470861606072909 / (nT * nT);
-  args.fs = fused ? *fused : FusedSelect{nullptr, nullptr, nullptr, 0, 0};
-  const int64_t nQ = qLimit - qFirst;
-  const int v = pick_variant(kb.ldT, variant);
-  int wpq = 0, np = 0;
-  for (const Variant &x : kVariants)
-    if (x.id == v) { wpq = x.wpq; np = x.np; }
-  if (v != 99 && (wpq == 0 || kb.ldT > (int64_t)128 * wpq * np)) return hipErrorInvalidValue;
-  switch (v) {
-    case 1: return launch_reg<1, 8, false>(args, nQ, stream);
-    case 2: return launch_reg<4, 2, false>(args, nQ, stream);
-    case 3: return launch_reg<4, 4, false>(args, nQ, stream);
-    case 4: return launch_reg<4, 8, false>(args, nQ, stream);
-    case 5: return launch_reg<8, 8, true>(args, nQ, stream);
-    case 6: return launch_reg<16, 5, true>(args, nQ, stream);
-    case 7: return launch_reg<16, 8, true>(args, nQ, stream);
-    case 8: return launch_reg<2, 4, false>(args, nQ, stream);
-    case 9: return launch_reg<8, 5, false>(args, nQ, stream);
-    case 10: return launch_reg<8, 10, true>(args, nQ, stream);
-    case 11: return launch_reg<16, 5, false>(args, nQ, stream);
-    case 12: return launch_reg<8, 10, false>(args, nQ, stream);
-    case 13: return launch_reg<4, 3, false>(args, nQ, stream);
-    case 14: return launch_reg<4, 5, false>(args, nQ, stream);
-    case 15: return launch_reg<4, 6, false>(args, nQ, stream);
-    case 16: return launch_reg<8, 6, false>(args, nQ, stream);
-    case 17: return launch_reg<8, 7, false>(args, nQ, stream);
-    case 18: return launch_reg<8, 8, false>(args, nQ, stream);
-    case 19: return launch_reg<8, 9, false>(args, nQ, stream);
-    case 99: {
-      const size_t shmem = eval_lds_doubles(4, args.K, false, 0) * sizeof(double);
-      const int64_t maxBlocks = 256 * 8;
-      const unsigned grid = (unsigned)(nQ < maxBlocks ? nQ : maxBlocks);
-      hipLaunchKernelGGL(eval_questions_f64_stream, dim3(grid), dim3(256), shmem, stream, args);
-      return hipGetLastError();
-    }
-    default: return hipErrorInvalidValue;
-  }
+  args.fs = FusedSelect{nullptr, nullptr, nullptr, 0, 0, 0};
+  args.slots = nullptr;
+  return args;
+}
+
+hipError_t LaunchEvalQuestions(const KbView &kb, const double *prior, const uint32_t *asked, int64_t qFirst,
+                               int64_t qLimit, double *priority, int variant, const FusedSelect *fused,
+                               hipStream_t stream) {
+  if (qLimit <= qFirst) return hipSuccess;
+  EvalArgs args = make_args(kb, qFirst, qLimit);
+  args.prior = prior;
+  args.asked = asked;
+  args.priority = priority;
+  if (fused) args.fs = *fused;
+  return launch_variant(args, kb.ldT, variant, 1, stream);
+}
+
+hipError_t LaunchEvalQuestionsBatch(const KbView &kb, const QuizSlot *slots, int nSlots, int64_t qFirst, int64_t qLimit,
+                                    int variant, const FusedSelect &fused, hipStream_t stream) {
+  if (qLimit <= qFirst || nSlots <= 0) return hipSuccess;
+  if (slots == nullptr || fused.scratch == nullptr || fused.scratchStride <= 0) return hipErrorInvalidValue;
+  EvalArgs args = make_args(kb, qFirst, qLimit);
+  args.fs = fused;
+  args.slots = slots;
+  return launch_variant(args, kb.ldT, variant, nSlots, stream);
 }
 
 }  // namespace pqa

@@ -210,7 +210,8 @@ HipEngine::~HipEngine() {
   if (_stream) hipStreamSynchronize(_stream);
   for (Quiz *q : _quizzes) if (q) DestroyQuiz(q);
   hipFree(_dCube); hipFree(_dVB); hipFree(_dPriority); hipFree(_dRunLength); hipFree(_dExps); hipFree(_dStatus);
-  hipFree(_dNOut); hipFree(_dSel); hipFree(_dSelScratch); hipFree(_dTGap); hipFree(_dQGap); hipFree(_dAqs); hipFree(_dTop);
+  hipFree(_dNOut); hipFree(_dSel); hipFree(_dSelScratch); hipFree(_dBatchSlots); hipFree(_dBatchScratch); hipFree(_dBatchPriority);
+  if (_hBatch) hipHostFree(_hBatch); hipFree(_dTGap); hipFree(_dQGap); hipFree(_dAqs); hipFree(_dTop);
   if (_hPinned) hipHostFree(_hPinned);
   if (_ownStream) hipStreamDestroy(_ownStream);
 }
@@ -470,7 +471,7 @@ Error HipEngine::EnqueueSelectArgmax(int64_t iQuiz, void *pOut) {
   Quiz *q = UseQuiz(err, iQuiz);
   if (!q) return err;
   // one launch: the sweep's last workgroup picks the argmax; reported index = local position + qFirst (GLOBAL id)
-  const FusedSelect fs{_dSelScratch, pOut ? (SelectResult *)pOut : _dSel, nullptr, NextLaunchTag(), _qFirst};
+  const FusedSelect fs{_dSelScratch, pOut ? (SelectResult *)pOut : _dSel, nullptr, NextLaunchTag(), _qFirst, 0};
   HIP_TRY(LaunchEvalQuestions(View(), q->dPrior, q->dAsked, 0, _Q, _dPriority, (int)_optEvalVariant, &fs, _stream));
   return Error();
 }
@@ -485,7 +486,7 @@ int64_t HipEngine::NextQuestionArgmax(Error &err, int64_t iQuiz) {
   // One launch; the last workgroup writes the winner and then a sequence number straight into host-coherent pinned
   // memory, which this thread polls: no D2H copy, no stream synchronisation on the critical path.
   const uint64_t seq = NextLaunchTag();
-  const FusedSelect fs{_dSelScratch, &_hPinned->sel, &_hPinned->seq, seq, 0};
+  const FusedSelect fs{_dSelScratch, &_hPinned->sel, &_hPinned->seq, seq, 0, 0};
   hipError_t he = LaunchEvalQuestions(View(), q->dPrior, q->dAsked, 0, _Q, _dPriority, (int)_optEvalVariant, &fs, _stream);
   if (he != hipSuccess) { err = HipErr(he, "NextQuestionArgmax"); return -1; }
   volatile uint64_t *flag = &_hPinned->seq;
@@ -511,6 +512,69 @@ int64_t HipEngine::NextQuestionArgmax(Error &err, int64_t iQuiz) {
     return -1;
   }
   return FinishSelection(err, q, _hPinned->sel.index);
+}
+
+// Argmax selections for several quizzes with ONE launch (grid.y = quiz): the launch / dispatch / hand-back overhead that
+// dominates a single selection on small knowledge bases is paid once per batch.  pOut[i] = the selected GLOBAL question of
+// pQuizzes[i], or -1 when that quiz has run out of questions (not an error of the call).
+Error HipEngine::NextQuestionArgmaxBatch(int64_t n, const int64_t *pQuizzes, int64_t *pOut) {
+  std::lock_guard<std::mutex> lk(_mu);
+  Error err = CheckRegular("compute next questions");
+  if (!err.ok()) return err;
+  if (n < 0 || n > kMaxBatch)
+    return Error::MakeP(ErrCode::IndexOutOfRange, RangeParams(n, 0, kMaxBatch), "Batch size is out of range.");
+  if (n == 0) return Error();
+  if (!pQuizzes || !pOut) return Error::Make(ErrCode::NullArgument, "Nullptr is passed in place of a batch buffer.");
+  hipSetDevice(_device);
+  if (!_hBatch) {  // first batch: staging in host-coherent pinned memory, per-quiz priority vectors, winner records
+    HIP_TRY(hipHostMalloc(&_hBatch, sizeof(BatchPinned), hipHostMallocMapped | hipHostMallocCoherent));
+    std::memset(_hBatch, 0, sizeof(BatchPinned));
+    HIP_TRY(hipMalloc(&_dBatchSlots, kMaxBatch * sizeof(QuizSlot)));
+    HIP_TRY(hipMalloc(&_dBatchScratch, (size_t)kMaxBatch * kBatchGrid * sizeof(SelectResult)));
+    HIP_TRY(hipMemset(_dBatchScratch, 0, (size_t)kMaxBatch * kBatchGrid * sizeof(SelectResult)));
+  }
+  if (_batchPriorityQ != _Q) {  // (re)sized with the knowledge base
+    if (_dBatchPriority) hipFree(_dBatchPriority);
+    _dBatchPriority = nullptr;
+    HIP_TRY(hipMalloc(&_dBatchPriority, (size_t)kMaxBatch * (size_t)_Q * sizeof(double)));
+    _batchPriorityQ = _Q;
+  }
+  std::vector<Quiz *> quizzes((size_t)n);
+  for (int64_t i = 0; i < n; i++) {
+    quizzes[i] = UseQuiz(err, pQuizzes[i]);
+    if (!quizzes[i]) return err;
+    for (int64_t j = 0; j < i; j++)
+      if (pQuizzes[j] == pQuizzes[i])
+        return Error::MakeP(ErrCode::IndexOutOfRange, "quizId=" + std::to_string(pQuizzes[i]), "A quiz appears twice in one batch.");
+    _hBatch->slots[i] = QuizSlot{quizzes[i]->dPrior, quizzes[i]->dAsked, _dBatchPriority + (size_t)i * (size_t)_Q,
+                                 &_hBatch->out[i], &_hBatch->seq[i]};
+  }
+  const uint64_t tag = NextLaunchTag();
+  HIP_TRY(hipMemcpyAsync(_dBatchSlots, _hBatch->slots, (size_t)n * sizeof(QuizSlot), hipMemcpyHostToDevice, _stream));
+  const FusedSelect fs{_dBatchScratch, nullptr, nullptr, tag, 0, kBatchGrid};
+  HIP_TRY(LaunchEvalQuestionsBatch(View(), _dBatchSlots, (int)n, 0, _Q, (int)_optEvalVariant, fs, _stream));
+  const auto t0 = std::chrono::steady_clock::now();
+  for (int64_t i = 0; i < n; i++) {
+    volatile uint64_t *flag = &_hBatch->seq[i];
+    uint64_t spins = 0;
+    while (*flag != tag) {
+      if ((++spins & 0xFFF) == 0) {
+        if (hipStreamQuery(_stream) == hipSuccess && *flag != tag) {  // the kernel retired without publishing
+          const hipError_t he = hipStreamSynchronize(_stream);
+          if (he != hipSuccess || *flag != tag) return HipErr(he == hipSuccess ? hipErrorUnknown : he, "NextQuestionArgmaxBatch (result flag)");
+        }
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(60))
+          return HipErr(hipErrorNotReady, "NextQuestionArgmaxBatch (timeout)");
+      }
+    }
+  }
+  std::atomic_thread_fence(std::memory_order_acquire);
+  for (int64_t i = 0; i < n; i++) {
+    if (_hBatch->out[i].index == -3) return HipErr(hipErrorLaunchFailure, "NextQuestionArgmaxBatch (incomplete sweep)");
+    Error e;
+    pOut[i] = FinishSelection(e, quizzes[i], _hBatch->out[i].index);  // -1 + QuestionsExhausted: reported as -1 only
+  }
+  return Error();
 }
 
 int64_t HipEngine::NextQuestionSampled(Error &err, int64_t iQuiz, uint64_t rnd) {

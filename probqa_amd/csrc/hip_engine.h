@@ -125,6 +125,7 @@ class HipEngine {
   int64_t NextQuestionArgmax(Error &err, int64_t iQuiz);
   int64_t NextQuestionSampled(Error &err, int64_t iQuiz, uint64_t rnd);
   Error GetPriors(int64_t iQuiz, double *pOut, int64_t n);
+  Error NextQuestionArgmaxBatch(int64_t n, const int64_t *pQuizzes, int64_t *pOut);
   Error Log2HotArray(const double *pIn, double *pOut, int64_t n);  // device log2hot over an array (tests)
   hipStream_t GetStream() const { return _stream; }
   Error SetStream(hipStream_t s);
@@ -166,7 +167,15 @@ class HipEngine {
   int64_t _topCapacity = 0;
   SelectResult *_dSel = nullptr;
   struct Pinned { SelectResult sel; uint64_t seq; int64_t status[2]; int64_t nOut; };
-  SelectResult *_dSelScratch = nullptr;  // its per-shard and per-workgroup winner records
+  SelectResult *_dSelScratch = nullptr;  // its per-workgroup winner records
+  // batched selections (NextQuestionArgmaxBatch); allocated on first use
+  static constexpr int64_t kMaxBatch = 256, kBatchGrid = 1024;
+  struct BatchPinned { QuizSlot slots[kMaxBatch]; SelectResult out[kMaxBatch]; uint64_t seq[kMaxBatch]; };
+  BatchPinned *_hBatch = nullptr;
+  QuizSlot *_dBatchSlots = nullptr;
+  SelectResult *_dBatchScratch = nullptr;
+  double *_dBatchPriority = nullptr;
+  int64_t _batchPriorityQ = -1;
   uint64_t _selSeq = 0;
   // Tag of the next fused launch: consecutive launches differ in the low 32 bits, and those are never 0 (the state of
   // freshly cleared records)

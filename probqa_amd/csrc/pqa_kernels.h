@@ -40,15 +40,29 @@ hipError_t LaunchLog2HotArray(const double *x, double *out, int64_t n, hipStream
 // `fused` (optional): let the sweep's last workgroup also pick the argmax, so that a selection is one launch.
 constexpr int kFusedMaxGrid = 4096;     // workgroups of a fused launch (one record each)
 struct FusedSelect {
-  SelectResult *scratch;  // kFusedMaxGrid device records (16-byte aligned): the workgroups' winners, tagged per launch
+  SelectResult *scratch;  // records (16-byte aligned): the workgroups' winners, tagged per launch; kFusedMaxGrid of them
+                          // for a single sweep, scratchStride per quiz for a batch
   SelectResult *out;      // device or host-coherent memory; index = position in priority[] + outBase
   uint64_t *seq;          // optional host-coherent flag, set to seqValue after `out` is visible
   uint64_t seqValue;      // launch tag: its low 32 bits must differ from those of the previous fused launch on `scratch`
   int64_t outBase;
+  int64_t scratchStride;  // batch only: records per quiz in `scratch` (the launch uses at most that many workgroups)
+};
+// One quiz of a batched sweep (blockIdx.y selects it): everything that differs between the quizzes of one launch.
+struct QuizSlot {
+  const double *prior;
+  const uint32_t *asked;
+  double *priority;       // this quiz's priority vector
+  SelectResult *out;      // host-coherent record of this quiz's winner
+  uint64_t *seq;          // host-coherent flag of this quiz
 };
 hipError_t LaunchEvalQuestions(const KbView &kb, const double *prior, const uint32_t *asked, int64_t qFirst,
                                int64_t qLimit, double *priority, int variant, const FusedSelect *fused,
                                hipStream_t stream);
+// The same sweep for nSlots quizzes in one launch (grid.y = quiz): `slots` is a DEVICE array; fused->scratch holds
+// nSlots * fused->scratchStride records; fused->out / seq are ignored (each slot has its own).
+hipError_t LaunchEvalQuestionsBatch(const KbView &kb, const QuizSlot *slots, int nSlots, int64_t qFirst, int64_t qLimit,
+                                    int variant, const FusedSelect &fused, hipStream_t stream);
 const char *EvalVariantName(const KbView &kb, int variant);
 
 // ---- selectors over priority[0..n) (questions qFirst..qFirst+n of the bitmaps); the reported index is

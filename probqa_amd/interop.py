@@ -125,6 +125,7 @@ HIP_EXPORTS = {
     "PqaEngine_EvalPriorities": (_vp, [_vp, _i64, _pdbl, _i64]),
     "PqaEngine_NextQuestionArgmax": (_i64, [_vp, _pvp, _i64]),
     "PqaHip_Log2Hot": (_vp, [_vp, _pdbl, _pdbl, _i64]),
+    "PqaEngine_NextQuestionArgmaxBatch": (_vp, [_vp, _i64, _pi64, _pi64]),
     "PqaEngine_NextQuestionSampled": (_i64, [_vp, _pvp, _i64, _u64]),
     "PqaHip_GetPriors": (_vp, [_vp, _i64, _pdbl, _i64]),
     "PqaHip_GetStream": (_vp, [_vp]),
@@ -478,6 +479,14 @@ class PqaEngine:
         q = _lib.PqaEngine_NextQuestionArgmax(self.c_engine, ctypes.byref(c_err), i_quiz)
         _check(c_err.value)
         return q
+
+    def next_question_argmax_batch(self, quizzes) -> List[int]:
+        """Argmax NextQuestion of several distinct quizzes with one launch; -1 for a quiz that has run out of questions."""
+        n = len(quizzes)
+        qs = (ctypes.c_int64 * max(n, 1))(*quizzes)
+        out = (ctypes.c_int64 * max(n, 1))()
+        _check(_lib.PqaEngine_NextQuestionArgmaxBatch(self.c_engine, n, qs, out))
+        return list(out[:n])
 
     def log2hot(self, x: np.ndarray) -> np.ndarray:
         """The device's Log2Hot over an array (the per-element function of the sweep)."""

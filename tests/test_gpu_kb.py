@@ -225,3 +225,35 @@ def test_concurrent_quizzes_from_threads(factory):
         t.join()
     assert sorted(together) == sorted(alone)
     eng.close()
+
+
+def test_batched_argmax_equals_one_by_one(factory):
+    """PqaEngine_NextQuestionArgmaxBatch: one launch for many quizzes, the same questions as quiz-by-quiz calls."""
+    for (K, Q, T, n) in ((5, 300, 1000, 37), (3, 7, 33, 5), (4, 40, 2500, 9)):
+        eng, *_ = make(factory, K, Q, T, seed=Q)
+        rng = np.random.default_rng(Q)
+        quizzes = []
+        for i in range(n):
+            quiz = eng.start_quiz()
+            for _ in range(int(rng.integers(0, min(Q - 1, 6)))):      # a different history per quiz
+                eng.next_question_argmax(quiz)
+                eng.record_answer(quiz, int(rng.integers(0, K)))
+            quizzes.append(quiz)
+        one_by_one = [eng.next_question_argmax(q) for q in quizzes]
+        assert eng.next_question_argmax_batch(quizzes) == one_by_one
+        assert [eng.get_active_question_id(q) for q in quizzes] == one_by_one
+        assert eng.next_question_argmax_batch(quizzes[::-1]) == one_by_one[::-1]   # order of the batch is the caller's
+        assert eng.next_question_argmax_batch([]) == []
+        with pytest.raises(interop.PqaException, match="twice"):
+            eng.next_question_argmax_batch([quizzes[0], quizzes[1], quizzes[0]])
+        with pytest.raises(interop.PqaException, match="absent|out of range"):
+            eng.next_question_argmax_batch([quizzes[0], 10_000])
+        eng.close()
+    # a quiz that has run out of questions reports -1 inside a batch, the others are unaffected
+    eng, *_ = make(factory, 3, 2, 9, seed=4)
+    a, b = eng.start_quiz(), eng.start_quiz()
+    for _ in range(2):
+        eng.next_question_argmax(a)
+        eng.record_answer(a, 1)
+    assert eng.next_question_argmax_batch([a, b]) == [-1, eng.next_question_argmax(b)]
+    eng.close()
