@@ -42,9 +42,17 @@ def main():
     ap.add_argument("--config", choices=sorted(CONFIGS), default="S")
     ap.add_argument("--variant", type=int, default=0, help="force an eval kernel shape (0 = auto)")
     ap.add_argument("--batch", type=int, default=64, help="quizzes per launch of the batched-selection extra (0 = skip)")
+    ap.add_argument("--force-collective", action="store_true",
+                    help="use the sharded selector (RCCL all-gather + host pick) even on one GPU: exercises the N>1 path")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=3.0, help="wall seconds of the CPU baseline leg")
     args = ap.parse_args()
+
+    # stdout carries exactly one line, the result: libraries that print there (RCCL's version banner, for one) are sent
+    # to stderr for the whole run
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
 
     import numpy as np
     import torch
@@ -63,10 +71,13 @@ def main():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU fallback")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    if world > 1 or args.force_collective:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group(backend="nccl", device_id=device)
 
     cfg = CONFIGS[args.config]
@@ -86,7 +97,7 @@ def main():
     ldT = eng.get_option("ldT")
 
     selector = None
-    if world > 1:
+    if world > 1 or args.force_collective:
         selector = pdist.ShardedSelector(lambda out: eng.enqueue_select_argmax(quiz, out.data_ptr()), device)
 
     def step():
@@ -178,7 +189,7 @@ def main():
             "workload": "%s fp64 cube resident in HBM, single in-flight quiz; step = priority sweep + argmax + "
                         "question id on host, synchronous call through the C ABI" % cfg["name"],
             "questions_per_gpu": q_local,
-            "parallelism": "question-axis shards x%d + 16B/rank all-gather" % world if world > 1 else "single GPU",
+            "parallelism": "question-axis shards x%d + 16B/rank all-gather" % world if selector is not None else "single GPU",
             "eval_kernel": eng.eval_kernel_name(),
             "selected_question": int(sel),
         },
@@ -203,9 +214,9 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(np, cfg, args.cpu_seconds)
     if rank == 0:
-        print(json.dumps(out))
+        os.write(result_fd, (json.dumps(out) + "\n").encode())
     eng.close()
-    if world > 1:
+    if world > 1 or args.force_collective:
         import torch.distributed as dist
 
         dist.destroy_process_group()
