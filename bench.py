@@ -41,7 +41,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--config", choices=sorted(CONFIGS), default="S")
     ap.add_argument("--variant", type=int, default=0, help="force an eval kernel shape (0 = auto)")
-    ap.add_argument("--batch", type=int, default=64, help="quizzes per launch of the batched-selection extra (0 = skip)")
+    ap.add_argument("--batch", type=int, default=-1,
+                    help="quizzes per launch of the batched-selection extra (0 = skip; default 64, or 8 for cubes over 1 GB)")
     ap.add_argument("--force-collective", action="store_true",
                     help="use the sharded selector (RCCL all-gather + host pick) even on one GPU: exercises the N>1 path")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -82,6 +83,8 @@ def main():
 
     cfg = CONFIGS[args.config]
     Q, K, T = cfg["Q"], cfg["K"], cfg["T"]
+    if args.batch < 0:
+        args.batch = 64 if Q * (K + 1) * T * 8 < 1e9 else 8
     q_first, q_limit = pdist.shard_range(Q, world, rank)
     q_local = q_limit - q_first
 
