@@ -5,7 +5,8 @@ A "step" is one complete NextQuestion of one quiz: the priority sweep over every
 sA[question][answer][target] cube (eval kernel) + the argmax selection + delivery of the selected question id to
 the host.  The cube is resident in HBM before the timed region.  Workload at N=1: BASELINE.json configs[1]
 (1000Q x 5A x 1000T fp64, single in-flight quiz).  N>1: the question axis of the same cube is sharded over the ranks
-(one process per GPU), each rank sweeps its shard and one 16-byte-per-rank RCCL all-gather picks the global argmax
+(one process per GPU), each rank sweeps its shard and the ranks' 16-byte winners meet in host shared memory written by
+the sweeps themselves (--exchange rccl: one RCCL all-gather instead), every rank picks the same global argmax
 ("strong" scaling, as north_star states it).  --config M runs configs[2] (10000x5x10000, the HBM-bound point).
 
 Prints ONE JSON line (rank 0).  Extra keys: roofline (dominant kernel, live HIP-event timing on the engine's stream),
@@ -44,7 +45,10 @@ def main():
     ap.add_argument("--batch", type=int, default=-1,
                     help="quizzes per launch of the batched-selection extra (0 = skip; default 64, or 8 for cubes over 1 GB)")
     ap.add_argument("--force-collective", action="store_true",
-                    help="use the sharded selector (RCCL all-gather + host pick) even on one GPU: exercises the N>1 path")
+                    help="use the sharded selector even on one GPU: exercises the N>1 path")
+    ap.add_argument("--exchange", choices=("shm", "rccl"), default="shm",
+                    help="how the shards' 16-byte winners meet: host shared memory written by the sweep itself "
+                         "(default), or an RCCL all-gather + D2H copy")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=3.0, help="wall seconds of the CPU baseline leg")
     args = ap.parse_args()
@@ -101,7 +105,32 @@ def main():
 
     selector = None
     if world > 1 or args.force_collective:
-        selector = pdist.ShardedSelector(lambda out: eng.enqueue_select_argmax(quiz, out.data_ptr()), device)
+        if args.exchange == "shm":
+            import torch.distributed as dist
+
+            name = "bench_%s" % os.environ.get("MASTER_PORT", "0")
+            ok = 1
+            try:
+                if rank == 0:
+                    selector = pdist.ShmSelector(eng, quiz, rank, world, name, create=True)
+            except Exception as e:  # noqa: BLE001 - every rank must take the same path
+                print("rank 0: shared-memory exchange unavailable (%r)" % (e,), file=sys.stderr)
+                ok = 0
+            dist.barrier()                      # the segment exists before the other ranks open it
+            try:
+                if rank != 0 and ok:
+                    selector = pdist.ShmSelector(eng, quiz, rank, world, name, create=False)
+            except Exception as e:  # noqa: BLE001
+                print("rank %d: shared-memory exchange unavailable (%r)" % (rank, e), file=sys.stderr)
+                ok = 0
+            flag = torch.tensor([ok], dtype=torch.int32, device=device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 0:           # one rank could not: all ranks use the collective
+                if selector is not None:
+                    selector.close()
+                selector, args.exchange = None, "rccl"
+        if selector is None:
+            selector = pdist.ShardedSelector(lambda out: eng.enqueue_select_argmax(quiz, out.data_ptr()), device)
 
     def step():
         if selector is None:
@@ -192,7 +221,9 @@ def main():
             "workload": "%s fp64 cube resident in HBM, single in-flight quiz; step = priority sweep + argmax + "
                         "question id on host, synchronous call through the C ABI" % cfg["name"],
             "questions_per_gpu": q_local,
-            "parallelism": "question-axis shards x%d + 16B/rank all-gather" % world if selector is not None else "single GPU",
+            "parallelism": ("question-axis shards x%d, winners exchanged through %s" % (
+            world, "host shared memory written by the sweep" if args.exchange == "shm" else "an RCCL all-gather"))
+        if selector is not None else "single GPU",
             "eval_kernel": eng.eval_kernel_name(),
             "selected_question": int(sel),
         },
@@ -218,6 +249,8 @@ def main():
         out["cpu_baseline"] = cpu_baseline(np, cfg, args.cpu_seconds)
     if rank == 0:
         os.write(result_fd, (json.dumps(out) + "\n").encode())
+    if selector is not None and hasattr(selector, "close"):
+        selector.close()
     eng.close()
     if world > 1 or args.force_collective:
         import torch.distributed as dist

@@ -77,6 +77,18 @@ PQACORE_API void *PqaHip_SetStream(void *pvEngine, void *hipStream); /* run on t
 PQACORE_API void *PqaHip_Synchronize(void *pvEngine);
 /* Enqueue sweep + local argmax; the 16-byte CiHipSelection is written to pOut (device or pinned host pointer). */
 PQACORE_API void *PqaHip_EnqueueSelectArgmax(void *pvEngine, const int64_t iQuiz, void *pOut);
+/* ---- exchange of the shards' winners through host memory shared by the ranks of a node (probqa_amd/dist.py).
+ * The 16-byte message per rank is latency-bound: the sweep's finisher writes {priority, GLOBAL index} to pOut and then
+ * flagValue to pFlag -- device-visible addresses of registered host memory -- and every rank's host picks the winner as
+ * soon as all flags carry the step's value.  No collective launch, no copy, no stream synchronisation. */
+PQACORE_API void *PqaHip_EnqueueSelectArgmaxFlag(void *pvEngine, const int64_t iQuiz, void *pOut, void *pFlag,
+                                                 const uint64_t flagValue);
+PQACORE_API void *PqaHip_HostRegister(void *pHost, const int64_t nBytes, void **ppDevice);
+PQACORE_API void *PqaHip_HostUnregister(void *pHost);
+/* Slots of strideBytes each, starting with {double priority; int64 index; uint64 flag}: wait until all `world` flags
+ * equal flagValue, then the exact global pick (max priority, lowest index on ties, NaN never wins, -1 if none). */
+PQACORE_API void *PqaHip_PickWhenAll(const void *pSlots, const int64_t world, const int64_t strideBytes,
+                                     const uint64_t flagValue, const double timeoutSec, double *pPriority, int64_t *pIndex);
 /* Enqueue only the sweep (dominant kernel), for kernel timing. */
 PQACORE_API void *PqaHip_EnqueueEval(void *pvEngine, const int64_t iQuiz);
 /* Device pointer of the quiz's prior vector (ldT doubles, *pLdT receives ldT) for collectives between shards. */

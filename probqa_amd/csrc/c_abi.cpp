@@ -1,10 +1,14 @@
 // c_abi.cpp -- the extern "C" surface of libPqaCore.so.
 // Shims follow reference ProbQA/PqaCore/PqaCInterop.cpp:45-408 (AssignPqaError / ReturnPqaError, the three
 // GET_ENGINE_OR_* null-handle conventions); declarations are in include/PqaCInterop.h and include/PqaHipExt.h.
+#include <atomic>
+#include <chrono>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <string>
 
 #include "hip_engine.h"
 
@@ -366,6 +370,57 @@ PQACORE_API void *PqaHip_SetStream(void *pvEngine, void *hipStream) {
 PQACORE_API void *PqaHip_Synchronize(void *pvEngine) {
   GET_ENGINE_OR_RET_ERR;
   return ReturnErr(pEng->Synchronize());
+}
+PQACORE_API void *PqaHip_EnqueueSelectArgmaxFlag(void *pvEngine, const int64_t iQuiz, void *pOut, void *pFlag,
+                                                 const uint64_t flagValue) {
+  GET_ENGINE_OR_RET_ERR;
+  return ReturnErr(pEng->EnqueueSelectArgmaxFlag(iQuiz, pOut, pFlag, flagValue));
+}
+// Host memory (e.g. a shared-memory segment mapped by every rank) made writable by this process's GPU.
+PQACORE_API void *PqaHip_HostRegister(void *pHost, const int64_t nBytes, void **ppDevice) {
+  if (!pHost || !ppDevice || nBytes <= 0) return ReturnErr(Error::Make(ErrCode::NullArgument, "Bad arguments to PqaHip_HostRegister."));
+  hipError_t he = hipHostRegister(pHost, (size_t)nBytes, hipHostRegisterMapped | hipHostRegisterPortable);
+  if (he == hipSuccess) he = hipHostGetDevicePointer(ppDevice, pHost, 0);
+  if (he != hipSuccess) return ReturnErr(Error::MakeP(ErrCode::StdException, std::string("hip=") + hipGetErrorString(he), "hipHostRegister failed."));
+  return nullptr;
+}
+PQACORE_API void *PqaHip_HostUnregister(void *pHost) {
+  if (pHost) hipHostUnregister(pHost);
+  return nullptr;
+}
+// Host-side half of the shared-memory exchange: spin until the flags of all `world` slots equal flagValue, then pick the
+// winner (maximum priority, lowest index on ties, NaN never wins, -1 if no slot has an eligible question).  A slot is
+// strideBytes long and starts with {double priority; int64 index; uint64 flag}.  Returns an error after timeoutSec.
+PQACORE_API void *PqaHip_PickWhenAll(const void *pSlots, const int64_t world, const int64_t strideBytes,
+                                     const uint64_t flagValue, const double timeoutSec, double *pPriority, int64_t *pIndex) {
+  if (!pSlots || !pPriority || !pIndex || world <= 0 || strideBytes < 24)
+    return ReturnErr(Error::Make(ErrCode::NullArgument, "Bad arguments to PqaHip_PickWhenAll."));
+  const char *base = (const char *)pSlots;
+  const auto t0 = std::chrono::steady_clock::now();
+  for (int64_t r = 0; r < world; r++) {
+    const volatile uint64_t *flag = (const volatile uint64_t *)(base + r * strideBytes + 16);
+    uint64_t spins = 0;
+    while (*flag != flagValue) {
+      if ((++spins & 0x3FFF) == 0 &&
+          std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeoutSec)
+        return ReturnErr(Error::MakeP(ErrCode::StdException, "rank=" + std::to_string(r), "Timed out waiting for a shard's selection."));
+    }
+  }
+  std::atomic_thread_fence(std::memory_order_acquire);
+  double bestP = 0;
+  int64_t bestI = -1;
+  for (int64_t r = 0; r < world; r++) {
+    double p;
+    int64_t i;
+    std::memcpy(&p, base + r * strideBytes, 8);
+    std::memcpy(&i, base + r * strideBytes + 8, 8);
+    if (i < 0) continue;
+    if (p != p) p = -HUGE_VAL;
+    if (bestI < 0 || p > bestP || (p == bestP && i < bestI)) { bestP = p; bestI = i; }
+  }
+  *pPriority = bestP;
+  *pIndex = bestI;
+  return nullptr;
 }
 PQACORE_API void *PqaHip_EnqueueSelectArgmax(void *pvEngine, const int64_t iQuiz, void *pOut) {
   GET_ENGINE_OR_RET_ERR;

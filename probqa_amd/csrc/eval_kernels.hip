@@ -152,7 +152,7 @@ __device__ __forceinline__ void fused_select(const EvalArgs &a, Best mine) {
     a.fs.out->index = !complete ? -3 : b.i < 0 ? -1 : b.i + a.fs.outBase;
     if (a.fs.seq != nullptr) {
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");  // system scope: the record is visible to the host before the flag
-      __hip_atomic_store(a.fs.seq, a.fs.seqValue, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(a.fs.seq, a.fs.flagValue, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
   }
 }
@@ -726,7 +726,7 @@ static EvalArgs make_args(const KbView &kb, int64_t qFirst, int64_t qLimit) {
   args.qLimit = qLimit;
   const double nT = (double)(kb.nValidTargets + 1);  // PqaCore/CEEvalQsSubtaskConsider.cpp:191
   args.vCompTail = 0.34657359027997265470861606072909 / (nT * nT);
-  args.fs = FusedSelect{nullptr, nullptr, nullptr, 0, 0, 0};
+  args.fs = FusedSelect{nullptr, nullptr, nullptr, 0, 0, 0, 0};
   args.slots = nullptr;
   return args;
 }

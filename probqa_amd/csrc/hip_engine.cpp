@@ -471,7 +471,23 @@ Error HipEngine::EnqueueSelectArgmax(int64_t iQuiz, void *pOut) {
   Quiz *q = UseQuiz(err, iQuiz);
   if (!q) return err;
   // one launch: the sweep's last workgroup picks the argmax; reported index = local position + qFirst (GLOBAL id)
-  const FusedSelect fs{_dSelScratch, pOut ? (SelectResult *)pOut : _dSel, nullptr, NextLaunchTag(), _qFirst, 0};
+  const FusedSelect fs{_dSelScratch, pOut ? (SelectResult *)pOut : _dSel, nullptr, NextLaunchTag(), _qFirst, 0, 0};
+  HIP_TRY(LaunchEvalQuestions(View(), q->dPrior, q->dAsked, 0, _Q, _dPriority, (int)_optEvalVariant, &fs, _stream));
+  return Error();
+}
+
+// The same, for a multi-process host loop that exchanges the shards' winners through host memory shared by the ranks
+// (probqa_amd/dist.py: ShmSelector): the record goes to pOut and then flagValue to pFlag, both device-visible addresses of
+// host-coherent (registered) memory, straight from the sweep's finisher -- no copy, no stream synchronisation.
+Error HipEngine::EnqueueSelectArgmaxFlag(int64_t iQuiz, void *pOut, void *pFlag, uint64_t flagValue) {
+  std::lock_guard<std::mutex> lk(_mu);
+  Error err = CheckRegular("compute next question");
+  if (!err.ok()) return err;
+  Quiz *q = UseQuiz(err, iQuiz);
+  if (!q) return err;
+  if (!pOut || !pFlag) return Error::Make(ErrCode::NullArgument, "Nullptr is passed in place of the record or the flag.");
+  hipSetDevice(_device);
+  const FusedSelect fs{_dSelScratch, (SelectResult *)pOut, (uint64_t *)pFlag, NextLaunchTag(), _qFirst, 0, flagValue};
   HIP_TRY(LaunchEvalQuestions(View(), q->dPrior, q->dAsked, 0, _Q, _dPriority, (int)_optEvalVariant, &fs, _stream));
   return Error();
 }
@@ -486,7 +502,7 @@ int64_t HipEngine::NextQuestionArgmax(Error &err, int64_t iQuiz) {
   // One launch; the last workgroup writes the winner and then a sequence number straight into host-coherent pinned
   // memory, which this thread polls: no D2H copy, no stream synchronisation on the critical path.
   const uint64_t seq = NextLaunchTag();
-  const FusedSelect fs{_dSelScratch, &_hPinned->sel, &_hPinned->seq, seq, 0, 0};
+  const FusedSelect fs{_dSelScratch, &_hPinned->sel, &_hPinned->seq, seq, 0, 0, seq};
   hipError_t he = LaunchEvalQuestions(View(), q->dPrior, q->dAsked, 0, _Q, _dPriority, (int)_optEvalVariant, &fs, _stream);
   if (he != hipSuccess) { err = HipErr(he, "NextQuestionArgmax"); return -1; }
   volatile uint64_t *flag = &_hPinned->seq;
@@ -551,7 +567,7 @@ Error HipEngine::NextQuestionArgmaxBatch(int64_t n, const int64_t *pQuizzes, int
   }
   const uint64_t tag = NextLaunchTag();
   HIP_TRY(hipMemcpyAsync(_dBatchSlots, _hBatch->slots, (size_t)n * sizeof(QuizSlot), hipMemcpyHostToDevice, _stream));
-  const FusedSelect fs{_dBatchScratch, nullptr, nullptr, tag, 0, kBatchGrid};
+  const FusedSelect fs{_dBatchScratch, nullptr, nullptr, tag, 0, kBatchGrid, tag};
   HIP_TRY(LaunchEvalQuestionsBatch(View(), _dBatchSlots, (int)n, 0, _Q, (int)_optEvalVariant, fs, _stream));
   const auto t0 = std::chrono::steady_clock::now();
   for (int64_t i = 0; i < n; i++) {

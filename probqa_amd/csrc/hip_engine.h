@@ -131,6 +131,7 @@ class HipEngine {
   Error SetStream(hipStream_t s);
   Error Synchronize();
   Error EnqueueSelectArgmax(int64_t iQuiz, void *pOut);
+  Error EnqueueSelectArgmaxFlag(int64_t iQuiz, void *pOut, void *pFlag, uint64_t flagValue);
   Error EnqueueEval(int64_t iQuiz);
   Error GetPriorDevicePtr(int64_t iQuiz, void **ppDev, int64_t *pLdT);
   Error RecordAnswerRemote(int64_t iQuiz, int64_t iAnswer);

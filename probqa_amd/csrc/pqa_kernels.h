@@ -43,10 +43,11 @@ struct FusedSelect {
   SelectResult *scratch;  // records (16-byte aligned): the workgroups' winners, tagged per launch; kFusedMaxGrid of them
                           // for a single sweep, scratchStride per quiz for a batch
   SelectResult *out;      // device or host-coherent memory; index = position in priority[] + outBase
-  uint64_t *seq;          // optional host-coherent flag, set to seqValue after `out` is visible
+  uint64_t *seq;          // optional host-coherent flag, set to flagValue after `out` is visible
   uint64_t seqValue;      // launch tag: its low 32 bits must differ from those of the previous fused launch on `scratch`
   int64_t outBase;
   int64_t scratchStride;  // batch only: records per quiz in `scratch` (the launch uses at most that many workgroups)
+  uint64_t flagValue;     // what *seq receives (the engine's own callers pass the launch tag)
 };
 // One quiz of a batched sweep (blockIdx.y selects it): everything that differs between the quizzes of one launch.
 struct QuizSlot {

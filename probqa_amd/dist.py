@@ -92,6 +92,72 @@ class ShardedSelector:
         return pick_global(recs)
 
 
+class ShmSelector:
+    """Global next-question selection over question shards, the ranks' 16-byte records exchanged through a host
+    shared-memory segment instead of a collective.
+
+    Why: the message is 16 bytes per rank, so the exchange is pure latency.  An RCCL all-gather costs a kernel launch, the
+    collective's own protocol, a D2H copy and a stream synchronisation per selection (~9 us even with ONE rank, measured;
+    more with eight) on top of a ~15 us sweep.  Here the sweep's finisher writes {priority, GLOBAL index} and then a
+    step number straight into rank r's 64-byte slot of a /dev/shm segment that every rank has mapped and registered with
+    its GPU (PqaHip_HostRegister), and every rank's host spins on the `world` step numbers (PqaHip_PickWhenAll) and
+    picks: no launch besides the sweep, no copy, no synchronisation.  Two slot sets alternate by step parity, so a fast
+    rank's step s+1 never overwrites what a slow rank still reads for step s (a rank cannot finish s+1 before every
+    rank has published s+1, which each does only after it is done with s).
+    torch.distributed is not involved on the data path; it stays the control plane (rendezvous, barriers, timing).
+    """
+
+    SLOT = 64
+
+    def __init__(self, engine, quiz: int, rank: int, world: int, name: str, create: Optional[bool] = None):
+        import mmap
+        import os
+
+        from . import interop
+
+        self.engine, self.quiz, self.rank, self.world = engine, quiz, rank, world
+        self.path = "/dev/shm/pqa_select_%s" % name
+        size = 2 * world * self.SLOT
+        if create is None:
+            create = rank == 0
+        if create:
+            fd = os.open(self.path, os.O_CREAT | os.O_RDWR | os.O_TRUNC, 0o600)
+            os.ftruncate(fd, size)          # zero-filled: step 0 is never used
+        else:
+            fd = os.open(self.path, os.O_RDWR)
+        try:
+            self._map = mmap.mmap(fd, size)
+        finally:
+            os.close(fd)
+        import ctypes
+
+        self._host = ctypes.addressof(ctypes.c_char.from_buffer(self._map))
+        self._dev = interop.host_register(self._host, size)
+        self._interop = interop
+        self.step = 0
+        self._owner = create
+
+    def select(self) -> Tuple[float, int]:
+        self.step += 1
+        half = (self.step & 1) * self.world * self.SLOT
+        mine = self._dev + half + self.rank * self.SLOT
+        self.engine.enqueue_select_argmax_flag(self.quiz, mine, mine + 16, self.step)
+        return self._interop.pick_when_all(self._host + half, self.world, self.SLOT, self.step)
+
+    def close(self) -> None:
+        import os
+
+        if self._map is not None:
+            self._interop.host_unregister(self._host)
+            self._map.close()
+            self._map = None
+            if self._owner:
+                try:
+                    os.unlink(self.path)
+                except OSError:
+                    pass
+
+
 def broadcast_prior(prior: torch.Tensor, owner_rank: int, group: Optional[dist.ProcessGroup] = None) -> None:
     """After RecordAnswer on the owner of the answered question: replicate the new prior vector."""
     if dist.is_initialized() and dist.get_world_size(group) > 1:

@@ -132,6 +132,10 @@ HIP_EXPORTS = {
     "PqaHip_SetStream": (_vp, [_vp, _vp]),
     "PqaHip_Synchronize": (_vp, [_vp]),
     "PqaHip_EnqueueSelectArgmax": (_vp, [_vp, _i64, _vp]),
+    "PqaHip_EnqueueSelectArgmaxFlag": (_vp, [_vp, _i64, _vp, _vp, ctypes.c_uint64]),
+    "PqaHip_HostRegister": (_vp, [_vp, _i64, _pvp]),
+    "PqaHip_HostUnregister": (_vp, [_vp]),
+    "PqaHip_PickWhenAll": (_vp, [_vp, _i64, _i64, ctypes.c_uint64, ctypes.c_double, _pdbl, _pi64]),
     "PqaHip_EnqueueEval": (_vp, [_vp, _i64]),
     "PqaHip_GetPriorDevicePtr": (_vp, [_vp, _i64, _pvp, _pi64]),
     "PqaHip_RecordAnswerRemote": (_vp, [_vp, _i64, _i64]),
@@ -272,6 +276,28 @@ def _check(c_err, throw: bool = True) -> Optional[PqaError]:
     if err and throw:
         raise PqaException(err.to_string(True))
     return err
+
+
+def host_register(address: int, n_bytes: int) -> int:
+    """Make host memory (e.g. a shared-memory segment) writable by this process's GPU; returns its device address."""
+    load_library()
+    dev = ctypes.c_void_p()
+    _check(_lib.PqaHip_HostRegister(ctypes.c_void_p(address), n_bytes, ctypes.byref(dev)))
+    return dev.value
+
+
+def host_unregister(address: int) -> None:
+    if _lib is not None:
+        _lib.PqaHip_HostUnregister(ctypes.c_void_p(address))
+
+
+def pick_when_all(address: int, world: int, stride: int, flag_value: int, timeout_s: float = 30.0):
+    """Host half of the shared-memory exchange: wait for all flags, then the exact global pick -> (priority, index)."""
+    load_library()
+    pri, idx = ctypes.c_double(), ctypes.c_int64()
+    _check(_lib.PqaHip_PickWhenAll(ctypes.c_void_p(address), world, stride, flag_value, timeout_s,
+                                   ctypes.byref(pri), ctypes.byref(idx)))
+    return pri.value, idx.value
 
 
 def _dptr(a: np.ndarray):
@@ -487,6 +513,10 @@ class PqaEngine:
         out = (ctypes.c_int64 * max(n, 1))()
         _check(_lib.PqaEngine_NextQuestionArgmaxBatch(self.c_engine, n, qs, out))
         return list(out[:n])
+
+    def enqueue_select_argmax_flag(self, i_quiz: int, out_dev: int, flag_dev: int, flag_value: int) -> None:
+        _check(_lib.PqaHip_EnqueueSelectArgmaxFlag(self.c_engine, i_quiz, ctypes.c_void_p(out_dev),
+                                                   ctypes.c_void_p(flag_dev), flag_value))
 
     def log2hot(self, x: np.ndarray) -> np.ndarray:
         """The device's Log2Hot over an array (the per-element function of the sweep)."""

@@ -99,3 +99,38 @@ def test_two_rank_sharded_selection_matches_single_process():
     ret = mgr.dict()
     mp.spawn(_worker, args=(world, port, ret), nprocs=world, join=True)
     assert ret[0] == ret[1] and len(ret[0]) == 4 and len(set(ret[0])) == 4
+
+
+def test_pick_when_all_host_half_of_the_shm_exchange():
+    """PqaHip_PickWhenAll: the host side of ShmSelector (no GPU involved): waits for every slot's step number, then the
+    exact pick.  Writers are threads that publish late and out of order."""
+    import ctypes
+    import struct
+    import threading
+    import time
+
+    from probqa_amd import interop
+
+    world, slot = 5, 64
+    buf = (ctypes.c_char * (world * slot))()
+    base = ctypes.addressof(buf)
+    records = [(2.0, 40), (7.5, 12), (float("nan"), 3), (7.5, 9), (0.0, -1)]   # tie on 7.5 -> index 9; NaN and -1 lose
+
+    def publish(r, delay):
+        time.sleep(delay)
+        struct.pack_into("<dq", buf, r * slot, *records[r])
+        struct.pack_into("<Q", buf, r * slot + 16, 17)
+
+    threads = [threading.Thread(target=publish, args=(r, 0.02 * (world - r))) for r in range(world)]
+    for t in threads:
+        t.start()
+    pri, idx = interop.pick_when_all(base, world, slot, 17, 5.0)
+    for t in threads:
+        t.join()
+    assert (pri, idx) == (7.5, 9)
+    with pytest.raises(interop.PqaException, match="Timed out"):
+        interop.pick_when_all(base, world, slot, 18, 0.05)          # nobody publishes step 18
+    struct.pack_into("<dq", buf, 3 * slot, 0.0, -1)
+    struct.pack_into("<dq", buf, 1 * slot, 0.0, -1)
+    struct.pack_into("<dq", buf, 0 * slot, 0.0, -1)
+    assert interop.pick_when_all(base, world, slot, 17, 1.0)[1] == 3   # only the NaN shard is left: it still has a question
