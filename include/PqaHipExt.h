@@ -91,7 +91,9 @@ PQACORE_API void *PqaHip_PickWhenAll(const void *pSlots, const int64_t world, co
                                      const uint64_t flagValue, const double timeoutSec, double *pPriority, int64_t *pIndex);
 /* Enqueue only the sweep (dominant kernel), for kernel timing. */
 PQACORE_API void *PqaHip_EnqueueEval(void *pvEngine, const int64_t iQuiz);
-/* Device pointer of the quiz's prior vector (ldT doubles, *pLdT receives ldT) for collectives between shards. */
+/* Device pointer of the quiz's prior vector (ldT doubles, *pLdT receives ldT) for collectives between shards.  The engine
+ * updates it in stream order (PqaEngine_RecordAnswer returns once its kernel is enqueued): read it on the engine's stream
+ * (PqaHip_GetStream / PqaHip_SetStream) or after PqaHip_Synchronize. */
 PQACORE_API void *PqaHip_GetPriorDevicePtr(void *pvEngine, const int64_t iQuiz, void **ppDev, int64_t *pLdT);
 /* RecordAnswer on a shard that does not own the active question: bookkeeping only; the owner's prior is expected to be
  * broadcast into PqaHip_GetPriorDevicePtr's buffer by the caller. */

@@ -211,6 +211,7 @@ HipEngine::~HipEngine() {
   for (Quiz *q : _quizzes) if (q) DestroyQuiz(q);
   hipFree(_dCube); hipFree(_dVB); hipFree(_dPriority); hipFree(_dRunLength); hipFree(_dExps); hipFree(_dStatus);
   hipFree(_dNOut); hipFree(_dSel); hipFree(_dSelScratch); hipFree(_dBatchSlots); hipFree(_dBatchScratch); hipFree(_dBatchPriority);
+  DropQuizBufferPool();
   if (_hBatch) hipHostFree(_hBatch); hipFree(_dTGap); hipFree(_dQGap); hipFree(_dAqs); hipFree(_dTop);
   if (_hPinned) hipHostFree(_hPinned);
   if (_ownStream) hipStreamDestroy(_ownStream);
@@ -299,9 +300,21 @@ Quiz *HipEngine::UseQuiz(Error &err, int64_t iQuiz) {
 
 void HipEngine::DestroyQuiz(Quiz *q) {
   if (!q) return;
-  hipFree(q->dPrior);
-  hipFree(q->dAsked);
+  if (q->dPrior && q->dAsked && _quizBufferPool.size() < 4096)
+    _quizBufferPool.push_back(QuizBuffers{q->dPrior, q->dAsked, _ldT, q->hAsked.size()});
+  else {
+    hipFree(q->dPrior);
+    hipFree(q->dAsked);
+  }
   delete q;
+}
+
+void HipEngine::DropQuizBufferPool() {
+  for (const QuizBuffers &b : _quizBufferPool) {
+    hipFree(b.dPrior);
+    hipFree(b.dAsked);
+  }
+  _quizBufferPool.clear();
 }
 
 int64_t HipEngine::CreateQuiz(Error &err, int64_t nAnswered, const AQ *pAQs) {
@@ -324,18 +337,33 @@ int64_t HipEngine::CreateQuiz(Error &err, int64_t nAnswered, const AQ *pAQs) {
   if (!allLocal)
     return fail(Error::MakeP(ErrCode::NotImplemented, "Feature=ResumeQuiz across shards",
                              "ResumeQuiz on a sharded engine needs every answered question to be local."));
-  hipError_t he = hipMalloc(&quiz->dPrior, (size_t)_ldT * sizeof(double));
-  if (he == hipSuccess) he = hipMalloc(&quiz->dAsked, quiz->hAsked.size() * sizeof(uint32_t));
-  if (he == hipSuccess)
-    he = hipMemcpyAsync(quiz->dAsked, quiz->hAsked.data(), quiz->hAsked.size() * sizeof(uint32_t), hipMemcpyHostToDevice, _stream);
+  hipError_t he = hipSuccess;
+  while (!_quizBufferPool.empty() && quiz->dPrior == nullptr) {
+    const QuizBuffers b = _quizBufferPool.back();
+    _quizBufferPool.pop_back();
+    if (b.ldT == _ldT && b.askedWords == quiz->hAsked.size()) {
+      quiz->dPrior = b.dPrior;
+      quiz->dAsked = b.dAsked;
+    } else {  // the knowledge base changed shape since that quiz was released
+      hipFree(b.dPrior);
+      hipFree(b.dAsked);
+    }
+  }
+  if (quiz->dPrior == nullptr) {
+    he = hipMalloc(&quiz->dPrior, (size_t)_ldT * sizeof(double));
+    if (he == hipSuccess) he = hipMalloc(&quiz->dAsked, quiz->hAsked.size() * sizeof(uint32_t));
+  }
+  if (he == hipSuccess)  // (StartQuiz: nothing asked yet, no host source needed; ResumeQuiz synchronises further down)
+    he = nAnswered == 0 ? hipMemsetAsync(quiz->dAsked, 0, quiz->hAsked.size() * sizeof(uint32_t), _stream)
+                        : hipMemcpyAsync(quiz->dAsked, quiz->hAsked.data(), quiz->hAsked.size() * sizeof(uint32_t),
+                                         hipMemcpyHostToDevice, _stream);
   if (he != hipSuccess) return fail(HipErr(he, "quiz allocation"));
   const KbView kb = View();
   if (nAnswered == 0) {
     // CECreateQuizStart::UpdateLikelihoods, reference PqaCore/CECreateQuizOperation.cpp:22-53
     he = LaunchStartQuiz(kb, quiz->dPrior, _optWorkers, _stream);
     if (he != hipSuccess) return fail(HipErr(he, "LaunchStartQuiz"));
-    he = hipStreamSynchronize(_stream);  // the H2D source (hAsked) must stay alive until the copy ran
-    if (he != hipSuccess) return fail(HipErr(he, "StartQuiz sync"));
+    // no synchronisation: every reader of the prior or the bitmap is ordered behind these on the engine's stream
   } else {
     // CECreateQuizResume::UpdateLikelihoods, reference PqaCore/CECreateQuizOperation.cpp:55-83
     if (nAnswered > _aqCapacity) {
@@ -392,9 +420,8 @@ Error HipEngine::ReleaseQuiz(int64_t iQuiz) {
   Quiz *q = UseQuiz(err, iQuiz);
   if (!q) return err;
   hipSetDevice(_device);
-  hipStreamSynchronize(_stream);
   UnassignQuiz(iQuiz);
-  DestroyQuiz(q);
+  DestroyQuiz(q);  // the buffers go to the pool; their next user is ordered behind pending work on the engine's stream
   return Error();
 }
 
@@ -492,6 +519,22 @@ Error HipEngine::EnqueueSelectArgmaxFlag(int64_t iQuiz, void *pOut, void *pFlag,
   return Error();
 }
 
+Error HipEngine::WaitFlag(volatile uint64_t *flag, uint64_t value, const char *what) {
+  const auto t0 = std::chrono::steady_clock::now();
+  uint64_t spins = 0;
+  while (*flag != value) {
+    if ((++spins & 0xFFF) == 0) {
+      if (hipStreamQuery(_stream) == hipSuccess && *flag != value) {  // the kernel retired without publishing
+        const hipError_t he = hipStreamSynchronize(_stream);
+        if (he != hipSuccess || *flag != value) return HipErr(he == hipSuccess ? hipErrorUnknown : he, what);
+      }
+      if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(30)) return HipErr(hipErrorNotReady, what);
+    }
+  }
+  std::atomic_thread_fence(std::memory_order_acquire);
+  return Error();
+}
+
 int64_t HipEngine::NextQuestionArgmax(Error &err, int64_t iQuiz) {
   std::lock_guard<std::mutex> lk(_mu);
   err = CheckRegular("compute next question");
@@ -505,23 +548,8 @@ int64_t HipEngine::NextQuestionArgmax(Error &err, int64_t iQuiz) {
   const FusedSelect fs{_dSelScratch, &_hPinned->sel, &_hPinned->seq, seq, 0, 0, seq};
   hipError_t he = LaunchEvalQuestions(View(), q->dPrior, q->dAsked, 0, _Q, _dPriority, (int)_optEvalVariant, &fs, _stream);
   if (he != hipSuccess) { err = HipErr(he, "NextQuestionArgmax"); return -1; }
-  volatile uint64_t *flag = &_hPinned->seq;
-  const auto t0 = std::chrono::steady_clock::now();
-  uint64_t spins = 0;
-  while (*flag != seq) {
-    if ((++spins & 0xFFF) == 0) {
-      if (hipStreamQuery(_stream) == hipSuccess && *flag != seq) {  // the kernel retired without publishing
-        if ((he = hipStreamSynchronize(_stream)) != hipSuccess || *flag != seq) {
-          err = HipErr(he == hipSuccess ? hipErrorUnknown : he, "NextQuestionArgmax (result flag)");
-          return -1;
-        }
-      }
-      if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(30)) {
-        err = HipErr(hipErrorNotReady, "NextQuestionArgmax (timeout)");
-        return -1;
-      }
-    }
-  }
+  err = WaitFlag(&_hPinned->seq, seq, "NextQuestionArgmax");
+  if (!err.ok()) return -1;
   std::atomic_thread_fence(std::memory_order_acquire);
   if (_hPinned->sel.index == -3) {  // the sweep's finisher gave up: some workgroup of the launch never reported
     err = HipErr(hipErrorLaunchFailure, "NextQuestionArgmax (incomplete sweep)");
@@ -603,10 +631,13 @@ int64_t HipEngine::NextQuestionSampled(Error &err, int64_t iQuiz, uint64_t rnd) 
   const KbView kb = View();
   const int64_t nSub = _optEvalSubtasks ? _optEvalSubtasks : 8 * _optWorkers;  // reference PqaCore/CpuEngine.cpp:339
   hipError_t he = LaunchEvalQuestions(kb, q->dPrior, q->dAsked, 0, _Q, _dPriority, (int)_optEvalVariant, nullptr, _stream);
-  if (he == hipSuccess) he = LaunchSelectSampled(_dPriority, _dQGap, q->dAsked, 0, _Q, nSub, rnd, _dRunLength, _dSel, _stream);
-  if (he == hipSuccess) he = hipMemcpyAsync(&_hPinned->sel, _dSel, sizeof(SelectResult), hipMemcpyDeviceToHost, _stream);
-  if (he == hipSuccess) he = hipStreamSynchronize(_stream);
+  const uint64_t op = ++_opSeq;  // the selector writes its record and then this number into host-coherent memory
+  if (he == hipSuccess)
+    he = LaunchSelectSampled(_dPriority, _dQGap, q->dAsked, 0, _Q, nSub, rnd, _dRunLength, &_hPinned->sel, &_hPinned->opFlag,
+                             op, _stream);
   if (he != hipSuccess) { err = HipErr(he, "NextQuestionSampled"); return -1; }
+  err = WaitFlag(&_hPinned->opFlag, op, "NextQuestionSampled");
+  if (!err.ok()) return -1;
   return FinishSelection(err, q, _hPinned->sel.index);
 }
 
@@ -662,12 +693,11 @@ Error HipEngine::RecordAnswerImpl(int64_t iQuiz, int64_t iAnswer, bool remote) {
   hipSetDevice(_device);
   const int64_t ql = aq - _qFirst;
   BitSet(q->hAsked, ql, true);
-  const size_t w = (size_t)(ql >> 5);
-  HIP_TRY(hipMemcpyAsync(q->dAsked + w, &q->hAsked[w], sizeof(uint32_t), hipMemcpyHostToDevice, _stream));
   // NLooseWorkers = max(1, hw - 1): reference PqaCore/CEQuiz.h:98, PqaCore/BaseCpuEngine.cpp:22
   const int64_t nLoose = std::max<int64_t>(1, _optWorkers - 1);
-  HIP_TRY(LaunchRecordAnswer(View(), q->dPrior, ql, iAnswer, nLoose, _stream));
-  HIP_TRY(hipStreamSynchronize(_stream));  // the 4-byte H2D source lives in hAsked; keep the call synchronous like the reference
+  // One launch, no copy, no synchronisation: the kernel also sets the question's bit in the device bitmap, and everything
+  // that reads the posterior or the bitmap afterwards is ordered behind it on the engine's stream.
+  HIP_TRY(LaunchRecordAnswer(View(), q->dPrior, q->dAsked, ql, iAnswer, nLoose, _stream));
   return Error();
 }
 
@@ -745,22 +775,16 @@ int64_t HipEngine::ListTopTargets(Error &err, int64_t iQuiz, int64_t maxCount, C
   hipSetDevice(_device);
   const int64_t want = std::min<int64_t>(maxCount, _T);
   if (want <= 256) {
-    if (want > _topCapacity) {
-      hipFree(_dTop);
-      _dTop = nullptr;
-      _topCapacity = 256;
-      if (hipMalloc(&_dTop, (size_t)_topCapacity * sizeof(RatedTargetDev)) != hipSuccess) {
-        _topCapacity = 0;
-        err = Error::Make(ErrCode::Internal, "hipMalloc failed for the top-targets buffer.");
-        return -1;
-      }
-    }
-    hipError_t he = LaunchTopTargets(View(), q->dPrior, want, _dTop, _dNOut, _stream);
-    if (he == hipSuccess) he = hipMemcpyAsync(&_hPinned->nOut, _dNOut, sizeof(int64_t), hipMemcpyDeviceToHost, _stream);
-    if (he == hipSuccess) he = hipMemcpyAsync(pDest, _dTop, (size_t)want * sizeof(RatedTargetDev), hipMemcpyDeviceToHost, _stream);
-    if (he == hipSuccess) he = hipStreamSynchronize(_stream);
+    // the kernel lists straight into host-coherent memory and then stores the operation number: no copy, no synchronise
+    const uint64_t op = ++_opSeq;
+    const hipError_t he = LaunchTopTargets(View(), q->dPrior, want, _hPinned->top, &_hPinned->nOut, &_hPinned->opFlag, op, _stream);
     if (he != hipSuccess) { err = HipErr(he, "ListTopTargets"); return -1; }
-    return _hPinned->nOut;
+    err = WaitFlag(&_hPinned->opFlag, op, "ListTopTargets");
+    if (!err.ok()) return -1;
+    const int64_t n = _hPinned->nOut;
+    static_assert(sizeof(RatedTargetDev) == sizeof(CiRatedTarget), "listed straight into the caller's layout");
+    std::memcpy(pDest, _hPinned->top, (size_t)n * sizeof(RatedTargetDev));
+    return n;
   }
   // large lists: sort on the host (the listing is O(T log T) on 8T bytes, not a cube operation)
   std::vector<double> pri((size_t)_T);

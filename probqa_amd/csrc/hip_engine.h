@@ -166,8 +166,20 @@ class HipEngine {
   int64_t _aqCapacity = 0;
   RatedTargetDev *_dTop = nullptr;
   int64_t _topCapacity = 0;
+  // Released quizzes' device buffers, reused by the next StartQuiz / ResumeQuiz of the same dimensions: hipMalloc / hipFree
+  // cost tens of microseconds and hipFree synchronises the device.  Reuse is ordered by the engine's stream.
+  struct QuizBuffers { double *dPrior; uint32_t *dAsked; int64_t ldT; size_t askedWords; };
+  std::vector<QuizBuffers> _quizBufferPool;
+  void DropQuizBufferPool();
   SelectResult *_dSel = nullptr;
-  struct Pinned { SelectResult sel; uint64_t seq; int64_t status[2]; int64_t nOut; };
+  struct Pinned {  // host-coherent: written by kernels, polled / read by the host without copies
+    SelectResult sel; uint64_t seq; int64_t status[2]; int64_t nOut;
+    uint64_t opFlag;               // completion flag of the sampled selection / top-targets kernels
+    RatedTargetDev top[256];
+  };
+  uint64_t _opSeq = 0;
+  // spin on a host-coherent flag until it holds `value` (the kernel's last store); falls back to the stream's status
+  Error WaitFlag(volatile uint64_t *flag, uint64_t value, const char *what);
   SelectResult *_dSelScratch = nullptr;  // its per-workgroup winner records
   // batched selections (NextQuestionArgmaxBatch); allocated on first use
   static constexpr int64_t kMaxBatch = 256, kBatchGrid = 1024;

@@ -93,7 +93,8 @@ __device__ __forceinline__ bool cand_better(const Cand &a, const Cand &b) {
 // maxCount rounds of workgroup argmax with a "taken" bitmap in LDS.  Meant for small maxCount (top-1 .. top-few-100).
 __global__ __launch_bounds__(1024) void top_targets_kernel(const double *__restrict__ prior,
                                                            const uint32_t *__restrict__ tgap, int64_t T,
-                                                           int64_t maxCount, RatedTargetDev *out, int64_t *nOut) {
+                                                           int64_t maxCount, RatedTargetDev *out, int64_t *nOut,
+                                                           uint64_t *flag, uint64_t flagValue) {
   extern __shared__ uint32_t taken[];  // ceil(T/32) words
   __shared__ double sp[16];
   __shared__ int64_t st[16];
@@ -138,7 +139,13 @@ __global__ __launch_bounds__(1024) void top_targets_kernel(const double *__restr
     if (sWin < 0) break;
     listed++;
   }
-  if (threadIdx.x == 0) *nOut = listed;
+  if (threadIdx.x == 0) {
+    *nOut = listed;
+    if (flag != nullptr) {  // `out` / `nOut` / `flag` in host-coherent memory: the host polls, no copy, no synchronise
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+      __hip_atomic_store(flag, flagValue, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
 }
 
 unsigned grid_for(int64_t n, int threads) {
@@ -239,10 +246,11 @@ hipError_t LaunchTrain(double *cube, double *vB, int64_t K, int64_t ldT, const i
 }
 
 hipError_t LaunchTopTargets(const KbView &kb, const double *prior, int64_t maxCount, RatedTargetDev *out,
-                            int64_t *nOut, hipStream_t stream) {
+                            int64_t *nOut, uint64_t *flag, uint64_t flagValue, hipStream_t stream) {
   const size_t shmem = (size_t)((kb.T + 31) / 32) * sizeof(uint32_t);
   if (shmem > 60 * 1024) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(top_targets_kernel, dim3(1), dim3(1024), shmem, stream, prior, kb.tgap, kb.T, maxCount, out, nOut);
+  hipLaunchKernelGGL(top_targets_kernel, dim3(1), dim3(1024), shmem, stream, prior, kb.tgap, kb.T, maxCount, out, nOut,
+                     flag, flagValue);
   return hipGetLastError();
 }
 

@@ -74,11 +74,11 @@ hipError_t LaunchSelectArgmax(const double *priority, const uint32_t *qgap, cons
 // runLength: scratch of n doubles. rnd: the 64-bit random number the reference would draw.
 hipError_t LaunchSelectSampled(const double *priority, const uint32_t *qgap, const uint32_t *asked, int64_t qFirst,
                                int64_t n, int64_t nSubtasks, uint64_t rnd, double *runLength, SelectResult *out,
-                               hipStream_t stream);
+                               uint64_t *flag, uint64_t flagValue, hipStream_t stream);
 
 // ---- prior updates (single workgroup, O(T)); nWorkers = emulated CPU worker count that fixes the summation order
 hipError_t LaunchStartQuiz(const KbView &kb, double *prior, int64_t nWorkers, hipStream_t stream);
-hipError_t LaunchRecordAnswer(const KbView &kb, double *prior, int64_t iQuestion, int64_t iAnswer, int64_t nWorkers,
+hipError_t LaunchRecordAnswer(const KbView &kb, double *prior, uint32_t *asked, int64_t iQuestion, int64_t iAnswer, int64_t nWorkers,
                               hipStream_t stream);
 // aqs: device array of (question, answer) int64 pairs.  exps: scratch of ldT int64.  status: device int64[2]
 // {error code (0 / 16 = I64Underflow), fullMax}.  bugCompat reproduces PqaCore/CEUpdatePriorsSubtaskMul.cpp:53.
@@ -105,7 +105,8 @@ hipError_t LaunchMoveTargets(double *cube, double *vB, int64_t K, int64_t ldT, i
                              int64_t n, hipStream_t stream);
 // ListTopTargets (PqaCore/CEListTopTargetsAlgorithm.cpp): top maxCount (prob,target) pairs, descending, gaps skipped.
 struct RatedTargetDev { int64_t iTarget; double prob; };
+// (flag != nullptr: out / nOut / flag are host-coherent; the kernel stores flagValue to *flag after its results)
 hipError_t LaunchTopTargets(const KbView &kb, const double *prior, int64_t maxCount, RatedTargetDev *out,
-                            int64_t *nOut, hipStream_t stream);
+                            int64_t *nOut, uint64_t *flag, uint64_t flagValue, hipStream_t stream);
 
 }  // namespace pqa

@@ -76,8 +76,12 @@ __global__ __launch_bounds__(kThreads) void start_quiz_kernel(PriorArgs a) {
   for (int64_t t = threadIdx.x; t < 4 * nVects; t += blockDim.x) a.prior[t] = a.prior[t] / total;  // CEDivTargPriors :19
 }
 
-__global__ __launch_bounds__(kThreads) void record_answer_kernel(PriorArgs a, int64_t iQuestion, int64_t iAnswer) {
+__global__ __launch_bounds__(kThreads) void record_answer_kernel(PriorArgs a, int64_t iQuestion, int64_t iAnswer,
+                                                                 uint32_t *asked) {
   extern __shared__ double lds[];
+  // CEQuiz::RecordAnswer marks the question as asked (PqaCore/CEQuiz.h:92); done here, in stream order with the sweeps
+  // that read the bitmap, so that the host call needs neither a copy nor a synchronisation
+  if (threadIdx.x == 0) asked[iQuestion >> 5] |= 1u << (iQuestion & 31);
   const int64_t nVects = (a.T + 3) >> 2;
   const double *rowA = a.cube + (iQuestion * (a.K + 1) + iAnswer) * a.ldT;  // CERecordAnswerSubtaskMul.cpp:25
   const double *rowD = a.cube + (iQuestion * (a.K + 1) + a.K) * a.ldT;      // :26
@@ -189,11 +193,11 @@ hipError_t LaunchStartQuiz(const KbView &kb, double *prior, int64_t nWorkers, hi
   return hipGetLastError();
 }
 
-hipError_t LaunchRecordAnswer(const KbView &kb, double *prior, int64_t iQuestion, int64_t iAnswer, int64_t nWorkers,
-                              hipStream_t stream) {
+hipError_t LaunchRecordAnswer(const KbView &kb, double *prior, uint32_t *asked, int64_t iQuestion, int64_t iAnswer,
+                              int64_t nWorkers, hipStream_t stream) {
   if (nWorkers < 1 || nWorkers > 4096) return hipErrorInvalidValue;
   hipLaunchKernelGGL(record_answer_kernel, dim3(1), dim3(kThreads), sum_lds_bytes(nWorkers), stream,
-                     make_args(kb, prior, nWorkers), iQuestion, iAnswer);
+                     make_args(kb, prior, nWorkers), iQuestion, iAnswer, asked);
   return hipGetLastError();
 }
 

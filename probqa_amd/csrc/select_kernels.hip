@@ -83,7 +83,7 @@ __global__ __launch_bounds__(1024) void select_sampled_kernel(const double *__re
                                                               const uint32_t *__restrict__ qgap,
                                                               const uint32_t *__restrict__ asked, int64_t qFirst,
                                                               int64_t n, int64_t nWorkers, uint64_t rnd,
-                                                              double *__restrict__ runLength, SelectResult *out) {
+                                                              double *__restrict__ runLength, SelectResult *out, uint64_t *flag, uint64_t flagValue) {
   extern __shared__ double grand[];  // nSubtasks doubles
   const int64_t quot = n / nWorkers, rem = n % nWorkers;
   const int64_t nSubtasks = (quot == 0) ? rem : nWorkers;  // CalcSplit stops once the items run out
@@ -123,6 +123,10 @@ __global__ __launch_bounds__(1024) void select_sampled_kernel(const double *__re
     }
     out->priority = totG;
     out->index = sel;
+    if (flag != nullptr) {  // `out` and `flag` in host-coherent memory: the host polls instead of copying + synchronising
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+      __hip_atomic_store(flag, flagValue, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
   }
 }
 
@@ -138,12 +142,12 @@ hipError_t LaunchSelectArgmax(const double *priority, const uint32_t *qgap, cons
 
 hipError_t LaunchSelectSampled(const double *priority, const uint32_t *qgap, const uint32_t *asked, int64_t qFirst,
                                int64_t n, int64_t nSubtasks, uint64_t rnd, double *runLength, SelectResult *out,
-                               hipStream_t stream) {
+                               uint64_t *flag, uint64_t flagValue, hipStream_t stream) {
   if (n <= 0 || nSubtasks <= 0) return hipErrorInvalidValue;
   const size_t shmem = (size_t)nSubtasks * sizeof(double);
   if (shmem > 64 * 1024) return hipErrorInvalidValue;
   hipLaunchKernelGGL(select_sampled_kernel, dim3(1), dim3(1024), shmem, stream, priority, qgap, asked, qFirst, n, nSubtasks,
-                     rnd, runLength, out);
+                     rnd, runLength, out, flag, flagValue);
   return hipGetLastError();
 }
 
