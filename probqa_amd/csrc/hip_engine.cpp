@@ -774,7 +774,7 @@ int64_t HipEngine::ListTopTargets(Error &err, int64_t iQuiz, int64_t maxCount, C
   if (!pDest) { err = Error::Make(ErrCode::NullArgument, "Nullptr is passed in place of the destination."); return -1; }
   hipSetDevice(_device);
   const int64_t want = std::min<int64_t>(maxCount, _T);
-  if (want <= 256) {
+  if (want <= 256 && _T <= 16384) {  // (the kernel keeps every target in registers: 16 per thread at most)
     // the kernel lists straight into host-coherent memory and then stores the operation number: no copy, no synchronise
     const uint64_t op = ++_opSeq;
     const hipError_t he = LaunchTopTargets(View(), q->dPrior, want, _hPinned->top, &_hPinned->nOut, &_hPinned->opFlag, op, _stream);

@@ -90,26 +90,32 @@ __device__ __forceinline__ bool cand_better(const Cand &a, const Cand &b) {
   return (a.p > b.p) || (a.p == b.p && a.t < b.t);
 }
 
-// maxCount rounds of workgroup argmax with a "taken" bitmap in LDS.  Meant for small maxCount (top-1 .. top-few-100).
+// Top-maxCount targets by probability (descending, lower index first on ties, gaps never listed).  Every thread holds its
+// E targets in registers; a round is one wave argmax by shuffles, one LDS exchange, ONE barrier (the per-wave results
+// alternate between two LDS rows by round parity), after which every thread knows the round's winner and its owner
+// retires it.  Meant for small maxCount (top-1 .. top-256); T <= 1024*E.
+template <int E>
 __global__ __launch_bounds__(1024) void top_targets_kernel(const double *__restrict__ prior,
                                                            const uint32_t *__restrict__ tgap, int64_t T,
                                                            int64_t maxCount, RatedTargetDev *out, int64_t *nOut,
                                                            uint64_t *flag, uint64_t flagValue) {
-  extern __shared__ uint32_t taken[];  // ceil(T/32) words
-  __shared__ double sp[16];
-  __shared__ int64_t st[16];
-  __shared__ int64_t sWin;
-  const int64_t nWords = (T + 31) / 32;
-  for (int64_t i = threadIdx.x; i < nWords; i += blockDim.x) taken[i] = tgap[i];  // gaps are never listed
-  __syncthreads();
+  __shared__ double sp[2][16];
+  __shared__ int64_t st[2][16];
+  Cand mine[E];
+#pragma unroll
+  for (int e = 0; e < E; e++) {
+    const int64_t t = threadIdx.x + (int64_t)e * 1024;
+    const bool ok = t < T && !bit_test(tgap, t);
+    mine[e].p = ok ? prior[t] : 0.0;
+    mine[e].t = ok ? t : -1;
+  }
+  const int lane = threadIdx.x % kWave, wave = threadIdx.x / kWave;
   int64_t listed = 0;
   for (int64_t r = 0; r < maxCount; r++) {
-    Cand b = {0.0, -1};
-    for (int64_t t = threadIdx.x; t < T; t += blockDim.x) {
-      if ((taken[t >> 5] >> (t & 31)) & 1u) continue;
-      const Cand c = {prior[t], t};
-      if (cand_better(c, b)) b = c;
-    }
+    Cand b = mine[0];
+#pragma unroll
+    for (int e = 1; e < E; e++)
+      if (cand_better(mine[e], b)) b = mine[e];
 #pragma unroll
     for (int m = kWave / 2; m >= 1; m >>= 1) {
       Cand o;
@@ -117,26 +123,25 @@ __global__ __launch_bounds__(1024) void top_targets_kernel(const double *__restr
       o.t = __shfl_xor(b.t, m, kWave);
       if (cand_better(o, b)) b = o;
     }
-    if (threadIdx.x % kWave == 0) {
-      sp[threadIdx.x / kWave] = b.p;
-      st[threadIdx.x / kWave] = b.t;
+    const int par = (int)(r & 1);
+    if (lane == 0) {
+      sp[par][wave] = b.p;
+      st[par][wave] = b.t;
     }
     __syncthreads();
+    Cand w = {sp[par][0], st[par][0]};
+    for (int i = 1; i < 16; i++) {
+      const Cand c = {sp[par][i], st[par][i]};
+      if (cand_better(c, w)) w = c;
+    }
+    if (w.t < 0) break;                 // the same for every thread
     if (threadIdx.x == 0) {
-      Cand w = {sp[0], st[0]};
-      for (int i = 1; i < (int)(blockDim.x / kWave); i++) {
-        const Cand c = {sp[i], st[i]};
-        if (cand_better(c, w)) w = c;
-      }
-      sWin = w.t;
-      if (w.t >= 0) {
-        out[r].iTarget = w.t;
-        out[r].prob = w.p;
-        taken[w.t >> 5] |= 1u << (w.t & 31);
-      }
+      out[r].iTarget = w.t;
+      out[r].prob = w.p;
     }
-    __syncthreads();
-    if (sWin < 0) break;
+#pragma unroll
+    for (int e = 0; e < E; e++)
+      if (mine[e].t == w.t) mine[e].t = -1;
     listed++;
   }
   if (threadIdx.x == 0) {
@@ -247,10 +252,14 @@ hipError_t LaunchTrain(double *cube, double *vB, int64_t K, int64_t ldT, const i
 
 hipError_t LaunchTopTargets(const KbView &kb, const double *prior, int64_t maxCount, RatedTargetDev *out,
                             int64_t *nOut, uint64_t *flag, uint64_t flagValue, hipStream_t stream) {
-  const size_t shmem = (size_t)((kb.T + 31) / 32) * sizeof(uint32_t);
-  if (shmem > 60 * 1024) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(top_targets_kernel, dim3(1), dim3(1024), shmem, stream, prior, kb.tgap, kb.T, maxCount, out, nOut,
-                     flag, flagValue);
+#define PQA_TOP(E)                                                                                                     \
+  hipLaunchKernelGGL(top_targets_kernel<E>, dim3(1), dim3(1024), 0, stream, prior, kb.tgap, kb.T, maxCount, out, nOut, \
+                     flag, flagValue)
+  if (kb.T <= 1024) PQA_TOP(1);
+  else if (kb.T <= 4096) PQA_TOP(4);
+  else if (kb.T <= 16384) PQA_TOP(16);
+  else return hipErrorInvalidValue;     // the host-side listing takes over (hip_engine.cpp)
+#undef PQA_TOP
   return hipGetLastError();
 }
 
