@@ -11,4 +11,4 @@ for line in sys.stdin:
 : > gpurun_out/variants.txt
 for v in $1; do python bench.py --steps 300 --warmup 20 --variant $v --no-cpu-baseline 2>>gpurun_out/bench.err | python -c "$fmt" >> gpurun_out/variants.txt; done
 for v in $2; do python bench.py --config M --steps 20 --warmup 3 --variant $v --no-cpu-baseline 2>>gpurun_out/bench.err | python -c "$fmt" >> gpurun_out/variants.txt; done
-python tools/relerr.py > gpurun_out/relerr.txt 2>&1
+
