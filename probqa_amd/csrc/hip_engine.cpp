@@ -243,6 +243,7 @@ Error HipEngine::SetOption(const char *name, int64_t value) {
   else if (n == "eval_subtasks") { if (value < 0 || value > 8192) goto bad; _optEvalSubtasks = value; }
   else if (n == "eval_variant") { if (value < 0) goto bad; _optEvalVariant = value; }
   else if (n == "bug_compat") { _optBugCompat = value ? 1 : 0; }
+  else if (n == "top_cache") { if (value < 0 || value > 256) goto bad; _optTopCache = value; }
   else if (n == "seed") { uint64_t s = (uint64_t)value; _rng[0] = SplitMix64(s); _rng[1] = SplitMix64(s); }
   else goto bad;
   return Error();
@@ -257,6 +258,7 @@ int64_t HipEngine::GetOption(const char *name) const {
   if (n == "eval_subtasks") return _optEvalSubtasks ? _optEvalSubtasks : 8 * _optWorkers;
   if (n == "eval_variant") return _optEvalVariant;
   if (n == "bug_compat") return _optBugCompat;
+  if (n == "top_cache") return _optTopCache;
   if (n == "ldT") return _ldT;
   if (n == "device") return _device;
   return -1;
@@ -300,6 +302,7 @@ Quiz *HipEngine::UseQuiz(Error &err, int64_t iQuiz) {
 
 void HipEngine::DestroyQuiz(Quiz *q) {
   if (!q) return;
+  if (_topOwner == q) _topOwner = nullptr;
   if (q->dPrior && q->dAsked && _quizBufferPool.size() < 4096)
     _quizBufferPool.push_back(QuizBuffers{q->dPrior, q->dAsked, _ldT, q->hAsked.size()});
   else {
@@ -689,6 +692,7 @@ Error HipEngine::RecordAnswerImpl(int64_t iQuiz, int64_t iAnswer, bool remote) {
                                : "The active question belongs to another shard: use PqaHip_RecordAnswerRemote.");
   q->answers.push_back(AQ{aq, iAnswer});
   q->activeQuestion = -1;
+  q->priorVersion++;  // (remote: the caller writes the owner's posterior into the quiz's buffer)
   if (!local) return Error();
   hipSetDevice(_device);
   const int64_t ql = aq - _qFirst;
@@ -697,7 +701,11 @@ Error HipEngine::RecordAnswerImpl(int64_t iQuiz, int64_t iAnswer, bool remote) {
   const int64_t nLoose = std::max<int64_t>(1, _optWorkers - 1);
   // One launch, no copy, no synchronisation: the kernel also sets the question's bit in the device bitmap, and everything
   // that reads the posterior or the bitmap afterwards is ordered behind it on the engine's stream.
-  HIP_TRY(LaunchRecordAnswer(View(), q->dPrior, q->dAsked, ql, iAnswer, nLoose, _stream));
+  const int64_t topCount = std::min<int64_t>(std::min<int64_t>(_optTopCache, 256), _T);
+  const uint64_t op = ++_opSeq;
+  HIP_TRY(LaunchRecordAnswer(View(), q->dPrior, q->dAsked, ql, iAnswer, nLoose, _hPinned->top, &_hPinned->nOut,
+                             &_hPinned->topFlag, op, topCount, _stream));
+  if (topCount > 0 && _T <= 16384) { _topOwner = q; _topOp = op; _topVersion = q->priorVersion; _topCount = topCount; }
   return Error();
 }
 
@@ -776,12 +784,16 @@ int64_t HipEngine::ListTopTargets(Error &err, int64_t iQuiz, int64_t maxCount, C
   const int64_t want = std::min<int64_t>(maxCount, _T);
   if (want <= 256 && _T <= 16384) {  // (the kernel keeps every target in registers: 16 per thread at most)
     // the kernel lists straight into host-coherent memory and then stores the operation number: no copy, no synchronise
-    const uint64_t op = ++_opSeq;
-    const hipError_t he = LaunchTopTargets(View(), q->dPrior, want, _hPinned->top, &_hPinned->nOut, &_hPinned->opFlag, op, _stream);
-    if (he != hipSuccess) { err = HipErr(he, "ListTopTargets"); return -1; }
-    err = WaitFlag(&_hPinned->opFlag, op, "ListTopTargets");
+    const bool cached = _topOwner == q && _topVersion == q->priorVersion;
+    if (!(cached && want <= _topCount)) {
+      const uint64_t op = ++_opSeq;
+      const hipError_t he = LaunchTopTargets(View(), q->dPrior, want, _hPinned->top, &_hPinned->nOut, &_hPinned->topFlag, op, _stream);
+      if (he != hipSuccess) { err = HipErr(he, "ListTopTargets"); return -1; }
+      _topOwner = q; _topOp = op; _topVersion = q->priorVersion; _topCount = want;
+    }
+    err = WaitFlag(&_hPinned->topFlag, _topOp, "ListTopTargets");
     if (!err.ok()) return -1;
-    const int64_t n = _hPinned->nOut;
+    const int64_t n = std::min<int64_t>(_hPinned->nOut, want);
     static_assert(sizeof(RatedTargetDev) == sizeof(CiRatedTarget), "listed straight into the caller's layout");
     std::memcpy(pDest, _hPinned->top, (size_t)n * sizeof(RatedTargetDev));
     return n;

@@ -77,6 +77,7 @@ struct Quiz {
   std::vector<uint32_t> hAsked;        // host mirror
   std::vector<AQ> answers;             // global question ids
   int64_t activeQuestion = -1;         // global id (reference CEQuiz::_activeQuestion)
+  uint64_t priorVersion = 0;           // bumped whenever the posterior changes
 };
 
 class HipEngine {
@@ -174,9 +175,15 @@ class HipEngine {
   SelectResult *_dSel = nullptr;
   struct Pinned {  // host-coherent: written by kernels, polled / read by the host without copies
     SelectResult sel; uint64_t seq; int64_t status[2]; int64_t nOut;
-    uint64_t opFlag;               // completion flag of the sampled selection / top-targets kernels
+    uint64_t opFlag;               // completion flag of the sampled selection kernel
+    uint64_t topFlag;              // completion flag of whatever listed into top[] last
     RatedTargetDev top[256];
   };
+  // top[] is a one-entry cache: RecordAnswer's kernel lists the new posterior's best targets there, and a ListTopTargets
+  // for the same quiz and posterior that asks for no more than were listed finds them without a launch
+  Quiz *_topOwner = nullptr;
+  uint64_t _topOp = 0, _topVersion = 0;
+  int64_t _topCount = 0;
   uint64_t _opSeq = 0;
   // spin on a host-coherent flag until it holds `value` (the kernel's last store); falls back to the stream's status
   Error WaitFlag(volatile uint64_t *flag, uint64_t value, const char *what);
@@ -212,6 +219,7 @@ class HipEngine {
   Mode _mode = Mode::Regular;
   // options
   int64_t _optSelect = 0, _optWorkers = 16, _optEvalSubtasks = 0, _optEvalVariant = 0, _optBugCompat = 0;
+  int64_t _optTopCache = 10;  // targets RecordAnswer's kernel lists ahead of the ListTopTargets that follows it (0: none)
   uint64_t _rng[2] = {0, 0};
 };
 

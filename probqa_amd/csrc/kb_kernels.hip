@@ -80,77 +80,13 @@ __global__ void train_kernel(double *__restrict__ cube, double *__restrict__ vB,
   if (blockIdx.x == 0 && threadIdx.x == 0) vB[iTarget] += amount;  // PqaCore/CpuEngine.cpp:172
 }
 
-struct Cand {
-  double p;
-  int64_t t;
-};
-__device__ __forceinline__ bool cand_better(const Cand &a, const Cand &b) {
-  if (b.t < 0) return a.t >= 0;
-  if (a.t < 0) return false;
-  return (a.p > b.p) || (a.p == b.p && a.t < b.t);
-}
-
-// Top-maxCount targets by probability (descending, lower index first on ties, gaps never listed).  Every thread holds its
-// E targets in registers; a round is one wave argmax by shuffles, one LDS exchange, ONE barrier (the per-wave results
-// alternate between two LDS rows by round parity), after which every thread knows the round's winner and its owner
-// retires it.  Meant for small maxCount (top-1 .. top-256); T <= 1024*E.
-template <int E>
+// ListTopTargets on the device (top_targets_publish in pqa_device.h); T <= 16384.
+static_assert(sizeof(TopOut) == sizeof(RatedTargetDev), "same record");
 __global__ __launch_bounds__(1024) void top_targets_kernel(const double *__restrict__ prior,
                                                            const uint32_t *__restrict__ tgap, int64_t T,
                                                            int64_t maxCount, RatedTargetDev *out, int64_t *nOut,
                                                            uint64_t *flag, uint64_t flagValue) {
-  __shared__ double sp[2][16];
-  __shared__ int64_t st[2][16];
-  Cand mine[E];
-#pragma unroll
-  for (int e = 0; e < E; e++) {
-    const int64_t t = threadIdx.x + (int64_t)e * 1024;
-    const bool ok = t < T && !bit_test(tgap, t);
-    mine[e].p = ok ? prior[t] : 0.0;
-    mine[e].t = ok ? t : -1;
-  }
-  const int lane = threadIdx.x % kWave, wave = threadIdx.x / kWave;
-  int64_t listed = 0;
-  for (int64_t r = 0; r < maxCount; r++) {
-    Cand b = mine[0];
-#pragma unroll
-    for (int e = 1; e < E; e++)
-      if (cand_better(mine[e], b)) b = mine[e];
-#pragma unroll
-    for (int m = kWave / 2; m >= 1; m >>= 1) {
-      Cand o;
-      o.p = __shfl_xor(b.p, m, kWave);
-      o.t = __shfl_xor(b.t, m, kWave);
-      if (cand_better(o, b)) b = o;
-    }
-    const int par = (int)(r & 1);
-    if (lane == 0) {
-      sp[par][wave] = b.p;
-      st[par][wave] = b.t;
-    }
-    __syncthreads();
-    Cand w = {sp[par][0], st[par][0]};
-    for (int i = 1; i < 16; i++) {
-      const Cand c = {sp[par][i], st[par][i]};
-      if (cand_better(c, w)) w = c;
-    }
-    if (w.t < 0) break;                 // the same for every thread
-    if (threadIdx.x == 0) {
-      out[r].iTarget = w.t;
-      out[r].prob = w.p;
-    }
-#pragma unroll
-    for (int e = 0; e < E; e++)
-      if (mine[e].t == w.t) mine[e].t = -1;
-    listed++;
-  }
-  if (threadIdx.x == 0) {
-    *nOut = listed;
-    if (flag != nullptr) {  // `out` / `nOut` / `flag` in host-coherent memory: the host polls, no copy, no synchronise
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
-      __hip_atomic_store(flag, flagValue, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-  }
+  top_targets_publish(prior, tgap, T, maxCount, reinterpret_cast<TopOut *>(out), nOut, flag, flagValue);
 }
 
 unsigned grid_for(int64_t n, int threads) {
@@ -252,14 +188,9 @@ hipError_t LaunchTrain(double *cube, double *vB, int64_t K, int64_t ldT, const i
 
 hipError_t LaunchTopTargets(const KbView &kb, const double *prior, int64_t maxCount, RatedTargetDev *out,
                             int64_t *nOut, uint64_t *flag, uint64_t flagValue, hipStream_t stream) {
-#define PQA_TOP(E)                                                                                                     \
-  hipLaunchKernelGGL(top_targets_kernel<E>, dim3(1), dim3(1024), 0, stream, prior, kb.tgap, kb.T, maxCount, out, nOut, \
-                     flag, flagValue)
-  if (kb.T <= 1024) PQA_TOP(1);
-  else if (kb.T <= 4096) PQA_TOP(4);
-  else if (kb.T <= 16384) PQA_TOP(16);
-  else return hipErrorInvalidValue;     // the host-side listing takes over (hip_engine.cpp)
-#undef PQA_TOP
+  if (kb.T > 16384) return hipErrorInvalidValue;  // the host-side listing takes over (hip_engine.cpp)
+  hipLaunchKernelGGL(top_targets_kernel, dim3(1), dim3(1024), 0, stream, prior, kb.tgap, kb.T, maxCount, out, nOut, flag,
+                     flagValue);
   return hipGetLastError();
 }
 

@@ -231,4 +231,114 @@ __device__ __forceinline__ double precise_sum4(const double *sum, const double *
   return a.get();
 }
 
+// ---- top-maxCount targets by probability -------------------------------------------------------------------------------
+// Descending probability, lower index first on ties, gaps never listed (reference PqaCore/CEListTopTargetsAlgorithm.cpp).
+// For a 1024-thread workgroup: every thread holds its E targets (t = tid + e*1024) in registers; a round is one wave
+// argmax by DPP / permlane swaps, one LDS exchange and ONE barrier (the per-wave results alternate between two LDS rows by
+// round parity), one 16-lane row argmax over the 16 waves' results, after which every thread knows the round's winner and
+// its owner retires it: ~0.3 us per round.  T <= 1024*E <= 16384; small maxCount.
+struct TopOut {
+  int64_t iTarget;
+  double prob;
+};
+struct TopCand {
+  double p;
+  int t;        // target index (T <= 16384), < 0: none
+};
+__device__ __forceinline__ bool top_better(const TopCand &a, const TopCand &b) {
+  if (b.t < 0) return a.t >= 0;
+  if (a.t < 0) return false;
+  return (a.p > b.p) || (a.p == b.p && a.t < b.t);
+}
+template <int CTRL>
+__device__ __forceinline__ TopCand top_dpp(const TopCand &c) {
+  return TopCand{mov_dpp<CTRL>(c.p), __builtin_amdgcn_update_dpp(0, c.t, CTRL, 0xF, 0xF, true)};
+}
+__device__ __forceinline__ void top_take(TopCand &b, const TopCand &o) {
+  if (top_better(o, b)) b = o;
+}
+// all-reduce (best candidate) over a 16-lane row / over the wave: DPP within rows, permlane swaps across them
+__device__ __forceinline__ TopCand row_top(TopCand b) {
+  top_take(b, top_dpp<kDppXor1>(b));
+  top_take(b, top_dpp<kDppXor2>(b));
+  top_take(b, top_dpp<kDppHalfMirror>(b));
+  top_take(b, top_dpp<kDppMirror>(b));
+  return b;
+}
+__device__ __forceinline__ TopCand wave_top(TopCand b) {
+  b = row_top(b);
+  {
+    const Pair p = swap16(b.p);
+    const auto t = __builtin_amdgcn_permlane16_swap((uint32_t)b.t, (uint32_t)b.t, false, false);
+    TopCand x{p.a, (int)t[0]}, y{p.b, (int)t[1]};
+    top_take(x, y);
+    b = x;
+  }
+  {
+    const Pair p = swap32(b.p);
+    const auto t = __builtin_amdgcn_permlane32_swap((uint32_t)b.t, (uint32_t)b.t, false, false);
+    TopCand x{p.a, (int)t[0]}, y{p.b, (int)t[1]};
+    top_take(x, y);
+    b = x;
+  }
+  return b;
+}
+template <int E>
+__device__ __forceinline__ int64_t top_targets_rounds(const double *prior, const uint32_t *tgap, int64_t T, int64_t maxCount,
+                                                      TopOut *out, double (*sp)[16], int (*st)[16]) {
+  TopCand mine[E];
+#pragma unroll
+  for (int e = 0; e < E; e++) {
+    const int64_t t = threadIdx.x + (int64_t)e * 1024;
+    const bool ok = t < T && !bit_test(tgap, t);
+    mine[e].p = ok ? prior[t] : 0.0;
+    mine[e].t = ok ? (int)t : -1;
+  }
+  const int lane = threadIdx.x % kWave, wave = threadIdx.x / kWave;
+  int64_t listed = 0;
+  for (int64_t r = 0; r < maxCount; r++) {
+    TopCand b = mine[0];
+#pragma unroll
+    for (int e = 1; e < E; e++) top_take(b, mine[e]);
+    b = wave_top(b);
+    const int par = (int)(r & 1);
+    if (lane == 0) {
+      sp[par][wave] = b.p;
+      st[par][wave] = b.t;
+    }
+    __syncthreads();
+    const TopCand w = row_top(TopCand{sp[par][lane % 16], st[par][lane % 16]});  // 16 waves -> one 16-lane row
+    if (w.t < 0) break;                 // the same for every thread
+    if (threadIdx.x == 0) out[r] = TopOut{w.t, w.p};   // `out`: LDS staging (top_targets_publish)
+#pragma unroll
+    for (int e = 0; e < E; e++)
+      if (mine[e].t == w.t) mine[e].t = -1;
+    listed++;
+  }
+  return listed;
+}
+// the list, its length and then a flag, into host-coherent memory (T <= 16384, maxCount <= 256).  The winners are staged
+// in LDS and leave in one coalesced burst at the end: a store to host memory per round costs more than the round.
+__device__ __forceinline__ void top_targets_publish(const double *prior, const uint32_t *tgap, int64_t T, int64_t maxCount,
+                                                    TopOut *out, int64_t *nOut, uint64_t *flag, uint64_t flagValue) {
+  __shared__ double sp[2][16];
+  __shared__ int st[2][16];
+  __shared__ TopOut staged[256];
+  if (maxCount > 256) maxCount = 256;
+  int64_t listed;
+  if (T <= 1024) listed = top_targets_rounds<1>(prior, tgap, T, maxCount, staged, sp, st);
+  else if (T <= 4096) listed = top_targets_rounds<4>(prior, tgap, T, maxCount, staged, sp, st);
+  else listed = top_targets_rounds<16>(prior, tgap, T, maxCount, staged, sp, st);
+  __syncthreads();
+  if ((int64_t)threadIdx.x < listed) out[threadIdx.x] = staged[threadIdx.x];
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    *nOut = listed;
+    if (flag != nullptr) {  // the host polls: no copy, no synchronise
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+      __hip_atomic_store(flag, flagValue, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+}
+
 }  // namespace pqa

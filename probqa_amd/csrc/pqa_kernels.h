@@ -66,6 +66,8 @@ hipError_t LaunchEvalQuestionsBatch(const KbView &kb, const QuizSlot *slots, int
                                     int variant, const FusedSelect &fused, hipStream_t stream);
 const char *EvalVariantName(const KbView &kb, int variant);
 
+struct RatedTargetDev { int64_t iTarget; double prob; };  // == CiRatedTarget
+
 // ---- selectors over priority[0..n) (questions qFirst..qFirst+n of the bitmaps); the reported index is
 // (position in priority[]) + outBase
 hipError_t LaunchSelectArgmax(const double *priority, const uint32_t *qgap, const uint32_t *asked, int64_t qFirst,
@@ -78,8 +80,11 @@ hipError_t LaunchSelectSampled(const double *priority, const uint32_t *qgap, con
 
 // ---- prior updates (single workgroup, O(T)); nWorkers = emulated CPU worker count that fixes the summation order
 hipError_t LaunchStartQuiz(const KbView &kb, double *prior, int64_t nWorkers, hipStream_t stream);
-hipError_t LaunchRecordAnswer(const KbView &kb, double *prior, uint32_t *asked, int64_t iQuestion, int64_t iAnswer, int64_t nWorkers,
-                              hipStream_t stream);
+// topOut (optional, host-coherent with topN / topFlag): also list the new posterior's topCount best targets, then store
+// topFlagValue to *topFlag.
+hipError_t LaunchRecordAnswer(const KbView &kb, double *prior, uint32_t *asked, int64_t iQuestion, int64_t iAnswer,
+                              int64_t nWorkers, RatedTargetDev *topOut, int64_t *topN, uint64_t *topFlag,
+                              uint64_t topFlagValue, int64_t topCount, hipStream_t stream);
 // aqs: device array of (question, answer) int64 pairs.  exps: scratch of ldT int64.  status: device int64[2]
 // {error code (0 / 16 = I64Underflow), fullMax}.  bugCompat reproduces PqaCore/CEUpdatePriorsSubtaskMul.cpp:53.
 hipError_t LaunchResumeQuiz(const KbView &kb, double *prior, int64_t *exps, const int64_t *aqs, int64_t nAnswered,
@@ -104,7 +109,6 @@ hipError_t LaunchFillTargets(double *cube, double *vB, int64_t K, int64_t ldT, i
 hipError_t LaunchMoveTargets(double *cube, double *vB, int64_t K, int64_t ldT, int64_t nQ, const int64_t *moves,
                              int64_t n, hipStream_t stream);
 // ListTopTargets (PqaCore/CEListTopTargetsAlgorithm.cpp): top maxCount (prob,target) pairs, descending, gaps skipped.
-struct RatedTargetDev { int64_t iTarget; double prob; };
 // (flag != nullptr: out / nOut / flag are host-coherent; the kernel stores flagValue to *flag after its results)
 hipError_t LaunchTopTargets(const KbView &kb, const double *prior, int64_t maxCount, RatedTargetDev *out,
                             int64_t *nOut, uint64_t *flag, uint64_t flagValue, hipStream_t stream);

@@ -76,8 +76,19 @@ __global__ __launch_bounds__(kThreads) void start_quiz_kernel(PriorArgs a) {
   for (int64_t t = threadIdx.x; t < 4 * nVects; t += blockDim.x) a.prior[t] = a.prior[t] / total;  // CEDivTargPriors :19
 }
 
+// `top` (optional): the call that follows RecordAnswer in every quiz loop is ListTopTargets (PqaClient.cpp:185, the website,
+// DichotomyTest.cpp:91), and a dependent launch costs ~8 us of dispatch whatever its size -- so the new posterior's top
+// targets are listed here, into host-coherent memory, and ListTopTargets finds them waiting.
+struct TopRequest {
+  TopOut *out;
+  int64_t *nOut;
+  uint64_t *flag;
+  uint64_t flagValue;
+  int64_t count;       // 0: no listing
+};
+
 __global__ __launch_bounds__(kThreads) void record_answer_kernel(PriorArgs a, int64_t iQuestion, int64_t iAnswer,
-                                                                 uint32_t *asked) {
+                                                                 uint32_t *asked, TopRequest top) {
   extern __shared__ double lds[];
   // CEQuiz::RecordAnswer marks the question as asked (PqaCore/CEQuiz.h:92); done here, in stream order with the sweeps
   // that read the bitmap, so that the host call needs neither a copy nor a synchronisation
@@ -92,6 +103,10 @@ __global__ __launch_bounds__(kThreads) void record_answer_kernel(PriorArgs a, in
   }
   const double total = reference_order_sum(a.prior, nVects, a.nWorkers, lds);
   for (int64_t t = threadIdx.x; t < 4 * nVects; t += blockDim.x) a.prior[t] = a.prior[t] / total;
+  if (top.count > 0) {
+    __syncthreads();  // (a thread lists exactly the targets it has just written; the barrier is for the shared LDS rows)
+    top_targets_publish(a.prior, a.tgap, a.T, top.count, top.out, top.nOut, top.flag, top.flagValue);
+  }
 }
 
 __device__ __forceinline__ int ceil_log2_u64(uint64_t val) {  // SRPlatform/Interface/SRMath.h:46-51
@@ -194,10 +209,13 @@ hipError_t LaunchStartQuiz(const KbView &kb, double *prior, int64_t nWorkers, hi
 }
 
 hipError_t LaunchRecordAnswer(const KbView &kb, double *prior, uint32_t *asked, int64_t iQuestion, int64_t iAnswer,
-                              int64_t nWorkers, hipStream_t stream) {
+                              int64_t nWorkers, RatedTargetDev *topOut, int64_t *topN, uint64_t *topFlag,
+                              uint64_t topFlagValue, int64_t topCount, hipStream_t stream) {
   if (nWorkers < 1 || nWorkers > 4096) return hipErrorInvalidValue;
   hipLaunchKernelGGL(record_answer_kernel, dim3(1), dim3(kThreads), sum_lds_bytes(nWorkers), stream,
-                     make_args(kb, prior, nWorkers), iQuestion, iAnswer, asked);
+                     make_args(kb, prior, nWorkers), iQuestion, iAnswer, asked,
+                     TopRequest{reinterpret_cast<TopOut *>(topOut), topN, topFlag, topFlagValue,
+                                (topOut && kb.T <= 16384) ? topCount : 0});
   return hipGetLastError();
 }
 

@@ -257,3 +257,40 @@ def test_batched_argmax_equals_one_by_one(factory):
         eng.record_answer(a, 1)
     assert eng.next_question_argmax_batch([a, b]) == [-1, eng.next_question_argmax(b)]
     eng.close()
+
+
+def test_top_targets_cache_behind_record_answer(factory):
+    """RecordAnswer's kernel lists the new posterior's best targets ahead of the ListTopTargets that follows it; whatever
+    path serves the list (that cache, or a launch), it is the descending-probability, lower-index-first listing of the
+    quiz's CURRENT posterior without gaps."""
+    K, Q, T = 4, 30, 500
+    eng, *_ = make(factory, K, Q, T, seed=8)
+    eng.set_target_gaps([3, 250, 499])
+    eng.set_option("select", 1)
+
+    def expect(quiz, n):
+        p = eng.get_priors(quiz)
+        order = sorted((t for t in range(T) if t not in (3, 250, 499)), key=lambda t: (-p[t], t))[:n]
+        return [(t, p[t]) for t in order]
+
+    def listed(quiz, n):
+        return [(r.i_target, r.prob) for r in eng.list_top_targets(quiz, n)]
+
+    a, b = eng.start_quiz(), eng.start_quiz()
+    rng = np.random.default_rng(3)
+    for step in range(6):
+        for quiz in (a, b):
+            eng.next_question(quiz)
+            eng.record_answer(quiz, int(rng.integers(0, K)))
+        # b answered last: its list is cached, a's is not; 5 fits the cache (10), 16 and 40 do not
+        for quiz, n in ((b, 5), (a, 5), (b, 16), (b, 40), (a, 16), (a, 1), (b, 1)):
+            assert listed(quiz, n) == expect(quiz, n), (step, quiz, n)
+    eng.set_option("top_cache", 0)
+    eng.next_question(a)
+    eng.record_answer(a, 0)
+    assert listed(a, 7) == expect(a, 7)
+    assert len(listed(a, 1000)) == T - 3          # more than there are: every non-gap target, host-side path
+    eng.release_quiz(a)
+    c = eng.start_quiz()                          # may reuse a's slot and buffers: nothing of a's list may survive
+    assert listed(c, 4) == expect(c, 4)
+    eng.close()
