@@ -655,6 +655,9 @@ hipError_t launch_reg(const EvalArgs &args, int64_t nQ, int nBatch, hipStream_t 
     }
     int perCU = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, kern, WPQ * 64, shmem) != hipSuccess || perCU < 1) perCU = 1;
+    // measured at 1000 x 5 x 1000 (wg256_np2): three resident workgroups per CU striding over the questions run the sweep in
+    // 14.9 us, four (every question its own workgroup) in 15.7, two in 17.5 -- do not rely on the register count to say 3
+    if (NP <= 2 && perCU > 3) perCU = 3;
     cachedPerCU = perCU;
     cachedShmem = shmem;
   }
