@@ -39,7 +39,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
-    ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5000,
+                    help="untimed steps first (the default is long enough for the GPU's clocks to settle: +2-4 %% at S)")
     ap.add_argument("--config", choices=sorted(CONFIGS), default="S")
     ap.add_argument("--variant", type=int, default=0, help="force an eval kernel shape (0 = auto)")
     ap.add_argument("--batch", type=int, default=-1,
