@@ -191,6 +191,20 @@ def main():
     else:
         pipelined = None
 
+    # ---- extra (not `value`): the same synchronous selection replayed from a HIP graph (SURVEY 8(d) asks for the variant)
+    graph_rate = None
+    if selector is None:
+        eng.set_option("use_graph", 1)
+        for _ in range(50):
+            eng.next_question_argmax(quiz)
+        torch.cuda.synchronize()
+        n_g = max(200, args.steps // 2)
+        tg0 = time.perf_counter()
+        for _ in range(n_g):
+            gsel = eng.next_question_argmax(quiz)
+        graph_rate = {"selections_per_sec": n_g / (time.perf_counter() - tg0), "agrees_with_launches": int(gsel) == int(sel)}
+        eng.set_option("use_graph", 0)
+
     # ---- extra (not `value`): many quizzes in flight, one launch per batch (PqaEngine_NextQuestionArgmaxBatch)
     batched = None
     if selector is None and args.batch > 0:
@@ -231,6 +245,7 @@ def main():
         "question_evals_per_sec": value * Q,
         "pipelined_selections_per_sec": pipelined,
         "batched": batched,
+        "hip_graph_replay": graph_rate,
         "roofline": {
             "bound": "hbm",
             "achieved": achieved,

@@ -38,7 +38,8 @@ PQACORE_API void *PqaEngineFactory_CreateHipEngineSharded(void *pvFactory, void 
 /* ---- options: "select" (0 = sampled like the reference [default], 1 = argmax), "workers" (emulated CPU worker count
  * fixing the summation order of the prior updates, default 16), "eval_subtasks" (question subtasks of the sampled
  * selector, default 8*workers as PqaCore/CpuEngine.cpp:339), "eval_variant" (0 = auto), "bug_compat" (reproduce
- * PqaCore/CEUpdatePriorsSubtaskMul.cpp:53), "seed" (selector RNG seed), "top_cache" (how many of the new posterior's best
+ * PqaCore/CEUpdatePriorsSubtaskMul.cpp:53), "seed" (selector RNG seed), "use_graph" (argmax NextQuestion replays a per-quiz HIP graph
+ * instead of launching the sweep), "top_cache" (how many of the new posterior's best
  * targets RecordAnswer's kernel lists ahead of the ListTopTargets call that follows it, default 10, 0 = none). */
 PQACORE_API void *PqaHip_SetOption(void *pvEngine, const char *name, int64_t value);
 PQACORE_API int64_t PqaHip_GetOption(void *pvEngine, const char *name);

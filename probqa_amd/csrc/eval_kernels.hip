@@ -96,7 +96,10 @@ __device__ __forceinline__ void fused_select(const EvalArgs &a, Best mine) {
   if (a.fs.scratch == nullptr) return;
   const int lane = threadIdx.x % kWave;
   const Best wg = wave_best(mine);
-  const uint64_t tag = (uint64_t)(uint32_t)a.fs.seqValue << 32;
+  uint64_t seqValue = a.fs.seqValue, flagValue = a.fs.flagValue;
+  if (a.fs.tagCell != nullptr)  // graph replay: the finisher of the previous replay left this launch's tag here
+    seqValue = flagValue = __hip_atomic_load(a.fs.tagCell, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const uint64_t tag = (uint64_t)(uint32_t)seqValue << 32;
   SelectResult *rec = a.fs.scratch;
   if (lane == 0) {
     typedef unsigned int u4 __attribute__((ext_vector_type(4)));
@@ -152,7 +155,12 @@ __device__ __forceinline__ void fused_select(const EvalArgs &a, Best mine) {
     a.fs.out->index = !complete ? -3 : b.i < 0 ? -1 : b.i + a.fs.outBase;
     if (a.fs.seq != nullptr) {
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");  // system scope: the record is visible to the host before the flag
-      __hip_atomic_store(a.fs.seq, a.fs.flagValue, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(a.fs.seq, flagValue, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    if (a.fs.tagCell != nullptr) {  // every workgroup has read the cell (it published): the next replay gets the next tag
+      uint64_t next = seqValue + 1;
+      if ((uint32_t)next == 0) next++;
+      __hip_atomic_store(a.fs.tagCell, next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
 }
@@ -729,7 +737,7 @@ static EvalArgs make_args(const KbView &kb, int64_t qFirst, int64_t qLimit) {
   args.qLimit = qLimit;
   const double nT = (double)(kb.nValidTargets + 1);  // PqaCore/CEEvalQsSubtaskConsider.cpp:191
   args.vCompTail = 0.34657359027997265470861606072909 / (nT * nT);
-  args.fs = FusedSelect{nullptr, nullptr, nullptr, 0, 0, 0, 0};
+  args.fs = FusedSelect{nullptr, nullptr, nullptr, 0, 0, 0, 0, nullptr};
   args.slots = nullptr;
   return args;
 }

@@ -212,12 +212,15 @@ HipEngine::~HipEngine() {
   hipFree(_dCube); hipFree(_dVB); hipFree(_dPriority); hipFree(_dRunLength); hipFree(_dExps); hipFree(_dStatus);
   hipFree(_dNOut); hipFree(_dSel); hipFree(_dSelScratch); hipFree(_dBatchSlots); hipFree(_dBatchScratch); hipFree(_dBatchPriority);
   DropQuizBufferPool();
+  for (auto &g : _graphs) hipGraphExecDestroy(g.second.exec);
+  hipFree(_dGraphScratch); hipFree(_dTagCell);
   if (_hBatch) hipHostFree(_hBatch); hipFree(_dTGap); hipFree(_dQGap); hipFree(_dAqs); hipFree(_dTop);
   if (_hPinned) hipHostFree(_hPinned);
   if (_ownStream) hipStreamDestroy(_ownStream);
 }
 
 Error HipEngine::UploadGaps() {
+  _kbVersion++;  // every change of the KB's shape or gaps passes through here: captured graphs hold the old view
   HIP_TRY(hipMemcpyAsync(_dTGap, _hTGap.data(), _hTGap.size() * sizeof(uint32_t), hipMemcpyHostToDevice, _stream));
   HIP_TRY(hipMemcpyAsync(_dQGap, _hQGap.data(), _hQGap.size() * sizeof(uint32_t), hipMemcpyHostToDevice, _stream));
   HIP_TRY(hipStreamSynchronize(_stream));
@@ -243,6 +246,7 @@ Error HipEngine::SetOption(const char *name, int64_t value) {
   else if (n == "eval_subtasks") { if (value < 0 || value > 8192) goto bad; _optEvalSubtasks = value; }
   else if (n == "eval_variant") { if (value < 0) goto bad; _optEvalVariant = value; }
   else if (n == "bug_compat") { _optBugCompat = value ? 1 : 0; }
+  else if (n == "use_graph") { _optUseGraph = value ? 1 : 0; }
   else if (n == "top_cache") { if (value < 0 || value > 256) goto bad; _optTopCache = value; }
   else if (n == "seed") { uint64_t s = (uint64_t)value; _rng[0] = SplitMix64(s); _rng[1] = SplitMix64(s); }
   else goto bad;
@@ -259,6 +263,7 @@ int64_t HipEngine::GetOption(const char *name) const {
   if (n == "eval_variant") return _optEvalVariant;
   if (n == "bug_compat") return _optBugCompat;
   if (n == "top_cache") return _optTopCache;
+  if (n == "use_graph") return _optUseGraph;
   if (n == "ldT") return _ldT;
   if (n == "device") return _device;
   return -1;
@@ -303,6 +308,10 @@ Quiz *HipEngine::UseQuiz(Error &err, int64_t iQuiz) {
 void HipEngine::DestroyQuiz(Quiz *q) {
   if (!q) return;
   if (_topOwner == q) _topOwner = nullptr;
+  {
+    auto it = _graphs.find(q);
+    if (it != _graphs.end()) { hipGraphExecDestroy(it->second.exec); _graphs.erase(it); }
+  }
   if (q->dPrior && q->dAsked && _quizBufferPool.size() < 4096)
     _quizBufferPool.push_back(QuizBuffers{q->dPrior, q->dAsked, _ldT, q->hAsked.size()});
   else {
@@ -501,7 +510,7 @@ Error HipEngine::EnqueueSelectArgmax(int64_t iQuiz, void *pOut) {
   Quiz *q = UseQuiz(err, iQuiz);
   if (!q) return err;
   // one launch: the sweep's last workgroup picks the argmax; reported index = local position + qFirst (GLOBAL id)
-  const FusedSelect fs{_dSelScratch, pOut ? (SelectResult *)pOut : _dSel, nullptr, NextLaunchTag(), _qFirst, 0, 0};
+  const FusedSelect fs{_dSelScratch, pOut ? (SelectResult *)pOut : _dSel, nullptr, NextLaunchTag(), _qFirst, 0, 0, nullptr};
   HIP_TRY(LaunchEvalQuestions(View(), q->dPrior, q->dAsked, 0, _Q, _dPriority, (int)_optEvalVariant, &fs, _stream));
   return Error();
 }
@@ -517,7 +526,7 @@ Error HipEngine::EnqueueSelectArgmaxFlag(int64_t iQuiz, void *pOut, void *pFlag,
   if (!q) return err;
   if (!pOut || !pFlag) return Error::Make(ErrCode::NullArgument, "Nullptr is passed in place of the record or the flag.");
   hipSetDevice(_device);
-  const FusedSelect fs{_dSelScratch, (SelectResult *)pOut, (uint64_t *)pFlag, NextLaunchTag(), _qFirst, 0, flagValue};
+  const FusedSelect fs{_dSelScratch, (SelectResult *)pOut, (uint64_t *)pFlag, NextLaunchTag(), _qFirst, 0, flagValue, nullptr};
   HIP_TRY(LaunchEvalQuestions(View(), q->dPrior, q->dAsked, 0, _Q, _dPriority, (int)_optEvalVariant, &fs, _stream));
   return Error();
 }
@@ -545,10 +554,11 @@ int64_t HipEngine::NextQuestionArgmax(Error &err, int64_t iQuiz) {
   Quiz *q = UseQuiz(err, iQuiz);
   if (!q) return -1;
   hipSetDevice(_device);
+  if (_optUseGraph) return NextQuestionArgmaxGraph(err, q);
   // One launch; the last workgroup writes the winner and then a sequence number straight into host-coherent pinned
   // memory, which this thread polls: no D2H copy, no stream synchronisation on the critical path.
   const uint64_t seq = NextLaunchTag();
-  const FusedSelect fs{_dSelScratch, &_hPinned->sel, &_hPinned->seq, seq, 0, 0, seq};
+  const FusedSelect fs{_dSelScratch, &_hPinned->sel, &_hPinned->seq, seq, 0, 0, seq, nullptr};
   hipError_t he = LaunchEvalQuestions(View(), q->dPrior, q->dAsked, 0, _Q, _dPriority, (int)_optEvalVariant, &fs, _stream);
   if (he != hipSuccess) { err = HipErr(he, "NextQuestionArgmax"); return -1; }
   err = WaitFlag(&_hPinned->seq, seq, "NextQuestionArgmax");
@@ -598,7 +608,7 @@ Error HipEngine::NextQuestionArgmaxBatch(int64_t n, const int64_t *pQuizzes, int
   }
   const uint64_t tag = NextLaunchTag();
   HIP_TRY(hipMemcpyAsync(_dBatchSlots, _hBatch->slots, (size_t)n * sizeof(QuizSlot), hipMemcpyHostToDevice, _stream));
-  const FusedSelect fs{_dBatchScratch, nullptr, nullptr, tag, 0, kBatchGrid, tag};
+  const FusedSelect fs{_dBatchScratch, nullptr, nullptr, tag, 0, kBatchGrid, tag, nullptr};
   HIP_TRY(LaunchEvalQuestionsBatch(View(), _dBatchSlots, (int)n, 0, _Q, (int)_optEvalVariant, fs, _stream));
   const auto t0 = std::chrono::steady_clock::now();
   for (int64_t i = 0; i < n; i++) {
@@ -622,6 +632,51 @@ Error HipEngine::NextQuestionArgmaxBatch(int64_t n, const int64_t *pQuizzes, int
     pOut[i] = FinishSelection(e, quizzes[i], _hBatch->out[i].index);  // -1 + QuestionsExhausted: reported as -1 only
   }
   return Error();
+}
+
+// The same selection replayed from a HIP graph (option "use_graph"; SURVEY 8(d) asks for the variant).  One graph per quiz:
+// a single kernel node, the fused sweep with CONSTANT arguments -- the per-launch tag lives in a device word that the
+// sweep's finisher advances (FusedSelect::tagCell), and the host mirrors the count.  Own record strip and tag cell, so
+// graph replays and plain launches never share tags.
+int64_t HipEngine::NextQuestionArgmaxGraph(Error &err, Quiz *q) {
+  if (!_dGraphScratch) {
+    hipError_t he = hipMalloc(&_dGraphScratch, kFusedMaxGrid * sizeof(SelectResult));
+    if (he == hipSuccess) he = hipMemsetAsync(_dGraphScratch, 0, kFusedMaxGrid * sizeof(SelectResult), _stream);
+    if (he == hipSuccess) he = hipMalloc(&_dTagCell, sizeof(uint64_t));
+    const uint64_t one = 1;
+    if (he == hipSuccess) he = hipMemcpyAsync(_dTagCell, &one, sizeof(one), hipMemcpyHostToDevice, _stream);
+    if (he == hipSuccess) he = hipStreamSynchronize(_stream);
+    if (he != hipSuccess) { err = HipErr(he, "graph selection buffers"); return -1; }
+    _graphTag = 1;
+  }
+  auto it = _graphs.find(q);
+  if (it == _graphs.end() || it->second.variant != _optEvalVariant || it->second.stream != _stream ||
+      it->second.kbVersion != _kbVersion) {
+    if (it != _graphs.end()) { hipGraphExecDestroy(it->second.exec); _graphs.erase(it); }
+    const FusedSelect fs{_dGraphScratch, &_hPinned->sel, &_hPinned->seq, 0, 0, 0, 0, _dTagCell};
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    hipError_t he = hipStreamBeginCapture(_stream, hipStreamCaptureModeThreadLocal);
+    if (he == hipSuccess) {
+      const hipError_t le = LaunchEvalQuestions(View(), q->dPrior, q->dAsked, 0, _Q, _dPriority, (int)_optEvalVariant, &fs, _stream);
+      he = hipStreamEndCapture(_stream, &graph);
+      if (he == hipSuccess) he = le;
+    }
+    if (he == hipSuccess) he = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    if (graph) hipGraphDestroy(graph);
+    if (he != hipSuccess) { err = HipErr(he, "graph capture of the selection"); return -1; }
+    it = _graphs.emplace(q, GraphEntry{exec, _optEvalVariant, _stream, _kbVersion}).first;
+  }
+  const uint64_t expect = _graphTag;
+  const hipError_t he = hipGraphLaunch(it->second.exec, _stream);
+  if (he != hipSuccess) { err = HipErr(he, "hipGraphLaunch"); return -1; }
+  uint64_t next = _graphTag + 1;                     // the finisher's own rule (fused_select)
+  if ((uint32_t)next == 0) next++;
+  _graphTag = next;
+  err = WaitFlag(&_hPinned->seq, expect, "NextQuestionArgmax (graph)");
+  if (!err.ok()) return -1;
+  if (_hPinned->sel.index == -3) { err = HipErr(hipErrorLaunchFailure, "NextQuestionArgmax (incomplete sweep)"); return -1; }
+  return FinishSelection(err, q, _hPinned->sel.index);
 }
 
 int64_t HipEngine::NextQuestionSampled(Error &err, int64_t iQuiz, uint64_t rnd) {

@@ -126,6 +126,7 @@ class HipEngine {
   int64_t NextQuestionArgmax(Error &err, int64_t iQuiz);
   int64_t NextQuestionSampled(Error &err, int64_t iQuiz, uint64_t rnd);
   Error GetPriors(int64_t iQuiz, double *pOut, int64_t n);
+  int64_t NextQuestionArgmaxGraph(Error &err, Quiz *q);
   Error NextQuestionArgmaxBatch(int64_t n, const int64_t *pQuizzes, int64_t *pOut);
   Error Log2HotArray(const double *pIn, double *pOut, int64_t n);  // device log2hot over an array (tests)
   hipStream_t GetStream() const { return _stream; }
@@ -171,6 +172,12 @@ class HipEngine {
   // cost tens of microseconds and hipFree synchronises the device.  Reuse is ordered by the engine's stream.
   struct QuizBuffers { double *dPrior; uint32_t *dAsked; int64_t ldT; size_t askedWords; };
   std::vector<QuizBuffers> _quizBufferPool;
+  struct GraphEntry { hipGraphExec_t exec; int64_t variant; hipStream_t stream; uint64_t kbVersion; };
+  uint64_t _kbVersion = 0;
+  std::unordered_map<Quiz *, GraphEntry> _graphs;  // option "use_graph"
+  SelectResult *_dGraphScratch = nullptr;
+  uint64_t *_dTagCell = nullptr;
+  uint64_t _graphTag = 1;
   void DropQuizBufferPool();
   SelectResult *_dSel = nullptr;
   struct Pinned {  // host-coherent: written by kernels, polled / read by the host without copies
@@ -219,6 +226,7 @@ class HipEngine {
   Mode _mode = Mode::Regular;
   // options
   int64_t _optSelect = 0, _optWorkers = 16, _optEvalSubtasks = 0, _optEvalVariant = 0, _optBugCompat = 0;
+  int64_t _optUseGraph = 0;   // NextQuestion (argmax) replays a per-quiz HIP graph instead of launching
   int64_t _optTopCache = 10;  // targets RecordAnswer's kernel lists ahead of the ListTopTargets that follows it (0: none)
   uint64_t _rng[2] = {0, 0};
 };

@@ -48,6 +48,9 @@ struct FusedSelect {
   int64_t outBase;
   int64_t scratchStride;  // batch only: records per quiz in `scratch` (the launch uses at most that many workgroups)
   uint64_t flagValue;     // what *seq receives (the engine's own callers pass the launch tag)
+  // Launches replayed from a HIP graph have constant arguments: with tagCell != nullptr both the launch tag and the flag
+  // value are read from this device word instead, and the finisher advances it for the next replay.
+  uint64_t *tagCell;
 };
 // One quiz of a batched sweep (blockIdx.y selects it): everything that differs between the quizzes of one launch.
 struct QuizSlot {

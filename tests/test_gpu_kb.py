@@ -294,3 +294,29 @@ def test_top_targets_cache_behind_record_answer(factory):
     c = eng.start_quiz()                          # may reuse a's slot and buffers: nothing of a's list may survive
     assert listed(c, 4) == expect(c, 4)
     eng.close()
+
+
+def test_graph_replay_variant_of_the_selection(factory):
+    """Option use_graph: NextQuestion (argmax) replays a per-quiz HIP graph.  Same questions as plain launches through
+    answers, gap changes (the captured view goes stale and is recaptured) and interleaved quizzes."""
+    K, Q, T = 5, 80, 600
+    eng, *_ = make(factory, K, Q, T, seed=12)
+    eng.set_option("select", 1)
+    rng = np.random.default_rng(5)
+    a, b = eng.start_quiz(), eng.start_quiz()
+    for step in range(8):
+        for quiz in (a, b, a):
+            eng.set_option("use_graph", 0)
+            want = eng.next_question(quiz)
+            eng.set_option("use_graph", 1)
+            assert eng.next_question(quiz) == want, (step, quiz)
+            assert eng.next_question(quiz) == want          # a second replay of the same graph
+        eng.record_answer(a, int(rng.integers(0, K)))
+        eng.set_option("use_graph", 1)
+        eng.next_question(b)
+        eng.record_answer(b, int(rng.integers(0, K)))
+        if step == 3:
+            eng.set_target_gaps([5, 17])
+        if step == 5:
+            eng.set_question_gaps([int(eng.next_question(a))])
+    eng.close()
