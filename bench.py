@@ -163,6 +163,16 @@ def main():
         elapsed = float(t.item())
     value = args.steps / elapsed
 
+    # ---- per-step latency distribution of the same synchronous call (median and p10 / p90)
+    lat = []
+    for _ in range(min(args.steps, 2000)):
+        t1 = time.perf_counter()
+        step()
+        lat.append(time.perf_counter() - t1)
+    lat.sort()
+    latency_us = {"p10": 1e6 * lat[len(lat) // 10], "p50": 1e6 * lat[len(lat) // 2], "p90": 1e6 * lat[(9 * len(lat)) // 10],
+                  "n": len(lat)}
+
     # ---- dominant kernel: live HIP-event timing on the engine's stream, back-to-back launches
     n_k = max(20, min(args.steps, 200))
     for _ in range(5):
@@ -243,6 +253,7 @@ def main():
             "selected_question": int(sel),
         },
         "question_evals_per_sec": value * Q,
+        "step_latency_us": latency_us,
         "pipelined_selections_per_sec": pipelined,
         "batched": batched,
         "hip_graph_replay": graph_rate,
