@@ -257,6 +257,22 @@ __device__ __forceinline__ void pass2_pair(double2 lh, double2 id, double2 pr, d
   v = fma(d1, d1, v);
 }
 
+// LDS-DMA: 16 bytes per lane from global memory straight into LDS, no destination VGPRs (buffer_load_dwordx4 ... offen lds:
+// row base in an SGPR descriptor, the lane's 32-bit byte offset in a VGPR -- no 64-bit address pairs either); completion is
+// counted by vmcnt but invisible to hipcc's own bookkeeping (wait for it explicitly).  M0 = wave-uniform LDS byte address
+// of the destination (16-byte aligned); lane i lands at M0 + 16*i.  Checked beyond 64 KiB by tools/glds_test.hip.
+typedef unsigned int dma_rsrc_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ dma_rsrc_t dma_rsrc(const void *row, int64_t bytes) {
+  const uint64_t base = (uint64_t)(uintptr_t)row;
+  return dma_rsrc_t{(unsigned)__builtin_amdgcn_readfirstlane((unsigned)base),
+                    (unsigned)__builtin_amdgcn_readfirstlane((unsigned)(base >> 32)) & 0xFFFFu, (unsigned)bytes, 0x00020000u};
+}
+__device__ __forceinline__ void dma16(dma_rsrc_t rsrc, unsigned byteOffset, unsigned ldsDst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(byteOffset), "s"(rsrc), "s"(__builtin_amdgcn_readfirstlane(ldsDst)) : "memory");
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // Register-resident sweep: WPQ waves per question, NP target pairs per lane.  Requires ldT <= 128*WPQ*NP.
 // PRLDS: keep the masked prior vector in LDS instead of registers (long rows: frees 4*NP VGPRs).
@@ -276,6 +292,13 @@ __device__ __forceinline__ void pass2_pair(double2 lh, double2 id, double2 pr, d
 // ------------------------------------------------------------------------------------------------------------------
 constexpr int kPend = 32;
 
+// (+ for register-prior shapes: the landing row of the next question's mD, np*64*wpq pairs, on a KiB boundary)
+__host__ __device__ constexpr size_t eval_lds_fixed_doubles(int wpq, int64_t K) {
+  return kLog2TableDoubles + 2 * (size_t)wpq + 2 * (size_t)(K + 2) * wpq + (size_t)kPend * (2 * (size_t)K + 3) + 2 * kWave;
+}
+__host__ __device__ constexpr size_t eval_md_row_offset_bytes(int wpq, int64_t K) {
+  return (eval_lds_fixed_doubles(wpq, K) * sizeof(double) + 1023) / 1024 * 1024;
+}
 __host__ __device__ constexpr size_t eval_lds_doubles(int wpq, int64_t K, bool prLds, int64_t ldT) {
   return kLog2TableDoubles + 2 * (size_t)wpq + 2 * (size_t)(K + 2) * wpq + (size_t)kPend * (2 * (size_t)K + 3) + 2 * kWave +
          (prLds ? (size_t)ldT + 2 : 0);
@@ -307,6 +330,11 @@ __global__ __launch_bounds__(WPQ * 64) void eval_questions_f64(EvalArgs a) {
   double *pend = partAll + 2 * (K + 2) * WPQ;
   Best *bestLds = reinterpret_cast<Best *>(pend + kPend * (2 * K + 3));  // wave 0's per-lane running argmax
   double2 *prLds = reinterpret_cast<double2 *>(bestLds + kWave);
+  // landing row of the NEXT question's mD (register-prior shapes): lane-private 16-byte slots, slot j of thread tid at
+  // mdRow[j*kThreads + tid]; filled by LDS-DMA while the current question's last answer is in pass 2
+  constexpr bool kMdLds = !PRLDS;
+  double2 *mdRow = reinterpret_cast<double2 *>(reinterpret_cast<char *>(smem) + eval_md_row_offset_bytes(WPQ, K));
+  const unsigned mdRowWaveAddr = (unsigned)(uintptr_t)mdRow + (unsigned)(threadIdx.x / kWave) * 1024u;
   const int nPart = (int)(K + 2);
   const int recLen = (int)(2 * K + 3);
   const int tid = threadIdx.x, lane = tid % kWave, wave = tid / kWave;
@@ -332,11 +360,22 @@ __global__ __launch_bounds__(WPQ * 64) void eval_questions_f64(EvalArgs a) {
     gapWord[j] = a.tgap[pc >> 4];                  // both bits of the pair (targets 2pc, 2pc+1) sit in one word
     prRaw[j] = reinterpret_cast<const double2 *>(a.prior)[pc];
   }
-  if (haveQ0) {
-    const RowRsrc rowD = row_rsrc(a.cube + q0 * qStride + K * ldT, rowBytes);
+  auto head_of_stream = [&](int64_t qq) __attribute__((always_inline)) {
+    if constexpr (kMdLds) {   // mD to its LDS landing row, the first answer row to the ring
+      const RowRsrc rowA = row_rsrc(a.cube + qq * qStride, rowBytes);
+      const dma_rsrc_t md = dma_rsrc(a.cube + qq * qStride + K * ldT, rowBytes);
 #pragma unroll
-    for (int j = 0; j < NP; j++) ring[j] = row_load(rowD, poff[j]);
-  }
+      for (int j = 0; j < NP; j++) {
+        ring[j] = row_load(rowA, poff[j]);
+        dma16(md, poff[j], mdRowWaveAddr + (unsigned)j * (kThreads * 16u));
+      }
+    } else {
+      const RowRsrc rowD = row_rsrc(a.cube + qq * qStride + K * ldT, rowBytes);
+#pragma unroll
+      for (int j = 0; j < NP; j++) ring[j] = row_load(rowD, poff[j]);
+    }
+  };
+  if (haveQ0) head_of_stream(q0);
   {
     static_assert((kLog2TableDoubles / 2) % kThreads == 0, "the table copy is an exact number of 16-byte loads per thread");
     constexpr int kTblPerThread = kLog2TableDoubles / 2 / kThreads;
@@ -374,11 +413,7 @@ __global__ __launch_bounds__(WPQ * 64) void eval_questions_f64(EvalArgs a) {
   int64_t q = q0;
   if (haveQ0 && (((q0Gap | q0Asked) >> (q0 & 31)) & 1u)) {     // the first candidate is skipped: restart the stream
     q = next_valid(q0);
-    if (q < a.qLimit) {
-      const RowRsrc rowD = row_rsrc(a.cube + q * qStride + K * ldT, rowBytes);
-#pragma unroll
-      for (int j = 0; j < NP; j++) ring[j] = row_load(rowD, poff[j]);
-    }
+    if (q < a.qLimit) head_of_stream(q);
   }
   __syncthreads();
 
@@ -387,7 +422,20 @@ __global__ __launch_bounds__(WPQ * 64) void eval_questions_f64(EvalArgs a) {
   while (q < a.qLimit) {
     const int64_t qn = next_valid(q + gridDim.x);
     const double *qBase = a.cube + q * qStride;
-    {
+    if constexpr (kMdLds) {
+      // mD arrived in LDS while the previous question finished, and the ring already holds this question's first answer
+      // (both requested during that question's last pass 1): nothing is waited for here.  With mD in the ring instead,
+      // the first answer row could only be requested now and its whole latency (~9k cycles of a 55k-cycle question at
+      // 10000 targets) stood between 1/D and pass 1.
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int j = 0; j < NP; j++) {
+        const double2 dv = mdRow[j * kThreads + tid];
+        invD[j].x = ((gapBits >> (2 * j)) & 1) ? 0.0 : div_nr(1.0, dv.x);           // :74 andnot(gapMask, 1/D)
+        invD[j].y = ((gapBits >> (2 * j + 1)) & 1) ? 0.0 : div_nr(1.0, dv.y);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {
       const RowRsrc rowA = row_rsrc(qBase, rowBytes);
 #pragma unroll
       for (int j = 0; j < NP; j++) {
@@ -408,8 +456,13 @@ __global__ __launch_bounds__(WPQ * 64) void eval_questions_f64(EvalArgs a) {
       // (cache-resident, row-sized) prior vector stands in, so that the refill stays unconditional -- a conditional
       // refill makes the ring a phi and costs a full vmcnt(0) + 2*NP moves per row
       const bool lastRow = k + 1 == K;
-      const RowRsrc rowN = row_rsrc(
-          !lastRow ? qBase + (k + 1) * ldT : qn < a.qLimit ? a.cube + qn * qStride + K * ldT : a.prior, rowBytes);
+      const bool moreQuestions = qn < a.qLimit;
+      // (register-prior shapes: the row after a question's last answer is the next question's FIRST answer; its mD row goes
+      //  to LDS, below)
+      const double *rowNext = !lastRow ? qBase + (k + 1) * ldT
+                              : !moreQuestions ? a.prior
+                              : a.cube + qn * qStride + (kMdLds ? 0 : K * ldT);
+      const RowRsrc rowN = row_rsrc(rowNext, rowBytes);
 #pragma unroll
       for (int j = 0; j < NP; j++) {
         double2 pv;
@@ -420,6 +473,13 @@ __global__ __launch_bounds__(WPQ * 64) void eval_questions_f64(EvalArgs a) {
         s1 += lh[j].y;
         ring[j] = row_load(rowN, poff[j]);
         __builtin_amdgcn_sched_barrier(0);
+      }
+      if (kMdLds && lastRow && moreQuestions) {
+        // after the loop, not inside it: hipcc does not count these, and a counted wait for a ring pair with fresh DMA
+        // requests behind it would wait for them too
+        const dma_rsrc_t mdNext = dma_rsrc(a.cube + qn * qStride + K * ldT, rowBytes);
+#pragma unroll
+        for (int j = 0; j < NP; j++) dma16(mdNext, poff[j], mdRowWaveAddr + (unsigned)j * (kThreads * 16u));
       }
       double Wk = wave_sum(s0 + s1);                           // :88
       if constexpr (WPQ > 1) {
@@ -646,7 +706,8 @@ int gNumCUs = 0;
 
 template <int WPQ, int NP, bool PRLDS>
 hipError_t launch_reg(const EvalArgs &args, int64_t nQ, int nBatch, hipStream_t stream) {
-  const size_t shmem = eval_lds_doubles(WPQ, args.K, PRLDS, args.ldT) * sizeof(double);
+  const size_t shmem = PRLDS ? eval_lds_doubles(WPQ, args.K, true, args.ldT) * sizeof(double)
+                             : eval_md_row_offset_bytes(WPQ, args.K) + (size_t)NP * WPQ * kWave * 16;
   auto kern = eval_questions_f64<WPQ, NP, PRLDS>;
   // attribute and occupancy are properties of (kernel, LDS size): asked once, not on every launch (the engine serialises
   // launches; a race between two engines would only repeat the query)

@@ -53,8 +53,15 @@ __device__ __forceinline__ double div_nr(double n, double d) {
 typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 using RowRsrc = __amdgpu_buffer_rsrc_t;
 
+// (the row pointer is wave-uniform by construction but hipcc cannot always prove it -- the question index comes out of
+// loaded bitmap words -- and a descriptor it believes divergent costs a readfirstlane "waterfall" loop around EVERY load:
+// 4 v_readfirstlane + 2 64-bit compares + exec juggling per 16-byte load.  Saying so once per row removes all of it.)
 __device__ __forceinline__ RowRsrc row_rsrc(const void *row, int64_t bytes) {
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(row), (short)0, (int)bytes, 0x00020000);
+  const uint64_t p = (uint64_t)(uintptr_t)row;
+  const uint64_t pu = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(p >> 32)) << 32) |
+                      (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)p);
+  return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>((uintptr_t)pu), (short)0,
+                                           __builtin_amdgcn_readfirstlane((int)bytes), 0x00020000);
 }
 __device__ __forceinline__ double2 row_load(RowRsrc rs, uint32_t byteOffset) {
   return __builtin_bit_cast(double2, __builtin_amdgcn_raw_buffer_load_b128(rs, byteOffset, 0, 0));
