@@ -7,7 +7,9 @@ the host.  The cube is resident in HBM before the timed region.  Workload at N=1
 (1000Q x 5A x 1000T fp64, single in-flight quiz).  N>1: the question axis of the same cube is sharded over the ranks
 (one process per GPU), each rank sweeps its shard and the ranks' 16-byte winners meet in host shared memory written by
 the sweeps themselves (--exchange rccl: one RCCL all-gather instead), every rank picks the same global argmax
-("strong" scaling, as north_star states it).  --config M runs configs[2] (10000x5x10000, the HBM-bound point).
+("strong" scaling, as north_star states it).  --config M runs configs[2] (10000x5x10000, the HBM-bound point); sharded
+runs of the default config also time configs[3] (the 10000x5x10000 cube over the same ranks) into the extra key
+"sharded_10000x5x10000".
 
 Prints ONE JSON line (rank 0).  Extra keys: roofline (dominant kernel, live HIP-event timing on the engine's stream),
 cpu_baseline (the AVX2+threads CPU port of the reference path, timed on this host; N=1 only).
@@ -90,48 +92,51 @@ def main():
     Q, K, T = cfg["Q"], cfg["K"], cfg["T"]
     if args.batch < 0:
         args.batch = 64 if Q * (K + 1) * T * 8 < 1e9 else 8
-    q_first, q_limit = pdist.shard_range(Q, world, rank)
-    q_local = q_limit - q_first
-
     factory = interop.PqaEngineFactory()
-    eng = factory.create_hip_engine(interop.EngineDefinition(K, q_local, T, init_amount=0.1), q_first, Q, local_rank)
-    eng.set_option("select", 1)
-    eng.set_option("eval_variant", args.variant)
-    eng.fill_synthetic(8.0, 0.5, SEED)
     stream = torch.cuda.Stream(device=device)
     torch.cuda.set_stream(stream)
-    eng.set_stream(stream.cuda_stream)
-    quiz = eng.start_quiz()
-    ldT = eng.get_option("ldT")
+    sharded = world > 1 or args.force_collective
 
-    selector = None
-    if world > 1 or args.force_collective:
-        if args.exchange == "shm":
-            import torch.distributed as dist
+    def make_engine(c, tag):
+        """This rank's shard of cube `c`, one quiz started, and (sharded runs) the selector over all ranks."""
+        qf, ql = pdist.shard_range(c["Q"], world, rank)
+        e = factory.create_hip_engine(interop.EngineDefinition(c["K"], ql - qf, c["T"], init_amount=0.1), qf, c["Q"], local_rank)
+        e.set_option("select", 1)
+        e.set_option("eval_variant", args.variant)
+        e.fill_synthetic(8.0, 0.5, SEED)
+        e.set_stream(stream.cuda_stream)
+        qz = e.start_quiz()
+        sel_obj = None
+        if sharded:
+            if args.exchange == "shm":
+                import torch.distributed as dist
 
-            name = "bench_%s" % os.environ.get("MASTER_PORT", "0")
-            ok = 1
-            try:
-                if rank == 0:
-                    selector = pdist.ShmSelector(eng, quiz, rank, world, name, create=True)
-            except Exception as e:  # noqa: BLE001 - every rank must take the same path
-                print("rank 0: shared-memory exchange unavailable (%r)" % (e,), file=sys.stderr)
-                ok = 0
-            dist.barrier()                      # the segment exists before the other ranks open it
-            try:
-                if rank != 0 and ok:
-                    selector = pdist.ShmSelector(eng, quiz, rank, world, name, create=False)
-            except Exception as e:  # noqa: BLE001
-                print("rank %d: shared-memory exchange unavailable (%r)" % (rank, e), file=sys.stderr)
-                ok = 0
-            flag = torch.tensor([ok], dtype=torch.int32, device=device)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            if int(flag.item()) == 0:           # one rank could not: all ranks use the collective
-                if selector is not None:
-                    selector.close()
-                selector, args.exchange = None, "rccl"
-        if selector is None:
-            selector = pdist.ShardedSelector(lambda out: eng.enqueue_select_argmax(quiz, out.data_ptr()), device)
+                name = "bench_%s_%s" % (os.environ.get("MASTER_PORT", "0"), tag)
+                ok = 1
+                try:
+                    if rank == 0:
+                        sel_obj = pdist.ShmSelector(e, qz, rank, world, name, create=True)
+                except Exception as ex:  # noqa: BLE001 - every rank must take the same path
+                    print("rank 0: shared-memory exchange unavailable (%r)" % (ex,), file=sys.stderr)
+                    ok = 0
+                dist.barrier()                      # the segment exists before the other ranks open it
+                try:
+                    if rank != 0 and ok:
+                        sel_obj = pdist.ShmSelector(e, qz, rank, world, name, create=False)
+                except Exception as ex:  # noqa: BLE001
+                    print("rank %d: shared-memory exchange unavailable (%r)" % (rank, ex), file=sys.stderr)
+                    ok = 0
+                flag = torch.tensor([ok], dtype=torch.int32, device=device)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                if int(flag.item()) == 0:           # one rank could not: all ranks use the collective
+                    if sel_obj is not None:
+                        sel_obj.close()
+                    sel_obj, args.exchange = None, "rccl"
+            if sel_obj is None:
+                sel_obj = pdist.ShardedSelector(lambda out: e.enqueue_select_argmax(qz, out.data_ptr()), device)
+        return e, qz, sel_obj, ql - qf
+
+    eng, quiz, selector, q_local = make_engine(cfg, "main")
 
     def step():
         if selector is None:
@@ -147,20 +152,39 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        sel = step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        sel = step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        import torch.distributed as dist
+    def timed(fn, warmup, steps):
+        """W untimed steps, then exactly K steps between barrier + synchronize; the maximum over ranks."""
+        r = None
+        for _ in range(warmup):
+            r = fn()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            r = fn()
+        barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            import torch.distributed as dist
 
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+            t = torch.tensor([dt], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt, r
+
+    def kernel_ms_of(e, qz, n_k):
+        """dominant kernel: live HIP-event timing on the engine's stream, back-to-back launches"""
+        for _ in range(5):
+            e.enqueue_eval(qz)
+        torch.cuda.synchronize()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record(stream)
+        for _ in range(n_k):
+            e.enqueue_eval(qz)
+        ev1.record(stream)
+        torch.cuda.synchronize()
+        return ev0.elapsed_time(ev1) / n_k
+
+    elapsed, sel = timed(step, args.warmup, args.steps)
     value = args.steps / elapsed
 
     # ---- per-step latency distribution of the same synchronous call (SURVEY 8(d): median and p10 / p90)
@@ -173,18 +197,7 @@ def main():
     latency_us = {"p10": 1e6 * lat[len(lat) // 10], "p50": 1e6 * lat[len(lat) // 2], "p90": 1e6 * lat[(9 * len(lat)) // 10],
                   "n": len(lat)}
 
-    # ---- dominant kernel: live HIP-event timing on the engine's stream, back-to-back launches
-    n_k = max(20, min(args.steps, 200))
-    for _ in range(5):
-        eng.enqueue_eval(quiz)
-    torch.cuda.synchronize()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    ev0.record(stream)
-    for _ in range(n_k):
-        eng.enqueue_eval(quiz)
-    ev1.record(stream)
-    torch.cuda.synchronize()
-    kernel_ms = ev0.elapsed_time(ev1) / n_k
+    kernel_ms = kernel_ms_of(eng, quiz, max(20, min(args.steps, 200)))
     alg_bytes = q_local * (K + 1) * T * 8  # one read of every sA row and the mD row, fp64
     achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
 
@@ -229,6 +242,23 @@ def main():
         batched = {"quizzes_per_launch": args.batch, "selections_per_sec": reps * args.batch / (time.perf_counter() - tb0),
                    "launches_timed": reps, "agrees_with_single": int(picks[0]) == int(sel)}
 
+    # ---- extra (not `value`), sharded runs only: BASELINE configs[3], the 10000x5x10000 cube over the same ranks -- the
+    # configuration where sharding the question axis is about bandwidth rather than about launch latency
+    sharded_m = None
+    if sharded and args.config == "S":
+        cm = CONFIGS["M"]
+        eng_m, quiz_m, sel_m, q_local_m = make_engine(cm, "m")
+        dt_m, pick_m = timed(lambda: sel_m.select()[1], 20, 200)
+        k_ms = kernel_ms_of(eng_m, quiz_m, 20)
+        bytes_m = q_local_m * (cm["K"] + 1) * cm["T"] * 8
+        sharded_m = {"workload": cm["name"] + " fp64, question axis sharded over the ranks", "selections_per_sec": 200 / dt_m,
+                     "ms_per_step": 1e3 * dt_m / 200, "questions_per_gpu": q_local_m, "selected_question": int(pick_m),
+                     "rank0_kernel_us": 1e3 * k_ms, "rank0_kernel_GBps": bytes_m / (k_ms * 1e-3) / 1e9,
+                     "eval_kernel": eng_m.eval_kernel_name()}
+        if hasattr(sel_m, "close"):
+            sel_m.close()
+        eng_m.close()
+
     out = {
         "metric": "next_question_selections_per_sec",
         "value": value,
@@ -257,6 +287,7 @@ def main():
         "pipelined_selections_per_sec": pipelined,
         "batched": batched,
         "hip_graph_replay": graph_rate,
+        "sharded_10000x5x10000": sharded_m,
         "roofline": {
             "bound": "hbm",
             "achieved": achieved,
