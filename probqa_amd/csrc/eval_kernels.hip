@@ -92,16 +92,20 @@ __device__ __forceinline__ Best wave_best(Best b) {       // every lane ends up 
 
 // Called by every lane of ONE wave per workgroup (the wave that stored the workgroup's priorities) with the lanes'
 // running bests.  Record word 1: launch tag (low 32 bits of seqValue) << 32 | index (0xFFFFFFFF: none).
-__device__ __forceinline__ void fused_select(const EvalArgs &a, Best mine) {
+// UNI (resident kernel): the record, the result and the flag are stored by every lane of the wave (same value, same address)
+// instead of by lane 0 -- inside the resident loop a lane-0-only store after the finisher's poll loop is parked by the
+// structurizer behind the loop exit of its wave while the other lanes run on to the next step's barrier: a deadlock
+// (tools/server_rt.hip reproduces it).
+template <bool UNI = false>
+__device__ __forceinline__ void fused_select(const EvalArgs &a, Best mine, int lane) {
   if (a.fs.scratch == nullptr) return;
-  const int lane = threadIdx.x % kWave;
   const Best wg = wave_best(mine);
   uint64_t seqValue = a.fs.seqValue, flagValue = a.fs.flagValue;
   if (a.fs.tagCell != nullptr)  // graph replay: the finisher of the previous replay left this launch's tag here
     seqValue = flagValue = __hip_atomic_load(a.fs.tagCell, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   const uint64_t tag = (uint64_t)(uint32_t)seqValue << 32;
   SelectResult *rec = a.fs.scratch;
-  if (lane == 0) {
+  if (UNI || lane == 0) {
     typedef unsigned int u4 __attribute__((ext_vector_type(4)));
     const uint64_t w0 = d2u(wg.p), w1 = tag | (uint32_t)(wg.i < 0 ? 0xFFFFFFFFu : (uint32_t)wg.i);
     const u4 v = {(unsigned)w0, (unsigned)(w0 >> 32), (unsigned)w1, (unsigned)(w1 >> 32)};
@@ -150,7 +154,7 @@ __device__ __forceinline__ void fused_select(const EvalArgs &a, Best mine) {
       }
   }
   b = wave_best(b);
-  if (lane == 0) {
+  if (UNI || lane == 0) {
     a.fs.out->priority = b.i < 0 ? 0.0 : b.p;
     a.fs.out->index = !complete ? -3 : b.i < 0 ? -1 : b.i + a.fs.outBase;
     if (a.fs.seq != nullptr) {
@@ -316,9 +320,33 @@ __device__ __forceinline__ void flush_pending(const EvalArgs &a, const double *p
   }
 }
 
-template <int WPQ, int NP, bool PRLDS>
-__global__ __launch_bounds__(WPQ * 64) void eval_questions_f64(EvalArgs a) {
-  select_quiz(a);
+// The sweep of one launch (SERVER = false) or of one step of the resident kernel (SERVER = true: the Log2Hot table is
+// already in LDS after the first step, and branches on the wave number are made provably uniform).
+// What changes between two steps of the resident kernel without a kernel boundary in between: the quiz's posterior and its
+// asked bits (rewritten by RecordAnswer's kernel, possibly on another XCD, whose L2 is not coherent with this one's).  The
+// resident kernel reads exactly these with agent-scope (sc1) loads, which are served past the non-coherent cache levels.
+// The cube and the gap bitmaps change only in operations that stop the resident kernel first (hip_engine.cpp: StopServer).
+// Tried instead: an acquire fence in every wave at the start of a step (what a kernel boundary does) -- correct, 44 us per
+// step against 22; per-XCD copies made by one leader workgroup per XCD and read with workgroup-scope (sc0) loads -- no
+// faster (the step is bound by pulling the 48 MB cube through the L2s, ~13 us, not by these 8 KB) and not coherent.
+template <bool COH>
+__device__ __forceinline__ uint32_t load_word(const uint32_t *p) {
+  if constexpr (COH) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else return *p;
+}
+template <bool COH>
+__device__ __forceinline__ double2 load_pair(const double2 *p) {
+  if constexpr (COH) {
+    const double *d = reinterpret_cast<const double *>(p);
+    return make_double2(__hip_atomic_load(d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                        __hip_atomic_load(d + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+  } else {
+    return *p;
+  }
+}
+
+template <int WPQ, int NP, bool PRLDS, bool SERVER>
+__device__ __forceinline__ void sweep_body(EvalArgs a, bool copyTable) {
   constexpr int kThreads = WPQ * kWave;
   constexpr int NPR = PRLDS ? 1 : NP;
   extern __shared__ double smem[];
@@ -334,10 +362,15 @@ __global__ __launch_bounds__(WPQ * 64) void eval_questions_f64(EvalArgs a) {
   // mdRow[j*kThreads + tid]; filled by LDS-DMA while the current question's last answer is in pass 2
   constexpr bool kMdLds = !PRLDS;
   double2 *mdRow = reinterpret_cast<double2 *>(reinterpret_cast<char *>(smem) + eval_md_row_offset_bytes(WPQ, K));
-  const unsigned mdRowWaveAddr = (unsigned)(uintptr_t)mdRow + (unsigned)(threadIdx.x / kWave) * 1024u;
   const int nPart = (int)(K + 2);
   const int recLen = (int)(2 * K + 3);
-  const int tid = threadIdx.x, lane = tid % kWave, wave = tid / kWave;
+  int tidRaw = threadIdx.x;
+  // resident kernel: nothing derived from the thread index may be hoisted out of the step loop (56 VGPRs of loop
+  // invariants otherwise, and a workgroup less per CU)
+  if constexpr (SERVER) asm volatile("" : "+v"(tidRaw));
+  const int tid = tidRaw, lane = tid % kWave;
+  const int wave = SERVER ? (int)__builtin_amdgcn_readfirstlane(tid / kWave) : tid / kWave;
+  const unsigned mdRowWaveAddr = (unsigned)(uintptr_t)mdRow + (unsigned)wave * 1024u;
   // ---- prologue.  Everything it needs from memory is independent of everything else, so all of it is requested
   // before anything is used: one memory round trip instead of a dozen dependent ones (with one question per workgroup,
   // as at 1000 x 1000, the prologue is on the critical path of the whole launch).  That includes the mD row of the first
@@ -351,14 +384,14 @@ __global__ __launch_bounds__(WPQ * 64) void eval_questions_f64(EvalArgs a) {
   const int64_t q0 = a.qFirst + blockIdx.x;
   const bool haveQ0 = q0 < a.qLimit;
   const int64_t q0c = haveQ0 ? q0 : a.qLimit - 1;  // (unconditional loads: a branch here would end the batch)
-  const uint32_t q0Gap = a.qgap[q0c >> 5], q0Asked = a.asked[q0c >> 5];
+  const uint32_t q0Gap = a.qgap[q0c >> 5], q0Asked = load_word<SERVER>(a.asked + (q0c >> 5));
 #pragma unroll
   for (int j = 0; j < NP; j++) {
     const int p = tid + j * kThreads;
     const int pc = p < nPairs ? p : (nPairs - 1);  // clamped: out-of-row lanes re-read the last pair and are masked
     poff[j] = (uint32_t)pc * 16u;
     gapWord[j] = a.tgap[pc >> 4];                  // both bits of the pair (targets 2pc, 2pc+1) sit in one word
-    prRaw[j] = reinterpret_cast<const double2 *>(a.prior)[pc];
+    prRaw[j] = load_pair<SERVER>(reinterpret_cast<const double2 *>(a.prior) + pc);
   }
   auto head_of_stream = [&](int64_t qq) __attribute__((always_inline)) {
     if constexpr (kMdLds) {   // mD to its LDS landing row, the first answer row to the ring
@@ -376,7 +409,7 @@ __global__ __launch_bounds__(WPQ * 64) void eval_questions_f64(EvalArgs a) {
     }
   };
   if (haveQ0) head_of_stream(q0);
-  {
+  if (copyTable) {
     static_assert((kLog2TableDoubles / 2) % kThreads == 0, "the table copy is an exact number of 16-byte loads per thread");
     constexpr int kTblPerThread = kLog2TableDoubles / 2 / kThreads;
     double2 tv[kTblPerThread];
@@ -404,7 +437,7 @@ __global__ __launch_bounds__(WPQ * 64) void eval_questions_f64(EvalArgs a) {
   if constexpr (PRLDS) { if (tid == 0) prLds[nPairs] = make_double2(0.0, 0.0); }
 
   auto next_valid = [&](int64_t q) {               // :54 gap / asked questions get priority 0 and leave the stream
-    while (q < a.qLimit && (bit_test(a.qgap, q) || bit_test(a.asked, q))) {
+    while (q < a.qLimit && (bit_test(a.qgap, q) || ((load_word<SERVER>(a.asked + (q >> 5)) >> (q & 31)) & 1u))) {
       if (tid == 0) store_priority(a.priority + (q - a.qFirst), 0.0);
       q += gridDim.x;
     }
@@ -532,8 +565,118 @@ __global__ __launch_bounds__(WPQ * 64) void eval_questions_f64(EvalArgs a) {
   }
   if (wave == 0) {
     flush_pending(a, pend, nPend, lane, bestLds[lane]);
-    fused_select(a, bestLds[lane]);
+    fused_select<SERVER>(a, bestLds[lane], lane);
   }
+}
+
+template <int WPQ, int NP, bool PRLDS>
+__global__ __launch_bounds__(WPQ * 64) void eval_questions_f64(EvalArgs a) {
+  select_quiz(a);
+  sweep_body<WPQ, NP, PRLDS, false>(a, true);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Resident form of the sweep (pqa_kernels.h: ServerMailbox).  Control flow around the steps is wave-uniform by
+// construction: whole waves poll (one address -> one transaction) and whole waves store, every wait is bounded, and the
+// kernel's lifetime is bounded by idleTicks whatever the host does.
+// ------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t uniform64(uint64_t x) {
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)x), hi = __builtin_amdgcn_readfirstlane((uint32_t)(x >> 32));
+  return ((uint64_t)hi << 32) | lo;
+}
+// A request is one 64-byte line -- 16 dwords, the same layout in the host's mailbox, in the device's hand-off block and in
+// LDS: {req / go, prior, asked, out, flag, flagValue, outBase, stop}.  Lane l of a wave moves dword l & 15, so that a poll, a
+// hand-off or a fetch of all the fields is ONE memory transaction (six dependent reads over PCIe cost 10 us; one costs 1.7).
+// The writers store the sequence number last (host: program order; workgroup 0: one store instruction for the line), so a
+// line that shows a new sequence number shows that request's fields.
+static_assert(offsetof(ServerMailbox, stop) == 56 && offsetof(ServerMailbox, state) == 64 && sizeof(ServerCtl) == 64, "request line");
+__device__ __forceinline__ uint64_t line_u64(uint32_t v, int i) {   // qword i of the line a wave holds
+  return (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)v, 2 * i) |
+         ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)v, 2 * i + 1) << 32);
+}
+
+template <int WPQ, int NP>
+// waves_per_eu(4, 4) = 128 VGPRs: three workgroups per CU then leave 128 registers per SIMD lane for the 256-thread posterior
+// kernels (<= 48) that must run beside the resident sweep (prior_kernels.hip: kSmallThreads)
+__global__ __launch_bounds__(WPQ * 64) __attribute__((amdgpu_waves_per_eu(4, 4)))
+void eval_server_f64(EvalArgs a, ServerMailbox *mb, ServerCtl *ctl, uint64_t lastSeq, uint64_t idleTicks,
+                     unsigned stepOffsetBytes) {
+  extern __shared__ double smem[];
+  uint32_t *step = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(smem) + stepOffsetBytes);   // 16 dwords
+  const int wave = (int)__builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+  const unsigned word = threadIdx.x & 15;
+  const bool first = blockIdx.x == 0;
+  uint32_t *mbWord = reinterpret_cast<uint32_t *>(mb) + word, *ctlWord = reinterpret_cast<uint32_t *>(ctl) + word;
+  uint64_t last = lastSeq;
+  bool copyTable = true;
+  for (;;) {
+    if (wave == 0) {
+      uint32_t v = 0;
+      uint64_t go = last;
+      const uint64_t t0 = wall_clock64();
+      if (first) {
+        for (;;) {
+          v = __hip_atomic_load(mbWord, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          go = line_u64(v, 0);
+          if (go != last) break;
+          const bool stop = line_u64(v, 7) != 0;
+          if (stop || wall_clock64() - t0 > idleTicks) {
+            // leaving: say so, then look once more -- the host posts first and reads `state` second (tools/server_rt.hip)
+            __hip_atomic_store(&mb->state, kServerExiting, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "");
+            v = __hip_atomic_load(mbWord, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            go = line_u64(v, 0);
+            if (go != last && !stop) {
+              __hip_atomic_store(&mb->state, kServerRunning, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            } else {
+              go = ~0ull;
+              v = 0xFFFFFFFFu;     // (every dword of the hand-off line, the sequence number included)
+            }
+            break;
+          }
+        }
+        if (go != ~0ull) __hip_atomic_store(&mb->taken, go, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(ctlWord, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // the whole line: one store instruction
+      } else {
+        for (;;) {
+          v = __hip_atomic_load(ctlWord, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          go = line_u64(v, 0);
+          if (go != last && go != 0) break;
+          if (wall_clock64() - t0 > 8 * idleTicks + 100000000ull) { v = 0xFFFFFFFFu; break; }   // workgroup 0 is gone
+          __builtin_amdgcn_s_sleep(1);
+        }
+      }
+      step[word] = v;   // lanes l, l+16, .. store the same dword
+    }
+    __syncthreads();
+    const uint64_t go = uniform64(reinterpret_cast<const uint64_t *>(step)[0]);
+    if (go == ~0ull) break;
+    EvalArgs b = a;
+    b.prior = reinterpret_cast<const double *>(uniform64(reinterpret_cast<const uint64_t *>(step)[1]));
+    b.asked = reinterpret_cast<const uint32_t *>(uniform64(reinterpret_cast<const uint64_t *>(step)[2]));
+    b.fs.out = reinterpret_cast<SelectResult *>(uniform64(reinterpret_cast<const uint64_t *>(step)[3]));
+    b.fs.seq = reinterpret_cast<uint64_t *>(uniform64(reinterpret_cast<const uint64_t *>(step)[4]));
+    b.fs.flagValue = uniform64(reinterpret_cast<const uint64_t *>(step)[5]);
+    b.fs.outBase = (int64_t)uniform64(reinterpret_cast<const uint64_t *>(step)[6]);
+    b.fs.seqValue = go;
+    // (as with the thread index: nothing derived from the launch constants may be hoisted out of the step loop)
+    asm volatile("" : "+s"(b.cube), "+s"(b.tgap), "+s"(b.qgap), "+s"(b.priority), "+s"(b.fs.scratch), "+s"(b.K), "+s"(b.ldT),
+                 "+s"(b.qFirst), "+s"(b.qLimit));
+    __syncthreads();   // the step block may be rewritten only after everybody has read it
+#ifdef PQA_SERVER_TRACE
+    const uint64_t tA = wall_clock64();
+#endif
+    sweep_body<WPQ, NP, false, true>(b, copyTable);
+    copyTable = false;
+    last = go;
+    if (first && wave == 0) __hip_atomic_store(&mb->done, go, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+#ifdef PQA_SERVER_TRACE
+    if (first && wave == 0) { mb->pad[0] = tA; mb->pad[1] = wall_clock64(); }
+    if (blockIdx.x == gridDim.x - 1 && wave == 0) { mb->pad[2] = tA; mb->pad[3] = wall_clock64(); }
+#endif
+    __syncthreads();   // closes every divergent region of the step before the next one's wait
+  }
+  if (first && wave == 0) __hip_atomic_store(&mb->state, kServerExited, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -637,7 +780,7 @@ __global__ __launch_bounds__(256) void eval_questions_f64_stream(EvalArgs a) {
     }
     qpar ^= 1;
   }
-  if (wave == 0) fused_select(a, best);   // lane 0 carries the workgroup's best, the other lanes none
+  if (wave == 0) fused_select(a, best, lane);   // lane 0 carries the workgroup's best, the other lanes none
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -823,6 +966,56 @@ hipError_t LaunchEvalQuestionsBatch(const KbView &kb, const QuizSlot *slots, int
   args.fs = fused;
   args.slots = slots;
   return launch_variant(args, kb.ldT, variant, nSlots, stream);
+}
+
+template <int WPQ, int NP>
+static hipError_t launch_server(const EvalArgs &args, ServerMailbox *mb, ServerCtl *ctl, uint64_t lastSeq, uint64_t idleTicks,
+                                hipStream_t stream) {
+  const size_t stepOffset = eval_md_row_offset_bytes(WPQ, args.K) + (size_t)NP * WPQ * kWave * 16;
+  const size_t shmem = stepOffset + 64;
+  auto kern = eval_server_f64<WPQ, NP>;
+  static size_t cachedShmem = ~(size_t)0;
+  static int cachedPerCU = 0;
+  if (shmem != cachedShmem) {
+    if (shmem > 64 * 1024) {
+      const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+      if (e != hipSuccess) return e;
+    }
+    if (gNumCUs == 0) {
+      int dev = 0, n = 0;
+      gNumCUs = (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
+    }
+    int perCU = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, kern, WPQ * 64, shmem) != hipSuccess || perCU < 1) perCU = 1;
+    if (NP <= 2 && perCU > 3) perCU = 3;   // as launch_reg
+    cachedPerCU = perCU;
+    cachedShmem = shmem;
+  }
+  // every workgroup must be resident at once: the steps are collective
+  const int64_t nQ = args.qLimit - args.qFirst, resident = (int64_t)gNumCUs * cachedPerCU;
+  int64_t grid = nQ < resident ? nQ : resident;
+  if (grid > kFusedMaxGrid) grid = kFusedMaxGrid;
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(WPQ * 64), shmem, stream, args, mb, ctl, lastSeq, idleTicks, (unsigned)stepOffset);
+  return hipGetLastError();
+}
+
+static int server_variant(const KbView &kb, int variant) {
+  const int v = pick_variant(kb.ldT, variant);
+  return v == 2 ? v : 0;   // wg256_np2: rows up to 1024 targets
+}
+bool EvalServerSupported(const KbView &kb, int variant) { return server_variant(kb, variant) != 0; }
+
+hipError_t LaunchEvalServer(const KbView &kb, int64_t qFirst, int64_t qLimit, double *priority, int variant,
+                            SelectResult *scratch, ServerMailbox *mailbox, ServerCtl *ctl, uint64_t lastSeq,
+                            uint64_t idleTicks, hipStream_t stream) {
+  if (qLimit <= qFirst || scratch == nullptr || mailbox == nullptr || ctl == nullptr) return hipErrorInvalidValue;
+  EvalArgs args = make_args(kb, qFirst, qLimit);
+  args.priority = priority;
+  args.fs.scratch = scratch;
+  switch (server_variant(kb, variant)) {
+    case 2: return launch_server<4, 2>(args, mailbox, ctl, lastSeq, idleTicks, stream);
+    default: return hipErrorNotSupported;
+  }
 }
 
 }  // namespace pqa

@@ -207,6 +207,10 @@ Error HipEngine::Init(const CiEngineDefinition &def, const CiHipShard *shard) {
 
 HipEngine::~HipEngine() {
   hipSetDevice(_device);
+  StopServer();
+  if (_serverStream) hipStreamDestroy(_serverStream);
+  if (_hMailbox) hipHostFree(_hMailbox);
+  hipFree(_dServerCtl);
   if (_stream) hipStreamSynchronize(_stream);
   for (Quiz *q : _quizzes) if (q) DestroyQuiz(q);
   hipFree(_dCube); hipFree(_dVB); hipFree(_dPriority); hipFree(_dRunLength); hipFree(_dExps); hipFree(_dStatus);
@@ -220,6 +224,7 @@ HipEngine::~HipEngine() {
 }
 
 Error HipEngine::UploadGaps() {
+  StopServer();  // its launch arguments hold the old view
   _kbVersion++;  // every change of the KB's shape or gaps passes through here: captured graphs hold the old view
   HIP_TRY(hipMemcpyAsync(_dTGap, _hTGap.data(), _hTGap.size() * sizeof(uint32_t), hipMemcpyHostToDevice, _stream));
   HIP_TRY(hipMemcpyAsync(_dQGap, _hQGap.data(), _hQGap.size() * sizeof(uint32_t), hipMemcpyHostToDevice, _stream));
@@ -232,6 +237,7 @@ KbView HipEngine::View() const {
   v.cube = _dCube; v.vB = _dVB; v.tgap = _dTGap; v.qgap = _dQGap;
   v.K = _K; v.Q = _Q; v.T = _T; v.ldT = _ldT;
   v.nValidTargets = _T - _nTargetGaps;
+  v.smallLaunches = _optServer ? 1 : 0;
   return v;
 }
 
@@ -239,7 +245,7 @@ KbView HipEngine::View() const {
 // options
 // ------------------------------------------------------------------------------------------------------------------
 Error HipEngine::SetOption(const char *name, int64_t value) {
-  std::lock_guard<std::mutex> lk(_mu);
+  std::lock_guard<EngineMutex> lk(_mu);
   const std::string n(name ? name : "");
   if (n == "select") { if (value != 0 && value != 1) goto bad; _optSelect = value; }
   else if (n == "workers") { if (value < 1 || value > 4096) goto bad; _optWorkers = value; }
@@ -248,6 +254,8 @@ Error HipEngine::SetOption(const char *name, int64_t value) {
   else if (n == "bug_compat") { _optBugCompat = value ? 1 : 0; }
   else if (n == "use_graph") { _optUseGraph = value ? 1 : 0; }
   else if (n == "top_cache") { if (value < 0 || value > 256) goto bad; _optTopCache = value; }
+  else if (n == "server") { if (!value) StopServer(); _optServer = value ? 1 : 0; }
+  else if (n == "server_idle_us") { if (value < 10 || value > 1000000) goto bad; StopServer(); _optServerIdleUs = value; }
   else if (n == "seed") { uint64_t s = (uint64_t)value; _rng[0] = SplitMix64(s); _rng[1] = SplitMix64(s); }
   else goto bad;
   return Error();
@@ -264,6 +272,10 @@ int64_t HipEngine::GetOption(const char *name) const {
   if (n == "bug_compat") return _optBugCompat;
   if (n == "top_cache") return _optTopCache;
   if (n == "use_graph") return _optUseGraph;
+  if (n == "server") return _optServer;
+  if (n == "server_idle_us") return _optServerIdleUs;
+  if (n == "debug_mailbox") return (int64_t)(uintptr_t)_hMailbox;
+  if (n == "server_active") return (_optServer && ServerUsable()) ? 1 : 0;
   if (n == "ldT") return _ldT;
   if (n == "device") return _device;
   return -1;
@@ -306,6 +318,7 @@ Quiz *HipEngine::UseQuiz(Error &err, int64_t iQuiz) {
 }
 
 void HipEngine::DestroyQuiz(Quiz *q) {
+  ServerQuiesce();
   if (!q) return;
   if (_topOwner == q) _topOwner = nullptr;
   {
@@ -408,7 +421,7 @@ int64_t HipEngine::CreateQuiz(Error &err, int64_t nAnswered, const AQ *pAQs) {
 }
 
 int64_t HipEngine::StartQuiz(Error &err) {
-  std::lock_guard<std::mutex> lk(_mu);
+  std::lock_guard<EngineMutex> lk(_mu);
   return CreateQuiz(err, 0, nullptr);
 }
 
@@ -421,12 +434,12 @@ int64_t HipEngine::ResumeQuiz(Error &err, int64_t nAnswered, const AQ *pAQs) {
     err = Error::Make(ErrCode::NullArgument, "Nullptr is passed in place of answered questions.");
     return -1;
   }
-  std::lock_guard<std::mutex> lk(_mu);
+  std::lock_guard<EngineMutex> lk(_mu);
   return CreateQuiz(err, nAnswered, pAQs);  // nAnswered == 0 -> StartQuiz (BaseEngine.cpp:393-395)
 }
 
 Error HipEngine::ReleaseQuiz(int64_t iQuiz) {
-  std::lock_guard<std::mutex> lk(_mu);
+  std::lock_guard<EngineMutex> lk(_mu);
   Error err = CheckRegular("release quiz");
   if (!err.ok()) return err;
   Quiz *q = UseQuiz(err, iQuiz);
@@ -494,7 +507,7 @@ int64_t HipEngine::FinishSelection(Error &err, Quiz *q, int64_t selLocal) {
 }
 
 Error HipEngine::EnqueueEval(int64_t iQuiz) {
-  std::lock_guard<std::mutex> lk(_mu);
+  std::lock_guard<EngineMutex> lk(_mu);
   Error err = CheckRegular("compute next question");
   if (!err.ok()) return err;
   Quiz *q = UseQuiz(err, iQuiz);
@@ -504,7 +517,7 @@ Error HipEngine::EnqueueEval(int64_t iQuiz) {
 }
 
 Error HipEngine::EnqueueSelectArgmax(int64_t iQuiz, void *pOut) {
-  std::lock_guard<std::mutex> lk(_mu);
+  std::lock_guard<EngineMutex> lk(_mu);
   Error err = CheckRegular("compute next question");
   if (!err.ok()) return err;
   Quiz *q = UseQuiz(err, iQuiz);
@@ -519,13 +532,14 @@ Error HipEngine::EnqueueSelectArgmax(int64_t iQuiz, void *pOut) {
 // (probqa_amd/dist.py: ShmSelector): the record goes to pOut and then flagValue to pFlag, both device-visible addresses of
 // host-coherent (registered) memory, straight from the sweep's finisher -- no copy, no stream synchronisation.
 Error HipEngine::EnqueueSelectArgmaxFlag(int64_t iQuiz, void *pOut, void *pFlag, uint64_t flagValue) {
-  std::lock_guard<std::mutex> lk(_mu);
+  std::lock_guard<EngineMutex> lk(_mu);
   Error err = CheckRegular("compute next question");
   if (!err.ok()) return err;
   Quiz *q = UseQuiz(err, iQuiz);
   if (!q) return err;
   if (!pOut || !pFlag) return Error::Make(ErrCode::NullArgument, "Nullptr is passed in place of the record or the flag.");
   hipSetDevice(_device);
+  if (_optServer && ServerUsable()) return ServerPost(q, (SelectResult *)pOut, (uint64_t *)pFlag, flagValue, _qFirst);
   const FusedSelect fs{_dSelScratch, (SelectResult *)pOut, (uint64_t *)pFlag, NextLaunchTag(), _qFirst, 0, flagValue, nullptr};
   HIP_TRY(LaunchEvalQuestions(View(), q->dPrior, q->dAsked, 0, _Q, _dPriority, (int)_optEvalVariant, &fs, _stream));
   return Error();
@@ -548,13 +562,25 @@ Error HipEngine::WaitFlag(volatile uint64_t *flag, uint64_t value, const char *w
 }
 
 int64_t HipEngine::NextQuestionArgmax(Error &err, int64_t iQuiz) {
-  std::lock_guard<std::mutex> lk(_mu);
+  std::lock_guard<EngineMutex> lk(_mu);
   err = CheckRegular("compute next question");
   if (!err.ok()) return -1;
   Quiz *q = UseQuiz(err, iQuiz);
   if (!q) return -1;
   hipSetDevice(_device);
   if (_optUseGraph) return NextQuestionArgmaxGraph(err, q);
+  if (_optServer && ServerUsable()) {
+    // resident sweep: post the request, poll the answer -- no launch on the critical path
+    const uint64_t value = ++_opSeq;
+    err = ServerPost(q, &_hPinned->sel, &_hPinned->seq, value, 0);
+    if (err.ok()) err = ServerWait(&_hPinned->seq, value, "NextQuestionArgmax");
+    if (!err.ok()) return -1;
+    if (_hPinned->sel.index == -3) {
+      err = HipErr(hipErrorLaunchFailure, "NextQuestionArgmax (incomplete sweep)");
+      return -1;
+    }
+    return FinishSelection(err, q, _hPinned->sel.index);
+  }
   // One launch; the last workgroup writes the winner and then a sequence number straight into host-coherent pinned
   // memory, which this thread polls: no D2H copy, no stream synchronisation on the critical path.
   const uint64_t seq = NextLaunchTag();
@@ -571,11 +597,119 @@ int64_t HipEngine::NextQuestionArgmax(Error &err, int64_t iQuiz) {
   return FinishSelection(err, q, _hPinned->sel.index);
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// resident sweep (pqa_kernels.h: ServerMailbox; eval_kernels.hip: eval_server_f64)
+// ------------------------------------------------------------------------------------------------------------------
+bool HipEngine::ServerUsable() const { return EvalServerSupported(View(), (int)_optEvalVariant) && _Q > 0; }
+
+void HipEngine::StopServer() {
+  if (!_serverLaunched) return;
+  hipSetDevice(_device);
+  volatile ServerMailbox *mb = _hMailbox;
+  mb->stop = 1;
+  std::atomic_thread_fence(std::memory_order_seq_cst);
+  hipStreamSynchronize(_serverStream);   // bounded: the kernel polls `stop` and leaves, or has left already
+  mb->stop = 0;
+  _serverLaunched = false;
+}
+
+void HipEngine::ServerQuiesce() {
+  if (!_serverLaunched || _serverPosted == 0) return;
+  volatile ServerMailbox *mb = _hMailbox;
+  const auto t0 = std::chrono::steady_clock::now();
+  uint64_t spins = 0;
+  while (mb->done != _serverPosted && mb->state != kServerExited)
+    if ((++spins & 0xFFF) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(30)) return;
+}
+
+Error HipEngine::ServerWait(volatile uint64_t *flag, uint64_t value, const char *what) {
+  const auto t0 = std::chrono::steady_clock::now();
+  uint64_t spins = 0;
+  volatile ServerMailbox *mb = _hMailbox;
+  while (*flag != value) {
+    if ((++spins & 0xFFF) == 0) {
+      if (mb->state == kServerExited && mb->taken != _serverPosted && *flag != value) return HipErr(hipErrorUnknown, what);
+      if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(30)) return HipErr(hipErrorNotReady, what);
+    }
+  }
+  std::atomic_thread_fence(std::memory_order_acquire);
+  return Error();
+}
+
+// Post one selection request for quiz `q`; the finisher writes {priority, index + outBase} to `out` and then flagValue to
+// `flag` (host-coherent memory).  Starts the kernel if none is resident.
+Error HipEngine::ServerPost(Quiz *q, SelectResult *out, uint64_t *flag, uint64_t flagValue, int64_t outBase) {
+  // the resident kernel is not ordered behind the engine's stream: wait for what that stream still runs
+  if (_pendingRecordOp != 0 && !_mu.wasBusy) {
+    Error e = WaitFlag(&_hPinned->topFlag, _pendingRecordOp, "ServerPost");
+    if (!e.ok()) return e;
+  } else if (_mu.wasBusy) {
+    HIP_TRY(hipStreamSynchronize(_stream));
+  }
+  _pendingRecordOp = 0;
+  _mu.busy = false;
+  if (!_serverStream) {
+    // A stream of its own PRIORITY, not just of its own: the runtime multiplexes streams of one priority over a few hardware
+    // queues, and a posterior kernel whose packet sits behind the resident kernel's in the same queue waits until that
+    // leaves (measured: 2 ms per quiz step, the idle time).  Queues are pooled per priority.
+    int prLeast = 0, prGreatest = 0;
+    HIP_TRY(hipDeviceGetStreamPriorityRange(&prLeast, &prGreatest));
+    HIP_TRY(hipStreamCreateWithPriority(&_serverStream, hipStreamNonBlocking, prLeast));
+    HIP_TRY(hipHostMalloc((void **)&_hMailbox, sizeof(ServerMailbox), hipHostMallocDefault));
+    std::memset(_hMailbox, 0, sizeof(ServerMailbox));
+    HIP_TRY(hipMalloc((void **)&_dServerCtl, sizeof(ServerCtl)));
+  }
+  if (_serverLaunched && (_serverKb != _kbVersion || _serverVariant != _optEvalVariant)) StopServer();
+  volatile ServerMailbox *mb = _hMailbox;
+  // the previous request's fields must have been read before they are overwritten
+  if (_serverLaunched && _serverPosted != 0) {
+    const auto t0 = std::chrono::steady_clock::now();
+    uint64_t spins = 0;
+    while (mb->taken != _serverPosted && mb->state != kServerExited) {
+      if ((++spins & 0xFFF) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(30))
+        return HipErr(hipErrorNotReady, "ServerPost (previous request never taken)");
+    }
+  }
+  const uint64_t prev = mb->req;
+  const uint64_t seq = NextLaunchTag();
+  mb->prior = q->dPrior;
+  mb->asked = q->dAsked;
+  mb->out = out;
+  mb->flag = flag;
+  mb->flagValue = flagValue;
+  mb->outBase = outBase;
+  std::atomic_thread_fence(std::memory_order_release);
+  mb->req = seq;
+  std::atomic_thread_fence(std::memory_order_seq_cst);
+  _serverPosted = seq;
+  if (_serverLaunched) {
+    // Posted first, looked second; the kernel says "leaving" first and looks second: one of the two sees the other.
+    uint64_t st = mb->state;
+    if (st == kServerExiting) {
+      const auto t0 = std::chrono::steady_clock::now();
+      while ((st = mb->state) == kServerExiting)
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(30)) return HipErr(hipErrorNotReady, "ServerPost");
+    }
+    if (st == kServerRunning) return Error();
+    _serverLaunched = false;   // it left without this request
+  }
+  HIP_TRY(hipStreamSynchronize(_serverStream));                       // the previous instance is gone entirely
+  HIP_TRY(hipMemsetAsync(_dServerCtl, 0, sizeof(ServerCtl), _serverStream));
+  mb->state = kServerRunning;
+  std::atomic_thread_fence(std::memory_order_seq_cst);
+  HIP_TRY(LaunchEvalServer(View(), 0, _Q, _dPriority, (int)_optEvalVariant, _dSelScratch, _hMailbox, _dServerCtl, prev,
+                           (uint64_t)_optServerIdleUs * 100, _serverStream));   // 100 MHz ticks
+  _serverLaunched = true;
+  _serverKb = _kbVersion;
+  _serverVariant = _optEvalVariant;
+  return Error();
+}
+
 // Argmax selections for several quizzes with ONE launch (grid.y = quiz): the launch / dispatch / hand-back overhead that
 // dominates a single selection on small knowledge bases is paid once per batch.  pOut[i] = the selected GLOBAL question of
 // pQuizzes[i], or -1 when that quiz has run out of questions (not an error of the call).
 Error HipEngine::NextQuestionArgmaxBatch(int64_t n, const int64_t *pQuizzes, int64_t *pOut) {
-  std::lock_guard<std::mutex> lk(_mu);
+  std::lock_guard<EngineMutex> lk(_mu);
   Error err = CheckRegular("compute next questions");
   if (!err.ok()) return err;
   if (n < 0 || n > kMaxBatch)
@@ -680,7 +814,7 @@ int64_t HipEngine::NextQuestionArgmaxGraph(Error &err, Quiz *q) {
 }
 
 int64_t HipEngine::NextQuestionSampled(Error &err, int64_t iQuiz, uint64_t rnd) {
-  std::lock_guard<std::mutex> lk(_mu);
+  std::lock_guard<EngineMutex> lk(_mu);
   err = CheckRegular("compute next question");
   if (!err.ok()) return -1;
   Quiz *q = UseQuiz(err, iQuiz);
@@ -702,12 +836,12 @@ int64_t HipEngine::NextQuestionSampled(Error &err, int64_t iQuiz, uint64_t rnd) 
 int64_t HipEngine::NextQuestion(Error &err, int64_t iQuiz) {
   if (_optSelect == 1) return NextQuestionArgmax(err, iQuiz);
   uint64_t rnd;
-  { std::lock_guard<std::mutex> lk(_mu); rnd = NextRandom(); }
+  { std::lock_guard<EngineMutex> lk(_mu); rnd = NextRandom(); }
   return NextQuestionSampled(err, iQuiz, rnd);
 }
 
 Error HipEngine::EvalPriorities(int64_t iQuiz, double *pOut, int64_t n) {
-  std::lock_guard<std::mutex> lk(_mu);
+  std::lock_guard<EngineMutex> lk(_mu);
   Error err = CheckRegular("compute next question");
   if (!err.ok()) return err;
   Quiz *q = UseQuiz(err, iQuiz);
@@ -725,7 +859,7 @@ Error HipEngine::EvalPriorities(int64_t iQuiz, double *pOut, int64_t n) {
 // RecordAnswer and friends
 // ------------------------------------------------------------------------------------------------------------------
 Error HipEngine::RecordAnswerImpl(int64_t iQuiz, int64_t iAnswer, bool remote) {
-  std::lock_guard<std::mutex> lk(_mu);
+  std::lock_guard<EngineMutex> lk(_mu);
   Error err = CheckRegular("record an answer");
   if (!err.ok()) return err;
   if (iAnswer < 0 || iAnswer >= _K)  // reference PqaCore/BaseEngine.cpp:447-451
@@ -745,6 +879,7 @@ Error HipEngine::RecordAnswerImpl(int64_t iQuiz, int64_t iAnswer, bool remote) {
     return Error::MakeP(ErrCode::IndexOutOfRange, RangeParams(aq, _qFirst, _qFirst + _Q - 1),
                         remote ? "RecordAnswerRemote on the shard that owns the active question."
                                : "The active question belongs to another shard: use PqaHip_RecordAnswerRemote.");
+  ServerQuiesce();
   q->answers.push_back(AQ{aq, iAnswer});
   q->activeQuestion = -1;
   q->priorVersion++;  // (remote: the caller writes the owner's posterior into the quiz's buffer)
@@ -760,7 +895,12 @@ Error HipEngine::RecordAnswerImpl(int64_t iQuiz, int64_t iAnswer, bool remote) {
   const uint64_t op = ++_opSeq;
   HIP_TRY(LaunchRecordAnswer(View(), q->dPrior, q->dAsked, ql, iAnswer, nLoose, _hPinned->top, &_hPinned->nOut,
                              &_hPinned->topFlag, op, topCount, _stream));
-  if (topCount > 0 && _T <= 16384) { _topOwner = q; _topOp = op; _topVersion = q->priorVersion; _topCount = topCount; }
+  if (topCount > 0 && _T <= 16384) {
+    _topOwner = q; _topOp = op; _topVersion = q->priorVersion; _topCount = topCount;
+    // the kernel stores `op` last: whoever sees it knows that everything enqueued on the stream so far has finished
+    _pendingRecordOp = op;
+    _mu.busy = _mu.wasBusy;   // (busy only if it was before this call: `op` covers this call's launch)
+  }
   return Error();
 }
 
@@ -768,7 +908,7 @@ Error HipEngine::RecordAnswer(int64_t iQuiz, int64_t iAnswer) { return RecordAns
 Error HipEngine::RecordAnswerRemote(int64_t iQuiz, int64_t iAnswer) { return RecordAnswerImpl(iQuiz, iAnswer, true); }
 
 int64_t HipEngine::GetActiveQuestionId(Error &err, int64_t iQuiz) {
-  std::lock_guard<std::mutex> lk(_mu);
+  std::lock_guard<EngineMutex> lk(_mu);
   err = CheckRegular("get active question ID for a quiz");
   if (!err.ok()) return -1;
   Quiz *q = UseQuiz(err, iQuiz);
@@ -777,7 +917,7 @@ int64_t HipEngine::GetActiveQuestionId(Error &err, int64_t iQuiz) {
 }
 
 Error HipEngine::SetActiveQuestion(int64_t iQuiz, int64_t iQuestion) {
-  std::lock_guard<std::mutex> lk(_mu);
+  std::lock_guard<EngineMutex> lk(_mu);
   Error err = CheckRegular("set active question ID for a quiz");
   if (!err.ok()) return err;
   Quiz *q = UseQuiz(err, iQuiz);
@@ -787,7 +927,7 @@ Error HipEngine::SetActiveQuestion(int64_t iQuiz, int64_t iQuestion) {
 }
 
 Error HipEngine::GetPriors(int64_t iQuiz, double *pOut, int64_t n) {
-  std::lock_guard<std::mutex> lk(_mu);
+  std::lock_guard<EngineMutex> lk(_mu);
   Error err;
   Quiz *q = UseQuiz(err, iQuiz);
   if (!q) return err;
@@ -800,7 +940,7 @@ Error HipEngine::GetPriors(int64_t iQuiz, double *pOut, int64_t n) {
 }
 
 Error HipEngine::Log2HotArray(const double *pIn, double *pOut, int64_t n) {
-  std::lock_guard<std::mutex> lk(_mu);
+  std::lock_guard<EngineMutex> lk(_mu);
   if (n < 0 || (n > 0 && (!pIn || !pOut))) return Error::Make(ErrCode::NullArgument, "Nullptr is passed in place of a Log2Hot buffer.");
   if (n == 0) return Error();
   hipSetDevice(_device);
@@ -818,7 +958,7 @@ Error HipEngine::Log2HotArray(const double *pIn, double *pOut, int64_t n) {
 }
 
 Error HipEngine::GetPriorDevicePtr(int64_t iQuiz, void **ppDev, int64_t *pLdT) {
-  std::lock_guard<std::mutex> lk(_mu);
+  std::lock_guard<EngineMutex> lk(_mu);
   Error err;
   Quiz *q = UseQuiz(err, iQuiz);
   if (!q) return err;
@@ -828,7 +968,7 @@ Error HipEngine::GetPriorDevicePtr(int64_t iQuiz, void **ppDev, int64_t *pLdT) {
 }
 
 int64_t HipEngine::ListTopTargets(Error &err, int64_t iQuiz, int64_t maxCount, CiRatedTarget *pDest) {
-  std::lock_guard<std::mutex> lk(_mu);
+  std::lock_guard<EngineMutex> lk(_mu);
   err = CheckRegular("list top targets");
   if (!err.ok()) return -1;
   Quiz *q = UseQuiz(err, iQuiz);
@@ -848,6 +988,10 @@ int64_t HipEngine::ListTopTargets(Error &err, int64_t iQuiz, int64_t maxCount, C
     }
     err = WaitFlag(&_hPinned->topFlag, _topOp, "ListTopTargets");
     if (!err.ok()) return -1;
+    // what was waited for was the newest work on the stream (this call's own launch, or RecordAnswer's kernel with nothing
+    // enqueued behind it): the stream is idle.  Otherwise this call has added nothing to it.
+    if (!cached || want > _topCount || (_pendingRecordOp == _topOp && !_mu.wasBusy)) { _mu.busy = false; _pendingRecordOp = 0; }
+    else _mu.busy = _mu.wasBusy;
     const int64_t n = std::min<int64_t>(_hPinned->nOut, want);
     static_assert(sizeof(RatedTargetDev) == sizeof(CiRatedTarget), "listed straight into the caller's layout");
     std::memcpy(pDest, _hPinned->top, (size_t)n * sizeof(RatedTargetDev));
@@ -876,7 +1020,8 @@ Error HipEngine::Train(int64_t nQuestions, const AQ *pAQs, int64_t iTarget, doub
     return Error::MakeP(ErrCode::NegativeCount, "count=" + std::to_string(nQuestions), "|nQuestions| must be non-negative.");
   if (amount <= 0)
     return Error::MakeP(ErrCode::NonPositiveAmount, "amount=" + std::to_string(amount), "|amount| must be positive.");
-  std::lock_guard<std::mutex> lk(_mu);
+  std::lock_guard<EngineMutex> lk(_mu);
+  StopServer();   // the cube changes: the resident sweep's XCD-local L2s would keep stale rows
   if (_mode == Mode::Shutdown) return Error::MakeP(ErrCode::ObjectShutDown, "RejectedOperation=Train", "Engine is shut down.");
   if (iTarget < 0 || iTarget >= _T)
     return Error::MakeP(ErrCode::IndexOutOfRange, RangeParams(iTarget, 0, _T - 1), "Target index is not in KB range.");
@@ -928,7 +1073,8 @@ Error HipEngine::RecordQuizTarget(int64_t iQuiz, int64_t iTarget, double amount)
     // reference PqaCore/BaseEngine.cpp:529-566
     if (amount <= 0)
       return Error::MakeP(ErrCode::NonPositiveAmount, "amount=" + std::to_string(amount), "|amount| must be positive.");
-    std::lock_guard<std::mutex> lk(_mu);
+    std::lock_guard<EngineMutex> lk(_mu);
+  StopServer();   // the cube changes: the resident sweep's XCD-local L2s would keep stale rows
     Error err = CheckRegular("record quiz target");
     if (!err.ok()) return err;
     if (iTarget < 0 || iTarget >= _T)
@@ -958,7 +1104,8 @@ void HipEngine::CopyDims(CiEngineDimensions *pDims) const {
 }
 
 Error HipEngine::StartMaintenance(bool forceQuizzes) {  // reference PqaCore/BaseEngine.cpp:640-690
-  std::lock_guard<std::mutex> lk(_mu);
+  std::lock_guard<EngineMutex> lk(_mu);
+  StopServer();
   if (_mode == Mode::Shutdown) return Error::MakeP(ErrCode::ObjectShutDown, "RejectedOperation=StartMaintenance", "Engine is shut down.");
   if (_mode == Mode::Maintenance) return Error::MakeP(ErrCode::MaintenanceModeAlreadyThis, "ActiveMode=#1", "Already in maintenance mode.");
   int64_t nActive = 0;
@@ -977,7 +1124,7 @@ Error HipEngine::StartMaintenance(bool forceQuizzes) {  // reference PqaCore/Bas
 }
 
 Error HipEngine::FinishMaintenance() {  // reference PqaCore/BaseEngine.cpp:692-712
-  std::lock_guard<std::mutex> lk(_mu);
+  std::lock_guard<EngineMutex> lk(_mu);
   if (_mode == Mode::Shutdown) return Error::MakeP(ErrCode::ObjectShutDown, "RejectedOperation=FinishMaintenance", "Engine is shut down.");
   if (_mode == Mode::Regular) return Error::MakeP(ErrCode::MaintenanceModeAlreadyThis, "ActiveMode=#0", "Already in regular mode.");
   _mode = Mode::Regular;
@@ -989,7 +1136,8 @@ Error HipEngine::Shutdown(const char *saveFilePath) {
     Error e = SaveKB(saveFilePath, false);
     if (!e.ok()) return e;
   }
-  std::lock_guard<std::mutex> lk(_mu);
+  std::lock_guard<EngineMutex> lk(_mu);
+  StopServer();
   if (_mode == Mode::Shutdown) return Error::MakeP(ErrCode::ObjectShutDown, "RejectedOperation=Shutdown", "Engine is already shut down.");
   hipSetDevice(_device);
   hipStreamSynchronize(_stream);
@@ -998,7 +1146,8 @@ Error HipEngine::Shutdown(const char *saveFilePath) {
 }
 
 Error HipEngine::SetStream(hipStream_t s) {
-  std::lock_guard<std::mutex> lk(_mu);
+  std::lock_guard<EngineMutex> lk(_mu);
+  StopServer();
   hipSetDevice(_device);
   HIP_TRY(hipStreamSynchronize(_stream));
   _stream = s ? s : _ownStream;
@@ -1015,7 +1164,8 @@ Error HipEngine::Synchronize() {
 // bulk KB transfer / synthetic KB / gaps
 // ------------------------------------------------------------------------------------------------------------------
 Error HipEngine::SetKB(const double *pA, const double *pD, const double *pB) {
-  std::lock_guard<std::mutex> lk(_mu);
+  std::lock_guard<EngineMutex> lk(_mu);
+  StopServer();
   if (!pA || !pD || !pB) return Error::Make(ErrCode::NullArgument, "Nullptr is passed in place of a KB array.");
   hipSetDevice(_device);
   const size_t rowB = (size_t)_T * sizeof(double), ldB = (size_t)_ldT * sizeof(double);
@@ -1030,7 +1180,7 @@ Error HipEngine::SetKB(const double *pA, const double *pD, const double *pB) {
 }
 
 Error HipEngine::GetKB(double *pA, double *pD, double *pB) {
-  std::lock_guard<std::mutex> lk(_mu);
+  std::lock_guard<EngineMutex> lk(_mu);
   hipSetDevice(_device);
   const size_t rowB = (size_t)_T * sizeof(double), ldB = (size_t)_ldT * sizeof(double);
   if (pA)
@@ -1044,7 +1194,8 @@ Error HipEngine::GetKB(double *pA, double *pD, double *pB) {
 }
 
 Error HipEngine::FillSynthetic(double nTrain, double noiseAmp, uint64_t seed) {
-  std::lock_guard<std::mutex> lk(_mu);
+  std::lock_guard<EngineMutex> lk(_mu);
+  StopServer();
   hipSetDevice(_device);
   HIP_TRY(LaunchFillSynthetic(_dCube, _dVB, _K, _Q, _T, _ldT, _qFirst, _qTotal, _initAmount, nTrain, noiseAmp, seed, _stream));
   HIP_TRY(hipStreamSynchronize(_stream));
@@ -1052,7 +1203,7 @@ Error HipEngine::FillSynthetic(double nTrain, double noiseAmp, uint64_t seed) {
 }
 
 Error HipEngine::SetTargetGaps(int64_t n, const int64_t *ids) {
-  std::lock_guard<std::mutex> lk(_mu);
+  std::lock_guard<EngineMutex> lk(_mu);
   for (int64_t i = 0; i < n; i++)
     if (ids[i] < 0 || ids[i] >= _T) return Error::MakeP(ErrCode::IndexOutOfRange, RangeParams(ids[i], 0, _T - 1), "Target index is not in KB range.");
   for (int64_t i = 0; i < n; i++)
@@ -1067,7 +1218,7 @@ Error HipEngine::SetTargetGaps(int64_t n, const int64_t *ids) {
 }
 
 Error HipEngine::SetQuestionGaps(int64_t n, const int64_t *ids) {
-  std::lock_guard<std::mutex> lk(_mu);
+  std::lock_guard<EngineMutex> lk(_mu);
   for (int64_t i = 0; i < n; i++)
     if (ids[i] < 0 || ids[i] >= _qTotal) return Error::MakeP(ErrCode::IndexOutOfRange, RangeParams(ids[i], 0, _qTotal - 1), "Question index is not in KB range.");
   for (int64_t i = 0; i < n; i++)

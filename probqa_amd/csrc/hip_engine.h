@@ -221,13 +221,36 @@ class HipEngine {
   std::vector<Quiz *> _quizzes;
   std::vector<int64_t> _quizGaps;
   friend struct KbIo;
-  mutable std::mutex _mu;
+  // The engine's lock.  Taking it also marks the engine's stream as possibly busy: the resident sweep runs on its own
+  // stream, so a request is posted only after whatever the other operations enqueued on `_stream` has finished
+  // (ServerPost); the selection paths, which leave nothing running, restore the mark they found.
+  struct EngineMutex {
+    std::mutex m;
+    bool busy = false, wasBusy = false;
+    void lock() { m.lock(); wasBusy = busy; busy = true; }
+    void unlock() { m.unlock(); }
+  };
+  mutable EngineMutex _mu;
   std::atomic<uint64_t> _nQuestionsAsked{0};
   Mode _mode = Mode::Regular;
   // options
   int64_t _optSelect = 0, _optWorkers = 16, _optEvalSubtasks = 0, _optEvalVariant = 0, _optBugCompat = 0;
   int64_t _optUseGraph = 0;   // NextQuestion (argmax) replays a per-quiz HIP graph instead of launching
   int64_t _optTopCache = 10;  // targets RecordAnswer's kernel lists ahead of the ListTopTargets that follows it (0: none)
+  // ---- resident sweep (option "server"; pqa_kernels.h: ServerMailbox)
+  int64_t _optServer = 0, _optServerIdleUs = 2000;
+  hipStream_t _serverStream = nullptr;
+  ServerMailbox *_hMailbox = nullptr;     // pinned
+  ServerCtl *_dServerCtl = nullptr;
+  bool _serverLaunched = false;           // a kernel instance has been launched and not yet seen to have left
+  uint64_t _serverKb = 0, _serverPosted = 0;
+  int64_t _serverVariant = 0;
+  uint64_t _pendingRecordOp = 0;          // RecordAnswer's kernel is the newest work on _stream and publishes this op number
+  bool ServerUsable() const;
+  Error ServerPost(Quiz *q, SelectResult *out, uint64_t *flag, uint64_t flagValue, int64_t outBase);
+  Error ServerWait(volatile uint64_t *flag, uint64_t value, const char *what);
+  void StopServer();
+  void ServerQuiesce();   // returns once the posted step (if any) has finished: before anything that writes what it reads
   uint64_t _rng[2] = {0, 0};
 };
 

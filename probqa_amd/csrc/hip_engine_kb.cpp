@@ -151,17 +151,20 @@ bool PermIdMgr::RemapPermId(int64_t srcPermId, int64_t destPermId) {  // :171-19
 // id maps and the quiz registry (reference PqaCore/BaseEngine.cpp:150-215, 780-802)
 // ------------------------------------------------------------------------------------------------------------------
 bool HipEngine::MapIds(int which, bool toPerm, int64_t count, int64_t *pIds) {
-  std::lock_guard<std::mutex> lk(_mu);
+  std::lock_guard<EngineMutex> lk(_mu);
+  StopServer();
   PermIdMgr &pim = which == 0 ? _pimQuestions : which == 1 ? _pimTargets : _pimQuizzes;
   for (int64_t i = 0; i < count; i++) pIds[i] = toPerm ? pim.PermFromComp(pIds[i]) : pim.CompFromPerm(pIds[i]);
   return true;
 }
 bool HipEngine::EnsurePermQuizGreater(int64_t bound) {
-  std::lock_guard<std::mutex> lk(_mu);
+  std::lock_guard<EngineMutex> lk(_mu);
+  StopServer();
   return _pimQuizzes.EnsurePermIdGreater(bound);
 }
 bool HipEngine::RemapQuizPermId(int64_t srcPermId, int64_t destPermId) {
-  std::lock_guard<std::mutex> lk(_mu);
+  std::lock_guard<EngineMutex> lk(_mu);
+  StopServer();
   return _pimQuizzes.RemapPermId(srcPermId, destPermId);
 }
 
@@ -190,7 +193,8 @@ Error HipEngine::ClearOldQuizzes(int64_t maxCount, double maxAgeSec) {  // BaseE
   if (maxCount < 0)
     return Error::MakeP(ErrCode::NegativeCount, "count=" + std::to_string(maxCount),
                         "The number of quizzes to keep cannot be less than 0.");
-  std::lock_guard<std::mutex> lk(_mu);
+  std::lock_guard<EngineMutex> lk(_mu);
+  StopServer();
   if (_mode != Mode::Regular) return Error();  // quizzes are not expected to exist in maintenance / shutdown mode
   hipSetDevice(_device);
   hipStreamSynchronize(_stream);
@@ -226,7 +230,8 @@ Error HipEngine::ClearOldQuizzes(int64_t maxCount, double maxAgeSec) {  // BaseE
 Error HipEngine::SaveKB(const char *filePath, bool doubleBuffer) {
   (void)doubleBuffer;  // the device copy already is the "second buffer": the file is written from a host snapshot
   if (!filePath) return Error::Make(ErrCode::NullArgument, "Nullptr is passed in place of KB file name.");
-  std::lock_guard<std::mutex> lk(_mu);
+  std::lock_guard<EngineMutex> lk(_mu);
+  StopServer();
   if (_qTotal != _Q) return Error::MakeP(ErrCode::NotImplemented, "Feature=SaveKB of a sharded engine", "Save the shards' owner instead.");
   FileCloser fc{std::fopen(filePath, "wb")};
   if (!fc.f)
@@ -403,7 +408,8 @@ Error HipEngine::ReallocKB(int64_t newQ, int64_t newT) {
 }
 
 Error HipEngine::AddQsTs(int64_t nQuestions, CiAddQorTParam *pAqps, int64_t nTargets, CiAddQorTParam *pAtps) {
-  std::lock_guard<std::mutex> lk(_mu);
+  std::lock_guard<EngineMutex> lk(_mu);
+  StopServer();
   if (_mode != Mode::Maintenance) return WrongModeErr("add questions/targets");
   if (nQuestions < 0 || nTargets < 0)
     return Error::MakeP(ErrCode::NegativeCount, "count=" + std::to_string(std::min(nQuestions, nTargets)), "Counts must be non-negative.");
@@ -466,7 +472,8 @@ Error HipEngine::AddQsTs(int64_t nQuestions, CiAddQorTParam *pAqps, int64_t nTar
 }
 
 Error HipEngine::RemoveQuestions(int64_t n, const int64_t *pQIds) {  // BaseEngine.cpp:722-743
-  std::lock_guard<std::mutex> lk(_mu);
+  std::lock_guard<EngineMutex> lk(_mu);
+  StopServer();
   if (_mode != Mode::Maintenance) return WrongModeErr("remove questions");
   for (int64_t i = 0; i < n; i++) {
     const int64_t iq = pQIds[i];
@@ -481,7 +488,8 @@ Error HipEngine::RemoveQuestions(int64_t n, const int64_t *pQIds) {  // BaseEngi
 }
 
 Error HipEngine::RemoveTargets(int64_t n, const int64_t *pTIds) {  // BaseEngine.cpp:745-765
-  std::lock_guard<std::mutex> lk(_mu);
+  std::lock_guard<EngineMutex> lk(_mu);
+  StopServer();
   if (_mode != Mode::Maintenance) return WrongModeErr("remove targets");
   for (int64_t i = 0; i < n; i++) {
     const int64_t it = pTIds[i];
@@ -498,7 +506,8 @@ Error HipEngine::RemoveTargets(int64_t n, const int64_t *pTIds) {  // BaseEngine
 
 Error HipEngine::Compact(int64_t *pnQuestions, const int64_t **ppOldQuestions, int64_t *pnTargets,
                          const int64_t **ppOldTargets) {  // CpuEngine::CompactSpec, CpuEngine.cpp:577-658
-  std::lock_guard<std::mutex> lk(_mu);
+  std::lock_guard<EngineMutex> lk(_mu);
+  StopServer();
   if (_mode != Mode::Maintenance) return WrongModeErr("compact the KB");
   if (!pnQuestions || !ppOldQuestions || !pnTargets || !ppOldTargets) return Error::Make(ErrCode::NullArgument, "Nullptr output.");
   hipSetDevice(_device);

@@ -82,11 +82,12 @@ __global__ void train_kernel(double *__restrict__ cube, double *__restrict__ vB,
 
 // ListTopTargets on the device (top_targets_publish in pqa_device.h); T <= 16384.
 static_assert(sizeof(TopOut) == sizeof(RatedTargetDev), "same record");
-__global__ __launch_bounds__(1024) void top_targets_kernel(const double *__restrict__ prior,
-                                                           const uint32_t *__restrict__ tgap, int64_t T,
-                                                           int64_t maxCount, RatedTargetDev *out, int64_t *nOut,
-                                                           uint64_t *flag, uint64_t flagValue) {
-  top_targets_publish(prior, tgap, T, maxCount, reinterpret_cast<TopOut *>(out), nOut, flag, flagValue);
+template <bool SMALL>
+__global__ __launch_bounds__(SMALL ? 256 : 1024) void top_targets_kernel(const double *__restrict__ prior,
+                                                                         const uint32_t *__restrict__ tgap, int64_t T,
+                                                                         int64_t maxCount, RatedTargetDev *out, int64_t *nOut,
+                                                                         uint64_t *flag, uint64_t flagValue) {
+  top_targets_publish<SMALL>(prior, tgap, T, maxCount, reinterpret_cast<TopOut *>(out), nOut, flag, flagValue);
 }
 
 unsigned grid_for(int64_t n, int threads) {
@@ -189,8 +190,12 @@ hipError_t LaunchTrain(double *cube, double *vB, int64_t K, int64_t ldT, const i
 hipError_t LaunchTopTargets(const KbView &kb, const double *prior, int64_t maxCount, RatedTargetDev *out,
                             int64_t *nOut, uint64_t *flag, uint64_t flagValue, hipStream_t stream) {
   if (kb.T > 16384) return hipErrorInvalidValue;  // the host-side listing takes over (hip_engine.cpp)
-  hipLaunchKernelGGL(top_targets_kernel, dim3(1), dim3(1024), 0, stream, prior, kb.tgap, kb.T, maxCount, out, nOut, flag,
-                     flagValue);
+  if (kb.smallLaunches && kb.T <= 1024)   // beside the resident sweep (prior_kernels.hip: kSmallThreads)
+    hipLaunchKernelGGL(top_targets_kernel<true>, dim3(1), dim3(256), 0, stream, prior, kb.tgap, kb.T, maxCount, out, nOut, flag,
+                       flagValue);
+  else
+    hipLaunchKernelGGL(top_targets_kernel<false>, dim3(1), dim3(1024), 0, stream, prior, kb.tgap, kb.T, maxCount, out, nOut, flag,
+                       flagValue);
   return hipGetLastError();
 }
 

@@ -240,7 +240,7 @@ __device__ __forceinline__ double precise_sum4(const double *sum, const double *
 
 // ---- top-maxCount targets by probability -------------------------------------------------------------------------------
 // Descending probability, lower index first on ties, gaps never listed (reference PqaCore/CEListTopTargetsAlgorithm.cpp).
-// For a 1024-thread workgroup: every thread holds its E targets (t = tid + e*1024) in registers; a round is one wave
+// For a workgroup of up to 1024 threads: every thread holds its E targets (t = tid + e*blockDim) in registers; a round is one wave
 // argmax by DPP / permlane swaps, one LDS exchange and ONE barrier (the per-wave results alternate between two LDS rows by
 // round parity), one 16-lane row argmax over the 16 waves' results, after which every thread knows the round's winner and
 // its owner retires it: ~0.3 us per round.  T <= 1024*E <= 16384; small maxCount.
@@ -296,7 +296,7 @@ __device__ __forceinline__ int64_t top_targets_rounds(const double *prior, const
   TopCand mine[E];
 #pragma unroll
   for (int e = 0; e < E; e++) {
-    const int64_t t = threadIdx.x + (int64_t)e * 1024;
+    const int64_t t = threadIdx.x + (int64_t)e * blockDim.x;
     const bool ok = t < T && !bit_test(tgap, t);
     mine[e].p = ok ? prior[t] : 0.0;
     mine[e].t = ok ? (int)t : -1;
@@ -326,15 +326,25 @@ __device__ __forceinline__ int64_t top_targets_rounds(const double *prior, const
 }
 // the list, its length and then a flag, into host-coherent memory (T <= 16384, maxCount <= 256).  The winners are staged
 // in LDS and leave in one coalesced burst at the end: a store to host memory per round costs more than the round.
+// SMALL: only the <= 4 targets per thread forms (a 256-thread launch over <= 1024 targets keeps 40 VGPRs and fits beside
+// the resident sweep's workgroups, prior_kernels.hip).
+template <bool SMALL = false>
 __device__ __forceinline__ void top_targets_publish(const double *prior, const uint32_t *tgap, int64_t T, int64_t maxCount,
                                                     TopOut *out, int64_t *nOut, uint64_t *flag, uint64_t flagValue) {
   __shared__ double sp[2][16];
   __shared__ int st[2][16];
   __shared__ TopOut staged[256];
   if (maxCount > 256) maxCount = 256;
+  // waves that do not exist never win a round
+  if (threadIdx.x < 32) {
+    sp[threadIdx.x >> 4][threadIdx.x & 15] = 0.0;
+    st[threadIdx.x >> 4][threadIdx.x & 15] = -1;
+  }
+  __syncthreads();
+  const int64_t perThread = (T + blockDim.x - 1) / blockDim.x;
   int64_t listed;
-  if (T <= 1024) listed = top_targets_rounds<1>(prior, tgap, T, maxCount, staged, sp, st);
-  else if (T <= 4096) listed = top_targets_rounds<4>(prior, tgap, T, maxCount, staged, sp, st);
+  if (perThread <= 1) listed = top_targets_rounds<1>(prior, tgap, T, maxCount, staged, sp, st);
+  else if (SMALL || perThread <= 4) listed = top_targets_rounds<4>(prior, tgap, T, maxCount, staged, sp, st);
   else listed = top_targets_rounds<16>(prior, tgap, T, maxCount, staged, sp, st);
   __syncthreads();
   if ((int64_t)threadIdx.x < listed) out[threadIdx.x] = staged[threadIdx.x];

@@ -23,6 +23,7 @@ struct KbView {
   const uint32_t *qgap;   // question gap bits, bits >= Q set
   int64_t K, Q, T, ldT;
   int64_t nValidTargets;  // T - #target gaps (PqaCore/CpuEngine.cpp:352)
+  int smallLaunches;      // the engine runs the resident sweep: posterior kernels over <= 1024 targets use 256 threads
 };
 
 struct SelectResult {     // 16 bytes, written by the select kernels
@@ -68,6 +69,44 @@ hipError_t LaunchEvalQuestions(const KbView &kb, const double *prior, const uint
 hipError_t LaunchEvalQuestionsBatch(const KbView &kb, const QuizSlot *slots, int nSlots, int64_t qFirst, int64_t qLimit,
                                     int variant, const FusedSelect &fused, hipStream_t stream);
 const char *EvalVariantName(const KbView &kb, int variant);
+
+// ---- resident sweep ("server"): ONE launch serves many selections.  The host posts a request in pinned memory; workgroup
+// 0 sees it, hands it to the other workgroups through a device word, everybody sweeps, the finisher answers straight into
+// host-coherent memory.  What a step saves is the launch + dispatch + ramp of one kernel (~8 us of a 26 us selection at
+// 1000 x 5 x 1000).  The kernel leaves by itself after idleTicks (100 MHz) without a request, or when asked to.
+struct ServerMailbox {            // host-coherent (pinned) memory, 128 bytes
+  // host -> device; the request fields are written before `req`
+  uint64_t req;                   // sequence number of the newest request (never 0 / ~0)
+  const double *prior;            // the quiz
+  const uint32_t *asked;
+  SelectResult *out;              // where the finisher writes {priority, index + outBase}
+  uint64_t *flag;                 // ... and then flagValue
+  uint64_t flagValue;
+  int64_t outBase;
+  uint64_t stop;                  // non-zero: leave now
+  // device -> host
+  uint64_t state;                 // kServerRunning / kServerExiting / kServerExited
+  uint64_t taken;                 // newest request the kernel has started on
+  uint64_t done;                  // newest request whose step has finished (its result was published before)
+  uint64_t pad[5];
+};
+constexpr uint64_t kServerRunning = 1, kServerExiting = 2, kServerExited = 3;
+struct ServerCtl {                // device memory, one line; zeroed before each launch: workgroup 0 -> the other workgroups
+  uint64_t go;                    // newest request (the line's fields belong to it); ~0: leave
+  const double *prior;
+  const uint32_t *asked;
+  SelectResult *out;
+  uint64_t *flag;
+  uint64_t flagValue;
+  int64_t outBase;
+  uint64_t pad;
+};
+// Only the short-row register shapes have a resident form (that is where a launch is a large part of a selection):
+// returns hipErrorNotSupported otherwise.  `scratch`: kFusedMaxGrid records.  lastSeq: the kernel serves requests != lastSeq.
+hipError_t LaunchEvalServer(const KbView &kb, int64_t qFirst, int64_t qLimit, double *priority, int variant,
+                            SelectResult *scratch, ServerMailbox *mailbox, ServerCtl *ctl, uint64_t lastSeq,
+                            uint64_t idleTicks, hipStream_t stream);
+bool EvalServerSupported(const KbView &kb, int variant);
 
 struct RatedTargetDev { int64_t iTarget; double prob; };  // == CiRatedTarget
 

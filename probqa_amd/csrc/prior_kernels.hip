@@ -22,6 +22,11 @@ namespace pqa {
 namespace {
 
 constexpr int kThreads = 1024;
+// While the resident sweep (eval_kernels.hip: eval_server_f64) holds three workgroups of 152 VGPRs on every CU, a
+// 1024-thread workgroup of these kernels fits nowhere and would wait for the sweep to leave.  With <= 1024 targets they are
+// launched with 256 threads instead (one wave per SIMD, <= 56 VGPRs): same arithmetic, same summation order.
+constexpr int kSmallThreads = 256;
+static inline bool small_launch(const KbView &kb) { return kb.smallLaunches && kb.T <= 4 * kSmallThreads; }
 
 __device__ __forceinline__ int64_t split_bound(int64_t i, int64_t quot, int64_t rem) {  // end of subtask i
   const int64_t n1 = (i + 1 < rem) ? (i + 1) : rem;
@@ -87,8 +92,9 @@ struct TopRequest {
   int64_t count;       // 0: no listing
 };
 
-__global__ __launch_bounds__(kThreads) void record_answer_kernel(PriorArgs a, int64_t iQuestion, int64_t iAnswer,
-                                                                 uint32_t *asked, TopRequest top) {
+template <bool SMALL>
+__global__ __launch_bounds__(SMALL ? kSmallThreads : kThreads) void record_answer_kernel(PriorArgs a, int64_t iQuestion, int64_t iAnswer,
+                                                                                         uint32_t *asked, TopRequest top) {
   extern __shared__ double lds[];
   // CEQuiz::RecordAnswer marks the question as asked (PqaCore/CEQuiz.h:92); done here, in stream order with the sweeps
   // that read the bitmap, so that the host call needs neither a copy nor a synchronisation
@@ -105,7 +111,7 @@ __global__ __launch_bounds__(kThreads) void record_answer_kernel(PriorArgs a, in
   for (int64_t t = threadIdx.x; t < 4 * nVects; t += blockDim.x) a.prior[t] = a.prior[t] / total;
   if (top.count > 0) {
     __syncthreads();  // (a thread lists exactly the targets it has just written; the barrier is for the shared LDS rows)
-    top_targets_publish(a.prior, a.tgap, a.T, top.count, top.out, top.nOut, top.flag, top.flagValue);
+    top_targets_publish<SMALL>(a.prior, a.tgap, a.T, top.count, top.out, top.nOut, top.flag, top.flagValue);
   }
 }
 
@@ -120,6 +126,7 @@ __global__ __launch_bounds__(kThreads) void resume_quiz_kernel(PriorArgs a, int6
                                                                int bugCompat, int64_t *status) {
   extern __shared__ double lds[];
   __shared__ long long sMax[kThreads / kWave];
+  const int nWaves = (int)(blockDim.x / kWave);
   __shared__ long long sCorr;
   const int64_t nVects = (a.T + 3) >> 2;
   // a8: every target runs its own chain of products over the answered questions, mantissa and exponent kept apart.
@@ -157,7 +164,7 @@ __global__ __launch_bounds__(kThreads) void resume_quiz_kernel(PriorArgs a, int6
   __syncthreads();
   if (threadIdx.x == 0) {
     long long fullMax = sMax[0];
-    for (int w = 1; w < kThreads / kWave; w++) fullMax = sMax[w] > fullMax ? sMax[w] : fullMax;
+    for (int w = 1; w < nWaves; w++) fullMax = sMax[w] > fullMax ? sMax[w] : fullMax;
     const long long highBound = 1023 + 1023 - ceil_log2_u64((uint64_t)a.T) - 2;  // CpuEngine.cpp:316
     const long long minAllowed = INT64_MIN + highBound + 1;                      // :317
     status[1] = fullMax;
@@ -203,7 +210,7 @@ PriorArgs make_args(const KbView &kb, double *prior, int64_t nWorkers) {
 
 hipError_t LaunchStartQuiz(const KbView &kb, double *prior, int64_t nWorkers, hipStream_t stream) {
   if (nWorkers < 1 || nWorkers > 4096) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(start_quiz_kernel, dim3(1), dim3(kThreads), sum_lds_bytes(nWorkers), stream,
+  hipLaunchKernelGGL(start_quiz_kernel, dim3(1), dim3(small_launch(kb) ? kSmallThreads : kThreads), sum_lds_bytes(nWorkers), stream,
                      make_args(kb, prior, nWorkers));
   return hipGetLastError();
 }
@@ -212,17 +219,20 @@ hipError_t LaunchRecordAnswer(const KbView &kb, double *prior, uint32_t *asked, 
                               int64_t nWorkers, RatedTargetDev *topOut, int64_t *topN, uint64_t *topFlag,
                               uint64_t topFlagValue, int64_t topCount, hipStream_t stream) {
   if (nWorkers < 1 || nWorkers > 4096) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(record_answer_kernel, dim3(1), dim3(kThreads), sum_lds_bytes(nWorkers), stream,
-                     make_args(kb, prior, nWorkers), iQuestion, iAnswer, asked,
-                     TopRequest{reinterpret_cast<TopOut *>(topOut), topN, topFlag, topFlagValue,
-                                (topOut && kb.T <= 16384) ? topCount : 0});
+  const TopRequest top{reinterpret_cast<TopOut *>(topOut), topN, topFlag, topFlagValue, (topOut && kb.T <= 16384) ? topCount : 0};
+  if (small_launch(kb))
+    hipLaunchKernelGGL(record_answer_kernel<true>, dim3(1), dim3(kSmallThreads), sum_lds_bytes(nWorkers), stream,
+                       make_args(kb, prior, nWorkers), iQuestion, iAnswer, asked, top);
+  else
+    hipLaunchKernelGGL(record_answer_kernel<false>, dim3(1), dim3(kThreads), sum_lds_bytes(nWorkers), stream,
+                       make_args(kb, prior, nWorkers), iQuestion, iAnswer, asked, top);
   return hipGetLastError();
 }
 
 hipError_t LaunchResumeQuiz(const KbView &kb, double *prior, int64_t *exps, const int64_t *aqs, int64_t nAnswered,
                             int64_t nWorkers, int bugCompat, int64_t *status, hipStream_t stream) {
   if (nWorkers < 1 || nWorkers > 4096 || nAnswered < 1) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(resume_quiz_kernel, dim3(1), dim3(kThreads), sum_lds_bytes(nWorkers), stream,
+  hipLaunchKernelGGL(resume_quiz_kernel, dim3(1), dim3(small_launch(kb) ? kSmallThreads : kThreads), sum_lds_bytes(nWorkers), stream,
                      make_args(kb, prior, nWorkers), exps, aqs, nAnswered, bugCompat, status);
   return hipGetLastError();
 }

@@ -1,0 +1,146 @@
+"""The resident sweep (option "server"): one launch serves many selections (csrc/eval_kernels.hip: eval_server_f64).
+It must be indistinguishable from the launch-per-selection path except in time."""
+import threading
+import time
+
+import pytest
+
+import cases
+from probqa_amd import interop
+
+pytestmark = pytest.mark.gpu
+
+
+def make(factory, server, Q=300, T=900, seed=5):
+    e = factory.create_hip_engine(interop.EngineDefinition(5, Q, T, init_amount=0.1), 0, Q, 0)
+    e.set_option("select", 1)
+    e.fill_synthetic(8.0, 0.5, seed)
+    e.set_option("server", server)
+    return e
+
+
+def script(e, n_quiz=3, n_steps=10, sleep_at=()):
+    out = []
+    for z in range(n_quiz):
+        quiz = e.start_quiz()
+        for i in range(n_steps):
+            q = e.next_question(quiz)
+            if i in sleep_at:
+                time.sleep(0.01)        # longer than the idle time: the resident kernel leaves and is started again
+            e.record_answer(quiz, (q * 7 + i + z) % 5)
+            top = e.list_top_targets(quiz, 5)
+            out.append((q, tuple((t.i_target, t.prob) for t in top)))
+        e.release_quiz(quiz)
+    return out
+
+
+def test_same_selections_and_posteriors_as_launch_per_selection(factory):
+    a = make(factory, 0)
+    b = make(factory, 1)
+    assert b.get_option("server_active") == 1
+    try:
+        assert script(a) == script(b, sleep_at=(2, 6))
+    finally:
+        a.close()
+        b.close()
+
+
+def test_priorities_of_a_resident_step_match_the_oracle(factory):
+    case = cases.Case("server", 5, 200, 700, seed=11)
+    orc = case.make_oracle()
+    eng = case.make_engine(factory)
+    eng.set_option("select", 1)
+    eng.set_option("server", 1)
+    try:
+        quiz = eng.start_quiz()
+        orc.start_quiz(16)
+        for step in range(6):
+            q = eng.next_question(quiz)             # resident step: writes the priority vector as a launch does
+            _, opri = orc.eval(128)
+            assert q == orc.select_argmax(opri)
+            eng.record_answer(quiz, step % 5)
+            orc.record_answer(q, step % 5)
+        eng.set_option("server", 0)
+        pri = eng.eval_priorities(quiz)
+        _, opri = orc.eval(128)
+        assert cases.rel_err(pri, opri).max() < 1e-9
+    finally:
+        eng.close()
+
+
+def test_kb_changes_between_resident_steps(factory):
+    """Training and gap changes stop the resident kernel (its XCD-local caches and launch arguments would be stale); the
+    next selection starts it again on the new knowledge base."""
+    a = make(factory, 0, seed=9)
+    b = make(factory, 1, seed=9)
+    try:
+        res = []
+        for e in (a, b):
+            quiz = e.start_quiz()
+            got = [e.next_question(quiz)]
+            e.record_answer(quiz, 1)
+            got.append(e.next_question(quiz))
+            e.record_answer(quiz, 2)
+            e.record_quiz_target(quiz, 17, 3.0)     # trains the cube
+            got.append(e.next_question(quiz))
+            e.record_answer(quiz, 0)
+            e.set_target_gaps([5, 6, 7])
+            e.set_question_gaps([got[-1] + 1 if got[-1] + 1 < 300 else 0])
+            quiz2 = e.start_quiz()
+            got.append(e.next_question(quiz2))
+            got.append(tuple(round(t.prob, 15) for t in e.list_top_targets(quiz2, 3)))
+            res.append(got)
+        assert res[0] == res[1]
+    finally:
+        a.close()
+        b.close()
+
+
+def test_stream_ordered_entry_point_through_the_resident_kernel(factory):
+    """PqaHip_EnqueueSelectArgmaxFlag (what the multi-GPU exchange calls) posts to the resident kernel as well."""
+    import torch
+
+    e = make(factory, 1)
+    ref = make(factory, 0)
+    try:
+        buf = torch.zeros(8, dtype=torch.int64).pin_memory()
+        quiz, rquiz = e.start_quiz(), ref.start_quiz()
+        for step in range(1, 6):
+            e.enqueue_select_argmax_flag(quiz, buf.data_ptr(), buf.data_ptr() + 16, step)
+            t0 = time.time()
+            while int(buf[2]) != step:
+                assert time.time() - t0 < 10
+            want = ref.next_question(rquiz)
+            assert int(buf[1]) == want
+            e.set_active_question(quiz, want)
+            e.record_answer(quiz, step % 5)
+            ref.record_answer(rquiz, step % 5)
+    finally:
+        e.close()
+        ref.close()
+
+
+def test_two_engines_and_threads_share_the_gpu(factory):
+    """Two engines with resident kernels cannot be resident together: each waits for the other to idle out.  Slow, but it
+    must neither hang nor change a result."""
+    engines = [make(factory, 1, seed=21), make(factory, 1, seed=22)]
+    refs = [make(factory, 0, seed=21), make(factory, 0, seed=22)]
+    for e in engines:
+        e.set_option("server_idle_us", 200)
+    want = [script(r, 1, 6) for r in refs]
+    got = [None, None]
+
+    def run(i):
+        got[i] = script(engines[i], 1, 6)
+
+    th = [threading.Thread(target=run, args=(i,)) for i in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=120)
+    try:
+        assert not any(t.is_alive() for t in th)
+        assert got == want
+    finally:
+        for e in engines + refs:
+            e.close()
