@@ -52,6 +52,7 @@ def main():
     ap.add_argument("--exchange", choices=("shm", "rccl"), default="shm",
                     help="how the shards' 16-byte winners meet: host shared memory written by the sweep itself "
                          "(default), or an RCCL all-gather + D2H copy")
+    ap.add_argument("--no-server", action="store_true", help="launch one kernel per selection even where a resident sweep exists")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=3.0, help="wall seconds of the CPU baseline leg")
     args = ap.parse_args()
@@ -184,6 +185,11 @@ def main():
         torch.cuda.synchronize()
         return ev0.elapsed_time(ev1) / n_k
 
+    # The resident sweep (engine option "server": one launch serves many selections, csrc/eval_kernels.hip) where the
+    # engine has one for the cube's shape; the launch-per-selection rate of the same call is reported beside it.
+    if not args.no_server:
+        eng.set_option("server", 1)
+    resident = bool(eng.get_option("server_active") == 1)
     elapsed, sel = timed(step, args.warmup, args.steps)
     value = args.steps / elapsed
 
@@ -197,6 +203,11 @@ def main():
     latency_us = {"p10": 1e6 * lat[len(lat) // 10], "p50": 1e6 * lat[len(lat) // 2], "p90": 1e6 * lat[(9 * len(lat)) // 10],
                   "n": len(lat)}
 
+    launch_rate = None
+    if resident:
+        eng.set_option("server", 0)   # everything below launches kernels that would wait for the resident one to leave
+        dt_l, sel_l = timed(step, min(args.warmup, 500), max(200, args.steps // 2))
+        launch_rate = {"selections_per_sec": max(200, args.steps // 2) / dt_l, "agrees_with_resident": int(sel_l) == int(sel)}
     kernel_ms = kernel_ms_of(eng, quiz, max(20, min(args.steps, 200)))
     alg_bytes = q_local * (K + 1) * T * 8  # one read of every sA row and the mD row, fp64
     achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
@@ -275,6 +286,8 @@ def main():
         "config": {
             "workload": "%s fp64 cube resident in HBM, single in-flight quiz; step = priority sweep + argmax + "
                         "question id on host, synchronous call through the C ABI" % cfg["name"],
+            "selection_path": "resident sweep kernel (engine option server=1): request and answer through pinned memory"
+            if resident else "one kernel launch per selection",
             "questions_per_gpu": q_local,
             "parallelism": ("question-axis shards x%d, winners exchanged through %s" % (
             world, "host shared memory written by the sweep" if args.exchange == "shm" else "an RCCL all-gather"))
@@ -284,6 +297,7 @@ def main():
         },
         "question_evals_per_sec": value * Q,
         "step_latency_us": latency_us,
+        "launch_per_selection": launch_rate,
         "pipelined_selections_per_sec": pipelined,
         "batched": batched,
         "hip_graph_replay": graph_rate,

@@ -40,7 +40,10 @@ PQACORE_API void *PqaEngineFactory_CreateHipEngineSharded(void *pvFactory, void 
  * selector, default 8*workers as PqaCore/CpuEngine.cpp:339), "eval_variant" (0 = auto), "bug_compat" (reproduce
  * PqaCore/CEUpdatePriorsSubtaskMul.cpp:53), "seed" (selector RNG seed), "use_graph" (argmax NextQuestion replays a per-quiz HIP graph
  * instead of launching the sweep), "top_cache" (how many of the new posterior's best
- * targets RecordAnswer's kernel lists ahead of the ListTopTargets call that follows it, default 10, 0 = none). */
+ * targets RecordAnswer's kernel lists ahead of the ListTopTargets call that follows it, default 10, 0 = none), "server"
+ * (argmax selections are served by a resident kernel instead of one launch each -- rows up to 1024 targets; default 0),
+ * "server_idle_us" (that kernel leaves after this long without a request, default 2000).  Read-only: "server_active",
+ * "ldT", "device". */
 PQACORE_API void *PqaHip_SetOption(void *pvEngine, const char *name, int64_t value);
 PQACORE_API int64_t PqaHip_GetOption(void *pvEngine, const char *name);
 PQACORE_API const char *PqaHip_EvalKernelName(void *pvEngine);
