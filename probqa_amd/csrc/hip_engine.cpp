@@ -512,6 +512,7 @@ Error HipEngine::EnqueueEval(int64_t iQuiz) {
   if (!err.ok()) return err;
   Quiz *q = UseQuiz(err, iQuiz);
   if (!q) return err;
+  StopServer();   // a launched sweep has no room beside the resident one and would wait for it to idle out
   HIP_TRY(LaunchEvalQuestions(View(), q->dPrior, q->dAsked, 0, _Q, _dPriority, (int)_optEvalVariant, nullptr, _stream));
   return Error();
 }
@@ -524,6 +525,7 @@ Error HipEngine::EnqueueSelectArgmax(int64_t iQuiz, void *pOut) {
   if (!q) return err;
   // one launch: the sweep's last workgroup picks the argmax; reported index = local position + qFirst (GLOBAL id)
   const FusedSelect fs{_dSelScratch, pOut ? (SelectResult *)pOut : _dSel, nullptr, NextLaunchTag(), _qFirst, 0, 0, nullptr};
+  StopServer();   // a launched sweep has no room beside the resident one and would wait for it to idle out
   HIP_TRY(LaunchEvalQuestions(View(), q->dPrior, q->dAsked, 0, _Q, _dPriority, (int)_optEvalVariant, &fs, _stream));
   return Error();
 }
@@ -541,6 +543,7 @@ Error HipEngine::EnqueueSelectArgmaxFlag(int64_t iQuiz, void *pOut, void *pFlag,
   hipSetDevice(_device);
   if (_optServer && ServerUsable()) return ServerPost(q, (SelectResult *)pOut, (uint64_t *)pFlag, flagValue, _qFirst);
   const FusedSelect fs{_dSelScratch, (SelectResult *)pOut, (uint64_t *)pFlag, NextLaunchTag(), _qFirst, 0, flagValue, nullptr};
+  StopServer();   // a launched sweep has no room beside the resident one and would wait for it to idle out
   HIP_TRY(LaunchEvalQuestions(View(), q->dPrior, q->dAsked, 0, _Q, _dPriority, (int)_optEvalVariant, &fs, _stream));
   return Error();
 }
@@ -585,6 +588,7 @@ int64_t HipEngine::NextQuestionArgmax(Error &err, int64_t iQuiz) {
   // memory, which this thread polls: no D2H copy, no stream synchronisation on the critical path.
   const uint64_t seq = NextLaunchTag();
   const FusedSelect fs{_dSelScratch, &_hPinned->sel, &_hPinned->seq, seq, 0, 0, seq, nullptr};
+  StopServer();   // a launched sweep has no room beside the resident one and would wait for it to idle out
   hipError_t he = LaunchEvalQuestions(View(), q->dPrior, q->dAsked, 0, _Q, _dPriority, (int)_optEvalVariant, &fs, _stream);
   if (he != hipSuccess) { err = HipErr(he, "NextQuestionArgmax"); return -1; }
   err = WaitFlag(&_hPinned->seq, seq, "NextQuestionArgmax");
@@ -743,6 +747,7 @@ Error HipEngine::NextQuestionArgmaxBatch(int64_t n, const int64_t *pQuizzes, int
   const uint64_t tag = NextLaunchTag();
   HIP_TRY(hipMemcpyAsync(_dBatchSlots, _hBatch->slots, (size_t)n * sizeof(QuizSlot), hipMemcpyHostToDevice, _stream));
   const FusedSelect fs{_dBatchScratch, nullptr, nullptr, tag, 0, kBatchGrid, tag, nullptr};
+  StopServer();   // a launched sweep has no room beside the resident one and would wait for it to idle out
   HIP_TRY(LaunchEvalQuestionsBatch(View(), _dBatchSlots, (int)n, 0, _Q, (int)_optEvalVariant, fs, _stream));
   const auto t0 = std::chrono::steady_clock::now();
   for (int64_t i = 0; i < n; i++) {
@@ -802,6 +807,7 @@ int64_t HipEngine::NextQuestionArgmaxGraph(Error &err, Quiz *q) {
     it = _graphs.emplace(q, GraphEntry{exec, _optEvalVariant, _stream, _kbVersion}).first;
   }
   const uint64_t expect = _graphTag;
+  StopServer();   // a launched sweep has no room beside the resident one and would wait for it to idle out
   const hipError_t he = hipGraphLaunch(it->second.exec, _stream);
   if (he != hipSuccess) { err = HipErr(he, "hipGraphLaunch"); return -1; }
   uint64_t next = _graphTag + 1;                     // the finisher's own rule (fused_select)
@@ -822,6 +828,7 @@ int64_t HipEngine::NextQuestionSampled(Error &err, int64_t iQuiz, uint64_t rnd) 
   hipSetDevice(_device);
   const KbView kb = View();
   const int64_t nSub = _optEvalSubtasks ? _optEvalSubtasks : 8 * _optWorkers;  // reference PqaCore/CpuEngine.cpp:339
+  StopServer();   // a launched sweep has no room beside the resident one and would wait for it to idle out
   hipError_t he = LaunchEvalQuestions(kb, q->dPrior, q->dAsked, 0, _Q, _dPriority, (int)_optEvalVariant, nullptr, _stream);
   const uint64_t op = ++_opSeq;  // the selector writes its record and then this number into host-coherent memory
   if (he == hipSuccess)
@@ -849,6 +856,7 @@ Error HipEngine::EvalPriorities(int64_t iQuiz, double *pOut, int64_t n) {
   if (!pOut) return Error::Make(ErrCode::NullArgument, "Nullptr is passed in place of the priority buffer.");
   if (n != _Q) return Error::MakeP(ErrCode::IndexOutOfRange, RangeParams(n, _Q, _Q), "Priority buffer length must equal the local question count.");
   hipSetDevice(_device);
+  StopServer();   // a launched sweep has no room beside the resident one and would wait for it to idle out
   HIP_TRY(LaunchEvalQuestions(View(), q->dPrior, q->dAsked, 0, _Q, _dPriority, (int)_optEvalVariant, nullptr, _stream));
   HIP_TRY(hipMemcpyAsync(pOut, _dPriority, (size_t)_Q * sizeof(double), hipMemcpyDeviceToHost, _stream));
   HIP_TRY(hipStreamSynchronize(_stream));

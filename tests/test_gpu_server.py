@@ -144,3 +144,22 @@ def test_two_engines_and_threads_share_the_gpu(factory):
     finally:
         for e in engines + refs:
             e.close()
+
+
+def test_launched_sweeps_between_resident_steps(factory):
+    """EvalPriorities, the batched and the graph selection launch kernels: they stop the resident one first (no room beside
+    it) and the next plain selection starts it again; all of them must agree."""
+    import numpy as np
+
+    e = make(factory, 1)
+    try:
+        quiz = e.start_quiz()
+        for i in range(4):
+            q = e.next_question_argmax(quiz)
+            pri = e.eval_priorities(quiz)
+            assert int(np.argmax(pri)) == q
+            assert e.next_question_argmax_batch([quiz])[0] == q
+            assert e.next_question_argmax(quiz) == q
+            e.record_answer(quiz, i % 5)
+    finally:
+        e.close()

@@ -111,9 +111,16 @@ int main(int argc, char **argv) {
   const int grid = argc > 1 ? atoi(argv[1]) : 768;
   const int steps = argc > 2 ? atoi(argv[2]) : 20000;
   Mailbox *mb;
-  CK(hipHostMalloc(&mb, sizeof(Mailbox), hipHostMallocCoherent));
   Mailbox *mbDev;
-  CK(hipHostGetDevicePointer((void **)&mbDev, mb, 0));
+  const bool vram = argc > 3 && atoi(argv[3]) != 0;   // mailbox in host-visible device memory instead of pinned host memory
+  if (vram) {
+    CK(hipExtMallocWithFlags((void **)&mb, sizeof(Mailbox), hipDeviceMallocFinegrained));
+    mbDev = mb;
+    printf("mailbox in fine-grained device memory at %p\n", (void *)mb);
+  } else {
+    CK(hipHostMalloc(&mb, sizeof(Mailbox), hipHostMallocCoherent));
+    CK(hipHostGetDevicePointer((void **)&mbDev, mb, 0));
+  }
   Ctl *ctl;
   u4 *rec;
   CK(hipMalloc(&ctl, sizeof(Ctl)));
