@@ -840,7 +840,7 @@ int pick_variant(int64_t ldT, int variant) {
   if (ldT <= 7168) return 17;
   if (ldT <= 8192) return 18;
   if (ldT <= 9216) return 19;
-  if (ldT <= 10240) return 12;
+  if (ldT <= 10240) return 10;   // priors in LDS: no spills at 10 pairs per lane (950 vs 1028 us at 10000 x 5 x 10000)
   if (ldT <= 16384) return 7;
   return 99;
 }
