@@ -248,78 +248,85 @@ struct TopOut {
   int64_t iTarget;
   double prob;
 };
-struct TopCand {
-  double p;
-  int t;        // target index (T <= 16384), < 0: none
-};
-__device__ __forceinline__ bool top_better(const TopCand &a, const TopCand &b) {
-  if (b.t < 0) return a.t >= 0;
-  if (a.t < 0) return false;
-  return (a.p > b.p) || (a.p == b.p && a.t < b.t);
+// A round = the maximum probability over the workgroup (v_max_f64 butterflies), then the lowest index among the targets
+// that hold it (integer-min butterflies, whose DPP form is one instruction per step): two short dependent chains.  The
+// first version carried {probability, index} pairs through one butterfly with a four-way comparison per step -- ten
+// steps of ~25 dependent instructions, 2.7 us per listed target, three quarters of RecordAnswer's kernel.
+// Listed: valid targets by descending probability, lower index first on ties; retired and invalid ones hold -1.
+__device__ __forceinline__ double wave_max(double v) {
+  v = __builtin_fmax(v, mov_dpp<kDppXor1>(v));
+  v = __builtin_fmax(v, mov_dpp<kDppXor2>(v));
+  v = __builtin_fmax(v, mov_dpp<kDppHalfMirror>(v));
+  v = __builtin_fmax(v, mov_dpp<kDppMirror>(v));
+  Pair p = swap16(v);
+  v = __builtin_fmax(p.a, p.b);
+  p = swap32(v);
+  return __builtin_fmax(p.a, p.b);
+}
+__device__ __forceinline__ double row_max(double v) {   // over the 16 lanes of a row
+  v = __builtin_fmax(v, mov_dpp<kDppXor1>(v));
+  v = __builtin_fmax(v, mov_dpp<kDppXor2>(v));
+  v = __builtin_fmax(v, mov_dpp<kDppHalfMirror>(v));
+  return __builtin_fmax(v, mov_dpp<kDppMirror>(v));
 }
 template <int CTRL>
-__device__ __forceinline__ TopCand top_dpp(const TopCand &c) {
-  return TopCand{mov_dpp<CTRL>(c.p), __builtin_amdgcn_update_dpp(0, c.t, CTRL, 0xF, 0xF, true)};
+__device__ __forceinline__ int min_dpp(int v) {
+  const int o = __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true);
+  return o < v ? o : v;
 }
-__device__ __forceinline__ void top_take(TopCand &b, const TopCand &o) {
-  if (top_better(o, b)) b = o;
+__device__ __forceinline__ int row_min(int v) {
+  v = min_dpp<kDppXor1>(v);
+  v = min_dpp<kDppXor2>(v);
+  v = min_dpp<kDppHalfMirror>(v);
+  return min_dpp<kDppMirror>(v);
 }
-// all-reduce (best candidate) over a 16-lane row / over the wave: DPP within rows, permlane swaps across them
-__device__ __forceinline__ TopCand row_top(TopCand b) {
-  top_take(b, top_dpp<kDppXor1>(b));
-  top_take(b, top_dpp<kDppXor2>(b));
-  top_take(b, top_dpp<kDppHalfMirror>(b));
-  top_take(b, top_dpp<kDppMirror>(b));
-  return b;
+__device__ __forceinline__ int wave_min(int v) {
+  v = row_min(v);
+  auto t = __builtin_amdgcn_permlane16_swap((uint32_t)v, (uint32_t)v, false, false);
+  v = (int)t[0] < (int)t[1] ? (int)t[0] : (int)t[1];
+  t = __builtin_amdgcn_permlane32_swap((uint32_t)v, (uint32_t)v, false, false);
+  return (int)t[0] < (int)t[1] ? (int)t[0] : (int)t[1];
 }
-__device__ __forceinline__ TopCand wave_top(TopCand b) {
-  b = row_top(b);
-  {
-    const Pair p = swap16(b.p);
-    const auto t = __builtin_amdgcn_permlane16_swap((uint32_t)b.t, (uint32_t)b.t, false, false);
-    TopCand x{p.a, (int)t[0]}, y{p.b, (int)t[1]};
-    top_take(x, y);
-    b = x;
-  }
-  {
-    const Pair p = swap32(b.p);
-    const auto t = __builtin_amdgcn_permlane32_swap((uint32_t)b.t, (uint32_t)b.t, false, false);
-    TopCand x{p.a, (int)t[0]}, y{p.b, (int)t[1]};
-    top_take(x, y);
-    b = x;
-  }
-  return b;
-}
+constexpr int kTopNone = 0x7FFFFFFF;
 template <int E>
 __device__ __forceinline__ int64_t top_targets_rounds(const double *prior, const uint32_t *tgap, int64_t T, int64_t maxCount,
                                                       TopOut *out, double (*sp)[16], int (*st)[16]) {
-  TopCand mine[E];
+  double p[E];
+  int t[E];
 #pragma unroll
   for (int e = 0; e < E; e++) {
-    const int64_t t = threadIdx.x + (int64_t)e * blockDim.x;
-    const bool ok = t < T && !bit_test(tgap, t);
-    mine[e].p = ok ? prior[t] : 0.0;
-    mine[e].t = ok ? (int)t : -1;
+    const int64_t tt = threadIdx.x + (int64_t)e * blockDim.x;
+    const bool ok = tt < T && !bit_test(tgap, tt);
+    p[e] = ok ? prior[tt] : -1.0;
+    if (!(p[e] >= 0.0)) p[e] = -1.0;       // (a NaN is never listed)
+    t[e] = (int)tt;
   }
   const int lane = threadIdx.x % kWave, wave = threadIdx.x / kWave;
   int64_t listed = 0;
   for (int64_t r = 0; r < maxCount; r++) {
-    TopCand b = mine[0];
+    double bp = p[0];
 #pragma unroll
-    for (int e = 1; e < E; e++) top_take(b, mine[e]);
-    b = wave_top(b);
+    for (int e = 1; e < E; e++) bp = __builtin_fmax(bp, p[e]);
+    const double wm = wave_max(bp);
+    int bt = kTopNone;
+#pragma unroll
+    for (int e = 0; e < E; e++) bt = (p[e] == wm && t[e] < bt) ? t[e] : bt;
+    bt = wave_min(bt);
     const int par = (int)(r & 1);
     if (lane == 0) {
-      sp[par][wave] = b.p;
-      st[par][wave] = b.t;
+      sp[par][wave] = wm;
+      st[par][wave] = bt;
     }
     __syncthreads();
-    const TopCand w = row_top(TopCand{sp[par][lane % 16], st[par][lane % 16]});  // 16 waves -> one 16-lane row
-    if (w.t < 0) break;                 // the same for every thread
-    if (threadIdx.x == 0) out[r] = TopOut{w.t, w.p};   // `out`: LDS staging (top_targets_publish)
+    const double mp = sp[par][lane % 16];     // up to 16 waves -> one 16-lane row (absent waves hold -1)
+    const int mt = st[par][lane % 16];
+    const double gm = row_max(mp);
+    if (!(gm >= 0.0)) break;                  // nothing left; the same for every thread
+    const int gt = row_min(mp == gm ? mt : kTopNone);
+    if (threadIdx.x == 0) out[r] = TopOut{gt, gm};   // `out`: LDS staging (top_targets_publish)
 #pragma unroll
     for (int e = 0; e < E; e++)
-      if (mine[e].t == w.t) mine[e].t = -1;
+      if (t[e] == gt) p[e] = -1.0;
     listed++;
   }
   return listed;
@@ -337,8 +344,8 @@ __device__ __forceinline__ void top_targets_publish(const double *prior, const u
   if (maxCount > 256) maxCount = 256;
   // waves that do not exist never win a round
   if (threadIdx.x < 32) {
-    sp[threadIdx.x >> 4][threadIdx.x & 15] = 0.0;
-    st[threadIdx.x >> 4][threadIdx.x & 15] = -1;
+    sp[threadIdx.x >> 4][threadIdx.x & 15] = -1.0;
+    st[threadIdx.x >> 4][threadIdx.x & 15] = kTopNone;
   }
   __syncthreads();
   const int64_t perThread = (T + blockDim.x - 1) / blockDim.x;
