@@ -5,7 +5,7 @@ TAG=$1; CFG=$2; VAR=$3; STEPS=${4:-50}
 OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-CMD="python $PWD/bench.py --config $CFG --variant $VAR --steps $STEPS --warmup 5 --no-cpu-baseline --batch 0"
+CMD="python $PWD/bench.py --config $CFG --variant $VAR --steps $STEPS --warmup 5 --no-cpu-baseline --batch 0 --no-server"
 cd /tmp
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- $CMD > $OUT/bench_trace.json 2> $OUT/trace.err
 for grp in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_LDS" \
