@@ -163,3 +163,29 @@ def test_launched_sweeps_between_resident_steps(factory):
             e.record_answer(quiz, i % 5)
     finally:
         e.close()
+
+
+def test_leaving_races_with_posting(factory):
+    """Idle time 100 us, requests after random pauses of 0..300 us: the kernel is leaving about as often as a request
+    arrives (tools/server_soak.py runs the same for longer).  Every selection must be served, and served right."""
+    import random
+
+    e = make(factory, 0)
+    try:
+        quiz = e.start_quiz()
+        want = e.next_question_argmax(quiz)
+        e.set_option("server", 1)
+        e.set_option("server_idle_us", 100)
+        rnd = random.Random(3)
+        t_end = time.time() + 2.0
+        n = 0
+        while time.time() < t_end:
+            pause = rnd.random() * 300e-6
+            t0 = time.perf_counter()
+            while time.perf_counter() - t0 < pause:
+                pass
+            assert e.next_question_argmax(quiz) == want
+            n += 1
+        assert n > 1000
+    finally:
+        e.close()
