@@ -42,7 +42,9 @@ PQACORE_API void *PqaEngineFactory_CreateHipEngineSharded(void *pvFactory, void 
  * instead of launching the sweep), "top_cache" (how many of the new posterior's best
  * targets RecordAnswer's kernel lists ahead of the ListTopTargets call that follows it, default 10, 0 = none), "server"
  * (argmax selections are served by a resident kernel instead of one launch each -- rows up to 1024 targets; default 0),
- * "server_idle_us" (that kernel leaves after this long without a request, default 2000).  Read-only: "server_active",
+ * "server_idle_us" (that kernel leaves after this long without a request, default 2000), "server_vram_mailbox" (requests
+ * are written to host-visible device memory where the platform maps it, default 1; set before the first selection).
+ * Read-only: "server_active",
  * "ldT", "device". */
 PQACORE_API void *PqaHip_SetOption(void *pvEngine, const char *name, int64_t value);
 PQACORE_API int64_t PqaHip_GetOption(void *pvEngine, const char *name);

@@ -599,14 +599,17 @@ template <int WPQ, int NP>
 // waves_per_eu(4, 4) = 128 VGPRs: three workgroups per CU then leave 128 registers per SIMD lane for the 256-thread posterior
 // kernels (<= 48) that must run beside the resident sweep (prior_kernels.hip: kSmallThreads)
 __global__ __launch_bounds__(WPQ * 64) __attribute__((amdgpu_waves_per_eu(4, 4)))
-void eval_server_f64(EvalArgs a, ServerMailbox *mb, ServerCtl *ctl, uint64_t lastSeq, uint64_t idleTicks,
-                     unsigned stepOffsetBytes) {
+void eval_server_f64(EvalArgs a, ServerMailbox *mb, uint32_t *requestLine, int everyonePolls, ServerCtl *ctl, uint64_t lastSeq,
+                     uint64_t idleTicks, unsigned stepOffsetBytes) {
   extern __shared__ double smem[];
   uint32_t *step = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(smem) + stepOffsetBytes);   // 16 dwords
   const int wave = (int)__builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
   const unsigned word = threadIdx.x & 15;
   const bool first = blockIdx.x == 0;
-  uint32_t *mbWord = reinterpret_cast<uint32_t *>(mb) + word, *ctlWord = reinterpret_cast<uint32_t *>(ctl) + word;
+  // requestLine: where the host writes requests -- the first line of the mailbox, or (everyonePolls) a line of host-visible
+  // DEVICE memory: then a poll is a local read instead of one over PCIe, cheap enough for every workgroup to watch the
+  // line itself instead of waiting for workgroup 0 to hand the request on (-2 us per step)
+  uint32_t *mbWord = requestLine + word, *ctlWord = reinterpret_cast<uint32_t *>(ctl) + word;
   uint64_t last = lastSeq;
   bool copyTable = true;
   for (;;) {
@@ -636,7 +639,20 @@ void eval_server_f64(EvalArgs a, ServerMailbox *mb, ServerCtl *ctl, uint64_t las
           }
         }
         if (go != ~0ull) __hip_atomic_store(&mb->taken, go, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        __hip_atomic_store(ctlWord, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // the whole line: one store instruction
+        if (!everyonePolls || go == ~0ull)
+          __hip_atomic_store(ctlWord, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // the whole line: one store instruction
+      } else if (everyonePolls) {
+        for (unsigned it = 0;; it++) {
+          v = __hip_atomic_load(mbWord, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          go = line_u64(v, 0);
+          if (go != last && go != 0) break;
+          if ((it & 15) == 15) {   // workgroup 0 says "leave" through the hand-off line
+            const uint32_t v2 = __hip_atomic_load(ctlWord, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (line_u64(v2, 0) == ~0ull) { v = v2; break; }
+            if (wall_clock64() - t0 > 8 * idleTicks + 100000000ull) { v = 0xFFFFFFFFu; break; }   // workgroup 0 is gone
+          }
+          __builtin_amdgcn_s_sleep(1);
+        }
       } else {
         for (;;) {
           v = __hip_atomic_load(ctlWord, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -974,8 +990,8 @@ hipError_t LaunchEvalQuestionsBatch(const KbView &kb, const QuizSlot *slots, int
 }
 
 template <int WPQ, int NP>
-static hipError_t launch_server(const EvalArgs &args, ServerMailbox *mb, ServerCtl *ctl, uint64_t lastSeq, uint64_t idleTicks,
-                                hipStream_t stream) {
+static hipError_t launch_server(const EvalArgs &args, ServerMailbox *mb, void *requestLine, bool everyonePolls, ServerCtl *ctl,
+                                uint64_t lastSeq, uint64_t idleTicks, hipStream_t stream) {
   const size_t stepOffset = eval_md_row_offset_bytes(WPQ, args.K) + (size_t)NP * WPQ * kWave * 16;
   const size_t shmem = stepOffset + 64;
   auto kern = eval_server_f64<WPQ, NP>;
@@ -1000,7 +1016,8 @@ static hipError_t launch_server(const EvalArgs &args, ServerMailbox *mb, ServerC
   const int64_t nQ = args.qLimit - args.qFirst, resident = (int64_t)gNumCUs * cachedPerCU;
   int64_t grid = nQ < resident ? nQ : resident;
   if (grid > kFusedMaxGrid) grid = kFusedMaxGrid;
-  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(WPQ * 64), shmem, stream, args, mb, ctl, lastSeq, idleTicks, (unsigned)stepOffset);
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(WPQ * 64), shmem, stream, args, mb, reinterpret_cast<uint32_t *>(requestLine),
+                     everyonePolls ? 1 : 0, ctl, lastSeq, idleTicks, (unsigned)stepOffset);
   return hipGetLastError();
 }
 
@@ -1011,14 +1028,15 @@ static int server_variant(const KbView &kb, int variant) {
 bool EvalServerSupported(const KbView &kb, int variant) { return server_variant(kb, variant) != 0; }
 
 hipError_t LaunchEvalServer(const KbView &kb, int64_t qFirst, int64_t qLimit, double *priority, int variant,
-                            SelectResult *scratch, ServerMailbox *mailbox, ServerCtl *ctl, uint64_t lastSeq,
-                            uint64_t idleTicks, hipStream_t stream) {
-  if (qLimit <= qFirst || scratch == nullptr || mailbox == nullptr || ctl == nullptr) return hipErrorInvalidValue;
+                            SelectResult *scratch, ServerMailbox *mailbox, void *requestLine, bool everyonePolls,
+                            ServerCtl *ctl, uint64_t lastSeq, uint64_t idleTicks, hipStream_t stream) {
+  if (qLimit <= qFirst || scratch == nullptr || mailbox == nullptr || requestLine == nullptr || ctl == nullptr)
+    return hipErrorInvalidValue;
   EvalArgs args = make_args(kb, qFirst, qLimit);
   args.priority = priority;
   args.fs.scratch = scratch;
   switch (server_variant(kb, variant)) {
-    case 2: return launch_server<4, 2>(args, mailbox, ctl, lastSeq, idleTicks, stream);
+    case 2: return launch_server<4, 2>(args, mailbox, requestLine, everyonePolls, ctl, lastSeq, idleTicks, stream);
     default: return hipErrorNotSupported;
   }
 }

@@ -209,6 +209,7 @@ HipEngine::~HipEngine() {
   hipSetDevice(_device);
   StopServer();
   if (_serverStream) hipStreamDestroy(_serverStream);
+  if (_serverRequestInVram) hipFree((void *)_serverRequest);
   if (_hMailbox) hipHostFree(_hMailbox);
   hipFree(_dServerCtl);
   if (_stream) hipStreamSynchronize(_stream);
@@ -255,6 +256,7 @@ Error HipEngine::SetOption(const char *name, int64_t value) {
   else if (n == "use_graph") { _optUseGraph = value ? 1 : 0; }
   else if (n == "top_cache") { if (value < 0 || value > 256) goto bad; _optTopCache = value; }
   else if (n == "server") { if (!value) StopServer(); _optServer = value ? 1 : 0; }
+  else if (n == "server_vram_mailbox") { if (_serverStream) goto bad; _optServerVramMailbox = value ? 1 : 0; }
   else if (n == "server_idle_us") { if (value < 10 || value > 1000000) goto bad; StopServer(); _optServerIdleUs = value; }
   else if (n == "seed") { uint64_t s = (uint64_t)value; _rng[0] = SplitMix64(s); _rng[1] = SplitMix64(s); }
   else goto bad;
@@ -274,6 +276,7 @@ int64_t HipEngine::GetOption(const char *name) const {
   if (n == "use_graph") return _optUseGraph;
   if (n == "server") return _optServer;
   if (n == "server_idle_us") return _optServerIdleUs;
+  if (n == "server_vram_mailbox") return _serverStream ? (_serverRequestInVram ? 1 : 0) : _optServerVramMailbox;
   if (n == "debug_mailbox") return (int64_t)(uintptr_t)_hMailbox;
   if (n == "server_active") return (_optServer && ServerUsable()) ? 1 : 0;
   if (n == "ldT") return _ldT;
@@ -609,11 +612,11 @@ bool HipEngine::ServerUsable() const { return EvalServerSupported(View(), (int)_
 void HipEngine::StopServer() {
   if (!_serverLaunched) return;
   hipSetDevice(_device);
-  volatile ServerMailbox *mb = _hMailbox;
-  mb->stop = 1;
+  _serverRequest[7] = 1;                 // `stop`
   std::atomic_thread_fence(std::memory_order_seq_cst);
   hipStreamSynchronize(_serverStream);   // bounded: the kernel polls `stop` and leaves, or has left already
-  mb->stop = 0;
+  _serverRequest[7] = 0;
+  std::atomic_thread_fence(std::memory_order_seq_cst);
   _serverLaunched = false;
 }
 
@@ -662,6 +665,20 @@ Error HipEngine::ServerPost(Quiz *q, SelectResult *out, uint64_t *flag, uint64_t
     HIP_TRY(hipHostMalloc((void **)&_hMailbox, sizeof(ServerMailbox), hipHostMallocDefault));
     std::memset(_hMailbox, 0, sizeof(ServerMailbox));
     HIP_TRY(hipMalloc((void **)&_dServerCtl, sizeof(ServerCtl)));
+    // The request line in device memory that the host can write (fine-grained allocation, mapped through the PCIe BAR):
+    // the kernel's polls become local reads.  Where the platform does not map it, the mailbox's own first line is used.
+    void *vram = nullptr;
+    int largeBar = 0;
+    if (_optServerVramMailbox && hipDeviceGetAttribute(&largeBar, hipDeviceAttributeIsLargeBar, _device) == hipSuccess && largeBar &&
+        hipExtMallocWithFlags(&vram, 64, hipDeviceMallocFinegrained) == hipSuccess && vram != nullptr) {
+      _serverRequest = (volatile uint64_t *)vram;   // large BAR: the device address is valid on the host as well
+      _serverRequestInVram = true;
+      for (int i = 0; i < 8; i++) _serverRequest[i] = 0;
+      std::atomic_thread_fence(std::memory_order_seq_cst);
+    } else {
+      (void)hipGetLastError();
+    }
+    if (!_serverRequestInVram) _serverRequest = &_hMailbox->req;
   }
   if (_serverLaunched && (_serverKb != _kbVersion || _serverVariant != _optEvalVariant)) StopServer();
   volatile ServerMailbox *mb = _hMailbox;
@@ -669,39 +686,51 @@ Error HipEngine::ServerPost(Quiz *q, SelectResult *out, uint64_t *flag, uint64_t
   if (_serverLaunched && _serverPosted != 0) {
     const auto t0 = std::chrono::steady_clock::now();
     uint64_t spins = 0;
-    while (mb->taken != _serverPosted && mb->state != kServerExited) {
+    // (every workgroup reads the line itself when it is in device memory: then not before the step is done)
+    while ((_serverRequestInVram ? mb->done : mb->taken) != _serverPosted && mb->state != kServerExited) {
       if ((++spins & 0xFFF) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(30))
         return HipErr(hipErrorNotReady, "ServerPost (previous request never taken)");
     }
   }
-  const uint64_t prev = mb->req;
+  const uint64_t prev = _serverReqSeq;
   const uint64_t seq = NextLaunchTag();
-  mb->prior = q->dPrior;
-  mb->asked = q->dAsked;
-  mb->out = out;
-  mb->flag = flag;
-  mb->flagValue = flagValue;
-  mb->outBase = outBase;
-  std::atomic_thread_fence(std::memory_order_release);
-  mb->req = seq;
+  volatile uint64_t *rq = _serverRequest;   // {req, prior, asked, out, flag, flagValue, outBase, stop}
+  rq[1] = (uint64_t)(uintptr_t)q->dPrior;
+  rq[2] = (uint64_t)(uintptr_t)q->dAsked;
+  rq[3] = (uint64_t)(uintptr_t)out;
+  rq[4] = (uint64_t)(uintptr_t)flag;
+  rq[5] = flagValue;
+  rq[6] = (uint64_t)outBase;
+  std::atomic_thread_fence(std::memory_order_seq_cst);   // (also drains the write-combining buffer of a BAR mapping)
+  rq[0] = seq;
   std::atomic_thread_fence(std::memory_order_seq_cst);
+  _serverReqSeq = seq;
   _serverPosted = seq;
   if (_serverLaunched) {
-    // Posted first, looked second; the kernel says "leaving" first and looks second: one of the two sees the other.
-    uint64_t st = mb->state;
-    if (st == kServerExiting) {
-      const auto t0 = std::chrono::steady_clock::now();
-      while ((st = mb->state) == kServerExiting)
-        if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(30)) return HipErr(hipErrorNotReady, "ServerPost");
+    // Taken, or gone?  The kernel acknowledges a request as soon as it reads it (~2 us); a kernel that was leaving when the
+    // request arrived ends in `exited` without the acknowledgement, and the request -- still in its line -- goes to a new
+    // one.  (With the line in host memory "write mine, then read yours" on both sides would decide this without waiting:
+    // PCIe keeps the kernel's read behind its write.  A line in device memory is written by the host with a posted write
+    // that may still be in flight when the host looks at `state`, so the acknowledgement is what is relied on.)
+    const auto t0 = std::chrono::steady_clock::now();
+    uint64_t spins = 0;
+    for (;;) {
+      if (mb->taken == seq) return Error();
+      if (mb->state == kServerExited) {
+        std::atomic_thread_fence(std::memory_order_acquire);
+        if (mb->taken == seq) return Error();
+        break;
+      }
+      if ((++spins & 0xFFF) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(30))
+        return HipErr(hipErrorNotReady, "ServerPost (request neither taken nor refused)");
     }
-    if (st == kServerRunning) return Error();
     _serverLaunched = false;   // it left without this request
   }
   HIP_TRY(hipStreamSynchronize(_serverStream));                       // the previous instance is gone entirely
   HIP_TRY(hipMemsetAsync(_dServerCtl, 0, sizeof(ServerCtl), _serverStream));
   mb->state = kServerRunning;
   std::atomic_thread_fence(std::memory_order_seq_cst);
-  HIP_TRY(LaunchEvalServer(View(), 0, _Q, _dPriority, (int)_optEvalVariant, _dSelScratch, _hMailbox, _dServerCtl, prev,
+  HIP_TRY(LaunchEvalServer(View(), 0, _Q, _dPriority, (int)_optEvalVariant, _dSelScratch, _hMailbox, (void *)_serverRequest, _serverRequestInVram, _dServerCtl, prev,
                            (uint64_t)_optServerIdleUs * 100, _serverStream));   // 100 MHz ticks
   _serverLaunched = true;
   _serverKb = _kbVersion;

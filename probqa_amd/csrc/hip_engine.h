@@ -238,10 +238,13 @@ class HipEngine {
   int64_t _optUseGraph = 0;   // NextQuestion (argmax) replays a per-quiz HIP graph instead of launching
   int64_t _optTopCache = 10;  // targets RecordAnswer's kernel lists ahead of the ListTopTargets that follows it (0: none)
   // ---- resident sweep (option "server"; pqa_kernels.h: ServerMailbox)
-  int64_t _optServer = 0, _optServerIdleUs = 2000;
+  int64_t _optServer = 0, _optServerIdleUs = 2000, _optServerVramMailbox = 1;
   hipStream_t _serverStream = nullptr;
   ServerMailbox *_hMailbox = nullptr;     // pinned
   ServerCtl *_dServerCtl = nullptr;
+  volatile uint64_t *_serverRequest = nullptr;   // the request line: host-visible device memory if the platform maps it, else the mailbox's
+  bool _serverRequestInVram = false;
+  uint64_t _serverReqSeq = 0;                    // the sequence number last written there (the line is never read by the host)
   bool _serverLaunched = false;           // a kernel instance has been launched and not yet seen to have left
   uint64_t _serverKb = 0, _serverPosted = 0;
   int64_t _serverVariant = 0;

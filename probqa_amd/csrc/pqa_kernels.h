@@ -103,9 +103,11 @@ struct ServerCtl {                // device memory, one line; zeroed before each
 };
 // Only the short-row register shapes have a resident form (that is where a launch is a large part of a selection):
 // returns hipErrorNotSupported otherwise.  `scratch`: kFusedMaxGrid records.  lastSeq: the kernel serves requests != lastSeq.
+// requestLine: the 64-byte line the host writes requests to -- the mailbox's own first line, or a line of host-visible device
+// memory (everyonePolls: every workgroup watches it; the host then waits for `done`, not `taken`, before the next request).
 hipError_t LaunchEvalServer(const KbView &kb, int64_t qFirst, int64_t qLimit, double *priority, int variant,
-                            SelectResult *scratch, ServerMailbox *mailbox, ServerCtl *ctl, uint64_t lastSeq,
-                            uint64_t idleTicks, hipStream_t stream);
+                            SelectResult *scratch, ServerMailbox *mailbox, void *requestLine, bool everyonePolls,
+                            ServerCtl *ctl, uint64_t lastSeq, uint64_t idleTicks, hipStream_t stream);
 bool EvalServerSupported(const KbView &kb, int variant);
 
 struct RatedTargetDev { int64_t iTarget; double prob; };  // == CiRatedTarget

@@ -11,10 +11,11 @@ from probqa_amd import interop
 pytestmark = pytest.mark.gpu
 
 
-def make(factory, server, Q=300, T=900, seed=5):
+def make(factory, server, Q=300, T=900, seed=5, vram=1):
     e = factory.create_hip_engine(interop.EngineDefinition(5, Q, T, init_amount=0.1), 0, Q, 0)
     e.set_option("select", 1)
     e.fill_synthetic(8.0, 0.5, seed)
+    e.set_option("server_vram_mailbox", vram)   # where requests are written: host-visible device memory, or pinned host memory
     e.set_option("server", server)
     return e
 
@@ -34,9 +35,10 @@ def script(e, n_quiz=3, n_steps=10, sleep_at=()):
     return out
 
 
-def test_same_selections_and_posteriors_as_launch_per_selection(factory):
+@pytest.mark.parametrize("vram", [1, 0], ids=["requests_in_device_memory", "requests_in_host_memory"])
+def test_same_selections_and_posteriors_as_launch_per_selection(factory, vram):
     a = make(factory, 0)
-    b = make(factory, 1)
+    b = make(factory, 1, vram=vram)
     assert b.get_option("server_active") == 1
     try:
         assert script(a) == script(b, sleep_at=(2, 6))
@@ -165,12 +167,13 @@ def test_launched_sweeps_between_resident_steps(factory):
         e.close()
 
 
-def test_leaving_races_with_posting(factory):
+@pytest.mark.parametrize("vram", [1, 0], ids=["requests_in_device_memory", "requests_in_host_memory"])
+def test_leaving_races_with_posting(factory, vram):
     """Idle time 100 us, requests after random pauses of 0..300 us: the kernel is leaving about as often as a request
     arrives (tools/server_soak.py runs the same for longer).  Every selection must be served, and served right."""
     import random
 
-    e = make(factory, 0)
+    e = make(factory, 0, vram=vram)
     try:
         quiz = e.start_quiz()
         want = e.next_question_argmax(quiz)
