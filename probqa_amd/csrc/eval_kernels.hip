@@ -1008,7 +1008,7 @@ static hipError_t launch_server(const EvalArgs &args, ServerMailbox *mb, void *r
     }
     int perCU = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, kern, WPQ * 64, shmem) != hipSuccess || perCU < 1) perCU = 1;
-    if (NP <= 2 && perCU > 3) perCU = 3;   // as launch_reg
+    if (NP <= 2 && perCU > 3) perCU = 3;   // as launch_reg (measured for the resident kernel too: 46.0 k selections/s at three per CU, 43.9 k at four)
     cachedPerCU = perCU;
     cachedShmem = shmem;
   }
