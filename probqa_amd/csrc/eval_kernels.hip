@@ -308,6 +308,16 @@ __host__ __device__ constexpr size_t eval_lds_doubles(int wpq, int64_t K, bool p
          (prLds ? (size_t)ldT + 2 : 0);
 }
 
+// Register-prior shapes of up to 8 waves keep the lanes' partial sums of a question -- K velocity sums, the entropy sum, the
+// lack sum -- in LDS ((K + 2) x threads doubles behind the mD landing row) and reduce them once per question, all waves
+// together, instead of one wave butterfly per sum and row: 18 VALU instructions per row and wave become one ds_write.
+// (Not the two 4-pair shapes: the change costs them four registers, which takes them from 165 / 167 to 169 and from three
+// waves per SIMD to two -- 41 instead of 37 us at 2000 targets.)
+__host__ __device__ constexpr bool eval_defers_sums(int wpq, int np, bool prLds) { return !prLds && wpq <= 8 && np != 4; }
+__host__ __device__ constexpr size_t eval_deferred_bytes(int wpq, int np, int64_t K, bool prLds) {
+  return eval_defers_sums(wpq, np, prLds) ? (size_t)(K + 2) * wpq * kWave * sizeof(double) : 0;
+}
+
 // epilogue wave only: one epilogue per lane over the queued questions; each lane keeps the best of its own
 __device__ __forceinline__ void flush_pending(const EvalArgs &a, const double *pend, int nPend, int lane, Best &best) {
   if (lane < nPend) {
@@ -371,6 +381,8 @@ __device__ __forceinline__ void sweep_body(EvalArgs a, bool copyTable) {
   const int tid = tidRaw, lane = tid % kWave;
   const int wave = SERVER ? (int)__builtin_amdgcn_readfirstlane(tid / kWave) : tid / kWave;
   const unsigned mdRowWaveAddr = (unsigned)(uintptr_t)mdRow + (unsigned)wave * 1024u;
+  constexpr bool kDefer = eval_defers_sums(WPQ, NP, PRLDS);
+  double *vdump = reinterpret_cast<double *>(reinterpret_cast<char *>(mdRow) + (size_t)NP * kThreads * 16);   // kDefer only
   // ---- prologue.  Everything it needs from memory is independent of everything else, so all of it is requested
   // before anything is used: one memory round trip instead of a dozen dependent ones (with one question per workgroup,
   // as at 1000 x 1000, the prologue is on the critical path of the whole launch).  That includes the mD row of the first
@@ -535,34 +547,70 @@ __device__ __forceinline__ void sweep_body(EvalArgs a, bool copyTable) {
         asm volatile("" : "+v"(accL), "+v"(hW), "+v"(v));
         __builtin_amdgcn_sched_barrier(0);
       }
-      v = wave_sum(v);
+      if constexpr (kDefer) {
+        vdump[k * kThreads + tid] = v;                         // :132, reduced with the question's other sums below
+        if (tid == 0) rec[k] = Wk;                             // :90
+      } else {
+        v = wave_sum(v);
+        if (lane == 0) {
+          if (wave == 0) rec[k] = Wk;                           // :90
+          part[k * WPQ + wave] = v;                              // :132
+        }
+      }
+    }
+    if constexpr (kDefer) {
+      // (the dump is single-buffered: a wave that runs ahead writes it again only behind the next question's first W
+      //  barrier, which no wave passes before every wave has read here)
+      vdump[K * kThreads + tid] = hW;
+      vdump[(K + 1) * kThreads + tid] = accL;
+      __syncthreads();
+      // every 32 lanes take one of the K + 2 sums: threads/32 partials each, then a 32-lane butterfly
+      constexpr int kGroups = kThreads / 32;
+      const int l32 = tid & 31;
+      for (int r = tid >> 5; r < nPart; r += kGroups) {
+        const double *src = vdump + r * kThreads + l32;
+        double acc = src[0];
+#pragma unroll
+        for (int i = 1; i < kGroups; i++) acc += src[32 * i];
+        acc += mov_dpp<kDppXor1>(acc);
+        acc += mov_dpp<kDppXor2>(acc);
+        acc += mov_dpp<kDppHalfMirror>(acc);
+        acc += mov_dpp<kDppMirror>(acc);
+        const Pair p = swap16(acc);
+        acc = p.a + p.b;
+        if (r < K) acc = rec[r] * sqrt(acc);                   // :156-157
+        if (l32 == 0) rec[K + r] = acc;
+      }
+      if (tid == 0) reinterpret_cast<int64_t *>(rec)[2 * K + 2] = q;
+      if (nPend + 1 == kPend) {
+        __syncthreads();                                       // the records of other waves
+        if (wave == 0) flush_pending(a, pend, kPend, lane, bestLds[lane]);
+      }
+    } else {
+      hW = wave_sum(hW);
+      accL = wave_sum(accL);
       if (lane == 0) {
-        if (wave == 0) rec[k] = Wk;                           // :90
-        part[k * WPQ + wave] = v;                              // :132
+        part[K * WPQ + wave] = hW;
+        part[(K + 1) * WPQ + wave] = accL;
       }
-    }
-    hW = wave_sum(hW);
-    accL = wave_sum(accL);
-    if (lane == 0) {
-      part[K * WPQ + wave] = hW;
-      part[(K + 1) * WPQ + wave] = accL;
-    }
-    if constexpr (WPQ > 1) __syncthreads();
-    if (wave == 0) {
-      // combine the waves' partials in wave order, one partial row per lane, and queue the question
-      for (int r = lane; r < nPart; r += kWave) {
-        double acc = part[r * WPQ];
-        for (int w2 = 1; w2 < WPQ; w2++) acc += part[r * WPQ + w2];
-        if (r < K) acc = rec[r] * sqrt(acc);                   // :156-157, one answer per lane
-        rec[K + r] = acc;
+      if constexpr (WPQ > 1) __syncthreads();
+      if (wave == 0) {
+        // combine the waves' partials in wave order, one partial row per lane, and queue the question
+        for (int r = lane; r < nPart; r += kWave) {
+          double acc = part[r * WPQ];
+          for (int w2 = 1; w2 < WPQ; w2++) acc += part[r * WPQ + w2];
+          if (r < K) acc = rec[r] * sqrt(acc);                   // :156-157, one answer per lane
+          rec[K + r] = acc;
+        }
+        if (lane == 0) reinterpret_cast<int64_t *>(rec)[2 * K + 2] = q;
+        if (nPend + 1 == kPend) flush_pending(a, pend, kPend, lane, bestLds[lane]);
       }
-      if (lane == 0) reinterpret_cast<int64_t *>(rec)[2 * K + 2] = q;
-      if (nPend + 1 == kPend) flush_pending(a, pend, kPend, lane, bestLds[lane]);
     }
     nPend = nPend + 1 == kPend ? 0 : nPend + 1;
     qpar ^= 1;
     q = qn;
   }
+  if constexpr (kDefer) __syncthreads();                       // the last questions' records, written by other waves
   if (wave == 0) {
     flush_pending(a, pend, nPend, lane, bestLds[lane]);
     fused_select<SERVER>(a, bestLds[lane], lane);
@@ -866,7 +914,8 @@ int gNumCUs = 0;
 template <int WPQ, int NP, bool PRLDS>
 hipError_t launch_reg(const EvalArgs &args, int64_t nQ, int nBatch, hipStream_t stream) {
   const size_t shmem = PRLDS ? eval_lds_doubles(WPQ, args.K, true, args.ldT) * sizeof(double)
-                             : eval_md_row_offset_bytes(WPQ, args.K) + (size_t)NP * WPQ * kWave * 16;
+                             : eval_md_row_offset_bytes(WPQ, args.K) + (size_t)NP * WPQ * kWave * 16 +
+                                   eval_deferred_bytes(WPQ, NP, args.K, PRLDS);
   auto kern = eval_questions_f64<WPQ, NP, PRLDS>;
   // attribute and occupancy are properties of (kernel, LDS size): asked once, not on every launch (the engine serialises
   // launches; a race between two engines would only repeat the query)
@@ -992,7 +1041,7 @@ hipError_t LaunchEvalQuestionsBatch(const KbView &kb, const QuizSlot *slots, int
 template <int WPQ, int NP>
 static hipError_t launch_server(const EvalArgs &args, ServerMailbox *mb, void *requestLine, bool everyonePolls, ServerCtl *ctl,
                                 uint64_t lastSeq, uint64_t idleTicks, hipStream_t stream) {
-  const size_t stepOffset = eval_md_row_offset_bytes(WPQ, args.K) + (size_t)NP * WPQ * kWave * 16;
+  const size_t stepOffset = eval_md_row_offset_bytes(WPQ, args.K) + (size_t)NP * WPQ * kWave * 16 + eval_deferred_bytes(WPQ, NP, args.K, false);
   const size_t shmem = stepOffset + 64;
   auto kern = eval_server_f64<WPQ, NP>;
   static size_t cachedShmem = ~(size_t)0;
