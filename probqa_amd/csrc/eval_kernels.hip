@@ -308,12 +308,12 @@ __host__ __device__ constexpr size_t eval_lds_doubles(int wpq, int64_t K, bool p
          (prLds ? (size_t)ldT + 2 : 0);
 }
 
-// Register-prior shapes of up to 8 waves keep the lanes' partial sums of a question -- K velocity sums, the entropy sum, the
-// lack sum -- in LDS ((K + 2) x threads doubles behind the mD landing row) and reduce them once per question, all waves
+// Shapes of up to 8 waves keep the lanes' partial sums of a question -- K velocity sums, the entropy sum, the
+// lack sum -- in LDS ((K + 2) x threads doubles behind the mD landing row / the LDS priors) and reduce them once per question, all waves
 // together, instead of one wave butterfly per sum and row: 18 VALU instructions per row and wave become one ds_write.
 // (Not the two 4-pair shapes: the change costs them four registers, which takes them from 165 / 167 to 169 and from three
 // waves per SIMD to two -- 41 instead of 37 us at 2000 targets.)
-__host__ __device__ constexpr bool eval_defers_sums(int wpq, int np, bool prLds) { return !prLds && wpq <= 8 && np != 4; }
+__host__ __device__ constexpr bool eval_defers_sums(int wpq, int np, bool prLds) { return wpq <= 8 && np != 4; }
 __host__ __device__ constexpr size_t eval_deferred_bytes(int wpq, int np, int64_t K, bool prLds) {
   return eval_defers_sums(wpq, np, prLds) ? (size_t)(K + 2) * wpq * kWave * sizeof(double) : 0;
 }
@@ -382,7 +382,8 @@ __device__ __forceinline__ void sweep_body(EvalArgs a, bool copyTable) {
   const int wave = SERVER ? (int)__builtin_amdgcn_readfirstlane(tid / kWave) : tid / kWave;
   const unsigned mdRowWaveAddr = (unsigned)(uintptr_t)mdRow + (unsigned)wave * 1024u;
   constexpr bool kDefer = eval_defers_sums(WPQ, NP, PRLDS);
-  double *vdump = reinterpret_cast<double *>(reinterpret_cast<char *>(mdRow) + (size_t)NP * kThreads * 16);   // kDefer only
+  double *vdump = PRLDS ? reinterpret_cast<double *>(prLds) + ldT + 2
+                        : reinterpret_cast<double *>(reinterpret_cast<char *>(mdRow) + (size_t)NP * kThreads * 16);   // kDefer only
   // ---- prologue.  Everything it needs from memory is independent of everything else, so all of it is requested
   // before anything is used: one memory round trip instead of a dozen dependent ones (with one question per workgroup,
   // as at 1000 x 1000, the prologue is on the critical path of the whole launch).  That includes the mD row of the first
@@ -913,9 +914,9 @@ int gNumCUs = 0;
 
 template <int WPQ, int NP, bool PRLDS>
 hipError_t launch_reg(const EvalArgs &args, int64_t nQ, int nBatch, hipStream_t stream) {
-  const size_t shmem = PRLDS ? eval_lds_doubles(WPQ, args.K, true, args.ldT) * sizeof(double)
-                             : eval_md_row_offset_bytes(WPQ, args.K) + (size_t)NP * WPQ * kWave * 16 +
-                                   eval_deferred_bytes(WPQ, NP, args.K, PRLDS);
+  const size_t shmem = (PRLDS ? eval_lds_doubles(WPQ, args.K, true, args.ldT) * sizeof(double)
+                              : eval_md_row_offset_bytes(WPQ, args.K) + (size_t)NP * WPQ * kWave * 16) +
+                       eval_deferred_bytes(WPQ, NP, args.K, PRLDS);
   auto kern = eval_questions_f64<WPQ, NP, PRLDS>;
   // attribute and occupancy are properties of (kernel, LDS size): asked once, not on every launch (the engine serialises
   // launches; a race between two engines would only repeat the query)
