@@ -54,6 +54,7 @@ def main():
                     help="how the shards' 16-byte winners meet: host shared memory written by the sweep itself "
                          "(default), or an RCCL all-gather + D2H copy")
     ap.add_argument("--no-server", action="store_true", help="launch one kernel per selection even where a resident sweep exists")
+    ap.add_argument("--no-quiz-loop", action="store_true", help="skip the quiz-loop extra")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=3.0, help="wall seconds of the CPU baseline leg")
     args = ap.parse_args()
@@ -254,6 +255,39 @@ def main():
         batched = {"quizzes_per_launch": args.batch, "selections_per_sec": reps * args.batch / (time.perf_counter() - tb0),
                    "launches_timed": reps, "agrees_with_single": int(picks[0]) == int(sel)}
 
+    # ---- extra (not `value`): the quiz loop the reference's only published rate is about (301.2 NextQuestion/s
+    # end to end on the author's 2017 desktop, PqaClient's learner loop at 1000 x 5 x 1000): NextQuestion with the reference's
+    # sampled selector, RecordAnswer by the binary-search rule, ListTopTargets(1), until the guess is on top or 30 questions
+    # were asked, then RecordQuizTarget.  On the synthetic trained cube of this run, not from a fresh KB.
+    quiz_loop = None
+    if selector is None and args.config == "S" and not args.no_quiz_loop:
+        from probqa_amd import synth
+
+        eng.set_option("select", 0)
+        eng.set_option("seed", SEED)
+        rng = np.random.default_rng(SEED)
+        asked, hits, n_q = 0, 0, 600
+        tq0 = time.perf_counter()
+        for _ in range(n_q):
+            guess = int(rng.integers(T))
+            qz = eng.start_quiz()
+            for _j in range(30):
+                qq = eng.next_question(qz)
+                asked += 1
+                eng.record_answer(qz, synth.dichotomy_answer(qq * T // Q, guess, max(1, 32 * T // 1000)))
+                top1 = eng.list_top_targets(qz, 1)
+                if top1 and top1[0].i_target == guess:
+                    hits += 1
+                    break
+            eng.record_quiz_target(qz, guess)
+            eng.release_quiz(qz)
+        dtq = time.perf_counter() - tq0
+        eng.set_option("select", 1)
+        quiz_loop = {"questions_per_sec": asked / dtq, "quizzes": n_q, "questions": asked, "guessed_on_top": hits,
+                     "published_reference_questions_per_sec": 301.2,
+                     "note": "reference figure: PqaClient learner loop on the author's 2017 desktop CPU (BASELINE.md); "
+                             "here: Python wrapper of the C ABI, one quiz at a time, sampled selector"}
+
     # ---- extra (not `value`), sharded runs only: BASELINE configs[3], the 10000x5x10000 cube over the same ranks -- the
     # configuration where sharding the question axis is about bandwidth rather than about launch latency
     sharded_m = None
@@ -302,6 +336,7 @@ def main():
         "pipelined_selections_per_sec": pipelined,
         "batched": batched,
         "hip_graph_replay": graph_rate,
+        "quiz_loop": quiz_loop,
         "sharded_10000x5x10000": sharded_m,
         "roofline": {
             "bound": "hbm",
