@@ -355,7 +355,7 @@ __device__ __forceinline__ double2 load_pair(const double2 *p) {
   }
 }
 
-template <int WPQ, int NP, bool PRLDS, bool SERVER>
+template <int WPQ, int NP, bool PRLDS, bool SERVER, bool DEFER>
 __device__ __forceinline__ void sweep_body(EvalArgs a, bool copyTable) {
   constexpr int kThreads = WPQ * kWave;
   constexpr int NPR = PRLDS ? 1 : NP;
@@ -381,7 +381,7 @@ __device__ __forceinline__ void sweep_body(EvalArgs a, bool copyTable) {
   const int tid = tidRaw, lane = tid % kWave;
   const int wave = SERVER ? (int)__builtin_amdgcn_readfirstlane(tid / kWave) : tid / kWave;
   const unsigned mdRowWaveAddr = (unsigned)(uintptr_t)mdRow + (unsigned)wave * 1024u;
-  constexpr bool kDefer = eval_defers_sums(WPQ, NP, PRLDS);
+  constexpr bool kDefer = DEFER;
   double *vdump = PRLDS ? reinterpret_cast<double *>(prLds) + ldT + 2
                         : reinterpret_cast<double *>(reinterpret_cast<char *>(mdRow) + (size_t)NP * kThreads * 16);   // kDefer only
   // ---- prologue.  Everything it needs from memory is independent of everything else, so all of it is requested
@@ -618,10 +618,13 @@ __device__ __forceinline__ void sweep_body(EvalArgs a, bool copyTable) {
   }
 }
 
-template <int WPQ, int NP, bool PRLDS>
+// DEFER: the question's lane sums leave the row loop (eval_defers_sums) -- the default where the shape has a deferred form
+// and the (K + 2) x threads doubles fit beside the rest of its LDS; a knowledge base with dozens of answers per question
+// falls back to the form without.
+template <int WPQ, int NP, bool PRLDS, bool DEFER>
 __global__ __launch_bounds__(WPQ * 64) void eval_questions_f64(EvalArgs a) {
   select_quiz(a);
-  sweep_body<WPQ, NP, PRLDS, false>(a, true);
+  sweep_body<WPQ, NP, PRLDS, false, DEFER>(a, true);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -644,7 +647,7 @@ __device__ __forceinline__ uint64_t line_u64(uint32_t v, int i) {   // qword i o
          ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)v, 2 * i + 1) << 32);
 }
 
-template <int WPQ, int NP>
+template <int WPQ, int NP, bool DEFER>
 // waves_per_eu(4, 4) = 128 VGPRs: three workgroups per CU then leave 128 registers per SIMD lane for the 256-thread posterior
 // kernels (<= 48) that must run beside the resident sweep (prior_kernels.hip: kSmallThreads)
 __global__ __launch_bounds__(WPQ * 64) __attribute__((amdgpu_waves_per_eu(4, 4)))
@@ -731,7 +734,7 @@ void eval_server_f64(EvalArgs a, ServerMailbox *mb, uint32_t *requestLine, int e
 #ifdef PQA_SERVER_TRACE
     const uint64_t tA = wall_clock64();
 #endif
-    sweep_body<WPQ, NP, false, true>(b, copyTable);
+    sweep_body<WPQ, NP, false, true, DEFER>(b, copyTable);
     copyTable = false;
     last = go;
     if (first && wave == 0) __hip_atomic_store(&mb->done, go, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -912,12 +915,17 @@ int pick_variant(int64_t ldT, int variant) {
 
 int gNumCUs = 0;
 
+constexpr size_t kLdsPerCU = 160 * 1024;   // gfx950
 template <int WPQ, int NP, bool PRLDS>
-hipError_t launch_reg(const EvalArgs &args, int64_t nQ, int nBatch, hipStream_t stream) {
-  const size_t shmem = (PRLDS ? eval_lds_doubles(WPQ, args.K, true, args.ldT) * sizeof(double)
-                              : eval_md_row_offset_bytes(WPQ, args.K) + (size_t)NP * WPQ * kWave * 16) +
-                       eval_deferred_bytes(WPQ, NP, args.K, PRLDS);
-  auto kern = eval_questions_f64<WPQ, NP, PRLDS>;
+constexpr size_t eval_base_lds_bytes(int64_t K, int64_t ldT) {
+  return PRLDS ? eval_lds_doubles(WPQ, K, true, ldT) * sizeof(double)
+               : eval_md_row_offset_bytes(WPQ, K) + (size_t)NP * WPQ * kWave * 16;
+}
+
+template <int WPQ, int NP, bool PRLDS, bool DEFER>
+hipError_t launch_reg_form(const EvalArgs &args, int64_t nQ, int nBatch, hipStream_t stream) {
+  const size_t shmem = eval_base_lds_bytes<WPQ, NP, PRLDS>(args.K, args.ldT) + (DEFER ? eval_deferred_bytes(WPQ, NP, args.K, PRLDS) : 0);
+  auto kern = eval_questions_f64<WPQ, NP, PRLDS, DEFER>;
   // attribute and occupancy are properties of (kernel, LDS size): asked once, not on every launch (the engine serialises
   // launches; a race between two engines would only repeat the query)
   static size_t cachedShmem = ~(size_t)0;
@@ -946,6 +954,15 @@ hipError_t launch_reg(const EvalArgs &args, int64_t nQ, int nBatch, hipStream_t 
   if (args.fs.scratch != nullptr && resGrid > maxRecords) resGrid = maxRecords;  // one winner record per workgroup
   hipLaunchKernelGGL(kern, dim3((unsigned)resGrid, (unsigned)nBatch), dim3(WPQ * 64), shmem, stream, args);
   return hipGetLastError();
+}
+
+template <int WPQ, int NP, bool PRLDS>
+hipError_t launch_reg(const EvalArgs &args, int64_t nQ, int nBatch, hipStream_t stream) {
+  if constexpr (eval_defers_sums(WPQ, NP, PRLDS)) {
+    if (eval_base_lds_bytes<WPQ, NP, PRLDS>(args.K, args.ldT) + eval_deferred_bytes(WPQ, NP, args.K, PRLDS) <= kLdsPerCU)
+      return launch_reg_form<WPQ, NP, PRLDS, true>(args, nQ, nBatch, stream);
+  }
+  return launch_reg_form<WPQ, NP, PRLDS, false>(args, nQ, nBatch, stream);
 }
 
 hipError_t launch_variant(const EvalArgs &args, int64_t ldT, int variant, int nBatch, hipStream_t stream) {
@@ -1039,12 +1056,12 @@ hipError_t LaunchEvalQuestionsBatch(const KbView &kb, const QuizSlot *slots, int
   return launch_variant(args, kb.ldT, variant, nSlots, stream);
 }
 
-template <int WPQ, int NP>
-static hipError_t launch_server(const EvalArgs &args, ServerMailbox *mb, void *requestLine, bool everyonePolls, ServerCtl *ctl,
+template <int WPQ, int NP, bool DEFER>
+static hipError_t launch_server_form(const EvalArgs &args, ServerMailbox *mb, void *requestLine, bool everyonePolls, ServerCtl *ctl,
                                 uint64_t lastSeq, uint64_t idleTicks, hipStream_t stream) {
-  const size_t stepOffset = eval_md_row_offset_bytes(WPQ, args.K) + (size_t)NP * WPQ * kWave * 16 + eval_deferred_bytes(WPQ, NP, args.K, false);
+  const size_t stepOffset = eval_base_lds_bytes<WPQ, NP, false>(args.K, args.ldT) + (DEFER ? eval_deferred_bytes(WPQ, NP, args.K, false) : 0);
   const size_t shmem = stepOffset + 64;
-  auto kern = eval_server_f64<WPQ, NP>;
+  auto kern = eval_server_f64<WPQ, NP, DEFER>;
   static size_t cachedShmem = ~(size_t)0;
   static int cachedPerCU = 0;
   if (shmem != cachedShmem) {
@@ -1069,6 +1086,14 @@ static hipError_t launch_server(const EvalArgs &args, ServerMailbox *mb, void *r
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(WPQ * 64), shmem, stream, args, mb, reinterpret_cast<uint32_t *>(requestLine),
                      everyonePolls ? 1 : 0, ctl, lastSeq, idleTicks, (unsigned)stepOffset);
   return hipGetLastError();
+}
+
+template <int WPQ, int NP>
+static hipError_t launch_server(const EvalArgs &args, ServerMailbox *mb, void *requestLine, bool everyonePolls, ServerCtl *ctl,
+                                uint64_t lastSeq, uint64_t idleTicks, hipStream_t stream) {
+  if (eval_base_lds_bytes<WPQ, NP, false>(args.K, args.ldT) + eval_deferred_bytes(WPQ, NP, args.K, false) + 64 <= kLdsPerCU)
+    return launch_server_form<WPQ, NP, true>(args, mb, requestLine, everyonePolls, ctl, lastSeq, idleTicks, stream);
+  return launch_server_form<WPQ, NP, false>(args, mb, requestLine, everyonePolls, ctl, lastSeq, idleTicks, stream);
 }
 
 static int server_variant(const KbView &kb, int variant) {
