@@ -97,8 +97,13 @@ __device__ __forceinline__ Best wave_best(Best b) {       // every lane ends up 
 // structurizer behind the loop exit of its wave while the other lanes run on to the next step's barrier: a deadlock
 // (tools/server_rt.hip reproduces it).
 template <bool UNI = false>
-__device__ __forceinline__ void fused_select(const EvalArgs &a, Best mine, int lane) {
+__device__ __forceinline__ void fused_select(const EvalArgs &a, Best mine, int lane, bool *allReported = nullptr) {
   if (a.fs.scratch == nullptr) return;
+  const bool sampled = a.fs.sampleSubtasks > 0;
+  // sampled: the finisher's workgroup reads every workgroup's priorities afterwards -- they must be visible before the record
+  // (they are write-through stores, store_priority: waiting for their acknowledgements is enough -- a release fence here
+  //  makes every workgroup write the whole L2 back, 7 us per launch)
+  if (sampled) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   const Best wg = wave_best(mine);
   uint64_t seqValue = a.fs.seqValue, flagValue = a.fs.flagValue;
   if (a.fs.tagCell != nullptr)  // graph replay: the finisher of the previous replay left this launch's tag here
@@ -154,6 +159,10 @@ __device__ __forceinline__ void fused_select(const EvalArgs &a, Best mine, int l
       }
   }
   b = wave_best(b);
+  if (sampled) {           // the selection follows (sweep_body); only whether the sweep is complete is handed on
+    if (allReported != nullptr && lane == 0) *allReported = complete;
+    return;
+  }
   if (UNI || lane == 0) {
     a.fs.out->priority = b.i < 0 ? 0.0 : b.p;
     a.fs.out->index = !complete ? -3 : b.i < 0 ? -1 : b.i + a.fs.outBase;
@@ -612,9 +621,28 @@ __device__ __forceinline__ void sweep_body(EvalArgs a, bool copyTable) {
     q = qn;
   }
   if constexpr (kDefer) __syncthreads();                       // the last questions' records, written by other waves
+  bool *allReported = reinterpret_cast<bool *>(redW);         // (the W exchange buffer is free now)
   if (wave == 0) {
     flush_pending(a, pend, nPend, lane, bestLds[lane]);
-    fused_select<SERVER>(a, bestLds[lane], lane);
+    fused_select<SERVER>(a, bestLds[lane], lane, allReported);
+  }
+  if constexpr (!SERVER) {
+    if (a.fs.scratch != nullptr && a.fs.sampleSubtasks > 0 && blockIdx.x == 0) {
+      // ---- the reference's selector, by this workgroup, over what every workgroup has written (fused_select above made
+      // sure they all have); the Log2Hot table's LDS holds the subtask totals
+      __syncthreads();
+      const bool complete = *allReported;
+      const SampledPick r = select_sampled_wg_lds<true>(a.priority, a.qgap, a.asked, a.qFirst, a.qLimit - a.qFirst,
+                                                        a.fs.sampleSubtasks, a.fs.sampleRnd, tbl);
+      if (tid == 0) {
+        a.fs.out->priority = r.priority;
+        a.fs.out->index = complete ? r.index + a.fs.outBase : -3;
+        if (a.fs.seq != nullptr) {
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+          __hip_atomic_store(a.fs.seq, a.fs.flagValue, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+      }
+    }
   }
 }
 
@@ -1029,7 +1057,7 @@ static EvalArgs make_args(const KbView &kb, int64_t qFirst, int64_t qLimit) {
   args.qLimit = qLimit;
   const double nT = (double)(kb.nValidTargets + 1);  // PqaCore/CEEvalQsSubtaskConsider.cpp:191
   args.vCompTail = 0.34657359027997265470861606072909 / (nT * nT);
-  args.fs = FusedSelect{nullptr, nullptr, nullptr, 0, 0, 0, 0, nullptr};
+  args.fs = FusedSelect{nullptr, nullptr, nullptr, 0, 0, 0, 0, nullptr, 0, 0, nullptr};
   args.slots = nullptr;
   return args;
 }
@@ -1099,6 +1127,9 @@ static hipError_t launch_server(const EvalArgs &args, ServerMailbox *mb, void *r
 static int server_variant(const KbView &kb, int variant) {
   const int v = pick_variant(kb.ldT, variant);
   return v == 2 ? v : 0;   // wg256_np2: rows up to 1024 targets
+}
+bool EvalVariantFusesSampled(const KbView &kb, int variant, int64_t nSubtasks) {   // a register shape, and the selection's LDS fits
+  return pick_variant(kb.ldT, variant) != 99 && select_sampled_lds_doubles(kb.Q, nSubtasks) <= kLog2TableDoubles;
 }
 bool EvalServerSupported(const KbView &kb, int variant) { return server_variant(kb, variant) != 0; }
 

@@ -256,6 +256,7 @@ Error HipEngine::SetOption(const char *name, int64_t value) {
   else if (n == "use_graph") { _optUseGraph = value ? 1 : 0; }
   else if (n == "top_cache") { if (value < 0 || value > 256) goto bad; _optTopCache = value; }
   else if (n == "server") { if (!value) StopServer(); _optServer = value ? 1 : 0; }
+  else if (n == "fused_sampled") { _optFusedSampled = value ? 1 : 0; }
   else if (n == "server_vram_mailbox") { if (_serverStream) goto bad; _optServerVramMailbox = value ? 1 : 0; }
   else if (n == "server_idle_us") { if (value < 10 || value > 1000000) goto bad; StopServer(); _optServerIdleUs = value; }
   else if (n == "seed") { uint64_t s = (uint64_t)value; _rng[0] = SplitMix64(s); _rng[1] = SplitMix64(s); }
@@ -276,6 +277,7 @@ int64_t HipEngine::GetOption(const char *name) const {
   if (n == "use_graph") return _optUseGraph;
   if (n == "server") return _optServer;
   if (n == "server_idle_us") return _optServerIdleUs;
+  if (n == "fused_sampled") return _optFusedSampled;
   if (n == "server_vram_mailbox") return _serverStream ? (_serverRequestInVram ? 1 : 0) : _optServerVramMailbox;
   if (n == "debug_mailbox") return (int64_t)(uintptr_t)_hMailbox;
   if (n == "server_active") return (_optServer && ServerUsable()) ? 1 : 0;
@@ -527,7 +529,7 @@ Error HipEngine::EnqueueSelectArgmax(int64_t iQuiz, void *pOut) {
   Quiz *q = UseQuiz(err, iQuiz);
   if (!q) return err;
   // one launch: the sweep's last workgroup picks the argmax; reported index = local position + qFirst (GLOBAL id)
-  const FusedSelect fs{_dSelScratch, pOut ? (SelectResult *)pOut : _dSel, nullptr, NextLaunchTag(), _qFirst, 0, 0, nullptr};
+  const FusedSelect fs{_dSelScratch, pOut ? (SelectResult *)pOut : _dSel, nullptr, NextLaunchTag(), _qFirst, 0, 0, nullptr, 0, 0, nullptr};
   StopServer();   // a launched sweep has no room beside the resident one and would wait for it to idle out
   HIP_TRY(LaunchEvalQuestions(View(), q->dPrior, q->dAsked, 0, _Q, _dPriority, (int)_optEvalVariant, &fs, _stream));
   return Error();
@@ -545,7 +547,7 @@ Error HipEngine::EnqueueSelectArgmaxFlag(int64_t iQuiz, void *pOut, void *pFlag,
   if (!pOut || !pFlag) return Error::Make(ErrCode::NullArgument, "Nullptr is passed in place of the record or the flag.");
   hipSetDevice(_device);
   if (_optServer && ServerUsable()) return ServerPost(q, (SelectResult *)pOut, (uint64_t *)pFlag, flagValue, _qFirst);
-  const FusedSelect fs{_dSelScratch, (SelectResult *)pOut, (uint64_t *)pFlag, NextLaunchTag(), _qFirst, 0, flagValue, nullptr};
+  const FusedSelect fs{_dSelScratch, (SelectResult *)pOut, (uint64_t *)pFlag, NextLaunchTag(), _qFirst, 0, flagValue, nullptr, 0, 0, nullptr};
   StopServer();   // a launched sweep has no room beside the resident one and would wait for it to idle out
   HIP_TRY(LaunchEvalQuestions(View(), q->dPrior, q->dAsked, 0, _Q, _dPriority, (int)_optEvalVariant, &fs, _stream));
   return Error();
@@ -590,7 +592,7 @@ int64_t HipEngine::NextQuestionArgmax(Error &err, int64_t iQuiz) {
   // One launch; the last workgroup writes the winner and then a sequence number straight into host-coherent pinned
   // memory, which this thread polls: no D2H copy, no stream synchronisation on the critical path.
   const uint64_t seq = NextLaunchTag();
-  const FusedSelect fs{_dSelScratch, &_hPinned->sel, &_hPinned->seq, seq, 0, 0, seq, nullptr};
+  const FusedSelect fs{_dSelScratch, &_hPinned->sel, &_hPinned->seq, seq, 0, 0, seq, nullptr, 0, 0, nullptr};
   StopServer();   // a launched sweep has no room beside the resident one and would wait for it to idle out
   hipError_t he = LaunchEvalQuestions(View(), q->dPrior, q->dAsked, 0, _Q, _dPriority, (int)_optEvalVariant, &fs, _stream);
   if (he != hipSuccess) { err = HipErr(he, "NextQuestionArgmax"); return -1; }
@@ -775,7 +777,7 @@ Error HipEngine::NextQuestionArgmaxBatch(int64_t n, const int64_t *pQuizzes, int
   }
   const uint64_t tag = NextLaunchTag();
   HIP_TRY(hipMemcpyAsync(_dBatchSlots, _hBatch->slots, (size_t)n * sizeof(QuizSlot), hipMemcpyHostToDevice, _stream));
-  const FusedSelect fs{_dBatchScratch, nullptr, nullptr, tag, 0, kBatchGrid, tag, nullptr};
+  const FusedSelect fs{_dBatchScratch, nullptr, nullptr, tag, 0, kBatchGrid, tag, nullptr, 0, 0, nullptr};
   StopServer();   // a launched sweep has no room beside the resident one and would wait for it to idle out
   HIP_TRY(LaunchEvalQuestionsBatch(View(), _dBatchSlots, (int)n, 0, _Q, (int)_optEvalVariant, fs, _stream));
   const auto t0 = std::chrono::steady_clock::now();
@@ -821,7 +823,7 @@ int64_t HipEngine::NextQuestionArgmaxGraph(Error &err, Quiz *q) {
   if (it == _graphs.end() || it->second.variant != _optEvalVariant || it->second.stream != _stream ||
       it->second.kbVersion != _kbVersion) {
     if (it != _graphs.end()) { hipGraphExecDestroy(it->second.exec); _graphs.erase(it); }
-    const FusedSelect fs{_dGraphScratch, &_hPinned->sel, &_hPinned->seq, 0, 0, 0, 0, _dTagCell};
+    const FusedSelect fs{_dGraphScratch, &_hPinned->sel, &_hPinned->seq, 0, 0, 0, 0, _dTagCell, 0, 0, nullptr};
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
     hipError_t he = hipStreamBeginCapture(_stream, hipStreamCaptureModeThreadLocal);
@@ -858,6 +860,17 @@ int64_t HipEngine::NextQuestionSampled(Error &err, int64_t iQuiz, uint64_t rnd) 
   const KbView kb = View();
   const int64_t nSub = _optEvalSubtasks ? _optEvalSubtasks : 8 * _optWorkers;  // reference PqaCore/CpuEngine.cpp:339
   StopServer();   // a launched sweep has no room beside the resident one and would wait for it to idle out
+  if (_optFusedSampled && EvalVariantFusesSampled(kb, (int)_optEvalVariant, nSub)) {
+    // ONE launch: the sweep's finisher workgroup runs the reference's selector once every workgroup has reported
+    const uint64_t seq = NextLaunchTag();
+    const FusedSelect fs{_dSelScratch, &_hPinned->sel, &_hPinned->seq, seq, 0, 0, seq, nullptr, nSub, rnd, _dRunLength};
+    const hipError_t he = LaunchEvalQuestions(kb, q->dPrior, q->dAsked, 0, _Q, _dPriority, (int)_optEvalVariant, &fs, _stream);
+    if (he != hipSuccess) { err = HipErr(he, "NextQuestionSampled"); return -1; }
+    err = WaitFlag(&_hPinned->seq, seq, "NextQuestionSampled");
+    if (!err.ok()) return -1;
+    if (_hPinned->sel.index == -3) { err = HipErr(hipErrorLaunchFailure, "NextQuestionSampled (incomplete sweep)"); return -1; }
+    return FinishSelection(err, q, _hPinned->sel.index);
+  }
   hipError_t he = LaunchEvalQuestions(kb, q->dPrior, q->dAsked, 0, _Q, _dPriority, (int)_optEvalVariant, nullptr, _stream);
   const uint64_t op = ++_opSeq;  // the selector writes its record and then this number into host-coherent memory
   if (he == hipSuccess)

@@ -238,6 +238,179 @@ __device__ __forceinline__ double precise_sum4(const double *sum, const double *
   return a.get();
 }
 
+// ---- the reference's sampled selector for one workgroup (PqaCore/CpuEngine.cpp:362-400) ------------------------------------
+// Per-subtask Kahan run lengths, Kahan grand totals, one uniform number, two upper_bounds -- step for step, so that with the
+// same priorities, subtask count and random number it returns the reference's question.  Called by every thread of the
+// workgroup (barriers inside); the result is valid in thread 0.  COH: the priorities were written by other workgroups of
+// the same launch (fused with the sweep) and are read past the non-coherent cache levels.
+// std::upper_bound: first element strictly greater than v
+__device__ __forceinline__ int64_t upper_bound_d(const double *a, int64_t n, double v) {
+  int64_t lo = 0, hi = n;
+  while (lo < hi) {
+    const int64_t mid = lo + ((hi - lo) >> 1);
+    if (!(v < a[mid])) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+// SRPoolRunner::CalcSplit bound i (reference: SRPlatform/Interface/SRPoolRunner.h:96-110) in closed form:
+// the first `rem` subtasks get quot+1 items.
+__device__ __forceinline__ int64_t calc_split_bound(int64_t i, int64_t quot, int64_t rem) {  // end of subtask i
+  const int64_t n1 = (i + 1 < rem) ? (i + 1) : rem;
+  return (i + 1) * quot + n1;
+}
+struct SampledPick { double priority; int64_t index; };
+template <bool COH>
+__device__ __forceinline__ SampledPick select_sampled_wg_impl(const double *priority, const uint32_t *qgap, const uint32_t *asked,
+                                                              int64_t qFirst, int64_t n, int64_t nWorkers, uint64_t rnd,
+                                                              double *runLength, double *grand) {
+  const int64_t quot = n / nWorkers, rem = n % nWorkers;
+  const int64_t nSubtasks = (quot == 0) ? rem : nWorkers;  // CalcSplit stops once the items run out
+  // per-subtask inclusive Kahan running sums (PqaCore/CEEvalQsSubtaskConsider.cpp:52,212-214)
+  for (int64_t s = threadIdx.x; s < nSubtasks; s += blockDim.x) {
+    const int64_t first = (s == 0) ? 0 : calc_split_bound(s - 1, quot, rem), limit = calc_split_bound(s, quot, rem);
+    Kahan1 acc;
+    acc.init(0.0);
+    for (int64_t i = first; i < limit; i++) {
+      // gap / asked questions only copy the running sum (:54-58); evaluated ones are Kahan-added (:212)
+      if (!(bit_test(qgap, qFirst + i) || bit_test(asked, qFirst + i)))
+        acc.add(COH ? __hip_atomic_load(priority + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : priority[i]);
+      runLength[i] = acc.get();
+    }
+    grand[s] = acc.get();
+  }
+  __syncthreads();
+  SampledPick r{0.0, -1};
+  if (threadIdx.x == 0) {
+    Kahan1 accTotG;
+    accTotG.init(0.0);                                         // PqaCore/CpuEngine.cpp:362
+    // 16 totals at a time: their loads are issued together and the results stored afterwards, so that only the Kahan
+    // chain itself (4 dependent operations per subtask) is serial, not an LDS round trip per subtask as well
+    for (int64_t s0 = 0; s0 < nSubtasks; s0 += 16) {
+      double g[16];
+#pragma unroll
+      for (int u = 0; u < 16; u++) g[u] = s0 + u < nSubtasks ? grand[s0 + u] : 0.0;
+#pragma unroll
+      for (int u = 0; u < 16; u++) {
+        if (s0 + u < nSubtasks) {
+          accTotG.add(g[u]);                                   // :366-367
+          g[u] = accTotG.get();                                // :368
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 16; u++)
+        if (s0 + u < nSubtasks) grand[s0 + u] = g[u];
+    }
+    const double totG = grand[nSubtasks - 1];                  // :375
+    // SRDoubleNumber::MakeRandom (SRPlatform/Interface/SRDoubleNumber.h:35-39)
+    const double selRunLen = totG * (double)rnd / 18446744073709551615.0;  // :379
+    int64_t sel;
+    const int64_t iWorker = upper_bound_d(grand, nSubtasks, selRunLen);    // :380-381
+    if (iWorker >= nSubtasks) {
+      sel = n - 1;                                             // :384
+    } else {
+      const double inWorkerRunLen = selRunLen - ((iWorker == 0) ? 0.0 : grand[iWorker - 1]);  // :388
+      const int64_t first = (iWorker == 0) ? 0 : calc_split_bound(iWorker - 1, quot, rem);    // :389
+      const int64_t limit = calc_split_bound(iWorker, quot, rem);                              // :390
+      sel = first + upper_bound_d(runLength + first, limit - first, inWorkerRunLen);           // :391
+      if (sel >= limit) sel = limit - 1;                       // :392-400
+    }
+    r.priority = totG;
+    r.index = sel;
+  }
+  return r;
+}
+
+// The same selection with everything it touches staged in LDS first (`lds`: n + nWorkers + n/64 + 2 doubles): the
+// priorities arrive in ONE parallel round of loads instead of one dependent load per item of a subtask's chain -- what
+// makes the selection affordable inside the sweep's launch, where those loads go past the caches (sc1, ~2 us each).
+template <bool COH>
+__device__ __forceinline__ SampledPick select_sampled_wg_lds(const double *priority, const uint32_t *qgap, const uint32_t *asked,
+                                                             int64_t qFirst, int64_t n, int64_t nWorkers, uint64_t rnd,
+                                                             double *lds) {
+  double *run = lds;                                   // priorities, then (in place) the run lengths
+  double *grand = lds + n;
+  uint32_t *skip = reinterpret_cast<uint32_t *>(grand + nWorkers);   // gap | asked bits of the n questions, local numbering
+  const int64_t nWords = (n + 31) >> 5;
+  for (int64_t i0 = threadIdx.x; i0 < n; i0 += 8 * (int64_t)blockDim.x) {   // eight loads in flight per thread, not one
+    double v[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      const int64_t i = i0 + u * (int64_t)blockDim.x;
+      v[u] = i < n ? (COH ? __hip_atomic_load(priority + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : priority[i]) : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      const int64_t i = i0 + u * (int64_t)blockDim.x;
+      if (i < n) run[i] = v[u];
+    }
+  }
+  for (int64_t w = threadIdx.x; w < nWords; w += blockDim.x) {
+    uint32_t bits = 0;
+    if ((qFirst & 31) == 0) {            // (every caller's case: whole words)
+      bits = qgap[(qFirst >> 5) + w] | asked[(qFirst >> 5) + w];
+    } else {
+      for (int b = 0; b < 32; b++) {
+        const int64_t i = (w << 5) + b;
+        if (i < n && (bit_test(qgap, qFirst + i) || bit_test(asked, qFirst + i))) bits |= 1u << b;
+      }
+    }
+    skip[w] = bits;
+  }
+  __syncthreads();
+  const int64_t quot = n / nWorkers, rem = n % nWorkers;
+  const int64_t nSubtasks = (quot == 0) ? rem : nWorkers;
+  for (int64_t s = threadIdx.x; s < nSubtasks; s += blockDim.x) {
+    const int64_t first = (s == 0) ? 0 : calc_split_bound(s - 1, quot, rem), limit = calc_split_bound(s, quot, rem);
+    Kahan1 acc;
+    acc.init(0.0);
+    for (int64_t i = first; i < limit; i++) {
+      if (!((skip[i >> 5] >> (i & 31)) & 1u)) acc.add(run[i]);   // :54-58 / :212
+      run[i] = acc.get();
+    }
+    grand[s] = acc.get();
+  }
+  __syncthreads();
+  SampledPick r{0.0, -1};
+  if (threadIdx.x == 0) {
+    Kahan1 accTotG;
+    accTotG.init(0.0);                                         // PqaCore/CpuEngine.cpp:362
+    // 16 totals at a time: their loads are issued together and the results stored afterwards, so that only the Kahan
+    // chain itself (4 dependent operations per subtask) is serial, not an LDS round trip per subtask as well
+    for (int64_t s0 = 0; s0 < nSubtasks; s0 += 16) {
+      double g[16];
+#pragma unroll
+      for (int u = 0; u < 16; u++) g[u] = s0 + u < nSubtasks ? grand[s0 + u] : 0.0;
+#pragma unroll
+      for (int u = 0; u < 16; u++) {
+        if (s0 + u < nSubtasks) {
+          accTotG.add(g[u]);                                   // :366-367
+          g[u] = accTotG.get();                                // :368
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 16; u++)
+        if (s0 + u < nSubtasks) grand[s0 + u] = g[u];
+    }
+    const double totG = grand[nSubtasks - 1];                  // :375
+    const double selRunLen = totG * (double)rnd / 18446744073709551615.0;  // :379
+    int64_t sel;
+    const int64_t iWorker = upper_bound_d(grand, nSubtasks, selRunLen);    // :380-381
+    if (iWorker >= nSubtasks) {
+      sel = n - 1;                                             // :384
+    } else {
+      const double inWorkerRunLen = selRunLen - ((iWorker == 0) ? 0.0 : grand[iWorker - 1]);  // :388
+      const int64_t first = (iWorker == 0) ? 0 : calc_split_bound(iWorker - 1, quot, rem);    // :389
+      const int64_t limit = calc_split_bound(iWorker, quot, rem);                              // :390
+      sel = first + upper_bound_d(run + first, limit - first, inWorkerRunLen);                 // :391
+      if (sel >= limit) sel = limit - 1;                       // :392-400
+    }
+    r.priority = totG;
+    r.index = sel;
+  }
+  return r;
+}
+__host__ __device__ constexpr int64_t select_sampled_lds_doubles(int64_t n, int64_t nWorkers) { return n + nWorkers + n / 64 + 2; }
+
 // ---- top-maxCount targets by probability -------------------------------------------------------------------------------
 // Descending probability, lower index first on ties, gaps never listed (reference PqaCore/CEListTopTargetsAlgorithm.cpp).
 // For a workgroup of up to 1024 threads: every thread holds its E targets (t = tid + e*blockDim) in registers; a round is one wave

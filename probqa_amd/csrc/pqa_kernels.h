@@ -52,6 +52,13 @@ struct FusedSelect {
   // Launches replayed from a HIP graph have constant arguments: with tagCell != nullptr both the launch tag and the flag
   // value are read from this device word instead, and the finisher advances it for the next replay.
   uint64_t *tagCell;
+  // The reference's sampled selector instead of the argmax, in the same launch: once the finisher has seen every
+  // workgroup's record, workgroup 0 runs the selection (select_sampled_wg_impl, pqa_device.h) over the priority vector and
+  // writes {sum of priorities, selected position} to `out`.  sampleSubtasks > 0 switches it on; priorities, run lengths and
+  // totals are staged in the LDS that held the Log2Hot table (EvalVariantFusesSampled says whether they fit).
+  int64_t sampleSubtasks;
+  uint64_t sampleRnd;
+  double *runLength;
 };
 // One quiz of a batched sweep (blockIdx.y selects it): everything that differs between the quizzes of one launch.
 struct QuizSlot {
@@ -69,6 +76,7 @@ hipError_t LaunchEvalQuestions(const KbView &kb, const double *prior, const uint
 hipError_t LaunchEvalQuestionsBatch(const KbView &kb, const QuizSlot *slots, int nSlots, int64_t qFirst, int64_t qLimit,
                                     int variant, const FusedSelect &fused, hipStream_t stream);
 const char *EvalVariantName(const KbView &kb, int variant);
+bool EvalVariantFusesSampled(const KbView &kb, int variant, int64_t nSubtasks);   // the launch can run the sampled selector itself
 
 // ---- resident sweep ("server"): ONE launch serves many selections.  The host posts a request in pinned memory; workgroup
 // 0 sees it, hands it to the other workgroups through a device word, everybody sweeps, the finisher answers straight into

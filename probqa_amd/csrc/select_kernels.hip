@@ -62,67 +62,16 @@ __global__ __launch_bounds__(1024) void select_argmax_kernel(const double *__res
   }
 }
 
-// std::upper_bound: first element strictly greater than v
-__device__ __forceinline__ int64_t upper_bound_d(const double *a, int64_t n, double v) {
-  int64_t lo = 0, hi = n;
-  while (lo < hi) {
-    const int64_t mid = lo + ((hi - lo) >> 1);
-    if (!(v < a[mid])) lo = mid + 1; else hi = mid;
-  }
-  return lo;
-}
-
-// SRPoolRunner::CalcSplit bound i (reference: SRPlatform/Interface/SRPoolRunner.h:96-110) in closed form:
-// the first `rem` subtasks get quot+1 items.
-__device__ __forceinline__ int64_t split_bound(int64_t i, int64_t quot, int64_t rem) {  // end of subtask i
-  const int64_t n1 = (i + 1 < rem) ? (i + 1) : rem;
-  return (i + 1) * quot + n1;
-}
-
 __global__ __launch_bounds__(1024) void select_sampled_kernel(const double *__restrict__ priority,
                                                               const uint32_t *__restrict__ qgap,
                                                               const uint32_t *__restrict__ asked, int64_t qFirst,
                                                               int64_t n, int64_t nWorkers, uint64_t rnd,
                                                               double *__restrict__ runLength, SelectResult *out, uint64_t *flag, uint64_t flagValue) {
   extern __shared__ double grand[];  // nSubtasks doubles
-  const int64_t quot = n / nWorkers, rem = n % nWorkers;
-  const int64_t nSubtasks = (quot == 0) ? rem : nWorkers;  // CalcSplit stops once the items run out
-  // per-subtask inclusive Kahan running sums (PqaCore/CEEvalQsSubtaskConsider.cpp:52,212-214)
-  for (int64_t s = threadIdx.x; s < nSubtasks; s += blockDim.x) {
-    const int64_t first = (s == 0) ? 0 : split_bound(s - 1, quot, rem), limit = split_bound(s, quot, rem);
-    Kahan1 acc;
-    acc.init(0.0);
-    for (int64_t i = first; i < limit; i++) {
-      // gap / asked questions only copy the running sum (:54-58); evaluated ones are Kahan-added (:212)
-      if (!(bit_test(qgap, qFirst + i) || bit_test(asked, qFirst + i))) acc.add(priority[i]);
-      runLength[i] = acc.get();
-    }
-    grand[s] = acc.get();
-  }
-  __syncthreads();
+  const SampledPick r = select_sampled_wg_impl<false>(priority, qgap, asked, qFirst, n, nWorkers, rnd, runLength, grand);
   if (threadIdx.x == 0) {
-    Kahan1 accTotG;
-    accTotG.init(0.0);                                         // PqaCore/CpuEngine.cpp:362
-    for (int64_t s = 0; s < nSubtasks; s++) {
-      accTotG.add(grand[s]);                                   // :366-367
-      grand[s] = accTotG.get();                                // :368
-    }
-    const double totG = grand[nSubtasks - 1];                  // :375
-    // SRDoubleNumber::MakeRandom (SRPlatform/Interface/SRDoubleNumber.h:35-39)
-    const double selRunLen = totG * (double)rnd / 18446744073709551615.0;  // :379
-    int64_t sel;
-    const int64_t iWorker = upper_bound_d(grand, nSubtasks, selRunLen);    // :380-381
-    if (iWorker >= nSubtasks) {
-      sel = n - 1;                                             // :384
-    } else {
-      const double inWorkerRunLen = selRunLen - ((iWorker == 0) ? 0.0 : grand[iWorker - 1]);  // :388
-      const int64_t first = (iWorker == 0) ? 0 : split_bound(iWorker - 1, quot, rem);         // :389
-      const int64_t limit = split_bound(iWorker, quot, rem);                                   // :390
-      sel = first + upper_bound_d(runLength + first, limit - first, inWorkerRunLen);           // :391
-      if (sel >= limit) sel = limit - 1;                       // :392-400
-    }
-    out->priority = totG;
-    out->index = sel;
+    out->priority = r.priority;
+    out->index = r.index;
     if (flag != nullptr) {  // `out` and `flag` in host-coherent memory: the host polls instead of copying + synchronising
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
       __hip_atomic_store(flag, flagValue, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);

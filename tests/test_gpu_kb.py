@@ -320,3 +320,25 @@ def test_graph_replay_variant_of_the_selection(factory):
         if step == 5:
             eng.set_question_gaps([int(eng.next_question(a))])
     eng.close()
+
+
+@pytest.mark.gpu
+def test_fused_sampled_selection_picks_the_same_question(factory):
+    """Option fused_sampled: the reference's selector run by the sweep's finisher workgroup (one launch) against the separate
+    selector kernel: the same question for the same random number, asked / gap questions never picked."""
+    eng = factory.create_hip_engine(interop.EngineDefinition(5, 700, 900, init_amount=0.1), 0, 700, 0)
+    try:
+        eng.fill_synthetic(8.0, 0.5, 3)
+        eng.set_question_gaps([5, 6, 300])
+        quiz = eng.start_quiz()
+        for step in range(6):
+            picks = []
+            for fused in (0, 1):
+                eng.set_option("fused_sampled", fused)
+                picks.append([eng.next_question_sampled(quiz, (0x9E3779B97F4A7C15 * (k + 1) + step) % 2**64) for k in range(40)])
+            assert picks[0] == picks[1]
+            assert not {5, 6, 300} & set(picks[0])
+            eng.set_active_question(quiz, picks[0][0])
+            eng.record_answer(quiz, step % 5)
+    finally:
+        eng.close()
