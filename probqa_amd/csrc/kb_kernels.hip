@@ -87,7 +87,8 @@ __global__ __launch_bounds__(SMALL ? 256 : 1024) void top_targets_kernel(const d
                                                                          const uint32_t *__restrict__ tgap, int64_t T,
                                                                          int64_t maxCount, RatedTargetDev *out, int64_t *nOut,
                                                                          uint64_t *flag, uint64_t flagValue) {
-  top_targets_publish<SMALL>(prior, tgap, T, maxCount, reinterpret_cast<TopOut *>(out), nOut, flag, flagValue);
+  __shared__ TopScratch scratch;
+  top_targets_publish<SMALL>(prior, tgap, T, maxCount, reinterpret_cast<TopOut *>(out), nOut, flag, flagValue, &scratch);
 }
 
 unsigned grid_for(int64_t n, int threads) {

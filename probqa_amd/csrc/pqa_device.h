@@ -508,12 +508,18 @@ __device__ __forceinline__ int64_t top_targets_rounds(const double *prior, const
 // in LDS and leave in one coalesced burst at the end: a store to host memory per round costs more than the round.
 // SMALL: only the <= 4 targets per thread forms (a 256-thread launch over <= 1024 targets keeps 40 VGPRs and fits beside
 // the resident sweep's workgroups, prior_kernels.hip).
+struct TopScratch {          // the listing's LDS: the caller's, so that a kernel whose LDS layout is fixed can place it
+  double sp[2][16];
+  int st[2][16];
+  TopOut staged[256];
+};
 template <bool SMALL = false>
 __device__ __forceinline__ void top_targets_publish(const double *prior, const uint32_t *tgap, int64_t T, int64_t maxCount,
-                                                    TopOut *out, int64_t *nOut, uint64_t *flag, uint64_t flagValue) {
-  __shared__ double sp[2][16];
-  __shared__ int st[2][16];
-  __shared__ TopOut staged[256];
+                                                    TopOut *out, int64_t *nOut, uint64_t *flag, uint64_t flagValue,
+                                                    TopScratch *scratch) {
+  double (*sp)[16] = scratch->sp;
+  int (*st)[16] = scratch->st;
+  TopOut *staged = scratch->staged;
   if (maxCount > 256) maxCount = 256;
   // waves that do not exist never win a round
   if (threadIdx.x < 32) {

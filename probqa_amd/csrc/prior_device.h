@@ -1,0 +1,102 @@
+// prior_device.h -- the posterior update of one answered question as a device function (RecordAnswer: reference
+// PqaCore/CERecordAnswerSubtaskMul.cpp:15-42, PqaCore/Summator.h:11-21, PqaCore/CEDivTargPriorsSubtask.h:12-30), shared by
+// its kernel (prior_kernels.hip) and by the resident sweep (eval_kernels.hip), which runs it between two selections without a
+// launch.  Bit-identical to the CPU engine: see prior_kernels.hip for the summation order that is reproduced here.
+#pragma once
+#include "pqa_device.h"
+
+namespace pqa {
+
+__device__ __forceinline__ int64_t prior_split_bound(int64_t i, int64_t quot, int64_t rem) {  // end of subtask i
+  const int64_t n1 = (i + 1 < rem) ? (i + 1) : rem;
+  return (i + 1) * quot + n1;
+}
+
+// Sum v[0 .. 4*nVects) exactly as the CPU engine does and return the total to every thread.
+// lds: 8*nSubtasks + 1 doubles.  Must be called by all threads; contains barriers.
+__device__ double reference_order_sum(const double *__restrict__ v, int64_t nVects, int64_t nWorkers, double *lds) {
+  const int64_t quot = nVects / nWorkers, rem = nVects % nWorkers;
+  const int64_t nSubtasks = (quot == 0) ? rem : nWorkers;
+  __syncthreads();  // v was written by other threads of this workgroup
+  for (int64_t ch = threadIdx.x; ch < nSubtasks * 4; ch += blockDim.x) {
+    const int64_t s = ch >> 2;
+    const int c = (int)(ch & 3);
+    const int64_t first = (s == 0) ? 0 : prior_split_bound(s - 1, quot, rem), limit = prior_split_bound(s, quot, rem);
+    double sum = 0, corr = 0;  // SRAccumVectDbl256::Add, SRPlatform/Interface/SRAccumVectDbl256.h:40-46
+    for (int64_t j = first; j < limit; j++) {
+      const double y = v[4 * j + c] - corr;
+      const double t = sum + y;
+      corr = (t - sum) - y;
+      sum = t;
+    }
+    lds[8 * s + c] = sum;
+    lds[8 * s + 4 + c] = corr;
+  }
+  __syncthreads();
+  // PreciseSum of each subtask's four lanes in parallel (one subtask per thread; the result replaces the subtask's first
+  // slot), then the serial Kahan over the subtasks in order: the same operations in the same order as one thread doing
+  // both, 1.4 us sooner at 16 workers
+  for (int64_t s2 = threadIdx.x; s2 < nSubtasks; s2 += blockDim.x) {
+    const double ps = precise_sum4(lds + 8 * s2, lds + 8 * s2 + 4);
+    lds[8 * s2] = ps;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    Kahan1 acc;  // Summator::ForPriors, PqaCore/Summator.h:14-19
+    acc.init(0.0);
+    for (int64_t s2 = 0; s2 < nSubtasks; s2++) acc.add(lds[8 * s2]);
+    lds[8 * nSubtasks] = acc.get();
+  }
+  __syncthreads();
+  return lds[8 * nSubtasks];
+}
+
+struct PriorArgs {
+  const double *cube;
+  const double *vB;
+  const uint32_t *tgap;
+  double *prior;
+  int64_t K, T, ldT, nWorkers;
+};
+
+// `top` (optional): the call that follows RecordAnswer in every quiz loop is ListTopTargets (PqaClient.cpp:185, the website,
+// DichotomyTest.cpp:91), and a dependent launch costs ~8 us of dispatch whatever its size -- so the new posterior's top
+// targets are listed here, into host-coherent memory, and ListTopTargets finds them waiting.
+struct TopRequest {
+  TopOut *out;
+  int64_t *nOut;
+  uint64_t *flag;
+  uint64_t flagValue;
+  int64_t count;       // 0: no listing
+};
+
+// COH: the caller is the resident kernel -- the old posterior may have been written by a kernel on another XCD (read past the
+// non-coherent cache levels), and the new one must reach memory before the sweep's workgroups on other XCDs read it.
+template <bool SMALL, bool COH>
+__device__ __forceinline__ void record_answer_body(PriorArgs a, int64_t iQuestion, int64_t iAnswer, uint32_t *asked, TopRequest top,
+                                                   double *lds, TopScratch *topScratch) {
+  // CEQuiz::RecordAnswer marks the question as asked (PqaCore/CEQuiz.h:92); done here, in stream order with the sweeps
+  // that read the bitmap, so that the host call needs neither a copy nor a synchronisation
+  if (threadIdx.x == 0) {
+    const uint32_t w = COH ? __hip_atomic_load(asked + (iQuestion >> 5), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : asked[iQuestion >> 5];
+    asked[iQuestion >> 5] = w | (1u << (iQuestion & 31));
+  }
+  const int64_t nVects = (a.T + 3) >> 2;
+  const double *rowA = a.cube + (iQuestion * (a.K + 1) + iAnswer) * a.ldT;  // CERecordAnswerSubtaskMul.cpp:25
+  const double *rowD = a.cube + (iQuestion * (a.K + 1) + a.K) * a.ldT;      // :26
+  for (int64_t t = threadIdx.x; t < a.ldT; t += blockDim.x) {
+    const double pQaGivenT = rowA[t] / rowD[t];                // :31
+    const double old = COH ? __hip_atomic_load(a.prior + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : a.prior[t];
+    const double product = old * pQaGivenT;                    // :34
+    a.prior[t] = bit_test(a.tgap, t) ? 0.0 : product;          // :35-37
+  }
+  const double total = reference_order_sum(a.prior, nVects, a.nWorkers, lds);
+  for (int64_t t = threadIdx.x; t < 4 * nVects; t += blockDim.x) a.prior[t] = a.prior[t] / total;
+  if constexpr (COH) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");   // posterior and asked bit out of this XCD's L2
+  if (top.count > 0) {
+    __syncthreads();  // (a thread lists exactly the targets it has just written; the barrier is for the shared LDS rows)
+    top_targets_publish<SMALL>(a.prior, a.tgap, a.T, top.count, top.out, top.nOut, top.flag, top.flagValue, topScratch);
+  }
+}
+
+}  // namespace pqa

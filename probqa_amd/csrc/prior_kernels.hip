@@ -16,6 +16,7 @@
 // (subtask, AVX-lane) chain.
 #include "pqa_device.h"
 #include "pqa_kernels.h"
+#include "prior_device.h"
 
 namespace pqa {
 
@@ -28,58 +29,6 @@ constexpr int kThreads = 1024;
 constexpr int kSmallThreads = 256;
 static inline bool small_launch(const KbView &kb) { return kb.smallLaunches && kb.T <= 4 * kSmallThreads; }
 
-__device__ __forceinline__ int64_t split_bound(int64_t i, int64_t quot, int64_t rem) {  // end of subtask i
-  const int64_t n1 = (i + 1 < rem) ? (i + 1) : rem;
-  return (i + 1) * quot + n1;
-}
-
-// Sum v[0 .. 4*nVects) exactly as the CPU engine does and return the total to every thread.
-// lds: 8*nSubtasks + 1 doubles.  Must be called by all threads; contains barriers.
-__device__ double reference_order_sum(const double *__restrict__ v, int64_t nVects, int64_t nWorkers, double *lds) {
-  const int64_t quot = nVects / nWorkers, rem = nVects % nWorkers;
-  const int64_t nSubtasks = (quot == 0) ? rem : nWorkers;
-  __syncthreads();  // v was written by other threads of this workgroup
-  for (int64_t ch = threadIdx.x; ch < nSubtasks * 4; ch += blockDim.x) {
-    const int64_t s = ch >> 2;
-    const int c = (int)(ch & 3);
-    const int64_t first = (s == 0) ? 0 : split_bound(s - 1, quot, rem), limit = split_bound(s, quot, rem);
-    double sum = 0, corr = 0;  // SRAccumVectDbl256::Add, SRPlatform/Interface/SRAccumVectDbl256.h:40-46
-    for (int64_t j = first; j < limit; j++) {
-      const double y = v[4 * j + c] - corr;
-      const double t = sum + y;
-      corr = (t - sum) - y;
-      sum = t;
-    }
-    lds[8 * s + c] = sum;
-    lds[8 * s + 4 + c] = corr;
-  }
-  __syncthreads();
-  // PreciseSum of each subtask's four lanes in parallel (one subtask per thread; the result replaces the subtask's first
-  // slot), then the serial Kahan over the subtasks in order: the same operations in the same order as one thread doing
-  // both, 1.4 us sooner at 16 workers
-  for (int64_t s2 = threadIdx.x; s2 < nSubtasks; s2 += blockDim.x) {
-    const double ps = precise_sum4(lds + 8 * s2, lds + 8 * s2 + 4);
-    lds[8 * s2] = ps;
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    Kahan1 acc;  // Summator::ForPriors, PqaCore/Summator.h:14-19
-    acc.init(0.0);
-    for (int64_t s2 = 0; s2 < nSubtasks; s2++) acc.add(lds[8 * s2]);
-    lds[8 * nSubtasks] = acc.get();
-  }
-  __syncthreads();
-  return lds[8 * nSubtasks];
-}
-
-struct PriorArgs {
-  const double *cube;
-  const double *vB;
-  const uint32_t *tgap;
-  double *prior;
-  int64_t K, T, ldT, nWorkers;
-};
-
 __global__ __launch_bounds__(kThreads) void start_quiz_kernel(PriorArgs a) {
   extern __shared__ double lds[];
   const int64_t nVects = (a.T + 3) >> 2;
@@ -89,38 +38,12 @@ __global__ __launch_bounds__(kThreads) void start_quiz_kernel(PriorArgs a) {
   for (int64_t t = threadIdx.x; t < 4 * nVects; t += blockDim.x) a.prior[t] = a.prior[t] / total;  // CEDivTargPriors :19
 }
 
-// `top` (optional): the call that follows RecordAnswer in every quiz loop is ListTopTargets (PqaClient.cpp:185, the website,
-// DichotomyTest.cpp:91), and a dependent launch costs ~8 us of dispatch whatever its size -- so the new posterior's top
-// targets are listed here, into host-coherent memory, and ListTopTargets finds them waiting.
-struct TopRequest {
-  TopOut *out;
-  int64_t *nOut;
-  uint64_t *flag;
-  uint64_t flagValue;
-  int64_t count;       // 0: no listing
-};
-
 template <bool SMALL>
 __global__ __launch_bounds__(SMALL ? kSmallThreads : kThreads) void record_answer_kernel(PriorArgs a, int64_t iQuestion, int64_t iAnswer,
                                                                                          uint32_t *asked, TopRequest top) {
   extern __shared__ double lds[];
-  // CEQuiz::RecordAnswer marks the question as asked (PqaCore/CEQuiz.h:92); done here, in stream order with the sweeps
-  // that read the bitmap, so that the host call needs neither a copy nor a synchronisation
-  if (threadIdx.x == 0) asked[iQuestion >> 5] |= 1u << (iQuestion & 31);
-  const int64_t nVects = (a.T + 3) >> 2;
-  const double *rowA = a.cube + (iQuestion * (a.K + 1) + iAnswer) * a.ldT;  // CERecordAnswerSubtaskMul.cpp:25
-  const double *rowD = a.cube + (iQuestion * (a.K + 1) + a.K) * a.ldT;      // :26
-  for (int64_t t = threadIdx.x; t < a.ldT; t += blockDim.x) {
-    const double pQaGivenT = rowA[t] / rowD[t];                // :31
-    const double product = a.prior[t] * pQaGivenT;             // :34
-    a.prior[t] = bit_test(a.tgap, t) ? 0.0 : product;          // :35-37
-  }
-  const double total = reference_order_sum(a.prior, nVects, a.nWorkers, lds);
-  for (int64_t t = threadIdx.x; t < 4 * nVects; t += blockDim.x) a.prior[t] = a.prior[t] / total;
-  if (top.count > 0) {
-    __syncthreads();  // (a thread lists exactly the targets it has just written; the barrier is for the shared LDS rows)
-    top_targets_publish<SMALL>(a.prior, a.tgap, a.T, top.count, top.out, top.nOut, top.flag, top.flagValue);
-  }
+  __shared__ TopScratch topScratch;
+  record_answer_body<SMALL, false>(a, iQuestion, iAnswer, asked, top, lds, &topScratch);
 }
 
 __device__ __forceinline__ int ceil_log2_u64(uint64_t val) {  // SRPlatform/Interface/SRMath.h:46-51
