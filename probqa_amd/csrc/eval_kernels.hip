@@ -320,9 +320,10 @@ __host__ __device__ constexpr size_t eval_lds_doubles(int wpq, int64_t K, bool p
 // Shapes of up to 8 waves keep the lanes' partial sums of a question -- K velocity sums, the entropy sum, the
 // lack sum -- in LDS ((K + 2) x threads doubles behind the mD landing row / the LDS priors) and reduce them once per question, all waves
 // together, instead of one wave butterfly per sum and row: 18 VALU instructions per row and wave become one ds_write.
-// (Not the two 4-pair shapes: the change costs them four registers, which takes them from 165 / 167 to 169 and from three
-// waves per SIMD to two -- 41 instead of 37 us at 2000 targets.)
-__host__ __device__ constexpr bool eval_defers_sums(int wpq, int np, bool prLds) { return wpq <= 8 && np != 4; }
+// (It costs four registers, which takes the two 4-pair shapes from 165 / 167 to 169 and from three waves per SIMD to two --
+// 41 instead of 37 us at 2000 targets: wg256_np4's kernel is held to three waves, eval_questions_f64_occ3 (35.7 us).  The
+// two-wave wg128_np4, the shape of batched launches, keeps the per-row butterflies: 92 k vs 84 k selections/s deferred.)
+__host__ __device__ constexpr bool eval_defers_sums(int wpq, int np, bool prLds) { return wpq <= 8 && !(wpq == 2 && np == 4); }
 __host__ __device__ constexpr size_t eval_deferred_bytes(int wpq, int np, int64_t K, bool prLds) {
   return eval_defers_sums(wpq, np, prLds) ? (size_t)(K + 2) * wpq * kWave * sizeof(double) : 0;
 }
@@ -654,6 +655,13 @@ __global__ __launch_bounds__(WPQ * 64) void eval_questions_f64(EvalArgs a) {
   select_quiz(a);
   sweep_body<WPQ, NP, PRLDS, false, DEFER>(a, true);
 }
+// The same kernel held to three waves per SIMD (168 VGPRs): the two 4-pair shapes need 169 with the deferred sums, and a
+// register spilled costs them less than a wave of occupancy does.
+template <int WPQ, int NP, bool PRLDS, bool DEFER>
+__global__ __launch_bounds__(WPQ * 64) __attribute__((amdgpu_waves_per_eu(3, 3))) void eval_questions_f64_occ3(EvalArgs a) {
+  select_quiz(a);
+  sweep_body<WPQ, NP, PRLDS, false, DEFER>(a, true);
+}
 
 // ------------------------------------------------------------------------------------------------------------------
 // Resident form of the sweep (pqa_kernels.h: ServerMailbox).  Control flow around the steps is wave-uniform by
@@ -953,7 +961,10 @@ constexpr size_t eval_base_lds_bytes(int64_t K, int64_t ldT) {
 template <int WPQ, int NP, bool PRLDS, bool DEFER>
 hipError_t launch_reg_form(const EvalArgs &args, int64_t nQ, int nBatch, hipStream_t stream) {
   const size_t shmem = eval_base_lds_bytes<WPQ, NP, PRLDS>(args.K, args.ldT) + (DEFER ? eval_deferred_bytes(WPQ, NP, args.K, PRLDS) : 0);
-  auto kern = eval_questions_f64<WPQ, NP, PRLDS, DEFER>;
+  auto kern = [] {
+    if constexpr (NP == 4 && WPQ <= 4 && DEFER) return eval_questions_f64_occ3<WPQ, NP, PRLDS, DEFER>;
+    else return eval_questions_f64<WPQ, NP, PRLDS, DEFER>;
+  }();
   // attribute and occupancy are properties of (kernel, LDS size): asked once, not on every launch (the engine serialises
   // launches; a race between two engines would only repeat the query)
   static size_t cachedShmem = ~(size_t)0;
