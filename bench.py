@@ -31,6 +31,8 @@ CONFIGS = {
     "M8": dict(Q=8000, K=5, T=8000, name="8000Qx5Ax8000T"),
     "M9": dict(Q=9000, K=5, T=9000, name="9000Qx5Ax9000T"),
     "T2": dict(Q=2000, K=5, T=2000, name="2000Qx5Ax2000T"),
+    "T25": dict(Q=2500, K=5, T=2500, name="2500Qx5Ax2500T"),
+    "T3": dict(Q=3000, K=5, T=3000, name="3000Qx5Ax3000T"),
     "T4": dict(Q=4000, K=5, T=4000, name="4000Qx5Ax4000T"),
     "T5": dict(Q=5000, K=5, T=5000, name="5000Qx5Ax5000T"),
 }

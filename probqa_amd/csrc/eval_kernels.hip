@@ -962,7 +962,7 @@ template <int WPQ, int NP, bool PRLDS, bool DEFER>
 hipError_t launch_reg_form(const EvalArgs &args, int64_t nQ, int nBatch, hipStream_t stream) {
   const size_t shmem = eval_base_lds_bytes<WPQ, NP, PRLDS>(args.K, args.ldT) + (DEFER ? eval_deferred_bytes(WPQ, NP, args.K, PRLDS) : 0);
   auto kern = [] {
-    if constexpr (NP == 4 && WPQ <= 4 && DEFER) return eval_questions_f64_occ3<WPQ, NP, PRLDS, DEFER>;
+    if constexpr (NP == 4 && WPQ == 4 && DEFER) return eval_questions_f64_occ3<WPQ, NP, PRLDS, DEFER>;   // (5 and 6 pairs: slower with the spills)
     else return eval_questions_f64<WPQ, NP, PRLDS, DEFER>;
   }();
   // attribute and occupancy are properties of (kernel, LDS size): asked once, not on every launch (the engine serialises
