@@ -191,9 +191,10 @@ def main():
 
     # The resident sweep (engine option "server": one launch serves many selections, csrc/eval_kernels.hip) where the
     # engine has one for the cube's shape; the launch-per-selection rate of the same call is reported beside it.
-    if not args.no_server:
+    uses_collective = selector is not None and args.exchange == "rccl"   # (that path enqueues launches on the stream)
+    if not args.no_server and not uses_collective:
         eng.set_option("server", 1)
-    resident = bool(eng.get_option("server_active") == 1)
+    resident = bool(eng.get_option("server_active") == 1) and not uses_collective
     elapsed, sel = timed(step, args.warmup, args.steps)
     value = args.steps / elapsed
 
