@@ -297,7 +297,8 @@ __device__ __forceinline__ void dma16(dma_rsrc_t rsrc, unsigned byteOffset, unsi
 // memory pipe never idles at a row or question boundary.
 //
 // LDS (doubles): log2 table [2048] | W exchange [2][WPQ] | partials [2][K+2][WPQ] | pending [kPend][2K+3] |
-//                running argmax [64][2] | prior [ldT + 2] if PRLDS
+//                running argmax [64][2] | prior [ldT + 2] if PRLDS, else (KiB-aligned) the mD landing row [NP*64*WPQ pairs] |
+//                deferred lane sums [K+2][64*WPQ] (eval_defers_sums) | the resident kernel's request line [8]
 //   partial rows: V_k (K rows), sum W_k*H_k (1 row), lack (1 row); the leading [2] alternates per question.
 //   pending: per finished question W_k[K], V_k[K], sum WH, lack, question index.  The scalar epilogue (exp2, log,
 //   divisions: ~1 us of dependent fp64 code) is not run per question by one lane while 511 wait at the next barrier;
