@@ -34,6 +34,7 @@ CONFIGS = {
     "T25": dict(Q=2500, K=5, T=2500, name="2500Qx5Ax2500T"),
     "T3": dict(Q=3000, K=5, T=3000, name="3000Qx5Ax3000T"),
     "T4": dict(Q=4000, K=5, T=4000, name="4000Qx5Ax4000T"),
+    "T45": dict(Q=4500, K=5, T=4500, name="4500Qx5Ax4500T"),
     "T5": dict(Q=5000, K=5, T=5000, name="5000Qx5Ax5000T"),
 }
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec

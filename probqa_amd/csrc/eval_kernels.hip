@@ -927,7 +927,9 @@ const Variant kVariants[] = {
     {10, 8, 10, true, "wg512_np10_prlds"},     {11, 16, 5, false, "wg1024_np5"}, {12, 8, 10, false, "wg512_np10"},
     {13, 4, 3, false, "wg256_np3"},            {14, 4, 5, false, "wg256_np5"},  {15, 4, 6, false, "wg256_np6"},
     {16, 8, 6, false, "wg512_np6"},            {17, 8, 7, false, "wg512_np7"},  {18, 8, 8, false, "wg512_np8"},
-    {19, 8, 9, false, "wg512_np9"},            {99, 4, 0, false, "stream256"},
+    {19, 8, 9, false, "wg512_np9"},            {20, 4, 10, true, "wg256_np10_prlds"}, {21, 4, 10, false, "wg256_np10"},
+    {22, 4, 6, true, "wg256_np6_prlds"},       {23, 4, 8, true, "wg256_np8_prlds"}, {24, 4, 9, true, "wg256_np9_prlds"},
+    {99, 4, 0, false, "stream256"},
 };
 
 // Default shape: the smallest capacity that holds a row (idle lanes are pure loss: at 8000 targets the np10 shape wastes a
@@ -940,7 +942,10 @@ int pick_variant(int64_t ldT, int variant) {
   if (ldT <= 2560) return 14;
   if (ldT <= 3072) return 15;
   if (ldT <= 4096) return 4;
-  if (ldT <= 5120) return 9;
+  // 4097..5120 targets: four waves of 9 / 10 pairs per lane with the priors in LDS, not eight waves of 5 -- half as many waves
+  // at the row barrier and half as many wave reductions per element (194 vs 218 us at 4500 targets, 234 vs 250 at 5000)
+  if (ldT <= 4608) return 24;
+  if (ldT <= 5120) return 20;
   if (ldT <= 6144) return 16;
   if (ldT <= 7168) return 17;
   if (ldT <= 8192) return 18;
@@ -1037,6 +1042,11 @@ hipError_t launch_variant(const EvalArgs &args, int64_t ldT, int variant, int nB
     case 17: return launch_reg<8, 7, false>(args, nQ, nBatch, stream);
     case 18: return launch_reg<8, 8, false>(args, nQ, nBatch, stream);
     case 19: return launch_reg<8, 9, false>(args, nQ, nBatch, stream);
+    case 20: return launch_reg<4, 10, true>(args, nQ, nBatch, stream);
+    case 21: return launch_reg<4, 10, false>(args, nQ, nBatch, stream);
+    case 22: return launch_reg<4, 6, true>(args, nQ, nBatch, stream);
+    case 23: return launch_reg<4, 8, true>(args, nQ, nBatch, stream);
+    case 24: return launch_reg<4, 9, true>(args, nQ, nBatch, stream);
     case 99: {
       const size_t shmem = eval_lds_doubles(4, args.K, false, 0) * sizeof(double);
       int64_t maxBlocks = 256 * 8;

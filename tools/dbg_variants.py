@@ -7,7 +7,7 @@ for T in (1000, 1500, 2500, 3000, 4000, 5000, 6000, 7000, 8000, 9000, 10000):
     orc=case.make_oracle(); eng=case.make_engine(f)
     quiz=eng.start_quiz(); orc.start_quiz(16)
     _,opri=orc.eval(128)
-    for v in (1,2,3,4,5,6,7,8,9,10,11,12,13,14,15,16,17,18,19,99):
+    for v in tuple(range(1, 25)) + (99,):
         eng.set_option("eval_variant", v)
         try:
             pri=eng.eval_priorities(quiz)
