@@ -28,6 +28,8 @@ sys.path.insert(0, ROOT)
 CONFIGS = {
     "S": dict(Q=1000, K=5, T=1000, name="1000Qx5Ax1000T"),
     "M": dict(Q=10000, K=5, T=10000, name="10000Qx5Ax10000T"),
+    "T6": dict(Q=6000, K=5, T=6000, name="6000Qx5Ax6000T"),
+    "T7": dict(Q=7000, K=5, T=7000, name="7000Qx5Ax7000T"),
     "M8": dict(Q=8000, K=5, T=8000, name="8000Qx5Ax8000T"),
     "M9": dict(Q=9000, K=5, T=9000, name="9000Qx5Ax9000T"),
     "T2": dict(Q=2000, K=5, T=2000, name="2000Qx5Ax2000T"),
