@@ -79,6 +79,26 @@ __global__ __launch_bounds__(1024) void select_sampled_kernel(const double *__re
   }
 }
 
+// The same selection with priorities, run lengths and totals staged in LDS (select_sampled_wg_lds): every global load of the
+// kernel is issued in one parallel round instead of one per item of a subtask's dependent chain.  For question counts whose
+// staging fits 64 KiB.
+__global__ __launch_bounds__(256) void select_sampled_lds_kernel(const double *__restrict__ priority,
+                                                                 const uint32_t *__restrict__ qgap,
+                                                                 const uint32_t *__restrict__ asked, int64_t qFirst, int64_t n,
+                                                                 int64_t nWorkers, uint64_t rnd, SelectResult *out, uint64_t *flag,
+                                                                 uint64_t flagValue) {
+  extern __shared__ double lds[];
+  const SampledPick r = select_sampled_wg_lds<false>(priority, qgap, asked, qFirst, n, nWorkers, rnd, lds);
+  if (threadIdx.x == 0) {
+    out->priority = r.priority;
+    out->index = r.index;
+    if (flag != nullptr) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+      __hip_atomic_store(flag, flagValue, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+}
+
 }  // namespace
 
 hipError_t LaunchSelectArgmax(const double *priority, const uint32_t *qgap, const uint32_t *asked, int64_t qFirst,
@@ -93,6 +113,12 @@ hipError_t LaunchSelectSampled(const double *priority, const uint32_t *qgap, con
                                int64_t n, int64_t nSubtasks, uint64_t rnd, double *runLength, SelectResult *out,
                                uint64_t *flag, uint64_t flagValue, hipStream_t stream) {
   if (n <= 0 || nSubtasks <= 0) return hipErrorInvalidValue;
+  const size_t staged = (size_t)select_sampled_lds_doubles(n, nSubtasks) * sizeof(double);
+  if (staged <= 64 * 1024) {
+    hipLaunchKernelGGL(select_sampled_lds_kernel, dim3(1), dim3(256), staged, stream, priority, qgap, asked, qFirst, n, nSubtasks,
+                       rnd, out, flag, flagValue);
+    return hipGetLastError();
+  }
   const size_t shmem = (size_t)nSubtasks * sizeof(double);
   if (shmem > 64 * 1024) return hipErrorInvalidValue;
   hipLaunchKernelGGL(select_sampled_kernel, dim3(1), dim3(1024), shmem, stream, priority, qgap, asked, qFirst, n, nSubtasks,
