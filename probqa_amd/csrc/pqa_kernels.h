@@ -76,6 +76,7 @@ hipError_t LaunchEvalQuestions(const KbView &kb, const double *prior, const uint
 hipError_t LaunchEvalQuestionsBatch(const KbView &kb, const QuizSlot *slots, int nSlots, int64_t qFirst, int64_t qLimit,
                                     int variant, const FusedSelect &fused, hipStream_t stream);
 const char *EvalVariantName(const KbView &kb, int variant);
+void SetEvalMaxGrid(int n);   // test hook: cap the workgroups of a sweep (0 = no cap), process-wide
 bool EvalVariantFusesSampled(const KbView &kb, int variant, int64_t nSubtasks);   // the launch can run the sampled selector itself
 
 // ---- resident sweep ("server"): ONE launch serves many selections.  The host posts a request in pinned memory; workgroup
