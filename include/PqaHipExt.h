@@ -44,7 +44,8 @@ PQACORE_API void *PqaEngineFactory_CreateHipEngineSharded(void *pvFactory, void 
  * (argmax selections are served by a resident kernel instead of one launch each -- rows up to 1024 targets; default 0),
  * "server_idle_us" (that kernel leaves after this long without a request, default 2000), "server_vram_mailbox" (requests
  * are written to host-visible device memory where the platform maps it, default 1; set before the first selection).
- * "fused_sampled" (the sampled NextQuestion as one launch instead of sweep + selector; default 0: measured slower).
+ * "fused_sampled" (the sampled NextQuestion as one launch instead of sweep + selector; default 0: measured slower),
+ * "eval_max_grid" (test hook: cap the workgroups of a sweep so that each streams many questions; 0 = no cap).
  * Read-only: "server_active",
  * "ldT", "device". */
 PQACORE_API void *PqaHip_SetOption(void *pvEngine, const char *name, int64_t value);

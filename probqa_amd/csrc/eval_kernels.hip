@@ -40,6 +40,7 @@ struct EvalArgs {
   double vCompTail;  // ln(sqrt 2) / (nValidTargets + 1)^2, PqaCore/CEEvalQsSubtaskConsider.cpp:191
   FusedSelect fs;
   const QuizSlot *slots;  // batched launch: per-quiz pointers, indexed by blockIdx.y (nullptr: a single quiz)
+  int maxGrid;            // host side only: KbView::maxGrid
 };
 
 // batched launch: this workgroup's quiz replaces the per-quiz fields of the arguments
@@ -956,9 +957,6 @@ int pick_variant(int64_t ldT, int variant) {
 }
 
 int gNumCUs = 0;
-// Test hook (engine option "eval_max_grid"): cap the number of workgroups of a sweep, so that a small cube makes every
-// workgroup stream dozens of questions -- the path that only thousand-question cubes reach otherwise.  0: no cap.
-int gEvalMaxGrid = 0;
 
 constexpr size_t kLdsPerCU = 160 * 1024;   // gfx950
 template <int WPQ, int NP, bool PRLDS>
@@ -1000,7 +998,7 @@ hipError_t launch_reg_form(const EvalArgs &args, int64_t nQ, int nBatch, hipStre
   int64_t resGrid = nQ < resident ? nQ : resident;
   const int64_t maxRecords = args.slots != nullptr ? args.fs.scratchStride : kFusedMaxGrid;
   if (args.fs.scratch != nullptr && resGrid > maxRecords) resGrid = maxRecords;  // one winner record per workgroup
-  if (gEvalMaxGrid > 0 && resGrid > gEvalMaxGrid) resGrid = gEvalMaxGrid;
+  if (args.maxGrid > 0 && resGrid > args.maxGrid) resGrid = args.maxGrid;   // (test hook: KbView::maxGrid)
   hipLaunchKernelGGL(kern, dim3((unsigned)resGrid, (unsigned)nBatch), dim3(WPQ * 64), shmem, stream, args);
   return hipGetLastError();
 }
@@ -1055,7 +1053,7 @@ hipError_t launch_variant(const EvalArgs &args, int64_t ldT, int variant, int nB
       const size_t shmem = eval_lds_doubles(4, args.K, false, 0) * sizeof(double);
       int64_t maxBlocks = 256 * 8;
       if (args.slots != nullptr && maxBlocks > args.fs.scratchStride) maxBlocks = args.fs.scratchStride;
-      if (gEvalMaxGrid > 0 && maxBlocks > gEvalMaxGrid) maxBlocks = gEvalMaxGrid;
+      if (args.maxGrid > 0 && maxBlocks > args.maxGrid) maxBlocks = args.maxGrid;
       const unsigned grid = (unsigned)(nQ < maxBlocks ? nQ : maxBlocks);
       hipLaunchKernelGGL(eval_questions_f64_stream, dim3(grid, (unsigned)nBatch), dim3(256), shmem, stream, args);
       return hipGetLastError();
@@ -1065,8 +1063,6 @@ hipError_t launch_variant(const EvalArgs &args, int64_t ldT, int variant, int nB
 }
 
 }  // namespace
-
-void SetEvalMaxGrid(int n) { gEvalMaxGrid = n > 0 ? n : 0; }
 
 const char *EvalVariantName(const KbView &kb, int variant) {
   const int v = pick_variant(kb.ldT, variant);
@@ -1088,6 +1084,7 @@ static EvalArgs make_args(const KbView &kb, int64_t qFirst, int64_t qLimit) {
   args.vCompTail = 0.34657359027997265470861606072909 / (nT * nT);
   args.fs = FusedSelect{nullptr, nullptr, nullptr, 0, 0, 0, 0, nullptr, 0, 0, nullptr};
   args.slots = nullptr;
+  args.maxGrid = kb.maxGrid;
   return args;
 }
 
@@ -1140,7 +1137,7 @@ static hipError_t launch_server_form(const EvalArgs &args, ServerMailbox *mb, vo
   const int64_t nQ = args.qLimit - args.qFirst, resident = (int64_t)gNumCUs * cachedPerCU;
   int64_t grid = nQ < resident ? nQ : resident;
   if (grid > kFusedMaxGrid) grid = kFusedMaxGrid;
-  if (gEvalMaxGrid > 0 && grid > gEvalMaxGrid) grid = gEvalMaxGrid;
+  if (args.maxGrid > 0 && grid > args.maxGrid) grid = args.maxGrid;
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(WPQ * 64), shmem, stream, args, mb, reinterpret_cast<uint32_t *>(requestLine),
                      everyonePolls ? 1 : 0, ctl, lastSeq, idleTicks, (unsigned)stepOffset);
   return hipGetLastError();

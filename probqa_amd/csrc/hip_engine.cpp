@@ -239,6 +239,7 @@ KbView HipEngine::View() const {
   v.K = _K; v.Q = _Q; v.T = _T; v.ldT = _ldT;
   v.nValidTargets = _T - _nTargetGaps;
   v.smallLaunches = _optServer ? 1 : 0;
+  v.maxGrid = (int)_optEvalMaxGrid;
   return v;
 }
 
@@ -256,7 +257,7 @@ Error HipEngine::SetOption(const char *name, int64_t value) {
   else if (n == "use_graph") { _optUseGraph = value ? 1 : 0; }
   else if (n == "top_cache") { if (value < 0 || value > 256) goto bad; _optTopCache = value; }
   else if (n == "server") { if (!value) StopServer(); _optServer = value ? 1 : 0; }
-  else if (n == "eval_max_grid") { if (value < 0 || value > 65535) goto bad; StopServer(); SetEvalMaxGrid((int)value); }
+  else if (n == "eval_max_grid") { if (value < 0 || value > 65535) goto bad; StopServer(); _optEvalMaxGrid = value; _kbVersion++; }
   else if (n == "fused_sampled") { _optFusedSampled = value ? 1 : 0; }
   else if (n == "server_vram_mailbox") { if (_serverStream) goto bad; _optServerVramMailbox = value ? 1 : 0; }
   else if (n == "server_idle_us") { if (value < 10 || value > 1000000) goto bad; StopServer(); _optServerIdleUs = value; }

@@ -237,6 +237,7 @@ class HipEngine {
   int64_t _optSelect = 0, _optWorkers = 16, _optEvalSubtasks = 0, _optEvalVariant = 0, _optBugCompat = 0;
   int64_t _optFusedSampled = 0;   // the sampled NextQuestion as ONE launch (the sweep's finisher workgroup runs the selector): correct,
                                   // but 38.3 vs 36.4 us at 1000 x 5 x 1000 -- one workgroup's serial selection costs more than a launch
+  int64_t _optEvalMaxGrid = 0;    // test hook: KbView::maxGrid
   int64_t _optUseGraph = 0;   // NextQuestion (argmax) replays a per-quiz HIP graph instead of launching
   int64_t _optTopCache = 10;  // targets RecordAnswer's kernel lists ahead of the ListTopTargets that follows it (0: none)
   // ---- resident sweep (option "server"; pqa_kernels.h: ServerMailbox)

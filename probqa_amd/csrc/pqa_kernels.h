@@ -24,6 +24,8 @@ struct KbView {
   int64_t K, Q, T, ldT;
   int64_t nValidTargets;  // T - #target gaps (PqaCore/CpuEngine.cpp:352)
   int smallLaunches;      // the engine runs the resident sweep: posterior kernels over <= 1024 targets use 256 threads
+  int maxGrid;            // test hook (engine option "eval_max_grid"): cap the workgroups of a sweep, so that a small cube makes
+                          // every workgroup stream dozens of questions; 0 = no cap
 };
 
 struct SelectResult {     // 16 bytes, written by the select kernels
@@ -76,7 +78,6 @@ hipError_t LaunchEvalQuestions(const KbView &kb, const double *prior, const uint
 hipError_t LaunchEvalQuestionsBatch(const KbView &kb, const QuizSlot *slots, int nSlots, int64_t qFirst, int64_t qLimit,
                                     int variant, const FusedSelect &fused, hipStream_t stream);
 const char *EvalVariantName(const KbView &kb, int variant);
-void SetEvalMaxGrid(int n);   // test hook: cap the workgroups of a sweep (0 = no cap), process-wide
 bool EvalVariantFusesSampled(const KbView &kb, int variant, int64_t nSubtasks);   // the launch can run the sampled selector itself
 
 // ---- resident sweep ("server"): ONE launch serves many selections.  The host posts a request in pinned memory; workgroup

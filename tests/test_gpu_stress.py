@@ -37,8 +37,9 @@ class Shadow:
         return [(t, p[t]) for t in order]
 
 
-@pytest.mark.parametrize("seed", [1, 2, 3])
-def test_random_interleaving_against_per_quiz_oracles(factory, seed):
+@pytest.mark.parametrize("seed,resident", [(1, False), (2, False), (3, False), (4, True), (5, True)],
+                         ids=["seed1", "seed2", "seed3", "seed4_resident_sweep", "seed5_resident_sweep"])
+def test_random_interleaving_against_per_quiz_oracles(factory, seed, resident):
     rng = np.random.default_rng(seed)
     kb = list(synth.synthetic_kb(K, Q, T, 0.1, 8.0, 0.5, 100 + seed))
     eng, err = factory.create_cpu_engine(interop.EngineDefinition(K, Q, T, init_amount=0.1))
@@ -46,6 +47,12 @@ def test_random_interleaving_against_per_quiz_oracles(factory, seed):
     eng.set_kb(*kb)
     eng.set_option("workers", cases.WORKERS)
     eng.set_option("select", 1)
+    if resident:
+        # plain selections through the resident kernel (stopped and restarted by the launches, the training and the idle
+        # time in between), five workgroups streaming the questions
+        eng.set_option("server", 1)
+        eng.set_option("server_idle_us", 300)
+        eng.set_option("eval_max_grid", 5)
     live = {}          # quiz id -> Shadow
     pending = {}       # quiz id -> question handed out and not yet answered
     for step in range(260):
