@@ -34,5 +34,14 @@ def random_case(i):
 @pytest.mark.parametrize("i", range(120))
 def test_random_case(i, factory):
     case = random_case(i)
-    worst = max(run_script(case, factory))
+    # every third case: two workgroups stream the questions (instead of one question per workgroup), every fifth through
+    # the fused form of the sampled selector, every seventh with the resident sweep where its shape exists
+    options = []
+    if i % 3 == 0:
+        options.append(("eval_max_grid", 2))
+    if i % 5 == 0:
+        options.append(("fused_sampled", 1))
+    if i % 7 == 0:
+        options.append(("server", 1))
+    worst = max(run_script(case, factory, options))
     assert worst < 1e-9, (case.name, worst)
