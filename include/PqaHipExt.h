@@ -98,6 +98,12 @@ PQACORE_API void *PqaHip_HostUnregister(void *pHost);
  * equal flagValue, then the exact global pick (max priority, lowest index on ties, NaN never wins, -1 if none). */
 PQACORE_API void *PqaHip_PickWhenAll(const void *pSlots, const int64_t world, const int64_t strideBytes,
                                      const uint64_t flagValue, const double timeoutSec, double *pPriority, int64_t *pIndex);
+/* The two calls above as one step: this shard's selection goes to slot `rank` (pSlotsDev = the device-visible address of
+ * pSlots), then the pick over all `world` slots. */
+PQACORE_API void *PqaHip_SelectThroughSlots(void *pvEngine, const int64_t iQuiz, const void *pSlots, void *pSlotsDev,
+                                            const int64_t rank, const int64_t world, const int64_t strideBytes,
+                                            const uint64_t flagValue, const double timeoutSec, double *pPriority,
+                                            int64_t *pIndex);
 /* Enqueue only the sweep (dominant kernel), for kernel timing. */
 PQACORE_API void *PqaHip_EnqueueEval(void *pvEngine, const int64_t iQuiz);
 /* Device pointer of the quiz's prior vector (ldT doubles, *pLdT receives ldT) for collectives between shards.  The engine

@@ -422,6 +422,20 @@ PQACORE_API void *PqaHip_PickWhenAll(const void *pSlots, const int64_t world, co
   *pIndex = bestI;
   return nullptr;
 }
+// One step of the shared-memory exchange in one call: enqueue this shard's selection with its record and flag in slot `rank`
+// of the host's slot array (pSlotsDev: the device-visible address of the same array), then wait for every rank and pick.
+PQACORE_API void *PqaHip_SelectThroughSlots(void *pvEngine, const int64_t iQuiz, const void *pSlots, void *pSlotsDev,
+                                            const int64_t rank, const int64_t world, const int64_t strideBytes,
+                                            const uint64_t flagValue, const double timeoutSec, double *pPriority,
+                                            int64_t *pIndex) {
+  GET_ENGINE_OR_RET_ERR;
+  if (!pSlots || !pSlotsDev || rank < 0 || rank >= world || strideBytes < 24)
+    return ReturnErr(Error::Make(ErrCode::NullArgument, "Bad arguments to PqaHip_SelectThroughSlots."));
+  char *mine = (char *)pSlotsDev + rank * strideBytes;
+  Error e = pEng->EnqueueSelectArgmaxFlag(iQuiz, mine, mine + 16, flagValue);
+  if (!e.ok()) return ReturnErr(std::move(e));
+  return PqaHip_PickWhenAll(pSlots, world, strideBytes, flagValue, timeoutSec, pPriority, pIndex);
+}
 PQACORE_API void *PqaHip_EnqueueSelectArgmax(void *pvEngine, const int64_t iQuiz, void *pOut) {
   GET_ENGINE_OR_RET_ERR;
   return ReturnErr(pEng->EnqueueSelectArgmax(iQuiz, pOut));

@@ -140,9 +140,9 @@ class ShmSelector:
     def select(self) -> Tuple[float, int]:
         self.step += 1
         half = (self.step & 1) * self.world * self.SLOT
-        mine = self._dev + half + self.rank * self.SLOT
-        self.engine.enqueue_select_argmax_flag(self.quiz, mine, mine + 16, self.step)
-        return self._interop.pick_when_all(self._host + half, self.world, self.SLOT, self.step)
+        # (one call into the library: enqueue with this rank's slot as the destination, then the pick over all slots)
+        return self.engine.select_through_slots(self.quiz, self._host + half, self._dev + half, self.rank, self.world, self.SLOT,
+                                                self.step)
 
     def close(self) -> None:
         import os

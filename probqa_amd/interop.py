@@ -136,6 +136,7 @@ HIP_EXPORTS = {
     "PqaHip_HostRegister": (_vp, [_vp, _i64, _pvp]),
     "PqaHip_HostUnregister": (_vp, [_vp]),
     "PqaHip_PickWhenAll": (_vp, [_vp, _i64, _i64, ctypes.c_uint64, ctypes.c_double, _pdbl, _pi64]),
+    "PqaHip_SelectThroughSlots": (_vp, [_vp, _i64, _vp, _vp, _i64, _i64, _i64, ctypes.c_uint64, ctypes.c_double, _pdbl, _pi64]),
     "PqaHip_EnqueueEval": (_vp, [_vp, _i64]),
     "PqaHip_GetPriorDevicePtr": (_vp, [_vp, _i64, _pvp, _pi64]),
     "PqaHip_RecordAnswerRemote": (_vp, [_vp, _i64, _i64]),
@@ -517,6 +518,14 @@ class PqaEngine:
     def enqueue_select_argmax_flag(self, i_quiz: int, out_dev: int, flag_dev: int, flag_value: int) -> None:
         _check(_lib.PqaHip_EnqueueSelectArgmaxFlag(self.c_engine, i_quiz, ctypes.c_void_p(out_dev),
                                                    ctypes.c_void_p(flag_dev), flag_value))
+
+    def select_through_slots(self, i_quiz: int, slots_host: int, slots_dev: int, rank: int, world: int, stride: int,
+                             flag_value: int, timeout_s: float = 30.0):
+        """One step of the shared-memory exchange (enqueue_select_argmax_flag + pick_when_all) -> (priority, index)."""
+        pri, idx = ctypes.c_double(), ctypes.c_int64()
+        _check(_lib.PqaHip_SelectThroughSlots(self.c_engine, i_quiz, ctypes.c_void_p(slots_host), ctypes.c_void_p(slots_dev),
+                                              rank, world, stride, flag_value, timeout_s, ctypes.byref(pri), ctypes.byref(idx)))
+        return pri.value, idx.value
 
     def log2hot(self, x: np.ndarray) -> np.ndarray:
         """The device's Log2Hot over an array (the per-element function of the sweep)."""
