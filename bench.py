@@ -160,15 +160,22 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def timed(fn, warmup, steps):
-        """W untimed steps, then exactly K steps between barrier + synchronize; the maximum over ranks."""
+    def timed(fn, warmup, steps, e=None):
+        """W untimed steps, then exactly K steps between barrier + synchronize; the maximum over ranks.
+        Every step is a synchronous call that has returned its result.  The engine is quiesced (PqaHip_Synchronize: its
+        stream is drained and its resident sweep kernel, if one is serving the selections, is told to leave -- a few
+        microseconds) before each device-wide synchronisation, which would otherwise sit out that kernel's idle time-out
+        (server_idle_us) inside the timed region: 2 ms, i.e. 5.5x the 20 timed steps of the driver's run in round 1."""
+        e = e or eng
         r = None
         for _ in range(warmup):
             r = fn()
+        e.synchronize()
         barrier()
         t0 = time.perf_counter()
         for _ in range(steps):
             r = fn()
+        e.synchronize()
         barrier()
         dt = time.perf_counter() - t0
         if world > 1:
@@ -300,7 +307,7 @@ def main():
     if sharded and args.config == "S":
         cm = CONFIGS["M"]
         eng_m, quiz_m, sel_m, q_local_m = make_engine(cm, "m")
-        dt_m, pick_m = timed(lambda: sel_m.select()[1], 20, 200)
+        dt_m, pick_m = timed(lambda: sel_m.select()[1], 20, 200, eng_m)
         k_ms = kernel_ms_of(eng_m, quiz_m, 20)
         bytes_m = q_local_m * (cm["K"] + 1) * cm["T"] * 8
         sharded_m = {"workload": cm["name"] + " fp64, question axis sharded over the ranks", "selections_per_sec": 200 / dt_m,
@@ -360,7 +367,16 @@ def main():
     }
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(np, cfg, args.cpu_seconds)
+        out["cpu_baseline"], cpu_argmax, cpu_margin = cpu_baseline(np, cfg, args.cpu_seconds)
+        # north_star: "with the argmax matching CpuEngine" -- the CPU port's priorities of the same cube and quiz state
+        # (after StartQuiz), its argmax (lowest index on ties) against the question the timed steps selected
+        if cpu_argmax is not None:
+            out["argmax_matches_cpu"] = int(cpu_argmax) == int(sel)
+            out["config"]["cpu_argmax"] = int(cpu_argmax)
+            out["config"]["cpu_top2_relative_margin"] = cpu_margin
+            if int(cpu_argmax) != int(sel):
+                print("bench.py: the engine selected question %d, the CPU port's argmax is %d (top-2 margin %.3g)"
+                      % (int(sel), int(cpu_argmax), cpu_margin), file=sys.stderr)
     if rank == 0:
         os.write(result_fd, (json.dumps(out) + "\n").encode())
     if selector is not None and hasattr(selector, "close"):
@@ -425,10 +441,16 @@ def cpu_baseline(np, cfg, seconds):
                     break
     except OSError:
         pass
+    cpu_argmax, cpu_margin = None, None
+    if Q == cfg["Q"]:   # the whole cube was swept: its argmax is what the engine's selection is held to
+        _, pri = orc.eval_avx2(threads)
+        cpu_argmax = orc.select_argmax(pri)
+        top = np.sort(pri)[::-1]
+        cpu_margin = float((top[0] - top[1]) / top[0]) if len(top) > 1 and top[0] > 0 else 1.0
     return {"value": sweeps, "unit": "selections/s", "cores": threads, "kind": "port",
             "sample": "%s, %d sweeps in %.1f s wall on %d threads (AVX2+FMA 4-lane Kahan port, 8*threads subtasks); "
                       "pool sizes tried: %s" % (sample, n, dt, threads, others),
-            "cpu_model": model}
+            "cpu_model": model}, cpu_argmax, cpu_margin
 
 
 if __name__ == "__main__":

@@ -1206,9 +1206,16 @@ Error HipEngine::SetStream(hipStream_t s) {
   return Error();
 }
 
+// Everything this engine has put on the device has finished when this returns -- the engine's stream AND the resident sweep
+// kernel, which is asked to leave (it is started again by the next selection).  What a caller does before a device-wide
+// synchronisation of its own: without it, hipDeviceSynchronize waits for the resident kernel's idle exit (server_idle_us).
 Error HipEngine::Synchronize() {
+  std::lock_guard<EngineMutex> lk(_mu);
   hipSetDevice(_device);
+  StopServer();
   HIP_TRY(hipStreamSynchronize(_stream));
+  _mu.busy = false;
+  _pendingRecordOp = 0;
   return Error();
 }
 
