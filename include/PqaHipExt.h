@@ -46,7 +46,9 @@ PQACORE_API void *PqaEngineFactory_CreateHipEngineSharded(void *pvFactory, void 
  * are written to host-visible device memory where the platform maps it, default 1; set before the first selection).
  * "fused_sampled" (the sampled NextQuestion as one launch instead of sweep + selector; default 0: measured slower),
  * "eval_max_grid" (test hook: cap the workgroups of a sweep so that each streams many questions; 0 = no cap).
- * Read-only: "server_active",
+ * "batch_min" (PqaEngine_NextQuestionArgmaxBatch: batches of at least this many quizzes take the row-sharing sweep, which
+ * reads the cube once per batch; default 32; Float engines always do), "batch_tile" (targets per LDS tile of that sweep, 0 = default).
+ * Read-only: "precision" (TPqaPrecisionType of the engine: 1 = Float, 3 = Double), "server_active",
  * "ldT", "device". */
 PQACORE_API void *PqaHip_SetOption(void *pvEngine, const char *name, int64_t value);
 PQACORE_API int64_t PqaHip_GetOption(void *pvEngine, const char *name);
@@ -73,6 +75,10 @@ PQACORE_API int64_t PqaEngine_NextQuestionSampled(void *pvEngine, void **ppError
  * of nQuizzes x PqaEngine_NextQuestion (reference PqaCore/CpuEngine.cpp:337-415 serves them one sweep at a time). */
 PQACORE_API void *PqaEngine_NextQuestionArgmaxBatch(void *pvEngine, const int64_t nQuizzes, const int64_t *pQuizzes,
                                                     int64_t *pQuestions);
+/* The priority vectors of nQuizzes <= 256 distinct quizzes from ONE sweep that reads the cube once for the whole batch
+ * (batch_kernels.hip): pOut[i * nLocalQuestions + q] = priority of local question q for pQuizzes[i], 0 for gap / asked
+ * questions.  The deterministic output behind PqaEngine_NextQuestionArgmaxBatch's row-sharing form. */
+PQACORE_API void *PqaEngine_EvalPrioritiesBatch(void *pvEngine, const int64_t nQuizzes, const int64_t *pQuizzes, double *pOut);
 /* pOut[i] = the device's Log2Hot(pIn[i]) (host buffers): the function the sweep applies to every posterior element
  * (replaces SRVectMath::Log2Hot, reference SRPlatform/Interface/SRVectMath.h:87-135), exposed so that it can be held to
  * the reference's own SRVectMathTest.Log2Hot criteria (SRPlatformTests/SRVectMathTest.cpp:45-103). */

@@ -1,0 +1,466 @@
+// batch_kernels.hip -- the priority sweep for MANY quizzes at once, and the fp32 sweeps, on CDNA4 (gfx950).
+//
+// Same arithmetic per (question, answer, target) element as CEEvalQsSubtaskConsider<>::Run (reference:
+// PqaCore/CEEvalQsSubtaskConsider.cpp:41-217) -- B independent NextQuestion sweeps over one knowledge base (the reference
+// serves concurrent quizzes one sweep each under a shared read lock, PqaCore/CpuEngine.cpp:357-361; BASELINE configs[4]:
+// "256 concurrent quizzes batched along a leading dim").
+//
+// Shape.  The single-quiz sweep (eval_kernels.hip) maps lanes to TARGETS and pays a wave reduction per row; run once per
+// quiz it also reads the cube once per quiz.  Here a lane is a QUIZ: wave w, lane l of a workgroup owns quiz 64 w + l for
+// the whole launch, so every sum over targets is a private serial sum in that lane's registers -- no cross-lane traffic
+// at all -- and a cube element, fetched once, serves all B quizzes:
+//   * the workgroup stages a tile of the cube in LDS -- for QB questions, KG answers and TC targets the products
+//     c = A * (1/D) (the reference's first multiplication, :81, shared by every quiz) and 1/D^2 (:117) -- computed once
+//     per batch instead of once per quiz;
+//   * every lane walks the tile target by target: the tile values are wave-uniform (one LDS address for all 64 lanes:
+//     a broadcast read, no bank conflicts), the lane's own operand is its quiz's masked prior, read from a transposed
+//     staging matrix PT[target][quiz] (one coalesced 256-byte row per wave and target);
+//   * pass 1 (W_k = sum_t c * prior, :66-88) and pass 2 (posterior, log2, entropy / lack / velocity sums, :95-128) each walk
+//     the row chunk by chunk; a row that fits one tile (ldT <= TC) is staged once for both passes.
+// Cube traffic per batch: Q (K+1) ldT s bytes once (twice for rows longer than a tile: pass 2 re-stages), whatever B is --
+// the previous batched launch (grid.y = quiz) read it B times.  The work is B Q K T element evaluations and for B >= 64 the
+// sweep is VALU-bound: ~31 fp64 / ~15 fp32 VALU slots per element against 9.6 / 4.8 bytes per B elements.
+//
+// Precision (R = double | float): R is the type of the cube, of the staged tile, of the transposed priors and of the
+// per-element arithmetic.  fp64 uses the reference's Log2Hot (pqa_device.h).  fp32 uses the hardware's v_log_f32 (1 ulp)
+// clamped to [-127, -2^-25/ln 2]: the Float analogue of Log2Hot(0) = -1023 (biased exponent field 0, SRVectMath.h:96-98)
+// and of its deliberately negative value at 1 (SRVectMath.cpp:41-43; the lack term divides by it).  Sums over targets run
+// in R over one chunk (<= TC terms) and are folded into fp64 totals per chunk; the per-question epilogue (:134-207: weighted
+// averages, exp2, log, ninth power) is always fp64 (eval_device.h) -- vComp^9 alone overflows fp32 for 10^5 targets.
+//
+// No MFMA: a reduction with a table / transcendental inner function.  (Pass 1 alone is a contraction, but it is 1 of ~15
+// slots per element.)
+#include "eval_device.h"
+#include "pqa_device.h"
+#include "pqa_kernels.h"
+
+namespace pqa {
+
+static __device__ double gLog2TableB[kLog2TableDoubles];  // this translation unit's copy of the Log2Hot table
+
+hipError_t UploadLog2TableBatch(const double *hostTable) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(gLog2TableB), hostTable, kLog2TableDoubles * sizeof(double));
+}
+
+namespace {
+
+constexpr int kTileThreads = 256;   // prep kernel
+
+// ---- PT[t][Bp] = quiz b's prior at target t, masked by the target gaps (:103), in R; columns b >= nSlots are zero ------
+template <typename R>
+__global__ __launch_bounds__(kTileThreads) void batch_prep_kernel(const QuizSlot *__restrict__ slots, int nSlots, int Bp,
+                                                                  const uint32_t *__restrict__ tgap, int64_t ldT, R *__restrict__ PT) {
+  __shared__ double tile[64][65];
+  const int64_t t0 = (int64_t)blockIdx.x * 64;
+  const int b0 = blockIdx.y * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;   // 4 rows of 64 per pass
+  for (int r = ty; r < 64; r += 4) {                        // r: quiz within the tile, tx: target (coalesced along t)
+    const int b = b0 + r;
+    const int64_t t = t0 + tx;
+    double v = 0.0;
+    if (b < nSlots && t < ldT && !bit_test(tgap, t)) v = slots[b].prior[t];
+    tile[r][tx] = v;
+  }
+  __syncthreads();
+  for (int r = ty; r < 64; r += 4) {                        // r: target within the tile, tx: quiz (coalesced along b)
+    const int64_t t = t0 + r;
+    if (t < ldT && b0 + tx < Bp) PT[t * Bp + b0 + tx] = (R)tile[tx][r];
+  }
+}
+
+// ---- per-element arithmetic ------------------------------------------------------------------------------------------
+template <typename R> struct Num;
+template <> struct Num<double> {
+  static constexpr bool kTable = true;
+  static __device__ __forceinline__ double log2p(double p, const double *tbl) { return log2hot(p, tbl); }
+  static __device__ __forceinline__ double rcp(double x) {    // 2^-48.8: below the rounding of the sum it feeds
+    double r = __builtin_amdgcn_rcp(x);
+    return fma(r, fma(-x, r, 1.0), r);
+  }
+  static __device__ __forceinline__ double inv(double x) { return div_nr(1.0, x); }   // exact quotient (:74, :91)
+};
+template <> struct Num<float> {
+  static constexpr bool kTable = false;
+  static __device__ __forceinline__ float log2p(float p, const double *) {
+    // v_log_f32: log2, 1 ulp; 0 -> -inf, clamped to the Float analogue of Log2Hot's range (see the file comment)
+    return __builtin_amdgcn_fmed3f(__builtin_amdgcn_logf(p), -127.0f, -4.2992253e-08f);
+  }
+  static __device__ __forceinline__ float rcp(float x) { return __builtin_amdgcn_rcpf(x); }   // 1 ulp
+  static __device__ __forceinline__ float inv(float x) { return 1.0f / x; }
+};
+
+struct BatchArgs {
+  const void *cube;          // R [Q][K+1][ldT]
+  const void *PT;            // R [ldT][Bp]
+  const uint32_t *tgap, *qgap;
+  const QuizSlot *slots;
+  int nSlots, Bp;
+  int64_t K, Q, ldT;
+  int TC;                    // targets per tile, a multiple of the workgroup's threads
+  double vCompTail;          // ln(sqrt 2) / (nValidTargets + 1)^2 (:191)
+  double *acc;               // fp64 totals, [grid][QB][2K+2][threads]: W_k (K), V_k (K), sum W_k H_k, lack
+  BatchRecord *recs;         // [grid][Bp]: every workgroup's best question per quiz
+  double *priorityT;         // optional [Q][Bp]: the priorities themselves (tests, EvalPrioritiesBatch)
+};
+
+// Tile in LDS: R tile[TC][QB][KG + 1]; entry [tc][qi][k < KG] = A[q][kg + k][t] * invD[q][t], entry [tc][qi][KG] = invD^2.
+// Gap targets hold zeros in both (:74, :79 andnot masks; the reference masks the lack term instead, :117).
+template <typename R, int QB, int KG>
+__device__ __forceinline__ void stage_tile(const BatchArgs &a, R *tile, int64_t q0, int64_t kg, int kN, int64_t t0, int tcN) {
+  const R *cube = static_cast<const R *>(a.cube);
+  const int64_t ldT = a.ldT, K = a.K;
+  for (int tc = threadIdx.x; tc < tcN; tc += blockDim.x) {
+    const int64_t t = t0 + tc;
+    const bool gap = bit_test(a.tgap, t);
+#pragma unroll
+    for (int qi = 0; qi < QB; qi++) {
+      const int64_t q = q0 + qi < a.Q ? q0 + qi : a.Q - 1;    // (beyond the last question: a copy whose results are dropped)
+      const R *qb = cube + q * (K + 1) * ldT;
+      const R d = qb[K * ldT + t];
+      const R invD = gap ? (R)0 : Num<R>::inv(d);             // :74
+      R *dst = tile + ((size_t)tc * QB + qi) * (KG + 1);
+#pragma unroll
+      for (int k = 0; k < KG; k++) dst[k] = k < kN ? qb[(kg + k) * ldT + t] * invD : (R)0;   // :81 (A * invD)
+      dst[KG] = invD * invD;                                   // :117
+    }
+  }
+}
+
+// One workgroup: NW = blockDim / 64 waves, lane (w, l) <-> quiz b = 64 w + l.  Questions in blocks of QB consecutive local
+// indices, answers in groups of KG (K <= KG: one group).
+// EXACT: K == KG, so the one answer group is full and nothing in the element loops depends on a run-time answer count.
+template <typename R, int QB, int KG, bool EXACT>
+__global__ __launch_bounds__(256) void eval_batch_kernel(BatchArgs a) {
+  extern __shared__ double smem[];
+  const double *tbl = smem;
+  R *tile = reinterpret_cast<R *>(smem + (Num<R>::kTable ? kLog2TableDoubles : 0));
+  if constexpr (Num<R>::kTable) {
+    if (!lds_table_at_zero(tbl)) __builtin_trap();            // log2hot addresses the table absolutely
+    for (int i = threadIdx.x; i < kLog2TableDoubles; i += blockDim.x) smem[i] = gLog2TableB[i];
+  }
+  const int tid = threadIdx.x, nThreads = blockDim.x;
+  const int b = tid;                                           // quiz of this lane
+  const bool live = b < a.nSlots;
+  const int64_t K = a.K, ldT = a.ldT;
+  const int Bp = a.Bp, TC = a.TC;
+  const int nChunks = (int)((ldT + TC - 1) / TC);
+  const R *pt = static_cast<const R *>(a.PT) + b;
+  const uint32_t *asked = live ? a.slots[b].asked : a.qgap;   // (idle lanes: any valid words)
+  const int nAcc = (int)(2 * K + 2);
+  double *acc = a.acc + (size_t)blockIdx.x * QB * nAcc * nThreads + tid;   // entry (qi, r) at acc[(qi * nAcc + r) * nThreads]
+  double bestP = 0.0;
+  int64_t bestQ = -1;
+  const int64_t nBlocks = (a.Q + QB - 1) / QB;
+  for (int64_t blk = blockIdx.x; blk < nBlocks; blk += gridDim.x) {
+    const int64_t q0 = blk * QB;
+    bool staged = false;                                       // single-tile rows, single answer group: pass 2 reuses pass 1's tile
+    for (int64_t kg = 0; kg < K; kg += KG) {
+      const int kN = EXACT ? KG : (int)(K - kg < KG ? K - kg : KG);
+      // ---- pass 1 (:66-88): W_k = sum_t (A * invD) * prior
+      double Wd[QB][KG];
+#pragma unroll
+      for (int qi = 0; qi < QB; qi++)
+#pragma unroll
+        for (int k = 0; k < KG; k++) Wd[qi][k] = 0.0;
+      for (int ch = 0; ch < nChunks; ch++) {
+        const int64_t t0 = (int64_t)ch * TC;
+        const int tcN = (int)(ldT - t0 < TC ? ldT - t0 : TC);
+        __syncthreads();                                       // everybody is done with the previous tile
+        stage_tile<R, QB, KG>(a, tile, q0, kg, kN, t0, tcN);
+        __syncthreads();
+        R W[QB][KG];
+#pragma unroll
+        for (int qi = 0; qi < QB; qi++)
+#pragma unroll
+          for (int k = 0; k < KG; k++) W[qi][k] = (R)0;
+        // the lane's priors are requested two targets ahead of their use (an L2 round trip is about as long as one target's
+        // arithmetic over the tile's QB x KG elements)
+        const R *ptc = pt + t0 * Bp;
+        R pi1 = ptc[0], pi2 = ptc[tcN > 1 ? Bp : 0];
+#pragma unroll 1
+        for (int tc = 0; tc < tcN; tc++) {
+          const R pi = pi1;
+          pi1 = pi2;
+          pi2 = ptc[(size_t)(tc + 2 < tcN ? tc + 2 : tcN - 1) * Bp];
+          const R *c = tile + (size_t)tc * QB * (KG + 1);
+#pragma unroll
+          for (int qi = 0; qi < QB; qi++)
+#pragma unroll
+            for (int k = 0; k < KG; k++)
+              if (EXACT || k < kN) W[qi][k] = fma(c[qi * (KG + 1) + k], pi, W[qi][k]);   // :81-82, :85
+        }
+#pragma unroll
+        for (int qi = 0; qi < QB; qi++)
+#pragma unroll
+          for (int k = 0; k < KG; k++) Wd[qi][k] += (double)W[qi][k];
+      }
+      staged = nChunks == 1;
+      R invW[QB][KG];
+#pragma unroll
+      for (int qi = 0; qi < QB; qi++)
+#pragma unroll
+        for (int k = 0; k < KG; k++) {
+          invW[qi][k] = (R)div_fast(1.0, Wd[qi][k]);            // :91
+          if (EXACT || k < kN) acc[(qi * nAcc + (int)kg + k) * nThreads] = Wd[qi][k];   // :90
+        }
+      // ---- pass 2 (:95-128)
+      for (int ch = 0; ch < nChunks; ch++) {
+        const int64_t t0 = (int64_t)ch * TC;
+        const int tcN = (int)(ldT - t0 < TC ? ldT - t0 : TC);
+        if (!staged) {
+          __syncthreads();
+          stage_tile<R, QB, KG>(a, tile, q0, kg, kN, t0, tcN);
+          __syncthreads();
+        }
+        R v[QB][KG], hW[QB], accL[QB];
+#pragma unroll
+        for (int qi = 0; qi < QB; qi++) {
+          hW[qi] = accL[qi] = (R)0;
+#pragma unroll
+          for (int k = 0; k < KG; k++) v[qi][k] = (R)0;
+        }
+        const R *ptc = pt + t0 * Bp;
+        R pi1 = ptc[0], pi2 = ptc[tcN > 1 ? Bp : 0];
+#pragma unroll 1
+        for (int tc = 0; tc < tcN; tc++) {
+          const R pi = pi1;
+          pi1 = pi2;
+          pi2 = ptc[(size_t)(tc + 2 < tcN ? tc + 2 : tcN - 1) * Bp];
+          const R *c = tile + (size_t)tc * QB * (KG + 1);
+#pragma unroll
+          for (int qi = 0; qi < QB; qi++) {
+            const R id2 = c[qi * (KG + 1) + KG];
+#pragma unroll
+            for (int k = 0; k < KG; k++) {
+              if (EXACT || k < kN) {
+                const R lh = c[qi * (KG + 1) + k] * pi;          // the likelihood again (:81-82): cheaper than keeping it
+                const R p = lh * invW[qi][k];                    // :97
+                const R l2 = Num<R>::log2p(p, tbl);              // :106
+                hW[qi] = fma(lh, l2, hW[qi]);                    // :113-114 weighted by W_k (eval_epilogue)
+                accL[qi] = fma(id2, Num<R>::rcp(l2), accL[qi]);  // :117
+                const R d = p - pi;                              // :119
+                v[qi][k] = fma(d, d, v[qi][k]);                  // :126-127
+              }
+            }
+          }
+        }
+        // fold the chunk's sums into the fp64 totals
+        const bool first = ch == 0;
+#pragma unroll
+        for (int qi = 0; qi < QB; qi++) {
+#pragma unroll
+          for (int k = 0; k < KG; k++)
+            if (EXACT || k < kN) {
+              double *p = acc + (qi * nAcc + (int)(K + kg) + k) * nThreads;
+              *p = (first ? 0.0 : *p) + (double)v[qi][k];
+            }
+          double *ph = acc + (qi * nAcc + (int)(2 * K)) * nThreads, *pl = ph + nThreads;
+          const bool firstOfQuestion = first && kg == 0;
+          *ph = (firstOfQuestion ? 0.0 : *ph) + (double)hW[qi];
+          *pl = (firstOfQuestion ? 0.0 : *pl) + (double)accL[qi];
+        }
+      }
+    }
+    // ---- epilogue (:134-207), one per (question, quiz), fp64
+#pragma unroll 1
+    for (int qi = 0; qi < QB; qi++) {
+      const int64_t q = q0 + qi;
+      if (q >= a.Q) break;
+      const bool skip = bit_test(a.qgap, q) || ((asked[q >> 5] >> (q & 31)) & 1u);   // :54
+      double pri = 0.0;
+      if (!skip) {
+        double *rec = acc + (size_t)qi * nAcc * nThreads;
+        // mWV[k] = W_k * sqrt(V_k) (:156-157) in place of V_k
+        for (int64_t k = 0; k < K; k++) rec[(K + k) * nThreads] = rec[k * nThreads] * sqrt(rec[(K + k) * nThreads]);
+        pri = eval_epilogue_strided(rec, -rec[2 * K * nThreads], rec + K * nThreads, K, rec[(2 * K + 1) * nThreads], a.vCompTail,
+                                    nThreads);
+      }
+      if (live) {
+        if (a.priorityT) a.priorityT[q * Bp + b] = pri;
+        if (!skip) {
+          const double cand = pri != pri ? -__builtin_huge_val() : pri;   // NaN never wins over a number
+          if (bestQ < 0 || cand > bestP) { bestP = cand; bestQ = q; }     // (questions ascend: the lowest index wins a tie)
+        }
+      }
+    }
+  }
+  a.recs[(size_t)blockIdx.x * Bp + b] = BatchRecord{bestP, bestQ};
+}
+
+// ---- every quiz's winner over the workgroups' records; the result and then the flag go to host-coherent memory ----------
+__global__ __launch_bounds__(256) void batch_pick_kernel(const BatchRecord *__restrict__ recs, int nRecs, int Bp,
+                                                         const QuizSlot *__restrict__ slots, int nSlots, int64_t outBase,
+                                                         uint64_t flagValue) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= nSlots) return;
+  double bp = 0.0;
+  int64_t bq = -1;
+  for (int g = 0; g < nRecs; g++) {
+    const BatchRecord r = recs[(size_t)g * Bp + b];
+    if (r.index >= 0 && (bq < 0 || r.priority > bp || (r.priority == bp && r.index < bq))) { bp = r.priority; bq = r.index; }
+  }
+  const QuizSlot s = slots[b];
+  s.out->priority = bq < 0 ? 0.0 : bp;
+  s.out->index = bq < 0 ? -1 : bq + outBase;
+  if (s.seq != nullptr) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");             // system scope: the record before the flag
+    __hip_atomic_store(s.seq, flagValue, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
+// ---- single-quiz sweep for Float engines: one 256-thread workgroup per question, lanes over targets, pass 2 re-reads the
+// row (L2 / Infinity Cache).  The fp32 twin of eval_questions_f64_stream (eval_kernels.hip); Double engines have the
+// register-resident shapes there.
+__device__ __forceinline__ float wave_sum_f(float v) {
+#pragma unroll
+  for (int m = kWave / 2; m >= 1; m >>= 1) v += __shfl_xor(v, m, kWave);
+  return v;
+}
+__global__ __launch_bounds__(256) void eval_questions_f32_stream(const float *__restrict__ cube, const double *__restrict__ prior,
+                                                                 const uint32_t *__restrict__ tgap, const uint32_t *__restrict__ qgap,
+                                                                 const uint32_t *__restrict__ asked, double *__restrict__ priority,
+                                                                 int64_t K, int64_t Q, int64_t ldT, double vCompTail) {
+  extern __shared__ double smem[];      // W_k [K] | W_k sqrt(V_k) [K] | partials [WPQ][4]
+  double *wk = smem, *wv = smem + K;
+  float *part = reinterpret_cast<float *>(smem + 2 * K);
+  const int tid = threadIdx.x, lane = tid % kWave, wave = tid / kWave;
+  for (int64_t q = blockIdx.x; q < Q; q += gridDim.x) {
+    if (bit_test(qgap, q) || bit_test(asked, q)) {
+      if (tid == 0) priority[q] = 0.0;
+      continue;
+    }
+    const float *qb = cube + q * (K + 1) * ldT, *rowD = qb + K * ldT;
+    double hWd = 0.0, accLd = 0.0;
+    for (int64_t k = 0; k < K; k++) {
+      const float *rowA = qb + k * ldT;
+      float s = 0.f;
+      for (int64_t t = tid; t < ldT; t += 256) {
+        const bool g = bit_test(tgap, t);
+        const float invD = g ? 0.f : 1.0f / rowD[t];
+        s += (rowA[t] * invD) * (g ? 0.f : (float)prior[t]);
+      }
+      s = wave_sum_f(s);
+      __syncthreads();                                        // the previous answer's partials have been read
+      if (lane == 0) part[wave] = s;
+      __syncthreads();
+      const float Wk = (part[0] + part[1]) + (part[2] + part[3]);
+      const float invWk = 1.0f / Wk;
+      float v = 0.f, hW = 0.f, accL = 0.f;
+      for (int64_t t = tid; t < ldT; t += 256) {
+        const bool g = bit_test(tgap, t);
+        const float invD = g ? 0.f : 1.0f / rowD[t];
+        const float pi = g ? 0.f : (float)prior[t];
+        const float lh = (rowA[t] * invD) * pi;
+        const float p = lh * invWk;
+        const float l2 = Num<float>::log2p(p, nullptr);
+        hW = fmaf(lh, l2, hW);
+        accL = fmaf(invD * invD, Num<float>::rcp(l2), accL);
+        const float d = p - pi;
+        v = fmaf(d, d, v);
+      }
+      v = wave_sum_f(v);
+      hW = wave_sum_f(hW);
+      accL = wave_sum_f(accL);
+      __syncthreads();
+      if (lane == 0) { part[4 + wave] = v; part[8 + wave] = hW; part[12 + wave] = accL; }
+      __syncthreads();
+      if (tid == 0) {
+        wk[k] = (double)Wk;
+        wv[k] = (double)Wk * sqrt((double)((part[4] + part[5]) + (part[6] + part[7])));
+      }
+      hWd += (double)((part[8] + part[9]) + (part[10] + part[11]));
+      accLd += (double)((part[12] + part[13]) + (part[14] + part[15]));
+    }
+    __syncthreads();
+    if (tid == 0) priority[q] = eval_epilogue(wk, -hWd, wv, K, accLd, vCompTail);
+    __syncthreads();
+  }
+}
+
+template <typename R, int QB, int KG, bool EXACT>
+hipError_t launch_batch(const BatchArgs &args0, int nThreads, size_t *accBytesNeeded, int *gridOut, bool queryOnly, hipStream_t stream) {
+  BatchArgs args = args0;
+  auto kern = eval_batch_kernel<R, QB, KG, EXACT>;
+  const size_t shmem = (Num<R>::kTable ? kLog2TableDoubles * sizeof(double) : 0) + (size_t)args.TC * QB * (KG + 1) * sizeof(R);
+  if (shmem > 160 * 1024) return hipErrorInvalidValue;
+  static size_t attrSet = 0;
+  if (shmem > 64 * 1024 && shmem > attrSet) {
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+    if (e != hipSuccess) return e;
+    attrSet = shmem;
+  }
+  int dev = 0, nCU = 0, perCU = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&nCU, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || nCU <= 0) nCU = 256;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, kern, nThreads, shmem) != hipSuccess || perCU < 1) perCU = 1;
+  const int64_t nBlocks = (args.Q + QB - 1) / QB;
+  int64_t grid = (int64_t)nCU * perCU;
+  if (grid > nBlocks) grid = nBlocks;
+  if (grid > kBatchMaxGrid) grid = kBatchMaxGrid;
+  *gridOut = (int)grid;
+  *accBytesNeeded = (size_t)grid * QB * (2 * args.K + 2) * nThreads * sizeof(double);
+  if (queryOnly) return hipSuccess;
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(nThreads), shmem, stream, args);
+  return hipGetLastError();
+}
+
+}  // namespace
+
+// Plan or run one batched sweep.  queryOnly: fill plan->{grid, accBytes, ptBytes, recBytes} for the caller to size its
+// scratch; otherwise prep (transposed priors) + sweep + pick on `stream`.
+hipError_t LaunchEvalBatch(const KbView &kb, const QuizSlot *slots, int nSlots, BatchPlan *plan, void *PT, double *acc,
+                           BatchRecord *recs, double *priorityT, int64_t outBase, uint64_t flagValue, bool queryOnly, hipStream_t stream) {
+  if (nSlots <= 0 || nSlots > 256 || plan == nullptr) return hipErrorInvalidValue;
+  const bool f32 = kb.elem == 4;
+  const int nThreads = ((nSlots + 63) / 64) * 64, Bp = nThreads;
+  BatchArgs a{};
+  a.cube = kb.cube; a.PT = PT; a.tgap = kb.tgap; a.qgap = kb.qgap; a.slots = slots; a.nSlots = nSlots; a.Bp = Bp;
+  a.K = kb.K; a.Q = kb.Q; a.ldT = kb.ldT;
+  int tc = plan->tileTargets > 0 ? plan->tileTargets : 256;
+  tc = ((tc + nThreads - 1) / nThreads) * nThreads;
+  a.TC = tc;
+  const double nT = (double)(kb.nValidTargets + 1);            // PqaCore/CEEvalQsSubtaskConsider.cpp:191
+  a.vCompTail = 0.34657359027997265470861606072909 / (nT * nT);
+  a.acc = acc; a.recs = recs; a.priorityT = priorityT;
+  plan->ptBytes = (size_t)kb.ldT * Bp * (f32 ? 4 : 8);
+  plan->Bp = Bp;
+  hipError_t e;
+  int grid = 0;
+  const bool k5 = kb.K == 5;
+  if (f32) e = k5 ? launch_batch<float, 4, 5, true>(a, nThreads, &plan->accBytes, &grid, true, stream)
+                  : launch_batch<float, 4, 4, false>(a, nThreads, &plan->accBytes, &grid, true, stream);
+  else e = k5 ? launch_batch<double, 2, 5, true>(a, nThreads, &plan->accBytes, &grid, true, stream)
+              : launch_batch<double, 2, 4, false>(a, nThreads, &plan->accBytes, &grid, true, stream);
+  if (e != hipSuccess) return e;
+  plan->grid = grid;
+  plan->recBytes = (size_t)grid * Bp * sizeof(BatchRecord);
+  if (queryOnly) return hipSuccess;
+  if (PT == nullptr || acc == nullptr || recs == nullptr) return hipErrorInvalidValue;
+  const dim3 pgrid((unsigned)((kb.ldT + 63) / 64), (unsigned)(Bp / 64));
+  if (f32) hipLaunchKernelGGL(batch_prep_kernel<float>, pgrid, dim3(kTileThreads), 0, stream, slots, nSlots, Bp, kb.tgap, kb.ldT, static_cast<float *>(PT));
+  else hipLaunchKernelGGL(batch_prep_kernel<double>, pgrid, dim3(kTileThreads), 0, stream, slots, nSlots, Bp, kb.tgap, kb.ldT, static_cast<double *>(PT));
+  e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  size_t dummy = 0;
+  if (f32) e = k5 ? launch_batch<float, 4, 5, true>(a, nThreads, &dummy, &grid, false, stream)
+                  : launch_batch<float, 4, 4, false>(a, nThreads, &dummy, &grid, false, stream);
+  else e = k5 ? launch_batch<double, 2, 5, true>(a, nThreads, &dummy, &grid, false, stream)
+              : launch_batch<double, 2, 4, false>(a, nThreads, &dummy, &grid, false, stream);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(batch_pick_kernel, dim3((unsigned)((nSlots + 255) / 256)), dim3(256), 0, stream, recs, grid, Bp, slots, nSlots,
+                     outBase, flagValue);
+  return hipGetLastError();
+}
+
+hipError_t LaunchEvalQuestionsF32(const KbView &kb, const double *prior, const uint32_t *asked, double *priority, hipStream_t stream) {
+  if (kb.elem != 4) return hipErrorInvalidValue;
+  const double nT = (double)(kb.nValidTargets + 1);
+  const double vCompTail = 0.34657359027997265470861606072909 / (nT * nT);
+  int64_t grid = kb.Q < 2048 ? kb.Q : 2048;
+  if (kb.maxGrid > 0 && grid > kb.maxGrid) grid = kb.maxGrid;
+  const size_t shmem = (size_t)(2 * kb.K + 8) * sizeof(double);
+  hipLaunchKernelGGL(eval_questions_f32_stream, dim3((unsigned)grid), dim3(256), shmem, stream, static_cast<const float *>(kb.cube), prior,
+                     kb.tgap, kb.qgap, asked, priority, kb.K, kb.Q, kb.ldT, vCompTail);
+  return hipGetLastError();
+}
+
+}  // namespace pqa

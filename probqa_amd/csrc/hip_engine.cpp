@@ -108,11 +108,15 @@ Error HipEngine::Init(const CiEngineDefinition &def, const CiHipShard *shard) {
       << "] [nTargets=" << def._nTargets << " of " << minT << "]";
     return Error::MakeP(ErrCode::InsufficientEngineDimensions, p.str(), "Engine dimensions are too small.");
   }
-  if (def._precType != 3 /*Double*/) {
-    return Error::MakeP(ErrCode::NotImplemented, "Feature=HipEngine precision other than Double",
-                        "Only TPqaPrecisionType::Double is instantiated (as in the reference CPU engine, "
-                        "PqaCore/PqaEngineBaseFactory.cpp:19-27).");
+  // TPqaPrecisionType (reference PqaCore/Interface/PqaCommon.h:17-24): Double is what the reference's CPU engine instantiates
+  // (PqaEngineBaseFactory.cpp:19-27), Float what its GPU engine does (:124-142); both exist here.
+  if (def._precType != 3 /*Double*/ && def._precType != 1 /*Float*/) {
+    return Error::MakeP(ErrCode::NotImplemented, "Feature=HipEngine precision other than Double and Float",
+                        "TPqaPrecisionType::Double and ::Float are instantiated (the reference: Double on the CPU, "
+                        "PqaCore/PqaEngineBaseFactory.cpp:19-27, Float on the GPU, :124-142).");
   }
+  _precType = def._precType;
+  _elem = def._precType == 1 ? 4 : 8;
   int nDev = 0;
   if (hipGetDeviceCount(&nDev) != hipSuccess || nDev <= 0) {
     return Error::Make(ErrCode::NotInitialized,
@@ -123,7 +127,7 @@ Error HipEngine::Init(const CiEngineDefinition &def, const CiHipShard *shard) {
   _precMantissa = def._precMantissa;
   _precExponent = def._precExponent;
   _initAmount = def._initAmount;
-  _ldT = ((_T + 15) / 16) * 16;
+  _ldT = RoundLdT(_T, _elem);
   _qFirst = shard ? shard->_qFirst : 0;
   _qTotal = shard ? shard->_qTotal : _Q;
   if (_qFirst < 0 || _qFirst + _Q > _qTotal)
@@ -168,13 +172,14 @@ Error HipEngine::Init(const CiEngineDefinition &def, const CiHipShard *shard) {
         tbl[0] = y0;
       }
       tblErr = UploadLog2Table(tbl.data());
+      if (tblErr == hipSuccess) tblErr = UploadLog2TableBatch(tbl.data());
     });
     HIP_TRY(tblErr);
   }
   HIP_TRY(hipStreamCreateWithFlags(&_ownStream, hipStreamNonBlocking));
   _stream = _ownStream;
   const size_t cubeElems = (size_t)_Q * (size_t)(_K + 1) * (size_t)_ldT;
-  HIP_TRY(hipMalloc(&_dCube, cubeElems * sizeof(double)));
+  HIP_TRY(hipMalloc(&_dCube, cubeElems * (size_t)_elem));
   HIP_TRY(hipMalloc(&_dVB, (size_t)_ldT * sizeof(double)));
   HIP_TRY(hipMalloc(&_dPriority, (size_t)_Q * sizeof(double)));
   HIP_TRY(hipMalloc(&_dRunLength, (size_t)_Q * sizeof(double)));
@@ -194,7 +199,7 @@ Error HipEngine::Init(const CiEngineDefinition &def, const CiHipShard *shard) {
   HIP_TRY(hipMalloc(&_dQGap, _hQGap.size() * sizeof(uint32_t)));
   Error e = UploadGaps();
   if (!e.ok()) return e;
-  HIP_TRY(LaunchFillFresh(_dCube, _dVB, _K, _Q, _T, _ldT, _initAmount, _stream));
+  HIP_TRY(LaunchFillFresh(_dCube, _elem, _dVB, _K, _Q, _T, _ldT, _initAmount, _stream));
   HIP_TRY(hipStreamSynchronize(_stream));
   _pimQuestions.GrowTo(_Q);  // reference PqaCore/BaseCpuEngine.cpp:24-25
   _pimTargets.GrowTo(_T);
@@ -216,6 +221,7 @@ HipEngine::~HipEngine() {
   for (Quiz *q : _quizzes) if (q) DestroyQuiz(q);
   hipFree(_dCube); hipFree(_dVB); hipFree(_dPriority); hipFree(_dRunLength); hipFree(_dExps); hipFree(_dStatus);
   hipFree(_dNOut); hipFree(_dSel); hipFree(_dSelScratch); hipFree(_dBatchSlots); hipFree(_dBatchScratch); hipFree(_dBatchPriority);
+  hipFree(_dBatchPT); hipFree(_dBatchAcc); hipFree(_dBatchRecs); hipFree(_dBatchPriT);
   DropQuizBufferPool();
   for (auto &g : _graphs) hipGraphExecDestroy(g.second.exec);
   hipFree(_dGraphScratch); hipFree(_dTagCell);
@@ -235,7 +241,7 @@ Error HipEngine::UploadGaps() {
 
 KbView HipEngine::View() const {
   KbView v;
-  v.cube = _dCube; v.vB = _dVB; v.tgap = _dTGap; v.qgap = _dQGap;
+  v.cube = _dCube; v.elem = _elem; v.vB = _dVB; v.tgap = _dTGap; v.qgap = _dQGap;
   v.K = _K; v.Q = _Q; v.T = _T; v.ldT = _ldT;
   v.nValidTargets = _T - _nTargetGaps;
   v.smallLaunches = _optServer ? 1 : 0;
@@ -259,6 +265,8 @@ Error HipEngine::SetOption(const char *name, int64_t value) {
   else if (n == "server") { if (!value) StopServer(); _optServer = value ? 1 : 0; }
   else if (n == "eval_max_grid") { if (value < 0 || value > 65535) goto bad; StopServer(); _optEvalMaxGrid = value; _kbVersion++; }
   else if (n == "fused_sampled") { _optFusedSampled = value ? 1 : 0; }
+  else if (n == "batch_min") { if (value < 1 || value > 257) goto bad; _optBatchMin = value; }
+  else if (n == "batch_tile") { if (value < 0 || value > 8192) goto bad; _optBatchTile = value; }
   else if (n == "server_vram_mailbox") { if (_serverStream) goto bad; _optServerVramMailbox = value ? 1 : 0; }
   else if (n == "server_idle_us") { if (value < 10 || value > 1000000) goto bad; StopServer(); _optServerIdleUs = value; }
   else if (n == "seed") { uint64_t s = (uint64_t)value; _rng[0] = SplitMix64(s); _rng[1] = SplitMix64(s); }
@@ -280,6 +288,9 @@ int64_t HipEngine::GetOption(const char *name) const {
   if (n == "server") return _optServer;
   if (n == "server_idle_us") return _optServerIdleUs;
   if (n == "fused_sampled") return _optFusedSampled;
+  if (n == "batch_min") return _optBatchMin;
+  if (n == "batch_tile") return _optBatchTile;
+  if (n == "precision") return _precType;
   if (n == "server_vram_mailbox") return _serverStream ? (_serverRequestInVram ? 1 : 0) : _optServerVramMailbox;
   if (n == "debug_mailbox") return (int64_t)(uintptr_t)_hMailbox;
   if (n == "server_active") return (_optServer && ServerUsable()) ? 1 : 0;
@@ -288,7 +299,7 @@ int64_t HipEngine::GetOption(const char *name) const {
   return -1;
 }
 
-const char *HipEngine::EvalKernelName() const { return EvalVariantName(View(), (int)_optEvalVariant); }
+const char *HipEngine::EvalKernelName() const { return _elem == 8 ? EvalVariantName(View(), (int)_optEvalVariant) : "f32_stream256"; }
 
 uint64_t HipEngine::NextRandom() {  // xorshift128+, the generator family of SRPlatform/Interface/SRFastRandom.h:60-72
   uint64_t s1 = _rng[0];
@@ -519,8 +530,22 @@ Error HipEngine::EnqueueEval(int64_t iQuiz) {
   if (!err.ok()) return err;
   Quiz *q = UseQuiz(err, iQuiz);
   if (!q) return err;
+  hipSetDevice(_device);
   StopServer();   // a launched sweep has no room beside the resident one and would wait for it to idle out
-  HIP_TRY(LaunchEvalQuestions(View(), q->dPrior, q->dAsked, 0, _Q, _dPriority, (int)_optEvalVariant, nullptr, _stream));
+  return LaunchSingleSweep(q, nullptr);
+}
+
+// The single-quiz sweep of this engine's precision on the engine's stream: the register-resident fp64 shapes with the fused
+// argmax (eval_kernels.hip) for Double engines; for Float engines the fp32 streaming sweep and, where a selection is asked
+// for, the argmax kernel behind it (batch_kernels.hip, select_kernels.hip).
+Error HipEngine::LaunchSingleSweep(Quiz *q, const FusedSelect *fused) {
+  if (_elem == 8) {
+    HIP_TRY(LaunchEvalQuestions(View(), q->dPrior, q->dAsked, 0, _Q, _dPriority, (int)_optEvalVariant, fused, _stream));
+    return Error();
+  }
+  HIP_TRY(LaunchEvalQuestionsF32(View(), q->dPrior, q->dAsked, _dPriority, _stream));
+  if (fused != nullptr)
+    HIP_TRY(LaunchSelectArgmax(_dPriority, _dQGap, q->dAsked, 0, _Q, fused->outBase, fused->out, fused->seq, fused->flagValue, _stream));
   return Error();
 }
 
@@ -532,9 +557,9 @@ Error HipEngine::EnqueueSelectArgmax(int64_t iQuiz, void *pOut) {
   if (!q) return err;
   // one launch: the sweep's last workgroup picks the argmax; reported index = local position + qFirst (GLOBAL id)
   const FusedSelect fs{_dSelScratch, pOut ? (SelectResult *)pOut : _dSel, nullptr, NextLaunchTag(), _qFirst, 0, 0, nullptr, 0, 0, nullptr};
+  hipSetDevice(_device);
   StopServer();   // a launched sweep has no room beside the resident one and would wait for it to idle out
-  HIP_TRY(LaunchEvalQuestions(View(), q->dPrior, q->dAsked, 0, _Q, _dPriority, (int)_optEvalVariant, &fs, _stream));
-  return Error();
+  return LaunchSingleSweep(q, &fs);
 }
 
 // The same, for a multi-process host loop that exchanges the shards' winners through host memory shared by the ranks
@@ -551,8 +576,7 @@ Error HipEngine::EnqueueSelectArgmaxFlag(int64_t iQuiz, void *pOut, void *pFlag,
   if (_optServer && ServerUsable()) return ServerPost(q, (SelectResult *)pOut, (uint64_t *)pFlag, flagValue, _qFirst);
   const FusedSelect fs{_dSelScratch, (SelectResult *)pOut, (uint64_t *)pFlag, NextLaunchTag(), _qFirst, 0, flagValue, nullptr, 0, 0, nullptr};
   StopServer();   // a launched sweep has no room beside the resident one and would wait for it to idle out
-  HIP_TRY(LaunchEvalQuestions(View(), q->dPrior, q->dAsked, 0, _Q, _dPriority, (int)_optEvalVariant, &fs, _stream));
-  return Error();
+  return LaunchSingleSweep(q, &fs);
 }
 
 Error HipEngine::WaitFlag(volatile uint64_t *flag, uint64_t value, const char *what) {
@@ -578,7 +602,7 @@ int64_t HipEngine::NextQuestionArgmax(Error &err, int64_t iQuiz) {
   Quiz *q = UseQuiz(err, iQuiz);
   if (!q) return -1;
   hipSetDevice(_device);
-  if (_optUseGraph) return NextQuestionArgmaxGraph(err, q);
+  if (_optUseGraph && _elem == 8) return NextQuestionArgmaxGraph(err, q);
   if (_optServer && ServerUsable()) {
     // resident sweep: post the request, poll the answer -- no launch on the critical path
     const uint64_t value = ++_opSeq;
@@ -596,8 +620,8 @@ int64_t HipEngine::NextQuestionArgmax(Error &err, int64_t iQuiz) {
   const uint64_t seq = NextLaunchTag();
   const FusedSelect fs{_dSelScratch, &_hPinned->sel, &_hPinned->seq, seq, 0, 0, seq, nullptr, 0, 0, nullptr};
   StopServer();   // a launched sweep has no room beside the resident one and would wait for it to idle out
-  hipError_t he = LaunchEvalQuestions(View(), q->dPrior, q->dAsked, 0, _Q, _dPriority, (int)_optEvalVariant, &fs, _stream);
-  if (he != hipSuccess) { err = HipErr(he, "NextQuestionArgmax"); return -1; }
+  err = LaunchSingleSweep(q, &fs);
+  if (!err.ok()) return -1;
   err = WaitFlag(&_hPinned->seq, seq, "NextQuestionArgmax");
   if (!err.ok()) return -1;
   std::atomic_thread_fence(std::memory_order_acquire);
@@ -611,7 +635,7 @@ int64_t HipEngine::NextQuestionArgmax(Error &err, int64_t iQuiz) {
 // ------------------------------------------------------------------------------------------------------------------
 // resident sweep (pqa_kernels.h: ServerMailbox; eval_kernels.hip: eval_server_f64)
 // ------------------------------------------------------------------------------------------------------------------
-bool HipEngine::ServerUsable() const { return EvalServerSupported(View(), (int)_optEvalVariant) && _Q > 0; }
+bool HipEngine::ServerUsable() const { return _elem == 8 && EvalServerSupported(View(), (int)_optEvalVariant) && _Q > 0; }
 
 void HipEngine::StopServer() {
   if (!_serverLaunched) return;
@@ -742,9 +766,69 @@ Error HipEngine::ServerPost(Quiz *q, SelectResult *out, uint64_t *flag, uint64_t
   return Error();
 }
 
-// Argmax selections for several quizzes with ONE launch (grid.y = quiz): the launch / dispatch / hand-back overhead that
-// dominates a single selection on small knowledge bases is paid once per batch.  pOut[i] = the selected GLOBAL question of
-// pQuizzes[i], or -1 when that quiz has run out of questions (not an error of the call).
+// Argmax selections for several quizzes at once.  pOut[i] = the selected GLOBAL question of pQuizzes[i], or -1 when that quiz
+// has run out of questions (not an error of the call).  Two forms:
+//   * the row-sharing sweep (batch_kernels.hip; batches of at least `batch_min` quizzes, and every batch of a Float engine):
+//     a lane is a quiz, the cube tile staged in LDS serves all quizzes of the batch -- the cube is read once per batch;
+//   * grid.y = quiz over the single-quiz kernel (small batches of Double engines): one launch, but one cube read per quiz.
+Error HipEngine::BatchSweep(int64_t n, const int64_t *pQuizzes, std::vector<Quiz *> &quizzes, bool wantPriorities, uint64_t tag) {
+  if (!_hBatch) {  // first batch: staging in host-coherent pinned memory, winner records
+    HIP_TRY(hipHostMalloc(&_hBatch, sizeof(BatchPinned), hipHostMallocMapped | hipHostMallocCoherent));
+    std::memset(_hBatch, 0, sizeof(BatchPinned));
+    HIP_TRY(hipMalloc(&_dBatchSlots, kMaxBatch * sizeof(QuizSlot)));
+    HIP_TRY(hipMalloc(&_dBatchScratch, (size_t)kMaxBatch * kBatchGrid * sizeof(SelectResult)));
+    HIP_TRY(hipMemset(_dBatchScratch, 0, (size_t)kMaxBatch * kBatchGrid * sizeof(SelectResult)));
+  }
+  const bool rowSharing = _elem == 4 || n >= _optBatchMin || wantPriorities;
+  if (!rowSharing && _batchPriorityQ != _Q) {  // per-quiz priority vectors of the grid.y form, (re)sized with the knowledge base
+    if (_dBatchPriority) hipFree(_dBatchPriority);
+    _dBatchPriority = nullptr;
+    _batchPriorityQ = -1;
+    HIP_TRY(hipMalloc(&_dBatchPriority, (size_t)kMaxBatch * (size_t)_Q * sizeof(double)));
+    _batchPriorityQ = _Q;
+  }
+  Error err;
+  quizzes.assign((size_t)n, nullptr);
+  for (int64_t i = 0; i < n; i++) {
+    quizzes[i] = UseQuiz(err, pQuizzes[i]);
+    if (!quizzes[i]) return err;
+    for (int64_t j = 0; j < i; j++)
+      if (pQuizzes[j] == pQuizzes[i])
+        return Error::MakeP(ErrCode::IndexOutOfRange, "quizId=" + std::to_string(pQuizzes[i]), "A quiz appears twice in one batch.");
+    _hBatch->slots[i] = QuizSlot{quizzes[i]->dPrior, quizzes[i]->dAsked, rowSharing ? nullptr : _dBatchPriority + (size_t)i * (size_t)_Q,
+                                 &_hBatch->out[i], &_hBatch->seq[i]};
+  }
+  HIP_TRY(hipMemcpyAsync(_dBatchSlots, _hBatch->slots, (size_t)n * sizeof(QuizSlot), hipMemcpyHostToDevice, _stream));
+  StopServer();   // a launched sweep has no room beside the resident one and would wait for it to idle out
+  if (!rowSharing) {
+    const FusedSelect fs{_dBatchScratch, nullptr, nullptr, tag, 0, kBatchGrid, tag, nullptr, 0, 0, nullptr};
+    HIP_TRY(LaunchEvalQuestionsBatch(View(), _dBatchSlots, (int)n, 0, _Q, (int)_optEvalVariant, fs, _stream));
+    return Error();
+  }
+  const KbView kb = View();
+  BatchPlan plan{};
+  plan.tileTargets = (int)_optBatchTile;
+  HIP_TRY(LaunchEvalBatch(kb, _dBatchSlots, (int)n, &plan, nullptr, nullptr, nullptr, nullptr, 0, tag, true, _stream));
+  auto grow = [&](void **p, size_t &have, size_t need) -> hipError_t {
+    if (need <= have) return hipSuccess;
+    hipStreamSynchronize(_stream);
+    hipFree(*p);
+    *p = nullptr;
+    have = 0;
+    const hipError_t e = hipMalloc(p, need);
+    if (e == hipSuccess) have = need;
+    return e;
+  };
+  HIP_TRY(grow(&_dBatchPT, _batchPTBytes, plan.ptBytes));
+  HIP_TRY(grow((void **)&_dBatchAcc, _batchAccBytes, plan.accBytes));
+  HIP_TRY(grow((void **)&_dBatchRecs, _batchRecBytes, plan.recBytes));
+  if (wantPriorities) HIP_TRY(grow((void **)&_dBatchPriT, _batchPriTBytes, (size_t)_Q * (size_t)plan.Bp * sizeof(double)));
+  HIP_TRY(LaunchEvalBatch(kb, _dBatchSlots, (int)n, &plan, _dBatchPT, _dBatchAcc, _dBatchRecs, wantPriorities ? _dBatchPriT : nullptr, 0, tag,
+                          false, _stream));
+  _lastBatchBp = plan.Bp;
+  return Error();
+}
+
 Error HipEngine::NextQuestionArgmaxBatch(int64_t n, const int64_t *pQuizzes, int64_t *pOut) {
   std::lock_guard<EngineMutex> lk(_mu);
   Error err = CheckRegular("compute next questions");
@@ -754,34 +838,21 @@ Error HipEngine::NextQuestionArgmaxBatch(int64_t n, const int64_t *pQuizzes, int
   if (n == 0) return Error();
   if (!pQuizzes || !pOut) return Error::Make(ErrCode::NullArgument, "Nullptr is passed in place of a batch buffer.");
   hipSetDevice(_device);
-  if (!_hBatch) {  // first batch: staging in host-coherent pinned memory, per-quiz priority vectors, winner records
-    HIP_TRY(hipHostMalloc(&_hBatch, sizeof(BatchPinned), hipHostMallocMapped | hipHostMallocCoherent));
-    std::memset(_hBatch, 0, sizeof(BatchPinned));
-    HIP_TRY(hipMalloc(&_dBatchSlots, kMaxBatch * sizeof(QuizSlot)));
-    HIP_TRY(hipMalloc(&_dBatchScratch, (size_t)kMaxBatch * kBatchGrid * sizeof(SelectResult)));
-    HIP_TRY(hipMemset(_dBatchScratch, 0, (size_t)kMaxBatch * kBatchGrid * sizeof(SelectResult)));
-  }
-  if (_batchPriorityQ != _Q) {  // (re)sized with the knowledge base
-    if (_dBatchPriority) hipFree(_dBatchPriority);
-    _dBatchPriority = nullptr;
-    HIP_TRY(hipMalloc(&_dBatchPriority, (size_t)kMaxBatch * (size_t)_Q * sizeof(double)));
-    _batchPriorityQ = _Q;
-  }
-  std::vector<Quiz *> quizzes((size_t)n);
-  for (int64_t i = 0; i < n; i++) {
-    quizzes[i] = UseQuiz(err, pQuizzes[i]);
-    if (!quizzes[i]) return err;
-    for (int64_t j = 0; j < i; j++)
-      if (pQuizzes[j] == pQuizzes[i])
-        return Error::MakeP(ErrCode::IndexOutOfRange, "quizId=" + std::to_string(pQuizzes[i]), "A quiz appears twice in one batch.");
-    _hBatch->slots[i] = QuizSlot{quizzes[i]->dPrior, quizzes[i]->dAsked, _dBatchPriority + (size_t)i * (size_t)_Q,
-                                 &_hBatch->out[i], &_hBatch->seq[i]};
-  }
   const uint64_t tag = NextLaunchTag();
-  HIP_TRY(hipMemcpyAsync(_dBatchSlots, _hBatch->slots, (size_t)n * sizeof(QuizSlot), hipMemcpyHostToDevice, _stream));
-  const FusedSelect fs{_dBatchScratch, nullptr, nullptr, tag, 0, kBatchGrid, tag, nullptr, 0, 0, nullptr};
-  StopServer();   // a launched sweep has no room beside the resident one and would wait for it to idle out
-  HIP_TRY(LaunchEvalQuestionsBatch(View(), _dBatchSlots, (int)n, 0, _Q, (int)_optEvalVariant, fs, _stream));
+  std::vector<Quiz *> quizzes;
+  err = BatchSweep(n, pQuizzes, quizzes, false, tag);
+  if (!err.ok()) return err;
+  err = WaitBatchFlags(n, tag);
+  if (!err.ok()) return err;
+  for (int64_t i = 0; i < n; i++) {
+    if (_hBatch->out[i].index == -3) return HipErr(hipErrorLaunchFailure, "NextQuestionArgmaxBatch (incomplete sweep)");
+    Error e;
+    pOut[i] = FinishSelection(e, quizzes[i], _hBatch->out[i].index);  // -1 + QuestionsExhausted: reported as -1 only
+  }
+  return Error();
+}
+
+Error HipEngine::WaitBatchFlags(int64_t n, uint64_t tag) {
   const auto t0 = std::chrono::steady_clock::now();
   for (int64_t i = 0; i < n; i++) {
     volatile uint64_t *flag = &_hBatch->seq[i];
@@ -790,19 +861,37 @@ Error HipEngine::NextQuestionArgmaxBatch(int64_t n, const int64_t *pQuizzes, int
       if ((++spins & 0xFFF) == 0) {
         if (hipStreamQuery(_stream) == hipSuccess && *flag != tag) {  // the kernel retired without publishing
           const hipError_t he = hipStreamSynchronize(_stream);
-          if (he != hipSuccess || *flag != tag) return HipErr(he == hipSuccess ? hipErrorUnknown : he, "NextQuestionArgmaxBatch (result flag)");
+          if (he != hipSuccess || *flag != tag) return HipErr(he == hipSuccess ? hipErrorUnknown : he, "batched selection (result flag)");
         }
-        if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(60))
-          return HipErr(hipErrorNotReady, "NextQuestionArgmaxBatch (timeout)");
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(600))
+          return HipErr(hipErrorNotReady, "batched selection (timeout)");
       }
     }
   }
   std::atomic_thread_fence(std::memory_order_acquire);
-  for (int64_t i = 0; i < n; i++) {
-    if (_hBatch->out[i].index == -3) return HipErr(hipErrorLaunchFailure, "NextQuestionArgmaxBatch (incomplete sweep)");
-    Error e;
-    pOut[i] = FinishSelection(e, quizzes[i], _hBatch->out[i].index);  // -1 + QuestionsExhausted: reported as -1 only
-  }
+  return Error();
+}
+
+// The priority vectors of n quizzes from ONE row-sharing sweep: pOut[i * Q + q] = priority of local question q for quiz
+// pQuizzes[i] (0 for gap / asked questions).  The deterministic output of the batched path, for parity checks.
+Error HipEngine::EvalPrioritiesBatch(int64_t n, const int64_t *pQuizzes, double *pOut) {
+  std::lock_guard<EngineMutex> lk(_mu);
+  Error err = CheckRegular("compute next questions");
+  if (!err.ok()) return err;
+  if (n < 0 || n > kMaxBatch)
+    return Error::MakeP(ErrCode::IndexOutOfRange, RangeParams(n, 0, kMaxBatch), "Batch size is out of range.");
+  if (n == 0) return Error();
+  if (!pQuizzes || !pOut) return Error::Make(ErrCode::NullArgument, "Nullptr is passed in place of a batch buffer.");
+  hipSetDevice(_device);
+  const uint64_t tag = NextLaunchTag();
+  std::vector<Quiz *> quizzes;
+  err = BatchSweep(n, pQuizzes, quizzes, true, tag);
+  if (!err.ok()) return err;
+  std::vector<double> host((size_t)_Q * (size_t)_lastBatchBp);
+  HIP_TRY(hipMemcpyAsync(host.data(), _dBatchPriT, host.size() * sizeof(double), hipMemcpyDeviceToHost, _stream));
+  HIP_TRY(hipStreamSynchronize(_stream));
+  for (int64_t i = 0; i < n; i++)
+    for (int64_t q = 0; q < _Q; q++) pOut[(size_t)i * (size_t)_Q + (size_t)q] = host[(size_t)q * (size_t)_lastBatchBp + (size_t)i];
   return Error();
 }
 
@@ -862,7 +951,7 @@ int64_t HipEngine::NextQuestionSampled(Error &err, int64_t iQuiz, uint64_t rnd) 
   const KbView kb = View();
   const int64_t nSub = _optEvalSubtasks ? _optEvalSubtasks : 8 * _optWorkers;  // reference PqaCore/CpuEngine.cpp:339
   StopServer();   // a launched sweep has no room beside the resident one and would wait for it to idle out
-  if (_optFusedSampled && EvalVariantFusesSampled(kb, (int)_optEvalVariant, nSub)) {
+  if (_optFusedSampled && _elem == 8 && EvalVariantFusesSampled(kb, (int)_optEvalVariant, nSub)) {
     // ONE launch: the sweep's finisher workgroup runs the reference's selector once every workgroup has reported
     const uint64_t seq = NextLaunchTag();
     const FusedSelect fs{_dSelScratch, &_hPinned->sel, &_hPinned->seq, seq, 0, 0, seq, nullptr, nSub, rnd, _dRunLength};
@@ -873,7 +962,9 @@ int64_t HipEngine::NextQuestionSampled(Error &err, int64_t iQuiz, uint64_t rnd) 
     if (_hPinned->sel.index == -3) { err = HipErr(hipErrorLaunchFailure, "NextQuestionSampled (incomplete sweep)"); return -1; }
     return FinishSelection(err, q, _hPinned->sel.index);
   }
-  hipError_t he = LaunchEvalQuestions(kb, q->dPrior, q->dAsked, 0, _Q, _dPriority, (int)_optEvalVariant, nullptr, _stream);
+  err = LaunchSingleSweep(q, nullptr);
+  if (!err.ok()) return -1;
+  hipError_t he = hipSuccess;
   const uint64_t op = ++_opSeq;  // the selector writes its record and then this number into host-coherent memory
   if (he == hipSuccess)
     he = LaunchSelectSampled(_dPriority, _dQGap, q->dAsked, 0, _Q, nSub, rnd, _dRunLength, &_hPinned->sel, &_hPinned->opFlag,
@@ -901,7 +992,8 @@ Error HipEngine::EvalPriorities(int64_t iQuiz, double *pOut, int64_t n) {
   if (n != _Q) return Error::MakeP(ErrCode::IndexOutOfRange, RangeParams(n, _Q, _Q), "Priority buffer length must equal the local question count.");
   hipSetDevice(_device);
   StopServer();   // a launched sweep has no room beside the resident one and would wait for it to idle out
-  HIP_TRY(LaunchEvalQuestions(View(), q->dPrior, q->dAsked, 0, _Q, _dPriority, (int)_optEvalVariant, nullptr, _stream));
+  err = LaunchSingleSweep(q, nullptr);
+  if (!err.ok()) return err;
   HIP_TRY(hipMemcpyAsync(pOut, _dPriority, (size_t)_Q * sizeof(double), hipMemcpyDeviceToHost, _stream));
   HIP_TRY(hipStreamSynchronize(_stream));
   return Error();
@@ -1108,11 +1200,11 @@ Error HipEngine::Train(int64_t nQuestions, const AQ *pAQs, int64_t iTarget, doub
   }
   if (nLocal > 0) HIP_TRY(hipMemcpyAsync(_dAqs, local.data(), local.size() * sizeof(int64_t), hipMemcpyHostToDevice, _stream));
   if (!dup) {
-    HIP_TRY(LaunchTrain(_dCube, _dVB, _K, _ldT, _dAqs, nLocal, iTarget, amount, _stream));
+    HIP_TRY(LaunchTrain(_dCube, _elem, _dVB, _K, _ldT, _dAqs, nLocal, iTarget, amount, _stream));
   } else {
     // duplicate questions: apply one by one in the given order (each step is the reference's Perform1); vB once
     for (int64_t i = 0; i < nLocal; i++)
-      HIP_TRY(LaunchTrain(_dCube, _dVB, _K, _ldT, _dAqs + 2 * i, 1, iTarget, i == 0 ? amount : 0.0, _stream));
+      HIP_TRY(LaunchTrain(_dCube, _elem, _dVB, _K, _ldT, _dAqs + 2 * i, 1, iTarget, i == 0 ? amount : 0.0, _stream));
   }
   HIP_TRY(hipStreamSynchronize(_stream));
   _nQuestionsAsked.fetch_add((uint64_t)nQuestions, std::memory_order_relaxed);  // reference CpuEngine.cpp:176
@@ -1227,13 +1319,25 @@ Error HipEngine::SetKB(const double *pA, const double *pD, const double *pB) {
   StopServer();
   if (!pA || !pD || !pB) return Error::Make(ErrCode::NullArgument, "Nullptr is passed in place of a KB array.");
   hipSetDevice(_device);
-  const size_t rowB = (size_t)_T * sizeof(double), ldB = (size_t)_ldT * sizeof(double);
+  const size_t el = (size_t)_elem, rowB = (size_t)_T * el, ldB = (size_t)_ldT * el;
+  // Float engines: the fp64 arrays are rounded to fp32 on the way in (a question's rows at a time through a staging buffer)
+  std::vector<float> stage;
+  if (_elem == 4) stage.resize((size_t)(_K + 1) * (size_t)_T);
   for (int64_t q = 0; q < _Q; q++) {
-    HIP_TRY(hipMemcpy2DAsync(_dCube + (size_t)q * (_K + 1) * _ldT, ldB, pA + (size_t)q * _K * _T, rowB, rowB, (size_t)_K,
-                             hipMemcpyHostToDevice, _stream));
+    const void *srcA = pA + (size_t)q * _K * _T, *srcD = pD + (size_t)q * _T;
+    if (_elem == 4) {
+      HIP_TRY(hipStreamSynchronize(_stream));   // the staging buffer is reused
+      for (size_t i = 0; i < (size_t)_K * (size_t)_T; i++) stage[i] = (float)pA[(size_t)q * _K * _T + i];
+      for (size_t i = 0; i < (size_t)_T; i++) stage[(size_t)_K * _T + i] = (float)pD[(size_t)q * _T + i];
+      srcA = stage.data();
+      srcD = stage.data() + (size_t)_K * _T;
+    }
+    HIP_TRY(hipMemcpy2DAsync(CubeAt(q), ldB, srcA, rowB, rowB, (size_t)_K, hipMemcpyHostToDevice, _stream));
+    HIP_TRY(hipMemcpyAsync(CubeAt(q, _K), srcD, rowB, hipMemcpyHostToDevice, _stream));
   }
-  HIP_TRY(hipMemcpy2DAsync(_dCube + (size_t)_K * _ldT, ldB * (size_t)(_K + 1), pD, rowB, rowB, (size_t)_Q, hipMemcpyHostToDevice, _stream));
-  HIP_TRY(hipMemcpyAsync(_dVB, pB, rowB, hipMemcpyHostToDevice, _stream));
+  std::vector<double> vb(pB, pB + _T);
+  if (_elem == 4) for (double &b : vb) b = (double)(float)b;   // vB is kept as fp64 words holding the engine's number type
+  HIP_TRY(hipMemcpyAsync(_dVB, vb.data(), (size_t)_T * sizeof(double), hipMemcpyHostToDevice, _stream));
   HIP_TRY(hipStreamSynchronize(_stream));
   return Error();
 }
@@ -1241,13 +1345,21 @@ Error HipEngine::SetKB(const double *pA, const double *pD, const double *pB) {
 Error HipEngine::GetKB(double *pA, double *pD, double *pB) {
   std::lock_guard<EngineMutex> lk(_mu);
   hipSetDevice(_device);
-  const size_t rowB = (size_t)_T * sizeof(double), ldB = (size_t)_ldT * sizeof(double);
-  if (pA)
-    for (int64_t q = 0; q < _Q; q++)
-      HIP_TRY(hipMemcpy2DAsync(pA + (size_t)q * _K * _T, rowB, _dCube + (size_t)q * (_K + 1) * _ldT, ldB, rowB, (size_t)_K,
-                               hipMemcpyDeviceToHost, _stream));
-  if (pD) HIP_TRY(hipMemcpy2DAsync(pD, rowB, _dCube + (size_t)_K * _ldT, ldB * (size_t)(_K + 1), rowB, (size_t)_Q, hipMemcpyDeviceToHost, _stream));
-  if (pB) HIP_TRY(hipMemcpyAsync(pB, _dVB, rowB, hipMemcpyDeviceToHost, _stream));
+  const size_t el = (size_t)_elem, rowB = (size_t)_T * el, ldB = (size_t)_ldT * el;
+  std::vector<float> stage;
+  if (_elem == 4) stage.resize((size_t)(_K + 1) * (size_t)_T);
+  for (int64_t q = 0; q < _Q; q++) {
+    if (_elem == 8) {
+      if (pA) HIP_TRY(hipMemcpy2DAsync(pA + (size_t)q * _K * _T, rowB, CubeAt(q), ldB, rowB, (size_t)_K, hipMemcpyDeviceToHost, _stream));
+      if (pD) HIP_TRY(hipMemcpyAsync(pD + (size_t)q * _T, CubeAt(q, _K), rowB, hipMemcpyDeviceToHost, _stream));
+    } else {
+      HIP_TRY(hipMemcpy2DAsync(stage.data(), rowB, CubeAt(q), ldB, rowB, (size_t)(_K + 1), hipMemcpyDeviceToHost, _stream));
+      HIP_TRY(hipStreamSynchronize(_stream));
+      if (pA) for (size_t i = 0; i < (size_t)_K * (size_t)_T; i++) pA[(size_t)q * _K * _T + i] = (double)stage[i];
+      if (pD) for (size_t i = 0; i < (size_t)_T; i++) pD[(size_t)q * _T + i] = (double)stage[(size_t)_K * _T + i];
+    }
+  }
+  if (pB) HIP_TRY(hipMemcpyAsync(pB, _dVB, (size_t)_T * sizeof(double), hipMemcpyDeviceToHost, _stream));
   HIP_TRY(hipStreamSynchronize(_stream));
   return Error();
 }
@@ -1256,7 +1368,7 @@ Error HipEngine::FillSynthetic(double nTrain, double noiseAmp, uint64_t seed) {
   std::lock_guard<EngineMutex> lk(_mu);
   StopServer();
   hipSetDevice(_device);
-  HIP_TRY(LaunchFillSynthetic(_dCube, _dVB, _K, _Q, _T, _ldT, _qFirst, _qTotal, _initAmount, nTrain, noiseAmp, seed, _stream));
+  HIP_TRY(LaunchFillSynthetic(_dCube, _elem, _dVB, _K, _Q, _T, _ldT, _qFirst, _qTotal, _initAmount, nTrain, noiseAmp, seed, _stream));
   HIP_TRY(hipStreamSynchronize(_stream));
   return Error();
 }

@@ -128,6 +128,7 @@ class HipEngine {
   Error GetPriors(int64_t iQuiz, double *pOut, int64_t n);
   int64_t NextQuestionArgmaxGraph(Error &err, Quiz *q);
   Error NextQuestionArgmaxBatch(int64_t n, const int64_t *pQuizzes, int64_t *pOut);
+  Error EvalPrioritiesBatch(int64_t n, const int64_t *pQuizzes, double *pOut);   // pOut[i][q], q < local question count
   Error Log2HotArray(const double *pIn, double *pOut, int64_t n);  // device log2hot over an array (tests)
   hipStream_t GetStream() const { return _stream; }
   Error SetStream(hipStream_t s);
@@ -162,7 +163,15 @@ class HipEngine {
   double _initAmount = 1;
   int _device = 0;
   hipStream_t _stream = nullptr, _ownStream = nullptr;
-  double *_dCube = nullptr, *_dVB = nullptr, *_dPriority = nullptr, *_dRunLength = nullptr;
+  // the cube: [Q][K+1][ldT] elements of _elem bytes -- double for Double engines, float for Float engines (reference
+  // PqaCore/Interface/PqaCommon.h:17-24; the reference instantiates Float for its GPU engine, PqaEngineBaseFactory.cpp:124-142).
+  // Everything else (vB, the quizzes' posteriors, priorities) is fp64 in both.
+  char *_dCube = nullptr;
+  int _elem = 8;
+  uint8_t _precType = 3;
+  char *CubeAt(int64_t q, int64_t row = 0) const { return _dCube + ((size_t)(q * (_K + 1) + row) * (size_t)_ldT) * (size_t)_elem; }
+  static int64_t RoundLdT(int64_t T, int elem) { const int64_t m = 128 / elem; return ((T + m - 1) / m) * m; }   // rows start on 128-byte lines
+  double *_dVB = nullptr, *_dPriority = nullptr, *_dRunLength = nullptr;
   uint32_t *_dTGap = nullptr, *_dQGap = nullptr;
   int64_t *_dExps = nullptr, *_dAqs = nullptr, *_dStatus = nullptr, *_dNOut = nullptr;
   int64_t _aqCapacity = 0;
@@ -203,6 +212,13 @@ class HipEngine {
   SelectResult *_dBatchScratch = nullptr;
   double *_dBatchPriority = nullptr;
   int64_t _batchPriorityQ = -1;
+  // the row-sharing batched sweep (batch_kernels.hip): scratch sized by its plan, grown on demand
+  void *_dBatchPT = nullptr; double *_dBatchAcc = nullptr; BatchRecord *_dBatchRecs = nullptr; double *_dBatchPriT = nullptr;
+  size_t _batchPTBytes = 0, _batchAccBytes = 0, _batchRecBytes = 0, _batchPriTBytes = 0;
+  Error BatchSweep(int64_t n, const int64_t *pQuizzes, std::vector<Quiz *> &quizzes, bool wantPriorities, uint64_t tag);
+  Error WaitBatchFlags(int64_t n, uint64_t tag);
+  int _lastBatchBp = 0;
+  Error LaunchSingleSweep(Quiz *q, const FusedSelect *fused);   // the single-quiz sweep of this engine's precision, on _stream
   uint64_t _selSeq = 0;
   // Tag of the next fused launch: consecutive launches differ in the low 32 bits, and those are never 0 (the state of
   // freshly cleared records)
@@ -238,6 +254,8 @@ class HipEngine {
   int64_t _optFusedSampled = 0;   // the sampled NextQuestion as ONE launch (the sweep's finisher workgroup runs the selector): correct,
                                   // but 38.3 vs 36.4 us at 1000 x 5 x 1000 -- one workgroup's serial selection costs more than a launch
   int64_t _optEvalMaxGrid = 0;    // test hook: KbView::maxGrid
+  int64_t _optBatchMin = 32;      // batches of at least this many quizzes take the row-sharing sweep (lane = quiz); smaller ones grid.y = quiz
+  int64_t _optBatchTile = 0;      // targets per LDS tile of that sweep (0 = default)
   int64_t _optUseGraph = 0;   // NextQuestion (argmax) replays a per-quiz HIP graph instead of launching
   int64_t _optTopCache = 10;  // targets RecordAnswer's kernel lists ahead of the ListTopTargets that follows it (0: none)
   // ---- resident sweep (option "server"; pqa_kernels.h: ServerMailbox)

@@ -237,38 +237,46 @@ Error HipEngine::SaveKB(const char *filePath, bool doubleBuffer) {
   if (!fc.f)
     return Error::MakeP(ErrCode::CantOpenFile, std::string("filePath=[") + filePath + "]", "Can't open the file to write KB to.");
   hipSetDevice(_device);
-  const uint64_t prec = PackPrecision(3 /*Double*/, _precMantissa, _precExponent);
+  const uint64_t prec = PackPrecision(_precType, _precMantissa, _precExponent);   // Double | Float: the element type of the arrays below
   const int64_t dims[3] = {_K, _Q, _T};
   const uint64_t nAsked = _nQuestionsAsked.load(std::memory_order_acquire);
   if (std::fwrite(&prec, 8, 1, fc.f) != 1) return FileErr(filePath, "Can't write precision definition header.");
   if (std::fwrite(dims, sizeof(dims), 1, fc.f) != 1) return FileErr(filePath, "Can't write engine dimensions header.");
   if (std::fwrite(&nAsked, 8, 1, fc.f) != 1) return FileErr(filePath, "Can't write the number of questions asked.");
   // statistics: a bounded host staging buffer, one batch of questions at a time
-  const size_t rowB = (size_t)_T * sizeof(double), ldB = (size_t)_ldT * sizeof(double);
+  const size_t rowB = (size_t)_T * (size_t)_elem, ldB = (size_t)_ldT * (size_t)_elem;
   const int64_t batch = std::max<int64_t>(1, (int64_t)((64u << 20) / (rowB * (size_t)_K)));
-  std::vector<double> host((size_t)std::min(batch, _Q) * (size_t)_K * (size_t)_T);
+  std::vector<char> host((size_t)std::min(batch, _Q) * (size_t)_K * rowB);
   for (int64_t q0 = 0; q0 < _Q; q0 += batch) {
     const int64_t nq = std::min(batch, _Q - q0);
     for (int64_t q = 0; q < nq; q++)
-      HIP_TRY(hipMemcpy2DAsync(host.data() + (size_t)q * _K * _T, rowB, _dCube + (size_t)(q0 + q) * (_K + 1) * _ldT, ldB, rowB,
+      HIP_TRY(hipMemcpy2DAsync(host.data() + (size_t)q * _K * rowB, rowB, CubeAt(q0 + q), ldB, rowB,
                                (size_t)_K, hipMemcpyDeviceToHost, _stream));
     HIP_TRY(hipStreamSynchronize(_stream));
     if (std::fwrite(host.data(), rowB, (size_t)(nq * _K), fc.f) != (size_t)(nq * _K))
       return FileErr(filePath, "Can't write the target dimension of _sA weights.");
   }
-  host.resize((size_t)std::min<int64_t>(batch * _K, _Q) * (size_t)_T);
+  host.resize((size_t)std::min<int64_t>(batch * _K, _Q) * rowB);
   for (int64_t q0 = 0; q0 < _Q; q0 += batch * _K) {
     const int64_t nq = std::min(batch * _K, _Q - q0);
-    HIP_TRY(hipMemcpy2DAsync(host.data(), rowB, _dCube + (size_t)q0 * (_K + 1) * _ldT + (size_t)_K * _ldT, ldB * (size_t)(_K + 1), rowB,
+    HIP_TRY(hipMemcpy2DAsync(host.data(), rowB, CubeAt(q0, _K), ldB * (size_t)(_K + 1), rowB,
                              (size_t)nq, hipMemcpyDeviceToHost, _stream));
     HIP_TRY(hipStreamSynchronize(_stream));
     if (std::fwrite(host.data(), rowB, (size_t)nq, fc.f) != (size_t)nq)
       return FileErr(filePath, "Can't write the target dimension of _mD weights.");
   }
-  host.resize((size_t)_T);
-  HIP_TRY(hipMemcpyAsync(host.data(), _dVB, rowB, hipMemcpyDeviceToHost, _stream));
-  HIP_TRY(hipStreamSynchronize(_stream));
-  if (std::fwrite(host.data(), rowB, 1, fc.f) != 1) return FileErr(filePath, "Can't write the _vB weights.");
+  {
+    std::vector<double> vb((size_t)_T);   // vB is fp64 on the device in both precisions; the file holds the engine's number type
+    HIP_TRY(hipMemcpyAsync(vb.data(), _dVB, (size_t)_T * sizeof(double), hipMemcpyDeviceToHost, _stream));
+    HIP_TRY(hipStreamSynchronize(_stream));
+    bool ok;
+    if (_elem == 8) ok = std::fwrite(vb.data(), sizeof(double), (size_t)_T, fc.f) == (size_t)_T;
+    else {
+      std::vector<float> vf(vb.begin(), vb.end());
+      ok = std::fwrite(vf.data(), sizeof(float), (size_t)_T, fc.f) == (size_t)_T;
+    }
+    if (!ok) return FileErr(filePath, "Can't write the _vB weights.");
+  }
   auto writeGaps = [&](const std::vector<int64_t> &gaps) {
     const int64_t n = (int64_t)gaps.size();
     return std::fwrite(&n, 8, 1, fc.f) == 1 && std::fwrite(gaps.data(), 8, (size_t)n, fc.f) == (size_t)n;
@@ -309,32 +317,38 @@ HipEngine *HipEngine::Load(Error &err, const char *filePath) {  // PqaEngineBase
   HipEngine &e = *eng;
   auto fail = [&](Error x) { err = std::move(x); return (HipEngine *)nullptr; };
   hipSetDevice(e._device);
-  const size_t rowB = (size_t)e._T * sizeof(double), ldB = (size_t)e._ldT * sizeof(double);
+  const size_t rowB = (size_t)e._T * (size_t)e._elem, ldB = (size_t)e._ldT * (size_t)e._elem;
   const int64_t batch = std::max<int64_t>(1, (int64_t)((64u << 20) / (rowB * (size_t)e._K)));
-  std::vector<double> host((size_t)std::min(batch, e._Q) * (size_t)e._K * (size_t)e._T);
+  std::vector<char> host((size_t)std::min(batch, e._Q) * (size_t)e._K * rowB);
   for (int64_t q0 = 0; q0 < e._Q; q0 += batch) {
     const int64_t nq = std::min(batch, e._Q - q0);
     if (std::fread(host.data(), rowB, (size_t)(nq * e._K), fc.f) != (size_t)(nq * e._K))
       return fail(FileErr(filePath, "Can't read the target dimension of _sA weights."));
     for (int64_t q = 0; q < nq; q++)
-      if (hipMemcpy2DAsync(e._dCube + (size_t)(q0 + q) * (e._K + 1) * e._ldT, ldB, host.data() + (size_t)q * e._K * e._T, rowB, rowB,
+      if (hipMemcpy2DAsync(e.CubeAt(q0 + q), ldB, host.data() + (size_t)q * e._K * rowB, rowB, rowB,
                            (size_t)e._K, hipMemcpyHostToDevice, e._stream) != hipSuccess)
         return fail(Error::Make(ErrCode::Internal, "HIP copy of _sA failed."));
     if (hipStreamSynchronize(e._stream) != hipSuccess) return fail(Error::Make(ErrCode::Internal, "HIP sync failed."));
   }
-  host.resize((size_t)std::min<int64_t>(batch * e._K, e._Q) * (size_t)e._T);
+  host.resize((size_t)std::min<int64_t>(batch * e._K, e._Q) * rowB);
   for (int64_t q0 = 0; q0 < e._Q; q0 += batch * e._K) {
     const int64_t nq = std::min(batch * e._K, e._Q - q0);
     if (std::fread(host.data(), rowB, (size_t)nq, fc.f) != (size_t)nq)
       return fail(FileErr(filePath, "Can't read the target dimension of _mD weights."));
-    if (hipMemcpy2DAsync(e._dCube + (size_t)q0 * (e._K + 1) * e._ldT + (size_t)e._K * e._ldT, ldB * (size_t)(e._K + 1), host.data(), rowB,
+    if (hipMemcpy2DAsync(e.CubeAt(q0, e._K), ldB * (size_t)(e._K + 1), host.data(), rowB,
                          rowB, (size_t)nq, hipMemcpyHostToDevice, e._stream) != hipSuccess ||
         hipStreamSynchronize(e._stream) != hipSuccess)
       return fail(Error::Make(ErrCode::Internal, "HIP copy of _mD failed."));
   }
-  host.resize((size_t)e._T);
-  if (std::fread(host.data(), rowB, 1, fc.f) != 1) return fail(FileErr(filePath, "Can't read the _vB weights."));
-  if (hipMemcpyAsync(e._dVB, host.data(), rowB, hipMemcpyHostToDevice, e._stream) != hipSuccess ||
+  std::vector<double> vb((size_t)e._T);
+  if (e._elem == 8) {
+    if (std::fread(vb.data(), sizeof(double), (size_t)e._T, fc.f) != (size_t)e._T) return fail(FileErr(filePath, "Can't read the _vB weights."));
+  } else {
+    std::vector<float> vf((size_t)e._T);
+    if (std::fread(vf.data(), sizeof(float), (size_t)e._T, fc.f) != (size_t)e._T) return fail(FileErr(filePath, "Can't read the _vB weights."));
+    std::copy(vf.begin(), vf.end(), vb.begin());
+  }
+  if (hipMemcpyAsync(e._dVB, vb.data(), (size_t)e._T * sizeof(double), hipMemcpyHostToDevice, e._stream) != hipSuccess ||
       hipStreamSynchronize(e._stream) != hipSuccess)
     return fail(Error::Make(ErrCode::Internal, "HIP copy of _vB failed."));
   e._nQuestionsAsked.store(nAsked);
@@ -363,44 +377,65 @@ HipEngine *HipEngine::Load(Error &err, const char *filePath) {  // PqaEngineBase
 // ------------------------------------------------------------------------------------------------------------------
 // maintenance-mode operations
 // ------------------------------------------------------------------------------------------------------------------
+namespace {
+// device allocation that is freed unless released: every buffer of a resize exists before the first one is committed
+template <typename T>
+struct DevBuf {
+  T *p = nullptr;
+  ~DevBuf() { if (p) hipFree(p); }
+  hipError_t Alloc(size_t bytes) { return hipMalloc(reinterpret_cast<void **>(&p), bytes); }
+  T *Release() { T *r = p; p = nullptr; return r; }
+};
+}  // namespace
+
+// Grow the knowledge base to newQ questions and newT targets.  All-or-nothing: every new buffer is allocated and filled
+// before the engine's members change, so a failure (out of memory while the old and the new cube coexist) leaves the engine
+// as it was.
 Error HipEngine::ReallocKB(int64_t newQ, int64_t newT) {
-  const int64_t newLdT = std::max(_ldT, ((newT + 15) / 16) * 16);
+  const int64_t newLdT = std::max(_ldT, RoundLdT(newT, _elem));
   const int64_t newCap = std::max(_capQ, newQ);
-  if (newLdT != _ldT || newCap != _capQ) {
-    double *cube = nullptr, *vB = nullptr;
-    HIP_TRY(hipMalloc(&cube, (size_t)newCap * (size_t)(_K + 1) * (size_t)newLdT * sizeof(double)));
-    HIP_TRY(hipMalloc(&vB, (size_t)newLdT * sizeof(double)));
-    // old rows keep their content; new padding columns get A = 0, D = 1 from the fill of new questions / a plain fill
-    HIP_TRY(LaunchFillFresh(cube, vB, _K, newCap, 0, newLdT, 0.0, _stream));  // T = 0: every column is "padding"
-    HIP_TRY(hipMemcpy2DAsync(cube, (size_t)newLdT * sizeof(double), _dCube, (size_t)_ldT * sizeof(double), (size_t)_T * sizeof(double),
-                             (size_t)_Q * (size_t)(_K + 1), hipMemcpyDeviceToDevice, _stream));
-    HIP_TRY(hipMemcpyAsync(vB, _dVB, (size_t)_T * sizeof(double), hipMemcpyDeviceToDevice, _stream));
-    HIP_TRY(hipStreamSynchronize(_stream));
-    hipFree(_dCube); hipFree(_dVB);
-    _dCube = cube; _dVB = vB;
-    if (newLdT != _ldT) {
-      hipFree(_dExps); _dExps = nullptr;
-      HIP_TRY(hipMalloc(&_dExps, (size_t)newLdT * sizeof(int64_t)));
-    }
-    if (newCap != _capQ) {
-      hipFree(_dPriority); hipFree(_dRunLength); _dPriority = _dRunLength = nullptr;
-      HIP_TRY(hipMalloc(&_dPriority, (size_t)newCap * sizeof(double)));
-      HIP_TRY(hipMalloc(&_dRunLength, (size_t)newCap * sizeof(double)));
-    }
-    _ldT = newLdT;
-    _capQ = newCap;
-  }
+  const bool regrow = newLdT != _ldT || newCap != _capQ;
+  DevBuf<char> cube;
+  DevBuf<double> vB, priority, runLength;
+  DevBuf<int64_t> exps;
+  DevBuf<uint32_t> tgapDev, qgapDev;
   // bitmaps: keep the old bits, new positions are not gaps, everything past the size is
-  std::vector<uint32_t> tg(BitWords(_ldT), 0), qg(BitWords(newQ), 0);
+  std::vector<uint32_t> tg(BitWords(newLdT), 0), qg(BitWords(newQ), 0);
   for (int64_t t = 0; t < _T; t++) if (BitTest(_hTGap, t)) BitSet(tg, t, true);
   for (int64_t t = newT; t < (int64_t)tg.size() * 32; t++) BitSet(tg, t, true);
   for (int64_t q = 0; q < _Q; q++) if (BitTest(_hQGap, q)) BitSet(qg, q, true);
   for (int64_t q = newQ; q < (int64_t)qg.size() * 32; q++) BitSet(qg, q, true);
+  HIP_TRY(tgapDev.Alloc(tg.size() * sizeof(uint32_t)));
+  HIP_TRY(qgapDev.Alloc(qg.size() * sizeof(uint32_t)));
+  if (regrow) {
+    const size_t el = (size_t)_elem;
+    HIP_TRY(cube.Alloc((size_t)newCap * (size_t)(_K + 1) * (size_t)newLdT * el));
+    HIP_TRY(vB.Alloc((size_t)newLdT * sizeof(double)));
+    if (newLdT != _ldT) HIP_TRY(exps.Alloc((size_t)newLdT * sizeof(int64_t)));
+    if (newCap != _capQ) {
+      HIP_TRY(priority.Alloc((size_t)newCap * sizeof(double)));
+      HIP_TRY(runLength.Alloc((size_t)newCap * sizeof(double)));
+    }
+    // old rows keep their content; new padding columns get A = 0, D = 1 from the fill of new questions / a plain fill
+    HIP_TRY(LaunchFillFresh(cube.p, _elem, vB.p, _K, newCap, 0, newLdT, 0.0, _stream));  // T = 0: every column is "padding"
+    HIP_TRY(hipMemcpy2DAsync(cube.p, (size_t)newLdT * el, _dCube, (size_t)_ldT * el, (size_t)_T * el,
+                             (size_t)_Q * (size_t)(_K + 1), hipMemcpyDeviceToDevice, _stream));
+    HIP_TRY(hipMemcpyAsync(vB.p, _dVB, (size_t)_T * sizeof(double), hipMemcpyDeviceToDevice, _stream));
+    HIP_TRY(hipStreamSynchronize(_stream));
+  }
+  // ---- commit (nothing below can fail except the bitmap upload, which leaves host and device views consistent in shape)
+  if (regrow) {
+    hipFree(_dCube); hipFree(_dVB);
+    _dCube = cube.Release(); _dVB = vB.Release();
+    if (exps.p) { hipFree(_dExps); _dExps = exps.Release(); }
+    if (priority.p) { hipFree(_dPriority); hipFree(_dRunLength); _dPriority = priority.Release(); _dRunLength = runLength.Release(); }
+    _ldT = newLdT;
+    _capQ = newCap;
+  }
   _hTGap.swap(tg);
   _hQGap.swap(qg);
-  hipFree(_dTGap); hipFree(_dQGap); _dTGap = _dQGap = nullptr;
-  HIP_TRY(hipMalloc(&_dTGap, _hTGap.size() * sizeof(uint32_t)));
-  HIP_TRY(hipMalloc(&_dQGap, _hQGap.size() * sizeof(uint32_t)));
+  hipFree(_dTGap); hipFree(_dQGap);
+  _dTGap = tgapDev.Release(); _dQGap = qgapDev.Release();
   _Q = newQ;
   _qTotal = newQ;
   _T = newT;
@@ -416,69 +451,85 @@ Error HipEngine::AddQsTs(int64_t nQuestions, CiAddQorTParam *pAqps, int64_t nTar
   if ((nQuestions > 0 && !pAqps) || (nTargets > 0 && !pAtps)) return Error::Make(ErrCode::NullArgument, "Nullptr parameters array.");
   if (_qFirst != 0 || _qTotal != _Q) return Error::MakeP(ErrCode::NotImplemented, "Feature=AddQsTs on a shard", "Not on a sharded engine.");
   hipSetDevice(_device);
-  // CpuEngine::AddQsTsSpec, reference PqaCore/CpuEngine.cpp:468-575
+  // CpuEngine::AddQsTsSpec, reference PqaCore/CpuEngine.cpp:468-575.  The ids are worked out first and committed -- gap
+  // lists, permanent ids, bitmaps, the caller's _index fields -- only after the resize and the fills have succeeded.
   const int64_t nQReuse = std::min<int64_t>(nQuestions, (int64_t)_questionGapList.size()), nQNew = nQuestions - nQReuse;
   const int64_t nTReuse = std::min<int64_t>(nTargets, (int64_t)_targetGapList.size()), nTNew = nTargets - nTReuse;
   const int64_t nQOld = _Q, nTOld = _T;
   std::vector<int64_t> qIds, tIds;
   std::vector<double> qInit, tInit;
-  for (int64_t i = 0; i < nQReuse; i++) {            // :476-482 gaps are reused LIFO
-    const int64_t curQ = _questionGapList.back();
+  for (int64_t i = 0; i < nQReuse; i++) qIds.push_back(_questionGapList[_questionGapList.size() - 1 - (size_t)i]);   // :476-482 gaps are reused LIFO
+  for (int64_t i = 0; i < nTReuse; i++) tIds.push_back(_targetGapList[_targetGapList.size() - 1 - (size_t)i]);       // :488-493
+  for (int64_t i = 0; i < nQNew; i++) qIds.push_back(nQOld + i);   // :500
+  // NOTE reference :516,:523,:529 index the target parameters with nQReuse + j; the evident intent nTReuse + j is used
+  for (int64_t j = 0; j < nTNew; j++) tIds.push_back(nTOld + j);    // :531
+  for (int64_t i = 0; i < nQuestions; i++) qInit.push_back(pAqps[i]._initAmount);
+  for (int64_t j = 0; j < nTargets; j++) tInit.push_back(pAtps[j]._initAmount);
+  // whole questions first, then target columns over the questions not (re)initialised just now
+  std::vector<uint32_t> skip(BitWords(nQOld + nQNew), 0);
+  for (int64_t i = 0; i < nQReuse; i++) BitSet(skip, qIds[(size_t)i], true);    // :558-560 only reused questions are skipped
+  DevBuf<int64_t> dQ, dT;
+  DevBuf<double> dQi, dTi;
+  DevBuf<uint32_t> dSkip;
+  HIP_TRY(Upload(&dQ.p, qIds, _stream));
+  HIP_TRY(Upload(&dQi.p, qInit, _stream));
+  HIP_TRY(Upload(&dT.p, tIds, _stream));
+  HIP_TRY(Upload(&dTi.p, tInit, _stream));
+  HIP_TRY(Upload(&dSkip.p, skip, _stream));
+  Error e = ReallocKB(nQOld + nQNew, nTOld + nTNew);   // all-or-nothing; the reused ids are still flagged as gaps
+  if (!e.ok()) return e;
+  // new target columns apply to every old question (:512-527); reused target columns skip reused questions (:553-567).
+  // New questions are filled over ALL columns with their own amount (:497-510), so they are filled last.
+  hipError_t he = hipSuccess;
+  if (nTReuse > 0) he = LaunchFillTargets(_dCube, _elem, _dVB, _K, _ldT, nQOld, dSkip.p, dT.p, dTi.p, nTReuse, _stream);
+  if (he == hipSuccess && nTNew > 0) he = LaunchFillTargets(_dCube, _elem, _dVB, _K, _ldT, nQOld, nullptr, dT.p + nTReuse, dTi.p + nTReuse, nTNew, _stream);
+  if (he == hipSuccess && nQuestions > 0) he = LaunchFillQuestions(_dCube, _elem, _K, _T, _ldT, dQ.p, dQi.p, nQuestions, _stream);
+  if (he == hipSuccess) he = hipStreamSynchronize(_stream);
+  if (he != hipSuccess) {   // (a failed launch: the device is gone) keep the id maps the size of the grown KB
+    _pimQuestions.GrowTo(_Q);
+    _pimTargets.GrowTo(_T);
+    return HipErr(he, "AddQsTs");
+  }
+  // ---- commit
+  for (int64_t i = 0; i < nQReuse; i++) {
+    const int64_t curQ = qIds[(size_t)i];
     _questionGapList.pop_back();
     BitSet(_hQGap, curQ, false);
     _pimQuestions.RenewComp(curQ);
-    pAqps[i]._index = curQ;
   }
-  for (int64_t i = 0; i < nTReuse; i++) {            // :488-493
-    const int64_t curT = _targetGapList.back();
+  for (int64_t i = 0; i < nTReuse; i++) {
+    const int64_t curT = tIds[(size_t)i];
     _targetGapList.pop_back();
     BitSet(_hTGap, curT, false);
     _nTargetGaps--;
     _pimTargets.RenewComp(curT);
-    pAtps[i]._index = curT;
   }
-  for (int64_t i = 0; i < nQNew; i++) pAqps[nQReuse + i]._index = nQOld + i;   // :500
-  // NOTE reference :516,:523,:529 index the target parameters with nQReuse + j; the evident intent nTReuse + j is used
-  for (int64_t j = 0; j < nTNew; j++) pAtps[nTReuse + j]._index = nTOld + j;    // :531
-  Error e = ReallocKB(nQOld + nQNew, nTOld + nTNew);
-  if (!e.ok()) return e;
   _pimQuestions.GrowTo(_Q);                           // :541-542
   _pimTargets.GrowTo(_T);
-  // initial amounts: whole questions first, then target columns over the questions not (re)initialised just now
-  std::vector<uint32_t> skip(BitWords(_Q), 0);
-  for (int64_t i = 0; i < nQuestions; i++) {
-    qIds.push_back(pAqps[i]._index);
-    qInit.push_back(pAqps[i]._initAmount);
-    if (i < nQReuse) BitSet(skip, pAqps[i]._index, true);    // :558-560 only reused questions are skipped
-  }
-  for (int64_t j = 0; j < nTargets; j++) { tIds.push_back(pAtps[j]._index); tInit.push_back(pAtps[j]._initAmount); }
-  int64_t *dQ = nullptr, *dT = nullptr;
-  double *dQi = nullptr, *dTi = nullptr;
-  uint32_t *dSkip = nullptr;
-  hipError_t he = Upload(&dQ, qIds, _stream);
-  if (he == hipSuccess) he = Upload(&dQi, qInit, _stream);
-  if (he == hipSuccess) he = Upload(&dT, tIds, _stream);
-  if (he == hipSuccess) he = Upload(&dTi, tInit, _stream);
-  if (he == hipSuccess) he = Upload(&dSkip, skip, _stream);
-  // new target columns apply to every old question (:512-527); reused target columns skip reused questions (:553-567).
-  // New questions are filled over ALL columns with their own amount (:497-510), so they are filled last.
-  if (he == hipSuccess && nTReuse > 0) he = LaunchFillTargets(_dCube, _dVB, _K, _ldT, nQOld, dSkip, dT, dTi, nTReuse, _stream);
-  if (he == hipSuccess && nTNew > 0) he = LaunchFillTargets(_dCube, _dVB, _K, _ldT, nQOld, nullptr, dT + nTReuse, dTi + nTReuse, nTNew, _stream);
-  if (he == hipSuccess && nQuestions > 0) he = LaunchFillQuestions(_dCube, _K, _T, _ldT, dQ, dQi, nQuestions, _stream);
-  if (he == hipSuccess) he = hipStreamSynchronize(_stream);
-  hipFree(dQ); hipFree(dQi); hipFree(dT); hipFree(dTi); hipFree(dSkip);
-  if (he != hipSuccess) return HipErr(he, "AddQsTs");
+  for (int64_t i = 0; i < nQuestions; i++) pAqps[i]._index = qIds[(size_t)i];
+  for (int64_t j = 0; j < nTargets; j++) pAtps[j]._index = tIds[(size_t)j];
   return UploadGaps();
 }
 
+// RemoveQuestions / RemoveTargets validate every id -- range, gaps, repeats within the call -- before the first one is removed:
+// a failing call changes nothing, on the host or on the device.  (The reference removes id by id and stops at the first
+// bad one, BaseEngine.cpp:722-765, leaving the earlier ones removed.)
 Error HipEngine::RemoveQuestions(int64_t n, const int64_t *pQIds) {  // BaseEngine.cpp:722-743
   std::lock_guard<EngineMutex> lk(_mu);
   StopServer();
   if (_mode != Mode::Maintenance) return WrongModeErr("remove questions");
+  if (n < 0) return Error::MakeP(ErrCode::NegativeCount, "count=" + std::to_string(n), "Counts must be non-negative.");
+  if (n > 0 && !pQIds) return Error::Make(ErrCode::NullArgument, "Nullptr ids array.");
+  if (_qFirst != 0 || _qTotal != _Q) return Error::MakeP(ErrCode::NotImplemented, "Feature=RemoveQuestions on a shard", "Not on a sharded engine.");
+  std::vector<uint32_t> seen(BitWords(_Q), 0);
   for (int64_t i = 0; i < n; i++) {
     const int64_t iq = pQIds[i];
-    if (iq < 0 || iq >= _Q || BitTest(_hQGap, iq))
+    if (iq < 0 || iq >= _Q || BitTest(_hQGap, iq) || BitTest(seen, iq))
       return Error::MakeP(ErrCode::AbsentId, "id=" + std::to_string(iq), "Question index is not in KB.");
+    BitSet(seen, iq, true);
+  }
+  for (int64_t i = 0; i < n; i++) {
+    const int64_t iq = pQIds[i];
     BitSet(_hQGap, iq, true);
     _questionGapList.push_back(iq);
     _pimQuestions.RemoveComp(iq);
@@ -491,10 +542,17 @@ Error HipEngine::RemoveTargets(int64_t n, const int64_t *pTIds) {  // BaseEngine
   std::lock_guard<EngineMutex> lk(_mu);
   StopServer();
   if (_mode != Mode::Maintenance) return WrongModeErr("remove targets");
+  if (n < 0) return Error::MakeP(ErrCode::NegativeCount, "count=" + std::to_string(n), "Counts must be non-negative.");
+  if (n > 0 && !pTIds) return Error::Make(ErrCode::NullArgument, "Nullptr ids array.");
+  std::vector<uint32_t> seen(BitWords(_T), 0);
   for (int64_t i = 0; i < n; i++) {
     const int64_t it = pTIds[i];
-    if (it < 0 || it >= _T || BitTest(_hTGap, it))
+    if (it < 0 || it >= _T || BitTest(_hTGap, it) || BitTest(seen, it))
       return Error::MakeP(ErrCode::AbsentId, "id=" + std::to_string(it), "Target index is not in KB (but rather at a gap).");
+    BitSet(seen, it, true);
+  }
+  for (int64_t i = 0; i < n; i++) {
+    const int64_t it = pTIds[i];
     BitSet(_hTGap, it, true);
     _targetGapList.push_back(it);
     _nTargetGaps++;
@@ -522,8 +580,9 @@ Error HipEngine::Compact(int64_t *pnQuestions, const int64_t **ppOldQuestions, i
       while (BitTest(_hQGap, iLast) && iLast > iFirst) iLast--;
       if (iFirst == iLast) break;
       oldQ[iFirst] = iLast;
-      HIP_TRY(hipMemcpyAsync(_dCube + (size_t)iFirst * (_K + 1) * _ldT, _dCube + (size_t)iLast * (_K + 1) * _ldT,
-                             (size_t)(_K + 1) * _ldT * sizeof(double), hipMemcpyDeviceToDevice, _stream));
+      const hipError_t ce = hipMemcpyAsync(CubeAt(iFirst), CubeAt(iLast), (size_t)(_K + 1) * (size_t)_ldT * (size_t)_elem,
+                                           hipMemcpyDeviceToDevice, _stream);
+      if (ce != hipSuccess) { std::free(oldQ); std::free(oldT); return HipErr(ce, "Compact (question move)"); }
       iLast--;
     }
   }
@@ -539,7 +598,7 @@ Error HipEngine::Compact(int64_t *pnQuestions, const int64_t **ppOldQuestions, i
   }
   int64_t *dMoves = nullptr;
   hipError_t he = Upload(&dMoves, moves, _stream);
-  if (he == hipSuccess) he = LaunchMoveTargets(_dCube, _dVB, _K, _ldT, nQ, dMoves, (int64_t)moves.size() / 2, _stream);
+  if (he == hipSuccess) he = LaunchMoveTargets(_dCube, _elem, _dVB, _K, _ldT, nQ, dMoves, (int64_t)moves.size() / 2, _stream);
   if (he == hipSuccess) he = hipStreamSynchronize(_stream);
   hipFree(dMoves);
   if (he != hipSuccess) { std::free(oldQ); std::free(oldT); return HipErr(he, "Compact"); }

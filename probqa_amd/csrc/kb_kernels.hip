@@ -10,14 +10,14 @@ namespace pqa {
 
 namespace {
 
-__global__ __launch_bounds__(256) void fill_fresh_kernel(double *__restrict__ cube, double *__restrict__ vB, int64_t K,
+__global__ __launch_bounds__(256) void fill_fresh_kernel(void *__restrict__ cube, int elem, double *__restrict__ vB, int64_t K,
                                                          int64_t Q, int64_t T, int64_t ldT, double initAmount) {
   const double init1 = initAmount, initSqr = init1 * init1, initMD = initSqr * (double)K;  // CpuEngine.cpp:45-47
   const int64_t total = Q * (K + 1) * ldT;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t t = i % ldT, r = (i / ldT) % (K + 1);
-    cube[i] = (t < T) ? (r < K ? initSqr : initMD) : (r < K ? 0.0 : 1.0);
-    if (i < ldT) vB[i] = (i < T) ? init1 : 0.0;
+    cube_st(cube, elem, i, (t < T) ? (r < K ? initSqr : initMD) : (r < K ? 0.0 : 1.0));
+    if (i < ldT) vB[i] = (i < T) ? (elem == 4 ? (double)(float)init1 : init1) : 0.0;   // (Float engines: vB holds fp32 values)
   }
 }
 
@@ -32,7 +32,7 @@ __device__ __forceinline__ double hash_unit(uint64_t seed, uint64_t idx) {  // u
 }
 
 // One thread per (question, target): loops over the answers so that D = sum_k A is accumulated in k order.
-__global__ __launch_bounds__(256) void fill_synth_kernel(double *__restrict__ cube, double *__restrict__ vB, int64_t K,
+__global__ __launch_bounds__(256) void fill_synth_kernel(void *__restrict__ cube, int elem, double *__restrict__ vB, int64_t K,
                                                          int64_t Q, int64_t T, int64_t ldT, int64_t qOffset,
                                                          int64_t qTotal, double initAmount, double nTrain,
                                                          double noiseAmp, uint64_t seed) {
@@ -40,10 +40,10 @@ __global__ __launch_bounds__(256) void fill_synth_kernel(double *__restrict__ cu
   const int64_t w = (32 * T) / 1000 > 1 ? (32 * T) / 1000 : 1;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t q = i / ldT, t = i % ldT;
-    double *col = cube + q * (K + 1) * ldT + t;
+    const int64_t col = q * (K + 1) * ldT + t;
     if (t >= T) {
-      for (int64_t k = 0; k < K; k++) col[k * ldT] = 0.0;
-      col[K * ldT] = 1.0;
+      for (int64_t k = 0; k < K; k++) cube_st(cube, elem, col + k * ldT, 0.0);
+      cube_st(cube, elem, col + K * ldT, 1.0);
     } else {
       const int64_t qg = qOffset + q;
       const int64_t x = (qg * T) / qTotal;
@@ -55,29 +55,36 @@ __global__ __launch_bounds__(256) void fill_synth_kernel(double *__restrict__ cu
         double a = initAmount;
         if (k == ans) a = a + nTrain;
         a = a + noiseAmp * hash_unit(seed, (uint64_t)((qg * K + k) * T + t));
-        const double a2 = a * a;  // the cube stores squares (PqaCore/CETrainOperation.cpp:15-25)
-        col[k * ldT] = a2;
+        double a2 = a * a;  // the cube stores squares (PqaCore/CETrainOperation.cpp:15-25)
+        if (elem == 4) a2 = (double)(float)a2;   // Float cube: D is the sum of the ROUNDED squares, as training would leave it
+        cube_st(cube, elem, col + k * ldT, a2);
         d = d + a2;
       }
-      col[K * ldT] = d;
+      cube_st(cube, elem, col + K * ldT, d);
     }
-    if (q == 0) vB[t] = (t < T) ? (initAmount + nTrain) + noiseAmp * hash_unit(seed ^ 0x5851F42D4C957F2DULL, (uint64_t)t) : 0.0;
+    if (q == 0) {
+      const double b = (t < T) ? (initAmount + nTrain) + noiseAmp * hash_unit(seed ^ 0x5851F42D4C957F2DULL, (uint64_t)t) : 0.0;
+      vB[t] = elem == 4 ? (double)(float)b : b;
+    }
   }
 }
 
-__global__ void train_kernel(double *__restrict__ cube, double *__restrict__ vB, int64_t K, int64_t ldT,
+__global__ void train_kernel(void *__restrict__ cube, int elem, double *__restrict__ vB, int64_t K, int64_t ldT,
                              const int64_t *__restrict__ aqs, int64_t nAQs, int64_t iTarget, double amount) {
   const double twoB = 2 * amount, bSquare = amount * amount;  // CETrainTaskNumSpec.h:24-32
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nAQs; i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t q = aqs[2 * i], ans = aqs[2 * i + 1];
-    double *pA = cube + (q * (K + 1) + ans) * ldT + iTarget;
-    double *pD = cube + (q * (K + 1) + K) * ldT + iTarget;
-    const double a = sqrt(*pA);                                // CETrainOperation.cpp:18
+    const int64_t iA = (q * (K + 1) + ans) * ldT + iTarget, iD = (q * (K + 1) + K) * ldT + iTarget;
+    const double oldA = cube_ld(cube, elem, iA);
+    const double a = sqrt(oldA);                               // CETrainOperation.cpp:18
     const double addend = a * twoB + bSquare;                  // :19
-    *pA = *pA + addend;                                        // :23-24
-    *pD = *pD + addend;                                        // :25
+    cube_st(cube, elem, iA, oldA + addend);                    // :23-24
+    cube_st(cube, elem, iD, cube_ld(cube, elem, iD) + addend); // :25
   }
-  if (blockIdx.x == 0 && threadIdx.x == 0) vB[iTarget] += amount;  // PqaCore/CpuEngine.cpp:172
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    const double b = vB[iTarget] + amount;                   // PqaCore/CpuEngine.cpp:172
+    vB[iTarget] = elem == 4 ? (double)(float)b : b;
+  }
 }
 
 // ListTopTargets on the device (top_targets_publish in pqa_device.h); T <= 16384.
@@ -100,90 +107,91 @@ unsigned grid_for(int64_t n, int threads) {
 
 // ---- maintenance (reference PqaCore/CpuEngine.cpp:468-658) ---------------------------------------------------------
 // (Re)initialise whole questions: A = init^2, D = init^2 * K on real targets; padding columns A = 0, D = 1.
-__global__ __launch_bounds__(256) void fill_questions_kernel(double *__restrict__ cube, int64_t K, int64_t T, int64_t ldT,
+__global__ __launch_bounds__(256) void fill_questions_kernel(void *__restrict__ cube, int elem, int64_t K, int64_t T, int64_t ldT,
                                                              const int64_t *__restrict__ qs,
                                                              const double *__restrict__ inits, int64_t n) {
   const int64_t per = (K + 1) * ldT, total = n * per;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t iq = i / per, r = (i % per) / ldT, t = i % ldT;
     const double initSqr = inits[iq] * inits[iq], initMD = initSqr * (double)K;  // :503-510 / :548-555
-    cube[qs[iq] * per + r * ldT + t] = (t < T) ? (r < K ? initSqr : initMD) : (r < K ? 0.0 : 1.0);
+    cube_st(cube, elem, qs[iq] * per + r * ldT + t, (t < T) ? (r < K ? initSqr : initMD) : (r < K ? 0.0 : 1.0));
   }
 }
 
 // (Re)initialise target columns over questions [0,nQ) except those flagged in skipQ (already initialised as questions).
-__global__ __launch_bounds__(256) void fill_targets_kernel(double *__restrict__ cube, double *__restrict__ vB, int64_t K,
+__global__ __launch_bounds__(256) void fill_targets_kernel(void *__restrict__ cube, int elem, double *__restrict__ vB, int64_t K,
                                                            int64_t ldT, int64_t nQ, const uint32_t *__restrict__ skipQ,
                                                            const int64_t *__restrict__ ts,
                                                            const double *__restrict__ inits, int64_t n) {
   const int64_t total = nQ * n;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t q = i / n, it = i % n;
-    if (q == 0) vB[ts[it]] = inits[it];                                          // :532 / :566
+    if (q == 0) vB[ts[it]] = elem == 4 ? (double)(float)inits[it] : inits[it];   // :532 / :566
     if (skipQ && bit_test(skipQ, q)) continue;                                   // :558-560
     const double initSqr = inits[it] * inits[it], initMD = initSqr * (double)K;  // :517,:523 / :556-557
-    double *col = cube + q * (K + 1) * ldT + ts[it];
-    for (int64_t k = 0; k < K; k++) col[k * ldT] = initSqr;
-    col[K * ldT] = initMD;
+    const int64_t col = q * (K + 1) * ldT + ts[it];
+    for (int64_t k = 0; k < K; k++) cube_st(cube, elem, col + k * ldT, initSqr);
+    cube_st(cube, elem, col + K * ldT, initMD);
   }
 }
 
 // Compaction of the target axis (:619-647): column dst <- column src for every kept question and for vB.
-__global__ __launch_bounds__(256) void move_targets_kernel(double *__restrict__ cube, double *__restrict__ vB, int64_t K,
+__global__ __launch_bounds__(256) void move_targets_kernel(void *__restrict__ cube, int elem, double *__restrict__ vB, int64_t K,
                                                            int64_t ldT, int64_t nQ, const int64_t *__restrict__ moves,
                                                            int64_t n) {
   const int64_t rows = nQ * (K + 1) + 1, total = rows * n;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t row = i / n, m = i % n;
-    double *base = (row < nQ * (K + 1)) ? cube + row * ldT : vB;
-    base[moves[2 * m + 1]] = base[moves[2 * m]];  // (src, dst) pairs; sources are never destinations (:604-618)
+    // (src, dst) pairs; sources are never destinations (:604-618)
+    if (row < nQ * (K + 1)) cube_st(cube, elem, row * ldT + moves[2 * m + 1], cube_ld(cube, elem, row * ldT + moves[2 * m]));
+    else vB[moves[2 * m + 1]] = vB[moves[2 * m]];
   }
 }
 
 }  // namespace
 
-hipError_t LaunchFillQuestions(double *cube, int64_t K, int64_t T, int64_t ldT, const int64_t *qs, const double *inits,
+hipError_t LaunchFillQuestions(void *cube, int elem, int64_t K, int64_t T, int64_t ldT, const int64_t *qs, const double *inits,
                                int64_t n, hipStream_t stream) {
   if (n <= 0) return hipSuccess;
-  hipLaunchKernelGGL(fill_questions_kernel, dim3(grid_for(n * (K + 1) * ldT, 256)), dim3(256), 0, stream, cube, K, T, ldT,
+  hipLaunchKernelGGL(fill_questions_kernel, dim3(grid_for(n * (K + 1) * ldT, 256)), dim3(256), 0, stream, cube, elem, K, T, ldT,
                      qs, inits, n);
   return hipGetLastError();
 }
 
-hipError_t LaunchFillTargets(double *cube, double *vB, int64_t K, int64_t ldT, int64_t nQ, const uint32_t *skipQ,
+hipError_t LaunchFillTargets(void *cube, int elem, double *vB, int64_t K, int64_t ldT, int64_t nQ, const uint32_t *skipQ,
                              const int64_t *ts, const double *inits, int64_t n, hipStream_t stream) {
   if (n <= 0) return hipSuccess;
-  hipLaunchKernelGGL(fill_targets_kernel, dim3(grid_for(nQ * n, 256)), dim3(256), 0, stream, cube, vB, K, ldT, nQ, skipQ, ts,
+  hipLaunchKernelGGL(fill_targets_kernel, dim3(grid_for(nQ * n, 256)), dim3(256), 0, stream, cube, elem, vB, K, ldT, nQ, skipQ, ts,
                      inits, n);
   return hipGetLastError();
 }
 
-hipError_t LaunchMoveTargets(double *cube, double *vB, int64_t K, int64_t ldT, int64_t nQ, const int64_t *moves,
+hipError_t LaunchMoveTargets(void *cube, int elem, double *vB, int64_t K, int64_t ldT, int64_t nQ, const int64_t *moves,
                              int64_t n, hipStream_t stream) {
   if (n <= 0) return hipSuccess;
-  hipLaunchKernelGGL(move_targets_kernel, dim3(grid_for((nQ * (K + 1) + 1) * n, 256)), dim3(256), 0, stream, cube, vB, K,
+  hipLaunchKernelGGL(move_targets_kernel, dim3(grid_for((nQ * (K + 1) + 1) * n, 256)), dim3(256), 0, stream, cube, elem, vB, K,
                      ldT, nQ, moves, n);
   return hipGetLastError();
 }
 
-hipError_t LaunchFillFresh(double *cube, double *vB, int64_t K, int64_t Q, int64_t T, int64_t ldT, double initAmount,
+hipError_t LaunchFillFresh(void *cube, int elem, double *vB, int64_t K, int64_t Q, int64_t T, int64_t ldT, double initAmount,
                            hipStream_t stream) {
-  hipLaunchKernelGGL(fill_fresh_kernel, dim3(grid_for(Q * (K + 1) * ldT, 256)), dim3(256), 0, stream, cube, vB, K, Q, T,
+  hipLaunchKernelGGL(fill_fresh_kernel, dim3(grid_for(Q * (K + 1) * ldT, 256)), dim3(256), 0, stream, cube, elem, vB, K, Q, T,
                      ldT, initAmount);
   return hipGetLastError();
 }
 
-hipError_t LaunchFillSynthetic(double *cube, double *vB, int64_t K, int64_t Q, int64_t T, int64_t ldT, int64_t qOffset,
+hipError_t LaunchFillSynthetic(void *cube, int elem, double *vB, int64_t K, int64_t Q, int64_t T, int64_t ldT, int64_t qOffset,
                                int64_t qTotal, double initAmount, double nTrain, double noiseAmp, uint64_t seed,
                                hipStream_t stream) {
-  hipLaunchKernelGGL(fill_synth_kernel, dim3(grid_for(Q * ldT, 256)), dim3(256), 0, stream, cube, vB, K, Q, T, ldT,
+  hipLaunchKernelGGL(fill_synth_kernel, dim3(grid_for(Q * ldT, 256)), dim3(256), 0, stream, cube, elem, vB, K, Q, T, ldT,
                      qOffset, qTotal, initAmount, nTrain, noiseAmp, seed);
   return hipGetLastError();
 }
 
-hipError_t LaunchTrain(double *cube, double *vB, int64_t K, int64_t ldT, const int64_t *aqs, int64_t nAQs,
+hipError_t LaunchTrain(void *cube, int elem, double *vB, int64_t K, int64_t ldT, const int64_t *aqs, int64_t nAQs,
                        int64_t iTarget, double amount, hipStream_t stream) {
-  hipLaunchKernelGGL(train_kernel, dim3(grid_for(nAQs, 64)), dim3(64), 0, stream, cube, vB, K, ldT, aqs, nAQs, iTarget,
+  hipLaunchKernelGGL(train_kernel, dim3(grid_for(nAQs, 64)), dim3(64), 0, stream, cube, elem, vB, K, ldT, aqs, nAQs, iTarget,
                      amount);
   return hipGetLastError();
 }

@@ -32,6 +32,17 @@ __device__ __forceinline__ bool bit_test(const uint32_t *__restrict__ bits, int6
   return (bits[i >> 5] >> (i & 31)) & 1u;
 }
 
+// ---- the cube's element type --------------------------------------------------------------------------------------
+// Double engines keep sA / mD as fp64, Float engines (TPqaPrecisionType::Float, reference PqaCore/Interface/PqaCommon.h:17-24)
+// as fp32.  The O(T) kernels around the sweep (posterior updates, training, maintenance) read and write single elements
+// through these two; their arithmetic is fp64 either way (a Float cube is rounded on the store).
+__device__ __forceinline__ double cube_ld(const void *cube, int elem, int64_t i) {
+  return elem == 8 ? static_cast<const double *>(cube)[i] : (double)static_cast<const float *>(cube)[i];
+}
+__device__ __forceinline__ void cube_st(void *cube, int elem, int64_t i, double v) {
+  if (elem == 8) static_cast<double *>(cube)[i] = v; else static_cast<float *>(cube)[i] = (float)v;
+}
+
 // ---- division ------------------------------------------------------------------------------------------------------
 // IEEE-correct quotient for operands that need no scaling (no denormals / overflow in n, d, n/d): v_rcp_f64 (2^-24.4
 // accurate on gfx950), one Newton step, then Markstein's residual correction.  37 cycles per wave instead of the 60-70

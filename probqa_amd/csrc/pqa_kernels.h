@@ -17,7 +17,8 @@
 namespace pqa {
 
 struct KbView {
-  const double *cube;     // [Q][K+1][ldT]
+  const void *cube;       // [Q][K+1][ldT], elements of `elem` bytes: double (Double engines) or float (Float engines)
+  int elem;               // 8 | 4
   const double *vB;       // [ldT]
   const uint32_t *tgap;   // target gap bits, ldT bits (+ slack), bits >= T set
   const uint32_t *qgap;   // question gap bits, bits >= Q set
@@ -77,6 +78,23 @@ hipError_t LaunchEvalQuestions(const KbView &kb, const double *prior, const uint
 // nSlots * fused->scratchStride records; fused->out / seq are ignored (each slot has its own).
 hipError_t LaunchEvalQuestionsBatch(const KbView &kb, const QuizSlot *slots, int nSlots, int64_t qFirst, int64_t qLimit,
                                     int variant, const FusedSelect &fused, hipStream_t stream);
+// ---- many quizzes per sweep, one cube read per batch (batch_kernels.hip): lane = quiz, the cube tile staged in LDS is shared by
+// all quizzes of the batch.  Double and Float engines.  nSlots <= 256.
+constexpr int kBatchMaxGrid = 2048;
+struct BatchRecord { double priority; int64_t index; };   // a workgroup's best question of one quiz (index < 0: none)
+struct BatchPlan {
+  int tileTargets;        // in: targets per LDS tile (0 = default)
+  int grid, Bp;           // out: workgroups of the sweep; quizzes rounded up to whole waves
+  size_t ptBytes, accBytes, recBytes;   // out: sizes of the scratch buffers PT / acc / recs the caller provides
+};
+// queryOnly: only fill `plan`.  Otherwise: transposed masked priors -> PT, the sweep, and every quiz's winner {priority,
+// local index + outBase} to its slot's `out`, then flagValue to its `seq` (host-coherent).  priorityT (optional):
+// [Q][plan->Bp] priorities, quiz-minor.
+hipError_t LaunchEvalBatch(const KbView &kb, const QuizSlot *slots, int nSlots, BatchPlan *plan, void *PT, double *acc,
+                           BatchRecord *recs, double *priorityT, int64_t outBase, uint64_t flagValue, bool queryOnly, hipStream_t stream);
+// Single-quiz sweep of a Float engine: priority[q] for every local question (0 for gap / asked).
+hipError_t LaunchEvalQuestionsF32(const KbView &kb, const double *prior, const uint32_t *asked, double *priority, hipStream_t stream);
+hipError_t UploadLog2TableBatch(const double *hostTable);
 const char *EvalVariantName(const KbView &kb, int variant);
 bool EvalVariantFusesSampled(const KbView &kb, int variant, int64_t nSubtasks);   // the launch can run the sampled selector itself
 
@@ -125,7 +143,8 @@ struct RatedTargetDev { int64_t iTarget; double prob; };  // == CiRatedTarget
 // ---- selectors over priority[0..n) (questions qFirst..qFirst+n of the bitmaps); the reported index is
 // (position in priority[]) + outBase
 hipError_t LaunchSelectArgmax(const double *priority, const uint32_t *qgap, const uint32_t *asked, int64_t qFirst,
-                              int64_t n, int64_t outBase, SelectResult *out, hipStream_t stream);
+                              int64_t n, int64_t outBase, SelectResult *out, uint64_t *flag, uint64_t flagValue,
+                              hipStream_t stream);   // flag (optional, host-coherent): receives flagValue after `out`
 // Reference selector (PqaCore/CpuEngine.cpp:362-400): per-subtask Kahan run lengths, grand totals, upper_bound.
 // runLength: scratch of n doubles. rnd: the 64-bit random number the reference would draw.
 hipError_t LaunchSelectSampled(const double *priority, const uint32_t *qgap, const uint32_t *asked, int64_t qFirst,
@@ -145,22 +164,22 @@ hipError_t LaunchResumeQuiz(const KbView &kb, double *prior, int64_t *exps, cons
                             int64_t nWorkers, int bugCompat, int64_t *status, hipStream_t stream);
 
 // ---- KB construction / mutation
-hipError_t LaunchFillFresh(double *cube, double *vB, int64_t K, int64_t Q, int64_t T, int64_t ldT, double initAmount,
+hipError_t LaunchFillFresh(void *cube, int elem, double *vB, int64_t K, int64_t Q, int64_t T, int64_t ldT, double initAmount,
                            hipStream_t stream);
 // Deterministic synthetic "binary-search trained + hash noise" cube (see probqa_amd/synth.py for the definition).
-hipError_t LaunchFillSynthetic(double *cube, double *vB, int64_t K, int64_t Q, int64_t T, int64_t ldT, int64_t qOffset,
+hipError_t LaunchFillSynthetic(void *cube, int elem, double *vB, int64_t K, int64_t Q, int64_t T, int64_t ldT, int64_t qOffset,
                                int64_t qTotal, double initAmount, double nTrain, double noiseAmp, uint64_t seed,
                                hipStream_t stream);
 // Train / RecordQuizTarget (PqaCore/CETrainOperation.cpp:15-25): aqs device array of nAQs (q,a) pairs, distinct q.
-hipError_t LaunchTrain(double *cube, double *vB, int64_t K, int64_t ldT, const int64_t *aqs, int64_t nAQs,
+hipError_t LaunchTrain(void *cube, int elem, double *vB, int64_t K, int64_t ldT, const int64_t *aqs, int64_t nAQs,
                        int64_t iTarget, double amount, hipStream_t stream);
 // Maintenance (PqaCore/CpuEngine.cpp:468-658): (re)initialise whole questions / whole target columns; compact the target
 // axis with (src,dst) column moves.  qs/ts/inits/moves are device arrays.
-hipError_t LaunchFillQuestions(double *cube, int64_t K, int64_t T, int64_t ldT, const int64_t *qs, const double *inits,
+hipError_t LaunchFillQuestions(void *cube, int elem, int64_t K, int64_t T, int64_t ldT, const int64_t *qs, const double *inits,
                                int64_t n, hipStream_t stream);
-hipError_t LaunchFillTargets(double *cube, double *vB, int64_t K, int64_t ldT, int64_t nQ, const uint32_t *skipQ,
+hipError_t LaunchFillTargets(void *cube, int elem, double *vB, int64_t K, int64_t ldT, int64_t nQ, const uint32_t *skipQ,
                              const int64_t *ts, const double *inits, int64_t n, hipStream_t stream);
-hipError_t LaunchMoveTargets(double *cube, double *vB, int64_t K, int64_t ldT, int64_t nQ, const int64_t *moves,
+hipError_t LaunchMoveTargets(void *cube, int elem, double *vB, int64_t K, int64_t ldT, int64_t nQ, const int64_t *moves,
                              int64_t n, hipStream_t stream);
 // ListTopTargets (PqaCore/CEListTopTargetsAlgorithm.cpp): top maxCount (prob,target) pairs, descending, gaps skipped.
 // (flag != nullptr: out / nOut / flag are host-coherent; the kernel stores flagValue to *flag after its results)

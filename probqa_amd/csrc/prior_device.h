@@ -52,7 +52,8 @@ __device__ double reference_order_sum(const double *__restrict__ v, int64_t nVec
 }
 
 struct PriorArgs {
-  const double *cube;
+  const void *cube;
+  int elem;
   const double *vB;
   const uint32_t *tgap;
   double *prior;
@@ -82,10 +83,10 @@ __device__ __forceinline__ void record_answer_body(PriorArgs a, int64_t iQuestio
     asked[iQuestion >> 5] = w | (1u << (iQuestion & 31));
   }
   const int64_t nVects = (a.T + 3) >> 2;
-  const double *rowA = a.cube + (iQuestion * (a.K + 1) + iAnswer) * a.ldT;  // CERecordAnswerSubtaskMul.cpp:25
-  const double *rowD = a.cube + (iQuestion * (a.K + 1) + a.K) * a.ldT;      // :26
+  const int64_t rowA = (iQuestion * (a.K + 1) + iAnswer) * a.ldT;  // CERecordAnswerSubtaskMul.cpp:25
+  const int64_t rowD = (iQuestion * (a.K + 1) + a.K) * a.ldT;      // :26
   for (int64_t t = threadIdx.x; t < a.ldT; t += blockDim.x) {
-    const double pQaGivenT = rowA[t] / rowD[t];                // :31
+    const double pQaGivenT = cube_ld(a.cube, a.elem, rowA + t) / cube_ld(a.cube, a.elem, rowD + t);   // :31
     const double old = COH ? __hip_atomic_load(a.prior + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : a.prior[t];
     const double product = old * pQaGivenT;                    // :34
     a.prior[t] = bit_test(a.tgap, t) ? 0.0 : product;          // :35-37

@@ -67,7 +67,7 @@ __global__ __launch_bounds__(kThreads) void resume_quiz_kernel(PriorArgs a, int6
     int64_t ex;
     {
       const int64_t q = aqs[0], ans = aqs[1];
-      const double pQaGivenT = a.cube[(q * (a.K + 1) + ans) * a.ldT + t] / a.cube[(q * (a.K + 1) + a.K) * a.ldT + t];
+      const double pQaGivenT = cube_ld(a.cube, a.elem, (q * (a.K + 1) + ans) * a.ldT + t) / cube_ld(a.cube, a.elem, (q * (a.K + 1) + a.K) * a.ldT + t);
       const double oldMant = bugCompat ? a.vB[t & 3] : a.vB[t];  // CEUpdatePriorsSubtaskMul.cpp:53 loads pvB, not pvB+j
       const uint64_t up = d2u(oldMant * pQaGivenT);              // :54
       mant = u2d(kExp0Up | (up & ~kExpMaskUp));                  // :56 MakeExponent0
@@ -75,7 +75,7 @@ __global__ __launch_bounds__(kThreads) void resume_quiz_kernel(PriorArgs a, int6
     }
     for (int64_t i = 1; i < nAnswered; i++) {
       const int64_t q = aqs[2 * i], ans = aqs[2 * i + 1];
-      const double pQaGivenT = a.cube[(q * (a.K + 1) + ans) * a.ldT + t] / a.cube[(q * (a.K + 1) + a.K) * a.ldT + t];
+      const double pQaGivenT = cube_ld(a.cube, a.elem, (q * (a.K + 1) + ans) * a.ldT + t) / cube_ld(a.cube, a.elem, (q * (a.K + 1) + a.K) * a.ldT + t);
       const uint64_t up = d2u(mant * pQaGivenT);                 // :75
       mant = u2d(kExp0Up | (up & ~kExpMaskUp));                  // :77
       ex += (int64_t)((up & kExpMaskUp) >> 52);                  // :80-82
@@ -127,6 +127,7 @@ size_t sum_lds_bytes(int64_t nWorkers) { return (size_t)(8 * nWorkers + 1) * siz
 PriorArgs make_args(const KbView &kb, double *prior, int64_t nWorkers) {
   PriorArgs a;
   a.cube = kb.cube;
+  a.elem = kb.elem;
   a.vB = kb.vB;
   a.tgap = kb.tgap;
   a.prior = prior;

@@ -25,7 +25,8 @@ __device__ __forceinline__ bool better(const Best &a, const Best &b) {  // is a 
 __global__ __launch_bounds__(1024) void select_argmax_kernel(const double *__restrict__ priority,
                                                              const uint32_t *__restrict__ qgap,
                                                              const uint32_t *__restrict__ asked, int64_t qFirst,
-                                                             int64_t n, int64_t outBase, SelectResult *out) {
+                                                             int64_t n, int64_t outBase, SelectResult *out, uint64_t *flag,
+                                                             uint64_t flagValue) {
   __shared__ double sp[16];
   __shared__ int64_t si[16];
   Best b = {0.0, -1};
@@ -59,6 +60,10 @@ __global__ __launch_bounds__(1024) void select_argmax_kernel(const double *__res
     }
     out->priority = r.p;
     out->index = r.i < 0 ? -1 : r.i - qFirst + outBase;
+    if (flag != nullptr) {  // `out` and `flag` in host-coherent memory: the host polls instead of copying + synchronising
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+      __hip_atomic_store(flag, flagValue, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
   }
 }
 
@@ -102,10 +107,11 @@ __global__ __launch_bounds__(256) void select_sampled_lds_kernel(const double *_
 }  // namespace
 
 hipError_t LaunchSelectArgmax(const double *priority, const uint32_t *qgap, const uint32_t *asked, int64_t qFirst,
-                              int64_t n, int64_t outBase, SelectResult *out, hipStream_t stream) {
+                              int64_t n, int64_t outBase, SelectResult *out, uint64_t *flag, uint64_t flagValue,
+                              hipStream_t stream) {
   const unsigned threads = n >= 1024 ? 1024 : (unsigned)(((n + 63) / 64) * 64 ? ((n + 63) / 64) * 64 : 64);
   hipLaunchKernelGGL(select_argmax_kernel, dim3(1), dim3(threads), 0, stream, priority, qgap, asked, qFirst, n,
-                     outBase, out);
+                     outBase, out, flag, flagValue);
   return hipGetLastError();
 }
 

@@ -125,6 +125,7 @@ HIP_EXPORTS = {
     "PqaEngine_EvalPriorities": (_vp, [_vp, _i64, _pdbl, _i64]),
     "PqaEngine_NextQuestionArgmax": (_i64, [_vp, _pvp, _i64]),
     "PqaHip_Log2Hot": (_vp, [_vp, _pdbl, _pdbl, _i64]),
+    "PqaEngine_EvalPrioritiesBatch": (_vp, [_vp, _i64, _pi64, _pdbl]),
     "PqaEngine_NextQuestionArgmaxBatch": (_vp, [_vp, _i64, _pi64, _pi64]),
     "PqaEngine_NextQuestionSampled": (_i64, [_vp, _pvp, _i64, _u64]),
     "PqaHip_GetPriors": (_vp, [_vp, _i64, _pdbl, _i64]),
@@ -514,6 +515,15 @@ class PqaEngine:
         out = (ctypes.c_int64 * max(n, 1))()
         _check(_lib.PqaEngine_NextQuestionArgmaxBatch(self.c_engine, n, qs, out))
         return list(out[:n])
+
+    def eval_priorities_batch(self, quizzes, n_local_questions: Optional[int] = None) -> np.ndarray:
+        """Priority vectors [len(quizzes), Q] of several distinct quizzes from one sweep that reads the cube once."""
+        n = len(quizzes)
+        nq = n_local_questions if n_local_questions is not None else self.copy_dims().n_questions
+        qs = (ctypes.c_int64 * max(n, 1))(*quizzes)
+        out = np.zeros((n, nq), dtype=np.float64)
+        _check(_lib.PqaEngine_EvalPrioritiesBatch(self.c_engine, n, qs, _dptr(out)))
+        return out
 
     def enqueue_select_argmax_flag(self, i_quiz: int, out_dev: int, flag_dev: int, flag_value: int) -> None:
         _check(_lib.PqaHip_EnqueueSelectArgmaxFlag(self.c_engine, i_quiz, ctypes.c_void_p(out_dev),

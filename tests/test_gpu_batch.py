@@ -1,0 +1,223 @@
+"""The row-sharing batched sweep (probqa_amd/csrc/batch_kernels.hip: a lane is a quiz, the cube is read once per batch) and
+the Float engine (TPqaPrecisionType::Float: fp32 cube, fp32 sweep arithmetic), through the C ABI.
+
+Oracle: the fp64 CPU restatement (oracle/), run once per quiz -- for Float engines on the cube ROUNDED to fp32, which is the
+cube the engine holds ("fp32 config: same generators evaluated in fp64 then rounded").
+
+Tolerances.  fp64 batched sweep: PRIORITY_RTOL = 1e-9 like the single-quiz sweep (a different summation order again: one
+serial sum per lane and tile, fp64 totals over the tiles).  fp32: F32_RTOL relative on the priorities of states where the
+posterior is not concentrated (the lack term -sum invD^2 / log2 p has a pole at p -> 1, where an fp32 posterior carries 6e-8
+of absolute error: SURVEY F3/F4); argmax asserted where the oracle's top-2 margin exceeds 10 x F32_RTOL.
+"""
+import numpy as np
+import pytest
+
+import cases
+import orclib
+from probqa_amd import interop, synth
+
+pytestmark = pytest.mark.gpu
+
+PRIORITY_RTOL = 1e-9
+# fp32 sweep vs fp64 oracle on the same (rounded) cube: F32_RTOL + F32_COND / |log2 pmax(question)|, pmax = the largest posterior
+# element the question's answers can produce (f32_tolerance below).  An fp32 posterior element carries ~1.2e-7 of relative
+# error (likelihood and 1/W_k rounded once each); the priority amplifies it twice: the velocity sum of (posterior - prior)^2
+# cancels where an answer barely moves the posterior, and vComp^9 = (ln sqrt2 - ln avgV + ..)^-9 multiplies the relative error
+# of avgV by 9 vComp -- that is F32_RTOL, measured up to 3e-3 on the fixtures; and the lack sum -sum invD^2 / log2 p turns it
+# into 1.7e-7 / |log2 p| relative on a term -- the second summand.  Measured maxima are printed by the tests.
+F32_RTOL = 5e-3
+F32_COND = 1e-6
+
+
+def scripted_quizzes(case, eng, n_quizzes, rng):
+    """n_quizzes quizzes with different answer histories (0..3 answers); returns [(quiz id, [(q, a), ...])]."""
+    out = []
+    valid_q = [q for q in range(case.Q) if q not in case.qgaps]
+    for i in range(n_quizzes):
+        quiz = eng.start_quiz()
+        hist = []
+        for q in rng.choice(valid_q, size=min(i % 4, len(valid_q) - 1), replace=False):
+            a = int(rng.integers(case.K))
+            eng.set_active_question(quiz, int(q))
+            eng.record_answer(quiz, a)
+            hist.append((int(q), a))
+        out.append((quiz, hist))
+    return out
+
+
+def oracle_priorities(orc, hist):
+    orc.start_quiz(cases.WORKERS)
+    for q, a in hist:
+        orc.record_answer(q, a, cases.WORKERS - 1)
+    _, pri = orc.eval(1)
+    return pri, orc.priors()
+
+
+def f32_tolerance(orc, case):
+    """Per-question tolerance of an fp32 sweep for the oracle's CURRENT quiz state (see F32_RTOL / F32_COND)."""
+    T = case.T
+    prior = orc.priors()
+    like = orc.A[:, :, :T] / orc.D[:, None, :T] * prior[None, None, :]
+    for t in case.tgaps:
+        like[:, :, t] = 0
+    w = like.sum(axis=2, keepdims=True)
+    pmax = np.minimum((like / np.where(w > 0, w, 1)).max(axis=(1, 2)), 1 - 2.0 ** -25)
+    return F32_RTOL + F32_COND / np.abs(np.log2(pmax))
+
+
+def rel_vec(pri, opri):
+    assert ((opri == 0) == (pri == 0)).all(), "gap / asked questions must have priority 0, and only they"
+    return np.where(opri != 0, cases.rel_err(pri, np.where(opri != 0, opri, 1)), 0.0)
+
+
+def rel_to(pri, opri):
+    assert ((opri == 0) == (pri == 0)).all(), "gap / asked questions must have priority 0, and only they"
+    nz = opri != 0
+    return cases.rel_err(pri[nz], opri[nz]).max() if nz.any() else 0.0
+
+
+@pytest.mark.parametrize("case", cases.small_cases(), ids=lambda c: c.name)
+@pytest.mark.parametrize("n_quizzes,tile", [(70, 0), (5, 64), (256, 0)], ids=["70q", "5q_tile64", "256q"])
+def test_fp64_batched_sweep_against_oracle_and_single(case, n_quizzes, tile, factory):
+    """Every quiz of a batch gets the priorities the single-quiz sweep and the oracle give it; the batch's selections are
+    the oracle's argmaxes.  tile=64 forces rows of > 64 targets through several LDS tiles (pass 2 re-stages)."""
+    if n_quizzes == 256 and case.Q > 100:
+        pytest.skip("256 oracle sweeps of the larger cubes are covered by the 70-quiz form")
+    rng = np.random.default_rng(77)
+    eng = case.make_engine(factory)
+    eng.set_option("batch_min", 1)
+    eng.set_option("batch_tile", tile)
+    orc = case.make_oracle()
+    quizzes = scripted_quizzes(case, eng, n_quizzes, rng)
+    ids = [q for q, _ in quizzes]
+    pri_b = eng.eval_priorities_batch(ids, case.Q)
+    picks = eng.next_question_argmax_batch(ids)
+    worst = 0.0
+    for i, (quiz, hist) in enumerate(quizzes):
+        if i % 7 == 0 or n_quizzes <= 8:       # the single-quiz sweep on a subset (it is itself held to the oracle elsewhere)
+            assert rel_to(pri_b[i], eng.eval_priorities(quiz)) < PRIORITY_RTOL
+        opri, opriors = oracle_priorities(orc, hist)
+        assert np.array_equal(eng.get_priors(quiz), opriors)
+        r = rel_to(pri_b[i], opri)
+        worst = max(worst, r)
+        assert r < PRIORITY_RTOL, f"quiz {i} ({hist}): {r:g}"
+        top = np.sort(opri)[::-1]
+        if top[0] > 0 and (top[0] - top[1]) / top[0] > 10 * PRIORITY_RTOL:
+            assert picks[i] == orc.select_argmax(opri), f"quiz {i}: argmax"
+    print(case.name, n_quizzes, "quizzes, tile", tile, ": max priority rel err %.2e" % worst)
+    eng.close()
+
+
+def float_engine(case, factory):
+    eng, err = factory.create_cpu_engine(interop.EngineDefinition(case.K, case.Q, case.T, init_amount=case.init,
+                                                                  prec_type=interop.PrecisionType.FLOAT, prec_exponent=8,
+                                                                  prec_mantissa=24))
+    assert err is None and eng is not None, err
+    assert eng.get_option("precision") == 1
+    A, D, B = case.kb()
+    eng.set_kb(A, D, B)
+    eng.set_option("workers", cases.WORKERS)
+    if case.tgaps:
+        eng.set_target_gaps(case.tgaps)
+    if case.qgaps:
+        eng.set_question_gaps(case.qgaps)
+    orc = orclib.Oracle(case.K, case.Q, case.T, case.init)
+    orc.set_kb(*(x.astype(np.float32).astype(np.float64) for x in (A, D, B)))
+    orc.set_target_gaps(case.tgaps)
+    orc.set_question_gaps(case.qgaps)
+    return eng, orc
+
+
+@pytest.mark.parametrize("case", cases.small_cases(), ids=lambda c: c.name)
+def test_float_engine_against_fp64_oracle_on_the_rounded_cube(case, factory):
+    """TPqaPrecisionType::Float: the cube is fp32 (GetKB returns the rounded values), posteriors are fp64 products of the
+    rounded likelihood ratios (bit-identical to the oracle on the rounded cube), the sweep is fp32: priorities within
+    F32_RTOL of the fp64 oracle, batched and single-quiz forms alike, argmax where the margin allows."""
+    rng = np.random.default_rng(99)
+    eng, orc = float_engine(case, factory)
+    A, D, B = eng.get_kb(case.Q)
+    assert np.array_equal(A, orc.A[:, :, : case.T]) and np.array_equal(D, orc.D[:, : case.T]) and np.array_equal(B, orc.B[: case.T])
+    quizzes = scripted_quizzes(case, eng, 70, rng)
+    ids = [q for q, _ in quizzes]
+    pri_b = eng.eval_priorities_batch(ids, case.Q)
+    picks = eng.next_question_argmax_batch(ids)
+    worst_b = worst_s = worst_f = 0.0
+    for i, (quiz, hist) in enumerate(quizzes):
+        opri, opriors = oracle_priorities(orc, hist)
+        assert np.array_equal(eng.get_priors(quiz), opriors), f"quiz {i}: posterior"
+        tol = f32_tolerance(orc, case)
+        rb = rel_vec(pri_b[i], opri)
+        worst_b = max(worst_b, (rb / tol).max())
+        assert (rb < tol).all(), f"quiz {i} ({hist}): batched fp32 sweep {rb.max():g}, {(rb / tol).max():g} of the tolerance"
+        if i % 5 == 0:
+            pri_s = eng.eval_priorities(quiz)
+            rs = rel_vec(pri_s, opri)
+            worst_s = max(worst_s, (rs / tol).max())
+            worst_f = max(worst_f, (rel_vec(pri_s, pri_b[i]) / tol).max())
+            assert (rs < tol).all() and (rel_vec(pri_s, pri_b[i]) < 2 * tol).all()
+        top = np.sort(opri)[::-1]
+        if top[0] > 0 and (top[0] - top[1]) / top[0] > 10 * tol.max():
+            want = orc.select_argmax(opri)
+            assert picks[i] == want, f"quiz {i}: batched argmax"
+            if i % 5 == 0:
+                assert eng.next_question_argmax(quiz) == want, f"quiz {i}: single-quiz argmax"
+    print(case.name, "fp32 vs fp64 oracle, fraction of the per-question tolerance: batched %.2f, single %.2f; forms %.2f" % (worst_b, worst_s, worst_f))
+    # the rest of the quiz surface on a Float engine: sampled selector, top targets, training, resume
+    quiz, hist = quizzes[-1]
+    q = eng.next_question(quiz)
+    assert 0 <= q < case.Q and q not in case.qgaps and q not in [h[0] for h in hist]
+    eng.record_answer(quiz, 0)
+    orc.start_quiz(cases.WORKERS)
+    for hq, ha in hist + [(q, 0)]:
+        orc.record_answer(hq, ha, cases.WORKERS - 1)
+    assert np.array_equal(eng.get_priors(quiz), orc.priors())
+    top = eng.list_top_targets(quiz, 3)
+    best = np.argsort(-orc.priors(), kind="stable")[:3]
+    assert [t.i_target for t in top] == best.tolist()
+    t0 = next(t for t in range(case.T) if t not in case.tgaps)
+    eng.train([interop.AnsweredQuestion(hq, ha) for hq, ha in hist[:1]] or [interop.AnsweredQuestion(q, 0)], t0, 1.5)
+    A2, D2, _ = eng.get_kb(case.Q)
+    hq, ha = (hist[:1] or [(q, 0)])[0]
+    want = (np.sqrt(A[hq, ha, t0]) * 3.0 + 2.25) + A[hq, ha, t0]
+    assert abs(A2[hq, ha, t0] - want) <= 1.2e-7 * want and abs(D2[hq, t0] - (D[hq, t0] + (want - A[hq, ha, t0]))) <= 2.4e-7 * D2[hq, t0]
+    eng.close()
+
+
+def test_float_engine_kb_file_round_trip(factory, tmp_path):
+    case = cases.small_cases()[1]
+    eng, _ = float_engine(case, factory)
+    path = str(tmp_path / "f32.kb")
+    eng.save_kb(path, False)
+    eng2, err = factory.load_cpu_engine(path)
+    assert err is None and eng2.get_option("precision") == 1
+    for a, b in zip(eng.get_kb(case.Q), eng2.get_kb(case.Q)):
+        assert np.array_equal(a, b)
+    q1, q2 = eng.start_quiz(), eng2.start_quiz()
+    assert np.array_equal(eng.eval_priorities(q1), eng2.eval_priorities(q2))
+    eng.close()
+    eng2.close()
+
+
+def test_batched_sweep_mid_size_fp64_and_fp32(factory):
+    """300 x 5 x 1000 (ldT = 1008 / 1024: four LDS tiles per row by default): 128 quizzes, a seeded subset against the oracle."""
+    case = cases.small_cases()[4]
+    rng = np.random.default_rng(5)
+    for prec in ("f64", "f32"):
+        if prec == "f64":
+            eng, orc = case.make_engine(factory), case.make_oracle()
+            tol = PRIORITY_RTOL
+        else:
+            eng, orc = float_engine(case, factory)
+            tol = None
+        eng.set_option("batch_min", 1)
+        quizzes = scripted_quizzes(case, eng, 128, rng)
+        ids = [q for q, _ in quizzes]
+        pri_b = eng.eval_priorities_batch(ids, case.Q)
+        worst = 0.0
+        for i in (0, 1, 2, 3, 63, 64, 65, 127):
+            opri, _ = oracle_priorities(orc, quizzes[i][1])
+            r = rel_vec(pri_b[i], opri)
+            worst = max(worst, (r / (tol if tol else f32_tolerance(orc, case))).max())
+        print("mid", prec, "max rel err as a fraction of the tolerance: %.3g" % worst)
+        assert worst < 1
+        eng.close()
