@@ -38,8 +38,17 @@ CONFIGS = {
     "T4": dict(Q=4000, K=5, T=4000, name="4000Qx5Ax4000T"),
     "T45": dict(Q=4500, K=5, T=4500, name="4500Qx5Ax4500T"),
     "T5": dict(Q=5000, K=5, T=5000, name="5000Qx5Ax5000T"),
+    # BASELINE configs[4]: 100000Q x 5A x 100000T fp32, 256 concurrent quizzes, question axis over 8 GPUs -- ONE GPU's shard
+    # (12500 questions, 30 GB); with --gpus N every rank holds such a shard of a cube N times as large (weak scaling)
+    "L1": dict(Q=12500, K=5, T=100000, name="12500Qx5Ax100000T", prec="f32", quizzes=256),
+    # the same batched path on small cubes (development / smoke sizes)
+    "LS": dict(Q=1000, K=5, T=1000, name="1000Qx5Ax1000T", prec="f32", quizzes=256),
+    "SB": dict(Q=1000, K=5, T=1000, name="1000Qx5Ax1000T", prec="f64", quizzes=256),
 }
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+FP32_VECTOR_PEAK_TFLOPS = 157.3   # same guide: 64 FLOP/clk/SIMD x 4 SIMDs x 256 CUs x 2.4 GHz
+FP64_VECTOR_PEAK_TFLOPS = 78.6    # half the fp32 vector rate (an fp64 FMA issues over 4 cycles per wave: tools/ubench_fp64.hip)
+FLOPS_PER_ELEMENT = 45            # the reference's operation count per (question, answer, target) element
 SEED = 20260928
 
 
@@ -98,6 +107,15 @@ def main():
 
     cfg = CONFIGS[args.config]
     Q, K, T = cfg["Q"], cfg["K"], cfg["T"]
+    if "quizzes" in cfg:
+        out = run_batched(args, cfg, np, torch, interop, pdist, world, rank, local_rank, device)
+        if rank == 0:
+            os.write(result_fd, (json.dumps(out) + "\n").encode())
+        if world > 1:
+            import torch.distributed as dist
+
+            dist.destroy_process_group()
+        return
     if args.batch < 0:
         args.batch = 64 if Q * (K + 1) * T * 8 < 1e9 else 8
     factory = interop.PqaEngineFactory()
@@ -218,6 +236,21 @@ def main():
     latency_us = {"p10": 1e6 * lat[len(lat) // 10], "p50": 1e6 * lat[len(lat) // 2], "p90": 1e6 * lat[(9 * len(lat)) // 10],
                   "n": len(lat)}
 
+    # ---- the dominant kernel ON THE `value` PATH.  Resident sweep: eval_server_f64's own 100 MHz clock, request in hand to answer
+    # published, per step (engine option server_last_step_ns); a launch per selection: eval_questions_f64, HIP events below.
+    server_step_us = None
+    if resident:
+        ticks = []
+        for _ in range(max(50, min(args.steps, 500))):
+            step()
+            ns = eng.get_option("server_last_step_ns")
+            if ns > 0:
+                ticks.append(ns * 1e-3)
+        if ticks:
+            ticks.sort()
+            server_step_us = {"mean": sum(ticks) / len(ticks), "p10": ticks[len(ticks) // 10], "p50": ticks[len(ticks) // 2],
+                              "p90": ticks[(9 * len(ticks)) // 10], "n": len(ticks)}
+
     launch_rate = None
     if resident:
         eng.set_option("server", 0)   # everything below launches kernels that would wait for the resident one to leave
@@ -225,7 +258,11 @@ def main():
         launch_rate = {"selections_per_sec": max(200, args.steps // 2) / dt_l, "agrees_with_resident": int(sel_l) == int(sel)}
     kernel_ms = kernel_ms_of(eng, quiz, max(20, min(args.steps, 200)))
     alg_bytes = q_local * (K + 1) * T * 8  # one read of every sA row and the mD row, fp64
-    achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+    alg_flops = q_local * K * T * FLOPS_PER_ELEMENT   # ~45 fp64 operations per (question, answer, target)
+    launched_us = kernel_ms * 1e3
+    # the contract's kernel = the one `value` was measured through
+    path_us = server_step_us["mean"] if server_step_us else launched_us
+    achieved = alg_bytes / (path_us * 1e-6) / 1e9
 
     # ---- stream-ordered (pipelined) throughput: selections enqueued back to back, results left on the device
     if selector is None:
@@ -358,11 +395,34 @@ def main():
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
             "traffic": pmc_traffic(args.config, world),
-            "kernel": "eval_questions_f64 (%s)" % eng.eval_kernel_name(),
-            "kernel_us": kernel_ms * 1e3,
+            "kernel": ("eval_server_f64 (wg256_np2, resident: one launch serves the selections; the kernel `value` went through)"
+                       if server_step_us else "eval_questions_f64 (%s)" % eng.eval_kernel_name()),
+            "kernel_us": path_us,
+            "kernel_us_source": ("the resident kernel's own 100 MHz clock per step, request in hand to answer published "
+                                 "(mean of %d steps; p10/p50/p90 in resident_step_us)" % server_step_us["n"]) if server_step_us
+            else "HIP events on the engine's stream around back-to-back launches (mean)",
+            "resident_step_us": server_step_us,
+            "launched_kernel": {"kernel": "eval_questions_f64 (%s)" % eng.eval_kernel_name(), "kernel_us": launched_us,
+                                "achieved": alg_bytes / (launched_us * 1e-6) / 1e9,
+                                "frac": alg_bytes / (launched_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                                "source": "HIP events on the engine's stream around back-to-back launches (mean); the "
+                                          "rocprofv3 --kernel-trace --stats summary of this kernel is under profiles/"},
             "algorithmic_bytes_per_launch": alg_bytes,
             "note": "48 MB cube fits the 256 MiB Infinity Cache: achieved GB/s is not an HBM measurement at this size; "
                     "use --config M for the HBM-bound point" if args.config == "S" else "cube exceeds the Infinity Cache",
+        },
+        # the other roofline ("report both"): the sweep's arithmetic against the fp64 vector peak
+        "roofline_valu": {
+            "bound": "valu_fp64",
+            "achieved": alg_flops / (path_us * 1e-6) / 1e12,
+            "peak": FP64_VECTOR_PEAK_TFLOPS,
+            "unit": "TFLOP/s",
+            "frac": alg_flops / (path_us * 1e-6) / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
+            "algorithmic_flops_per_launch": alg_flops,
+            "flops_per_element": FLOPS_PER_ELEMENT,
+            "pmc": pmc_valu(args.config, world),
+            "note": "algorithmic flops = Q K T x 45 (the reference's operation count, SURVEY 8(d)); pmc = VALU instructions and "
+                    "VALU-busy cycles per launch of the launched kernel from the committed counter pass (profiles/)",
         },
     }
 
@@ -388,6 +448,199 @@ def main():
         dist.destroy_process_group()
 
 
+def run_batched(args, cfg, np, torch, interop, pdist, world, rank, local_rank, device):
+    """BASELINE configs[4]: B quizzes in flight, one batched NextQuestion per step -- the row-sharing sweep
+    (probqa_amd/csrc/batch_kernels.hip: a lane is a quiz, the cube is read once per batch).  A step = the argmax selections
+    of all B quizzes: transposed priors + sweep + per-quiz pick on the device, question ids on the host.  N > 1: every rank
+    holds its own Q-question shard (weak scaling: the cube grows with N), the ranks' per-quiz winners (16 B x B) meet in one
+    RCCL all-gather and every rank makes the same picks."""
+    import torch.distributed as dist
+
+    Q, K, T, B = cfg["Q"], cfg["K"], cfg["T"], cfg["quizzes"]
+    f32 = cfg["prec"] == "f32"
+    steps = args.steps if args.steps != 2000 else (3 if Q * T > 1e8 else 20)       # the defaults are sized for the S config
+    warmup = args.warmup if args.warmup != 5000 else 1
+    factory = interop.PqaEngineFactory()
+    stream = torch.cuda.Stream(device=device)
+    torch.cuda.set_stream(stream)
+    q_total = Q * world
+    kw = dict(prec_type=interop.PrecisionType.FLOAT, prec_exponent=8, prec_mantissa=24) if f32 else {}
+    eng = factory.create_hip_engine(interop.EngineDefinition(K, Q, T, init_amount=0.1, **kw), rank * Q, q_total, local_rank)
+    eng.set_option("select", 1)
+    eng.set_option("batch_min", 1)
+    eng.fill_synthetic(8.0, 0.5, SEED)
+    eng.set_stream(stream.cuda_stream)
+    # B quizzes in different states: quiz i has answered question (37 i) mod Qtotal with answer i mod K (the owner rank records
+    # it, the new posterior is copied to the other ranks' engines)
+    quizzes = [eng.start_quiz() for _ in range(B)]
+    for i, qz in enumerate(quizzes):
+        qa = (37 * i) % q_total
+        owner = qa // Q
+        eng.set_active_question(qz, qa)
+        if owner == rank:
+            eng.record_answer(qz, i % K)
+        else:
+            eng.record_answer_remote(qz, i % K)
+        if world > 1:
+            ptr, ld = eng.prior_device_ptr(qz)
+            eng.synchronize()
+            pdist.broadcast_prior(pdist.tensor_from_device_ptr(ptr, ld, device), owner)
+
+    def step():
+        if world == 1:
+            return eng.next_question_argmax_batch(quizzes)
+        mine = torch.from_numpy(eng.select_argmax_batch(quizzes)).to(device)          # [B, 2] (priority, global index)
+        allw = torch.empty((world, B, 2), dtype=torch.float64, device=device)
+        dist.all_gather_into_tensor(allw, mine)
+        allw = allw.cpu().numpy()
+        picks = []
+        for b in range(B):
+            best, bp = -1, 0.0
+            for r in range(world):
+                p, qi = allw[r, b]
+                if qi >= 0 and (best < 0 or p > bp or (p == bp and qi < best)):
+                    best, bp = int(qi), p
+            picks.append(best)
+        return picks
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    picks = None
+    for _ in range(warmup):
+        picks = step()
+    eng.synchronize()
+    barrier()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record(stream)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        picks = step()
+    ev1.record(stream)
+    eng.synchronize()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    kernel_ms = ev0.elapsed_time(ev1) / steps      # the sweep + its two small companions (prep, pick), on the engine's stream
+    value = B * steps / dt
+    s = 4 if f32 else 8
+    elements = Q * K * T * B
+    alg_flops = elements * FLOPS_PER_ELEMENT
+    alg_bytes = Q * (K + 1) * T * s                # the cube once per batch (SURVEY 8(d): "read once per batch of 256 quizzes")
+    peak = FP32_VECTOR_PEAK_TFLOPS if f32 else FP64_VECTOR_PEAK_TFLOPS
+    tf = alg_flops / (kernel_ms * 1e-3) / 1e12
+    out = {
+        "metric": "next_question_selections_per_sec",
+        "value": value,
+        "unit": "selections/s",
+        "n_gpus": world,
+        "steps": steps,
+        "warmup": warmup,
+        "ms_per_step": 1e3 * dt / steps,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32" if f32 else "f64",
+        "data": "synthetic",
+        "config": {
+            "workload": "%s %s cube per GPU resident in HBM (%.1f GB), %d concurrent quizzes batched along a leading dimension; "
+                        "step = one batched NextQuestion: argmax selection for every quiz, question ids on the host"
+                        % (cfg["name"], cfg["prec"], alg_bytes / 1e9, B),
+            "quizzes_per_batch": B,
+            "questions_per_gpu": Q,
+            "questions_total": q_total,
+            "parallelism": "single GPU" if world == 1 else "question-axis shards x%d (one %d-question shard per GPU), the "
+                           "ranks' per-quiz winners exchanged by one RCCL all-gather of %d B per rank" % (world, Q, 16 * B),
+            "eval_kernel": "eval_batch_kernel<%s> (lane = quiz, LDS tile shared by the batch)" % ("float" if f32 else "double"),
+            "selected_question_of_quiz_0": int(picks[0]),
+        },
+        "question_evals_per_sec": value * q_total,
+        "element_evals_per_sec_per_gpu": elements / (dt / steps),
+        # SURVEY 8(d): this configuration is bound by the vector ALU (transcendental + fp32 arithmetic per element), not by HBM
+        "roofline": {
+            "bound": "valu_fp32" if f32 else "valu_fp64",
+            "achieved": tf,
+            "peak": peak,
+            "unit": "TFLOP/s",
+            "frac": tf / peak,
+            "traffic": pmc_traffic(args.config, world),
+            "kernel": "eval_batch_kernel",
+            "kernel_us": kernel_ms * 1e3,
+            "kernel_us_source": "HIP events on the engine's stream around the timed steps (sweep + prep + pick kernels; the sweep "
+                                "is > 99.9 % of it at this size)",
+            "algorithmic_flops_per_launch": alg_flops,
+            "flops_per_element": FLOPS_PER_ELEMENT,
+            "pmc": pmc_valu(args.config, world),
+            "note": "flops = B Q K T x 45 (the reference's operation count per element, SURVEY 8(d)); peak = the %s vector peak"
+                    % ("fp32" if f32 else "fp64"),
+        },
+        "roofline_hbm": {
+            "bound": "hbm",
+            "achieved": alg_bytes / (kernel_ms * 1e-3) / 1e9,
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": alg_bytes / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "algorithmic_bytes_per_launch": alg_bytes,
+            "note": "algorithmic bytes = the cube once per batch; the batch's work is B x that many element evaluations, so the HBM "
+                    "side idles (SURVEY 8(d)) -- `traffic` above is the measured fetch per batch, priors included",
+        },
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"], out["sample_parity"] = cpu_baseline_batched(np, cfg, eng, quizzes, args.cpu_seconds, f32)
+    eng.close()
+    return out
+
+
+def cpu_baseline_batched(np, cfg, eng, quizzes, seconds, f32):
+    """The CPU port (fp64 -- the reference's CPU engine has no other precision) on a bounded sample of the same workload: the
+    first `n_q` questions of the cube, quiz 0's state; its rate is scaled to whole sweeps of the per-GPU cube.  The same sample
+    checks the GPU batch's priorities for quizzes 0 and 1."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import orclib
+    from probqa_amd import synth
+
+    Q, K, T = cfg["Q"], cfg["K"], cfg["T"]
+    n_q = max(8, min(Q, int(2e7 // (K * T))))                   # ~2e7 elements: tens of milliseconds per sweep per core
+    hw = os.cpu_count() or 1
+    A, D, Bv = synth.synthetic_kb(K, n_q, T, 0.1, 8.0, 0.5, SEED, q_offset=0, q_total=Q)
+    if f32:
+        A, D, Bv = (x.astype(np.float32).astype(np.float64) for x in (A, D, Bv))
+    orc = orclib.Oracle(K, n_q, T, 0.1)
+    orc.set_kb(A, D, Bv)
+    pri_gpu = eng.eval_priorities_batch(quizzes[:64], Q)        # one more batched sweep, priorities kept
+    parity = {}
+    for i in (0, 1):
+        orc.mants[:T] = eng.get_priors(quizzes[i])
+        _, opri = orc.eval_avx2(min(hw, 32))
+        got = pri_gpu[i][:n_q]
+        nz = (opri != 0) & (got != 0)      # (the quiz's own asked question has priority 0 on the GPU; the sample oracle has no asked bits)
+        parity["quiz_%d_max_rel_err" % i] = float(np.max(np.abs(got[nz] - opri[nz]) / opri[nz])) if nz.any() else 0.0
+    parity["questions"] = n_q
+    parity["note"] = "GPU batched sweep vs the fp64 CPU port on the first %d questions of the (rounded) cube" % n_q
+    tried = []
+    for threads in sorted({min(hw, 64), min(hw, 32), min(hw, 16)}):
+        orc.eval_avx2(threads)
+        n, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < seconds / 3 or n < 3:
+            orc.eval_avx2(threads)
+            n += 1
+        dt = time.perf_counter() - t0
+        tried.append((n / dt * (n_q / Q), threads, n, dt))
+    sweeps, threads, n, dt = max(tried)
+    return ({"value": sweeps, "unit": "selections/s", "cores": threads, "kind": "port",
+             "sample": "first %d of %d questions of the %s cube, fp64 AVX2+FMA 4-lane Kahan port, one quiz at a time (the reference "
+                       "serves concurrent quizzes one sweep each): %d sample sweeps in %.1f s on %d threads, scaled by %d/%d to "
+                       "whole-cube selections/s; pool sizes tried: %s"
+                       % (n_q, Q, cfg["name"], n, dt, threads, n_q, Q, ", ".join("%d thr: %.3g/s" % (t, v) for v, t, _, _ in tried))},
+            parity)
+
+
 def pmc_traffic(config, world):
     """HBM-side read bytes per launch of the sweep kernel from the rocprofv3 PMC pass of this workload (FETCH_SIZE in its
     own --pmc run, KB -> bytes, doubled as MI355X_MICROARCH.md prescribes for 16 B/lane streaming reads on gfx950).
@@ -398,6 +651,17 @@ def pmc_traffic(config, world):
     try:
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
             return json.load(f).get(config, {}).get("bytes_per_launch")
+    except (OSError, ValueError):
+        return None
+
+
+def pmc_valu(config, world):
+    """VALU counters per launch of the sweep from the committed PMC pass (profiles/traffic.json, written by tools/prof.sh)."""
+    if world != 1:
+        return None
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            return json.load(f).get(config, {}).get("valu")
     except (OSError, ValueError):
         return None
 

@@ -47,8 +47,9 @@ PQACORE_API void *PqaEngineFactory_CreateHipEngineSharded(void *pvFactory, void 
  * "fused_sampled" (the sampled NextQuestion as one launch instead of sweep + selector; default 0: measured slower),
  * "eval_max_grid" (test hook: cap the workgroups of a sweep so that each streams many questions; 0 = no cap).
  * "batch_min" (PqaEngine_NextQuestionArgmaxBatch: batches of at least this many quizzes take the row-sharing sweep, which
- * reads the cube once per batch; default 32; Float engines always do), "batch_tile" (targets per LDS tile of that sweep, 0 = default).
- * Read-only: "precision" (TPqaPrecisionType of the engine: 1 = Float, 3 = Double), "server_active",
+ * reads the cube once per batch; default 0 = decided by how many waves the batch gives that sweep; Float engines always take it), "batch_tile" (targets per LDS tile of that sweep, 0 = default).
+ * Read-only: "server_last_step_ns" (device-side duration of the newest finished step of the resident sweep: request in hand
+ * to answer published, from the kernel's own 100 MHz clock; -1 if there is none), "precision" (TPqaPrecisionType of the engine: 1 = Float, 3 = Double), "server_active",
  * "ldT", "device". */
 PQACORE_API void *PqaHip_SetOption(void *pvEngine, const char *name, int64_t value);
 PQACORE_API int64_t PqaHip_GetOption(void *pvEngine, const char *name);
@@ -78,6 +79,10 @@ PQACORE_API void *PqaEngine_NextQuestionArgmaxBatch(void *pvEngine, const int64_
 /* The priority vectors of nQuizzes <= 256 distinct quizzes from ONE sweep that reads the cube once for the whole batch
  * (batch_kernels.hip): pOut[i * nLocalQuestions + q] = priority of local question q for pQuizzes[i], 0 for gap / asked
  * questions.  The deterministic output behind PqaEngine_NextQuestionArgmaxBatch's row-sharing form. */
+/* This engine's (shard's) winners of a batch, without NextQuestion's bookkeeping: pOut[i] = {priority, GLOBAL question index or
+ * -1} of pQuizzes[i].  A host that shards the question axis gathers these from the shards, picks per quiz (maximum priority,
+ * lowest index on ties) and calls PqaEngine_SetActiveQuestion on every shard. */
+PQACORE_API void *PqaHip_SelectArgmaxBatch(void *pvEngine, const int64_t nQuizzes, const int64_t *pQuizzes, CiHipSelection *pOut);
 PQACORE_API void *PqaEngine_EvalPrioritiesBatch(void *pvEngine, const int64_t nQuizzes, const int64_t *pQuizzes, double *pOut);
 /* pOut[i] = the device's Log2Hot(pIn[i]) (host buffers): the function the sweep applies to every posterior element
  * (replaces SRVectMath::Log2Hot, reference SRPlatform/Interface/SRVectMath.h:87-135), exposed so that it can be held to

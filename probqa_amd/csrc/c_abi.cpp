@@ -355,6 +355,10 @@ PQACORE_API void *PqaEngine_NextQuestionArgmaxBatch(void *pvEngine, const int64_
   GET_ENGINE_OR_RET_ERR;
   return ReturnErr(pEng->NextQuestionArgmaxBatch(nQuizzes, pQuizzes, pQuestions));
 }
+PQACORE_API void *PqaHip_SelectArgmaxBatch(void *pvEngine, const int64_t nQuizzes, const int64_t *pQuizzes, CiHipSelection *pOut) {
+  GET_ENGINE_OR_RET_ERR;
+  return ReturnErr(pEng->SelectArgmaxBatch(nQuizzes, pQuizzes, pOut));
+}
 PQACORE_API void *PqaEngine_EvalPrioritiesBatch(void *pvEngine, const int64_t nQuizzes, const int64_t *pQuizzes, double *pOut) {
   GET_ENGINE_OR_RET_ERR;
   return ReturnErr(pEng->EvalPrioritiesBatch(nQuizzes, pQuizzes, pOut));

@@ -265,7 +265,7 @@ Error HipEngine::SetOption(const char *name, int64_t value) {
   else if (n == "server") { if (!value) StopServer(); _optServer = value ? 1 : 0; }
   else if (n == "eval_max_grid") { if (value < 0 || value > 65535) goto bad; StopServer(); _optEvalMaxGrid = value; _kbVersion++; }
   else if (n == "fused_sampled") { _optFusedSampled = value ? 1 : 0; }
-  else if (n == "batch_min") { if (value < 1 || value > 257) goto bad; _optBatchMin = value; }
+  else if (n == "batch_min") { if (value < 0 || value > 257) goto bad; _optBatchMin = value; }
   else if (n == "batch_tile") { if (value < 0 || value > 8192) goto bad; _optBatchTile = value; }
   else if (n == "server_vram_mailbox") { if (_serverStream) goto bad; _optServerVramMailbox = value ? 1 : 0; }
   else if (n == "server_idle_us") { if (value < 10 || value > 1000000) goto bad; StopServer(); _optServerIdleUs = value; }
@@ -293,6 +293,14 @@ int64_t HipEngine::GetOption(const char *name) const {
   if (n == "precision") return _precType;
   if (n == "server_vram_mailbox") return _serverStream ? (_serverRequestInVram ? 1 : 0) : _optServerVramMailbox;
   if (n == "debug_mailbox") return (int64_t)(uintptr_t)_hMailbox;
+  if (n == "server_last_step_ns") {   // device-side duration of the newest finished step of the resident sweep (-1: none)
+    if (!_hMailbox || _serverPosted == 0) return -1;
+    volatile ServerMailbox *mb = _hMailbox;
+    const auto t0 = std::chrono::steady_clock::now();
+    while (mb->pad[1] != _serverPosted)   // written right after the answer
+      if (mb->state == kServerExited || std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(100)) return -1;
+    return (int64_t)mb->pad[0] * 10;      // 100 MHz ticks
+  }
   if (n == "server_active") return (_optServer && ServerUsable()) ? 1 : 0;
   if (n == "ldT") return _ldT;
   if (n == "device") return _device;
@@ -779,7 +787,12 @@ Error HipEngine::BatchSweep(int64_t n, const int64_t *pQuizzes, std::vector<Quiz
     HIP_TRY(hipMalloc(&_dBatchScratch, (size_t)kMaxBatch * kBatchGrid * sizeof(SelectResult)));
     HIP_TRY(hipMemset(_dBatchScratch, 0, (size_t)kMaxBatch * kBatchGrid * sizeof(SelectResult)));
   }
-  const bool rowSharing = _elem == 4 || n >= _optBatchMin || wantPriorities;
+  // Which form: the row-sharing sweep has one wave per 64 quizzes and block of questions -- on a small cube a small batch
+  // leaves most of the chip's 1024 SIMDs without a wave (1000 x 5 x 1000, 64 quizzes: 500 waves, 40 k selections/s against
+  // 92 k for grid.y = quiz, whose 48 MB cube is re-read from the Infinity Cache), while 256 quizzes fill it (133 k vs 95 k).
+  // batch_min = 0 (default) decides by the wave count; an explicit value decides by the batch size alone.
+  const int64_t qb = _elem == 4 ? 4 : 2, wavesRowSharing = ((n + 63) / 64) * ((_Q + qb - 1) / qb);
+  const bool rowSharing = _elem == 4 || wantPriorities || (_optBatchMin > 0 ? n >= _optBatchMin : (n >= 32 && wavesRowSharing >= 1536));
   if (!rowSharing && _batchPriorityQ != _Q) {  // per-quiz priority vectors of the grid.y form, (re)sized with the knowledge base
     if (_dBatchPriority) hipFree(_dBatchPriority);
     _dBatchPriority = nullptr;
@@ -848,6 +861,32 @@ Error HipEngine::NextQuestionArgmaxBatch(int64_t n, const int64_t *pQuizzes, int
     if (_hBatch->out[i].index == -3) return HipErr(hipErrorLaunchFailure, "NextQuestionArgmaxBatch (incomplete sweep)");
     Error e;
     pOut[i] = FinishSelection(e, quizzes[i], _hBatch->out[i].index);  // -1 + QuestionsExhausted: reported as -1 only
+  }
+  return Error();
+}
+
+// The batch's local winners without the bookkeeping of NextQuestion: pOut[i] = {priority, GLOBAL question index or -1} of
+// pQuizzes[i] over this engine's questions -- what a host that shards the question axis exchanges between the shards before it
+// sets the active questions (PqaEngine_SetActiveQuestion).
+Error HipEngine::SelectArgmaxBatch(int64_t n, const int64_t *pQuizzes, CiHipSelection *pOut) {
+  std::lock_guard<EngineMutex> lk(_mu);
+  Error err = CheckRegular("compute next questions");
+  if (!err.ok()) return err;
+  if (n < 0 || n > kMaxBatch)
+    return Error::MakeP(ErrCode::IndexOutOfRange, RangeParams(n, 0, kMaxBatch), "Batch size is out of range.");
+  if (n == 0) return Error();
+  if (!pQuizzes || !pOut) return Error::Make(ErrCode::NullArgument, "Nullptr is passed in place of a batch buffer.");
+  hipSetDevice(_device);
+  const uint64_t tag = NextLaunchTag();
+  std::vector<Quiz *> quizzes;
+  err = BatchSweep(n, pQuizzes, quizzes, false, tag);
+  if (!err.ok()) return err;
+  err = WaitBatchFlags(n, tag);
+  if (!err.ok()) return err;
+  for (int64_t i = 0; i < n; i++) {
+    if (_hBatch->out[i].index == -3) return HipErr(hipErrorLaunchFailure, "SelectArgmaxBatch (incomplete sweep)");
+    pOut[i]._priority = _hBatch->out[i].priority;
+    pOut[i]._iQuestion = _hBatch->out[i].index < 0 ? -1 : _hBatch->out[i].index + _qFirst;
   }
   return Error();
 }

@@ -128,7 +128,8 @@ class HipEngine {
   Error GetPriors(int64_t iQuiz, double *pOut, int64_t n);
   int64_t NextQuestionArgmaxGraph(Error &err, Quiz *q);
   Error NextQuestionArgmaxBatch(int64_t n, const int64_t *pQuizzes, int64_t *pOut);
-  Error EvalPrioritiesBatch(int64_t n, const int64_t *pQuizzes, double *pOut);   // pOut[i][q], q < local question count
+  Error EvalPrioritiesBatch(int64_t n, const int64_t *pQuizzes, double *pOut);
+  Error SelectArgmaxBatch(int64_t n, const int64_t *pQuizzes, CiHipSelection *pOut);   // pOut[i][q], q < local question count
   Error Log2HotArray(const double *pIn, double *pOut, int64_t n);  // device log2hot over an array (tests)
   hipStream_t GetStream() const { return _stream; }
   Error SetStream(hipStream_t s);
@@ -254,7 +255,7 @@ class HipEngine {
   int64_t _optFusedSampled = 0;   // the sampled NextQuestion as ONE launch (the sweep's finisher workgroup runs the selector): correct,
                                   // but 38.3 vs 36.4 us at 1000 x 5 x 1000 -- one workgroup's serial selection costs more than a launch
   int64_t _optEvalMaxGrid = 0;    // test hook: KbView::maxGrid
-  int64_t _optBatchMin = 32;      // batches of at least this many quizzes take the row-sharing sweep (lane = quiz); smaller ones grid.y = quiz
+  int64_t _optBatchMin = 0;       // batches of at least this many quizzes take the row-sharing sweep (lane = quiz), smaller ones grid.y = quiz; 0 = by the number of waves the batch gives the row-sharing sweep
   int64_t _optBatchTile = 0;      // targets per LDS tile of that sweep (0 = default)
   int64_t _optUseGraph = 0;   // NextQuestion (argmax) replays a per-quiz HIP graph instead of launching
   int64_t _optTopCache = 10;  // targets RecordAnswer's kernel lists ahead of the ListTopTargets that follows it (0: none)

@@ -126,6 +126,7 @@ HIP_EXPORTS = {
     "PqaEngine_NextQuestionArgmax": (_i64, [_vp, _pvp, _i64]),
     "PqaHip_Log2Hot": (_vp, [_vp, _pdbl, _pdbl, _i64]),
     "PqaEngine_EvalPrioritiesBatch": (_vp, [_vp, _i64, _pi64, _pdbl]),
+    "PqaHip_SelectArgmaxBatch": (_vp, [_vp, _i64, _pi64, ctypes.POINTER(CiHipSelection)]),
     "PqaEngine_NextQuestionArgmaxBatch": (_vp, [_vp, _i64, _pi64, _pi64]),
     "PqaEngine_NextQuestionSampled": (_i64, [_vp, _pvp, _i64, _u64]),
     "PqaHip_GetPriors": (_vp, [_vp, _i64, _pdbl, _i64]),
@@ -515,6 +516,14 @@ class PqaEngine:
         out = (ctypes.c_int64 * max(n, 1))()
         _check(_lib.PqaEngine_NextQuestionArgmaxBatch(self.c_engine, n, qs, out))
         return list(out[:n])
+
+    def select_argmax_batch(self, quizzes) -> np.ndarray:
+        """This engine's (shard's) winners of a batch: array [n, 2] of (priority, GLOBAL question index or -1)."""
+        n = len(quizzes)
+        qs = (ctypes.c_int64 * max(n, 1))(*quizzes)
+        out = (CiHipSelection * max(n, 1))()
+        _check(_lib.PqaHip_SelectArgmaxBatch(self.c_engine, n, qs, out))
+        return np.array([(out[i].priority, out[i].iQuestion) for i in range(n)], dtype=np.float64).reshape(n, 2)
 
     def eval_priorities_batch(self, quizzes, n_local_questions: Optional[int] = None) -> np.ndarray:
         """Priority vectors [len(quizzes), Q] of several distinct quizzes from one sweep that reads the cube once."""
