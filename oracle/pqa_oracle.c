@@ -188,19 +188,87 @@ void orc_kb_set_target_gap(OrcKB *kb, int64_t t, int isGap) {
 }
 void orc_kb_set_question_gap(OrcKB *kb, int64_t q, int isGap) { bit_set(kb->questionGaps, q, isGap); }
 
-/* PqaCore/CETrainOperation.cpp:15-25 (ProcessOne with _inc2B = 2b, _incBSquare = b*b, CETrainTaskNumSpec.h:24-32);
- * PqaCore/CpuEngine.cpp:172 (_vB[iTarget] += amount).  Distinct questions only: the reference's pairing of duplicate
- * questions (Perform2) depends on a lock-free bucket order and is not deterministic. */
-void orc_kb_train(OrcKB *kb, int64_t nAQs, const OrcAQ *aqs, int64_t iTarget, double amount) {
-  const double twoB = 2 * amount, bSquare = amount * amount;
-  for (int64_t i = 0; i < nAQs; i++) {
-    double *pA = &kb->A[((size_t)aqs[i].iQuestion * kb->nAnswers + aqs[i].iAnswer) * kb->ldT + iTarget];
-    double *pD = &kb->D[(size_t)aqs[i].iQuestion * kb->ldT + iTarget];
-    const double a = sqrt(*pA);
-    const double addend = a * twoB + bSquare;
-    *pA = *pA + addend;
-    *pD = *pD + addend;
+/* ---- training: PqaCore/CETrainOperation.cpp:15-83, PqaCore/CETrainTaskNumSpec.h:24-32 ------------------------------
+ * The cube stores squares: one training step takes a = sqrt(A) to a + b, i.e. A += 2ab + b^2, D += the same. */
+static double *kb_a(OrcKB *kb, OrcAQ aq, int64_t t) {
+  return &kb->A[((size_t)aq.iQuestion * kb->nAnswers + aq.iAnswer) * kb->ldT + t];
+}
+static double *kb_d(OrcKB *kb, OrcAQ aq, int64_t t) { return &kb->D[(size_t)aq.iQuestion * kb->ldT + t]; }
+
+/* CETrainOperation::ProcessOne (:15-25) */
+static void train_process_one(OrcKB *kb, OrcAQ aq, int64_t t, double twoB, double bSquare) {
+  double *pA = kb_a(kb, aq, t), *pD = kb_d(kb, aq, t);
+  const double a = sqrt(*pA);                 /* :18 */
+  const double addend = a * twoB + bSquare;   /* :19 */
+  *pA = *pA + addend;                         /* :23-24 */
+  *pD = *pD + addend;                         /* :25 */
+}
+/* CETrainOperation::Perform1 (:28-30) */
+static void train_perform1(OrcKB *kb, OrcAQ aq, int64_t t, double b) { train_process_one(kb, aq, t, 2 * b, b * b); }
+/* CETrainOperation::Perform2 (:32-83): two answered questions at once.  Three cases:
+ *   same question, same answer (:34-35): ONE step of 2b -- ProcessOne with _inc4B = 4b and _incSquare2B = 4 b^2;
+ *   same question, different answers (:37-54): each answer's cell gets its own addend, but mD gets TWICE THE FIRST answer's
+ *     addend (:46-47 "twice the amount in element #2": sseAddend[0] + sseAddend[0]), not the sum of the two;
+ *   different questions (:56-82): two independent Perform1 steps, vectorised. */
+static void train_perform2(OrcKB *kb, OrcAQ first, OrcAQ second, int64_t t, double b) {
+  const double twoB = 2 * b, bSquare = b * b;
+  if (first.iQuestion == second.iQuestion) {
+    if (first.iAnswer == second.iAnswer) {
+      train_process_one(kb, first, t, 4 * b, 4 * bSquare);   /* :35, CETrainTaskNumSpec.h:29-30 */
+    } else {
+      double *pA1 = kb_a(kb, first, t), *pA2 = kb_a(kb, second, t), *pD = kb_d(kb, first, t);
+      const double add1 = sqrt(*pA1) * twoB + bSquare, add2 = sqrt(*pA2) * twoB + bSquare;   /* :42-44 */
+      const double addD = add1 + add1;                       /* :45-46 */
+      *pA1 = *pA1 + add1;                                    /* :47-53 */
+      *pA2 = *pA2 + add2;
+      *pD = *pD + addD;
+    }
+  } else {
+    train_perform1(kb, first, t, b);                         /* :62-81: lane-wise the same operations as two ProcessOne */
+    train_perform1(kb, second, t, b);
   }
+}
+
+/* CpuEngine::TrainSpec (PqaCore/CpuEngine.cpp:102-183): the answered questions are distributed into nWorkers buckets by
+ * iQuestion % nWorkers (CETrainSubtaskDistrib.h:46-52; each bucket is a LIFO list), then every bucket is consumed from its
+ * newest entry backwards, two entries at a time through Perform2, a last odd one through Perform1 (CETrainSubtaskAdd.cpp:17-38).
+ * The reference distributes with several threads racing on an atomic sequence counter; restated here for the order a
+ * single distributing thread produces (sequence number = position in pAQs).  Buckets hold disjoint questions, so the order
+ * between buckets does not matter.  Then _vB[iTarget] += amount (:172). */
+void orc_kb_train_workers(OrcKB *kb, int64_t nAQs, const OrcAQ *aqs, int64_t iTarget, double amount, int64_t nWorkers) {
+  int64_t *last = (int64_t *)malloc(sizeof(int64_t) * (size_t)nWorkers);
+  int64_t *prev = (int64_t *)malloc(sizeof(int64_t) * (size_t)(nAQs > 0 ? nAQs : 1));
+  for (int64_t w = 0; w < nWorkers; w++) last[w] = -1;
+  for (int64_t i = 0; i < nAQs; i++) {                       /* CETrainSubtaskDistrib::Run */
+    const int64_t bucket = aqs[i].iQuestion % nWorkers;
+    prev[i] = last[bucket];
+    last[bucket] = i;
+  }
+  for (int64_t w = 0; w < nWorkers; w++) {                   /* CETrainSubtaskAdd::Run */
+    int64_t iLast = last[w];
+    while (iLast != -1) {
+      const OrcAQ first = aqs[iLast];
+      iLast = prev[iLast];
+      if (iLast == -1) { train_perform1(kb, first, iTarget, amount); break; }
+      const OrcAQ second = aqs[iLast];
+      train_perform2(kb, first, second, iTarget, amount);
+      iLast = prev[iLast];
+    }
+  }
+  free(last);
+  free(prev);
+  kb->B[iTarget] += amount;
+}
+/* Distinct questions: every step is a Perform1 whatever the pairing (kept for the callers that train that way). */
+void orc_kb_train(OrcKB *kb, int64_t nAQs, const OrcAQ *aqs, int64_t iTarget, double amount) {
+  orc_kb_train_workers(kb, nAQs, aqs, iTarget, amount, 1);
+}
+/* CpuEngine::RecordQuizTargetSpec (PqaCore/CpuEngine.cpp:442-466): the quiz's answers in order, pairs (0,1), (2,3), ...
+ * through Perform2, a last odd one through Perform1; _vB[iTarget] += amount. */
+void orc_kb_record_quiz_target(OrcKB *kb, int64_t nAQs, const OrcAQ *aqs, int64_t iTarget, double amount) {
+  int64_t i = 0;
+  for (; i < nAQs - 1; i += 2) train_perform2(kb, aqs[i], aqs[i + 1], iTarget, amount);
+  if (i == nAQs - 1) train_perform1(kb, aqs[i], iTarget, amount);
   kb->B[iTarget] += amount;
 }
 

@@ -80,8 +80,13 @@ OrcKB  *orc_kb_create(int64_t nAnswers, int64_t nQuestions, int64_t nTargets, do
 void    orc_kb_destroy(OrcKB *kb);
 void    orc_kb_set_target_gap(OrcKB *kb, int64_t t, int isGap);
 void    orc_kb_set_question_gap(OrcKB *kb, int64_t q, int isGap);
-/* Train with distinct questions: A += 2*sqrt(A)*b + b^2, D += same, B[t] += b */
-void    orc_kb_train(OrcKB *kb, int64_t nAQs, const OrcAQ *aqs, int64_t iTarget, double amount);
+/* Train: A += 2*sqrt(A)*b + b^2, D += same, B[t] += b; repeated questions by the rules of CETrainOperation::Perform2
+ * (PqaCore/CETrainOperation.cpp:32-83) in the bucket order of CpuEngine::TrainSpec (nWorkers buckets by iQuestion % nWorkers,
+ * each consumed newest first, two at a time; CETrainSubtaskDistrib.h:46-52, CETrainSubtaskAdd.cpp:17-38). */
+void    orc_kb_train_workers(OrcKB *kb, int64_t nAQs, const OrcAQ *aqs, int64_t iTarget, double amount, int64_t nWorkers);
+void    orc_kb_train(OrcKB *kb, int64_t nAQs, const OrcAQ *aqs, int64_t iTarget, double amount);   /* nWorkers = 1 */
+/* RecordQuizTarget (PqaCore/CpuEngine.cpp:442-466): the answers in order, pairwise through Perform2 */
+void    orc_kb_record_quiz_target(OrcKB *kb, int64_t nAQs, const OrcAQ *aqs, int64_t iTarget, double amount);
 OrcQuiz *orc_quiz_create(const OrcKB *kb);
 void    orc_quiz_destroy(OrcQuiz *q);
 

@@ -89,6 +89,34 @@ template <> struct Num<float> {
   static __device__ __forceinline__ float inv(float x) { return 1.0f / x; }
 };
 
+// The lane's priors, requested ahead of their use: body(tc, prior of target tc) for tc in [0, tcN), tcN even; ptc = the lane's
+// column of PT at the tile's first target.  A load whose value is consumed an iteration later is placed by the scheduler right
+// before that use (it shortens the live range), which puts a full L2 round trip in front of every target -- measured, the waves
+// of the 12500 x 5 x 100000 sweep sat in s_waitcnt for 48 % of their cycles.  The scheduling barrier right behind each load
+// keeps it where it is written: two targets (one loop iteration) ahead of its use; the compiler's own wait-count bookkeeping
+// stays in charge of the waits.  The empty asm statements keep the vectorizer from pairing the two unrolled targets'
+// operations lane by lane (both targets' values live at once: 256 VGPRs and spills).
+template <typename R, typename F>
+__device__ __forceinline__ void walk_targets(const R *ptc, int Bp, int tcN, F &&body) {
+  R pA = ptc[0], pB = ptc[Bp];
+#pragma unroll 1
+  for (int tc = 0; tc < tcN; tc += 2) {
+    const int nA = tc + 2 < tcN ? tc + 2 : tcN - 1, nB = tc + 3 < tcN ? tc + 3 : tcN - 1;   // (the tail re-reads the last target)
+    const R a = pA;
+    pA = ptc[(size_t)nA * Bp];
+    __builtin_amdgcn_sched_barrier(0);
+    body(tc, a);
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    const R b = pB;
+    pB = ptc[(size_t)nB * Bp];
+    __builtin_amdgcn_sched_barrier(0);
+    body(tc + 1, b);
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
 struct BatchArgs {
   const void *cube;          // R [Q][K+1][ldT]
   const void *PT;            // R [ldT][Bp]
@@ -98,7 +126,7 @@ struct BatchArgs {
   int64_t K, Q, ldT;
   int TC;                    // targets per tile, a multiple of the workgroup's threads
   double vCompTail;          // ln(sqrt 2) / (nValidTargets + 1)^2 (:191)
-  double *acc;               // fp64 totals, [grid][QB][2K+2][threads]: W_k (K), V_k (K), sum W_k H_k, lack
+  double *acc;               // fp64 totals, [grid][threads][QB][2K+2]: W_k (K), V_k (K), sum W_k H_k, lack
   BatchRecord *recs;         // [grid][Bp]: every workgroup's best question per quiz
   double *priorityT;         // optional [Q][Bp]: the priorities themselves (tests, EvalPrioritiesBatch)
 };
@@ -147,7 +175,10 @@ __global__ __launch_bounds__(256) void eval_batch_kernel(BatchArgs a) {
   const R *pt = static_cast<const R *>(a.PT) + b;
   const uint32_t *asked = live ? a.slots[b].asked : a.qgap;   // (idle lanes: any valid words)
   const int nAcc = (int)(2 * K + 2);
-  double *acc = a.acc + (size_t)blockIdx.x * QB * nAcc * nThreads + tid;   // entry (qi, r) at acc[(qi * nAcc + r) * nThreads]
+  // entry (qi, r) of this lane at acc[qi * nAcc + r]: one contiguous record per lane, so that every entry is the lane's base
+  // pointer plus a (wave-uniform, mostly compile-time) offset -- with entries nThreads apart the 48 addresses were hoisted out of
+  // the tile loops as loop invariants and held 96 VGPRs through them
+  double *acc = a.acc + ((size_t)blockIdx.x * nThreads + tid) * (size_t)(QB * nAcc);
   double bestP = 0.0;
   int64_t bestQ = -1;
   const int64_t nBlocks = (a.Q + QB - 1) / QB;
@@ -173,22 +204,14 @@ __global__ __launch_bounds__(256) void eval_batch_kernel(BatchArgs a) {
         for (int qi = 0; qi < QB; qi++)
 #pragma unroll
           for (int k = 0; k < KG; k++) W[qi][k] = (R)0;
-        // the lane's priors are requested two targets ahead of their use (an L2 round trip is about as long as one target's
-        // arithmetic over the tile's QB x KG elements)
-        const R *ptc = pt + t0 * Bp;
-        R pi1 = ptc[0], pi2 = ptc[tcN > 1 ? Bp : 0];
-#pragma unroll 1
-        for (int tc = 0; tc < tcN; tc++) {
-          const R pi = pi1;
-          pi1 = pi2;
-          pi2 = ptc[(size_t)(tc + 2 < tcN ? tc + 2 : tcN - 1) * Bp];
+        walk_targets<R>(pt + t0 * Bp, Bp, tcN, [&](int tc, R pi) __attribute__((always_inline)) {
           const R *c = tile + (size_t)tc * QB * (KG + 1);
 #pragma unroll
           for (int qi = 0; qi < QB; qi++)
 #pragma unroll
             for (int k = 0; k < KG; k++)
               if (EXACT || k < kN) W[qi][k] = fma(c[qi * (KG + 1) + k], pi, W[qi][k]);   // :81-82, :85
-        }
+        });
 #pragma unroll
         for (int qi = 0; qi < QB; qi++)
 #pragma unroll
@@ -201,7 +224,7 @@ __global__ __launch_bounds__(256) void eval_batch_kernel(BatchArgs a) {
 #pragma unroll
         for (int k = 0; k < KG; k++) {
           invW[qi][k] = (R)div_fast(1.0, Wd[qi][k]);            // :91
-          if (EXACT || k < kN) acc[(qi * nAcc + (int)kg + k) * nThreads] = Wd[qi][k];   // :90
+          if (EXACT || k < kN) acc[qi * nAcc + (int)kg + k] = Wd[qi][k];   // :90
         }
       // ---- pass 2 (:95-128)
       for (int ch = 0; ch < nChunks; ch++) {
@@ -219,13 +242,7 @@ __global__ __launch_bounds__(256) void eval_batch_kernel(BatchArgs a) {
 #pragma unroll
           for (int k = 0; k < KG; k++) v[qi][k] = (R)0;
         }
-        const R *ptc = pt + t0 * Bp;
-        R pi1 = ptc[0], pi2 = ptc[tcN > 1 ? Bp : 0];
-#pragma unroll 1
-        for (int tc = 0; tc < tcN; tc++) {
-          const R pi = pi1;
-          pi1 = pi2;
-          pi2 = ptc[(size_t)(tc + 2 < tcN ? tc + 2 : tcN - 1) * Bp];
+        walk_targets<R>(pt + t0 * Bp, Bp, tcN, [&](int tc, R pi) __attribute__((always_inline)) {
           const R *c = tile + (size_t)tc * QB * (KG + 1);
 #pragma unroll
           for (int qi = 0; qi < QB; qi++) {
@@ -242,8 +259,10 @@ __global__ __launch_bounds__(256) void eval_batch_kernel(BatchArgs a) {
                 v[qi][k] = fma(d, d, v[qi][k]);                  // :126-127
               }
             }
+            __builtin_amdgcn_sched_barrier(0);   // one question's KG elements in flight at a time: enough independent chains to cover
+                                                 // the transcendental latency, and a third of the registers of all QB x KG at once
           }
-        }
+        });
         // fold the chunk's sums into the fp64 totals
         const bool first = ch == 0;
 #pragma unroll
@@ -251,10 +270,10 @@ __global__ __launch_bounds__(256) void eval_batch_kernel(BatchArgs a) {
 #pragma unroll
           for (int k = 0; k < KG; k++)
             if (EXACT || k < kN) {
-              double *p = acc + (qi * nAcc + (int)(K + kg) + k) * nThreads;
+              double *p = acc + qi * nAcc + (int)(K + kg) + k;
               *p = (first ? 0.0 : *p) + (double)v[qi][k];
             }
-          double *ph = acc + (qi * nAcc + (int)(2 * K)) * nThreads, *pl = ph + nThreads;
+          double *ph = acc + qi * nAcc + (int)(2 * K), *pl = ph + 1;
           const bool firstOfQuestion = first && kg == 0;
           *ph = (firstOfQuestion ? 0.0 : *ph) + (double)hW[qi];
           *pl = (firstOfQuestion ? 0.0 : *pl) + (double)accL[qi];
@@ -269,11 +288,10 @@ __global__ __launch_bounds__(256) void eval_batch_kernel(BatchArgs a) {
       const bool skip = bit_test(a.qgap, q) || ((asked[q >> 5] >> (q & 31)) & 1u);   // :54
       double pri = 0.0;
       if (!skip) {
-        double *rec = acc + (size_t)qi * nAcc * nThreads;
+        double *rec = acc + (size_t)qi * nAcc;
         // mWV[k] = W_k * sqrt(V_k) (:156-157) in place of V_k
-        for (int64_t k = 0; k < K; k++) rec[(K + k) * nThreads] = rec[k * nThreads] * sqrt(rec[(K + k) * nThreads]);
-        pri = eval_epilogue_strided(rec, -rec[2 * K * nThreads], rec + K * nThreads, K, rec[(2 * K + 1) * nThreads], a.vCompTail,
-                                    nThreads);
+        for (int64_t k = 0; k < K; k++) rec[K + k] = rec[k] * sqrt(rec[K + k]);
+        pri = eval_epilogue(rec, -rec[2 * K], rec + K, K, rec[2 * K + 1], a.vCompTail);
       }
       if (live) {
         if (a.priorityT) a.priorityT[q * Bp + b] = pri;
@@ -383,7 +401,7 @@ hipError_t launch_batch(const BatchArgs &args0, int nThreads, size_t *accBytesNe
   auto kern = eval_batch_kernel<R, QB, KG, EXACT>;
   const size_t shmem = (Num<R>::kTable ? kLog2TableDoubles * sizeof(double) : 0) + (size_t)args.TC * QB * (KG + 1) * sizeof(R);
   if (shmem > 160 * 1024) return hipErrorInvalidValue;
-  static size_t attrSet = 0;
+  static size_t attrSet = 0;   // (per instantiation)
   if (shmem > 64 * 1024 && shmem > attrSet) {
     const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
     if (e != hipSuccess) return e;
@@ -426,10 +444,21 @@ hipError_t LaunchEvalBatch(const KbView &kb, const QuizSlot *slots, int nSlots, 
   hipError_t e;
   int grid = 0;
   const bool k5 = kb.K == 5;
-  if (f32) e = k5 ? launch_batch<float, 4, 5, true>(a, nThreads, &plan->accBytes, &grid, true, stream)
-                  : launch_batch<float, 4, 4, false>(a, nThreads, &plan->accBytes, &grid, true, stream);
-  else e = k5 ? launch_batch<double, 2, 5, true>(a, nThreads, &plan->accBytes, &grid, true, stream)
-              : launch_batch<double, 2, 4, false>(a, nThreads, &plan->accBytes, &grid, true, stream);
+  // questions per block: the more, the fewer prior loads and tile reads per element -- and the more registers
+  const int qb = plan->questionsPerBlock > 0 ? plan->questionsPerBlock : (f32 ? 4 : 2);
+  auto run = [&](bool query, size_t *accBytes) -> hipError_t {
+    if (f32) {
+      if (k5) return qb >= 4 ? launch_batch<float, 4, 5, true>(a, nThreads, accBytes, &grid, query, stream)
+                             : launch_batch<float, 2, 5, true>(a, nThreads, accBytes, &grid, query, stream);
+      return qb >= 4 ? launch_batch<float, 4, 4, false>(a, nThreads, accBytes, &grid, query, stream)
+                     : launch_batch<float, 2, 4, false>(a, nThreads, accBytes, &grid, query, stream);
+    }
+    if (k5) return qb >= 2 ? launch_batch<double, 2, 5, true>(a, nThreads, accBytes, &grid, query, stream)
+                           : launch_batch<double, 1, 5, true>(a, nThreads, accBytes, &grid, query, stream);
+    return qb >= 2 ? launch_batch<double, 2, 4, false>(a, nThreads, accBytes, &grid, query, stream)
+                   : launch_batch<double, 1, 4, false>(a, nThreads, accBytes, &grid, query, stream);
+  };
+  e = run(true, &plan->accBytes);
   if (e != hipSuccess) return e;
   plan->grid = grid;
   plan->recBytes = (size_t)grid * Bp * sizeof(BatchRecord);
@@ -441,10 +470,7 @@ hipError_t LaunchEvalBatch(const KbView &kb, const QuizSlot *slots, int nSlots, 
   e = hipGetLastError();
   if (e != hipSuccess) return e;
   size_t dummy = 0;
-  if (f32) e = k5 ? launch_batch<float, 4, 5, true>(a, nThreads, &dummy, &grid, false, stream)
-                  : launch_batch<float, 4, 4, false>(a, nThreads, &dummy, &grid, false, stream);
-  else e = k5 ? launch_batch<double, 2, 5, true>(a, nThreads, &dummy, &grid, false, stream)
-              : launch_batch<double, 2, 4, false>(a, nThreads, &dummy, &grid, false, stream);
+  e = run(false, &dummy);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(batch_pick_kernel, dim3((unsigned)((nSlots + 255) / 256)), dim3(256), 0, stream, recs, grid, Bp, slots, nSlots,
                      outBase, flagValue);

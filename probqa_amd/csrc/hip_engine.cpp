@@ -266,6 +266,7 @@ Error HipEngine::SetOption(const char *name, int64_t value) {
   else if (n == "eval_max_grid") { if (value < 0 || value > 65535) goto bad; StopServer(); _optEvalMaxGrid = value; _kbVersion++; }
   else if (n == "fused_sampled") { _optFusedSampled = value ? 1 : 0; }
   else if (n == "batch_min") { if (value < 0 || value > 257) goto bad; _optBatchMin = value; }
+  else if (n == "batch_qb") { if (value < 0 || value > 4) goto bad; _optBatchQb = value; }
   else if (n == "batch_tile") { if (value < 0 || value > 8192) goto bad; _optBatchTile = value; }
   else if (n == "server_vram_mailbox") { if (_serverStream) goto bad; _optServerVramMailbox = value ? 1 : 0; }
   else if (n == "server_idle_us") { if (value < 10 || value > 1000000) goto bad; StopServer(); _optServerIdleUs = value; }
@@ -290,6 +291,7 @@ int64_t HipEngine::GetOption(const char *name) const {
   if (n == "fused_sampled") return _optFusedSampled;
   if (n == "batch_min") return _optBatchMin;
   if (n == "batch_tile") return _optBatchTile;
+  if (n == "batch_qb") return _optBatchQb;
   if (n == "precision") return _precType;
   if (n == "server_vram_mailbox") return _serverStream ? (_serverRequestInVram ? 1 : 0) : _optServerVramMailbox;
   if (n == "debug_mailbox") return (int64_t)(uintptr_t)_hMailbox;
@@ -791,7 +793,7 @@ Error HipEngine::BatchSweep(int64_t n, const int64_t *pQuizzes, std::vector<Quiz
   // leaves most of the chip's 1024 SIMDs without a wave (1000 x 5 x 1000, 64 quizzes: 500 waves, 40 k selections/s against
   // 92 k for grid.y = quiz, whose 48 MB cube is re-read from the Infinity Cache), while 256 quizzes fill it (133 k vs 95 k).
   // batch_min = 0 (default) decides by the wave count; an explicit value decides by the batch size alone.
-  const int64_t qb = _elem == 4 ? 4 : 2, wavesRowSharing = ((n + 63) / 64) * ((_Q + qb - 1) / qb);
+  const int64_t qb = _optBatchQb > 0 ? _optBatchQb : (_elem == 4 ? 4 : 2), wavesRowSharing = ((n + 63) / 64) * ((_Q + qb - 1) / qb);
   const bool rowSharing = _elem == 4 || wantPriorities || (_optBatchMin > 0 ? n >= _optBatchMin : (n >= 32 && wavesRowSharing >= 1536));
   if (!rowSharing && _batchPriorityQ != _Q) {  // per-quiz priority vectors of the grid.y form, (re)sized with the knowledge base
     if (_dBatchPriority) hipFree(_dBatchPriority);
@@ -821,6 +823,7 @@ Error HipEngine::BatchSweep(int64_t n, const int64_t *pQuizzes, std::vector<Quiz
   const KbView kb = View();
   BatchPlan plan{};
   plan.tileTargets = (int)_optBatchTile;
+  plan.questionsPerBlock = (int)_optBatchQb;
   HIP_TRY(LaunchEvalBatch(kb, _dBatchSlots, (int)n, &plan, nullptr, nullptr, nullptr, nullptr, 0, tag, true, _stream));
   auto grow = [&](void **p, size_t &have, size_t need) -> hipError_t {
     if (need <= have) return hipSuccess;

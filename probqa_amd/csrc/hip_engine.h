@@ -256,6 +256,7 @@ class HipEngine {
                                   // but 38.3 vs 36.4 us at 1000 x 5 x 1000 -- one workgroup's serial selection costs more than a launch
   int64_t _optEvalMaxGrid = 0;    // test hook: KbView::maxGrid
   int64_t _optBatchMin = 0;       // batches of at least this many quizzes take the row-sharing sweep (lane = quiz), smaller ones grid.y = quiz; 0 = by the number of waves the batch gives the row-sharing sweep
+  int64_t _optBatchQb = 0;        // questions per block of that sweep (0 = default)
   int64_t _optBatchTile = 0;      // targets per LDS tile of that sweep (0 = default)
   int64_t _optUseGraph = 0;   // NextQuestion (argmax) replays a per-quiz HIP graph instead of launching
   int64_t _optTopCache = 10;  // targets RecordAnswer's kernel lists ahead of the ListTopTargets that follows it (0: none)

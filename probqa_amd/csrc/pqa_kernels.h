@@ -84,6 +84,7 @@ constexpr int kBatchMaxGrid = 2048;
 struct BatchRecord { double priority; int64_t index; };   // a workgroup's best question of one quiz (index < 0: none)
 struct BatchPlan {
   int tileTargets;        // in: targets per LDS tile (0 = default)
+  int questionsPerBlock;  // in: questions staged together (0 = default: 4 fp32, 2 fp64; else the largest built shape <= this)
   int grid, Bp;           // out: workgroups of the sweep; quizzes rounded up to whole waves
   size_t ptBytes, accBytes, recBytes;   // out: sizes of the scratch buffers PT / acc / recs the caller provides
 };

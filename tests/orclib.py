@@ -63,6 +63,8 @@ def lib() -> ctypes.CDLL:
         "orc_kb_set_target_gap": (None, [pKB, i64, ctypes.c_int]),
         "orc_kb_set_question_gap": (None, [pKB, i64, ctypes.c_int]),
         "orc_kb_train": (None, [pKB, i64, ctypes.POINTER(OrcAQ), i64, ctypes.c_double]),
+        "orc_kb_train_workers": (None, [pKB, i64, ctypes.POINTER(OrcAQ), i64, ctypes.c_double, i64]),
+        "orc_kb_record_quiz_target": (None, [pKB, i64, ctypes.POINTER(OrcAQ), i64, ctypes.c_double]),
         "orc_quiz_create": (pQz, [pKB]),
         "orc_quiz_destroy": (None, [pQz]),
         "orc_eval_subtask": (None, [pKB, pQz, i64, i64, i64, pd, pd]),
@@ -127,9 +129,16 @@ class Oracle:
         for q in qs:
             self.L.orc_kb_set_question_gap(self.kb, int(q), 1)
 
-    def train(self, aqs, i_target: int, amount: float = 1.0):
+    def train(self, aqs, i_target: int, amount: float = 1.0, n_workers: int = 16):
+        """CpuEngine::TrainSpec for a thread pool of n_workers (repeated questions pair up by its bucket order)."""
         arr = (OrcAQ * max(len(aqs), 1))(*[OrcAQ(q, a) for q, a in aqs])
-        self.L.orc_kb_train(self.kb, len(aqs), arr, i_target, amount)
+        self.L.orc_kb_train_workers(self.kb, len(aqs), arr, i_target, amount, n_workers)
+
+    def record_quiz_target(self, i_target: int, amount: float = 1.0, aqs=None):
+        """RecordQuizTarget over the quiz's answers (or the given ones), in order."""
+        aqs = self.answers if aqs is None else aqs
+        arr = (OrcAQ * max(len(aqs), 1))(*[OrcAQ(q, a) for q, a in aqs])
+        self.L.orc_kb_record_quiz_target(self.kb, len(aqs), arr, i_target, amount)
 
     def start_quiz(self, n_workers: int = 16):
         self.answers = []

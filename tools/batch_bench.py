@@ -9,6 +9,7 @@ prec, B = sys.argv[4], int(sys.argv[5])
 tile = int(sys.argv[6]) if len(sys.argv) > 6 else 0
 bmin = int(sys.argv[7]) if len(sys.argv) > 7 else 1
 reps = int(sys.argv[8]) if len(sys.argv) > 8 else 5
+qb = int(sys.argv[9]) if len(sys.argv) > 9 else 0
 f = interop.PqaEngineFactory()
 if prec == "f32":
     d = interop.EngineDefinition(K, Q, T, init_amount=0.1, prec_type=interop.PrecisionType.FLOAT, prec_exponent=8, prec_mantissa=24)
@@ -19,6 +20,7 @@ assert err is None, err
 eng.fill_synthetic(8.0, 0.5, 20260928)
 eng.set_option("batch_min", bmin)
 eng.set_option("batch_tile", tile)
+eng.set_option("batch_qb", qb)
 quizzes = [eng.start_quiz() for _ in range(B)]
 picks = eng.next_question_argmax_batch(quizzes)
 t0 = time.perf_counter()
@@ -26,6 +28,6 @@ for _ in range(reps):
     picks = eng.next_question_argmax_batch(quizzes)
 dt = (time.perf_counter() - t0) / reps
 el = Q * K * T * B
-print("%dx%dx%d %s B=%d tile=%d min=%d: %.3f ms/batch, %.0f selections/s, %.3g element-evals/s, pick0=%d"
-      % (Q, K, T, prec, B, tile, bmin, dt * 1e3, B / dt, el / dt, picks[0]))
+print("%dx%dx%d %s B=%d tile=%d min=%d qb=%d: %.3f ms/batch, %.0f selections/s, %.3g element-evals/s, pick0=%d"
+      % (Q, K, T, prec, B, tile, bmin, qb, dt * 1e3, B / dt, el / dt, picks[0]))
 eng.close()
