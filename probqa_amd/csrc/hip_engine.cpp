@@ -1201,81 +1201,128 @@ int64_t HipEngine::ListTopTargets(Error &err, int64_t iQuiz, int64_t maxCount, C
 // ------------------------------------------------------------------------------------------------------------------
 // training (reference PqaCore/CpuEngine.cpp:102-183, :442-466; PqaCore/CETrainOperation.cpp:15-25)
 // ------------------------------------------------------------------------------------------------------------------
+// The steps of one training call in the reference's pairing, for this engine's (shard's) questions.
+//   fromQuiz = false: CpuEngine::TrainSpec (CpuEngine.cpp:102-183) -- the answered questions go into nWorkers LIFO buckets by
+//     iQuestion % nWorkers (CETrainSubtaskDistrib.h:46-52; restated for one distributing thread, i.e. sequence = position in
+//     pAQs: the reference's distributing threads race for the sequence numbers), every bucket is consumed newest first, two
+//     entries at a time through Perform2, a last odd one through Perform1 (CETrainSubtaskAdd.cpp:17-38);
+//   fromQuiz = true: CpuEngine::RecordQuizTargetSpec (CpuEngine.cpp:442-466) -- the quiz's answers in order, pairs (0,1), (2,3) ...
+// Perform2 over two different questions is two independent Perform1 steps (CETrainOperation.cpp:56-82); over one question it
+// is a step of kind 2 (same answer) or 3 (different answers), see kb_kernels.hip.  The steps come out grouped by question
+// (chains), each chain in execution order; steps on other shards' questions are dropped.
+void HipEngine::BuildTrainSteps(int64_t n, const AQ *pAQs, bool fromQuiz, std::vector<TrainStep> &steps, std::vector<int64_t> &chainStart) const {
+  std::vector<std::pair<int64_t, TrainStep>> ordered;   // (execution rank, step)
+  int64_t rank = 0;
+  auto local = [&](int64_t q) { return q >= _qFirst && q < _qFirst + _Q; };
+  auto perform1 = [&](const AQ &aq) {
+    if (local(aq.iQuestion)) ordered.push_back({rank++, TrainStep{1, aq.iQuestion - _qFirst, aq.iAnswer, aq.iAnswer}});
+  };
+  auto perform2 = [&](const AQ &first, const AQ &second) {
+    if (first.iQuestion != second.iQuestion) { perform1(first); perform1(second); return; }
+    if (!local(first.iQuestion)) return;
+    ordered.push_back({rank++, TrainStep{first.iAnswer == second.iAnswer ? 2 : 3, first.iQuestion - _qFirst, first.iAnswer, second.iAnswer}});
+  };
+  if (fromQuiz) {
+    int64_t i = 0;
+    for (; i < n - 1; i += 2) perform2(pAQs[i], pAQs[i + 1]);
+    if (i == n - 1) perform1(pAQs[i]);
+  } else {
+    const int64_t nWorkers = _optWorkers;
+    std::vector<int64_t> last((size_t)nWorkers, -1), prev((size_t)std::max<int64_t>(n, 1), -1);
+    for (int64_t i = 0; i < n; i++) {
+      const int64_t bucket = pAQs[i].iQuestion % nWorkers;
+      prev[i] = last[bucket];
+      last[bucket] = i;
+    }
+    for (int64_t w = 0; w < nWorkers; w++) {
+      int64_t iLast = last[w];
+      while (iLast != -1) {
+        const AQ &first = pAQs[iLast];
+        iLast = prev[iLast];
+        if (iLast == -1) { perform1(first); break; }
+        perform2(first, pAQs[iLast]);
+        iLast = prev[iLast];
+      }
+    }
+  }
+  std::stable_sort(ordered.begin(), ordered.end(), [](const auto &x, const auto &y) { return x.second.q < y.second.q; });
+  steps.clear();
+  chainStart.clear();
+  for (size_t i = 0; i < ordered.size(); i++) {
+    if (i == 0 || ordered[i].second.q != ordered[i - 1].second.q) chainStart.push_back((int64_t)i);
+    steps.push_back(ordered[i].second);
+  }
+  chainStart.push_back((int64_t)ordered.size());
+}
+
+// Validation (CETrainSubtaskDistrib.h:26-45, CpuEngine.cpp:138-155) + the steps on the device; the caller holds the lock.
+Error HipEngine::TrainLocked(int64_t nQuestions, const AQ *pAQs, int64_t iTarget, double amount, bool fromQuiz) {
+  StopServer();   // the cube changes: the resident sweep's XCD-local L2s would keep stale rows
+  if (iTarget < 0 || iTarget >= _T)
+    return Error::MakeP(ErrCode::IndexOutOfRange, RangeParams(iTarget, 0, _T - 1), "Target index is not in KB range.");
+  if (BitTest(_hTGap, iTarget))
+    return Error::MakeP(ErrCode::AbsentId, "id=" + std::to_string(iTarget), "Target index is not in KB (but rather at a gap).");
+  for (int64_t i = 0; i < nQuestions; i++) {
+    const int64_t iq = pAQs[i].iQuestion, ia = pAQs[i].iAnswer;
+    if (iq < 0 || iq >= _qTotal)
+      return Error::MakeP(ErrCode::IndexOutOfRange, RangeParams(iq, 0, _qTotal - 1), "Question index is not in KB range.");
+    if (iq >= _qFirst && iq < _qFirst + _Q && BitTest(_hQGap, iq - _qFirst))
+      return Error::MakeP(ErrCode::AbsentId, "id=" + std::to_string(iq), "Question index is not in KB (but rather at a gap).");
+    if (ia < 0 || ia >= _K)
+      return Error::MakeP(ErrCode::IndexOutOfRange, RangeParams(ia, 0, _K - 1), "Answer index is not in KB range.");
+  }
+  std::vector<TrainStep> steps;
+  std::vector<int64_t> chainStart;
+  BuildTrainSteps(nQuestions, pAQs, fromQuiz, steps, chainStart);
+  hipSetDevice(_device);
+  // one device buffer for both arrays: [steps | chainStart]
+  const size_t stepBytes = steps.size() * sizeof(TrainStep), chainBytes = chainStart.size() * sizeof(int64_t);
+  const int64_t needWords = (int64_t)((stepBytes + chainBytes) / sizeof(int64_t));
+  if (needWords > 2 * _aqCapacity) {
+    hipFree(_dAqs);
+    _dAqs = nullptr;
+    _aqCapacity = 0;
+    const int64_t cap = std::max<int64_t>((needWords + 1) / 2, 64);
+    HIP_TRY(hipMalloc(&_dAqs, (size_t)cap * 2 * sizeof(int64_t)));
+    _aqCapacity = cap;
+  }
+  char *dBuf = reinterpret_cast<char *>(_dAqs);
+  if (stepBytes > 0) HIP_TRY(hipMemcpyAsync(dBuf, steps.data(), stepBytes, hipMemcpyHostToDevice, _stream));
+  HIP_TRY(hipMemcpyAsync(dBuf + stepBytes, chainStart.data(), chainBytes, hipMemcpyHostToDevice, _stream));
+  HIP_TRY(LaunchTrainSteps(_dCube, _elem, _dVB, _K, _ldT, reinterpret_cast<const TrainStep *>(dBuf),
+                           reinterpret_cast<const int64_t *>(dBuf + stepBytes), (int64_t)chainStart.size() - 1, iTarget, amount, _stream));
+  HIP_TRY(hipStreamSynchronize(_stream));   // (the host vectors are the copies' sources)
+  return Error();
+}
+
 Error HipEngine::Train(int64_t nQuestions, const AQ *pAQs, int64_t iTarget, double amount) {
   if (nQuestions < 0)
     return Error::MakeP(ErrCode::NegativeCount, "count=" + std::to_string(nQuestions), "|nQuestions| must be non-negative.");
   if (amount <= 0)
     return Error::MakeP(ErrCode::NonPositiveAmount, "amount=" + std::to_string(amount), "|amount| must be positive.");
+  if (nQuestions > 0 && pAQs == nullptr) return Error::Make(ErrCode::NullArgument, "Nullptr is passed in place of answered questions.");
   std::lock_guard<EngineMutex> lk(_mu);
-  StopServer();   // the cube changes: the resident sweep's XCD-local L2s would keep stale rows
   if (_mode == Mode::Shutdown) return Error::MakeP(ErrCode::ObjectShutDown, "RejectedOperation=Train", "Engine is shut down.");
+  Error e = TrainLocked(nQuestions, pAQs, iTarget, amount, false);
+  if (e.ok()) _nQuestionsAsked.fetch_add((uint64_t)nQuestions, std::memory_order_relaxed);  // reference CpuEngine.cpp:176
+  return e;
+}
+
+Error HipEngine::RecordQuizTarget(int64_t iQuiz, int64_t iTarget, double amount) {
+  // reference PqaCore/BaseEngine.cpp:529-566, PqaCore/CpuEngine.cpp:442-466: the quiz's answers, pairwise in order, under ONE
+  // hold of the lock (the quiz cannot be answered or released in between); the asked-questions counter is not touched
+  if (amount <= 0)
+    return Error::MakeP(ErrCode::NonPositiveAmount, "amount=" + std::to_string(amount), "|amount| must be positive.");
+  std::lock_guard<EngineMutex> lk(_mu);
+  Error err = CheckRegular("record quiz target");
+  if (!err.ok()) return err;
   if (iTarget < 0 || iTarget >= _T)
     return Error::MakeP(ErrCode::IndexOutOfRange, RangeParams(iTarget, 0, _T - 1), "Target index is not in KB range.");
   if (BitTest(_hTGap, iTarget))
     return Error::MakeP(ErrCode::AbsentId, "id=" + std::to_string(iTarget), "Target index is not in KB (but rather at a gap).");
-  std::vector<int64_t> local;
-  local.reserve(2 * (size_t)nQuestions);
-  bool dup = false;
-  std::vector<int64_t> seen;
-  for (int64_t i = 0; i < nQuestions; i++) {
-    const int64_t iq = pAQs[i].iQuestion, ia = pAQs[i].iAnswer;
-    // CETrainSubtaskDistrib validation (reference PqaCore/CETrainSubtaskDistrib.h)
-    if (iq < 0 || iq >= _qTotal)
-      return Error::MakeP(ErrCode::IndexOutOfRange, RangeParams(iq, 0, _qTotal - 1), "Question index is not in KB range.");
-    if (ia < 0 || ia >= _K)
-      return Error::MakeP(ErrCode::IndexOutOfRange, RangeParams(ia, 0, _K - 1), "Answer index is not in KB range.");
-    if (iq < _qFirst || iq >= _qFirst + _Q) continue;
-    if (BitTest(_hQGap, iq - _qFirst))
-      return Error::MakeP(ErrCode::AbsentId, "id=" + std::to_string(iq), "Question index is not in KB (but rather at a gap).");
-    if (std::find(seen.begin(), seen.end(), iq) != seen.end()) dup = true;
-    seen.push_back(iq);
-    local.push_back(iq - _qFirst);
-    local.push_back(ia);
-  }
-  hipSetDevice(_device);
-  const int64_t nLocal = (int64_t)local.size() / 2;
-  if (nLocal > _aqCapacity) {
-    hipFree(_dAqs);
-    _dAqs = nullptr;
-    _aqCapacity = std::max<int64_t>(nLocal, 64);
-    HIP_TRY(hipMalloc(&_dAqs, (size_t)_aqCapacity * 2 * sizeof(int64_t)));
-  }
-  if (nLocal > 0) HIP_TRY(hipMemcpyAsync(_dAqs, local.data(), local.size() * sizeof(int64_t), hipMemcpyHostToDevice, _stream));
-  if (!dup) {
-    HIP_TRY(LaunchTrain(_dCube, _elem, _dVB, _K, _ldT, _dAqs, nLocal, iTarget, amount, _stream));
-  } else {
-    // duplicate questions: apply one by one in the given order (each step is the reference's Perform1); vB once
-    for (int64_t i = 0; i < nLocal; i++)
-      HIP_TRY(LaunchTrain(_dCube, _elem, _dVB, _K, _ldT, _dAqs + 2 * i, 1, iTarget, i == 0 ? amount : 0.0, _stream));
-  }
-  HIP_TRY(hipStreamSynchronize(_stream));
-  _nQuestionsAsked.fetch_add((uint64_t)nQuestions, std::memory_order_relaxed);  // reference CpuEngine.cpp:176
-  return Error();
-}
-
-Error HipEngine::RecordQuizTarget(int64_t iQuiz, int64_t iTarget, double amount) {
-  std::vector<AQ> answers;
-  {
-    // reference PqaCore/BaseEngine.cpp:529-566
-    if (amount <= 0)
-      return Error::MakeP(ErrCode::NonPositiveAmount, "amount=" + std::to_string(amount), "|amount| must be positive.");
-    std::lock_guard<EngineMutex> lk(_mu);
-  StopServer();   // the cube changes: the resident sweep's XCD-local L2s would keep stale rows
-    Error err = CheckRegular("record quiz target");
-    if (!err.ok()) return err;
-    if (iTarget < 0 || iTarget >= _T)
-      return Error::MakeP(ErrCode::IndexOutOfRange, RangeParams(iTarget, 0, _T - 1), "Target index is not in KB range.");
-    if (BitTest(_hTGap, iTarget))
-      return Error::MakeP(ErrCode::AbsentId, "id=" + std::to_string(iTarget), "Target index is not in KB (but rather at a gap).");
-    Quiz *q = UseQuiz(err, iQuiz);
-    if (!q) return err;
-    answers = q->answers;
-  }
-  // reference PqaCore/CpuEngine.cpp:442-466: train on the quiz's answers; the asked-questions counter is not bumped
-  const uint64_t before = _nQuestionsAsked.load();
-  Error e = Train((int64_t)answers.size(), answers.data(), iTarget, amount);
-  _nQuestionsAsked.store(before);
-  return e;
+  Quiz *q = UseQuiz(err, iQuiz);
+  if (!q) return err;
+  return TrainLocked((int64_t)q->answers.size(), q->answers.data(), iTarget, amount, true);
 }
 
 // ------------------------------------------------------------------------------------------------------------------

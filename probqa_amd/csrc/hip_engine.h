@@ -152,6 +152,8 @@ class HipEngine {
   int64_t FindNearestQuestion(int64_t iMiddleGlobal, const Quiz *q) const;  // BaseEngine.cpp:60-124
   bool QuestionUnavailable(const Quiz *q, int64_t qGlobal) const;
   Error RecordAnswerImpl(int64_t iQuiz, int64_t iAnswer, bool remote);
+  void BuildTrainSteps(int64_t n, const AQ *pAQs, bool fromQuiz, std::vector<TrainStep> &steps, std::vector<int64_t> &chainStart) const;
+  Error TrainLocked(int64_t nQuestions, const AQ *pAQs, int64_t iTarget, double amount, bool fromQuiz);
   uint64_t NextRandom();
   Error UploadGaps();
   Error ReallocKB(int64_t newQ, int64_t newT);               // grow the device cube / vB / per-question buffers

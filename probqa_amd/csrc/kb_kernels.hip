@@ -1,7 +1,7 @@
 // kb_kernels.hip -- knowledge-base construction / mutation and top-target listing on gfx950.
 //   fill_fresh      : CpuEngine ctor (reference: PqaCore/CpuEngine.cpp:44-84)  A = init^2, D = init^2*K, B = init
 //   fill_synthetic  : deterministic benchmark / test cube, bit-identical to probqa_amd/synth.py (numpy)
-//   train           : CETrainOperation::ProcessOne (PqaCore/CETrainOperation.cpp:15-25) for distinct questions
+//   train           : CETrainOperation::Perform1 / Perform2 (PqaCore/CETrainOperation.cpp:15-83)
 //   top_targets     : ListTopTargets (PqaCore/CEListTopTargetsAlgorithm.cpp:30-95): descending probability
 #include "pqa_device.h"
 #include "pqa_kernels.h"
@@ -69,20 +69,39 @@ __global__ __launch_bounds__(256) void fill_synth_kernel(void *__restrict__ cube
   }
 }
 
-__global__ void train_kernel(void *__restrict__ cube, int elem, double *__restrict__ vB, int64_t K, int64_t ldT,
-                             const int64_t *__restrict__ aqs, int64_t nAQs, int64_t iTarget, double amount) {
+// Training (reference PqaCore/CETrainOperation.cpp:15-83).  The host turns the call's answered questions into steps in the
+// reference's own pairing order (hip_engine.cpp: BuildTrainSteps) and groups the steps by question: steps on different
+// questions touch different cells and run in parallel, one thread per question; a question's steps run in order.
+//   kind 1  Perform1 (:28-30, and either half of a Perform2 over two different questions, :56-82): a = sqrt(A); A, D += 2ab + b^2
+//   kind 2  Perform2, same question and answer (:34-35): ONE step of 2b -- A, D += 4ab + 4b^2 (_inc4B, _incSquare2B)
+//   kind 3  Perform2, same question, answers a1 != a2 (:37-54): each cell its own addend; D += TWICE THE FIRST cell's addend (:45-46)
+__global__ void train_steps_kernel(void *__restrict__ cube, int elem, double *__restrict__ vB, int64_t K, int64_t ldT,
+                                   const TrainStep *__restrict__ steps, const int64_t *__restrict__ chainStart, int64_t nChains,
+                                   int64_t iTarget, double amount) {
   const double twoB = 2 * amount, bSquare = amount * amount;  // CETrainTaskNumSpec.h:24-32
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nAQs; i += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t q = aqs[2 * i], ans = aqs[2 * i + 1];
-    const int64_t iA = (q * (K + 1) + ans) * ldT + iTarget, iD = (q * (K + 1) + K) * ldT + iTarget;
-    const double oldA = cube_ld(cube, elem, iA);
-    const double a = sqrt(oldA);                               // CETrainOperation.cpp:18
-    const double addend = a * twoB + bSquare;                  // :19
-    cube_st(cube, elem, iA, oldA + addend);                    // :23-24
-    cube_st(cube, elem, iD, cube_ld(cube, elem, iD) + addend); // :25
+  const double fourB = 4 * amount, square2B = 4 * bSquare;
+  for (int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; c < nChains; c += (int64_t)gridDim.x * blockDim.x) {
+    for (int64_t i = chainStart[c]; i < chainStart[c + 1]; i++) {
+      const TrainStep st = steps[i];
+      const int64_t iA = (st.q * (K + 1) + st.a1) * ldT + iTarget, iD = (st.q * (K + 1) + K) * ldT + iTarget;
+      const double oldA = cube_ld(cube, elem, iA);
+      const double a = sqrt(oldA);                               // CETrainOperation.cpp:18
+      if (st.kind == 3) {
+        const int64_t iA2 = (st.q * (K + 1) + st.a2) * ldT + iTarget;
+        const double oldA2 = cube_ld(cube, elem, iA2);
+        const double add1 = a * twoB + bSquare, add2 = sqrt(oldA2) * twoB + bSquare;   // :42-44
+        cube_st(cube, elem, iA, oldA + add1);                    // :47-53
+        cube_st(cube, elem, iA2, oldA2 + add2);
+        cube_st(cube, elem, iD, cube_ld(cube, elem, iD) + (add1 + add1));
+      } else {
+        const double addend = st.kind == 2 ? a * fourB + square2B : a * twoB + bSquare;   // :19
+        cube_st(cube, elem, iA, oldA + addend);                  // :23-24
+        cube_st(cube, elem, iD, cube_ld(cube, elem, iD) + addend);   // :25
+      }
+    }
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) {
-    const double b = vB[iTarget] + amount;                   // PqaCore/CpuEngine.cpp:172
+    const double b = vB[iTarget] + amount;                   // PqaCore/CpuEngine.cpp:172, :462
     vB[iTarget] = elem == 4 ? (double)(float)b : b;
   }
 }
@@ -189,10 +208,10 @@ hipError_t LaunchFillSynthetic(void *cube, int elem, double *vB, int64_t K, int6
   return hipGetLastError();
 }
 
-hipError_t LaunchTrain(void *cube, int elem, double *vB, int64_t K, int64_t ldT, const int64_t *aqs, int64_t nAQs,
-                       int64_t iTarget, double amount, hipStream_t stream) {
-  hipLaunchKernelGGL(train_kernel, dim3(grid_for(nAQs, 64)), dim3(64), 0, stream, cube, elem, vB, K, ldT, aqs, nAQs, iTarget,
-                     amount);
+hipError_t LaunchTrainSteps(void *cube, int elem, double *vB, int64_t K, int64_t ldT, const TrainStep *steps,
+                            const int64_t *chainStart, int64_t nChains, int64_t iTarget, double amount, hipStream_t stream) {
+  hipLaunchKernelGGL(train_steps_kernel, dim3(grid_for(nChains, 64)), dim3(64), 0, stream, cube, elem, vB, K, ldT, steps, chainStart,
+                     nChains, iTarget, amount);
   return hipGetLastError();
 }
 

@@ -171,9 +171,12 @@ hipError_t LaunchFillFresh(void *cube, int elem, double *vB, int64_t K, int64_t 
 hipError_t LaunchFillSynthetic(void *cube, int elem, double *vB, int64_t K, int64_t Q, int64_t T, int64_t ldT, int64_t qOffset,
                                int64_t qTotal, double initAmount, double nTrain, double noiseAmp, uint64_t seed,
                                hipStream_t stream);
-// Train / RecordQuizTarget (PqaCore/CETrainOperation.cpp:15-25): aqs device array of nAQs (q,a) pairs, distinct q.
-hipError_t LaunchTrain(void *cube, int elem, double *vB, int64_t K, int64_t ldT, const int64_t *aqs, int64_t nAQs,
-                       int64_t iTarget, double amount, hipStream_t stream);
+// Train / RecordQuizTarget (PqaCore/CETrainOperation.cpp:15-83).  steps: device array in execution order, grouped by question;
+// chain c = steps[chainStart[c] .. chainStart[c + 1]) all on one question (chainStart: nChains + 1 entries).  Always adds
+// `amount` to vB[iTarget], also with no steps.
+struct TrainStep { int64_t kind, q, a1, a2; };   // kind 1 | 2 | 3, see kb_kernels.hip; q local
+hipError_t LaunchTrainSteps(void *cube, int elem, double *vB, int64_t K, int64_t ldT, const TrainStep *steps,
+                            const int64_t *chainStart, int64_t nChains, int64_t iTarget, double amount, hipStream_t stream);
 // Maintenance (PqaCore/CpuEngine.cpp:468-658): (re)initialise whole questions / whole target columns; compact the target
 // axis with (src,dst) column moves.  qs/ts/inits/moves are device arrays.
 hipError_t LaunchFillQuestions(void *cube, int elem, int64_t K, int64_t T, int64_t ldT, const int64_t *qs, const double *inits,

@@ -342,3 +342,61 @@ def test_fused_sampled_selection_picks_the_same_question(factory):
             eng.record_answer(quiz, step % 5)
     finally:
         eng.close()
+
+
+def _kb_equal(eng, orc, Q, T):
+    A, D, B = eng.get_kb(Q)
+    return np.array_equal(A, orc.A[:, :, :T]) and np.array_equal(D, orc.D[:, :T]) and np.array_equal(B, orc.B[:T])
+
+
+def test_training_with_repeated_questions_bit_identical_to_oracle(factory):
+    """Train / RecordQuizTarget with repeated questions: CETrainOperation::Perform2's three cases in the reference's pairing
+    order (PqaCore/CETrainOperation.cpp:32-83; CpuEngine.cpp:102-183 bucket order, :442-466 sequential pairs), bit for bit
+    against the oracle -- including mD getting twice the FIRST answer's addend when one question comes with two answers."""
+    import orclib
+
+    case = cases.small_cases()[2]            # 50 x 4 x 67
+    K, Q, T = case.K, case.Q, case.T
+    eng = case.make_engine(factory)
+    orc = case.make_oracle()
+    asked0 = eng.get_total_questions_asked()
+    scripts = [
+        ([(7, 1), (7, 1)], 3, 0.8),                                   # same question, same answer
+        ([(7, 1), (7, 2)], 3, 1.0),                                   # same question, different answers
+        ([(7, 1), (8, 0), (7, 1)], 5, 0.5),                           # buckets 7 and 8: (7,7) pairs up, 8 alone
+        ([(1, 0), (17, 1), (33, 2), (1, 0), (17, 3), (49, 1), (1, 2)], 9, 1.7),   # all in bucket 1 of 16: cross-question pairs
+        ([(q % Q, (q * 7) % K) for q in range(0, 3 * Q, 2)], 11, 0.3),            # every other question, three rounds
+        ([], 2, 2.0),                                                 # no questions: only vB moves
+    ]
+    n_trained = 0
+    for aqs, t, amount in scripts:
+        eng.train([interop.AnsweredQuestion(q, a) for q, a in aqs], t, amount)
+        orc.train(aqs, t, amount, cases.WORKERS)
+        n_trained += len(aqs)
+        assert _kb_equal(eng, orc, Q, T), f"Train {aqs[:4]}..."
+    assert eng.get_total_questions_asked() == asked0 + n_trained      # CpuEngine.cpp:176
+    # RecordQuizTarget after a re-asked question: the quiz's answer list holds question 12 twice, in positions 0 and 1 / 0 and 2
+    for answers in ([(12, 1), (12, 1), (30, 0)], [(12, 1), (30, 0), (12, 3)], [(5, 2), (5, 0)], [(40, 3)]):
+        quiz = eng.start_quiz()
+        orc.start_quiz(cases.WORKERS)
+        for q, a in answers:
+            eng.set_active_question(quiz, q)
+            eng.record_answer(quiz, a)
+            orc.record_answer(q, a, cases.WORKERS - 1)
+        assert np.array_equal(eng.get_priors(quiz), orc.priors())
+        before = eng.get_total_questions_asked()
+        eng.record_quiz_target(quiz, 20, 0.9)
+        orc.record_quiz_target(20, 0.9)
+        assert _kb_equal(eng, orc, Q, T), f"RecordQuizTarget {answers}"
+        assert eng.get_total_questions_asked() == before               # CpuEngine.cpp:442-466 leaves the counter alone
+        eng.release_quiz(quiz)
+    # the sweep reads the trained cube
+    quiz = eng.start_quiz()
+    orc.start_quiz(cases.WORKERS)
+    _, opri = orc.eval(1)
+    assert cases.rel_err(eng.eval_priorities(quiz), opri).max() < 1e-9
+    e = eng.train([interop.AnsweredQuestion(Q, 0)], 0, 1.0, throw=False)
+    assert e is not None and "Question index is not in KB range" in e.to_string(True)
+    e = eng.train([interop.AnsweredQuestion(0, K)], 0, 1.0, throw=False)
+    assert e is not None and "Answer index is not in KB range" in e.to_string(True)
+    eng.close()

@@ -241,3 +241,48 @@ def test_oracle_reproduces_golden_fixture(name):
     got = make_golden.run_case(make_golden.case_from_meta(meta))
     for key in data.files:
         assert np.array_equal(got[key], data[key]), (name, key)
+
+
+def test_training_pairing_rules():
+    """CETrainOperation::Perform2's three cases and the bucket order of CpuEngine::TrainSpec, against hand-written algebra
+    (reference PqaCore/CETrainOperation.cpp:32-83, CETrainSubtaskDistrib.h:46-52, CETrainSubtaskAdd.cpp:17-38)."""
+    K, Q, T, init, b = 4, 6, 5, 0.3, 0.7
+    A0, D0 = init * init, init * init * K
+
+    def fresh():
+        return orclib.Oracle(K, Q, T, init)
+
+    def step(a2, amount):  # one step of `amount` on a cell holding a2
+        return a2 + (np.sqrt(a2) * (2 * amount) + amount * amount)
+
+    # same question, same answer: ONE step of 2b (4ab + 4b^2), D gets the same addend
+    o = fresh()
+    o.record_quiz_target(2, b, aqs=[(1, 3), (1, 3)])
+    add = np.sqrt(A0) * (4 * b) + 4 * (b * b)
+    assert o.A[1, 3, 2] == A0 + add and o.D[1, 2] == D0 + add
+    assert abs(o.A[1, 3, 2] - (init + 2 * b) ** 2) < 1e-14 and abs(o.B[2] - (init + b)) < 1e-15
+    # same question, different answers: each cell its own addend, D gets TWICE THE FIRST one's
+    o = fresh()
+    o.A[1, 0, 2], o.A[1, 3, 2] = 4.0, 9.0
+    o.record_quiz_target(2, b, aqs=[(1, 0), (1, 3)])
+    add1, add2 = 2.0 * (2 * b) + b * b, 3.0 * (2 * b) + b * b
+    assert o.A[1, 0, 2] == 4.0 + add1 and o.A[1, 3, 2] == 9.0 + add2 and o.D[1, 2] == D0 + (add1 + add1)
+    # different questions: two independent Perform1 steps; an odd last entry is a Perform1
+    o = fresh()
+    o.record_quiz_target(0, b, aqs=[(0, 1), (4, 2), (5, 0)])
+    for q, a in ((0, 1), (4, 2), (5, 0)):
+        assert o.A[q, a, 0] == step(A0, b) and o.D[q, 0] == D0 + (step(A0, b) - A0)
+    # RecordQuizTarget pairs by POSITION: (1,3),(2,0) | (1,3): question 1 is stepped twice by b, not once by 2b
+    o = fresh()
+    o.record_quiz_target(3, b, aqs=[(1, 3), (2, 0), (1, 3)])
+    assert o.A[1, 3, 3] == step(step(A0, b), b)
+    # Train buckets by question % workers, each bucket consumed newest first in pairs: with 4 workers the entries of question 1
+    # (positions 0, 2, 3; all in bucket 1 together with question 5 at position 1) are consumed as (3,2) | (1,0):
+    # Perform2(same question 1, same answer) = one 2b step, then Perform2(question 5, question 1) = one b step each
+    o = fresh()
+    o.train([(1, 3), (5, 0), (1, 3), (1, 3)], 4, b, n_workers=4)
+    assert o.A[1, 3, 4] == step(A0 + add, b) and o.A[5, 0, 4] == step(A0, b)
+    # with one worker per question nothing pairs up across questions, the pairing within question 1 is (3,2) | (0)
+    o2 = fresh()
+    o2.train([(1, 3), (5, 0), (1, 3), (1, 3)], 4, b, n_workers=64)
+    assert o2.A[1, 3, 4] == o.A[1, 3, 4] and o2.A[5, 0, 4] == o.A[5, 0, 4]
