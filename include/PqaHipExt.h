@@ -30,6 +30,8 @@ extern "C" {
 
 /* Same as PqaEngineFactory_CreateCpuEngine (which creates the HIP engine too); explicit name for new callers. */
 PQACORE_API void *PqaEngineFactory_CreateHipEngine(void *pvFactory, void **ppError, const CiEngineDefinition *pEngDef);
+/* Same as PqaEngineFactory_LoadCpuEngine (which loads into the HIP engine too); explicit name for new callers. */
+PQACORE_API void *PqaEngineFactory_LoadHipEngine(void *pvFactory, void **ppError, const char *filePath, uint64_t memPoolMaxBytes);
 /* Engine over questions [_qFirst, _qFirst + pEngDef->_nQuestions) of a KB with _qTotal questions.  Question ids in
  * every call on such an engine are GLOBAL ids. */
 PQACORE_API void *PqaEngineFactory_CreateHipEngineSharded(void *pvFactory, void **ppError,

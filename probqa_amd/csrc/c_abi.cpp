@@ -1,6 +1,7 @@
 // c_abi.cpp -- the extern "C" surface of libPqaCore.so.
-// Shims follow reference ProbQA/PqaCore/PqaCInterop.cpp:45-408 (AssignPqaError / ReturnPqaError, the three
-// GET_ENGINE_OR_* null-handle conventions); declarations are in include/PqaCInterop.h and include/PqaHipExt.h.
+// Shims follow reference ProbQA/PqaCore/PqaCInterop.cpp:45-408 (AssignPqaError / ReturnPqaError and its three null-handle
+// conventions: return an error object, set *ppError, or log and return 0); declarations are in include/PqaCInterop.h and
+// include/PqaHipExt.h.
 #include <atomic>
 #include <chrono>
 #include <cmath>
@@ -49,16 +50,16 @@ char *DupString(const std::string &s) {
   return p;
 }
 
-#define GET_ENGINE_OR_RET_ERR                                   \
+#define ENGINE_OR_RETURN_ERROR                                   \
   HipEngine *pEng = static_cast<HipEngine *>(pvEngine);         \
   if (pEng == nullptr) return new Error(NullEngine());
-#define GET_ENGINE_OR_ASSIGN_ERR(retVal)                        \
+#define ENGINE_OR_SET_ERROR(retVal)                        \
   HipEngine *pEng = static_cast<HipEngine *>(pvEngine);         \
   if (pEng == nullptr) {                                        \
     if (ppError) *ppError = new Error(NullEngine());            \
     return retVal;                                              \
   }
-#define GET_ENGINE_OR_LOG_ERR(retVal)                                               \
+#define ENGINE_OR_LOG(retVal)                                               \
   HipEngine *pEng = static_cast<HipEngine *>(pvEngine);                             \
   if (pEng == nullptr) {                                                            \
     std::fprintf(stderr, "PqaCore: Nullptr is passed in place of IPqaEngine.\n");   \
@@ -86,10 +87,12 @@ extern "C" {
 
 PQACORE_API void CiDebugBreak(void) { /* reference requests a debugger; nothing to do here */ }
 
+// The process-wide default logger (reference SRPlatform/SRDefaultLogger.cpp:47-83): a file logger once Logger_Init has named
+// it, the debug stream (here: stderr) until then.  A second initialisation is an error, reported as an owned C string.
 PQACORE_API uint8_t Logger_Init(void **ppStrErr, const char *baseName) {
-  (void)baseName;  // the MI355X engine logs anomalies to stderr; there is no file logger to initialise
-  if (ppStrErr) *ppStrErr = nullptr;
-  return 1;
+  const std::string err = pqa::DefaultLogger::Init(baseName);
+  if (ppStrErr) *ppStrErr = err.empty() ? nullptr : DupString(err);
+  return err.empty() ? 1 : 0;
 }
 
 PQACORE_API void CiReleaseString(void *pvString) { delete[] static_cast<char *>(pvString); }
@@ -120,6 +123,10 @@ PQACORE_API void *PqaEngineFactory_LoadCpuEngine(void *pvFactory, void **ppError
   return eng;
 }
 
+PQACORE_API void *PqaEngineFactory_LoadHipEngine(void *pvFactory, void **ppError, const char *filePath, uint64_t memPoolMaxBytes) {
+  return PqaEngineFactory_LoadCpuEngine(pvFactory, ppError, filePath, memPoolMaxBytes);
+}
+
 PQACORE_API void CiReleasePqaError(void *pvErr) { delete static_cast<Error *>(pvErr); }
 
 PQACORE_API void *PqaError_ToString(void *pvError, const uint8_t withParams) {
@@ -132,45 +139,45 @@ PQACORE_API void CiReleasePqaEngine(void *pvEngine) { delete static_cast<HipEngi
 
 PQACORE_API void *PqaEngine_Train(void *pvEngine, int64_t nQuestions, const CiAnsweredQuestion *const pAQs,
                                   const int64_t iTarget, const double amount) {
-  GET_ENGINE_OR_RET_ERR;
+  ENGINE_OR_RETURN_ERROR;
   return ReturnErr(pEng->Train(nQuestions, reinterpret_cast<const AQ *>(pAQs), iTarget, amount));
 }
 
 PQACORE_API uint8_t PqaEngine_QuestionPermFromComp(void *pvEngine, const int64_t count, int64_t *pIds) {
-  GET_ENGINE_OR_LOG_ERR(0);
+  ENGINE_OR_LOG(0);
   return pEng->MapIds(0, true, count, pIds) ? 1 : 0;
 }
 PQACORE_API uint8_t PqaEngine_QuestionCompFromPerm(void *pvEngine, const int64_t count, int64_t *pIds) {
-  GET_ENGINE_OR_LOG_ERR(0);
+  ENGINE_OR_LOG(0);
   return pEng->MapIds(0, false, count, pIds) ? 1 : 0;
 }
 PQACORE_API uint8_t PqaEngine_TargetPermFromComp(void *pvEngine, const int64_t count, int64_t *pIds) {
-  GET_ENGINE_OR_LOG_ERR(0);
+  ENGINE_OR_LOG(0);
   return pEng->MapIds(1, true, count, pIds) ? 1 : 0;
 }
 PQACORE_API uint8_t PqaEngine_TargetCompFromPerm(void *pvEngine, const int64_t count, int64_t *pIds) {
-  GET_ENGINE_OR_LOG_ERR(0);
+  ENGINE_OR_LOG(0);
   return pEng->MapIds(1, false, count, pIds) ? 1 : 0;
 }
 PQACORE_API uint8_t PqaEngine_QuizPermFromComp(void *pvEngine, const int64_t count, int64_t *pIds) {
-  GET_ENGINE_OR_LOG_ERR(0);
+  ENGINE_OR_LOG(0);
   return pEng->MapIds(2, true, count, pIds) ? 1 : 0;
 }
 PQACORE_API uint8_t PqaEngine_QuizCompFromPerm(void *pvEngine, const int64_t count, int64_t *pIds) {
-  GET_ENGINE_OR_LOG_ERR(0);
+  ENGINE_OR_LOG(0);
   return pEng->MapIds(2, false, count, pIds) ? 1 : 0;
 }
 PQACORE_API uint8_t PqaEngine_EnsurePermQuizGreater(void *pvEngine, const int64_t bound) {
-  GET_ENGINE_OR_LOG_ERR(0);
+  ENGINE_OR_LOG(0);
   return pEng->EnsurePermQuizGreater(bound) ? 1 : 0;
 }
 PQACORE_API uint8_t PqaEngine_RemapQuizPermId(void *pvEngine, const int64_t srcPermId, const int64_t destPermId) {
-  GET_ENGINE_OR_LOG_ERR(0);
+  ENGINE_OR_LOG(0);
   return pEng->RemapQuizPermId(srcPermId, destPermId) ? 1 : 0;
 }
 
 PQACORE_API uint64_t PqaEngine_GetTotalQuestionsAsked(void *pvEngine, void **ppError) {
-  GET_ENGINE_OR_ASSIGN_ERR(0);
+  ENGINE_OR_SET_ERROR(0);
   Error err;
   const uint64_t n = pEng->GetTotalQuestionsAsked(err);
   AssignErr(ppError, err);
@@ -178,13 +185,13 @@ PQACORE_API uint64_t PqaEngine_GetTotalQuestionsAsked(void *pvEngine, void **ppE
 }
 
 PQACORE_API uint8_t PqaEngine_CopyDims(void *pvEngine, CiEngineDimensions *pDims) {
-  GET_ENGINE_OR_LOG_ERR(0);
+  ENGINE_OR_LOG(0);
   pEng->CopyDims(pDims);
   return 1;
 }
 
 PQACORE_API int64_t PqaEngine_StartQuiz(void *pvEngine, void **ppError) {
-  GET_ENGINE_OR_ASSIGN_ERR(-1);
+  ENGINE_OR_SET_ERROR(-1);
   Error err;
   const int64_t id = pEng->StartQuiz(err);
   AssignErr(ppError, err);
@@ -193,7 +200,7 @@ PQACORE_API int64_t PqaEngine_StartQuiz(void *pvEngine, void **ppError) {
 
 PQACORE_API int64_t PqaEngine_ResumeQuiz(void *pvEngine, void **ppError, const int64_t nAnswered,
                                          const CiAnsweredQuestion *const pAQs) {
-  GET_ENGINE_OR_ASSIGN_ERR(-1);
+  ENGINE_OR_SET_ERROR(-1);
   Error err;
   const int64_t id = pEng->ResumeQuiz(err, nAnswered, reinterpret_cast<const AQ *>(pAQs));
   AssignErr(ppError, err);
@@ -201,7 +208,7 @@ PQACORE_API int64_t PqaEngine_ResumeQuiz(void *pvEngine, void **ppError, const i
 }
 
 PQACORE_API int64_t PqaEngine_NextQuestion(void *pvEngine, void **ppError, const int64_t iQuiz) {
-  GET_ENGINE_OR_ASSIGN_ERR(-1);
+  ENGINE_OR_SET_ERROR(-1);
   Error err;
   const int64_t q = pEng->NextQuestion(err, iQuiz);
   AssignErr(ppError, err);
@@ -209,17 +216,17 @@ PQACORE_API int64_t PqaEngine_NextQuestion(void *pvEngine, void **ppError, const
 }
 
 PQACORE_API void *PqaEngine_RecordAnswer(void *pvEngine, const int64_t iQuiz, const int64_t iAnswer) {
-  GET_ENGINE_OR_RET_ERR;
+  ENGINE_OR_RETURN_ERROR;
   return ReturnErr(pEng->RecordAnswer(iQuiz, iAnswer));
 }
 
 PQACORE_API void *PqaEngine_ClearOldQuizzes(void *pvEngine, const int64_t maxCount, const double maxAgeSec) {
-  GET_ENGINE_OR_RET_ERR;
+  ENGINE_OR_RETURN_ERROR;
   return ReturnErr(pEng->ClearOldQuizzes(maxCount, maxAgeSec));
 }
 
 PQACORE_API int64_t PqaEngine_GetActiveQuestionId(void *pvEngine, void **ppError, const int64_t iQuiz) {
-  GET_ENGINE_OR_ASSIGN_ERR(-1);
+  ENGINE_OR_SET_ERROR(-1);
   Error err;
   const int64_t q = pEng->GetActiveQuestionId(err, iQuiz);
   AssignErr(ppError, err);
@@ -227,13 +234,13 @@ PQACORE_API int64_t PqaEngine_GetActiveQuestionId(void *pvEngine, void **ppError
 }
 
 PQACORE_API void *PqaEngine_SetActiveQuestion(void *pvEngine, const int64_t iQuiz, const int64_t iQuestion) {
-  GET_ENGINE_OR_RET_ERR;
+  ENGINE_OR_RETURN_ERROR;
   return ReturnErr(pEng->SetActiveQuestion(iQuiz, iQuestion));
 }
 
 PQACORE_API int64_t PqaEngine_ListTopTargets(void *pvEngine, void **ppError, const int64_t iQuiz,
                                              const int64_t maxCount, CiRatedTarget *pDest) {
-  GET_ENGINE_OR_ASSIGN_ERR(-1);
+  ENGINE_OR_SET_ERROR(-1);
   Error err;
   const int64_t n = pEng->ListTopTargets(err, iQuiz, maxCount, pDest);
   AssignErr(ppError, err);
@@ -242,97 +249,101 @@ PQACORE_API int64_t PqaEngine_ListTopTargets(void *pvEngine, void **ppError, con
 
 PQACORE_API void *PqaEngine_RecordQuizTarget(void *pvEngine, const int64_t iQuiz, const int64_t iTarget,
                                              const double amount) {
-  GET_ENGINE_OR_RET_ERR;
+  ENGINE_OR_RETURN_ERROR;
   return ReturnErr(pEng->RecordQuizTarget(iQuiz, iTarget, amount));
 }
 
 PQACORE_API void *PqaEngine_ReleaseQuiz(void *pvEngine, const int64_t iQuiz) {
-  GET_ENGINE_OR_RET_ERR;
+  ENGINE_OR_RETURN_ERROR;
   return ReturnErr(pEng->ReleaseQuiz(iQuiz));
 }
 
 PQACORE_API void *PqaEngine_SaveKB(void *pvEngine, const char *const filePath, const uint8_t bDoubleBuffer) {
-  GET_ENGINE_OR_RET_ERR;
+  ENGINE_OR_RETURN_ERROR;
   return ReturnErr(pEng->SaveKB(filePath, bDoubleBuffer != 0));
 }
 
 PQACORE_API void *PqaEngine_StartMaintenance(void *pvEngine, const bool forceQuizzes) {
-  GET_ENGINE_OR_RET_ERR;
+  ENGINE_OR_RETURN_ERROR;
   return ReturnErr(pEng->StartMaintenance(forceQuizzes));
 }
 PQACORE_API void *PqaEngine_FinishMaintenance(void *pvEngine) {
-  GET_ENGINE_OR_RET_ERR;
+  ENGINE_OR_RETURN_ERROR;
   return ReturnErr(pEng->FinishMaintenance());
 }
 PQACORE_API void *PqaEngine_AddQsTs(void *pvEngine, const int64_t nQuestions, CiAddQorTParam *pAddQuestionParams,
                                     const int64_t nTargets, CiAddQorTParam *pAddTargetParams) {
-  GET_ENGINE_OR_RET_ERR;
+  ENGINE_OR_RETURN_ERROR;
   return ReturnErr(pEng->AddQsTs(nQuestions, pAddQuestionParams, nTargets, pAddTargetParams));
 }
 PQACORE_API void *PqaEngine_RemoveQuestions(void *pvEngine, const int64_t nQuestions, const int64_t *pQIds) {
-  GET_ENGINE_OR_RET_ERR;
+  ENGINE_OR_RETURN_ERROR;
   return ReturnErr(pEng->RemoveQuestions(nQuestions, pQIds));
 }
 PQACORE_API void *PqaEngine_RemoveTargets(void *pvEngine, const int64_t nTargets, const int64_t *pTIds) {
-  GET_ENGINE_OR_RET_ERR;
+  ENGINE_OR_RETURN_ERROR;
   return ReturnErr(pEng->RemoveTargets(nTargets, pTIds));
 }
 PQACORE_API void *PqaEngine_Compact(void *pvEngine, int64_t *pnQuestions, int64_t const **const ppOldQuestions,
                                     int64_t *pnTargets, int64_t const **const ppOldTargets) {
-  GET_ENGINE_OR_RET_ERR;
+  ENGINE_OR_RETURN_ERROR;
   return ReturnErr(pEng->Compact(pnQuestions, ppOldQuestions, pnTargets, ppOldTargets));
 }
 PQACORE_API void CiReleaseCompaction(const int64_t *p) { std::free(const_cast<int64_t *>(p)); }
 
 PQACORE_API void *PqaEngine_Shutdown(void *pvEngine, const char *const saveFilePath) {
-  GET_ENGINE_OR_RET_ERR;
+  ENGINE_OR_RETURN_ERROR;
   return ReturnErr(pEng->Shutdown(saveFilePath));
 }
+// BaseEngine::SetLogger (reference PqaCore/BaseEngine.cpp:252-258): nullptr selects the default logger -- that case is served.
+// Any other value is a pointer to an SRPlat::ISRLogger, a C++ object of the MSVC ABI (SRPlatform/Interface/ISRLogger.h:11-25,
+// virtual Log(Severity, const SRString&)): none of the C-ABI wrappers can make one (ProbQA.py and the .NET layer only call
+// Logger_Init), and this library cannot call through a foreign vtable.
 PQACORE_API void *PqaEngine_SetLogger(void *pvEngine, void *pSRLogger) {
-  GET_ENGINE_OR_RET_ERR;
-  (void)pSRLogger;  // ISRLogger is an MSVC-ABI C++ object; it cannot be consumed here
-  return ReturnErr(NotImpl("SetLogger"));
+  ENGINE_OR_RETURN_ERROR;
+  if (pSRLogger == nullptr) return nullptr;
+  return ReturnErr(NotImpl("SetLogger with a caller-supplied ISRLogger object (MSVC C++ ABI)"));
 }
 
 // ---------------------------------------------------------------------------------------------------- PqaHipExt.h
 PQACORE_API void *PqaHip_SetOption(void *pvEngine, const char *name, int64_t value) {
-  GET_ENGINE_OR_RET_ERR;
+  ENGINE_OR_RETURN_ERROR;
   return ReturnErr(pEng->SetOption(name, value));
 }
 PQACORE_API int64_t PqaHip_GetOption(void *pvEngine, const char *name) {
-  GET_ENGINE_OR_LOG_ERR(-1);
+  ENGINE_OR_LOG(-1);
   return pEng->GetOption(name);
 }
 PQACORE_API const char *PqaHip_EvalKernelName(void *pvEngine) {
-  GET_ENGINE_OR_LOG_ERR("");
+  ENGINE_OR_LOG("");
   return pEng->EvalKernelName();
 }
 PQACORE_API void *PqaHip_SetKB(void *pvEngine, const double *pA, const double *pD, const double *pB) {
-  GET_ENGINE_OR_RET_ERR;
+  ENGINE_OR_RETURN_ERROR;
   return ReturnErr(pEng->SetKB(pA, pD, pB));
 }
 PQACORE_API void *PqaHip_GetKB(void *pvEngine, double *pA, double *pD, double *pB) {
-  GET_ENGINE_OR_RET_ERR;
+  ENGINE_OR_RETURN_ERROR;
   return ReturnErr(pEng->GetKB(pA, pD, pB));
 }
 PQACORE_API void *PqaHip_FillSynthetic(void *pvEngine, double nTrain, double noiseAmp, uint64_t seed) {
-  GET_ENGINE_OR_RET_ERR;
+  ENGINE_OR_RETURN_ERROR;
   return ReturnErr(pEng->FillSynthetic(nTrain, noiseAmp, seed));
 }
 PQACORE_API void *PqaHip_SetTargetGaps(void *pvEngine, int64_t n, const int64_t *pTargets) {
-  GET_ENGINE_OR_RET_ERR;
+  ENGINE_OR_RETURN_ERROR;
   return ReturnErr(pEng->SetTargetGaps(n, pTargets));
 }
 PQACORE_API void *PqaHip_SetQuestionGaps(void *pvEngine, int64_t n, const int64_t *pQuestions) {
-  GET_ENGINE_OR_RET_ERR;
+  ENGINE_OR_RETURN_ERROR;
   return ReturnErr(pEng->SetQuestionGaps(n, pQuestions));
 }
 PQACORE_API void *PqaEngine_EvalPriorities(void *pvEngine, const int64_t iQuiz, double *pOut, const int64_t n) {
-  GET_ENGINE_OR_RET_ERR;
+  ENGINE_OR_RETURN_ERROR;
   return ReturnErr(pEng->EvalPriorities(iQuiz, pOut, n));
 }
 PQACORE_API int64_t PqaEngine_NextQuestionArgmax(void *pvEngine, void **ppError, const int64_t iQuiz) {
-  GET_ENGINE_OR_ASSIGN_ERR(-1);
+  ENGINE_OR_SET_ERROR(-1);
   Error err;
   const int64_t q = pEng->NextQuestionArgmax(err, iQuiz);
   AssignErr(ppError, err);
@@ -340,48 +351,48 @@ PQACORE_API int64_t PqaEngine_NextQuestionArgmax(void *pvEngine, void **ppError,
 }
 PQACORE_API int64_t PqaEngine_NextQuestionSampled(void *pvEngine, void **ppError, const int64_t iQuiz,
                                                   const uint64_t rnd) {
-  GET_ENGINE_OR_ASSIGN_ERR(-1);
+  ENGINE_OR_SET_ERROR(-1);
   Error err;
   const int64_t q = pEng->NextQuestionSampled(err, iQuiz, rnd);
   AssignErr(ppError, err);
   return q;
 }
 PQACORE_API void *PqaHip_GetPriors(void *pvEngine, const int64_t iQuiz, double *pOut, const int64_t n) {
-  GET_ENGINE_OR_RET_ERR;
+  ENGINE_OR_RETURN_ERROR;
   return ReturnErr(pEng->GetPriors(iQuiz, pOut, n));
 }
 PQACORE_API void *PqaEngine_NextQuestionArgmaxBatch(void *pvEngine, const int64_t nQuizzes, const int64_t *pQuizzes,
                                                     int64_t *pQuestions) {
-  GET_ENGINE_OR_RET_ERR;
+  ENGINE_OR_RETURN_ERROR;
   return ReturnErr(pEng->NextQuestionArgmaxBatch(nQuizzes, pQuizzes, pQuestions));
 }
 PQACORE_API void *PqaHip_SelectArgmaxBatch(void *pvEngine, const int64_t nQuizzes, const int64_t *pQuizzes, CiHipSelection *pOut) {
-  GET_ENGINE_OR_RET_ERR;
+  ENGINE_OR_RETURN_ERROR;
   return ReturnErr(pEng->SelectArgmaxBatch(nQuizzes, pQuizzes, pOut));
 }
 PQACORE_API void *PqaEngine_EvalPrioritiesBatch(void *pvEngine, const int64_t nQuizzes, const int64_t *pQuizzes, double *pOut) {
-  GET_ENGINE_OR_RET_ERR;
+  ENGINE_OR_RETURN_ERROR;
   return ReturnErr(pEng->EvalPrioritiesBatch(nQuizzes, pQuizzes, pOut));
 }
 PQACORE_API void *PqaHip_Log2Hot(void *pvEngine, const double *pIn, double *pOut, const int64_t n) {
-  GET_ENGINE_OR_RET_ERR;
+  ENGINE_OR_RETURN_ERROR;
   return ReturnErr(pEng->Log2HotArray(pIn, pOut, n));
 }
 PQACORE_API void *PqaHip_GetStream(void *pvEngine) {
-  GET_ENGINE_OR_LOG_ERR(nullptr);
+  ENGINE_OR_LOG(nullptr);
   return pEng->GetStream();
 }
 PQACORE_API void *PqaHip_SetStream(void *pvEngine, void *hipStream) {
-  GET_ENGINE_OR_RET_ERR;
+  ENGINE_OR_RETURN_ERROR;
   return ReturnErr(pEng->SetStream(static_cast<hipStream_t>(hipStream)));
 }
 PQACORE_API void *PqaHip_Synchronize(void *pvEngine) {
-  GET_ENGINE_OR_RET_ERR;
+  ENGINE_OR_RETURN_ERROR;
   return ReturnErr(pEng->Synchronize());
 }
 PQACORE_API void *PqaHip_EnqueueSelectArgmaxFlag(void *pvEngine, const int64_t iQuiz, void *pOut, void *pFlag,
                                                  const uint64_t flagValue) {
-  GET_ENGINE_OR_RET_ERR;
+  ENGINE_OR_RETURN_ERROR;
   return ReturnErr(pEng->EnqueueSelectArgmaxFlag(iQuiz, pOut, pFlag, flagValue));
 }
 // Host memory (e.g. a shared-memory segment mapped by every rank) made writable by this process's GPU.
@@ -436,7 +447,7 @@ PQACORE_API void *PqaHip_SelectThroughSlots(void *pvEngine, const int64_t iQuiz,
                                             const int64_t rank, const int64_t world, const int64_t strideBytes,
                                             const uint64_t flagValue, const double timeoutSec, double *pPriority,
                                             int64_t *pIndex) {
-  GET_ENGINE_OR_RET_ERR;
+  ENGINE_OR_RETURN_ERROR;
   if (!pSlots || !pSlotsDev || rank < 0 || rank >= world || strideBytes < 24)
     return ReturnErr(Error::Make(ErrCode::NullArgument, "Bad arguments to PqaHip_SelectThroughSlots."));
   char *mine = (char *)pSlotsDev + rank * strideBytes;
@@ -445,19 +456,19 @@ PQACORE_API void *PqaHip_SelectThroughSlots(void *pvEngine, const int64_t iQuiz,
   return PqaHip_PickWhenAll(pSlots, world, strideBytes, flagValue, timeoutSec, pPriority, pIndex);
 }
 PQACORE_API void *PqaHip_EnqueueSelectArgmax(void *pvEngine, const int64_t iQuiz, void *pOut) {
-  GET_ENGINE_OR_RET_ERR;
+  ENGINE_OR_RETURN_ERROR;
   return ReturnErr(pEng->EnqueueSelectArgmax(iQuiz, pOut));
 }
 PQACORE_API void *PqaHip_EnqueueEval(void *pvEngine, const int64_t iQuiz) {
-  GET_ENGINE_OR_RET_ERR;
+  ENGINE_OR_RETURN_ERROR;
   return ReturnErr(pEng->EnqueueEval(iQuiz));
 }
 PQACORE_API void *PqaHip_GetPriorDevicePtr(void *pvEngine, const int64_t iQuiz, void **ppDev, int64_t *pLdT) {
-  GET_ENGINE_OR_RET_ERR;
+  ENGINE_OR_RETURN_ERROR;
   return ReturnErr(pEng->GetPriorDevicePtr(iQuiz, ppDev, pLdT));
 }
 PQACORE_API void *PqaHip_RecordAnswerRemote(void *pvEngine, const int64_t iQuiz, const int64_t iAnswer) {
-  GET_ENGINE_OR_RET_ERR;
+  ENGINE_OR_RETURN_ERROR;
   return ReturnErr(pEng->RecordAnswerRemote(iQuiz, iAnswer));
 }
 

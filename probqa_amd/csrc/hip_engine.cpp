@@ -7,7 +7,10 @@
 #include <cstdio>
 #include <cstring>
 #include <random>
+#include <cstdlib>
 #include <sstream>
+
+#include <unistd.h>
 
 namespace pqa {
 
@@ -53,10 +56,50 @@ std::string Error::ToString(bool withParams) const {
   return s + "]";
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// default logger (reference SRPlatform/SRDefaultLogger.cpp:47-83; file naming of SRPlatform/SRLoggerFactory + FileLogger:
+// <baseName>_<UTC date-time>_<pid>.log is what this build uses)
+// ------------------------------------------------------------------------------------------------------------------
+namespace {
+std::mutex gLogMu;
+FILE *gLogFile = nullptr;
+}  // namespace
+
+std::string DefaultLogger::Init(const char *baseName) {
+  std::lock_guard<std::mutex> lk(gLogMu);
+  if (gLogFile != nullptr)
+    return "Default logger seems already initialized by the moment of calling DefaultLoggerImpl::Init().";
+  if (baseName == nullptr || *baseName == 0) return "Nullptr or empty string is passed in place of the log file base name.";
+  char stamp[64];
+  const time_t now = time(nullptr);
+  struct tm tmv;
+  gmtime_r(&now, &tmv);
+  std::strftime(stamp, sizeof(stamp), "%Y-%m-%d_%H-%M-%S", &tmv);
+  const std::string path = std::string(baseName) + "_" + stamp + "_" + std::to_string((long long)getpid()) + ".log";
+  FILE *f = std::fopen(path.c_str(), "a");
+  if (f == nullptr) return "Can't open the log file " + path + ".";
+  gLogFile = f;
+  return std::string();
+}
+
+void DefaultLogger::Log(Severity sev, const std::string &message) {
+  static const char *names[] = {"None", "Info", "Warning", "Error", "Critical"};
+  std::lock_guard<std::mutex> lk(gLogMu);
+  FILE *f = gLogFile ? gLogFile : stderr;
+  char stamp[64];
+  const time_t now = time(nullptr);
+  struct tm tmv;
+  gmtime_r(&now, &tmv);
+  std::strftime(stamp, sizeof(stamp), "%Y-%m-%d %H:%M:%S", &tmv);
+  std::fprintf(f, "%s [%s] %s\n", stamp, names[(int)sev <= 4 ? (int)sev : 0], message.c_str());
+  std::fflush(f);
+}
+
 namespace {
 
 Error HipErr(hipError_t e, const char *what) {
   std::string msg = std::string("HIP failure in ") + what + ": " + hipGetErrorString(e);
+  DefaultLogger::Log(DefaultLogger::Severity::Error, msg);
   return Error::MakeP(ErrCode::Internal, std::string("Internal error at hip_engine.cpp(") + what + ")", msg);
 }
 #define HIP_TRY(expr)                                   \
@@ -207,7 +250,42 @@ Error HipEngine::Init(const CiEngineDefinition &def, const CiHipShard *shard) {
   uint64_t seed = ((uint64_t)rd() << 32) ^ rd();
   _rng[0] = SplitMix64(seed);
   _rng[1] = SplitMix64(seed);
+  ApplyEnvironment();
   return Error();
+}
+
+// The reference's wrappers can only call PqaEngineFactory_CreateCpuEngine / _LoadCpuEngine (ProbQA.py:131-145,
+// PqaEngineFactory.cs:24-33) and know nothing of PqaHip_SetOption: what they cannot say in a call they say in the environment.
+//   PQA_SELECT=sample|argmax   NextQuestion's selector (default sample: the reference's weighted draw, CpuEngine.cpp:362-400)
+//   PQA_SERVER=0|1             argmax selections through the resident sweep kernel
+//   PQA_BUG_COMPAT=0|1         ResumeQuiz as the reference binary (1, default) or as evidently intended (0)
+//   PQA_WORKERS=n              emulated thread-pool size (summation order of the posterior updates, training buckets)
+//   PQA_SEED=n                 seed of the selector's generator (the reference's cannot be seeded)
+//   PQA_DEVICES=i[,j,...]      device ordinal(s): read by the factory (c_abi.cpp), which builds one shard per listed device
+void HipEngine::ApplyEnvironment() {
+  auto num = [](const char *name, int64_t lo, int64_t hi, int64_t &out) {
+    const char *v = std::getenv(name);
+    if (!v || !*v) return false;
+    char *end = nullptr;
+    const long long x = std::strtoll(v, &end, 10);
+    if (end == v || *end != 0 || x < lo || x > hi) {
+      std::fprintf(stderr, "PqaCore: ignoring %s=%s (expected an integer in %lld..%lld)\n", name, v, (long long)lo, (long long)hi);
+      return false;
+    }
+    out = x;
+    return true;
+  };
+  if (const char *v = std::getenv("PQA_SELECT")) {
+    const std::string sel(v);
+    if (sel == "argmax" || sel == "1") _optSelect = 1;
+    else if (sel == "sample" || sel == "sampled" || sel == "0") _optSelect = 0;
+    else if (!sel.empty()) std::fprintf(stderr, "PqaCore: ignoring PQA_SELECT=%s (expected sample or argmax)\n", v);
+  }
+  int64_t x = 0;
+  if (num("PQA_SERVER", 0, 1, x)) _optServer = x;
+  if (num("PQA_BUG_COMPAT", 0, 1, x)) _optBugCompat = x;
+  if (num("PQA_WORKERS", 1, kMaxWorkers, x)) _optWorkers = x;
+  if (num("PQA_SEED", INT64_MIN, INT64_MAX, x)) { uint64_t s = (uint64_t)x; _rng[0] = SplitMix64(s); _rng[1] = SplitMix64(s); }
 }
 
 HipEngine::~HipEngine() {
@@ -256,7 +334,7 @@ Error HipEngine::SetOption(const char *name, int64_t value) {
   std::lock_guard<EngineMutex> lk(_mu);
   const std::string n(name ? name : "");
   if (n == "select") { if (value != 0 && value != 1) goto bad; _optSelect = value; }
-  else if (n == "workers") { if (value < 1 || value > 4096) goto bad; _optWorkers = value; }
+  else if (n == "workers") { if (value < 1 || value > kMaxWorkers) goto bad; _optWorkers = value; }
   else if (n == "eval_subtasks") { if (value < 0 || value > 8192) goto bad; _optEvalSubtasks = value; }
   else if (n == "eval_variant") { if (value < 0) goto bad; _optEvalVariant = value; }
   else if (n == "bug_compat") { _optBugCompat = value ? 1 : 0; }

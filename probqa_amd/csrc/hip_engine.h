@@ -49,6 +49,13 @@ const char *ErrCodeName(ErrCode c);  // reference PqaCore/PqaErrors.cpp:13-62
 
 struct AQ { int64_t iQuestion, iAnswer; };
 
+// SRDefaultLogger (reference SRPlatform/SRDefaultLogger.cpp): stderr until Init names a file, that file afterwards.
+struct DefaultLogger {
+  enum class Severity : uint8_t { None = 0, Info, Warning, Error, Critical };   // ISRLogger::Severity
+  static std::string Init(const char *baseName);   // "" on success, the error text otherwise
+  static void Log(Severity sev, const std::string &message);
+};
+
 // PermanentIdManager (reference PqaCore/PermanentIdManager.{h,cpp}): compact id <-> permanent id, survives compaction
 class PermIdMgr {
  public:
@@ -253,7 +260,11 @@ class HipEngine {
   std::atomic<uint64_t> _nQuestionsAsked{0};
   Mode _mode = Mode::Regular;
   // options
-  int64_t _optSelect = 0, _optWorkers = 16, _optEvalSubtasks = 0, _optEvalVariant = 0, _optBugCompat = 0;
+  int64_t _optSelect = 0, _optWorkers = 16, _optEvalSubtasks = 0, _optEvalVariant = 0;
+  // ResumeQuiz seeds the first answered question's product from vector 0 of vB for every target vector, as the reference binary
+  // does (PqaCore/CEUpdatePriorsSubtaskMul.cpp:53 loads pvB, not pvB + j): the drop-in default.  0 = the evident intent.
+  int64_t _optBugCompat = 1;
+  void ApplyEnvironment();   // PQA_SELECT / PQA_SERVER / PQA_BUG_COMPAT / PQA_WORKERS / PQA_SEED: defaults for unchanged wrappers
   int64_t _optFusedSampled = 0;   // the sampled NextQuestion as ONE launch (the sweep's finisher workgroup runs the selector): correct,
                                   // but 38.3 vs 36.4 us at 1000 x 5 x 1000 -- one workgroup's serial selection costs more than a launch
   int64_t _optEvalMaxGrid = 0;    // test hook: KbView::maxGrid

@@ -141,7 +141,7 @@ PriorArgs make_args(const KbView &kb, double *prior, int64_t nWorkers) {
 }  // namespace
 
 hipError_t LaunchStartQuiz(const KbView &kb, double *prior, int64_t nWorkers, hipStream_t stream) {
-  if (nWorkers < 1 || nWorkers > 4096) return hipErrorInvalidValue;
+  if (nWorkers < 1 || nWorkers > kMaxWorkers) return hipErrorInvalidValue;
   hipLaunchKernelGGL(start_quiz_kernel, dim3(1), dim3(small_launch(kb) ? kSmallThreads : kThreads), sum_lds_bytes(nWorkers), stream,
                      make_args(kb, prior, nWorkers));
   return hipGetLastError();
@@ -150,7 +150,7 @@ hipError_t LaunchStartQuiz(const KbView &kb, double *prior, int64_t nWorkers, hi
 hipError_t LaunchRecordAnswer(const KbView &kb, double *prior, uint32_t *asked, int64_t iQuestion, int64_t iAnswer,
                               int64_t nWorkers, RatedTargetDev *topOut, int64_t *topN, uint64_t *topFlag,
                               uint64_t topFlagValue, int64_t topCount, hipStream_t stream) {
-  if (nWorkers < 1 || nWorkers > 4096) return hipErrorInvalidValue;
+  if (nWorkers < 1 || nWorkers > kMaxWorkers) return hipErrorInvalidValue;
   const TopRequest top{reinterpret_cast<TopOut *>(topOut), topN, topFlag, topFlagValue, (topOut && kb.T <= 16384) ? topCount : 0};
   if (small_launch(kb))
     hipLaunchKernelGGL(record_answer_kernel<true>, dim3(1), dim3(kSmallThreads), sum_lds_bytes(nWorkers), stream,
@@ -163,7 +163,7 @@ hipError_t LaunchRecordAnswer(const KbView &kb, double *prior, uint32_t *asked, 
 
 hipError_t LaunchResumeQuiz(const KbView &kb, double *prior, int64_t *exps, const int64_t *aqs, int64_t nAnswered,
                             int64_t nWorkers, int bugCompat, int64_t *status, hipStream_t stream) {
-  if (nWorkers < 1 || nWorkers > 4096 || nAnswered < 1) return hipErrorInvalidValue;
+  if (nWorkers < 1 || nWorkers > kMaxWorkers || nAnswered < 1) return hipErrorInvalidValue;
   hipLaunchKernelGGL(resume_quiz_kernel, dim3(1), dim3(small_launch(kb) ? kSmallThreads : kThreads), sum_lds_bytes(nWorkers), stream,
                      make_args(kb, prior, nWorkers), exps, aqs, nAnswered, bugCompat, status);
   return hipGetLastError();

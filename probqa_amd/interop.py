@@ -114,6 +114,7 @@ HIP_EXPORTS = {
     "PqaEngineFactory_CreateHipEngine": (_vp, [_vp, _pvp, ctypes.POINTER(CiEngineDefinition)]),
     "PqaEngineFactory_CreateHipEngineSharded": (_vp, [_vp, _pvp, ctypes.POINTER(CiEngineDefinition),
                                                       ctypes.POINTER(CiHipShard)]),
+    "PqaEngineFactory_LoadHipEngine": (_vp, [_vp, _pvp, ctypes.c_char_p, _u64]),
     "PqaHip_SetOption": (_vp, [_vp, ctypes.c_char_p, _i64]),
     "PqaHip_GetOption": (_i64, [_vp, ctypes.c_char_p]),
     "PqaHip_EvalKernelName": (ctypes.c_char_p, [_vp]),

@@ -400,3 +400,72 @@ def test_training_with_repeated_questions_bit_identical_to_oracle(factory):
     e = eng.train([interop.AnsweredQuestion(0, K)], 0, 1.0, throw=False)
     assert e is not None and "Answer index is not in KB range" in e.to_string(True)
     eng.close()
+
+
+def test_environment_selects_engine_behaviour_for_unchanged_wrappers(factory, tmp_path):
+    """ProbQA.py / ProbQANetCore can only call PqaEngineFactory_CreateCpuEngine; what they cannot say in a call is
+    read from the environment at creation (PQA_SELECT, PQA_SERVER, PQA_BUG_COMPAT, PQA_WORKERS, PQA_SEED)."""
+    import os
+    import orclib
+
+    case = cases.small_cases()[4]          # 300 x 5 x 1000: the resident sweep serves rows of <= 1024 targets
+    keys = ("PQA_SELECT", "PQA_SERVER", "PQA_BUG_COMPAT", "PQA_WORKERS", "PQA_SEED")
+    saved = {k: os.environ.get(k) for k in keys}
+    try:
+        for k in keys:
+            os.environ.pop(k, None)
+        eng = case.make_engine(factory)
+        assert (eng.get_option("select"), eng.get_option("server"), eng.get_option("bug_compat")) == (0, 0, 1)
+        eng.close()
+        os.environ.update({"PQA_SELECT": "argmax", "PQA_SERVER": "1", "PQA_BUG_COMPAT": "0", "PQA_WORKERS": "8", "PQA_SEED": "42"})
+        eng, err = factory.create_cpu_engine(interop.EngineDefinition(case.K, case.Q, case.T, init_amount=case.init))
+        assert err is None
+        assert (eng.get_option("select"), eng.get_option("server"), eng.get_option("bug_compat"), eng.get_option("workers")) == (1, 1, 0, 8)
+        eng.set_kb(*case.kb())
+        quiz = eng.start_quiz()
+        pri = eng.eval_priorities(quiz)
+        assert eng.next_question(quiz) == int(np.argmax(pri))      # the plain ABI call takes the argmax ...
+        assert eng.get_option("server_active") == 1                 # ... through the resident sweep
+        orc = case.make_oracle()
+        aqs = case.answers
+        assert orc.resume_quiz(aqs, 8, False) == 0
+        q2 = eng.resume_quiz([interop.AnsweredQuestion(q, a) for q, a in aqs])
+        assert np.array_equal(eng.get_priors(q2), orc.priors())     # PQA_BUG_COMPAT=0: the evident intent of :53
+        eng.close()
+        os.environ["PQA_SELECT"] = "nonsense"                        # ignored with a message, the default stays
+        os.environ["PQA_WORKERS"] = "0"
+        eng = case.make_engine(factory)
+        assert eng.get_option("select") == 0
+        eng.close()
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    # the explicit loader name and the logger entry points
+    eng = case.make_engine(factory)
+    path = str(tmp_path / "env.kb")
+    eng.save_kb(path, False)
+    c_err = ctypes_void()
+    c_eng = interop._lib.PqaEngineFactory_LoadHipEngine(factory.c_factory, ctypes_byref(c_err), path.encode(), 0)
+    assert c_eng and not c_err.value
+    eng2 = interop.PqaEngine(c_eng)
+    assert np.array_equal(eng2.get_kb(case.Q)[0], eng.get_kb(case.Q)[0])
+    assert interop._lib.PqaEngine_SetLogger(eng.c_engine, None) is None     # nullptr = the default logger (BaseEngine.cpp:252-258)
+    e = interop._lib.PqaEngine_SetLogger(eng.c_engine, 1)
+    assert e and "SetLogger" in interop.PqaError(e).to_string(True)
+    eng.close()
+    eng2.close()
+
+
+def ctypes_void():
+    import ctypes
+
+    return ctypes.c_void_p()
+
+
+def ctypes_byref(x):
+    import ctypes
+
+    return ctypes.byref(x)

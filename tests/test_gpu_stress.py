@@ -22,7 +22,7 @@ class Shadow:
         self.orc = orclib.Oracle(K, Q, T, 0.1)
         self.orc.set_kb(*kb_arrays)
         if asked:
-            assert self.orc.resume_quiz(list(asked), cases.WORKERS) == 0
+            assert self.orc.resume_quiz(list(asked), cases.WORKERS, True) == 0
         else:
             self.orc.start_quiz(cases.WORKERS)
         self.asked = {q for q, _ in asked}
