@@ -355,6 +355,37 @@ def main():
             sel_m.close()
         eng_m.close()
 
+    # ---- extra (not `value`), sharded runs only: the SAME sharding inside ONE process behind the plain C ABI
+    # (probqa_amd/csrc/sharded_engine.cpp: PQA_DEVICES lists the devices, PqaEngineFactory_CreateCpuEngine builds one shard per
+    # device and PqaEngine_NextQuestion fans out over them -- what the reference's unchanged wrappers get).  Rank 0 drives all
+    # `world` GPUs while the other ranks wait at a barrier.
+    one_process = None
+    if sharded and world > 1:
+        if rank == 0:
+            one_process = {}
+            os.environ["PQA_DEVICES"] = ",".join(str(d) for d in range(world))
+            try:
+                for key, c, n_steps in (("1000x5x1000", CONFIGS["S"], 2000), ("10000x5x10000", CONFIGS["M"], 200)):
+                    e1, err = factory.create_cpu_engine(interop.EngineDefinition(c["K"], c["Q"], c["T"], init_amount=0.1))
+                    if err is not None:
+                        one_process[key] = {"error": err.to_string(True)}
+                        continue
+                    e1.set_option("select", 1)
+                    e1.fill_synthetic(8.0, 0.5, SEED)
+                    qz1 = e1.start_quiz()
+                    for _ in range(50):
+                        p1 = e1.next_question(qz1)
+                    t1 = time.perf_counter()
+                    for _ in range(n_steps):
+                        p1 = e1.next_question(qz1)
+                    d1 = time.perf_counter() - t1
+                    one_process[key] = {"selections_per_sec": n_steps / d1, "us_per_step": 1e6 * d1 / n_steps, "shards": e1.get_option("shards"),
+                                        "selected_question": int(p1)}
+                    e1.close()
+            finally:
+                os.environ.pop("PQA_DEVICES", None)
+        barrier()
+
     out = {
         "metric": "next_question_selections_per_sec",
         "value": value,
@@ -388,6 +419,7 @@ def main():
         "hip_graph_replay": graph_rate,
         "quiz_loop": quiz_loop,
         "sharded_10000x5x10000": sharded_m,
+        "one_process_sharded_engine": one_process,
         "roofline": {
             "bound": "hbm",
             "achieved": achieved,

@@ -10,6 +10,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <vector>
 
 #include "hip_engine.h"
 
@@ -51,16 +52,16 @@ char *DupString(const std::string &s) {
 }
 
 #define ENGINE_OR_RETURN_ERROR                                   \
-  HipEngine *pEng = static_cast<HipEngine *>(pvEngine);         \
+  pqa::IEngine *pEng = static_cast<pqa::IEngine *>(pvEngine);         \
   if (pEng == nullptr) return new Error(NullEngine());
 #define ENGINE_OR_SET_ERROR(retVal)                        \
-  HipEngine *pEng = static_cast<HipEngine *>(pvEngine);         \
+  pqa::IEngine *pEng = static_cast<pqa::IEngine *>(pvEngine);         \
   if (pEng == nullptr) {                                        \
     if (ppError) *ppError = new Error(NullEngine());            \
     return retVal;                                              \
   }
 #define ENGINE_OR_LOG(retVal)                                               \
-  HipEngine *pEng = static_cast<HipEngine *>(pvEngine);                             \
+  pqa::IEngine *pEng = static_cast<pqa::IEngine *>(pvEngine);                             \
   if (pEng == nullptr) {                                                            \
     std::fprintf(stderr, "PqaCore: Nullptr is passed in place of IPqaEngine.\n");   \
     return retVal;                                                                  \
@@ -76,7 +77,38 @@ void *CreateEngine(void *pvFactory, void **ppError, const CiEngineDefinition *pE
     return nullptr;
   }
   Error err;
-  HipEngine *eng = HipEngine::Create(err, *pEngDef, pShard);
+  // PQA_DEVICES=i[,j,...] (unchanged wrappers cannot name a device): one ordinal = that device; several = one shard of
+  // the question axis per listed device (an ordinal may repeat: several shards on one device), behind this one engine handle
+  std::vector<int> devices;
+  if (pShard == nullptr) {
+    if (const char *v = std::getenv("PQA_DEVICES")) {
+      const char *p = v;
+      bool ok = *p != 0;
+      while (ok && *p) {
+        char *end = nullptr;
+        const long d = std::strtol(p, &end, 10);
+        if (end == p || d < 0 || d > 1023) { ok = false; break; }
+        devices.push_back((int)d);
+        p = end;
+        if (*p == ',') p++; else if (*p != 0) ok = false;
+      }
+      if (!ok) {
+        if (*v) std::fprintf(stderr, "PqaCore: ignoring PQA_DEVICES=%s (expected a comma-separated list of device ordinals)\n", v);
+        devices.clear();
+      }
+    }
+  }
+  pqa::IEngine *eng = nullptr;
+  if (devices.size() >= 2) {
+    eng = pqa::CreateShardedEngine(err, *pEngDef, devices);
+  } else {
+    CiHipShard whole;
+    if (devices.size() == 1) {
+      whole._qFirst = 0; whole._qTotal = pEngDef->_nQuestions; whole._device = devices[0]; whole._reserved = 0;
+      pShard = &whole;
+    }
+    eng = HipEngine::Create(err, *pEngDef, pShard);
+  }
   AssignErr(ppError, err);
   return eng;
 }
@@ -135,7 +167,7 @@ PQACORE_API void *PqaError_ToString(void *pvError, const uint8_t withParams) {
   return DupString(pErr->ToString(withParams != 0));
 }
 
-PQACORE_API void CiReleasePqaEngine(void *pvEngine) { delete static_cast<HipEngine *>(pvEngine); }
+PQACORE_API void CiReleasePqaEngine(void *pvEngine) { delete static_cast<pqa::IEngine *>(pvEngine); }
 
 PQACORE_API void *PqaEngine_Train(void *pvEngine, int64_t nQuestions, const CiAnsweredQuestion *const pAQs,
                                   const int64_t iTarget, const double amount) {

@@ -8,6 +8,7 @@
 #include <cstring>
 #include <random>
 #include <cstdlib>
+#include <functional>
 #include <sstream>
 
 #include <unistd.h>
@@ -448,7 +449,11 @@ void HipEngine::DropQuizBufferPool() {
   _quizBufferPool.clear();
 }
 
-int64_t HipEngine::CreateQuiz(Error &err, int64_t nAnswered, const AQ *pAQs) {
+// rows / srcPrior: support for a knowledge base whose question axis is split over several engines (sharded_engine.cpp).
+//   rows != nullptr: the 2 nAnswered row pointers of LaunchResumeQuiz, resolved by the owners of the answered questions;
+//   srcPrior != nullptr: the posterior was computed by another engine -- copy it (after `ready`) instead of computing it.
+int64_t HipEngine::CreateQuiz(Error &err, int64_t nAnswered, const AQ *pAQs, const void *const *rows, const double *srcPrior,
+                              int srcDevice, hipEvent_t ready) {
   err = CheckRegular("Start/Resume quiz");
   if (!err.ok()) return -1;
   hipSetDevice(_device);
@@ -465,9 +470,10 @@ int64_t HipEngine::CreateQuiz(Error &err, int64_t nAnswered, const AQ *pAQs) {
       return fail(Error::MakeP(ErrCode::IndexOutOfRange, RangeParams(ia, 0, _K - 1), "Answer index is not in KB range."));
     if (iq >= _qFirst && iq < _qFirst + _Q) BitSet(quiz->hAsked, iq - _qFirst, true); else allLocal = false;
   }
-  if (!allLocal)
-    return fail(Error::MakeP(ErrCode::NotImplemented, "Feature=ResumeQuiz across shards",
-                             "ResumeQuiz on a sharded engine needs every answered question to be local."));
+  if (!allLocal && rows == nullptr && srcPrior == nullptr)
+    return fail(Error::MakeP(ErrCode::NotImplemented, "Feature=ResumeQuiz across separately driven shards",
+                             "An answered question belongs to another shard: its rows are not reachable from this engine alone "
+                             "(PQA_DEVICES / the sharded engine of one process resolves them)."));
   hipError_t he = hipSuccess;
   while (!_quizBufferPool.empty() && quiz->dPrior == nullptr) {
     const QuizBuffers b = _quizBufferPool.back();
@@ -490,7 +496,13 @@ int64_t HipEngine::CreateQuiz(Error &err, int64_t nAnswered, const AQ *pAQs) {
                                          hipMemcpyHostToDevice, _stream);
   if (he != hipSuccess) return fail(HipErr(he, "quiz allocation"));
   const KbView kb = View();
-  if (nAnswered == 0) {
+  if (srcPrior != nullptr) {
+    if (ready != nullptr) he = hipStreamWaitEvent(_stream, ready, 0);
+    if (he == hipSuccess)
+      he = hipMemcpyPeerAsync(quiz->dPrior, _device, srcPrior, srcDevice, (size_t)_ldT * sizeof(double), _stream);
+    if (he != hipSuccess) return fail(HipErr(he, "adopting another shard's posterior"));
+    for (int64_t i = 0; i < nAnswered; i++) quiz->answers.push_back(pAQs[i]);
+  } else if (nAnswered == 0) {
     // CECreateQuizStart::UpdateLikelihoods, reference PqaCore/CECreateQuizOperation.cpp:22-53
     he = LaunchStartQuiz(kb, quiz->dPrior, _optWorkers, _stream);
     if (he != hipSuccess) return fail(HipErr(he, "LaunchStartQuiz"));
@@ -504,11 +516,17 @@ int64_t HipEngine::CreateQuiz(Error &err, int64_t nAnswered, const AQ *pAQs) {
       he = hipMalloc(&_dAqs, (size_t)_aqCapacity * 2 * sizeof(int64_t));
       if (he != hipSuccess) { _aqCapacity = 0; return fail(HipErr(he, "aq buffer")); }
     }
-    std::vector<int64_t> local(2 * (size_t)nAnswered);
-    for (int64_t i = 0; i < nAnswered; i++) { local[2 * i] = pAQs[i].iQuestion - _qFirst; local[2 * i + 1] = pAQs[i].iAnswer; }
-    he = hipMemcpyAsync(_dAqs, local.data(), local.size() * sizeof(int64_t), hipMemcpyHostToDevice, _stream);
+    std::vector<const void *> local(2 * (size_t)nAnswered);
+    for (int64_t i = 0; i < nAnswered; i++) {
+      if (rows != nullptr) { local[2 * i] = rows[2 * i]; local[2 * i + 1] = rows[2 * i + 1]; continue; }
+      local[2 * i] = CubeAt(pAQs[i].iQuestion - _qFirst, pAQs[i].iAnswer);
+      local[2 * i + 1] = CubeAt(pAQs[i].iQuestion - _qFirst, _K);
+    }
+    static_assert(sizeof(void *) == sizeof(int64_t), "the pointer list travels in the answered-question buffer");
+    he = hipMemcpyAsync(_dAqs, local.data(), local.size() * sizeof(void *), hipMemcpyHostToDevice, _stream);
     if (he == hipSuccess)
-      he = LaunchResumeQuiz(kb, quiz->dPrior, _dExps, _dAqs, nAnswered, _optWorkers, (int)_optBugCompat, _dStatus, _stream);
+      he = LaunchResumeQuiz(kb, quiz->dPrior, _dExps, reinterpret_cast<const void *const *>(_dAqs), nAnswered, _optWorkers,
+                            (int)_optBugCompat, _dStatus, _stream);
     if (he == hipSuccess)
       he = hipMemcpyAsync(_hPinned->status, _dStatus, 2 * sizeof(int64_t), hipMemcpyDeviceToHost, _stream);
     if (he == hipSuccess) he = hipStreamSynchronize(_stream);
@@ -528,7 +546,7 @@ int64_t HipEngine::CreateQuiz(Error &err, int64_t nAnswered, const AQ *pAQs) {
 
 int64_t HipEngine::StartQuiz(Error &err) {
   std::lock_guard<EngineMutex> lk(_mu);
-  return CreateQuiz(err, 0, nullptr);
+  return CreateQuiz(err, 0, nullptr, nullptr, nullptr, 0, nullptr);
 }
 
 int64_t HipEngine::ResumeQuiz(Error &err, int64_t nAnswered, const AQ *pAQs) {
@@ -541,7 +559,54 @@ int64_t HipEngine::ResumeQuiz(Error &err, int64_t nAnswered, const AQ *pAQs) {
     return -1;
   }
   std::lock_guard<EngineMutex> lk(_mu);
-  return CreateQuiz(err, nAnswered, pAQs);  // nAnswered == 0 -> StartQuiz (BaseEngine.cpp:393-395)
+  return CreateQuiz(err, nAnswered, pAQs, nullptr, nullptr, 0, nullptr);  // nAnswered == 0 -> StartQuiz (BaseEngine.cpp:393-395)
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// what a sharded engine (sharded_engine.cpp) needs from its shards beyond the public surface
+// ------------------------------------------------------------------------------------------------------------------
+Error HipEngine::GetRowPointers(int64_t qGlobal, int64_t iAnswer, const void **ppA, const void **ppD) {
+  std::lock_guard<EngineMutex> lk(_mu);
+  if (!OwnsQuestion(qGlobal))
+    return Error::MakeP(ErrCode::IndexOutOfRange, RangeParams(qGlobal, _qFirst, _qFirst + _Q - 1), "Question is not held by this shard.");
+  if (iAnswer < 0 || iAnswer >= _K)
+    return Error::MakeP(ErrCode::IndexOutOfRange, RangeParams(iAnswer, 0, _K - 1), "Answer index is not in KB range.");
+  *ppA = CubeAt(qGlobal - _qFirst, iAnswer);
+  *ppD = CubeAt(qGlobal - _qFirst, _K);
+  return Error();
+}
+
+int64_t HipEngine::ResumeQuizRows(Error &err, int64_t nAnswered, const AQ *pAQs, const void *const *rows) {
+  std::lock_guard<EngineMutex> lk(_mu);
+  return CreateQuiz(err, nAnswered, pAQs, rows, nullptr, 0, nullptr);
+}
+
+int64_t HipEngine::ResumeQuizAdopt(Error &err, int64_t nAnswered, const AQ *pAQs, const double *srcPrior, int srcDevice, hipEvent_t ready) {
+  std::lock_guard<EngineMutex> lk(_mu);
+  return CreateQuiz(err, nAnswered, pAQs, nullptr, srcPrior, srcDevice, ready);
+}
+
+// The owner of the answered question has computed the new posterior: replace this shard's copy, in stream order.
+Error HipEngine::AdoptPrior(int64_t iQuiz, const double *srcPrior, int srcDevice, hipEvent_t ready) {
+  std::lock_guard<EngineMutex> lk(_mu);
+  Error err;
+  Quiz *q = UseQuiz(err, iQuiz);
+  if (!q) return err;
+  hipSetDevice(_device);
+  ServerQuiesce();
+  if (ready != nullptr) HIP_TRY(hipStreamWaitEvent(_stream, ready, 0));
+  HIP_TRY(hipMemcpyPeerAsync(q->dPrior, _device, srcPrior, srcDevice, (size_t)_ldT * sizeof(double), _stream));
+  q->priorVersion++;
+  return Error();
+}
+
+Error HipEngine::QuestionState(int64_t iQuiz, int64_t qGlobal, bool *pUnavailable) {
+  std::lock_guard<EngineMutex> lk(_mu);
+  Error err;
+  Quiz *q = UseQuiz(err, iQuiz);
+  if (!q) return err;
+  *pUnavailable = !OwnsQuestion(qGlobal) || QuestionUnavailable(q, qGlobal - _qFirst);
+  return Error();
 }
 
 Error HipEngine::ReleaseQuiz(int64_t iQuiz) {
@@ -563,12 +628,13 @@ bool HipEngine::QuestionUnavailable(const Quiz *q, int64_t qLocal) const {
   return BitTest(_hQGap, qLocal) || BitTest(q->hAsked, qLocal);
 }
 
-// BaseEngine::FindNearestQuestion, reference PqaCore/BaseEngine.cpp:60-124 (over the local question range)
-int64_t HipEngine::FindNearestQuestion(int64_t iMiddle, const Quiz *q) const {
+// BaseEngine::FindNearestQuestion, reference PqaCore/BaseEngine.cpp:60-124: the available question "nearest" to iMiddle as the
+// reference finds it -- exact within iMiddle's own 64-bit pack, then pack by pack outwards, comparing only the two packs at the
+// same pack distance.  avail(p): bit i set = question 64 p + i is neither asked nor a gap (bits past nQuestions clear).
+int64_t FindNearestInPacks(int64_t iMiddle, int64_t nQuestions, const std::function<uint64_t(int64_t)> &avail) {
   const uint32_t dInf = 200;
   const int64_t iPack64 = iMiddle >> 6;
   const uint32_t iWithin = (uint32_t)(iMiddle & 63);
-  auto avail = [&](int64_t p) { return ~(Pack64(_hQGap, p) | Pack64(q->hAsked, p)); };
   const uint64_t available = avail(iPack64);
   if (available != 0) {
     const uint64_t baseMask = (1ULL << iWithin) - 1;
@@ -577,7 +643,7 @@ int64_t HipEngine::FindNearestQuestion(int64_t iMiddle, const Quiz *q) const {
     const uint32_t dLower = lower ? (iWithin - (uint32_t)(63 - __builtin_clzll(lower))) : dInf;
     return (dHigher < dLower) ? iMiddle + dHigher : iMiddle - dLower;
   }
-  const int64_t limPack64 = (_Q + 63) >> 6;
+  const int64_t limPack64 = (nQuestions + 63) >> 6;
   int64_t i = 1;
   while ((iPack64 >= i) && (iPack64 + i < limPack64)) {
     const uint64_t availLeft = avail(iPack64 - i), availRight = avail(iPack64 + i);
@@ -598,6 +664,21 @@ int64_t HipEngine::FindNearestQuestion(int64_t iMiddle, const Quiz *q) const {
     return iMiddle + ((uint32_t)__builtin_ctzll(availRight) + 64 - iWithin) + ((i - 1) << 6);
   }
   return -1;
+}
+
+int64_t HipEngine::FindNearestQuestion(int64_t iMiddle, const Quiz *q) const {   // (over the local question range)
+  return FindNearestInPacks(iMiddle, _Q, [&](int64_t p) { return ~(Pack64(_hQGap, p) | Pack64(q->hAsked, p)); });
+}
+
+// bit i of words[i / 32] set = LOCAL question i is asked in the quiz or a gap (bits past the local count set)
+Error HipEngine::UnavailableWords(int64_t iQuiz, std::vector<uint32_t> &words) {
+  std::lock_guard<EngineMutex> lk(_mu);
+  Error err;
+  Quiz *q = UseQuiz(err, iQuiz);
+  if (!q) return err;
+  words.resize(_hQGap.size());
+  for (size_t w = 0; w < words.size(); w++) words[w] = _hQGap[w] | q->hAsked[w];
+  return Error();
 }
 
 int64_t HipEngine::FinishSelection(Error &err, Quiz *q, int64_t selLocal) {

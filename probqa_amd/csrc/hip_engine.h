@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 
 #include <atomic>
+#include <functional>
 #include <cstdint>
 #include <memory>
 #include <mutex>
@@ -87,65 +88,137 @@ struct Quiz {
   uint64_t priorVersion = 0;           // bumped whenever the posterior changes
 };
 
-class HipEngine {
+// What the C ABI (c_abi.cpp) drives: one engine on one device (HipEngine), or the question axis of one knowledge base split
+// over several devices of the process (ShardedEngine, sharded_engine.cpp) -- the reference's IPqaEngine surface
+// (PqaCore/Interface/IPqaEngine.h:14-113) plus the additive calls of include/PqaHipExt.h.
+class IEngine {
+ public:
+  virtual ~IEngine() {}
+  virtual Error Train(int64_t nQuestions, const AQ *pAQs, int64_t iTarget, double amount) = 0;
+  virtual uint64_t GetTotalQuestionsAsked(Error &err) = 0;
+  virtual void CopyDims(CiEngineDimensions *pDims) const = 0;
+  virtual int64_t StartQuiz(Error &err) = 0;
+  virtual int64_t ResumeQuiz(Error &err, int64_t nAnswered, const AQ *pAQs) = 0;
+  virtual int64_t NextQuestion(Error &err, int64_t iQuiz) = 0;
+  virtual Error RecordAnswer(int64_t iQuiz, int64_t iAnswer) = 0;
+  virtual int64_t GetActiveQuestionId(Error &err, int64_t iQuiz) = 0;
+  virtual Error SetActiveQuestion(int64_t iQuiz, int64_t iQuestion) = 0;
+  virtual int64_t ListTopTargets(Error &err, int64_t iQuiz, int64_t maxCount, CiRatedTarget *pDest) = 0;
+  virtual Error RecordQuizTarget(int64_t iQuiz, int64_t iTarget, double amount) = 0;
+  virtual Error ReleaseQuiz(int64_t iQuiz) = 0;
+  virtual Error StartMaintenance(bool forceQuizzes) = 0;
+  virtual Error FinishMaintenance() = 0;
+  virtual Error Shutdown(const char *saveFilePath) = 0;
+  virtual bool MapIds(int which, bool toPerm, int64_t count, int64_t *pIds) = 0;
+  virtual bool EnsurePermQuizGreater(int64_t bound) = 0;
+  virtual bool RemapQuizPermId(int64_t srcPermId, int64_t destPermId) = 0;
+  virtual Error SaveKB(const char *filePath, bool doubleBuffer) = 0;
+  virtual Error AddQsTs(int64_t nQuestions, CiAddQorTParam *pAqps, int64_t nTargets, CiAddQorTParam *pAtps) = 0;
+  virtual Error RemoveQuestions(int64_t n, const int64_t *pQIds) = 0;
+  virtual Error RemoveTargets(int64_t n, const int64_t *pTIds) = 0;
+  virtual Error Compact(int64_t *pnQuestions, const int64_t **ppOldQuestions, int64_t *pnTargets, const int64_t **ppOldTargets) = 0;
+  virtual Error ClearOldQuizzes(int64_t maxCount, double maxAgeSec) = 0;
+  // ---- additive (PqaHipExt.h)
+  virtual Error SetOption(const char *name, int64_t value) = 0;
+  virtual int64_t GetOption(const char *name) const = 0;
+  virtual const char *EvalKernelName() const = 0;
+  virtual Error SetKB(const double *pA, const double *pD, const double *pB) = 0;
+  virtual Error GetKB(double *pA, double *pD, double *pB) = 0;
+  virtual Error FillSynthetic(double nTrain, double noiseAmp, uint64_t seed) = 0;
+  virtual Error SetTargetGaps(int64_t n, const int64_t *ids) = 0;
+  virtual Error SetQuestionGaps(int64_t n, const int64_t *ids) = 0;
+  virtual Error EvalPriorities(int64_t iQuiz, double *pOut, int64_t n) = 0;
+  virtual int64_t NextQuestionArgmax(Error &err, int64_t iQuiz) = 0;
+  virtual int64_t NextQuestionSampled(Error &err, int64_t iQuiz, uint64_t rnd) = 0;
+  virtual Error GetPriors(int64_t iQuiz, double *pOut, int64_t n) = 0;
+  virtual Error NextQuestionArgmaxBatch(int64_t n, const int64_t *pQuizzes, int64_t *pOut) = 0;
+  virtual Error EvalPrioritiesBatch(int64_t n, const int64_t *pQuizzes, double *pOut) = 0;
+  virtual Error SelectArgmaxBatch(int64_t n, const int64_t *pQuizzes, CiHipSelection *pOut) = 0;
+  virtual Error Log2HotArray(const double *pIn, double *pOut, int64_t n) = 0;
+  virtual hipStream_t GetStream() const = 0;
+  virtual Error SetStream(hipStream_t s) = 0;
+  virtual Error Synchronize() = 0;
+  virtual Error EnqueueSelectArgmax(int64_t iQuiz, void *pOut) = 0;
+  virtual Error EnqueueSelectArgmaxFlag(int64_t iQuiz, void *pOut, void *pFlag, uint64_t flagValue) = 0;
+  virtual Error EnqueueEval(int64_t iQuiz) = 0;
+  virtual Error GetPriorDevicePtr(int64_t iQuiz, void **ppDev, int64_t *pLdT) = 0;
+  virtual Error RecordAnswerRemote(int64_t iQuiz, int64_t iAnswer) = 0;
+};
+
+class HipEngine : public IEngine {
  public:
   static HipEngine *Create(Error &err, const CiEngineDefinition &def, const CiHipShard *shard);
-  ~HipEngine();
+  ~HipEngine() override;
 
   // ---- reference IPqaEngine surface (names as in IPqaEngine.h)
-  Error Train(int64_t nQuestions, const AQ *pAQs, int64_t iTarget, double amount);
-  uint64_t GetTotalQuestionsAsked(Error &err);
-  void CopyDims(CiEngineDimensions *pDims) const;
-  int64_t StartQuiz(Error &err);
-  int64_t ResumeQuiz(Error &err, int64_t nAnswered, const AQ *pAQs);
-  int64_t NextQuestion(Error &err, int64_t iQuiz);
-  Error RecordAnswer(int64_t iQuiz, int64_t iAnswer);
-  int64_t GetActiveQuestionId(Error &err, int64_t iQuiz);
-  Error SetActiveQuestion(int64_t iQuiz, int64_t iQuestion);
-  int64_t ListTopTargets(Error &err, int64_t iQuiz, int64_t maxCount, CiRatedTarget *pDest);
-  Error RecordQuizTarget(int64_t iQuiz, int64_t iTarget, double amount);
-  Error ReleaseQuiz(int64_t iQuiz);
-  Error StartMaintenance(bool forceQuizzes);
-  Error FinishMaintenance();
-  Error Shutdown(const char *saveFilePath);
+  Error Train(int64_t nQuestions, const AQ *pAQs, int64_t iTarget, double amount) override;
+  uint64_t GetTotalQuestionsAsked(Error &err) override;
+  void CopyDims(CiEngineDimensions *pDims) const override;
+  int64_t StartQuiz(Error &err) override;
+  int64_t ResumeQuiz(Error &err, int64_t nAnswered, const AQ *pAQs) override;
+  int64_t NextQuestion(Error &err, int64_t iQuiz) override;
+  Error RecordAnswer(int64_t iQuiz, int64_t iAnswer) override;
+  int64_t GetActiveQuestionId(Error &err, int64_t iQuiz) override;
+  Error SetActiveQuestion(int64_t iQuiz, int64_t iQuestion) override;
+  int64_t ListTopTargets(Error &err, int64_t iQuiz, int64_t maxCount, CiRatedTarget *pDest) override;
+  Error RecordQuizTarget(int64_t iQuiz, int64_t iTarget, double amount) override;
+  Error ReleaseQuiz(int64_t iQuiz) override;
+  Error StartMaintenance(bool forceQuizzes) override;
+  Error FinishMaintenance() override;
+  Error Shutdown(const char *saveFilePath) override;
   // which: 0 questions, 1 targets, 2 quizzes; toPerm: compact -> permanent (reference BaseEngine.cpp:150-215)
-  bool MapIds(int which, bool toPerm, int64_t count, int64_t *pIds);
-  bool EnsurePermQuizGreater(int64_t bound);
-  bool RemapQuizPermId(int64_t srcPermId, int64_t destPermId);
-  Error SaveKB(const char *filePath, bool doubleBuffer);
+  bool MapIds(int which, bool toPerm, int64_t count, int64_t *pIds) override;
+  bool EnsurePermQuizGreater(int64_t bound) override;
+  bool RemapQuizPermId(int64_t srcPermId, int64_t destPermId) override;
+  Error SaveKB(const char *filePath, bool doubleBuffer) override;
   static HipEngine *Load(Error &err, const char *filePath);
-  Error AddQsTs(int64_t nQuestions, CiAddQorTParam *pAqps, int64_t nTargets, CiAddQorTParam *pAtps);
-  Error RemoveQuestions(int64_t n, const int64_t *pQIds);
-  Error RemoveTargets(int64_t n, const int64_t *pTIds);
-  Error Compact(int64_t *pnQuestions, const int64_t **ppOldQuestions, int64_t *pnTargets, const int64_t **ppOldTargets);
-  Error ClearOldQuizzes(int64_t maxCount, double maxAgeSec);
+  Error AddQsTs(int64_t nQuestions, CiAddQorTParam *pAqps, int64_t nTargets, CiAddQorTParam *pAtps) override;
+  Error RemoveQuestions(int64_t n, const int64_t *pQIds) override;
+  Error RemoveTargets(int64_t n, const int64_t *pTIds) override;
+  Error Compact(int64_t *pnQuestions, const int64_t **ppOldQuestions, int64_t *pnTargets, const int64_t **ppOldTargets) override;
+  Error ClearOldQuizzes(int64_t maxCount, double maxAgeSec) override;
 
   // ---- additive (PqaHipExt.h)
-  Error SetOption(const char *name, int64_t value);
-  int64_t GetOption(const char *name) const;
-  const char *EvalKernelName() const;
-  Error SetKB(const double *pA, const double *pD, const double *pB);
-  Error GetKB(double *pA, double *pD, double *pB);
-  Error FillSynthetic(double nTrain, double noiseAmp, uint64_t seed);
-  Error SetTargetGaps(int64_t n, const int64_t *ids);
-  Error SetQuestionGaps(int64_t n, const int64_t *ids);
-  Error EvalPriorities(int64_t iQuiz, double *pOut, int64_t n);
-  int64_t NextQuestionArgmax(Error &err, int64_t iQuiz);
-  int64_t NextQuestionSampled(Error &err, int64_t iQuiz, uint64_t rnd);
-  Error GetPriors(int64_t iQuiz, double *pOut, int64_t n);
+  Error SetOption(const char *name, int64_t value) override;
+  int64_t GetOption(const char *name) const override;
+  const char *EvalKernelName() const override;
+  Error SetKB(const double *pA, const double *pD, const double *pB) override;
+  Error GetKB(double *pA, double *pD, double *pB) override;
+  Error FillSynthetic(double nTrain, double noiseAmp, uint64_t seed) override;
+  Error SetTargetGaps(int64_t n, const int64_t *ids) override;
+  Error SetQuestionGaps(int64_t n, const int64_t *ids) override;
+  Error EvalPriorities(int64_t iQuiz, double *pOut, int64_t n) override;
+  int64_t NextQuestionArgmax(Error &err, int64_t iQuiz) override;
+  int64_t NextQuestionSampled(Error &err, int64_t iQuiz, uint64_t rnd) override;
+  Error GetPriors(int64_t iQuiz, double *pOut, int64_t n) override;
   int64_t NextQuestionArgmaxGraph(Error &err, Quiz *q);
-  Error NextQuestionArgmaxBatch(int64_t n, const int64_t *pQuizzes, int64_t *pOut);
-  Error EvalPrioritiesBatch(int64_t n, const int64_t *pQuizzes, double *pOut);
-  Error SelectArgmaxBatch(int64_t n, const int64_t *pQuizzes, CiHipSelection *pOut);   // pOut[i][q], q < local question count
-  Error Log2HotArray(const double *pIn, double *pOut, int64_t n);  // device log2hot over an array (tests)
-  hipStream_t GetStream() const { return _stream; }
-  Error SetStream(hipStream_t s);
-  Error Synchronize();
-  Error EnqueueSelectArgmax(int64_t iQuiz, void *pOut);
-  Error EnqueueSelectArgmaxFlag(int64_t iQuiz, void *pOut, void *pFlag, uint64_t flagValue);
-  Error EnqueueEval(int64_t iQuiz);
-  Error GetPriorDevicePtr(int64_t iQuiz, void **ppDev, int64_t *pLdT);
-  Error RecordAnswerRemote(int64_t iQuiz, int64_t iAnswer);
+  Error NextQuestionArgmaxBatch(int64_t n, const int64_t *pQuizzes, int64_t *pOut) override;
+  Error EvalPrioritiesBatch(int64_t n, const int64_t *pQuizzes, double *pOut) override;
+  Error SelectArgmaxBatch(int64_t n, const int64_t *pQuizzes, CiHipSelection *pOut) override;   // pOut[i][q], q < local question count
+  Error Log2HotArray(const double *pIn, double *pOut, int64_t n) override;  // device log2hot over an array (tests)
+  hipStream_t GetStream() const override { return _stream; }
+  Error SetStream(hipStream_t s) override;
+  Error Synchronize() override;
+  Error EnqueueSelectArgmax(int64_t iQuiz, void *pOut) override;
+  Error EnqueueSelectArgmaxFlag(int64_t iQuiz, void *pOut, void *pFlag, uint64_t flagValue) override;
+  Error EnqueueEval(int64_t iQuiz) override;
+  Error GetPriorDevicePtr(int64_t iQuiz, void **ppDev, int64_t *pLdT) override;
+  Error RecordAnswerRemote(int64_t iQuiz, int64_t iAnswer) override;
+
+  // ---- what a sharded engine needs from its shards (sharded_engine.cpp)
+  int Device() const { return _device; }
+  int64_t FirstQuestion() const { return _qFirst; }
+  int64_t LocalQuestions() const { return _Q; }
+  int64_t RowLength() const { return _ldT; }
+  bool OwnsQuestion(int64_t qGlobal) const { return qGlobal >= _qFirst && qGlobal < _qFirst + _Q; }
+  const double *PriorityDevicePtr() const { return _dPriority; }   // filled by EnqueueEval, local question order
+  void BumpQuestionsAsked(uint64_t n) { _nQuestionsAsked.fetch_add(n, std::memory_order_relaxed); }
+  Error GetRowPointers(int64_t qGlobal, int64_t iAnswer, const void **ppA, const void **ppD);
+  int64_t ResumeQuizRows(Error &err, int64_t nAnswered, const AQ *pAQs, const void *const *rows);
+  int64_t ResumeQuizAdopt(Error &err, int64_t nAnswered, const AQ *pAQs, const double *srcPrior, int srcDevice, hipEvent_t ready);
+  Error AdoptPrior(int64_t iQuiz, const double *srcPrior, int srcDevice, hipEvent_t ready);
+  Error QuestionState(int64_t iQuiz, int64_t qGlobal, bool *pUnavailable);
+  Error UnavailableWords(int64_t iQuiz, std::vector<uint32_t> &words);
 
  private:
   HipEngine() = default;
@@ -153,7 +226,8 @@ class HipEngine {
   KbView View() const;
   Quiz *UseQuiz(Error &err, int64_t iQuiz);                 // reference BaseEngine::UseQuiz, BaseEngine.cpp:399-419
   Error CheckRegular(const char *what) const;               // MaintenanceSwitch gate of BaseEngine.cpp:423-427 etc.
-  int64_t CreateQuiz(Error &err, int64_t nAnswered, const AQ *pAQs);  // CpuEngine::CreateQuizInternal
+  int64_t CreateQuiz(Error &err, int64_t nAnswered, const AQ *pAQs, const void *const *rows, const double *srcPrior, int srcDevice,
+                     hipEvent_t ready);  // CpuEngine::CreateQuizInternal
   void DestroyQuiz(Quiz *q);
   int64_t FinishSelection(Error &err, Quiz *q, int64_t sel);  // gap/asked fallback + bookkeeping (CpuEngine.cpp:404-413)
   int64_t FindNearestQuestion(int64_t iMiddleGlobal, const Quiz *q) const;  // BaseEngine.cpp:60-124
@@ -292,5 +366,9 @@ class HipEngine {
   void ServerQuiesce();   // returns once the posted step (if any) has finished: before anything that writes what it reads
   uint64_t _rng[2] = {0, 0};
 };
+
+int64_t FindNearestInPacks(int64_t iMiddle, int64_t nQuestions, const std::function<uint64_t(int64_t)> &avail);
+// One knowledge base over several devices of this process (sharded_engine.cpp); devices.size() >= 2.
+IEngine *CreateShardedEngine(Error &err, const CiEngineDefinition &def, const std::vector<int> &devices);
 
 }  // namespace pqa

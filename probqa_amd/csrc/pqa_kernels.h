@@ -161,9 +161,10 @@ hipError_t LaunchStartQuiz(const KbView &kb, double *prior, int64_t nWorkers, hi
 hipError_t LaunchRecordAnswer(const KbView &kb, double *prior, uint32_t *asked, int64_t iQuestion, int64_t iAnswer,
                               int64_t nWorkers, RatedTargetDev *topOut, int64_t *topN, uint64_t *topFlag,
                               uint64_t topFlagValue, int64_t topCount, hipStream_t stream);
-// aqs: device array of (question, answer) int64 pairs.  exps: scratch of ldT int64.  status: device int64[2]
+// rows: device array of 2 nAnswered row pointers, {sA[q_i][a_i], mD[q_i]} per answered question (rows of kb.elem-byte elements,
+// ldT long; they may live on another device of the process).  exps: scratch of ldT int64.  status: device int64[2]
 // {error code (0 / 16 = I64Underflow), fullMax}.  bugCompat reproduces PqaCore/CEUpdatePriorsSubtaskMul.cpp:53.
-hipError_t LaunchResumeQuiz(const KbView &kb, double *prior, int64_t *exps, const int64_t *aqs, int64_t nAnswered,
+hipError_t LaunchResumeQuiz(const KbView &kb, double *prior, int64_t *exps, const void *const *rows, int64_t nAnswered,
                             int64_t nWorkers, int bugCompat, int64_t *status, hipStream_t stream);
 
 // ---- KB construction / mutation

@@ -52,8 +52,11 @@ __device__ __forceinline__ int ceil_log2_u64(uint64_t val) {  // SRPlatform/Inte
   return index + ((val & (val - 1)) ? 1 : 0);
 }
 
+// rows: for answered question i the rows sA[q_i][a_i][.] (rows[2i]) and mD[q_i][.] (rows[2i + 1]) -- pointers instead of
+// indices, so that the rows of a question held by ANOTHER device of the process (a shard of the question axis,
+// sharded_engine.cpp) are read in place over xGMI peer access.
 __global__ __launch_bounds__(kThreads) void resume_quiz_kernel(PriorArgs a, int64_t *__restrict__ exps,
-                                                               const int64_t *__restrict__ aqs, int64_t nAnswered,
+                                                               const void *const *__restrict__ rows, int64_t nAnswered,
                                                                int bugCompat, int64_t *status) {
   extern __shared__ double lds[];
   __shared__ long long sMax[kThreads / kWave];
@@ -66,16 +69,14 @@ __global__ __launch_bounds__(kThreads) void resume_quiz_kernel(PriorArgs a, int6
     double mant;
     int64_t ex;
     {
-      const int64_t q = aqs[0], ans = aqs[1];
-      const double pQaGivenT = cube_ld(a.cube, a.elem, (q * (a.K + 1) + ans) * a.ldT + t) / cube_ld(a.cube, a.elem, (q * (a.K + 1) + a.K) * a.ldT + t);
+      const double pQaGivenT = cube_ld(rows[0], a.elem, t) / cube_ld(rows[1], a.elem, t);
       const double oldMant = bugCompat ? a.vB[t & 3] : a.vB[t];  // CEUpdatePriorsSubtaskMul.cpp:53 loads pvB, not pvB+j
       const uint64_t up = d2u(oldMant * pQaGivenT);              // :54
       mant = u2d(kExp0Up | (up & ~kExpMaskUp));                  // :56 MakeExponent0
       ex = (int64_t)((up & kExpMaskUp) >> 52);                   // :59 ExtractExponents64<false>
     }
     for (int64_t i = 1; i < nAnswered; i++) {
-      const int64_t q = aqs[2 * i], ans = aqs[2 * i + 1];
-      const double pQaGivenT = cube_ld(a.cube, a.elem, (q * (a.K + 1) + ans) * a.ldT + t) / cube_ld(a.cube, a.elem, (q * (a.K + 1) + a.K) * a.ldT + t);
+      const double pQaGivenT = cube_ld(rows[2 * i], a.elem, t) / cube_ld(rows[2 * i + 1], a.elem, t);
       const uint64_t up = d2u(mant * pQaGivenT);                 // :75
       mant = u2d(kExp0Up | (up & ~kExpMaskUp));                  // :77
       ex += (int64_t)((up & kExpMaskUp) >> 52);                  // :80-82
@@ -161,11 +162,11 @@ hipError_t LaunchRecordAnswer(const KbView &kb, double *prior, uint32_t *asked, 
   return hipGetLastError();
 }
 
-hipError_t LaunchResumeQuiz(const KbView &kb, double *prior, int64_t *exps, const int64_t *aqs, int64_t nAnswered,
+hipError_t LaunchResumeQuiz(const KbView &kb, double *prior, int64_t *exps, const void *const *rows, int64_t nAnswered,
                             int64_t nWorkers, int bugCompat, int64_t *status, hipStream_t stream) {
   if (nWorkers < 1 || nWorkers > kMaxWorkers || nAnswered < 1) return hipErrorInvalidValue;
   hipLaunchKernelGGL(resume_quiz_kernel, dim3(1), dim3(small_launch(kb) ? kSmallThreads : kThreads), sum_lds_bytes(nWorkers), stream,
-                     make_args(kb, prior, nWorkers), exps, aqs, nAnswered, bugCompat, status);
+                     make_args(kb, prior, nWorkers), exps, rows, nAnswered, bugCompat, status);
   return hipGetLastError();
 }
 

@@ -1,0 +1,503 @@
+// sharded_engine.cpp -- one knowledge base, its question axis split over several devices of ONE process, behind the same C ABI.
+//
+// every question's priority depends only on its own sA / mD rows and on the (small, replicated) posterior, so
+// the sweep shards by question with no data-path collective; what the shards exchange per selection is 16 bytes each.
+// PQA_DEVICES=0,1,...,7 makes PqaEngineFactory_CreateCpuEngine build this engine instead of a single-device one, so that the
+// reference's unchanged wrappers -- which can only call PqaEngine_NextQuestion (PqaCInterop.cpp:261-267) -- reach all the GPUs
+// of a node.  Shard s is a complete HipEngine over the contiguous question range SRPoolRunner::CalcSplit gives it
+// (SRPlatform/Interface/SRPoolRunner.h:96-110), with replicas of vB, the gap bitmaps and every quiz's posterior.
+//
+//   NextQuestion (argmax)  every shard's sweep is enqueued on its own device and stream; each finisher writes {priority, GLOBAL
+//                          index} and then the step number into this engine's pinned slots; the host picks when all have
+//                          landed (maximum priority, lowest index on ties).  No collective launch, no copies, no stream sync.
+//   NextQuestion (sampled) the reference's selector needs every priority in global order: each shard's priority vector
+//                          (8 bytes per question) is copied to the host and the selection -- per-subtask Kahan run lengths,
+//                          grand totals, two upper_bounds (CpuEngine.cpp:362-400) -- runs there, with the same subtask split
+//                          over the GLOBAL question range as an unsharded engine.
+//   RecordAnswer           runs on the owner of the active question; the new posterior goes to the other shards by peer copies
+//                          (hipMemcpyPeerAsync, ordered by events: no host synchronisation).
+//   ResumeQuiz             shard 0 computes the posterior from row POINTERS, reading other shards' rows in place over peer
+//                          access (xGMI); the other shards adopt it.
+//   Train / RecordQuizTarget   every shard applies the steps that fall on its questions (and its vB replica).
+// Where the rows are: peer access is enabled between all listed devices at creation; several shards on one device (tests on a
+// single GPU) need none.  Not sharded (NotImplemented on this engine): maintenance-mode edits of the dimensions and the .kb file.
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cmath>
+#include <cstring>
+
+#include "hip_engine.h"
+
+namespace pqa {
+
+namespace {
+
+Error NotSharded(const char *what) {
+  return Error::MakeP(ErrCode::NotImplemented, std::string("Feature=") + what + " on a sharded engine",
+                      std::string(what) + " is not available when the question axis is split over several devices (PQA_DEVICES).");
+}
+
+struct alignas(64) Slot {          // one per shard, host-coherent pinned memory
+  double priority;
+  int64_t index;
+  uint64_t flag;
+};
+
+struct HostKahan {                 // SRAccumulator<SRDoubleNumber> (SRPlatform/Interface/SRAccumulator.h:15-39)
+  double sum = 0, corr = 0;
+  void add(double v) {
+    const double y = v - corr;
+    const double t = sum + y;
+    corr = (t - sum) - y;
+    sum = t;
+  }
+  double get() const { return sum - corr; }
+};
+
+}  // namespace
+
+class ShardedEngine final : public IEngine {
+ public:
+  static ShardedEngine *Create(Error &err, const CiEngineDefinition &def, const std::vector<int> &devices);
+  ~ShardedEngine() override;
+
+  Error Train(int64_t n, const AQ *pAQs, int64_t iTarget, double amount) override {
+    std::lock_guard<std::mutex> lk(_mu);
+    for (auto &s : _sh) { Error e = s->Train(n, pAQs, iTarget, amount); if (!e.ok()) return e; }
+    return Error();
+  }
+  uint64_t GetTotalQuestionsAsked(Error &err) override { return _sh[0]->GetTotalQuestionsAsked(err); }
+  void CopyDims(CiEngineDimensions *pDims) const override { _sh[0]->CopyDims(pDims); }
+  int64_t StartQuiz(Error &err) override;
+  int64_t ResumeQuiz(Error &err, int64_t nAnswered, const AQ *pAQs) override;
+  int64_t NextQuestion(Error &err, int64_t iQuiz) override;
+  Error RecordAnswer(int64_t iQuiz, int64_t iAnswer) override;
+  int64_t GetActiveQuestionId(Error &err, int64_t iQuiz) override { return _sh[0]->GetActiveQuestionId(err, iQuiz); }
+  Error SetActiveQuestion(int64_t iQuiz, int64_t iQuestion) override { return All([&](HipEngine &e) { return e.SetActiveQuestion(iQuiz, iQuestion); }); }
+  int64_t ListTopTargets(Error &err, int64_t iQuiz, int64_t maxCount, CiRatedTarget *pDest) override {
+    std::lock_guard<std::mutex> lk(_mu);
+    return _sh[_lastOwner.count(iQuiz) ? _lastOwner[iQuiz] : 0]->ListTopTargets(err, iQuiz, maxCount, pDest);   // (its kernel listed them already)
+  }
+  Error RecordQuizTarget(int64_t iQuiz, int64_t iTarget, double amount) override { return All([&](HipEngine &e) { return e.RecordQuizTarget(iQuiz, iTarget, amount); }); }
+  Error ReleaseQuiz(int64_t iQuiz) override {
+    std::lock_guard<std::mutex> lk(_mu);
+    _lastOwner.erase(iQuiz);
+    for (auto &s : _sh) { Error e = s->ReleaseQuiz(iQuiz); if (!e.ok()) return e; }
+    return Error();
+  }
+  Error StartMaintenance(bool force) override { return All([&](HipEngine &e) { return e.StartMaintenance(force); }); }
+  Error FinishMaintenance() override { return All([&](HipEngine &e) { return e.FinishMaintenance(); }); }
+  Error Shutdown(const char *saveFilePath) override {
+    if (saveFilePath && *saveFilePath) return NotSharded("Shutdown with a KB file");
+    return All([&](HipEngine &e) { return e.Shutdown(nullptr); });
+  }
+  bool MapIds(int which, bool toPerm, int64_t count, int64_t *pIds) override {
+    if (which == 0) {   // questions: compact == permanent until maintenance edits, which this engine does not take
+      return true;
+    }
+    return _sh[0]->MapIds(which, toPerm, count, pIds);
+  }
+  bool EnsurePermQuizGreater(int64_t bound) override { bool ok = true; for (auto &s : _sh) ok = s->EnsurePermQuizGreater(bound) && ok; return ok; }
+  bool RemapQuizPermId(int64_t a, int64_t b) override { bool ok = true; for (auto &s : _sh) ok = s->RemapQuizPermId(a, b) && ok; return ok; }
+  Error SaveKB(const char *, bool) override { return NotSharded("SaveKB"); }
+  Error AddQsTs(int64_t, CiAddQorTParam *, int64_t, CiAddQorTParam *) override { return NotSharded("AddQsTs"); }
+  Error RemoveQuestions(int64_t, const int64_t *) override { return NotSharded("RemoveQuestions"); }
+  Error RemoveTargets(int64_t, const int64_t *) override { return NotSharded("RemoveTargets"); }
+  Error Compact(int64_t *, const int64_t **, int64_t *, const int64_t **) override { return NotSharded("Compact"); }
+  Error ClearOldQuizzes(int64_t maxCount, double maxAgeSec) override { return All([&](HipEngine &e) { return e.ClearOldQuizzes(maxCount, maxAgeSec); }); }
+
+  Error SetOption(const char *name, int64_t value) override {
+    const std::string n(name ? name : "");
+    if (n == "select") _select = value;   // (kept here too: NextQuestion dispatches on it)
+    if (n == "seed") { _rng[0] = 0x9E3779B97F4A7C15ULL ^ (uint64_t)value; _rng[1] = 0xBF58476D1CE4E5B9ULL + ((uint64_t)value << 1); }
+    return All([&](HipEngine &e) { return e.SetOption(name, value); });
+  }
+  int64_t GetOption(const char *name) const override {
+    const std::string n(name ? name : "");
+    if (n == "shards") return (int64_t)_sh.size();
+    return _sh[0]->GetOption(name);
+  }
+  const char *EvalKernelName() const override { return _sh[0]->EvalKernelName(); }
+  Error SetKB(const double *pA, const double *pD, const double *pB) override {
+    std::lock_guard<std::mutex> lk(_mu);
+    for (auto &s : _sh) {
+      const size_t q0 = (size_t)s->FirstQuestion();
+      Error e = s->SetKB(pA + q0 * (size_t)_K * (size_t)_T, pD + q0 * (size_t)_T, pB);
+      if (!e.ok()) return e;
+    }
+    return Error();
+  }
+  Error GetKB(double *pA, double *pD, double *pB) override {
+    std::lock_guard<std::mutex> lk(_mu);
+    for (auto &s : _sh) {
+      const size_t q0 = (size_t)s->FirstQuestion();
+      Error e = s->GetKB(pA ? pA + q0 * (size_t)_K * (size_t)_T : nullptr, pD ? pD + q0 * (size_t)_T : nullptr, s == _sh[0] ? pB : nullptr);
+      if (!e.ok()) return e;
+    }
+    return Error();
+  }
+  Error FillSynthetic(double nTrain, double noiseAmp, uint64_t seed) override { return All([&](HipEngine &e) { return e.FillSynthetic(nTrain, noiseAmp, seed); }); }
+  Error SetTargetGaps(int64_t n, const int64_t *ids) override { return All([&](HipEngine &e) { return e.SetTargetGaps(n, ids); }); }
+  Error SetQuestionGaps(int64_t n, const int64_t *ids) override { return All([&](HipEngine &e) { return e.SetQuestionGaps(n, ids); }); }
+  Error EvalPriorities(int64_t iQuiz, double *pOut, int64_t n) override {
+    if (n != _Q) return Error::MakeP(ErrCode::IndexOutOfRange, "n=" + std::to_string(n), "Priority buffer length must equal the question count.");
+    std::lock_guard<std::mutex> lk(_mu);
+    for (auto &s : _sh) { Error e = s->EvalPriorities(iQuiz, pOut + s->FirstQuestion(), s->LocalQuestions()); if (!e.ok()) return e; }
+    return Error();
+  }
+  int64_t NextQuestionArgmax(Error &err, int64_t iQuiz) override;
+  int64_t NextQuestionSampled(Error &err, int64_t iQuiz, uint64_t rnd) override;
+  Error GetPriors(int64_t iQuiz, double *pOut, int64_t n) override { return _sh[0]->GetPriors(iQuiz, pOut, n); }
+  Error NextQuestionArgmaxBatch(int64_t n, const int64_t *pQuizzes, int64_t *pOut) override;
+  Error EvalPrioritiesBatch(int64_t n, const int64_t *pQuizzes, double *pOut) override {
+    std::lock_guard<std::mutex> lk(_mu);
+    std::vector<double> part;
+    for (auto &s : _sh) {
+      part.resize((size_t)n * (size_t)s->LocalQuestions());
+      Error e = s->EvalPrioritiesBatch(n, pQuizzes, part.data());
+      if (!e.ok()) return e;
+      for (int64_t i = 0; i < n; i++)
+        std::memcpy(pOut + (size_t)i * (size_t)_Q + (size_t)s->FirstQuestion(), part.data() + (size_t)i * (size_t)s->LocalQuestions(),
+                    (size_t)s->LocalQuestions() * sizeof(double));
+    }
+    return Error();
+  }
+  Error SelectArgmaxBatch(int64_t n, const int64_t *pQuizzes, CiHipSelection *pOut) override;
+  Error Log2HotArray(const double *pIn, double *pOut, int64_t n) override { return _sh[0]->Log2HotArray(pIn, pOut, n); }
+  hipStream_t GetStream() const override { return _sh[0]->GetStream(); }
+  Error SetStream(hipStream_t) override { return NotSharded("SetStream"); }
+  Error Synchronize() override { return All([&](HipEngine &e) { return e.Synchronize(); }); }
+  Error EnqueueSelectArgmax(int64_t, void *) override { return NotSharded("EnqueueSelectArgmax"); }
+  Error EnqueueSelectArgmaxFlag(int64_t, void *, void *, uint64_t) override { return NotSharded("EnqueueSelectArgmaxFlag"); }
+  Error EnqueueEval(int64_t iQuiz) override { return All([&](HipEngine &e) { return e.EnqueueEval(iQuiz); }); }
+  Error GetPriorDevicePtr(int64_t iQuiz, void **ppDev, int64_t *pLdT) override { return _sh[0]->GetPriorDevicePtr(iQuiz, ppDev, pLdT); }
+  Error RecordAnswerRemote(int64_t, int64_t) override { return NotSharded("RecordAnswerRemote"); }
+
+ private:
+  ShardedEngine() = default;
+  template <typename F>
+  Error All(F &&f) {
+    std::lock_guard<std::mutex> lk(_mu);
+    for (auto &s : _sh) { Error e = f(*s); if (!e.ok()) return e; }
+    return Error();
+  }
+  int OwnerOf(int64_t qGlobal) const {
+    for (size_t s = 0; s < _sh.size(); s++) if (_sh[s]->OwnsQuestion(qGlobal)) return (int)s;
+    return -1;
+  }
+  int64_t SelectArgmaxLocked(Error &err, int64_t iQuiz, double *pPriority);
+  int64_t Commit(Error &err, int64_t iQuiz, int64_t qGlobal);
+  uint64_t NextRandom() {   // xorshift128+, the generator family of SRPlatform/Interface/SRFastRandom.h:60-72
+    uint64_t s1 = _rng[0];
+    const uint64_t s0 = _rng[1];
+    _rng[0] = s0;
+    s1 ^= s1 << 23;
+    _rng[1] = s1 ^ s0 ^ (s1 >> 18) ^ (s0 >> 5);
+    return _rng[1] + s0;
+  }
+
+  std::vector<std::unique_ptr<HipEngine>> _sh;
+  std::mutex _mu;
+  int64_t _K = 0, _Q = 0, _T = 0;
+  int64_t _select = 0;
+  Slot *_slots = nullptr;               // [shards], pinned + mapped: written by the sweeps' finishers, polled here
+  uint64_t _step = 0;
+  std::vector<hipEvent_t> _posteriorReady;   // per shard: recorded behind the RecordAnswer kernel whose posterior the others copy
+  std::vector<hipEvent_t> _copyDone;         // per shard: recorded behind its copy of another shard's posterior
+  std::unordered_map<int64_t, int> _lastOwner;   // quiz -> the shard whose RecordAnswer kernel ran last (it listed the top targets)
+  std::vector<double> _hostPriority;
+  uint64_t _rng[2] = {0x9E3779B97F4A7C15ULL, 0xBF58476D1CE4E5B9ULL};
+};
+
+ShardedEngine::~ShardedEngine() {
+  for (size_t s = 0; s < _sh.size(); s++) {
+    hipSetDevice(_sh[s]->Device());
+    if (s < _posteriorReady.size() && _posteriorReady[s]) hipEventDestroy(_posteriorReady[s]);
+    if (s < _copyDone.size() && _copyDone[s]) hipEventDestroy(_copyDone[s]);
+  }
+  _sh.clear();
+  if (_slots) hipHostFree(_slots);
+}
+
+ShardedEngine *ShardedEngine::Create(Error &err, const CiEngineDefinition &def, const std::vector<int> &devices) {
+  std::unique_ptr<ShardedEngine> eng(new ShardedEngine());
+  const int64_t N = (int64_t)devices.size();
+  if (def._nQuestions < N) {
+    err = Error::MakeP(ErrCode::InsufficientEngineDimensions, "[nQuestions=" + std::to_string(def._nQuestions) + " of " + std::to_string(N) + "]",
+                       "Fewer questions than devices in PQA_DEVICES.");
+    return nullptr;
+  }
+  eng->_K = def._nAnswers; eng->_Q = def._nQuestions; eng->_T = def._nTargets;
+  // peer access between all pairs of distinct devices: the posterior copies and ResumeQuiz's in-place row reads go over xGMI
+  for (int a : devices)
+    for (int b : devices)
+      if (a != b) {
+        int can = 0;
+        if (hipDeviceCanAccessPeer(&can, a, b) == hipSuccess && can) {
+          hipSetDevice(a);
+          const hipError_t e = hipDeviceEnablePeerAccess(b, 0);
+          if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();
+          (void)hipGetLastError();
+        }
+      }
+  // SRPoolRunner::CalcSplit (SRPlatform/Interface/SRPoolRunner.h:96-110): the first Q % N shards hold one question more
+  const int64_t quot = def._nQuestions / N, rem = def._nQuestions % N;
+  int64_t first = 0;
+  for (int64_t s = 0; s < N; s++) {
+    CiEngineDefinition d = def;
+    d._nQuestions = quot + (s < rem ? 1 : 0);
+    CiHipShard sh;
+    sh._qFirst = first; sh._qTotal = def._nQuestions; sh._device = devices[(size_t)s]; sh._reserved = 0;
+    HipEngine *e = HipEngine::Create(err, d, &sh);
+    if (!e) return nullptr;
+    eng->_sh.emplace_back(e);
+    first += d._nQuestions;
+  }
+  if (hipHostMalloc((void **)&eng->_slots, sizeof(Slot) * (size_t)N, hipHostMallocMapped | hipHostMallocCoherent | hipHostMallocPortable) != hipSuccess) {
+    err = Error::Make(ErrCode::Internal, "Can't allocate the shards' selection slots.");
+    return nullptr;
+  }
+  std::memset(eng->_slots, 0, sizeof(Slot) * (size_t)N);
+  eng->_posteriorReady.assign((size_t)N, nullptr);
+  eng->_copyDone.assign((size_t)N, nullptr);
+  for (int64_t s = 0; s < N; s++) {
+    hipSetDevice(devices[(size_t)s]);
+    if (hipEventCreateWithFlags(&eng->_posteriorReady[(size_t)s], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&eng->_copyDone[(size_t)s], hipEventDisableTiming) != hipSuccess) {
+      err = Error::Make(ErrCode::Internal, "Can't create the shards' ordering events.");
+      return nullptr;
+    }
+  }
+  eng->_select = eng->_sh[0]->GetOption("select");
+  eng->_hostPriority.resize((size_t)def._nQuestions);
+  err = Error();
+  return eng.release();
+}
+
+int64_t ShardedEngine::StartQuiz(Error &err) {
+  std::lock_guard<std::mutex> lk(_mu);
+  int64_t id = -1;
+  for (size_t s = 0; s < _sh.size(); s++) {
+    const int64_t got = _sh[s]->StartQuiz(err);
+    if (got < 0) return -1;
+    if (s == 0) id = got;
+    else if (got != id) { err = Error::Make(ErrCode::Internal, "The shards' quiz registries have diverged."); return -1; }
+  }
+  return id;
+}
+
+int64_t ShardedEngine::ResumeQuiz(Error &err, int64_t nAnswered, const AQ *pAQs) {
+  if (nAnswered < 0) { err = Error::MakeP(ErrCode::NegativeCount, "count=" + std::to_string(nAnswered), "|nAnswered| must be non-negative."); return -1; }
+  if (nAnswered == 0) return StartQuiz(err);   // BaseEngine.cpp:393-395
+  if (pAQs == nullptr) { err = Error::Make(ErrCode::NullArgument, "Nullptr is passed in place of answered questions."); return -1; }
+  std::lock_guard<std::mutex> lk(_mu);
+  std::vector<const void *> rows(2 * (size_t)nAnswered);
+  for (int64_t i = 0; i < nAnswered; i++) {
+    const int owner = OwnerOf(pAQs[i].iQuestion);
+    if (owner < 0) { err = Error::MakeP(ErrCode::IndexOutOfRange, "subjIndex=" + std::to_string(pAQs[i].iQuestion), "Question index is not in KB range."); return -1; }
+    err = _sh[(size_t)owner]->GetRowPointers(pAQs[i].iQuestion, pAQs[i].iAnswer, &rows[2 * (size_t)i], &rows[2 * (size_t)i + 1]);
+    if (!err.ok()) return -1;
+  }
+  // shard 0 computes (remote rows are read in place), the others adopt its posterior
+  const int64_t id = _sh[0]->ResumeQuizRows(err, nAnswered, pAQs, rows.data());
+  if (id < 0) return -1;
+  void *src = nullptr;
+  int64_t ld = 0;
+  err = _sh[0]->GetPriorDevicePtr(id, &src, &ld);
+  if (!err.ok()) return -1;
+  hipSetDevice(_sh[0]->Device());
+  if (hipEventRecord(_posteriorReady[0], _sh[0]->GetStream()) != hipSuccess) { err = Error::Make(ErrCode::Internal, "hipEventRecord failed."); return -1; }
+  for (size_t s = 1; s < _sh.size(); s++) {
+    const int64_t got = _sh[s]->ResumeQuizAdopt(err, nAnswered, pAQs, (const double *)src, _sh[0]->Device(), _posteriorReady[0]);
+    if (got < 0) return -1;
+    if (got != id) { err = Error::Make(ErrCode::Internal, "The shards' quiz registries have diverged."); return -1; }
+  }
+  return id;
+}
+
+// Everything NextQuestion does after the pick (CpuEngine.cpp:403-413): the question becomes the quiz's active question on every
+// shard, the asked-questions counter moves once.
+int64_t ShardedEngine::Commit(Error &err, int64_t iQuiz, int64_t qGlobal) {
+  if (qGlobal < 0) { err = Error::Make(ErrCode::QuestionsExhausted, "Found no unasked question that is not in a gap."); return -1; }
+  for (auto &s : _sh) { err = s->SetActiveQuestion(iQuiz, qGlobal); if (!err.ok()) return -1; }
+  _sh[0]->BumpQuestionsAsked(1);
+  return qGlobal;
+}
+
+int64_t ShardedEngine::SelectArgmaxLocked(Error &err, int64_t iQuiz, double *pPriority) {
+  if (++_step == 0) ++_step;
+  const uint64_t step = _step;
+  for (size_t s = 0; s < _sh.size(); s++) {
+    // the slots are mapped + portable: their host address is what every device sees
+    err = _sh[s]->EnqueueSelectArgmaxFlag(iQuiz, &_slots[s].priority, &_slots[s].flag, step);
+    if (!err.ok()) return -1;
+  }
+  const auto t0 = std::chrono::steady_clock::now();
+  for (size_t s = 0; s < _sh.size(); s++) {
+    volatile uint64_t *flag = &_slots[s].flag;
+    uint64_t spins = 0;
+    while (*flag != step)
+      if ((++spins & 0x3FFF) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(60)) {
+        err = Error::MakeP(ErrCode::Internal, "shard=" + std::to_string(s), "Timed out waiting for a shard's selection.");
+        return -1;
+      }
+  }
+  std::atomic_thread_fence(std::memory_order_acquire);
+  double bestP = 0;
+  int64_t bestI = -1;
+  for (size_t s = 0; s < _sh.size(); s++) {
+    double p = _slots[s].priority;
+    const int64_t i = _slots[s].index;
+    if (i == -3) { err = Error::Make(ErrCode::Internal, "A shard's sweep did not complete."); return -1; }
+    if (i < 0) continue;
+    if (p != p) p = -HUGE_VAL;
+    if (bestI < 0 || p > bestP || (p == bestP && i < bestI)) { bestP = p; bestI = i; }
+  }
+  if (pPriority) *pPriority = bestP;
+  err = Error();
+  return bestI;
+}
+
+int64_t ShardedEngine::NextQuestionArgmax(Error &err, int64_t iQuiz) {
+  std::lock_guard<std::mutex> lk(_mu);
+  const int64_t q = SelectArgmaxLocked(err, iQuiz, nullptr);
+  if (!err.ok()) return -1;
+  return Commit(err, iQuiz, q);
+}
+
+// The reference's selector (PqaCore/CpuEngine.cpp:362-400) over the GLOBAL question range: the same per-subtask Kahan run
+// lengths, grand totals and upper_bounds as select_sampled_wg_impl (pqa_device.h) runs on one device, here on the host over the
+// shards' priority vectors -- with the same priorities, subtask count and random number it picks the question an unsharded
+// engine picks.
+int64_t ShardedEngine::NextQuestionSampled(Error &err, int64_t iQuiz, uint64_t rnd) {
+  std::lock_guard<std::mutex> lk(_mu);
+  for (auto &s : _sh) { err = s->EnqueueEval(iQuiz); if (!err.ok()) return -1; }
+  for (auto &s : _sh) {
+    hipSetDevice(s->Device());
+    if (hipMemcpyAsync(_hostPriority.data() + s->FirstQuestion(), s->PriorityDevicePtr(), (size_t)s->LocalQuestions() * sizeof(double),
+                       hipMemcpyDeviceToHost, s->GetStream()) != hipSuccess) { err = Error::Make(ErrCode::Internal, "Copy of a shard's priorities failed."); return -1; }
+  }
+  for (auto &s : _sh) {
+    hipSetDevice(s->Device());
+    if (hipStreamSynchronize(s->GetStream()) != hipSuccess) { err = Error::Make(ErrCode::Internal, "A shard's sweep failed."); return -1; }
+  }
+  // which questions are asked or gaps, in global numbering (the shards' ranges are not multiples of 32)
+  std::vector<uint64_t> skip((size_t)((_Q + 63) / 64) + 1, 0);
+  {
+    std::vector<uint32_t> words;
+    for (auto &s : _sh) {
+      err = s->UnavailableWords(iQuiz, words);
+      if (!err.ok()) return -1;
+      for (int64_t i = 0; i < s->LocalQuestions(); i++)
+        if ((words[(size_t)(i >> 5)] >> (i & 31)) & 1u) skip[(size_t)((s->FirstQuestion() + i) >> 6)] |= 1ULL << ((s->FirstQuestion() + i) & 63);
+    }
+    for (int64_t q = _Q; q < (int64_t)skip.size() * 64; q++) skip[(size_t)(q >> 6)] |= 1ULL << (q & 63);
+  }
+  auto skipped = [&](int64_t q) { return (skip[(size_t)(q >> 6)] >> (q & 63)) & 1ULL; };
+  const int64_t n = _Q, nWorkers = _sh[0]->GetOption("eval_subtasks");
+  const int64_t quot = n / nWorkers, rem = n % nWorkers, nSubtasks = quot == 0 ? rem : nWorkers;   // CalcSplit
+  auto bound = [&](int64_t i) { return (i + 1) * quot + std::min<int64_t>(i + 1, rem); };           // end of subtask i
+  std::vector<double> grand((size_t)nSubtasks);
+  std::vector<double> &run = _hostPriority;   // priorities, then (in place) the run lengths
+  for (int64_t s = 0; s < nSubtasks; s++) {
+    HostKahan acc;
+    for (int64_t i = s == 0 ? 0 : bound(s - 1); i < bound(s); i++) {
+      if (!skipped(i)) acc.add(run[(size_t)i]);   // gap / asked questions only copy the running sum (CEEvalQsSubtaskConsider.cpp:54-58, :212)
+      run[(size_t)i] = acc.get();
+    }
+    grand[(size_t)s] = acc.get();
+  }
+  HostKahan tot;                                                 // CpuEngine.cpp:362-368
+  for (int64_t s = 0; s < nSubtasks; s++) { tot.add(grand[(size_t)s]); grand[(size_t)s] = tot.get(); }
+  const double totG = grand[(size_t)nSubtasks - 1];
+  const double selRunLen = totG * (double)rnd / 18446744073709551615.0;   // :379, SRDoubleNumber::MakeRandom
+  int64_t sel;
+  const int64_t iWorker = std::upper_bound(grand.begin(), grand.end(), selRunLen) - grand.begin();   // :380-381
+  if (iWorker >= nSubtasks) sel = n - 1;                          // :384
+  else {
+    const double inWorker = selRunLen - (iWorker == 0 ? 0.0 : grand[(size_t)iWorker - 1]);   // :388
+    const int64_t first = iWorker == 0 ? 0 : bound(iWorker - 1), limit = bound(iWorker);
+    sel = std::upper_bound(run.begin() + first, run.begin() + limit, inWorker) - run.begin();   // :391
+    if (sel >= limit) sel = limit - 1;                            // :392-400
+  }
+  // :403-407 a gap / asked pick falls to BaseEngine::FindNearestQuestion, over the global bitmap
+  if (skipped(sel)) sel = FindNearestInPacks(sel, n, [&](int64_t p) { return ~skip[(size_t)p]; });
+  return Commit(err, iQuiz, sel);
+}
+
+int64_t ShardedEngine::NextQuestion(Error &err, int64_t iQuiz) {
+  if (_select == 1) return NextQuestionArgmax(err, iQuiz);
+  uint64_t rnd;
+  { std::lock_guard<std::mutex> lk(_mu); rnd = NextRandom(); }
+  return NextQuestionSampled(err, iQuiz, rnd);
+}
+
+Error ShardedEngine::RecordAnswer(int64_t iQuiz, int64_t iAnswer) {
+  std::lock_guard<std::mutex> lk(_mu);
+  Error err;
+  const int64_t aq = _sh[0]->GetActiveQuestionId(err, iQuiz);
+  if (!err.ok()) return err;
+  const int owner = aq < 0 ? 0 : OwnerOf(aq);   // (no / invalid active question: let a shard produce the reference's error)
+  if (owner < 0) return _sh[0]->RecordAnswer(iQuiz, iAnswer);
+  HipEngine &o = *_sh[(size_t)owner];
+  // the owner's kernel rewrites its posterior: not before the other shards have taken their copies of the previous one
+  hipSetDevice(o.Device());
+  for (size_t s = 0; s < _sh.size(); s++)
+    if ((int)s != owner && hipStreamWaitEvent(o.GetStream(), _copyDone[s], 0) != hipSuccess) return Error::Make(ErrCode::Internal, "hipStreamWaitEvent failed.");
+  err = o.RecordAnswer(iQuiz, iAnswer);
+  if (!err.ok()) return err;
+  if (hipEventRecord(_posteriorReady[(size_t)owner], o.GetStream()) != hipSuccess) return Error::Make(ErrCode::Internal, "hipEventRecord failed.");
+  void *src = nullptr;
+  int64_t ld = 0;
+  err = o.GetPriorDevicePtr(iQuiz, &src, &ld);
+  if (!err.ok()) return err;
+  for (size_t s = 0; s < _sh.size(); s++) {
+    if ((int)s == owner) continue;
+    err = _sh[s]->RecordAnswerRemote(iQuiz, iAnswer);
+    if (!err.ok()) return err;
+    err = _sh[s]->AdoptPrior(iQuiz, (const double *)src, o.Device(), _posteriorReady[(size_t)owner]);
+    if (!err.ok()) return err;
+    hipSetDevice(_sh[s]->Device());
+    if (hipEventRecord(_copyDone[s], _sh[s]->GetStream()) != hipSuccess) return Error::Make(ErrCode::Internal, "hipEventRecord failed.");
+  }
+  _lastOwner[iQuiz] = owner;
+  return Error();
+}
+
+Error ShardedEngine::SelectArgmaxBatch(int64_t n, const int64_t *pQuizzes, CiHipSelection *pOut) {
+  std::lock_guard<std::mutex> lk(_mu);
+  std::vector<CiHipSelection> part((size_t)n);
+  for (size_t s = 0; s < _sh.size(); s++) {
+    Error e = _sh[s]->SelectArgmaxBatch(n, pQuizzes, part.data());
+    if (!e.ok()) return e;
+    for (int64_t i = 0; i < n; i++) {
+      const CiHipSelection &c = part[(size_t)i];
+      CiHipSelection &b = pOut[i];
+      if (s == 0) { b = c; continue; }
+      if (c._iQuestion >= 0 && (b._iQuestion < 0 || c._priority > b._priority || (c._priority == b._priority && c._iQuestion < b._iQuestion))) b = c;
+    }
+  }
+  return Error();
+}
+
+Error ShardedEngine::NextQuestionArgmaxBatch(int64_t n, const int64_t *pQuizzes, int64_t *pOut) {
+  if (n < 0 || n > 256) return Error::MakeP(ErrCode::IndexOutOfRange, "n=" + std::to_string(n), "Batch size is out of range.");
+  if (n == 0) return Error();
+  if (!pQuizzes || !pOut) return Error::Make(ErrCode::NullArgument, "Nullptr is passed in place of a batch buffer.");
+  std::vector<CiHipSelection> best((size_t)n);
+  Error e = SelectArgmaxBatch(n, pQuizzes, best.data());
+  if (!e.ok()) return e;
+  std::lock_guard<std::mutex> lk(_mu);
+  for (int64_t i = 0; i < n; i++) {
+    Error ce;
+    pOut[i] = Commit(ce, pQuizzes[i], best[(size_t)i]._iQuestion);   // -1 + QuestionsExhausted: reported as -1 only
+  }
+  return Error();
+}
+
+IEngine *CreateShardedEngine(Error &err, const CiEngineDefinition &def, const std::vector<int> &devices) {
+  return ShardedEngine::Create(err, def, devices);
+}
+
+}  // namespace pqa

@@ -1,0 +1,126 @@
+"""One knowledge base over several shards of ONE process behind the plain C ABI (probqa_amd/csrc/sharded_engine.cpp):
+PQA_DEVICES lists a device per shard and PqaEngineFactory_CreateCpuEngine -- the only factory call the reference's wrappers can
+make -- returns an engine whose every call fans out over the shards.  On a single-GPU box the ordinal 0 is listed several times
+(several shards on one device): the same code path as eight GPUs, minus the peer copies crossing xGMI.
+
+Held to: a whole-cube engine (same selections, bit-identical posteriors) AND the oracle, step by step."""
+import os
+
+import numpy as np
+import pytest
+
+import cases
+import orclib
+from probqa_amd import interop
+
+pytestmark = pytest.mark.gpu
+
+PRIORITY_RTOL = 1e-9
+SUBTASKS = 8 * cases.WORKERS
+
+
+class devices:
+    def __init__(self, spec):
+        self.spec = spec
+
+    def __enter__(self):
+        self.saved = os.environ.get("PQA_DEVICES")
+        os.environ["PQA_DEVICES"] = self.spec
+
+    def __exit__(self, *a):
+        if self.saved is None:
+            os.environ.pop("PQA_DEVICES", None)
+        else:
+            os.environ["PQA_DEVICES"] = self.saved
+
+
+@pytest.mark.parametrize("case", [cases.small_cases()[1], cases.small_cases()[2], cases.small_cases()[4]], ids=lambda c: c.name)
+@pytest.mark.parametrize("spec", ["0,0", "0,0,0,0,0"], ids=["2shards", "5shards"])
+def test_sharded_engine_behind_the_plain_abi(case, spec, factory):
+    with devices(spec):
+        sh = case.make_engine(factory)            # PqaEngineFactory_CreateCpuEngine, nothing else
+    assert sh.get_option("shards") == spec.count(",") + 1
+    whole = case.make_engine(factory)
+    assert whole.get_option("shards") == -1
+    orc = case.make_oracle()
+    dims = sh.copy_dims()
+    assert (dims.n_answers, dims.n_questions, dims.n_targets) == (case.K, case.Q, case.T)
+    for a, b in zip(sh.get_kb(case.Q), whole.get_kb(case.Q)):
+        assert np.array_equal(a, b)
+    qs, qw = sh.start_quiz(), whole.start_quiz()
+    orc.start_quiz(cases.WORKERS)
+    valid = [q for q in range(case.Q) if q not in case.qgaps]
+    rng = np.random.default_rng(3)
+    for step in range(6):
+        assert np.array_equal(sh.get_priors(qs), orc.priors()), f"step {step}: posterior"
+        pri = sh.eval_priorities(qs, case.Q)
+        run, opri = orc.eval(SUBTASKS)
+        assert ((opri == 0) == (pri == 0)).all() and cases.rel_err(pri[opri != 0], opri[opri != 0]).max() < PRIORITY_RTOL
+        assert np.array_equal(pri, whole.eval_priorities(qw))          # same kernels over the same rows
+        want = orc.select_argmax(opri)
+        assert sh.next_question_argmax(qs) == want == whole.next_question_argmax(qw)
+        assert sh.get_active_question_id(qs) == want
+        for rnd in (0, 1, 2**63, 2**64 - 1, 0x9E3779B97F4A7C15):
+            assert sh.next_question_sampled(qs, rnd) == orc.select_sampled(run, SUBTASKS, rnd) == whole.next_question_sampled(qw, rnd), hex(rnd)
+        assert sh.next_question_argmax_batch([qs]) == [want]
+        # answer a question of a (mostly) different shard every step
+        q = valid[(step * len(valid)) // 6 + int(rng.integers(3))]
+        while q in [x for x, _ in orc.answers]:
+            q = valid[(valid.index(q) + 1) % len(valid)]
+        a = int(rng.integers(case.K))
+        for e, z in ((sh, qs), (whole, qw)):
+            e.set_active_question(z, q)
+            e.record_answer(z, a)
+        orc.record_answer(q, a, cases.WORKERS - 1)
+        ts, tw = sh.list_top_targets(qs, 4), whole.list_top_targets(qw, 4)
+        assert [(t.i_target, t.prob) for t in ts] == [(t.i_target, t.prob) for t in tw]
+    # ResumeQuiz across shards (the answered questions' rows live on different shards), both settings of the :53 switch
+    aqs = list(orc.answers)
+    for bug in (1, 0):
+        sh.set_option("bug_compat", bug)
+        o2 = case.make_oracle()
+        assert o2.resume_quiz(aqs, cases.WORKERS, bool(bug)) == 0
+        q2 = sh.resume_quiz([interop.AnsweredQuestion(q, a) for q, a in aqs])
+        assert np.array_equal(sh.get_priors(q2), o2.priors())
+        _, opri = o2.eval(SUBTASKS)
+        pri = sh.eval_priorities(q2, case.Q)
+        assert ((opri == 0) == (pri == 0)).all() and cases.rel_err(pri[opri != 0], opri[opri != 0]).max() < PRIORITY_RTOL
+        sh.release_quiz(q2)
+    # training reaches every shard's rows and every vB replica
+    t0 = next(t for t in range(case.T) if t not in case.tgaps)
+    train = [(valid[0], 1), (valid[-1], 0), (valid[len(valid) // 2], 2), (valid[0], 1)]
+    sh.train([interop.AnsweredQuestion(q, a) for q, a in train], t0, 0.7)
+    orc.train(train, t0, 0.7, cases.WORKERS)
+    sh.record_quiz_target(qs, t0, 1.1)
+    orc.record_quiz_target(t0, 1.1)
+    A, D, B = sh.get_kb(case.Q)
+    assert np.array_equal(A, orc.A[:, :, : case.T]) and np.array_equal(D, orc.D[:, : case.T]) and np.array_equal(B, orc.B[: case.T])
+    q3 = sh.start_quiz()
+    orc.start_quiz(cases.WORKERS)
+    assert np.array_equal(sh.get_priors(q3), orc.priors())
+    # many quizzes at once: every shard sweeps the batch, the winners are merged per quiz
+    quizzes = [q3] + [sh.start_quiz() for _ in range(39)]
+    _, opri = orc.eval(SUBTASKS)
+    assert sh.next_question_argmax_batch(quizzes) == [orc.select_argmax(opri)] * 40
+    e = sh.save_kb("/tmp/never.kb", False, throw=False)
+    assert e is not None and "sharded engine" in e.to_string(True)
+    sh.close()
+    whole.close()
+
+
+def test_sharded_engine_exhausts_questions_like_the_whole_one(factory):
+    case = cases.small_cases()[0]        # 8 questions over 3 shards (3 + 3 + 2)
+    with devices("0,0,0"):
+        sh = case.make_engine(factory)
+    sh.set_option("select", 1)
+    quiz = sh.start_quiz()
+    asked = []
+    for _ in range(case.Q):
+        q = sh.next_question(quiz)
+        assert q not in asked
+        asked.append(q)
+        sh.record_answer(quiz, 0)
+    assert sorted(asked) == list(range(case.Q))
+    with pytest.raises(interop.PqaException, match="run out of questions"):
+        sh.next_question(quiz)
+    sh.close()
