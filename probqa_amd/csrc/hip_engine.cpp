@@ -204,11 +204,10 @@ Error HipEngine::Init(const CiEngineDefinition &def, const CiHipShard *shard) {
       {
         const double m = 1.0 + 0x1p-11, c = tbl[1];
         const double u = (1.0 - m) * c;
-        double sr = 1.0 - u;
-        sr = std::fma(-u, sr, 1.0);
-        sr = std::fma(-u, sr, 1.0);
-        const double t = u * sr, t3 = t * (t * t);
-        const double terms01 = std::fma(1.0 / 3, t3, t);
+        double pc = std::fma(u, -2.0, 4.0 / 3);
+        pc = std::fma(u, pc, -1.0);
+        pc = std::fma(u, pc, 1.0);
+        const double terms01 = u * pc;
         auto at1 = [&](double y0) { return std::fma(terms01, 2.8853900817779268147198493620038, y0) + 0.0; };
         double y0 = tbl[0];
         while (at1(y0) >= 0) y0 = std::nextafter(y0, 0.0);

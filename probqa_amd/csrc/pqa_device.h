@@ -85,10 +85,11 @@ __device__ __forceinline__ double2 row_load(RowRsrc rs, uint32_t byteOffset) {
 // reference's CPU code; each entry carries a second double, 1/(2m).
 // log2hot() follows the reference operation for operation -- exponent / mantissa split, bucket midpoint, t = (z-m)/(z+m),
 // the two explicit FMAs, + exponent -- except for how the quotient t is formed: the reference divides; here
-// z+m = 2m(1+u), u = (z-m)/(2m), so t = u/(1+u) = u - u^2 + u^3 - u^4 (next term u^5, |u| <= 2^-12: 2^-48 of t).
-// That is 6 fp64 operations instead of a 37-cycle exact division.  |t| <= 2^-12, so the truncation reaches the result
-// below 3e-18 absolute: the value is the reference's Log2Hot(x) except where that perturbation crosses a rounding
-// boundary of the last two operations (0.06 % of arguments, by one rounding unit; tools/log2hot_stats.py).  The host
+// z+m = 2m(1+u), u = (z-m)/(2m), so t = u/(1+u) = u - u^2 + u^3 - u^4 ..., and the series t + t^3/3 of :118 is evaluated as one
+// degree-4 polynomial in u (next term 3 u^5, |u| <= 2^-12): 4 fp64 operations instead of a 37-cycle exact division and three
+// more.  The truncation reaches the result below 8e-18 absolute: the value is the reference's Log2Hot(x) except where that
+// perturbation crosses a rounding boundary of the last two operations (a fraction of a percent of arguments, by one
+// rounding unit; tools/log2hot_stats.py).  The host
 // re-seats table entry 0 so that Log2Hot(1) stays negative under this arithmetic (hip_engine.cpp).  The priority vector
 // is compared at 1e-9 relative (measured 4e-14, set by the summation order -- DESIGN.md section 5), not bit for bit.
 // tbl: LDS copy of the table; it sits at LDS address 0 (first thing in the dynamic segment of kernels without static
@@ -116,13 +117,13 @@ __device__ __forceinline__ double log2hot(double x, const double *__restrict__ t
   const uint32_t mhi = (zhi & 0xFFFFFC00u) | 0x200u;           // bucket midpoint (:108): low 42 bits <- 100...0
   const double m = u2d((uint64_t)mhi << 32);
   const double u = (z - m) * yc.y;                             // z - m is exact (same binade, |z-m| < 2^-10)
-  double s = 1.0 - u;
-  s = fma(-u, s, 1.0);
-  s = fma(-u, s, 1.0);
-  const double t = u * s;                                      // :111-114
-  const double t2 = t * t;
-  const double t3 = t * t2;
-  const double terms01 = fma(1.0 / 3, t3, t);                  // :118
+  // :111-118 t = (z-m)/(z+m) = u/(1+u), terms01 = t + t^3/3 -- as ONE polynomial in u: with t = u - u^2 + u^3 - u^4 + ... and
+  // t^3 = u^3 - 3u^4 + ..., terms01 = u - u^2 + (4/3) u^3 - 2 u^4 (next term 3 u^5 <= 3 * 2^-60: 7.5e-18 on the result).
+  // Four operations for what the quotient (4) and the two-term series (3) took.
+  double c = fma(u, -2.0, 4.0 / 3);
+  c = fma(u, c, -1.0);
+  c = fma(u, c, 1.0);
+  const double terms01 = u * c;
   const double log2z = fma(terms01, 2.8853900817779268147198493620038, yc.x);  // :122
   return log2z + de;                                           // :131-133
 }
