@@ -243,20 +243,39 @@ __global__ __launch_bounds__(256) void eval_batch_kernel(BatchArgs a) {
           for (int k = 0; k < KG; k++) v[qi][k] = (R)0;
         }
         walk_targets<R>(pt + t0 * Bp, Bp, tcN, [&](int tc, R pi) __attribute__((always_inline)) {
+          // the target's tile values -- QB x (KG + 1) wave-uniform numbers -- are all requested before the first of them is used:
+          // behind the scheduling barrier of each question group they would be fetched group by group, an LDS round trip each
           const R *c = tile + (size_t)tc * QB * (KG + 1);
+          R cv[QB][KG + 1];
+#pragma unroll
+          for (int qi = 0; qi < QB; qi++)
+#pragma unroll
+            for (int k = 0; k <= KG; k++) cv[qi][k] = c[qi * (KG + 1) + k];
+          __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
           for (int qi = 0; qi < QB; qi++) {
-            const R id2 = c[qi * (KG + 1) + KG];
+            const R id2 = cv[qi][KG];
+            // one element: likelihood again (:81-82: cheaper than keeping it), posterior (:97), its log2 (:106), the entropy term
+            // weighted by W_k (:113-114, eval_epilogue), the velocity term (:119, :126-127); returns log2 for the lack term
+            auto element = [&](int k) __attribute__((always_inline)) {
+              const R lh = cv[qi][k] * pi;
+              const R p = lh * invW[qi][k];
+              const R l2 = Num<R>::log2p(p, tbl);
+              hW[qi] = fma(lh, l2, hW[qi]);
+              const R d = p - pi;
+              v[qi][k] = fma(d, d, v[qi][k]);
+              return l2;
+            };
+            // :117 lack += invD^2 / log2(p): two answers of the same question and target share invD^2, so they share ONE
+            // reciprocal -- 1/a + 1/b = (a + b) / (a b) -- the quarter-rate instruction of the pair (a b stays within
+            // [2e-15, 2e4] in fp32: the logarithms are clamped to [-127, -4e-8]; in fp64 within [1e-38, 1e6])
 #pragma unroll
-            for (int k = 0; k < KG; k++) {
-              if (EXACT || k < kN) {
-                const R lh = c[qi * (KG + 1) + k] * pi;          // the likelihood again (:81-82): cheaper than keeping it
-                const R p = lh * invW[qi][k];                    // :97
-                const R l2 = Num<R>::log2p(p, tbl);              // :106
-                hW[qi] = fma(lh, l2, hW[qi]);                    // :113-114 weighted by W_k (eval_epilogue)
-                accL[qi] = fma(id2, Num<R>::rcp(l2), accL[qi]);  // :117
-                const R d = p - pi;                              // :119
-                v[qi][k] = fma(d, d, v[qi][k]);                  // :126-127
+            for (int k = 0; k < KG; k += 2) {
+              if (k + 1 < KG && (EXACT || k + 1 < kN)) {
+                const R la = element(k), lb = element(k + 1);
+                accL[qi] = fma(id2 * (la + lb), Num<R>::rcp(la * lb), accL[qi]);
+              } else if (EXACT || k < kN) {
+                accL[qi] = fma(id2, Num<R>::rcp(element(k)), accL[qi]);
               }
             }
             __builtin_amdgcn_sched_barrier(0);   // one question's KG elements in flight at a time: enough independent chains to cover
