@@ -30,6 +30,8 @@
 //
 // No MFMA: a reduction with a table / transcendental inner function.  (Pass 1 alone is a contraction, but it is 1 of ~15
 // slots per element.)
+#include <algorithm>
+
 #include "eval_device.h"
 #include "pqa_device.h"
 #include "pqa_kernels.h"
@@ -345,36 +347,69 @@ __global__ __launch_bounds__(256) void batch_pick_kernel(const BatchRecord *__re
   }
 }
 
-// ---- single-quiz sweep for Float engines: one 256-thread workgroup per question, lanes over targets, pass 2 re-reads the
-// row (L2 / Infinity Cache).  The fp32 twin of eval_questions_f64_stream (eval_kernels.hip); Double engines have the
-// register-resident shapes there.
+// ---- single-quiz sweep for Float engines: one 256-thread workgroup per question, lanes over targets (16 bytes per lane and
+// load), the answer row read again by pass 2 (from L2: a row is 4 T bytes).  LDSROW (rows of up to kF32LdsTargets targets): the
+// masked prior, converted to fp32 once per workgroup, and the question's 1/D, computed once per question (v_rcp_f32 + one
+// Newton step: 2^-22.5 -> full fp32 precision), live in LDS; longer rows recompute both per element.  The fp32 twin of the
+// streaming form of eval_kernels.hip -- Double engines have the register-resident shapes there; the Float configuration the
+// work went into is the batched one above (BASELINE configs[4]).
+constexpr int kF32LdsTargets = 16384;
 __device__ __forceinline__ float wave_sum_f(float v) {
 #pragma unroll
   for (int m = kWave / 2; m >= 1; m >>= 1) v += __shfl_xor(v, m, kWave);
   return v;
 }
+__device__ __forceinline__ float rcp_f32_nr(float x) {
+  const float r = __builtin_amdgcn_rcpf(x);
+  return fmaf(r, fmaf(-x, r, 1.0f), r);
+}
+template <bool LDSROW>
 __global__ __launch_bounds__(256) void eval_questions_f32_stream(const float *__restrict__ cube, const double *__restrict__ prior,
                                                                  const uint32_t *__restrict__ tgap, const uint32_t *__restrict__ qgap,
                                                                  const uint32_t *__restrict__ asked, double *__restrict__ priority,
                                                                  int64_t K, int64_t Q, int64_t ldT, double vCompTail) {
-  extern __shared__ double smem[];      // W_k [K] | W_k sqrt(V_k) [K] | partials [WPQ][4]
+  extern __shared__ double smem[];      // W_k [K] | W_k sqrt(V_k) [K] | partials [16 floats] | LDSROW: prior [ldT] | 1/D [ldT] (floats)
   double *wk = smem, *wv = smem + K;
   float *part = reinterpret_cast<float *>(smem + 2 * K);
+  float4 *prL = reinterpret_cast<float4 *>(part + 16), *idL = prL + (ldT >> 2);
   const int tid = threadIdx.x, lane = tid % kWave, wave = tid / kWave;
+  const int64_t nQuads = ldT >> 2;      // ldT is a multiple of 32 floats
+  auto prior4 = [&](int64_t i) __attribute__((always_inline)) {   // masked prior of targets 4i .. 4i+3 (:103)
+    const uint32_t g = tgap[i >> 3] >> ((4 * i) & 31);
+    const double2 a = reinterpret_cast<const double2 *>(prior)[2 * i], b = reinterpret_cast<const double2 *>(prior)[2 * i + 1];
+    return make_float4((g & 1) ? 0.f : (float)a.x, (g & 2) ? 0.f : (float)a.y, (g & 4) ? 0.f : (float)b.x, (g & 8) ? 0.f : (float)b.y);
+  };
+  auto invd4 = [&](const float4 *rowD, int64_t i) __attribute__((always_inline)) {   // masked 1/D (:74)
+    const uint32_t g = tgap[i >> 3] >> ((4 * i) & 31);
+    const float4 d = rowD[i];
+    return make_float4((g & 1) ? 0.f : rcp_f32_nr(d.x), (g & 2) ? 0.f : rcp_f32_nr(d.y), (g & 4) ? 0.f : rcp_f32_nr(d.z),
+                       (g & 8) ? 0.f : rcp_f32_nr(d.w));
+  };
+  if constexpr (LDSROW)
+    for (int64_t i = tid; i < nQuads; i += 256) prL[i] = prior4(i);
   for (int64_t q = blockIdx.x; q < Q; q += gridDim.x) {
     if (bit_test(qgap, q) || bit_test(asked, q)) {
       if (tid == 0) priority[q] = 0.0;
       continue;
     }
-    const float *qb = cube + q * (K + 1) * ldT, *rowD = qb + K * ldT;
+    const float *qb = cube + q * (K + 1) * ldT;
+    const float4 *rowD = reinterpret_cast<const float4 *>(qb + K * ldT);
+    __syncthreads();                                          // the previous question is done with the LDS rows
+    if constexpr (LDSROW)
+      for (int64_t i = tid; i < nQuads; i += 256) idL[i] = invd4(rowD, i);
+    __syncthreads();
     double hWd = 0.0, accLd = 0.0;
     for (int64_t k = 0; k < K; k++) {
-      const float *rowA = qb + k * ldT;
+      const float4 *rowA = reinterpret_cast<const float4 *>(qb + k * ldT);
       float s = 0.f;
-      for (int64_t t = tid; t < ldT; t += 256) {
-        const bool g = bit_test(tgap, t);
-        const float invD = g ? 0.f : 1.0f / rowD[t];
-        s += (rowA[t] * invD) * (g ? 0.f : (float)prior[t]);
+      for (int64_t i = tid; i < nQuads; i += 256) {
+        const float4 a = rowA[i];
+        float4 id, pr;
+        if constexpr (LDSROW) { id = idL[i]; pr = prL[i]; } else { id = invd4(rowD, i); pr = prior4(i); }
+        s += (a.x * id.x) * pr.x;                              // :81-82
+        s += (a.y * id.y) * pr.y;
+        s += (a.z * id.z) * pr.z;
+        s += (a.w * id.w) * pr.w;
       }
       s = wave_sum_f(s);
       __syncthreads();                                        // the previous answer's partials have been read
@@ -383,17 +418,24 @@ __global__ __launch_bounds__(256) void eval_questions_f32_stream(const float *__
       const float Wk = (part[0] + part[1]) + (part[2] + part[3]);
       const float invWk = 1.0f / Wk;
       float v = 0.f, hW = 0.f, accL = 0.f;
-      for (int64_t t = tid; t < ldT; t += 256) {
-        const bool g = bit_test(tgap, t);
-        const float invD = g ? 0.f : 1.0f / rowD[t];
-        const float pi = g ? 0.f : (float)prior[t];
-        const float lh = (rowA[t] * invD) * pi;
-        const float p = lh * invWk;
-        const float l2 = Num<float>::log2p(p, nullptr);
-        hW = fmaf(lh, l2, hW);
-        accL = fmaf(invD * invD, Num<float>::rcp(l2), accL);
-        const float d = p - pi;
+      auto element = [&](float a, float id, float pi) __attribute__((always_inline)) {
+        const float lh = (a * id) * pi;
+        const float p = lh * invWk;                            // :97
+        const float l2 = Num<float>::log2p(p, nullptr);        // :106
+        hW = fmaf(lh, l2, hW);                                 // :113-114 weighted by W_k
+        const float d = p - pi;                                // :119
         v = fmaf(d, d, v);
+        return l2;
+      };
+      for (int64_t i = tid; i < nQuads; i += 256) {
+        const float4 a = rowA[i];
+        float4 id, pr;
+        if constexpr (LDSROW) { id = idL[i]; pr = prL[i]; } else { id = invd4(rowD, i); pr = prior4(i); }
+        // :117 lack += invD^2 / log2 p, two targets per reciprocal: (ix^2 lb + iy^2 la) / (la lb)
+        const float la = element(a.x, id.x, pr.x), lb = element(a.y, id.y, pr.y);
+        accL = fmaf(fmaf(id.x * id.x, lb, (id.y * id.y) * la), Num<float>::rcp(la * lb), accL);
+        const float lc = element(a.z, id.z, pr.z), ld = element(a.w, id.w, pr.w);
+        accL = fmaf(fmaf(id.z * id.z, ld, (id.w * id.w) * lc), Num<float>::rcp(lc * ld), accL);
       }
       v = wave_sum_f(v);
       hW = wave_sum_f(hW);
@@ -410,7 +452,6 @@ __global__ __launch_bounds__(256) void eval_questions_f32_stream(const float *__
     }
     __syncthreads();
     if (tid == 0) priority[q] = eval_epilogue(wk, -hWd, wv, K, accLd, vCompTail);
-    __syncthreads();
   }
 }
 
@@ -500,11 +541,26 @@ hipError_t LaunchEvalQuestionsF32(const KbView &kb, const double *prior, const u
   if (kb.elem != 4) return hipErrorInvalidValue;
   const double nT = (double)(kb.nValidTargets + 1);
   const double vCompTail = 0.34657359027997265470861606072909 / (nT * nT);
-  int64_t grid = kb.Q < 2048 ? kb.Q : 2048;
+  const bool ldsRow = kb.ldT <= kF32LdsTargets;
+  size_t shmem = (size_t)(2 * kb.K + 8) * sizeof(double) + (ldsRow ? (size_t)kb.ldT * 8 : 0);
+  static bool attrSet = false;
+  if (ldsRow && shmem > 64 * 1024 && !attrSet) {
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(eval_questions_f32_stream<true>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
+    if (e != hipSuccess) return e;
+    attrSet = true;
+  }
+  int dev = 0, nCU = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&nCU, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || nCU <= 0) nCU = 256;
+  const int perCU = ldsRow ? (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / shmem)) : 8;
+  int64_t grid = std::min<int64_t>(kb.Q, (int64_t)nCU * perCU);
   if (kb.maxGrid > 0 && grid > kb.maxGrid) grid = kb.maxGrid;
-  const size_t shmem = (size_t)(2 * kb.K + 8) * sizeof(double);
-  hipLaunchKernelGGL(eval_questions_f32_stream, dim3((unsigned)grid), dim3(256), shmem, stream, static_cast<const float *>(kb.cube), prior,
-                     kb.tgap, kb.qgap, asked, priority, kb.K, kb.Q, kb.ldT, vCompTail);
+  if (ldsRow)
+    hipLaunchKernelGGL(eval_questions_f32_stream<true>, dim3((unsigned)grid), dim3(256), shmem, stream, static_cast<const float *>(kb.cube),
+                       prior, kb.tgap, kb.qgap, asked, priority, kb.K, kb.Q, kb.ldT, vCompTail);
+  else
+    hipLaunchKernelGGL(eval_questions_f32_stream<false>, dim3((unsigned)grid), dim3(256), shmem, stream, static_cast<const float *>(kb.cube),
+                       prior, kb.tgap, kb.qgap, asked, priority, kb.K, kb.Q, kb.ldT, vCompTail);
   return hipGetLastError();
 }
 
