@@ -522,18 +522,7 @@ def run_batched(args, cfg, np, torch, interop, pdist, world, rank, local_rank, d
         if world == 1:
             return eng.next_question_argmax_batch(quizzes)
         mine = torch.from_numpy(eng.select_argmax_batch(quizzes)).to(device)          # [B, 2] (priority, global index)
-        allw = torch.empty((world, B, 2), dtype=torch.float64, device=device)
-        dist.all_gather_into_tensor(allw, mine)
-        allw = allw.cpu().numpy()
-        picks = []
-        for b in range(B):
-            best, bp = -1, 0.0
-            for r in range(world):
-                p, qi = allw[r, b]
-                if qi >= 0 and (best < 0 or p > bp or (p == bp and qi < best)):
-                    best, bp = int(qi), p
-            picks.append(best)
-        return picks
+        return pdist.select_batch(mine)
 
     def barrier():
         torch.cuda.synchronize()

@@ -53,6 +53,38 @@ def pick_global(records) -> Tuple[float, int]:
     return best_p, best_i
 
 
+def pick_batch(all_winners) -> List[int]:
+    """all_winners: [world, B, 2] float64 (priority, GLOBAL question index as a float, -1 = none), the ranks' per-quiz winners of
+    one batched sweep (PqaHip_SelectArgmaxBatch), gathered.  Returns the B global picks: maximum priority, lowest index on ties,
+    NaN never wins, -1 where no shard had an eligible question."""
+    arr = all_winners.cpu().numpy() if isinstance(all_winners, torch.Tensor) else all_winners
+    world, n_quizzes = arr.shape[0], arr.shape[1]
+    picks = []
+    for b in range(n_quizzes):
+        best, best_p = -1, 0.0
+        for r in range(world):
+            p, qi = float(arr[r, b, 0]), int(arr[r, b, 1])
+            if qi < 0:
+                continue
+            if p != p:
+                p = float("-inf")
+            if best < 0 or p > best_p or (p == best_p and qi < best):
+                best, best_p = qi, p
+        picks.append(best)
+    return picks
+
+
+def select_batch(local_winners: torch.Tensor, group: Optional[dist.ProcessGroup] = None) -> List[int]:
+    """One batched selection over the shards: local_winners [B, 2] of this rank (device tensor under RCCL, CPU tensor under
+    gloo) -> one all-gather of 16 B x B per rank -> the same B picks on every rank."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world == 1:
+        return pick_batch(local_winners.unsqueeze(0))
+    parts = [torch.empty_like(local_winners) for _ in range(world)]
+    dist.all_gather(parts, local_winners.contiguous(), group=group)   # (the list form: RCCL and gloo both have it)
+    return pick_batch(torch.stack(parts))
+
+
 class ShardedSelector:
     """Global next-question selection over question shards.
 

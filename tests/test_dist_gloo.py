@@ -134,3 +134,62 @@ def test_pick_when_all_host_half_of_the_shm_exchange():
     struct.pack_into("<dq", buf, 1 * slot, 0.0, -1)
     struct.pack_into("<dq", buf, 0 * slot, 0.0, -1)
     assert interop.pick_when_all(base, world, slot, 17, 1.0)[1] == 3   # only the NaN shard is left: it still has a question
+
+
+def test_pick_batch_ties_nan_and_empty():
+    allw = np.zeros((3, 4, 2))
+    allw[:, :, 1] = -1
+    allw[0, 0], allw[1, 0], allw[2, 0] = (1.0, 5), (3.0, 9), (2.0, 1)            # plain maximum
+    allw[0, 1], allw[1, 1] = (3.0, 9), (3.0, 4)                                   # tie -> lowest index
+    allw[0, 2], allw[2, 2] = (float("nan"), 2), (1.0, 7)                          # NaN never wins
+    assert pdist.pick_batch(allw) == [9, 4, 7, -1]                                # last quiz: no shard has a question
+
+
+def _batch_worker(rank, world, port, ret):
+    """BASELINE configs[4]'s N > 1 path (bench.py run_batched): every rank sweeps ITS shard for all B quizzes, the per-quiz
+    winners meet in one all-gather, every rank makes the same picks -- the single-process oracle's argmaxes."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import cases
+    import orclib
+
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    case = cases.Case("distb", 5, 47, 70, seed=78, qgaps=[11], answers=[])
+    A, D, B = case.kb()
+    q0, q1 = pdist.shard_range(case.Q, world, rank)
+    n_quizzes = 6
+    histories = [[((7 * i + 3 * j) % case.Q, (i + j) % case.K) for j in range(i % 3)] for i in range(n_quizzes)]
+    histories = [[(q, a) for q, a in h if q != 11] for h in histories]
+    mine, want = np.zeros((n_quizzes, 2)), []
+    for b, hist in enumerate(histories):
+        full = case.make_oracle()
+        full.start_quiz(16)
+        for q, a in hist:
+            full.record_answer(q, a, 15)
+        _, fpri = full.eval(8)
+        want.append(full.select_argmax(fpri))
+        shard = orclib.Oracle(case.K, q1 - q0, case.T, case.init)      # the rank's shard with the SAME posterior and asked bits
+        shard.set_kb(A[q0:q1], D[q0:q1], B)
+        shard.set_question_gaps([q - q0 for q in case.qgaps if q0 <= q < q1])
+        shard.start_quiz(16)
+        shard.mants[: case.T] = full.priors()
+        asked = np.ctypeslib.as_array(shard.quiz.contents.asked, shape=((q1 - q0 + 7) // 8,))
+        for q, _ in hist:
+            if q0 <= q < q1:
+                asked[(q - q0) >> 3] |= 1 << ((q - q0) & 7)
+        _, pri = shard.eval(8)
+        i = shard.select_argmax(pri)
+        mine[b] = (pri[i], i + q0) if i >= 0 else (0.0, -1)
+    picks = pdist.select_batch(torch.from_numpy(mine))
+    assert picks == want, (rank, picks, want)
+    ret[rank] = picks
+    dist.destroy_process_group()
+
+
+def test_two_rank_batched_selection_matches_single_process():
+    world, port = 2, _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_batch_worker, args=(world, port, ret), nprocs=world, join=True)
+    assert ret[0] == ret[1] and len(ret[0]) == 6
