@@ -19,14 +19,17 @@ from probqa_amd import interop, synth
 pytestmark = pytest.mark.gpu
 
 PRIORITY_RTOL = 1e-9
-# fp32 sweep vs fp64 oracle on the same (rounded) cube: F32_RTOL + F32_COND / |log2 pmax(question)|, pmax = the largest posterior
-# element the question's answers can produce (f32_tolerance below).  An fp32 posterior element carries ~1.2e-7 of relative
-# error (likelihood and 1/W_k rounded once each); the priority amplifies it twice: the velocity sum of (posterior - prior)^2
-# cancels where an answer barely moves the posterior, and vComp^9 = (ln sqrt2 - ln avgV + ..)^-9 multiplies the relative error
-# of avgV by 9 vComp -- that is F32_RTOL, measured up to 3e-3 on the fixtures; and the lack sum -sum invD^2 / log2 p turns it
-# into 1.7e-7 / |log2 p| relative on a term -- the second summand.  Measured maxima are printed by the tests.
-F32_RTOL = 5e-3
-F32_COND = 1e-6
+# fp32 sweep vs fp64 oracle on the same (rounded) cube.  An fp32 likelihood / posterior element carries 2^-23..2^-22 of relative
+# rounding error, and how much of it reaches a priority is a property of the QUESTION AND QUIZ STATE, not of the kernel: the
+# velocity sum of (posterior - prior)^2 cancels where an answer barely moves the posterior, vComp^9 = (ln sqrt2 - ln avgV + ..)^-9
+# multiplies avgV's relative error by 9 vComp, the lack sum -sum invD^2 / log2 p has a pole at p -> 1.  The stated tolerance
+# therefore is, per question,
+#     F32_RTOL  +  F32_AMPLIFY x (relative change of the fp64 priority when every likelihood, and every answer row's 1/W_k, is
+#                                  perturbed by 2^-23 relative)
+# with the second term measured numerically (f32_tolerance: the priority formula of CEEvalQsSubtaskConsider.cpp:62-207 in numpy
+# fp64, four random perturbations).  The tests print the measured maxima as fractions of this bound.
+F32_RTOL = 5e-4
+F32_AMPLIFY = 6.0
 
 
 def scripted_quizzes(case, eng, n_quizzes, rng):
@@ -53,16 +56,45 @@ def oracle_priorities(orc, hist):
     return pri, orc.priors()
 
 
-def f32_tolerance(orc, case):
-    """Per-question tolerance of an fp32 sweep for the oracle's CURRENT quiz state (see F32_RTOL / F32_COND)."""
-    T = case.T
-    prior = orc.priors()
-    like = orc.A[:, :, :T] / orc.D[:, None, :T] * prior[None, None, :]
-    for t in case.tgaps:
-        like[:, :, t] = 0
+def np_priorities(like, inv_d2, prior, n_valid, post_scale=None):
+    """priority[q] from likelihoods like[q,k,t] (0 at gaps), invD^2[q,t] (0 at gaps), masked prior[t]: the formula of
+    CEEvalQsSubtaskConsider.cpp:62-207 in numpy fp64 (library log2; gap / zero elements contribute nothing)."""
     w = like.sum(axis=2, keepdims=True)
-    pmax = np.minimum((like / np.where(w > 0, w, 1)).max(axis=(1, 2)), 1 - 2.0 ** -25)
-    return F32_RTOL + F32_COND / np.abs(np.log2(pmax))
+    post = like / np.where(w > 0, w, 1)
+    if post_scale is not None:
+        post = post * post_scale                                        # a rounded 1/W_k moves a whole answer row together
+    with np.errstate(divide="ignore", invalid="ignore"):
+        l2 = np.where(post > 0, np.log2(np.where(post > 0, post, 1)), -1023.0)
+        l2 = np.minimum(l2, -1e-19)                                     # Log2Hot(1) is (just) negative
+        h = -(post * l2).sum(axis=2)                                      # [Q, K]
+        lack = -(inv_d2[:, None, :] / l2).sum(axis=(1, 2))
+    v = np.sqrt(((post - prior[None, None, :]) ** 2).sum(axis=2))
+    wk = w[:, :, 0]
+    tot = np.maximum(wk.sum(axis=1), 1e-300)
+    avg_h, avg_v = (wk * h).sum(axis=1) / tot, (wk * v).sum(axis=1) / tot
+    ln_sqrt2 = 0.34657359027997264
+    vcomp = 1.0 / (ln_sqrt2 - np.log(np.maximum(avg_v, 1e-300)) + ln_sqrt2 / (n_valid + 1) ** 2)
+    return lack * vcomp ** 9 / np.exp2(avg_h) ** 2
+
+
+def f32_tolerance(orc, case):
+    """Per-question tolerance of an fp32 sweep for the oracle's CURRENT quiz state (see F32_RTOL / F32_AMPLIFY)."""
+    T = case.T
+    prior = orc.priors().copy()
+    inv_d = 1.0 / orc.D[:, :T]
+    for t in case.tgaps:
+        prior[t] = 0
+        inv_d[:, t] = 0
+    like = orc.A[:, :, :T] * inv_d[:, None, :] * prior[None, None, :]
+    n_valid = T - len(case.tgaps)
+    base = np_priorities(like, inv_d ** 2, prior, n_valid)
+    rng = np.random.default_rng(12345)
+    dev = np.zeros_like(base)
+    for _ in range(4):
+        noisy = like * (1 + 2.0 ** -23 * rng.uniform(-1, 1, size=like.shape))
+        scale = 1 + 2.0 ** -23 * rng.uniform(-1, 1, size=like.shape[:2] + (1,))
+        dev = np.maximum(dev, np.abs(np_priorities(noisy, inv_d ** 2, prior, n_valid, scale) - base) / np.maximum(np.abs(base), 1e-300))
+    return F32_RTOL + F32_AMPLIFY * dev
 
 
 def rel_vec(pri, opri):

@@ -45,3 +45,51 @@ def test_random_case(i, factory):
         options.append(("server", 1))
     worst = max(run_script(case, factory, options))
     assert worst < 1e-9, (case.name, worst)
+
+
+@pytest.mark.parametrize("i", range(48))
+def test_random_case_batched(i, factory):
+    """The same random cases through the row-sharing batched sweep: 1..130 quizzes in different states (prefixes of the case's
+    answer script), Double engines (even i, bar 1e-9) and Float engines (odd i, the stated fp32 tolerance), random LDS tile."""
+    import orclib
+    import test_gpu_batch as tb
+
+    case = random_case(i)
+    rng = np.random.default_rng(5000 + i)
+    if i % 2 == 0:
+        eng, orc = case.make_engine(factory), case.make_oracle()
+    else:
+        eng, orc = tb.float_engine(case, factory)
+    eng.set_option("batch_min", 1)
+    eng.set_option("batch_tile", int(rng.choice([0, 64, 128])))
+    eng.set_option("batch_qb", int(rng.choice([0, 1, 2])))
+    n = int(rng.integers(1, 131))
+    quizzes, hists = [], []
+    for j in range(n):
+        quiz = eng.start_quiz()
+        hist = case.answers[: j % (len(case.answers) + 1)]
+        for q, a in hist:
+            eng.set_active_question(quiz, q)
+            eng.record_answer(quiz, a)
+        quizzes.append(quiz)
+        hists.append(hist)
+    pri = eng.eval_priorities_batch(quizzes, case.Q)
+    picks = eng.next_question_argmax_batch(quizzes)
+    seen = {}
+    for j in range(n):
+        key = len(hists[j])
+        if key not in seen:            # the oracle once per distinct state
+            opri, opriors = tb.oracle_priorities(orc, hists[j])
+            tol = 1e-9 if i % 2 == 0 else tb.f32_tolerance(orc, case)
+            seen[key] = (opri, opriors, tol, orc.select_argmax(opri))
+        opri, opriors, tol, want = seen[key]
+        assert np.array_equal(eng.get_priors(quizzes[j]), opriors)
+        rel = tb.rel_vec(pri[j], opri)
+        assert (rel < tol).all(), (case.name, j, float(rel.max()))
+        top = np.sort(opri)[::-1]
+        margin = (top[0] - top[1]) / top[0] if len(top) > 1 and top[0] > 0 else 1.0
+        if want < 0:
+            assert picks[j] == -1
+        elif margin > 10 * np.max(tol):
+            assert picks[j] == want, (case.name, j)
+    eng.close()
