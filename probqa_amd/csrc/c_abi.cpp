@@ -67,6 +67,28 @@ char *DupString(const std::string &s) {
     return retVal;                                                                  \
   }
 
+// PQA_DEVICES=i[,j,...]: empty when unset or malformed (a malformed value is reported and ignored)
+std::vector<int> DevicesFromEnvironment() {
+  std::vector<int> devices;
+  const char *v = std::getenv("PQA_DEVICES");
+  if (!v) return devices;
+  const char *p = v;
+  bool ok = *p != 0;
+  while (ok && *p) {
+    char *end = nullptr;
+    const long d = std::strtol(p, &end, 10);
+    if (end == p || d < 0 || d > 1023) { ok = false; break; }
+    devices.push_back((int)d);
+    p = end;
+    if (*p == ',') p++; else if (*p != 0) ok = false;
+  }
+  if (!ok) {
+    if (*v) std::fprintf(stderr, "PqaCore: ignoring PQA_DEVICES=%s (expected a comma-separated list of device ordinals)\n", v);
+    devices.clear();
+  }
+  return devices;
+}
+
 void *CreateEngine(void *pvFactory, void **ppError, const CiEngineDefinition *pEngDef, const CiHipShard *pShard) {
   if (pvFactory == nullptr) {  // PqaCInterop.cpp:93-98
     if (ppError) *ppError = new Error(Error::Make(ErrCode::NullArgument, "Nullptr is passed in place of IPqaEngineFactory."));
@@ -80,24 +102,7 @@ void *CreateEngine(void *pvFactory, void **ppError, const CiEngineDefinition *pE
   // PQA_DEVICES=i[,j,...] (unchanged wrappers cannot name a device): one ordinal = that device; several = one shard of
   // the question axis per listed device (an ordinal may repeat: several shards on one device), behind this one engine handle
   std::vector<int> devices;
-  if (pShard == nullptr) {
-    if (const char *v = std::getenv("PQA_DEVICES")) {
-      const char *p = v;
-      bool ok = *p != 0;
-      while (ok && *p) {
-        char *end = nullptr;
-        const long d = std::strtol(p, &end, 10);
-        if (end == p || d < 0 || d > 1023) { ok = false; break; }
-        devices.push_back((int)d);
-        p = end;
-        if (*p == ',') p++; else if (*p != 0) ok = false;
-      }
-      if (!ok) {
-        if (*v) std::fprintf(stderr, "PqaCore: ignoring PQA_DEVICES=%s (expected a comma-separated list of device ordinals)\n", v);
-        devices.clear();
-      }
-    }
-  }
+  if (pShard == nullptr) devices = DevicesFromEnvironment();
   pqa::IEngine *eng = nullptr;
   if (devices.size() >= 2) {
     eng = pqa::CreateShardedEngine(err, *pEngDef, devices);
@@ -150,6 +155,19 @@ PQACORE_API void *PqaEngineFactory_LoadCpuEngine(void *pvFactory, void **ppError
     return nullptr;
   }
   Error err;
+  const std::vector<int> devices = DevicesFromEnvironment();
+  if (devices.size() >= 2) {
+    err = Error::MakeP(ErrCode::NotImplemented, "Feature=LoadCpuEngine over several devices (PQA_DEVICES)",
+                       "A .kb file is loaded into one device; create the sharded engine and fill it through PqaHip_SetKB or training.");
+    AssignErr(ppError, err);
+    return nullptr;
+  }
+  if (devices.size() == 1 && hipSetDevice(devices[0]) != hipSuccess) {
+    (void)hipGetLastError();
+    err = Error::MakeP(ErrCode::IndexOutOfRange, "device=" + std::to_string(devices[0]), "No such HIP device (PQA_DEVICES).");
+    AssignErr(ppError, err);
+    return nullptr;
+  }
   HipEngine *eng = HipEngine::Load(err, filePath);
   AssignErr(ppError, err);
   return eng;

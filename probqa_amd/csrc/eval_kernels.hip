@@ -564,6 +564,24 @@ __device__ __forceinline__ void sweep_body(EvalArgs a, bool copyTable) {
       // sure they all have); the Log2Hot table's LDS holds the subtask totals
       __syncthreads();
       const bool complete = *allReported;
+      if (a.fs.hostPriority != nullptr) {
+        // every workgroup's priorities are in device memory (write-through stores, acknowledged before its record): one round
+        // of loads past the non-coherent cache levels, one coalesced burst to the host, then the flag
+        const int64_t n = a.qLimit - a.qFirst;
+        for (int64_t i = tid; i < n; i += kThreads)
+          a.fs.hostPriority[i] = __hip_atomic_load(a.priority + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");            // system scope: this thread's part of the vector is out
+        __syncthreads();
+        if (tid == 0) {
+          a.fs.out->priority = 0.0;
+          a.fs.out->index = complete ? 0 : -3;
+          if (a.fs.seq != nullptr) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+            __hip_atomic_store(a.fs.seq, a.fs.flagValue, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          }
+        }
+        return;
+      }
       const SampledPick r = select_sampled_wg_lds<true>(a.priority, a.qgap, a.asked, a.qFirst, a.qLimit - a.qFirst,
                                                         a.fs.sampleSubtasks, a.fs.sampleRnd, tbl);
       if (tid == 0) {
@@ -1012,7 +1030,7 @@ static EvalArgs make_args(const KbView &kb, int64_t qFirst, int64_t qLimit) {
   args.qLimit = qLimit;
   const double nT = (double)(kb.nValidTargets + 1);  // PqaCore/CEEvalQsSubtaskConsider.cpp:191
   args.vCompTail = 0.34657359027997265470861606072909 / (nT * nT);
-  args.fs = FusedSelect{nullptr, nullptr, nullptr, 0, 0, 0, 0, nullptr, 0, 0, nullptr};
+  args.fs = FusedSelect{nullptr, nullptr, nullptr, 0, 0, 0, 0, nullptr, 0, 0, nullptr, nullptr};
   args.slots = nullptr;
   args.maxGrid = kb.maxGrid;
   return args;
@@ -1088,6 +1106,7 @@ static int server_variant(const KbView &kb, int variant) {
 bool EvalVariantFusesSampled(const KbView &kb, int variant, int64_t nSubtasks) {   // a register shape, and the selection's LDS fits
   return pick_variant(kb.ldT, variant) != 99 && select_sampled_lds_doubles(kb.Q, nSubtasks) <= kLog2TableDoubles;
 }
+bool EvalVariantHasFinisherWorkgroup(const KbView &kb, int variant) { return pick_variant(kb.ldT, variant) != 99; }   // a register shape
 bool EvalServerSupported(const KbView &kb, int variant) { return server_variant(kb, variant) != 0; }
 
 hipError_t LaunchEvalServer(const KbView &kb, int64_t qFirst, int64_t qLimit, double *priority, int variant,

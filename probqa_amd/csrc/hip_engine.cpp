@@ -305,6 +305,7 @@ HipEngine::~HipEngine() {
   hipFree(_dGraphScratch); hipFree(_dTagCell);
   if (_hBatch) hipHostFree(_hBatch); hipFree(_dTGap); hipFree(_dQGap); hipFree(_dAqs); hipFree(_dTop);
   if (_hPinned) hipHostFree(_hPinned);
+  if (_hHostPriority) hipHostFree(_hHostPriority);
   if (_ownStream) hipStreamDestroy(_ownStream);
 }
 
@@ -343,6 +344,7 @@ Error HipEngine::SetOption(const char *name, int64_t value) {
   else if (n == "server") { if (!value) StopServer(); _optServer = value ? 1 : 0; }
   else if (n == "eval_max_grid") { if (value < 0 || value > 65535) goto bad; StopServer(); _optEvalMaxGrid = value; _kbVersion++; }
   else if (n == "fused_sampled") { _optFusedSampled = value ? 1 : 0; }
+  else if (n == "host_sampled") { _optHostSampled = value ? 1 : 0; }
   else if (n == "batch_min") { if (value < 0 || value > 257) goto bad; _optBatchMin = value; }
   else if (n == "batch_qb") { if (value < 0 || value > 4) goto bad; _optBatchQb = value; }
   else if (n == "batch_tile") { if (value < 0 || value > 8192) goto bad; _optBatchTile = value; }
@@ -367,6 +369,7 @@ int64_t HipEngine::GetOption(const char *name) const {
   if (n == "server") return _optServer;
   if (n == "server_idle_us") return _optServerIdleUs;
   if (n == "fused_sampled") return _optFusedSampled;
+  if (n == "host_sampled") return _optHostSampled;
   if (n == "batch_min") return _optBatchMin;
   if (n == "batch_tile") return _optBatchTile;
   if (n == "batch_qb") return _optBatchQb;
@@ -665,6 +668,40 @@ int64_t FindNearestInPacks(int64_t iMiddle, int64_t nQuestions, const std::funct
   return -1;
 }
 
+// The reference's selector (PqaCore/CpuEngine.cpp:362-400) on the host, over a priority vector the sweep has delivered: the same
+// per-subtask Kahan run lengths (CEEvalQsSubtaskConsider.cpp:52-58, :212-214), Kahan grand totals and two upper_bounds as
+// select_sampled_wg_impl (pqa_device.h) -- operation for operation, so with the same priorities, subtask count and random number it
+// picks the same question.  run: priorities in, run lengths out.  Returns the pick before the gap / asked fallback (:403-407).
+int64_t SelectSampledHost(double *run, int64_t n, int64_t nWorkers, uint64_t rnd, const std::function<bool(int64_t)> &skipped) {
+  struct Kahan {                 // SRAccumulator<SRDoubleNumber> (SRPlatform/Interface/SRAccumulator.h:15-39)
+    double sum = 0, corr = 0;
+    void add(double v) { const double y = v - corr; const double t = sum + y; corr = (t - sum) - y; sum = t; }
+    double get() const { return sum - corr; }
+  };
+  const int64_t quot = n / nWorkers, rem = n % nWorkers, nSubtasks = quot == 0 ? rem : nWorkers;   // SRPoolRunner::CalcSplit
+  auto bound = [&](int64_t i) { return (i + 1) * quot + std::min<int64_t>(i + 1, rem); };           // end of subtask i
+  std::vector<double> grand((size_t)nSubtasks);
+  for (int64_t s = 0; s < nSubtasks; s++) {
+    Kahan acc;
+    for (int64_t i = s == 0 ? 0 : bound(s - 1); i < bound(s); i++) {
+      if (!skipped(i)) acc.add(run[i]);   // gap / asked questions only copy the running sum
+      run[i] = acc.get();
+    }
+    grand[(size_t)s] = acc.get();
+  }
+  Kahan tot;                                                     // CpuEngine.cpp:362-368
+  for (int64_t s = 0; s < nSubtasks; s++) { tot.add(grand[(size_t)s]); grand[(size_t)s] = tot.get(); }
+  const double totG = grand[(size_t)nSubtasks - 1];
+  const double selRunLen = totG * (double)rnd / 18446744073709551615.0;   // :379, SRDoubleNumber::MakeRandom
+  const int64_t iWorker = std::upper_bound(grand.begin(), grand.end(), selRunLen) - grand.begin();   // :380-381
+  if (iWorker >= nSubtasks) return n - 1;                         // :384
+  const double inWorker = selRunLen - (iWorker == 0 ? 0.0 : grand[(size_t)iWorker - 1]);   // :388
+  const int64_t first = iWorker == 0 ? 0 : bound(iWorker - 1), limit = bound(iWorker);
+  int64_t sel = std::upper_bound(run + first, run + limit, inWorker) - run;   // :391
+  if (sel >= limit) sel = limit - 1;                              // :392-400
+  return sel;
+}
+
 int64_t HipEngine::FindNearestQuestion(int64_t iMiddle, const Quiz *q) const {   // (over the local question range)
   return FindNearestInPacks(iMiddle, _Q, [&](int64_t p) { return ~(Pack64(_hQGap, p) | Pack64(q->hAsked, p)); });
 }
@@ -724,7 +761,7 @@ Error HipEngine::EnqueueSelectArgmax(int64_t iQuiz, void *pOut) {
   Quiz *q = UseQuiz(err, iQuiz);
   if (!q) return err;
   // one launch: the sweep's last workgroup picks the argmax; reported index = local position + qFirst (GLOBAL id)
-  const FusedSelect fs{_dSelScratch, pOut ? (SelectResult *)pOut : _dSel, nullptr, NextLaunchTag(), _qFirst, 0, 0, nullptr, 0, 0, nullptr};
+  const FusedSelect fs{_dSelScratch, pOut ? (SelectResult *)pOut : _dSel, nullptr, NextLaunchTag(), _qFirst, 0, 0, nullptr, 0, 0, nullptr, nullptr};
   hipSetDevice(_device);
   StopServer();   // a launched sweep has no room beside the resident one and would wait for it to idle out
   return LaunchSingleSweep(q, &fs);
@@ -742,7 +779,7 @@ Error HipEngine::EnqueueSelectArgmaxFlag(int64_t iQuiz, void *pOut, void *pFlag,
   if (!pOut || !pFlag) return Error::Make(ErrCode::NullArgument, "Nullptr is passed in place of the record or the flag.");
   hipSetDevice(_device);
   if (_optServer && ServerUsable()) return ServerPost(q, (SelectResult *)pOut, (uint64_t *)pFlag, flagValue, _qFirst);
-  const FusedSelect fs{_dSelScratch, (SelectResult *)pOut, (uint64_t *)pFlag, NextLaunchTag(), _qFirst, 0, flagValue, nullptr, 0, 0, nullptr};
+  const FusedSelect fs{_dSelScratch, (SelectResult *)pOut, (uint64_t *)pFlag, NextLaunchTag(), _qFirst, 0, flagValue, nullptr, 0, 0, nullptr, nullptr};
   StopServer();   // a launched sweep has no room beside the resident one and would wait for it to idle out
   return LaunchSingleSweep(q, &fs);
 }
@@ -786,7 +823,7 @@ int64_t HipEngine::NextQuestionArgmax(Error &err, int64_t iQuiz) {
   // One launch; the last workgroup writes the winner and then a sequence number straight into host-coherent pinned
   // memory, which this thread polls: no D2H copy, no stream synchronisation on the critical path.
   const uint64_t seq = NextLaunchTag();
-  const FusedSelect fs{_dSelScratch, &_hPinned->sel, &_hPinned->seq, seq, 0, 0, seq, nullptr, 0, 0, nullptr};
+  const FusedSelect fs{_dSelScratch, &_hPinned->sel, &_hPinned->seq, seq, 0, 0, seq, nullptr, 0, 0, nullptr, nullptr};
   StopServer();   // a launched sweep has no room beside the resident one and would wait for it to idle out
   err = LaunchSingleSweep(q, &fs);
   if (!err.ok()) return -1;
@@ -974,7 +1011,7 @@ Error HipEngine::BatchSweep(int64_t n, const int64_t *pQuizzes, std::vector<Quiz
   HIP_TRY(hipMemcpyAsync(_dBatchSlots, _hBatch->slots, (size_t)n * sizeof(QuizSlot), hipMemcpyHostToDevice, _stream));
   StopServer();   // a launched sweep has no room beside the resident one and would wait for it to idle out
   if (!rowSharing) {
-    const FusedSelect fs{_dBatchScratch, nullptr, nullptr, tag, 0, kBatchGrid, tag, nullptr, 0, 0, nullptr};
+    const FusedSelect fs{_dBatchScratch, nullptr, nullptr, tag, 0, kBatchGrid, tag, nullptr, 0, 0, nullptr, nullptr};
     HIP_TRY(LaunchEvalQuestionsBatch(View(), _dBatchSlots, (int)n, 0, _Q, (int)_optEvalVariant, fs, _stream));
     return Error();
   }
@@ -1114,7 +1151,7 @@ int64_t HipEngine::NextQuestionArgmaxGraph(Error &err, Quiz *q) {
   if (it == _graphs.end() || it->second.variant != _optEvalVariant || it->second.stream != _stream ||
       it->second.kbVersion != _kbVersion) {
     if (it != _graphs.end()) { hipGraphExecDestroy(it->second.exec); _graphs.erase(it); }
-    const FusedSelect fs{_dGraphScratch, &_hPinned->sel, &_hPinned->seq, 0, 0, 0, 0, _dTagCell, 0, 0, nullptr};
+    const FusedSelect fs{_dGraphScratch, &_hPinned->sel, &_hPinned->seq, 0, 0, 0, 0, _dTagCell, 0, 0, nullptr, nullptr};
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
     hipError_t he = hipStreamBeginCapture(_stream, hipStreamCaptureModeThreadLocal);
@@ -1151,10 +1188,32 @@ int64_t HipEngine::NextQuestionSampled(Error &err, int64_t iQuiz, uint64_t rnd) 
   const KbView kb = View();
   const int64_t nSub = _optEvalSubtasks ? _optEvalSubtasks : 8 * _optWorkers;  // reference PqaCore/CpuEngine.cpp:339
   StopServer();   // a launched sweep has no room beside the resident one and would wait for it to idle out
+  if (_optHostSampled && !_optFusedSampled && _elem == 8 && EvalVariantHasFinisherWorkgroup(kb, (int)_optEvalVariant)) {
+    // ONE launch, and the selection on the host: the sweep's finisher workgroup copies the finished priority vector (8 bytes per
+    // question) into host-coherent memory and sets the flag; the selector's O(Q) scalar Kahan steps take the host a few
+    // microseconds -- less than the dispatch of the selector kernel they replace.
+    if (_hostPriorityCap < _capQ) {
+      if (_hHostPriority) hipHostFree(_hHostPriority);
+      _hHostPriority = nullptr;
+      _hostPriorityCap = 0;
+      const hipError_t ae = hipHostMalloc((void **)&_hHostPriority, (size_t)_capQ * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent);
+      if (ae != hipSuccess) { err = HipErr(ae, "host priority buffer"); return -1; }
+      _hostPriorityCap = _capQ;
+    }
+    const uint64_t seq = NextLaunchTag();
+    const FusedSelect fs{_dSelScratch, &_hPinned->sel, &_hPinned->seq, seq, 0, 0, seq, nullptr, 1, 0, nullptr, _hHostPriority};
+    const hipError_t he = LaunchEvalQuestions(kb, q->dPrior, q->dAsked, 0, _Q, _dPriority, (int)_optEvalVariant, &fs, _stream);
+    if (he != hipSuccess) { err = HipErr(he, "NextQuestionSampled"); return -1; }
+    err = WaitFlag(&_hPinned->seq, seq, "NextQuestionSampled");
+    if (!err.ok()) return -1;
+    if (_hPinned->sel.index == -3) { err = HipErr(hipErrorLaunchFailure, "NextQuestionSampled (incomplete sweep)"); return -1; }
+    const int64_t sel = SelectSampledHost(_hHostPriority, _Q, nSub, rnd, [&](int64_t i) { return BitTest(_hQGap, i) || BitTest(q->hAsked, i); });
+    return FinishSelection(err, q, sel);
+  }
   if (_optFusedSampled && _elem == 8 && EvalVariantFusesSampled(kb, (int)_optEvalVariant, nSub)) {
     // ONE launch: the sweep's finisher workgroup runs the reference's selector once every workgroup has reported
     const uint64_t seq = NextLaunchTag();
-    const FusedSelect fs{_dSelScratch, &_hPinned->sel, &_hPinned->seq, seq, 0, 0, seq, nullptr, nSub, rnd, _dRunLength};
+    const FusedSelect fs{_dSelScratch, &_hPinned->sel, &_hPinned->seq, seq, 0, 0, seq, nullptr, nSub, rnd, _dRunLength, nullptr};
     const hipError_t he = LaunchEvalQuestions(kb, q->dPrior, q->dAsked, 0, _Q, _dPriority, (int)_optEvalVariant, &fs, _stream);
     if (he != hipSuccess) { err = HipErr(he, "NextQuestionSampled"); return -1; }
     err = WaitFlag(&_hPinned->seq, seq, "NextQuestionSampled");

@@ -339,6 +339,9 @@ class HipEngine : public IEngine {
   // does (PqaCore/CEUpdatePriorsSubtaskMul.cpp:53 loads pvB, not pvB + j): the drop-in default.  0 = the evident intent.
   int64_t _optBugCompat = 1;
   void ApplyEnvironment();   // PQA_SELECT / PQA_SERVER / PQA_BUG_COMPAT / PQA_WORKERS / PQA_SEED: defaults for unchanged wrappers
+  int64_t _optHostSampled = 1;    // the sampled NextQuestion as ONE launch + the selector on the host (the finisher workgroup hands over the priority vector)
+  double *_hHostPriority = nullptr;   // host-coherent, _hostPriorityCap doubles
+  int64_t _hostPriorityCap = 0;
   int64_t _optFusedSampled = 0;   // the sampled NextQuestion as ONE launch (the sweep's finisher workgroup runs the selector): correct,
                                   // but 38.3 vs 36.4 us at 1000 x 5 x 1000 -- one workgroup's serial selection costs more than a launch
   int64_t _optEvalMaxGrid = 0;    // test hook: KbView::maxGrid
@@ -367,6 +370,7 @@ class HipEngine : public IEngine {
   uint64_t _rng[2] = {0, 0};
 };
 
+int64_t SelectSampledHost(double *run, int64_t n, int64_t nWorkers, uint64_t rnd, const std::function<bool(int64_t)> &skipped);
 int64_t FindNearestInPacks(int64_t iMiddle, int64_t nQuestions, const std::function<uint64_t(int64_t)> &avail);
 // One knowledge base over several devices of this process (sharded_engine.cpp); devices.size() >= 2.
 IEngine *CreateShardedEngine(Error &err, const CiEngineDefinition &def, const std::vector<int> &devices);

@@ -62,6 +62,10 @@ struct FusedSelect {
   int64_t sampleSubtasks;
   uint64_t sampleRnd;
   double *runLength;
+  // ... or, with hostPriority != nullptr (and sampleSubtasks > 0): workgroup 0 only copies the finished priority vector into
+  // this host-coherent buffer and then sets the flag; the host runs the selector (O(Q) scalar Kahan steps, microseconds)
+  // instead of a second kernel whose dispatch alone costs more.
+  double *hostPriority;
 };
 // One quiz of a batched sweep (blockIdx.y selects it): everything that differs between the quizzes of one launch.
 struct QuizSlot {
@@ -98,6 +102,7 @@ hipError_t LaunchEvalQuestionsF32(const KbView &kb, const double *prior, const u
 hipError_t UploadLog2TableBatch(const double *hostTable);
 const char *EvalVariantName(const KbView &kb, int variant);
 bool EvalVariantFusesSampled(const KbView &kb, int variant, int64_t nSubtasks);   // the launch can run the sampled selector itself
+bool EvalVariantHasFinisherWorkgroup(const KbView &kb, int variant);              // ... or hand the priority vector to the host (hostPriority)
 
 // ---- resident sweep ("server"): ONE launch serves many selections.  The host posts a request in pinned memory; workgroup
 // 0 sees it, hands it to the other workgroups through a device word, everybody sweeps, the finisher answers straight into

@@ -395,32 +395,8 @@ int64_t ShardedEngine::NextQuestionSampled(Error &err, int64_t iQuiz, uint64_t r
     for (int64_t q = _Q; q < (int64_t)skip.size() * 64; q++) skip[(size_t)(q >> 6)] |= 1ULL << (q & 63);
   }
   auto skipped = [&](int64_t q) { return (skip[(size_t)(q >> 6)] >> (q & 63)) & 1ULL; };
-  const int64_t n = _Q, nWorkers = _sh[0]->GetOption("eval_subtasks");
-  const int64_t quot = n / nWorkers, rem = n % nWorkers, nSubtasks = quot == 0 ? rem : nWorkers;   // CalcSplit
-  auto bound = [&](int64_t i) { return (i + 1) * quot + std::min<int64_t>(i + 1, rem); };           // end of subtask i
-  std::vector<double> grand((size_t)nSubtasks);
-  std::vector<double> &run = _hostPriority;   // priorities, then (in place) the run lengths
-  for (int64_t s = 0; s < nSubtasks; s++) {
-    HostKahan acc;
-    for (int64_t i = s == 0 ? 0 : bound(s - 1); i < bound(s); i++) {
-      if (!skipped(i)) acc.add(run[(size_t)i]);   // gap / asked questions only copy the running sum (CEEvalQsSubtaskConsider.cpp:54-58, :212)
-      run[(size_t)i] = acc.get();
-    }
-    grand[(size_t)s] = acc.get();
-  }
-  HostKahan tot;                                                 // CpuEngine.cpp:362-368
-  for (int64_t s = 0; s < nSubtasks; s++) { tot.add(grand[(size_t)s]); grand[(size_t)s] = tot.get(); }
-  const double totG = grand[(size_t)nSubtasks - 1];
-  const double selRunLen = totG * (double)rnd / 18446744073709551615.0;   // :379, SRDoubleNumber::MakeRandom
-  int64_t sel;
-  const int64_t iWorker = std::upper_bound(grand.begin(), grand.end(), selRunLen) - grand.begin();   // :380-381
-  if (iWorker >= nSubtasks) sel = n - 1;                          // :384
-  else {
-    const double inWorker = selRunLen - (iWorker == 0 ? 0.0 : grand[(size_t)iWorker - 1]);   // :388
-    const int64_t first = iWorker == 0 ? 0 : bound(iWorker - 1), limit = bound(iWorker);
-    sel = std::upper_bound(run.begin() + first, run.begin() + limit, inWorker) - run.begin();   // :391
-    if (sel >= limit) sel = limit - 1;                            // :392-400
-  }
+  const int64_t n = _Q;
+  int64_t sel = SelectSampledHost(_hostPriority.data(), n, _sh[0]->GetOption("eval_subtasks"), rnd, [&](int64_t q) { return skipped(q) != 0; });
   // :403-407 a gap / asked pick falls to BaseEngine::FindNearestQuestion, over the global bitmap
   if (skipped(sel)) sel = FindNearestInPacks(sel, n, [&](int64_t p) { return ~skip[(size_t)p]; });
   return Commit(err, iQuiz, sel);
