@@ -315,6 +315,8 @@ def main():
 
         eng.set_option("select", 0)
         eng.set_option("seed", SEED)
+        # (server off: RecordQuizTarget rewrites the cube at the end of every quiz, which stops a resident kernel -- measured 15.6 k
+        #  questions/s with it against 17.6 k with one launch per selection; the selector itself runs on the host either way)
         rng = np.random.default_rng(SEED)
         asked, hits, n_q = 0, 0, 600
         tq0 = time.perf_counter()
@@ -335,6 +337,7 @@ def main():
         eng.set_option("select", 1)
         quiz_loop = {"questions_per_sec": asked / dtq, "quizzes": n_q, "questions": asked, "guessed_on_top": hits,
                      "published_reference_questions_per_sec": 301.2,
+                     "selection_path": "one launch per selection (the sweep's finisher hands the priority vector to the host) + the reference's selector on the host",
                      "note": "reference figure: PqaClient learner loop on the author's 2017 desktop CPU (BASELINE.md); "
                              "here: Python wrapper of the C ABI, one quiz at a time, sampled selector"}
 

@@ -162,7 +162,7 @@ __device__ __forceinline__ void fused_select(const EvalArgs &a, Best mine, int l
   }
   b = wave_best(b);
   if (sampled) {           // the selection follows (sweep_body); only whether the sweep is complete is handed on
-    if (allReported != nullptr && lane == 0) *allReported = complete;
+    if (allReported != nullptr && (UNI || lane == 0)) *allReported = complete;
     return;
   }
   if (UNI || lane == 0) {
@@ -558,30 +558,36 @@ __device__ __forceinline__ void sweep_body(EvalArgs a, bool copyTable) {
     flush_pending(a, pend, nPend, lane, bestLds[lane]);
     fused_select<SERVER>(a, bestLds[lane], lane, allReported);
   }
+  if (a.fs.scratch != nullptr && a.fs.sampleSubtasks > 0 && a.fs.hostPriority != nullptr) {
+    // ---- the reference's selector on the HOST: workgroup 0 hands the finished priority vector over.  Every workgroup's
+    // priorities are in device memory (write-through stores, acknowledged before its record, and fused_select above has seen
+    // every record): one round of loads past the non-coherent cache levels, one coalesced burst into host-coherent memory, then
+    // the flag.  Launched and resident form alike (resident: the stores of the last step are made by the whole wave).
+    if (blockIdx.x == 0) {
+      __syncthreads();
+      const bool complete = *allReported;
+      const int64_t n = a.qLimit - a.qFirst;
+      for (int64_t i = tid; i < n; i += kThreads)
+        a.fs.hostPriority[i] = __hip_atomic_load(a.priority + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");            // system scope: this thread's part of the vector is out
+      __syncthreads();
+      if (SERVER ? wave == 0 : tid == 0) {
+        a.fs.out->priority = 0.0;
+        a.fs.out->index = complete ? 0 : -3;
+        if (a.fs.seq != nullptr) {
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+          __hip_atomic_store(a.fs.seq, a.fs.flagValue, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+      }
+    }
+    return;
+  }
   if constexpr (!SERVER) {
     if (a.fs.scratch != nullptr && a.fs.sampleSubtasks > 0 && blockIdx.x == 0) {
       // ---- the reference's selector, by this workgroup, over what every workgroup has written (fused_select above made
       // sure they all have); the Log2Hot table's LDS holds the subtask totals
       __syncthreads();
       const bool complete = *allReported;
-      if (a.fs.hostPriority != nullptr) {
-        // every workgroup's priorities are in device memory (write-through stores, acknowledged before its record): one round
-        // of loads past the non-coherent cache levels, one coalesced burst to the host, then the flag
-        const int64_t n = a.qLimit - a.qFirst;
-        for (int64_t i = tid; i < n; i += kThreads)
-          a.fs.hostPriority[i] = __hip_atomic_load(a.priority + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");            // system scope: this thread's part of the vector is out
-        __syncthreads();
-        if (tid == 0) {
-          a.fs.out->priority = 0.0;
-          a.fs.out->index = complete ? 0 : -3;
-          if (a.fs.seq != nullptr) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
-            __hip_atomic_store(a.fs.seq, a.fs.flagValue, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-          }
-        }
-        return;
-      }
       const SampledPick r = select_sampled_wg_lds<true>(a.priority, a.qgap, a.asked, a.qFirst, a.qLimit - a.qFirst,
                                                         a.fs.sampleSubtasks, a.fs.sampleRnd, tbl);
       if (tid == 0) {
@@ -710,7 +716,9 @@ void eval_server_f64(EvalArgs a, ServerMailbox *mb, uint32_t *requestLine, int e
     b.fs.out = reinterpret_cast<SelectResult *>(uniform64(reinterpret_cast<const uint64_t *>(step)[3]));
     b.fs.seq = reinterpret_cast<uint64_t *>(uniform64(reinterpret_cast<const uint64_t *>(step)[4]));
     b.fs.flagValue = uniform64(reinterpret_cast<const uint64_t *>(step)[5]);
-    b.fs.outBase = (int64_t)uniform64(reinterpret_cast<const uint64_t *>(step)[6]);
+    const uint64_t ob = uniform64(reinterpret_cast<const uint64_t *>(step)[6]);
+    b.fs.outBase = (int64_t)(ob & ~kServerHandOver);
+    b.fs.sampleSubtasks = (ob & kServerHandOver) ? 1 : 0;   // the priority vector goes to the host (FusedSelect::hostPriority), no argmax
     b.fs.seqValue = go;
     // (as with the thread index: nothing derived from the launch constants may be hoisted out of the step loop)
     asm volatile("" : "+s"(b.cube), "+s"(b.tgap), "+s"(b.qgap), "+s"(b.priority), "+s"(b.fs.scratch), "+s"(b.K), "+s"(b.ldT),
@@ -1111,12 +1119,13 @@ bool EvalServerSupported(const KbView &kb, int variant) { return server_variant(
 
 hipError_t LaunchEvalServer(const KbView &kb, int64_t qFirst, int64_t qLimit, double *priority, int variant,
                             SelectResult *scratch, ServerMailbox *mailbox, void *requestLine, bool everyonePolls,
-                            ServerCtl *ctl, uint64_t lastSeq, uint64_t idleTicks, hipStream_t stream) {
+                            ServerCtl *ctl, uint64_t lastSeq, uint64_t idleTicks, double *hostPriority, hipStream_t stream) {
   if (qLimit <= qFirst || scratch == nullptr || mailbox == nullptr || requestLine == nullptr || ctl == nullptr)
     return hipErrorInvalidValue;
   EvalArgs args = make_args(kb, qFirst, qLimit);
   args.priority = priority;
   args.fs.scratch = scratch;
+  args.fs.hostPriority = hostPriority;
   switch (server_variant(kb, variant)) {
     case 2: return launch_server<4, 2>(args, mailbox, requestLine, everyonePolls, ctl, lastSeq, idleTicks, stream);
     default: return hipErrorNotSupported;

@@ -784,6 +784,17 @@ Error HipEngine::EnqueueSelectArgmaxFlag(int64_t iQuiz, void *pOut, void *pFlag,
   return LaunchSingleSweep(q, &fs);
 }
 
+hipError_t HipEngine::EnsureHostPriority() {
+  if (_hostPriorityCap >= _capQ && _hHostPriority != nullptr) return hipSuccess;
+  StopServer();   // (its launch arguments hold the old buffer)
+  if (_hHostPriority) hipHostFree(_hHostPriority);
+  _hHostPriority = nullptr;
+  _hostPriorityCap = 0;
+  const hipError_t e = hipHostMalloc((void **)&_hHostPriority, (size_t)_capQ * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent);
+  if (e == hipSuccess) _hostPriorityCap = _capQ;
+  return e;
+}
+
 Error HipEngine::WaitFlag(volatile uint64_t *flag, uint64_t value, const char *what) {
   const auto t0 = std::chrono::steady_clock::now();
   uint64_t spins = 0;
@@ -963,8 +974,9 @@ Error HipEngine::ServerPost(Quiz *q, SelectResult *out, uint64_t *flag, uint64_t
   HIP_TRY(hipMemsetAsync(_dServerCtl, 0, sizeof(ServerCtl), _serverStream));
   mb->state = kServerRunning;
   std::atomic_thread_fence(std::memory_order_seq_cst);
+  HIP_TRY(EnsureHostPriority());   // (a launch argument of the resident kernel: requests may ask for the priority vector)
   HIP_TRY(LaunchEvalServer(View(), 0, _Q, _dPriority, (int)_optEvalVariant, _dSelScratch, _hMailbox, (void *)_serverRequest, _serverRequestInVram, _dServerCtl, prev,
-                           (uint64_t)_optServerIdleUs * 100, _serverStream));   // 100 MHz ticks
+                           (uint64_t)_optServerIdleUs * 100, _hHostPriority, _serverStream));   // 100 MHz ticks
   _serverLaunched = true;
   _serverKb = _kbVersion;
   _serverVariant = _optEvalVariant;
@@ -1187,19 +1199,23 @@ int64_t HipEngine::NextQuestionSampled(Error &err, int64_t iQuiz, uint64_t rnd) 
   hipSetDevice(_device);
   const KbView kb = View();
   const int64_t nSub = _optEvalSubtasks ? _optEvalSubtasks : 8 * _optWorkers;  // reference PqaCore/CpuEngine.cpp:339
+  if (_optServer && _optHostSampled && !_optFusedSampled && ServerUsable()) {
+    // resident sweep: post the request with the hand-over mark, poll the flag, select on the host -- no launch on the path
+    const uint64_t value = ++_opSeq;
+    err = ServerPost(q, &_hPinned->sel, &_hPinned->seq, value, (int64_t)kServerHandOver);
+    if (err.ok()) err = ServerWait(&_hPinned->seq, value, "NextQuestionSampled");
+    if (!err.ok()) return -1;
+    if (_hPinned->sel.index == -3) { err = HipErr(hipErrorLaunchFailure, "NextQuestionSampled (incomplete sweep)"); return -1; }
+    const int64_t sel = SelectSampledHost(_hHostPriority, _Q, nSub, rnd, [&](int64_t i) { return BitTest(_hQGap, i) || BitTest(q->hAsked, i); });
+    return FinishSelection(err, q, sel);
+  }
   StopServer();   // a launched sweep has no room beside the resident one and would wait for it to idle out
   if (_optHostSampled && !_optFusedSampled && _elem == 8 && EvalVariantHasFinisherWorkgroup(kb, (int)_optEvalVariant)) {
     // ONE launch, and the selection on the host: the sweep's finisher workgroup copies the finished priority vector (8 bytes per
     // question) into host-coherent memory and sets the flag; the selector's O(Q) scalar Kahan steps take the host a few
     // microseconds -- less than the dispatch of the selector kernel they replace.
-    if (_hostPriorityCap < _capQ) {
-      if (_hHostPriority) hipHostFree(_hHostPriority);
-      _hHostPriority = nullptr;
-      _hostPriorityCap = 0;
-      const hipError_t ae = hipHostMalloc((void **)&_hHostPriority, (size_t)_capQ * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent);
-      if (ae != hipSuccess) { err = HipErr(ae, "host priority buffer"); return -1; }
-      _hostPriorityCap = _capQ;
-    }
+    const hipError_t ae = EnsureHostPriority();
+    if (ae != hipSuccess) { err = HipErr(ae, "host priority buffer"); return -1; }
     const uint64_t seq = NextLaunchTag();
     const FusedSelect fs{_dSelScratch, &_hPinned->sel, &_hPinned->seq, seq, 0, 0, seq, nullptr, 1, 0, nullptr, _hHostPriority};
     const hipError_t he = LaunchEvalQuestions(kb, q->dPrior, q->dAsked, 0, _Q, _dPriority, (int)_optEvalVariant, &fs, _stream);

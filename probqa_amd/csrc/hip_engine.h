@@ -342,6 +342,7 @@ class HipEngine : public IEngine {
   int64_t _optHostSampled = 1;    // the sampled NextQuestion as ONE launch + the selector on the host (the finisher workgroup hands over the priority vector)
   double *_hHostPriority = nullptr;   // host-coherent, _hostPriorityCap doubles
   int64_t _hostPriorityCap = 0;
+  hipError_t EnsureHostPriority();
   int64_t _optFusedSampled = 0;   // the sampled NextQuestion as ONE launch (the sweep's finisher workgroup runs the selector): correct,
                                   // but 38.3 vs 36.4 us at 1000 x 5 x 1000 -- one workgroup's serial selection costs more than a launch
   int64_t _optEvalMaxGrid = 0;    // test hook: KbView::maxGrid

@@ -139,9 +139,12 @@ struct ServerCtl {                // device memory, one line; zeroed before each
 // returns hipErrorNotSupported otherwise.  `scratch`: kFusedMaxGrid records.  lastSeq: the kernel serves requests != lastSeq.
 // requestLine: the 64-byte line the host writes requests to -- the mailbox's own first line, or a line of host-visible device
 // memory (everyonePolls: every workgroup watches it; the host then waits for `done`, not `taken`, before the next request).
+// hostPriority (optional, host-coherent, qLimit - qFirst doubles): a request whose outBase carries kServerHandOver is answered
+// with the priority vector itself (for the host's sampled selector) instead of the argmax.
+constexpr uint64_t kServerHandOver = 1ull << 62;
 hipError_t LaunchEvalServer(const KbView &kb, int64_t qFirst, int64_t qLimit, double *priority, int variant,
                             SelectResult *scratch, ServerMailbox *mailbox, void *requestLine, bool everyonePolls,
-                            ServerCtl *ctl, uint64_t lastSeq, uint64_t idleTicks, hipStream_t stream);
+                            ServerCtl *ctl, uint64_t lastSeq, uint64_t idleTicks, double *hostPriority, hipStream_t stream);
 bool EvalServerSupported(const KbView &kb, int variant);
 
 struct RatedTargetDev { int64_t iTarget; double prob; };  // == CiRatedTarget
