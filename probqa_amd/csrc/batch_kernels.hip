@@ -363,15 +363,18 @@ __device__ __forceinline__ float rcp_f32_nr(float x) {
   const float r = __builtin_amdgcn_rcpf(x);
   return fmaf(r, fmaf(-x, r, 1.0f), r);
 }
-template <bool LDSROW>
-__global__ __launch_bounds__(256) void eval_questions_f32_stream(const float *__restrict__ cube, const double *__restrict__ prior,
+// NT threads per workgroup: 256 for short rows (several workgroups per CU), 1024 for long ones (the row's two LDS vectors allow one
+// workgroup per CU: sixteen waves instead of four keep its SIMDs busy).
+template <bool LDSROW, int NT>
+__global__ __launch_bounds__(NT) void eval_questions_f32_stream(const float *__restrict__ cube, const double *__restrict__ prior,
                                                                  const uint32_t *__restrict__ tgap, const uint32_t *__restrict__ qgap,
                                                                  const uint32_t *__restrict__ asked, double *__restrict__ priority,
                                                                  int64_t K, int64_t Q, int64_t ldT, double vCompTail) {
-  extern __shared__ double smem[];      // W_k [K] | W_k sqrt(V_k) [K] | partials [16 floats] | LDSROW: prior [ldT] | 1/D [ldT] (floats)
+  constexpr int NW = NT / kWave;
+  extern __shared__ double smem[];      // W_k [K] | W_k sqrt(V_k) [K] | partials [4][16 floats] | LDSROW: prior [ldT] | 1/D [ldT] (floats)
   double *wk = smem, *wv = smem + K;
   float *part = reinterpret_cast<float *>(smem + 2 * K);
-  float4 *prL = reinterpret_cast<float4 *>(part + 16), *idL = prL + (ldT >> 2);
+  float4 *prL = reinterpret_cast<float4 *>(part + 64), *idL = prL + (ldT >> 2);
   const int tid = threadIdx.x, lane = tid % kWave, wave = tid / kWave;
   const int64_t nQuads = ldT >> 2;      // ldT is a multiple of 32 floats
   auto prior4 = [&](int64_t i) __attribute__((always_inline)) {   // masked prior of targets 4i .. 4i+3 (:103)
@@ -386,7 +389,7 @@ __global__ __launch_bounds__(256) void eval_questions_f32_stream(const float *__
                        (g & 8) ? 0.f : rcp_f32_nr(d.w));
   };
   if constexpr (LDSROW)
-    for (int64_t i = tid; i < nQuads; i += 256) prL[i] = prior4(i);
+    for (int64_t i = tid; i < nQuads; i += NT) prL[i] = prior4(i);
   for (int64_t q = blockIdx.x; q < Q; q += gridDim.x) {
     if (bit_test(qgap, q) || bit_test(asked, q)) {
       if (tid == 0) priority[q] = 0.0;
@@ -396,13 +399,13 @@ __global__ __launch_bounds__(256) void eval_questions_f32_stream(const float *__
     const float4 *rowD = reinterpret_cast<const float4 *>(qb + K * ldT);
     __syncthreads();                                          // the previous question is done with the LDS rows
     if constexpr (LDSROW)
-      for (int64_t i = tid; i < nQuads; i += 256) idL[i] = invd4(rowD, i);
+      for (int64_t i = tid; i < nQuads; i += NT) idL[i] = invd4(rowD, i);
     __syncthreads();
     double hWd = 0.0, accLd = 0.0;
     for (int64_t k = 0; k < K; k++) {
       const float4 *rowA = reinterpret_cast<const float4 *>(qb + k * ldT);
       float s = 0.f;
-      for (int64_t i = tid; i < nQuads; i += 256) {
+      for (int64_t i = tid; i < nQuads; i += NT) {
         const float4 a = rowA[i];
         float4 id, pr;
         if constexpr (LDSROW) { id = idL[i]; pr = prL[i]; } else { id = invd4(rowD, i); pr = prior4(i); }
@@ -415,7 +418,9 @@ __global__ __launch_bounds__(256) void eval_questions_f32_stream(const float *__
       __syncthreads();                                        // the previous answer's partials have been read
       if (lane == 0) part[wave] = s;
       __syncthreads();
-      const float Wk = (part[0] + part[1]) + (part[2] + part[3]);
+      float Wk = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; w++) Wk += part[w];
       const float invWk = 1.0f / Wk;
       float v = 0.f, hW = 0.f, accL = 0.f;
       auto element = [&](float a, float id, float pi) __attribute__((always_inline)) {
@@ -427,7 +432,7 @@ __global__ __launch_bounds__(256) void eval_questions_f32_stream(const float *__
         v = fmaf(d, d, v);
         return l2;
       };
-      for (int64_t i = tid; i < nQuads; i += 256) {
+      for (int64_t i = tid; i < nQuads; i += NT) {
         const float4 a = rowA[i];
         float4 id, pr;
         if constexpr (LDSROW) { id = idL[i]; pr = prL[i]; } else { id = invd4(rowD, i); pr = prior4(i); }
@@ -441,14 +446,17 @@ __global__ __launch_bounds__(256) void eval_questions_f32_stream(const float *__
       hW = wave_sum_f(hW);
       accL = wave_sum_f(accL);
       __syncthreads();
-      if (lane == 0) { part[4 + wave] = v; part[8 + wave] = hW; part[12 + wave] = accL; }
+      if (lane == 0) { part[16 + wave] = v; part[32 + wave] = hW; part[48 + wave] = accL; }
       __syncthreads();
+      float vS = 0.f, hS = 0.f, lS = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; w++) { vS += part[16 + w]; hS += part[32 + w]; lS += part[48 + w]; }
       if (tid == 0) {
         wk[k] = (double)Wk;
-        wv[k] = (double)Wk * sqrt((double)((part[4] + part[5]) + (part[6] + part[7])));
+        wv[k] = (double)Wk * sqrt((double)vS);
       }
-      hWd += (double)((part[8] + part[9]) + (part[10] + part[11]));
-      accLd += (double)((part[12] + part[13]) + (part[14] + part[15]));
+      hWd += (double)hS;
+      accLd += (double)lS;
     }
     __syncthreads();
     if (tid == 0) priority[q] = eval_epilogue(wk, -hWd, wv, K, accLd, vCompTail);
@@ -541,26 +549,27 @@ hipError_t LaunchEvalQuestionsF32(const KbView &kb, const double *prior, const u
   if (kb.elem != 4) return hipErrorInvalidValue;
   const double nT = (double)(kb.nValidTargets + 1);
   const double vCompTail = 0.34657359027997265470861606072909 / (nT * nT);
-  const bool ldsRow = kb.ldT <= kF32LdsTargets;
-  size_t shmem = (size_t)(2 * kb.K + 8) * sizeof(double) + (ldsRow ? (size_t)kb.ldT * 8 : 0);
+  const bool ldsRow = kb.ldT <= kF32LdsTargets, big = kb.ldT >= 4096;
+  const size_t shmem = (size_t)(2 * kb.K + 32) * sizeof(double) + (ldsRow ? (size_t)kb.ldT * 8 : 0);
   static bool attrSet = false;
   if (ldsRow && shmem > 64 * 1024 && !attrSet) {
-    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(eval_questions_f32_stream<true>),
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(eval_questions_f32_stream<true, 1024>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
     if (e != hipSuccess) return e;
     attrSet = true;
   }
   int dev = 0, nCU = 0;
   if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&nCU, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || nCU <= 0) nCU = 256;
-  const int perCU = ldsRow ? (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / shmem)) : 8;
+  const int nt = big ? 1024 : 256;
+  int perCU = (int)std::max<size_t>(1, std::min<size_t>((size_t)(2048 / nt), (160 * 1024) / std::max<size_t>(shmem, 1)));
   int64_t grid = std::min<int64_t>(kb.Q, (int64_t)nCU * perCU);
   if (kb.maxGrid > 0 && grid > kb.maxGrid) grid = kb.maxGrid;
-  if (ldsRow)
-    hipLaunchKernelGGL(eval_questions_f32_stream<true>, dim3((unsigned)grid), dim3(256), shmem, stream, static_cast<const float *>(kb.cube),
-                       prior, kb.tgap, kb.qgap, asked, priority, kb.K, kb.Q, kb.ldT, vCompTail);
-  else
-    hipLaunchKernelGGL(eval_questions_f32_stream<false>, dim3((unsigned)grid), dim3(256), shmem, stream, static_cast<const float *>(kb.cube),
-                       prior, kb.tgap, kb.qgap, asked, priority, kb.K, kb.Q, kb.ldT, vCompTail);
+  const float *cube = static_cast<const float *>(kb.cube);
+#define PQA_F32_LAUNCH(L, N) hipLaunchKernelGGL((eval_questions_f32_stream<L, N>), dim3((unsigned)grid), dim3(N), shmem, stream, cube, prior, \
+                                                kb.tgap, kb.qgap, asked, priority, kb.K, kb.Q, kb.ldT, vCompTail)
+  if (ldsRow) { if (big) PQA_F32_LAUNCH(true, 1024); else PQA_F32_LAUNCH(true, 256); }
+  else PQA_F32_LAUNCH(false, 1024);
+#undef PQA_F32_LAUNCH
   return hipGetLastError();
 }
 
