@@ -46,7 +46,9 @@ PQACORE_API void *PqaEngineFactory_CreateHipEngineSharded(void *pvFactory, void 
  * (argmax selections are served by a resident kernel instead of one launch each -- rows up to 1024 targets; default 0),
  * "server_idle_us" (that kernel leaves after this long without a request, default 2000), "server_vram_mailbox" (requests
  * are written to host-visible device memory where the platform maps it, default 1; set before the first selection).
- * "fused_sampled" (the sampled NextQuestion as one launch instead of sweep + selector; default 0: measured slower),
+ * "host_sampled" (the sampled NextQuestion as one launch whose finisher hands the priority vector to the host, which runs the
+ * reference's selector itself; default 1 -- 0: sweep + selector kernel), "fused_sampled" (the selector inside the sweep's launch;
+ * default 0: measured slower),
  * "eval_max_grid" (test hook: cap the workgroups of a sweep so that each streams many questions; 0 = no cap).
  * "batch_min" (PqaEngine_NextQuestionArgmaxBatch: batches of at least this many quizzes take the row-sharing sweep, which
  * reads the cube once per batch; default 0 = decided by how many waves the batch gives that sweep; Float engines always take it), "batch_tile" (targets per LDS tile of that sweep, 0 = default).
