@@ -44,7 +44,7 @@ PQACORE_API void *PqaEngineFactory_CreateHipEngineSharded(void *pvFactory, void 
  * instead of launching the sweep), "top_cache" (how many of the new posterior's best
  * targets RecordAnswer's kernel lists ahead of the ListTopTargets call that follows it, default 10, 0 = none), "server"
  * (argmax selections are served by a resident kernel instead of one launch each -- rows up to 1024 targets; default 0),
- * "server_idle_us" (that kernel leaves after this long without a request, default 2000), "server_vram_mailbox" (requests
+ * "server_idle_us" (that kernel leaves after this long without a request, default 500: what a device-wide synchronisation of the host waits at most -- PqaHip_Synchronize asks it to leave at once), "server_vram_mailbox" (requests
  * are written to host-visible device memory where the platform maps it, default 1; set before the first selection).
  * "host_sampled" (the sampled NextQuestion as one launch whose finisher hands the priority vector to the host, which runs the
  * reference's selector itself; default 1 -- 0: sweep + selector kernel), "fused_sampled" (the selector inside the sweep's launch;

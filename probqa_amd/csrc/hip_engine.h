@@ -352,7 +352,7 @@ class HipEngine : public IEngine {
   int64_t _optUseGraph = 0;   // NextQuestion (argmax) replays a per-quiz HIP graph instead of launching
   int64_t _optTopCache = 10;  // targets RecordAnswer's kernel lists ahead of the ListTopTargets that follows it (0: none)
   // ---- resident sweep (option "server"; pqa_kernels.h: ServerMailbox)
-  int64_t _optServer = 0, _optServerIdleUs = 2000, _optServerVramMailbox = 1;
+  int64_t _optServer = 0, _optServerIdleUs = 500, _optServerVramMailbox = 1;
   hipStream_t _serverStream = nullptr;
   ServerMailbox *_hMailbox = nullptr;     // pinned
   ServerCtl *_dServerCtl = nullptr;
