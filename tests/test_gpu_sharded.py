@@ -124,3 +124,76 @@ def test_sharded_engine_exhausts_questions_like_the_whole_one(factory):
     with pytest.raises(interop.PqaException, match="run out of questions"):
         sh.next_question(quiz)
     sh.close()
+
+
+def test_config3_shape_eight_shards_on_one_device(factory):
+    """BASELINE configs[3] -- 10000Q x 5A x 10000T fp64 over 8 shards -- with all eight shards on the one device of this box:
+    the one-process sharded engine's selections (argmax and the reference's sampled selector) and posteriors equal the
+    whole-cube engine's over a short quiz."""
+    Q, K, T = 10000, 5, 10000
+    with devices("0,0,0,0,0,0,0,0"):
+        sh, err = factory.create_cpu_engine(interop.EngineDefinition(K, Q, T, init_amount=0.1))
+    assert err is None and sh.get_option("shards") == 8
+    whole, err = factory.create_cpu_engine(interop.EngineDefinition(K, Q, T, init_amount=0.1))
+    assert err is None
+    for e in (sh, whole):
+        e.set_option("workers", cases.WORKERS)
+        e.fill_synthetic(8.0, 0.5, 20260928)
+    qs, qw = sh.start_quiz(), whole.start_quiz()
+    for step in range(3):
+        a, b = sh.next_question_argmax(qs), whole.next_question_argmax(qw)
+        assert a == b, (step, a, b)
+        for rnd in (1, 2**63 + 12345, 2**64 - 1):
+            assert sh.next_question_sampled(qs, rnd) == whole.next_question_sampled(qw, rnd)
+        for e, z in ((sh, qs), (whole, qw)):
+            e.set_active_question(z, (a + 1250 * step) % Q)      # a question of another shard each step
+            e.record_answer(z, step % K)
+        assert np.array_equal(sh.get_priors(qs), whole.get_priors(qw))
+    sh.close()
+    whole.close()
+
+
+def test_config4_shape_sharded_batch_on_one_device(factory):
+    """BASELINE configs[4]'s shape -- rows of 100000 targets, fp32, 256 quizzes batched, question axis over 8 shards -- scaled
+    to 8 x 250 questions on the one device of this box: the sharded engine's batched selections equal the whole-cube Float
+    engine's, and a sample of priorities agrees with the fp64 oracle on the rounded rows within the fp32 tolerance."""
+    import orclib
+    import test_gpu_batch as tb
+    from probqa_amd import synth
+
+    Q, K, T, B = 2000, 5, 100000, 256
+    kw = dict(init_amount=0.1, prec_type=interop.PrecisionType.FLOAT, prec_exponent=8, prec_mantissa=24)
+    with devices("0,0,0,0,0,0,0,0"):
+        sh, err = factory.create_cpu_engine(interop.EngineDefinition(K, Q, T, **kw))
+    assert err is None and sh.get_option("shards") == 8 and sh.get_option("precision") == 1
+    whole, err = factory.create_cpu_engine(interop.EngineDefinition(K, Q, T, **kw))
+    assert err is None
+    quizzes = []
+    for e in (sh, whole):
+        e.set_option("workers", cases.WORKERS)
+        e.fill_synthetic(8.0, 0.5, 20260928)
+        qz = [e.start_quiz() for _ in range(B)]
+        for i, z in enumerate(qz):
+            if i % 3:
+                e.set_active_question(z, (37 * i) % Q)
+                e.record_answer(z, i % K)
+        quizzes.append(qz)
+    picks_s, picks_w = sh.next_question_argmax_batch(quizzes[0]), whole.next_question_argmax_batch(quizzes[1])
+    assert picks_s == picks_w
+    assert all(0 <= p < Q for p in picks_s)
+    # a sample against the oracle: 6 questions' rows rebuilt on the host (rounded to fp32), quiz 1's posterior
+    sample = [0, 249, 250, 1007, 1750, 1999]
+    orc = orclib.Oracle(K, len(sample), T, 0.1)
+    for j, q in enumerate(sample):
+        Aq, Dq, Bq = synth.synthetic_kb(K, 1, T, 0.1, 8.0, 0.5, 20260928, q_offset=q, q_total=Q)
+        orc.A[j, :, :T], orc.D[j, :T] = Aq[0].astype(np.float32), Dq[0].astype(np.float32)
+    orc.B[:T] = Bq.astype(np.float32)
+    orc.mants[:T] = sh.get_priors(quizzes[0][1])
+    _, opri = orc.eval_avx2(8)
+    pri = sh.eval_priorities_batch(quizzes[0][:64], Q)[1][sample]
+    keep = pri != 0                                       # (quiz 1 has asked question 37)
+    rel = np.abs(pri[keep] - opri[keep]) / opri[keep]
+    print("config-4 shape, sharded batch: max rel err vs fp64 oracle on the sample %.2e" % rel.max())
+    assert rel.max() < 5e-4
+    sh.close()
+    whole.close()
