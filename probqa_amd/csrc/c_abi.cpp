@@ -157,10 +157,9 @@ PQACORE_API void *PqaEngineFactory_LoadCpuEngine(void *pvFactory, void **ppError
   Error err;
   const std::vector<int> devices = DevicesFromEnvironment();
   if (devices.size() >= 2) {
-    err = Error::MakeP(ErrCode::NotImplemented, "Feature=LoadCpuEngine over several devices (PQA_DEVICES)",
-                       "A .kb file is loaded into one device; create the sharded engine and fill it through PqaHip_SetKB or training.");
+    pqa::IEngine *sharded = pqa::LoadShardedEngine(err, filePath, devices);
     AssignErr(ppError, err);
-    return nullptr;
+    return sharded;
   }
   if (devices.size() == 1 && hipSetDevice(devices[0]) != hipSuccess) {
     (void)hipGetLastError();
@@ -168,7 +167,7 @@ PQACORE_API void *PqaEngineFactory_LoadCpuEngine(void *pvFactory, void **ppError
     AssignErr(ppError, err);
     return nullptr;
   }
-  HipEngine *eng = HipEngine::Load(err, filePath);
+  pqa::IEngine *eng = HipEngine::Load(err, filePath);
   AssignErr(ppError, err);
   return eng;
 }

@@ -218,6 +218,21 @@ class HipEngine : public IEngine {
   int64_t ResumeQuizAdopt(Error &err, int64_t nAnswered, const AQ *pAQs, const double *srcPrior, int srcDevice, hipEvent_t ready);
   Error AdoptPrior(int64_t iQuiz, const double *srcPrior, int srcDevice, hipEvent_t ready);
   Error QuestionState(int64_t iQuiz, int64_t qGlobal, bool *pUnavailable);
+  // .kb arrays of this engine's questions at the file's current position (hip_engine_kb.cpp); the engine's lock is not taken
+  Error IoRows(FILE *f, const char *filePath, bool mD, bool write);
+  Error IoVB(FILE *f, const char *filePath, bool write);
+  Error SetVBFromHost(const double *vb);
+  void GetGapLists(std::vector<int64_t> &questionsGlobal, std::vector<int64_t> &targets) const {
+    for (int64_t q : _questionGapList) questionsGlobal.push_back(q + _qFirst);
+    targets = _targetGapList;
+  }
+  const PermIdMgr &TargetPim() const { return _pimTargets; }
+  void SetTargetPim(const PermIdMgr &p) { _pimTargets = p; }
+  void SetQuizPim(const PermIdMgr &p) { _pimQuizzes = p; }
+  void SetQuestionsAsked(uint64_t n) { _nQuestionsAsked.store(n); }
+  uint8_t PrecisionType() const { return _precType; }
+  uint32_t PrecMantissa() const { return _precMantissa; }
+  uint16_t PrecExponent() const { return _precExponent; }
   Error UnavailableWords(int64_t iQuiz, std::vector<uint32_t> &words);
 
  private:
@@ -375,5 +390,6 @@ int64_t SelectSampledHost(double *run, int64_t n, int64_t nWorkers, uint64_t rnd
 int64_t FindNearestInPacks(int64_t iMiddle, int64_t nQuestions, const std::function<uint64_t(int64_t)> &avail);
 // One knowledge base over several devices of this process (sharded_engine.cpp); devices.size() >= 2.
 IEngine *CreateShardedEngine(Error &err, const CiEngineDefinition &def, const std::vector<int> &devices);
+IEngine *LoadShardedEngine(Error &err, const char *filePath, const std::vector<int> &devices);
 
 }  // namespace pqa

@@ -222,6 +222,66 @@ Error HipEngine::ClearOldQuizzes(int64_t maxCount, double maxAgeSec) {  // BaseE
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// the arrays of a .kb file, this engine's questions only: sequential I/O at the file's current position through a bounded
+// host staging buffer.  The same code serves a whole-cube engine and every shard of a sharded one (the file orders its rows
+// by question, so the shards' blocks follow each other).
+// ------------------------------------------------------------------------------------------------------------------
+Error HipEngine::IoRows(FILE *f, const char *filePath, bool mD, bool write) {   // sA rows [q][a] of T elements, or mD rows [q]
+  hipSetDevice(_device);
+  const size_t rowB = (size_t)_T * (size_t)_elem, ldB = (size_t)_ldT * (size_t)_elem;
+  const int64_t rowsPerQ = mD ? 1 : _K;
+  const int64_t batch = std::max<int64_t>(1, (int64_t)((64u << 20) / (rowB * (size_t)rowsPerQ)));
+  std::vector<char> host((size_t)std::min(batch, _Q) * (size_t)rowsPerQ * rowB);
+  const char *what = mD ? "the target dimension of _mD weights." : "the target dimension of _sA weights.";
+  for (int64_t q0 = 0; q0 < _Q; q0 += batch) {
+    const int64_t nq = std::min(batch, _Q - q0);
+    const size_t nRows = (size_t)(nq * rowsPerQ);
+    if (!write && std::fread(host.data(), rowB, nRows, f) != nRows) return FileErr(filePath, (std::string("Can't read ") + what).c_str());
+    for (int64_t q = 0; q < nq; q++) {
+      char *h = host.data() + (size_t)q * (size_t)rowsPerQ * rowB;
+      char *d = CubeAt(q0 + q, mD ? _K : 0);
+      if (write) HIP_TRY(hipMemcpy2DAsync(h, rowB, d, ldB, rowB, (size_t)rowsPerQ, hipMemcpyDeviceToHost, _stream));
+      else HIP_TRY(hipMemcpy2DAsync(d, ldB, h, rowB, rowB, (size_t)rowsPerQ, hipMemcpyHostToDevice, _stream));
+    }
+    HIP_TRY(hipStreamSynchronize(_stream));
+    if (write && std::fwrite(host.data(), rowB, nRows, f) != nRows) return FileErr(filePath, (std::string("Can't write ") + what).c_str());
+  }
+  return Error();
+}
+
+// vB: fp64 on the device in both precisions; the file holds the engine's number type
+Error HipEngine::IoVB(FILE *f, const char *filePath, bool write) {
+  hipSetDevice(_device);
+  std::vector<double> vb((size_t)_T);
+  std::vector<float> vf(_elem == 4 ? (size_t)_T : 0);
+  if (write) {
+    HIP_TRY(hipMemcpyAsync(vb.data(), _dVB, (size_t)_T * sizeof(double), hipMemcpyDeviceToHost, _stream));
+    HIP_TRY(hipStreamSynchronize(_stream));
+    bool ok;
+    if (_elem == 8) ok = std::fwrite(vb.data(), sizeof(double), (size_t)_T, f) == (size_t)_T;
+    else {
+      std::copy(vb.begin(), vb.end(), vf.begin());
+      ok = std::fwrite(vf.data(), sizeof(float), (size_t)_T, f) == (size_t)_T;
+    }
+    return ok ? Error() : FileErr(filePath, "Can't write the _vB weights.");
+  }
+  if (_elem == 8) {
+    if (std::fread(vb.data(), sizeof(double), (size_t)_T, f) != (size_t)_T) return FileErr(filePath, "Can't read the _vB weights.");
+  } else {
+    if (std::fread(vf.data(), sizeof(float), (size_t)_T, f) != (size_t)_T) return FileErr(filePath, "Can't read the _vB weights.");
+    std::copy(vf.begin(), vf.end(), vb.begin());
+  }
+  return SetVBFromHost(vb.data());
+}
+
+Error HipEngine::SetVBFromHost(const double *vb) {
+  hipSetDevice(_device);
+  HIP_TRY(hipMemcpyAsync(_dVB, vb, (size_t)_T * sizeof(double), hipMemcpyHostToDevice, _stream));
+  HIP_TRY(hipStreamSynchronize(_stream));
+  return Error();
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // .kb persistence (layout of reference PqaCore/BaseEngine.cpp:323-385 + PqaCore/CpuEngine.cpp:664-688):
 //   PrecisionDefinition (8 B) | EngineDimensions {nAnswers, nQuestions, nTargets} | u64 nQuestionsAsked |
 //   sA rows [q][a] of nTargets doubles | mD rows [q] | vB | question gaps (i64 n, n ids) | target gaps |
@@ -243,40 +303,10 @@ Error HipEngine::SaveKB(const char *filePath, bool doubleBuffer) {
   if (std::fwrite(&prec, 8, 1, fc.f) != 1) return FileErr(filePath, "Can't write precision definition header.");
   if (std::fwrite(dims, sizeof(dims), 1, fc.f) != 1) return FileErr(filePath, "Can't write engine dimensions header.");
   if (std::fwrite(&nAsked, 8, 1, fc.f) != 1) return FileErr(filePath, "Can't write the number of questions asked.");
-  // statistics: a bounded host staging buffer, one batch of questions at a time
-  const size_t rowB = (size_t)_T * (size_t)_elem, ldB = (size_t)_ldT * (size_t)_elem;
-  const int64_t batch = std::max<int64_t>(1, (int64_t)((64u << 20) / (rowB * (size_t)_K)));
-  std::vector<char> host((size_t)std::min(batch, _Q) * (size_t)_K * rowB);
-  for (int64_t q0 = 0; q0 < _Q; q0 += batch) {
-    const int64_t nq = std::min(batch, _Q - q0);
-    for (int64_t q = 0; q < nq; q++)
-      HIP_TRY(hipMemcpy2DAsync(host.data() + (size_t)q * _K * rowB, rowB, CubeAt(q0 + q), ldB, rowB,
-                               (size_t)_K, hipMemcpyDeviceToHost, _stream));
-    HIP_TRY(hipStreamSynchronize(_stream));
-    if (std::fwrite(host.data(), rowB, (size_t)(nq * _K), fc.f) != (size_t)(nq * _K))
-      return FileErr(filePath, "Can't write the target dimension of _sA weights.");
-  }
-  host.resize((size_t)std::min<int64_t>(batch * _K, _Q) * rowB);
-  for (int64_t q0 = 0; q0 < _Q; q0 += batch * _K) {
-    const int64_t nq = std::min(batch * _K, _Q - q0);
-    HIP_TRY(hipMemcpy2DAsync(host.data(), rowB, CubeAt(q0, _K), ldB * (size_t)(_K + 1), rowB,
-                             (size_t)nq, hipMemcpyDeviceToHost, _stream));
-    HIP_TRY(hipStreamSynchronize(_stream));
-    if (std::fwrite(host.data(), rowB, (size_t)nq, fc.f) != (size_t)nq)
-      return FileErr(filePath, "Can't write the target dimension of _mD weights.");
-  }
-  {
-    std::vector<double> vb((size_t)_T);   // vB is fp64 on the device in both precisions; the file holds the engine's number type
-    HIP_TRY(hipMemcpyAsync(vb.data(), _dVB, (size_t)_T * sizeof(double), hipMemcpyDeviceToHost, _stream));
-    HIP_TRY(hipStreamSynchronize(_stream));
-    bool ok;
-    if (_elem == 8) ok = std::fwrite(vb.data(), sizeof(double), (size_t)_T, fc.f) == (size_t)_T;
-    else {
-      std::vector<float> vf(vb.begin(), vb.end());
-      ok = std::fwrite(vf.data(), sizeof(float), (size_t)_T, fc.f) == (size_t)_T;
-    }
-    if (!ok) return FileErr(filePath, "Can't write the _vB weights.");
-  }
+  Error e = IoRows(fc.f, filePath, false, true);      // sA rows [q][a]
+  if (e.ok()) e = IoRows(fc.f, filePath, true, true);  // mD rows [q]
+  if (e.ok()) e = IoVB(fc.f, filePath, true);
+  if (!e.ok()) return e;
   auto writeGaps = [&](const std::vector<int64_t> &gaps) {
     const int64_t n = (int64_t)gaps.size();
     return std::fwrite(&n, 8, 1, fc.f) == 1 && std::fwrite(gaps.data(), 8, (size_t)n, fc.f) == (size_t)n;
@@ -317,40 +347,10 @@ HipEngine *HipEngine::Load(Error &err, const char *filePath) {  // PqaEngineBase
   HipEngine &e = *eng;
   auto fail = [&](Error x) { err = std::move(x); return (HipEngine *)nullptr; };
   hipSetDevice(e._device);
-  const size_t rowB = (size_t)e._T * (size_t)e._elem, ldB = (size_t)e._ldT * (size_t)e._elem;
-  const int64_t batch = std::max<int64_t>(1, (int64_t)((64u << 20) / (rowB * (size_t)e._K)));
-  std::vector<char> host((size_t)std::min(batch, e._Q) * (size_t)e._K * rowB);
-  for (int64_t q0 = 0; q0 < e._Q; q0 += batch) {
-    const int64_t nq = std::min(batch, e._Q - q0);
-    if (std::fread(host.data(), rowB, (size_t)(nq * e._K), fc.f) != (size_t)(nq * e._K))
-      return fail(FileErr(filePath, "Can't read the target dimension of _sA weights."));
-    for (int64_t q = 0; q < nq; q++)
-      if (hipMemcpy2DAsync(e.CubeAt(q0 + q), ldB, host.data() + (size_t)q * e._K * rowB, rowB, rowB,
-                           (size_t)e._K, hipMemcpyHostToDevice, e._stream) != hipSuccess)
-        return fail(Error::Make(ErrCode::Internal, "HIP copy of _sA failed."));
-    if (hipStreamSynchronize(e._stream) != hipSuccess) return fail(Error::Make(ErrCode::Internal, "HIP sync failed."));
-  }
-  host.resize((size_t)std::min<int64_t>(batch * e._K, e._Q) * rowB);
-  for (int64_t q0 = 0; q0 < e._Q; q0 += batch * e._K) {
-    const int64_t nq = std::min(batch * e._K, e._Q - q0);
-    if (std::fread(host.data(), rowB, (size_t)nq, fc.f) != (size_t)nq)
-      return fail(FileErr(filePath, "Can't read the target dimension of _mD weights."));
-    if (hipMemcpy2DAsync(e.CubeAt(q0, e._K), ldB * (size_t)(e._K + 1), host.data(), rowB,
-                         rowB, (size_t)nq, hipMemcpyHostToDevice, e._stream) != hipSuccess ||
-        hipStreamSynchronize(e._stream) != hipSuccess)
-      return fail(Error::Make(ErrCode::Internal, "HIP copy of _mD failed."));
-  }
-  std::vector<double> vb((size_t)e._T);
-  if (e._elem == 8) {
-    if (std::fread(vb.data(), sizeof(double), (size_t)e._T, fc.f) != (size_t)e._T) return fail(FileErr(filePath, "Can't read the _vB weights."));
-  } else {
-    std::vector<float> vf((size_t)e._T);
-    if (std::fread(vf.data(), sizeof(float), (size_t)e._T, fc.f) != (size_t)e._T) return fail(FileErr(filePath, "Can't read the _vB weights."));
-    std::copy(vf.begin(), vf.end(), vb.begin());
-  }
-  if (hipMemcpyAsync(e._dVB, vb.data(), (size_t)e._T * sizeof(double), hipMemcpyHostToDevice, e._stream) != hipSuccess ||
-      hipStreamSynchronize(e._stream) != hipSuccess)
-    return fail(Error::Make(ErrCode::Internal, "HIP copy of _vB failed."));
+  Error ioErr = e.IoRows(fc.f, filePath, false, false);
+  if (ioErr.ok()) ioErr = e.IoRows(fc.f, filePath, true, false);
+  if (ioErr.ok()) ioErr = e.IoVB(fc.f, filePath, false);
+  if (!ioErr.ok()) return fail(std::move(ioErr));
   e._nQuestionsAsked.store(nAsked);
   auto readGaps = [&](std::vector<int64_t> &gaps, int64_t limit) {
     int64_t n;

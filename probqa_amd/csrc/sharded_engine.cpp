@@ -19,12 +19,15 @@
 //   ResumeQuiz             shard 0 computes the posterior from row POINTERS, reading other shards' rows in place over peer
 //                          access (xGMI); the other shards adopt it.
 //   Train / RecordQuizTarget   every shard applies the steps that fall on its questions (and its vB replica).
+//   SaveKB / LoadCpuEngine the file orders its rows by question: every shard streams its own block (same byte layout as a whole-cube
+//                          engine's file: a KB saved sharded loads unsharded and vice versa).
 // Where the rows are: peer access is enabled between all listed devices at creation; several shards on one device (tests on a
-// single GPU) need none.  Not sharded (NotImplemented on this engine): maintenance-mode edits of the dimensions and the .kb file.
+// single GPU) need none.  Not sharded (NotImplemented on this engine): maintenance-mode edits of the dimensions.
 #include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <cmath>
+#include <cstdio>
 #include <cstring>
 
 #include "hip_engine.h"
@@ -89,18 +92,24 @@ class ShardedEngine final : public IEngine {
   Error StartMaintenance(bool force) override { return All([&](HipEngine &e) { return e.StartMaintenance(force); }); }
   Error FinishMaintenance() override { return All([&](HipEngine &e) { return e.FinishMaintenance(); }); }
   Error Shutdown(const char *saveFilePath) override {
-    if (saveFilePath && *saveFilePath) return NotSharded("Shutdown with a KB file");
+    if (saveFilePath && *saveFilePath) { Error e = SaveKB(saveFilePath, false); if (!e.ok()) return e; }   // BaseEngine.cpp:270-300
     return All([&](HipEngine &e) { return e.Shutdown(nullptr); });
   }
   bool MapIds(int which, bool toPerm, int64_t count, int64_t *pIds) override {
-    if (which == 0) {   // questions: compact == permanent until maintenance edits, which this engine does not take
-      return true;
+    if (which == 0) {   // questions: the global compact <-> permanent map lives here (the shards' own maps are over local ids)
+      bool ok = true;
+      for (int64_t i = 0; i < count; i++) {
+        pIds[i] = toPerm ? _pimQuestions.PermFromComp(pIds[i]) : _pimQuestions.CompFromPerm(pIds[i]);
+        ok = ok && pIds[i] != -1;
+      }
+      return ok;
     }
     return _sh[0]->MapIds(which, toPerm, count, pIds);
   }
   bool EnsurePermQuizGreater(int64_t bound) override { bool ok = true; for (auto &s : _sh) ok = s->EnsurePermQuizGreater(bound) && ok; return ok; }
   bool RemapQuizPermId(int64_t a, int64_t b) override { bool ok = true; for (auto &s : _sh) ok = s->RemapQuizPermId(a, b) && ok; return ok; }
-  Error SaveKB(const char *, bool) override { return NotSharded("SaveKB"); }
+  Error SaveKB(const char *filePath, bool doubleBuffer) override;
+  static ShardedEngine *Load(Error &err, const char *filePath, const std::vector<int> &devices);
   Error AddQsTs(int64_t, CiAddQorTParam *, int64_t, CiAddQorTParam *) override { return NotSharded("AddQsTs"); }
   Error RemoveQuestions(int64_t, const int64_t *) override { return NotSharded("RemoveQuestions"); }
   Error RemoveTargets(int64_t, const int64_t *) override { return NotSharded("RemoveTargets"); }
@@ -139,7 +148,11 @@ class ShardedEngine final : public IEngine {
   }
   Error FillSynthetic(double nTrain, double noiseAmp, uint64_t seed) override { return All([&](HipEngine &e) { return e.FillSynthetic(nTrain, noiseAmp, seed); }); }
   Error SetTargetGaps(int64_t n, const int64_t *ids) override { return All([&](HipEngine &e) { return e.SetTargetGaps(n, ids); }); }
-  Error SetQuestionGaps(int64_t n, const int64_t *ids) override { return All([&](HipEngine &e) { return e.SetQuestionGaps(n, ids); }); }
+  Error SetQuestionGaps(int64_t n, const int64_t *ids) override {
+    Error e = All([&](HipEngine &eng) { return eng.SetQuestionGaps(n, ids); });
+    if (e.ok()) for (int64_t i = 0; i < n; i++) _pimQuestions.RemoveComp(ids[i]);
+    return e;
+  }
   Error EvalPriorities(int64_t iQuiz, double *pOut, int64_t n) override {
     if (n != _Q) return Error::MakeP(ErrCode::IndexOutOfRange, "n=" + std::to_string(n), "Priority buffer length must equal the question count.");
     std::lock_guard<std::mutex> lk(_mu);
@@ -207,6 +220,7 @@ class ShardedEngine final : public IEngine {
   std::vector<hipEvent_t> _copyDone;         // per shard: recorded behind its copy of another shard's posterior
   std::unordered_map<int64_t, int> _lastOwner;   // quiz -> the shard whose RecordAnswer kernel ran last (it listed the top targets)
   std::vector<double> _hostPriority;
+  PermIdMgr _pimQuestions;                   // global question ids
   uint64_t _rng[2] = {0x9E3779B97F4A7C15ULL, 0xBF58476D1CE4E5B9ULL};
 };
 
@@ -271,6 +285,7 @@ ShardedEngine *ShardedEngine::Create(Error &err, const CiEngineDefinition &def, 
   }
   eng->_select = eng->_sh[0]->GetOption("select");
   eng->_hostPriority.resize((size_t)def._nQuestions);
+  eng->_pimQuestions.GrowTo(def._nQuestions);
   err = Error();
   return eng.release();
 }
@@ -470,6 +485,111 @@ Error ShardedEngine::NextQuestionArgmaxBatch(int64_t n, const int64_t *pQuizzes,
     pOut[i] = Commit(ce, pQuizzes[i], best[(size_t)i]._iQuestion);   // -1 + QuestionsExhausted: reported as -1 only
   }
   return Error();
+}
+
+// ---- .kb file (layout of reference PqaCore/BaseEngine.cpp:323-385 + PqaCore/CpuEngine.cpp:664-688, see hip_engine_kb.cpp): the
+// file orders its rows by question, so the shards' blocks follow each other -- every shard streams its own rows through its
+// own staging buffer; vB, the target gaps and the target / quiz id maps are replicas (shard 0's are written).
+namespace {
+Error KbFileErr(const char *path, const char *msg) {
+  return Error::MakeP(ErrCode::FileOp, std::string("filePath=[") + (path ? path : "") + "]", msg);
+}
+struct FileGuard {
+  FILE *f;
+  ~FileGuard() { if (f) std::fclose(f); }
+};
+}  // namespace
+
+Error ShardedEngine::SaveKB(const char *filePath, bool doubleBuffer) {
+  (void)doubleBuffer;
+  if (!filePath) return Error::Make(ErrCode::NullArgument, "Nullptr is passed in place of KB file name.");
+  std::lock_guard<std::mutex> lk(_mu);
+  for (auto &s : _sh) { Error e = s->Synchronize(); if (!e.ok()) return e; }   // (also parks resident sweeps)
+  FileGuard fg{std::fopen(filePath, "wb")};
+  if (!fg.f) return Error::MakeP(ErrCode::CantOpenFile, std::string("filePath=[") + filePath + "]", "Can't open the file to write KB to.");
+  HipEngine &s0 = *_sh[0];
+  const uint64_t prec = (uint64_t)(s0.PrecisionType() & 0xF) | ((uint64_t)(s0.PrecMantissa() & 0xFFFFFFF) << 4) | ((uint64_t)s0.PrecExponent() << 32);
+  const int64_t dims[3] = {_K, _Q, _T};
+  Error ae;
+  const uint64_t nAsked = s0.GetTotalQuestionsAsked(ae);
+  if (std::fwrite(&prec, 8, 1, fg.f) != 1 || std::fwrite(dims, sizeof(dims), 1, fg.f) != 1 || std::fwrite(&nAsked, 8, 1, fg.f) != 1)
+    return KbFileErr(filePath, "Can't write the KB file header.");
+  for (auto &s : _sh) { Error e = s->IoRows(fg.f, filePath, false, true); if (!e.ok()) return e; }
+  for (auto &s : _sh) { Error e = s->IoRows(fg.f, filePath, true, true); if (!e.ok()) return e; }
+  { Error e = s0.IoVB(fg.f, filePath, true); if (!e.ok()) return e; }
+  std::vector<int64_t> qGaps, tGaps, tmp;
+  for (auto &s : _sh) s->GetGapLists(qGaps, tmp);
+  s0.GetGapLists(tmp, tGaps);
+  auto writeGaps = [&](const std::vector<int64_t> &gaps) {
+    const int64_t n = (int64_t)gaps.size();
+    return std::fwrite(&n, 8, 1, fg.f) == 1 && std::fwrite(gaps.data(), 8, (size_t)n, fg.f) == (size_t)n;
+  };
+  if (!writeGaps(qGaps) || !writeGaps(tGaps)) return KbFileErr(filePath, "Can't write the gaps.");
+  PermIdMgr noQuizzes;
+  if (!_pimQuestions.Save(fg.f) || !s0.TargetPim().Save(fg.f) || !noQuizzes.Save(fg.f, true))
+    return KbFileErr(filePath, "Can't write the permanent-compact ID mappings.");
+  if (std::fflush(fg.f) != 0) return KbFileErr(filePath, "Failed in hard flushing the KB.");
+  FILE *f = fg.f;
+  fg.f = nullptr;
+  if (std::fclose(f) != 0) return KbFileErr(filePath, "Failed in closing the file.");
+  return Error();
+}
+
+ShardedEngine *ShardedEngine::Load(Error &err, const char *filePath, const std::vector<int> &devices) {
+  if (!filePath) { err = Error::Make(ErrCode::NullArgument, "Nullptr is passed in place of KB file name."); return nullptr; }
+  FileGuard fg{std::fopen(filePath, "rb")};
+  if (!fg.f) { err = Error::MakeP(ErrCode::CantOpenFile, std::string("filePath=[") + filePath + "]", "Can't open the KB file to read."); return nullptr; }
+  uint64_t prec = 0, nAsked = 0;
+  int64_t dims[3];
+  if (std::fread(&prec, 8, 1, fg.f) != 1 || std::fread(dims, sizeof(dims), 1, fg.f) != 1 || std::fread(&nAsked, 8, 1, fg.f) != 1) {
+    err = KbFileErr(filePath, "Can't read the KB file header.");
+    return nullptr;
+  }
+  CiEngineDefinition def;
+  std::memset(&def, 0, sizeof(def));
+  def._nAnswers = dims[0]; def._nQuestions = dims[1]; def._nTargets = dims[2];
+  def._precType = (uint8_t)(prec & 0xF);
+  def._precMantissa = (uint32_t)((prec >> 4) & 0xFFFFFFF);
+  def._precExponent = (uint16_t)((prec >> 32) & 0xFFFF);
+  def._initAmount = 1.0;   // not stored in the file; every count is overwritten below
+  std::unique_ptr<ShardedEngine> eng(Create(err, def, devices));
+  if (!eng) return nullptr;
+  auto fail = [&](Error e) { err = std::move(e); return (ShardedEngine *)nullptr; };
+  for (auto &s : eng->_sh) { Error e = s->IoRows(fg.f, filePath, false, false); if (!e.ok()) return fail(std::move(e)); }
+  for (auto &s : eng->_sh) { Error e = s->IoRows(fg.f, filePath, true, false); if (!e.ok()) return fail(std::move(e)); }
+  {
+    Error e = eng->_sh[0]->IoVB(fg.f, filePath, false);
+    if (!e.ok()) return fail(std::move(e));
+    std::vector<double> vb((size_t)dims[2]);   // shard 0's vB (already in the engine's number type) to the other replicas
+    e = eng->_sh[0]->GetKB(nullptr, nullptr, vb.data());
+    for (size_t i = 1; e.ok() && i < eng->_sh.size(); i++) e = eng->_sh[i]->SetVBFromHost(vb.data());
+    if (!e.ok()) return fail(std::move(e));
+  }
+  eng->_sh[0]->SetQuestionsAsked(nAsked);
+  auto readGaps = [&](std::vector<int64_t> &gaps, int64_t limit) {
+    int64_t n;
+    if (std::fread(&n, 8, 1, fg.f) != 1 || n < 0 || n > limit) return false;
+    gaps.resize((size_t)n);
+    if (std::fread(gaps.data(), 8, (size_t)n, fg.f) != (size_t)n) return false;
+    for (int64_t g : gaps) if (g < 0 || g >= limit) return false;
+    return true;
+  };
+  std::vector<int64_t> qGaps, tGaps;
+  if (!readGaps(qGaps, dims[1]) || !readGaps(tGaps, dims[2])) return fail(KbFileErr(filePath, "Can't read the gaps."));
+  for (auto &s : eng->_sh) {
+    Error e = s->SetQuestionGaps((int64_t)qGaps.size(), qGaps.data());
+    if (e.ok()) e = s->SetTargetGaps((int64_t)tGaps.size(), tGaps.data());
+    if (!e.ok()) return fail(std::move(e));
+  }
+  PermIdMgr pimT, pimZ;
+  if (!eng->_pimQuestions.Load(fg.f) || !pimT.Load(fg.f) || !pimZ.Load(fg.f)) return fail(KbFileErr(filePath, "Can't read the permanent-compact ID mappings."));
+  for (auto &s : eng->_sh) { s->SetTargetPim(pimT); s->SetQuizPim(pimZ); }
+  err = Error();
+  return eng.release();
+}
+
+IEngine *LoadShardedEngine(Error &err, const char *filePath, const std::vector<int> &devices) {
+  return ShardedEngine::Load(err, filePath, devices);
 }
 
 IEngine *CreateShardedEngine(Error &err, const CiEngineDefinition &def, const std::vector<int> &devices) {

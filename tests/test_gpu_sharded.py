@@ -102,10 +102,53 @@ def test_sharded_engine_behind_the_plain_abi(case, spec, factory):
     quizzes = [q3] + [sh.start_quiz() for _ in range(39)]
     _, opri = orc.eval(SUBTASKS)
     assert sh.next_question_argmax_batch(quizzes) == [orc.select_argmax(opri)] * 40
-    e = sh.save_kb("/tmp/never.kb", False, throw=False)
+    sh.start_maintenance(True)                      # maintenance edits of the dimensions are not sharded
+    e = sh.add_qs_ts([interop.AddQuestionParam(1.0)], [], throw=False)
     assert e is not None and "sharded engine" in e.to_string(True)
+    sh.finish_maintenance()
     sh.close()
     whole.close()
+
+
+@pytest.mark.parametrize("prec", ["f64", "f32"])
+def test_kb_file_crosses_between_sharded_and_whole_engines(prec, factory, tmp_path):
+    """A .kb file written by a sharded engine loads into a whole-cube engine and the other way round (same byte layout: the
+    file orders its rows by question, every shard streams its own block), gaps and id maps included."""
+    import test_gpu_batch as tb
+
+    case = cases.small_cases()[1]            # 37 x 5 x 101 with target and question gaps
+    def make():
+        if prec == "f32":
+            return tb.float_engine(case, factory)[0]
+        return case.make_engine(factory)
+    with devices("0,0,0"):
+        sh = make()
+    whole = make()
+    train = [(5, 1), (30, 2), (17, 0)]
+    for e in (sh, whole):
+        e.train([interop.AnsweredQuestion(q, a) for q, a in train], 7, 1.3)
+    p_sh, p_wh = str(tmp_path / "sharded.kb"), str(tmp_path / "whole.kb")
+    sh.save_kb(p_sh, False)
+    whole.save_kb(p_wh, False)
+    assert open(p_sh, "rb").read() == open(p_wh, "rb").read()           # byte-identical files
+    from_sharded, err = factory.load_cpu_engine(p_sh)                    # sharded file -> whole engine
+    assert err is None and from_sharded.get_option("shards") == -1
+    with devices("0,0"):
+        from_whole, err = factory.load_cpu_engine(p_wh)                  # whole file -> sharded engine (another split)
+    assert err is None and from_whole.get_option("shards") == 2
+    ref = whole.get_kb(case.Q)
+    for e in (from_sharded, from_whole):
+        for a, b in zip(ref, e.get_kb(case.Q)):
+            assert np.array_equal(a, b)
+        assert e.get_total_questions_asked() == whole.get_total_questions_asked()
+        assert e.question_perm_from_comp([0, 5, 36]) == whole.question_perm_from_comp([0, 5, 36])
+        assert e.target_perm_from_comp([0, 50, 100]) == whole.target_perm_from_comp([0, 50, 100])
+        qa, qb = e.start_quiz(), whole.start_quiz()
+        assert np.array_equal(e.get_priors(qa), whole.get_priors(qb))
+        assert np.array_equal(e.eval_priorities(qa, case.Q), whole.eval_priorities(qb))
+        whole.release_quiz(qb)
+    for e in (sh, whole, from_sharded, from_whole):
+        e.close()
 
 
 def test_sharded_engine_exhausts_questions_like_the_whole_one(factory):
