@@ -14,12 +14,15 @@ from probqa_amd import interop, synth
 pytestmark = pytest.mark.gpu
 
 
-def make(factory, K, Q, T, init=0.1, seed=5):
-    eng, err = factory.create_cpu_engine(interop.EngineDefinition(K, Q, T, init_amount=init))
+def make(factory, K, Q, T, init=0.1, seed=5, f32=False):
+    kw = dict(prec_type=interop.PrecisionType.FLOAT, prec_exponent=8, prec_mantissa=24) if f32 else {}
+    eng, err = factory.create_cpu_engine(interop.EngineDefinition(K, Q, T, init_amount=init, **kw))
     assert err is None, err
     eng.set_option("workers", cases.WORKERS)
     A, D, B = synth.synthetic_kb(K, Q, T, init, 8.0, 0.5, seed)
     eng.set_kb(A, D, B)
+    if f32:   # a Float engine holds the values rounded to fp32
+        A, D, B = (x.astype(np.float32).astype(np.float64) for x in (A, D, B))
     return eng, A, D, B
 
 
@@ -106,9 +109,11 @@ def test_dimensions_growth_like_reference_test(factory):
     eng.close()
 
 
-def test_add_remove_compact_against_numpy_model(factory):
+@pytest.mark.parametrize("f32", [False, True], ids=["double", "float"])
+def test_add_remove_compact_against_numpy_model(f32, factory):
     K, Q, T = 4, 12, 19
-    eng, A, D, B = make(factory, K, Q, T, seed=9)
+    r = (lambda x: float(np.float32(x))) if f32 else (lambda x: x)      # the engine's number type
+    eng, A, D, B = make(factory, K, Q, T, seed=9, f32=f32)
     eng.start_maintenance(False)
     eng.remove_questions([2, 9])
     eng.remove_targets([0, 5, 18])
@@ -122,9 +127,9 @@ def test_add_remove_compact_against_numpy_model(factory):
     A = np.concatenate([A, np.zeros((1, K, T))], axis=0)
     D = np.concatenate([D, np.zeros((1, T))], axis=0)
     for t, amount in ((18, 0.3), (5, 0.7)):          # reused target columns over the questions not re-initialised
-        A[:, :, t], D[:, t], B[t] = amount * amount, amount * amount * K, amount
+        A[:, :, t], D[:, t], B[t] = r(amount * amount), r(amount * amount * K), r(amount)
     for q, amount in ((9, 0.5), (2, 0.25), (12, 2.0)):  # whole questions, every column
-        A[q], D[q] = amount * amount, amount * amount * K
+        A[q], D[q] = r(amount * amount), r(amount * amount * K)
     d = eng.copy_dims()
     assert (d.n_questions, d.n_targets) == (13, 19)
     A2, D2, B2 = eng.get_kb()
@@ -146,7 +151,7 @@ def test_add_remove_compact_against_numpy_model(factory):
     assert eng.question_perm_from_comp([3]) == [14] and eng.question_comp_from_perm([14, 3]) == [3, -1]
     eng.finish_maintenance()
     # the compacted KB behaves like a KB created with those numbers
-    ref, *_ = make(factory, K, 11, 18)
+    ref, *_ = make(factory, K, 11, 18, f32=f32)
     ref.set_kb(A3, D3, B3)
     q1, q2 = eng.start_quiz(), ref.start_quiz()
     assert np.array_equal(eng.get_priors(q1), ref.get_priors(q2))
