@@ -37,16 +37,33 @@ class Shadow:
         return [(t, p[t]) for t in order]
 
 
-@pytest.mark.parametrize("seed,resident", [(1, False), (2, False), (3, False), (4, True), (5, True)],
-                         ids=["seed1", "seed2", "seed3", "seed4_resident_sweep", "seed5_resident_sweep"])
-def test_random_interleaving_against_per_quiz_oracles(factory, seed, resident):
+@pytest.mark.parametrize("seed,mode", [(1, "plain"), (2, "plain"), (3, "plain"), (4, "resident"), (5, "resident"),
+                                       (6, "row_sharing_batches"), (7, "three_shards"), (8, "three_shards")],
+                         ids=["seed1", "seed2", "seed3", "seed4_resident_sweep", "seed5_resident_sweep", "seed6_row_sharing_batches",
+                              "seed7_three_shards", "seed8_three_shards"])
+def test_random_interleaving_against_per_quiz_oracles(factory, seed, mode):
+    import os
+
     rng = np.random.default_rng(seed)
     kb = list(synth.synthetic_kb(K, Q, T, 0.1, 8.0, 0.5, 100 + seed))
-    eng, err = factory.create_cpu_engine(interop.EngineDefinition(K, Q, T, init_amount=0.1))
+    saved = os.environ.get("PQA_DEVICES")
+    if mode == "three_shards":     # the same calls through the one-process sharded engine (three shards on this box's one device)
+        os.environ["PQA_DEVICES"] = "0,0,0"
+    try:
+        eng, err = factory.create_cpu_engine(interop.EngineDefinition(K, Q, T, init_amount=0.1))
+    finally:
+        if saved is None:
+            os.environ.pop("PQA_DEVICES", None)
+        else:
+            os.environ["PQA_DEVICES"] = saved
     assert err is None
+    assert eng.get_option("shards") == (3 if mode == "three_shards" else -1)
     eng.set_kb(*kb)
     eng.set_option("workers", cases.WORKERS)
     eng.set_option("select", 1)
+    resident = mode == "resident"
+    if mode == "row_sharing_batches":
+        eng.set_option("batch_min", 1)   # every batch through the lane-per-quiz sweep
     if resident:
         # plain selections through the resident kernel (stopped and restarted by the launches, the training and the idle
         # time in between), five workgroups streaming the questions
