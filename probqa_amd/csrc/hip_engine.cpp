@@ -284,6 +284,7 @@ void HipEngine::ApplyEnvironment() {
   int64_t x = 0;
   if (num("PQA_SERVER", 0, 1, x)) _optServer = x;
   if (num("PQA_BUG_COMPAT", 0, 1, x)) _optBugCompat = x;
+  if (num("PQA_SPECULATE", 0, 1, x)) _optSpeculate = x;
   if (num("PQA_WORKERS", 1, kMaxWorkers, x)) _optWorkers = x;
   if (num("PQA_SEED", INT64_MIN, INT64_MAX, x)) { uint64_t s = (uint64_t)x; _rng[0] = SplitMix64(s); _rng[1] = SplitMix64(s); }
 }
@@ -340,8 +341,9 @@ Error HipEngine::SetOption(const char *name, int64_t value) {
   else if (n == "eval_variant") { if (value < 0) goto bad; _optEvalVariant = value; }
   else if (n == "bug_compat") { _optBugCompat = value ? 1 : 0; }
   else if (n == "use_graph") { _optUseGraph = value ? 1 : 0; }
-  else if (n == "top_cache") { if (value < 0 || value > 256) goto bad; _optTopCache = value; }
-  else if (n == "server") { if (!value) StopServer(); _optServer = value ? 1 : 0; }
+  else if (n == "top_cache") { if (value < 0 || value > 256) goto bad; _optTopCache = value; _topWantRecent = value; }
+  else if (n == "server") { StopServer(); _optServer = value ? 1 : 0; }
+  else if (n == "speculate") { DropSpeculation(); _optSpeculate = value ? 1 : 0; _specScore = 0; }
   else if (n == "eval_max_grid") { if (value < 0 || value > 65535) goto bad; StopServer(); _optEvalMaxGrid = value; _kbVersion++; }
   else if (n == "fused_sampled") { _optFusedSampled = value ? 1 : 0; }
   else if (n == "host_sampled") { _optHostSampled = value ? 1 : 0; }
@@ -370,6 +372,9 @@ int64_t HipEngine::GetOption(const char *name) const {
   if (n == "server_idle_us") return _optServerIdleUs;
   if (n == "fused_sampled") return _optFusedSampled;
   if (n == "host_sampled") return _optHostSampled;
+  if (n == "speculate") return _optSpeculate;
+  if (n == "spec_hits") return (int64_t)_specHits;         // speculative sweeps a NextQuestion used ...
+  if (n == "spec_dropped") return (int64_t)_specDropped;   // ... and those nothing used
   if (n == "batch_min") return _optBatchMin;
   if (n == "batch_tile") return _optBatchTile;
   if (n == "batch_qb") return _optBatchQb;
@@ -430,6 +435,7 @@ void HipEngine::DestroyQuiz(Quiz *q) {
   ServerQuiesce();
   if (!q) return;
   if (_topOwner == q) _topOwner = nullptr;
+  if (_spec.quiz == q) DropSpeculation();
   {
     auto it = _graphs.find(q);
     if (it != _graphs.end()) { hipGraphExecDestroy(it->second.exec); _graphs.erase(it); }
@@ -833,11 +839,14 @@ int64_t HipEngine::NextQuestionArgmax(Error &err, int64_t iQuiz) {
   }
   // One launch; the last workgroup writes the winner and then a sequence number straight into host-coherent pinned
   // memory, which this thread polls: no D2H copy, no stream synchronisation on the critical path.
-  const uint64_t seq = NextLaunchTag();
-  const FusedSelect fs{_dSelScratch, &_hPinned->sel, &_hPinned->seq, seq, 0, 0, seq, nullptr, 0, 0, nullptr, nullptr};
-  StopServer();   // a launched sweep has no room beside the resident one and would wait for it to idle out
-  err = LaunchSingleSweep(q, &fs);
-  if (!err.ok()) return -1;
+  uint64_t seq;
+  if (!TakeSpeculation(q, 1, &seq)) {   // (else: RecordAnswer has launched this very sweep already)
+    seq = NextLaunchTag();
+    const FusedSelect fs{_dSelScratch, &_hPinned->sel, &_hPinned->seq, seq, 0, 0, seq, nullptr, 0, 0, nullptr, nullptr};
+    StopServer();   // a launched sweep has no room beside the resident one and would wait for it to idle out
+    err = LaunchSingleSweep(q, &fs);
+    if (!err.ok()) return -1;
+  }
   err = WaitFlag(&_hPinned->seq, seq, "NextQuestionArgmax");
   if (!err.ok()) return -1;
   std::atomic_thread_fence(std::memory_order_acquire);
@@ -854,6 +863,7 @@ int64_t HipEngine::NextQuestionArgmax(Error &err, int64_t iQuiz) {
 bool HipEngine::ServerUsable() const { return _elem == 8 && EvalServerSupported(View(), (int)_optEvalVariant) && _Q > 0; }
 
 void HipEngine::StopServer() {
+  DropSpeculation();   // whatever ends the resident sweep's view of the engine (cube, gaps, stream, buffers) ends a speculative result's too
   if (!_serverLaunched) return;
   hipSetDevice(_device);
   _serverRequest[7] = 1;                 // `stop`
@@ -1209,17 +1219,22 @@ int64_t HipEngine::NextQuestionSampled(Error &err, int64_t iQuiz, uint64_t rnd) 
     const int64_t sel = SelectSampledHost(_hHostPriority, _Q, nSub, rnd, [&](int64_t i) { return BitTest(_hQGap, i) || BitTest(q->hAsked, i); });
     return FinishSelection(err, q, sel);
   }
-  StopServer();   // a launched sweep has no room beside the resident one and would wait for it to idle out
+  uint64_t specTag = 0;
+  const bool speculated = TakeSpeculation(q, 2, &specTag);   // RecordAnswer has launched the sweep already
+  if (!speculated) StopServer();   // a launched sweep has no room beside the resident one and would wait for it to idle out
   if (_optHostSampled && !_optFusedSampled && _elem == 8 && EvalVariantHasFinisherWorkgroup(kb, (int)_optEvalVariant)) {
     // ONE launch, and the selection on the host: the sweep's finisher workgroup copies the finished priority vector (8 bytes per
     // question) into host-coherent memory and sets the flag; the selector's O(Q) scalar Kahan steps take the host a few
     // microseconds -- less than the dispatch of the selector kernel they replace.
     const hipError_t ae = EnsureHostPriority();
     if (ae != hipSuccess) { err = HipErr(ae, "host priority buffer"); return -1; }
-    const uint64_t seq = NextLaunchTag();
-    const FusedSelect fs{_dSelScratch, &_hPinned->sel, &_hPinned->seq, seq, 0, 0, seq, nullptr, 1, 0, nullptr, _hHostPriority};
-    const hipError_t he = LaunchEvalQuestions(kb, q->dPrior, q->dAsked, 0, _Q, _dPriority, (int)_optEvalVariant, &fs, _stream);
-    if (he != hipSuccess) { err = HipErr(he, "NextQuestionSampled"); return -1; }
+    uint64_t seq = specTag;
+    if (!speculated) {
+      seq = NextLaunchTag();
+      const FusedSelect fs{_dSelScratch, &_hPinned->sel, &_hPinned->seq, seq, 0, 0, seq, nullptr, 1, 0, nullptr, _hHostPriority};
+      const hipError_t he = LaunchEvalQuestions(kb, q->dPrior, q->dAsked, 0, _Q, _dPriority, (int)_optEvalVariant, &fs, _stream);
+      if (he != hipSuccess) { err = HipErr(he, "NextQuestionSampled"); return -1; }
+    }
     err = WaitFlag(&_hPinned->seq, seq, "NextQuestionSampled");
     if (!err.ok()) return -1;
     if (_hPinned->sel.index == -3) { err = HipErr(hipErrorLaunchFailure, "NextQuestionSampled (incomplete sweep)"); return -1; }
@@ -1310,7 +1325,8 @@ Error HipEngine::RecordAnswerImpl(int64_t iQuiz, int64_t iAnswer, bool remote) {
   const int64_t nLoose = std::max<int64_t>(1, _optWorkers - 1);
   // One launch, no copy, no synchronisation: the kernel also sets the question's bit in the device bitmap, and everything
   // that reads the posterior or the bitmap afterwards is ordered behind it on the engine's stream.
-  const int64_t topCount = std::min<int64_t>(std::min<int64_t>(_optTopCache, 256), _T);
+  // as many as ListTopTargets has been asking for lately (every listed target is a round of the kernel's selection), `top_cache` at most
+  const int64_t topCount = std::min<int64_t>(std::min<int64_t>(std::min<int64_t>(_optTopCache, _topWantRecent), 256), _T);
   const uint64_t op = ++_opSeq;
   HIP_TRY(LaunchRecordAnswer(View(), q->dPrior, q->dAsked, ql, iAnswer, nLoose, _hPinned->top, &_hPinned->nOut,
                              &_hPinned->topFlag, op, topCount, _stream));
@@ -1320,7 +1336,48 @@ Error HipEngine::RecordAnswerImpl(int64_t iQuiz, int64_t iAnswer, bool remote) {
     _pendingRecordOp = op;
     _mu.busy = _mu.wasBusy;   // (busy only if it was before this call: `op` covers this call's launch)
   }
+  Speculate(q);
   return Error();
+}
+
+// The sweep NextQuestion would launch for `q` now, launched now (see Speculation in hip_engine.h).  Whole-cube Double engines
+// with the launched selection paths only: the resident sweep and graph replay have no launch to move, shards' selections are
+// driven by the sharded engine, and the Float sweep has no finisher that hands its result over.
+void HipEngine::Speculate(Quiz *q) {
+  DropSpeculation();   // (one at a time: the hand-over buffers are the engine's)
+  if (!_optSpeculate || _optServer || _optUseGraph || _elem != 8 || _qTotal != _Q || _Q <= 0) return;
+  if (_specScore < -4 && (++_specProbe & 31) != 0) return;   // the client does not follow RecordAnswer with NextQuestion: probe now and then
+  const KbView kb = View();
+  int kind = 0;
+  if (_optSelect == 1) kind = 1;
+  else if (_optHostSampled && !_optFusedSampled && EvalVariantHasFinisherWorkgroup(kb, (int)_optEvalVariant)) kind = 2;
+  if (kind == 0) return;
+  if (kind == 2 && EnsureHostPriority() != hipSuccess) return;
+  const uint64_t seq = NextLaunchTag();
+  const FusedSelect fs{_dSelScratch, &_hPinned->sel, &_hPinned->seq, seq, 0, 0, seq, nullptr, kind == 2 ? 1 : 0, 0, nullptr,
+                       kind == 2 ? _hHostPriority : nullptr};
+  if (LaunchEvalQuestions(kb, q->dPrior, q->dAsked, 0, _Q, _dPriority, (int)_optEvalVariant, &fs, _stream) != hipSuccess) {
+    (void)hipGetLastError();   // NextQuestion will launch for itself and report
+    return;
+  }
+  _spec.quiz = q; _spec.priorVersion = q->priorVersion; _spec.tag = seq; _spec.kind = kind;
+  _spec.variant = _optEvalVariant; _spec.stream = _stream;
+  _pendingRecordOp = 0;   // the posterior kernel's flag no longer says that the stream is idle
+  _mu.busy = true;
+}
+
+// True (and the launch tag to wait for) if the pending speculative sweep is exactly the launch a NextQuestion of `kind` for `q`
+// would make now: same quiz and posterior, no fused launch since (they share the records and the hand-over buffers).
+bool HipEngine::TakeSpeculation(Quiz *q, int kind, uint64_t *pTag) {
+  if (_spec.quiz == nullptr) return false;
+  const bool match = _spec.quiz == q && _spec.kind == kind && _spec.priorVersion == q->priorVersion && _spec.tag == _selSeq &&
+                     _spec.variant == _optEvalVariant && _spec.stream == _stream && !_optServer && !_optUseGraph;
+  if (!match) { DropSpeculation(); return false; }
+  _spec.quiz = nullptr;
+  _specHits++;
+  if (_specScore < 8) _specScore++;
+  *pTag = _spec.tag;
+  return true;
 }
 
 Error HipEngine::RecordAnswer(int64_t iQuiz, int64_t iAnswer) { return RecordAnswerImpl(iQuiz, iAnswer, false); }
@@ -1396,6 +1453,7 @@ int64_t HipEngine::ListTopTargets(Error &err, int64_t iQuiz, int64_t maxCount, C
   if (!pDest) { err = Error::Make(ErrCode::NullArgument, "Nullptr is passed in place of the destination."); return -1; }
   hipSetDevice(_device);
   const int64_t want = std::min<int64_t>(maxCount, _T);
+  _topWantRecent = want >= _topWantRecent ? want : want + (_topWantRecent - want) * 7 / 8;   // (decays towards smaller requests)
   if (want <= 256 && _T <= 16384) {  // (the kernel keeps every target in registers: 16 per thread at most)
     // the kernel lists straight into host-coherent memory and then stores the operation number: no copy, no synchronise
     const bool cached = _topOwner == q && _topVersion == q->priorVersion;

@@ -364,7 +364,28 @@ class HipEngine : public IEngine {
   int64_t _optBatchMin = 0;       // batches of at least this many quizzes take the row-sharing sweep (lane = quiz), smaller ones grid.y = quiz; 0 = by the number of waves the batch gives the row-sharing sweep
   int64_t _optBatchQb = 0;        // questions per block of that sweep (0 = default)
   int64_t _optBatchTile = 0;      // targets per LDS tile of that sweep (0 = default)
+  // ---- the next sweep ahead of its request (option "speculate"): RecordAnswer enqueues, right behind its posterior kernel, the
+  // sweep the NextQuestion that normally follows would launch -- the client's time between the two calls (the wrapper's own
+  // overhead, ListTopTargets, a person reading the question) overlaps with it, and that NextQuestion only waits for the flag.
+  // The result is used only if nothing has touched the quiz, the cube, the gaps or the hand-over buffers since (every such
+  // operation drops it); the random number of the sampled selector is drawn when NextQuestion is called, as before.
+  struct Speculation {
+    Quiz *quiz = nullptr;
+    uint64_t priorVersion = 0, tag = 0;
+    int kind = 0;            // 1: argmax record in _hPinned->sel; 2: priority vector in _hHostPriority
+    int64_t variant = 0;
+    hipStream_t stream = nullptr;
+  } _spec;
+  int64_t _optSpeculate = 1;
+  int _specScore = 0;        // +1 per speculation used, -1 per speculation dropped: below -4 only every 32nd RecordAnswer speculates
+  uint64_t _specProbe = 0, _specHits = 0, _specDropped = 0;
+  void Speculate(Quiz *q);
+  bool TakeSpeculation(Quiz *q, int kind, uint64_t *pTag);
+  void DropSpeculation() {
+    if (_spec.quiz != nullptr) { _spec.quiz = nullptr; _specDropped++; if (_specScore > -8) _specScore--; }
+  }
   int64_t _optUseGraph = 0;   // NextQuestion (argmax) replays a per-quiz HIP graph instead of launching
+  int64_t _topWantRecent = 10;   // what ListTopTargets has been asked for lately
   int64_t _optTopCache = 10;  // targets RecordAnswer's kernel lists ahead of the ListTopTargets that follows it (0: none)
   // ---- resident sweep (option "server"; pqa_kernels.h: ServerMailbox)
   int64_t _optServer = 0, _optServerIdleUs = 500, _optServerVramMailbox = 1;

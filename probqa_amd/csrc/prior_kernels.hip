@@ -32,10 +32,11 @@ static inline bool small_launch(const KbView &kb) { return kb.smallLaunches && k
 __global__ __launch_bounds__(kThreads) void start_quiz_kernel(PriorArgs a) {
   extern __shared__ double lds[];
   const int64_t nVects = (a.T + 3) >> 2;
+  double *stage = prior_stage(a, lds);
   for (int64_t t = threadIdx.x; t < a.ldT; t += blockDim.x)
-    a.prior[t] = bit_test(a.tgap, t) ? 0.0 : a.vB[t];          // CESetPriorsSubtaskSum.cpp:28-31
-  const double total = reference_order_sum(a.prior, nVects, a.nWorkers, lds);
-  for (int64_t t = threadIdx.x; t < 4 * nVects; t += blockDim.x) a.prior[t] = a.prior[t] / total;  // CEDivTargPriors :19
+    stage[t] = bit_test(a.tgap, t) ? 0.0 : a.vB[t];            // CESetPriorsSubtaskSum.cpp:28-31
+  const double total = reference_order_sum(stage, nVects, a.nWorkers, lds);
+  for (int64_t t = threadIdx.x; t < a.ldT; t += blockDim.x) a.prior[t] = t < 4 * nVects ? stage[t] / total : stage[t];  // CEDivTargPriors :19
 }
 
 template <bool SMALL>
@@ -124,8 +125,13 @@ __global__ __launch_bounds__(kThreads) void resume_quiz_kernel(PriorArgs a, int6
 }
 
 size_t sum_lds_bytes(int64_t nWorkers) { return (size_t)(8 * nWorkers + 1) * sizeof(double); }
+// (64 KB of dynamic LDS need no opt-in; 1000 targets at 16 workers: 9 KB)
+bool stage_fits(const KbView &kb, int64_t nWorkers) { return sum_lds_bytes(nWorkers) + (size_t)kb.ldT * sizeof(double) <= 65536; }
+size_t staged_lds_bytes(const KbView &kb, int64_t nWorkers) {
+  return sum_lds_bytes(nWorkers) + (stage_fits(kb, nWorkers) ? (size_t)kb.ldT * sizeof(double) : 0);
+}
 
-PriorArgs make_args(const KbView &kb, double *prior, int64_t nWorkers) {
+PriorArgs make_args(const KbView &kb, double *prior, int64_t nWorkers, bool staged = false) {
   PriorArgs a;
   a.cube = kb.cube;
   a.elem = kb.elem;
@@ -136,6 +142,7 @@ PriorArgs make_args(const KbView &kb, double *prior, int64_t nWorkers) {
   a.T = kb.T;
   a.ldT = kb.ldT;
   a.nWorkers = nWorkers;
+  a.stage = staged && stage_fits(kb, nWorkers) ? 1 : 0;
   return a;
 }
 
@@ -143,8 +150,8 @@ PriorArgs make_args(const KbView &kb, double *prior, int64_t nWorkers) {
 
 hipError_t LaunchStartQuiz(const KbView &kb, double *prior, int64_t nWorkers, hipStream_t stream) {
   if (nWorkers < 1 || nWorkers > kMaxWorkers) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(start_quiz_kernel, dim3(1), dim3(small_launch(kb) ? kSmallThreads : kThreads), sum_lds_bytes(nWorkers), stream,
-                     make_args(kb, prior, nWorkers));
+  hipLaunchKernelGGL(start_quiz_kernel, dim3(1), dim3(small_launch(kb) ? kSmallThreads : kThreads), staged_lds_bytes(kb, nWorkers), stream,
+                     make_args(kb, prior, nWorkers, true));
   return hipGetLastError();
 }
 
@@ -154,11 +161,11 @@ hipError_t LaunchRecordAnswer(const KbView &kb, double *prior, uint32_t *asked, 
   if (nWorkers < 1 || nWorkers > kMaxWorkers) return hipErrorInvalidValue;
   const TopRequest top{reinterpret_cast<TopOut *>(topOut), topN, topFlag, topFlagValue, (topOut && kb.T <= 16384) ? topCount : 0};
   if (small_launch(kb))
-    hipLaunchKernelGGL(record_answer_kernel<true>, dim3(1), dim3(kSmallThreads), sum_lds_bytes(nWorkers), stream,
-                       make_args(kb, prior, nWorkers), iQuestion, iAnswer, asked, top);
+    hipLaunchKernelGGL(record_answer_kernel<true>, dim3(1), dim3(kSmallThreads), staged_lds_bytes(kb, nWorkers), stream,
+                       make_args(kb, prior, nWorkers, true), iQuestion, iAnswer, asked, top);
   else
-    hipLaunchKernelGGL(record_answer_kernel<false>, dim3(1), dim3(kThreads), sum_lds_bytes(nWorkers), stream,
-                       make_args(kb, prior, nWorkers), iQuestion, iAnswer, asked, top);
+    hipLaunchKernelGGL(record_answer_kernel<false>, dim3(1), dim3(kThreads), staged_lds_bytes(kb, nWorkers), stream,
+                       make_args(kb, prior, nWorkers, true), iQuestion, iAnswer, asked, top);
   return hipGetLastError();
 }
 

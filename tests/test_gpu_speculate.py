@@ -1,0 +1,109 @@
+"""The sweep ahead of its request (option "speculate", hip_engine.h: Speculation): RecordAnswer launches the sweep the following
+NextQuestion would launch.  Same questions as an engine that does not speculate and as the oracle, on every step; the result is
+dropped when anything touches the quiz, the cube or the gaps in between."""
+import numpy as np
+import pytest
+
+import cases
+from probqa_amd import interop
+
+pytestmark = pytest.mark.gpu
+
+SUBTASKS = 8 * cases.WORKERS
+
+
+def make(case, factory, speculate, select):
+    eng = case.make_engine(factory)
+    eng.set_option("speculate", speculate)
+    eng.set_option("select", select)
+    eng.set_option("seed", 77)
+    return eng
+
+
+@pytest.mark.parametrize("select", [0, 1], ids=["sampled", "argmax"])
+@pytest.mark.parametrize("dims", [(5, 40, 300), (5, 1000, 1000), (3, 64, 2500)], ids=lambda d: "%dx%dx%d" % (d[1], d[0], d[2]))
+def test_same_questions_with_and_without(dims, select, factory):
+    K, Q, T = dims
+    case = cases.Case("spec", K, Q, T, seed=31)
+    a, b = make(case, factory, 1, select), make(case, factory, 0, select)
+    orc = case.make_oracle()
+    rng = np.random.default_rng(5)
+    qa, qb = a.start_quiz(), b.start_quiz()
+    orc.start_quiz(cases.WORKERS)
+    n_steps = min(12, Q - 1)
+    for step in range(n_steps):
+        if select == 1:
+            ga, gb = a.next_question(qa), b.next_question(qb)
+            run, opri = orc.eval(SUBTASKS)
+            assert ga == gb == orc.select_argmax(opri), step
+        else:
+            rnd = int(rng.integers(0, 2**63)) * 2 + int(rng.integers(0, 2))
+            ga, gb = a.next_question_sampled(qa, rnd), b.next_question_sampled(qb, rnd)
+            run, opri = orc.eval(SUBTASKS)
+            assert ga == gb == orc.select_sampled(run, SUBTASKS, rnd), step
+        ans = int(rng.integers(0, K))
+        a.record_answer(qa, ans)
+        b.record_answer(qb, ans)
+        orc.record_answer(ga, ans, cases.WORKERS - 1)
+        if step % 3 == 2:   # the cached top targets are RecordAnswer's own; asking for them leaves the speculation alone
+            ta, tb = a.list_top_targets(qa, 3), b.list_top_targets(qb, 3)
+            assert [(t.i_target, t.prob) for t in ta] == [(t.i_target, t.prob) for t in tb]
+    assert np.array_equal(a.get_priors(qa), orc.priors())
+    # every NextQuestion after the first found its sweep launched; the last RecordAnswer's speculation is still pending
+    assert a.get_option("spec_hits") == n_steps - 1
+    assert b.get_option("spec_hits") == 0 and b.get_option("spec_dropped") == 0
+    a.release_quiz(qa)
+    assert a.get_option("spec_dropped") == 1
+    a.close()
+    b.close()
+
+
+def test_dropped_when_something_intervenes(factory):
+    """Between RecordAnswer and NextQuestion: another quiz's selection, training (the cube changes), new gaps, a changed
+    posterior.  The question asked afterwards is the one an engine that never speculates asks in the same state."""
+    case = cases.Case("spec_drop", 5, 48, 400, seed=32)
+    a, b = make(case, factory, 1, 1), make(case, factory, 0, 1)
+
+    def both(fn):
+        ra, rb = fn(a), fn(b)
+        assert ra == rb
+        return ra
+
+    q1 = both(lambda e: e.start_quiz())
+    q2 = both(lambda e: e.start_quiz())
+    first = both(lambda e: e.next_question(q1))
+    both(lambda e: e.record_answer(q1, 2))
+    both(lambda e: e.next_question(q2))                      # another quiz's sweep takes the hand-over buffers
+    dropped = a.get_option("spec_dropped")
+    assert dropped >= 1
+    second = both(lambda e: e.next_question(q1))
+    assert second != first
+    both(lambda e: e.record_answer(q1, 1))
+    both(lambda e: e.train([interop.AnsweredQuestion(3, 1), interop.AnsweredQuestion(7, 4)], 11, 5.0))       # the cube changes under the speculative result
+    assert a.get_option("spec_dropped") == dropped + 1
+    both(lambda e: e.next_question(q1))
+    both(lambda e: e.record_answer(q1, 0))
+    nxt = int(np.argmax(b.eval_priorities(q1)))
+    both(lambda e: e.set_question_gaps([nxt]))               # the question the speculation has picked goes away
+    got = both(lambda e: e.next_question(q1))
+    assert got != nxt
+    both(lambda e: e.record_answer(q1, 3))
+    both(lambda e: e.record_answer(q2, 3))                   # the newer RecordAnswer's speculation replaces the older one
+    both(lambda e: e.next_question(q2))                      # ... and serves that quiz
+    assert a.get_option("spec_hits") == 1
+    both(lambda e: e.next_question(q1))
+    a.close()
+    b.close()
+
+
+def test_stops_speculating_for_a_client_that_never_follows_up(factory):
+    case = cases.Case("spec_idle", 5, 32, 200, seed=33)
+    eng = make(case, factory, 1, 1)
+    quiz = eng.start_quiz()
+    for q in range(30):            # answers to questions the client picks itself: no NextQuestion at all
+        eng.set_active_question(quiz, q)
+        eng.record_answer(quiz, q % 5)
+    # after five drops in a row only every 32nd RecordAnswer speculates
+    assert eng.get_option("spec_dropped") <= 8
+    assert eng.get_option("spec_hits") == 0
+    eng.close()
