@@ -267,6 +267,11 @@ __device__ __forceinline__ void flush_pending(const EvalArgs &a, const double *p
     const int64_t q = reinterpret_cast<const int64_t *>(rec)[2 * K + 2];
     const double pri = eval_epilogue(rec, -rec[2 * K], rec + K, K, rec[2 * K + 1], a.vCompTail);  // :130
     store_priority(a.priority + (q - a.qFirst), pri);
+    // hand-over of the priority vector to the host (FusedSelect::hostPriority): every workgroup delivers its own questions as it
+    // finishes them -- a gather by the finisher's workgroup after the last record (a round of loads past the L2s, a burst over
+    // the host link, a fence) put 5 us behind the sweep's 13.5
+    if (a.fs.hostPriority != nullptr && a.fs.sampleSubtasks > 0)
+      __hip_atomic_store(a.fs.hostPriority + (q - a.qFirst), pri, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     best_offer(best, pri, q - a.qFirst);
   }
 }
@@ -559,18 +564,13 @@ __device__ __forceinline__ void sweep_body(EvalArgs a, bool copyTable) {
     fused_select<SERVER>(a, bestLds[lane], lane, allReported);
   }
   if (a.fs.scratch != nullptr && a.fs.sampleSubtasks > 0 && a.fs.hostPriority != nullptr) {
-    // ---- the reference's selector on the HOST: workgroup 0 hands the finished priority vector over.  Every workgroup's
-    // priorities are in device memory (write-through stores, acknowledged before its record, and fused_select above has seen
-    // every record): one round of loads past the non-coherent cache levels, one coalesced burst into host-coherent memory, then
-    // the flag.  Launched and resident form alike (resident: the stores of the last step are made by the whole wave).
+    // ---- the reference's selector on the HOST: the priorities are in host-coherent memory already (flush_pending: each
+    // workgroup stored its own and waited for the acknowledgements before its record went out, and fused_select above has seen
+    // every record), so workgroup 0 only raises the flag.  Launched and resident form alike (resident: the stores of the last
+    // step are made by the whole wave).  Asked and gap questions have no entry: the selector skips them by the bitmaps.
     if (blockIdx.x == 0) {
       __syncthreads();
       const bool complete = *allReported;
-      const int64_t n = a.qLimit - a.qFirst;
-      for (int64_t i = tid; i < n; i += kThreads)
-        a.fs.hostPriority[i] = __hip_atomic_load(a.priority + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");            // system scope: this thread's part of the vector is out
-      __syncthreads();
       if (SERVER ? wave == 0 : tid == 0) {
         a.fs.out->priority = 0.0;
         a.fs.out->index = complete ? 0 : -3;
