@@ -337,7 +337,9 @@ def main():
         eng.set_option("select", 1)
         quiz_loop = {"questions_per_sec": asked / dtq, "quizzes": n_q, "questions": asked, "guessed_on_top": hits,
                      "published_reference_questions_per_sec": 301.2,
-                     "selection_path": "one launch per selection (the sweep's finisher hands the priority vector to the host) + the reference's selector on the host",
+                     "selection_path": "one launch per selection, made by StartQuiz / RecordAnswer ahead of the NextQuestion that follows (option speculate); "
+                                       "every workgroup hands its priorities to the host, the reference's selector runs there",
+                     "speculative_sweeps": {"used": int(eng.get_option("spec_hits")), "dropped": int(eng.get_option("spec_dropped"))},
                      "note": "reference figure: PqaClient learner loop on the author's 2017 desktop CPU (BASELINE.md); "
                              "here: Python wrapper of the C ABI, one quiz at a time, sampled selector"}
 

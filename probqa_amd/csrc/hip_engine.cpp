@@ -554,7 +554,13 @@ int64_t HipEngine::CreateQuiz(Error &err, int64_t nAnswered, const AQ *pAQs, con
 
 int64_t HipEngine::StartQuiz(Error &err) {
   std::lock_guard<EngineMutex> lk(_mu);
-  return CreateQuiz(err, 0, nullptr, nullptr, nullptr, 0, nullptr);
+  return SpeculateFor(CreateQuiz(err, 0, nullptr, nullptr, nullptr, 0, nullptr));
+}
+
+// (what follows StartQuiz / ResumeQuiz is NextQuestion: its sweep goes out right behind the kernel that sets the priors)
+int64_t HipEngine::SpeculateFor(int64_t iQuiz) {
+  if (iQuiz >= 0 && (size_t)iQuiz < _quizzes.size() && _quizzes[(size_t)iQuiz] != nullptr) Speculate(_quizzes[(size_t)iQuiz]);
+  return iQuiz;
 }
 
 int64_t HipEngine::ResumeQuiz(Error &err, int64_t nAnswered, const AQ *pAQs) {
@@ -567,7 +573,7 @@ int64_t HipEngine::ResumeQuiz(Error &err, int64_t nAnswered, const AQ *pAQs) {
     return -1;
   }
   std::lock_guard<EngineMutex> lk(_mu);
-  return CreateQuiz(err, nAnswered, pAQs, nullptr, nullptr, 0, nullptr);  // nAnswered == 0 -> StartQuiz (BaseEngine.cpp:393-395)
+  return SpeculateFor(CreateQuiz(err, nAnswered, pAQs, nullptr, nullptr, 0, nullptr));  // nAnswered == 0 -> StartQuiz (BaseEngine.cpp:393-395)
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -1566,6 +1572,14 @@ Error HipEngine::TrainLocked(int64_t nQuestions, const AQ *pAQs, int64_t iTarget
   std::vector<int64_t> chainStart;
   BuildTrainSteps(nQuestions, pAQs, fromQuiz, steps, chainStart);
   hipSetDevice(_device);
+  if (steps.size() <= (size_t)kTrainInlineSteps && chainStart.size() <= (size_t)kTrainInlineSteps + 1) {
+    TrainStepsInline in;
+    in.nChains = (int64_t)chainStart.size() - 1;
+    std::copy(chainStart.begin(), chainStart.end(), in.chainStart);
+    std::copy(steps.begin(), steps.end(), in.steps);
+    HIP_TRY(LaunchTrainStepsInline(_dCube, _elem, _dVB, _K, _ldT, in, iTarget, amount, _stream));
+    return Error();   // (later operations of the engine are ordered behind it on the stream)
+  }
   // one device buffer for both arrays: [steps | chainStart]
   const size_t stepBytes = steps.size() * sizeof(TrainStep), chainBytes = chainStart.size() * sizeof(int64_t);
   const int64_t needWords = (int64_t)((stepBytes + chainBytes) / sizeof(int64_t));

@@ -380,6 +380,7 @@ class HipEngine : public IEngine {
   int _specScore = 0;        // +1 per speculation used, -1 per speculation dropped: below -4 only every 32nd RecordAnswer speculates
   uint64_t _specProbe = 0, _specHits = 0, _specDropped = 0;
   void Speculate(Quiz *q);
+  int64_t SpeculateFor(int64_t iQuiz);
   bool TakeSpeculation(Quiz *q, int kind, uint64_t *pTag);
   void DropSpeculation() {
     if (_spec.quiz != nullptr) { _spec.quiz = nullptr; _specDropped++; if (_specScore > -8) _specScore--; }

@@ -75,9 +75,9 @@ __global__ __launch_bounds__(256) void fill_synth_kernel(void *__restrict__ cube
 //   kind 1  Perform1 (:28-30, and either half of a Perform2 over two different questions, :56-82): a = sqrt(A); A, D += 2ab + b^2
 //   kind 2  Perform2, same question and answer (:34-35): ONE step of 2b -- A, D += 4ab + 4b^2 (_inc4B, _incSquare2B)
 //   kind 3  Perform2, same question, answers a1 != a2 (:37-54): each cell its own addend; D += TWICE THE FIRST cell's addend (:45-46)
-__global__ void train_steps_kernel(void *__restrict__ cube, int elem, double *__restrict__ vB, int64_t K, int64_t ldT,
-                                   const TrainStep *__restrict__ steps, const int64_t *__restrict__ chainStart, int64_t nChains,
-                                   int64_t iTarget, double amount) {
+__device__ __forceinline__ void train_steps_body(void *__restrict__ cube, int elem, double *__restrict__ vB, int64_t K, int64_t ldT,
+                                                 const TrainStep *__restrict__ steps, const int64_t *__restrict__ chainStart, int64_t nChains,
+                                                 int64_t iTarget, double amount) {
   const double twoB = 2 * amount, bSquare = amount * amount;  // CETrainTaskNumSpec.h:24-32
   const double fourB = 4 * amount, square2B = 4 * bSquare;
   for (int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; c < nChains; c += (int64_t)gridDim.x * blockDim.x) {
@@ -104,6 +104,17 @@ __global__ void train_steps_kernel(void *__restrict__ cube, int elem, double *__
     const double b = vB[iTarget] + amount;                   // PqaCore/CpuEngine.cpp:172, :462
     vB[iTarget] = elem == 4 ? (double)(float)b : b;
   }
+}
+__global__ void train_steps_kernel(void *__restrict__ cube, int elem, double *__restrict__ vB, int64_t K, int64_t ldT,
+                                   const TrainStep *__restrict__ steps, const int64_t *__restrict__ chainStart, int64_t nChains,
+                                   int64_t iTarget, double amount) {
+  train_steps_body(cube, elem, vB, K, ldT, steps, chainStart, nChains, iTarget, amount);
+}
+// The same with the steps in the kernel's arguments: the training call at the end of a quiz has a handful of them, and two
+// staged copies plus the wait for them (the host vectors are their sources) cost four times what the launch does.
+__global__ void train_steps_inline_kernel(void *__restrict__ cube, int elem, double *__restrict__ vB, int64_t K, int64_t ldT,
+                                          TrainStepsInline in, int64_t iTarget, double amount) {
+  train_steps_body(cube, elem, vB, K, ldT, in.steps, in.chainStart, in.nChains, iTarget, amount);
 }
 
 // ListTopTargets on the device (top_targets_publish in pqa_device.h); T <= 16384.
@@ -212,6 +223,12 @@ hipError_t LaunchTrainSteps(void *cube, int elem, double *vB, int64_t K, int64_t
                             const int64_t *chainStart, int64_t nChains, int64_t iTarget, double amount, hipStream_t stream) {
   hipLaunchKernelGGL(train_steps_kernel, dim3(grid_for(nChains, 64)), dim3(64), 0, stream, cube, elem, vB, K, ldT, steps, chainStart,
                      nChains, iTarget, amount);
+  return hipGetLastError();
+}
+
+hipError_t LaunchTrainStepsInline(void *cube, int elem, double *vB, int64_t K, int64_t ldT, const TrainStepsInline &in,
+                                  int64_t iTarget, double amount, hipStream_t stream) {
+  hipLaunchKernelGGL(train_steps_inline_kernel, dim3(1), dim3(64), 0, stream, cube, elem, vB, K, ldT, in, iTarget, amount);
   return hipGetLastError();
 }
 

@@ -188,6 +188,15 @@ hipError_t LaunchFillSynthetic(void *cube, int elem, double *vB, int64_t K, int6
 struct TrainStep { int64_t kind, q, a1, a2; };   // kind 1 | 2 | 3, see kb_kernels.hip; q local
 hipError_t LaunchTrainSteps(void *cube, int elem, double *vB, int64_t K, int64_t ldT, const TrainStep *steps,
                             const int64_t *chainStart, int64_t nChains, int64_t iTarget, double amount, hipStream_t stream);
+// Up to kTrainInlineSteps steps travel in the kernel's arguments (no staging copy, nothing for the host to wait for).
+constexpr int kTrainInlineSteps = 48;
+struct TrainStepsInline {
+  int64_t nChains;
+  int64_t chainStart[kTrainInlineSteps + 1];
+  TrainStep steps[kTrainInlineSteps];
+};
+hipError_t LaunchTrainStepsInline(void *cube, int elem, double *vB, int64_t K, int64_t ldT, const TrainStepsInline &in,
+                                  int64_t iTarget, double amount, hipStream_t stream);
 // Maintenance (PqaCore/CpuEngine.cpp:468-658): (re)initialise whole questions / whole target columns; compact the target
 // axis with (src,dst) column moves.  qs/ts/inits/moves are device arrays.
 hipError_t LaunchFillQuestions(void *cube, int elem, int64_t K, int64_t T, int64_t ldT, const int64_t *qs, const double *inits,

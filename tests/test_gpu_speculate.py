@@ -1,5 +1,5 @@
-"""The sweep ahead of its request (option "speculate", hip_engine.h: Speculation): RecordAnswer launches the sweep the following
-NextQuestion would launch.  Same questions as an engine that does not speculate and as the oracle, on every step; the result is
+"""The sweep ahead of its request (option "speculate", hip_engine.h: Speculation): StartQuiz, ResumeQuiz and RecordAnswer launch
+the sweep the following NextQuestion would launch.  Same questions as an engine that does not speculate and as the oracle, on every step; the result is
 dropped when anything touches the quiz, the cube or the gaps in between."""
 import numpy as np
 import pytest
@@ -49,8 +49,8 @@ def test_same_questions_with_and_without(dims, select, factory):
             ta, tb = a.list_top_targets(qa, 3), b.list_top_targets(qb, 3)
             assert [(t.i_target, t.prob) for t in ta] == [(t.i_target, t.prob) for t in tb]
     assert np.array_equal(a.get_priors(qa), orc.priors())
-    # every NextQuestion after the first found its sweep launched; the last RecordAnswer's speculation is still pending
-    assert a.get_option("spec_hits") == n_steps - 1
+    # every NextQuestion found its sweep launched (by StartQuiz, then by RecordAnswer); the last RecordAnswer's is still pending
+    assert a.get_option("spec_hits") == n_steps
     assert b.get_option("spec_hits") == 0 and b.get_option("spec_dropped") == 0
     a.release_quiz(qa)
     assert a.get_option("spec_dropped") == 1
@@ -87,6 +87,7 @@ def test_dropped_when_something_intervenes(factory):
     both(lambda e: e.set_question_gaps([nxt]))               # the question the speculation has picked goes away
     got = both(lambda e: e.next_question(q1))
     assert got != nxt
+    a.set_option("speculate", 1)                             # (six drops in a row: the engine had stopped speculating; start over)
     both(lambda e: e.record_answer(q1, 3))
     both(lambda e: e.record_answer(q2, 3))                   # the newer RecordAnswer's speculation replaces the older one
     both(lambda e: e.next_question(q2))                      # ... and serves that quiz
