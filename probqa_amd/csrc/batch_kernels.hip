@@ -268,18 +268,21 @@ __global__ __launch_bounds__(256) void eval_batch_kernel(BatchArgs a) {
               v[qi][k] = fma(d, d, v[qi][k]);
               return l2;
             };
-            // :117 lack += invD^2 / log2(p): two answers of the same question and target share invD^2, so they share ONE
-            // reciprocal -- 1/a + 1/b = (a + b) / (a b) -- the quarter-rate instruction of the pair (a b stays within
-            // [2e-15, 2e4] in fp32: the logarithms are clamped to [-127, -4e-8]; in fp64 within [1e-38, 1e6])
+            // :117 lack += invD^2 / log2(p): the answers of one question and target share invD^2, so they share ONE reciprocal --
+            // sum_k 1/l_k = N / D with D = prod l_k and N = sum_k prod_{j != k} l_j, built up answer by answer (N <- N l + D,
+            // D <- D l: two full-rate operations per answer for the quarter-rate instruction they replace).  All l_k < 0, so the
+            // terms of N have one sign (no cancellation); in fp32 |l| is clamped to [4.3e-8, 127]: |D| in [1.5e-37, 3.3e10] for the
+            // at most five answers of a group, in fp64 (|l| in [5.7e-20, 1023]) within [6e-97, 1.2e15].
+            R accN = (R)1, accD = (R)1;
+            bool any = false;
 #pragma unroll
-            for (int k = 0; k < KG; k += 2) {
-              if (k + 1 < KG && (EXACT || k + 1 < kN)) {
-                const R la = element(k), lb = element(k + 1);
-                accL[qi] = fma(id2 * (la + lb), Num<R>::rcp(la * lb), accL[qi]);
-              } else if (EXACT || k < kN) {
-                accL[qi] = fma(id2, Num<R>::rcp(element(k)), accL[qi]);
+            for (int k = 0; k < KG; k++)
+              if (EXACT || k < kN) {
+                const R l = element(k);
+                if (!any) { accD = l; any = true; }
+                else { accN = fma(accN, l, accD); accD = accD * l; }
               }
-            }
+            if (any) accL[qi] = fma(id2 * accN, Num<R>::rcp(accD), accL[qi]);
             __builtin_amdgcn_sched_barrier(0);   // one question's KG elements in flight at a time: enough independent chains to cover
                                                  // the transcendental latency, and a third of the registers of all QB x KG at once
           }
@@ -501,7 +504,9 @@ hipError_t LaunchEvalBatch(const KbView &kb, const QuizSlot *slots, int nSlots, 
   BatchArgs a{};
   a.cube = kb.cube; a.PT = PT; a.tgap = kb.tgap; a.qgap = kb.qgap; a.slots = slots; a.nSlots = nSlots; a.Bp = Bp;
   a.K = kb.K; a.Q = kb.Q; a.ldT = kb.ldT;
-  int tc = plan->tileTargets > 0 ? plan->tileTargets : 256;
+  // default tile (measured, 256 quizzes): fp64 256 targets; fp32 512 (2000 x 5 x 100000: 91.2 ms against 93.6 at 256 and 129.8 at
+  // 1024), and a row of up to 1024 targets whole -- staged once for both passes (1000 x 5 x 1000: 341 k selections/s against 324 k)
+  int tc = plan->tileTargets > 0 ? plan->tileTargets : !f32 ? 256 : kb.ldT <= 1024 ? 1024 : 512;
   tc = ((tc + nThreads - 1) / nThreads) * nThreads;
   a.TC = tc;
   const double nT = (double)(kb.nValidTargets + 1);            // PqaCore/CEEvalQsSubtaskConsider.cpp:191
