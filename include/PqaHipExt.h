@@ -42,13 +42,17 @@ PQACORE_API void *PqaEngineFactory_CreateHipEngineSharded(void *pvFactory, void 
  * selector, default 8*workers as PqaCore/CpuEngine.cpp:339), "eval_variant" (0 = auto), "bug_compat" (reproduce
  * PqaCore/CEUpdatePriorsSubtaskMul.cpp:53), "seed" (selector RNG seed), "use_graph" (argmax NextQuestion replays a per-quiz HIP graph
  * instead of launching the sweep), "top_cache" (how many of the new posterior's best
- * targets RecordAnswer's kernel lists ahead of the ListTopTargets call that follows it, default 10, 0 = none), "server"
+ * targets RecordAnswer's kernel lists at most ahead of the ListTopTargets call that follows it -- it lists as many as ListTopTargets
+ * has been asked for lately; default 10, 0 = none), "server"
  * (argmax selections are served by a resident kernel instead of one launch each -- rows up to 1024 targets; default 0),
  * "server_idle_us" (that kernel leaves after this long without a request, default 500: what a device-wide synchronisation of the host waits at most -- PqaHip_Synchronize asks it to leave at once), "server_vram_mailbox" (requests
  * are written to host-visible device memory where the platform maps it, default 1; set before the first selection).
  * "host_sampled" (the sampled NextQuestion as one launch whose finisher hands the priority vector to the host, which runs the
  * reference's selector itself; default 1 -- 0: sweep + selector kernel), "fused_sampled" (the selector inside the sweep's launch;
  * default 0: measured slower),
+ * "speculate" (StartQuiz / ResumeQuiz / RecordAnswer launch the sweep of the NextQuestion that normally follows them, which then only
+ * waits for its result; same questions either way; default 1, also PQA_SPECULATE; read-only "spec_hits" / "spec_dropped" count the
+ * speculative sweeps that were used / dropped),
  * "eval_max_grid" (test hook: cap the workgroups of a sweep so that each streams many questions; 0 = no cap).
  * "batch_min" (PqaEngine_NextQuestionArgmaxBatch: batches of at least this many quizzes take the row-sharing sweep, which
  * reads the cube once per batch; default 0 = decided by how many waves the batch gives that sweep; Float engines always take it), "batch_tile" (targets per LDS tile of that sweep, 0 = default).
