@@ -395,7 +395,10 @@ int64_t HipEngine::GetOption(const char *name) const {
   return -1;
 }
 
-const char *HipEngine::EvalKernelName() const { return _elem == 8 ? EvalVariantName(View(), (int)_optEvalVariant) : "f32_stream256"; }
+const char *HipEngine::EvalKernelName() const { 
+  if (_elem == 8) return EvalVariantName(View(), (int)_optEvalVariant);
+  return _optEvalVariant != 99 ? EvalF32KernelName(View(), (int)_optEvalVariant) : "f32_stream";
+}
 
 uint64_t HipEngine::NextRandom() {  // xorshift128+, the generator family of SRPlatform/Interface/SRFastRandom.h:60-72
   uint64_t s1 = _rng[0];
@@ -760,7 +763,10 @@ Error HipEngine::LaunchSingleSweep(Quiz *q, const FusedSelect *fused) {
     HIP_TRY(LaunchEvalQuestions(View(), q->dPrior, q->dAsked, 0, _Q, _dPriority, (int)_optEvalVariant, fused, _stream));
     return Error();
   }
-  HIP_TRY(LaunchEvalQuestionsF32(View(), q->dPrior, q->dAsked, _dPriority, _stream));
+  if (_optEvalVariant != 99 && EvalF32RegisterShape(View(), (int)_optEvalVariant))   // (variant 99: the streaming form, as for Double engines)
+    HIP_TRY(LaunchEvalQuestionsF32Reg(View(), q->dPrior, q->dAsked, _dPriority, (int)_optEvalVariant, _stream));
+  else
+    HIP_TRY(LaunchEvalQuestionsF32(View(), q->dPrior, q->dAsked, _dPriority, _stream));
   if (fused != nullptr)
     HIP_TRY(LaunchSelectArgmax(_dPriority, _dQGap, q->dAsked, 0, _Q, fused->outBase, fused->out, fused->seq, fused->flagValue, _stream));
   return Error();

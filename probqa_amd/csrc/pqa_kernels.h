@@ -99,6 +99,11 @@ hipError_t LaunchEvalBatch(const KbView &kb, const QuizSlot *slots, int nSlots, 
                            BatchRecord *recs, double *priorityT, int64_t outBase, uint64_t flagValue, bool queryOnly, hipStream_t stream);
 // Single-quiz sweep of a Float engine: priority[q] for every local question (0 for gap / asked).
 hipError_t LaunchEvalQuestionsF32(const KbView &kb, const double *prior, const uint32_t *asked, double *priority, hipStream_t stream);
+// ... with the question's rows held in registers (eval_f32_kernels.hip): rows of up to 16384 targets, up to 16 answers
+bool EvalF32RegisterShape(const KbView &kb, int variant);
+const char *EvalF32KernelName(const KbView &kb, int variant);
+hipError_t LaunchEvalQuestionsF32Reg(const KbView &kb, const double *prior, const uint32_t *asked, double *priority, int variant,
+                                     hipStream_t stream);
 hipError_t UploadLog2TableBatch(const double *hostTable);
 const char *EvalVariantName(const KbView &kb, int variant);
 bool EvalVariantFusesSampled(const KbView &kb, int variant, int64_t nSubtasks);   // the launch can run the sampled selector itself

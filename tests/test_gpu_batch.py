@@ -253,3 +253,52 @@ def test_batched_sweep_mid_size_fp64_and_fp32(factory):
         print("mid", prec, "max rel err as a fraction of the tolerance: %.3g" % worst)
         assert worst < 1
         eng.close()
+
+
+@pytest.mark.parametrize("T,K,name", [(900, 5, "f32_wg256_nq1"), (1500, 3, "f32_wg256_nq2"), (2500, 5, "f32_wg256_nq3"),
+                                     (4000, 5, "f32_wg256_nq4"), (4500, 5, "f32_wg320_nq4"), (6000, 2, "f32_wg384_nq4"),
+                                     (8000, 5, "f32_wg512_nq4"), (10000, 5, "f32_wg640_nq4"),
+                                     (11000, 16, "f32_wg704_nq4"), (12000, 5, "f32_wg768_nq4"),
+                                     (16384, 5, "f32_wg1024_nq4"), (20000, 5, "f32_stream"), (900, 17, "f32_stream")],
+                         ids=lambda v: str(v))
+def test_float_single_quiz_register_shapes(T, K, name, factory):
+    """The single-quiz sweep of a Float engine, every register shape (eval_f32_kernels.hip) and the streaming form behind them:
+    against the fp64 oracle on the rounded cube at the fp32 tolerance, after StartQuiz and after three answers, with target and
+    question gaps, one question per workgroup and two workgroups streaming all questions; the streaming form (variant 99) on
+    the same states within twice the tolerance of the register form."""
+    Q = 14
+    rng = np.random.default_rng(T)
+    tgaps = sorted(rng.choice(T, 7, replace=False).tolist()) + [T - 1]
+    case = cases.Case("f32shape_%d" % T, K, Q, T, seed=T, tgaps=sorted(set(tgaps)), qgaps=[3],
+                      answers=[(5, 1), (0, K - 1), (13, 0)])
+    eng, orc = float_engine(case, factory)
+    assert eng.eval_kernel_name() == name
+    quiz = eng.start_quiz()
+    tol = f32_tolerance(orc, case)
+    worst = 0.0
+    for step in range(len(case.answers) + 1):
+        hist = case.answers[:step]
+        opri, opriors = oracle_priorities(orc, hist)
+        assert np.array_equal(eng.get_priors(quiz), opriors)
+        forms = {}
+        for grid in (0, 2):
+            eng.set_option("eval_max_grid", grid)
+            forms[grid] = eng.eval_priorities(quiz)
+            r = rel_vec(forms[grid], opri)
+            worst = max(worst, (r / tol).max())
+            assert (r < tol).all(), (name, step, grid, float((r / tol).max()))
+        eng.set_option("eval_max_grid", 0)
+        eng.set_option("eval_variant", 99)
+        stream = eng.eval_priorities(quiz)
+        eng.set_option("eval_variant", 0)
+        assert (rel_vec(stream, forms[0]) < 2 * tol).all()
+        assert forms[0][3] == 0 and all(forms[0][q] == 0 for q, _ in hist)      # gap and asked questions
+        top = np.sort(opri)[::-1]
+        if (top[0] - top[1]) / top[0] > 10 * tol.max():
+            assert eng.next_question_argmax(quiz) == orc.select_argmax(opri)
+        if step < len(case.answers):
+            q, a = case.answers[step]
+            eng.set_active_question(quiz, q)
+            eng.record_answer(quiz, a)
+    print(name, "max rel err as a fraction of the tolerance: %.3g" % worst)
+    eng.close()
