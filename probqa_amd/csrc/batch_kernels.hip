@@ -357,11 +357,7 @@ __global__ __launch_bounds__(256) void batch_pick_kernel(const BatchRecord *__re
 // streaming form of eval_kernels.hip -- Double engines have the register-resident shapes there; the Float configuration the
 // work went into is the batched one above (BASELINE configs[4]).
 constexpr int kF32LdsTargets = 16384;
-__device__ __forceinline__ float wave_sum_f(float v) {
-#pragma unroll
-  for (int m = kWave / 2; m >= 1; m >>= 1) v += __shfl_xor(v, m, kWave);
-  return v;
-}
+__device__ __forceinline__ float wave_sum_f(float v) { return wave_sum_f32(v); }
 __device__ __forceinline__ float rcp_f32_nr(float x) {
   const float r = __builtin_amdgcn_rcpf(x);
   return fmaf(r, fmaf(-x, r, 1.0f), r);

@@ -1,0 +1,473 @@
+// cluster_kernels.hip -- the single-quiz priority sweep for LONG rows (more than 16384 targets), fp32 and fp64, gfx950.
+//
+// Reference: PqaCore/CEEvalQsSubtaskConsider.cpp:41-217.  The sweep makes two passes over a question's K answer rows -- pass 1
+// W_k = sum_t (A/D) prior, pass 2 everything that needs 1/W_k -- and a row of 10^5 targets fits neither the registers nor the LDS
+// of one workgroup: the plain streaming forms (eval_kernels.hip "stream256", batch_kernels.hip eval_questions_f32_stream) read
+// every answer row twice and the mD row once per pass and answer (1.3 / 1.7 TB/s of cube at 2000 x 5 x 100000, fp64 / fp32).
+//
+// Here a question is swept by a CLUSTER of C workgroups, each owning one contiguous slice of the target axis:
+//   * pass 1: a workgroup streams its slice of the question's K + 1 rows once (all requested before any is used), keeps the
+//     likelihoods (A * invD) * prior of its slice in LDS, 1/D and the masked priors in registers, and publishes its partial W_k;
+//   * the members exchange their partials as 16-byte records {value, question count of the cluster} written with one
+//     write-through store each: no atomics, no fences, no counter.  Every member polls all C x K records of the question with one
+//     coalesced round of loads past the L2s (value and tag arrive together) until all carry the question's tag, and adds them in
+//     slice order -- the same W_k, bit for bit, in all of them;
+//   * pass 2 runs on the LDS copy: posterior, log2, entropy / velocity sums, the lack term with one reciprocal per target over
+//     the answers of the question (batch_kernels.hip); the partial sums go out the same way, and ONE member (they take turns)
+//     folds them into the question's totals right after the NEXT question's exchange -- by then every member has published
+//     them, so it never waits;
+//   * the fp64 epilogues (:134-207) run in a second small kernel, one thread per question.
+// The cube is read ONCE.  Two workgroups of different clusters share a CU, so that one streams while the other waits for its
+// cluster.  The grid is exactly the number of workgroups the device holds at once (they wait for each other).
+// Slices, partial sums and their order are fixed by (ldT, K, C) alone: results do not depend on timing.
+#include <algorithm>
+#include <atomic>
+#include <cstdio>
+#include <cstdlib>
+
+#include "eval_device.h"
+#include "pqa_device.h"
+#include "pqa_kernels.h"
+
+namespace pqa {
+
+static __device__ double gLog2TableC[kLog2TableDoubles];   // this translation unit's copy of the Log2Hot table
+
+hipError_t UploadLog2TableCluster(const double *hostTable) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(gLog2TableC), hostTable, kLog2TableDoubles * sizeof(double));
+}
+
+namespace {
+
+constexpr int kClusterThreads = 512;
+constexpr int kMaxK = 16;
+
+template <typename R> struct Vec;
+template <> struct Vec<float> { typedef float4 type; static constexpr int N = 4; };
+template <> struct Vec<double> { typedef double2 type; static constexpr int N = 2; };
+
+template <typename R> struct NumC;
+template <> struct NumC<double> {
+  static constexpr bool kTable = true;
+  static __device__ __forceinline__ double log2p(double p, const double *tbl) { return log2hot(p, tbl); }
+  static __device__ __forceinline__ double rcp(double x) {      // 2^-48.8: below the rounding of the sum it feeds
+    const double r = __builtin_amdgcn_rcp(x);
+    return fma(r, fma(-x, r, 1.0), r);
+  }
+  static __device__ __forceinline__ double inv(double x) { return div_nr(1.0, x); }   // exact quotient (:74, :91)
+};
+template <> struct NumC<float> {
+  static constexpr bool kTable = false;
+  static __device__ __forceinline__ float log2p(float p, const double *) {   // (batch_kernels.hip: Num<float>::log2p)
+    return __builtin_amdgcn_fmed3f(__builtin_amdgcn_logf(p), -127.0f, -4.2992253e-08f);
+  }
+  static __device__ __forceinline__ float rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+  static __device__ __forceinline__ float inv(float x) { const float r = __builtin_amdgcn_rcpf(x); return fmaf(r, fmaf(-x, r, 1.0f), r); }
+};
+
+template <typename R> __device__ __forceinline__ R &at(typename Vec<R>::type &v, int e) { return reinterpret_cast<R *>(&v)[e]; }
+template <typename R> __device__ __forceinline__ R at(const typename Vec<R>::type &v, int e) { return reinterpret_cast<const R *>(&v)[e]; }
+
+__device__ __forceinline__ double wave_sum_d(double v) { return wave_sum(v); }   // (DPP + permlane swaps, pqa_device.h)
+
+struct alignas(16) ExRec { double value; unsigned long long tag; };
+
+struct ClusterArgs {
+  const void *cube;           // R [Q][K+1][ldT]
+  const double *prior;
+  const uint32_t *tgap, *qgap, *asked;
+  int64_t K, Q, ldT;
+  int C, nClusters;           // workgroups per cluster, clusters (grid = C * nClusters)
+  int sliceUnits;             // 16-byte units of a row per slice
+  // exchange, per cluster g: recW[g][2][C][kMaxK], recS[g][2][C][kMaxK + 2] records (the [2]: parity of the question count)
+  ExRec *recW, *recS;
+  unsigned long long tagBase;  // launch number << 32: records of earlier launches never match
+  double *totals;             // [Q][2 kMaxK + 2]: W_k | V_k | sum W_k H_k | lack
+  double *priority;           // skipped questions get their 0 here
+};
+
+// The members of a cluster run on different XCDs, whose L2s are not coherent with each other: records are written through (sc1)
+// and read past the L2s (sc1), 16 bytes at a time -- value and tag travel together (as the sweep's winner records do,
+// eval_kernels.hip: fused_select).
+typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void put_record(ExRec *p, double v, unsigned long long tag) {
+  const unsigned long long w0 = d2u(v);
+  const u4 x = {(unsigned)w0, (unsigned)(w0 >> 32), (unsigned)tag, (unsigned)(tag >> 32)};
+  asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(x) : "memory");
+}
+template <typename R, int NU>   // NU: 16-byte units of a slice per thread; two workgroups per CU (<= 128 registers)
+__global__ __launch_bounds__(kClusterThreads, 4) void eval_cluster_kernel(ClusterArgs a) {
+  typedef typename Vec<R>::type V;
+  constexpr int VN = Vec<R>::N;
+  constexpr int NW = kClusterThreads / kWave;
+  extern __shared__ double smem[];
+  const double *tbl = smem;
+  // LDS (all dynamic: the Log2Hot table must sit at address 0): table | likelihoods [K][sliceUnits] | the waves' partials
+  // [kMaxK + 2][NW] | W_k [kMaxK] | the waves' votes [NW] | the members' partials [C][K + 2]
+  V *lhL = reinterpret_cast<V *>(smem + (NumC<R>::kTable ? kLog2TableDoubles : 0));
+  double (*red)[NW] = reinterpret_cast<double (*)[NW]>(lhL + (size_t)a.K * a.sliceUnits);
+  double *wTot = &red[kMaxK + 2][0];
+  int *votes = reinterpret_cast<int *>(wTot + kMaxK);          // [NW]
+  double *xch = wTot + kMaxK + NW / 2;                          // [C][K + 2]: the members' partials of one question
+  if constexpr (NumC<R>::kTable) {
+    if (!lds_table_at_zero(tbl)) __builtin_trap();            // log2hot addresses the table absolutely
+    for (int i = threadIdx.x; i < kLog2TableDoubles; i += kClusterThreads) smem[i] = gLog2TableC[i];
+  }
+  const int tid = threadIdx.x, lane = tid % kWave, wave = tid / kWave;
+  const int64_t K = a.K, ldT = a.ldT;
+  const int C = a.C, g = blockIdx.x / C, m = blockIdx.x % C;   // cluster, member (= slice)
+  const int nUnits = (int)(ldT / VN), SU = a.sliceUnits;
+  const int u0 = m * SU;                                        // first unit of the slice
+  const int nMine = u0 >= nUnits ? 0 : (nUnits - u0 < SU ? nUnits - u0 : SU);
+  const R *cube = static_cast<const R *>(a.cube);
+  const int64_t qStride = (K + 1) * ldT;
+  // ---- the thread's units of the slice, its masked priors (:103) and gap bits
+  int ui[NU];            // unit index within the row (clamped; units beyond the slice are masked)
+  uint32_t gapBits[NU];
+  V pr[NU];
+#pragma unroll
+  for (int j = 0; j < NU; j++) {
+    const int s = tid + j * kClusterThreads;
+    const bool in = s < nMine;
+    ui[j] = in ? u0 + s : (nUnits - 1);
+    const int64_t t0 = (int64_t)ui[j] * VN;
+    const uint32_t gbits = in ? (a.tgap[t0 >> 5] >> (t0 & 31)) & ((1u << VN) - 1) : (1u << VN) - 1;   // (bits past T are set)
+    gapBits[j] = gbits;
+#pragma unroll
+    for (int e = 0; e < VN; e++) at<R>(pr[j], e) = ((gbits >> e) & 1) ? (R)0 : (R)a.prior[t0 + e];
+  }
+  ExRec *recW = a.recW + (size_t)g * 2 * C * kMaxK, *recS = a.recS + (size_t)g * 2 * C * (kMaxK + 2);
+  unsigned long long round = 0;                                 // questions this cluster has swept
+  const unsigned long long tagBase = a.tagBase;
+  int64_t qPrev = -1;                                           // the previous question, whose pass-2 partials are still to be folded
+  // All C x n records of one exchange (n values per member, tag = the question's count), one coalesced round of loads per poll,
+  // into xch[member][n].  Returns once every record carries the tag.
+  // The loads are compiler-visible buffer loads with the sc1 bit (past the L2s), not inline assembly: `between` -- the request for
+  // the next question's rows -- is issued BEHIND the first round of record loads and the wait for that round leaves the younger
+  // row loads in flight (loads return in order: behind the rows, the first poll waited for all of them -- 4 us per question).
+  auto gather = [&](const ExRec *recs, int stride, int n, unsigned long long tag, auto &&between) {
+    const int total = C * n;                                    // <= 1024 (cluster_shape)
+    const RowRsrc rs = row_rsrc(recs, (int64_t)C * stride * (int64_t)sizeof(ExRec));
+    constexpr int kAuxSc1 = 16;
+    uint32_t off[2];
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+      const int r = tid + u * kClusterThreads;
+      const int rc = r < total ? r : 0;
+      const int mm = rc / n, kk = rc - mm * n;
+      off[u] = (uint32_t)((mm * stride + kk) * (int)sizeof(ExRec));
+    }
+    unsigned spins = 0;
+    for (bool first = true;; first = false) {
+      u32x4_t x[2];
+#pragma unroll
+      for (int u = 0; u < 2; u++)
+        if (u == 0 || total > kClusterThreads) x[u] = __builtin_amdgcn_raw_buffer_load_b128(rs, off[u], 0, kAuxSc1);
+      if (first) between();
+      int ok = 1;
+#pragma unroll
+      for (int u = 0; u < 2; u++) {
+        const int r = tid + u * kClusterThreads;
+        if ((u == 0 || total > kClusterThreads) && r < total) {
+          const unsigned long long t = (unsigned long long)x[u][2] | ((unsigned long long)x[u][3] << 32);
+          if (t == tag) xch[r] = u2d((unsigned long long)x[u][0] | ((unsigned long long)x[u][1] << 32)); else ok = 0;
+        }
+      }
+      // (not __syncthreads_and: the library's workgroup reduction brings static LDS, and the Log2Hot table must sit at address 0)
+      const int waveOk = __all(ok);
+      __syncthreads();                                          // the previous round's votes have been read
+      if (lane == 0) votes[wave] = waveOk;
+      __syncthreads();
+      int all = 1;
+      for (int w = 0; w < NW; w++) all &= votes[w];
+      if (all) break;
+      __builtin_amdgcn_s_sleep(4);
+      if (++spins > (1u << 26)) __builtin_trap();               // (minutes: a member died -- no silent hang)
+    }
+  };
+  // sums over the members of the n values of xch[member][n], into out[0 .. n): wave w takes the columns w, w + NW, ...; lane l adds
+  // the members l, l + 64, ... and the wave's DPP tree the lanes (one member after the other it is C dependent LDS round trips:
+  // 7600 cycles at 98 members).  A fixed order, the same in every member of the cluster.
+  auto sum_members = [&](int n, double *out) {
+    for (int col = wave; col < n; col += NW) {
+      double s = 0.0;
+      for (int i = lane; i < C; i += kWave) s += xch[i * n + col];
+      s = wave_sum(s);
+      if (lane == 0) out[col] = s;
+    }
+  };
+  // the pass-2 partials of question `qq` (count `cnt`), folded into its totals; W_k passed along
+  auto fold = [&](int64_t qq, unsigned long long cnt, const double *wOfQ) {
+    gather(recS + (size_t)(cnt & 1) * C * (kMaxK + 2), kMaxK + 2, (int)K + 2, tagBase + cnt + 1, [] {});
+    sum_members((int)K + 2, red[0]);                            // (red[] is free between the exchange and pass 2)
+    __syncthreads();
+    if (tid < K + 2) {
+      const double s = red[0][tid];
+      double *tot = a.totals + (size_t)qq * (2 * kMaxK + 2);
+      if (tid < K) { tot[tid] = wOfQ[tid]; tot[kMaxK + tid] = s; }
+      else tot[2 * kMaxK + (tid - K)] = s;
+    }
+    __syncthreads();
+  };
+
+  auto next_valid = [&](int64_t q) {    // :54 gap / asked questions get priority 0 and are skipped (the same decision in every member)
+    while (q < a.Q && (bit_test(a.qgap, q) || bit_test(a.asked, q))) {
+      if (m == 0 && tid == 0) a.priority[q] = 0.0;
+      q += a.nClusters;
+    }
+    return q;
+  };
+  auto load_units = [&](const R *rowPtr, V (&dst)[NU]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < NU; j++) dst[j] = reinterpret_cast<const V *>(rowPtr)[ui[j]];
+  };
+  if constexpr (NumC<R>::kTable) __syncthreads();
+  int64_t q = next_valid(g);
+  // A thread's share of a row is one or two 16-byte units, i.e. a row costs it one memory round trip whatever its length: requested
+  // a row ahead the K + 1 rows of a question are K + 1 round trips in a row (12 of the 15 us a question took).  So ALL rows of the
+  // NEXT question (up to kRowsAhead answer rows; the few beyond are fetched on the spot) are requested at once, right after pass 1
+  // has consumed the current ones, and fly during the exchange and pass 2.
+  constexpr int kRowsAhead = NU == 1 ? 8 : 5;   // (two units per thread: five rows are what 128 registers hold)
+  V dN[NU], rows[kRowsAhead][NU];
+  auto request_question = [&](int64_t qq) __attribute__((always_inline)) {
+    const R *base = cube + qq * qStride;
+    load_units(base + K * ldT, dN);
+#pragma unroll
+    for (int k = 0; k < kRowsAhead; k++)
+      if (k < K) load_units(base + k * ldT, rows[k]);
+  };
+  if (q < a.Q) request_question(q);
+  while (q < a.Q) {
+    const int par = (int)(round & 1);
+    const R *qb = cube + q * qStride;
+    const int64_t qNext = next_valid(q + a.nClusters);
+    // ---- pass 1 (:66-88) on the slice of the K + 1 rows
+    V id[NU];
+#pragma unroll
+    for (int j = 0; j < NU; j++)
+#pragma unroll
+      for (int e = 0; e < VN; e++) at<R>(id[j], e) = ((gapBits[j] >> e) & 1) ? (R)0 : NumC<R>::inv(at<R>(dN[j], e));   // :74
+    auto pass1_row = [&](int64_t k, const V (&row)[NU]) __attribute__((always_inline)) {
+      R s = (R)0;
+#pragma unroll
+      for (int j = 0; j < NU; j++) {
+        V lh;
+#pragma unroll
+        for (int e = 0; e < VN; e++) {
+          at<R>(lh, e) = (at<R>(row[j], e) * at<R>(id[j], e)) * at<R>(pr[j], e);   // :81-82
+          s += at<R>(lh, e);
+        }
+        const int sl = tid + j * kClusterThreads;
+        if (sl < SU) lhL[k * SU + sl] = lh;
+      }
+      const double sw = wave_sum_d((double)s);
+      if (lane == 0) red[k][wave] = sw;
+    };
+#pragma unroll
+    for (int k = 0; k < kRowsAhead; k++)
+      if (k < K) pass1_row(k, rows[k]);
+    for (int64_t k = kRowsAhead; k < K; k++) {                  // (more than kRowsAhead answers)
+      V late[NU];
+      load_units(qb + k * ldT, late);
+      pass1_row(k, late);
+    }
+    __syncthreads();
+    if (tid < K) {
+      double w = 0.0;
+      for (int i = 0; i < NW; i++) w += red[tid][i];
+      put_record(recW + ((size_t)par * C + m) * kMaxK + tid, w, tagBase + round + 1);
+    }
+    // ---- the cluster meets: everybody's partials, in slice order
+    gather(recW + (size_t)par * C * kMaxK, kMaxK, (int)K, tagBase + round + 1, [&]() __attribute__((always_inline)) {
+      if (qNext < a.Q) request_question(qNext);                 // the next question's rows fly during the exchange and pass 2
+    });
+    sum_members((int)K, red[8]);                                // W_k of this question, parked (rows 8.. of red[]; fold uses rows 0..2) while wTot still holds the previous one's
+    __syncthreads();                                            // (xch is read)
+    // the member whose turn it is folds the PREVIOUS question's pass-2 partials: every member published them before it published
+    // this question's W partials, which have all just been seen
+    if (qPrev >= 0 && (int)((round - 1) % (unsigned long long)C) == m) fold(qPrev, round - 1, wTot);
+    if (tid < K) wTot[tid] = red[8][tid];
+    __syncthreads();
+    // ---- pass 2 (:95-128) from LDS, answer by answer; the lack term's N / D pairs (batch_kernels.hip) run across the answers
+    V accN[NU], accD[NU];
+    R hW = (R)0, accL = (R)0;
+    for (int64_t k = 0; k < K; k++) {
+      const R invWk = (R)div_fast(1.0, wTot[k]);                // :91
+      R vk = (R)0;
+#pragma unroll
+      for (int j = 0; j < NU; j++) {
+        const int sl = tid + j * kClusterThreads;
+        if (sl < SU) {
+          const V lh = lhL[k * SU + sl];
+#pragma unroll
+          for (int e = 0; e < VN; e++) {
+            const R l = at<R>(lh, e), pi = at<R>(pr[j], e);
+            const R p = l * invWk;                              // :97
+            const R l2 = NumC<R>::log2p(p, tbl);                // :106
+            hW = fma(l, l2, hW);                                // :113-114 weighted by W_k (eval_epilogue)
+            const R dd = p - pi;                                // :119
+            vk = fma(dd, dd, vk);                               // :126-127
+            // :117 sum_k 1 / log2 p_k = N / D, built answer by answer
+            if (k == 0) { at<R>(accN[j], e) = (R)1; at<R>(accD[j], e) = l2; }
+            else { at<R>(accN[j], e) = fma(at<R>(accN[j], e), l2, at<R>(accD[j], e)); at<R>(accD[j], e) = at<R>(accD[j], e) * l2; }
+          }
+        }
+      }
+      const double s = wave_sum_d((double)vk);
+      if (lane == 0) red[k][wave] = s;
+    }
+#pragma unroll
+    for (int j = 0; j < NU; j++) {
+      const int sl = tid + j * kClusterThreads;
+      if (sl < SU) {
+#pragma unroll
+        for (int e = 0; e < VN; e++) {
+          const R i1 = at<R>(id[j], e);
+          accL = fma((i1 * at<R>(accN[j], e)) * i1, NumC<R>::rcp(at<R>(accD[j], e)), accL);
+        }
+      }
+    }
+    {
+      const double s1 = wave_sum_d((double)hW), s2 = wave_sum_d((double)accL);
+      if (lane == 0) { red[K][wave] = s1; red[K + 1][wave] = s2; }
+    }
+    __syncthreads();
+    if (tid < K + 2) {
+      double s = 0.0;
+      for (int i = 0; i < NW; i++) s += red[tid][i];
+      put_record(recS + ((size_t)par * C + m) * (kMaxK + 2) + tid, s, tagBase + round + 1);
+    }
+    qPrev = q;
+    round++;
+    q = qNext;
+    __syncthreads();                                            // red[] and the LDS rows are free again
+  }
+  // the last question's partials: its turn-taker waits for them (the only wait of its kind)
+  if (qPrev >= 0 && (int)((round - 1) % (unsigned long long)C) == m) fold(qPrev, round - 1, wTot);
+}
+
+// :134-207, one thread per question
+__global__ __launch_bounds__(256) void cluster_epilogue_kernel(const double *__restrict__ totals, const uint32_t *__restrict__ qgap,
+                                                               const uint32_t *__restrict__ asked, double *__restrict__ priority,
+                                                               int64_t K, int64_t Q, double vCompTail) {
+  const int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (q >= Q || bit_test(qgap, q) || bit_test(asked, q)) return;
+  const double *tot = totals + (size_t)q * (2 * kMaxK + 2);
+  double mW[kMaxK], mWV[kMaxK];
+  for (int64_t k = 0; k < K; k++) { mW[k] = tot[k]; mWV[k] = tot[k] * sqrt(tot[kMaxK + k]); }   // :156-157
+  priority[q] = eval_epilogue(mW, -tot[2 * kMaxK], mWV, K, tot[2 * kMaxK + 1], vCompTail);
+}
+
+constexpr size_t kFixedLdsBytes = ((size_t)(kMaxK + 2) * (kClusterThreads / kWave) + kMaxK + kClusterThreads / kWave / 2) * sizeof(double);   // red[][] + wTot[] + votes[]
+constexpr size_t kExchangeLdsBytes = 8 * 1024;   // xch[C][K + 2] doubles: clusters of up to 1024 / (K + 2) members
+struct ClusterShape { int C, nClusters, sliceUnits, nu; size_t shmem; };
+
+template <typename R, int NU>
+bool occupancy_two(size_t shmem) {
+  static int cached = -1;
+  static size_t cachedShmem = 0;
+  if (cached >= 0 && cachedShmem == shmem) return cached >= 2;
+  auto kern = eval_cluster_kernel<R, NU>;
+  hipError_t e = hipSuccess;
+  if (shmem > 64 * 1024) e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+  int perCU = 0;
+  if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, kern, kClusterThreads, shmem);
+  if (e != hipSuccess) { perCU = 0; (void)hipGetLastError(); }   // (not this launch's error: the caller falls back to the streaming form)
+  cached = perCU;
+  cachedShmem = shmem;
+  return perCU >= 2;
+}
+
+// Slices as long as two workgroups' LDS per CU allow (72 KB each, the fp64 table included): the fewer members a cluster has, the
+// fewer partials every member adds per question.
+template <typename R>
+bool cluster_shape(const KbView &kb, int nCU, ClusterShape *out) {
+  constexpr int VN = Vec<R>::N;
+  if (kb.K > kMaxK || kb.K < 1) return false;
+  const int64_t nUnits = kb.ldT / VN;
+  const size_t tableBytes = NumC<R>::kTable ? kLog2TableDoubles * sizeof(double) : 0;
+  const size_t budget = 72 * 1024 - tableBytes - kFixedLdsBytes - kExchangeLdsBytes;
+  int64_t maxUnits = (int64_t)(budget / ((size_t)kb.K * 16));
+  // fp32: up to two units per thread (fewer members per cluster: 1797 vs 2018 us at 2000 x 5 x 100000); fp64: one -- with two the
+  // next question's rows do not fit the 128 registers beside pass 2 and spill (6160 vs 4459 us)
+  maxUnits = std::min<int64_t>(maxUnits, (NumC<R>::kTable ? 1 : 2) * kClusterThreads);
+  maxUnits = maxUnits / kWave * kWave;
+  if (maxUnits < kWave) return false;
+  const int64_t C = (nUnits + maxUnits - 1) / maxUnits;
+  const int capacity = 2 * nCU;
+  if (C > capacity || (size_t)C * (kb.K + 2) * sizeof(double) > kExchangeLdsBytes) return false;
+  int64_t su = ((nUnits + C - 1) / C + kWave - 1) / kWave * kWave;        // whole waves of units
+  out->C = (int)C;
+  out->nClusters = (int)std::max<int64_t>(1, std::min<int64_t>(capacity / C, kb.Q));
+  out->sliceUnits = (int)su;
+  out->nu = su <= kClusterThreads ? 1 : 2;
+  out->shmem = tableBytes + (size_t)kb.K * su * 16 + kFixedLdsBytes + kExchangeLdsBytes;
+  return out->nu == 1 ? occupancy_two<R, 1>(out->shmem) : occupancy_two<R, 2>(out->shmem);
+}
+
+int device_cus() {
+  int dev = 0, nCU = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&nCU, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || nCU <= 0) nCU = 256;
+  return nCU;
+}
+
+}  // namespace
+
+// Rows longer than the register shapes take (ldT > 16384), up to 16 answers, two workgroups per CU resident.
+bool EvalClusterSupported(const KbView &kb) {
+  if (kb.ldT <= 16384) return false;
+  ClusterShape s;
+  return kb.elem == 4 ? cluster_shape<float>(kb, device_cus(), &s) : cluster_shape<double>(kb, device_cus(), &s);
+}
+
+const char *EvalClusterKernelName(const KbView &kb) {
+  static thread_local char name[48];
+  ClusterShape s{};
+  const bool ok = kb.elem == 4 ? cluster_shape<float>(kb, device_cus(), &s) : cluster_shape<double>(kb, device_cus(), &s);
+  if (!ok) return "stream";
+  std::snprintf(name, sizeof(name), "%s_cluster%d_x%d", kb.elem == 4 ? "f32" : "f64", s.C, s.nClusters);
+  return name;
+}
+
+// bytes of exchange scratch the launch needs (records + totals; cleared once by the caller); 0 if the shape is not supported
+size_t EvalClusterScratchBytes(const KbView &kb) {
+  ClusterShape s{};
+  const bool ok = kb.elem == 4 ? cluster_shape<float>(kb, device_cus(), &s) : cluster_shape<double>(kb, device_cus(), &s);
+  if (!ok) return 0;
+  const size_t perCluster = (size_t)2 * s.C * (2 * kMaxK + 2) * sizeof(ExRec);
+  return (size_t)s.nClusters * perCluster + (size_t)kb.Q * (2 * kMaxK + 2) * sizeof(double) + 256;
+}
+
+hipError_t LaunchEvalCluster(const KbView &kb, const double *prior, const uint32_t *asked, double *priority, void *scratch, hipStream_t stream) {
+  ClusterShape s{};
+  const bool f32 = kb.elem == 4;
+  const bool ok = f32 ? cluster_shape<float>(kb, device_cus(), &s) : cluster_shape<double>(kb, device_cus(), &s);
+  if (!ok || scratch == nullptr) return hipErrorInvalidValue;
+  char *p = static_cast<char *>(scratch);
+  ClusterArgs a{};
+  a.cube = kb.cube; a.prior = prior; a.tgap = kb.tgap; a.qgap = kb.qgap; a.asked = asked;
+  a.K = kb.K; a.Q = kb.Q; a.ldT = kb.ldT; a.C = s.C; a.nClusters = s.nClusters; a.sliceUnits = s.sliceUnits;
+  a.recW = reinterpret_cast<ExRec *>(p);
+  a.recS = a.recW + (size_t)s.nClusters * 2 * s.C * kMaxK;
+  a.totals = reinterpret_cast<double *>(a.recS + (size_t)s.nClusters * 2 * s.C * (kMaxK + 2));
+  a.priority = priority;
+  static std::atomic<unsigned long long> launches{0};
+  a.tagBase = (launches.fetch_add(1) + 1) << 32;
+  hipError_t e = hipSuccess;
+  const dim3 grid((unsigned)(s.C * s.nClusters));
+  if (f32) {
+    if (s.nu == 1) hipLaunchKernelGGL((eval_cluster_kernel<float, 1>), grid, dim3(kClusterThreads), s.shmem, stream, a);
+    else hipLaunchKernelGGL((eval_cluster_kernel<float, 2>), grid, dim3(kClusterThreads), s.shmem, stream, a);
+  } else {
+    if (s.nu == 1) hipLaunchKernelGGL((eval_cluster_kernel<double, 1>), grid, dim3(kClusterThreads), s.shmem, stream, a);
+    else hipLaunchKernelGGL((eval_cluster_kernel<double, 2>), grid, dim3(kClusterThreads), s.shmem, stream, a);
+  }
+  e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  const double nT = (double)(kb.nValidTargets + 1);             // PqaCore/CEEvalQsSubtaskConsider.cpp:191
+  hipLaunchKernelGGL(cluster_epilogue_kernel, dim3((unsigned)((kb.Q + 255) / 256)), dim3(256), 0, stream, a.totals, kb.qgap, asked,
+                     priority, kb.K, kb.Q, 0.34657359027997265470861606072909 / (nT * nT));
+  return hipGetLastError();
+}
+
+}  // namespace pqa

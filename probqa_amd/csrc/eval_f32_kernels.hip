@@ -30,11 +30,6 @@ namespace pqa {
 
 namespace {
 
-__device__ __forceinline__ float wave_sum_f32(float v) {
-#pragma unroll
-  for (int m = kWave / 2; m >= 1; m >>= 1) v += __shfl_xor(v, m, kWave);
-  return v;
-}
 __device__ __forceinline__ float rcp_nr_f32(float x) {       // 2^-22.5 -> full fp32 precision
   const float r = __builtin_amdgcn_rcpf(x);
   return fmaf(r, fmaf(-x, r, 1.0f), r);

@@ -216,6 +216,7 @@ Error HipEngine::Init(const CiEngineDefinition &def, const CiHipShard *shard) {
       }
       tblErr = UploadLog2Table(tbl.data());
       if (tblErr == hipSuccess) tblErr = UploadLog2TableBatch(tbl.data());
+      if (tblErr == hipSuccess) tblErr = UploadLog2TableCluster(tbl.data());
     });
     HIP_TRY(tblErr);
   }
@@ -300,7 +301,7 @@ HipEngine::~HipEngine() {
   for (Quiz *q : _quizzes) if (q) DestroyQuiz(q);
   hipFree(_dCube); hipFree(_dVB); hipFree(_dPriority); hipFree(_dRunLength); hipFree(_dExps); hipFree(_dStatus);
   hipFree(_dNOut); hipFree(_dSel); hipFree(_dSelScratch); hipFree(_dBatchSlots); hipFree(_dBatchScratch); hipFree(_dBatchPriority);
-  hipFree(_dBatchPT); hipFree(_dBatchAcc); hipFree(_dBatchRecs); hipFree(_dBatchPriT);
+  hipFree(_dBatchPT); hipFree(_dBatchAcc); hipFree(_dBatchRecs); hipFree(_dBatchPriT); hipFree(_dClusterScratch);
   DropQuizBufferPool();
   for (auto &g : _graphs) hipGraphExecDestroy(g.second.exec);
   hipFree(_dGraphScratch); hipFree(_dTagCell);
@@ -396,6 +397,7 @@ int64_t HipEngine::GetOption(const char *name) const {
 }
 
 const char *HipEngine::EvalKernelName() const { 
+  if (UseClusterSweep()) return EvalClusterKernelName(View());
   if (_elem == 8) return EvalVariantName(View(), (int)_optEvalVariant);
   return _optEvalVariant != 99 ? EvalF32KernelName(View(), (int)_optEvalVariant) : "f32_stream";
 }
@@ -758,7 +760,27 @@ Error HipEngine::EnqueueEval(int64_t iQuiz) {
 // The single-quiz sweep of this engine's precision on the engine's stream: the register-resident fp64 shapes with the fused
 // argmax (eval_kernels.hip) for Double engines; for Float engines the fp32 streaming sweep and, where a selection is asked
 // for, the argmax kernel behind it (batch_kernels.hip, select_kernels.hip).
+bool HipEngine::UseClusterSweep() const { return _optEvalVariant == 0 && _ldT > 16384 && EvalClusterSupported(View()); }
+
 Error HipEngine::LaunchSingleSweep(Quiz *q, const FusedSelect *fused) {
+  if (UseClusterSweep()) {
+    // long rows, either precision: the question split over a cluster of workgroups, then the epilogues, then (where a selection
+    // is asked for) the argmax kernel
+    const size_t need = EvalClusterScratchBytes(View());
+    if (need > _clusterScratchBytes) {
+      HIP_TRY(hipStreamSynchronize(_stream));
+      hipFree(_dClusterScratch);
+      _dClusterScratch = nullptr;
+      _clusterScratchBytes = 0;
+      HIP_TRY(hipMalloc(&_dClusterScratch, need));
+      HIP_TRY(hipMemsetAsync(_dClusterScratch, 0, need, _stream));   // (no record of fresh memory may look like a launch's)
+      _clusterScratchBytes = need;
+    }
+    HIP_TRY(LaunchEvalCluster(View(), q->dPrior, q->dAsked, _dPriority, _dClusterScratch, _stream));
+    if (fused != nullptr)
+      HIP_TRY(LaunchSelectArgmax(_dPriority, _dQGap, q->dAsked, 0, _Q, fused->outBase, fused->out, fused->seq, fused->flagValue, _stream));
+    return Error();
+  }
   if (_elem == 8) {
     HIP_TRY(LaunchEvalQuestions(View(), q->dPrior, q->dAsked, 0, _Q, _dPriority, (int)_optEvalVariant, fused, _stream));
     return Error();
@@ -1368,7 +1390,8 @@ void HipEngine::Speculate(Quiz *q) {
   const uint64_t seq = NextLaunchTag();
   const FusedSelect fs{_dSelScratch, &_hPinned->sel, &_hPinned->seq, seq, 0, 0, seq, nullptr, kind == 2 ? 1 : 0, 0, nullptr,
                        kind == 2 ? _hHostPriority : nullptr};
-  if (LaunchEvalQuestions(kb, q->dPrior, q->dAsked, 0, _Q, _dPriority, (int)_optEvalVariant, &fs, _stream) != hipSuccess) {
+  if (kind == 1 ? !LaunchSingleSweep(q, &fs).ok()
+                : LaunchEvalQuestions(kb, q->dPrior, q->dAsked, 0, _Q, _dPriority, (int)_optEvalVariant, &fs, _stream) != hipSuccess) {
     (void)hipGetLastError();   // NextQuestion will launch for itself and report
     return;
   }

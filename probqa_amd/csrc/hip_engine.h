@@ -317,6 +317,9 @@ class HipEngine : public IEngine {
   Error BatchSweep(int64_t n, const int64_t *pQuizzes, std::vector<Quiz *> &quizzes, bool wantPriorities, uint64_t tag);
   Error WaitBatchFlags(int64_t n, uint64_t tag);
   int _lastBatchBp = 0;
+  void *_dClusterScratch = nullptr;   // exchange buffers of the long-row sweep (cluster_kernels.hip), grown on demand
+  size_t _clusterScratchBytes = 0;
+  bool UseClusterSweep() const;       // rows beyond the register shapes, automatic variant, shape supported
   Error LaunchSingleSweep(Quiz *q, const FusedSelect *fused);   // the single-quiz sweep of this engine's precision, on _stream
   uint64_t _selSeq = 0;
   // Tag of the next fused launch: consecutive launches differ in the low 32 bits, and those are never 0 (the state of

@@ -191,6 +191,25 @@ __device__ __forceinline__ double wave_sum(double v) {
   return p.a + p.b;
 }
 
+// The same for a float: 4 DPP steps, 2 permlane swaps -- six full-rate instruction pairs instead of the six ds_bpermute round
+// trips (~100 cycles each, in series) that __shfl_xor costs.
+template <int CTRL>
+__device__ __forceinline__ float mov_dpp_f32(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float wave_sum_f32(float v) {
+  v += mov_dpp_f32<kDppXor1>(v);
+  v += mov_dpp_f32<kDppXor2>(v);
+  v += mov_dpp_f32<kDppHalfMirror>(v);
+  v += mov_dpp_f32<kDppMirror>(v);
+  const uint32_t b = __builtin_bit_cast(uint32_t, v);
+  const auto r = __builtin_amdgcn_permlane16_swap(b, b, false, false);
+  v = __builtin_bit_cast(float, (uint32_t)r[0]) + __builtin_bit_cast(float, (uint32_t)r[1]);
+  const uint32_t c = __builtin_bit_cast(uint32_t, v);
+  const auto r2 = __builtin_amdgcn_permlane32_swap(c, c, false, false);
+  return __builtin_bit_cast(float, (uint32_t)r2[0]) + __builtin_bit_cast(float, (uint32_t)r2[1]);
+}
+
 __device__ __forceinline__ Comp wave_sum_comp(Comp v) {
   v = comp_merge(v, Comp{mov_dpp<kDppXor1>(v.s), mov_dpp<kDppXor1>(v.c)});
   v = comp_merge(v, Comp{mov_dpp<kDppXor2>(v.s), mov_dpp<kDppXor2>(v.c)});

@@ -105,6 +105,13 @@ const char *EvalF32KernelName(const KbView &kb, int variant);
 hipError_t LaunchEvalQuestionsF32Reg(const KbView &kb, const double *prior, const uint32_t *asked, double *priority, int variant,
                                      hipStream_t stream);
 hipError_t UploadLog2TableBatch(const double *hostTable);
+// The single-quiz sweep for rows beyond the register shapes (ldT > 16384), fp32 and fp64: a question split over a cluster of
+// workgroups (cluster_kernels.hip).  `scratch`: EvalClusterScratchBytes(kb) bytes of device memory (exchange + totals).
+hipError_t UploadLog2TableCluster(const double *hostTable);
+bool EvalClusterSupported(const KbView &kb);
+const char *EvalClusterKernelName(const KbView &kb);
+size_t EvalClusterScratchBytes(const KbView &kb);
+hipError_t LaunchEvalCluster(const KbView &kb, const double *prior, const uint32_t *asked, double *priority, void *scratch, hipStream_t stream);
 const char *EvalVariantName(const KbView &kb, int variant);
 bool EvalVariantFusesSampled(const KbView &kb, int variant, int64_t nSubtasks);   // the launch can run the sampled selector itself
 bool EvalVariantHasFinisherWorkgroup(const KbView &kb, int variant);              // ... or hand the priority vector to the host (hostPriority)

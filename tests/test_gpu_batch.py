@@ -259,10 +259,12 @@ def test_batched_sweep_mid_size_fp64_and_fp32(factory):
                                      (4000, 5, "f32_wg256_nq4"), (4500, 5, "f32_wg320_nq4"), (6000, 2, "f32_wg384_nq4"),
                                      (8000, 5, "f32_wg512_nq4"), (10000, 5, "f32_wg640_nq4"),
                                      (11000, 16, "f32_wg704_nq4"), (12000, 5, "f32_wg768_nq4"),
-                                     (16384, 5, "f32_wg1024_nq4"), (20000, 5, "f32_stream"), (900, 17, "f32_stream")],
+                                     (16384, 5, "f32_wg1024_nq4"), (20000, 5, "f32_cluster7_x14"), (70000, 3, "f32_cluster18_x14"),
+                                     (900, 17, "f32_stream")],
                          ids=lambda v: str(v))
 def test_float_single_quiz_register_shapes(T, K, name, factory):
-    """The single-quiz sweep of a Float engine, every register shape (eval_f32_kernels.hip) and the streaming form behind them:
+    """The single-quiz sweep of a Float engine, every register shape (eval_f32_kernels.hip), the cluster form for long rows
+    (cluster_kernels.hip) and the streaming form behind them:
     against the fp64 oracle on the rounded cube at the fp32 tolerance, after StartQuiz and after three answers, with target and
     question gaps, one question per workgroup and two workgroups streaming all questions; the streaming form (variant 99) on
     the same states within twice the tolerance of the register form."""
@@ -301,4 +303,39 @@ def test_float_single_quiz_register_shapes(T, K, name, factory):
             eng.set_active_question(quiz, q)
             eng.record_answer(quiz, a)
     print(name, "max rel err as a fraction of the tolerance: %.3g" % worst)
+    eng.close()
+
+
+@pytest.mark.parametrize("T,K,name", [(20000, 5, "f64_cluster20_x14"), (40000, 2, "f64_cluster40_x12"), (16500, 9, "f64_cluster26_x14")],
+                         ids=lambda v: str(v))
+def test_double_long_rows_cluster_sweep(T, K, name, factory):
+    """Rows beyond the register shapes on a Double engine: the question split over a cluster of workgroups (cluster_kernels.hip).
+    Against the oracle at the stated bar, after StartQuiz and after three answers, with gaps; the streaming form (variant 99) on
+    the same states; argmax and the sampled selector's pick as the oracle's."""
+    Q = 14
+    rng = np.random.default_rng(T + K)
+    tgaps = sorted(set(rng.choice(T, 9, replace=False).tolist() + [T - 1, 0]))
+    case = cases.Case("f64long_%d" % T, K, Q, T, seed=T + 1, tgaps=tgaps, qgaps=[7], answers=[(5, 1), (0, K - 1), (13, 0)])
+    eng, orc = case.make_engine(factory), case.make_oracle()
+    assert eng.eval_kernel_name() == name
+    quiz = eng.start_quiz()
+    worst = 0.0
+    for step in range(len(case.answers) + 1):
+        hist = case.answers[:step]
+        opri, opriors = oracle_priorities(orc, hist)
+        assert np.array_equal(eng.get_priors(quiz), opriors)
+        pri = eng.eval_priorities(quiz)
+        r = rel_vec(pri, opri)
+        worst = max(worst, r.max())
+        assert r.max() < PRIORITY_RTOL, (name, step, float(r.max()))
+        eng.set_option("eval_variant", 99)
+        assert rel_vec(eng.eval_priorities(quiz), pri).max() < PRIORITY_RTOL
+        eng.set_option("eval_variant", 0)
+        assert pri[7] == 0 and all(pri[q] == 0 for q, _ in hist)
+        assert eng.next_question_argmax(quiz) == orc.select_argmax(opri)
+        if step < len(case.answers):
+            q, a = case.answers[step]
+            eng.set_active_question(quiz, q)
+            eng.record_answer(quiz, a)
+    print(name, "max rel err %.3g" % worst)
     eng.close()
