@@ -98,7 +98,32 @@ void run_pk(int wavesPerSimd) {
   hipFree(cyc);
 }
 
+// tick rate of s_memtime: a kernel that spins for a fixed number of ticks, timed by HIP events
+__global__ void spin_ticks(long long n, long long *out) {
+  const long long t0 = __builtin_amdgcn_s_memtime();
+  long long t = t0;
+  while (t - t0 < n) { __builtin_amdgcn_s_sleep(8); t = __builtin_amdgcn_s_memtime(); }
+  out[0] = t - t0;
+}
+static void calibrate() {
+  long long *d;
+  hipMalloc(&d, 8);
+  hipEvent_t a, b;
+  hipEventCreate(&a); hipEventCreate(&b);
+  for (int rep = 0; rep < 2; rep++) {
+    hipEventRecord(a);
+    hipLaunchKernelGGL(spin_ticks, dim3(1), dim3(64), 0, 0, 100000000LL, d);
+    hipEventRecord(b);
+    hipEventSynchronize(b);
+    float ms = 0; hipEventElapsedTime(&ms, a, b);
+    long long h = 0; hipMemcpy(&h, d, 8, hipMemcpyDeviceToHost);
+    printf("s_memtime: %lld ticks in %.3f ms -> %.1f MHz\n", h, ms, h / (ms * 1e3));
+  }
+  hipFree(d);
+}
+
 int main() {
+  calibrate();
   for (int w : {1, 2, 4}) {
     if (w == 1) { run<0, 16>("v_fma_f32", 1); run<3, 16>("v_add_f32", 1); run<1, 16>("v_log_f32 + add", 1, 1); run<2, 16>("v_rcp_f32 + add", 1, 1); run<4, 16>("v_med3_f32 + add", 1, 1); run<5, 16>("mul + v_exp_f32", 1, 1); run<6, 16>("v_sqrt_f32 + add", 1, 1); run_pk<16>(1); }
     if (w == 2) { run<0, 16>("v_fma_f32", 2); run<1, 16>("v_log_f32 + add", 2, 1); run<2, 16>("v_rcp_f32 + add", 2, 1); run_pk<16>(2); }
