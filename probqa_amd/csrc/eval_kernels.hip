@@ -105,7 +105,7 @@ __device__ __forceinline__ void fused_select(const EvalArgs &a, Best mine, int l
   // sampled: the finisher's workgroup reads every workgroup's priorities afterwards -- they must be visible before the record
   // (they are write-through stores, store_priority: waiting for their acknowledgements is enough -- a release fence here
   //  makes every workgroup write the whole L2 back, 7 us per launch)
-  if (sampled) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (sampled && a.fs.hostPriority == nullptr) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (host hand-over: tagged records)
   const Best wg = wave_best(mine);
   uint64_t seqValue = a.fs.seqValue, flagValue = a.fs.flagValue;
   if (a.fs.tagCell != nullptr)  // graph replay: the finisher of the previous replay left this launch's tag here
@@ -268,10 +268,15 @@ __device__ __forceinline__ void flush_pending(const EvalArgs &a, const double *p
     const double pri = eval_epilogue(rec, -rec[2 * K], rec + K, K, rec[2 * K + 1], a.vCompTail);  // :130
     store_priority(a.priority + (q - a.qFirst), pri);
     // hand-over of the priority vector to the host (FusedSelect::hostPriority): every workgroup delivers its own questions as it
-    // finishes them -- a gather by the finisher's workgroup after the last record (a round of loads past the L2s, a burst over
-    // the host link, a fence) put 5 us behind the sweep's 13.5
-    if (a.fs.hostPriority != nullptr && a.fs.sampleSubtasks > 0)
-      __hip_atomic_store(a.fs.hostPriority + (q - a.qFirst), pri, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    // finishes them, one 16-byte record {priority, launch tag} each, and waits for nothing -- a gather by the finisher's workgroup
+    // after the last record (a round of loads past the L2s, a burst over the host link, a fence) put 5 us behind the sweep's 13.5,
+    // and every workgroup waiting for its own stores' acknowledgements before reporting still 3.5
+    if (a.fs.hostPriority != nullptr && a.fs.sampleSubtasks > 0) {
+      typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+      const uint64_t w0 = d2u(pri), w1 = a.fs.seqValue;
+      const u4 x = {(unsigned)w0, (unsigned)(w0 >> 32), (unsigned)w1, (unsigned)(w1 >> 32)};
+      asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(a.fs.hostPriority + (q - a.qFirst)), "v"(x) : "memory");
+    }
     best_offer(best, pri, q - a.qFirst);
   }
 }
@@ -564,10 +569,10 @@ __device__ __forceinline__ void sweep_body(EvalArgs a, bool copyTable) {
     fused_select<SERVER>(a, bestLds[lane], lane, allReported);
   }
   if (a.fs.scratch != nullptr && a.fs.sampleSubtasks > 0 && a.fs.hostPriority != nullptr) {
-    // ---- the reference's selector on the HOST: the priorities are in host-coherent memory already (flush_pending: each
-    // workgroup stored its own and waited for the acknowledgements before its record went out, and fused_select above has seen
-    // every record), so workgroup 0 only raises the flag.  Launched and resident form alike (resident: the stores of the last
-    // step are made by the whole wave).  Asked and gap questions have no entry: the selector skips them by the bitmaps.
+    // ---- the reference's selector on the HOST: the priorities are on their way to host-coherent memory (flush_pending: tagged
+    // records) and fused_select above has seen every workgroup's record, so workgroup 0 only raises the flag.  Launched and
+    // resident form alike (resident: the stores of the last step are made by the whole wave).  Asked and gap questions have no
+    // entry: the selector skips them by the bitmaps.
     if (blockIdx.x == 0) {
       __syncthreads();
       const bool complete = *allReported;
@@ -1119,7 +1124,7 @@ bool EvalServerSupported(const KbView &kb, int variant) { return server_variant(
 
 hipError_t LaunchEvalServer(const KbView &kb, int64_t qFirst, int64_t qLimit, double *priority, int variant,
                             SelectResult *scratch, ServerMailbox *mailbox, void *requestLine, bool everyonePolls,
-                            ServerCtl *ctl, uint64_t lastSeq, uint64_t idleTicks, double *hostPriority, hipStream_t stream) {
+                            ServerCtl *ctl, uint64_t lastSeq, uint64_t idleTicks, TaggedPriority *hostPriority, hipStream_t stream) {
   if (qLimit <= qFirst || scratch == nullptr || mailbox == nullptr || requestLine == nullptr || ctl == nullptr)
     return hipErrorInvalidValue;
   EvalArgs args = make_args(kb, qFirst, qLimit);

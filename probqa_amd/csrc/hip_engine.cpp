@@ -830,9 +830,30 @@ hipError_t HipEngine::EnsureHostPriority() {
   if (_hHostPriority) hipHostFree(_hHostPriority);
   _hHostPriority = nullptr;
   _hostPriorityCap = 0;
-  const hipError_t e = hipHostMalloc((void **)&_hHostPriority, (size_t)_capQ * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent);
-  if (e == hipSuccess) _hostPriorityCap = _capQ;
+  const hipError_t e = hipHostMalloc((void **)&_hHostPriority, (size_t)_capQ * sizeof(TaggedPriority), hipHostMallocMapped | hipHostMallocCoherent);
+  if (e == hipSuccess) {
+    std::memset(_hHostPriority, 0, (size_t)_capQ * sizeof(TaggedPriority));   // (no launch has tag 0)
+    _hostPriorityCap = _capQ;
+  }
   return e;
+}
+
+// After the flag: the entries of the questions the sweep evaluated, each taken once it carries the launch's tag (the flag says
+// that every workgroup has reported, not that every one of its stores has landed).
+Error HipEngine::CollectHostPriority(uint64_t tag, const Quiz *q) {
+  _hostRun.resize((size_t)_Q);
+  const volatile TaggedPriority *rec = _hHostPriority;
+  const auto t0 = std::chrono::steady_clock::now();
+  for (int64_t i = 0; i < _Q; i++) {
+    if (BitTest(_hQGap, i) || BitTest(q->hAsked, i)) { _hostRun[(size_t)i] = 0.0; continue; }
+    uint64_t spins = 0;
+    while (rec[i].tag != tag)
+      if ((++spins & 0xFFFF) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(30))
+        return HipErr(hipErrorNotReady, "priority vector hand-over");
+    std::atomic_thread_fence(std::memory_order_acquire);
+    _hostRun[(size_t)i] = rec[i].priority;
+  }
+  return Error();
 }
 
 Error HipEngine::WaitFlag(volatile uint64_t *flag, uint64_t value, const char *what) {
@@ -1250,7 +1271,9 @@ int64_t HipEngine::NextQuestionSampled(Error &err, int64_t iQuiz, uint64_t rnd) 
     if (err.ok()) err = ServerWait(&_hPinned->seq, value, "NextQuestionSampled");
     if (!err.ok()) return -1;
     if (_hPinned->sel.index == -3) { err = HipErr(hipErrorLaunchFailure, "NextQuestionSampled (incomplete sweep)"); return -1; }
-    const int64_t sel = SelectSampledHost(_hHostPriority, _Q, nSub, rnd, [&](int64_t i) { return BitTest(_hQGap, i) || BitTest(q->hAsked, i); });
+    err = CollectHostPriority(_serverPosted, q);
+    if (!err.ok()) return -1;
+    const int64_t sel = SelectSampledHost(_hostRun.data(), _Q, nSub, rnd, [&](int64_t i) { return BitTest(_hQGap, i) || BitTest(q->hAsked, i); });
     return FinishSelection(err, q, sel);
   }
   uint64_t specTag = 0;
@@ -1272,7 +1295,9 @@ int64_t HipEngine::NextQuestionSampled(Error &err, int64_t iQuiz, uint64_t rnd) 
     err = WaitFlag(&_hPinned->seq, seq, "NextQuestionSampled");
     if (!err.ok()) return -1;
     if (_hPinned->sel.index == -3) { err = HipErr(hipErrorLaunchFailure, "NextQuestionSampled (incomplete sweep)"); return -1; }
-    const int64_t sel = SelectSampledHost(_hHostPriority, _Q, nSub, rnd, [&](int64_t i) { return BitTest(_hQGap, i) || BitTest(q->hAsked, i); });
+    err = CollectHostPriority(seq, q);
+    if (!err.ok()) return -1;
+    const int64_t sel = SelectSampledHost(_hostRun.data(), _Q, nSub, rnd, [&](int64_t i) { return BitTest(_hQGap, i) || BitTest(q->hAsked, i); });
     return FinishSelection(err, q, sel);
   }
   if (_optFusedSampled && _elem == 8 && EvalVariantFusesSampled(kb, (int)_optEvalVariant, nSub)) {

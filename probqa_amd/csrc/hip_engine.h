@@ -358,7 +358,9 @@ class HipEngine : public IEngine {
   int64_t _optBugCompat = 1;
   void ApplyEnvironment();   // PQA_SELECT / PQA_SERVER / PQA_BUG_COMPAT / PQA_WORKERS / PQA_SEED: defaults for unchanged wrappers
   int64_t _optHostSampled = 1;    // the sampled NextQuestion as ONE launch + the selector on the host (the finisher workgroup hands over the priority vector)
-  double *_hHostPriority = nullptr;   // host-coherent, _hostPriorityCap doubles
+  TaggedPriority *_hHostPriority = nullptr;   // host-coherent, _hostPriorityCap records {priority, launch tag}
+  std::vector<double> _hostRun;               // the vector the host-side selector works on
+  Error CollectHostPriority(uint64_t tag, const Quiz *q);   // the launch's entries out of _hHostPriority into _hostRun
   int64_t _hostPriorityCap = 0;
   hipError_t EnsureHostPriority();
   int64_t _optFusedSampled = 0;   // the sampled NextQuestion as ONE launch (the sweep's finisher workgroup runs the selector): correct,

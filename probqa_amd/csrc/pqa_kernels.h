@@ -43,6 +43,8 @@ hipError_t LaunchLog2HotArray(const double *x, double *out, int64_t n, hipStream
 // Returns hipSuccess or the launch error.  `variant`: 0 = auto, otherwise forces a kernel shape (tests/bench).
 // `fused` (optional): let the sweep's last workgroup also pick the argmax, so that a selection is one launch.
 constexpr int kFusedMaxGrid = 4096;     // workgroups of a fused launch (one record each)
+struct alignas(16) TaggedPriority { double priority; uint64_t tag; };
+
 struct FusedSelect {
   SelectResult *scratch;  // records (16-byte aligned): the workgroups' winners, tagged per launch; kFusedMaxGrid of them
                           // for a single sweep, scratchStride per quiz for a batch
@@ -62,10 +64,12 @@ struct FusedSelect {
   int64_t sampleSubtasks;
   uint64_t sampleRnd;
   double *runLength;
-  // ... or, with hostPriority != nullptr (and sampleSubtasks > 0): workgroup 0 only copies the finished priority vector into
-  // this host-coherent buffer and then sets the flag; the host runs the selector (O(Q) scalar Kahan steps, microseconds)
-  // instead of a second kernel whose dispatch alone costs more.
-  double *hostPriority;
+  // ... or, with hostPriority != nullptr (and sampleSubtasks > 0): the host runs the selector (O(Q) scalar Kahan steps,
+  // microseconds) instead of a second kernel whose dispatch alone costs more.  Every workgroup stores the priorities of its own
+  // questions into this host-coherent array as 16-byte records {priority, launch tag} (one store each, nothing waited for); the
+  // finisher raises the flag once it has seen every workgroup's record; the host takes an entry when it carries the launch's tag
+  // (it almost always does by then; a straggling store is waited for there, not by two thousand waves on the device).
+  TaggedPriority *hostPriority;
 };
 // One quiz of a batched sweep (blockIdx.y selects it): everything that differs between the quizzes of one launch.
 struct QuizSlot {
@@ -156,7 +160,7 @@ struct ServerCtl {                // device memory, one line; zeroed before each
 constexpr uint64_t kServerHandOver = 1ull << 62;
 hipError_t LaunchEvalServer(const KbView &kb, int64_t qFirst, int64_t qLimit, double *priority, int variant,
                             SelectResult *scratch, ServerMailbox *mailbox, void *requestLine, bool everyonePolls,
-                            ServerCtl *ctl, uint64_t lastSeq, uint64_t idleTicks, double *hostPriority, hipStream_t stream);
+                            ServerCtl *ctl, uint64_t lastSeq, uint64_t idleTicks, TaggedPriority *hostPriority, hipStream_t stream);
 bool EvalServerSupported(const KbView &kb, int variant);
 
 struct RatedTargetDev { int64_t iTarget; double prob; };  // == CiRatedTarget
