@@ -68,6 +68,12 @@ class ShardedEngine final : public IEngine {
   Error Train(int64_t n, const AQ *pAQs, int64_t iTarget, double amount) override {
     std::lock_guard<std::mutex> lk(_mu);
     for (auto &s : _sh) { Error e = s->Train(n, pAQs, iTarget, amount); if (!e.ok()) return e; }
+    return SyncShards();
+  }
+  // A shard's training kernel is ordered before that shard's later work only (its own stream); another shard's ResumeQuiz reads
+  // this shard's rows in place over peer access: the cube is settled before the call returns.
+  Error SyncShards() {
+    for (auto &s : _sh) { Error e = s->Synchronize(); if (!e.ok()) return e; }
     return Error();
   }
   uint64_t GetTotalQuestionsAsked(Error &err) override { return _sh[0]->GetTotalQuestionsAsked(err); }
@@ -82,7 +88,10 @@ class ShardedEngine final : public IEngine {
     std::lock_guard<std::mutex> lk(_mu);
     return _sh[_lastOwner.count(iQuiz) ? _lastOwner[iQuiz] : 0]->ListTopTargets(err, iQuiz, maxCount, pDest);   // (its kernel listed them already)
   }
-  Error RecordQuizTarget(int64_t iQuiz, int64_t iTarget, double amount) override { return All([&](HipEngine &e) { return e.RecordQuizTarget(iQuiz, iTarget, amount); }); }
+  Error RecordQuizTarget(int64_t iQuiz, int64_t iTarget, double amount) override {
+    Error e = All([&](HipEngine &sh) { return sh.RecordQuizTarget(iQuiz, iTarget, amount); });
+    return e.ok() ? SyncShards() : e;
+  }
   Error ReleaseQuiz(int64_t iQuiz) override {
     std::lock_guard<std::mutex> lk(_mu);
     _lastOwner.erase(iQuiz);
