@@ -895,7 +895,7 @@ int64_t HipEngine::NextQuestionArgmax(Error &err, int64_t iQuiz) {
   // One launch; the last workgroup writes the winner and then a sequence number straight into host-coherent pinned
   // memory, which this thread polls: no D2H copy, no stream synchronisation on the critical path.
   uint64_t seq;
-  if (!TakeSpeculation(q, 1, &seq)) {   // (else: RecordAnswer has launched this very sweep already)
+  if (TakeSpeculation(q, 1 << 1, &seq) == 0) {   // (else: RecordAnswer has launched this very sweep already)
     seq = NextLaunchTag();
     const FusedSelect fs{_dSelScratch, &_hPinned->sel, &_hPinned->seq, seq, 0, 0, seq, nullptr, 0, 0, nullptr, nullptr};
     StopServer();   // a launched sweep has no room beside the resident one and would wait for it to idle out
@@ -1277,9 +1277,10 @@ int64_t HipEngine::NextQuestionSampled(Error &err, int64_t iQuiz, uint64_t rnd) 
     return FinishSelection(err, q, sel);
   }
   uint64_t specTag = 0;
-  const bool speculated = TakeSpeculation(q, 2, &specTag);   // RecordAnswer has launched the sweep already
-  if (!speculated) StopServer();   // a launched sweep has no room beside the resident one and would wait for it to idle out
-  if (_optHostSampled && !_optFusedSampled && _elem == 8 && EvalVariantHasFinisherWorkgroup(kb, (int)_optEvalVariant)) {
+  const int took = TakeSpeculation(q, (1 << 2) | (1 << 3), &specTag);   // 2 / 3: RecordAnswer has launched the sweep already
+  const bool speculated = took == 2;
+  if (took == 0) StopServer();   // a launched sweep has no room beside the resident one and would wait for it to idle out
+  if (took != 3 && _optHostSampled && !_optFusedSampled && _elem == 8 && EvalVariantHasFinisherWorkgroup(kb, (int)_optEvalVariant)) {
     // ONE launch, and the selection on the host: the sweep's finisher workgroup copies the finished priority vector (8 bytes per
     // question) into host-coherent memory and sets the flag; the selector's O(Q) scalar Kahan steps take the host a few
     // microseconds -- less than the dispatch of the selector kernel they replace.
@@ -1300,7 +1301,7 @@ int64_t HipEngine::NextQuestionSampled(Error &err, int64_t iQuiz, uint64_t rnd) 
     const int64_t sel = SelectSampledHost(_hostRun.data(), _Q, nSub, rnd, [&](int64_t i) { return BitTest(_hQGap, i) || BitTest(q->hAsked, i); });
     return FinishSelection(err, q, sel);
   }
-  if (_optFusedSampled && _elem == 8 && EvalVariantFusesSampled(kb, (int)_optEvalVariant, nSub)) {
+  if (took != 3 && _optFusedSampled && _elem == 8 && EvalVariantFusesSampled(kb, (int)_optEvalVariant, nSub)) {
     // ONE launch: the sweep's finisher workgroup runs the reference's selector once every workgroup has reported
     const uint64_t seq = NextLaunchTag();
     const FusedSelect fs{_dSelScratch, &_hPinned->sel, &_hPinned->seq, seq, 0, 0, seq, nullptr, nSub, rnd, _dRunLength, nullptr};
@@ -1311,8 +1312,10 @@ int64_t HipEngine::NextQuestionSampled(Error &err, int64_t iQuiz, uint64_t rnd) 
     if (_hPinned->sel.index == -3) { err = HipErr(hipErrorLaunchFailure, "NextQuestionSampled (incomplete sweep)"); return -1; }
     return FinishSelection(err, q, _hPinned->sel.index);
   }
-  err = LaunchSingleSweep(q, nullptr);
-  if (!err.ok()) return -1;
+  if (took != 3) {   // (else: the priorities are in _dPriority already, or on their way there in stream order)
+    err = LaunchSingleSweep(q, nullptr);
+    if (!err.ok()) return -1;
+  }
   hipError_t he = hipSuccess;
   const uint64_t op = ++_opSeq;  // the selector writes its record and then this number into host-coherent memory
   if (he == hipSuccess)
@@ -1399,24 +1402,27 @@ Error HipEngine::RecordAnswerImpl(int64_t iQuiz, int64_t iAnswer, bool remote) {
   return Error();
 }
 
-// The sweep NextQuestion would launch for `q` now, launched now (see Speculation in hip_engine.h).  Whole-cube Double engines
-// with the launched selection paths only: the resident sweep and graph replay have no launch to move, shards' selections are
-// driven by the sharded engine, and the Float sweep has no finisher that hands its result over.
+// The sweep NextQuestion would launch for `q` now, launched now (see Speculation in hip_engine.h).  Whole-cube engines with the
+// launched selection paths only: the resident sweep and graph replay have no launch to move, and shards' selections are driven by
+// the sharded engine.  Where the sweep has no finisher that hands its result over (Float engines, long rows), the sampled selector's
+// kernel -- it needs the random number -- is launched by NextQuestion over the priorities the speculative sweep left.
 void HipEngine::Speculate(Quiz *q) {
   DropSpeculation();   // (one at a time: the hand-over buffers are the engine's)
-  if (!_optSpeculate || _optServer || _optUseGraph || _elem != 8 || _qTotal != _Q || _Q <= 0) return;
+  if (!_optSpeculate || _optServer || _optUseGraph || _qTotal != _Q || _Q <= 0) return;
   if (_specScore < -4 && (++_specProbe & 31) != 0) return;   // the client does not follow RecordAnswer with NextQuestion: probe now and then
   const KbView kb = View();
   int kind = 0;
   if (_optSelect == 1) kind = 1;
-  else if (_optHostSampled && !_optFusedSampled && EvalVariantHasFinisherWorkgroup(kb, (int)_optEvalVariant)) kind = 2;
+  else if (_optHostSampled && !_optFusedSampled && _elem == 8 && EvalVariantHasFinisherWorkgroup(kb, (int)_optEvalVariant)) kind = 2;
+  else if (!(_optFusedSampled && _elem == 8)) kind = 3;   // Float engines, long rows: the sweep now, the selector kernel at NextQuestion
   if (kind == 0) return;
   if (kind == 2 && EnsureHostPriority() != hipSuccess) return;
   const uint64_t seq = NextLaunchTag();
   const FusedSelect fs{_dSelScratch, &_hPinned->sel, &_hPinned->seq, seq, 0, 0, seq, nullptr, kind == 2 ? 1 : 0, 0, nullptr,
                        kind == 2 ? _hHostPriority : nullptr};
-  if (kind == 1 ? !LaunchSingleSweep(q, &fs).ok()
-                : LaunchEvalQuestions(kb, q->dPrior, q->dAsked, 0, _Q, _dPriority, (int)_optEvalVariant, &fs, _stream) != hipSuccess) {
+  if (kind == 1   ? !LaunchSingleSweep(q, &fs).ok()
+      : kind == 3 ? !LaunchSingleSweep(q, nullptr).ok()
+                  : LaunchEvalQuestions(kb, q->dPrior, q->dAsked, 0, _Q, _dPriority, (int)_optEvalVariant, &fs, _stream) != hipSuccess) {
     (void)hipGetLastError();   // NextQuestion will launch for itself and report
     return;
   }
@@ -1426,18 +1432,19 @@ void HipEngine::Speculate(Quiz *q) {
   _mu.busy = true;
 }
 
-// True (and the launch tag to wait for) if the pending speculative sweep is exactly the launch a NextQuestion of `kind` for `q`
-// would make now: same quiz and posterior, no fused launch since (they share the records and the hand-over buffers).
-bool HipEngine::TakeSpeculation(Quiz *q, int kind, uint64_t *pTag) {
-  if (_spec.quiz == nullptr) return false;
-  const bool match = _spec.quiz == q && _spec.kind == kind && _spec.priorVersion == q->priorVersion && _spec.tag == _selSeq &&
+// The kind (and the launch tag to wait for) of the pending speculative sweep if it is exactly a launch a NextQuestion accepting the
+// kinds of `kindMask` (bit k: kind k) would make for `q` now -- same quiz and posterior, no fused launch since (they share the
+// records and the hand-over buffers) -- else 0, and the speculation is dropped.
+int HipEngine::TakeSpeculation(Quiz *q, int kindMask, uint64_t *pTag) {
+  if (_spec.quiz == nullptr) return 0;
+  const bool match = _spec.quiz == q && ((kindMask >> _spec.kind) & 1) && _spec.priorVersion == q->priorVersion && _spec.tag == _selSeq &&
                      _spec.variant == _optEvalVariant && _spec.stream == _stream && !_optServer && !_optUseGraph;
-  if (!match) { DropSpeculation(); return false; }
+  if (!match) { DropSpeculation(); return 0; }
   _spec.quiz = nullptr;
   _specHits++;
   if (_specScore < 8) _specScore++;
   *pTag = _spec.tag;
-  return true;
+  return _spec.kind;
 }
 
 Error HipEngine::RecordAnswer(int64_t iQuiz, int64_t iAnswer) { return RecordAnswerImpl(iQuiz, iAnswer, false); }

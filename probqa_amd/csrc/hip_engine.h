@@ -377,7 +377,7 @@ class HipEngine : public IEngine {
   struct Speculation {
     Quiz *quiz = nullptr;
     uint64_t priorVersion = 0, tag = 0;
-    int kind = 0;            // 1: argmax record in _hPinned->sel; 2: priority vector in _hHostPriority
+    int kind = 0;            // 1: argmax record in _hPinned->sel; 2: priority vector in _hHostPriority; 3: priorities in _dPriority
     int64_t variant = 0;
     hipStream_t stream = nullptr;
   } _spec;
@@ -386,7 +386,7 @@ class HipEngine : public IEngine {
   uint64_t _specProbe = 0, _specHits = 0, _specDropped = 0;
   void Speculate(Quiz *q);
   int64_t SpeculateFor(int64_t iQuiz);
-  bool TakeSpeculation(Quiz *q, int kind, uint64_t *pTag);
+  int TakeSpeculation(Quiz *q, int kindMask, uint64_t *pTag);
   void DropSpeculation() {
     if (_spec.quiz != nullptr) { _spec.quiz = nullptr; _specDropped++; if (_specScore > -8) _specScore--; }
   }

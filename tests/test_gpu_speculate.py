@@ -12,8 +12,12 @@ pytestmark = pytest.mark.gpu
 SUBTASKS = 8 * cases.WORKERS
 
 
-def make(case, factory, speculate, select):
-    eng = case.make_engine(factory)
+def make(case, factory, speculate, select, f32=False):
+    if f32:
+        import test_gpu_batch as tb
+        eng, _ = tb.float_engine(case, factory)
+    else:
+        eng = case.make_engine(factory)
     eng.set_option("speculate", speculate)
     eng.set_option("select", select)
     eng.set_option("seed", 77)
@@ -108,3 +112,31 @@ def test_stops_speculating_for_a_client_that_never_follows_up(factory):
     assert eng.get_option("spec_dropped") <= 8
     assert eng.get_option("spec_hits") == 0
     eng.close()
+
+
+@pytest.mark.parametrize("select", [0, 1], ids=["sampled", "argmax"])
+@pytest.mark.parametrize("f32,dims", [(True, (5, 48, 700)), (True, (5, 30, 5000)), (False, (5, 16, 20000)), (True, (3, 16, 17000))],
+                         ids=["f32_48x5x700", "f32_30x5x5000", "f64_long_rows", "f32_long_rows"])
+def test_float_engines_and_long_rows(f32, dims, select, factory):
+    """Where the sweep has no finisher that hands its result over -- Float engines, rows beyond the register shapes -- RecordAnswer
+    launches the sweep alone and the sampled selector's kernel follows at NextQuestion: the same questions as without."""
+    K, Q, T = dims
+    case = cases.Case("spec_f", K, Q, T, seed=41)
+    a, b = make(case, factory, 1, select, f32), make(case, factory, 0, select, f32)
+    rng = np.random.default_rng(6)
+    qa, qb = a.start_quiz(), b.start_quiz()
+    n_steps = min(8, Q - 1)
+    for step in range(n_steps):
+        if select == 1:
+            ga, gb = a.next_question(qa), b.next_question(qb)
+        else:
+            rnd = int(rng.integers(0, 2**63)) * 2 + int(rng.integers(0, 2))
+            ga, gb = a.next_question_sampled(qa, rnd), b.next_question_sampled(qb, rnd)
+        assert ga == gb, step
+        ans = int(rng.integers(0, K))
+        a.record_answer(qa, ans)
+        b.record_answer(qb, ans)
+    assert np.array_equal(a.get_priors(qa), b.get_priors(qb))
+    assert a.get_option("spec_hits") == n_steps and b.get_option("spec_hits") == 0
+    a.close()
+    b.close()
