@@ -503,7 +503,8 @@ int64_t HipEngine::CreateQuiz(Error &err, int64_t nAnswered, const AQ *pAQs, con
     he = hipMalloc(&quiz->dPrior, (size_t)_ldT * sizeof(double));
     if (he == hipSuccess) he = hipMalloc(&quiz->dAsked, quiz->hAsked.size() * sizeof(uint32_t));
   }
-  if (he == hipSuccess)  // (StartQuiz: nothing asked yet, no host source needed; ResumeQuiz synchronises further down)
+  const bool startClears = nAnswered == 0 && srcPrior == nullptr;   // StartQuiz: its kernel clears the bitmap itself
+  if (he == hipSuccess && !startClears)   // (ResumeQuiz synchronises further down: the host source stays valid)
     he = nAnswered == 0 ? hipMemsetAsync(quiz->dAsked, 0, quiz->hAsked.size() * sizeof(uint32_t), _stream)
                         : hipMemcpyAsync(quiz->dAsked, quiz->hAsked.data(), quiz->hAsked.size() * sizeof(uint32_t),
                                          hipMemcpyHostToDevice, _stream);
@@ -517,7 +518,7 @@ int64_t HipEngine::CreateQuiz(Error &err, int64_t nAnswered, const AQ *pAQs, con
     for (int64_t i = 0; i < nAnswered; i++) quiz->answers.push_back(pAQs[i]);
   } else if (nAnswered == 0) {
     // CECreateQuizStart::UpdateLikelihoods, reference PqaCore/CECreateQuizOperation.cpp:22-53
-    he = LaunchStartQuiz(kb, quiz->dPrior, _optWorkers, _stream);
+    he = LaunchStartQuiz(kb, quiz->dPrior, quiz->dAsked, (int64_t)quiz->hAsked.size(), _optWorkers, _stream);
     if (he != hipSuccess) return fail(HipErr(he, "LaunchStartQuiz"));
     // no synchronisation: every reader of the prior or the bitmap is ordered behind these on the engine's stream
   } else {

@@ -179,7 +179,7 @@ hipError_t LaunchSelectSampled(const double *priority, const uint32_t *qgap, con
 // ---- prior updates (single workgroup, O(T)); nWorkers = emulated CPU worker count that fixes the summation order.
 // The subtasks' partial sums live in (8 nWorkers + 1) doubles of LDS, within the 64 KiB a launch gets without opting in.
 constexpr int64_t kMaxWorkers = 1000;
-hipError_t LaunchStartQuiz(const KbView &kb, double *prior, int64_t nWorkers, hipStream_t stream);
+hipError_t LaunchStartQuiz(const KbView &kb, double *prior, uint32_t *asked, int64_t askedWords, int64_t nWorkers, hipStream_t stream);
 // topOut (optional, host-coherent with topN / topFlag): also list the new posterior's topCount best targets, then store
 // topFlagValue to *topFlag.
 hipError_t LaunchRecordAnswer(const KbView &kb, double *prior, uint32_t *asked, int64_t iQuestion, int64_t iAnswer,

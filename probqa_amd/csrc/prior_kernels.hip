@@ -29,8 +29,10 @@ constexpr int kThreads = 1024;
 constexpr int kSmallThreads = 256;
 static inline bool small_launch(const KbView &kb) { return kb.smallLaunches && kb.T <= 4 * kSmallThreads; }
 
-__global__ __launch_bounds__(kThreads) void start_quiz_kernel(PriorArgs a) {
+// (clears the new quiz's asked bitmap as well: a memset beside it is a second launch)
+__global__ __launch_bounds__(kThreads) void start_quiz_kernel(PriorArgs a, uint32_t *__restrict__ asked, int64_t askedWords) {
   extern __shared__ double lds[];
+  for (int64_t i = threadIdx.x; i < askedWords; i += blockDim.x) asked[i] = 0;
   const int64_t nVects = (a.T + 3) >> 2;
   double *stage = prior_stage(a, lds);
   for (int64_t t = threadIdx.x; t < a.ldT; t += blockDim.x)
@@ -148,10 +150,10 @@ PriorArgs make_args(const KbView &kb, double *prior, int64_t nWorkers, bool stag
 
 }  // namespace
 
-hipError_t LaunchStartQuiz(const KbView &kb, double *prior, int64_t nWorkers, hipStream_t stream) {
+hipError_t LaunchStartQuiz(const KbView &kb, double *prior, uint32_t *asked, int64_t askedWords, int64_t nWorkers, hipStream_t stream) {
   if (nWorkers < 1 || nWorkers > kMaxWorkers) return hipErrorInvalidValue;
   hipLaunchKernelGGL(start_quiz_kernel, dim3(1), dim3(small_launch(kb) ? kSmallThreads : kThreads), staged_lds_bytes(kb, nWorkers), stream,
-                     make_args(kb, prior, nWorkers, true));
+                     make_args(kb, prior, nWorkers, true), asked, askedWords);
   return hipGetLastError();
 }
 
