@@ -883,7 +883,7 @@ int64_t HipEngine::NextQuestionArgmax(Error &err, int64_t iQuiz) {
   if (_optUseGraph && _elem == 8) return NextQuestionArgmaxGraph(err, q);
   if (_optServer && ServerUsable()) {
     // resident sweep: post the request, poll the answer -- no launch on the critical path
-    const uint64_t value = ++_opSeq;
+    const uint64_t value = kServerFlagBase | ++_opSeq;   // (its own range: see kGraphFlagBase)
     err = ServerPost(q, &_hPinned->sel, &_hPinned->seq, value, 0);
     if (err.ok()) err = ServerWait(&_hPinned->seq, value, "NextQuestionArgmax");
     if (!err.ok()) return -1;
@@ -1219,11 +1219,11 @@ int64_t HipEngine::NextQuestionArgmaxGraph(Error &err, Quiz *q) {
     hipError_t he = hipMalloc(&_dGraphScratch, kFusedMaxGrid * sizeof(SelectResult));
     if (he == hipSuccess) he = hipMemsetAsync(_dGraphScratch, 0, kFusedMaxGrid * sizeof(SelectResult), _stream);
     if (he == hipSuccess) he = hipMalloc(&_dTagCell, sizeof(uint64_t));
-    const uint64_t one = 1;
+    const uint64_t one = kGraphFlagBase + 1;
     if (he == hipSuccess) he = hipMemcpyAsync(_dTagCell, &one, sizeof(one), hipMemcpyHostToDevice, _stream);
     if (he == hipSuccess) he = hipStreamSynchronize(_stream);
     if (he != hipSuccess) { err = HipErr(he, "graph selection buffers"); return -1; }
-    _graphTag = 1;
+    _graphTag = one;
   }
   auto it = _graphs.find(q);
   if (it == _graphs.end() || it->second.variant != _optEvalVariant || it->second.stream != _stream ||
@@ -1267,7 +1267,7 @@ int64_t HipEngine::NextQuestionSampled(Error &err, int64_t iQuiz, uint64_t rnd) 
   const int64_t nSub = _optEvalSubtasks ? _optEvalSubtasks : 8 * _optWorkers;  // reference PqaCore/CpuEngine.cpp:339
   if (_optServer && _optHostSampled && !_optFusedSampled && ServerUsable()) {
     // resident sweep: post the request with the hand-over mark, poll the flag, select on the host -- no launch on the path
-    const uint64_t value = ++_opSeq;
+    const uint64_t value = kServerFlagBase | ++_opSeq;   // (its own range: see kGraphFlagBase)
     err = ServerPost(q, &_hPinned->sel, &_hPinned->seq, value, (int64_t)kServerHandOver);
     if (err.ok()) err = ServerWait(&_hPinned->seq, value, "NextQuestionSampled");
     if (!err.ok()) return -1;

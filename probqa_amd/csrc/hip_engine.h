@@ -285,7 +285,12 @@ class HipEngine : public IEngine {
   std::unordered_map<Quiz *, GraphEntry> _graphs;  // option "use_graph"
   SelectResult *_dGraphScratch = nullptr;
   uint64_t *_dTagCell = nullptr;
-  uint64_t _graphTag = 1;
+  // The launched, graph-replayed and resident selections all report through _hPinned->sel / ->seq, each waiting for "its" value of
+  // the flag: the three sequences live in disjoint ranges, or a selection would find the flag already holding its value -- left by
+  // another path's earlier selection -- and return that one's question (graph tag 1, then the resident sweep's first request, also
+  // 1: found by the soak of tools/stress_more.py).  Launch tags (NextLaunchTag) count from 1 and stay below 2^40.
+  static constexpr uint64_t kGraphFlagBase = 1ull << 40, kServerFlagBase = 2ull << 40;
+  uint64_t _graphTag = kGraphFlagBase + 1;
   void DropQuizBufferPool();
   SelectResult *_dSel = nullptr;
   struct Pinned {  // host-coherent: written by kernels, polled / read by the host without copies

@@ -8,6 +8,8 @@ import pytest
 import cases
 from probqa_amd import interop
 
+SUBTASKS = 8 * cases.WORKERS
+
 pytestmark = pytest.mark.gpu
 
 
@@ -192,3 +194,36 @@ def test_leaving_races_with_posting(factory, vram):
         assert n > 1000
     finally:
         e.close()
+
+
+@pytest.mark.parametrize("first", ["graph", "launch", "resident"])
+@pytest.mark.parametrize("second", ["graph", "launch", "resident"])
+def test_selection_paths_do_not_mistake_each_others_flags(first, second, factory):
+    """The launched, graph-replayed and resident selections report through the same pinned record and flag.  A selection through
+    one path right after the engine's first selection through another: the flag still holds the other path's value, which must
+    not pass for this selection's (graph tag 1 and the resident sweep's first request used to be the same number: the second
+    quiz got the first one's question)."""
+    case = cases.Case("flags", 4, 48, 300, seed=130)
+    eng = case.make_engine(factory)
+    eng.set_option("select", 1)
+    orc_a, orc_b = case.make_oracle(), case.make_oracle()
+
+    def via(path, quiz):
+        eng.set_option("server", 1 if path == "resident" else 0)
+        eng.set_option("use_graph", 1 if path == "graph" else 0)
+        got = eng.next_question(quiz)
+        eng.set_option("use_graph", 0)
+        return got
+
+    qa = eng.resume_quiz([interop.AnsweredQuestion(27, 0), interop.AnsweredQuestion(11, 3)])
+    assert orc_a.resume_quiz([(27, 0), (11, 3)], cases.WORKERS, True) == 0
+    want_a = orc_a.select_argmax(orc_a.eval(SUBTASKS)[1])
+    assert via(first, qa) == want_a
+    qb = eng.resume_quiz([interop.AnsweredQuestion(want_a, 2)])
+    assert orc_b.resume_quiz([(want_a, 2)], cases.WORKERS, True) == 0
+    want_b = orc_b.select_argmax(orc_b.eval(SUBTASKS)[1])
+    assert want_b != want_a
+    assert via(second, qb) == want_b
+    for path in ("graph", "launch", "resident"):      # and once more round, each path after the others
+        assert via(path, qa) == want_a and via(path, qb) == want_b
+    eng.close()

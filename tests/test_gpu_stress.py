@@ -38,9 +38,11 @@ class Shadow:
 
 
 @pytest.mark.parametrize("seed,mode", [(1, "plain"), (2, "plain"), (3, "plain"), (4, "resident"), (5, "resident"),
-                                       (6, "row_sharing_batches"), (7, "three_shards"), (8, "three_shards")],
+                                       (6, "row_sharing_batches"), (7, "three_shards"), (8, "three_shards"),
+                                       (20, "resident"), (30, "resident"), (51, "resident")],   # (found by tools/stress_more.py)
                          ids=["seed1", "seed2", "seed3", "seed4_resident_sweep", "seed5_resident_sweep", "seed6_row_sharing_batches",
-                              "seed7_three_shards", "seed8_three_shards"])
+                              "seed7_three_shards", "seed8_three_shards", "seed20_resident_sweep", "seed30_resident_sweep",
+                              "seed51_resident_sweep"])
 def test_random_interleaving_against_per_quiz_oracles(factory, seed, mode):
     import os
 
