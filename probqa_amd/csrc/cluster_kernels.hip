@@ -395,7 +395,12 @@ bool cluster_shape(const KbView &kb, int nCU, ClusterShape *out) {
   if (maxUnits < kWave) return false;
   const int64_t C = (nUnits + maxUnits - 1) / maxUnits;
   const int capacity = 2 * nCU;
-  if (C > capacity || (size_t)C * (kb.K + 2) * sizeof(double) > kExchangeLdsBytes) return false;
+  // A cluster's members wait for each other, so they must become resident together.  Workgroups of a launch are dispatched in
+  // order: at any time a launch has at most ONE incomplete cluster on the device (its frontier), every other resident cluster is
+  // complete and finishes its questions whatever else happens -- so even several such launches in flight at once (shards of one
+  // engine on one device, two processes on one GPU) keep making progress as long as their frontiers together do not fill the
+  // device.  Clusters of at most a quarter of the device: three launches at once can never.
+  if (C > capacity / 4 || (size_t)C * (kb.K + 2) * sizeof(double) > kExchangeLdsBytes) return false;
   int64_t su = ((nUnits + C - 1) / C + kWave - 1) / kWave * kWave;        // whole waves of units
   out->C = (int)C;
   out->nClusters = (int)std::max<int64_t>(1, std::min<int64_t>(capacity / C, kb.Q));
