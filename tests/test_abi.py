@@ -64,7 +64,9 @@ def test_null_handles_follow_the_reference_convention(factory):
     assert "IPqaEngineFactory" in interop.PqaError(c_err.value).to_string(True)
     lib.CiReleasePqaError(None)
     lib.CiReleasePqaEngine(None)
-    assert lib.Logger_Init(ctypes.byref(ctypes.c_void_p()), b"x") == 1
+    import tempfile
+    base = os.path.join(tempfile.mkdtemp(prefix="pqa_log_"), "x")   # (the log file <base>_<UTC time>_<pid>.log: not into the repository)
+    assert lib.Logger_Init(ctypes.byref(ctypes.c_void_p()), base.encode()) == 1
 
 
 def test_no_cpu_fallback_without_a_gpu(factory):
