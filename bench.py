@@ -70,8 +70,15 @@ def main():
     ap.add_argument("--no-server", action="store_true", help="launch one kernel per selection even where a resident sweep exists")
     ap.add_argument("--no-quiz-loop", action="store_true", help="skip the quiz-loop extra")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-points", action="store_true", help="one GPU, default config: skip the M and L1 points (hbm_point_M, valu_point_L1)")
+    ap.add_argument("--sharded-configs", default="S,M,L1", help="sharded runs: which of the extras S, M, L1 to run (both exchanges each)")
+    ap.add_argument("--l1-config", default="L1", choices=("L1", "LS", "SB"), help="the batched configuration of the sharded extras (tests use a small one)")
     ap.add_argument("--cpu-seconds", type=float, default=3.0, help="wall seconds of the CPU baseline leg")
     args = ap.parse_args()
+
+    # `python bench.py --gpus N` by itself: start the N ranks (one process per GPU) the way the driver does
+    if args.gpus > 1 and "RANK" not in os.environ:
+        raise SystemExit(self_spawn(args.gpus))
 
     # stdout carries exactly one line, the result: libraries that print there (RCCL's version banner, for one) are sent
     # to stderr for the whole run
@@ -88,33 +95,28 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
-        args.gpus = world
+    args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
-    if world > 1 or args.force_collective:
-        import torch.distributed as dist
-
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
-        os.environ.setdefault("RANK", "0")
-        os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group(backend="nccl", device_id=device)
+    # Fewer devices than ranks (a 1-GPU box asked for --gpus 2): a DRY RUN of the N > 1 path -- the ranks share devices, the
+    # control plane is gloo (RCCL refuses two ranks on one device) and the RCCL exchange is reported as skipped.
+    n_dev = torch.cuda.device_count()
+    dev_index = local_rank % n_dev
+    oversub = world > n_dev
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
+    ctl = Ctl(torch, world, device, oversub, args.force_collective)
+    if oversub:
+        args.no_server = True      # two engines' resident kernels on one device wait for each other's idle exit
+        print("bench.py: %d ranks on %d device(s): dry run of the sharded path (gloo control plane, no RCCL exchange)" % (world, n_dev), file=sys.stderr)
 
     cfg = CONFIGS[args.config]
     Q, K, T = cfg["Q"], cfg["K"], cfg["T"]
     if "quizzes" in cfg:
-        out = run_batched(args, cfg, np, torch, interop, pdist, world, rank, local_rank, device)
+        out = run_batched(args, cfg, np, torch, interop, pdist, ctl, rank, dev_index, device)
         if rank == 0:
             os.write(result_fd, (json.dumps(out) + "\n").encode())
-        if world > 1:
-            import torch.distributed as dist
-
-            dist.destroy_process_group()
+        ctl.close()
         return
     if args.batch < 0:
         args.batch = 64 if Q * (K + 1) * T * 8 < 1e9 else 8
@@ -123,46 +125,50 @@ def main():
     torch.cuda.set_stream(stream)
     sharded = world > 1 or args.force_collective
 
-    def make_engine(c, tag):
-        """This rank's shard of cube `c`, one quiz started, and (sharded runs) the selector over all ranks."""
+    def make_engine(c):
+        """This rank's shard of cube `c` and one quiz started."""
         qf, ql = pdist.shard_range(c["Q"], world, rank)
-        e = factory.create_hip_engine(interop.EngineDefinition(c["K"], ql - qf, c["T"], init_amount=0.1), qf, c["Q"], local_rank)
+        e = factory.create_hip_engine(interop.EngineDefinition(c["K"], ql - qf, c["T"], init_amount=0.1), qf, c["Q"], dev_index)
         e.set_option("select", 1)
         e.set_option("eval_variant", args.variant)
         e.fill_synthetic(8.0, 0.5, SEED)
         e.set_stream(stream.cuda_stream)
-        qz = e.start_quiz()
-        sel_obj = None
-        if sharded:
-            if args.exchange == "shm":
-                import torch.distributed as dist
+        return e, e.start_quiz(), ql - qf
 
-                name = "bench_%s_%s" % (os.environ.get("MASTER_PORT", "0"), tag)
-                ok = 1
-                try:
-                    if rank == 0:
-                        sel_obj = pdist.ShmSelector(e, qz, rank, world, name, create=True)
-                except Exception as ex:  # noqa: BLE001 - every rank must take the same path
-                    print("rank 0: shared-memory exchange unavailable (%r)" % (ex,), file=sys.stderr)
-                    ok = 0
-                dist.barrier()                      # the segment exists before the other ranks open it
-                try:
-                    if rank != 0 and ok:
-                        sel_obj = pdist.ShmSelector(e, qz, rank, world, name, create=False)
-                except Exception as ex:  # noqa: BLE001
-                    print("rank %d: shared-memory exchange unavailable (%r)" % (rank, ex), file=sys.stderr)
-                    ok = 0
-                flag = torch.tensor([ok], dtype=torch.int32, device=device)
-                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-                if int(flag.item()) == 0:           # one rank could not: all ranks use the collective
-                    if sel_obj is not None:
-                        sel_obj.close()
-                    sel_obj, args.exchange = None, "rccl"
-            if sel_obj is None:
-                sel_obj = pdist.ShardedSelector(lambda out: e.enqueue_select_argmax(qz, out.data_ptr()), device)
-        return e, qz, sel_obj, ql - qf
+    def make_selector(e, qz, kind, tag):
+        """The exchange of the shards' 16-byte winners: "shm" (slots in host shared memory written by the sweeps' finishers) or
+        "rccl" (one all-gather).  Every rank takes the same path: returns (selector or None, kind actually used)."""
+        if kind == "shm":
+            name = "bench_%s_%s" % (os.environ.get("MASTER_PORT", "0"), tag)
+            sel_obj, ok = None, 1
+            try:
+                if rank == 0:
+                    sel_obj = pdist.ShmSelector(e, qz, rank, world, name, create=True)
+            except Exception as ex:  # noqa: BLE001 - every rank must take the same path
+                print("rank 0: shared-memory exchange unavailable (%r)" % (ex,), file=sys.stderr)
+                ok = 0
+            ctl.barrier()                       # the segment exists before the other ranks open it
+            try:
+                if rank != 0 and ok:
+                    sel_obj = pdist.ShmSelector(e, qz, rank, world, name, create=False)
+            except Exception as ex:  # noqa: BLE001
+                print("rank %d: shared-memory exchange unavailable (%r)" % (rank, ex), file=sys.stderr)
+                ok = 0
+            if ctl.min_int(ok) == 1:
+                return sel_obj, "shm"
+            if sel_obj is not None:             # one rank could not: all ranks use the collective
+                sel_obj.close()
+            kind = "rccl"
+        if not ctl.rccl:
+            return None, "none"                 # (dry run on shared devices: no RCCL)
+        return pdist.ShardedSelector(lambda out: e.enqueue_select_argmax(qz, out.data_ptr()), device), "rccl"
 
-    eng, quiz, selector, q_local = make_engine(cfg, "main")
+    eng, quiz, q_local = make_engine(cfg)
+    selector = None
+    if sharded:
+        selector, args.exchange = make_selector(eng, quiz, args.exchange, "main")
+        if selector is None:
+            raise SystemExit("no exchange available for the sharded run")
 
     def step():
         if selector is None:
@@ -170,13 +176,7 @@ def main():
         _, q = selector.select()
         return q
 
-    def barrier():
-        torch.cuda.synchronize()
-        if world > 1:
-            import torch.distributed as dist
-
-            dist.barrier()
-        torch.cuda.synchronize()
+    barrier = ctl.barrier
 
     def timed(fn, warmup, steps, e=None):
         """W untimed steps, then exactly K steps between barrier + synchronize; the maximum over ranks.
@@ -195,14 +195,7 @@ def main():
             r = fn()
         e.synchronize()
         barrier()
-        dt = time.perf_counter() - t0
-        if world > 1:
-            import torch.distributed as dist
-
-            t = torch.tensor([dt], dtype=torch.float64, device=device)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
-        return dt, r
+        return ctl.max_float(time.perf_counter() - t0), r
 
     def kernel_ms_of(e, qz, n_k):
         """dominant kernel: live HIP-event timing on the engine's stream, back-to-back launches"""
@@ -343,22 +336,53 @@ def main():
                      "note": "reference figure: PqaClient learner loop on the author's 2017 desktop CPU (BASELINE.md); "
                              "here: Python wrapper of the C ABI, one quiz at a time, sampled selector"}
 
-    # ---- extra (not `value`), sharded runs only: BASELINE configs[3], the 10000x5x10000 cube over the same ranks -- the
-    # configuration where sharding the question axis is about bandwidth rather than about launch latency
-    sharded_m = None
+    # ---- extras (not `value`), sharded runs only.  Every one of them reports BOTH exchanges of the shards' winners: the slots
+    # in host shared memory that the sweeps' finishers write (the default path of `value`) and the RCCL all-gather that
+    # north_star names -- S (this cube), M = BASELINE configs[3] (10000x5x10000 over the same ranks: where sharding is about
+    # bandwidth rather than launch latency), L1 = BASELINE configs[4] (one 12500x5x100000 fp32 shard per rank, 256 quizzes).
+    def both_exchanges(e, qz, tag, warm, n_steps, first=None):
+        """{kind: {selections_per_sec, us_per_step, selected_question}} for shm and rccl on engine `e` (resident sweep off)."""
+        res = {}
+        e.set_option("server", 0)
+        for kind in ("shm", "rccl"):
+            if first is not None and kind == first[0]:
+                res[kind] = first[1]
+                continue
+            sel_x, used = make_selector(e, qz, kind, tag + kind)
+            if sel_x is None or used != kind:
+                res[kind] = {"skipped": "the ranks share a device: RCCL refuses that" if kind == "rccl" and not ctl.rccl else "unavailable on this host"}
+                if sel_x is not None and hasattr(sel_x, "close"):
+                    sel_x.close()
+                continue
+            dt_x, pick_x = timed(lambda: sel_x.select()[1], warm, n_steps, e)
+            res[kind] = {"selections_per_sec": n_steps / dt_x, "us_per_step": 1e6 * dt_x / n_steps, "selected_question": int(pick_x)}
+            if hasattr(sel_x, "close"):
+                sel_x.close()
+        return res
+
+    exchanges_s, sharded_m, sharded_l1 = None, None, None
+    want = set(x for x in args.sharded_configs.split(",") if x)
     if sharded and args.config == "S":
-        cm = CONFIGS["M"]
-        eng_m, quiz_m, sel_m, q_local_m = make_engine(cm, "m")
-        dt_m, pick_m = timed(lambda: sel_m.select()[1], 20, 200, eng_m)
-        k_ms = kernel_ms_of(eng_m, quiz_m, 20)
-        bytes_m = q_local_m * (cm["K"] + 1) * cm["T"] * 8
-        sharded_m = {"workload": cm["name"] + " fp64, question axis sharded over the ranks", "selections_per_sec": 200 / dt_m,
-                     "ms_per_step": 1e3 * dt_m / 200, "questions_per_gpu": q_local_m, "selected_question": int(pick_m),
-                     "rank0_kernel_us": 1e3 * k_ms, "rank0_kernel_GBps": bytes_m / (k_ms * 1e-3) / 1e9,
-                     "eval_kernel": eng_m.eval_kernel_name()}
-        if hasattr(sel_m, "close"):
-            sel_m.close()
-        eng_m.close()
+        if "S" in want:
+            exchanges_s = both_exchanges(eng, quiz, "s", 200, max(500, min(args.steps, 2000)),
+                                         None if resident else (args.exchange, {"selections_per_sec": value, "us_per_step": 1e6 / value, "selected_question": int(sel)}))
+            exchanges_s["note"] = "one launch per selection on both (the timed `value` uses %s%s)" % (
+                args.exchange, " through the resident sweep" if resident else "")
+        if "M" in want:
+            cm = CONFIGS["M"]
+            eng_m, quiz_m, q_local_m = make_engine(cm)
+            ex_m = both_exchanges(eng_m, quiz_m, "m", 20, 200)
+            k_ms = kernel_ms_of(eng_m, quiz_m, 20)
+            bytes_m = q_local_m * (cm["K"] + 1) * cm["T"] * 8
+            best = ex_m.get("shm") if "selections_per_sec" in ex_m.get("shm", {}) else ex_m.get("rccl", {})
+            sharded_m = {"workload": cm["name"] + " fp64, question axis sharded over the ranks", "exchange": ex_m,
+                         "selections_per_sec": best.get("selections_per_sec"), "ms_per_step": 1e-3 * best.get("us_per_step", 0.0),
+                         "questions_per_gpu": q_local_m, "selected_question": best.get("selected_question"),
+                         "rank0_kernel_us": 1e3 * k_ms, "rank0_kernel_GBps": bytes_m / (k_ms * 1e-3) / 1e9,
+                         "eval_kernel": eng_m.eval_kernel_name()}
+            eng_m.close()
+        if "L1" in want:
+            sharded_l1 = run_batched(args, CONFIGS[args.l1_config], np, torch, interop, pdist, ctl, rank, dev_index, device, compact=True)
 
     # ---- extra (not `value`), sharded runs only: the SAME sharding inside ONE process behind the plain C ABI
     # (probqa_amd/csrc/sharded_engine.cpp: PQA_DEVICES lists the devices, PqaEngineFactory_CreateCpuEngine builds one shard per
@@ -368,9 +392,11 @@ def main():
     if sharded and world > 1:
         if rank == 0:
             one_process = {}
-            os.environ["PQA_DEVICES"] = ",".join(str(d) for d in range(world))
+            os.environ["PQA_DEVICES"] = ",".join(str(d % n_dev) for d in range(world))
             try:
                 for key, c, n_steps in (("1000x5x1000", CONFIGS["S"], 2000), ("10000x5x10000", CONFIGS["M"], 200)):
+                    if ("S" if c is CONFIGS["S"] else "M") not in want:
+                        continue
                     e1, err = factory.create_cpu_engine(interop.EngineDefinition(c["K"], c["Q"], c["T"], init_amount=0.1))
                     if err is not None:
                         one_process[key] = {"error": err.to_string(True)}
@@ -387,9 +413,47 @@ def main():
                     one_process[key] = {"selections_per_sec": n_steps / d1, "us_per_step": 1e6 * d1 / n_steps, "shards": e1.get_option("shards"),
                                         "selected_question": int(p1)}
                     e1.close()
+                if "L1" in want:
+                    # BASELINE configs[4] as ONE engine: world x 12500 questions x 100000 targets fp32, 256 quizzes per batched call;
+                    # every shard's sweep is enqueued before the first is waited for (shards_in_flight_max == shards)
+                    c = CONFIGS[args.l1_config]
+                    kw = dict(prec_type=interop.PrecisionType.FLOAT, prec_exponent=8, prec_mantissa=24) if c["prec"] == "f32" else {}
+                    e1, err = factory.create_cpu_engine(interop.EngineDefinition(c["K"], c["Q"] * world, c["T"], init_amount=0.1, **kw))
+                    if err is not None:
+                        one_process[c["name"] + "_per_shard"] = {"error": err.to_string(True)}
+                    else:
+                        e1.set_option("select", 1)
+                        e1.set_option("batch_min", 1)
+                        e1.fill_synthetic(8.0, 0.5, SEED)
+                        qzs = [e1.start_quiz() for _ in range(c["quizzes"])]
+                        for i, qz1 in enumerate(qzs):
+                            e1.set_active_question(qz1, (37 * i) % (c["Q"] * world))
+                            e1.record_answer(qz1, i % c["K"])
+                        p1 = e1.next_question_argmax_batch(qzs)
+                        n_b = 2
+                        t1 = time.perf_counter()
+                        for _ in range(n_b):
+                            p1 = e1.next_question_argmax_batch(qzs)
+                        d1 = time.perf_counter() - t1
+                        one_process[c["name"] + "_per_shard"] = {
+                            "selections_per_sec": n_b * len(qzs) / d1, "ms_per_batch": 1e3 * d1 / n_b, "shards": e1.get_option("shards"),
+                            "shards_in_flight_max": e1.get_option("shards_in_flight_max"), "quizzes_per_batch": len(qzs),
+                            "selected_question_of_quiz_0": int(p1[0])}
+                        e1.close()
             finally:
                 os.environ.pop("PQA_DEVICES", None)
         barrier()
+
+    # ---- extras (not `value`), one GPU, default config: the two other measured points of the path in the line the driver runs --
+    # the HBM-bound point M (BASELINE configs[2]: 10000x5x10000 fp64, one quiz) and the VALU-bound point L1 (configs[4]'s
+    # per-GPU shard: 12500x5x100000 fp32, 256 quizzes per batched sweep), each with a bounded parity sample against the CPU port.
+    hbm_point_m, valu_point_l1 = None, None
+    if not sharded and args.config == "S" and not args.no_points:
+        free_b = torch.cuda.mem_get_info(device)[0]
+        if free_b > 12e9:
+            hbm_point_m = point_m(args, np, torch, interop, factory, stream, kernel_ms_of)
+        if free_b > 80e9:
+            valu_point_l1 = run_batched(args, CONFIGS["L1"], np, torch, interop, pdist, ctl, rank, dev_index, device, compact=True)
 
     out = {
         "metric": "next_question_selections_per_sec",
@@ -423,8 +487,12 @@ def main():
         "batched": batched,
         "hip_graph_replay": graph_rate,
         "quiz_loop": quiz_loop,
+        "exchange_1000x5x1000": exchanges_s,
         "sharded_10000x5x10000": sharded_m,
+        "sharded_12500x5x100000_per_gpu": sharded_l1,
         "one_process_sharded_engine": one_process,
+        "hbm_point_M": hbm_point_m,
+        "valu_point_L1": valu_point_l1,
         "roofline": {
             "bound": "hbm",
             "achieved": achieved,
@@ -479,30 +547,153 @@ def main():
     if selector is not None and hasattr(selector, "close"):
         selector.close()
     eng.close()
-    if world > 1 or args.force_collective:
-        import torch.distributed as dist
-
-        dist.destroy_process_group()
+    ctl.close()
 
 
-def run_batched(args, cfg, np, torch, interop, pdist, world, rank, local_rank, device):
+def self_spawn(n):
+    """`python bench.py --gpus N` typed by itself: run the same command line as N ranks under torch.distributed.run (one
+    process per GPU, rendezvous on 127.0.0.1) -- what the driver's launch line does.  Returns the launcher's exit code."""
+    import socket
+    import subprocess
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
+class Ctl:
+    """The control plane of a run: rendezvous, barriers, max-over-ranks timing.  torch.distributed with backend nccl (= RCCL);
+    gloo when several ranks share a device (dry run of the N > 1 path on a smaller box).  One rank: no process group at all,
+    unless --force-collective asks for the RCCL path with a world of one."""
+
+    def __init__(self, torch, world, device, oversub, force):
+        self.torch, self.world, self.device = torch, world, device
+        self.dist = None
+        self.rccl = False
+        if world > 1 or force:
+            import torch.distributed as dist
+
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
+            if oversub:
+                dist.init_process_group(backend="gloo")
+            else:
+                dist.init_process_group(backend="nccl", device_id=device)
+                self.rccl = True
+            self.dist = dist
+        self.tdev = device if self.rccl else torch.device("cpu")
+
+    def barrier(self):
+        self.torch.cuda.synchronize()
+        if self.world > 1:
+            self.dist.barrier()
+        self.torch.cuda.synchronize()
+
+    def max_float(self, x):
+        if self.world == 1:
+            return x
+        t = self.torch.tensor([x], dtype=self.torch.float64, device=self.tdev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def min_int(self, x):
+        if self.world == 1:
+            return int(x)
+        t = self.torch.tensor([int(x)], dtype=self.torch.int32, device=self.tdev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN)
+        return int(t.item())
+
+    def broadcast_prior(self, pdist, ptr, ld, owner):
+        """A quiz's new posterior from the rank that computed it to every rank's engine (8 ldT bytes)."""
+        if self.world == 1:
+            return
+        t = pdist.tensor_from_device_ptr(ptr, ld, self.device)
+        if self.rccl:
+            self.dist.broadcast(t, src=owner)
+        else:                       # gloo dry run: through the host
+            h = t.cpu()
+            self.dist.broadcast(h, src=owner)
+            t.copy_(h)
+
+    def close(self):
+        if self.dist is not None:
+            self.dist.destroy_process_group()
+            self.dist = None
+
+
+def point_m(args, np, torch, interop, factory, stream, kernel_ms_of):
+    """BASELINE configs[2] inside the default run: 10000x5x10000 fp64, one quiz -- 30 synchronous selections, the sweep kernel
+    by HIP events, and a parity sample (the first 200 questions' priorities against the CPU port on the generator's rows)."""
+    c = CONFIGS["M"]
+    Q, K, T = c["Q"], c["K"], c["T"]
+    e = factory.create_hip_engine(interop.EngineDefinition(K, Q, T, init_amount=0.1), 0, Q, torch.cuda.current_device())
+    e.set_option("select", 1)
+    e.fill_synthetic(8.0, 0.5, SEED)
+    e.set_stream(stream.cuda_stream)
+    qz = e.start_quiz()
+    for _ in range(5):
+        pick = e.next_question_argmax(qz)
+    torch.cuda.synchronize()
+    n = 30
+    t0 = time.perf_counter()
+    for _ in range(n):
+        pick = e.next_question_argmax(qz)
+    dt = time.perf_counter() - t0
+    k_ms = kernel_ms_of(e, qz, 20)
+    alg = Q * (K + 1) * T * 8
+    out = {"workload": c["name"] + " fp64, single in-flight quiz (BASELINE configs[2])", "selections_per_sec": n / dt, "ms_per_step": 1e3 * dt / n,
+           "steps": n, "kernel": "eval_questions_f64 (%s)" % e.eval_kernel_name(), "kernel_us": 1e3 * k_ms,
+           "kernel_us_source": "HIP events on the engine's stream around 20 back-to-back launches (mean)",
+           "algorithmic_bytes_per_launch": alg, "achieved": alg / (k_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           "frac": alg / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "selected_question": int(pick)}
+    if not args.no_cpu_baseline:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import orclib
+        from probqa_amd import synth
+
+        n_q = 200
+        pri = e.eval_priorities(qz, Q)
+        orc = orclib.Oracle(K, n_q, T, 0.1)
+        orc.set_kb(*synth.synthetic_kb(K, n_q, T, 0.1, 8.0, 0.5, SEED, q_offset=0, q_total=Q))
+        orc.mants[:T] = e.get_priors(qz)
+        _, opri = orc.eval_avx2(min(os.cpu_count() or 1, 16))
+        rel = np.abs(pri[:n_q] - opri) / np.maximum(np.abs(opri), 1e-300)
+        out["sample_parity"] = {"questions": n_q, "max_rel_err": float(rel.max()),
+                                "argmax_of_sample_matches_cpu": int(np.argmax(pri[:n_q])) == int(orc.select_argmax(opri)),
+                                "note": "GPU priorities of the first %d questions against the fp64 CPU port on the generator's rows" % n_q}
+    e.close()
+    return out
+
+
+def run_batched(args, cfg, np, torch, interop, pdist, ctl, rank, dev_index, device, compact=False):
     """BASELINE configs[4]: B quizzes in flight, one batched NextQuestion per step -- the row-sharing sweep
     (probqa_amd/csrc/batch_kernels.hip: a lane is a quiz, the cube is read once per batch).  A step = the argmax selections
     of all B quizzes: transposed priors + sweep + per-quiz pick on the device, question ids on the host.  N > 1: every rank
-    holds its own Q-question shard (weak scaling: the cube grows with N), the ranks' per-quiz winners (16 B x B) meet in one
-    RCCL all-gather and every rank makes the same picks."""
-    import torch.distributed as dist
-
+    holds its own Q-question shard (weak scaling: the cube grows with N); the ranks' per-quiz winners (16 B x B) meet in host
+    shared memory (they are on the host when the batched call returns) or in one RCCL all-gather -- both are timed -- and every
+    rank makes the same picks.  compact: the short form that rides in the default run's line (2 steps, 1 warm-up)."""
+    world = ctl.world
     Q, K, T, B = cfg["Q"], cfg["K"], cfg["T"], cfg["quizzes"]
     f32 = cfg["prec"] == "f32"
-    steps = args.steps if args.steps != 2000 else (3 if Q * T > 1e8 else 20)       # the defaults are sized for the S config
-    warmup = args.warmup if args.warmup != 5000 else 1
+    if compact:
+        steps, warmup = (2, 1) if Q * T > 1e8 else (10, 2)
+    else:
+        steps = args.steps if args.steps != 2000 else (3 if Q * T > 1e8 else 20)       # the defaults are sized for the S config
+        warmup = args.warmup if args.warmup != 5000 else 1
     factory = interop.PqaEngineFactory()
     stream = torch.cuda.Stream(device=device)
     torch.cuda.set_stream(stream)
     q_total = Q * world
     kw = dict(prec_type=interop.PrecisionType.FLOAT, prec_exponent=8, prec_mantissa=24) if f32 else {}
-    eng = factory.create_hip_engine(interop.EngineDefinition(K, Q, T, init_amount=0.1, **kw), rank * Q, q_total, local_rank)
+    eng = factory.create_hip_engine(interop.EngineDefinition(K, Q, T, init_amount=0.1, **kw), rank * Q, q_total, dev_index)
     eng.set_option("select", 1)
     eng.set_option("batch_min", 1)
     eng.fill_synthetic(8.0, 0.5, SEED)
@@ -521,39 +712,55 @@ def run_batched(args, cfg, np, torch, interop, pdist, world, rank, local_rank, d
         if world > 1:
             ptr, ld = eng.prior_device_ptr(qz)
             eng.synchronize()
-            pdist.broadcast_prior(pdist.tensor_from_device_ptr(ptr, ld, device), owner)
+            ctl.broadcast_prior(pdist, ptr, ld, owner)
 
-    def step():
+    shm = None
+    if world > 1:
+        name = "bench_%s_b%d" % (os.environ.get("MASTER_PORT", "0"), Q)
+        if rank == 0:
+            shm = pdist.ShmBatchExchange(B, rank, world, name, create=True)
+        ctl.barrier()
+        if rank != 0:
+            shm = pdist.ShmBatchExchange(B, rank, world, name, create=False)
+
+    def step_shm():
         if world == 1:
             return eng.next_question_argmax_batch(quizzes)
+        return shm.exchange(eng.select_argmax_batch(quizzes))
+
+    def step_rccl():
         mine = torch.from_numpy(eng.select_argmax_batch(quizzes)).to(device)          # [B, 2] (priority, global index)
         return pdist.select_batch(mine)
 
-    def barrier():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+    barrier = ctl.barrier
 
-    picks = None
-    for _ in range(warmup):
-        picks = step()
-    eng.synchronize()
-    barrier()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    ev0.record(stream)
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        picks = step()
-    ev1.record(stream)
-    eng.synchronize()
-    barrier()
-    dt = time.perf_counter() - t0
+    def timed_steps(step):
+        picks = None
+        for _ in range(warmup):
+            picks = step()
+        eng.synchronize()
+        barrier()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record(stream)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            picks = step()
+        ev1.record(stream)
+        eng.synchronize()
+        barrier()
+        dt = ctl.max_float(time.perf_counter() - t0)
+        return dt, ev0.elapsed_time(ev1) / steps, picks
+
+    dt, kernel_ms, picks = timed_steps(step_shm)
+    exchange = None
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    kernel_ms = ev0.elapsed_time(ev1) / steps      # the sweep + its two small companions (prep, pick), on the engine's stream
+        exchange = {"shm": {"selections_per_sec": B * steps / dt, "ms_per_step": 1e3 * dt / steps, "selected_question_of_quiz_0": int(picks[0])}}
+        if ctl.rccl:
+            dt_r, _, picks_r = timed_steps(step_rccl)
+            exchange["rccl"] = {"selections_per_sec": B * steps / dt_r, "ms_per_step": 1e3 * dt_r / steps, "selected_question_of_quiz_0": int(picks_r[0]),
+                                "same_picks_as_shm": [int(x) for x in picks_r] == [int(x) for x in picks]}
+        else:
+            exchange["rccl"] = {"skipped": "the ranks share a device: RCCL refuses that"}
     value = B * steps / dt
     s = 4 if f32 else 8
     elements = Q * K * T * B
@@ -561,6 +768,19 @@ def run_batched(args, cfg, np, torch, interop, pdist, world, rank, local_rank, d
     alg_bytes = Q * (K + 1) * T * s                # the cube once per batch ("read once per batch of 256 quizzes")
     peak = FP32_VECTOR_PEAK_TFLOPS if f32 else FP64_VECTOR_PEAK_TFLOPS
     tf = alg_flops / (kernel_ms * 1e-3) / 1e12
+    if compact:
+        out = {"workload": "%s %s per GPU (%.1f GB), %d quizzes per batched sweep (BASELINE configs[4]'s shard)" % (cfg["name"], cfg["prec"], alg_bytes / 1e9, B),
+               "selections_per_sec": value, "ms_per_step": 1e3 * dt / steps, "steps": steps, "n_gpus": world, "questions_total": q_total,
+               "kernel": "eval_batch_kernel<%s>" % ("float" if f32 else "double"), "kernel_us": kernel_ms * 1e3,
+               "kernel_us_source": "HIP events on the engine's stream around the timed steps (sweep + prep + pick kernels)",
+               "bound": "valu_fp32" if f32 else "valu_fp64", "achieved": tf, "peak": peak, "unit": "TFLOP/s", "frac": tf / peak,
+               "algorithmic_flops_per_launch": alg_flops, "exchange": exchange, "selected_question_of_quiz_0": int(picks[0])}
+        if rank == 0 and world == 1 and not args.no_cpu_baseline:
+            _, out["sample_parity"] = cpu_baseline_batched(np, cfg, eng, quizzes, min(args.cpu_seconds, 1.5), f32)
+        if shm is not None:
+            shm.close()
+        eng.close()
+        return out
     out = {
         "metric": "next_question_selections_per_sec",
         "value": value,
@@ -582,11 +802,13 @@ def run_batched(args, cfg, np, torch, interop, pdist, world, rank, local_rank, d
             "questions_per_gpu": Q,
             "questions_total": q_total,
             "parallelism": "single GPU" if world == 1 else "question-axis shards x%d (one %d-question shard per GPU), the "
-                           "ranks' per-quiz winners exchanged by one RCCL all-gather of %d B per rank" % (world, Q, 16 * B),
+                           "ranks' per-quiz winners (%d B per rank) exchanged through host shared memory (`exchange` has the RCCL "
+                           "all-gather beside it)" % (world, Q, 16 * B),
             "eval_kernel": "eval_batch_kernel<%s> (lane = quiz, LDS tile shared by the batch)" % ("float" if f32 else "double"),
             "selected_question_of_quiz_0": int(picks[0]),
         },
         "question_evals_per_sec": value * q_total,
+        "exchange": exchange,
         "element_evals_per_sec_per_gpu": elements / (dt / steps),
         # this configuration is bound by the vector ALU (transcendental + fp32 arithmetic per element), not by HBM
         "roofline": {
@@ -619,6 +841,8 @@ def run_batched(args, cfg, np, torch, interop, pdist, world, rank, local_rank, d
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"], out["sample_parity"] = cpu_baseline_batched(np, cfg, eng, quizzes, args.cpu_seconds, f32)
+    if shm is not None:
+        shm.close()
     eng.close()
     return out
 

@@ -468,15 +468,19 @@ hipError_t launch_batch(const BatchArgs &args0, int nThreads, size_t *accBytesNe
   auto kern = eval_batch_kernel<R, QB, KG, EXACT>;
   const size_t shmem = (Num<R>::kTable ? kLog2TableDoubles * sizeof(double) : 0) + (size_t)args.TC * QB * (KG + 1) * sizeof(R);
   if (shmem > 160 * 1024) return hipErrorInvalidValue;
-  static size_t attrSet = 0;   // (per instantiation)
-  if (shmem > 64 * 1024 && shmem > attrSet) {
-    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-    if (e != hipSuccess) return e;
-    attrSet = shmem;
+  static LaunchCache cache;   // (per instantiation and device; the occupancy also depends on the thread count: part of the key)
+  const int devSlot = LaunchCache::Device();
+  const size_t key = shmem * 2048 + (size_t)nThreads;
+  int perCU = 0;
+  if (!cache.Get(devSlot, key, &perCU)) {
+    if (shmem > 64 * 1024) {
+      const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+      if (e != hipSuccess) return e;
+    }
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, kern, nThreads, shmem) != hipSuccess || perCU < 1) perCU = 1;
+    cache.Put(devSlot, key, perCU);
   }
-  int dev = 0, nCU = 0, perCU = 0;
-  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&nCU, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || nCU <= 0) nCU = 256;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, kern, nThreads, shmem) != hipSuccess || perCU < 1) perCU = 1;
+  const int nCU = cache.NumCUs(devSlot);
   const int64_t nBlocks = (args.Q + QB - 1) / QB;
   int64_t grid = (int64_t)nCU * perCU;
   if (grid > nBlocks) grid = nBlocks;
@@ -552,15 +556,16 @@ hipError_t LaunchEvalQuestionsF32(const KbView &kb, const double *prior, const u
   const double vCompTail = 0.34657359027997265470861606072909 / (nT * nT);
   const bool ldsRow = kb.ldT <= kF32LdsTargets, big = kb.ldT >= 4096;
   const size_t shmem = (size_t)(2 * kb.K + 32) * sizeof(double) + (ldsRow ? (size_t)kb.ldT * 8 : 0);
-  static bool attrSet = false;
-  if (ldsRow && shmem > 64 * 1024 && !attrSet) {
+  static LaunchCache cache;   // (per device)
+  const int devSlot = LaunchCache::Device();
+  int attrSet = 0;
+  if (ldsRow && shmem > 64 * 1024 && !cache.Get(devSlot, 1, &attrSet)) {
     const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(eval_questions_f32_stream<true, 1024>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
     if (e != hipSuccess) return e;
-    attrSet = true;
+    cache.Put(devSlot, 1, 1);
   }
-  int dev = 0, nCU = 0;
-  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&nCU, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || nCU <= 0) nCU = 256;
+  const int nCU = cache.NumCUs(devSlot);
   const int nt = big ? 1024 : 256;
   int perCU = (int)std::max<size_t>(1, std::min<size_t>((size_t)(2048 / nt), (160 * 1024) / std::max<size_t>(shmem, 1)));
   int64_t grid = std::min<int64_t>(kb.Q, (int64_t)nCU * perCU);

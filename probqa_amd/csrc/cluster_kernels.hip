@@ -364,17 +364,16 @@ struct ClusterShape { int C, nClusters, sliceUnits, nu; size_t shmem; };
 
 template <typename R, int NU>
 bool occupancy_two(size_t shmem) {
-  static int cached = -1;
-  static size_t cachedShmem = 0;
-  if (cached >= 0 && cachedShmem == shmem) return cached >= 2;
+  static LaunchCache cache;   // (per instantiation and device)
+  const int dev = LaunchCache::Device();
+  int perCU = 0;
+  if (cache.Get(dev, shmem, &perCU)) return perCU >= 2;
   auto kern = eval_cluster_kernel<R, NU>;
   hipError_t e = hipSuccess;
   if (shmem > 64 * 1024) e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-  int perCU = 0;
   if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, kern, kClusterThreads, shmem);
   if (e != hipSuccess) { perCU = 0; (void)hipGetLastError(); }   // (not this launch's error: the caller falls back to the streaming form)
-  cached = perCU;
-  cachedShmem = shmem;
+  cache.Put(dev, shmem, perCU);
   return perCU >= 2;
 }
 

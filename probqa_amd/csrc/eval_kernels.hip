@@ -917,7 +917,6 @@ int pick_variant(int64_t ldT, int variant) {
   return 99;
 }
 
-int gNumCUs = 0;
 
 constexpr size_t kLdsPerCU = 160 * 1024;   // gfx950
 template <int WPQ, int NP, bool PRLDS>
@@ -933,18 +932,14 @@ hipError_t launch_reg_form(const EvalArgs &args, int64_t nQ, int nBatch, hipStre
     if constexpr (NP == 4 && WPQ == 4 && DEFER) return eval_questions_f64_occ3<WPQ, NP, PRLDS, DEFER>;   // (5 and 6 pairs: slower with the spills)
     else return eval_questions_f64<WPQ, NP, PRLDS, DEFER>;
   }();
-  // attribute and occupancy are properties of (kernel, LDS size): asked once, not on every launch (the engine serialises
-  // launches; a race between two engines would only repeat the query)
-  static size_t cachedShmem = ~(size_t)0;
-  static int cachedPerCU = 0;
-  if (shmem != cachedShmem) {
+  // attribute and occupancy are properties of (kernel, LDS size, device): asked once per device, not on every launch
+  static LaunchCache cache;
+  const int dev = LaunchCache::Device();
+  int cachedPerCU = 0;
+  if (!cache.Get(dev, shmem, &cachedPerCU)) {
     if (shmem > 64 * 1024) {
       const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
       if (e != hipSuccess) return e;
-    }
-    if (gNumCUs == 0) {
-      int dev = 0, n = 0;
-      gNumCUs = (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
     }
     int perCU = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, kern, WPQ * 64, shmem) != hipSuccess || perCU < 1) perCU = 1;
@@ -952,8 +947,9 @@ hipError_t launch_reg_form(const EvalArgs &args, int64_t nQ, int nBatch, hipStre
     // 14.9 us, four (every question its own workgroup) in 15.7, two in 17.5 -- do not rely on the register count to say 3
     if (NP <= 2 && perCU > 3) perCU = 3;
     cachedPerCU = perCU;
-    cachedShmem = shmem;
+    cache.Put(dev, shmem, perCU);
   }
+  const int gNumCUs = cache.NumCUs(dev);
   // one question per workgroup while they all fit on the chip at once; otherwise a resident grid that strides
   const int64_t resident = (int64_t)gNumCUs * cachedPerCU;
   int64_t resGrid = nQ < resident ? nQ : resident;
@@ -1077,23 +1073,21 @@ static hipError_t launch_server_form(const EvalArgs &args, ServerMailbox *mb, vo
   const size_t stepOffset = eval_base_lds_bytes<WPQ, NP, false>(args.K, args.ldT) + (DEFER ? eval_deferred_bytes(WPQ, NP, args.K, false) : 0);
   const size_t shmem = stepOffset + 64;
   auto kern = eval_server_f64<WPQ, NP, DEFER>;
-  static size_t cachedShmem = ~(size_t)0;
-  static int cachedPerCU = 0;
-  if (shmem != cachedShmem) {
+  static LaunchCache cache;
+  const int dev = LaunchCache::Device();
+  int cachedPerCU = 0;
+  if (!cache.Get(dev, shmem, &cachedPerCU)) {
     if (shmem > 64 * 1024) {
       const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
       if (e != hipSuccess) return e;
-    }
-    if (gNumCUs == 0) {
-      int dev = 0, n = 0;
-      gNumCUs = (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
     }
     int perCU = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, kern, WPQ * 64, shmem) != hipSuccess || perCU < 1) perCU = 1;
     if (NP <= 2 && perCU > 3) perCU = 3;   // as launch_reg (measured for the resident kernel too: 46.0 k selections/s at three per CU, 43.9 k at four)
     cachedPerCU = perCU;
-    cachedShmem = shmem;
+    cache.Put(dev, shmem, perCU);
   }
+  const int gNumCUs = cache.NumCUs(dev);
   // every workgroup must be resident at once: the steps are collective
   const int64_t nQ = args.qLimit - args.qFirst, resident = (int64_t)gNumCUs * cachedPerCU;
   int64_t grid = nQ < resident ? nQ : resident;

@@ -1118,25 +1118,79 @@ Error HipEngine::BatchSweep(int64_t n, const int64_t *pQuizzes, std::vector<Quiz
   return Error();
 }
 
-Error HipEngine::NextQuestionArgmaxBatch(int64_t n, const int64_t *pQuizzes, int64_t *pOut) {
-  std::lock_guard<EngineMutex> lk(_mu);
+// A batched selection in two halves, so that a caller driving several engines (sharded_engine.cpp) has every engine's sweep in
+// flight before it waits for the first: EnqueueBatch validates, stages the quizzes' slots and launches (nothing is waited for),
+// CollectBatch* wait for that launch's flags.  The batch staging buffers are the engine's: one batch at a time between the two.
+Error HipEngine::EnqueueBatchLocked(int64_t n, const int64_t *pQuizzes, bool wantPriorities, uint64_t *pTag) {
   Error err = CheckRegular("compute next questions");
   if (!err.ok()) return err;
   if (n < 0 || n > kMaxBatch)
     return Error::MakeP(ErrCode::IndexOutOfRange, RangeParams(n, 0, kMaxBatch), "Batch size is out of range.");
+  *pTag = 0;
   if (n == 0) return Error();
-  if (!pQuizzes || !pOut) return Error::Make(ErrCode::NullArgument, "Nullptr is passed in place of a batch buffer.");
+  if (!pQuizzes) return Error::Make(ErrCode::NullArgument, "Nullptr is passed in place of a batch buffer.");
   hipSetDevice(_device);
   const uint64_t tag = NextLaunchTag();
-  std::vector<Quiz *> quizzes;
-  err = BatchSweep(n, pQuizzes, quizzes, false, tag);
+  err = BatchSweep(n, pQuizzes, _batchQuizzes, wantPriorities, tag);
   if (!err.ok()) return err;
-  err = WaitBatchFlags(n, tag);
+  *pTag = tag;
+  return Error();
+}
+
+Error HipEngine::CollectBatchSelectionsLocked(int64_t n, uint64_t tag, CiHipSelection *pOut) {
+  if (n == 0) return Error();
+  if (!pOut) return Error::Make(ErrCode::NullArgument, "Nullptr is passed in place of a batch buffer.");
+  hipSetDevice(_device);
+  Error err = WaitBatchFlags(n, tag);
   if (!err.ok()) return err;
   for (int64_t i = 0; i < n; i++) {
-    if (_hBatch->out[i].index == -3) return HipErr(hipErrorLaunchFailure, "NextQuestionArgmaxBatch (incomplete sweep)");
-    Error e;
-    pOut[i] = FinishSelection(e, quizzes[i], _hBatch->out[i].index);  // -1 + QuestionsExhausted: reported as -1 only
+    if (_hBatch->out[i].index == -3) return HipErr(hipErrorLaunchFailure, "batched selection (incomplete sweep)");
+    pOut[i]._priority = _hBatch->out[i].priority;
+    pOut[i]._iQuestion = _hBatch->out[i].index < 0 ? -1 : _hBatch->out[i].index + _qFirst;
+  }
+  return Error();
+}
+
+Error HipEngine::EnqueueBatch(int64_t n, const int64_t *pQuizzes, bool wantPriorities, uint64_t *pTag) {
+  std::lock_guard<EngineMutex> lk(_mu);
+  return EnqueueBatchLocked(n, pQuizzes, wantPriorities, pTag);
+}
+
+Error HipEngine::CollectBatchSelections(int64_t n, uint64_t tag, CiHipSelection *pOut) {
+  std::lock_guard<EngineMutex> lk(_mu);
+  return CollectBatchSelectionsLocked(n, tag, pOut);
+}
+
+// pOut[i * Q + q] (local questions) of the batch enqueued with wantPriorities
+Error HipEngine::CollectBatchPriorities(int64_t n, double *pOut) {
+  std::lock_guard<EngineMutex> lk(_mu);
+  return CollectBatchPrioritiesLocked(n, pOut);
+}
+
+Error HipEngine::CollectBatchPrioritiesLocked(int64_t n, double *pOut) {
+  if (n == 0) return Error();
+  if (!pOut) return Error::Make(ErrCode::NullArgument, "Nullptr is passed in place of a batch buffer.");
+  hipSetDevice(_device);
+  std::vector<double> host((size_t)_Q * (size_t)_lastBatchBp);
+  HIP_TRY(hipMemcpyAsync(host.data(), _dBatchPriT, host.size() * sizeof(double), hipMemcpyDeviceToHost, _stream));
+  HIP_TRY(hipStreamSynchronize(_stream));
+  for (int64_t i = 0; i < n; i++)
+    for (int64_t q = 0; q < _Q; q++) pOut[(size_t)i * (size_t)_Q + (size_t)q] = host[(size_t)q * (size_t)_lastBatchBp + (size_t)i];
+  return Error();
+}
+
+Error HipEngine::NextQuestionArgmaxBatch(int64_t n, const int64_t *pQuizzes, int64_t *pOut) {
+  std::lock_guard<EngineMutex> lk(_mu);
+  if (n > 0 && !pOut) return Error::Make(ErrCode::NullArgument, "Nullptr is passed in place of a batch buffer.");
+  uint64_t tag = 0;
+  Error err = EnqueueBatchLocked(n, pQuizzes, false, &tag);
+  if (!err.ok() || n == 0) return err;
+  std::vector<CiHipSelection> sel((size_t)n);
+  err = CollectBatchSelectionsLocked(n, tag, sel.data());
+  if (!err.ok()) return err;
+  for (int64_t i = 0; i < n; i++) {
+    Error e;   // -1 + QuestionsExhausted: reported as -1 only
+    pOut[i] = FinishSelection(e, _batchQuizzes[(size_t)i], sel[(size_t)i]._iQuestion < 0 ? -1 : sel[(size_t)i]._iQuestion - _qFirst);
   }
   return Error();
 }
@@ -1146,25 +1200,11 @@ Error HipEngine::NextQuestionArgmaxBatch(int64_t n, const int64_t *pQuizzes, int
 // sets the active questions (PqaEngine_SetActiveQuestion).
 Error HipEngine::SelectArgmaxBatch(int64_t n, const int64_t *pQuizzes, CiHipSelection *pOut) {
   std::lock_guard<EngineMutex> lk(_mu);
-  Error err = CheckRegular("compute next questions");
-  if (!err.ok()) return err;
-  if (n < 0 || n > kMaxBatch)
-    return Error::MakeP(ErrCode::IndexOutOfRange, RangeParams(n, 0, kMaxBatch), "Batch size is out of range.");
-  if (n == 0) return Error();
-  if (!pQuizzes || !pOut) return Error::Make(ErrCode::NullArgument, "Nullptr is passed in place of a batch buffer.");
-  hipSetDevice(_device);
-  const uint64_t tag = NextLaunchTag();
-  std::vector<Quiz *> quizzes;
-  err = BatchSweep(n, pQuizzes, quizzes, false, tag);
-  if (!err.ok()) return err;
-  err = WaitBatchFlags(n, tag);
-  if (!err.ok()) return err;
-  for (int64_t i = 0; i < n; i++) {
-    if (_hBatch->out[i].index == -3) return HipErr(hipErrorLaunchFailure, "SelectArgmaxBatch (incomplete sweep)");
-    pOut[i]._priority = _hBatch->out[i].priority;
-    pOut[i]._iQuestion = _hBatch->out[i].index < 0 ? -1 : _hBatch->out[i].index + _qFirst;
-  }
-  return Error();
+  if (n > 0 && !pOut) return Error::Make(ErrCode::NullArgument, "Nullptr is passed in place of a batch buffer.");
+  uint64_t tag = 0;
+  Error err = EnqueueBatchLocked(n, pQuizzes, false, &tag);
+  if (!err.ok() || n == 0) return err;
+  return CollectBatchSelectionsLocked(n, tag, pOut);
 }
 
 Error HipEngine::WaitBatchFlags(int64_t n, uint64_t tag) {
@@ -1191,23 +1231,11 @@ Error HipEngine::WaitBatchFlags(int64_t n, uint64_t tag) {
 // pQuizzes[i] (0 for gap / asked questions).  The deterministic output of the batched path, for parity checks.
 Error HipEngine::EvalPrioritiesBatch(int64_t n, const int64_t *pQuizzes, double *pOut) {
   std::lock_guard<EngineMutex> lk(_mu);
-  Error err = CheckRegular("compute next questions");
-  if (!err.ok()) return err;
-  if (n < 0 || n > kMaxBatch)
-    return Error::MakeP(ErrCode::IndexOutOfRange, RangeParams(n, 0, kMaxBatch), "Batch size is out of range.");
-  if (n == 0) return Error();
-  if (!pQuizzes || !pOut) return Error::Make(ErrCode::NullArgument, "Nullptr is passed in place of a batch buffer.");
-  hipSetDevice(_device);
-  const uint64_t tag = NextLaunchTag();
-  std::vector<Quiz *> quizzes;
-  err = BatchSweep(n, pQuizzes, quizzes, true, tag);
-  if (!err.ok()) return err;
-  std::vector<double> host((size_t)_Q * (size_t)_lastBatchBp);
-  HIP_TRY(hipMemcpyAsync(host.data(), _dBatchPriT, host.size() * sizeof(double), hipMemcpyDeviceToHost, _stream));
-  HIP_TRY(hipStreamSynchronize(_stream));
-  for (int64_t i = 0; i < n; i++)
-    for (int64_t q = 0; q < _Q; q++) pOut[(size_t)i * (size_t)_Q + (size_t)q] = host[(size_t)q * (size_t)_lastBatchBp + (size_t)i];
-  return Error();
+  if (n > 0 && !pOut) return Error::Make(ErrCode::NullArgument, "Nullptr is passed in place of a batch buffer.");
+  uint64_t tag = 0;
+  Error err = EnqueueBatchLocked(n, pQuizzes, true, &tag);
+  if (!err.ok() || n == 0) return err;
+  return CollectBatchPrioritiesLocked(n, pOut);
 }
 
 // The same selection replayed from a HIP graph (option "use_graph"; SURVEY 8(d) asks for the variant).  One graph per quiz:
@@ -1614,9 +1642,9 @@ void HipEngine::BuildTrainSteps(int64_t n, const AQ *pAQs, bool fromQuiz, std::v
   chainStart.push_back((int64_t)ordered.size());
 }
 
-// Validation (CETrainSubtaskDistrib.h:26-45, CpuEngine.cpp:138-155) + the steps on the device; the caller holds the lock.
-Error HipEngine::TrainLocked(int64_t nQuestions, const AQ *pAQs, int64_t iTarget, double amount, bool fromQuiz) {
-  StopServer();   // the cube changes: the resident sweep's XCD-local L2s would keep stale rows
+// Validation of a training call (CETrainSubtaskDistrib.h:26-45, CpuEngine.cpp:138-155): ranges over the GLOBAL question range, gaps
+// for this engine's own questions.  The reference validates every answered question before any Add subtask runs.
+Error HipEngine::ValidateTrainLocked(int64_t nQuestions, const AQ *pAQs, int64_t iTarget) const {
   if (iTarget < 0 || iTarget >= _T)
     return Error::MakeP(ErrCode::IndexOutOfRange, RangeParams(iTarget, 0, _T - 1), "Target index is not in KB range.");
   if (BitTest(_hTGap, iTarget))
@@ -1629,6 +1657,28 @@ Error HipEngine::TrainLocked(int64_t nQuestions, const AQ *pAQs, int64_t iTarget
       return Error::MakeP(ErrCode::AbsentId, "id=" + std::to_string(iq), "Question index is not in KB (but rather at a gap).");
     if (ia < 0 || ia >= _K)
       return Error::MakeP(ErrCode::IndexOutOfRange, RangeParams(ia, 0, _K - 1), "Answer index is not in KB range.");
+  }
+  return Error();
+}
+
+// What a sharded engine asks of every shard BEFORE any shard trains (a gap question owned by shard k must not leave shards
+// 0..k-1 trained): the validation of Train (iQuiz < 0) or of RecordQuizTarget (the quiz's own answers), nothing else.
+Error HipEngine::ValidateTrain(int64_t nQuestions, const AQ *pAQs, int64_t iTarget, int64_t iQuiz) {
+  std::lock_guard<EngineMutex> lk(_mu);
+  if (iQuiz < 0) return ValidateTrainLocked(nQuestions, pAQs, iTarget);
+  Error err = CheckRegular("record quiz target");
+  if (!err.ok()) return err;
+  Quiz *q = UseQuiz(err, iQuiz);
+  if (!q) return err;
+  return ValidateTrainLocked((int64_t)q->answers.size(), q->answers.data(), iTarget);
+}
+
+// Validation + the steps on the device; the caller holds the lock.
+Error HipEngine::TrainLocked(int64_t nQuestions, const AQ *pAQs, int64_t iTarget, double amount, bool fromQuiz) {
+  StopServer();   // the cube changes: the resident sweep's XCD-local L2s would keep stale rows
+  {
+    Error ve = ValidateTrainLocked(nQuestions, pAQs, iTarget);
+    if (!ve.ok()) return ve;
   }
   std::vector<TrainStep> steps;
   std::vector<int64_t> chainStart;

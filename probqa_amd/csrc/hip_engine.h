@@ -234,6 +234,13 @@ class HipEngine : public IEngine {
   uint32_t PrecMantissa() const { return _precMantissa; }
   uint16_t PrecExponent() const { return _precExponent; }
   Error UnavailableWords(int64_t iQuiz, std::vector<uint32_t> &words);
+  // a batched selection in two halves: every shard's sweep is in flight before the first one is waited for
+  Error EnqueueBatch(int64_t n, const int64_t *pQuizzes, bool wantPriorities, uint64_t *pTag);
+  Error CollectBatchSelections(int64_t n, uint64_t tag, CiHipSelection *pOut);
+  Error CollectBatchPriorities(int64_t n, double *pOut);
+  Error ValidateTrain(int64_t nQuestions, const AQ *pAQs, int64_t iTarget, int64_t iQuiz);
+  bool IsRegularMode() const { return _mode == Mode::Regular; }
+  const PermIdMgr &QuizPim() const { return _pimQuizzes; }
 
  private:
   HipEngine() = default;
@@ -250,6 +257,7 @@ class HipEngine : public IEngine {
   Error RecordAnswerImpl(int64_t iQuiz, int64_t iAnswer, bool remote);
   void BuildTrainSteps(int64_t n, const AQ *pAQs, bool fromQuiz, std::vector<TrainStep> &steps, std::vector<int64_t> &chainStart) const;
   Error TrainLocked(int64_t nQuestions, const AQ *pAQs, int64_t iTarget, double amount, bool fromQuiz);
+  Error ValidateTrainLocked(int64_t nQuestions, const AQ *pAQs, int64_t iTarget) const;
   uint64_t NextRandom();
   Error UploadGaps();
   Error ReallocKB(int64_t newQ, int64_t newT);               // grow the device cube / vB / per-question buffers
@@ -321,6 +329,10 @@ class HipEngine : public IEngine {
   size_t _batchPTBytes = 0, _batchAccBytes = 0, _batchRecBytes = 0, _batchPriTBytes = 0;
   Error BatchSweep(int64_t n, const int64_t *pQuizzes, std::vector<Quiz *> &quizzes, bool wantPriorities, uint64_t tag);
   Error WaitBatchFlags(int64_t n, uint64_t tag);
+  Error EnqueueBatchLocked(int64_t n, const int64_t *pQuizzes, bool wantPriorities, uint64_t *pTag);
+  Error CollectBatchSelectionsLocked(int64_t n, uint64_t tag, CiHipSelection *pOut);
+  Error CollectBatchPrioritiesLocked(int64_t n, double *pOut);
+  std::vector<Quiz *> _batchQuizzes;   // the quizzes of the batch between its two halves
   int _lastBatchBp = 0;
   void *_dClusterScratch = nullptr;   // exchange buffers of the long-row sweep (cluster_kernels.hip), grown on demand
   size_t _clusterScratchBytes = 0;

@@ -14,7 +14,36 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 namespace pqa {
+
+// What a launch wrapper has asked the runtime about one kernel instantiation, PER DEVICE: the opt-in to more than 64 KiB of
+// dynamic LDS (hipFuncSetAttribute) belongs to the device that was current when it was made, and one process drives
+// several devices (sharded_engine.cpp).  One function-local static per instantiation; engines on different threads may
+// race for a slot -- they would store the same value.
+struct LaunchCache {
+  static constexpr int kDevices = 64;
+  std::atomic<uint64_t> slot[kDevices];   // (LDS bytes << 16) | (workgroups per CU + 1); 0 = nothing asked yet
+  std::atomic<int> numCUs[kDevices];
+  static int Device() { int d = 0; return hipGetDevice(&d) == hipSuccess ? (d & (kDevices - 1)) : 0; }
+  bool Get(int dev, size_t shmem, int *perCU) const {
+    const uint64_t v = slot[dev].load(std::memory_order_acquire);
+    if (v == 0 || (v >> 16) != (uint64_t)shmem) return false;
+    *perCU = (int)(v & 0xFFFF) - 1;
+    return true;
+  }
+  void Put(int dev, size_t shmem, int perCU) { slot[dev].store(((uint64_t)shmem << 16) | (uint64_t)(perCU + 1), std::memory_order_release); }
+  int NumCUs(int dev) {
+    int n = numCUs[dev].load(std::memory_order_relaxed);
+    if (n == 0) {
+      int d = 0;
+      n = (hipGetDevice(&d) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d) == hipSuccess && n > 0) ? n : 256;
+      numCUs[dev].store(n, std::memory_order_relaxed);
+    }
+    return n;
+  }
+};
 
 struct KbView {
   const void *cube;       // [Q][K+1][ldT], elements of `elem` bytes: double (Double engines) or float (Float engines)

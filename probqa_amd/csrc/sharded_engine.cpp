@@ -28,7 +28,9 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <random>
 
 #include "hip_engine.h"
 
@@ -65,8 +67,12 @@ class ShardedEngine final : public IEngine {
   static ShardedEngine *Create(Error &err, const CiEngineDefinition &def, const std::vector<int> &devices);
   ~ShardedEngine() override;
 
+  // The reference validates every answered question before any Add subtask runs (CETrainSubtaskDistrib.h:26-45): a gap question
+  // owned by shard k must not leave shards 0..k-1 trained and their vB replicas ahead -- every shard validates, then every shard trains.
   Error Train(int64_t n, const AQ *pAQs, int64_t iTarget, double amount) override {
     std::lock_guard<std::mutex> lk(_mu);
+    if (n >= 0 && amount > 0 && (n == 0 || pAQs != nullptr))   // (else: shard 0 produces the reference's argument error, before any kernel)
+      for (auto &s : _sh) { Error e = s->ValidateTrain(n, pAQs, iTarget, -1); if (!e.ok()) return e; }
     for (auto &s : _sh) { Error e = s->Train(n, pAQs, iTarget, amount); if (!e.ok()) return e; }
     return SyncShards();
   }
@@ -82,21 +88,37 @@ class ShardedEngine final : public IEngine {
   int64_t ResumeQuiz(Error &err, int64_t nAnswered, const AQ *pAQs) override;
   int64_t NextQuestion(Error &err, int64_t iQuiz) override;
   Error RecordAnswer(int64_t iQuiz, int64_t iAnswer) override;
-  int64_t GetActiveQuestionId(Error &err, int64_t iQuiz) override { return _sh[0]->GetActiveQuestionId(err, iQuiz); }
-  Error SetActiveQuestion(int64_t iQuiz, int64_t iQuestion) override { return All([&](HipEngine &e) { return e.SetActiveQuestion(iQuiz, iQuestion); }); }
+  int64_t GetActiveQuestionId(Error &err, int64_t iQuiz) override {
+    std::lock_guard<std::mutex> lk(_mu);
+    Touch(iQuiz);
+    return _sh[0]->GetActiveQuestionId(err, iQuiz);
+  }
+  Error SetActiveQuestion(int64_t iQuiz, int64_t iQuestion) override {
+    std::lock_guard<std::mutex> lk(_mu);
+    Touch(iQuiz);
+    for (auto &s : _sh) { Error e = s->SetActiveQuestion(iQuiz, iQuestion); if (!e.ok()) return e; }
+    return Error();
+  }
   int64_t ListTopTargets(Error &err, int64_t iQuiz, int64_t maxCount, CiRatedTarget *pDest) override {
     std::lock_guard<std::mutex> lk(_mu);
+    Touch(iQuiz);
     return _sh[_lastOwner.count(iQuiz) ? _lastOwner[iQuiz] : 0]->ListTopTargets(err, iQuiz, maxCount, pDest);   // (its kernel listed them already)
   }
   Error RecordQuizTarget(int64_t iQuiz, int64_t iTarget, double amount) override {
-    Error e = All([&](HipEngine &sh) { return sh.RecordQuizTarget(iQuiz, iTarget, amount); });
-    return e.ok() ? SyncShards() : e;
+    std::lock_guard<std::mutex> lk(_mu);
+    Touch(iQuiz);
+    if (amount > 0)
+      for (auto &s : _sh) { Error e = s->ValidateTrain(0, nullptr, iTarget, iQuiz); if (!e.ok()) return e; }
+    for (auto &s : _sh) { Error e = s->RecordQuizTarget(iQuiz, iTarget, amount); if (!e.ok()) return e; }
+    return SyncShards();
   }
   Error ReleaseQuiz(int64_t iQuiz) override {
     std::lock_guard<std::mutex> lk(_mu);
     _lastOwner.erase(iQuiz);
-    for (auto &s : _sh) { Error e = s->ReleaseQuiz(iQuiz); if (!e.ok()) return e; }
-    return Error();
+    _usage.erase(iQuiz);
+    Error first;   // every shard releases (a shard that has not got the quiz says so): the registries stay in step
+    for (auto &s : _sh) { Error e = s->ReleaseQuiz(iQuiz); if (!e.ok() && first.ok()) first = e; }
+    return first;
   }
   Error StartMaintenance(bool force) override { return All([&](HipEngine &e) { return e.StartMaintenance(force); }); }
   Error FinishMaintenance() override { return All([&](HipEngine &e) { return e.FinishMaintenance(); }); }
@@ -123,17 +145,21 @@ class ShardedEngine final : public IEngine {
   Error RemoveQuestions(int64_t, const int64_t *) override { return NotSharded("RemoveQuestions"); }
   Error RemoveTargets(int64_t, const int64_t *) override { return NotSharded("RemoveTargets"); }
   Error Compact(int64_t *, const int64_t **, int64_t *, const int64_t **) override { return NotSharded("Compact"); }
-  Error ClearOldQuizzes(int64_t maxCount, double maxAgeSec) override { return All([&](HipEngine &e) { return e.ClearOldQuizzes(maxCount, maxAgeSec); }); }
+  Error ClearOldQuizzes(int64_t maxCount, double maxAgeSec) override;
 
   Error SetOption(const char *name, int64_t value) override {
     const std::string n(name ? name : "");
+    Error e = All([&](HipEngine &sh) { return sh.SetOption(name, value); });
+    if (!e.ok()) return e;   // (a value the shards refuse changes nothing here either)
+    std::lock_guard<std::mutex> lk(_mu);
     if (n == "select") _select = value;   // (kept here too: NextQuestion dispatches on it)
-    if (n == "seed") { _rng[0] = 0x9E3779B97F4A7C15ULL ^ (uint64_t)value; _rng[1] = 0xBF58476D1CE4E5B9ULL + ((uint64_t)value << 1); }
-    return All([&](HipEngine &e) { return e.SetOption(name, value); });
+    if (n == "seed") Seed((uint64_t)value);
+    return Error();
   }
   int64_t GetOption(const char *name) const override {
     const std::string n(name ? name : "");
     if (n == "shards") return (int64_t)_sh.size();
+    if (n == "shards_in_flight_max") return _shardsInFlightMax;   // the most shards whose sweeps were enqueued before the first was waited for (newest call)
     return _sh[0]->GetOption(name);
   }
   const char *EvalKernelName() const override { return _sh[0]->EvalKernelName(); }
@@ -170,14 +196,27 @@ class ShardedEngine final : public IEngine {
   }
   int64_t NextQuestionArgmax(Error &err, int64_t iQuiz) override;
   int64_t NextQuestionSampled(Error &err, int64_t iQuiz, uint64_t rnd) override;
-  Error GetPriors(int64_t iQuiz, double *pOut, int64_t n) override { return _sh[0]->GetPriors(iQuiz, pOut, n); }
+  Error GetPriors(int64_t iQuiz, double *pOut, int64_t n) override {
+    std::lock_guard<std::mutex> lk(_mu);
+    Touch(iQuiz);
+    return _sh[0]->GetPriors(iQuiz, pOut, n);
+  }
   Error NextQuestionArgmaxBatch(int64_t n, const int64_t *pQuizzes, int64_t *pOut) override;
   Error EvalPrioritiesBatch(int64_t n, const int64_t *pQuizzes, double *pOut) override {
     std::lock_guard<std::mutex> lk(_mu);
+    // every shard's sweep is in flight (its own device and stream) before the first one is waited for
+    _shardsInFlightMax = 0;
+    for (auto &s : _sh) {
+      uint64_t tag = 0;
+      Error e = s->EnqueueBatch(n, pQuizzes, true, &tag);
+      if (!e.ok()) return e;
+      _shardsInFlightMax++;
+    }
+    for (int64_t i = 0; i < n && pQuizzes; i++) Touch(pQuizzes[i]);
     std::vector<double> part;
     for (auto &s : _sh) {
       part.resize((size_t)n * (size_t)s->LocalQuestions());
-      Error e = s->EvalPrioritiesBatch(n, pQuizzes, part.data());
+      Error e = s->CollectBatchPriorities(n, part.data());
       if (!e.ok()) return e;
       for (int64_t i = 0; i < n; i++)
         std::memcpy(pOut + (size_t)i * (size_t)_Q + (size_t)s->FirstQuestion(), part.data() + (size_t)i * (size_t)s->LocalQuestions(),
@@ -231,6 +270,25 @@ class ShardedEngine final : public IEngine {
   std::vector<double> _hostPriority;
   PermIdMgr _pimQuestions;                   // global question ids
   uint64_t _rng[2] = {0x9E3779B97F4A7C15ULL, 0xBF58476D1CE4E5B9ULL};
+  void Seed(uint64_t x) {   // SplitMix64 into the two words of the generator, as HipEngine does
+    auto next = [&x] {
+      uint64_t z = (x += 0x9E3779B97F4A7C15ULL);
+      z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+      z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+      return z ^ (z >> 31);
+    };
+    _rng[0] = next();
+    _rng[1] = next();
+  }
+  int64_t _shardsInFlightMax = 0;
+  // BaseQuiz::OnUsage (BaseEngine.cpp:417) for the engine as a whole: the shards are touched at different times (ListTopTargets
+  // reaches one of them, GetPriors shard 0), so which quizzes ClearOldQuizzes evicts is decided HERE, once, and every shard
+  // releases the same ids in the same order -- the shards' registries (ids, gaps) never diverge.
+  std::unordered_map<int64_t, time_t> _usage;
+  void Touch(int64_t iQuiz) { auto it = _usage.find(iQuiz); if (it != _usage.end()) it->second = time(nullptr); }
+  void ReleaseEverywhere(int64_t iQuiz, size_t nShards) {   // roll a partly created quiz back
+    for (size_t s = 0; s < nShards; s++) (void)_sh[s]->ReleaseQuiz(iQuiz);
+  }
 };
 
 ShardedEngine::~ShardedEngine() {
@@ -293,6 +351,16 @@ ShardedEngine *ShardedEngine::Create(Error &err, const CiEngineDefinition &def, 
     }
   }
   eng->_select = eng->_sh[0]->GetOption("select");
+  {   // the selector's generator: from the system's entropy like the reference's (SRFastRandom.h:31-40), or PQA_SEED
+    std::random_device rd;
+    uint64_t seed = ((uint64_t)rd() << 32) ^ rd();
+    if (const char *v = std::getenv("PQA_SEED")) {
+      char *end = nullptr;
+      const long long x = std::strtoll(v, &end, 10);
+      if (end != v && *end == 0) seed = (uint64_t)x;
+    }
+    eng->Seed(seed);
+  }
   eng->_hostPriority.resize((size_t)def._nQuestions);
   eng->_pimQuestions.GrowTo(def._nQuestions);
   err = Error();
@@ -304,10 +372,16 @@ int64_t ShardedEngine::StartQuiz(Error &err) {
   int64_t id = -1;
   for (size_t s = 0; s < _sh.size(); s++) {
     const int64_t got = _sh[s]->StartQuiz(err);
-    if (got < 0) return -1;
+    if (got < 0) { if (s > 0) ReleaseEverywhere(id, s); return -1; }   // (e.g. out of memory on shard s: the earlier shards' quiz goes again)
     if (s == 0) id = got;
-    else if (got != id) { err = Error::Make(ErrCode::Internal, "The shards' quiz registries have diverged."); return -1; }
+    else if (got != id) {
+      (void)_sh[s]->ReleaseQuiz(got);
+      ReleaseEverywhere(id, s);
+      err = Error::Make(ErrCode::Internal, "The shards' quiz registries have diverged.");
+      return -1;
+    }
   }
+  _usage[id] = time(nullptr);
   return id;
 }
 
@@ -334,10 +408,55 @@ int64_t ShardedEngine::ResumeQuiz(Error &err, int64_t nAnswered, const AQ *pAQs)
   if (hipEventRecord(_posteriorReady[0], _sh[0]->GetStream()) != hipSuccess) { err = Error::Make(ErrCode::Internal, "hipEventRecord failed."); return -1; }
   for (size_t s = 1; s < _sh.size(); s++) {
     const int64_t got = _sh[s]->ResumeQuizAdopt(err, nAnswered, pAQs, (const double *)src, _sh[0]->Device(), _posteriorReady[0]);
-    if (got < 0) return -1;
-    if (got != id) { err = Error::Make(ErrCode::Internal, "The shards' quiz registries have diverged."); return -1; }
+    if (got < 0) { ReleaseEverywhere(id, s); return -1; }
+    if (got != id) {
+      (void)_sh[s]->ReleaseQuiz(got);
+      ReleaseEverywhere(id, s);
+      err = Error::Make(ErrCode::Internal, "The shards' quiz registries have diverged.");
+      return -1;
+    }
+    // shard 0's next posterior kernel of this quiz (RecordAnswer on owner 0) waits for this copy of the one it rewrites
+    hipSetDevice(_sh[s]->Device());
+    if (hipEventRecord(_copyDone[s], _sh[s]->GetStream()) != hipSuccess) { ReleaseEverywhere(id, _sh.size()); err = Error::Make(ErrCode::Internal, "hipEventRecord failed."); return -1; }
   }
+  _lastOwner[id] = 0;
+  _usage[id] = time(nullptr);
   return id;
+}
+
+// BaseEngine::ClearOldQuizzes (BaseEngine.cpp:814-873), decided once for all shards: first everything older than maxAgeSec, then
+// the oldest of the rest (a max-heap by age) until maxCount remain.
+Error ShardedEngine::ClearOldQuizzes(int64_t maxCount, double maxAgeSec) {
+  if (maxCount < 0)
+    return Error::MakeP(ErrCode::NegativeCount, "count=" + std::to_string(maxCount), "The number of quizzes to keep cannot be less than 0.");
+  std::lock_guard<std::mutex> lk(_mu);
+  if (!_sh[0]->IsRegularMode()) return Error();   // quizzes are not expected to exist in maintenance / shutdown mode
+  struct QuizAge { int64_t iQuiz; double ageSec; bool operator<(const QuizAge &o) const { return ageSec < o.ageSec; } };
+  std::vector<int64_t> ids;
+  for (const auto &kv : _usage) ids.push_back(kv.first);
+  std::sort(ids.begin(), ids.end());   // (registry order, as the reference walks it)
+  std::vector<QuizAge> ages;
+  std::vector<int64_t> evict;
+  const time_t callTime = time(nullptr);
+  for (int64_t id : ids) {
+    const double ageSec = difftime(callTime, _usage[id]);
+    if (ageSec > maxAgeSec) evict.push_back(id); else ages.push_back(QuizAge{id, ageSec});
+  }
+  if ((int64_t)ages.size() > maxCount) {
+    std::make_heap(ages.begin(), ages.end());
+    while ((int64_t)ages.size() > maxCount) {
+      evict.push_back(ages.front().iQuiz);
+      std::pop_heap(ages.begin(), ages.end());
+      ages.pop_back();
+    }
+  }
+  Error first;
+  for (int64_t id : evict) {
+    _lastOwner.erase(id);
+    _usage.erase(id);
+    for (auto &s : _sh) { Error e = s->ReleaseQuiz(id); if (!e.ok() && first.ok()) first = e; }
+  }
+  return first;
 }
 
 // Everything NextQuestion does after the pick (CpuEngine.cpp:403-413): the question becomes the quiz's active question on every
@@ -385,6 +504,7 @@ int64_t ShardedEngine::SelectArgmaxLocked(Error &err, int64_t iQuiz, double *pPr
 
 int64_t ShardedEngine::NextQuestionArgmax(Error &err, int64_t iQuiz) {
   std::lock_guard<std::mutex> lk(_mu);
+  Touch(iQuiz);
   const int64_t q = SelectArgmaxLocked(err, iQuiz, nullptr);
   if (!err.ok()) return -1;
   return Commit(err, iQuiz, q);
@@ -396,6 +516,7 @@ int64_t ShardedEngine::NextQuestionArgmax(Error &err, int64_t iQuiz) {
 // engine picks.
 int64_t ShardedEngine::NextQuestionSampled(Error &err, int64_t iQuiz, uint64_t rnd) {
   std::lock_guard<std::mutex> lk(_mu);
+  Touch(iQuiz);
   for (auto &s : _sh) { err = s->EnqueueEval(iQuiz); if (!err.ok()) return -1; }
   for (auto &s : _sh) {
     hipSetDevice(s->Device());
@@ -435,6 +556,7 @@ int64_t ShardedEngine::NextQuestion(Error &err, int64_t iQuiz) {
 
 Error ShardedEngine::RecordAnswer(int64_t iQuiz, int64_t iAnswer) {
   std::lock_guard<std::mutex> lk(_mu);
+  Touch(iQuiz);
   Error err;
   const int64_t aq = _sh[0]->GetActiveQuestionId(err, iQuiz);
   if (!err.ok()) return err;
@@ -465,12 +587,24 @@ Error ShardedEngine::RecordAnswer(int64_t iQuiz, int64_t iAnswer) {
   return Error();
 }
 
+// Every shard's batched sweep is enqueued -- on its own device and stream -- before the first one is waited for: on N devices a
+// batch takes one shard's time, not N shards' (SRPoolRunner's subtasks run side by side too, SRPlatform/Interface/SRPoolRunner.h:96-110).
 Error ShardedEngine::SelectArgmaxBatch(int64_t n, const int64_t *pQuizzes, CiHipSelection *pOut) {
   std::lock_guard<std::mutex> lk(_mu);
-  std::vector<CiHipSelection> part((size_t)n);
+  if (n > 0 && !pOut) return Error::Make(ErrCode::NullArgument, "Nullptr is passed in place of a batch buffer.");
+  std::vector<uint64_t> tags(_sh.size(), 0);
+  _shardsInFlightMax = 0;
   for (size_t s = 0; s < _sh.size(); s++) {
-    Error e = _sh[s]->SelectArgmaxBatch(n, pQuizzes, part.data());
-    if (!e.ok()) return e;
+    Error e = _sh[s]->EnqueueBatch(n, pQuizzes, false, &tags[s]);
+    if (!e.ok()) return e;   // (validation fails on shard 0, before anything was launched)
+    _shardsInFlightMax++;
+  }
+  for (int64_t i = 0; i < n; i++) Touch(pQuizzes[i]);
+  std::vector<CiHipSelection> part((size_t)n);
+  Error first;
+  for (size_t s = 0; s < _sh.size(); s++) {
+    Error e = _sh[s]->CollectBatchSelections(n, tags[s], part.data());
+    if (!e.ok()) { if (first.ok()) first = e; continue; }   // (the other shards' launches are still waited for)
     for (int64_t i = 0; i < n; i++) {
       const CiHipSelection &c = part[(size_t)i];
       CiHipSelection &b = pOut[i];
@@ -478,7 +612,7 @@ Error ShardedEngine::SelectArgmaxBatch(int64_t n, const int64_t *pQuizzes, CiHip
       if (c._iQuestion >= 0 && (b._iQuestion < 0 || c._priority > b._priority || (c._priority == b._priority && c._iQuestion < b._iQuestion))) b = c;
     }
   }
-  return Error();
+  return first;
 }
 
 Error ShardedEngine::NextQuestionArgmaxBatch(int64_t n, const int64_t *pQuizzes, int64_t *pOut) {
@@ -534,8 +668,8 @@ Error ShardedEngine::SaveKB(const char *filePath, bool doubleBuffer) {
     return std::fwrite(&n, 8, 1, fg.f) == 1 && std::fwrite(gaps.data(), 8, (size_t)n, fg.f) == (size_t)n;
   };
   if (!writeGaps(qGaps) || !writeGaps(tGaps)) return KbFileErr(filePath, "Can't write the gaps.");
-  PermIdMgr noQuizzes;
-  if (!_pimQuestions.Save(fg.f) || !s0.TargetPim().Save(fg.f) || !noQuizzes.Save(fg.f, true))
+  // (the live quiz map with empty = true keeps its next permanent id, as BaseEngine.cpp:379 and HipEngine::SaveKB write it)
+  if (!_pimQuestions.Save(fg.f) || !s0.TargetPim().Save(fg.f) || !s0.QuizPim().Save(fg.f, true))
     return KbFileErr(filePath, "Can't write the permanent-compact ID mappings.");
   if (std::fflush(fg.f) != 0) return KbFileErr(filePath, "Failed in hard flushing the KB.");
   FILE *f = fg.f;

@@ -190,6 +190,81 @@ class ShmSelector:
                     pass
 
 
+class ShmBatchExchange:
+    """The ranks' per-quiz winners of one BATCHED sweep (PqaHip_SelectArgmaxBatch: [B, 2] = priority, GLOBAL index) exchanged
+    through a host shared-memory segment: the records are on the host already when the batched call returns, so the exchange is
+    16 B x B of stores per rank and a spin on `world` step numbers -- no collective launch, no H2D / D2H copy.  Two slot sets
+    alternate by step parity (as ShmSelector).  x86 keeps stores in order: the records are written before the step number."""
+
+    def __init__(self, n_quizzes: int, rank: int, world: int, name: str, create: Optional[bool] = None):
+        import mmap
+        import os
+
+        import numpy as np
+
+        self.B, self.rank, self.world = n_quizzes, rank, world
+        self.stride = 16 * n_quizzes + 64               # records, then the step number on its own line
+        self.path = "/dev/shm/pqa_batch_%s" % name
+        size = 2 * world * self.stride
+        if create is None:
+            create = rank == 0
+        fd = os.open(self.path, (os.O_CREAT | os.O_TRUNC | os.O_RDWR) if create else os.O_RDWR, 0o600)
+        try:
+            if create:
+                os.ftruncate(fd, size)
+            self._map = mmap.mmap(fd, size)
+        finally:
+            os.close(fd)
+        self._bytes = np.frombuffer(self._map, dtype=np.uint8)
+        self.step = 0
+        self._owner = create
+
+    def _slot(self, half: int, r: int):
+        import numpy as np
+
+        off = (half * self.world + r) * self.stride
+        recs = self._bytes[off:off + 16 * self.B].view(np.float64).reshape(self.B, 2)
+        flag = self._bytes[off + 16 * self.B:off + 16 * self.B + 8].view(np.uint64)
+        return recs, flag
+
+    def exchange(self, local_winners, timeout_s: float = 600.0) -> List[int]:
+        """local_winners: numpy [B, 2] of this rank -> the B global picks, the same on every rank."""
+        import time
+
+        import numpy as np
+
+        self.step += 1
+        half = self.step & 1
+        recs, flag = self._slot(half, self.rank)
+        recs[:] = local_winners
+        flag[0] = self.step
+        gathered = np.empty((self.world, self.B, 2), dtype=np.float64)
+        t0 = time.perf_counter()
+        for r in range(self.world):
+            rr, ff = self._slot(half, r)
+            while int(ff[0]) != self.step:
+                if time.perf_counter() - t0 > timeout_s:
+                    raise TimeoutError("rank %d never published step %d" % (r, self.step))
+            gathered[r] = rr
+        return pick_batch(gathered)
+
+    def close(self) -> None:
+        import os
+
+        if self._map is not None:
+            self._bytes = None
+            try:
+                self._map.close()
+            except BufferError:
+                pass
+            self._map = None
+            if self._owner:
+                try:
+                    os.unlink(self.path)
+                except OSError:
+                    pass
+
+
 def broadcast_prior(prior: torch.Tensor, owner_rank: int, group: Optional[dist.ProcessGroup] = None) -> None:
     """After RecordAnswer on the owner of the answered question: replicate the new prior vector."""
     if dist.is_initialized() and dist.get_world_size(group) > 1:

@@ -1,0 +1,37 @@
+"""`python bench.py --gpus 2` typed by itself must work: bench.py starts its own ranks under
+torch.distributed.run; on a box with fewer devices than ranks the ranks share a device (gloo control plane, the RCCL exchange
+reported as skipped) -- a dry run of the N > 1 path: sharded S with the shared-memory exchange, the batched configuration over
+two shards, and the one-process sharded engine whose batched call has every shard in flight."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_gpus_2_self_spawns():
+    env = dict(os.environ)
+    env.pop("RANK", None)
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "50", "--warmup", "20", "--no-quiz-loop",
+                        "--sharded-configs", "S,L1", "--l1-config", "LS", "--batch", "0"],
+                       capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["value"] > 0 and out["scaling"] == "strong"
+    assert out["config"]["questions_per_gpu"] == 500
+    ex = out["exchange_1000x5x1000"]
+    assert ex["shm"]["selections_per_sec"] > 0 and ("selections_per_sec" in ex["rccl"] or "skipped" in ex["rccl"])
+    b = out["sharded_12500x5x100000_per_gpu"]
+    assert b["n_gpus"] == 2 and b["exchange"]["shm"]["selections_per_sec"] > 0
+    one = out["one_process_sharded_engine"]
+    assert one["1000x5x1000"]["shards"] == 2
+    l1 = [v for k, v in one.items() if k.endswith("_per_shard")][0]
+    assert l1["shards"] == 2 and l1["shards_in_flight_max"] == 2

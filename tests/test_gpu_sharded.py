@@ -240,3 +240,97 @@ def test_config4_shape_sharded_batch_on_one_device(factory):
     assert rel.max() < 5e-4
     sh.close()
     whole.close()
+
+
+def test_sharded_batch_has_every_shard_in_flight(factory):
+    """A batched selection on a sharded engine enqueues every shard's sweep before it waits for the first
+    (sharded_engine.cpp: SelectArgmaxBatch): `shards_in_flight_max` == the shard count, and the picks are a whole engine's."""
+    case = cases.Case("shbatch", 5, 97, 130, seed=41, qgaps=[3, 60])
+    with devices("0,0,0"):
+        sh = case.make_engine(factory)
+    whole = case.make_engine(factory)
+    for e in (sh, whole):
+        e.set_option("batch_min", 1)
+    n = 9
+    qs, qw = [sh.start_quiz() for _ in range(n)], [whole.start_quiz() for _ in range(n)]
+    valid = [q for q in range(case.Q) if q not in case.qgaps]
+    for i in range(n):
+        for e, z in ((sh, qs[i]), (whole, qw[i])):
+            e.set_active_question(z, valid[(11 * i) % len(valid)])
+            e.record_answer(z, i % case.K)
+    assert sh.get_option("shards_in_flight_max") == 0
+    picks = sh.next_question_argmax_batch(qs)
+    assert sh.get_option("shards_in_flight_max") == 3
+    assert picks == whole.next_question_argmax_batch(qw)
+    pri = sh.eval_priorities_batch(qs, case.Q)
+    assert sh.get_option("shards_in_flight_max") == 3
+    assert cases.rel_err(pri, whole.eval_priorities_batch(qw, case.Q)).max() < 1e-11
+    for i in range(n):
+        assert picks[i] == int(np.argmax(pri[i])) or pri[i][picks[i]] == pri[i].max()
+    sh.close()
+    whole.close()
+
+
+def test_sharded_train_validates_every_shard_before_any_trains(factory):
+    """a gap question owned by a LATER shard must fail the call before the earlier shards have trained (the reference
+    validates every answered question before any Add subtask runs, CETrainSubtaskDistrib.h:26-45)."""
+    case = cases.Case("shtrain", 4, 40, 50, seed=5, qgaps=[33])
+    with devices("0,0,0,0"):
+        sh = case.make_engine(factory)
+    before = sh.get_kb(case.Q)
+    err = sh.train([interop.AnsweredQuestion(2, 1), interop.AnsweredQuestion(33, 0)], 7, 1.5, throw=False)
+    assert err is not None and "gap" in err.to_string(True)
+    after = sh.get_kb(case.Q)
+    for a, b in zip(before, after):
+        assert np.array_equal(a, b)            # nothing was trained, no vB replica moved
+    # and the engine still works: the shards agree on the priors
+    q = sh.start_quiz()
+    assert sh.next_question_argmax(q) >= 0
+    sh.close()
+
+
+def test_sharded_clear_old_quizzes_is_decided_once(factory):
+    """eviction by ClearOldQuizzes is decided in the sharded engine, not per shard -- afterwards the shards' quiz
+    registries still agree (StartQuiz works and reuses the freed ids)."""
+    case = cases.Case("shclear", 3, 30, 40, seed=6)
+    with devices("0,0"):
+        sh = case.make_engine(factory)
+    quizzes = [sh.start_quiz() for _ in range(6)]
+    sh.list_top_targets(quizzes[1], 2)        # touches ONE shard only
+    sh.get_priors(quizzes[2])                 # touches shard 0 only
+    sh.clear_old_quizzes(2, 1e9)              # keep the two most recently used
+    alive = []
+    for z in quizzes:
+        try:
+            sh.get_active_question_id(z)
+            alive.append(z)
+        except interop.PqaException:
+            pass
+    assert len(alive) == 2
+    fresh = [sh.start_quiz() for _ in range(5)]          # the registries have not diverged
+    assert len(set(fresh)) == 5 and not set(fresh) & set(alive)
+    for z in fresh + alive:
+        assert sh.next_question_argmax(z) >= 0
+    sh.close()
+
+
+def test_sharded_engine_seeds_its_selector(factory):
+    """the sharded engine's own generator is seeded from entropy (or PQA_SEED), not from constants."""
+    case = cases.Case("shseed", 3, 60, 40, seed=8)
+
+    def draws():
+        with devices("0,0"):
+            e = case.make_engine(factory)
+        z = e.start_quiz()
+        out = [e.next_question(z) for _ in range(12)]
+        e.close()
+        return out
+
+    a, b = draws(), draws()
+    assert a != b                                          # 60 questions, 12 draws: equal sequences would mean a fixed seed
+    os.environ["PQA_SEED"] = "12345"
+    try:
+        c, d = draws(), draws()
+    finally:
+        os.environ.pop("PQA_SEED", None)
+    assert c == d
