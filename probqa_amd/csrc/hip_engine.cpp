@@ -11,6 +11,9 @@
 #include <functional>
 #include <sstream>
 
+#include <immintrin.h>
+#include <sys/prctl.h>
+#include <time.h>
 #include <unistd.h>
 
 namespace pqa {
@@ -262,6 +265,7 @@ Error HipEngine::Init(const CiEngineDefinition &def, const CiHipShard *shard) {
 //   PQA_BUG_COMPAT=0|1         ResumeQuiz as the reference binary (1, default) or as evidently intended (0)
 //   PQA_WORKERS=n              emulated thread-pool size (summation order of the posterior updates, training buckets)
 //   PQA_SEED=n                 seed of the selector's generator (the reference's cannot be seeded)
+//   PQA_COMBINE=0|1            concurrent NextQuestion calls of different quizzes share one sweep, RecordAnswer's kernels are gathered (1, default)
 //   PQA_DEVICES=i[,j,...]      device ordinal(s): read by the factory (c_abi.cpp), which builds one shard per listed device
 void HipEngine::ApplyEnvironment() {
   auto num = [](const char *name, int64_t lo, int64_t hi, int64_t &out) {
@@ -286,6 +290,7 @@ void HipEngine::ApplyEnvironment() {
   if (num("PQA_SERVER", 0, 1, x)) _optServer = x;
   if (num("PQA_BUG_COMPAT", 0, 1, x)) _optBugCompat = x;
   if (num("PQA_SPECULATE", 0, 1, x)) _optSpeculate = x;
+  if (num("PQA_COMBINE", 0, 1, x)) _optCombine = x;
   if (num("PQA_WORKERS", 1, kMaxWorkers, x)) _optWorkers = x;
   if (num("PQA_SEED", INT64_MIN, INT64_MAX, x)) { uint64_t s = (uint64_t)x; _rng[0] = SplitMix64(s); _rng[1] = SplitMix64(s); }
 }
@@ -300,12 +305,18 @@ HipEngine::~HipEngine() {
   if (_stream) hipStreamSynchronize(_stream);
   for (Quiz *q : _quizzes) if (q) DestroyQuiz(q);
   hipFree(_dCube); hipFree(_dVB); hipFree(_dPriority); hipFree(_dRunLength); hipFree(_dExps); hipFree(_dStatus);
-  hipFree(_dNOut); hipFree(_dSel); hipFree(_dSelScratch); hipFree(_dBatchSlots); hipFree(_dBatchScratch); hipFree(_dBatchPriority);
-  hipFree(_dBatchPT); hipFree(_dBatchAcc); hipFree(_dBatchRecs); hipFree(_dBatchPriT); hipFree(_dClusterScratch);
+  hipFree(_dNOut); hipFree(_dSel); hipFree(_dSelScratch); hipFree(_dClusterScratch);
+  for (BatchCtx &c : _ctx) {
+    hipFree(c.dSlots); hipFree(c.dScratch); hipFree(c.dPriority); hipFree(c.dPT); hipFree(c.dAcc); hipFree(c.dRecs); hipFree(c.dPriT);
+    if (c.hPri) hipHostFree(c.hPri);
+    if (c.event) hipEventDestroy(c.event);
+    if (c.h) hipHostFree(c.h);
+  }
   DropQuizBufferPool();
   for (auto &g : _graphs) hipGraphExecDestroy(g.second.exec);
   hipFree(_dGraphScratch); hipFree(_dTagCell);
-  if (_hBatch) hipHostFree(_hBatch); hipFree(_dTGap); hipFree(_dQGap); hipFree(_dAqs); hipFree(_dTop);
+  for (QuizPinned *slab : _pinSlabs) hipHostFree(slab);
+  hipFree(_dTGap); hipFree(_dQGap); hipFree(_dAqs); hipFree(_dTop);
   if (_hPinned) hipHostFree(_hPinned);
   if (_hHostPriority) hipHostFree(_hHostPriority);
   if (_ownStream) hipStreamDestroy(_ownStream);
@@ -336,7 +347,10 @@ KbView HipEngine::View() const {
 Error HipEngine::SetOption(const char *name, int64_t value) {
   std::lock_guard<EngineMutex> lk(_mu);
   const std::string n(name ? name : "");
+  (void)FlushUpdates();   // (deferred updates run under the options they were recorded under)
   if (n == "select") { if (value != 0 && value != 1) goto bad; _optSelect = value; }
+  else if (n == "combine") { _optCombine = value ? 1 : 0; }
+  else if (n == "combine_linger_us") { if (value < 0 || value > 10000) goto bad; _optLingerUs = value; }
   else if (n == "workers") { if (value < 1 || value > kMaxWorkers) goto bad; _optWorkers = value; }
   else if (n == "eval_subtasks") { if (value < 0 || value > 8192) goto bad; _optEvalSubtasks = value; }
   else if (n == "eval_variant") { if (value < 0) goto bad; _optEvalVariant = value; }
@@ -374,6 +388,23 @@ int64_t HipEngine::GetOption(const char *name) const {
   if (n == "fused_sampled") return _optFusedSampled;
   if (n == "host_sampled") return _optHostSampled;
   if (n == "speculate") return _optSpeculate;
+  if (n == "combine") return _optCombine;
+  if (n == "combine_linger_us") return _optLingerUs;
+  if (n == "combined_batches") return (int64_t)_combBatches;        // sweeps that served more than one NextQuestion call ...
+  if (n == "combined_requests") return (int64_t)_combRequests;      // ... the calls they served ...
+  if (n == "combined_max_batch") return (int64_t)_combMaxBatch;     // ... and the largest of them
+  if (n == "update_flushes") return (int64_t)_flushes;              // launches that ran deferred RecordAnswers ...
+  if (n == "updates_flushed") return (int64_t)_flushedUpdates;      // ... the updates they ran ...
+  if (n == "update_max_flush") return (int64_t)_maxFlush;           // ... and the most in one launch
+  // where the combined sweeps' time went (ns, summed): waiting for the engine, launching, waiting for the device, waiting for
+  // the engine again, selecting on the host
+  if (n == "combined_ns_lock") return (int64_t)_combNs[0];
+  if (n == "combined_ns_launch") return (int64_t)_combNs[1];
+  if (n == "combined_ns_device") return (int64_t)_combNs[2];
+  if (n == "combined_ns_relock") return (int64_t)_combNs[3];
+  if (n == "combined_ns_select") return (int64_t)_combNs[4];
+  if (n == "combined_ns_selmu") return (int64_t)_combNs[5];
+  if (n == "combined_ns_readers") return (int64_t)_combNs[6];
   if (n == "spec_hits") return (int64_t)_specHits;         // speculative sweeps a NextQuestion used ...
   if (n == "spec_dropped") return (int64_t)_specDropped;   // ... and those nothing used
   if (n == "batch_min") return _optBatchMin;
@@ -436,10 +467,32 @@ Quiz *HipEngine::UseQuiz(Error &err, int64_t iQuiz) {
   return _quizzes[iQuiz];
 }
 
+QuizPinned *HipEngine::TakePin() {
+  if (_pinFree.empty()) {
+    QuizPinned *slab = nullptr;
+    if (hipHostMalloc((void **)&slab, kPinSlab * sizeof(QuizPinned), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) {
+      (void)hipGetLastError();
+      return nullptr;
+    }
+    std::memset(slab, 0, kPinSlab * sizeof(QuizPinned));
+    _pinSlabs.push_back(slab);
+    for (int i = kPinSlab - 1; i >= 0; i--) _pinFree.push_back(slab + i);
+  }
+  QuizPinned *p = _pinFree.back();
+  _pinFree.pop_back();
+  return p;
+}
+
 void HipEngine::DestroyQuiz(Quiz *q) {
   ServerQuiesce();
   if (!q) return;
-  if (_topOwner == q) _topOwner = nullptr;
+  while (q->inSelection.load(std::memory_order_acquire)) _mm_pause();   // (a NextQuestion of this quiz is selecting on another thread: a client's error, waited out)
+  if (q->updatePending) (void)FlushUpdates();   // (its kernel works on the buffers that go back to the pool)
+  if (q->pin != nullptr) {
+    if (_pendingRecordFlag == &q->pin->topFlag) { _pendingRecordOp = 0; _pendingRecordFlag = nullptr; _mu.busy = true; }
+    _pinFree.push_back(q->pin);
+    q->pin = nullptr;
+  }
   if (_spec.quiz == q) DropSpeculation();
   {
     auto it = _graphs.find(q);
@@ -471,7 +524,16 @@ int64_t HipEngine::CreateQuiz(Error &err, int64_t nAnswered, const AQ *pAQs, con
   if (!err.ok()) return -1;
   hipSetDevice(_device);
   std::unique_ptr<Quiz> quiz(new Quiz());
-  auto fail = [&](Error e) { err = std::move(e); hipFree(quiz->dPrior); hipFree(quiz->dAsked); return (int64_t)-1; };
+  auto fail = [&](Error e) {
+    err = std::move(e);
+    hipFree(quiz->dPrior);
+    hipFree(quiz->dAsked);
+    if (quiz->pin) _pinFree.push_back(quiz->pin);
+    return (int64_t)-1;
+  };
+  quiz->serial = ++_quizSerial;
+  quiz->pin = TakePin();
+  if (quiz->pin == nullptr) return fail(HipErr(hipErrorOutOfMemory, "quiz result lines"));
   quiz->hAsked.assign(BitWords(_Q), 0);
   // validate the answered questions and set their "asked" bits (reference PqaCore/CpuEngine.cpp:216-233)
   bool allLocal = true;
@@ -559,6 +621,7 @@ int64_t HipEngine::CreateQuiz(Error &err, int64_t nAnswered, const AQ *pAQs, con
 }
 
 int64_t HipEngine::StartQuiz(Error &err) {
+  CallScope scope(_activeCallers);
   std::lock_guard<EngineMutex> lk(_mu);
   return SpeculateFor(CreateQuiz(err, 0, nullptr, nullptr, nullptr, 0, nullptr));
 }
@@ -578,6 +641,7 @@ int64_t HipEngine::ResumeQuiz(Error &err, int64_t nAnswered, const AQ *pAQs) {
     err = Error::Make(ErrCode::NullArgument, "Nullptr is passed in place of answered questions.");
     return -1;
   }
+  CallScope scope(_activeCallers);
   std::lock_guard<EngineMutex> lk(_mu);
   return SpeculateFor(CreateQuiz(err, nAnswered, pAQs, nullptr, nullptr, 0, nullptr));  // nAnswered == 0 -> StartQuiz (BaseEngine.cpp:393-395)
 }
@@ -614,6 +678,7 @@ Error HipEngine::AdoptPrior(int64_t iQuiz, const double *srcPrior, int srcDevice
   if (!q) return err;
   hipSetDevice(_device);
   ServerQuiesce();
+  { Error fe = FlushUpdates(); if (!fe.ok()) return fe; }
   if (ready != nullptr) HIP_TRY(hipStreamWaitEvent(_stream, ready, 0));
   HIP_TRY(hipMemcpyPeerAsync(q->dPrior, _device, srcPrior, srcDevice, (size_t)_ldT * sizeof(double), _stream));
   q->priorVersion++;
@@ -630,6 +695,7 @@ Error HipEngine::QuestionState(int64_t iQuiz, int64_t qGlobal, bool *pUnavailabl
 }
 
 Error HipEngine::ReleaseQuiz(int64_t iQuiz) {
+  CallScope scope(_activeCallers);
   std::lock_guard<EngineMutex> lk(_mu);
   Error err = CheckRegular("release quiz");
   if (!err.ok()) return err;
@@ -857,6 +923,33 @@ Error HipEngine::CollectHostPriority(uint64_t tag, const Quiz *q) {
   return Error();
 }
 
+// The same wait for MANY client threads at once (ListTopTargets while other clients are inside the engine): each waits for its own
+// quiz's flag, typically behind a combined sweep of a few hundred microseconds -- spinning all the while, dozens of them eat the
+// cores the process is allowed.  A short spin (the kernel may be about to finish), then naps of ~20 us.
+Error HipEngine::WaitFlagNapping(volatile uint64_t *flag, uint64_t value, const char *what) {
+  for (int spins = 0; spins < 2000; spins++) {
+    if (*flag == value) { std::atomic_thread_fence(std::memory_order_acquire); return Error(); }
+    _mm_pause();
+  }
+  static thread_local bool slackSet = false;
+  if (!slackSet) { prctl(PR_SET_TIMERSLACK, 2000UL, 0, 0, 0); slackSet = true; }   // (the default slack rounds a 20 us nap up to 70)
+  const auto t0 = std::chrono::steady_clock::now();
+  uint64_t naps = 0;
+  while (*flag != value) {
+    struct timespec ts{0, 20000};
+    nanosleep(&ts, nullptr);
+    if ((++naps & 0x3FF) == 0) {
+      if (hipStreamQuery(_stream) == hipSuccess && *flag != value) {  // the kernel retired without publishing
+        const hipError_t he = hipStreamSynchronize(_stream);
+        if (he != hipSuccess || *flag != value) return HipErr(he == hipSuccess ? hipErrorUnknown : he, what);
+      }
+      if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(30)) return HipErr(hipErrorNotReady, what);
+    }
+  }
+  std::atomic_thread_fence(std::memory_order_acquire);
+  return Error();
+}
+
 Error HipEngine::WaitFlag(volatile uint64_t *flag, uint64_t value, const char *what) {
   const auto t0 = std::chrono::steady_clock::now();
   uint64_t spins = 0;
@@ -873,13 +966,17 @@ Error HipEngine::WaitFlag(volatile uint64_t *flag, uint64_t value, const char *w
   return Error();
 }
 
-int64_t HipEngine::NextQuestionArgmax(Error &err, int64_t iQuiz) {
-  std::lock_guard<EngineMutex> lk(_mu);
+int64_t HipEngine::NextQuestionArgmax(Error &err, int64_t iQuiz) { return Combine(err, iQuiz, 0, 0); }
+
+// One quiz, by itself (the caller holds _mu)
+int64_t HipEngine::NextQuestionArgmaxLocked(Error &err, int64_t iQuiz) {
   err = CheckRegular("compute next question");
   if (!err.ok()) return -1;
   Quiz *q = UseQuiz(err, iQuiz);
   if (!q) return -1;
   hipSetDevice(_device);
+  err = FlushUpdates();
+  if (!err.ok()) return -1;
   if (_optUseGraph && _elem == 8) return NextQuestionArgmaxGraph(err, q);
   if (_optServer && ServerUsable()) {
     // resident sweep: post the request, poll the answer -- no launch on the critical path
@@ -919,6 +1016,7 @@ int64_t HipEngine::NextQuestionArgmax(Error &err, int64_t iQuiz) {
 bool HipEngine::ServerUsable() const { return _elem == 8 && EvalServerSupported(View(), (int)_optEvalVariant) && _Q > 0; }
 
 void HipEngine::StopServer() {
+  (void)FlushUpdates();   // whoever stops the resident sweep is about to read or change what the deferred updates read or write
   DropSpeculation();   // whatever ends the resident sweep's view of the engine (cube, gaps, stream, buffers) ends a speculative result's too
   if (!_serverLaunched) return;
   hipSetDevice(_device);
@@ -957,8 +1055,8 @@ Error HipEngine::ServerWait(volatile uint64_t *flag, uint64_t value, const char 
 // `flag` (host-coherent memory).  Starts the kernel if none is resident.
 Error HipEngine::ServerPost(Quiz *q, SelectResult *out, uint64_t *flag, uint64_t flagValue, int64_t outBase) {
   // the resident kernel is not ordered behind the engine's stream: wait for what that stream still runs
-  if (_pendingRecordOp != 0 && !_mu.wasBusy) {
-    Error e = WaitFlag(&_hPinned->topFlag, _pendingRecordOp, "ServerPost");
+  if (_pendingRecordOp != 0 && _pendingRecordFlag != nullptr && !_mu.wasBusy) {
+    Error e = WaitFlag(_pendingRecordFlag, _pendingRecordOp, "ServerPost");
     if (!e.ok()) return e;
   } else if (_mu.wasBusy) {
     HIP_TRY(hipStreamSynchronize(_stream));
@@ -1054,13 +1152,14 @@ Error HipEngine::ServerPost(Quiz *q, SelectResult *out, uint64_t *flag, uint64_t
 //   * the row-sharing sweep (batch_kernels.hip; batches of at least `batch_min` quizzes, and every batch of a Float engine):
 //     a lane is a quiz, the cube tile staged in LDS serves all quizzes of the batch -- the cube is read once per batch;
 //   * grid.y = quiz over the single-quiz kernel (small batches of Double engines): one launch, but one cube read per quiz.
-Error HipEngine::BatchSweep(int64_t n, const int64_t *pQuizzes, std::vector<Quiz *> &quizzes, bool wantPriorities, uint64_t tag) {
-  if (!_hBatch) {  // first batch: staging in host-coherent pinned memory, winner records
-    HIP_TRY(hipHostMalloc(&_hBatch, sizeof(BatchPinned), hipHostMallocMapped | hipHostMallocCoherent));
-    std::memset(_hBatch, 0, sizeof(BatchPinned));
-    HIP_TRY(hipMalloc(&_dBatchSlots, kMaxBatch * sizeof(QuizSlot)));
-    HIP_TRY(hipMalloc(&_dBatchScratch, (size_t)kMaxBatch * kBatchGrid * sizeof(SelectResult)));
-    HIP_TRY(hipMemset(_dBatchScratch, 0, (size_t)kMaxBatch * kBatchGrid * sizeof(SelectResult)));
+Error HipEngine::BatchSweep(BatchCtx &c, int64_t n, const int64_t *pQuizzes, std::vector<Quiz *> &quizzes, bool wantPriorities, uint64_t tag,
+                            bool hostPriorities, bool *pQuizMinor) {
+  if (!c.h) {  // first batch: staging in host-coherent pinned memory, winner records
+    HIP_TRY(hipHostMalloc(&c.h, sizeof(BatchPinned), hipHostMallocMapped | hipHostMallocCoherent));
+    std::memset(c.h, 0, sizeof(BatchPinned));
+    HIP_TRY(hipMalloc(&c.dSlots, kMaxBatch * sizeof(QuizSlot)));
+    HIP_TRY(hipMalloc(&c.dScratch, (size_t)kMaxBatch * kBatchGrid * sizeof(SelectResult)));
+    HIP_TRY(hipMemset(c.dScratch, 0, (size_t)kMaxBatch * kBatchGrid * sizeof(SelectResult)));
   }
   // Which form: the row-sharing sweep has one wave per 64 quizzes and block of questions -- on a small cube a small batch
   // leaves most of the chip's 1024 SIMDs without a wave (1000 x 5 x 1000, 64 quizzes: 500 waves, 40 k selections/s against
@@ -1068,12 +1167,31 @@ Error HipEngine::BatchSweep(int64_t n, const int64_t *pQuizzes, std::vector<Quiz
   // batch_min = 0 (default) decides by the wave count; an explicit value decides by the batch size alone.
   const int64_t qb = _optBatchQb > 0 ? _optBatchQb : (_elem == 4 ? 4 : 2), wavesRowSharing = ((n + 63) / 64) * ((_Q + qb - 1) / qb);
   const bool rowSharing = _elem == 4 || wantPriorities || (_optBatchMin > 0 ? n >= _optBatchMin : (n >= 32 && wavesRowSharing >= 1536));
-  if (!rowSharing && _batchPriorityQ != _Q) {  // per-quiz priority vectors of the grid.y form, (re)sized with the knowledge base
-    if (_dBatchPriority) hipFree(_dBatchPriority);
-    _dBatchPriority = nullptr;
-    _batchPriorityQ = -1;
-    HIP_TRY(hipMalloc(&_dBatchPriority, (size_t)kMaxBatch * (size_t)_Q * sizeof(double)));
-    _batchPriorityQ = _Q;
+  if (hostPriorities) {
+    wantPriorities = rowSharing;   // (the row-sharing sweep keeps its priority matrix; grid.y = quiz writes per-quiz vectors anyway)
+    if (pQuizMinor) *pQuizMinor = rowSharing;
+    if (!c.event) HIP_TRY(hipEventCreateWithFlags(&c.event, hipEventDisableTiming));
+  }
+  auto copyToHost = [&](const double *src, size_t doubles) -> Error {
+    if (c.readers.load(std::memory_order_acquire) != 0)   // (ServeQueue has waited for them before it took the lock they need)
+      return Error::Make(ErrCode::Internal, "A priority buffer is still being read.");
+    if (doubles > c.hPriDoubles) {
+      HIP_TRY(hipStreamSynchronize(_stream));   // (nothing of an earlier batch is on its way into the old buffer)
+      if (c.hPri) hipHostFree(c.hPri);
+      c.hPri = nullptr;
+      c.hPriDoubles = 0;
+      HIP_TRY(hipHostMalloc((void **)&c.hPri, doubles * sizeof(double), hipHostMallocDefault));
+      c.hPriDoubles = doubles;
+    }
+    HIP_TRY(hipMemcpyAsync(c.hPri, src, doubles * sizeof(double), hipMemcpyDeviceToHost, _stream));
+    return Error();
+  };
+  if (!rowSharing && c.priorityQ != _Q) {  // per-quiz priority vectors of the grid.y form, (re)sized with the knowledge base
+    if (c.dPriority) hipFree(c.dPriority);
+    c.dPriority = nullptr;
+    c.priorityQ = -1;
+    HIP_TRY(hipMalloc(&c.dPriority, (size_t)kMaxBatch * (size_t)_Q * sizeof(double)));
+    c.priorityQ = _Q;
   }
   Error err;
   quizzes.assign((size_t)n, nullptr);
@@ -1083,21 +1201,22 @@ Error HipEngine::BatchSweep(int64_t n, const int64_t *pQuizzes, std::vector<Quiz
     for (int64_t j = 0; j < i; j++)
       if (pQuizzes[j] == pQuizzes[i])
         return Error::MakeP(ErrCode::IndexOutOfRange, "quizId=" + std::to_string(pQuizzes[i]), "A quiz appears twice in one batch.");
-    _hBatch->slots[i] = QuizSlot{quizzes[i]->dPrior, quizzes[i]->dAsked, rowSharing ? nullptr : _dBatchPriority + (size_t)i * (size_t)_Q,
-                                 &_hBatch->out[i], &_hBatch->seq[i]};
+    c.h->slots[i] = QuizSlot{quizzes[i]->dPrior, quizzes[i]->dAsked, rowSharing ? nullptr : c.dPriority + (size_t)i * (size_t)_Q,
+                                 &c.h->out[i], &c.h->seq[i]};
   }
-  HIP_TRY(hipMemcpyAsync(_dBatchSlots, _hBatch->slots, (size_t)n * sizeof(QuizSlot), hipMemcpyHostToDevice, _stream));
+  HIP_TRY(hipMemcpyAsync(c.dSlots, c.h->slots, (size_t)n * sizeof(QuizSlot), hipMemcpyHostToDevice, _stream));
   StopServer();   // a launched sweep has no room beside the resident one and would wait for it to idle out
   if (!rowSharing) {
-    const FusedSelect fs{_dBatchScratch, nullptr, nullptr, tag, 0, kBatchGrid, tag, nullptr, 0, 0, nullptr, nullptr};
-    HIP_TRY(LaunchEvalQuestionsBatch(View(), _dBatchSlots, (int)n, 0, _Q, (int)_optEvalVariant, fs, _stream));
+    const FusedSelect fs{c.dScratch, nullptr, nullptr, tag, 0, kBatchGrid, tag, nullptr, 0, 0, nullptr, nullptr};
+    HIP_TRY(LaunchEvalQuestionsBatch(View(), c.dSlots, (int)n, 0, _Q, (int)_optEvalVariant, fs, _stream));
+    if (hostPriorities) return copyToHost(c.dPriority, (size_t)n * (size_t)_Q);
     return Error();
   }
   const KbView kb = View();
   BatchPlan plan{};
   plan.tileTargets = (int)_optBatchTile;
   plan.questionsPerBlock = (int)_optBatchQb;
-  HIP_TRY(LaunchEvalBatch(kb, _dBatchSlots, (int)n, &plan, nullptr, nullptr, nullptr, nullptr, 0, tag, true, _stream));
+  HIP_TRY(LaunchEvalBatch(kb, c.dSlots, (int)n, &plan, nullptr, nullptr, nullptr, nullptr, 0, tag, true, _stream));
   auto grow = [&](void **p, size_t &have, size_t need) -> hipError_t {
     if (need <= have) return hipSuccess;
     hipStreamSynchronize(_stream);
@@ -1108,13 +1227,14 @@ Error HipEngine::BatchSweep(int64_t n, const int64_t *pQuizzes, std::vector<Quiz
     if (e == hipSuccess) have = need;
     return e;
   };
-  HIP_TRY(grow(&_dBatchPT, _batchPTBytes, plan.ptBytes));
-  HIP_TRY(grow((void **)&_dBatchAcc, _batchAccBytes, plan.accBytes));
-  HIP_TRY(grow((void **)&_dBatchRecs, _batchRecBytes, plan.recBytes));
-  if (wantPriorities) HIP_TRY(grow((void **)&_dBatchPriT, _batchPriTBytes, (size_t)_Q * (size_t)plan.Bp * sizeof(double)));
-  HIP_TRY(LaunchEvalBatch(kb, _dBatchSlots, (int)n, &plan, _dBatchPT, _dBatchAcc, _dBatchRecs, wantPriorities ? _dBatchPriT : nullptr, 0, tag,
+  HIP_TRY(grow(&c.dPT, c.ptBytes, plan.ptBytes));
+  HIP_TRY(grow((void **)&c.dAcc, c.accBytes, plan.accBytes));
+  HIP_TRY(grow((void **)&c.dRecs, c.recBytes, plan.recBytes));
+  if (wantPriorities) HIP_TRY(grow((void **)&c.dPriT, c.priTBytes, (size_t)_Q * (size_t)plan.Bp * sizeof(double)));
+  HIP_TRY(LaunchEvalBatch(kb, c.dSlots, (int)n, &plan, c.dPT, c.dAcc, c.dRecs, wantPriorities ? c.dPriT : nullptr, 0, tag,
                           false, _stream));
-  _lastBatchBp = plan.Bp;
+  c.lastBp = plan.Bp;
+  if (hostPriorities) return copyToHost(c.dPriT, (size_t)_Q * (size_t)plan.Bp);
   return Error();
 }
 
@@ -1130,8 +1250,10 @@ Error HipEngine::EnqueueBatchLocked(int64_t n, const int64_t *pQuizzes, bool wan
   if (n == 0) return Error();
   if (!pQuizzes) return Error::Make(ErrCode::NullArgument, "Nullptr is passed in place of a batch buffer.");
   hipSetDevice(_device);
+  err = FlushUpdates();
+  if (!err.ok()) return err;
   const uint64_t tag = NextLaunchTag();
-  err = BatchSweep(n, pQuizzes, _batchQuizzes, wantPriorities, tag);
+  err = BatchSweep(_ctx[0], n, pQuizzes, _batchQuizzes, wantPriorities, tag);
   if (!err.ok()) return err;
   *pTag = tag;
   return Error();
@@ -1141,12 +1263,13 @@ Error HipEngine::CollectBatchSelectionsLocked(int64_t n, uint64_t tag, CiHipSele
   if (n == 0) return Error();
   if (!pOut) return Error::Make(ErrCode::NullArgument, "Nullptr is passed in place of a batch buffer.");
   hipSetDevice(_device);
-  Error err = WaitBatchFlags(n, tag);
+  BatchCtx &c = _ctx[0];
+  Error err = WaitBatchFlags(c, n, tag);
   if (!err.ok()) return err;
   for (int64_t i = 0; i < n; i++) {
-    if (_hBatch->out[i].index == -3) return HipErr(hipErrorLaunchFailure, "batched selection (incomplete sweep)");
-    pOut[i]._priority = _hBatch->out[i].priority;
-    pOut[i]._iQuestion = _hBatch->out[i].index < 0 ? -1 : _hBatch->out[i].index + _qFirst;
+    if (c.h->out[i].index == -3) return HipErr(hipErrorLaunchFailure, "batched selection (incomplete sweep)");
+    pOut[i]._priority = c.h->out[i].priority;
+    pOut[i]._iQuestion = c.h->out[i].index < 0 ? -1 : c.h->out[i].index + _qFirst;
   }
   return Error();
 }
@@ -1171,15 +1294,17 @@ Error HipEngine::CollectBatchPrioritiesLocked(int64_t n, double *pOut) {
   if (n == 0) return Error();
   if (!pOut) return Error::Make(ErrCode::NullArgument, "Nullptr is passed in place of a batch buffer.");
   hipSetDevice(_device);
-  std::vector<double> host((size_t)_Q * (size_t)_lastBatchBp);
-  HIP_TRY(hipMemcpyAsync(host.data(), _dBatchPriT, host.size() * sizeof(double), hipMemcpyDeviceToHost, _stream));
+  BatchCtx &c = _ctx[0];
+  std::vector<double> host((size_t)_Q * (size_t)c.lastBp);
+  HIP_TRY(hipMemcpyAsync(host.data(), c.dPriT, host.size() * sizeof(double), hipMemcpyDeviceToHost, _stream));
   HIP_TRY(hipStreamSynchronize(_stream));
   for (int64_t i = 0; i < n; i++)
-    for (int64_t q = 0; q < _Q; q++) pOut[(size_t)i * (size_t)_Q + (size_t)q] = host[(size_t)q * (size_t)_lastBatchBp + (size_t)i];
+    for (int64_t q = 0; q < _Q; q++) pOut[(size_t)i * (size_t)_Q + (size_t)q] = host[(size_t)q * (size_t)c.lastBp + (size_t)i];
   return Error();
 }
 
 Error HipEngine::NextQuestionArgmaxBatch(int64_t n, const int64_t *pQuizzes, int64_t *pOut) {
+  std::lock_guard<std::mutex> selLk(_ctx[0].mu);   // (this context's staging buffers: not while a leader's combined sweep uses them)
   std::lock_guard<EngineMutex> lk(_mu);
   if (n > 0 && !pOut) return Error::Make(ErrCode::NullArgument, "Nullptr is passed in place of a batch buffer.");
   uint64_t tag = 0;
@@ -1199,6 +1324,7 @@ Error HipEngine::NextQuestionArgmaxBatch(int64_t n, const int64_t *pQuizzes, int
 // pQuizzes[i] over this engine's questions -- what a host that shards the question axis exchanges between the shards before it
 // sets the active questions (PqaEngine_SetActiveQuestion).
 Error HipEngine::SelectArgmaxBatch(int64_t n, const int64_t *pQuizzes, CiHipSelection *pOut) {
+  std::lock_guard<std::mutex> selLk(_ctx[0].mu);   // (this context's staging buffers: not while a leader's combined sweep uses them)
   std::lock_guard<EngineMutex> lk(_mu);
   if (n > 0 && !pOut) return Error::Make(ErrCode::NullArgument, "Nullptr is passed in place of a batch buffer.");
   uint64_t tag = 0;
@@ -1207,10 +1333,10 @@ Error HipEngine::SelectArgmaxBatch(int64_t n, const int64_t *pQuizzes, CiHipSele
   return CollectBatchSelectionsLocked(n, tag, pOut);
 }
 
-Error HipEngine::WaitBatchFlags(int64_t n, uint64_t tag) {
+Error HipEngine::WaitBatchFlags(BatchCtx &c, int64_t n, uint64_t tag) {
   const auto t0 = std::chrono::steady_clock::now();
   for (int64_t i = 0; i < n; i++) {
-    volatile uint64_t *flag = &_hBatch->seq[i];
+    volatile uint64_t *flag = &c.h->seq[i];
     uint64_t spins = 0;
     while (*flag != tag) {
       if ((++spins & 0xFFF) == 0) {
@@ -1230,6 +1356,7 @@ Error HipEngine::WaitBatchFlags(int64_t n, uint64_t tag) {
 // The priority vectors of n quizzes from ONE row-sharing sweep: pOut[i * Q + q] = priority of local question q for quiz
 // pQuizzes[i] (0 for gap / asked questions).  The deterministic output of the batched path, for parity checks.
 Error HipEngine::EvalPrioritiesBatch(int64_t n, const int64_t *pQuizzes, double *pOut) {
+  std::lock_guard<std::mutex> selLk(_ctx[0].mu);   // (this context's staging buffers: not while a leader's combined sweep uses them)
   std::lock_guard<EngineMutex> lk(_mu);
   if (n > 0 && !pOut) return Error::Make(ErrCode::NullArgument, "Nullptr is passed in place of a batch buffer.");
   uint64_t tag = 0;
@@ -1284,13 +1411,16 @@ int64_t HipEngine::NextQuestionArgmaxGraph(Error &err, Quiz *q) {
   return FinishSelection(err, q, _hPinned->sel.index);
 }
 
-int64_t HipEngine::NextQuestionSampled(Error &err, int64_t iQuiz, uint64_t rnd) {
-  std::lock_guard<EngineMutex> lk(_mu);
+int64_t HipEngine::NextQuestionSampled(Error &err, int64_t iQuiz, uint64_t rnd) { return Combine(err, iQuiz, 1, rnd); }
+
+int64_t HipEngine::NextQuestionSampledLocked(Error &err, int64_t iQuiz, uint64_t rnd) {
   err = CheckRegular("compute next question");
   if (!err.ok()) return -1;
   Quiz *q = UseQuiz(err, iQuiz);
   if (!q) return -1;
   hipSetDevice(_device);
+  err = FlushUpdates();
+  if (!err.ok()) return -1;
   const KbView kb = View();
   const int64_t nSub = _optEvalSubtasks ? _optEvalSubtasks : 8 * _optWorkers;  // reference PqaCore/CpuEngine.cpp:339
   if (_optServer && _optHostSampled && !_optFusedSampled && ServerUsable()) {
@@ -1357,10 +1487,275 @@ int64_t HipEngine::NextQuestionSampled(Error &err, int64_t iQuiz, uint64_t rnd) 
 }
 
 int64_t HipEngine::NextQuestion(Error &err, int64_t iQuiz) {
-  if (_optSelect == 1) return NextQuestionArgmax(err, iQuiz);
+  if (_optSelect == 1) return Combine(err, iQuiz, 0, 0);
   uint64_t rnd;
-  { std::lock_guard<EngineMutex> lk(_mu); rnd = NextRandom(); }
-  return NextQuestionSampled(err, iQuiz, rnd);
+  { std::lock_guard<std::mutex> lk(_rngMu); rnd = NextRandom(); }   // (drawn when the call arrives, whatever sweep serves it)
+  return Combine(err, iQuiz, 1, rnd);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// concurrent NextQuestion calls (see SelRequest in hip_engine.h)
+// ------------------------------------------------------------------------------------------------------------------
+int64_t HipEngine::Combine(Error &err, int64_t iQuiz, int kind, uint64_t rnd) {
+  CallScope scope(_activeCallers);
+  if (!_optCombine) {
+    std::lock_guard<EngineMutex> lk(_mu);
+    return kind == 0 ? NextQuestionArgmaxLocked(err, iQuiz) : NextQuestionSampledLocked(err, iQuiz, rnd);
+  }
+  SelRequest r;
+  r.iQuiz = iQuiz; r.kind = kind; r.rnd = rnd;
+  bool lead;
+  {
+    std::lock_guard<std::mutex> lk(_combMu);
+    _combQueue.push_back(&r);
+    lead = !_leaderActive;
+    if (lead) _leaderActive = true;
+  }
+  if (!lead) {
+    // (a combined sweep takes a fraction of a millisecond, and a thread woken through the kernel arrives tens of
+    //  microseconds after its neighbours; but dozens of spinning client threads eat the cores the process is allowed:
+    //  a short spin, then sleep)
+    int st = 0;
+    for (int spins = 0; spins < 1500 && (st = r.state.load(std::memory_order_acquire)) == 0; spins++) _mm_pause();
+    if (st == 0) {
+      std::unique_lock<std::mutex> lk(_combMu);
+      _combCv.wait(lk, [&] { return r.state.load(std::memory_order_acquire) != 0; });
+      st = r.state.load(std::memory_order_acquire);
+    }
+    if (st == 1) { err = r.err; return r.result; }
+    if (st == 3) {   // the sweep has run: this quiz's priorities are on the host, the selection is this thread's own work
+      const int64_t sel = SelectFromPriorities(&r);
+      r.ctx->readers.fetch_sub(1, std::memory_order_release);
+      err = r.err;
+      return sel;
+    }
+    // (2: the leader before served its own batch and handed the lead to this, the oldest waiting request)
+  }
+  ServeQueue(&r);
+  err = r.err;
+  return r.result;
+}
+
+// One request of a combined sweep, after the sweep: this quiz's priority vector out of the batch's matrix, then the selector (as
+// the single-quiz path's host_sampled form: SelectSampledHost; the argmax by the device's rule: maximum, lowest index on ties,
+// NaN never wins), then NextQuestion's bookkeeping under the engine's lock.
+int64_t HipEngine::SelectFromPriorities(SelRequest *r) {
+  // No engine lock: the priorities are the sweep's, the asked / gap bits the leader's snapshot of the moment it launched the
+  // sweep (what the kernel saw), the quiz object is held by inSelection, and the two things written -- the quiz's active
+  // question, the asked-questions counter -- are this quiz's own or atomic.
+  Quiz *q = r->quiz;
+  const int64_t nQ = r->nQ;
+  auto skip = [&](int64_t k) { return BitTest(r->unavailable, k); };
+  std::vector<double> run((size_t)nQ);
+  for (int64_t k = 0; k < nQ; k++) run[(size_t)k] = skip(k) ? 0.0 : r->pri[(size_t)k * (size_t)r->priStride];
+  int64_t pick = -1;
+  if (r->kind == 1) {
+    pick = SelectSampledHost(run.data(), nQ, r->nSub, r->rnd, skip);
+  } else {
+    double best = 0;
+    for (int64_t k = 0; k < nQ; k++) {
+      if (skip(k)) continue;
+      double p = run[(size_t)k];
+      if (p != p) p = -HUGE_VAL;
+      if (pick < 0 || p > best) { best = p; pick = k; }
+    }
+  }
+  // reference PqaCore/CpuEngine.cpp:403-413 (FinishSelection, over the snapshot)
+  if (pick >= 0 && skip(pick)) pick = FindNearestInPacks(pick, nQ, [&](int64_t p) { return ~Pack64(r->unavailable, p); });
+  if (pick < 0) {
+    r->err = Error::Make(ErrCode::QuestionsExhausted, "Found no unasked question that is not in a gap.");
+    r->result = -1;
+  } else {
+    q->activeQuestion = _qFirst + pick;
+    _nQuestionsAsked.fetch_add(1, std::memory_order_relaxed);
+    r->result = q->activeQuestion;
+  }
+  q->inSelection.store(false, std::memory_order_release);
+  return r->result;
+}
+
+// The leader's turn: ONE batch -- everything posted so far, distinct quizzes, `own` among them (it is the oldest request).  The
+// lead goes on to the oldest request still waiting (or is given up) as soon as the batch's sweep is LAUNCHED: the next leader
+// gathers and launches the next sweep -- into the other of the two batch contexts -- while this one's runs, so that the device
+// finds the next sweep queued when it finishes this one.
+void HipEngine::ServeQueue(SelRequest *own) {
+  // The clients whose RecordAnswers ran since the last combined sweep are on their way here (their ListTopTargets have just
+  // returned): a leader that starts at once sweeps for the two or three that were quickest and makes the rest wait for a
+  // second sweep.  So it waits -- microseconds -- until most of them have posted, or nobody new comes.
+  // While the previous leader's sweep still runs there is no hurry at all: a sweep launched now only queues behind it, so the
+  // requests that arrive until it is (nearly) done ride along for free.
+  if (_optLingerUs > 0 && Concurrent()) {   // (alone in the engine: nobody to wait for)
+    const int64_t expect = std::min<int64_t>(_flushedSinceSweep.load(std::memory_order_relaxed), _activeCallers.load(std::memory_order_relaxed) - 1);
+    const BatchCtx &other = _ctx[_ctxNext ^ 1];
+    const auto t0 = std::chrono::steady_clock::now();
+    const auto limit = std::chrono::microseconds(_optLingerUs), limitBusy = std::chrono::microseconds(8 * _optLingerUs);
+    for (;;) {
+      size_t have;
+      { std::lock_guard<std::mutex> lk(_combMu); have = _combQueue.size(); }
+      const bool busy = other.inFlight.load(std::memory_order_relaxed);
+      if (!busy && (expect <= 1 || (int64_t)have * 5 >= expect * 4)) break;
+      if (busy && (int64_t)have >= _activeCallers.load(std::memory_order_relaxed) - 1) break;   // (everybody is here)
+      for (int i = 0; i < 32; i++) _mm_pause();
+      if (std::chrono::steady_clock::now() - t0 > (busy ? limitBusy : limit)) break;
+    }
+  }
+  // this batch's context: its previous sweep has been collected, and the clients that were selecting out of its priority
+  // buffer -- they need no lock for that -- are done (normally long ago)
+  BatchCtx &c = _ctx[_ctxNext];
+  _ctxNext ^= 1;
+  const auto tA = std::chrono::steady_clock::now();
+  std::unique_lock<std::mutex> ctxLock(c.mu);
+  while (c.readers.load(std::memory_order_acquire) != 0) _mm_pause();
+  std::vector<SelRequest *> batch;
+  {
+    std::lock_guard<std::mutex> lk(_combMu);
+    std::vector<SelRequest *> rest;
+    for (SelRequest *r : _combQueue) {
+      bool take = (int64_t)batch.size() < kMaxBatch;
+      for (size_t i = 0; take && i < batch.size(); i++) take = batch[i]->iQuiz != r->iQuiz;   // a quiz once per sweep
+      (take ? batch : rest).push_back(r);
+    }
+    _combQueue.swap(rest);
+  }
+  Flight f;
+  f.tA = tA;
+  LaunchBatch(c, batch, f);   // (under the engine's lock; what could not be launched has its error -- or its result, for a batch of one)
+  {
+    std::lock_guard<std::mutex> lk(_combMu);
+    if (_combQueue.empty()) _leaderActive = false;
+    else _combQueue.front()->state.store(2, std::memory_order_release);
+  }
+  _combCv.notify_all();
+  const bool ownSelects = f.live.empty() ? false : CollectBatch(c, batch, f, own);
+  ctxLock.unlock();
+  for (SelRequest *r : batch)
+    if (r != nullptr && r != own) r->state.store(1, std::memory_order_release);   // (r is its caller's again from here on)
+  { std::lock_guard<std::mutex> g(_combMu); }   // (a sleeper that has just found its state 0 is inside wait() by now)
+  _combCv.notify_all();
+  if (ownSelects) {
+    SelectFromPriorities(own);
+    c.readers.fetch_sub(1, std::memory_order_release);
+  }
+}
+
+// Validate and launch (the caller holds the context; the engine's lock is taken and released here).  f.live: the requests whose
+// sweep is in flight; every other request of `batch` has its result or error.
+void HipEngine::LaunchBatch(BatchCtx &c, std::vector<SelRequest *> &batch, Flight &f) {
+  auto single = [&](SelRequest *r) {
+    r->result = r->kind == 0 ? NextQuestionArgmaxLocked(r->err, r->iQuiz) : NextQuestionSampledLocked(r->err, r->iQuiz, r->rnd);
+  };
+  std::lock_guard<EngineMutex> lk(_mu);
+  f.tB = std::chrono::steady_clock::now();
+  if (batch.size() == 1) { _flushedSinceSweep.store(0, std::memory_order_relaxed); single(batch[0]); return; }
+  auto failAll = [&](const Error &e) { for (SelRequest *r : batch) { r->err = e; r->result = -1; } };
+  Error err = CheckRegular("compute next question");
+  if (!err.ok()) { failAll(err); return; }
+  hipSetDevice(_device);
+  err = FlushUpdates();
+  if (!err.ok()) { failAll(err); return; }
+  std::vector<SelRequest *> live;
+  std::vector<int64_t> ids;
+  for (SelRequest *r : batch) {
+    Error qe;
+    if (UseQuiz(qe, r->iQuiz) == nullptr) { r->err = qe; r->result = -1; continue; }
+    live.push_back(r);
+    ids.push_back(r->iQuiz);
+    f.anySampled = f.anySampled || r->kind == 1;
+  }
+  if (live.empty()) return;
+  if (live.size() == 1 || (_optServer && ServerUsable()) || _optUseGraph) {   // (the resident sweep and graph replay serve one quiz at a time)
+    for (SelRequest *r : live) single(r);
+    return;
+  }
+  const int64_t n = (int64_t)live.size();
+  f.tag = NextLaunchTag();
+  std::vector<Quiz *> quizzes;
+  err = BatchSweep(c, n, ids.data(), quizzes, false, f.tag, f.anySampled, &f.quizMinor);
+  if (!err.ok()) { for (SelRequest *r : live) { r->err = err; r->result = -1; } return; }
+  const int64_t nSubtasks = _optEvalSubtasks ? _optEvalSubtasks : 8 * _optWorkers;  // reference PqaCore/CpuEngine.cpp:339
+  for (int64_t i = 0; i < n; i++) {
+    SelRequest *r = live[(size_t)i];
+    Quiz *q = quizzes[(size_t)i];
+    r->serial = q->serial;
+    if (!f.anySampled) continue;
+    // what the client needs to select for itself once the priorities are on the host: the quiz (held), the asked questions and
+    // gaps as the sweep sees them
+    r->quiz = q;
+    q->inSelection.store(true, std::memory_order_relaxed);
+    r->nQ = _Q;
+    r->nSub = nSubtasks;
+    r->unavailable.resize(_hQGap.size());
+    for (size_t w = 0; w < r->unavailable.size(); w++) r->unavailable[w] = _hQGap[w] | q->hAsked[w];
+  }
+  f.Bp = c.lastBp;
+  f.nQ = _Q;
+  if (f.anySampled) f.he = hipEventRecord(c.event, _stream);
+  _combBatches++;
+  _combRequests += (uint64_t)n;
+  if ((uint64_t)n > _combMaxBatch) _combMaxBatch = (uint64_t)n;
+  _lastCombined.store(n, std::memory_order_relaxed);
+  _flushedSinceSweep.store(0, std::memory_order_relaxed);
+  f.live.swap(live);
+  c.inFlight.store(true, std::memory_order_relaxed);
+  f.tC = std::chrono::steady_clock::now();
+}
+
+// Wait for the sweep and hand the results out -- the engine open to the other clients' calls meanwhile (RecordAnswer,
+// ListTopTargets, StartQuiz ... and the next leader's launch).  Returns true if `own` is to select for itself.
+bool HipEngine::CollectBatch(BatchCtx &c, std::vector<SelRequest *> &batch, Flight &f, SelRequest *own) {
+  const int64_t n = (int64_t)f.live.size();
+  Error err;
+  hipError_t he = f.he;
+  if (he == hipSuccess && f.anySampled) he = hipEventSynchronize(c.event);
+  if (he == hipSuccess && !f.anySampled) err = WaitBatchFlags(c, n, f.tag);
+  c.inFlight.store(false, std::memory_order_relaxed);
+  const auto tD = std::chrono::steady_clock::now();
+  auto ns = [](auto a, auto b) { return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(b - a).count(); };
+  if (he != hipSuccess) err = HipErr(he, "combined selection");
+  if (!err.ok()) {
+    for (SelRequest *r : f.live) {
+      r->err = err;
+      r->result = -1;
+      if (r->quiz) r->quiz->inSelection.store(false, std::memory_order_release);
+    }
+    return false;
+  }
+  _combNs[0] += ns(f.tA, f.tB); _combNs[1] += ns(f.tB, f.tC); _combNs[2] += ns(f.tC, tD);
+  if (f.anySampled) {
+    // The priority vectors are on the host: every client selects for ITSELF (the O(Q) scalar Kahan steps of the reference's
+    // selector, CpuEngine.cpp:362-400, run on as many cores as there are clients), the leader only for its own request.
+    c.readers.fetch_add((int)n, std::memory_order_acq_rel);
+    bool ownLive = false;
+    for (int64_t i = 0; i < n; i++) {
+      SelRequest *r = f.live[(size_t)i];
+      r->pri = f.quizMinor ? c.hPri + i : c.hPri + (size_t)i * (size_t)f.nQ;
+      r->priStride = f.quizMinor ? f.Bp : 1;
+      r->ctx = &c;
+      if (r == own) { ownLive = true; continue; }
+      for (SelRequest *&slot : batch) if (slot == r) slot = nullptr;   // (published here: not the caller's to publish again)
+      r->state.store(3, std::memory_order_release);
+    }
+    { std::lock_guard<std::mutex> g(_combMu); }   // (a sleeper that has just found its state 0 is inside wait() by now)
+    _combCv.notify_all();
+    _combNs[3] += ns(tD, std::chrono::steady_clock::now());
+    return ownLive;
+  }
+  std::lock_guard<EngineMutex> lk(_mu);
+  const auto tE = std::chrono::steady_clock::now();
+  for (int64_t i = 0; i < n; i++) {
+    SelRequest *r = f.live[(size_t)i];
+    Quiz *q = ((size_t)r->iQuiz < _quizzes.size()) ? _quizzes[(size_t)r->iQuiz] : nullptr;
+    if (q == nullptr || q->serial != r->serial) {   // released while its sweep ran (a client's error: IPqaEngine.h:44)
+      r->err = Error::MakeP(ErrCode::AbsentId, "id=" + std::to_string(r->iQuiz), "Quiz index is not in the registry (but rather at a gap).");
+      r->result = -1;
+      continue;
+    }
+    if (c.h->out[i].index == -3) { r->err = HipErr(hipErrorLaunchFailure, "combined selection (incomplete sweep)"); r->result = -1; continue; }
+    r->result = FinishSelection(r->err, q, c.h->out[i].index);
+  }
+  _combNs[3] += ns(tD, tE);
+  _combNs[4] += ns(tE, std::chrono::steady_clock::now());
+  return false;
 }
 
 Error HipEngine::EvalPriorities(int64_t iQuiz, double *pOut, int64_t n) {
@@ -1384,6 +1779,7 @@ Error HipEngine::EvalPriorities(int64_t iQuiz, double *pOut, int64_t n) {
 // RecordAnswer and friends
 // ------------------------------------------------------------------------------------------------------------------
 Error HipEngine::RecordAnswerImpl(int64_t iQuiz, int64_t iAnswer, bool remote) {
+  CallScope scope(_activeCallers);
   std::lock_guard<EngineMutex> lk(_mu);
   Error err = CheckRegular("record an answer");
   if (!err.ok()) return err;
@@ -1405,6 +1801,10 @@ Error HipEngine::RecordAnswerImpl(int64_t iQuiz, int64_t iAnswer, bool remote) {
                         remote ? "RecordAnswerRemote on the shard that owns the active question."
                                : "The active question belongs to another shard: use PqaHip_RecordAnswerRemote.");
   ServerQuiesce();
+  if (q->updatePending) {   // (a second answer for a quiz whose first is still deferred: that one runs now)
+    Error fe = FlushUpdates();
+    if (!fe.ok()) return fe;
+  }
   q->answers.push_back(AQ{aq, iAnswer});
   q->activeQuestion = -1;
   q->priorVersion++;  // (remote: the caller writes the owner's posterior into the quiz's buffer)
@@ -1412,22 +1812,67 @@ Error HipEngine::RecordAnswerImpl(int64_t iQuiz, int64_t iAnswer, bool remote) {
   hipSetDevice(_device);
   const int64_t ql = aq - _qFirst;
   BitSet(q->hAsked, ql, true);
+  _pendingUpdates.push_back(PendingUpdate{q, ql, iAnswer});
+  _pendingCount.store(_pendingUpdates.size(), std::memory_order_relaxed);
+  q->updatePending = true;
+  // Other client threads inside the engine: leave the kernel to whoever next needs a posterior -- it runs all the updates that
+  // have gathered by then in one launch.  Alone: launch now, and the sweep of the NextQuestion that follows right behind it.
+  if (Concurrent()) return Error();
+  Error fe = FlushUpdates();
+  if (!fe.ok()) return fe;
+  Speculate(q);
+  return Error();
+}
+
+// The deferred RecordAnswers, on the engine's stream: one launch, no copy, no synchronisation -- the kernel also sets the
+// question's bit in the quiz's device bitmap and lists the new posterior's best targets into the quiz's own pinned lines (as
+// many as ListTopTargets has been asking for lately; every listed target is a round of the kernel's selection, `top_cache` at
+// most), and everything that reads a posterior or a bitmap afterwards is ordered behind it on the stream.
+Error HipEngine::FlushUpdates() {
+  if (_pendingUpdates.empty()) return Error();
+  std::vector<PendingUpdate> ups;
+  ups.swap(_pendingUpdates);
+  _pendingCount.store(0, std::memory_order_relaxed);
+  for (PendingUpdate &u : ups) u.q->updatePending = false;
+  hipSetDevice(_device);
+  ServerQuiesce();
   // NLooseWorkers = max(1, hw - 1): reference PqaCore/CEQuiz.h:98, PqaCore/BaseCpuEngine.cpp:22
   const int64_t nLoose = std::max<int64_t>(1, _optWorkers - 1);
-  // One launch, no copy, no synchronisation: the kernel also sets the question's bit in the device bitmap, and everything
-  // that reads the posterior or the bitmap afterwards is ordered behind it on the engine's stream.
-  // as many as ListTopTargets has been asking for lately (every listed target is a round of the kernel's selection), `top_cache` at most
-  const int64_t topCount = std::min<int64_t>(std::min<int64_t>(std::min<int64_t>(_optTopCache, _topWantRecent), 256), _T);
-  const uint64_t op = ++_opSeq;
-  HIP_TRY(LaunchRecordAnswer(View(), q->dPrior, q->dAsked, ql, iAnswer, nLoose, _hPinned->top, &_hPinned->nOut,
-                             &_hPinned->topFlag, op, topCount, _stream));
-  if (topCount > 0 && _T <= 16384) {
-    _topOwner = q; _topOp = op; _topVersion = q->priorVersion; _topCount = topCount;
-    // the kernel stores `op` last: whoever sees it knows that everything enqueued on the stream so far has finished
-    _pendingRecordOp = op;
-    _mu.busy = _mu.wasBusy;   // (busy only if it was before this call: `op` covers this call's launch)
+  const int64_t topCount = _T <= 16384 ? std::min<int64_t>(std::min<int64_t>(std::min<int64_t>(_optTopCache, _topWantRecent), kQuizTop), _T) : 0;
+  _flushes++;
+  _flushedUpdates += ups.size();
+  _flushedSinceSweep.fetch_add((int64_t)ups.size(), std::memory_order_relaxed);
+  if (ups.size() > _maxFlush) _maxFlush = ups.size();
+  auto listed = [&](Quiz *q, uint64_t op) { q->topOp = op; q->topVersion = q->priorVersion; q->topCount = topCount; };
+  if (ups.size() == 1) {
+    const PendingUpdate &u = ups[0];
+    const uint64_t op = ++_opSeq;
+    HIP_TRY(LaunchRecordAnswer(View(), u.q->dPrior, u.q->dAsked, u.qLocal, u.iAnswer, nLoose, u.q->pin->top, &u.q->pin->nOut,
+                               &u.q->pin->topFlag, op, topCount, _stream));
+    listed(u.q, op);
+    if (topCount > 0) {
+      // the kernel stores `op` last: whoever sees it knows that everything enqueued on the stream so far has finished
+      _pendingRecordOp = op;
+      _pendingRecordFlag = &u.q->pin->topFlag;
+      _mu.busy = _mu.wasBusy;   // (busy only if it was before this call: `op` covers this call's launch)
+    }
+    return Error();
   }
-  Speculate(q);
+  const KbView kb = View();
+  for (size_t first = 0; first < ups.size(); first += kRecordInline) {
+    RecordBatchInline b;
+    b.n = (int32_t)std::min<size_t>(kRecordInline, ups.size() - first);
+    b.topCount = (int32_t)topCount;
+    for (int32_t i = 0; i < b.n; i++) {
+      const PendingUpdate &u = ups[first + (size_t)i];
+      const uint64_t op = ++_opSeq;
+      b.s[i] = RecordSlot{u.q->dPrior, u.q->dAsked, (int32_t)u.qLocal, (int32_t)u.iAnswer, u.q->pin->top, &u.q->pin->nOut, &u.q->pin->topFlag, op};
+      listed(u.q, op);
+    }
+    HIP_TRY(LaunchRecordAnswerBatch(kb, b, nLoose, _stream));
+  }
+  _pendingRecordOp = 0;   // (the workgroups of a batched launch finish in any order: no one flag says that the stream is idle)
+  _pendingRecordFlag = nullptr;
   return Error();
 }
 
@@ -1438,6 +1883,7 @@ Error HipEngine::RecordAnswerImpl(int64_t iQuiz, int64_t iAnswer, bool remote) {
 void HipEngine::Speculate(Quiz *q) {
   DropSpeculation();   // (one at a time: the hand-over buffers are the engine's)
   if (!_optSpeculate || _optServer || _optUseGraph || _qTotal != _Q || _Q <= 0) return;
+  if (Concurrent()) return;   // (several clients: their NextQuestions are served together, by a batched sweep)
   if (_specScore < -4 && (++_specProbe & 31) != 0) return;   // the client does not follow RecordAnswer with NextQuestion: probe now and then
   const KbView kb = View();
   int kind = 0;
@@ -1506,6 +1952,7 @@ Error HipEngine::GetPriors(int64_t iQuiz, double *pOut, int64_t n) {
   if (!pOut) return Error::Make(ErrCode::NullArgument, "Nullptr is passed in place of the prior buffer.");
   if (n != _T) return Error::MakeP(ErrCode::IndexOutOfRange, RangeParams(n, _T, _T), "Prior buffer length must equal nTargets.");
   hipSetDevice(_device);
+  { Error fe = FlushUpdates(); if (!fe.ok()) return fe; }
   HIP_TRY(hipMemcpyAsync(pOut, q->dPrior, (size_t)_T * sizeof(double), hipMemcpyDeviceToHost, _stream));
   HIP_TRY(hipStreamSynchronize(_stream));
   return Error();
@@ -1534,13 +1981,15 @@ Error HipEngine::GetPriorDevicePtr(int64_t iQuiz, void **ppDev, int64_t *pLdT) {
   Error err;
   Quiz *q = UseQuiz(err, iQuiz);
   if (!q) return err;
+  { Error fe = FlushUpdates(); if (!fe.ok()) return fe; }   // (the caller is about to read the buffer in stream order)
   if (ppDev) *ppDev = q->dPrior;
   if (pLdT) *pLdT = _ldT;
   return Error();
 }
 
 int64_t HipEngine::ListTopTargets(Error &err, int64_t iQuiz, int64_t maxCount, CiRatedTarget *pDest) {
-  std::lock_guard<EngineMutex> lk(_mu);
+  CallScope scope(_activeCallers);
+  std::unique_lock<EngineMutex> lk(_mu);
   err = CheckRegular("list top targets");
   if (!err.ok()) return -1;
   Quiz *q = UseQuiz(err, iQuiz);
@@ -1548,25 +1997,70 @@ int64_t HipEngine::ListTopTargets(Error &err, int64_t iQuiz, int64_t maxCount, C
   if (maxCount <= 0) return 0;
   if (!pDest) { err = Error::Make(ErrCode::NullArgument, "Nullptr is passed in place of the destination."); return -1; }
   hipSetDevice(_device);
+  if (q->updatePending && _optLingerUs > 0 && Concurrent()) {
+    // Group commit.  This quiz's RecordAnswer is deferred, and the clients that got their questions from the same combined sweep
+    // are recording their answers right now: give them a moment, so that ONE launch runs all of them.  Whoever comes out of the
+    // wait first launches; the others find their update on its way.
+    const size_t target = (size_t)std::max<int64_t>(2, std::min<int64_t>(_lastCombined.load(std::memory_order_relaxed), _activeCallers.load(std::memory_order_relaxed) - 1));
+    if (_pendingUpdates.size() < target) {
+      lk.unlock();
+      const auto t0 = std::chrono::steady_clock::now();
+      const auto limit = std::chrono::microseconds(_optLingerUs);
+      for (;;) {
+        const size_t have = _pendingCount.load(std::memory_order_relaxed);
+        if (have == 0 || have >= target) break;   // (0: somebody has launched them)
+        for (int i = 0; i < 32; i++) _mm_pause();
+        if (std::chrono::steady_clock::now() - t0 > limit) break;
+      }
+      lk.lock();
+      q = UseQuiz(err, iQuiz);
+      if (!q) return -1;
+    }
+  }
+  err = FlushUpdates();   // (this quiz's RecordAnswer, and whatever other quizzes' have gathered, in one launch)
+  if (!err.ok()) return -1;
   const int64_t want = std::min<int64_t>(maxCount, _T);
   _topWantRecent = want >= _topWantRecent ? want : want + (_topWantRecent - want) * 7 / 8;   // (decays towards smaller requests)
-  if (want <= 256 && _T <= 16384) {  // (the kernel keeps every target in registers: 16 per thread at most)
-    // the kernel lists straight into host-coherent memory and then stores the operation number: no copy, no synchronise
-    const bool cached = _topOwner == q && _topVersion == q->priorVersion;
-    if (!(cached && want <= _topCount)) {
+  static_assert(sizeof(RatedTargetDev) == sizeof(CiRatedTarget), "listed straight into the caller's layout");
+  if (want <= kQuizTop && _T <= 16384) {  // (the kernel keeps every target in registers: 16 per thread at most)
+    // the kernel lists straight into the quiz's host-coherent lines and then stores the operation number: no copy, no synchronise
+    const bool cached = q->topOp != 0 && q->topVersion == q->priorVersion && want <= q->topCount;
+    if (!cached) {
       const uint64_t op = ++_opSeq;
-      const hipError_t he = LaunchTopTargets(View(), q->dPrior, want, _hPinned->top, &_hPinned->nOut, &_hPinned->topFlag, op, _stream);
+      const hipError_t he = LaunchTopTargets(View(), q->dPrior, want, q->pin->top, &q->pin->nOut, &q->pin->topFlag, op, _stream);
       if (he != hipSuccess) { err = HipErr(he, "ListTopTargets"); return -1; }
-      _topOwner = q; _topOp = op; _topVersion = q->priorVersion; _topCount = want;
+      q->topOp = op; q->topVersion = q->priorVersion; q->topCount = want;
     }
-    err = WaitFlag(&_hPinned->topFlag, _topOp, "ListTopTargets");
+    QuizPinned *pin = q->pin;
+    const uint64_t op = q->topOp;
+    if (Concurrent()) {
+      // other clients are inside the engine: wait with the engine open to them (the lines are this quiz's own)
+      lk.unlock();
+      err = WaitFlagNapping(&pin->topFlag, op, "ListTopTargets");
+      if (!err.ok()) return -1;
+      const int64_t n = std::min<int64_t>(pin->nOut, want);
+      std::memcpy(pDest, pin->top, (size_t)n * sizeof(RatedTargetDev));
+      return n;
+    }
+    err = WaitFlag(&pin->topFlag, op, "ListTopTargets");
     if (!err.ok()) return -1;
     // what was waited for was the newest work on the stream (this call's own launch, or RecordAnswer's kernel with nothing
     // enqueued behind it): the stream is idle.  Otherwise this call has added nothing to it.
-    if (!cached || want > _topCount || (_pendingRecordOp == _topOp && !_mu.wasBusy)) { _mu.busy = false; _pendingRecordOp = 0; }
+    if (!cached || (_pendingRecordOp == op && !_mu.wasBusy)) { _mu.busy = false; _pendingRecordOp = 0; }
     else _mu.busy = _mu.wasBusy;
+    const int64_t n = std::min<int64_t>(pin->nOut, want);
+    std::memcpy(pDest, pin->top, (size_t)n * sizeof(RatedTargetDev));
+    return n;
+  }
+  if (want <= 256 && _T <= 16384) {   // longer lists: the engine's own lines, the engine held while the kernel runs
+    const uint64_t op = ++_opSeq;
+    const hipError_t he = LaunchTopTargets(View(), q->dPrior, want, _hPinned->top, &_hPinned->nOut, &_hPinned->topFlag, op, _stream);
+    if (he != hipSuccess) { err = HipErr(he, "ListTopTargets"); return -1; }
+    err = WaitFlag(&_hPinned->topFlag, op, "ListTopTargets");
+    if (!err.ok()) return -1;
+    _mu.busy = false;   // (this call's own launch was the newest work on the stream)
+    _pendingRecordOp = 0;
     const int64_t n = std::min<int64_t>(_hPinned->nOut, want);
-    static_assert(sizeof(RatedTargetDev) == sizeof(CiRatedTarget), "listed straight into the caller's layout");
     std::memcpy(pDest, _hPinned->top, (size_t)n * sizeof(RatedTargetDev));
     return n;
   }
@@ -1730,6 +2224,7 @@ Error HipEngine::RecordQuizTarget(int64_t iQuiz, int64_t iTarget, double amount)
   // hold of the lock (the quiz cannot be answered or released in between); the asked-questions counter is not touched
   if (amount <= 0)
     return Error::MakeP(ErrCode::NonPositiveAmount, "amount=" + std::to_string(amount), "|amount| must be positive.");
+  CallScope scope(_activeCallers);
   std::lock_guard<EngineMutex> lk(_mu);
   Error err = CheckRegular("record quiz target");
   if (!err.ok()) return err;

@@ -9,6 +9,8 @@
 #include <hip/hip_runtime.h>
 
 #include <atomic>
+#include <chrono>
+#include <condition_variable>
 #include <functional>
 #include <cstdint>
 #include <memory>
@@ -16,6 +18,7 @@
 #include <cstdio>
 #include <ctime>
 #include <string>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -78,6 +81,17 @@ class PermIdMgr {
   std::unordered_map<int64_t, int64_t> _perm2comp;
 };
 
+// A quiz's own lines of host-coherent pinned memory: what the kernels working for ONE quiz hand to the host without a copy --
+// the posterior's best targets (listed by RecordAnswer's kernel ahead of the ListTopTargets that follows it) and their flag.
+// Per quiz, so that the quizzes of different client threads never wait for each other's results.
+constexpr int kQuizTop = 32;
+struct QuizPinned {
+  RatedTargetDev top[kQuizTop];
+  int64_t nOut;
+  uint64_t topFlag;
+  uint64_t pad[6];
+};
+
 struct Quiz {
   time_t lastUsage = 0;                // reference BaseQuiz::OnUsage
   double *dPrior = nullptr;            // ldT doubles, device
@@ -86,6 +100,15 @@ struct Quiz {
   std::vector<AQ> answers;             // global question ids
   int64_t activeQuestion = -1;         // global id (reference CEQuiz::_activeQuestion)
   uint64_t priorVersion = 0;           // bumped whenever the posterior changes
+  uint64_t serial = 0;                 // unique per created quiz: a registry slot reused by a later quiz is not this quiz
+  QuizPinned *pin = nullptr;           // this quiz's host-coherent result lines (pooled by the engine)
+  // the listing in pin->top: made by the kernel that published `topOp` to pin->topFlag, of the posterior `topVersion`
+  uint64_t topOp = 0, topVersion = 0;
+  int64_t topCount = 0;
+  std::atomic<bool> updatePending{false};   // a RecordAnswer of this quiz waits in the engine's list of deferred updates
+  // A client of a combined sweep is selecting for this quiz outside the engine's lock (SelectFromPriorities): the quiz object
+  // stays until it is done (a ReleaseQuiz from another thread -- a client's error, IPqaEngine.h:44 -- waits).
+  std::atomic<bool> inSelection{false};
 };
 
 // What the C ABI (c_abi.cpp) drives: one engine on one device (HipEngine), or the question axis of one knowledge base split
@@ -307,33 +330,117 @@ class HipEngine : public IEngine {
     uint64_t topFlag;              // completion flag of whatever listed into top[] last
     RatedTargetDev top[256];
   };
-  // top[] is a one-entry cache: RecordAnswer's kernel lists the new posterior's best targets there, and a ListTopTargets
-  // for the same quiz and posterior that asks for no more than were listed finds them without a launch
-  Quiz *_topOwner = nullptr;
-  uint64_t _topOp = 0, _topVersion = 0;
-  int64_t _topCount = 0;
+  // (Pinned::top: listings of more than kQuizTop targets; up to kQuizTop the quiz's own lines are used, where RecordAnswer's
+  //  kernel lists the new posterior's best targets ahead of the ListTopTargets for the same quiz and posterior)
   uint64_t _opSeq = 0;
+  // ---- the quizzes' pinned lines: slabs of host-coherent memory, handed out per quiz, returned at its release
+  std::vector<QuizPinned *> _pinSlabs, _pinFree;
+  static constexpr int kPinSlab = 256;
+  QuizPinned *TakePin();
+  // ---- deferred posterior updates.  While several client threads are inside the engine, RecordAnswer only does its
+  // bookkeeping and leaves the kernel to whoever next needs a posterior (ListTopTargets, NextQuestion, ...): that caller launches
+  // ONE kernel for all the updates that have gathered (grid.x = update; prior_kernels.hip: record_answer_batch_kernel) instead
+  // of one launch each.  Alone in the engine, RecordAnswer launches at once, as before.
+  struct BatchCtx;
+  struct PendingUpdate { Quiz *q; int64_t qLocal, iAnswer; };
+  std::vector<PendingUpdate> _pendingUpdates;
+  Error FlushUpdates();                       // the caller holds _mu
+  uint64_t _flushes = 0, _flushedUpdates = 0, _maxFlush = 0;
+  std::atomic<int> _activeCallers{0};         // client threads inside quiz-level calls right now
+  struct CallScope {
+    std::atomic<int> &n;
+    explicit CallScope(std::atomic<int> &c) : n(c) { n.fetch_add(1, std::memory_order_relaxed); }
+    ~CallScope() { n.fetch_sub(1, std::memory_order_relaxed); }
+  };
+  bool Concurrent() const { return _optCombine && _activeCallers.load(std::memory_order_relaxed) > 1; }
+  int64_t _optCombine = 1;                    // option "combine" / PQA_COMBINE: 0 = every call by itself, as before
+  // ---- combining of concurrent NextQuestion calls (reference: every client's NextQuestion runs under a SHARED lock,
+  // PqaCore/CpuEngine.cpp:357-361, Interface/IPqaEngine.h:44).  A caller posts its request; if a leader is at work it waits
+  // for its result, otherwise it becomes the leader: it takes everything posted so far -- distinct quizzes -- and serves it
+  // with ONE row-sharing / grid.y sweep (BatchSweep), selects per quiz, hands the results out and, if requests are waiting
+  // again, passes the lead to the oldest of them.  One request: the single-quiz path, as before.
+  struct SelRequest {
+    int64_t iQuiz = -1;
+    int kind = 0;                      // 0: argmax, 1: sampled (rnd)
+    uint64_t rnd = 0;
+    int64_t result = -1;
+    Error err;
+    std::atomic<int> state{0};         // 0 waiting, 1 served, 2 lead handed over: serve the queue yourself,
+                                       // 3 the sweep is done: select for yourself from pri[] (the leader does not do it for everybody)
+    const double *pri = nullptr;       // state 3: priority of local question k at pri[k * priStride]
+    int64_t priStride = 0;
+    BatchCtx *ctx = nullptr;           // state 3: whose reader count is this request's to release
+    uint64_t serial = 0;               // state 3: the quiz the sweep ran for
+    Quiz *quiz = nullptr;              // state 3: held by inSelection
+    std::vector<uint32_t> unavailable; // state 3: the quiz's asked questions and the gaps as they were when the sweep was launched
+    int64_t nQ = 0, nSub = 0;
+  };
+  int64_t SelectFromPriorities(SelRequest *r);     // the host-side selector + FinishSelection for one request of a combined sweep
+  std::atomic<size_t> _pendingCount{0};            // == _pendingUpdates.size(), readable without the lock
+  std::atomic<int64_t> _flushedSinceSweep{0};      // RecordAnswers launched since the newest combined sweep: their clients' NextQuestions are on their way
+  std::atomic<int64_t> _lastCombined{0};           // requests of the newest combined sweep: as many RecordAnswers are about to arrive
+  int64_t _optLingerUs = 20;                       // option "combine_linger_us": how long a ListTopTargets waits for them before it launches the updates
+  std::mutex _combMu;
+  std::condition_variable _combCv;
+  std::vector<SelRequest *> _combQueue;
+  bool _leaderActive = false;
+  int64_t Combine(Error &err, int64_t iQuiz, int kind, uint64_t rnd);
+  void ServeQueue(SelRequest *own);
+  struct Flight {                      // a combined sweep between its launch and its collection
+    std::vector<SelRequest *> live;
+    uint64_t tag = 0;
+    bool anySampled = false, quizMinor = false;
+    int64_t Bp = 0, nQ = 0;
+    hipError_t he = hipSuccess;
+    std::chrono::steady_clock::time_point tA, tB, tC;
+  };
+  void LaunchBatch(BatchCtx &c, std::vector<SelRequest *> &batch, Flight &f);
+  bool CollectBatch(BatchCtx &c, std::vector<SelRequest *> &batch, Flight &f, SelRequest *own);   // true: `own` is to select for itself
+  int64_t NextQuestionArgmaxLocked(Error &err, int64_t iQuiz);
+  int64_t NextQuestionSampledLocked(Error &err, int64_t iQuiz, uint64_t rnd);
+  std::mutex _rngMu;
+  uint64_t _quizSerial = 0;
+  uint64_t _combBatches = 0, _combRequests = 0, _combMaxBatch = 0;
+  std::atomic<uint64_t> _combNs[7] = {{0}, {0}, {0}, {0}, {0}, {0}, {0}};
+  volatile uint64_t *_pendingRecordFlag = nullptr;   // where _pendingRecordOp will appear
   // spin on a host-coherent flag until it holds `value` (the kernel's last store); falls back to the stream's status
   Error WaitFlag(volatile uint64_t *flag, uint64_t value, const char *what);
+  Error WaitFlagNapping(volatile uint64_t *flag, uint64_t value, const char *what);   // for many waiters at once: a short spin, then naps
   SelectResult *_dSelScratch = nullptr;  // its per-workgroup winner records
   // batched selections (NextQuestionArgmaxBatch); allocated on first use
   static constexpr int64_t kMaxBatch = 256, kBatchGrid = 1024;
   struct BatchPinned { QuizSlot slots[kMaxBatch]; SelectResult out[kMaxBatch]; uint64_t seq[kMaxBatch]; };
-  BatchPinned *_hBatch = nullptr;
-  QuizSlot *_dBatchSlots = nullptr;
-  SelectResult *_dBatchScratch = nullptr;
-  double *_dBatchPriority = nullptr;
-  int64_t _batchPriorityQ = -1;
-  // the row-sharing batched sweep (batch_kernels.hip): scratch sized by its plan, grown on demand
-  void *_dBatchPT = nullptr; double *_dBatchAcc = nullptr; BatchRecord *_dBatchRecs = nullptr; double *_dBatchPriT = nullptr;
-  size_t _batchPTBytes = 0, _batchAccBytes = 0, _batchRecBytes = 0, _batchPriTBytes = 0;
-  Error BatchSweep(int64_t n, const int64_t *pQuizzes, std::vector<Quiz *> &quizzes, bool wantPriorities, uint64_t tag);
-  Error WaitBatchFlags(int64_t n, uint64_t tag);
+  // Everything ONE batched sweep in flight needs of its own: the staged slots and winner records, the scratch of the
+  // row-sharing sweep (batch_kernels.hip; sized by its plan, grown on demand), the host copy of the priority vectors.  Two of
+  // them: the batch calls of the ABI and the shards' halves use the first; the leaders of combined sweeps alternate, so that
+  // the next sweep is launched while the previous one runs.
+  struct BatchCtx {
+    std::mutex mu;                       // one batch at a time in this context (taken before the engine's lock)
+    BatchPinned *h = nullptr;
+    QuizSlot *dSlots = nullptr;
+    SelectResult *dScratch = nullptr;
+    double *dPriority = nullptr;
+    int64_t priorityQ = -1;
+    void *dPT = nullptr; double *dAcc = nullptr; BatchRecord *dRecs = nullptr; double *dPriT = nullptr;
+    size_t ptBytes = 0, accBytes = 0, recBytes = 0, priTBytes = 0;
+    int lastBp = 0;
+    double *hPri = nullptr;              // pinned: the batch's priority vectors for the host-side selector
+    size_t hPriDoubles = 0;
+    std::atomic<int> readers{0};         // clients still selecting out of hPri
+    hipEvent_t event = nullptr;
+    std::atomic<bool> inFlight{false};   // a leader's sweep launched and not yet collected
+  };
+  BatchCtx _ctx[2];
+  int _ctxNext = 0;                      // (the leader's)
+  // wantPriorities: the row-sharing sweep with its priority matrix kept (EvalPrioritiesBatch).  hostPriorities: whichever form
+  // suits the batch, and the quizzes' priority vectors copied into _hBatchPri (layout: *pQuizMinor) for the host's selector.
+  Error BatchSweep(BatchCtx &c, int64_t n, const int64_t *pQuizzes, std::vector<Quiz *> &quizzes, bool wantPriorities, uint64_t tag,
+                   bool hostPriorities = false, bool *pQuizMinor = nullptr);
+  Error WaitBatchFlags(BatchCtx &c, int64_t n, uint64_t tag);
   Error EnqueueBatchLocked(int64_t n, const int64_t *pQuizzes, bool wantPriorities, uint64_t *pTag);
   Error CollectBatchSelectionsLocked(int64_t n, uint64_t tag, CiHipSelection *pOut);
   Error CollectBatchPrioritiesLocked(int64_t n, double *pOut);
   std::vector<Quiz *> _batchQuizzes;   // the quizzes of the batch between its two halves
-  int _lastBatchBp = 0;
   void *_dClusterScratch = nullptr;   // exchange buffers of the long-row sweep (cluster_kernels.hip), grown on demand
   size_t _clusterScratchBytes = 0;
   bool UseClusterSweep() const;       // rows beyond the register shapes, automatic variant, shape supported
@@ -360,10 +467,22 @@ class HipEngine : public IEngine {
   // stream, so a request is posted only after whatever the other operations enqueued on `_stream` has finished
   // (ServerPost); the selection paths, which leave nothing running, restore the mark they found.
   struct EngineMutex {
+    // (a sleeping lock on purpose: the client threads of a server may outnumber the cores it is allowed -- the GPU boxes of
+    //  this project give a container 16 of 256 hardware threads -- and spinning waiters, tried in round 3 as a test-and-set and
+    //  as a ticket lock, burn that allowance: 64 client threads fell from 45 k to 13 k questions/s, 256 to 0.3 k)
     std::mutex m;
     bool busy = false, wasBusy = false;
     void lock() { m.lock(); wasBusy = busy; busy = true; }
+    void lock_urgent() { lock(); }
     void unlock() { m.unlock(); }
+  };
+  struct UrgentLock {   // (RAII for lock_urgent, re-lockable like std::unique_lock)
+    EngineMutex &mu;
+    bool held = false;
+    explicit UrgentLock(EngineMutex &m) : mu(m) { lock(); }
+    ~UrgentLock() { if (held) unlock(); }
+    void lock() { mu.lock_urgent(); held = true; }
+    void unlock() { mu.unlock(); held = false; }
   };
   mutable EngineMutex _mu;
   std::atomic<uint64_t> _nQuestionsAsked{0};

@@ -214,6 +214,24 @@ hipError_t LaunchStartQuiz(const KbView &kb, double *prior, uint32_t *asked, int
 hipError_t LaunchRecordAnswer(const KbView &kb, double *prior, uint32_t *asked, int64_t iQuestion, int64_t iAnswer,
                               int64_t nWorkers, RatedTargetDev *topOut, int64_t *topN, uint64_t *topFlag,
                               uint64_t topFlagValue, int64_t topCount, hipStream_t stream);
+// Several quizzes' RecordAnswer in ONE launch (grid.x = update; the same workgroup code and summation order per quiz as
+// LaunchRecordAnswer, so every posterior is bit-identical to the one-by-one result): up to kRecordInline updates travel in the
+// kernel's arguments.  CERecordAnswerSubtaskMul.cpp:15-42 per quiz; the reference runs concurrent quizzes' updates side by side.
+constexpr int kRecordInline = 40;
+struct RecordSlot {
+  double *prior;
+  uint32_t *asked;
+  int32_t iQuestion, iAnswer;     // local question
+  RatedTargetDev *topOut;         // host-coherent lines of the quiz (optional)
+  int64_t *topN;
+  uint64_t *topFlag;
+  uint64_t topFlagValue;
+};
+struct RecordBatchInline {
+  int32_t n, topCount;
+  RecordSlot s[kRecordInline];
+};
+hipError_t LaunchRecordAnswerBatch(const KbView &kb, const RecordBatchInline &batch, int64_t nWorkers, hipStream_t stream);
 // rows: device array of 2 nAnswered row pointers, {sA[q_i][a_i], mD[q_i]} per answered question (rows of kb.elem-byte elements,
 // ldT long; they may live on another device of the process).  exps: scratch of ldT int64.  status: device int64[2]
 // {error code (0 / 16 = I64Underflow), fullMax}.  bugCompat reproduces PqaCore/CEUpdatePriorsSubtaskMul.cpp:53.

@@ -49,6 +49,17 @@ __global__ __launch_bounds__(SMALL ? kSmallThreads : kThreads) void record_answe
   record_answer_body<SMALL, false>(a, iQuestion, iAnswer, asked, top, lds, &topScratch);
 }
 
+// grid.x = update: workgroup i runs quiz i's RecordAnswer exactly as record_answer_kernel would
+template <bool SMALL>
+__global__ __launch_bounds__(SMALL ? kSmallThreads : kThreads) void record_answer_batch_kernel(PriorArgs a, RecordBatchInline batch) {
+  extern __shared__ double lds[];
+  __shared__ TopScratch topScratch;
+  const RecordSlot &s = batch.s[blockIdx.x];
+  a.prior = s.prior;
+  const TopRequest top{reinterpret_cast<TopOut *>(s.topOut), s.topN, s.topFlag, s.topFlagValue, s.topOut ? (int64_t)batch.topCount : 0};
+  record_answer_body<SMALL, false>(a, s.iQuestion, s.iAnswer, s.asked, top, lds, &topScratch);
+}
+
 __device__ __forceinline__ int ceil_log2_u64(uint64_t val) {  // SRPlatform/Interface/SRMath.h:46-51
   if (!val) return 0;
   const int index = 63 - __clzll((long long)val);
@@ -168,6 +179,20 @@ hipError_t LaunchRecordAnswer(const KbView &kb, double *prior, uint32_t *asked, 
   else
     hipLaunchKernelGGL(record_answer_kernel<false>, dim3(1), dim3(kThreads), staged_lds_bytes(kb, nWorkers), stream,
                        make_args(kb, prior, nWorkers, true), iQuestion, iAnswer, asked, top);
+  return hipGetLastError();
+}
+
+hipError_t LaunchRecordAnswerBatch(const KbView &kb, const RecordBatchInline &batch, int64_t nWorkers, hipStream_t stream) {
+  if (nWorkers < 1 || nWorkers > kMaxWorkers || batch.n < 1 || batch.n > kRecordInline) return hipErrorInvalidValue;
+  RecordBatchInline b = batch;
+  if (kb.T > 16384) b.topCount = 0;
+  // 256-thread workgroups whenever the rows are short: several quizzes' updates share a CU
+  if (kb.T <= 4 * kSmallThreads)
+    hipLaunchKernelGGL(record_answer_batch_kernel<true>, dim3((unsigned)b.n), dim3(kSmallThreads), staged_lds_bytes(kb, nWorkers), stream,
+                       make_args(kb, nullptr, nWorkers, true), b);
+  else
+    hipLaunchKernelGGL(record_answer_batch_kernel<false>, dim3((unsigned)b.n), dim3(kThreads), staged_lds_bytes(kb, nWorkers), stream,
+                       make_args(kb, nullptr, nWorkers, true), b);
   return hipGetLastError();
 }
 

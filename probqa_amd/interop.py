@@ -168,6 +168,35 @@ def load_library(path: Optional[str] = None) -> ctypes.CDLL:
     return lib
 
 
+class PqaClientStats(ctypes.Structure):  # probqa_amd/client/pqa_client.cpp
+    _fields_ = [("nQuizzes", ctypes.c_int64), ("nQuestions", ctypes.c_int64), ("nGuessedOnTop", ctypes.c_int64),
+                ("nErrors", ctypes.c_int64), ("seconds", ctypes.c_double), ("transcriptHash", ctypes.c_uint64)]
+
+
+CLIENT_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libPqaClient.so")
+_client = None
+
+
+def run_learners(engine: "PqaEngine", n_threads: int, n_quizzes: int, max_questions: int = 30, seed: int = 1, train: bool = True) -> dict:
+    """The reference's learner client (PqaClient/PqaClient.cpp:150-245) as native threads on ONE engine, through the C ABI only:
+    `n_threads` threads share `n_quizzes` quizzes (StartQuiz, NextQuestion / RecordAnswer / ListTopTargets(1) until the guess is
+    on top or `max_questions` were asked, RecordQuizTarget if `train`, ReleaseQuiz)."""
+    global _client
+    load_library()
+    if _client is None:
+        if not os.path.exists(CLIENT_LIB_PATH):
+            raise OSError(f"{CLIENT_LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'`")
+        _client = ctypes.CDLL(CLIENT_LIB_PATH)
+        _client.PqaClient_RunLearners.restype = ctypes.c_int64
+        _client.PqaClient_RunLearners.argtypes = [_vp, _i64, _i64, _i64, ctypes.c_uint64, _i64, ctypes.POINTER(PqaClientStats)]
+    st = PqaClientStats()
+    rc = _client.PqaClient_RunLearners(engine.c_engine, n_threads, n_quizzes, max_questions, seed, 1 if train else 0, ctypes.byref(st))
+    if rc != 0:
+        raise PqaException("PqaClient_RunLearners refused its arguments")
+    return {"quizzes": st.nQuizzes, "questions": st.nQuestions, "guessed_on_top": st.nGuessedOnTop, "errors": st.nErrors,
+            "seconds": st.seconds, "transcript_hash": st.transcriptHash, "threads": n_threads}
+
+
 class PqaException(Exception):  # reference ProbQA.py:300-302
     pass
 
