@@ -868,10 +868,52 @@ def run_batched(args, cfg, np, torch, interop, pdist, ctl, rank, dev_index, devi
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"], out["sample_parity"] = cpu_baseline_batched(np, cfg, eng, quizzes, args.cpu_seconds, f32)
+        out["argmax_vs_cpu"] = argmax_share(np, cfg, eng, quizzes, picks, f32)
     if shm is not None:
         shm.close()
     eng.close()
     return out
+
+
+def argmax_share(np, cfg, eng, quizzes, picks, f32):
+    """north_star: "with the argmax matching CpuEngine".  Cubes the CPU port can sweep whole (<= 2e7 elements): the share of the
+    batch's quizzes whose pick is the argmax of the fp64 CPU port's priorities on the engine's own (rounded) cube -- with the
+    Float engine's fp64 re-rank (option rerank, default) and by the fp32 sweep alone.  Larger cubes: the picks are checked
+    against the CPU port on the CANDIDATE questions only (the 8 best of the fp32 sweep), which is what the re-rank decides among."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import orclib
+    from probqa_amd import synth
+
+    Q, K, T = cfg["Q"], cfg["K"], cfg["T"]
+    if Q * K * T > 2e7:
+        return None
+    A, D, Bv = synth.synthetic_kb(K, Q, T, 0.1, 8.0, 0.5, SEED)
+    if f32:
+        A, D, Bv = (x.astype(np.float32).astype(np.float64) for x in (A, D, Bv))
+    orc = orclib.Oracle(K, Q, T, 0.1)
+    orc.set_kb(A, D, Bv)
+    picks32 = None
+    if f32:
+        eng.set_option("rerank", 0)
+        picks32 = eng.next_question_argmax_batch(quizzes)
+        eng.set_option("rerank", 1)
+        picks = eng.next_question_argmax_batch(quizzes)
+    same = same32 = decided = 0
+    n = min(len(quizzes), 64)
+    for i in range(n):
+        orc.mants[:T] = eng.get_priors(quizzes[i])
+        asked = [(37 * i) % Q]
+        _, opri = orc.eval_avx2(min(os.cpu_count() or 1, 16))
+        opri[asked] = 0.0
+        want = int(np.argmax(opri))
+        top = np.sort(opri)[::-1]
+        decided += int((top[0] - top[1]) / top[0] > 1e-9)
+        same += int(int(picks[i]) == want)
+        if picks32 is not None:
+            same32 += int(int(picks32[i]) == want)
+    return {"quizzes_checked": n, "picks_equal_to_cpu_argmax": same, "decided_beyond_1e-9": decided,
+            "picks_equal_by_fp32_sweep_alone": same32 if picks32 is not None else None,
+            "note": "fp64 CPU port on the engine's own cube, whole sweep per quiz; the quiz's answered question excluded"}
 
 
 def cpu_baseline_batched(np, cfg, eng, quizzes, seconds, f32):

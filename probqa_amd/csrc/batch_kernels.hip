@@ -497,7 +497,8 @@ hipError_t launch_batch(const BatchArgs &args0, int nThreads, size_t *accBytesNe
 // Plan or run one batched sweep.  queryOnly: fill plan->{grid, accBytes, ptBytes, recBytes} for the caller to size its
 // scratch; otherwise prep (transposed priors) + sweep + pick on `stream`.
 hipError_t LaunchEvalBatch(const KbView &kb, const QuizSlot *slots, int nSlots, BatchPlan *plan, void *PT, double *acc,
-                           BatchRecord *recs, double *priorityT, int64_t outBase, uint64_t flagValue, bool queryOnly, hipStream_t stream) {
+                           BatchRecord *recs, double *priorityT, int64_t outBase, uint64_t flagValue, bool queryOnly, hipStream_t stream,
+                           bool skipPick) {
   if (nSlots <= 0 || nSlots > 256 || plan == nullptr) return hipErrorInvalidValue;
   const bool f32 = kb.elem == 4;
   const int nThreads = ((nSlots + 63) / 64) * 64, Bp = nThreads;
@@ -544,7 +545,7 @@ hipError_t LaunchEvalBatch(const KbView &kb, const QuizSlot *slots, int nSlots, 
   if (e != hipSuccess) return e;
   size_t dummy = 0;
   e = run(false, &dummy);
-  if (e != hipSuccess) return e;
+  if (e != hipSuccess || skipPick) return e;
   hipLaunchKernelGGL(batch_pick_kernel, dim3((unsigned)((nSlots + 255) / 256)), dim3(256), 0, stream, recs, grid, Bp, slots, nSlots,
                      outBase, flagValue);
   return hipGetLastError();

@@ -307,7 +307,7 @@ HipEngine::~HipEngine() {
   hipFree(_dCube); hipFree(_dVB); hipFree(_dPriority); hipFree(_dRunLength); hipFree(_dExps); hipFree(_dStatus);
   hipFree(_dNOut); hipFree(_dSel); hipFree(_dSelScratch); hipFree(_dClusterScratch);
   for (BatchCtx &c : _ctx) {
-    hipFree(c.dSlots); hipFree(c.dScratch); hipFree(c.dPriority); hipFree(c.dPT); hipFree(c.dAcc); hipFree(c.dRecs); hipFree(c.dPriT);
+    hipFree(c.dSlots); hipFree(c.dScratch); hipFree(c.dPriority); hipFree(c.dPT); hipFree(c.dAcc); hipFree(c.dRecs); hipFree(c.dPriT); hipFree(c.dRerank);
     if (c.hPri) hipHostFree(c.hPri);
     if (c.event) hipEventDestroy(c.event);
     if (c.h) hipHostFree(c.h);
@@ -363,6 +363,7 @@ Error HipEngine::SetOption(const char *name, int64_t value) {
   else if (n == "fused_sampled") { _optFusedSampled = value ? 1 : 0; }
   else if (n == "host_sampled") { _optHostSampled = value ? 1 : 0; }
   else if (n == "batch_min") { if (value < 0 || value > 257) goto bad; _optBatchMin = value; }
+  else if (n == "rerank") { _optRerank = value ? 1 : 0; }
   else if (n == "batch_qb") { if (value < 0 || value > 4) goto bad; _optBatchQb = value; }
   else if (n == "batch_tile") { if (value < 0 || value > 8192) goto bad; _optBatchTile = value; }
   else if (n == "server_vram_mailbox") { if (_serverStream) goto bad; _optServerVramMailbox = value ? 1 : 0; }
@@ -408,6 +409,7 @@ int64_t HipEngine::GetOption(const char *name) const {
   if (n == "spec_hits") return (int64_t)_specHits;         // speculative sweeps a NextQuestion used ...
   if (n == "spec_dropped") return (int64_t)_specDropped;   // ... and those nothing used
   if (n == "batch_min") return _optBatchMin;
+  if (n == "rerank") return _optRerank;
   if (n == "batch_tile") return _optBatchTile;
   if (n == "batch_qb") return _optBatchQb;
   if (n == "precision") return _precType;
@@ -1230,9 +1232,13 @@ Error HipEngine::BatchSweep(BatchCtx &c, int64_t n, const int64_t *pQuizzes, std
   HIP_TRY(grow(&c.dPT, c.ptBytes, plan.ptBytes));
   HIP_TRY(grow((void **)&c.dAcc, c.accBytes, plan.accBytes));
   HIP_TRY(grow((void **)&c.dRecs, c.recBytes, plan.recBytes));
-  if (wantPriorities) HIP_TRY(grow((void **)&c.dPriT, c.priTBytes, (size_t)_Q * (size_t)plan.Bp * sizeof(double)));
-  HIP_TRY(LaunchEvalBatch(kb, c.dSlots, (int)n, &plan, c.dPT, c.dAcc, c.dRecs, wantPriorities ? c.dPriT : nullptr, 0, tag,
-                          false, _stream));
+  // Float engines: the fp32 sweep nominates every quiz's best questions, fp64 decides among them (option "rerank", default on)
+  const bool rerank = _elem == 4 && _optRerank != 0;
+  if (wantPriorities || rerank) HIP_TRY(grow((void **)&c.dPriT, c.priTBytes, (size_t)_Q * (size_t)plan.Bp * sizeof(double)));
+  if (rerank) HIP_TRY(grow(&c.dRerank, c.rerankBytes, BatchRerankScratchBytes()));
+  HIP_TRY(LaunchEvalBatch(kb, c.dSlots, (int)n, &plan, c.dPT, c.dAcc, c.dRecs, (wantPriorities || rerank) ? c.dPriT : nullptr, 0, tag,
+                          false, _stream, rerank));
+  if (rerank) HIP_TRY(LaunchBatchRerank(kb, c.dSlots, (int)n, plan.Bp, c.dPriT, c.dRerank, 0, tag, _stream));
   c.lastBp = plan.Bp;
   if (hostPriorities) return copyToHost(c.dPriT, (size_t)_Q * (size_t)plan.Bp);
   return Error();

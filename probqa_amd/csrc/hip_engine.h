@@ -422,7 +422,8 @@ class HipEngine : public IEngine {
     double *dPriority = nullptr;
     int64_t priorityQ = -1;
     void *dPT = nullptr; double *dAcc = nullptr; BatchRecord *dRecs = nullptr; double *dPriT = nullptr;
-    size_t ptBytes = 0, accBytes = 0, recBytes = 0, priTBytes = 0;
+    size_t ptBytes = 0, accBytes = 0, recBytes = 0, priTBytes = 0, rerankBytes = 0;
+    void *dRerank = nullptr;             // Float engines: the candidates of the fp64 re-rank and their priorities
     int lastBp = 0;
     double *hPri = nullptr;              // pinned: the batch's priority vectors for the host-side selector
     size_t hPriDoubles = 0;
@@ -503,6 +504,7 @@ class HipEngine : public IEngine {
                                   // but 38.3 vs 36.4 us at 1000 x 5 x 1000 -- one workgroup's serial selection costs more than a launch
   int64_t _optEvalMaxGrid = 0;    // test hook: KbView::maxGrid
   int64_t _optBatchMin = 0;       // batches of at least this many quizzes take the row-sharing sweep (lane = quiz), smaller ones grid.y = quiz; 0 = by the number of waves the batch gives the row-sharing sweep
+  int64_t _optRerank = 1;         // Float engines' batched argmax: the fp32 sweep's best 8 questions per quiz re-ranked in fp64
   int64_t _optBatchQb = 0;        // questions per block of that sweep (0 = default)
   int64_t _optBatchTile = 0;      // targets per LDS tile of that sweep (0 = default)
   // ---- the next sweep ahead of its request (option "speculate"): RecordAnswer enqueues, right behind its posterior kernel, the

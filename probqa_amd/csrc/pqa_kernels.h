@@ -129,7 +129,14 @@ struct BatchPlan {
 // local index + outBase} to its slot's `out`, then flagValue to its `seq` (host-coherent).  priorityT (optional):
 // [Q][plan->Bp] priorities, quiz-minor.
 hipError_t LaunchEvalBatch(const KbView &kb, const QuizSlot *slots, int nSlots, BatchPlan *plan, void *PT, double *acc,
-                           BatchRecord *recs, double *priorityT, int64_t outBase, uint64_t flagValue, bool queryOnly, hipStream_t stream);
+                           BatchRecord *recs, double *priorityT, int64_t outBase, uint64_t flagValue, bool queryOnly, hipStream_t stream,
+                           bool skipPick = false);   // skipPick: the caller picks (LaunchBatchRerank)
+// skipPick (LaunchEvalBatch's flagValue == 0 is not used for this: see the argument): Float engines' batched ARGMAX -- the fp32
+// sweep nominates, fp64 decides (eval_kernels.hip: batch_rerank_kernel).  priorityT: the sweep's [Q][Bp] matrix; scratch:
+// BatchRerankScratchBytes() of device memory.  Writes every quiz's winner and flag like LaunchEvalBatch's own pick.
+size_t BatchRerankScratchBytes();
+hipError_t LaunchBatchRerank(const KbView &kb, const QuizSlot *slots, int nSlots, int Bp, const double *priorityT, void *scratch,
+                             int64_t outBase, uint64_t flagValue, hipStream_t stream);
 // Single-quiz sweep of a Float engine: priority[q] for every local question (0 for gap / asked).
 hipError_t LaunchEvalQuestionsF32(const KbView &kb, const double *prior, const uint32_t *asked, double *priority, hipStream_t stream);
 // ... with the question's rows held in registers (eval_f32_kernels.hip): rows of up to 16384 targets, up to 16 answers

@@ -75,3 +75,29 @@ def rel_err(a, b):
     a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
     den = np.maximum(np.abs(b), 1e-300)
     return np.abs(a - b) / den
+
+
+def lack_conditioning(case, priors):
+    """How ill-conditioned the reference's own priority formula is in this quiz state: lack = -sum invD^2 / log2(p) has a pole at
+    p -> 1, where Log2Hot(p) = log2(2p) - 1 carries an absolute rounding of ~1e-16 whatever the arithmetic -- and so does p
+    itself (a last-place difference of W_k, i.e. of the summation ORDER, moves log2 p by 1.6e-16).  Returns min |log2 p| over
+    every question, answer and non-gap target with p > 0: two correct evaluations of the formula agree to about
+    2^-52 / that (measured in round 2's soak within a factor of three; exact Log2Hot near 1 -- tried in round 3 -- does not
+    change the offenders: the difference is W_k's last place)."""
+    A, D, _ = case.kb()
+    pr = np.array(priors, dtype=np.float64).copy()
+    valid = np.ones(case.T, dtype=bool)
+    valid[list(case.tgaps)] = False
+    pr[~valid] = 0.0
+    best = np.inf
+    for q in range(case.Q):
+        if q in case.qgaps:
+            continue
+        lh = (A[q] / D[q][None, :]) * pr[None, :]           # [K, T]
+        W = lh.sum(axis=1, keepdims=True)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            p = np.where(W > 0, lh / W, 0.0)
+            l2 = np.abs(np.log2(p[:, valid][p[:, valid] > 0]))
+        if l2.size:
+            best = min(best, float(l2.min()))
+    return best
