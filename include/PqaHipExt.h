@@ -84,6 +84,13 @@ PQACORE_API int64_t PqaEngine_NextQuestionSampled(void *pvEngine, void **ppError
  * of nQuizzes x PqaEngine_NextQuestion (reference PqaCore/CpuEngine.cpp:337-415 serves them one sweep at a time). */
 PQACORE_API void *PqaEngine_NextQuestionArgmaxBatch(void *pvEngine, const int64_t nQuizzes, const int64_t *pQuizzes,
                                                     int64_t *pQuestions);
+/* RecordAnswer for nQuizzes quizzes (each with an active question) in one call and ONE launch -- every posterior bit-identical to
+ * PqaEngine_RecordAnswer's (reference PqaCore/CERecordAnswerSubtaskMul.cpp:15-42 per quiz) -- and StartQuiz for nQuizzes new
+ * quizzes likewise (pQuizzes receives their ids; all or none).  What a server with many quizzes in flight calls beside
+ * PqaEngine_NextQuestionArgmaxBatch; concurrent PqaEngine_RecordAnswer calls of different client threads are gathered into the
+ * same batched launch by the engine itself (option "combine"). */
+PQACORE_API void *PqaEngine_RecordAnswerBatch(void *pvEngine, const int64_t nQuizzes, const int64_t *pQuizzes, const int64_t *pAnswers);
+PQACORE_API void *PqaEngine_StartQuizBatch(void *pvEngine, const int64_t nQuizzes, int64_t *pQuizzes);
 /* The priority vectors of nQuizzes <= 256 distinct quizzes from ONE sweep that reads the cube once for the whole batch
  * (batch_kernels.hip): pOut[i * nLocalQuestions + q] = priority of local question q for pQuizzes[i], 0 for gap / asked
  * questions.  The deterministic output behind PqaEngine_NextQuestionArgmaxBatch's row-sharing form. */

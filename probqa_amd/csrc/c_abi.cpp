@@ -415,6 +415,14 @@ PQACORE_API void *PqaEngine_NextQuestionArgmaxBatch(void *pvEngine, const int64_
   ENGINE_OR_RETURN_ERROR;
   return ReturnErr(pEng->NextQuestionArgmaxBatch(nQuizzes, pQuizzes, pQuestions));
 }
+PQACORE_API void *PqaEngine_RecordAnswerBatch(void *pvEngine, const int64_t nQuizzes, const int64_t *pQuizzes, const int64_t *pAnswers) {
+  ENGINE_OR_RETURN_ERROR;
+  return ReturnErr(pEng->RecordAnswerBatch(nQuizzes, pQuizzes, pAnswers));
+}
+PQACORE_API void *PqaEngine_StartQuizBatch(void *pvEngine, const int64_t nQuizzes, int64_t *pQuizzes) {
+  ENGINE_OR_RETURN_ERROR;
+  return ReturnErr(pEng->StartQuizBatch(nQuizzes, pQuizzes));
+}
 PQACORE_API void *PqaHip_SelectArgmaxBatch(void *pvEngine, const int64_t nQuizzes, const int64_t *pQuizzes, CiHipSelection *pOut) {
   ENGINE_OR_RETURN_ERROR;
   return ReturnErr(pEng->SelectArgmaxBatch(nQuizzes, pQuizzes, pOut));

@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <cstddef>
 #include <cstdio>
 #include <cstring>
 #include <random>
@@ -582,8 +583,14 @@ int64_t HipEngine::CreateQuiz(Error &err, int64_t nAnswered, const AQ *pAQs, con
     for (int64_t i = 0; i < nAnswered; i++) quiz->answers.push_back(pAQs[i]);
   } else if (nAnswered == 0) {
     // CECreateQuizStart::UpdateLikelihoods, reference PqaCore/CECreateQuizOperation.cpp:22-53
-    he = LaunchStartQuiz(kb, quiz->dPrior, quiz->dAsked, (int64_t)quiz->hAsked.size(), _optWorkers, _stream);
-    if (he != hipSuccess) return fail(HipErr(he, "LaunchStartQuiz"));
+    if (_startBatch != nullptr) {   // StartQuizBatch: one launch for all its quizzes
+      _startBatch->prior[_startBatch->n] = quiz->dPrior;
+      _startBatch->asked[_startBatch->n] = quiz->dAsked;
+      _startBatch->n++;
+    } else {
+      he = LaunchStartQuiz(kb, quiz->dPrior, quiz->dAsked, (int64_t)quiz->hAsked.size(), _optWorkers, _stream);
+      if (he != hipSuccess) return fail(HipErr(he, "LaunchStartQuiz"));
+    }
     // no synchronisation: every reader of the prior or the bitmap is ordered behind these on the engine's stream
   } else {
     // CECreateQuizResume::UpdateLikelihoods, reference PqaCore/CECreateQuizOperation.cpp:55-83
@@ -1787,6 +1794,62 @@ Error HipEngine::EvalPriorities(int64_t iQuiz, double *pOut, int64_t n) {
 Error HipEngine::RecordAnswerImpl(int64_t iQuiz, int64_t iAnswer, bool remote) {
   CallScope scope(_activeCallers);
   std::lock_guard<EngineMutex> lk(_mu);
+  return RecordAnswerLocked(iQuiz, iAnswer, remote, !Concurrent());
+}
+
+// Several quizzes' answers in one call and ONE launch (grid.x = quiz: record_answer_batch_kernel; every quiz's posterior is the
+// one RecordAnswer gives it, bit for bit -- the same workgroup code and summation order).  Quiz i must have an active question
+// (NextQuestion / SetActiveQuestion).  An invalid entry fails the call; the entries before it stay recorded.
+Error HipEngine::RecordAnswerBatch(int64_t n, const int64_t *pQuizzes, const int64_t *pAnswers) {
+  if (n < 0) return Error::MakeP(ErrCode::NegativeCount, "count=" + std::to_string(n), "|nQuizzes| must be non-negative.");
+  if (n > 0 && (!pQuizzes || !pAnswers)) return Error::Make(ErrCode::NullArgument, "Nullptr is passed in place of a batch buffer.");
+  CallScope scope(_activeCallers);
+  std::lock_guard<EngineMutex> lk(_mu);
+  Error first;
+  for (int64_t i = 0; i < n && first.ok(); i++) first = RecordAnswerLocked(pQuizzes[i], pAnswers[i], false, false);
+  Error fe = FlushUpdates();
+  return first.ok() ? fe : first;
+}
+
+// n new quizzes and ONE launch for their priors (grid.x = quiz).  All or nothing.
+Error HipEngine::StartQuizBatch(int64_t n, int64_t *pQuizzes) {
+  if (n < 0) return Error::MakeP(ErrCode::NegativeCount, "count=" + std::to_string(n), "|nQuizzes| must be non-negative.");
+  if (n > 0 && !pQuizzes) return Error::Make(ErrCode::NullArgument, "Nullptr is passed in place of a batch buffer.");
+  CallScope scope(_activeCallers);
+  std::lock_guard<EngineMutex> lk(_mu);
+  hipSetDevice(_device);
+  StartBatchInline batch;
+  batch.n = 0;
+  batch.askedWords = (int64_t)BitWords(_Q);
+  Error err;
+  auto launch = [&]() -> Error {
+    if (batch.n == 0) return Error();
+    HIP_TRY(LaunchStartQuizBatch(View(), batch, _optWorkers, _stream));
+    batch.n = 0;
+    return Error();
+  };
+  int64_t made = 0;
+  for (; made < n; made++) {
+    _startBatch = &batch;
+    pQuizzes[made] = CreateQuiz(err, 0, nullptr, nullptr, nullptr, 0, nullptr);
+    _startBatch = nullptr;
+    if (pQuizzes[made] < 0) break;
+    if (batch.n == kStartInline) { err = launch(); if (!err.ok()) { made++; break; } }
+  }
+  if (err.ok()) err = launch();
+  if (!err.ok()) {   // roll back: the call creates all its quizzes or none
+    for (int64_t i = 0; i < made; i++)
+      if (pQuizzes[i] >= 0 && (size_t)pQuizzes[i] < _quizzes.size() && _quizzes[(size_t)pQuizzes[i]]) {
+        Quiz *q = _quizzes[(size_t)pQuizzes[i]];
+        UnassignQuiz(pQuizzes[i]);
+        DestroyQuiz(q);
+      }
+    return err;
+  }
+  return Error();
+}
+
+Error HipEngine::RecordAnswerLocked(int64_t iQuiz, int64_t iAnswer, bool remote, bool flushNow) {
   Error err = CheckRegular("record an answer");
   if (!err.ok()) return err;
   if (iAnswer < 0 || iAnswer >= _K)  // reference PqaCore/BaseEngine.cpp:447-451
@@ -1823,7 +1886,7 @@ Error HipEngine::RecordAnswerImpl(int64_t iQuiz, int64_t iAnswer, bool remote) {
   q->updatePending = true;
   // Other client threads inside the engine: leave the kernel to whoever next needs a posterior -- it runs all the updates that
   // have gathered by then in one launch.  Alone: launch now, and the sweep of the NextQuestion that follows right behind it.
-  if (Concurrent()) return Error();
+  if (!flushNow) return Error();
   Error fe = FlushUpdates();
   if (!fe.ok()) return fe;
   Speculate(q);
@@ -1864,15 +1927,17 @@ Error HipEngine::FlushUpdates() {
     }
     return Error();
   }
+  static_assert(kQuizTopDev == kQuizTop && offsetof(QuizPinned, nOut) == kQuizTop * sizeof(RatedTargetDev) &&
+                offsetof(QuizPinned, topFlag) == offsetof(QuizPinned, nOut) + 8, "the batched kernel addresses the quiz's lines by layout");
   const KbView kb = View();
+  static thread_local RecordBatchInline b;   // (10 KB: not on a client thread's stack for every flush)
   for (size_t first = 0; first < ups.size(); first += kRecordInline) {
-    RecordBatchInline b;
     b.n = (int32_t)std::min<size_t>(kRecordInline, ups.size() - first);
     b.topCount = (int32_t)topCount;
     for (int32_t i = 0; i < b.n; i++) {
       const PendingUpdate &u = ups[first + (size_t)i];
       const uint64_t op = ++_opSeq;
-      b.s[i] = RecordSlot{u.q->dPrior, u.q->dAsked, (int32_t)u.qLocal, (int32_t)u.iAnswer, u.q->pin->top, &u.q->pin->nOut, &u.q->pin->topFlag, op};
+      b.s[i] = RecordSlot{u.q->dPrior, u.q->dAsked, u.q->pin, (int32_t)u.qLocal, (int32_t)u.iAnswer, op};
       listed(u.q, op);
     }
     HIP_TRY(LaunchRecordAnswerBatch(kb, b, nLoose, _stream));

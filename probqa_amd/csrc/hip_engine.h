@@ -166,6 +166,8 @@ class IEngine {
   virtual Error EnqueueEval(int64_t iQuiz) = 0;
   virtual Error GetPriorDevicePtr(int64_t iQuiz, void **ppDev, int64_t *pLdT) = 0;
   virtual Error RecordAnswerRemote(int64_t iQuiz, int64_t iAnswer) = 0;
+  virtual Error RecordAnswerBatch(int64_t n, const int64_t *pQuizzes, const int64_t *pAnswers) = 0;
+  virtual Error StartQuizBatch(int64_t n, int64_t *pQuizzes) = 0;
 };
 
 class HipEngine : public IEngine {
@@ -227,6 +229,8 @@ class HipEngine : public IEngine {
   Error EnqueueEval(int64_t iQuiz) override;
   Error GetPriorDevicePtr(int64_t iQuiz, void **ppDev, int64_t *pLdT) override;
   Error RecordAnswerRemote(int64_t iQuiz, int64_t iAnswer) override;
+  Error RecordAnswerBatch(int64_t n, const int64_t *pQuizzes, const int64_t *pAnswers) override;
+  Error StartQuizBatch(int64_t n, int64_t *pQuizzes) override;
 
   // ---- what a sharded engine needs from its shards (sharded_engine.cpp)
   int Device() const { return _device; }
@@ -278,6 +282,8 @@ class HipEngine : public IEngine {
   int64_t FindNearestQuestion(int64_t iMiddleGlobal, const Quiz *q) const;  // BaseEngine.cpp:60-124
   bool QuestionUnavailable(const Quiz *q, int64_t qGlobal) const;
   Error RecordAnswerImpl(int64_t iQuiz, int64_t iAnswer, bool remote);
+  Error RecordAnswerLocked(int64_t iQuiz, int64_t iAnswer, bool remote, bool flushNow);
+  StartBatchInline *_startBatch = nullptr;   // StartQuizBatch: CreateQuiz queues the new quizzes' buffers here instead of launching
   void BuildTrainSteps(int64_t n, const AQ *pAQs, bool fromQuiz, std::vector<TrainStep> &steps, std::vector<int64_t> &chainStart) const;
   Error TrainLocked(int64_t nQuestions, const AQ *pAQs, int64_t iTarget, double amount, bool fromQuiz);
   Error ValidateTrainLocked(int64_t nQuestions, const AQ *pAQs, int64_t iTarget) const;

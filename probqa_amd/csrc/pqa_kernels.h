@@ -224,21 +224,29 @@ hipError_t LaunchRecordAnswer(const KbView &kb, double *prior, uint32_t *asked, 
 // Several quizzes' RecordAnswer in ONE launch (grid.x = update; the same workgroup code and summation order per quiz as
 // LaunchRecordAnswer, so every posterior is bit-identical to the one-by-one result): up to kRecordInline updates travel in the
 // kernel's arguments.  CERecordAnswerSubtaskMul.cpp:15-42 per quiz; the reference runs concurrent quizzes' updates side by side.
-constexpr int kRecordInline = 40;
-struct RecordSlot {
+constexpr int kRecordInline = 256;
+struct RecordSlot {               // 40 bytes: 256 of them are 10 KB of kernel arguments
   double *prior;
   uint32_t *asked;
+  void *pin;                      // the quiz's host-coherent lines {RatedTargetDev top[kQuizTopDev]; int64 nOut; uint64 topFlag} (optional)
   int32_t iQuestion, iAnswer;     // local question
-  RatedTargetDev *topOut;         // host-coherent lines of the quiz (optional)
-  int64_t *topN;
-  uint64_t *topFlag;
   uint64_t topFlagValue;
 };
+constexpr int kQuizTopDev = 32;   // == kQuizTop (hip_engine.h)
 struct RecordBatchInline {
   int32_t n, topCount;
   RecordSlot s[kRecordInline];
 };
 hipError_t LaunchRecordAnswerBatch(const KbView &kb, const RecordBatchInline &batch, int64_t nWorkers, hipStream_t stream);
+// Several quizzes' StartQuiz in ONE launch (grid.x = quiz; every workgroup runs CESetPriorsSubtaskSum exactly as LaunchStartQuiz).
+constexpr int kStartInline = 256;
+struct StartBatchInline {
+  int32_t n;
+  int64_t askedWords;
+  double *prior[kStartInline];
+  uint32_t *asked[kStartInline];
+};
+hipError_t LaunchStartQuizBatch(const KbView &kb, const StartBatchInline &batch, int64_t nWorkers, hipStream_t stream);
 // rows: device array of 2 nAnswered row pointers, {sA[q_i][a_i], mD[q_i]} per answered question (rows of kb.elem-byte elements,
 // ldT long; they may live on another device of the process).  exps: scratch of ldT int64.  status: device int64[2]
 // {error code (0 / 16 = I64Underflow), fullMax}.  bugCompat reproduces PqaCore/CEUpdatePriorsSubtaskMul.cpp:53.

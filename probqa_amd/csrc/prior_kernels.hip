@@ -41,6 +41,19 @@ __global__ __launch_bounds__(kThreads) void start_quiz_kernel(PriorArgs a, uint3
   for (int64_t t = threadIdx.x; t < a.ldT; t += blockDim.x) a.prior[t] = t < 4 * nVects ? stage[t] / total : stage[t];  // CEDivTargPriors :19
 }
 
+__global__ __launch_bounds__(kThreads) void start_quiz_batch_kernel(PriorArgs a, StartBatchInline batch) {
+  extern __shared__ double lds[];
+  uint32_t *asked = batch.asked[blockIdx.x];
+  a.prior = batch.prior[blockIdx.x];
+  for (int64_t i = threadIdx.x; i < batch.askedWords; i += blockDim.x) asked[i] = 0;
+  const int64_t nVects = (a.T + 3) >> 2;
+  double *stage = prior_stage(a, lds);
+  for (int64_t t = threadIdx.x; t < a.ldT; t += blockDim.x)
+    stage[t] = bit_test(a.tgap, t) ? 0.0 : a.vB[t];            // CESetPriorsSubtaskSum.cpp:28-31
+  const double total = reference_order_sum(stage, nVects, a.nWorkers, lds);
+  for (int64_t t = threadIdx.x; t < a.ldT; t += blockDim.x) a.prior[t] = t < 4 * nVects ? stage[t] / total : stage[t];  // CEDivTargPriors :19
+}
+
 template <bool SMALL>
 __global__ __launch_bounds__(SMALL ? kSmallThreads : kThreads) void record_answer_kernel(PriorArgs a, int64_t iQuestion, int64_t iAnswer,
                                                                                          uint32_t *asked, TopRequest top) {
@@ -56,7 +69,9 @@ __global__ __launch_bounds__(SMALL ? kSmallThreads : kThreads) void record_answe
   __shared__ TopScratch topScratch;
   const RecordSlot &s = batch.s[blockIdx.x];
   a.prior = s.prior;
-  const TopRequest top{reinterpret_cast<TopOut *>(s.topOut), s.topN, s.topFlag, s.topFlagValue, s.topOut ? (int64_t)batch.topCount : 0};
+  TopOut *topOut = reinterpret_cast<TopOut *>(s.pin);
+  int64_t *topN = reinterpret_cast<int64_t *>(topOut + kQuizTopDev);
+  const TopRequest top{topOut, topN, reinterpret_cast<uint64_t *>(topN + 1), s.topFlagValue, s.pin ? (int64_t)batch.topCount : 0};
   record_answer_body<SMALL, false>(a, s.iQuestion, s.iAnswer, s.asked, top, lds, &topScratch);
 }
 
@@ -179,6 +194,13 @@ hipError_t LaunchRecordAnswer(const KbView &kb, double *prior, uint32_t *asked, 
   else
     hipLaunchKernelGGL(record_answer_kernel<false>, dim3(1), dim3(kThreads), staged_lds_bytes(kb, nWorkers), stream,
                        make_args(kb, prior, nWorkers, true), iQuestion, iAnswer, asked, top);
+  return hipGetLastError();
+}
+
+hipError_t LaunchStartQuizBatch(const KbView &kb, const StartBatchInline &batch, int64_t nWorkers, hipStream_t stream) {
+  if (nWorkers < 1 || nWorkers > kMaxWorkers || batch.n < 1 || batch.n > kStartInline) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(start_quiz_batch_kernel, dim3((unsigned)batch.n), dim3(kb.T <= 4 * kSmallThreads ? kSmallThreads : kThreads),
+                     staged_lds_bytes(kb, nWorkers), stream, make_args(kb, nullptr, nWorkers, true), batch);
   return hipGetLastError();
 }
 

@@ -234,6 +234,20 @@ class ShardedEngine final : public IEngine {
   Error EnqueueEval(int64_t iQuiz) override { return All([&](HipEngine &e) { return e.EnqueueEval(iQuiz); }); }
   Error GetPriorDevicePtr(int64_t iQuiz, void **ppDev, int64_t *pLdT) override { return _sh[0]->GetPriorDevicePtr(iQuiz, ppDev, pLdT); }
   Error RecordAnswerRemote(int64_t, int64_t) override { return NotSharded("RecordAnswerRemote"); }
+  Error RecordAnswerBatch(int64_t n, const int64_t *pQuizzes, const int64_t *pAnswers) override {   // (each answer on the shard that owns its question)
+    if (n > 0 && (!pQuizzes || !pAnswers)) return Error::Make(ErrCode::NullArgument, "Nullptr is passed in place of a batch buffer.");
+    for (int64_t i = 0; i < n; i++) { Error e = RecordAnswer(pQuizzes[i], pAnswers[i]); if (!e.ok()) return e; }
+    return Error();
+  }
+  Error StartQuizBatch(int64_t n, int64_t *pQuizzes) override {
+    if (n > 0 && !pQuizzes) return Error::Make(ErrCode::NullArgument, "Nullptr is passed in place of a batch buffer.");
+    for (int64_t i = 0; i < n; i++) {
+      Error e;
+      pQuizzes[i] = StartQuiz(e);
+      if (pQuizzes[i] < 0) { for (int64_t j = 0; j < i; j++) (void)ReleaseQuiz(pQuizzes[j]); return e; }
+    }
+    return Error();
+  }
 
  private:
   ShardedEngine() = default;

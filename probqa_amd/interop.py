@@ -143,6 +143,8 @@ HIP_EXPORTS = {
     "PqaHip_EnqueueEval": (_vp, [_vp, _i64]),
     "PqaHip_GetPriorDevicePtr": (_vp, [_vp, _i64, _pvp, _pi64]),
     "PqaHip_RecordAnswerRemote": (_vp, [_vp, _i64, _i64]),
+    "PqaEngine_RecordAnswerBatch": (_vp, [_vp, _i64, _pi64, _pi64]),
+    "PqaEngine_StartQuizBatch": (_vp, [_vp, _i64, _pi64]),
 }
 
 _lib = None
@@ -614,6 +616,19 @@ class PqaEngine:
         ld = ctypes.c_int64()
         _check(_lib.PqaHip_GetPriorDevicePtr(self.c_engine, i_quiz, ctypes.byref(dev), ctypes.byref(ld)))
         return dev.value or 0, ld.value
+
+    def record_answer_batch(self, quizzes, answers):
+        """RecordAnswer of several quizzes (each with an active question) in one launch."""
+        n = len(quizzes)
+        qs = (ctypes.c_int64 * max(n, 1))(*quizzes)
+        ans = (ctypes.c_int64 * max(n, 1))(*answers)
+        _check(_lib.PqaEngine_RecordAnswerBatch(self.c_engine, n, qs, ans))
+
+    def start_quiz_batch(self, n: int) -> List[int]:
+        """n new quizzes, one launch for their priors."""
+        out = (ctypes.c_int64 * max(n, 1))()
+        _check(_lib.PqaEngine_StartQuizBatch(self.c_engine, n, out))
+        return list(out[:n])
 
     def record_answer_remote(self, i_quiz: int, i_answer: int):
         _check(_lib.PqaHip_RecordAnswerRemote(self.c_engine, i_quiz, i_answer))

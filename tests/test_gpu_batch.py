@@ -375,3 +375,50 @@ def test_float_batched_argmax_is_the_fp64_argmax(case, factory):
     print(case.name, ": fp64 argmax picked in %d / %d quizzes with the re-rank (%d decided beyond 1e-9), %d / %d by fp32 alone"
           % (same, len(quizzes), decided, same32, len(quizzes)))
     eng.close()
+
+
+@pytest.mark.parametrize("dims", [(5, 40, 300), (4, 30, 20000), (3, 20, 1100)], ids=lambda d: "%dx%dx%d" % (d[1], d[0], d[2]))
+def test_batched_posterior_updates_are_bit_identical(dims, factory):
+    """PqaEngine_StartQuizBatch / PqaEngine_RecordAnswerBatch: n quizzes' StartQuiz / RecordAnswer in ONE
+    launch each (grid.x = quiz; the workgroup code and summation order of the one-quiz kernels), against the same calls one by
+    one AND the oracle: posteriors bit for bit, top targets, and the deferred form the engine uses for concurrent clients.
+    Rows of 20000 targets: beyond the LDS staging and the in-kernel top listing."""
+    K, Q, T = dims
+    case = cases.Case("updbatch", K, Q, T, seed=T, qgaps=[2], tgaps=[1, T - 2])
+    eng = case.make_engine(factory)
+    orc = case.make_oracle()
+    n = 150
+    rng = np.random.default_rng(T)
+    batch = eng.start_quiz_batch(n)
+    singles = [eng.start_quiz() for _ in range(n)]
+    assert len(set(batch + singles)) == 2 * n
+    orc.start_quiz(cases.WORKERS)
+    p0 = orc.priors()
+    for z in (batch[0], batch[77], batch[-1], singles[3]):
+        assert np.array_equal(eng.get_priors(z), p0)
+    valid = [q for q in range(Q) if q not in case.qgaps]
+    for step in range(2):
+        qs = [int(valid[int(rng.integers(len(valid)))]) for _ in range(n)]
+        ans = [int(rng.integers(K)) for _ in range(n)]
+        for i in range(n):
+            for z in (batch[i], singles[i]):
+                if step == 1 and qs[i] in [q for q, _ in hist[i]]:
+                    qs[i] = next(q for q in valid if q not in [x for x, _ in hist[i]])
+                eng.set_active_question(z, qs[i])
+        if step == 0:
+            hist = [[] for _ in range(n)]
+        eng.record_answer_batch(batch, ans)
+        for i in range(n):
+            eng.record_answer(singles[i], ans[i])
+            hist[i].append((qs[i], ans[i]))
+        for i in range(0, n, 13):
+            a, b = eng.get_priors(batch[i]), eng.get_priors(singles[i])
+            assert np.array_equal(a, b), f"step {step} quiz {i}"
+            _, opriors = oracle_priorities(orc, hist[i])
+            assert np.array_equal(a, opriors), f"step {step} quiz {i}: oracle"
+            ta, tb2 = eng.list_top_targets(batch[i], 5), eng.list_top_targets(singles[i], 5)
+            assert [(t.i_target, t.prob) for t in ta] == [(t.i_target, t.prob) for t in tb2]
+    assert eng.get_option("update_max_flush") >= n
+    with pytest.raises(interop.PqaException, match="active question"):
+        eng.record_answer_batch([batch[0]], [0])            # no active question any more
+    eng.close()
