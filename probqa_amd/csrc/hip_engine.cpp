@@ -765,6 +765,25 @@ int64_t FindNearestInPacks(int64_t iMiddle, int64_t nQuestions, const std::funct
 // per-subtask Kahan run lengths (CEEvalQsSubtaskConsider.cpp:52-58, :212-214), Kahan grand totals and two upper_bounds as
 // select_sampled_wg_impl (pqa_device.h) -- operation for operation, so with the same priorities, subtask count and random number it
 // picks the same question.  run: priorities in, run lengths out.  Returns the pick before the gap / asked fallback (:403-407).
+// The reference reports numeric anomalies of a sweep in its log -- non-finite grand totals of the priorities (CpuEngine.cpp:370-373),
+// a non-positive grand total (:375-377), a priority that is not a positive finite number (CEEvalQsSubtaskConsider.cpp:209-211) --
+// and goes on.  So does this engine, for what reaches the host: the selected question's priority, the totals of the sampled
+// selector.  (NaN never wins an argmax here, so a NaN winner means that every available question's priority is NaN.)  At most
+// kAnomalyLogLimit entries per process: a broken knowledge base would otherwise write one per selection.
+namespace {
+std::atomic<int> gAnomaliesLogged{0};
+constexpr int kAnomalyLogLimit = 200;
+}  // namespace
+void LogAnomaly(DefaultLogger::Severity sev, const char *what, double value) {
+  if (gAnomaliesLogged.fetch_add(1, std::memory_order_relaxed) >= kAnomalyLogLimit) return;
+  char buf[64];
+  std::snprintf(buf, sizeof(buf), "%.17g", value);
+  DefaultLogger::Log(sev, std::string(what) + buf);
+}
+void CheckPriority(double priority, int64_t index) {   // CEEvalQsSubtaskConsider.cpp:209-211, for the question that was selected
+  if (index >= 0 && !(priority > 0 && std::isfinite(priority))) LogAnomaly(DefaultLogger::Severity::Warning, "Got priority=", priority);
+}
+
 int64_t SelectSampledHost(double *run, int64_t n, int64_t nWorkers, uint64_t rnd, const std::function<bool(int64_t)> &skipped) {
   struct Kahan {                 // SRAccumulator<SRDoubleNumber> (SRPlatform/Interface/SRAccumulator.h:15-39)
     double sum = 0, corr = 0;
@@ -783,8 +802,14 @@ int64_t SelectSampledHost(double *run, int64_t n, int64_t nWorkers, uint64_t rnd
     grand[(size_t)s] = acc.get();
   }
   Kahan tot;                                                     // CpuEngine.cpp:362-368
-  for (int64_t s = 0; s < nSubtasks; s++) { tot.add(grand[(size_t)s]); grand[(size_t)s] = tot.get(); }
+  for (int64_t s = 0; s < nSubtasks; s++) {
+    tot.add(grand[(size_t)s]);
+    grand[(size_t)s] = tot.get();
+    if (!std::isfinite(grand[(size_t)s]))                          // :370-373
+      LogAnomaly(DefaultLogger::Severity::Error, "Overflow or underflow has happened in the question evaluation subtasks: ", grand[(size_t)s]);
+  }
   const double totG = grand[(size_t)nSubtasks - 1];
+  if (totG <= 0) LogAnomaly(DefaultLogger::Severity::Warning, "Grand-grand total is ", totG);   // :375-377
   const double selRunLen = totG * (double)rnd / 18446744073709551615.0;   // :379, SRDoubleNumber::MakeRandom
   const int64_t iWorker = std::upper_bound(grand.begin(), grand.end(), selRunLen) - grand.begin();   // :380-381
   if (iWorker >= nSubtasks) return n - 1;                         // :384
@@ -997,7 +1022,8 @@ int64_t HipEngine::NextQuestionArgmaxLocked(Error &err, int64_t iQuiz) {
       err = HipErr(hipErrorLaunchFailure, "NextQuestionArgmax (incomplete sweep)");
       return -1;
     }
-    return FinishSelection(err, q, _hPinned->sel.index);
+    CheckPriority(_hPinned->sel.priority, _hPinned->sel.index);
+  return FinishSelection(err, q, _hPinned->sel.index);
   }
   // One launch; the last workgroup writes the winner and then a sequence number straight into host-coherent pinned
   // memory, which this thread polls: no D2H copy, no stream synchronisation on the critical path.
@@ -1016,6 +1042,7 @@ int64_t HipEngine::NextQuestionArgmaxLocked(Error &err, int64_t iQuiz) {
     err = HipErr(hipErrorLaunchFailure, "NextQuestionArgmax (incomplete sweep)");
     return -1;
   }
+  CheckPriority(_hPinned->sel.priority, _hPinned->sel.index);
   return FinishSelection(err, q, _hPinned->sel.index);
 }
 
@@ -1281,6 +1308,7 @@ Error HipEngine::CollectBatchSelectionsLocked(int64_t n, uint64_t tag, CiHipSele
   if (!err.ok()) return err;
   for (int64_t i = 0; i < n; i++) {
     if (c.h->out[i].index == -3) return HipErr(hipErrorLaunchFailure, "batched selection (incomplete sweep)");
+    CheckPriority(c.h->out[i].priority, c.h->out[i].index);
     pOut[i]._priority = c.h->out[i].priority;
     pOut[i]._iQuestion = c.h->out[i].index < 0 ? -1 : c.h->out[i].index + _qFirst;
   }
@@ -1421,6 +1449,7 @@ int64_t HipEngine::NextQuestionArgmaxGraph(Error &err, Quiz *q) {
   err = WaitFlag(&_hPinned->seq, expect, "NextQuestionArgmax (graph)");
   if (!err.ok()) return -1;
   if (_hPinned->sel.index == -3) { err = HipErr(hipErrorLaunchFailure, "NextQuestionArgmax (incomplete sweep)"); return -1; }
+  CheckPriority(_hPinned->sel.priority, _hPinned->sel.index);
   return FinishSelection(err, q, _hPinned->sel.index);
 }
 
@@ -1482,7 +1511,8 @@ int64_t HipEngine::NextQuestionSampledLocked(Error &err, int64_t iQuiz, uint64_t
     err = WaitFlag(&_hPinned->seq, seq, "NextQuestionSampled");
     if (!err.ok()) return -1;
     if (_hPinned->sel.index == -3) { err = HipErr(hipErrorLaunchFailure, "NextQuestionSampled (incomplete sweep)"); return -1; }
-    return FinishSelection(err, q, _hPinned->sel.index);
+    CheckPriority(_hPinned->sel.priority, _hPinned->sel.index);
+  return FinishSelection(err, q, _hPinned->sel.index);
   }
   if (took != 3) {   // (else: the priorities are in _dPriority already, or on their way there in stream order)
     err = LaunchSingleSweep(q, nullptr);
@@ -1496,6 +1526,7 @@ int64_t HipEngine::NextQuestionSampledLocked(Error &err, int64_t iQuiz, uint64_t
   if (he != hipSuccess) { err = HipErr(he, "NextQuestionSampled"); return -1; }
   err = WaitFlag(&_hPinned->opFlag, op, "NextQuestionSampled");
   if (!err.ok()) return -1;
+  CheckPriority(_hPinned->sel.priority, _hPinned->sel.index);
   return FinishSelection(err, q, _hPinned->sel.index);
 }
 
@@ -1764,6 +1795,7 @@ bool HipEngine::CollectBatch(BatchCtx &c, std::vector<SelRequest *> &batch, Flig
       continue;
     }
     if (c.h->out[i].index == -3) { r->err = HipErr(hipErrorLaunchFailure, "combined selection (incomplete sweep)"); r->result = -1; continue; }
+    CheckPriority(c.h->out[i].priority, c.h->out[i].index);
     r->result = FinishSelection(r->err, q, c.h->out[i].index);
   }
   _combNs[3] += ns(tD, tE);

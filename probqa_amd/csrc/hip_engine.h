@@ -267,6 +267,15 @@ class HipEngine : public IEngine {
   Error CollectBatchPriorities(int64_t n, double *pOut);
   Error ValidateTrain(int64_t nQuestions, const AQ *pAQs, int64_t iTarget, int64_t iQuiz);
   bool IsRegularMode() const { return _mode == Mode::Regular; }
+  bool IsMaintenanceMode() const { return _mode == Mode::Maintenance; }
+  double InitAmount() const { return _initAmount; }
+  const void *QuestionBlock(int64_t qLocal) const { return CubeAt(qLocal); }
+  const double *VBDevicePtr() const { return _dVB; }
+  // a rebuilt shard takes its questions' rows from the old shards' cubes (in place, over peer access) ...
+  Error AdoptRows(const std::vector<const void *> &srcBlocks, int64_t ldTsrc, const std::vector<int64_t> &colMap, const double *srcVB);
+  // ... and initialises added target columns and questions as CpuEngine::AddQsTsSpec does (CpuEngine.cpp:497-567)
+  Error ApplyFills(const std::vector<int64_t> &tIds, const std::vector<double> &tInit, const std::vector<int64_t> &qLocalIds,
+                   const std::vector<double> &qInit);
   const PermIdMgr &QuizPim() const { return _pimQuizzes; }
 
  private:
@@ -557,6 +566,8 @@ class HipEngine : public IEngine {
   uint64_t _rng[2] = {0, 0};
 };
 
+void LogAnomaly(DefaultLogger::Severity sev, const char *what, double value);   // the reference's numeric-anomaly log entries (rate-limited)
+void CheckPriority(double priority, int64_t index);
 int64_t SelectSampledHost(double *run, int64_t n, int64_t nWorkers, uint64_t rnd, const std::function<bool(int64_t)> &skipped);
 int64_t FindNearestInPacks(int64_t iMiddle, int64_t nQuestions, const std::function<uint64_t(int64_t)> &avail);
 // One knowledge base over several devices of this process (sharded_engine.cpp); devices.size() >= 2.

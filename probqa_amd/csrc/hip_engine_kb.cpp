@@ -511,6 +511,44 @@ Error HipEngine::AddQsTs(int64_t nQuestions, CiAddQorTParam *pAqps, int64_t nTar
   return UploadGaps();
 }
 
+Error HipEngine::AdoptRows(const std::vector<const void *> &srcBlocks, int64_t ldTsrc, const std::vector<int64_t> &colMap, const double *srcVB) {
+  std::lock_guard<EngineMutex> lk(_mu);
+  StopServer();
+  if ((int64_t)srcBlocks.size() != _Q || (int64_t)colMap.size() != _T)
+    return Error::Make(ErrCode::Internal, "AdoptRows: the maps do not have this shard's dimensions.");
+  hipSetDevice(_device);
+  const void **dSrc = nullptr;
+  int64_t *dMap = nullptr;
+  hipError_t he = Upload(&dSrc, srcBlocks, _stream);
+  if (he == hipSuccess) he = Upload(&dMap, colMap, _stream);
+  if (he == hipSuccess) he = LaunchAdoptRows(_dCube, _elem, _dVB, _K, _Q, _T, _ldT, dSrc, ldTsrc, srcVB, dMap, _stream);
+  if (he == hipSuccess) he = hipStreamSynchronize(_stream);
+  hipFree(dSrc);
+  hipFree(dMap);
+  if (he != hipSuccess) return HipErr(he, "AdoptRows");
+  return Error();
+}
+
+Error HipEngine::ApplyFills(const std::vector<int64_t> &tIds, const std::vector<double> &tInit, const std::vector<int64_t> &qLocalIds,
+                            const std::vector<double> &qInit) {
+  std::lock_guard<EngineMutex> lk(_mu);
+  StopServer();
+  hipSetDevice(_device);
+  DevBuf<int64_t> dQ, dT;
+  DevBuf<double> dQi, dTi;
+  HIP_TRY(Upload(&dQ.p, qLocalIds, _stream));
+  HIP_TRY(Upload(&dQi.p, qInit, _stream));
+  HIP_TRY(Upload(&dT.p, tIds, _stream));
+  HIP_TRY(Upload(&dTi.p, tInit, _stream));
+  // target columns over every question, then whole questions over every column (the reference skips the re-initialised
+  // questions in the first step only because the second overwrites them anyway, CpuEngine.cpp:558-560)
+  hipError_t he = LaunchFillTargets(_dCube, _elem, _dVB, _K, _ldT, _Q, nullptr, dT.p, dTi.p, (int64_t)tIds.size(), _stream);
+  if (he == hipSuccess) he = LaunchFillQuestions(_dCube, _elem, _K, _T, _ldT, dQ.p, dQi.p, (int64_t)qLocalIds.size(), _stream);
+  if (he == hipSuccess) he = hipStreamSynchronize(_stream);
+  if (he != hipSuccess) return HipErr(he, "ApplyFills");
+  return Error();
+}
+
 // RemoveQuestions / RemoveTargets validate every id -- range, gaps, repeats within the call -- before the first one is removed:
 // a failing call changes nothing, on the host or on the device.  (The reference removes id by id and stops at the first
 // bad one, BaseEngine.cpp:722-765, leaving the earlier ones removed.)

@@ -178,7 +178,35 @@ __global__ __launch_bounds__(256) void move_targets_kernel(void *__restrict__ cu
   }
 }
 
+// Rebuild of a shard after a change of the dimensions (sharded_engine.cpp): question q of the new cube takes the rows of the
+// block src[q] -- which may live on another device of the process (peer access) -- with its columns picked by colMap (new
+// target t <- old target colMap[t]; -1: a new column, left as the fresh fill made it and initialised afterwards).
+__global__ __launch_bounds__(256) void adopt_rows_kernel(void *__restrict__ dst, int elem, int64_t K, int64_t nQ, int64_t Tn, int64_t ldTn,
+                                                         const void *const *__restrict__ src, int64_t ldTs,
+                                                         const int64_t *__restrict__ colMap) {
+  const int64_t per = (K + 1) * Tn, total = nQ * per;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t q = i / per, r = (i % per) / Tn, t = i % Tn;
+    const void *s = src[q];
+    const int64_t c = colMap[t];
+    if (s != nullptr && c >= 0) cube_st(dst, elem, (q * (K + 1) + r) * ldTn + t, cube_ld(s, elem, r * ldTs + c));
+  }
+}
+__global__ __launch_bounds__(256) void adopt_vb_kernel(double *__restrict__ dst, const double *__restrict__ src, const int64_t *__restrict__ colMap,
+                                                       int64_t Tn) {
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < Tn; t += (int64_t)gridDim.x * blockDim.x)
+    if (colMap[t] >= 0) dst[t] = src[colMap[t]];
+}
+
 }  // namespace
+
+hipError_t LaunchAdoptRows(void *dst, int elem, double *dstVB, int64_t K, int64_t nQ, int64_t Tn, int64_t ldTn, const void *const *src,
+                           int64_t ldTs, const double *srcVB, const int64_t *colMap, hipStream_t stream) {
+  if (nQ <= 0 || Tn <= 0) return hipSuccess;
+  hipLaunchKernelGGL(adopt_rows_kernel, dim3(grid_for(nQ * (K + 1) * Tn, 256)), dim3(256), 0, stream, dst, elem, K, nQ, Tn, ldTn, src, ldTs, colMap);
+  hipLaunchKernelGGL(adopt_vb_kernel, dim3(grid_for(Tn, 256)), dim3(256), 0, stream, dstVB, srcVB, colMap, Tn);
+  return hipGetLastError();
+}
 
 hipError_t LaunchFillQuestions(void *cube, int elem, int64_t K, int64_t T, int64_t ldT, const int64_t *qs, const double *inits,
                                int64_t n, hipStream_t stream) {

@@ -281,6 +281,10 @@ hipError_t LaunchFillQuestions(void *cube, int elem, int64_t K, int64_t T, int64
                                int64_t n, hipStream_t stream);
 hipError_t LaunchFillTargets(void *cube, int elem, double *vB, int64_t K, int64_t ldT, int64_t nQ, const uint32_t *skipQ,
                              const int64_t *ts, const double *inits, int64_t n, hipStream_t stream);
+// src: device array of nQ block pointers (question q's K + 1 rows, ldTs apart; nullptr: nothing to take), colMap: device array of
+// Tn old column indices (-1: a new column).  vB likewise.
+hipError_t LaunchAdoptRows(void *dst, int elem, double *dstVB, int64_t K, int64_t nQ, int64_t Tn, int64_t ldTn, const void *const *src,
+                           int64_t ldTs, const double *srcVB, const int64_t *colMap, hipStream_t stream);
 hipError_t LaunchMoveTargets(void *cube, int elem, double *vB, int64_t K, int64_t ldT, int64_t nQ, const int64_t *moves,
                              int64_t n, hipStream_t stream);
 // ListTopTargets (PqaCore/CEListTopTargetsAlgorithm.cpp): top maxCount (prob,target) pairs, descending, gaps skipped.

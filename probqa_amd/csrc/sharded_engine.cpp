@@ -141,10 +141,10 @@ class ShardedEngine final : public IEngine {
   bool RemapQuizPermId(int64_t a, int64_t b) override { bool ok = true; for (auto &s : _sh) ok = s->RemapQuizPermId(a, b) && ok; return ok; }
   Error SaveKB(const char *filePath, bool doubleBuffer) override;
   static ShardedEngine *Load(Error &err, const char *filePath, const std::vector<int> &devices);
-  Error AddQsTs(int64_t, CiAddQorTParam *, int64_t, CiAddQorTParam *) override { return NotSharded("AddQsTs"); }
-  Error RemoveQuestions(int64_t, const int64_t *) override { return NotSharded("RemoveQuestions"); }
-  Error RemoveTargets(int64_t, const int64_t *) override { return NotSharded("RemoveTargets"); }
-  Error Compact(int64_t *, const int64_t **, int64_t *, const int64_t **) override { return NotSharded("Compact"); }
+  Error AddQsTs(int64_t nQuestions, CiAddQorTParam *pAqps, int64_t nTargets, CiAddQorTParam *pAtps) override;
+  Error RemoveQuestions(int64_t n, const int64_t *pQIds) override;
+  Error RemoveTargets(int64_t n, const int64_t *pTIds) override;
+  Error Compact(int64_t *pnQuestions, const int64_t **ppOldQuestions, int64_t *pnTargets, const int64_t **ppOldTargets) override;
   Error ClearOldQuizzes(int64_t maxCount, double maxAgeSec) override;
 
   Error SetOption(const char *name, int64_t value) override {
@@ -185,7 +185,9 @@ class ShardedEngine final : public IEngine {
   Error SetTargetGaps(int64_t n, const int64_t *ids) override { return All([&](HipEngine &e) { return e.SetTargetGaps(n, ids); }); }
   Error SetQuestionGaps(int64_t n, const int64_t *ids) override {
     Error e = All([&](HipEngine &eng) { return eng.SetQuestionGaps(n, ids); });
-    if (e.ok()) for (int64_t i = 0; i < n; i++) _pimQuestions.RemoveComp(ids[i]);
+    if (e.ok())
+      for (int64_t i = 0; i < n; i++)
+        if (std::find(_qGapList.begin(), _qGapList.end(), ids[i]) == _qGapList.end()) { _qGapList.push_back(ids[i]); _pimQuestions.RemoveComp(ids[i]); }
     return e;
   }
   Error EvalPriorities(int64_t iQuiz, double *pOut, int64_t n) override {
@@ -295,6 +297,22 @@ class ShardedEngine final : public IEngine {
     _rng[1] = next();
   }
   int64_t _shardsInFlightMax = 0;
+  // ---- maintenance-mode edits of the dimensions (CpuEngine.cpp:468-658, BaseEngine.cpp:721-873): the ids are worked out HERE,
+  // over the global question axis, exactly as the unsharded engine works them out; the data moves by REBUILDING the shards --
+  // new shards over SRPoolRunner::CalcSplit of the new question count, every new question taking its rows from wherever the old
+  // shards hold them (in place over peer access, columns picked by the target map), all-or-nothing (the old shards stay until
+  // the new ones are complete).
+  std::vector<int64_t> _qGapList;           // global question gaps, LIFO like PqaCore/GapTracker.h (the shards keep bitmaps of their own)
+  std::vector<int> _devices;
+  Error Rebuild(int64_t newQ, int64_t newT, const std::vector<int64_t> &srcQ, const std::vector<int64_t> &srcT,
+                const std::vector<int64_t> &qGaps, const std::vector<int64_t> &tGaps, const PermIdMgr &pimT,
+                const std::vector<int64_t> &fillT, const std::vector<double> &fillTInit, const std::vector<int64_t> &fillQ,
+                const std::vector<double> &fillQInit);
+  Error MaintenanceOnly(const char *what) const {
+    if (_sh[0]->IsMaintenanceMode()) return Error();
+    return Error::Make(ErrCode::WrongMode, std::string("Can't perform maintenance-only mode operation - ") + what +
+                                               " - because current mode is not maintenance (but regular/shutdown?).");
+  }
   // BaseQuiz::OnUsage (BaseEngine.cpp:417) for the engine as a whole: the shards are touched at different times (ListTopTargets
   // reaches one of them, GetPriors shard 0), so which quizzes ClearOldQuizzes evicts is decided HERE, once, and every shard
   // releases the same ids in the same order -- the shards' registries (ids, gaps) never diverge.
@@ -324,6 +342,7 @@ ShardedEngine *ShardedEngine::Create(Error &err, const CiEngineDefinition &def, 
     return nullptr;
   }
   eng->_K = def._nAnswers; eng->_Q = def._nQuestions; eng->_T = def._nTargets;
+  eng->_devices = devices;
   // peer access between all pairs of distinct devices: the posterior copies and ResumeQuiz's in-place row reads go over xGMI
   for (int a : devices)
     for (int b : devices)
@@ -511,6 +530,7 @@ int64_t ShardedEngine::SelectArgmaxLocked(Error &err, int64_t iQuiz, double *pPr
     if (p != p) p = -HUGE_VAL;
     if (bestI < 0 || p > bestP || (p == bestP && i < bestI)) { bestP = p; bestI = i; }
   }
+  CheckPriority(bestP, bestI);   // (the reference's "Got priority=" warning, for the question that was selected)
   if (pPriority) *pPriority = bestP;
   err = Error();
   return bestI;
@@ -644,6 +664,196 @@ Error ShardedEngine::NextQuestionArgmaxBatch(int64_t n, const int64_t *pQuizzes,
   return Error();
 }
 
+// ---- maintenance ------------------------------------------------------------------------------------------------------------
+Error ShardedEngine::RemoveQuestions(int64_t n, const int64_t *pQIds) {   // BaseEngine.cpp:722-743; all ids validated before the first is removed
+  std::lock_guard<std::mutex> lk(_mu);
+  Error e = MaintenanceOnly("remove questions");
+  if (!e.ok()) return e;
+  if (n < 0) return Error::MakeP(ErrCode::NegativeCount, "count=" + std::to_string(n), "Counts must be non-negative.");
+  if (n > 0 && !pQIds) return Error::Make(ErrCode::NullArgument, "Nullptr ids array.");
+  for (int64_t i = 0; i < n; i++) {
+    const int64_t iq = pQIds[i];
+    bool bad = iq < 0 || iq >= _Q || std::find(_qGapList.begin(), _qGapList.end(), iq) != _qGapList.end();
+    for (int64_t j = 0; j < i && !bad; j++) bad = pQIds[j] == iq;
+    if (bad) return Error::MakeP(ErrCode::AbsentId, "id=" + std::to_string(iq), "Question index is not in KB.");
+  }
+  for (auto &s : _sh) { e = s->SetQuestionGaps(n, pQIds); if (!e.ok()) return e; }
+  for (int64_t i = 0; i < n; i++) { _qGapList.push_back(pQIds[i]); _pimQuestions.RemoveComp(pQIds[i]); }
+  return Error();
+}
+
+Error ShardedEngine::RemoveTargets(int64_t n, const int64_t *pTIds) {   // BaseEngine.cpp:745-765
+  std::lock_guard<std::mutex> lk(_mu);
+  Error e = MaintenanceOnly("remove targets");
+  if (!e.ok()) return e;
+  // (the target axis is replicated: every shard validates and removes the same ids; shard 0 refuses a bad call before any other is asked)
+  for (auto &s : _sh) { e = s->RemoveTargets(n, pTIds); if (!e.ok()) return e; }
+  return Error();
+}
+
+// New shards for new dimensions.  srcQ[q'] / srcT[t']: the old global question / target whose data new q' / t' takes, -1 for none
+// (a gap, or an id that fillQ / fillT initialise).  The registries that are not data -- gaps, id maps, options, mode -- are
+// carried over.  On failure nothing has changed.
+Error ShardedEngine::Rebuild(int64_t newQ, int64_t newT, const std::vector<int64_t> &srcQ, const std::vector<int64_t> &srcT,
+                             const std::vector<int64_t> &qGaps, const std::vector<int64_t> &tGaps, const PermIdMgr &pimT,
+                             const std::vector<int64_t> &fillT, const std::vector<double> &fillTInit, const std::vector<int64_t> &fillQ,
+                             const std::vector<double> &fillQInit) {
+  const int64_t N = (int64_t)_sh.size();
+  if (newQ < N) return Error::MakeP(ErrCode::InsufficientEngineDimensions, "[nQuestions=" + std::to_string(newQ) + " of " + std::to_string(N) + "]",
+                                    "Fewer questions than devices in PQA_DEVICES.");
+  HipEngine &s0 = *_sh[0];
+  CiEngineDefinition def;
+  std::memset(&def, 0, sizeof(def));
+  def._nAnswers = _K; def._nTargets = newT;
+  def._precType = s0.PrecisionType(); def._precMantissa = s0.PrecMantissa(); def._precExponent = s0.PrecExponent();
+  def._initAmount = s0.InitAmount();
+  Error err;
+  for (auto &s : _sh) { err = s->Synchronize(); if (!err.ok()) return err; }
+  std::vector<std::unique_ptr<HipEngine>> fresh;
+  const int64_t quot = newQ / N, rem = newQ % N;   // SRPoolRunner::CalcSplit
+  int64_t first = 0;
+  for (int64_t s = 0; s < N; s++) {
+    CiEngineDefinition d = def;
+    d._nQuestions = quot + (s < rem ? 1 : 0);
+    CiHipShard sh;
+    sh._qFirst = first; sh._qTotal = newQ; sh._device = _devices[(size_t)s]; sh._reserved = 0;
+    HipEngine *e = HipEngine::Create(err, d, &sh);
+    if (!e) return err;
+    fresh.emplace_back(e);
+    // its questions' rows, from wherever the old shards hold them
+    std::vector<const void *> blocks((size_t)d._nQuestions, nullptr);
+    for (int64_t q = 0; q < d._nQuestions; q++) {
+      const int64_t old = srcQ[(size_t)(first + q)];
+      if (old < 0) continue;
+      const int owner = OwnerOf(old);
+      blocks[(size_t)q] = _sh[(size_t)owner]->QuestionBlock(old - _sh[(size_t)owner]->FirstQuestion());
+    }
+    err = e->AdoptRows(blocks, s0.RowLength(), srcT, _sh[(size_t)s]->VBDevicePtr());   // (vB: the replica on the same device)
+    if (!err.ok()) return err;
+    std::vector<int64_t> localQ;
+    std::vector<double> localInit;
+    for (size_t i = 0; i < fillQ.size(); i++)
+      if (fillQ[i] >= first && fillQ[i] < first + d._nQuestions) { localQ.push_back(fillQ[i] - first); localInit.push_back(fillQInit[i]); }
+    err = e->ApplyFills(fillT, fillTInit, localQ, localInit);
+    if (!err.ok()) return err;
+    err = e->SetQuestionGaps((int64_t)qGaps.size(), qGaps.data());
+    if (err.ok()) err = e->SetTargetGaps((int64_t)tGaps.size(), tGaps.data());
+    if (!err.ok()) return err;
+    e->SetTargetPim(pimT);
+    e->SetQuizPim(_sh[(size_t)s]->QuizPim());
+    Error ae;
+    e->SetQuestionsAsked(s == 0 ? s0.GetTotalQuestionsAsked(ae) : 0);
+    for (const char *opt : {"select", "workers", "eval_subtasks", "eval_variant", "bug_compat", "top_cache", "speculate", "host_sampled",
+                            "fused_sampled", "batch_min", "batch_qb", "batch_tile", "rerank", "combine", "server", "use_graph"}) {
+      const int64_t v = _sh[(size_t)s]->GetOption(opt);
+      if (v >= 0) (void)e->SetOption(opt, std::string(opt) == "eval_subtasks" && v == 8 * _sh[(size_t)s]->GetOption("workers") ? 0 : v);
+    }
+    err = e->StartMaintenance(false);
+    if (!err.ok()) return err;
+    first += d._nQuestions;
+  }
+  // ---- commit
+  _sh.swap(fresh);
+  _Q = newQ;
+  _T = newT;
+  _qGapList = qGaps;
+  _hostPriority.assign((size_t)newQ, 0.0);
+  _lastOwner.clear();
+  _usage.clear();
+  return Error();
+}
+
+Error ShardedEngine::AddQsTs(int64_t nQuestions, CiAddQorTParam *pAqps, int64_t nTargets, CiAddQorTParam *pAtps) {
+  std::lock_guard<std::mutex> lk(_mu);
+  Error e = MaintenanceOnly("add questions/targets");
+  if (!e.ok()) return e;
+  if (nQuestions < 0 || nTargets < 0)
+    return Error::MakeP(ErrCode::NegativeCount, "count=" + std::to_string(std::min(nQuestions, nTargets)), "Counts must be non-negative.");
+  if ((nQuestions > 0 && !pAqps) || (nTargets > 0 && !pAtps)) return Error::Make(ErrCode::NullArgument, "Nullptr parameters array.");
+  // CpuEngine::AddQsTsSpec, reference PqaCore/CpuEngine.cpp:468-575, over the GLOBAL ids (as HipEngine::AddQsTs over its own):
+  // gaps are reused LIFO, the rest is appended
+  std::vector<int64_t> tGapList, tmp;
+  _sh[0]->GetGapLists(tmp, tGapList);
+  const int64_t nQReuse = std::min<int64_t>(nQuestions, (int64_t)_qGapList.size()), nQNew = nQuestions - nQReuse;
+  const int64_t nTReuse = std::min<int64_t>(nTargets, (int64_t)tGapList.size()), nTNew = nTargets - nTReuse;
+  std::vector<int64_t> qIds, tIds;
+  std::vector<double> qInit, tInit;
+  for (int64_t i = 0; i < nQReuse; i++) qIds.push_back(_qGapList[_qGapList.size() - 1 - (size_t)i]);   // :476-482
+  for (int64_t i = 0; i < nTReuse; i++) tIds.push_back(tGapList[tGapList.size() - 1 - (size_t)i]);      // :488-493
+  for (int64_t i = 0; i < nQNew; i++) qIds.push_back(_Q + i);                                           // :500
+  for (int64_t j = 0; j < nTNew; j++) tIds.push_back(_T + j);                                           // :531
+  for (int64_t i = 0; i < nQuestions; i++) qInit.push_back(pAqps[i]._initAmount);
+  for (int64_t j = 0; j < nTargets; j++) tInit.push_back(pAtps[j]._initAmount);
+  const int64_t newQ = _Q + nQNew, newT = _T + nTNew;
+  std::vector<int64_t> srcQ((size_t)newQ, -1), srcT((size_t)newT, -1);
+  for (int64_t q = 0; q < _Q; q++) srcQ[(size_t)q] = q;      // (a gap's rows travel too: they are nobody's)
+  for (int64_t t = 0; t < _T; t++) srcT[(size_t)t] = t;
+  for (int64_t id : qIds) if (id < _Q) srcQ[(size_t)id] = -1;   // re-initialised below
+  std::vector<int64_t> qGaps(_qGapList.begin(), _qGapList.end() - nQReuse), tGaps(tGapList.begin(), tGapList.end() - nTReuse);
+  PermIdMgr pimT = _sh[0]->TargetPim();
+  for (int64_t i = 0; i < nTReuse; i++) pimT.RenewComp(tIds[(size_t)i]);
+  pimT.GrowTo(newT);                                           // :541-542
+  PermIdMgr pimQ = _pimQuestions;
+  for (int64_t i = 0; i < nQReuse; i++) pimQ.RenewComp(qIds[(size_t)i]);
+  pimQ.GrowTo(newQ);
+  // (the rebuilt shards mark their remaining gaps themselves: their own id maps are over local ids and are not consulted)
+  e = Rebuild(newQ, newT, srcQ, srcT, qGaps, tGaps, pimT, tIds, tInit, qIds, qInit);
+  if (!e.ok()) return e;
+  _pimQuestions = pimQ;
+  for (int64_t i = 0; i < nQuestions; i++) pAqps[i]._index = qIds[(size_t)i];
+  for (int64_t j = 0; j < nTargets; j++) pAtps[j]._index = tIds[(size_t)j];
+  return Error();
+}
+
+Error ShardedEngine::Compact(int64_t *pnQuestions, const int64_t **ppOldQuestions, int64_t *pnTargets, const int64_t **ppOldTargets) {
+  std::lock_guard<std::mutex> lk(_mu);
+  Error e = MaintenanceOnly("compact the KB");
+  if (!e.ok()) return e;
+  if (!pnQuestions || !ppOldQuestions || !pnTargets || !ppOldTargets) return Error::Make(ErrCode::NullArgument, "Nullptr output.");
+  // CpuEngine::CompactSpec, CpuEngine.cpp:577-658, over the global axes (the pairing of HipEngine::Compact)
+  std::vector<int64_t> tGapList, tmp;
+  _sh[0]->GetGapLists(tmp, tGapList);
+  std::vector<char> qGap((size_t)_Q, 0), tGap((size_t)_T, 0);
+  for (int64_t g : _qGapList) qGap[(size_t)g] = 1;
+  for (int64_t g : tGapList) tGap[(size_t)g] = 1;
+  const int64_t nQ = _Q - (int64_t)_qGapList.size(), nT = _T - (int64_t)tGapList.size();
+  if (nQ < (int64_t)_sh.size())
+    return Error::MakeP(ErrCode::InsufficientEngineDimensions, "[nQuestions=" + std::to_string(nQ) + " of " + std::to_string(_sh.size()) + "]",
+                        "Fewer questions than devices in PQA_DEVICES would remain.");
+  std::vector<int64_t> oldQ((size_t)std::max<int64_t>(nQ, 1)), oldT((size_t)std::max<int64_t>(nT, 1));
+  {   // questions: a gap in the kept prefix takes the LAST surviving question (:586-601)
+    int64_t iFirst = 0, iLast = _Q - 1;
+    for (; iFirst <= iLast; iFirst++) {
+      if (!qGap[(size_t)iFirst]) { oldQ[(size_t)iFirst] = iFirst; continue; }
+      while (qGap[(size_t)iLast] && iLast > iFirst) iLast--;
+      if (iFirst == iLast) break;
+      oldQ[(size_t)iFirst] = iLast;
+      iLast--;
+    }
+  }
+  {   // targets: gaps of the kept prefix (ascending) take the survivors of the dropped tail (ascending) (:604-618)
+    std::vector<int64_t> dst, src;
+    for (int64_t t = 0; t < nT; t++) if (tGap[(size_t)t]) dst.push_back(t); else oldT[(size_t)t] = t;
+    for (int64_t t = nT; t < _T; t++) if (!tGap[(size_t)t]) src.push_back(t);
+    for (size_t i = 0; i < dst.size(); i++) oldT[dst[i]] = src[i];
+  }
+  oldQ.resize((size_t)nQ);
+  oldT.resize((size_t)nT);
+  PermIdMgr pimT = _sh[0]->TargetPim(), pimQ = _pimQuestions;
+  pimT.OnCompact(nT, oldT.data());
+  pimQ.OnCompact(nQ, oldQ.data());
+  e = Rebuild(nQ, nT, oldQ, oldT, {}, {}, pimT, {}, {}, {}, {});
+  if (!e.ok()) return e;
+  _pimQuestions = pimQ;
+  int64_t *outQ = (int64_t *)std::malloc(sizeof(int64_t) * (size_t)std::max<int64_t>(nQ, 1));
+  int64_t *outT = (int64_t *)std::malloc(sizeof(int64_t) * (size_t)std::max<int64_t>(nT, 1));
+  std::copy(oldQ.begin(), oldQ.end(), outQ);
+  std::copy(oldT.begin(), oldT.end(), outT);
+  *pnQuestions = nQ; *pnTargets = nT;
+  *ppOldQuestions = outQ; *ppOldTargets = outT;
+  return Error();
+}
+
 // ---- .kb file (layout of reference PqaCore/BaseEngine.cpp:323-385 + PqaCore/CpuEngine.cpp:664-688, see hip_engine_kb.cpp): the
 // file orders its rows by question, so the shards' blocks follow each other -- every shard streams its own rows through its
 // own staging buffer; vB, the target gaps and the target / quiz id maps are replicas (shard 0's are written).
@@ -674,8 +884,7 @@ Error ShardedEngine::SaveKB(const char *filePath, bool doubleBuffer) {
   for (auto &s : _sh) { Error e = s->IoRows(fg.f, filePath, false, true); if (!e.ok()) return e; }
   for (auto &s : _sh) { Error e = s->IoRows(fg.f, filePath, true, true); if (!e.ok()) return e; }
   { Error e = s0.IoVB(fg.f, filePath, true); if (!e.ok()) return e; }
-  std::vector<int64_t> qGaps, tGaps, tmp;
-  for (auto &s : _sh) s->GetGapLists(qGaps, tmp);
+  std::vector<int64_t> qGaps = _qGapList, tGaps, tmp;   // (LIFO order, as the reference's GapTracker saves it)
   s0.GetGapLists(tmp, tGaps);
   auto writeGaps = [&](const std::vector<int64_t> &gaps) {
     const int64_t n = (int64_t)gaps.size();
@@ -733,6 +942,7 @@ ShardedEngine *ShardedEngine::Load(Error &err, const char *filePath, const std::
   };
   std::vector<int64_t> qGaps, tGaps;
   if (!readGaps(qGaps, dims[1]) || !readGaps(tGaps, dims[2])) return fail(KbFileErr(filePath, "Can't read the gaps."));
+  eng->_qGapList = qGaps;
   for (auto &s : eng->_sh) {
     Error e = s->SetQuestionGaps((int64_t)qGaps.size(), qGaps.data());
     if (e.ok()) e = s->SetTargetGaps((int64_t)tGaps.size(), tGaps.data());

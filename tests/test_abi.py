@@ -67,6 +67,7 @@ def test_null_handles_follow_the_reference_convention(factory):
     import tempfile
     base = os.path.join(tempfile.mkdtemp(prefix="pqa_log_"), "x")   # (the log file <base>_<UTC time>_<pid>.log: not into the repository)
     assert lib.Logger_Init(ctypes.byref(ctypes.c_void_p()), base.encode()) == 1
+    os.environ["PQA_TEST_LOG_BASE"] = base       # (tests that expect log entries later in this process look here)
 
 
 def test_no_cpu_fallback_without_a_gpu(factory):

