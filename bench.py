@@ -527,6 +527,7 @@ def main():
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
             "traffic": pmc_traffic(args.config, world),
+            "traffic_from_other_sources_than_the_tree": pmc_is_stale(args.config),
             "kernel": ("eval_server_f64 (wg256_np2, resident: one launch serves the selections; the kernel `value` went through)"
                        if server_step_us else "eval_questions_f64 (%s)" % eng.eval_kernel_name()),
             "kernel_us": path_us,
@@ -970,6 +971,25 @@ def pmc_traffic(config, world):
     try:
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
             return json.load(f).get(config, {}).get("bytes_per_launch")
+    except (OSError, ValueError):
+        return None
+
+
+def kernel_sources_sha16():
+    """sha256 (first 16 hex digits) of the kernel sources, as tools/prof.sh records it beside the counters it collects."""
+    import hashlib
+
+    d = os.path.join(ROOT, "probqa_amd", "csrc")
+    return hashlib.sha256(b"".join(open(os.path.join(d, f), "rb").read() for f in sorted(os.listdir(d)) if f.endswith((".hip", ".h")))).hexdigest()[:16]
+
+
+def pmc_is_stale(config):
+    """True if the committed counter pass (profiles/traffic.json) was taken from other kernel sources than the ones in the tree:
+    `roofline.traffic` / `roofline_valu.pmc` are that pass's numbers, not this run's (bench.py cannot collect counters on itself)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            rec = json.load(f).get(config, {})
+        return rec.get("kernel_sources_sha16") != kernel_sources_sha16()
     except (OSError, ValueError):
         return None
 

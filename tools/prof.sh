@@ -6,13 +6,15 @@
 # Outputs under gpurun_out/prof_<tag>/: the raw csv files, summary.txt (kernel stats + per-launch counter averages) and
 # traffic_<config>.json = {bytes_per_launch (FETCH_SIZE, KB -> bytes, x2 as MI355X_MICROARCH.md prescribes for 16 B/lane
 # streaming reads on gfx950), valu: {...}} -- copy both into profiles/ (traffic_<config>.json merges into profiles/traffic.json).
+#        tools/prof.sh <tag> custom:<kernel-name-substring> <command ...>     (any command: the same passes, counters of that kernel)
 TAG=$1; CFG=$2; VAR=${3:-0}; STEPS=${4:-50}
 OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 case $CFG in
+  custom:*) KERNEL=${CFG#custom:}; shift 2; CMD="$*"; CFG=$KERNEL ;;
   L1|LS|SB) CMD="python $PWD/bench.py --config $CFG --steps $STEPS --warmup 1 --no-cpu-baseline"; KERNEL=eval_batch_kernel ;;
-  *) CMD="python $PWD/bench.py --config $CFG --variant $VAR --steps $STEPS --warmup 5 --no-cpu-baseline --batch 0 --no-server --no-quiz-loop"; KERNEL=eval_questions ;;
+  *) CMD="python $PWD/bench.py --config $CFG --variant $VAR --steps $STEPS --warmup 5 --no-cpu-baseline --batch 0 --no-server --no-quiz-loop --no-points"; KERNEL=eval_questions ;;
 esac
 cd /tmp
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- $CMD > $OUT/bench_trace.json 2> $OUT/trace.err
@@ -40,7 +42,9 @@ for d in sorted(glob.glob(out+"/pmc_*/")):
             k=row["Counter_Name"]; acc[k][0]+=1; acc[k][1]+=float(row["Counter_Value"])
         for k,(n,s) in acc.items():
             print("pmc %-24s per-launch avg of %s: %.6g (n=%d)"%(k,kern,s/n,n)); vals[k]=s/n
-rec={"command": "$CMD", "kernel": kern}
+import hashlib
+src=hashlib.sha256(b"".join(open(os.path.join("$PWD","probqa_amd","csrc",f),"rb").read() for f in sorted(os.listdir(os.path.join("$PWD","probqa_amd","csrc"))) if f.endswith((".hip",".h")))).hexdigest()[:16]
+rec={"command": "$CMD", "kernel": kern, "kernel_sources_sha16": src}
 if "FETCH_SIZE" in vals:
     rec.update({"bytes_per_launch": vals["FETCH_SIZE"]*1024*2, "fetch_size_kb_raw": vals["FETCH_SIZE"],
                 "correction": "x1024 (KB) x2 (gfx950 wide-read undercount, MI355X_MICROARCH.md HBM section)"})
