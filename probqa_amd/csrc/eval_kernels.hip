@@ -53,6 +53,7 @@ __device__ __forceinline__ void select_quiz(EvalArgs &a) {
   a.priority = s.priority;
   a.fs.out = s.out;
   a.fs.seq = s.seq;
+  a.fs.hostPriority = s.hostPriority;
   a.fs.scratch += (size_t)blockIdx.y * (size_t)a.fs.scratchStride;
 }
 

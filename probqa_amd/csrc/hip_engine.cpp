@@ -1189,7 +1189,7 @@ Error HipEngine::ServerPost(Quiz *q, SelectResult *out, uint64_t *flag, uint64_t
 //     a lane is a quiz, the cube tile staged in LDS serves all quizzes of the batch -- the cube is read once per batch;
 //   * grid.y = quiz over the single-quiz kernel (small batches of Double engines): one launch, but one cube read per quiz.
 Error HipEngine::BatchSweep(BatchCtx &c, int64_t n, const int64_t *pQuizzes, std::vector<Quiz *> &quizzes, bool wantPriorities, uint64_t tag,
-                            bool hostPriorities, bool *pQuizMinor) {
+                            bool hostPriorities, bool *pQuizMinor, bool *pTagged) {
   if (!c.h) {  // first batch: staging in host-coherent pinned memory, winner records
     HIP_TRY(hipHostMalloc(&c.h, sizeof(BatchPinned), hipHostMallocMapped | hipHostMallocCoherent));
     std::memset(c.h, 0, sizeof(BatchPinned));
@@ -1218,6 +1218,7 @@ Error HipEngine::BatchSweep(BatchCtx &c, int64_t n, const int64_t *pQuizzes, std
       c.hPriDoubles = 0;
       HIP_TRY(hipHostMalloc((void **)&c.hPri, doubles * sizeof(double), hipHostMallocDefault));
       c.hPriDoubles = doubles;
+      c.hPriCoherent = false;
     }
     HIP_TRY(hipMemcpyAsync(c.hPri, src, doubles * sizeof(double), hipMemcpyDeviceToHost, _stream));
     return Error();
@@ -1238,14 +1239,36 @@ Error HipEngine::BatchSweep(BatchCtx &c, int64_t n, const int64_t *pQuizzes, std
       if (pQuizzes[j] == pQuizzes[i])
         return Error::MakeP(ErrCode::IndexOutOfRange, "quizId=" + std::to_string(pQuizzes[i]), "A quiz appears twice in one batch.");
     c.h->slots[i] = QuizSlot{quizzes[i]->dPrior, quizzes[i]->dAsked, rowSharing ? nullptr : c.dPriority + (size_t)i * (size_t)_Q,
-                                 &c.h->out[i], &c.h->seq[i]};
+                                 &c.h->out[i], &c.h->seq[i], nullptr};
+  }
+  // grid.y = quiz and the priorities wanted on the host: every workgroup stores the priorities of its questions there itself, one
+  // {priority, launch tag} record each (as the single-quiz sweep's hand-over, FusedSelect::hostPriority) -- no copy behind the
+  // sweep and no event: the quiz's flag says that every workgroup has reported, an entry is taken once it carries the tag
+  const bool tagged = hostPriorities && !rowSharing && EvalVariantHasFinisherWorkgroup(View(), (int)_optEvalVariant);
+  if (pTagged) *pTagged = tagged;
+  if (tagged) {
+    const size_t doubles = 2 * (size_t)n * (size_t)_Q;
+    if (c.readers.load(std::memory_order_acquire) != 0) return Error::Make(ErrCode::Internal, "A priority buffer is still being read.");
+    if (doubles > c.hPriDoubles || !c.hPriCoherent) {
+      HIP_TRY(hipStreamSynchronize(_stream));
+      if (c.hPri) hipHostFree(c.hPri);
+      c.hPri = nullptr;
+      c.hPriDoubles = 0;
+      const size_t want = std::max(doubles, 2 * (size_t)64 * (size_t)_Q);
+      HIP_TRY(hipHostMalloc((void **)&c.hPri, want * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent));
+      std::memset(c.hPri, 0, want * sizeof(double));   // (no launch has tag 0)
+      c.hPriDoubles = want;
+      c.hPriCoherent = true;
+    }
+    for (int64_t i = 0; i < n; i++) c.h->slots[i].hostPriority = reinterpret_cast<TaggedPriority *>(c.hPri) + (size_t)i * (size_t)_Q;
   }
   HIP_TRY(hipMemcpyAsync(c.dSlots, c.h->slots, (size_t)n * sizeof(QuizSlot), hipMemcpyHostToDevice, _stream));
   StopServer();   // a launched sweep has no room beside the resident one and would wait for it to idle out
   if (!rowSharing) {
-    const FusedSelect fs{c.dScratch, nullptr, nullptr, tag, 0, kBatchGrid, tag, nullptr, 0, 0, nullptr, nullptr};
+    const FusedSelect fs{c.dScratch, nullptr, nullptr, tag, 0, kBatchGrid, tag, nullptr, tagged ? 1 : 0, 0, nullptr,
+                         tagged ? reinterpret_cast<TaggedPriority *>(c.hPri) : nullptr};
     HIP_TRY(LaunchEvalQuestionsBatch(View(), c.dSlots, (int)n, 0, _Q, (int)_optEvalVariant, fs, _stream));
-    if (hostPriorities) return copyToHost(c.dPriority, (size_t)n * (size_t)_Q);
+    if (hostPriorities && !tagged) return copyToHost(c.dPriority, (size_t)n * (size_t)_Q);
     return Error();
   }
   const KbView kb = View();
@@ -1591,7 +1614,26 @@ int64_t HipEngine::SelectFromPriorities(SelRequest *r) {
   const int64_t nQ = r->nQ;
   auto skip = [&](int64_t k) { return BitTest(r->unavailable, k); };
   std::vector<double> run((size_t)nQ);
-  for (int64_t k = 0; k < nQ; k++) run[(size_t)k] = skip(k) ? 0.0 : r->pri[(size_t)k * (size_t)r->priStride];
+  if (r->priTag != 0) {
+    // (the quiz's flag said that every workgroup had reported, not that every one of its stores had landed: an entry is taken
+    //  once it carries the launch's tag -- it almost always does by now)
+    const volatile double *rec = r->pri;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int64_t k = 0; k < nQ; k++) {
+      if (skip(k)) { run[(size_t)k] = 0.0; continue; }
+      const volatile uint64_t *tagWord = reinterpret_cast<const volatile uint64_t *>(rec + 2 * k + 1);
+      for (uint64_t spins = 0; *tagWord != r->priTag;)
+        if ((++spins & 0xFFFF) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(30)) {
+          r->err = HipErr(hipErrorNotReady, "priority vector hand-over (combined sweep)");
+          q->inSelection.store(false, std::memory_order_release);
+          return r->result = -1;
+        }
+      std::atomic_thread_fence(std::memory_order_acquire);
+      run[(size_t)k] = rec[2 * k];
+    }
+  } else {
+    for (int64_t k = 0; k < nQ; k++) run[(size_t)k] = skip(k) ? 0.0 : r->pri[(size_t)k * (size_t)r->priStride];
+  }
   int64_t pick = -1;
   if (r->kind == 1) {
     pick = SelectSampledHost(run.data(), nQ, r->nSub, r->rnd, skip);
@@ -1714,7 +1756,7 @@ void HipEngine::LaunchBatch(BatchCtx &c, std::vector<SelRequest *> &batch, Fligh
   const int64_t n = (int64_t)live.size();
   f.tag = NextLaunchTag();
   std::vector<Quiz *> quizzes;
-  err = BatchSweep(c, n, ids.data(), quizzes, false, f.tag, f.anySampled, &f.quizMinor);
+  err = BatchSweep(c, n, ids.data(), quizzes, false, f.tag, f.anySampled, &f.quizMinor, &f.tagged);
   if (!err.ok()) { for (SelRequest *r : live) { r->err = err; r->result = -1; } return; }
   const int64_t nSubtasks = _optEvalSubtasks ? _optEvalSubtasks : 8 * _optWorkers;  // reference PqaCore/CpuEngine.cpp:339
   for (int64_t i = 0; i < n; i++) {
@@ -1733,7 +1775,7 @@ void HipEngine::LaunchBatch(BatchCtx &c, std::vector<SelRequest *> &batch, Fligh
   }
   f.Bp = c.lastBp;
   f.nQ = _Q;
-  if (f.anySampled) f.he = hipEventRecord(c.event, _stream);
+  if (f.anySampled && !f.tagged) f.he = hipEventRecord(c.event, _stream);
   _combBatches++;
   _combRequests += (uint64_t)n;
   if ((uint64_t)n > _combMaxBatch) _combMaxBatch = (uint64_t)n;
@@ -1750,8 +1792,11 @@ bool HipEngine::CollectBatch(BatchCtx &c, std::vector<SelRequest *> &batch, Flig
   const int64_t n = (int64_t)f.live.size();
   Error err;
   hipError_t he = f.he;
-  if (he == hipSuccess && f.anySampled) he = hipEventSynchronize(c.event);
-  if (he == hipSuccess && !f.anySampled) err = WaitBatchFlags(c, n, f.tag);
+  if (he == hipSuccess && f.anySampled && !f.tagged) he = hipEventSynchronize(c.event);
+  if (he == hipSuccess && (!f.anySampled || f.tagged)) err = WaitBatchFlags(c, n, f.tag);
+  if (err.ok() && f.tagged)
+    for (int64_t i = 0; i < n && err.ok(); i++)
+      if (c.h->out[i].index == -3) err = HipErr(hipErrorLaunchFailure, "combined selection (incomplete sweep)");
   c.inFlight.store(false, std::memory_order_relaxed);
   const auto tD = std::chrono::steady_clock::now();
   auto ns = [](auto a, auto b) { return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(b - a).count(); };
@@ -1772,8 +1817,9 @@ bool HipEngine::CollectBatch(BatchCtx &c, std::vector<SelRequest *> &batch, Flig
     bool ownLive = false;
     for (int64_t i = 0; i < n; i++) {
       SelRequest *r = f.live[(size_t)i];
-      r->pri = f.quizMinor ? c.hPri + i : c.hPri + (size_t)i * (size_t)f.nQ;
-      r->priStride = f.quizMinor ? f.Bp : 1;
+      r->pri = f.tagged ? c.hPri + 2 * (size_t)i * (size_t)f.nQ : f.quizMinor ? c.hPri + i : c.hPri + (size_t)i * (size_t)f.nQ;
+      r->priStride = f.tagged ? 2 : f.quizMinor ? f.Bp : 1;
+      r->priTag = f.tagged ? f.tag : 0;
       r->ctx = &c;
       if (r == own) { ownLive = true; continue; }
       for (SelRequest *&slot : batch) if (slot == r) slot = nullptr;   // (published here: not the caller's to publish again)

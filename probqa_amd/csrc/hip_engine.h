@@ -384,6 +384,7 @@ class HipEngine : public IEngine {
                                        // 3 the sweep is done: select for yourself from pri[] (the leader does not do it for everybody)
     const double *pri = nullptr;       // state 3: priority of local question k at pri[k * priStride]
     int64_t priStride = 0;
+    uint64_t priTag = 0;               // != 0: pri[k * priStride + 1] is the entry's launch tag -- the entry is taken once it carries this one
     BatchCtx *ctx = nullptr;           // state 3: whose reader count is this request's to release
     uint64_t serial = 0;               // state 3: the quiz the sweep ran for
     Quiz *quiz = nullptr;              // state 3: held by inSelection
@@ -404,7 +405,7 @@ class HipEngine : public IEngine {
   struct Flight {                      // a combined sweep between its launch and its collection
     std::vector<SelRequest *> live;
     uint64_t tag = 0;
-    bool anySampled = false, quizMinor = false;
+    bool anySampled = false, quizMinor = false, tagged = false;
     int64_t Bp = 0, nQ = 0;
     hipError_t he = hipSuccess;
     std::chrono::steady_clock::time_point tA, tB, tC;
@@ -440,8 +441,9 @@ class HipEngine : public IEngine {
     size_t ptBytes = 0, accBytes = 0, recBytes = 0, priTBytes = 0, rerankBytes = 0;
     void *dRerank = nullptr;             // Float engines: the candidates of the fp64 re-rank and their priorities
     int lastBp = 0;
-    double *hPri = nullptr;              // pinned: the batch's priority vectors for the host-side selector
-    size_t hPriDoubles = 0;
+    double *hPri = nullptr;              // pinned: the batch's priority vectors for the host-side selector -- copied there behind the
+    size_t hPriDoubles = 0;              // row-sharing sweep, or written there by the grid.y = quiz sweep itself as {priority, launch tag} records
+    bool hPriCoherent = false;           // hPri is host-coherent mapped memory (the kernels write it) rather than a copy's destination
     std::atomic<int> readers{0};         // clients still selecting out of hPri
     hipEvent_t event = nullptr;
     std::atomic<bool> inFlight{false};   // a leader's sweep launched and not yet collected
@@ -451,7 +453,7 @@ class HipEngine : public IEngine {
   // wantPriorities: the row-sharing sweep with its priority matrix kept (EvalPrioritiesBatch).  hostPriorities: whichever form
   // suits the batch, and the quizzes' priority vectors copied into _hBatchPri (layout: *pQuizMinor) for the host's selector.
   Error BatchSweep(BatchCtx &c, int64_t n, const int64_t *pQuizzes, std::vector<Quiz *> &quizzes, bool wantPriorities, uint64_t tag,
-                   bool hostPriorities = false, bool *pQuizMinor = nullptr);
+                   bool hostPriorities = false, bool *pQuizMinor = nullptr, bool *pTagged = nullptr);
   Error WaitBatchFlags(BatchCtx &c, int64_t n, uint64_t tag);
   Error EnqueueBatchLocked(int64_t n, const int64_t *pQuizzes, bool wantPriorities, uint64_t *pTag);
   Error CollectBatchSelectionsLocked(int64_t n, uint64_t tag, CiHipSelection *pOut);

@@ -107,6 +107,8 @@ struct QuizSlot {
   double *priority;       // this quiz's priority vector
   SelectResult *out;      // host-coherent record of this quiz's winner
   uint64_t *seq;          // host-coherent flag of this quiz
+  TaggedPriority *hostPriority;   // optional (grid.y = quiz launches with FusedSelect::sampleSubtasks > 0): this quiz's priorities go to
+                                  // the host as tagged records, as FusedSelect::hostPriority delivers a single quiz's
 };
 hipError_t LaunchEvalQuestions(const KbView &kb, const double *prior, const uint32_t *asked, int64_t qFirst,
                                int64_t qLimit, double *priority, int variant, const FusedSelect *fused,
