@@ -336,32 +336,6 @@ def main():
                      "note": "reference figure: PqaClient learner loop on the author's 2017 desktop CPU (BASELINE.md); "
                              "here: Python wrapper of the C ABI, one quiz at a time, sampled selector"}
 
-    # ---- extra (not `value`): the same learner loop from MANY CLIENT THREADS on the one engine -- what the reference's published
-    # rate is (PqaClient.cpp:238-245: the sum over hardware_concurrency learner threads, every NextQuestion under a shared lock,
-    # CpuEngine.cpp:357-361).  Native threads through the C ABI (probqa_amd/client/pqa_client.cpp), sampled selector, training at
-    # the end of every quiz; the engine combines the concurrent NextQuestion calls into batched sweeps and the RecordAnswers
-    # into batched launches (engine option "combine").
-    quiz_loop_threads = None
-    if selector is None and args.config == "S" and not args.no_quiz_loop:
-        eng.set_option("select", 0)
-        eng.set_option("seed", SEED)
-        quiz_loop_threads = {}
-        for nt in (1, 16, 64, 256):
-            b0 = (eng.get_option("combined_batches"), eng.get_option("combined_requests"), eng.get_option("update_flushes"), eng.get_option("updates_flushed"))
-            r = interop.run_learners(eng, nt, 400 if nt == 1 else 2400, 30, seed=SEED + nt, train=True)
-            b1 = (eng.get_option("combined_batches"), eng.get_option("combined_requests"), eng.get_option("update_flushes"), eng.get_option("updates_flushed"))
-            quiz_loop_threads[str(nt)] = {
-                "questions_per_sec": r["questions"] / r["seconds"], "quizzes": r["quizzes"], "questions": r["questions"],
-                "guessed_on_top": r["guessed_on_top"], "errors": r["errors"],
-                "next_questions_per_combined_sweep": (b1[1] - b0[1]) / max(1, b1[0] - b0[0]),
-                "record_answers_per_launch": (b1[3] - b0[3]) / max(1, b1[2] - b0[2])}
-        base = quiz_loop_threads["1"]["questions_per_sec"]
-        for k, v in quiz_loop_threads.items():
-            v["vs_one_thread"] = v["questions_per_sec"] / base
-        quiz_loop_threads["note"] = ("native client threads on ONE engine through the plain C ABI (PqaEngine_NextQuestion / RecordAnswer / "
-                                     "ListTopTargets / RecordQuizTarget); published reference figure: 301.2 questions/s over all threads")
-        eng.set_option("select", 1)
-
     # ---- extras (not `value`), sharded runs only.  Every one of them reports BOTH exchanges of the shards' winners: the slots
     # in host shared memory that the sweeps' finishers write (the default path of `value`) and the RCCL all-gather that
     # north_star names -- S (this cube), M = BASELINE configs[3] (10000x5x10000 over the same ranks: where sharding is about
@@ -481,6 +455,47 @@ def main():
         if free_b > 80e9:
             valu_point_l1 = run_batched(args, CONFIGS["L1"], np, torch, interop, pdist, ctl, rank, dev_index, device, compact=True)
 
+    # ---- extra (not `value`): the same learner loop from MANY CLIENT THREADS on the one engine -- what the reference's published
+    # rate is (PqaClient.cpp:238-245: the sum over hardware_concurrency learner threads, every NextQuestion under a shared lock,
+    # CpuEngine.cpp:357-361).  Native threads through the C ABI (probqa_amd/client/pqa_client.cpp), sampled selector, training at
+    # the end of every quiz; the engine combines the concurrent NextQuestion calls into batched sweeps and the RecordAnswers
+    # into batched launches (engine option "combine").
+    quiz_loop_threads, learners_hung = None, False
+    if selector is None and args.config == "S" and not args.no_quiz_loop:
+        eng.set_option("select", 0)
+        eng.set_option("seed", SEED)
+        quiz_loop_threads = {}
+        import threading
+
+        for nt in (1, 16, 64, 256):
+            b0 = (eng.get_option("combined_batches"), eng.get_option("combined_requests"), eng.get_option("update_flushes"), eng.get_option("updates_flushed"))
+            # (a watchdog: were the client threads ever to block each other, the line -- everything else is measured by now -- is
+            #  still printed, with the fact in it)
+            box = {}
+            th = threading.Thread(target=lambda: box.update(r=interop.run_learners(eng, nt, 400 if nt == 1 else 2400, 30, seed=SEED + nt, train=True)),
+                                  daemon=True)
+            th.start()
+            th.join(120.0)
+            if th.is_alive() or "r" not in box:
+                quiz_loop_threads[str(nt)] = {"error": "the learner threads did not finish within 120 s"}
+                learners_hung = True
+                break
+            r = box["r"]
+            b1 = (eng.get_option("combined_batches"), eng.get_option("combined_requests"), eng.get_option("update_flushes"), eng.get_option("updates_flushed"))
+            quiz_loop_threads[str(nt)] = {
+                "questions_per_sec": r["questions"] / r["seconds"], "quizzes": r["quizzes"], "questions": r["questions"],
+                "guessed_on_top": r["guessed_on_top"], "errors": r["errors"],
+                "next_questions_per_combined_sweep": (b1[1] - b0[1]) / max(1, b1[0] - b0[0]),
+                "record_answers_per_launch": (b1[3] - b0[3]) / max(1, b1[2] - b0[2])}
+        base = quiz_loop_threads["1"].get("questions_per_sec")
+        for k, v in quiz_loop_threads.items():
+            if base and "questions_per_sec" in v:
+                v["vs_one_thread"] = v["questions_per_sec"] / base
+        quiz_loop_threads["note"] = ("native client threads on ONE engine through the plain C ABI (PqaEngine_NextQuestion / RecordAnswer / "
+                                     "ListTopTargets / RecordQuizTarget); published reference figure: 301.2 questions/s over all threads")
+        if not learners_hung:
+            eng.set_option("select", 1)
+
     out = {
         "metric": "next_question_selections_per_sec",
         "value": value,
@@ -572,6 +587,8 @@ def main():
                       % (int(sel), int(cpu_argmax), cpu_margin), file=sys.stderr)
     if rank == 0:
         os.write(result_fd, (json.dumps(out) + "\n").encode())
+    if learners_hung:
+        os._exit(0)      # (the engine's client threads are stuck: its destructor would wait for them)
     if selector is not None and hasattr(selector, "close"):
         selector.close()
     eng.close()
