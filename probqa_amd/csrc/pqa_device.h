@@ -110,7 +110,11 @@ __device__ __forceinline__ double log2hot(double x, const double *__restrict__ t
   // planted in the low word of 2^52 -- exact, and an integer shift + one fp64 add instead of shift, add and a
   // quarter-rate v_cvt_f64_i32
   const double de = u2d(0x4330000000000000ULL | (uint64_t)(hi >> 20)) - 4503599627371519.0;
+#ifdef PQA_ABLATE_TABLE_CONFLICTS   // measurement only (wrong values): every lane reads its own 16 bytes -- the gather without its bank conflicts
+  const uint32_t tblByte = (((hi >> 6) & 0x0u) | ((uint32_t)__lane_id() << 4)) & 0x3FF0u;
+#else
   const uint32_t tblByte = (hi >> 6) & 0x3FF0u;                // top 10 mantissa bits (:101-102), times 16
+#endif
   (void)tbl;
   typedef double f64x2_t __attribute__((ext_vector_type(2)));
   const f64x2_t yc = *reinterpret_cast<const __attribute__((address_space(3))) f64x2_t *>((uintptr_t)tblByte);

@@ -86,3 +86,21 @@ def test_combining_can_be_switched_off(factory):
     again = interop.run_learners(eng, 16, 48, 8, seed=2, train=False)
     assert again["transcript_hash"] == many["transcript_hash"]
     eng.close()
+
+
+@pytest.mark.parametrize("option", [("server", 1), ("use_graph", 1), ("speculate", 0), ("combine_linger_us", 0), ("host_sampled", 0)],
+                         ids=lambda o: "%s=%d" % o)
+def test_native_learners_under_every_selection_path(option, factory):
+    """The combining of concurrent calls beside the engine's other selection paths -- the resident sweep and graph replay serve one
+    quiz at a time (a combined batch falls back to them request by request), speculation off, no lingering, the selector kernel
+    instead of the host's selector: 32 learner threads, the digest of all transcripts equals the one-thread run's."""
+    eng = _engine(factory, 5, 300, 1000, 6, 1)
+    eng.set_option(*option)
+    one = interop.run_learners(eng, 1, 64, 10, seed=4, train=False)
+    many = interop.run_learners(eng, 32, 64, 10, seed=4, train=False)
+    assert one["errors"] == 0 and many["errors"] == 0
+    assert (many["questions"], many["transcript_hash"]) == (one["questions"], one["transcript_hash"])
+    eng.set_option("select", 0)                      # the sampled selector: interleaving-dependent, must simply work
+    again = interop.run_learners(eng, 32, 64, 10, seed=5, train=True)
+    assert again["errors"] == 0 and again["quizzes"] == 64
+    eng.close()
