@@ -329,18 +329,229 @@ __global__ __launch_bounds__(256) void eval_batch_kernel(BatchArgs a) {
   a.recs[(size_t)blockIdx.x * Bp + b] = BatchRecord{bestP, bestQ};
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// The sweep for a FEW DOZEN quizzes at once, fp64, short rows (round 3).  Between the single-quiz sweep with grid.y = quiz
+// (lanes over targets: a wave reduction per row and quiz, the cube re-read per quiz -- 11-14 us per quiz at 1000 x 5 x 1000) and
+// the row-sharing sweep above (a lane is a quiz: no reductions, but 64 quizzes per wave or its lanes idle, and a lane walks the
+// whole row serially: it needs ~200 quizzes to fill the chip) there was nothing for the batches a server with dozens of client
+// threads produces (hip_engine.cpp: Combine -- 5 to 60 quizzes per combined sweep).  Here a lane is a (quiz, chunk of the
+// row): QS quiz slots x 64 / QS chunks per wave, four waves per workgroup, one QUESTION per workgroup at a time --
+//   * the workgroup stages the question's whole row block in LDS once: c = A * (1/D) for every answer and 1/D^2 (the divisions
+//     and the cube's bytes shared by all quizzes of the launch);
+//   * lane (slot s, chunk c) walks targets c, c + nCh, c + 2 nCh ...: lanes of one chunk read one LDS address (broadcast), the 64 / QS
+//     chunks of a wave read neighbouring entries (different banks); the lane's own operand is its quiz's masked prior out of
+//     the transposed matrix PT[target][quiz] (batch_prep_kernel);
+//   * every sum over targets is a serial sum over T / nCh targets in the lane's registers, folded over the chunks by one or two
+//     permlane swaps inside the wave (the lanes of a quiz are 16 or 32 apart) and one LDS exchange between the four waves:
+//     two short folds per question and quiz (W_k; then the K + 2 pass-2 sums) instead of a butterfly per row;
+//   * one lane per quiz runs the fp64 epilogue and keeps the quiz's best question; priorities go to the priority matrix and /
+//     or straight to the host as tagged records (QuizSlot::hostPriority), as the other sweeps deliver them.
+// Per (question, quiz) ~31 VALU slots per element as the row-sharing sweep, against ~50 per element pair-half of the register
+// form with its reductions.  K == 5 (the configuration every benchmark of the reference uses); rows up to kMidMaxTargets.
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int kMidThreads = 256, kMidK = 5;
+constexpr int64_t kMidMaxTargets = 2560;   // (K + 1) x 8 B x ldT + the table + the exchange within the CU's 160 KB (two workgroups per CU up to ~1050 targets)
+
+struct MidArgs {
+  const double *cube;        // [Q][K+1][ldT]
+  const double *PT;          // [ldT][Bp]
+  const uint32_t *tgap, *qgap;
+  const QuizSlot *slots;
+  int nSlots, Bp;
+  int64_t Q, ldT;
+  double vCompTail;
+  BatchRecord *recs;         // [grid.x][Bp]
+  double *priorityT;         // optional [Q][Bp]
+  uint64_t tag;              // launch tag of the host hand-over records
+};
+
+template <int QS> __device__ __forceinline__ double chunk_fold(double v) {   // sum over the lanes of one quiz slot within a wave
+  if constexpr (QS <= 16) { const Pair p = swap16(v); v = p.a + p.b; }
+  if constexpr (QS <= 32) { const Pair p = swap32(v); v = p.a + p.b; }
+  return v;
+}
+
+// The lane's priors of its targets chunk, chunk + nCh, ... -- `cnt` of them -- eight at a time, the NEXT eight requested before the
+// current eight are worked on: the loads are L2 round trips (~0.4 us) and an iteration of pass 1 is five fused multiply-adds --
+// one load ahead (the first version) made the sweep wait a round trip per target: 290 us per launch whatever the batch.
+template <typename F>
+__device__ __forceinline__ void walk_chunk(const double *pt, int Bp, int chunk, int nCh, int cnt, F &&body) {
+  constexpr int U = 8;
+  double cur[U], nxt[U];
+  const size_t stride = (size_t)nCh * (size_t)Bp;
+  const double *p = pt + (size_t)chunk * Bp;
+#pragma unroll
+  for (int e = 0; e < U; e++) cur[e] = p[(size_t)(e < cnt ? e : cnt - 1) * stride];
+  for (int i0 = 0; i0 < cnt; i0 += U) {
+    const bool more = i0 + U < cnt;
+#pragma unroll
+    for (int e = 0; e < U; e++) {
+      const int i = i0 + U + e;
+      nxt[e] = p[(size_t)(i < cnt ? i : cnt - 1) * stride];   // (the tail re-reads the lane's last target)
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int e = 0; e < U; e++)
+      if (i0 + e < cnt) body((i0 + e) * nCh + chunk, cur[e]);
+    if (more) {
+#pragma unroll
+      for (int e = 0; e < U; e++) cur[e] = nxt[e];
+    }
+  }
+}
+
+template <int QS>
+__global__ __launch_bounds__(kMidThreads) void eval_midbatch_kernel(MidArgs a) {
+  constexpr int K = kMidK, NW = kMidThreads / kWave, NSUB = kWave / QS, NCH = NW * NSUB;
+  extern __shared__ double smem[];
+  const double *tbl = smem;
+  if (!lds_table_at_zero(tbl)) __builtin_trap();            // log2hot addresses the table absolutely
+  double *tile = smem + kLog2TableDoubles;                  // [ldT][K + 1]
+  double *red = tile + (size_t)a.ldT * (K + 1);             // [NW][K + 2][QS]
+  for (int i = threadIdx.x; i < kLog2TableDoubles; i += kMidThreads) smem[i] = gLog2TableB[i];
+  const int tid = threadIdx.x, lane = tid % kWave, wave = tid / kWave;
+  const int slot = lane % QS, chunk = wave * NSUB + lane / QS;
+  const int b = blockIdx.y * QS + slot;                     // this lane's quiz
+  const bool live = b < a.nSlots;
+  const int64_t ldT = a.ldT;
+  const int Bp = a.Bp;
+  const double *pt = a.PT + (live ? b : 0);
+  const QuizSlot qs = a.slots[live ? b : 0];
+  const uint32_t *asked = live ? qs.asked : a.qgap;
+  const bool head = wave == 0 && lane < QS;                 // the lane that runs this quiz's epilogues
+  const int cnt = (int)((ldT - chunk + NCH - 1) / NCH);     // targets of this lane: chunk, chunk + NCH, ...
+  double bestP = 0.0;
+  int64_t bestQ = -1;
+  for (int64_t q = blockIdx.x; q < a.Q; q += gridDim.x) {
+    __syncthreads();                                        // everybody is done with the previous question's tile (and the table is in)
+    {
+      const double *qb = a.cube + q * (K + 1) * ldT;
+      for (int64_t t = tid; t < ldT; t += kMidThreads) {
+        const double invD = bit_test(a.tgap, t) ? 0.0 : div_nr(1.0, qb[K * ldT + t]);   // :74
+        double *dst = tile + t * (K + 1);
+#pragma unroll
+        for (int k = 0; k < K; k++) dst[k] = qb[k * ldT + t] * invD;                      // :81
+        dst[K] = invD * invD;                                                             // :117
+      }
+    }
+    __syncthreads();
+    // ---- pass 1 (:66-88)
+    double W[K];
+#pragma unroll
+    for (int k = 0; k < K; k++) W[k] = 0.0;
+    walk_chunk(pt, Bp, chunk, NCH, cnt, [&](int tc, double pi) __attribute__((always_inline)) {
+      const double *c = tile + (size_t)tc * (K + 1);
+#pragma unroll
+      for (int k = 0; k < K; k++) W[k] = fma(c[k], pi, W[k]);                             // :81-82, :85
+    });
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+      W[k] = chunk_fold<QS>(W[k]);
+      if (lane < QS) red[(wave * (K + 2) + k) * QS + slot] = W[k];
+    }
+    __syncthreads();
+    double invW[K];
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+      double w = 0.0;
+#pragma unroll
+      for (int w2 = 0; w2 < NW; w2++) w += red[(w2 * (K + 2) + k) * QS + slot];
+      W[k] = w;                                                                           // :88-90 (the same bits in every lane of the quiz)
+      invW[k] = div_fast(1.0, w);                                                         // :91
+    }
+    __syncthreads();                                        // (the exchange buffer is used again below)
+    // ---- pass 2 (:95-128)
+    double v[K], hW = 0.0, accL = 0.0;
+#pragma unroll
+    for (int k = 0; k < K; k++) v[k] = 0.0;
+    walk_chunk(pt, Bp, chunk, NCH, cnt, [&](int tc, double pi) __attribute__((always_inline)) {
+      const double *c = tile + (size_t)tc * (K + 1);
+      double cv[K + 1];
+#pragma unroll
+      for (int k = 0; k <= K; k++) cv[k] = c[k];
+      // :117 one reciprocal for the K lack terms of the target (see eval_batch_kernel: N / D built answer by answer)
+      double accN = 1.0, accD = 1.0;
+#pragma unroll
+      for (int k = 0; k < K; k++) {
+        const double lh = cv[k] * pi;                                                     // :81-82
+        const double p = lh * invW[k];                                                    // :97
+        const double l2 = Num<double>::log2p(p, tbl);                                     // :106
+        hW = fma(lh, l2, hW);                                                             // :113-114 weighted by W_k (eval_epilogue)
+        const double d = p - pi;                                                          // :119
+        v[k] = fma(d, d, v[k]);                                                           // :126-127
+        if (k == 0) accD = l2;
+        else { accN = fma(accN, l2, accD); accD = accD * l2; }
+      }
+      accL = fma(cv[K] * accN, Num<double>::rcp(accD), accL);
+    });
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+      v[k] = chunk_fold<QS>(v[k]);
+      if (lane < QS) red[(wave * (K + 2) + k) * QS + slot] = v[k];
+    }
+    hW = chunk_fold<QS>(hW);
+    accL = chunk_fold<QS>(accL);
+    if (lane < QS) {
+      red[(wave * (K + 2) + K) * QS + slot] = hW;
+      red[(wave * (K + 2) + K + 1) * QS + slot] = accL;
+    }
+    __syncthreads();
+    // ---- epilogue (:134-207), one lane per quiz
+    if (head) {
+      const bool skip = bit_test(a.qgap, q) || ((asked[q >> 5] >> (q & 31)) & 1u);        // :54
+      double pri = 0.0;
+      if (!skip) {
+        double mW[K], mWV[K], sums[2];
+#pragma unroll
+        for (int r = 0; r < K + 2; r++) {
+          double s2 = 0.0;
+#pragma unroll
+          for (int w2 = 0; w2 < NW; w2++) s2 += red[(w2 * (K + 2) + r) * QS + slot];
+          if (r < K) { mW[r] = W[r]; mWV[r] = W[r] * sqrt(s2); }                          // :156-157
+          else sums[r - K] = s2;
+        }
+        pri = eval_epilogue(mW, -sums[0], mWV, K, sums[1], a.vCompTail);
+      }
+      if (live) {
+        if (a.priorityT) a.priorityT[q * Bp + b] = pri;
+        if (!skip) {
+          if (qs.hostPriority != nullptr) {   // the host's selector: {priority, launch tag}, one write-through store (eval_kernels.hip: flush_pending)
+            typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+            const uint64_t w0 = d2u(pri), w1 = a.tag;
+            const u4 x = {(unsigned)w0, (unsigned)(w0 >> 32), (unsigned)w1, (unsigned)(w1 >> 32)};
+            asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(qs.hostPriority + q), "v"(x) : "memory");
+          }
+          const double cand = pri != pri ? -__builtin_huge_val() : pri;                   // NaN never wins over a number
+          if (bestQ < 0 || cand > bestP) { bestP = cand; bestQ = q; }                     // (questions ascend: the lowest index wins a tie)
+        }
+      }
+    }
+  }
+  if (head && b < Bp) a.recs[(size_t)blockIdx.x * Bp + b] = BatchRecord{bestP, bestQ};
+}
+
 // ---- every quiz's winner over the workgroups' records; the result and then the flag go to host-coherent memory ----------
-__global__ __launch_bounds__(256) void batch_pick_kernel(const BatchRecord *__restrict__ recs, int nRecs, int Bp,
-                                                         const QuizSlot *__restrict__ slots, int nSlots, int64_t outBase,
-                                                         uint64_t flagValue) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+// One wave per quiz: lane l merges records l, l + 64, ... (each a workgroup's best for this quiz), then the lanes' bests are merged
+// by shuffles.  (Until round 3 one THREAD per quiz walked all ~500 records, a dependent load each: 150 us behind every batched
+// sweep -- a tenth of the 256-quiz sweep at 1000 x 5 x 1000, more than the whole sweep for the batches of a few dozen quizzes.)
+__global__ __launch_bounds__(64) void batch_pick_kernel(const BatchRecord *__restrict__ recs, int nRecs, int Bp,
+                                                        const QuizSlot *__restrict__ slots, int nSlots, int64_t outBase,
+                                                        uint64_t flagValue) {
+  const int b = blockIdx.x, lane = threadIdx.x;
   if (b >= nSlots) return;
   double bp = 0.0;
   int64_t bq = -1;
-  for (int g = 0; g < nRecs; g++) {
+  for (int g = lane; g < nRecs; g += 64) {
     const BatchRecord r = recs[(size_t)g * Bp + b];
     if (r.index >= 0 && (bq < 0 || r.priority > bp || (r.priority == bp && r.index < bq))) { bp = r.priority; bq = r.index; }
   }
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) {
+    const double op = __shfl_xor(bp, m, 64);
+    const int64_t oq = __shfl_xor(bq, m, 64);
+    if (oq >= 0 && (bq < 0 || op > bp || (op == bp && oq < bq))) { bp = op; bq = oq; }
+  }
+  if (lane != 0) return;
   const QuizSlot s = slots[b];
   s.out->priority = bq < 0 ? 0.0 : bp;
   s.out->index = bq < 0 ? -1 : bq + outBase;
@@ -546,7 +757,64 @@ hipError_t LaunchEvalBatch(const KbView &kb, const QuizSlot *slots, int nSlots, 
   size_t dummy = 0;
   e = run(false, &dummy);
   if (e != hipSuccess || skipPick) return e;
-  hipLaunchKernelGGL(batch_pick_kernel, dim3((unsigned)((nSlots + 255) / 256)), dim3(256), 0, stream, recs, grid, Bp, slots, nSlots,
+  hipLaunchKernelGGL(batch_pick_kernel, dim3((unsigned)nSlots), dim3(64), 0, stream, recs, grid, Bp, slots, nSlots,
+                     outBase, flagValue);
+  return hipGetLastError();
+}
+
+// ---- the sweep for a few dozen quizzes (eval_midbatch_kernel): Double engines, K == 5, rows up to kMidMaxTargets --------------
+bool EvalMidBatchSupported(const KbView &kb) { return kb.elem == 8 && kb.K == kMidK && kb.ldT <= kMidMaxTargets; }
+
+// plan: out grid / Bp / ptBytes / recBytes (queryOnly), as LaunchEvalBatch; PT and recs from the caller.  Every quiz's winner goes to
+// its slot's `out` and flagValue to its `seq`; slots with hostPriority get their priorities as tagged records (tag = flagValue).
+hipError_t LaunchEvalMidBatch(const KbView &kb, const QuizSlot *slots, int nSlots, BatchPlan *plan, void *PT, BatchRecord *recs,
+                              double *priorityT, int64_t outBase, uint64_t flagValue, bool queryOnly, hipStream_t stream) {
+  if (!EvalMidBatchSupported(kb) || nSlots <= 0 || nSlots > 256 || plan == nullptr) return hipErrorInvalidValue;
+  const int Bp = ((nSlots + 63) / 64) * 64;
+  // quiz slots per wave: as few as hold the batch (more chunks per wave: shorter serial sums), 64 beyond 32 quizzes
+  const int QS = nSlots <= 16 ? 16 : nSlots <= 32 ? 32 : 64;
+  const int groups = (nSlots + QS - 1) / QS;
+  static LaunchCache cache;
+  const int devSlot = LaunchCache::Device();
+  const int nCU = cache.NumCUs(devSlot);
+  const size_t shmem = (size_t)(kLog2TableDoubles + kb.ldT * (kMidK + 1) + (kMidThreads / kWave) * (kMidK + 2) * QS) * sizeof(double);
+  if (shmem > 160 * 1024) return hipErrorInvalidValue;
+  const int perCU = (int)std::max<size_t>(1, std::min<size_t>(3, (160 * 1024) / shmem));
+  int64_t grid = std::min<int64_t>(kb.Q, std::max<int64_t>(1, (int64_t)nCU * perCU / groups));
+  if (grid > kBatchMaxGrid) grid = kBatchMaxGrid;
+  if (kb.maxGrid > 0 && grid > kb.maxGrid) grid = kb.maxGrid;
+  plan->grid = (int)grid;
+  plan->Bp = Bp;
+  plan->ptBytes = (size_t)kb.ldT * Bp * sizeof(double);
+  plan->accBytes = 0;
+  plan->recBytes = (size_t)grid * Bp * sizeof(BatchRecord);
+  if (queryOnly) return hipSuccess;
+  if (PT == nullptr || recs == nullptr) return hipErrorInvalidValue;
+  int attr = 0;
+  const size_t key = shmem * 128 + (size_t)QS;
+  if (shmem > 64 * 1024 && !cache.Get(devSlot, key, &attr)) {
+    hipError_t e = hipSuccess;
+    if (QS == 16) e = hipFuncSetAttribute(reinterpret_cast<const void *>(eval_midbatch_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+    else if (QS == 32) e = hipFuncSetAttribute(reinterpret_cast<const void *>(eval_midbatch_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+    else e = hipFuncSetAttribute(reinterpret_cast<const void *>(eval_midbatch_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+    if (e != hipSuccess) return e;
+    cache.Put(devSlot, key, 1);
+  }
+  const dim3 pgrid((unsigned)((kb.ldT + 63) / 64), (unsigned)(Bp / 64));
+  hipLaunchKernelGGL(batch_prep_kernel<double>, pgrid, dim3(kTileThreads), 0, stream, slots, nSlots, Bp, kb.tgap, kb.ldT, static_cast<double *>(PT));
+  MidArgs a{};
+  a.cube = static_cast<const double *>(kb.cube); a.PT = static_cast<const double *>(PT); a.tgap = kb.tgap; a.qgap = kb.qgap;
+  a.slots = slots; a.nSlots = nSlots; a.Bp = Bp; a.Q = kb.Q; a.ldT = kb.ldT;
+  const double nT = (double)(kb.nValidTargets + 1);            // PqaCore/CEEvalQsSubtaskConsider.cpp:191
+  a.vCompTail = 0.34657359027997265470861606072909 / (nT * nT);
+  a.recs = recs; a.priorityT = priorityT; a.tag = flagValue;
+  const dim3 g((unsigned)grid, (unsigned)groups);
+  if (QS == 16) hipLaunchKernelGGL(eval_midbatch_kernel<16>, g, dim3(kMidThreads), shmem, stream, a);
+  else if (QS == 32) hipLaunchKernelGGL(eval_midbatch_kernel<32>, g, dim3(kMidThreads), shmem, stream, a);
+  else hipLaunchKernelGGL(eval_midbatch_kernel<64>, g, dim3(kMidThreads), shmem, stream, a);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(batch_pick_kernel, dim3((unsigned)nSlots), dim3(64), 0, stream, recs, (int)grid, Bp, slots, nSlots,
                      outBase, flagValue);
   return hipGetLastError();
 }

@@ -351,6 +351,7 @@ Error HipEngine::SetOption(const char *name, int64_t value) {
   (void)FlushUpdates();   // (deferred updates run under the options they were recorded under)
   if (n == "select") { if (value != 0 && value != 1) goto bad; _optSelect = value; }
   else if (n == "combine") { _optCombine = value ? 1 : 0; }
+  else if (n == "combine_spin") { _optCombineSpin = value ? 1 : 0; }
   else if (n == "combine_linger_us") { if (value < 0 || value > 10000) goto bad; _optLingerUs = value; }
   else if (n == "workers") { if (value < 1 || value > kMaxWorkers) goto bad; _optWorkers = value; }
   else if (n == "eval_subtasks") { if (value < 0 || value > 8192) goto bad; _optEvalSubtasks = value; }
@@ -365,6 +366,7 @@ Error HipEngine::SetOption(const char *name, int64_t value) {
   else if (n == "host_sampled") { _optHostSampled = value ? 1 : 0; }
   else if (n == "batch_min") { if (value < 0 || value > 257) goto bad; _optBatchMin = value; }
   else if (n == "rerank") { _optRerank = value ? 1 : 0; }
+  else if (n == "batch_form") { if (value < 0 || value > 3) goto bad; _optBatchForm = value; }
   else if (n == "batch_qb") { if (value < 0 || value > 4) goto bad; _optBatchQb = value; }
   else if (n == "batch_tile") { if (value < 0 || value > 8192) goto bad; _optBatchTile = value; }
   else if (n == "server_vram_mailbox") { if (_serverStream) goto bad; _optServerVramMailbox = value ? 1 : 0; }
@@ -392,6 +394,8 @@ int64_t HipEngine::GetOption(const char *name) const {
   if (n == "speculate") return _optSpeculate;
   if (n == "combine") return _optCombine;
   if (n == "combine_linger_us") return _optLingerUs;
+  if (n == "combine_spin") return _optCombineSpin;
+  if (n == "allowed_cpus") return AllowedCpus();
   if (n == "combined_batches") return (int64_t)_combBatches;        // sweeps that served more than one NextQuestion call ...
   if (n == "combined_requests") return (int64_t)_combRequests;      // ... the calls they served ...
   if (n == "combined_max_batch") return (int64_t)_combMaxBatch;     // ... and the largest of them
@@ -411,6 +415,7 @@ int64_t HipEngine::GetOption(const char *name) const {
   if (n == "spec_dropped") return (int64_t)_specDropped;   // ... and those nothing used
   if (n == "batch_min") return _optBatchMin;
   if (n == "rerank") return _optRerank;
+  if (n == "batch_form") return _optBatchForm;
   if (n == "batch_tile") return _optBatchTile;
   if (n == "batch_qb") return _optBatchQb;
   if (n == "precision") return _precType;
@@ -1202,7 +1207,15 @@ Error HipEngine::BatchSweep(BatchCtx &c, int64_t n, const int64_t *pQuizzes, std
   // 92 k for grid.y = quiz, whose 48 MB cube is re-read from the Infinity Cache), while 256 quizzes fill it (133 k vs 95 k).
   // batch_min = 0 (default) decides by the wave count; an explicit value decides by the batch size alone.
   const int64_t qb = _optBatchQb > 0 ? _optBatchQb : (_elem == 4 ? 4 : 2), wavesRowSharing = ((n + 63) / 64) * ((_Q + qb - 1) / qb);
-  const bool rowSharing = _elem == 4 || wantPriorities || (_optBatchMin > 0 ? n >= _optBatchMin : (n >= 32 && wavesRowSharing >= 1536));
+  bool rowSharing = _elem == 4 || wantPriorities || (_optBatchMin > 0 ? n >= _optBatchMin : (n >= 32 && wavesRowSharing >= 1536));
+  // ... and between the two, for a few dozen quizzes over short rows (a server's combined sweeps): a lane is a (quiz, chunk of the
+  // row) -- batch_kernels.hip: eval_midbatch_kernel.  Option batch_form: 0 = by these rules, 1 grid.y = quiz, 2 row-sharing, 3 this one.
+  // By the measured costs at 1000 x 5 x 1000 (tools/midbatch_bench.py): grid.y ~11.3 us per quiz + 25; this form 138 / 229 us for up
+  // to 16 / 32 quizzes (its lanes come in 16 or 32 quiz slots) and 6.2 us per slot of 64 beyond: it wins from 11 quizzes on, except 17 and 18.
+  bool mid = EvalMidBatchSupported(View()) && ((_optBatchForm == 0 && !rowSharing && ((n >= 11 && n <= 16) || n >= 19)) || _optBatchForm == 3);
+  if (_optBatchForm == 1 && _elem == 8 && !wantPriorities) { rowSharing = false; mid = false; }
+  if (_optBatchForm == 2) { rowSharing = true; mid = false; }
+  if (mid) rowSharing = false;
   if (hostPriorities) {
     wantPriorities = rowSharing;   // (the row-sharing sweep keeps its priority matrix; grid.y = quiz writes per-quiz vectors anyway)
     if (pQuizMinor) *pQuizMinor = rowSharing;
@@ -1244,7 +1257,7 @@ Error HipEngine::BatchSweep(BatchCtx &c, int64_t n, const int64_t *pQuizzes, std
   // grid.y = quiz and the priorities wanted on the host: every workgroup stores the priorities of its questions there itself, one
   // {priority, launch tag} record each (as the single-quiz sweep's hand-over, FusedSelect::hostPriority) -- no copy behind the
   // sweep and no event: the quiz's flag says that every workgroup has reported, an entry is taken once it carries the tag
-  const bool tagged = hostPriorities && !rowSharing && EvalVariantHasFinisherWorkgroup(View(), (int)_optEvalVariant);
+  const bool tagged = hostPriorities && !rowSharing && (mid || EvalVariantHasFinisherWorkgroup(View(), (int)_optEvalVariant));
   if (pTagged) *pTagged = tagged;
   if (tagged) {
     const size_t doubles = 2 * (size_t)n * (size_t)_Q;
@@ -1264,6 +1277,27 @@ Error HipEngine::BatchSweep(BatchCtx &c, int64_t n, const int64_t *pQuizzes, std
   }
   HIP_TRY(hipMemcpyAsync(c.dSlots, c.h->slots, (size_t)n * sizeof(QuizSlot), hipMemcpyHostToDevice, _stream));
   StopServer();   // a launched sweep has no room beside the resident one and would wait for it to idle out
+  auto grow = [&](void **p, size_t &have, size_t need) -> hipError_t {
+    if (need <= have) return hipSuccess;
+    hipStreamSynchronize(_stream);
+    hipFree(*p);
+    *p = nullptr;
+    have = 0;
+    const hipError_t e = hipMalloc(p, need);
+    if (e == hipSuccess) have = need;
+    return e;
+  };
+  if (mid) {
+    const KbView kb = View();
+    BatchPlan plan{};
+    HIP_TRY(LaunchEvalMidBatch(kb, c.dSlots, (int)n, &plan, nullptr, nullptr, nullptr, 0, tag, true, _stream));
+    HIP_TRY(grow(&c.dPT, c.ptBytes, plan.ptBytes));
+    HIP_TRY(grow((void **)&c.dRecs, c.recBytes, plan.recBytes));
+    if (wantPriorities) HIP_TRY(grow((void **)&c.dPriT, c.priTBytes, (size_t)_Q * (size_t)plan.Bp * sizeof(double)));
+    HIP_TRY(LaunchEvalMidBatch(kb, c.dSlots, (int)n, &plan, c.dPT, c.dRecs, wantPriorities ? c.dPriT : nullptr, 0, tag, false, _stream));
+    c.lastBp = plan.Bp;
+    return Error();
+  }
   if (!rowSharing) {
     const FusedSelect fs{c.dScratch, nullptr, nullptr, tag, 0, kBatchGrid, tag, nullptr, tagged ? 1 : 0, 0, nullptr,
                          tagged ? reinterpret_cast<TaggedPriority *>(c.hPri) : nullptr};
@@ -1276,16 +1310,6 @@ Error HipEngine::BatchSweep(BatchCtx &c, int64_t n, const int64_t *pQuizzes, std
   plan.tileTargets = (int)_optBatchTile;
   plan.questionsPerBlock = (int)_optBatchQb;
   HIP_TRY(LaunchEvalBatch(kb, c.dSlots, (int)n, &plan, nullptr, nullptr, nullptr, nullptr, 0, tag, true, _stream));
-  auto grow = [&](void **p, size_t &have, size_t need) -> hipError_t {
-    if (need <= have) return hipSuccess;
-    hipStreamSynchronize(_stream);
-    hipFree(*p);
-    *p = nullptr;
-    have = 0;
-    const hipError_t e = hipMalloc(p, need);
-    if (e == hipSuccess) have = need;
-    return e;
-  };
   HIP_TRY(grow(&c.dPT, c.ptBytes, plan.ptBytes));
   HIP_TRY(grow((void **)&c.dAcc, c.accBytes, plan.accBytes));
   HIP_TRY(grow((void **)&c.dRecs, c.recBytes, plan.recBytes));
@@ -1563,8 +1587,36 @@ int64_t HipEngine::NextQuestion(Error &err, int64_t iQuiz) {
 // ------------------------------------------------------------------------------------------------------------------
 // concurrent NextQuestion calls (see SelRequest in hip_engine.h)
 // ------------------------------------------------------------------------------------------------------------------
+// How many CPUs the process may keep busy: a container's CPU quota (cgroup v2 cpu.max / v1 cfs quota) or else the affinity mask.
+// The GPU boxes of this project allow a container 16 of the host's 256 hardware threads: waiting policies that spin are right for
+// up to that many client threads and wrong beyond (measured: 64 spinning clients 40 k questions/s against 54 k sleeping).
+int HipEngine::AllowedCpus() {
+  static const int n = [] {
+    int cpus = (int)std::thread::hardware_concurrency();
+    if (cpus <= 0) cpus = 1;
+    if (FILE *f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {
+      char quota[32] = {0};
+      long long period = 0;
+      if (std::fscanf(f, "%31s %lld", quota, &period) == 2 && period > 0 && quota[0] != 'm') {
+        const long long q = std::atoll(quota);
+        if (q > 0) cpus = std::min<int>(cpus, (int)std::max<long long>(1, q / period));
+      }
+      std::fclose(f);
+    } else if (FILE *g = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {
+      long long q = -1, period = 100000;
+      if (std::fscanf(g, "%lld", &q) != 1) q = -1;
+      std::fclose(g);
+      if (FILE *h = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (std::fscanf(h, "%lld", &period) != 1) period = 100000; std::fclose(h); }
+      if (q > 0 && period > 0) cpus = std::min<int>(cpus, (int)std::max<long long>(1, q / period));
+    }
+    return cpus;
+  }();
+  return n;
+}
+
 int64_t HipEngine::Combine(Error &err, int64_t iQuiz, int kind, uint64_t rnd) {
   CallScope scope(_activeCallers);
+  _mu.spinFirst.store(ClientsFitCpus() && _activeCallers.load(std::memory_order_relaxed) > 1, std::memory_order_relaxed);
   if (!_optCombine) {
     std::lock_guard<EngineMutex> lk(_mu);
     return kind == 0 ? NextQuestionArgmaxLocked(err, iQuiz) : NextQuestionSampledLocked(err, iQuiz, rnd);
@@ -1583,11 +1635,34 @@ int64_t HipEngine::Combine(Error &err, int64_t iQuiz, int kind, uint64_t rnd) {
     //  microseconds after its neighbours; but dozens of spinning client threads eat the cores the process is allowed:
     //  a short spin, then sleep)
     int st = 0;
+    const auto tw0 = std::chrono::steady_clock::now();
     for (int spins = 0; spins < 1500 && (st = r.state.load(std::memory_order_acquire)) == 0; spins++) _mm_pause();
+    if (st == 0 && ClientsFitCpus()) {
+      // Fewer clients than CPUs: sleep most of the expected wait (about as long as the last combined sweeps took), spin the rest --
+      // woken through the kernel the clients of one sweep arrive tens of microseconds apart.  More clients than CPUs: the
+      // condition variable only (spinning waiters would take the CPUs from the threads that have work).
+      const int64_t expect = _sweepNsEwma.load(std::memory_order_relaxed);
+      if (expect > 90000) {
+        static thread_local bool slackSet = false;
+        if (!slackSet) { prctl(PR_SET_TIMERSLACK, 2000UL, 0, 0, 0); slackSet = true; }
+        const auto until = tw0 + std::chrono::nanoseconds(std::min<int64_t>(expect - 50000, 2000000));
+        // (in naps of 40 us: the lead may be handed to this request meanwhile, and the next sweep waits for its leader)
+        while ((st = r.state.load(std::memory_order_acquire)) == 0 && std::chrono::steady_clock::now() < until) {
+          struct timespec ts{0, 40000};
+          nanosleep(&ts, nullptr);
+        }
+      }
+      for (int spins = 0; spins < 12000 && (st = r.state.load(std::memory_order_acquire)) == 0; spins++) _mm_pause();
+    }
     if (st == 0) {
       std::unique_lock<std::mutex> lk(_combMu);
       _combCv.wait(lk, [&] { return r.state.load(std::memory_order_acquire) != 0; });
       st = r.state.load(std::memory_order_acquire);
+    }
+    {
+      const int64_t waited = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - tw0).count();
+      const int64_t old = _sweepNsEwma.load(std::memory_order_relaxed);
+      _sweepNsEwma.store(old == 0 ? waited : old + (waited - old) / 8, std::memory_order_relaxed);
     }
     if (st == 1) { err = r.err; return r.result; }
     if (st == 3) {   // the sweep has run: this quiz's priorities are on the host, the selection is this thread's own work

@@ -368,6 +368,9 @@ class HipEngine : public IEngine {
     ~CallScope() { n.fetch_sub(1, std::memory_order_relaxed); }
   };
   bool Concurrent() const { return _optCombine && _activeCallers.load(std::memory_order_relaxed) > 1; }
+  static int AllowedCpus();                   // the CPUs this process may use: the cgroup's quota (cpu.max) or the affinity mask
+  int64_t _optCombineSpin = 1;                // option "combine_spin": 1 = waiting clients spin while they are fewer than the allowed CPUs, 0 = they always sleep
+  bool ClientsFitCpus() const { return _optCombineSpin && _activeCallers.load(std::memory_order_relaxed) + 2 <= AllowedCpus(); }
   int64_t _optCombine = 1;                    // option "combine" / PQA_COMBINE: 0 = every call by itself, as before
   // ---- combining of concurrent NextQuestion calls (reference: every client's NextQuestion runs under a SHARED lock,
   // PqaCore/CpuEngine.cpp:357-361, Interface/IPqaEngine.h:44).  A caller posts its request; if a leader is at work it waits
@@ -394,6 +397,7 @@ class HipEngine : public IEngine {
   int64_t SelectFromPriorities(SelRequest *r);     // the host-side selector + FinishSelection for one request of a combined sweep
   std::atomic<size_t> _pendingCount{0};            // == _pendingUpdates.size(), readable without the lock
   std::atomic<int64_t> _flushedSinceSweep{0};      // RecordAnswers launched since the newest combined sweep: their clients' NextQuestions are on their way
+  std::atomic<int64_t> _sweepNsEwma{0};            // how long a follower of a combined sweep waits for its result (moving average): it sleeps most of that, then spins
   std::atomic<int64_t> _lastCombined{0};           // requests of the newest combined sweep: as many RecordAnswers are about to arrive
   int64_t _optLingerUs = 20;                       // option "combine_linger_us": how long a ListTopTargets waits for them before it launches the updates
   std::mutex _combMu;
@@ -490,7 +494,18 @@ class HipEngine : public IEngine {
     //  as a ticket lock, burn that allowance: 64 client threads fell from 45 k to 13 k questions/s, 256 to 0.3 k)
     std::mutex m;
     bool busy = false, wasBusy = false;
-    void lock() { m.lock(); wasBusy = busy; busy = true; }
+    // (spinFirst -- set while the client threads are fewer than the CPUs the process may use: a bounded spin before sleeping; the
+    //  holder is usually a microsecond of bookkeeping or one kernel launch away from releasing, and being woken through the kernel
+    //  costs tens of microseconds.  With more clients than CPUs every spinning waiter takes time from a thread that has work.)
+    std::atomic<bool> spinFirst{false};
+    void lock() {
+      if (spinFirst.load(std::memory_order_relaxed))
+        for (int i = 0; i < 400; i++) {
+          if (m.try_lock()) { wasBusy = busy; busy = true; return; }
+          for (int j = 0; j < 4; j++) __builtin_ia32_pause();
+        }
+      m.lock(); wasBusy = busy; busy = true;
+    }
     void lock_urgent() { lock(); }
     void unlock() { m.unlock(); }
   };
@@ -521,6 +536,7 @@ class HipEngine : public IEngine {
                                   // but 38.3 vs 36.4 us at 1000 x 5 x 1000 -- one workgroup's serial selection costs more than a launch
   int64_t _optEvalMaxGrid = 0;    // test hook: KbView::maxGrid
   int64_t _optBatchMin = 0;       // batches of at least this many quizzes take the row-sharing sweep (lane = quiz), smaller ones grid.y = quiz; 0 = by the number of waves the batch gives the row-sharing sweep
+  int64_t _optBatchForm = 0;      // 0: the batch's form by its size and the cube's shape; 1 grid.y = quiz, 2 row-sharing, 3 (quiz, chunk) lanes
   int64_t _optRerank = 1;         // Float engines' batched argmax: the fp32 sweep's best 8 questions per quiz re-ranked in fp64
   int64_t _optBatchQb = 0;        // questions per block of that sweep (0 = default)
   int64_t _optBatchTile = 0;      // targets per LDS tile of that sweep (0 = default)

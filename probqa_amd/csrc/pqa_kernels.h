@@ -133,6 +133,11 @@ struct BatchPlan {
 hipError_t LaunchEvalBatch(const KbView &kb, const QuizSlot *slots, int nSlots, BatchPlan *plan, void *PT, double *acc,
                            BatchRecord *recs, double *priorityT, int64_t outBase, uint64_t flagValue, bool queryOnly, hipStream_t stream,
                            bool skipPick = false);   // skipPick: the caller picks (LaunchBatchRerank)
+// The sweep for a few dozen quizzes (batch_kernels.hip: eval_midbatch_kernel; Double engines, K == 5, short rows): a lane is a
+// (quiz, chunk of the row).  plan / PT / recs / priorityT / flags as LaunchEvalBatch; slots with hostPriority get tagged records.
+bool EvalMidBatchSupported(const KbView &kb);
+hipError_t LaunchEvalMidBatch(const KbView &kb, const QuizSlot *slots, int nSlots, BatchPlan *plan, void *PT, BatchRecord *recs,
+                              double *priorityT, int64_t outBase, uint64_t flagValue, bool queryOnly, hipStream_t stream);
 // skipPick (LaunchEvalBatch's flagValue == 0 is not used for this: see the argument): Float engines' batched ARGMAX -- the fp32
 // sweep nominates, fp64 decides (eval_kernels.hip: batch_rerank_kernel).  priorityT: the sweep's [Q][Bp] matrix; scratch:
 // BatchRerankScratchBytes() of device memory.  Writes every quiz's winner and flag like LaunchEvalBatch's own pick.

@@ -422,3 +422,38 @@ def test_batched_posterior_updates_are_bit_identical(dims, factory):
     with pytest.raises(interop.PqaException, match="active question"):
         eng.record_answer_batch([batch[0]], [0])            # no active question any more
     eng.close()
+
+
+@pytest.mark.parametrize("dims", [(37, 101), (300, 1000), (64, 50), (90, 2000)], ids=lambda d: "%dx5x%d" % d)
+@pytest.mark.parametrize("n_quizzes", [3, 16, 17, 33, 70], ids=lambda n: "%dq" % n)
+def test_fp64_midbatch_sweep_against_oracle(dims, n_quizzes, factory):
+    """The sweep for a few dozen quizzes (batch_kernels.hip: eval_midbatch_kernel -- a lane is a (quiz, chunk of the row); what the
+    engine's combined sweeps for concurrent clients use): every quiz's priorities against the oracle (1e-9) and against the
+    row-sharing sweep (1e-11), the selections = the oracle's argmaxes, with target and question gaps, 16 / 32 / 64 quiz slots per
+    wave, rows that do not fill their last chunk, and workgroups that sweep many questions (eval_max_grid)."""
+    Q, T = dims
+    rng = np.random.default_rng(Q + n_quizzes)
+    case = cases.Case("mid_%dx5x%d" % dims, 5, Q, T, seed=Q + T, tgaps=sorted(rng.choice(T, 3, replace=False).tolist()),
+                      qgaps=sorted(rng.choice(Q, 2, replace=False).tolist()))
+    eng = case.make_engine(factory)
+    orc = case.make_oracle()
+    quizzes = scripted_quizzes(case, eng, n_quizzes, rng)
+    ids = [q for q, _ in quizzes]
+    pri_rs = eng.eval_priorities_batch(ids, case.Q)                 # row-sharing
+    for max_grid in (0, 3):
+        eng.set_option("eval_max_grid", max_grid)
+        eng.set_option("batch_form", 3)
+        pri = eng.eval_priorities_batch(ids, case.Q)
+        picks = eng.next_question_argmax_batch(ids)
+        eng.set_option("batch_form", 0)
+        assert cases.rel_err(pri, pri_rs).max() < 1e-11
+        for i, (quiz, hist) in enumerate(quizzes):
+            if i % 5 and n_quizzes > 20:
+                continue
+            opri, opriors = oracle_priorities(orc, hist)
+            assert np.array_equal(eng.get_priors(quiz), opriors)
+            assert rel_to(pri[i], opri) < PRIORITY_RTOL, f"quiz {i} ({hist})"
+            top = np.sort(opri)[::-1]
+            if top[0] > 0 and (top[0] - top[1]) / top[0] > 10 * PRIORITY_RTOL:
+                assert picks[i] == orc.select_argmax(opri), f"quiz {i}: argmax"
+    eng.close()

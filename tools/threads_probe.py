@@ -7,6 +7,8 @@ f = interop.PqaEngineFactory()
 e, err = f.create_cpu_engine(interop.EngineDefinition(5, 1000, 1000, init_amount=0.1))
 e.fill_synthetic(8.0, 0.5, 20260928)
 e.set_option("select", int(os.environ.get("SELECT", "0")))
+if "SPIN" in os.environ:
+    e.set_option("combine_spin", int(os.environ["SPIN"]))
 if "LINGER" in os.environ:
     e.set_option("combine_linger_us", int(os.environ["LINGER"]))
 keys = ["combined_batches", "combined_requests", "update_flushes", "updates_flushed", "combined_ns_lock", "combined_ns_launch",
