@@ -645,9 +645,10 @@ __device__ __forceinline__ uint64_t line_u64(uint32_t v, int i) {   // qword i o
 }
 
 template <int WPQ, int NP, bool DEFER>
-// waves_per_eu(4, 4) = 128 VGPRs: three workgroups per CU then leave 128 registers per SIMD lane for the 256-thread posterior
-// kernels (<= 48) that must run beside the resident sweep (prior_kernels.hip: kSmallThreads)
-__global__ __launch_bounds__(WPQ * 64) __attribute__((amdgpu_waves_per_eu(4, 4)))
+// Three workgroups per CU with the 154 registers the kernel wants (3 x 160 of the 512 per SIMD lane).  Capped at 128 (waves_per_eu
+// (4, 4), until round 3) it spilled 17 registers and a step took 19.0 us instead of 17.0.  The 32 registers left per lane are what the
+// 256-thread posterior kernels that must run beside the resident sweep fit into (prior_kernels.hip: kSmallThreads; 24 - 30 each).
+__global__ __launch_bounds__(WPQ * 64) __attribute__((amdgpu_waves_per_eu(3, 3)))
 void eval_server_f64(EvalArgs a, ServerMailbox *mb, uint32_t *requestLine, int everyonePolls, ServerCtl *ctl, uint64_t lastSeq,
                      uint64_t idleTicks, unsigned stepOffsetBytes) {
   extern __shared__ double smem[];

@@ -14,6 +14,9 @@ __device__ __forceinline__ int64_t prior_split_bound(int64_t i, int64_t quot, in
 
 // Sum v[0 .. 4*nVects) exactly as the CPU engine does and return the total to every thread.
 // lds: 8*nSubtasks + 1 doubles.  Must be called by all threads; contains barriers.
+// AHEAD: request sixteen elements of a chain at once (long rows, values in global memory); the 256-thread forms that run beside
+// the resident sweep have their values in LDS and must stay within the registers it leaves them.
+template <bool AHEAD = true>
 __device__ double reference_order_sum(const double *__restrict__ v, int64_t nVects, int64_t nWorkers, double *lds) {
   const int64_t quot = nVects / nWorkers, rem = nVects % nWorkers;
   const int64_t nSubtasks = (quot == 0) ? rem : nWorkers;
@@ -27,6 +30,7 @@ __device__ double reference_order_sum(const double *__restrict__ v, int64_t nVec
     // order (a chain is T / (4 nWorkers) elements long -- 1667 at 100000 targets and 15 subtasks -- and one L2 round trip per
     // element, taken one after the other, was 0.4 us each: 736 us of StartQuiz, 356 us of RecordAnswer there).
     int64_t j = first;
+    if constexpr (AHEAD)
     for (; j + 16 <= limit; j += 16) {
       double x[16];
 #pragma unroll
@@ -111,6 +115,7 @@ __device__ __forceinline__ void record_answer_body(PriorArgs a, int64_t iQuestio
   //  trip each otherwise; the element arithmetic and its order per element are unchanged)
   const int64_t step = blockDim.x;
   int64_t t = threadIdx.x;
+  if constexpr (!SMALL)
   for (; t + 3 * step < a.ldT; t += 4 * step) {
     double av[4], dv[4], old[4];
 #pragma unroll
@@ -131,8 +136,9 @@ __device__ __forceinline__ void record_answer_body(PriorArgs a, int64_t iQuestio
     const double product = old * pQaGivenT;                    // :34
     stage[t] = bit_test(a.tgap, t) ? 0.0 : product;            // :35-37
   }
-  const double total = reference_order_sum(stage, nVects, a.nWorkers, lds);
+  const double total = reference_order_sum<!SMALL>(stage, nVects, a.nWorkers, lds);
   t = threadIdx.x;
+  if constexpr (!SMALL)
   for (; t + 3 * step < a.ldT; t += 4 * step) {
     double x[4];
 #pragma unroll

@@ -23,21 +23,24 @@ namespace pqa {
 namespace {
 
 constexpr int kThreads = 1024;
-// While the resident sweep (eval_kernels.hip: eval_server_f64) holds three workgroups of 152 VGPRs on every CU, a
+// While the resident sweep (eval_kernels.hip: eval_server_f64) holds three workgroups of 154 (allocated: 160) VGPRs on every CU, a
 // 1024-thread workgroup of these kernels fits nowhere and would wait for the sweep to leave.  With <= 1024 targets they are
-// launched with 256 threads instead (one wave per SIMD, <= 56 VGPRs): same arithmetic, same summation order.
+// launched with 256 threads instead (one wave per SIMD, within the 32 VGPRs that are left: 24 - 30): same arithmetic, same
+// summation order, without the load batching of the long-row forms.
 constexpr int kSmallThreads = 256;
 static inline bool small_launch(const KbView &kb) { return kb.smallLaunches && kb.T <= 4 * kSmallThreads; }
 
 // (clears the new quiz's asked bitmap as well: a memset beside it is a second launch)
-__global__ __launch_bounds__(kThreads) void start_quiz_kernel(PriorArgs a, uint32_t *__restrict__ asked, int64_t askedWords) {
+// SMALL: the 256-thread form that runs beside the resident sweep (within the 32 registers it leaves per lane)
+template <bool SMALL>
+__global__ __launch_bounds__(SMALL ? kSmallThreads : kThreads) void start_quiz_kernel(PriorArgs a, uint32_t *__restrict__ asked, int64_t askedWords) {
   extern __shared__ double lds[];
   for (int64_t i = threadIdx.x; i < askedWords; i += blockDim.x) asked[i] = 0;
   const int64_t nVects = (a.T + 3) >> 2;
   double *stage = prior_stage(a, lds);
   for (int64_t t = threadIdx.x; t < a.ldT; t += blockDim.x)
     stage[t] = bit_test(a.tgap, t) ? 0.0 : a.vB[t];            // CESetPriorsSubtaskSum.cpp:28-31
-  const double total = reference_order_sum(stage, nVects, a.nWorkers, lds);
+  const double total = reference_order_sum<!SMALL>(stage, nVects, a.nWorkers, lds);
   for (int64_t t = threadIdx.x; t < a.ldT; t += blockDim.x) a.prior[t] = t < 4 * nVects ? stage[t] / total : stage[t];  // CEDivTargPriors :19
 }
 
@@ -178,8 +181,12 @@ PriorArgs make_args(const KbView &kb, double *prior, int64_t nWorkers, bool stag
 
 hipError_t LaunchStartQuiz(const KbView &kb, double *prior, uint32_t *asked, int64_t askedWords, int64_t nWorkers, hipStream_t stream) {
   if (nWorkers < 1 || nWorkers > kMaxWorkers) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(start_quiz_kernel, dim3(1), dim3(small_launch(kb) ? kSmallThreads : kThreads), staged_lds_bytes(kb, nWorkers), stream,
-                     make_args(kb, prior, nWorkers, true), asked, askedWords);
+  if (small_launch(kb))
+    hipLaunchKernelGGL(start_quiz_kernel<true>, dim3(1), dim3(kSmallThreads), staged_lds_bytes(kb, nWorkers), stream,
+                       make_args(kb, prior, nWorkers, true), asked, askedWords);
+  else
+    hipLaunchKernelGGL(start_quiz_kernel<false>, dim3(1), dim3(kThreads), staged_lds_bytes(kb, nWorkers), stream,
+                       make_args(kb, prior, nWorkers, true), asked, askedWords);
   return hipGetLastError();
 }
 
