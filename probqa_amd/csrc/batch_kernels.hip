@@ -347,10 +347,10 @@ __global__ __launch_bounds__(256) void eval_batch_kernel(BatchArgs a) {
 //   * one lane per quiz runs the fp64 epilogue and keeps the quiz's best question; priorities go to the priority matrix and /
 //     or straight to the host as tagged records (QuizSlot::hostPriority), as the other sweeps deliver them.
 // Per (question, quiz) ~31 VALU slots per element as the row-sharing sweep, against ~50 per element pair-half of the register
-// form with its reductions.  K == 5 (the configuration every benchmark of the reference uses); rows up to kMidMaxTargets.
+// form with its reductions.  Two to eight answers (five -- the configuration every benchmark of the reference uses -- with nothing depending on a
+// run-time count); rows whose block fits the CU's LDS (2500 targets at five answers).
 // ------------------------------------------------------------------------------------------------------------------
-constexpr int kMidThreads = 256, kMidK = 5;
-constexpr int64_t kMidMaxTargets = 2560;   // (K + 1) x 8 B x ldT + the table + the exchange within the CU's 160 KB (two workgroups per CU up to ~1050 targets)
+constexpr int kMidThreads = 256, kMidMaxK = 8;   // answers: 5 (exact) or any number up to 8
 
 struct MidArgs {
   const double *cube;        // [Q][K+1][ldT]
@@ -358,7 +358,7 @@ struct MidArgs {
   const uint32_t *tgap, *qgap;
   const QuizSlot *slots;
   int nSlots, Bp;
-  int64_t Q, ldT;
+  int64_t Q, ldT, K;
   double vCompTail;
   BatchRecord *recs;         // [grid.x][Bp]
   double *priorityT;         // optional [Q][Bp]
@@ -400,9 +400,11 @@ __device__ __forceinline__ void walk_chunk(const double *pt, int Bp, int chunk, 
   }
 }
 
-template <int QS>
+// KM: the answers the arrays hold; EXACT: K == KM (nothing in the element loops depends on a run-time answer count)
+template <int QS, int KM, bool EXACT>
 __global__ __launch_bounds__(kMidThreads) void eval_midbatch_kernel(MidArgs a) {
-  constexpr int K = kMidK, NW = kMidThreads / kWave, NSUB = kWave / QS, NCH = NW * NSUB;
+  constexpr int K = KM, NW = kMidThreads / kWave, NSUB = kWave / QS, NCH = NW * NSUB;
+  const int kN = EXACT ? KM : (int)a.K;                     // the answers there are
   extern __shared__ double smem[];
   const double *tbl = smem;
   if (!lds_table_at_zero(tbl)) __builtin_trap();            // log2hot addresses the table absolutely
@@ -425,12 +427,12 @@ __global__ __launch_bounds__(kMidThreads) void eval_midbatch_kernel(MidArgs a) {
   for (int64_t q = blockIdx.x; q < a.Q; q += gridDim.x) {
     __syncthreads();                                        // everybody is done with the previous question's tile (and the table is in)
     {
-      const double *qb = a.cube + q * (K + 1) * ldT;
+      const double *qb = a.cube + q * (kN + 1) * ldT;
       for (int64_t t = tid; t < ldT; t += kMidThreads) {
-        const double invD = bit_test(a.tgap, t) ? 0.0 : div_nr(1.0, qb[K * ldT + t]);   // :74
+        const double invD = bit_test(a.tgap, t) ? 0.0 : div_nr(1.0, qb[kN * ldT + t]);  // :74
         double *dst = tile + t * (K + 1);
 #pragma unroll
-        for (int k = 0; k < K; k++) dst[k] = qb[k * ldT + t] * invD;                      // :81
+        for (int k = 0; k < K; k++) dst[k] = (EXACT || k < kN) ? qb[k * ldT + t] * invD : 0.0;   // :81
         dst[K] = invD * invD;                                                             // :117
       }
     }
@@ -457,7 +459,7 @@ __global__ __launch_bounds__(kMidThreads) void eval_midbatch_kernel(MidArgs a) {
 #pragma unroll
       for (int w2 = 0; w2 < NW; w2++) w += red[(w2 * (K + 2) + k) * QS + slot];
       W[k] = w;                                                                           // :88-90 (the same bits in every lane of the quiz)
-      invW[k] = div_fast(1.0, w);                                                         // :91
+      invW[k] = (EXACT || k < kN) ? div_fast(1.0, w) : 0.0;                               // :91
     }
     __syncthreads();                                        // (the exchange buffer is used again below)
     // ---- pass 2 (:95-128)
@@ -473,6 +475,7 @@ __global__ __launch_bounds__(kMidThreads) void eval_midbatch_kernel(MidArgs a) {
       double accN = 1.0, accD = 1.0;
 #pragma unroll
       for (int k = 0; k < K; k++) {
+        if (!EXACT && k >= kN) break;
         const double lh = cv[k] * pi;                                                     // :81-82
         const double p = lh * invW[k];                                                    // :97
         const double l2 = Num<double>::log2p(p, tbl);                                     // :106
@@ -510,7 +513,7 @@ __global__ __launch_bounds__(kMidThreads) void eval_midbatch_kernel(MidArgs a) {
           if (r < K) { mW[r] = W[r]; mWV[r] = W[r] * sqrt(s2); }                          // :156-157
           else sums[r - K] = s2;
         }
-        pri = eval_epilogue(mW, -sums[0], mWV, K, sums[1], a.vCompTail);
+        pri = eval_epilogue(mW, -sums[0], mWV, kN, sums[1], a.vCompTail);
       }
       if (live) {
         if (a.priorityT) a.priorityT[q * Bp + b] = pri;
@@ -763,7 +766,11 @@ hipError_t LaunchEvalBatch(const KbView &kb, const QuizSlot *slots, int nSlots, 
 }
 
 // ---- the sweep for a few dozen quizzes (eval_midbatch_kernel): Double engines, K == 5, rows up to kMidMaxTargets --------------
-bool EvalMidBatchSupported(const KbView &kb) { return kb.elem == 8 && kb.K == kMidK && kb.ldT <= kMidMaxTargets; }
+bool EvalMidBatchSupported(const KbView &kb) {
+  const int64_t km = kb.K == 5 ? 5 : kMidMaxK;
+  return kb.elem == 8 && kb.K >= 2 && kb.K <= kMidMaxK &&
+         (size_t)(kLog2TableDoubles + kb.ldT * (km + 1) + (kMidThreads / kWave) * (km + 2) * 64) * sizeof(double) <= 160 * 1024;
+}
 
 // plan: out grid / Bp / ptBytes / recBytes (queryOnly), as LaunchEvalBatch; PT and recs from the caller.  Every quiz's winner goes to
 // its slot's `out` and flagValue to its `seq`; slots with hostPriority get their priorities as tagged records (tag = flagValue).
@@ -777,7 +784,8 @@ hipError_t LaunchEvalMidBatch(const KbView &kb, const QuizSlot *slots, int nSlot
   static LaunchCache cache;
   const int devSlot = LaunchCache::Device();
   const int nCU = cache.NumCUs(devSlot);
-  const size_t shmem = (size_t)(kLog2TableDoubles + kb.ldT * (kMidK + 1) + (kMidThreads / kWave) * (kMidK + 2) * QS) * sizeof(double);
+  const int KM = kb.K == 5 ? 5 : kMidMaxK;
+  const size_t shmem = (size_t)(kLog2TableDoubles + kb.ldT * (KM + 1) + (kMidThreads / kWave) * (KM + 2) * QS) * sizeof(double);
   if (shmem > 160 * 1024) return hipErrorInvalidValue;
   const int perCU = (int)std::max<size_t>(1, std::min<size_t>(3, (160 * 1024) / shmem));
   int64_t grid = std::min<int64_t>(kb.Q, std::max<int64_t>(1, (int64_t)nCU * perCU / groups));
@@ -790,13 +798,14 @@ hipError_t LaunchEvalMidBatch(const KbView &kb, const QuizSlot *slots, int nSlot
   plan->recBytes = (size_t)grid * Bp * sizeof(BatchRecord);
   if (queryOnly) return hipSuccess;
   if (PT == nullptr || recs == nullptr) return hipErrorInvalidValue;
+  // the instantiation: quiz slots per wave x (five answers exactly | up to eight)
+  void (*kern)(MidArgs) = nullptr;
+  if (KM == 5) kern = QS == 16 ? eval_midbatch_kernel<16, 5, true> : QS == 32 ? eval_midbatch_kernel<32, 5, true> : eval_midbatch_kernel<64, 5, true>;
+  else kern = QS == 16 ? eval_midbatch_kernel<16, kMidMaxK, false> : QS == 32 ? eval_midbatch_kernel<32, kMidMaxK, false> : eval_midbatch_kernel<64, kMidMaxK, false>;
   int attr = 0;
-  const size_t key = shmem * 128 + (size_t)QS;
+  const size_t key = shmem * 1024 + (size_t)QS * 16 + (size_t)KM;
   if (shmem > 64 * 1024 && !cache.Get(devSlot, key, &attr)) {
-    hipError_t e = hipSuccess;
-    if (QS == 16) e = hipFuncSetAttribute(reinterpret_cast<const void *>(eval_midbatch_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-    else if (QS == 32) e = hipFuncSetAttribute(reinterpret_cast<const void *>(eval_midbatch_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-    else e = hipFuncSetAttribute(reinterpret_cast<const void *>(eval_midbatch_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
     if (e != hipSuccess) return e;
     cache.Put(devSlot, key, 1);
   }
@@ -804,14 +813,12 @@ hipError_t LaunchEvalMidBatch(const KbView &kb, const QuizSlot *slots, int nSlot
   hipLaunchKernelGGL(batch_prep_kernel<double>, pgrid, dim3(kTileThreads), 0, stream, slots, nSlots, Bp, kb.tgap, kb.ldT, static_cast<double *>(PT));
   MidArgs a{};
   a.cube = static_cast<const double *>(kb.cube); a.PT = static_cast<const double *>(PT); a.tgap = kb.tgap; a.qgap = kb.qgap;
-  a.slots = slots; a.nSlots = nSlots; a.Bp = Bp; a.Q = kb.Q; a.ldT = kb.ldT;
+  a.slots = slots; a.nSlots = nSlots; a.Bp = Bp; a.Q = kb.Q; a.ldT = kb.ldT; a.K = kb.K;
   const double nT = (double)(kb.nValidTargets + 1);            // PqaCore/CEEvalQsSubtaskConsider.cpp:191
   a.vCompTail = 0.34657359027997265470861606072909 / (nT * nT);
   a.recs = recs; a.priorityT = priorityT; a.tag = flagValue;
   const dim3 g((unsigned)grid, (unsigned)groups);
-  if (QS == 16) hipLaunchKernelGGL(eval_midbatch_kernel<16>, g, dim3(kMidThreads), shmem, stream, a);
-  else if (QS == 32) hipLaunchKernelGGL(eval_midbatch_kernel<32>, g, dim3(kMidThreads), shmem, stream, a);
-  else hipLaunchKernelGGL(eval_midbatch_kernel<64>, g, dim3(kMidThreads), shmem, stream, a);
+  hipLaunchKernelGGL(kern, g, dim3(kMidThreads), shmem, stream, a);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(batch_pick_kernel, dim3((unsigned)nSlots), dim3(64), 0, stream, recs, (int)grid, Bp, slots, nSlots,

@@ -424,16 +424,17 @@ def test_batched_posterior_updates_are_bit_identical(dims, factory):
     eng.close()
 
 
-@pytest.mark.parametrize("dims", [(37, 101), (300, 1000), (64, 50), (90, 2000)], ids=lambda d: "%dx5x%d" % d)
+@pytest.mark.parametrize("dims", [(37, 5, 101), (300, 5, 1000), (64, 5, 50), (90, 5, 2000), (40, 3, 300), (50, 8, 700), (33, 2, 64)],
+                         ids=lambda d: "%dx%dx%d" % d)
 @pytest.mark.parametrize("n_quizzes", [3, 16, 17, 33, 70], ids=lambda n: "%dq" % n)
 def test_fp64_midbatch_sweep_against_oracle(dims, n_quizzes, factory):
     """The sweep for a few dozen quizzes (batch_kernels.hip: eval_midbatch_kernel -- a lane is a (quiz, chunk of the row); what the
     engine's combined sweeps for concurrent clients use): every quiz's priorities against the oracle (1e-9) and against the
-    row-sharing sweep (1e-11), the selections = the oracle's argmaxes, with target and question gaps, 16 / 32 / 64 quiz slots per
-    wave, rows that do not fill their last chunk, and workgroups that sweep many questions (eval_max_grid)."""
-    Q, T = dims
+    row-sharing sweep (1e-11), the selections = the oracle's argmaxes, with target and question gaps, two to eight answers, 16 / 32 / 64
+    quiz slots per wave, rows that do not fill their last chunk, and workgroups that sweep many questions (eval_max_grid)."""
+    Q, K, T = dims
     rng = np.random.default_rng(Q + n_quizzes)
-    case = cases.Case("mid_%dx5x%d" % dims, 5, Q, T, seed=Q + T, tgaps=sorted(rng.choice(T, 3, replace=False).tolist()),
+    case = cases.Case("mid_%dx%dx%d" % dims, K, Q, T, seed=Q + T, tgaps=sorted(rng.choice(T, 3, replace=False).tolist()),
                       qgaps=sorted(rng.choice(Q, 2, replace=False).tolist()))
     eng = case.make_engine(factory)
     orc = case.make_oracle()
