@@ -7,6 +7,7 @@
 //
 // This file is a CLIENT of libPqaCore.so: it calls the reference's C ABI (include/PqaCInterop.h) and nothing else -- no engine
 // internals, no HIP.  bench.py's `quiz_loop_threads` extra and tests/test_gpu_concurrent.py drive it through ctypes.
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <cstdint>
@@ -46,6 +47,11 @@ __attribute__((visibility("default"))) int64_t PqaClient_RunLearners(void *pvEng
   const int64_t width = (32 * T) / 1000 > 1 ? (32 * T) / 1000 : 1;
   std::atomic<int64_t> nextQuiz{0}, questions{0}, onTop{0}, errors{0}, done{0};
   std::atomic<uint64_t> digest{0};
+  std::atomic<int64_t> nsIn[6] = {{0}, {0}, {0}, {0}, {0}, {0}};   // StartQuiz, NextQuestion, RecordAnswer, ListTopTargets, RecordQuizTarget, ReleaseQuiz
+  auto now = [] { return std::chrono::steady_clock::now(); };
+  auto spent = [&](int which, std::chrono::steady_clock::time_point t0) {
+    nsIn[which].fetch_add(std::chrono::duration_cast<std::chrono::nanoseconds>(now() - t0).count(), std::memory_order_relaxed);
+  };
   const bool verbose = std::getenv("PQA_CLIENT_VERBOSE") != nullptr;
   auto failed = [&](void *e, const char *what) {
     if (verbose && errors.load() < 5) {
@@ -62,28 +68,44 @@ __attribute__((visibility("default"))) int64_t PqaClient_RunLearners(void *pvEng
       if (i >= nQuizzes) return;
       const int64_t guess = (int64_t)(mix64(seed + (uint64_t)i) % (uint64_t)T);
       void *err = nullptr;
+      auto t0 = now();
       const int64_t quiz = PqaEngine_StartQuiz(pvEngine, &err);
+      spent(0, t0);
       if (err) { failed(err, "StartQuiz"); continue; }
       uint64_t h = mix64((uint64_t)guess + 0x9E3779B97F4A7C15ULL);
       bool top = false;
       for (int64_t j = 0; j < maxQuestions && !top; j++) {
+        t0 = now();
         const int64_t q = PqaEngine_NextQuestion(pvEngine, &err, quiz);
+        spent(1, t0);
         if (err) { failed(err, "NextQuestion"); err = nullptr; break; }
         questions.fetch_add(1, std::memory_order_relaxed);
         const int64_t x = q * T / Q;   // the target the question "asks about" on the synthetic binary-search cube
         const int64_t a = guess < x - width ? 0 : guess < x ? 1 : guess == x ? 2 : guess <= x + width ? 3 : 4;
-        if (void *e = PqaEngine_RecordAnswer(pvEngine, quiz, a)) { failed(e, "RecordAnswer"); break; }
+        t0 = now();
+        void *e1 = PqaEngine_RecordAnswer(pvEngine, quiz, a);
+        spent(2, t0);
+        if (e1) { failed(e1, "RecordAnswer"); break; }
         CiRatedTarget best;
         best._iTarget = -1;
+        t0 = now();
         const int64_t n = PqaEngine_ListTopTargets(pvEngine, &err, quiz, 1, &best);
+        spent(3, t0);
         if (err) { failed(err, "ListTopTargets"); err = nullptr; break; }
         h = mix64(h ^ mix64((uint64_t)q * 31 + (uint64_t)a) ^ (uint64_t)(n > 0 ? best._iTarget : -1));
         top = n > 0 && best._iTarget == guess;
       }
       if (top) onTop++;
-      if (train)
-        if (void *e = PqaEngine_RecordQuizTarget(pvEngine, quiz, guess, 1.0)) failed(e, "RecordQuizTarget");
-      if (void *e = PqaEngine_ReleaseQuiz(pvEngine, quiz)) failed(e, "ReleaseQuiz");
+      if (train) {
+        t0 = now();
+        void *e2 = PqaEngine_RecordQuizTarget(pvEngine, quiz, guess, 1.0);
+        spent(4, t0);
+        if (e2) failed(e2, "RecordQuizTarget");
+      }
+      t0 = now();
+      void *e3 = PqaEngine_ReleaseQuiz(pvEngine, quiz);
+      spent(5, t0);
+      if (e3) failed(e3, "ReleaseQuiz");
       digest.fetch_add(h, std::memory_order_relaxed);   // (a sum: the order in which the threads finish does not matter)
       done++;
     }
@@ -102,6 +124,11 @@ __attribute__((visibility("default"))) int64_t PqaClient_RunLearners(void *pvEng
   pStats->nGuessedOnTop = onTop.load();
   pStats->nErrors = errors.load();
   pStats->transcriptHash = digest.load();
+  if (verbose) {
+    const double nq = (double)std::max<int64_t>(1, questions.load()), nz = (double)std::max<int64_t>(1, done.load());
+    std::fprintf(stderr, "pqa_client: %lld threads, us per call: NextQuestion %.1f  RecordAnswer %.1f  ListTopTargets %.1f | per quiz: StartQuiz %.1f  RecordQuizTarget %.1f  ReleaseQuiz %.1f\n",
+                 (long long)nThreads, nsIn[1] / nq * 1e-3, nsIn[2] / nq * 1e-3, nsIn[3] / nq * 1e-3, nsIn[0] / nz * 1e-3, nsIn[4] / nz * 1e-3, nsIn[5] / nz * 1e-3);
+  }
   return 0;
 }
 
