@@ -13,6 +13,8 @@
 #include <sstream>
 
 #include <immintrin.h>
+#include <linux/futex.h>
+#include <sys/syscall.h>
 #include <sys/prctl.h>
 #include <time.h>
 #include <unistd.h>
@@ -135,6 +137,20 @@ uint64_t SplitMix64(uint64_t &x) {
 
 std::once_flag gTableOnce[64];
 
+// A waiting client sleeps on ITS OWN request's state word and is woken alone (futex): with one condition variable for all
+// requests every published batch woke every sleeper, most of them only to find their own request unserved and sleep again.
+inline void FutexWait(std::atomic<int> *word, int expected) {
+  syscall(SYS_futex, reinterpret_cast<int *>(word), FUTEX_WAIT_PRIVATE, expected, nullptr, nullptr, 0);
+}
+inline void FutexWakeOne(std::atomic<int> *word) { syscall(SYS_futex, reinterpret_cast<int *>(word), FUTEX_WAKE_PRIVATE, 1, nullptr, nullptr, 0); }
+// The new state, then the wake -- always: whether the owner sleeps cannot be asked once the state is stored (it may have seen it,
+// returned and gone with its request), and a wake on a word nobody sleeps on only costs the call.
+inline void PublishState(std::atomic<int> *word, int state) {
+  word->store(state, std::memory_order_release);
+  FutexWakeOne(word);
+}
+static_assert(sizeof(std::atomic<int>) == sizeof(int), "the state word is slept on as a futex");
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -148,6 +164,7 @@ HipEngine *HipEngine::Create(Error &err, const CiEngineDefinition &def, const Ci
 }
 
 Error HipEngine::Init(const CiEngineDefinition &def, const CiHipShard *shard) {
+  _mu.owner = this;
   // reference PqaCore/PqaEngineBaseFactory.cpp:29-42: minimum dimensions
   const int64_t minA = 2, minQ = 1, minT = 2;
   if (def._nAnswers < minA || def._nQuestions < minQ || def._nTargets < minT) {
@@ -352,6 +369,7 @@ Error HipEngine::SetOption(const char *name, int64_t value) {
   if (n == "select") { if (value != 0 && value != 1) goto bad; _optSelect = value; }
   else if (n == "combine") { _optCombine = value ? 1 : 0; }
   else if (n == "combine_spin") { _optCombineSpin = value ? 1 : 0; }
+  else if (n == "post_always") { _optPostAlways = value ? 1 : 0; }   // test hook: RecordAnswer / ListTopTargets always as posted operations
   else if (n == "combine_linger_us") { if (value < 0 || value > 10000) goto bad; _optLingerUs = value; }
   else if (n == "workers") { if (value < 1 || value > kMaxWorkers) goto bad; _optWorkers = value; }
   else if (n == "eval_subtasks") { if (value < 0 || value > 8192) goto bad; _optEvalSubtasks = value; }
@@ -395,10 +413,13 @@ int64_t HipEngine::GetOption(const char *name) const {
   if (n == "combine") return _optCombine;
   if (n == "combine_linger_us") return _optLingerUs;
   if (n == "combine_spin") return _optCombineSpin;
+  if (n == "post_always") return _optPostAlways;
   if (n == "allowed_cpus") return AllowedCpus();
   if (n == "combined_batches") return (int64_t)_combBatches;        // sweeps that served more than one NextQuestion call ...
   if (n == "combined_requests") return (int64_t)_combRequests;      // ... the calls they served ...
   if (n == "combined_max_batch") return (int64_t)_combMaxBatch;     // ... and the largest of them
+  if (n == "posted_ops") return (int64_t)_postedOps;                 // RecordAnswer / ListTopTargets calls that found the engine taken and were run by its holder ...
+  if (n == "posted_drains") return (int64_t)_postedDrains;           // ... in this many rounds
   if (n == "update_flushes") return (int64_t)_flushes;              // launches that ran deferred RecordAnswers ...
   if (n == "updates_flushed") return (int64_t)_flushedUpdates;      // ... the updates they ran ...
   if (n == "update_max_flush") return (int64_t)_maxFlush;           // ... and the most in one launch
@@ -1614,6 +1635,99 @@ int HipEngine::AllowedCpus() {
   return n;
 }
 
+// ---- posted operations (hip_engine.h)
+void HipEngine::EngineMutex::unlock() {
+  for (;;) {
+    std::atomic<int> *wake[64];
+    size_t nWake = 0;
+    std::vector<std::atomic<int> *> more;
+    if (owner != nullptr && owner->_posted.load(std::memory_order_acquire) != nullptr) {
+      owner->DrainPosted();
+      std::vector<std::atomic<int> *> &w = owner->_postedWake;
+      if (w.size() <= 64) { nWake = w.size(); std::copy(w.begin(), w.end(), wake); }
+      else more.swap(w);
+      w.clear();
+    }
+    m.unlock();
+    for (size_t i = 0; i < nWake; i++) FutexWakeOne(wake[i]);
+    for (std::atomic<int> *word : more) FutexWakeOne(word);
+    // Posted between the drain and the release: its thread saw the lock taken and sleeps.  (Both sides are a locked
+    // read-modify-write followed by a load -- the post then try_lock there, the release then this load here: one of the two sees
+    // the other.)  If somebody else has the lock by now, the operation is theirs to run.
+    if (owner == nullptr || owner->_posted.load(std::memory_order_seq_cst) == nullptr || !m.try_lock()) return;
+  }
+}
+
+void HipEngine::RunPosted(PostedOp &op) {
+  PostedOp *head = _posted.load(std::memory_order_relaxed);
+  do op.next = head; while (!_posted.compare_exchange_weak(head, &op, std::memory_order_seq_cst, std::memory_order_relaxed));
+  for (;;) {
+    if (_mu.try_lock()) { _mu.unlock(); }   // (free after all: run it -- and the others' -- here)
+    for (int spins = 0; spins < 300; spins++) {
+      if (op.state.load(std::memory_order_acquire) == 1) return;
+      _mm_pause();
+    }
+    int expected = 0;
+    if (op.state.compare_exchange_strong(expected, 2, std::memory_order_seq_cst) || expected == 2) {
+      // (the timeout is a belt to the braces above: a millisecond, then the lock is tried again)
+      struct timespec ts{0, 1000000};
+      syscall(SYS_futex, reinterpret_cast<int *>(&op.state), FUTEX_WAIT_PRIVATE, 2, &ts, nullptr, 0);
+    }
+    if (op.state.load(std::memory_order_acquire) == 1) return;
+  }
+}
+
+// Everything posted so far, in the order it was posted.  The RecordAnswers first go where RecordAnswer puts them (the list of
+// deferred updates); then ONE launch runs every deferred update if a ListTopTargets of this drain needs its quiz's posterior;
+// then the combined sweeps leaders have posted; then the listings that the update kernel has not made already.
+void HipEngine::DrainPosted() {
+  PostedOp *list = _posted.exchange(nullptr, std::memory_order_acq_rel);
+  if (list == nullptr) return;
+  PostedOp *ordered = nullptr;
+  while (list != nullptr) { PostedOp *n = list->next; list->next = ordered; ordered = list; list = n; }
+  _postedDrains++;
+  bool needFlush = false;
+  for (PostedOp *op = ordered; op != nullptr; op = op->next) {
+    _postedOps++;
+    if (op->kind == 1) { op->err = RecordAnswerLocked(op->iQuiz, op->arg, op->remote, false); continue; }
+    if (op->kind == 3) continue;
+    op->result = -1;
+    op->err = CheckRegular("list top targets");
+    if (!op->err.ok()) continue;
+    op->quiz = UseQuiz(op->err, op->iQuiz);
+    if (op->quiz != nullptr && op->quiz->updatePending) needFlush = true;
+  }
+  Error flushErr;
+  if (needFlush) flushErr = FlushUpdates();
+  for (PostedOp *op = ordered; op != nullptr; op = op->next)
+    if (op->kind == 3) LaunchBatchLocked(*op->ctx, *op->batch, *op->flight);   // (behind the updates, ahead of the listings: the sweep is what the most clients wait for)
+  for (PostedOp *op = ordered; op != nullptr;) {
+    PostedOp *const next = op->next;   // (the operation is its thread's again the moment its state says so)
+    if (op->kind == 2 && op->quiz != nullptr) {
+      Quiz *q = op->quiz;
+      const int64_t want = std::min<int64_t>(op->arg, _T);
+      if (!flushErr.ok()) op->err = flushErr;
+      else if (want > kQuizTop || _T > 16384) op->result = -2;
+      else {
+        _topWantRecent = want >= _topWantRecent ? want : want + (_topWantRecent - want) * 7 / 8;
+        const bool cached = q->topOp != 0 && q->topVersion == q->priorVersion && want <= q->topCount;
+        hipError_t he = hipSuccess;
+        if (!cached) {
+          hipSetDevice(_device);
+          const uint64_t opNo = ++_opSeq;
+          he = LaunchTopTargets(View(), q->dPrior, want, q->pin->top, &q->pin->nOut, &q->pin->topFlag, opNo, _stream);
+          if (he == hipSuccess) { q->topOp = opNo; q->topVersion = q->priorVersion; q->topCount = want; }
+        }
+        if (he != hipSuccess) op->err = HipErr(he, "ListTopTargets");
+        else { op->pin = q->pin; op->flagOp = q->topOp; op->result = want; }
+      }
+    }
+    std::atomic<int> *word = &op->state;
+    if (word->exchange(1, std::memory_order_acq_rel) == 2) _postedWake.push_back(word);
+    op = next;
+  }
+}
+
 int64_t HipEngine::Combine(Error &err, int64_t iQuiz, int kind, uint64_t rnd) {
   CallScope scope(_activeCallers);
   _mu.spinFirst.store(ClientsFitCpus() && _activeCallers.load(std::memory_order_relaxed) > 1, std::memory_order_relaxed);
@@ -1654,9 +1768,8 @@ int64_t HipEngine::Combine(Error &err, int64_t iQuiz, int kind, uint64_t rnd) {
       }
       for (int spins = 0; spins < 12000 && (st = r.state.load(std::memory_order_acquire)) == 0; spins++) _mm_pause();
     }
-    if (st == 0) {
-      std::unique_lock<std::mutex> lk(_combMu);
-      _combCv.wait(lk, [&] { return r.state.load(std::memory_order_acquire) != 0; });
+    while (st == 0) {
+      FutexWait(&r.state, 0);   // (returns at once if the state is no longer 0)
       st = r.state.load(std::memory_order_acquire);
     }
     {
@@ -1735,6 +1848,19 @@ int64_t HipEngine::SelectFromPriorities(SelRequest *r) {
   return r->result;
 }
 
+// How many of `m` waiting requests a combined sweep should take.  The (quiz, chunk) sweep costs by its quiz slots -- 16, 32 or
+// groups of 64 (tools/midbatch_bench.py at 1000 x 5 x 1000: 107 / 192 / 362 us of kernel) -- so 20 requests cost what 32 do; with
+// the device as the bottleneck of a busy server, a sweep of 16 now and the other 4 with the next one serve more clients per second.
+int64_t HipEngine::PreferredCombinedBatch(int64_t m) const {
+  if (_optBatchForm != 0 || _elem != 8 || !EvalMidBatchSupported(View())) return m;
+  if (m <= 16) return m;
+  if (m <= 25) return 16;
+  if (m <= 32) return m;
+  if (m <= 51) return 32;
+  const int64_t full = m / 64 * 64, rem = m % 64;
+  return rem == 0 || rem >= 52 ? m : std::max<int64_t>(full, 32);
+}
+
 // The leader's turn: ONE batch -- everything posted so far, distinct quizzes, `own` among them (it is the oldest request).  The
 // lead goes on to the oldest request still waiting (or is given up) as soon as the batch's sweep is LAUNCHED: the next leader
 // gathers and launches the next sweep -- into the other of the two batch contexts -- while this one's runs, so that the device
@@ -1776,6 +1902,13 @@ void HipEngine::ServeQueue(SelRequest *own) {
       for (size_t i = 0; take && i < batch.size(); i++) take = batch[i]->iQuiz != r->iQuiz;   // a quiz once per sweep
       (take ? batch : rest).push_back(r);
     }
+    // (the sweep's lanes come in groups: the newest requests beyond the last well-filled group wait for the next sweep -- it is
+    //  launched right behind this one)
+    const size_t keep = (size_t)PreferredCombinedBatch((int64_t)batch.size());
+    if (keep < batch.size()) {
+      rest.insert(rest.begin(), batch.begin() + (std::ptrdiff_t)keep, batch.end());
+      batch.resize(keep);
+    }
     _combQueue.swap(rest);
   }
   Flight f;
@@ -1784,15 +1917,12 @@ void HipEngine::ServeQueue(SelRequest *own) {
   {
     std::lock_guard<std::mutex> lk(_combMu);
     if (_combQueue.empty()) _leaderActive = false;
-    else _combQueue.front()->state.store(2, std::memory_order_release);
+    else PublishState(&_combQueue.front()->state, 2);
   }
-  _combCv.notify_all();
   const bool ownSelects = f.live.empty() ? false : CollectBatch(c, batch, f, own);
   ctxLock.unlock();
   for (SelRequest *r : batch)
-    if (r != nullptr && r != own) r->state.store(1, std::memory_order_release);   // (r is its caller's again from here on)
-  { std::lock_guard<std::mutex> g(_combMu); }   // (a sleeper that has just found its state 0 is inside wait() by now)
-  _combCv.notify_all();
+    if (r != nullptr && r != own) PublishState(&r->state, 1);   // (r is its caller's again from here on)
   if (ownSelects) {
     SelectFromPriorities(own);
     c.readers.fetch_sub(1, std::memory_order_release);
@@ -1802,10 +1932,22 @@ void HipEngine::ServeQueue(SelRequest *own) {
 // Validate and launch (the caller holds the context; the engine's lock is taken and released here).  f.live: the requests whose
 // sweep is in flight; every other request of `batch` has its result or error.
 void HipEngine::LaunchBatch(BatchCtx &c, std::vector<SelRequest *> &batch, Flight &f) {
+  if (batch.size() > 1 && !_mu.try_lock()) {   // (the engine is taken: its holder launches this sweep on its way out)
+    PostedOp op;
+    op.kind = 3; op.ctx = &c; op.batch = &batch; op.flight = &f;
+    RunPosted(op);
+    return;
+  }
+  std::unique_lock<EngineMutex> lk(_mu, std::defer_lock);
+  if (batch.size() > 1) lk = std::unique_lock<EngineMutex>(_mu, std::adopt_lock);
+  else lk.lock();
+  LaunchBatchLocked(c, batch, f);
+}
+
+void HipEngine::LaunchBatchLocked(BatchCtx &c, std::vector<SelRequest *> &batch, Flight &f) {
   auto single = [&](SelRequest *r) {
     r->result = r->kind == 0 ? NextQuestionArgmaxLocked(r->err, r->iQuiz) : NextQuestionSampledLocked(r->err, r->iQuiz, r->rnd);
   };
-  std::lock_guard<EngineMutex> lk(_mu);
   f.tB = std::chrono::steady_clock::now();
   if (batch.size() == 1) { _flushedSinceSweep.store(0, std::memory_order_relaxed); single(batch[0]); return; }
   auto failAll = [&](const Error &e) { for (SelRequest *r : batch) { r->err = e; r->result = -1; } };
@@ -1838,8 +1980,8 @@ void HipEngine::LaunchBatch(BatchCtx &c, std::vector<SelRequest *> &batch, Fligh
     SelRequest *r = live[(size_t)i];
     Quiz *q = quizzes[(size_t)i];
     r->serial = q->serial;
-    if (!f.anySampled) continue;
-    // what the client needs to select for itself once the priorities are on the host: the quiz (held), the asked questions and
+    // what finishes the selection once the sweep has run (the client itself, from the priorities, if any request of the batch is
+    // sampled; else the leader, from the kernel's choices) without the engine's lock: the quiz (held), the asked questions and
     // gaps as the sweep sees them
     r->quiz = q;
     q->inSelection.store(true, std::memory_order_relaxed);
@@ -1898,26 +2040,33 @@ bool HipEngine::CollectBatch(BatchCtx &c, std::vector<SelRequest *> &batch, Flig
       r->ctx = &c;
       if (r == own) { ownLive = true; continue; }
       for (SelRequest *&slot : batch) if (slot == r) slot = nullptr;   // (published here: not the caller's to publish again)
-      r->state.store(3, std::memory_order_release);
+      PublishState(&r->state, 3);
     }
-    { std::lock_guard<std::mutex> g(_combMu); }   // (a sleeper that has just found its state 0 is inside wait() by now)
-    _combCv.notify_all();
-    _combNs[3] += ns(tD, std::chrono::steady_clock::now());
+        _combNs[3] += ns(tD, std::chrono::steady_clock::now());
     return ownLive;
   }
-  std::lock_guard<EngineMutex> lk(_mu);
+  // The kernel's choices: finished here for every request, and without the engine's lock -- the quizzes are held (inSelection:
+  // a ReleaseQuiz of one waits), what is written is each quiz's own or atomic.
   const auto tE = std::chrono::steady_clock::now();
   for (int64_t i = 0; i < n; i++) {
     SelRequest *r = f.live[(size_t)i];
-    Quiz *q = ((size_t)r->iQuiz < _quizzes.size()) ? _quizzes[(size_t)r->iQuiz] : nullptr;
-    if (q == nullptr || q->serial != r->serial) {   // released while its sweep ran (a client's error: IPqaEngine.h:44)
-      r->err = Error::MakeP(ErrCode::AbsentId, "id=" + std::to_string(r->iQuiz), "Quiz index is not in the registry (but rather at a gap).");
-      r->result = -1;
-      continue;
+    Quiz *q = r->quiz;
+    int64_t pick = c.h->out[i].index;
+    if (pick == -3) { r->err = HipErr(hipErrorLaunchFailure, "combined selection (incomplete sweep)"); r->result = -1; }
+    else {
+      CheckPriority(c.h->out[i].priority, pick);
+      // reference PqaCore/CpuEngine.cpp:403-413 (FinishSelection, over the snapshot)
+      if (pick >= 0 && BitTest(r->unavailable, pick)) pick = FindNearestInPacks(pick, r->nQ, [&](int64_t p) { return ~Pack64(r->unavailable, p); });
+      if (pick < 0) {
+        r->err = Error::Make(ErrCode::QuestionsExhausted, "Found no unasked question that is not in a gap.");
+        r->result = -1;
+      } else {
+        q->activeQuestion = _qFirst + pick;
+        _nQuestionsAsked.fetch_add(1, std::memory_order_relaxed);
+        r->result = q->activeQuestion;
+      }
     }
-    if (c.h->out[i].index == -3) { r->err = HipErr(hipErrorLaunchFailure, "combined selection (incomplete sweep)"); r->result = -1; continue; }
-    CheckPriority(c.h->out[i].priority, c.h->out[i].index);
-    r->result = FinishSelection(r->err, q, c.h->out[i].index);
+    q->inSelection.store(false, std::memory_order_release);
   }
   _combNs[3] += ns(tD, tE);
   _combNs[4] += ns(tE, std::chrono::steady_clock::now());
@@ -1946,7 +2095,15 @@ Error HipEngine::EvalPriorities(int64_t iQuiz, double *pOut, int64_t n) {
 // ------------------------------------------------------------------------------------------------------------------
 Error HipEngine::RecordAnswerImpl(int64_t iQuiz, int64_t iAnswer, bool remote) {
   CallScope scope(_activeCallers);
-  std::lock_guard<EngineMutex> lk(_mu);
+  if (_optCombine && (_optPostAlways || !_mu.try_lock())) {   // somebody is inside the engine: it runs this call's bookkeeping on its way out
+    PostedOp op;
+    op.kind = 1; op.iQuiz = iQuiz; op.arg = iAnswer; op.remote = remote;
+    RunPosted(op);
+    return op.err;
+  }
+  std::unique_lock<EngineMutex> lk(_mu, std::defer_lock);
+  if (_optCombine) lk = std::unique_lock<EngineMutex>(_mu, std::adopt_lock);
+  else lk.lock();
   return RecordAnswerLocked(iQuiz, iAnswer, remote, !Concurrent());
 }
 
@@ -2213,7 +2370,26 @@ Error HipEngine::GetPriorDevicePtr(int64_t iQuiz, void **ppDev, int64_t *pLdT) {
 
 int64_t HipEngine::ListTopTargets(Error &err, int64_t iQuiz, int64_t maxCount, CiRatedTarget *pDest) {
   CallScope scope(_activeCallers);
-  std::unique_lock<EngineMutex> lk(_mu);
+  std::unique_lock<EngineMutex> lk(_mu, std::defer_lock);
+  if (!_optCombine || maxCount <= 0 || pDest == nullptr) lk.lock();
+  else if (!_optPostAlways && _mu.try_lock()) lk = std::unique_lock<EngineMutex>(_mu, std::adopt_lock);
+  else {
+    // somebody is inside the engine: it launches what this call needs on its way out (the quiz's deferred update among all that
+    // have gathered, the listing if the update kernel has not made it); the wait for the quiz's own lines is this thread's
+    PostedOp op;
+    op.kind = 2; op.iQuiz = iQuiz; op.arg = maxCount;
+    RunPosted(op);
+    if (op.result != -2) {
+      err = op.err;
+      if (!err.ok() || op.result < 0) return -1;
+      err = WaitFlagNapping(&op.pin->topFlag, op.flagOp, "ListTopTargets");
+      if (!err.ok()) return -1;
+      const int64_t n = std::min<int64_t>(op.pin->nOut, op.result);
+      std::memcpy(pDest, op.pin->top, (size_t)n * sizeof(RatedTargetDev));
+      return n;
+    }
+    lk.lock();   // (a list longer than the quiz's lines hold)
+  }
   err = CheckRegular("list top targets");
   if (!err.ok()) return -1;
   Quiz *q = UseQuiz(err, iQuiz);

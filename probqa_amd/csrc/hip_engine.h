@@ -370,6 +370,7 @@ class HipEngine : public IEngine {
   bool Concurrent() const { return _optCombine && _activeCallers.load(std::memory_order_relaxed) > 1; }
   static int AllowedCpus();                   // the CPUs this process may use: the cgroup's quota (cpu.max) or the affinity mask
   int64_t _optCombineSpin = 1;                // option "combine_spin": 1 = waiting clients spin while they are fewer than the allowed CPUs, 0 = they always sleep
+  int64_t _optPostAlways = 0;                 // option "post_always" (test hook): the posted form of RecordAnswer / ListTopTargets even when the engine is free
   bool ClientsFitCpus() const { return _optCombineSpin && _activeCallers.load(std::memory_order_relaxed) + 2 <= AllowedCpus(); }
   int64_t _optCombine = 1;                    // option "combine" / PQA_COMBINE: 0 = every call by itself, as before
   // ---- combining of concurrent NextQuestion calls (reference: every client's NextQuestion runs under a SHARED lock,
@@ -401,11 +402,39 @@ class HipEngine : public IEngine {
   std::atomic<int64_t> _lastCombined{0};           // requests of the newest combined sweep: as many RecordAnswers are about to arrive
   int64_t _optLingerUs = 20;                       // option "combine_linger_us": how long a ListTopTargets waits for them before it launches the updates
   std::mutex _combMu;
-  std::condition_variable _combCv;
   std::vector<SelRequest *> _combQueue;
   bool _leaderActive = false;
   int64_t Combine(Error &err, int64_t iQuiz, int kind, uint64_t rnd);
+  // ---- posted operations.  With dozens of client threads the engine's lock is not held long but changes hands through the
+  // kernel every time: each RecordAnswer and ListTopTargets slept on it and was woken by the thread before it, one wake-up
+  // latency per call, serially (64 threads: 200 us inside a RecordAnswer that works for 1).  So a call that finds the lock
+  // taken does not queue on it: it posts its operation and sleeps on the operation's own word; whoever holds the lock runs
+  // everything posted so far right before it lets go (EngineMutex::unlock) -- the RecordAnswers of a drain into the list of
+  // deferred updates, ONE launch for all the posteriors its ListTopTargets ask for -- and wakes the posters, all at once.
+  struct Flight;
+  struct PostedOp {
+    int kind = 0;                      // 1: RecordAnswer(iQuiz, arg = iAnswer, remote); 2: ListTopTargets' launch (arg = maxCount);
+                                       // 3: a leader's LaunchBatch(ctx, batch, flight)
+    int64_t iQuiz = -1, arg = 0;
+    bool remote = false;
+    Error err;
+    int64_t result = 0;                // kind 2: the number of targets to take from `pin` once it carries `flagOp`; -2: take the lock yourself
+    QuizPinned *pin = nullptr;
+    uint64_t flagOp = 0;
+    Quiz *quiz = nullptr;              // (the drain's own, between its two passes)
+    BatchCtx *ctx = nullptr;
+    std::vector<SelRequest *> *batch = nullptr;
+    Flight *flight = nullptr;
+    std::atomic<int> state{0};         // 0 posted, 2 posted and its thread asleep on this word, 1 done
+    PostedOp *next = nullptr;
+  };
+  std::atomic<PostedOp *> _posted{nullptr};
+  std::vector<std::atomic<int> *> _postedWake;     // the drain's sleepers, woken once the lock is released
+  uint64_t _postedOps = 0, _postedDrains = 0;
+  void DrainPosted();                              // (the engine's lock held)
+  void RunPosted(PostedOp &op);                    // post, and return when somebody has run it
   void ServeQueue(SelRequest *own);
+  int64_t PreferredCombinedBatch(int64_t m) const;
   struct Flight {                      // a combined sweep between its launch and its collection
     std::vector<SelRequest *> live;
     uint64_t tag = 0;
@@ -415,6 +444,7 @@ class HipEngine : public IEngine {
     std::chrono::steady_clock::time_point tA, tB, tC;
   };
   void LaunchBatch(BatchCtx &c, std::vector<SelRequest *> &batch, Flight &f);
+  void LaunchBatchLocked(BatchCtx &c, std::vector<SelRequest *> &batch, Flight &f);
   bool CollectBatch(BatchCtx &c, std::vector<SelRequest *> &batch, Flight &f, SelRequest *own);   // true: `own` is to select for itself
   int64_t NextQuestionArgmaxLocked(Error &err, int64_t iQuiz);
   int64_t NextQuestionSampledLocked(Error &err, int64_t iQuiz, uint64_t rnd);
@@ -498,6 +528,12 @@ class HipEngine : public IEngine {
     //  holder is usually a microsecond of bookkeeping or one kernel launch away from releasing, and being woken through the kernel
     //  costs tens of microseconds.  With more clients than CPUs every spinning waiter takes time from a thread that has work.)
     std::atomic<bool> spinFirst{false};
+    HipEngine *owner = nullptr;
+    bool try_lock() {
+      if (!m.try_lock()) return false;
+      wasBusy = busy; busy = true;
+      return true;
+    }
     void lock() {
       if (spinFirst.load(std::memory_order_relaxed))
         for (int i = 0; i < 400; i++) {
@@ -507,7 +543,7 @@ class HipEngine : public IEngine {
       m.lock(); wasBusy = busy; busy = true;
     }
     void lock_urgent() { lock(); }
-    void unlock() { m.unlock(); }
+    void unlock();   // (runs the posted operations first: hip_engine.cpp)
   };
   struct UrgentLock {   // (RAII for lock_urgent, re-lockable like std::unique_lock)
     EngineMutex &mu;

@@ -69,6 +69,7 @@ def test_native_learner_threads_same_transcripts_and_combined(factory):
     assert (many["questions"], many["guessed_on_top"], many["transcript_hash"]) == (one["questions"], one["guessed_on_top"], one["transcript_hash"])
     assert eng.get_option("combined_batches") > 0 and eng.get_option("combined_max_batch") > 4
     assert eng.get_option("update_max_flush") > 1
+    assert eng.get_option("posted_ops") > 0 and eng.get_option("posted_drains") > 0     # calls that found the engine taken
     # with training at the end of every quiz and the sampled selector the transcripts depend on the interleaving; the run must
     # still complete without an error and teach the cube (most guesses end on top)
     eng.set_option("select", 0)
@@ -104,3 +105,36 @@ def test_native_learners_under_every_selection_path(option, factory):
     again = interop.run_learners(eng, 32, 64, 10, seed=5, train=True)
     assert again["errors"] == 0 and again["quizzes"] == 64
     eng.close()
+
+
+def test_posted_operations_equal_direct_calls(factory):
+    """RecordAnswer and ListTopTargets in their posted form (what a call does that finds the engine taken: hip_engine.h, posted
+    operations) against the direct form: the same transcripts, top lists and errors.  Option post_always forces the form."""
+    a = _engine(factory, 5, 60, 200, 4, 1)
+    b = _engine(factory, 5, 60, 200, 4, 1)
+    b.set_option("post_always", 1)
+    for eng in (a, b):
+        eng.set_option("select", 1)
+    qa, qb = a.start_quiz(), b.start_quiz()
+    for step in range(12):
+        na, nb = a.next_question(qa), b.next_question(qb)
+        assert na == nb
+        a.record_answer(qa, (step * 3) % 5)
+        b.record_answer(qb, (step * 3) % 5)
+        for want in (1, 5, 32, 40):      # (40: more than a quiz's pinned lines hold -- the posted form hands it back)
+            ta, tb = a.list_top_targets(qa, want), b.list_top_targets(qb, want)
+            assert [(t.i_target, t.prob) for t in ta] == [(t.i_target, t.prob) for t in tb]
+    assert b.get_option("posted_ops") >= 12 * 5 and a.get_option("posted_ops") == 0
+    # the errors come back through the operation
+    for eng in (a, b):
+        with pytest.raises(interop.PqaException) as e1:
+            eng.record_answer(qa if eng is a else qb, 0)            # no active question
+        assert "active question" in str(e1.value)
+        with pytest.raises(interop.PqaException):
+            eng.record_answer(12345, 0)                              # no such quiz
+        with pytest.raises(interop.PqaException):
+            eng.list_top_targets(12345, 3)
+        eng.next_question(qa if eng is a else qb)
+        with pytest.raises(interop.PqaException):
+            eng.record_answer(qa if eng is a else qb, 5)             # answer out of range
+    a.close(); b.close()
