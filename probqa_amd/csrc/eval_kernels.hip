@@ -469,7 +469,11 @@ __device__ __forceinline__ void sweep_body(EvalArgs a, bool copyTable) {
         lh[j].y = (ring[j].y * invD[j].y) * pv.y;
         s0 += lh[j].x;  // <= 2*NP terms per lane: plain sums, then the butterfly -- a 64*WPQ-leaf pairwise tree
         s1 += lh[j].y;
+#ifdef PQA_ABLATE_REFILL   // measurement only (wrong values): the stream's rows are not loaded -- what the sweep costs without its memory
+        asm volatile("" : "+v"(ring[j].x), "+v"(ring[j].y));
+#else
         ring[j] = row_load(rowN, poff[j]);
+#endif
         __builtin_amdgcn_sched_barrier(0);
       }
       if (kMdLds && lastRow && moreQuestions) {

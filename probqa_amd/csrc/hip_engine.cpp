@@ -254,6 +254,8 @@ Error HipEngine::Init(const CiEngineDefinition &def, const CiHipShard *shard) {
   HIP_TRY(hipMalloc(&_dSel, sizeof(SelectResult)));
   HIP_TRY(hipMalloc(&_dSelScratch, kFusedMaxGrid * sizeof(SelectResult)));
   HIP_TRY(hipMemset(_dSelScratch, 0, kFusedMaxGrid * sizeof(SelectResult)));  // tag 0 is never used by a launch
+  HIP_TRY(hipMalloc(&_dPriorScratch, (8 * kMaxWorkers + 2) * sizeof(double)));
+  HIP_TRY(hipMemset(_dPriorScratch, 0, (8 * kMaxWorkers + 2) * sizeof(double)));   // (the arrival counter starts at 0; every launch leaves it there)
   HIP_TRY(hipHostMalloc(&_hPinned, sizeof(Pinned), hipHostMallocMapped | hipHostMallocCoherent));
   std::memset(_hPinned, 0, sizeof(Pinned));
   _hTGap.assign(BitWords(_ldT), 0);
@@ -323,7 +325,7 @@ HipEngine::~HipEngine() {
   if (_stream) hipStreamSynchronize(_stream);
   for (Quiz *q : _quizzes) if (q) DestroyQuiz(q);
   hipFree(_dCube); hipFree(_dVB); hipFree(_dPriority); hipFree(_dRunLength); hipFree(_dExps); hipFree(_dStatus);
-  hipFree(_dNOut); hipFree(_dSel); hipFree(_dSelScratch); hipFree(_dClusterScratch);
+  hipFree(_dNOut); hipFree(_dSel); hipFree(_dSelScratch); hipFree(_dPriorScratch); hipFree(_dClusterScratch);
   for (BatchCtx &c : _ctx) {
     hipFree(c.dSlots); hipFree(c.dScratch); hipFree(c.dPriority); hipFree(c.dPT); hipFree(c.dAcc); hipFree(c.dRecs); hipFree(c.dPriT); hipFree(c.dRerank);
     if (c.hPri) hipHostFree(c.hPri);
@@ -355,6 +357,7 @@ KbView HipEngine::View() const {
   v.K = _K; v.Q = _Q; v.T = _T; v.ldT = _ldT;
   v.nValidTargets = _T - _nTargetGaps;
   v.smallLaunches = _optServer ? 1 : 0;
+  v.priorScratch = _optLongRowForm ? _dPriorScratch : nullptr;
   v.maxGrid = (int)_optEvalMaxGrid;
   return v;
 }
@@ -369,6 +372,7 @@ Error HipEngine::SetOption(const char *name, int64_t value) {
   if (n == "select") { if (value != 0 && value != 1) goto bad; _optSelect = value; }
   else if (n == "combine") { _optCombine = value ? 1 : 0; }
   else if (n == "combine_spin") { _optCombineSpin = value ? 1 : 0; }
+  else if (n == "long_row_form") { _optLongRowForm = value ? 1 : 0; }   // 0: the one-workgroup posterior kernels for rows beyond 16384 targets too
   else if (n == "post_always") { _optPostAlways = value ? 1 : 0; }   // test hook: RecordAnswer / ListTopTargets always as posted operations
   else if (n == "combine_linger_us") { if (value < 0 || value > 10000) goto bad; _optLingerUs = value; }
   else if (n == "workers") { if (value < 1 || value > kMaxWorkers) goto bad; _optWorkers = value; }
@@ -414,6 +418,7 @@ int64_t HipEngine::GetOption(const char *name) const {
   if (n == "combine_linger_us") return _optLingerUs;
   if (n == "combine_spin") return _optCombineSpin;
   if (n == "post_always") return _optPostAlways;
+  if (n == "long_row_form") return _optLongRowForm;
   if (n == "allowed_cpus") return AllowedCpus();
   if (n == "combined_batches") return (int64_t)_combBatches;        // sweeps that served more than one NextQuestion call ...
   if (n == "combined_requests") return (int64_t)_combRequests;      // ... the calls they served ...

@@ -457,6 +457,8 @@ class HipEngine : public IEngine {
   Error WaitFlag(volatile uint64_t *flag, uint64_t value, const char *what);
   Error WaitFlagNapping(volatile uint64_t *flag, uint64_t value, const char *what);   // for many waiters at once: a short spin, then naps
   SelectResult *_dSelScratch = nullptr;  // its per-workgroup winner records
+  double *_dPriorScratch = nullptr;      // the long-row posterior kernels' subtask sums (KbView::priorScratch)
+  int64_t _optLongRowForm = 1;           // option "long_row_form": StartQuiz / RecordAnswer over rows beyond 16384 targets as one workgroup per subtask of the sum
   // batched selections (NextQuestionArgmaxBatch); allocated on first use
   static constexpr int64_t kMaxBatch = 256, kBatchGrid = 1024;
   struct BatchPinned { QuizSlot slots[kMaxBatch]; SelectResult out[kMaxBatch]; uint64_t seq[kMaxBatch]; };

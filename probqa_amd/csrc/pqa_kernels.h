@@ -54,6 +54,7 @@ struct KbView {
   int64_t K, Q, T, ldT;
   int64_t nValidTargets;  // T - #target gaps (PqaCore/CpuEngine.cpp:352)
   int smallLaunches;      // the engine runs the resident sweep: posterior kernels over <= 1024 targets use 256 threads
+  double *priorScratch;   // 8 * kMaxWorkers + 2 doubles (device): the subtasks' sums of the long-row posterior kernels (prior_kernels.hip); may be null
   int maxGrid;            // test hook (engine option "eval_max_grid"): cap the workgroups of a sweep, so that a small cube makes
                           // every workgroup stream dozens of questions; 0 = no cap
 };

@@ -1,7 +1,7 @@
 // prior_device.h -- the posterior update of one answered question as a device function (RecordAnswer: reference
 // PqaCore/CERecordAnswerSubtaskMul.cpp:15-42, PqaCore/Summator.h:11-21, PqaCore/CEDivTargPriorsSubtask.h:12-30), shared by
-// its kernel (prior_kernels.hip) and by the resident sweep (eval_kernels.hip), which runs it between two selections without a
-// launch.  Bit-identical to the CPU engine: see prior_kernels.hip for the summation order that is reproduced here.
+// the one-quiz and the batched kernels of prior_kernels.hip.  Bit-identical to the CPU engine: see prior_kernels.hip for the
+// summation order that is reproduced here.
 #pragma once
 #include "pqa_device.h"
 

@@ -155,6 +155,125 @@ __global__ __launch_bounds__(kThreads) void resume_quiz_kernel(PriorArgs a, int6
   for (int64_t t = threadIdx.x; t < 4 * nVects; t += blockDim.x) a.prior[t] = a.prior[t] / total;
 }
 
+// ---- long rows (ldT > 16384: BASELINE configs[4]'s 100000 targets).  One workgroup per SUBTASK of the reference's sum instead of
+// one for the row: the element-wise step of a subtask's ~T / nWorkers targets is one or two rounds of loads for 1024 threads
+// (a hundred rounds for one workgroup over the whole row), its four Kahan chains -- the reference's order, so still one lane
+// each -- walk values that are in LDS, and the chains of all subtasks run at the same time on different CUs.  The workgroup
+// that finishes last adds the subtasks' sums (PreciseSum per subtask, serial Kahan over the subtasks: as reference_order_sum).
+// The division by the total is a second launch over the whole row (long_row_divide_kernel): a dependent launch is ~8 us, a
+// device-wide wait inside one kernel would need every workgroup resident at once.  Same operations on the same values in the
+// same order as the one-workgroup kernels: bit-identical.
+// scratch: [8 * kMaxWorkers] partial sums and corrections, then the total, then the arrival counter (a 32-bit word).
+template <bool RECORD>
+__global__ __launch_bounds__(kThreads) void long_row_stage_kernel(PriorArgs a, int64_t iQuestion, int64_t iAnswer, uint32_t *__restrict__ asked,
+                                                                  int64_t askedWords, double *__restrict__ scratch, int valuesInLds) {
+  extern __shared__ double lds[];   // 8 * nSubtasks + 1 doubles for the last workgroup's sum, then this subtask's values
+  __shared__ int isLast;
+  const int64_t nVects = (a.T + 3) >> 2;
+  const int64_t quot = nVects / a.nWorkers, rem = nVects % a.nWorkers;
+  const int64_t nSubtasks = gridDim.x, s = blockIdx.x;
+  const int64_t first = (s == 0) ? 0 : prior_split_bound(s - 1, quot, rem), limit = prior_split_bound(s, quot, rem);
+  const int64_t e0 = 4 * first, e1 = (s == nSubtasks - 1) ? a.ldT : 4 * limit;   // (the last subtask's workgroup also takes the row's padding)
+  double *vals = lds + 8 * nSubtasks + 1;
+  if constexpr (RECORD) {
+    if (s == 0 && threadIdx.x == 0) asked[iQuestion >> 5] |= 1u << (iQuestion & 31);   // CEQuiz::RecordAnswer, PqaCore/CEQuiz.h:92
+  } else {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < askedWords; i += (int64_t)gridDim.x * blockDim.x) asked[i] = 0;
+  }
+  const int64_t rowA = RECORD ? (iQuestion * (a.K + 1) + iAnswer) * a.ldT : 0;  // CERecordAnswerSubtaskMul.cpp:25
+  const int64_t rowD = RECORD ? (iQuestion * (a.K + 1) + a.K) * a.ldT : 0;      // :26
+  const int64_t step = blockDim.x;
+  int64_t t = e0 + threadIdx.x;
+  for (; t + 3 * step < e1; t += 4 * step) {
+    double x[4];
+    if constexpr (RECORD) {
+      double av[4], dv[4], old[4];
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        av[e] = cube_ld(a.cube, a.elem, rowA + t + e * step);
+        dv[e] = cube_ld(a.cube, a.elem, rowD + t + e * step);
+        old[e] = a.prior[t + e * step];
+      }
+#pragma unroll
+      for (int e = 0; e < 4; e++) x[e] = old[e] * (av[e] / dv[e]);             // :31, :34
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; e++) x[e] = a.vB[t + e * step];                    // CESetPriorsSubtaskSum.cpp:28-31
+    }
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      const double v = bit_test(a.tgap, t + e * step) ? 0.0 : x[e];             // CERecordAnswerSubtaskMul.cpp:35-37
+      a.prior[t + e * step] = v;
+      if (valuesInLds) vals[t + e * step - e0] = v;
+    }
+  }
+  for (; t < e1; t += step) {
+    double x;
+    if constexpr (RECORD) x = a.prior[t] * (cube_ld(a.cube, a.elem, rowA + t) / cube_ld(a.cube, a.elem, rowD + t));
+    else x = a.vB[t];
+    const double v = bit_test(a.tgap, t) ? 0.0 : x;
+    a.prior[t] = v;
+    if (valuesInLds) vals[t - e0] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 4) {
+    // one chain per lane (SRAccumVectDbl256::Add, SRPlatform/Interface/SRAccumVectDbl256.h:40-46), sixteen values requested ahead
+    const int c = (int)threadIdx.x;
+    // (element t at v[t - off]: an LDS pointer moved below its segment is no LDS pointer any more)
+    const double *v = valuesInLds ? vals : a.prior;
+    const int64_t off = valuesInLds ? e0 : 0;
+    double sum = 0, corr = 0;
+    int64_t j = first;
+    for (; j + 16 <= limit; j += 16) {
+      double x[16];
+#pragma unroll
+      for (int e = 0; e < 16; e++) x[e] = v[4 * (j + e) + c - off];
+#pragma unroll
+      for (int e = 0; e < 16; e++) {
+        const double y = x[e] - corr;
+        const double u = sum + y;
+        corr = (u - sum) - y;
+        sum = u;
+      }
+    }
+    for (; j < limit; j++) {
+      const double y = v[4 * j + c - off] - corr;
+      const double u = sum + y;
+      corr = (u - sum) - y;
+      sum = u;
+    }
+    __hip_atomic_store(scratch + 8 * s + c, sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(scratch + 8 * s + 4 + c, corr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  unsigned *counter = reinterpret_cast<unsigned *>(scratch + 8 * kMaxWorkers + 1);
+  if (threadIdx.x < kWave) {   // (the chains' wave: its release covers the four lanes' stores)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    if (threadIdx.x == 0) isLast = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(nSubtasks - 1);
+  }
+  __syncthreads();
+  if (!isLast) return;
+  for (int64_t i = threadIdx.x; i < 8 * nSubtasks; i += blockDim.x) lds[i] = __hip_atomic_load(scratch + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  for (int64_t s2 = threadIdx.x; s2 < nSubtasks; s2 += blockDim.x) {
+    const double ps = precise_sum4(lds + 8 * s2, lds + 8 * s2 + 4);
+    lds[8 * s2] = ps;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    Kahan1 acc;  // Summator::ForPriors, PqaCore/Summator.h:14-19
+    acc.init(0.0);
+    for (int64_t s2 = 0; s2 < nSubtasks; s2++) acc.add(lds[8 * s2]);
+    scratch[8 * kMaxWorkers] = acc.get();
+    __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // for the next launch on the stream
+  }
+}
+
+__global__ __launch_bounds__(256) void long_row_divide_kernel(double *__restrict__ prior, const double *__restrict__ scratch, int64_t n4) {
+  const double total = scratch[8 * kMaxWorkers];
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n4; t += (int64_t)gridDim.x * blockDim.x)
+    prior[t] = prior[t] / total;   // CEDivTargPriors :19
+}
+
 size_t sum_lds_bytes(int64_t nWorkers) { return (size_t)(8 * nWorkers + 1) * sizeof(double); }
 // (64 KB of dynamic LDS need no opt-in; 1000 targets at 16 workers: 9 KB)
 bool stage_fits(const KbView &kb, int64_t nWorkers) { return sum_lds_bytes(nWorkers) + (size_t)kb.ldT * sizeof(double) <= 65536; }
@@ -179,8 +298,25 @@ PriorArgs make_args(const KbView &kb, double *prior, int64_t nWorkers, bool stag
 
 }  // namespace
 
+// The long-row form: its launches, or false if the row is short / the engine gave no scratch.
+template <bool RECORD>
+static bool launch_long_row(const KbView &kb, double *prior, uint32_t *asked, int64_t askedWords, int64_t iQuestion, int64_t iAnswer,
+                            int64_t nWorkers, hipStream_t stream) {
+  if (kb.ldT <= 16384 || kb.priorScratch == nullptr) return false;
+  const int64_t nVects = (kb.T + 3) >> 2, quot = nVects / nWorkers, rem = nVects % nWorkers;
+  const int64_t nSubtasks = quot == 0 ? rem : nWorkers;
+  const size_t values = (size_t)(4 * (quot + 1) + (kb.ldT - 4 * nVects)) * sizeof(double);
+  const bool inLds = sum_lds_bytes(nSubtasks) + values <= 65536;
+  hipLaunchKernelGGL(long_row_stage_kernel<RECORD>, dim3((unsigned)nSubtasks), dim3(kThreads), sum_lds_bytes(nSubtasks) + (inLds ? values : 0), stream,
+                     make_args(kb, prior, nWorkers), iQuestion, iAnswer, asked, askedWords, kb.priorScratch, inLds ? 1 : 0);
+  const int64_t n4 = 4 * nVects;
+  hipLaunchKernelGGL(long_row_divide_kernel, dim3((unsigned)std::min<int64_t>((n4 + 1023) / 1024, 1024)), dim3(256), 0, stream, prior, kb.priorScratch, n4);
+  return true;
+}
+
 hipError_t LaunchStartQuiz(const KbView &kb, double *prior, uint32_t *asked, int64_t askedWords, int64_t nWorkers, hipStream_t stream) {
   if (nWorkers < 1 || nWorkers > kMaxWorkers) return hipErrorInvalidValue;
+  if (launch_long_row<false>(kb, prior, asked, askedWords, 0, 0, nWorkers, stream)) return hipGetLastError();
   if (small_launch(kb))
     hipLaunchKernelGGL(start_quiz_kernel<true>, dim3(1), dim3(kSmallThreads), staged_lds_bytes(kb, nWorkers), stream,
                        make_args(kb, prior, nWorkers, true), asked, askedWords);
@@ -195,6 +331,7 @@ hipError_t LaunchRecordAnswer(const KbView &kb, double *prior, uint32_t *asked, 
                               uint64_t topFlagValue, int64_t topCount, hipStream_t stream) {
   if (nWorkers < 1 || nWorkers > kMaxWorkers) return hipErrorInvalidValue;
   const TopRequest top{reinterpret_cast<TopOut *>(topOut), topN, topFlag, topFlagValue, (topOut && kb.T <= 16384) ? topCount : 0};
+  if (top.count == 0 && launch_long_row<true>(kb, prior, asked, 0, iQuestion, iAnswer, nWorkers, stream)) return hipGetLastError();
   if (small_launch(kb))
     hipLaunchKernelGGL(record_answer_kernel<true>, dim3(1), dim3(kSmallThreads), staged_lds_bytes(kb, nWorkers), stream,
                        make_args(kb, prior, nWorkers, true), iQuestion, iAnswer, asked, top);

@@ -424,6 +424,37 @@ def test_batched_posterior_updates_are_bit_identical(dims, factory):
     eng.close()
 
 
+@pytest.mark.parametrize("workers", [16, 2, 7], ids=lambda w: "%dworkers" % w)
+@pytest.mark.parametrize("T", [70001, 16390], ids=lambda t: "%dtargets" % t)
+def test_long_row_posterior_kernels_are_bit_identical(T, workers, factory):
+    """StartQuiz / RecordAnswer over rows beyond 16384 targets (one workgroup per subtask of the reference's sum,
+    prior_kernels.hip: long_row_stage_kernel + long_row_divide_kernel) against the one-workgroup kernels (option long_row_form = 0)
+    and the oracle, bit for bit: the subtasks' values in LDS (16 workers) and in memory (2 workers: one subtask is the whole row),
+    a row that is not a multiple of four targets, target gaps at both ends."""
+    K, Q = 3, 12
+    case = cases.Case("longrow", K, Q, T, seed=T + workers, qgaps=[4], tgaps=[0, 5, T - 1])
+    eng = case.make_engine(factory)
+    eng.set_option("workers", workers)
+    orc = case.make_oracle()
+    quizzes = []
+    for form in (1, 0):
+        eng.set_option("long_row_form", form)
+        quizzes.append(eng.start_quiz())
+    orc.start_quiz(workers)
+    for z in quizzes:
+        assert np.array_equal(eng.get_priors(z), orc.priors())
+    for step, (q, a) in enumerate([(3, 1), (0, 2), (11, 0)]):
+        for form, z in zip((1, 0), quizzes):
+            eng.set_option("long_row_form", form)
+            eng.set_active_question(z, q)
+            eng.record_answer(z, a)
+        orc.record_answer(q, a, max(1, workers - 1))
+        p1, p0 = eng.get_priors(quizzes[0]), eng.get_priors(quizzes[1])
+        assert np.array_equal(p1, p0), f"step {step}: the two forms"
+        assert np.array_equal(p1, orc.priors()), f"step {step}: oracle"
+    eng.close()
+
+
 @pytest.mark.parametrize("dims", [(37, 5, 101), (300, 5, 1000), (64, 5, 50), (90, 5, 2000), (40, 3, 300), (50, 8, 700), (33, 2, 64)],
                          ids=lambda d: "%dx%dx%d" % d)
 @pytest.mark.parametrize("n_quizzes", [3, 16, 17, 33, 70], ids=lambda n: "%dq" % n)
