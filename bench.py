@@ -640,7 +640,7 @@ class Ctl:
         self.torch.cuda.synchronize()
         if self.world > 1:
             self.dist.barrier()
-        self.torch.cuda.synchronize()
+            self.torch.cuda.synchronize()
 
     def max_float(self, x):
         if self.world == 1:

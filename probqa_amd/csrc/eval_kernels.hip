@@ -1278,14 +1278,14 @@ static hipError_t launch_server_form(const EvalArgs &args, ServerMailbox *mb, vo
 template <int WPQ, int NP>
 static hipError_t launch_server(const EvalArgs &args, ServerMailbox *mb, void *requestLine, bool everyonePolls, ServerCtl *ctl,
                                 uint64_t lastSeq, uint64_t idleTicks, hipStream_t stream) {
-  if (eval_base_lds_bytes<WPQ, NP, false>(args.K, args.ldT) + eval_deferred_bytes(WPQ, NP, args.K, false) + 64 <= kLdsPerCU)
+  if (eval_defers_sums(WPQ, NP, false) && eval_base_lds_bytes<WPQ, NP, false>(args.K, args.ldT) + eval_deferred_bytes(WPQ, NP, args.K, false) + 64 <= kLdsPerCU)
     return launch_server_form<WPQ, NP, true>(args, mb, requestLine, everyonePolls, ctl, lastSeq, idleTicks, stream);
   return launch_server_form<WPQ, NP, false>(args, mb, requestLine, everyonePolls, ctl, lastSeq, idleTicks, stream);
 }
 
 static int server_variant(const KbView &kb, int variant) {
   const int v = pick_variant(kb.ldT, variant);
-  return v == 2 ? v : 0;   // wg256_np2: rows up to 1024 targets
+  return v == 2 || (v == 8 && variant == 8) ? v : 0;   // wg256_np2: rows up to 1024 targets (wg128_np4: on request)
 }
 bool EvalVariantFusesSampled(const KbView &kb, int variant, int64_t nSubtasks) {   // a register shape, and the selection's LDS fits
   return pick_variant(kb.ldT, variant) != 99 && select_sampled_lds_doubles(kb.Q, nSubtasks) <= kLog2TableDoubles;
@@ -1304,6 +1304,7 @@ hipError_t LaunchEvalServer(const KbView &kb, int64_t qFirst, int64_t qLimit, do
   args.fs.hostPriority = hostPriority;
   switch (server_variant(kb, variant)) {
     case 2: return launch_server<4, 2>(args, mailbox, requestLine, everyonePolls, ctl, lastSeq, idleTicks, stream);
+    case 8: return launch_server<2, 4>(args, mailbox, requestLine, everyonePolls, ctl, lastSeq, idleTicks, stream);
     default: return hipErrorNotSupported;
   }
 }

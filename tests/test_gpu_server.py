@@ -49,12 +49,17 @@ def test_same_selections_and_posteriors_as_launch_per_selection(factory, vram):
         b.close()
 
 
-def test_priorities_of_a_resident_step_match_the_oracle(factory):
+@pytest.mark.parametrize("variant", [0, 8], ids=["wg256_np2", "wg128_np4"])
+def test_priorities_of_a_resident_step_match_the_oracle(factory, variant):
+    """(wg128_np4: the two-wave form that gives every question of a 1000-question cube a resident workgroup -- VERDICT r2 #4's
+    first suggestion; measured 16.7 us per step against 15.9, so it stays a variant on request: eval_variant = 8)"""
     case = cases.Case("server", 5, 200, 700, seed=11)
     orc = case.make_oracle()
     eng = case.make_engine(factory)
     eng.set_option("select", 1)
+    eng.set_option("eval_variant", variant)
     eng.set_option("server", 1)
+    assert eng.get_option("server_active") == 1
     try:
         quiz = eng.start_quiz()
         orc.start_quiz(16)
