@@ -21,6 +21,7 @@
 #include "pqa_device.h"
 #include "eval_device.h"
 #include "pqa_kernels.h"
+#include "prior_device.h"
 
 namespace pqa {
 
@@ -30,6 +31,7 @@ hipError_t UploadLog2Table(const double *hostTable) {
   return hipMemcpyToSymbol(HIP_SYMBOL(gLog2Table), hostTable, kLog2TableDoubles * sizeof(double));
 }
 
+// (prior_device.h: reference_order_sum, TopRequest -- the posterior update that eval_questions_f64_upd runs ahead of its sweep)
 struct EvalArgs {
   const double *cube;
   const double *prior;
@@ -42,6 +44,12 @@ struct EvalArgs {
   FusedSelect fs;
   const QuizSlot *slots;  // batched launch: per-quiz pointers, indexed by blockIdx.y (nullptr: a single quiz)
   int maxGrid;            // host side only: KbView::maxGrid
+  // eval_questions_f64_upd only: the answer whose posterior update runs in the sweep's prologue (sweep_body, FUSE)
+  const double *updRowA, *updRowD;   // sA[q][a][.], mD[q][.] of the answered question
+  int64_t updQuestion;               // its index (local): asked from this sweep on
+  int64_t updVects, updWorkers;      // ceil(T / 4), the subtasks of the reference's sum
+  int64_t updT;
+  TopRequest updTop;                 // the new posterior's best targets, listed by workgroup 0 (count 0: none)
 };
 
 // batched launch: this workgroup's quiz replaces the per-quiz fields of the arguments
@@ -307,7 +315,16 @@ __device__ __forceinline__ double2 load_pair(const double2 *p) {
   }
 }
 
-template <int WPQ, int NP, bool PRLDS, bool SERVER, bool DEFER>
+// FUSE: RecordAnswer's posterior update in the prologue (single-quiz launches of the register-prior shapes with rows of up to 1024
+// targets).  A lone client's critical path is RecordAnswer -> posterior kernel -> the sweep of the NextQuestion that follows
+// (launched speculatively right behind it): the sweep cannot start before the posterior kernel has finished, 5 us of kernel
+// and a dispatch gap for 8 KB of arithmetic.  Here EVERY workgroup of the sweep computes the posterior itself -- the old prior and
+// the answered question's two rows are 24 KB from L2, the element operations and the reference-order sum are those of
+// record_answer_body, so every workgroup gets the same bits that kernel would have written -- and sweeps with it; the last
+// workgroup also lists the posterior's best targets right away (ListTopTargets is the client's next call), and workgroup 0, as the
+// finisher that has seen every workgroup's record (so nobody reads the old prior any more), stores the posterior over the old prior
+// at the end.
+template <int WPQ, int NP, bool PRLDS, bool SERVER, bool DEFER, bool FUSE = false>
 __device__ __forceinline__ void sweep_body(EvalArgs a, bool copyTable) {
   constexpr int kThreads = WPQ * kWave;
   constexpr int NPR = PRLDS ? 1 : NP;
@@ -374,15 +391,67 @@ __device__ __forceinline__ void sweep_body(EvalArgs a, bool copyTable) {
     }
   };
   if (haveQ0) head_of_stream(q0);
-  if (copyTable) {
-    static_assert((kLog2TableDoubles / 2) % kThreads == 0, "the table copy is an exact number of 16-byte loads per thread");
-    constexpr int kTblPerThread = kLog2TableDoubles / 2 / kThreads;
-    double2 tv[kTblPerThread];
-    const double2 *src = reinterpret_cast<const double2 *>(gLog2Table);
+  static_assert((kLog2TableDoubles / 2) % kThreads == 0, "the table copy is an exact number of 16-byte loads per thread");
+  constexpr int kTblPerThread = kLog2TableDoubles / 2 / kThreads;
+  double2 tv[kTblPerThread];
+  if constexpr (!FUSE) {
+    if (copyTable) {
+      const double2 *src = reinterpret_cast<const double2 *>(gLog2Table);
 #pragma unroll
-    for (int i = 0; i < kTblPerThread; i++) tv[i] = src[tid + i * kThreads];
+      for (int i = 0; i < kTblPerThread; i++) tv[i] = src[tid + i * kThreads];
 #pragma unroll
-    for (int i = 0; i < kTblPerThread; i++) reinterpret_cast<double2 *>(tbl)[tid + i * kThreads] = tv[i];
+      for (int i = 0; i < kTblPerThread; i++) reinterpret_cast<double2 *>(tbl)[tid + i * kThreads] = tv[i];
+    }
+  }
+  if constexpr (FUSE) {
+    static_assert(!PRLDS && !SERVER && NP * kThreads <= 512, "rows of up to 1024 targets: the table's LDS holds the update's scratch first");
+    // scratch in the LDS the Log2Hot table takes afterwards: the un-normalised values [1024] | the sum's partials [8 * 51 + 1] | the listing's scratch
+    double *stage = tbl, *sums = tbl + 1024;
+    TopScratch *topScratch = reinterpret_cast<TopScratch *>(tbl + 1440);
+    static_assert(1440 * sizeof(double) + sizeof(TopScratch) <= kLog2TableDoubles * sizeof(double), "update scratch within the table's LDS");
+    double2 av[NP], dv[NP];
+    const RowRsrc ra = row_rsrc(a.updRowA, rowBytes), rd = row_rsrc(a.updRowD, rowBytes);
+#pragma unroll
+    for (int j = 0; j < NP; j++) { av[j] = row_load(ra, poff[j]); dv[j] = row_load(rd, poff[j]); }
+#pragma unroll
+    for (int j = 0; j < NP; j++) {
+      const int p = tid + j * kThreads;
+      if (p < nPairs) {
+        const int sh = (2 * p) & 31;
+        const double x0 = prRaw[j].x * (av[j].x / dv[j].x), x1 = prRaw[j].y * (av[j].y / dv[j].y);   // CERecordAnswerSubtaskMul.cpp:31, :34
+        stage[2 * p] = ((gapWord[j] >> sh) & 1u) ? 0.0 : x0;                                            // :35-37
+        stage[2 * p + 1] = ((gapWord[j] >> (sh + 1)) & 1u) ? 0.0 : x1;
+      }
+    }
+    const double total = reference_order_sum<true>(stage, a.updVects, a.updWorkers, sums);   // (sixteen values of a chain requested at once: its 17 LDS round trips in a row were 1 us)
+    // the table, requested now (held across the whole update its values went through scratch memory, 12 MB per launch): it
+    // arrives while the divisions run
+    const double2 *tblSrc = reinterpret_cast<const double2 *>(gLog2Table);
+    const double2 tv0 = tblSrc[tid], tv1 = tblSrc[tid + kThreads], tv2 = tblSrc[tid + 2 * kThreads], tv3 = tblSrc[tid + 3 * kThreads];
+    static_assert(kTblPerThread == 4, "four 16-byte table loads per thread");
+#pragma unroll
+    for (int j = 0; j < NP; j++) {
+      const int p = tid + j * kThreads;
+      if (p < nPairs) {
+        double2 v = make_double2(stage[2 * p], stage[2 * p + 1]);
+        if (2 * p < 4 * a.updVects) v.x = v.x / total;                                                  // CEDivTargPriors :19
+        if (2 * p + 1 < 4 * a.updVects) v.y = v.y / total;
+        prRaw[j] = v;
+        if (blockIdx.x == gridDim.x - 1) { stage[2 * p] = v.x; stage[2 * p + 1] = v.y; }   // (the thread's own elements)
+      }
+    }
+    // the listing is the LAST workgroup's: of a grid that strides over the questions it has the fewest, while workgroup 0 -- the
+    // finisher -- has the most and is what the launch waits for
+    if (blockIdx.x == gridDim.x - 1) {
+      if (tid == 0) const_cast<uint32_t *>(a.asked)[a.updQuestion >> 5] |= 1u << (a.updQuestion & 31);   // CEQuiz::RecordAnswer, PqaCore/CEQuiz.h:92
+      if (a.updTop.count > 0) {
+        __syncthreads();
+        top_targets_publish<true>(stage, a.tgap, a.updT, a.updTop.count, a.updTop.out, a.updTop.nOut, a.updTop.flag, a.updTop.flagValue, topScratch);
+      }
+    }
+    __syncthreads();   // the scratch is the table's from here on
+    double2 *tblDst = reinterpret_cast<double2 *>(tbl);
+    tblDst[tid] = tv0; tblDst[tid + kThreads] = tv1; tblDst[tid + 2 * kThreads] = tv2; tblDst[tid + 3 * kThreads] = tv3;
   }
   // Per-lane constants of the sweep: masked priors and gap flags of the lane's targets.
   uint32_t gapBits = 0;  // bit 2j / 2j+1 : target pair j element 0 / 1 is a gap (or beyond the row)
@@ -402,14 +471,14 @@ __device__ __forceinline__ void sweep_body(EvalArgs a, bool copyTable) {
   if constexpr (PRLDS) { if (tid == 0) prLds[nPairs] = make_double2(0.0, 0.0); }
 
   auto next_valid = [&](int64_t q) {               // :54 gap / asked questions get priority 0 and leave the stream
-    while (q < a.qLimit && (bit_test(a.qgap, q) || ((load_word<SERVER>(a.asked + (q >> 5)) >> (q & 31)) & 1u))) {
+    while (q < a.qLimit && (bit_test(a.qgap, q) || ((load_word<SERVER>(a.asked + (q >> 5)) >> (q & 31)) & 1u) || (FUSE && q == a.updQuestion))) {
       if (tid == 0) store_priority(a.priority + (q - a.qFirst), 0.0);
       q += gridDim.x;
     }
     return q;
   };
   int64_t q = q0;
-  if (haveQ0 && (((q0Gap | q0Asked) >> (q0 & 31)) & 1u)) {     // the first candidate is skipped: restart the stream
+  if (haveQ0 && ((((q0Gap | q0Asked) >> (q0 & 31)) & 1u) || (FUSE && q0 == a.updQuestion))) {     // the first candidate is skipped: restart the stream
     q = next_valid(q0);
     if (q < a.qLimit) head_of_stream(q);
   }
@@ -573,6 +642,17 @@ __device__ __forceinline__ void sweep_body(EvalArgs a, bool copyTable) {
     flush_pending(a, pend, nPend, lane, bestLds[lane]);
     fused_select<SERVER>(a, bestLds[lane], lane, allReported);
   }
+  if constexpr (FUSE) {
+    if (blockIdx.x == 0) {
+      // every workgroup has reported (fused_select above has seen their records): the old prior has no readers left
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < NP; j++) {
+        const int p = tid + j * kThreads;
+        if (p < nPairs) reinterpret_cast<double2 *>(const_cast<double *>(a.prior))[p] = pr[j];
+      }
+    }
+  }
   if (a.fs.scratch != nullptr && a.fs.sampleSubtasks > 0 && a.fs.hostPriority != nullptr) {
     // ---- the reference's selector on the HOST: the priorities are on their way to host-coherent memory (flush_pending: tagged
     // records) and fused_select above has seen every workgroup's record, so workgroup 0 only raises the flag.  Launched and
@@ -626,6 +706,12 @@ template <int WPQ, int NP, bool PRLDS, bool DEFER>
 __global__ __launch_bounds__(WPQ * 64) __attribute__((amdgpu_waves_per_eu(3, 3))) void eval_questions_f64_occ3(EvalArgs a) {
   select_quiz(a);
   sweep_body<WPQ, NP, PRLDS, false, DEFER>(a, true);
+}
+
+// RecordAnswer's posterior update + the sweep of the NextQuestion that follows, one launch (sweep_body: FUSE)
+template <int WPQ, int NP, bool DEFER>
+__global__ __launch_bounds__(WPQ * 64) void eval_questions_f64_upd(EvalArgs a) {
+  sweep_body<WPQ, NP, false, false, DEFER, true>(a, true);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -1232,6 +1318,56 @@ hipError_t LaunchEvalQuestions(const KbView &kb, const double *prior, const uint
   args.priority = priority;
   if (fused) args.fs = *fused;
   return launch_variant(args, kb.ldT, variant, 1, stream);
+}
+
+// ---- the posterior update of one answer + the sweep over the new posterior (eval_questions_f64_upd).  Whole-cube Double engines,
+// the 2-pair shape (rows of up to 1024 targets), a fused selection (its finisher is what knows when the old prior may be replaced).
+bool EvalFusesUpdate(const KbView &kb, int variant, int64_t nWorkers) {
+  const int64_t nVects = (kb.T + 3) >> 2, quot = nVects / nWorkers, rem = nVects % nWorkers;
+  const int64_t nSubtasks = quot == 0 ? rem : nWorkers;
+  return kb.elem == 8 && pick_variant(kb.ldT, variant) == 2 && kb.ldT <= 1024 && nSubtasks <= 51 && kb.maxGrid == 0 &&
+         eval_base_lds_bytes<4, 2, false>(kb.K, kb.ldT) + eval_deferred_bytes(4, 2, kb.K, false) <= kLdsPerCU;
+}
+
+hipError_t LaunchEvalQuestionsWithUpdate(const KbView &kb, double *prior, uint32_t *asked, double *priority, int variant, const FusedSelect &fused,
+                                         int64_t iQuestion, int64_t iAnswer, int64_t nWorkers, RatedTargetDev *topOut, int64_t *topN,
+                                         uint64_t *topFlag, uint64_t topFlagValue, int64_t topCount, hipStream_t stream) {
+  if (!EvalFusesUpdate(kb, variant, nWorkers) || fused.scratch == nullptr || nWorkers < 1) return hipErrorInvalidValue;
+  EvalArgs args = make_args(kb, 0, kb.Q);
+  args.prior = prior;
+  args.asked = asked;
+  args.priority = priority;
+  args.fs = fused;
+  const double *cube = static_cast<const double *>(kb.cube);
+  args.updRowA = cube + (iQuestion * (kb.K + 1) + iAnswer) * kb.ldT;   // CERecordAnswerSubtaskMul.cpp:25
+  args.updRowD = cube + (iQuestion * (kb.K + 1) + kb.K) * kb.ldT;      // :26
+  args.updQuestion = iQuestion;
+  args.updVects = (kb.T + 3) >> 2;
+  args.updWorkers = nWorkers;
+  args.updT = kb.T;
+  args.updTop = TopRequest{reinterpret_cast<TopOut *>(topOut), topN, topFlag, topFlagValue, topOut ? topCount : 0};
+  constexpr int WPQ = 4, NP = 2;
+  const size_t shmem = eval_base_lds_bytes<WPQ, NP, false>(args.K, args.ldT) + eval_deferred_bytes(WPQ, NP, args.K, false);
+  auto kern = eval_questions_f64_upd<WPQ, NP, true>;
+  static LaunchCache cache;
+  const int dev = LaunchCache::Device();
+  int cachedPerCU = 0;
+  if (!cache.Get(dev, shmem, &cachedPerCU)) {
+    if (shmem > 64 * 1024) {
+      const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+      if (e != hipSuccess) return e;
+    }
+    int perCU = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, kern, WPQ * 64, shmem) != hipSuccess || perCU < 1) perCU = 1;
+    if (perCU > 3) perCU = 3;   // as launch_reg_form
+    cachedPerCU = perCU;
+    cache.Put(dev, shmem, perCU);
+  }
+  const int64_t resident = (int64_t)cache.NumCUs(dev) * cachedPerCU;
+  int64_t grid = kb.Q < resident ? kb.Q : resident;
+  if (grid > kFusedMaxGrid) grid = kFusedMaxGrid;
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(WPQ * 64), shmem, stream, args);
+  return hipGetLastError();
 }
 
 hipError_t LaunchEvalQuestionsBatch(const KbView &kb, const QuizSlot *slots, int nSlots, int64_t qFirst, int64_t qLimit,

@@ -373,6 +373,7 @@ Error HipEngine::SetOption(const char *name, int64_t value) {
   else if (n == "combine") { _optCombine = value ? 1 : 0; }
   else if (n == "combine_spin") { _optCombineSpin = value ? 1 : 0; }
   else if (n == "long_row_form") { _optLongRowForm = value ? 1 : 0; }   // 0: the one-workgroup posterior kernels for rows beyond 16384 targets too
+  else if (n == "fuse_update") { _optFuseUpdate = value ? 1 : 0; }   // RecordAnswer's posterior update inside the speculative sweep's launch
   else if (n == "post_always") { _optPostAlways = value ? 1 : 0; }   // test hook: RecordAnswer / ListTopTargets always as posted operations
   else if (n == "combine_linger_us") { if (value < 0 || value > 10000) goto bad; _optLingerUs = value; }
   else if (n == "workers") { if (value < 1 || value > kMaxWorkers) goto bad; _optWorkers = value; }
@@ -418,6 +419,8 @@ int64_t HipEngine::GetOption(const char *name) const {
   if (n == "combine_linger_us") return _optLingerUs;
   if (n == "combine_spin") return _optCombineSpin;
   if (n == "post_always") return _optPostAlways;
+  if (n == "fuse_update") return _optFuseUpdate;
+  if (n == "fused_updates") return (int64_t)_fusedUpdates;           // RecordAnswers whose update ran inside the sweep's launch
   if (n == "long_row_form") return _optLongRowForm;
   if (n == "allowed_cpus") return AllowedCpus();
   if (n == "combined_batches") return (int64_t)_combBatches;        // sweeps that served more than one NextQuestion call ...
@@ -2196,6 +2199,9 @@ Error HipEngine::RecordAnswerLocked(int64_t iQuiz, int64_t iAnswer, bool remote,
   hipSetDevice(_device);
   const int64_t ql = aq - _qFirst;
   BitSet(q->hAsked, ql, true);
+  // Alone in the engine, the client's next call but one is NextQuestion: where the sweep's shape allows it, ONE launch updates the
+  // posterior and sweeps with it (Speculate with the update: eval_kernels.hip, eval_questions_f64_upd)
+  if (flushNow && _pendingUpdates.empty() && Speculate(q, ql, iAnswer)) return Error();
   _pendingUpdates.push_back(PendingUpdate{q, ql, iAnswer});
   _pendingCount.store(_pendingUpdates.size(), std::memory_order_relaxed);
   q->updatePending = true;
@@ -2266,31 +2272,54 @@ Error HipEngine::FlushUpdates() {
 // launched selection paths only: the resident sweep and graph replay have no launch to move, and shards' selections are driven by
 // the sharded engine.  Where the sweep has no finisher that hands its result over (Float engines, long rows), the sampled selector's
 // kernel -- it needs the random number -- is launched by NextQuestion over the priorities the speculative sweep left.
-void HipEngine::Speculate(Quiz *q) {
-  DropSpeculation();   // (one at a time: the hand-over buffers are the engine's)
-  if (!_optSpeculate || _optServer || _optUseGraph || _qTotal != _Q || _Q <= 0) return;
-  if (Concurrent()) return;   // (several clients: their NextQuestions are served together, by a batched sweep)
-  if (_specScore < -4 && (++_specProbe & 31) != 0) return;   // the client does not follow RecordAnswer with NextQuestion: probe now and then
+// updQuestion >= 0: the answer RecordAnswer has just been given and has NOT launched an update for -- the sweep's launch computes
+// the posterior itself (eval_questions_f64_upd: no posterior kernel for the sweep to wait for).  Returns true if that launch was
+// made (the posterior, the asked bit and the listing of the best targets are on their way, as FlushUpdates would have them);
+// false: nothing was launched for the update, the caller goes the usual way.
+bool HipEngine::Speculate(Quiz *q, int64_t updQuestion, int64_t updAnswer) {
+  const bool withUpdate = updQuestion >= 0;
+  if (!withUpdate) DropSpeculation();   // (one at a time: the hand-over buffers are the engine's)
+  if (!_optSpeculate || _optServer || _optUseGraph || _qTotal != _Q || _Q <= 0) return false;
+  if (Concurrent()) return false;   // (several clients: their NextQuestions are served together, by a batched sweep)
+  if (withUpdate && (!_optFuseUpdate || _specScore < -4)) return false;
+  if (_specScore < -4 && (++_specProbe & 31) != 0) return false;   // the client does not follow RecordAnswer with NextQuestion: probe now and then
   const KbView kb = View();
   int kind = 0;
   if (_optSelect == 1) kind = 1;
   else if (_optHostSampled && !_optFusedSampled && _elem == 8 && EvalVariantHasFinisherWorkgroup(kb, (int)_optEvalVariant)) kind = 2;
   else if (!(_optFusedSampled && _elem == 8)) kind = 3;   // Float engines, long rows: the sweep now, the selector kernel at NextQuestion
-  if (kind == 0) return;
-  if (kind == 2 && EnsureHostPriority() != hipSuccess) return;
+  if (kind == 0) return false;
+  const int64_t nLoose = std::max<int64_t>(1, _optWorkers - 1);   // reference PqaCore/CEQuiz.h:98, PqaCore/BaseCpuEngine.cpp:22
+  if (withUpdate && (kind == 3 || UseClusterSweep() || !EvalFusesUpdate(kb, (int)_optEvalVariant, nLoose))) return false;
+  if (kind == 2 && EnsureHostPriority() != hipSuccess) return false;
+  if (withUpdate) DropSpeculation();
   const uint64_t seq = NextLaunchTag();
   const FusedSelect fs{_dSelScratch, &_hPinned->sel, &_hPinned->seq, seq, 0, 0, seq, nullptr, kind == 2 ? 1 : 0, 0, nullptr,
                        kind == 2 ? _hHostPriority : nullptr};
-  if (kind == 1   ? !LaunchSingleSweep(q, &fs).ok()
-      : kind == 3 ? !LaunchSingleSweep(q, nullptr).ok()
-                  : LaunchEvalQuestions(kb, q->dPrior, q->dAsked, 0, _Q, _dPriority, (int)_optEvalVariant, &fs, _stream) != hipSuccess) {
+  if (withUpdate) {
+    const int64_t topCount = std::min<int64_t>(std::min<int64_t>(std::min<int64_t>(_optTopCache, _topWantRecent), kQuizTop), _T);
+    const uint64_t op = _opSeq + 1;
+    if (LaunchEvalQuestionsWithUpdate(kb, q->dPrior, q->dAsked, _dPriority, (int)_optEvalVariant, fs, updQuestion, updAnswer, nLoose, q->pin->top,
+                                      &q->pin->nOut, &q->pin->topFlag, op, topCount, _stream) != hipSuccess) {
+      (void)hipGetLastError();   // the usual way: posterior kernel, then the sweep
+      return false;
+    }
+    _opSeq = op;
+    q->topOp = op; q->topVersion = q->priorVersion; q->topCount = topCount;
+    _flushes++; _flushedUpdates++; _fusedUpdates++;
+    if (_maxFlush < 1) _maxFlush = 1;
+  } else if (kind == 1   ? !LaunchSingleSweep(q, &fs).ok()
+             : kind == 3 ? !LaunchSingleSweep(q, nullptr).ok()
+                         : LaunchEvalQuestions(kb, q->dPrior, q->dAsked, 0, _Q, _dPriority, (int)_optEvalVariant, &fs, _stream) != hipSuccess) {
     (void)hipGetLastError();   // NextQuestion will launch for itself and report
-    return;
+    return false;
   }
   _spec.quiz = q; _spec.priorVersion = q->priorVersion; _spec.tag = seq; _spec.kind = kind;
   _spec.variant = _optEvalVariant; _spec.stream = _stream;
   _pendingRecordOp = 0;   // the posterior kernel's flag no longer says that the stream is idle
+  _pendingRecordFlag = nullptr;
   _mu.busy = true;
+  return withUpdate;
 }
 
 // The kind (and the launch tag to wait for) of the pending speculative sweep if it is exactly a launch a NextQuestion accepting the

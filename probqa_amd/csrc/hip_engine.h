@@ -593,7 +593,9 @@ class HipEngine : public IEngine {
   int64_t _optSpeculate = 1;
   int _specScore = 0;        // +1 per speculation used, -1 per speculation dropped: below -4 only every 32nd RecordAnswer speculates
   uint64_t _specProbe = 0, _specHits = 0, _specDropped = 0;
-  void Speculate(Quiz *q);
+  bool Speculate(Quiz *q, int64_t updQuestion = -1, int64_t updAnswer = -1);
+  int64_t _optFuseUpdate = 1;   // option "fuse_update"
+  uint64_t _fusedUpdates = 0;
   int64_t SpeculateFor(int64_t iQuiz);
   int TakeSpeculation(Quiz *q, int kindMask, uint64_t *pTag);
   void DropSpeculation() {

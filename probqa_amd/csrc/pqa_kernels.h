@@ -207,7 +207,15 @@ hipError_t LaunchEvalServer(const KbView &kb, int64_t qFirst, int64_t qLimit, do
                             ServerCtl *ctl, uint64_t lastSeq, uint64_t idleTicks, TaggedPriority *hostPriority, hipStream_t stream);
 bool EvalServerSupported(const KbView &kb, int variant);
 
+
 struct RatedTargetDev { int64_t iTarget; double prob; };  // == CiRatedTarget
+// RecordAnswer's posterior update in the prologue of the sweep that follows it (eval_kernels.hip: eval_questions_f64_upd): one
+// launch does what LaunchRecordAnswer + LaunchEvalQuestions do (same posterior bits, same priorities), and the sweep does not wait
+// for a posterior kernel.  `fused` must name a selection (scratch != nullptr); the listing arguments as LaunchRecordAnswer's.
+bool EvalFusesUpdate(const KbView &kb, int variant, int64_t nWorkers);
+hipError_t LaunchEvalQuestionsWithUpdate(const KbView &kb, double *prior, uint32_t *asked, double *priority, int variant, const FusedSelect &fused,
+                                         int64_t iQuestion, int64_t iAnswer, int64_t nWorkers, RatedTargetDev *topOut, int64_t *topN,
+                                         uint64_t *topFlag, uint64_t topFlagValue, int64_t topCount, hipStream_t stream);
 
 // ---- selectors over priority[0..n) (questions qFirst..qFirst+n of the bitmaps); the reported index is
 // (position in priority[]) + outBase

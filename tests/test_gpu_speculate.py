@@ -140,3 +140,49 @@ def test_float_engines_and_long_rows(f32, dims, select, factory):
     assert a.get_option("spec_hits") == n_steps and b.get_option("spec_hits") == 0
     a.close()
     b.close()
+
+
+@pytest.mark.parametrize("select", [0, 1], ids=["sampled", "argmax"])
+@pytest.mark.parametrize("dims,workers", [((5, 1000, 1000), 16), ((5, 40, 300), 16), ((2, 77, 1024), 16), ((7, 50, 997), 5), ((3, 64, 700), 40)],
+                         ids=lambda d: str(d).replace(" ", ""))
+def test_update_inside_the_sweeps_launch(dims, workers, select, factory):
+    """RecordAnswer's posterior update in the prologue of the speculative sweep (eval_kernels.hip: eval_questions_f64_upd; option
+    fuse_update): against an engine that launches the posterior kernel first and against the oracle, on every step -- the
+    posterior bit for bit, the listing of the best targets, the question selected next (the answered question is asked from the
+    same launch on), with target and question gaps, 2 to 7 answers, rows that fill the 1024-target shape exactly, several worker
+    counts (the subtasks of the reference's sum)."""
+    K, Q, T = dims
+    case = cases.Case("fuse", K, Q, T, seed=T + K, tgaps=[0, T // 2, T - 1], qgaps=[3])
+    a, b = make(case, factory, 1, select), make(case, factory, 1, select)
+    for e in (a, b):
+        e.set_option("workers", workers)
+    b.set_option("fuse_update", 0)
+    orc = case.make_oracle()
+    rng = np.random.default_rng(K + T)
+    qa, qb = a.start_quiz(), b.start_quiz()
+    orc.start_quiz(workers)
+    n_steps = min(14, Q - 2)
+    for step in range(n_steps):
+        if select == 1:
+            ga, gb = a.next_question(qa), b.next_question(qb)
+            run, opri = orc.eval(SUBTASKS)
+            assert ga == gb == orc.select_argmax(opri), step
+        else:
+            rnd = int(rng.integers(0, 2**63)) * 2 + int(rng.integers(0, 2))
+            ga, gb = a.next_question_sampled(qa, rnd), b.next_question_sampled(qb, rnd)
+            run, opri = orc.eval(SUBTASKS)
+            assert ga == gb == orc.select_sampled(run, SUBTASKS, rnd), step
+        ans = int(rng.integers(0, K))
+        a.record_answer(qa, ans)
+        b.record_answer(qb, ans)
+        orc.record_answer(ga, ans, max(1, workers - 1))
+        if step % 2 == 0:
+            ta, tb = a.list_top_targets(qa, 5), b.list_top_targets(qb, 5)
+            assert [(t.i_target, t.prob) for t in ta] == [(t.i_target, t.prob) for t in tb], step
+        if step % 4 == 1:       # (reading the posterior leaves the speculation alone)
+            pa = a.get_priors(qa)
+            assert np.array_equal(pa, b.get_priors(qb)) and np.array_equal(pa, orc.priors()), step
+    assert np.array_equal(a.get_priors(qa), orc.priors())
+    assert a.get_option("fused_updates") == n_steps and b.get_option("fused_updates") == 0
+    assert a.get_option("spec_hits") == n_steps
+    a.close(); b.close()

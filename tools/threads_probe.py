@@ -9,6 +9,8 @@ e.fill_synthetic(8.0, 0.5, 20260928)
 e.set_option("select", int(os.environ.get("SELECT", "0")))
 if "SPIN" in os.environ:
     e.set_option("combine_spin", int(os.environ["SPIN"]))
+if "FUSE" in os.environ:
+    e.set_option("fuse_update", int(os.environ["FUSE"]))
 if "LINGER" in os.environ:
     e.set_option("combine_linger_us", int(os.environ["LINGER"]))
 keys = ["combined_batches", "combined_requests", "update_flushes", "updates_flushed", "combined_ns_lock", "combined_ns_launch",
