@@ -665,7 +665,16 @@ int64_t HipEngine::CreateQuiz(Error &err, int64_t nAnswered, const AQ *pAQs, con
 
 int64_t HipEngine::StartQuiz(Error &err) {
   CallScope scope(_activeCallers);
-  std::lock_guard<EngineMutex> lk(_mu);
+  if (_optCombine && (_optPostAlways || !_mu.try_lock())) {   // (the engine is taken: the quizzes started meanwhile share ONE launch)
+    PostedOp op;
+    op.kind = 4;
+    RunPosted(op);
+    err = op.err;
+    return op.result;
+  }
+  std::unique_lock<EngineMutex> lk(_mu, std::defer_lock);
+  if (_optCombine) lk = std::unique_lock<EngineMutex>(_mu, std::adopt_lock);
+  else lk.lock();
   return SpeculateFor(CreateQuiz(err, 0, nullptr, nullptr, nullptr, 0, nullptr));
 }
 
@@ -739,7 +748,19 @@ Error HipEngine::QuestionState(int64_t iQuiz, int64_t qGlobal, bool *pUnavailabl
 
 Error HipEngine::ReleaseQuiz(int64_t iQuiz) {
   CallScope scope(_activeCallers);
-  std::lock_guard<EngineMutex> lk(_mu);
+  if (_optCombine && (_optPostAlways || !_mu.try_lock())) {
+    PostedOp op;
+    op.kind = 5; op.iQuiz = iQuiz;
+    RunPosted(op);
+    return op.err;
+  }
+  std::unique_lock<EngineMutex> lk(_mu, std::defer_lock);
+  if (_optCombine) lk = std::unique_lock<EngineMutex>(_mu, std::adopt_lock);
+  else lk.lock();
+  return ReleaseQuizLocked(iQuiz);
+}
+
+Error HipEngine::ReleaseQuizLocked(int64_t iQuiz) {
   Error err = CheckRegular("release quiz");
   if (!err.ok()) return err;
   Quiz *q = UseQuiz(err, iQuiz);
@@ -1686,7 +1707,7 @@ void HipEngine::RunPosted(PostedOp &op) {
 }
 
 // Everything posted so far, in the order it was posted.  The RecordAnswers first go where RecordAnswer puts them (the list of
-// deferred updates); then ONE launch runs every deferred update if a ListTopTargets of this drain needs its quiz's posterior;
+// deferred updates), ReleaseQuiz and RecordQuizTarget run as they come; the StartQuiz calls then share one launch; then ONE launch runs every deferred update if a ListTopTargets of this drain needs its quiz's posterior;
 // then the combined sweeps leaders have posted; then the listings that the update kernel has not made already.
 void HipEngine::DrainPosted() {
   PostedOp *list = _posted.exchange(nullptr, std::memory_order_acq_rel);
@@ -1695,9 +1716,13 @@ void HipEngine::DrainPosted() {
   while (list != nullptr) { PostedOp *n = list->next; list->next = ordered; ordered = list; list = n; }
   _postedDrains++;
   bool needFlush = false;
+  int64_t nStarts = 0;
   for (PostedOp *op = ordered; op != nullptr; op = op->next) {
     _postedOps++;
     if (op->kind == 1) { op->err = RecordAnswerLocked(op->iQuiz, op->arg, op->remote, false); continue; }
+    if (op->kind == 5) { op->err = ReleaseQuizLocked(op->iQuiz); continue; }
+    if (op->kind == 6) { op->err = RecordQuizTargetLocked(op->iQuiz, op->arg, op->amount); continue; }
+    if (op->kind == 4) { nStarts++; continue; }
     if (op->kind == 3) continue;
     op->result = -1;
     op->err = CheckRegular("list top targets");
@@ -1707,6 +1732,39 @@ void HipEngine::DrainPosted() {
   }
   Error flushErr;
   if (needFlush) flushErr = FlushUpdates();
+  if (nStarts > 0) {
+    // the StartQuiz calls of this drain: ONE launch sets all their priors (as StartQuizBatch; chunks of kStartInline)
+    hipSetDevice(_device);
+    static thread_local StartBatchInline batch;   // (4 KB of pointers: not on a client thread's stack)
+    batch.n = 0;
+    batch.askedWords = (int64_t)BitWords(_Q);
+    std::vector<PostedOp *> chunk;
+    auto launch = [&]() {
+      if (batch.n > 0) {
+        const hipError_t he = LaunchStartQuizBatch(View(), batch, _optWorkers, _stream);
+        if (he != hipSuccess)
+          for (PostedOp *o : chunk)
+            if (o->result >= 0) {
+              Quiz *q = _quizzes[(size_t)o->result];
+              UnassignQuiz(o->result);
+              DestroyQuiz(q);
+              o->result = -1;
+              o->err = HipErr(he, "StartQuiz");
+            }
+      }
+      batch.n = 0;
+      chunk.clear();
+    };
+    for (PostedOp *op = ordered; op != nullptr; op = op->next) {
+      if (op->kind != 4) continue;
+      _startBatch = &batch;
+      op->result = CreateQuiz(op->err, 0, nullptr, nullptr, nullptr, 0, nullptr);
+      _startBatch = nullptr;
+      chunk.push_back(op);
+      if (batch.n == kStartInline) launch();
+    }
+    launch();
+  }
   for (PostedOp *op = ordered; op != nullptr; op = op->next)
     if (op->kind == 3) LaunchBatchLocked(*op->ctx, *op->batch, *op->flight);   // (behind the updates, ahead of the listings: the sweep is what the most clients wait for)
   for (PostedOp *op = ordered; op != nullptr;) {
@@ -2659,7 +2717,19 @@ Error HipEngine::RecordQuizTarget(int64_t iQuiz, int64_t iTarget, double amount)
   if (amount <= 0)
     return Error::MakeP(ErrCode::NonPositiveAmount, "amount=" + std::to_string(amount), "|amount| must be positive.");
   CallScope scope(_activeCallers);
-  std::lock_guard<EngineMutex> lk(_mu);
+  if (_optCombine && (_optPostAlways || !_mu.try_lock())) {
+    PostedOp op;
+    op.kind = 6; op.iQuiz = iQuiz; op.arg = iTarget; op.amount = amount;
+    RunPosted(op);
+    return op.err;
+  }
+  std::unique_lock<EngineMutex> lk(_mu, std::defer_lock);
+  if (_optCombine) lk = std::unique_lock<EngineMutex>(_mu, std::adopt_lock);
+  else lk.lock();
+  return RecordQuizTargetLocked(iQuiz, iTarget, amount);
+}
+
+Error HipEngine::RecordQuizTargetLocked(int64_t iQuiz, int64_t iTarget, double amount) {
   Error err = CheckRegular("record quiz target");
   if (!err.ok()) return err;
   if (iTarget < 0 || iTarget >= _T)

@@ -414,7 +414,9 @@ class HipEngine : public IEngine {
   struct Flight;
   struct PostedOp {
     int kind = 0;                      // 1: RecordAnswer(iQuiz, arg = iAnswer, remote); 2: ListTopTargets' launch (arg = maxCount);
-                                       // 3: a leader's LaunchBatch(ctx, batch, flight)
+                                       // 3: a leader's LaunchBatch(ctx, batch, flight); 4: StartQuiz (result = the quiz);
+                                       // 5: ReleaseQuiz(iQuiz); 6: RecordQuizTarget(iQuiz, arg = iTarget, amount)
+    double amount = 0;
     int64_t iQuiz = -1, arg = 0;
     bool remote = false;
     Error err;
@@ -432,6 +434,8 @@ class HipEngine : public IEngine {
   std::vector<std::atomic<int> *> _postedWake;     // the drain's sleepers, woken once the lock is released
   uint64_t _postedOps = 0, _postedDrains = 0;
   void DrainPosted();                              // (the engine's lock held)
+  Error ReleaseQuizLocked(int64_t iQuiz);
+  Error RecordQuizTargetLocked(int64_t iQuiz, int64_t iTarget, double amount);
   void RunPosted(PostedOp &op);                    // post, and return when somebody has run it
   void ServeQueue(SelRequest *own);
   int64_t PreferredCombinedBatch(int64_t m) const;

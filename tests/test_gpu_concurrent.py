@@ -125,6 +125,17 @@ def test_posted_operations_equal_direct_calls(factory):
             ta, tb = a.list_top_targets(qa, want), b.list_top_targets(qb, want)
             assert [(t.i_target, t.prob) for t in ta] == [(t.i_target, t.prob) for t in tb]
     assert b.get_option("posted_ops") >= 12 * 5 and a.get_option("posted_ops") == 0
+    # RecordQuizTarget, ReleaseQuiz and StartQuiz in the posted form: the trained cube gives the same priorities to a new quiz
+    a.record_quiz_target(qa, 7)
+    b.record_quiz_target(qb, 7)
+    a.release_quiz(qa)
+    b.release_quiz(qb)
+    qa, qb = a.start_quiz(), b.start_quiz()
+    assert np.array_equal(a.eval_priorities(qa), b.eval_priorities(qb)) and np.array_equal(a.get_priors(qa), b.get_priors(qb))
+    with pytest.raises(interop.PqaException):
+        b.release_quiz(4321)
+    with pytest.raises(interop.PqaException):
+        b.record_quiz_target(qb, 10**6)
     # the errors come back through the operation
     for eng in (a, b):
         with pytest.raises(interop.PqaException) as e1:
