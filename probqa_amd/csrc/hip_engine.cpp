@@ -427,7 +427,9 @@ int64_t HipEngine::GetOption(const char *name) const {
   if (n == "combined_requests") return (int64_t)_combRequests;      // ... the calls they served ...
   if (n == "combined_max_batch") return (int64_t)_combMaxBatch;     // ... and the largest of them
   if (n == "posted_ops") return (int64_t)_postedOps;                 // RecordAnswer / ListTopTargets calls that found the engine taken and were run by its holder ...
-  if (n == "posted_drains") return (int64_t)_postedDrains;           // ... in this many rounds
+  if (n == "posted_drains") return (int64_t)_postedDrains;
+  if (n == "train_batches") return (int64_t)_trainBatches;           // launches that ran posted RecordQuizTarget calls together ...
+  if (n == "train_batch_calls") return (int64_t)_trainBatchCalls;    // ... this many of them           // ... in this many rounds
   if (n == "update_flushes") return (int64_t)_flushes;              // launches that ran deferred RecordAnswers ...
   if (n == "updates_flushed") return (int64_t)_flushedUpdates;      // ... the updates they ran ...
   if (n == "update_max_flush") return (int64_t)_maxFlush;           // ... and the most in one launch
@@ -1716,12 +1718,12 @@ void HipEngine::DrainPosted() {
   while (list != nullptr) { PostedOp *n = list->next; list->next = ordered; ordered = list; list = n; }
   _postedDrains++;
   bool needFlush = false;
-  int64_t nStarts = 0;
+  int64_t nStarts = 0, nTrains = 0;
   for (PostedOp *op = ordered; op != nullptr; op = op->next) {
     _postedOps++;
     if (op->kind == 1) { op->err = RecordAnswerLocked(op->iQuiz, op->arg, op->remote, false); continue; }
     if (op->kind == 5) { op->err = ReleaseQuizLocked(op->iQuiz); continue; }
-    if (op->kind == 6) { op->err = RecordQuizTargetLocked(op->iQuiz, op->arg, op->amount); continue; }
+    if (op->kind == 6) { nTrains++; continue; }
     if (op->kind == 4) { nStarts++; continue; }
     if (op->kind == 3) continue;
     op->result = -1;
@@ -1732,6 +1734,7 @@ void HipEngine::DrainPosted() {
   }
   Error flushErr;
   if (needFlush) flushErr = FlushUpdates();
+  if (nTrains > 0) TrainPosted(ordered);
   if (nStarts > 0) {
     // the StartQuiz calls of this drain: ONE launch sets all their priors (as StartQuizBatch; chunks of kStartInline)
     hipSetDevice(_device);
@@ -1792,6 +1795,64 @@ void HipEngine::DrainPosted() {
     if (word->exchange(1, std::memory_order_acq_rel) == 2) _postedWake.push_back(word);
     op = next;
   }
+}
+
+// The RecordQuizTarget calls of a drain (kind 6), in the order they were posted: calls with different targets touch disjoint cells
+// and go out in ONE launch (train_batch_inline_kernel: a workgroup per call); a call whose target is already in the batch, or that
+// does not fit the kernel's arguments, closes the batch first (or runs alone, the usual way).
+void HipEngine::TrainPosted(PostedOp *ordered) {
+  static thread_local TrainBatchInline tb;   // (2.5 KB)
+  tb.nCalls = 0; tb.nChainsTotal = 0; tb.nSteps = 0;
+  std::vector<PostedOp *> inBatch;
+  hipSetDevice(_device);
+  auto launch = [&]() {
+    if (tb.nCalls > 0) {
+      const hipError_t he = LaunchTrainBatchInline(_dCube, _elem, _dVB, _K, _ldT, tb, _stream);
+      if (he != hipSuccess) for (PostedOp *o : inBatch) o->err = HipErr(he, "RecordQuizTarget");
+      _trainBatches++;
+      _trainBatchCalls += (uint64_t)tb.nCalls;
+    }
+    tb.nCalls = 0; tb.nChainsTotal = 0; tb.nSteps = 0;
+    inBatch.clear();
+  };
+  bool stopped = false;
+  for (PostedOp *op = ordered; op != nullptr; op = op->next) {
+    if (op->kind != 6) continue;
+    op->err = CheckRegular("record quiz target");
+    if (!op->err.ok()) continue;
+    const int64_t iTarget = op->arg;
+    Quiz *q = UseQuiz(op->err, op->iQuiz);
+    if (q == nullptr) continue;
+    op->err = ValidateTrainLocked((int64_t)q->answers.size(), q->answers.data(), iTarget);
+    if (!op->err.ok()) continue;
+    if (!stopped) { StopServer(); stopped = true; }   // the cube changes (and the deferred updates read it as it was: they run first)
+    std::vector<TrainStep> steps;
+    std::vector<int64_t> chainStart;
+    BuildTrainSteps((int64_t)q->answers.size(), q->answers.data(), true, steps, chainStart);
+    const int64_t nChains = (int64_t)chainStart.size() - 1;
+    bool fits = (int64_t)steps.size() <= kTrainBatchSteps && nChains + 1 <= (int64_t)(sizeof(tb.chainStart) / sizeof(tb.chainStart[0]));
+    for (const TrainStep &st : steps) fits = fits && st.q <= INT32_MAX && st.a1 < 256 && st.a2 < 256;
+    if (!fits) {   // a long quiz: the usual way, in its place in the order
+      launch();
+      op->err = TrainLocked((int64_t)q->answers.size(), q->answers.data(), iTarget, op->amount, true);
+      continue;
+    }
+    bool clash = tb.nCalls == kTrainBatchCalls || tb.nSteps + (int64_t)steps.size() > kTrainBatchSteps ||
+                 tb.nChainsTotal + tb.nCalls + nChains + 1 > (int64_t)(sizeof(tb.chainStart) / sizeof(tb.chainStart[0]));
+    for (int c = 0; c < tb.nCalls && !clash; c++) clash = tb.calls[c].iTarget == iTarget;
+    if (clash) launch();
+    TrainBatchCall &call = tb.calls[tb.nCalls];
+    call.iTarget = iTarget; call.amount = op->amount; call.firstChain = tb.nChainsTotal; call.nChains = (int32_t)nChains;
+    uint16_t *cs = tb.chainStart + tb.nChainsTotal + tb.nCalls;   // (every call's chain starts are followed by one end marker)
+    for (int64_t c = 0; c <= nChains; c++) cs[c] = (uint16_t)(tb.nSteps + chainStart[(size_t)c]);
+    for (size_t i = 0; i < steps.size(); i++)
+      tb.steps[tb.nSteps + (int64_t)i] = TrainBatchStep{(int32_t)steps[i].q, (uint8_t)steps[i].kind, (uint8_t)steps[i].a1, (uint8_t)steps[i].a2, 0};
+    tb.nSteps += (int32_t)steps.size();
+    tb.nChainsTotal += (int32_t)nChains;
+    tb.nCalls++;
+    inBatch.push_back(op);
+  }
+  launch();
 }
 
 int64_t HipEngine::Combine(Error &err, int64_t iQuiz, int kind, uint64_t rnd) {

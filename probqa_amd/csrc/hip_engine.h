@@ -434,6 +434,8 @@ class HipEngine : public IEngine {
   std::vector<std::atomic<int> *> _postedWake;     // the drain's sleepers, woken once the lock is released
   uint64_t _postedOps = 0, _postedDrains = 0;
   void DrainPosted();                              // (the engine's lock held)
+  void TrainPosted(PostedOp *ordered);             // the drain's RecordQuizTarget calls
+  uint64_t _trainBatches = 0, _trainBatchCalls = 0;
   Error ReleaseQuizLocked(int64_t iQuiz);
   Error RecordQuizTargetLocked(int64_t iQuiz, int64_t iTarget, double amount);
   void RunPosted(PostedOp &op);                    // post, and return when somebody has run it

@@ -117,6 +117,43 @@ __global__ void train_steps_inline_kernel(void *__restrict__ cube, int elem, dou
   train_steps_body(cube, elem, vB, K, ldT, in.steps, in.chainStart, in.nChains, iTarget, amount);
 }
 
+// Several calls' steps, one workgroup per call (the calls' targets differ: no cell belongs to two of them).  The arithmetic of a step
+// is train_steps_body's.
+__global__ void train_batch_inline_kernel(void *__restrict__ cube, int elem, double *__restrict__ vB, int64_t K, int64_t ldT, TrainBatchInline in) {
+  const TrainBatchCall call = in.calls[blockIdx.x];
+  const int64_t iTarget = call.iTarget;
+  const double amount = call.amount;
+  const double twoB = 2 * amount, bSquare = amount * amount;  // CETrainTaskNumSpec.h:24-32
+  const double fourB = 4 * amount, square2B = 4 * bSquare;
+  // chain c of the call: steps [chainStart[firstChain + callIndex + c], chainStart[firstChain + callIndex + c + 1]) -- every call's
+  // chain starts are followed by one end marker, so call b's entries begin at firstChain + b
+  const uint16_t *cs = in.chainStart + call.firstChain + blockIdx.x;
+  for (int c = threadIdx.x; c < call.nChains; c += blockDim.x) {
+    for (int i = cs[c]; i < cs[c + 1]; i++) {
+      const TrainBatchStep st = in.steps[i];
+      const int64_t iA = ((int64_t)st.q * (K + 1) + st.a1) * ldT + iTarget, iD = ((int64_t)st.q * (K + 1) + K) * ldT + iTarget;
+      const double oldA = cube_ld(cube, elem, iA);
+      const double a = sqrt(oldA);                               // CETrainOperation.cpp:18
+      if (st.kind == 3) {
+        const int64_t iA2 = ((int64_t)st.q * (K + 1) + st.a2) * ldT + iTarget;
+        const double oldA2 = cube_ld(cube, elem, iA2);
+        const double add1 = a * twoB + bSquare, add2 = sqrt(oldA2) * twoB + bSquare;   // :42-44
+        cube_st(cube, elem, iA, oldA + add1);                    // :47-53
+        cube_st(cube, elem, iA2, oldA2 + add2);
+        cube_st(cube, elem, iD, cube_ld(cube, elem, iD) + (add1 + add1));
+      } else {
+        const double addend = st.kind == 2 ? a * fourB + square2B : a * twoB + bSquare;   // :19
+        cube_st(cube, elem, iA, oldA + addend);                  // :23-24
+        cube_st(cube, elem, iD, cube_ld(cube, elem, iD) + addend);   // :25
+      }
+    }
+  }
+  if (threadIdx.x == 0) {
+    const double b = vB[iTarget] + amount;                   // PqaCore/CpuEngine.cpp:172, :462
+    vB[iTarget] = elem == 4 ? (double)(float)b : b;
+  }
+}
+
 // ListTopTargets on the device (top_targets_publish in pqa_device.h); T <= 16384.
 static_assert(sizeof(TopOut) == sizeof(RatedTargetDev), "same record");
 template <bool SMALL>
@@ -257,6 +294,12 @@ hipError_t LaunchTrainSteps(void *cube, int elem, double *vB, int64_t K, int64_t
 hipError_t LaunchTrainStepsInline(void *cube, int elem, double *vB, int64_t K, int64_t ldT, const TrainStepsInline &in,
                                   int64_t iTarget, double amount, hipStream_t stream) {
   hipLaunchKernelGGL(train_steps_inline_kernel, dim3(1), dim3(64), 0, stream, cube, elem, vB, K, ldT, in, iTarget, amount);
+  return hipGetLastError();
+}
+
+hipError_t LaunchTrainBatchInline(void *cube, int elem, double *vB, int64_t K, int64_t ldT, const TrainBatchInline &in, hipStream_t stream) {
+  if (in.nCalls < 1 || in.nCalls > kTrainBatchCalls) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(train_batch_inline_kernel, dim3((unsigned)in.nCalls), dim3(64), 0, stream, cube, elem, vB, K, ldT, in);
   return hipGetLastError();
 }
 

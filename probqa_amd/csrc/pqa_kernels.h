@@ -291,6 +291,19 @@ struct TrainStepsInline {
 };
 hipError_t LaunchTrainStepsInline(void *cube, int elem, double *vB, int64_t K, int64_t ldT, const TrainStepsInline &in,
                                   int64_t iTarget, double amount, hipStream_t stream);
+// Several training calls -- each with its own target and amount, DIFFERENT targets (their cells are disjoint then) -- in one launch:
+// workgroup c runs call c's chains exactly as train_steps_inline_kernel would.  What a server's clients' RecordQuizTarget calls
+// become when they arrive together (hip_engine.cpp: DrainPosted).
+constexpr int kTrainBatchCalls = 24, kTrainBatchSteps = 192;
+struct TrainBatchStep { int32_t q; uint8_t kind, a1, a2, pad; };
+struct TrainBatchCall { int64_t iTarget; double amount; int32_t firstChain, nChains; };
+struct TrainBatchInline {
+  int32_t nCalls, nChainsTotal, nSteps, pad;
+  TrainBatchCall calls[kTrainBatchCalls];
+  uint16_t chainStart[kTrainBatchSteps + kTrainBatchCalls + 8];   // per call: its chains' starts and one end, indices into steps[]
+  TrainBatchStep steps[kTrainBatchSteps];
+};
+hipError_t LaunchTrainBatchInline(void *cube, int elem, double *vB, int64_t K, int64_t ldT, const TrainBatchInline &in, hipStream_t stream);
 // Maintenance (PqaCore/CpuEngine.cpp:468-658): (re)initialise whole questions / whole target columns; compact the target
 // axis with (src,dst) column moves.  qs/ts/inits/moves are device arrays.
 hipError_t LaunchFillQuestions(void *cube, int elem, int64_t K, int64_t T, int64_t ldT, const int64_t *qs, const double *inits,

@@ -75,6 +75,7 @@ def test_native_learner_threads_same_transcripts_and_combined(factory):
     eng.set_option("select", 0)
     trained = interop.run_learners(eng, 48, 192, 30, seed=10, train=True)
     assert trained["errors"] == 0 and trained["quizzes"] == 192 and trained["guessed_on_top"] > 96
+    assert eng.get_option("train_batch_calls") > eng.get_option("train_batches") > 0     # RecordQuizTarget calls that shared a launch
     eng.close()
 
 
@@ -148,4 +149,50 @@ def test_posted_operations_equal_direct_calls(factory):
         eng.next_question(qa if eng is a else qb)
         with pytest.raises(interop.PqaException):
             eng.record_answer(qa if eng is a else qb, 5)             # answer out of range
+    a.close(); b.close()
+
+
+def test_training_calls_that_arrive_together_share_a_launch(factory):
+    """RecordQuizTarget from many threads at once (the end of the reference's learner loop, PqaClient.cpp:214-222): the calls a
+    drain finds posted go out in ONE launch (kb_kernels.hip: train_batch_inline_kernel -- a workgroup per call, different targets;
+    a target met twice closes the batch).  Held to the same calls made one after the other on a second engine: the whole cube bit
+    for bit (different targets touch disjoint cells, so the order of arrival does not matter), including a question answered twice
+    in one quiz (Perform2's same-question rules) and a target that two quizzes share."""
+    n = 24
+    a = _engine(factory, 5, 60, 200, 9, 1)
+    b = _engine(factory, 5, 60, 200, 9, 1)
+    a.set_option("post_always", 1)
+    quizzes = {}
+    for eng in (a, b):
+        zs = []
+        for i in range(n):
+            z = eng.start_quiz()
+            for step in range(2 + i % 4):
+                qq = (7 * i + 11 * step) % 60 if not (i % 5 == 0 and step == 1) else (7 * i) % 60     # (every fifth quiz repeats its first question)
+                if qq == 5:
+                    qq = 6                                                                            # (5 is a gap of the fixture)
+                eng.set_active_question(z, qq)
+                eng.record_answer(z, (i + step) % 5)
+            zs.append(z)
+        quizzes[id(eng)] = zs
+    targets = [3 + 7 * i for i in range(n)]
+    targets[-1] = targets[0]                       # one target twice: the second call closes the first's batch
+    start = threading.Barrier(n - 1)
+
+    def train(i):
+        start.wait()
+        a.record_quiz_target(quizzes[id(a)][i], targets[i], 1.0 + 0.25 * (i % 3))
+
+    # (the two calls that share a target are not concurrent: their order would show in mD's roundings)
+    ts = [threading.Thread(target=train, args=(i,)) for i in range(n - 1)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    a.record_quiz_target(quizzes[id(a)][n - 1], targets[n - 1], 1.0 + 0.25 * ((n - 1) % 3))
+    for i in range(n):
+        b.record_quiz_target(quizzes[id(b)][i], targets[i], 1.0 + 0.25 * (i % 3))
+    for x, y in zip(a.get_kb(), b.get_kb()):
+        assert np.array_equal(x, y)
+    assert a.get_option("train_batch_calls") == n and b.get_option("train_batch_calls") == 0
     a.close(); b.close()
