@@ -841,7 +841,9 @@ void CheckPriority(double priority, int64_t index) {   // CEEvalQsSubtaskConside
   if (index >= 0 && !(priority > 0 && std::isfinite(priority))) LogAnomaly(DefaultLogger::Severity::Warning, "Got priority=", priority);
 }
 
-int64_t SelectSampledHost(double *run, int64_t n, int64_t nWorkers, uint64_t rnd, const std::function<bool(int64_t)> &skipped) {
+namespace {
+template <class Skip>
+int64_t SelectSampledHostT(double *run, int64_t n, int64_t nWorkers, uint64_t rnd, const Skip &skipped) {
   struct Kahan {                 // SRAccumulator<SRDoubleNumber> (SRPlatform/Interface/SRAccumulator.h:15-39)
     double sum = 0, corr = 0;
     void add(double v) { const double y = v - corr; const double t = sum + y; corr = (t - sum) - y; sum = t; }
@@ -875,6 +877,16 @@ int64_t SelectSampledHost(double *run, int64_t n, int64_t nWorkers, uint64_t rnd
   int64_t sel = std::upper_bound(run + first, run + limit, inWorker) - run;   // :391
   if (sel >= limit) sel = limit - 1;                              // :392-400
   return sel;
+}
+}  // namespace
+int64_t SelectSampledHost(double *run, int64_t n, int64_t nWorkers, uint64_t rnd, const std::function<bool(int64_t)> &skipped) {
+  return SelectSampledHostT(run, n, nWorkers, rnd, skipped);
+}
+// (the same over bit words -- a question is skipped if its bit is set in either array; `b` may be null: the test inlined
+//  instead of a call through std::function per question, 1000 of them per selection)
+int64_t SelectSampledHostBits(double *run, int64_t n, int64_t nWorkers, uint64_t rnd, const uint32_t *a, const uint32_t *b) {
+  if (b == nullptr) return SelectSampledHostT(run, n, nWorkers, rnd, [a](int64_t i) { return ((a[i >> 5] >> (i & 31)) & 1u) != 0; });
+  return SelectSampledHostT(run, n, nWorkers, rnd, [a, b](int64_t i) { return (((a[i >> 5] | b[i >> 5]) >> (i & 31)) & 1u) != 0; });
 }
 
 int64_t HipEngine::FindNearestQuestion(int64_t iMiddle, const Quiz *q) const {   // (over the local question range)
@@ -1573,7 +1585,7 @@ int64_t HipEngine::NextQuestionSampledLocked(Error &err, int64_t iQuiz, uint64_t
     if (_hPinned->sel.index == -3) { err = HipErr(hipErrorLaunchFailure, "NextQuestionSampled (incomplete sweep)"); return -1; }
     err = CollectHostPriority(_serverPosted, q);
     if (!err.ok()) return -1;
-    const int64_t sel = SelectSampledHost(_hostRun.data(), _Q, nSub, rnd, [&](int64_t i) { return BitTest(_hQGap, i) || BitTest(q->hAsked, i); });
+    const int64_t sel = SelectSampledHostBits(_hostRun.data(), _Q, nSub, rnd, _hQGap.data(), q->hAsked.data());
     return FinishSelection(err, q, sel);
   }
   uint64_t specTag = 0;
@@ -1598,7 +1610,7 @@ int64_t HipEngine::NextQuestionSampledLocked(Error &err, int64_t iQuiz, uint64_t
     if (_hPinned->sel.index == -3) { err = HipErr(hipErrorLaunchFailure, "NextQuestionSampled (incomplete sweep)"); return -1; }
     err = CollectHostPriority(seq, q);
     if (!err.ok()) return -1;
-    const int64_t sel = SelectSampledHost(_hostRun.data(), _Q, nSub, rnd, [&](int64_t i) { return BitTest(_hQGap, i) || BitTest(q->hAsked, i); });
+    const int64_t sel = SelectSampledHostBits(_hostRun.data(), _Q, nSub, rnd, _hQGap.data(), q->hAsked.data());
     return FinishSelection(err, q, sel);
   }
   if (took != 3 && _optFusedSampled && _elem == 8 && EvalVariantFusesSampled(kb, (int)_optEvalVariant, nSub)) {
@@ -1951,7 +1963,7 @@ int64_t HipEngine::SelectFromPriorities(SelRequest *r) {
   }
   int64_t pick = -1;
   if (r->kind == 1) {
-    pick = SelectSampledHost(run.data(), nQ, r->nSub, r->rnd, skip);
+    pick = SelectSampledHostBits(run.data(), nQ, r->nSub, r->rnd, r->unavailable.data(), nullptr);
   } else {
     double best = 0;
     for (int64_t k = 0; k < nQ; k++) {

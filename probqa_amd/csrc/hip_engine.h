@@ -633,6 +633,7 @@ class HipEngine : public IEngine {
 void LogAnomaly(DefaultLogger::Severity sev, const char *what, double value);   // the reference's numeric-anomaly log entries (rate-limited)
 void CheckPriority(double priority, int64_t index);
 int64_t SelectSampledHost(double *run, int64_t n, int64_t nWorkers, uint64_t rnd, const std::function<bool(int64_t)> &skipped);
+int64_t SelectSampledHostBits(double *run, int64_t n, int64_t nWorkers, uint64_t rnd, const uint32_t *a, const uint32_t *b);
 int64_t FindNearestInPacks(int64_t iMiddle, int64_t nQuestions, const std::function<uint64_t(int64_t)> &avail);
 // One knowledge base over several devices of this process (sharded_engine.cpp); devices.size() >= 2.
 IEngine *CreateShardedEngine(Error &err, const CiEngineDefinition &def, const std::vector<int> &devices);
