@@ -53,6 +53,15 @@ PQACORE_API void *PqaEngineFactory_CreateHipEngineSharded(void *pvFactory, void 
  * "speculate" (StartQuiz / ResumeQuiz / RecordAnswer launch the sweep of the NextQuestion that normally follows them, which then only
  * waits for its result; same questions either way; default 1, also PQA_SPECULATE; read-only "spec_hits" / "spec_dropped" count the
  * speculative sweeps that were used / dropped),
+ * "fuse_update" (RecordAnswer's posterior update runs inside the launch of that speculative sweep where its shape allows it -- rows
+ * of up to 1024 targets -- instead of in a kernel of its own ahead of it; same bits; default 1; read-only "fused_updates"),
+ * "combine" (concurrent client threads: their NextQuestion calls share batched sweeps, their RecordAnswer / StartQuiz /
+ * RecordQuizTarget calls share launches, and a call that finds the engine taken posts its operation to the thread inside instead
+ * of queueing on the lock; default 1, also PQA_COMBINE; "combine_linger_us": how long a leader / a ListTopTargets waits for the
+ * other clients' requests, default 20; read-only "combined_batches", "combined_requests", "combined_max_batch", "update_flushes",
+ * "updates_flushed", "update_max_flush", "posted_ops", "posted_drains", "train_batches", "train_batch_calls"),
+ * "long_row_form" (StartQuiz / RecordAnswer over rows beyond 16384 targets as one workgroup per subtask of the reference's sum
+ * plus a division launch; default 1), "post_always" (test hook: the posted form of the quiz-level calls even when the engine is free),
  * "eval_max_grid" (test hook: cap the workgroups of a sweep so that each streams many questions; 0 = no cap).
  * "batch_min" (PqaEngine_NextQuestionArgmaxBatch: batches of at least this many quizzes take the row-sharing sweep, which
  * reads the cube once per batch; default 0 = decided by how many waves the batch gives that sweep; Float engines always take it), "batch_tile" (targets per LDS tile of that sweep, 0 = default).
