@@ -330,9 +330,11 @@ def main():
         eng.set_option("select", 1)
         quiz_loop = {"questions_per_sec": asked / dtq, "quizzes": n_q, "questions": asked, "guessed_on_top": hits,
                      "published_reference_questions_per_sec": 301.2,
-                     "selection_path": "one launch per selection, made by StartQuiz / RecordAnswer ahead of the NextQuestion that follows (option speculate); "
+                     "selection_path": "one launch per selection, made by StartQuiz / RecordAnswer ahead of the NextQuestion that follows (option speculate) -- "
+                                       "RecordAnswer's posterior update runs inside that launch (option fuse_update); "
                                        "every workgroup hands its priorities to the host, the reference's selector runs there",
-                     "speculative_sweeps": {"used": int(eng.get_option("spec_hits")), "dropped": int(eng.get_option("spec_dropped"))},
+                     "speculative_sweeps": {"used": int(eng.get_option("spec_hits")), "dropped": int(eng.get_option("spec_dropped")),
+                                            "with_the_posterior_update_inside": int(eng.get_option("fused_updates"))},
                      "note": "reference figure: PqaClient learner loop on the author's 2017 desktop CPU (BASELINE.md); "
                              "here: Python wrapper of the C ABI, one quiz at a time, sampled selector"}
 
