@@ -994,12 +994,16 @@ def pmc_traffic(config, world):
         return None
 
 
+KERNEL_HEADERS = ("pqa_device.h", "eval_device.h", "prior_device.h", "pqa_kernels.h")   # (what the kernels include; hip_engine.h is the host's)
+
+
 def kernel_sources_sha16():
     """sha256 (first 16 hex digits) of the kernel sources, as tools/prof.sh records it beside the counters it collects."""
     import hashlib
 
     d = os.path.join(ROOT, "probqa_amd", "csrc")
-    return hashlib.sha256(b"".join(open(os.path.join(d, f), "rb").read() for f in sorted(os.listdir(d)) if f.endswith((".hip", ".h")))).hexdigest()[:16]
+    return hashlib.sha256(b"".join(open(os.path.join(d, f), "rb").read() for f in sorted(os.listdir(d))
+                                   if f.endswith(".hip") or f in KERNEL_HEADERS)).hexdigest()[:16]
 
 
 def pmc_is_stale(config):

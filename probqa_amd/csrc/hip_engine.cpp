@@ -1742,6 +1742,7 @@ void HipEngine::DrainPosted() {
     op->err = CheckRegular("list top targets");
     if (!op->err.ok()) continue;
     op->quiz = UseQuiz(op->err, op->iQuiz);
+    if (op->quiz != nullptr) op->serial = op->quiz->serial;
     if (op->quiz != nullptr && op->quiz->updatePending) needFlush = true;
   }
   Error flushErr;
@@ -1787,7 +1788,10 @@ void HipEngine::DrainPosted() {
     if (op->kind == 2 && op->quiz != nullptr) {
       Quiz *q = op->quiz;
       const int64_t want = std::min<int64_t>(op->arg, _T);
-      if (!flushErr.ok()) op->err = flushErr;
+      // (a ReleaseQuiz of the same quiz later in this drain -- a client's error, IPqaEngine.h:44 -- has taken it away since)
+      const bool gone = (size_t)op->iQuiz >= _quizzes.size() || _quizzes[(size_t)op->iQuiz] != q || q->serial != op->serial;
+      if (gone) { op->result = -1; op->err = Error::MakeP(ErrCode::AbsentId, "id=" + std::to_string(op->iQuiz), "Quiz index is not in the registry (but rather at a gap)."); }
+      else if (!flushErr.ok()) op->err = flushErr;
       else if (want > kQuizTop || _T > 16384) op->result = -2;
       else {
         _topWantRecent = want >= _topWantRecent ? want : want + (_topWantRecent - want) * 7 / 8;

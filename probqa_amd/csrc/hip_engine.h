@@ -424,6 +424,7 @@ class HipEngine : public IEngine {
     QuizPinned *pin = nullptr;
     uint64_t flagOp = 0;
     Quiz *quiz = nullptr;              // (the drain's own, between its two passes)
+    uint64_t serial = 0;
     BatchCtx *ctx = nullptr;
     std::vector<SelRequest *> *batch = nullptr;
     Flight *flight = nullptr;

@@ -307,6 +307,8 @@ class PqaError:
 
 
 def _check(c_err, throw: bool = True) -> Optional[PqaError]:
+    if not c_err:       # (the common case of every call: nothing to wrap)
+        return None
     err = PqaError.factor(c_err)
     if err and throw:
         raise PqaException(err.to_string(True))
@@ -436,7 +438,10 @@ class PqaEngine:
         arr = (CiRatedTarget * max(max_count, 1))()
         c_err = ctypes.c_void_p()
         n = _lib.PqaEngine_ListTopTargets(self.c_engine, ctypes.byref(c_err), i_quiz, max_count, arr)
-        _check(c_err.value)
+        if c_err.value:
+            _check(c_err.value)
+        if n == 1:      # (the learner loop's ListTopTargets(1))
+            return [RatedTarget(arr[0].iTarget, arr[0].prob)]
         return [RatedTarget(arr[i].iTarget, arr[i].prob) for i in range(n)]
 
     def record_quiz_target(self, i_quiz: int, i_target: int, amount: float = 1.0, throw: bool = True):

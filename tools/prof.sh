@@ -43,7 +43,7 @@ for d in sorted(glob.glob(out+"/pmc_*/")):
         for k,(n,s) in acc.items():
             print("pmc %-24s per-launch avg of %s: %.6g (n=%d)"%(k,kern,s/n,n)); vals[k]=s/n
 import hashlib
-src=hashlib.sha256(b"".join(open(os.path.join("$PWD","probqa_amd","csrc",f),"rb").read() for f in sorted(os.listdir(os.path.join("$PWD","probqa_amd","csrc"))) if f.endswith((".hip",".h")))).hexdigest()[:16]
+src=hashlib.sha256(b"".join(open(os.path.join("$PWD","probqa_amd","csrc",f),"rb").read() for f in sorted(os.listdir(os.path.join("$PWD","probqa_amd","csrc"))) if f.endswith(".hip") or f in ("pqa_device.h","eval_device.h","prior_device.h","pqa_kernels.h"))).hexdigest()[:16]
 rec={"command": "$CMD", "kernel": kern, "kernel_sources_sha16": src}
 if "FETCH_SIZE" in vals:
     rec.update({"bytes_per_launch": vals["FETCH_SIZE"]*1024*2, "fetch_size_kb_raw": vals["FETCH_SIZE"],
