@@ -107,7 +107,6 @@ __global__ __launch_bounds__(kClusterThreads, 4) void eval_cluster_kernel(Cluste
   V *lhL = reinterpret_cast<V *>(smem + (NumC<R>::kTable ? kLog2TableDoubles : 0));
   double (*red)[NW] = reinterpret_cast<double (*)[NW]>(lhL + (size_t)a.K * a.sliceUnits);
   double *wTot = &red[kMaxK + 2][0];
-  int *votes = reinterpret_cast<int *>(wTot + kMaxK);          // [NW]
   double *xch = wTot + kMaxK + NW / 2;                          // [C][K + 2]: the members' partials of one question
   if constexpr (NumC<R>::kTable) {
     if (!lds_table_at_zero(tbl)) __builtin_trap();            // log2hot addresses the table absolutely
@@ -145,6 +144,9 @@ __global__ __launch_bounds__(kClusterThreads, 4) void eval_cluster_kernel(Cluste
   // The loads are compiler-visible buffer loads with the sc1 bit (past the L2s), not inline assembly: `between` -- the request for
   // the next question's rows -- is issued BEHIND the first round of record loads and the wait for that round leaves the younger
   // row loads in flight (loads return in order: behind the rows, the first poll waited for all of them -- 4 us per question).
+  // Every wave polls for ITS records (thread t: records t and t + 512) until they all carry the tag, then ONE barrier (round 3).
+  // Polling in lock step -- two barriers and a vote of the eight waves per round -- made a round ~2 us and an exchange three
+  // rounds on average (13.5 M vector loads per launch against 7 M of rows in the counters): 6 of a question's 9 us.
   auto gather = [&](const ExRec *recs, int stride, int n, unsigned long long tag, auto &&between) {
     const int total = C * n;                                    // <= 1024 (cluster_shape)
     const RowRsrc rs = row_rsrc(recs, (int64_t)C * stride * (int64_t)sizeof(ExRec));
@@ -173,17 +175,11 @@ __global__ __launch_bounds__(kClusterThreads, 4) void eval_cluster_kernel(Cluste
           if (t == tag) xch[r] = u2d((unsigned long long)x[u][0] | ((unsigned long long)x[u][1] << 32)); else ok = 0;
         }
       }
-      // (not __syncthreads_and: the library's workgroup reduction brings static LDS, and the Log2Hot table must sit at address 0)
-      const int waveOk = __all(ok);
-      __syncthreads();                                          // the previous round's votes have been read
-      if (lane == 0) votes[wave] = waveOk;
-      __syncthreads();
-      int all = 1;
-      for (int w = 0; w < NW; w++) all &= votes[w];
-      if (all) break;
-      __builtin_amdgcn_s_sleep(4);
+      if (__all(ok)) break;                                     // (this wave's records: the other waves wait for theirs)
+      __builtin_amdgcn_s_sleep(1);
       if (++spins > (1u << 26)) __builtin_trap();               // (minutes: a member died -- no silent hang)
     }
+    __syncthreads();
   };
   // sums over the members of the n values of xch[member][n], into out[0 .. n): wave w takes the columns w, w + NW, ...; lane l adds
   // the members l, l + 64, ... and the wave's DPP tree the lanes (one member after the other it is C dependent LDS round trips:
