@@ -186,3 +186,27 @@ def test_update_inside_the_sweeps_launch(dims, workers, select, factory):
     assert a.get_option("fused_updates") == n_steps and b.get_option("fused_updates") == 0
     assert a.get_option("spec_hits") == n_steps
     a.close(); b.close()
+
+
+@pytest.mark.parametrize("dims,workers,why", [((5, 40, 300), 60, "more subtasks than the update's LDS scratch holds"),
+                                              ((5, 30, 1500), 16, "rows beyond the 2-pair shape")],
+                         ids=["60_workers", "1500_targets"])
+def test_update_falls_back_to_its_own_kernel(dims, workers, why, factory):
+    """Where the sweep's launch cannot take the update (eval_kernels.hip: EvalFusesUpdate) RecordAnswer launches the posterior
+    kernel and the sweep behind it, as before: same posteriors and questions as the oracle, nothing counted as fused."""
+    K, Q, T = dims
+    case = cases.Case("nofuse", K, Q, T, seed=T + workers)
+    eng = make(case, factory, 1, 1)
+    eng.set_option("workers", workers)
+    orc = case.make_oracle()
+    qz = eng.start_quiz()
+    orc.start_quiz(workers)
+    for step in range(6):
+        g = eng.next_question(qz)
+        _, opri = orc.eval(SUBTASKS)
+        assert g == orc.select_argmax(opri), step
+        eng.record_answer(qz, step % K)
+        orc.record_answer(g, step % K, max(1, workers - 1))
+    assert np.array_equal(eng.get_priors(qz), orc.priors())
+    assert eng.get_option("fused_updates") == 0 and eng.get_option("spec_hits") == 6, why
+    eng.close()
