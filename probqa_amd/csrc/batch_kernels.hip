@@ -366,6 +366,7 @@ struct MidArgs {
 };
 
 template <int QS> __device__ __forceinline__ double chunk_fold(double v) {   // sum over the lanes of one quiz slot within a wave
+  if constexpr (QS <= 8) v += mov_dpp<0x128>(v);             // row_ror:8 -- the lane eight away in the row of sixteen
   if constexpr (QS <= 16) { const Pair p = swap16(v); v = p.a + p.b; }
   if constexpr (QS <= 32) { const Pair p = swap32(v); v = p.a + p.b; }
   return v;
@@ -779,7 +780,7 @@ hipError_t LaunchEvalMidBatch(const KbView &kb, const QuizSlot *slots, int nSlot
   if (!EvalMidBatchSupported(kb) || nSlots <= 0 || nSlots > 256 || plan == nullptr) return hipErrorInvalidValue;
   const int Bp = ((nSlots + 63) / 64) * 64;
   // quiz slots per wave: as few as hold the batch (more chunks per wave: shorter serial sums), 64 beyond 32 quizzes
-  const int QS = nSlots <= 16 ? 16 : nSlots <= 32 ? 32 : 64;
+  const int QS = nSlots <= 8 ? 8 : nSlots <= 16 ? 16 : nSlots <= 32 ? 32 : 64;
   const int groups = (nSlots + QS - 1) / QS;
   static LaunchCache cache;
   const int devSlot = LaunchCache::Device();
@@ -800,8 +801,8 @@ hipError_t LaunchEvalMidBatch(const KbView &kb, const QuizSlot *slots, int nSlot
   if (PT == nullptr || recs == nullptr) return hipErrorInvalidValue;
   // the instantiation: quiz slots per wave x (five answers exactly | up to eight)
   void (*kern)(MidArgs) = nullptr;
-  if (KM == 5) kern = QS == 16 ? eval_midbatch_kernel<16, 5, true> : QS == 32 ? eval_midbatch_kernel<32, 5, true> : eval_midbatch_kernel<64, 5, true>;
-  else kern = QS == 16 ? eval_midbatch_kernel<16, kMidMaxK, false> : QS == 32 ? eval_midbatch_kernel<32, kMidMaxK, false> : eval_midbatch_kernel<64, kMidMaxK, false>;
+  if (KM == 5) kern = QS == 8 ? eval_midbatch_kernel<8, 5, true> : QS == 16 ? eval_midbatch_kernel<16, 5, true> : QS == 32 ? eval_midbatch_kernel<32, 5, true> : eval_midbatch_kernel<64, 5, true>;
+  else kern = QS == 8 ? eval_midbatch_kernel<8, kMidMaxK, false> : QS == 16 ? eval_midbatch_kernel<16, kMidMaxK, false> : QS == 32 ? eval_midbatch_kernel<32, kMidMaxK, false> : eval_midbatch_kernel<64, kMidMaxK, false>;
   int attr = 0;
   const size_t key = shmem * 1024 + (size_t)QS * 16 + (size_t)KM;
   if (shmem > 64 * 1024 && !cache.Get(devSlot, key, &attr)) {

@@ -1274,9 +1274,10 @@ Error HipEngine::BatchSweep(BatchCtx &c, int64_t n, const int64_t *pQuizzes, std
   bool rowSharing = _elem == 4 || wantPriorities || (_optBatchMin > 0 ? n >= _optBatchMin : (n >= 32 && wavesRowSharing >= 1536));
   // ... and between the two, for a few dozen quizzes over short rows (a server's combined sweeps): a lane is a (quiz, chunk of the
   // row) -- batch_kernels.hip: eval_midbatch_kernel.  Option batch_form: 0 = by these rules, 1 grid.y = quiz, 2 row-sharing, 3 this one.
-  // By the measured costs at 1000 x 5 x 1000 (tools/midbatch_bench.py): grid.y ~11.3 us per quiz + 25; this form 138 / 229 us for up
-  // to 16 / 32 quizzes (its lanes come in 16 or 32 quiz slots) and 6.2 us per slot of 64 beyond: it wins from 11 quizzes on, except 17 and 18.
-  bool mid = EvalMidBatchSupported(View()) && ((_optBatchForm == 0 && !rowSharing && ((n >= 11 && n <= 16) || n >= 19)) || _optBatchForm == 3);
+  // By the measured costs at 1000 x 5 x 1000 (tools/midbatch_bench.py): grid.y ~11.3 us per quiz + 25; this form 87 / 138 / 229 us for up
+  // to 8 / 16 / 32 quizzes (its lanes come in 8, 16 or 32 quiz slots) and 6.2 us per slot of 64 beyond: it wins at 7 and 8 quizzes and from
+  // 11 on, except 17 and 18.
+  bool mid = EvalMidBatchSupported(View()) && ((_optBatchForm == 0 && !rowSharing && (n == 7 || n == 8 || (n >= 11 && n <= 16) || n >= 19)) || _optBatchForm == 3);
   if (_optBatchForm == 1 && _elem == 8 && !wantPriorities) { rowSharing = false; mid = false; }
   if (_optBatchForm == 2) { rowSharing = true; mid = false; }
   if (mid) rowSharing = false;
@@ -1991,11 +1992,13 @@ int64_t HipEngine::SelectFromPriorities(SelRequest *r) {
   return r->result;
 }
 
-// How many of `m` waiting requests a combined sweep should take.  The (quiz, chunk) sweep costs by its quiz slots -- 16, 32 or
-// groups of 64 (tools/midbatch_bench.py at 1000 x 5 x 1000: 107 / 192 / 362 us of kernel) -- so 20 requests cost what 32 do; with
+// How many of `m` waiting requests a combined sweep should take.  The (quiz, chunk) sweep costs by its quiz slots -- 8, 16, 32 or
+// groups of 64 (tools/midbatch_bench.py at 1000 x 5 x 1000: 60 / 107 / 192 / 362 us of kernel) -- so 20 requests cost what 32 do; with
 // the device as the bottleneck of a busy server, a sweep of 16 now and the other 4 with the next one serve more clients per second.
 int64_t HipEngine::PreferredCombinedBatch(int64_t m) const {
   if (_optBatchForm != 0 || _elem != 8 || !EvalMidBatchSupported(View())) return m;
+  if (m <= 8) return m;
+  if (m <= 10) return 8;
   if (m <= 16) return m;
   if (m <= 25) return 16;
   if (m <= 32) return m;

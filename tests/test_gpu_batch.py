@@ -457,7 +457,7 @@ def test_long_row_posterior_kernels_are_bit_identical(T, workers, factory):
 
 @pytest.mark.parametrize("dims", [(37, 5, 101), (300, 5, 1000), (64, 5, 50), (90, 5, 2000), (40, 3, 300), (50, 8, 700), (33, 2, 64)],
                          ids=lambda d: "%dx%dx%d" % d)
-@pytest.mark.parametrize("n_quizzes", [3, 16, 17, 33, 70], ids=lambda n: "%dq" % n)
+@pytest.mark.parametrize("n_quizzes", [3, 8, 16, 17, 33, 70], ids=lambda n: "%dq" % n)
 def test_fp64_midbatch_sweep_against_oracle(dims, n_quizzes, factory):
     """The sweep for a few dozen quizzes (batch_kernels.hip: eval_midbatch_kernel -- a lane is a (quiz, chunk of the row); what the
     engine's combined sweeps for concurrent clients use): every quiz's priorities against the oracle (1e-9) and against the
