@@ -409,3 +409,24 @@ def test_sharded_maintenance_equals_whole_engine(f32, factory, tmp_path):
         both(lambda e: e.record_answer(qs if e is sh else qw, step % K))
     sh.close()
     whole.close()
+
+
+def test_learner_threads_on_a_sharded_engine(factory):
+    """Many client threads on ONE sharded engine (one client at a time inside it: the combining of concurrent calls is the
+    single-device engine's): 24 native learner threads, argmax selector, no training -- the digest of all transcripts equals
+    the one-thread run's and a whole-cube engine's; then with training and the sampled selector it must simply work."""
+    case = cases.Case("shthreads", 5, 120, 400, seed=21, qgaps=[9])
+    with devices("0,0,0"):
+        sh = case.make_engine(factory)
+    whole = case.make_engine(factory)
+    for e in (sh, whole):
+        e.set_option("select", 1)
+    one = interop.run_learners(sh, 1, 48, 8, seed=3, train=False)
+    many = interop.run_learners(sh, 24, 48, 8, seed=3, train=False)
+    ref = interop.run_learners(whole, 1, 48, 8, seed=3, train=False)
+    assert one["errors"] == many["errors"] == ref["errors"] == 0
+    assert (one["questions"], one["transcript_hash"]) == (many["questions"], many["transcript_hash"]) == (ref["questions"], ref["transcript_hash"])
+    sh.set_option("select", 0)
+    trained = interop.run_learners(sh, 24, 96, 12, seed=4, train=True)
+    assert trained["errors"] == 0 and trained["quizzes"] == 96
+    sh.close(); whole.close()
