@@ -149,6 +149,17 @@ PQACORE_API void *PqaHip_GetPriorDevicePtr(void *pvEngine, const int64_t iQuiz, 
  * broadcast into PqaHip_GetPriorDevicePtr's buffer by the caller. */
 PQACORE_API void *PqaHip_RecordAnswerRemote(void *pvEngine, const int64_t iQuiz, const int64_t iAnswer);
 
+/* Host bookkeeping of the engine that needs no device, driven by a small script so that it is testable where there is no GPU.
+   what = "id_ledger": pIn is a sequence of operations on one fresh compact<->permanent id map (reference behaviour:
+   PqaCore/PermanentIdManager.cpp), each {op, a, b}: 0 permanent id of slot a; 1 slot of permanent id a; 2 raise the issue floor
+   to a; 3 vacate slot a; 4 reissue slot a; 5 extend to a slots; 6 rename permanent a to b; 7 repack to a slots, the b = a source
+   slots following inline; 8 write to a temporary file, read back into a second map, continue on that one; 9 the number of slots that hold an id.  One result per
+   operation into pOut (ids, or 0 / 1 for the boolean ones).
+   what = "let_go": pIn = {now, maxCount, maxAgeSec, n, then n x {quiz id, last usage}}; pOut receives the count and then the ids
+   ClearOldQuizzes would release, in release order (reference behaviour: PqaCore/BaseEngine.cpp:814-873).
+   Returns the number of results written, or -1 for a malformed script / too small an output. */
+PQACORE_API int64_t PqaHip_HostLogicProbe(const char *what, const int64_t *pIn, const int64_t nIn, int64_t *pOut, const int64_t nOut);
+
 #ifdef __cplusplus
 }
 #endif

@@ -529,4 +529,57 @@ PQACORE_API void *PqaHip_RecordAnswerRemote(void *pvEngine, const int64_t iQuiz,
   return ReturnErr(pEng->RecordAnswerRemote(iQuiz, iAnswer));
 }
 
+PQACORE_API int64_t PqaHip_HostLogicProbe(const char *what, const int64_t *pIn, const int64_t nIn, int64_t *pOut, const int64_t nOut) {
+  const std::string w(what ? what : "");
+  if (nIn < 0 || nOut < 0 || (nIn > 0 && !pIn) || (nOut > 0 && !pOut)) return -1;
+  if (w == "id_ledger") {
+    pqa::IdLedger ledger;
+    int64_t i = 0, nRes = 0;
+    while (i < nIn) {
+      if (i + 3 > nIn || nRes >= nOut) return -1;
+      const int64_t op = pIn[i], a = pIn[i + 1], b = pIn[i + 2];
+      i += 3;
+      int64_t r;
+      switch (op) {
+        case 0: r = ledger.PermanentOf(a); break;
+        case 1: r = ledger.SlotOf(a); break;
+        case 2: r = ledger.RaiseFloor(a); break;
+        case 3: r = ledger.Vacate(a); break;
+        case 4: r = ledger.Reissue(a); break;
+        case 5: r = ledger.Extend(a); break;
+        case 6: r = ledger.Rename(a, b); break;
+        case 7:
+          if (a < 0 || b != a || i + a > nIn) return -1;
+          r = ledger.Repack(a, pIn + i);
+          i += a;
+          break;
+        case 8: {
+          FILE *f = std::tmpfile();
+          if (!f) return -1;
+          pqa::IdLedger back;
+          r = ledger.Write(f) && std::fseek(f, 0, SEEK_SET) == 0 && back.Read(f);
+          std::fclose(f);
+          if (r) ledger = back;
+          break;
+        }
+        case 9: r = ledger.LiveSlots(); break;
+        default: return -1;
+      }
+      pOut[nRes++] = r;
+    }
+    return nRes;
+  }
+  if (w == "let_go") {
+    if (nIn < 4 || pIn[3] < 0 || nIn != 4 + 2 * pIn[3]) return -1;
+    std::vector<pqa::QuizUsage> inUse;
+    for (int64_t k = 0; k < pIn[3]; k++) inUse.push_back(pqa::QuizUsage{pIn[4 + 2 * k], (time_t)pIn[5 + 2 * k]});
+    const std::vector<int64_t> ids = pqa::QuizzesToLetGo(inUse, (time_t)pIn[0], pIn[1], (double)pIn[2]);
+    if ((int64_t)ids.size() + 1 > nOut) return -1;
+    pOut[0] = (int64_t)ids.size();
+    for (size_t k = 0; k < ids.size(); k++) pOut[1 + k] = ids[k];
+    return (int64_t)ids.size() + 1;
+  }
+  return -1;
+}
+
 }  // extern "C"

@@ -268,8 +268,8 @@ Error HipEngine::Init(const CiEngineDefinition &def, const CiHipShard *shard) {
   if (!e.ok()) return e;
   HIP_TRY(LaunchFillFresh(_dCube, _elem, _dVB, _K, _Q, _T, _ldT, _initAmount, _stream));
   HIP_TRY(hipStreamSynchronize(_stream));
-  _pimQuestions.GrowTo(_Q);  // reference PqaCore/BaseCpuEngine.cpp:24-25
-  _pimTargets.GrowTo(_T);
+  _questionIds.Extend(_Q);  // reference PqaCore/BaseCpuEngine.cpp:24-25
+  _targetIds.Extend(_T);
   std::random_device rd;  // the reference seeds from RDRAND (SRPlatform/Interface/SRFastRandom.h:31-40)
   uint64_t seed = ((uint64_t)rd() << 32) ^ rd();
   _rng[0] = SplitMix64(seed);
@@ -2967,7 +2967,7 @@ Error HipEngine::SetTargetGaps(int64_t n, const int64_t *ids) {
       BitSet(_hTGap, ids[i], true);
       _nTargetGaps++;
       _targetGapList.push_back(ids[i]);
-      _pimTargets.RemoveComp(ids[i]);
+      _targetIds.Vacate(ids[i]);
     }
   hipSetDevice(_device);
   return UploadGaps();
@@ -2981,7 +2981,7 @@ Error HipEngine::SetQuestionGaps(int64_t n, const int64_t *ids) {
     if (ids[i] >= _qFirst && ids[i] < _qFirst + _Q && !BitTest(_hQGap, ids[i] - _qFirst)) {
       BitSet(_hQGap, ids[i] - _qFirst, true);
       _questionGapList.push_back(ids[i] - _qFirst);
-      _pimQuestions.RemoveComp(ids[i] - _qFirst);
+      _questionIds.Vacate(ids[i] - _qFirst);
     }
   hipSetDevice(_device);
   return UploadGaps();

@@ -60,26 +60,47 @@ struct DefaultLogger {
   static void Log(Severity sev, const std::string &message);
 };
 
-// PermanentIdManager (reference PqaCore/PermanentIdManager.{h,cpp}): compact id <-> permanent id, survives compaction
-class PermIdMgr {
+// The two-way map between the dense ("compact") ids the arrays are indexed by and the ids a caller may keep across edits of the
+// knowledge base ("permanent": never reissued).  Behaviour of the reference's PermanentIdManager (PqaCore/PermanentIdManager.h)
+// as its callers and the .kb format see it; the structure is this file's own: the forward table is the array the file stores,
+// the reverse direction is a vector ordered by permanent id -- ids are issued in increasing order, so it grows at its end -- whose
+// entries are only trusted when the forward table agrees (a vacated slot leaves its entry behind; it is swept out when half of
+// the vector is such leftovers).
+class IdLedger {
  public:
-  int64_t PermFromComp(int64_t compId) const;
-  int64_t CompFromPerm(int64_t permId) const;
-  bool Save(FILE *fpout, bool empty = false) const;
-  bool Load(FILE *fpin);
-  bool EnsurePermIdGreater(int64_t bound);
-  bool RemoveComp(int64_t compId);
-  bool RenewComp(int64_t compId);
-  bool GrowTo(int64_t nComp);
-  bool OnCompact(int64_t nNew, const int64_t *pOldIds);
-  bool RemapPermId(int64_t srcPermId, int64_t destPermId);
-  void Clear() { _comp2perm.clear(); _perm2comp.clear(); }
+  static constexpr int64_t kNone = -1;                  // cInvalidPqaId
+  int64_t PermanentOf(int64_t slot) const { return InRange(slot) ? _permOf[(size_t)slot] : kNone; }
+  int64_t SlotOf(int64_t permanent) const;
+  bool Write(FILE *f, bool withoutSlots = false) const; // {next id to issue, slot count, the forward table}: the file's layout
+  bool Read(FILE *f);
+  bool RaiseFloor(int64_t bound);                       // ids issued from now on exceed `bound`; false if they did already
+  bool Vacate(int64_t slot);                            // the slot's permanent id is retired
+  bool Reissue(int64_t slot);                           // a vacated slot gets the next permanent id
+  bool Extend(int64_t nSlots);                          // new slots at the end, each under the next permanent id
+  bool Repack(int64_t nSlots, const int64_t *from);     // slot i takes over what slot from[i] held; nothing else survives
+  bool Rename(int64_t permanent, int64_t toPermanent);  // a live id is re-labelled with an unused id from the past
+  int64_t LiveSlots() const { return _live; }
+  void Clear() { _permOf.clear(); _byPerm.clear(); _live = 0; }
 
  private:
-  int64_t _nextPermId = 0;
-  std::vector<int64_t> _comp2perm;
-  std::unordered_map<int64_t, int64_t> _perm2comp;
+  struct Back { int64_t permanent, slot; };
+  bool InRange(int64_t slot) const { return slot >= 0 && slot < (int64_t)_permOf.size(); }
+  bool Live(const Back &b) const { return _permOf[(size_t)b.slot] == b.permanent; }
+  size_t LowerBound(int64_t permanent) const;
+  void Enter(int64_t permanent, int64_t slot);
+  void Rebuild();
+  int64_t _issueNext = 0;
+  int64_t _live = 0;                 // slots that hold a permanent id
+  std::vector<int64_t> _permOf;      // slot -> permanent id, kNone for a vacated slot
+  std::vector<Back> _byPerm;         // ascending by permanent id; at most one entry per id
 };
+
+// Which quizzes a ClearOldQuizzes(maxCount, maxAgeSec) call lets go (behaviour of BaseEngine::ClearOldQuizzes): every quiz
+// unused for longer than maxAgeSec, then the longest-unused of the rest until maxCount remain.  `quizzes` in registry order;
+// the result in the order they are to be released (it decides which registry slots the next quizzes reuse first): the aged-out
+// ones in registry order, then by age, the longest-unused first, equal ages by registry order.
+struct QuizUsage { int64_t id; time_t lastUsage; };
+std::vector<int64_t> QuizzesToLetGo(const std::vector<QuizUsage> &quizzes, time_t now, int64_t maxCount, double maxAgeSec);
 
 // A quiz's own lines of host-coherent pinned memory: what the kernels working for ONE quiz hand to the host without a copy --
 // the posterior's best targets (listed by RecordAnswer's kernel ahead of the ListTopTargets that follows it) and their flag.
@@ -253,9 +274,9 @@ class HipEngine : public IEngine {
     for (int64_t q : _questionGapList) questionsGlobal.push_back(q + _qFirst);
     targets = _targetGapList;
   }
-  const PermIdMgr &TargetPim() const { return _pimTargets; }
-  void SetTargetPim(const PermIdMgr &p) { _pimTargets = p; }
-  void SetQuizPim(const PermIdMgr &p) { _pimQuizzes = p; }
+  const IdLedger &TargetIds() const { return _targetIds; }
+  void SetTargetIds(const IdLedger &l) { _targetIds = l; }
+  void SetQuizIds(const IdLedger &l) { _quizIds = l; }
   void SetQuestionsAsked(uint64_t n) { _nQuestionsAsked.store(n); }
   uint8_t PrecisionType() const { return _precType; }
   uint32_t PrecMantissa() const { return _precMantissa; }
@@ -276,7 +297,7 @@ class HipEngine : public IEngine {
   // ... and initialises added target columns and questions as CpuEngine::AddQsTsSpec does (CpuEngine.cpp:497-567)
   Error ApplyFills(const std::vector<int64_t> &tIds, const std::vector<double> &tInit, const std::vector<int64_t> &qLocalIds,
                    const std::vector<double> &qInit);
-  const PermIdMgr &QuizPim() const { return _pimQuizzes; }
+  const IdLedger &QuizIds() const { return _quizIds; }
 
  private:
   HipEngine() = default;
@@ -518,7 +539,7 @@ class HipEngine : public IEngine {
   int64_t _nTargetGaps = 0;
   int64_t _capQ = 0;                        // questions the device buffers are allocated for (>= _Q)
   std::vector<int64_t> _questionGapList, _targetGapList;  // LIFO, like reference PqaCore/GapTracker.h
-  PermIdMgr _pimQuestions, _pimTargets, _pimQuizzes;
+  IdLedger _questionIds, _targetIds, _quizIds;
   uint32_t _precMantissa = 0;
   uint16_t _precExponent = 0;
   std::vector<Quiz *> _quizzes;

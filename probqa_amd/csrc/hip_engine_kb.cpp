@@ -60,91 +60,137 @@ hipError_t Upload(T **dst, const std::vector<T> &src, hipStream_t stream) {
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------------------------
-// PermIdMgr == PermanentIdManager (reference PqaCore/PermanentIdManager.cpp)
+// IdLedger: compact slot <-> permanent id (hip_engine.h).  What callers and files observe follows the reference's
+// PermanentIdManager; see the class comment for the structure.
 // ------------------------------------------------------------------------------------------------------------------
-int64_t PermIdMgr::PermFromComp(int64_t compId) const {
-  if (compId < 0 || compId >= (int64_t)_comp2perm.size()) return -1;
-  return _comp2perm[compId];
+size_t IdLedger::LowerBound(int64_t permanent) const {
+  size_t lo = 0, hi = _byPerm.size();
+  while (lo < hi) {
+    const size_t mid = lo + (hi - lo) / 2;
+    if (_byPerm[mid].permanent < permanent) lo = mid + 1; else hi = mid;
+  }
+  return lo;
 }
-int64_t PermIdMgr::CompFromPerm(int64_t permId) const {
-  auto it = _perm2comp.find(permId);
-  return it == _perm2comp.end() ? -1 : it->second;
+
+int64_t IdLedger::SlotOf(int64_t permanent) const {
+  const size_t at = LowerBound(permanent);
+  if (at == _byPerm.size() || _byPerm[at].permanent != permanent || !Live(_byPerm[at])) return kNone;
+  return _byPerm[at].slot;
 }
-bool PermIdMgr::Save(FILE *fpout, bool empty) const {  // :26-38
-  const int64_t nComp = empty ? 0 : (int64_t)_comp2perm.size();
-  if (std::fwrite(&_nextPermId, sizeof(_nextPermId), 1, fpout) != 1) return false;
-  if (std::fwrite(&nComp, sizeof(nComp), 1, fpout) != 1) return false;
-  return (int64_t)std::fwrite(_comp2perm.data(), sizeof(int64_t), (size_t)nComp, fpout) == nComp;
+
+// Records that `slot` now carries `permanent` (the forward table is already written).  A leftover entry of the same id -- its
+// slot was vacated earlier -- is taken over; otherwise the entry goes where the order puts it, which for a freshly issued id is
+// the end.
+void IdLedger::Enter(int64_t permanent, int64_t slot) {
+  if (_byPerm.empty() || _byPerm.back().permanent < permanent) { _byPerm.push_back(Back{permanent, slot}); return; }
+  const size_t at = LowerBound(permanent);
+  if (at < _byPerm.size() && _byPerm[at].permanent == permanent) _byPerm[at].slot = slot;
+  else _byPerm.insert(_byPerm.begin() + (ptrdiff_t)at, Back{permanent, slot});
 }
-bool PermIdMgr::Load(FILE *fpin) {  // :40-60
-  int64_t nComp;
-  if (std::fread(&_nextPermId, sizeof(_nextPermId), 1, fpin) != 1) return false;
-  if (std::fread(&nComp, sizeof(nComp), 1, fpin) != 1 || nComp < 0) return false;
-  _comp2perm.resize((size_t)nComp);
-  _perm2comp.clear();
-  if ((int64_t)std::fread(_comp2perm.data(), sizeof(int64_t), (size_t)nComp, fpin) != nComp) return false;
-  for (int64_t i = 0; i < nComp; i++)
-    if (_comp2perm[i] != -1) _perm2comp.emplace(_comp2perm[i], i);
+
+void IdLedger::Rebuild() {
+  _byPerm.clear();
+  _live = 0;
+  for (int64_t slot = 0; slot < (int64_t)_permOf.size(); slot++)
+    if (_permOf[(size_t)slot] != kNone) { _byPerm.push_back(Back{_permOf[(size_t)slot], slot}); _live++; }
+  std::sort(_byPerm.begin(), _byPerm.end(), [](const Back &x, const Back &y) { return x.permanent < y.permanent; });
+}
+
+bool IdLedger::Write(FILE *f, bool withoutSlots) const {
+  const int64_t header[2] = {_issueNext, withoutSlots ? 0 : (int64_t)_permOf.size()};
+  if (std::fwrite(header, sizeof(header), 1, f) != 1) return false;
+  return header[1] == 0 || std::fwrite(_permOf.data(), sizeof(int64_t), (size_t)header[1], f) == (size_t)header[1];
+}
+
+bool IdLedger::Read(FILE *f) {
+  int64_t header[2];
+  if (std::fread(header, sizeof(header), 1, f) != 1 || header[1] < 0) return false;
+  std::vector<int64_t> table((size_t)header[1]);
+  if (header[1] > 0 && std::fread(table.data(), sizeof(int64_t), table.size(), f) != table.size()) return false;
+  _issueNext = header[0];
+  _permOf.swap(table);
+  Rebuild();
   return true;
 }
-bool PermIdMgr::EnsurePermIdGreater(int64_t bound) {
-  if (_nextPermId <= bound) { _nextPermId = bound + 1; return true; }
-  return false;
-}
-bool PermIdMgr::RemoveComp(int64_t compId) {
-  if (compId < 0 || compId >= (int64_t)_comp2perm.size()) return false;
-  const int64_t iPerm = _comp2perm[compId];
-  if (iPerm == -1) return false;
-  auto it = _perm2comp.find(iPerm);
-  if (it == _perm2comp.end()) return false;
-  _perm2comp.erase(it);
-  _comp2perm[compId] = -1;
+
+bool IdLedger::RaiseFloor(int64_t bound) {
+  if (bound < _issueNext) return false;
+  _issueNext = bound + 1;
   return true;
 }
-bool PermIdMgr::RenewComp(int64_t compId) {
-  if (compId < 0 || compId >= (int64_t)_comp2perm.size() || _comp2perm[compId] != -1) return false;
-  _comp2perm[compId] = _nextPermId;
-  _perm2comp.emplace(_nextPermId, compId);
-  _nextPermId++;
-  return true;
-}
-bool PermIdMgr::GrowTo(int64_t nComp) {
-  if (nComp < (int64_t)_comp2perm.size()) return false;
-  for (int64_t i = (int64_t)_comp2perm.size(); i < nComp; i++) {
-    _comp2perm.push_back(_nextPermId);
-    _perm2comp.emplace(_nextPermId, i);
-    _nextPermId++;
+
+bool IdLedger::Vacate(int64_t slot) {
+  if (!InRange(slot) || _permOf[(size_t)slot] == kNone) return false;
+  _permOf[(size_t)slot] = kNone;     // its entry in _byPerm no longer agrees with the table: a leftover from here on
+  _live--;
+  if (_byPerm.size() > 64 && (int64_t)_byPerm.size() > 2 * _live) {
+    size_t kept = 0;
+    for (const Back &b : _byPerm) if (Live(b)) _byPerm[kept++] = b;
+    _byPerm.resize(kept);
   }
   return true;
 }
-bool PermIdMgr::OnCompact(int64_t nNew, const int64_t *pOldIds) {  // :125-169
-  if (nNew > (int64_t)_comp2perm.size() || nNew != (int64_t)_perm2comp.size()) return false;
-  for (int64_t i = 0; i < nNew; i++) {
-    const int64_t oldComp = pOldIds[i];
-    if (oldComp < 0 || oldComp >= (int64_t)_comp2perm.size()) return false;
-    const int64_t oldPerm = _comp2perm[oldComp];
-    if (oldPerm == -1) return false;
-    auto it = _perm2comp.find(oldPerm);
-    if (it == _perm2comp.end()) return false;
-    it->second = i;
-  }
-  _comp2perm.assign((size_t)nNew, -1);
-  for (const auto &m : _perm2comp) {
-    if (m.second < 0 || m.second >= nNew) return false;
-    _comp2perm[m.second] = m.first;
+
+bool IdLedger::Reissue(int64_t slot) {
+  if (!InRange(slot) || _permOf[(size_t)slot] != kNone) return false;   // (a slot that still holds an id is vacated first)
+  _permOf[(size_t)slot] = _issueNext;
+  Enter(_issueNext++, slot);
+  _live++;
+  return true;
+}
+
+bool IdLedger::Extend(int64_t nSlots) {
+  if (nSlots < (int64_t)_permOf.size()) return false;
+  _permOf.reserve((size_t)nSlots);
+  while ((int64_t)_permOf.size() < nSlots) {
+    Enter(_issueNext, (int64_t)_permOf.size());
+    _permOf.push_back(_issueNext++);
+    _live++;
   }
   return true;
 }
-bool PermIdMgr::RemapPermId(int64_t srcPermId, int64_t destPermId) {  // :171-190
-  if (destPermId >= _nextPermId) return false;
-  if (_perm2comp.find(destPermId) != _perm2comp.end()) return false;
-  auto it = _perm2comp.find(srcPermId);
-  if (it == _perm2comp.end()) return false;
-  const int64_t comp = it->second;
-  _perm2comp.erase(it);
-  _perm2comp.emplace(destPermId, comp);
-  _comp2perm[comp] = destPermId;
+
+// Compaction: the nSlots live slots move to 0 .. nSlots-1, slot i taking the permanent id slot from[i] held.  Checked as a whole
+// before anything changes: exactly the live slots, each once.
+bool IdLedger::Repack(int64_t nSlots, const int64_t *from) {
+  if (nSlots != _live || nSlots > (int64_t)_permOf.size()) return false;
+  std::vector<int64_t> packed((size_t)nSlots);
+  std::vector<bool> taken(_permOf.size(), false);
+  for (int64_t i = 0; i < nSlots; i++) {
+    const int64_t src = from[i];
+    if (!InRange(src) || _permOf[(size_t)src] == kNone || taken[(size_t)src]) return false;
+    taken[(size_t)src] = true;
+    packed[(size_t)i] = _permOf[(size_t)src];
+  }
+  _permOf.swap(packed);
+  Rebuild();
   return true;
+}
+
+bool IdLedger::Rename(int64_t permanent, int64_t toPermanent) {
+  if (toPermanent < 0 || toPermanent >= _issueNext) return false;   // only ids that can no longer be issued (the reference lets the
+                                                                    // invalid id -1 through and corrupts its maps with it: refused here)
+  if (SlotOf(toPermanent) != kNone) return false;       // in use
+  const int64_t slot = SlotOf(permanent);
+  if (slot == kNone) return false;
+  _permOf[(size_t)slot] = toPermanent;                  // the old id's entry becomes a leftover
+  Enter(toPermanent, slot);
+  return true;
+}
+
+std::vector<int64_t> QuizzesToLetGo(const std::vector<QuizUsage> &quizzes, time_t now, int64_t maxCount, double maxAgeSec) {
+  std::vector<int64_t> out;
+  std::vector<QuizUsage> rest;
+  for (const QuizUsage &u : quizzes) {
+    if (difftime(now, u.lastUsage) > maxAgeSec) out.push_back(u.id); else rest.push_back(u);
+  }
+  if ((int64_t)rest.size() > maxCount) {
+    const size_t surplus = rest.size() - (size_t)maxCount;
+    // (stable: equal usage times -- the clock has one-second resolution -- stay in registry order)
+    std::stable_sort(rest.begin(), rest.end(), [](const QuizUsage &x, const QuizUsage &y) { return x.lastUsage < y.lastUsage; });
+    for (size_t i = 0; i < surplus; i++) out.push_back(rest[i].id);
+  }
+  return out;
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -153,19 +199,19 @@ bool PermIdMgr::RemapPermId(int64_t srcPermId, int64_t destPermId) {  // :171-19
 bool HipEngine::MapIds(int which, bool toPerm, int64_t count, int64_t *pIds) {
   std::lock_guard<EngineMutex> lk(_mu);
   StopServer();
-  PermIdMgr &pim = which == 0 ? _pimQuestions : which == 1 ? _pimTargets : _pimQuizzes;
-  for (int64_t i = 0; i < count; i++) pIds[i] = toPerm ? pim.PermFromComp(pIds[i]) : pim.CompFromPerm(pIds[i]);
+  IdLedger &ids = which == 0 ? _questionIds : which == 1 ? _targetIds : _quizIds;
+  for (int64_t i = 0; i < count; i++) pIds[i] = toPerm ? ids.PermanentOf(pIds[i]) : ids.SlotOf(pIds[i]);
   return true;
 }
 bool HipEngine::EnsurePermQuizGreater(int64_t bound) {
   std::lock_guard<EngineMutex> lk(_mu);
   StopServer();
-  return _pimQuizzes.EnsurePermIdGreater(bound);
+  return _quizIds.RaiseFloor(bound);
 }
 bool HipEngine::RemapQuizPermId(int64_t srcPermId, int64_t destPermId) {
   std::lock_guard<EngineMutex> lk(_mu);
   StopServer();
-  return _pimQuizzes.RemapPermId(srcPermId, destPermId);
+  return _quizIds.Rename(srcPermId, destPermId);
 }
 
 int64_t HipEngine::AssignQuiz(Quiz *q) {
@@ -173,11 +219,11 @@ int64_t HipEngine::AssignQuiz(Quiz *q) {
   if (!_quizGaps.empty()) {
     id = _quizGaps.back();
     _quizGaps.pop_back();
-    _pimQuizzes.RenewComp(id);
+    _quizIds.Reissue(id);
   } else {
     id = (int64_t)_quizzes.size();
     _quizzes.push_back(nullptr);
-    _pimQuizzes.GrowTo((int64_t)_quizzes.size());
+    _quizIds.Extend((int64_t)_quizzes.size());
   }
   _quizzes[(size_t)id] = q;
   return id;
@@ -186,10 +232,10 @@ int64_t HipEngine::AssignQuiz(Quiz *q) {
 void HipEngine::UnassignQuiz(int64_t iQuiz) {
   _quizzes[(size_t)iQuiz] = nullptr;
   _quizGaps.push_back(iQuiz);
-  _pimQuizzes.RemoveComp(iQuiz);
+  _quizIds.Vacate(iQuiz);
 }
 
-Error HipEngine::ClearOldQuizzes(int64_t maxCount, double maxAgeSec) {  // BaseEngine.cpp:814-873
+Error HipEngine::ClearOldQuizzes(int64_t maxCount, double maxAgeSec) {  // behaviour: BaseEngine.cpp:814-873
   if (maxCount < 0)
     return Error::MakeP(ErrCode::NegativeCount, "count=" + std::to_string(maxCount),
                         "The number of quizzes to keep cannot be less than 0.");
@@ -198,25 +244,13 @@ Error HipEngine::ClearOldQuizzes(int64_t maxCount, double maxAgeSec) {  // BaseE
   if (_mode != Mode::Regular) return Error();  // quizzes are not expected to exist in maintenance / shutdown mode
   hipSetDevice(_device);
   hipStreamSynchronize(_stream);
-  struct QuizAge { int64_t iQuiz; double ageSec; bool operator<(const QuizAge &o) const { return ageSec < o.ageSec; } };
-  std::vector<QuizAge> ages;
-  const time_t callTime = time(nullptr);
-  for (int64_t i = 0; i < (int64_t)_quizzes.size(); i++) {
-    Quiz *q = _quizzes[(size_t)i];
-    if (!q) continue;
-    const double ageSec = difftime(callTime, q->lastUsage);
-    if (ageSec > maxAgeSec) { UnassignQuiz(i); DestroyQuiz(q); continue; }
-    ages.push_back(QuizAge{i, ageSec});
-  }
-  if ((int64_t)ages.size() > maxCount) {
-    std::make_heap(ages.begin(), ages.end());
-    while ((int64_t)ages.size() > maxCount) {  // the oldest quiz sits at the heap's top
-      Quiz *q = _quizzes[(size_t)ages.front().iQuiz];
-      UnassignQuiz(ages.front().iQuiz);
-      DestroyQuiz(q);
-      std::pop_heap(ages.begin(), ages.end());
-      ages.pop_back();
-    }
+  std::vector<QuizUsage> inUse;
+  for (size_t slot = 0; slot < _quizzes.size(); slot++)
+    if (_quizzes[slot]) inUse.push_back(QuizUsage{(int64_t)slot, _quizzes[slot]->lastUsage});
+  for (int64_t id : QuizzesToLetGo(inUse, time(nullptr), maxCount, maxAgeSec)) {
+    Quiz *q = _quizzes[(size_t)id];
+    UnassignQuiz(id);
+    DestroyQuiz(q);
   }
   return Error();
 }
@@ -313,9 +347,9 @@ Error HipEngine::SaveKB(const char *filePath, bool doubleBuffer) {
   };
   if (!writeGaps(_questionGapList)) return FileErr(filePath, "Can't write the question gaps.");
   if (!writeGaps(_targetGapList)) return FileErr(filePath, "Can't write the target gaps.");
-  if (!_pimQuestions.Save(fc.f)) return FileErr(filePath, "Can't write the question permanent-compact ID mappings.");
-  if (!_pimTargets.Save(fc.f)) return FileErr(filePath, "Can't write the target permanent-compact ID mappings.");
-  if (!_pimQuizzes.Save(fc.f, true)) return FileErr(filePath, "Can't write the quiz permanent-compact ID mappings.");
+  if (!_questionIds.Write(fc.f)) return FileErr(filePath, "Can't write the question permanent-compact ID mappings.");
+  if (!_targetIds.Write(fc.f)) return FileErr(filePath, "Can't write the target permanent-compact ID mappings.");
+  if (!_quizIds.Write(fc.f, true)) return FileErr(filePath, "Can't write the quiz permanent-compact ID mappings.");
   if (std::fflush(fc.f) != 0) return FileErr(filePath, "Failed in hard flushing the KB.");
   FILE *f = fc.f;
   fc.f = nullptr;
@@ -365,9 +399,9 @@ HipEngine *HipEngine::Load(Error &err, const char *filePath) {  // PqaEngineBase
   for (int64_t g : e._questionGapList) BitSet(e._hQGap, g, true);
   for (int64_t g : e._targetGapList) BitSet(e._hTGap, g, true);
   e._nTargetGaps = (int64_t)e._targetGapList.size();
-  if (!e._pimQuestions.Load(fc.f)) return fail(FileErr(filePath, "Can't read the question permanent-compact ID mapping."));
-  if (!e._pimTargets.Load(fc.f)) return fail(FileErr(filePath, "Can't read the target permanent-compact ID mapping."));
-  if (!e._pimQuizzes.Load(fc.f)) return fail(FileErr(filePath, "Can't read the quizzes permanent-compact ID mapping."));
+  if (!e._questionIds.Read(fc.f)) return fail(FileErr(filePath, "Can't read the question permanent-compact ID mapping."));
+  if (!e._targetIds.Read(fc.f)) return fail(FileErr(filePath, "Can't read the target permanent-compact ID mapping."));
+  if (!e._quizIds.Read(fc.f)) return fail(FileErr(filePath, "Can't read the quizzes permanent-compact ID mapping."));
   Error ue = e.UploadGaps();
   if (!ue.ok()) return fail(std::move(ue));
   err = Error();
@@ -486,8 +520,8 @@ Error HipEngine::AddQsTs(int64_t nQuestions, CiAddQorTParam *pAqps, int64_t nTar
   if (he == hipSuccess && nQuestions > 0) he = LaunchFillQuestions(_dCube, _elem, _K, _T, _ldT, dQ.p, dQi.p, nQuestions, _stream);
   if (he == hipSuccess) he = hipStreamSynchronize(_stream);
   if (he != hipSuccess) {   // (a failed launch: the device is gone) keep the id maps the size of the grown KB
-    _pimQuestions.GrowTo(_Q);
-    _pimTargets.GrowTo(_T);
+    _questionIds.Extend(_Q);
+    _targetIds.Extend(_T);
     return HipErr(he, "AddQsTs");
   }
   // ---- commit
@@ -495,17 +529,17 @@ Error HipEngine::AddQsTs(int64_t nQuestions, CiAddQorTParam *pAqps, int64_t nTar
     const int64_t curQ = qIds[(size_t)i];
     _questionGapList.pop_back();
     BitSet(_hQGap, curQ, false);
-    _pimQuestions.RenewComp(curQ);
+    _questionIds.Reissue(curQ);
   }
   for (int64_t i = 0; i < nTReuse; i++) {
     const int64_t curT = tIds[(size_t)i];
     _targetGapList.pop_back();
     BitSet(_hTGap, curT, false);
     _nTargetGaps--;
-    _pimTargets.RenewComp(curT);
+    _targetIds.Reissue(curT);
   }
-  _pimQuestions.GrowTo(_Q);                           // :541-542
-  _pimTargets.GrowTo(_T);
+  _questionIds.Extend(_Q);                           // :541-542
+  _targetIds.Extend(_T);
   for (int64_t i = 0; i < nQuestions; i++) pAqps[i]._index = qIds[(size_t)i];
   for (int64_t j = 0; j < nTargets; j++) pAtps[j]._index = tIds[(size_t)j];
   return UploadGaps();
@@ -570,7 +604,7 @@ Error HipEngine::RemoveQuestions(int64_t n, const int64_t *pQIds) {  // BaseEngi
     const int64_t iq = pQIds[i];
     BitSet(_hQGap, iq, true);
     _questionGapList.push_back(iq);
-    _pimQuestions.RemoveComp(iq);
+    _questionIds.Vacate(iq);
   }
   hipSetDevice(_device);
   return UploadGaps();
@@ -594,7 +628,7 @@ Error HipEngine::RemoveTargets(int64_t n, const int64_t *pTIds) {  // BaseEngine
     BitSet(_hTGap, it, true);
     _targetGapList.push_back(it);
     _nTargetGaps++;
-    _pimTargets.RemoveComp(it);
+    _targetIds.Vacate(it);
   }
   hipSetDevice(_device);
   return UploadGaps();
@@ -640,8 +674,8 @@ Error HipEngine::Compact(int64_t *pnQuestions, const int64_t **ppOldQuestions, i
   if (he == hipSuccess) he = hipStreamSynchronize(_stream);
   hipFree(dMoves);
   if (he != hipSuccess) { std::free(oldQ); std::free(oldT); return HipErr(he, "Compact"); }
-  _pimQuestions.OnCompact(nQ, oldQ);
-  _pimTargets.OnCompact(nT, oldT);
+  _questionIds.Repack(nQ, oldQ);
+  _targetIds.Repack(nT, oldT);
   _questionGapList.clear();
   _targetGapList.clear();
   _nTargetGaps = 0;

@@ -22,7 +22,8 @@
 //   SaveKB / LoadCpuEngine the file orders its rows by question: every shard streams its own block (same byte layout as a whole-cube
 //                          engine's file: a KB saved sharded loads unsharded and vice versa).
 // Where the rows are: peer access is enabled between all listed devices at creation; several shards on one device (tests on a
-// single GPU) need none.  Not sharded (NotImplemented on this engine): maintenance-mode edits of the dimensions.
+// single GPU) need none.  Maintenance-mode edits of the dimensions rebuild the shards (Rebuild below).  Not sharded (NotImplemented on
+// this engine): SetStream and the stream-ordered single-shard entry points.
 #include <algorithm>
 #include <atomic>
 #include <chrono>
@@ -120,17 +121,25 @@ class ShardedEngine final : public IEngine {
     for (auto &s : _sh) { Error e = s->ReleaseQuiz(iQuiz); if (!e.ok() && first.ok()) first = e; }
     return first;
   }
-  Error StartMaintenance(bool force) override { return All([&](HipEngine &e) { return e.StartMaintenance(force); }); }
+  // A forced switch destroys the shards' quizzes (BaseEngine.cpp:650-668), a shutdown likewise: what this engine keeps per quiz goes too
+  // -- a stale usage time would make ClearOldQuizzes release an id no shard has, a stale owner would serve a later quiz of that id.
+  Error StartMaintenance(bool force) override {
+    Error e = All([&](HipEngine &sh) { return sh.StartMaintenance(force); });
+    if (e.ok() && force) ForgetQuizzes();
+    return e;
+  }
   Error FinishMaintenance() override { return All([&](HipEngine &e) { return e.FinishMaintenance(); }); }
   Error Shutdown(const char *saveFilePath) override {
     if (saveFilePath && *saveFilePath) { Error e = SaveKB(saveFilePath, false); if (!e.ok()) return e; }   // BaseEngine.cpp:270-300
-    return All([&](HipEngine &e) { return e.Shutdown(nullptr); });
+    Error e = All([&](HipEngine &sh) { return sh.Shutdown(nullptr); });
+    if (e.ok()) ForgetQuizzes();
+    return e;
   }
   bool MapIds(int which, bool toPerm, int64_t count, int64_t *pIds) override {
     if (which == 0) {   // questions: the global compact <-> permanent map lives here (the shards' own maps are over local ids)
       bool ok = true;
       for (int64_t i = 0; i < count; i++) {
-        pIds[i] = toPerm ? _pimQuestions.PermFromComp(pIds[i]) : _pimQuestions.CompFromPerm(pIds[i]);
+        pIds[i] = toPerm ? _questionIds.PermanentOf(pIds[i]) : _questionIds.SlotOf(pIds[i]);
         ok = ok && pIds[i] != -1;
       }
       return ok;
@@ -187,7 +196,7 @@ class ShardedEngine final : public IEngine {
     Error e = All([&](HipEngine &eng) { return eng.SetQuestionGaps(n, ids); });
     if (e.ok())
       for (int64_t i = 0; i < n; i++)
-        if (std::find(_qGapList.begin(), _qGapList.end(), ids[i]) == _qGapList.end()) { _qGapList.push_back(ids[i]); _pimQuestions.RemoveComp(ids[i]); }
+        if (std::find(_qGapList.begin(), _qGapList.end(), ids[i]) == _qGapList.end()) { _qGapList.push_back(ids[i]); _questionIds.Vacate(ids[i]); }
     return e;
   }
   Error EvalPriorities(int64_t iQuiz, double *pOut, int64_t n) override {
@@ -284,7 +293,7 @@ class ShardedEngine final : public IEngine {
   std::vector<hipEvent_t> _copyDone;         // per shard: recorded behind its copy of another shard's posterior
   std::unordered_map<int64_t, int> _lastOwner;   // quiz -> the shard whose RecordAnswer kernel ran last (it listed the top targets)
   std::vector<double> _hostPriority;
-  PermIdMgr _pimQuestions;                   // global question ids
+  IdLedger _questionIds;                   // global question ids
   uint64_t _rng[2] = {0x9E3779B97F4A7C15ULL, 0xBF58476D1CE4E5B9ULL};
   void Seed(uint64_t x) {   // SplitMix64 into the two words of the generator, as HipEngine does
     auto next = [&x] {
@@ -305,7 +314,7 @@ class ShardedEngine final : public IEngine {
   std::vector<int64_t> _qGapList;           // global question gaps, LIFO like PqaCore/GapTracker.h (the shards keep bitmaps of their own)
   std::vector<int> _devices;
   Error Rebuild(int64_t newQ, int64_t newT, const std::vector<int64_t> &srcQ, const std::vector<int64_t> &srcT,
-                const std::vector<int64_t> &qGaps, const std::vector<int64_t> &tGaps, const PermIdMgr &pimT,
+                const std::vector<int64_t> &qGaps, const std::vector<int64_t> &tGaps, const IdLedger &targetIds,
                 const std::vector<int64_t> &fillT, const std::vector<double> &fillTInit, const std::vector<int64_t> &fillQ,
                 const std::vector<double> &fillQInit);
   Error MaintenanceOnly(const char *what) const {
@@ -317,6 +326,7 @@ class ShardedEngine final : public IEngine {
   // reaches one of them, GetPriors shard 0), so which quizzes ClearOldQuizzes evicts is decided HERE, once, and every shard
   // releases the same ids in the same order -- the shards' registries (ids, gaps) never diverge.
   std::unordered_map<int64_t, time_t> _usage;
+  void ForgetQuizzes() { std::lock_guard<std::mutex> lk(_mu); _usage.clear(); _lastOwner.clear(); }
   void Touch(int64_t iQuiz) { auto it = _usage.find(iQuiz); if (it != _usage.end()) it->second = time(nullptr); }
   void ReleaseEverywhere(int64_t iQuiz, size_t nShards) {   // roll a partly created quiz back
     for (size_t s = 0; s < nShards; s++) (void)_sh[s]->ReleaseQuiz(iQuiz);
@@ -395,7 +405,7 @@ ShardedEngine *ShardedEngine::Create(Error &err, const CiEngineDefinition &def, 
     eng->Seed(seed);
   }
   eng->_hostPriority.resize((size_t)def._nQuestions);
-  eng->_pimQuestions.GrowTo(def._nQuestions);
+  eng->_questionIds.Extend(def._nQuestions);
   err = Error();
   return eng.release();
 }
@@ -457,34 +467,18 @@ int64_t ShardedEngine::ResumeQuiz(Error &err, int64_t nAnswered, const AQ *pAQs)
   return id;
 }
 
-// BaseEngine::ClearOldQuizzes (BaseEngine.cpp:814-873), decided once for all shards: first everything older than maxAgeSec, then
-// the oldest of the rest (a max-heap by age) until maxCount remain.
+// ClearOldQuizzes (behaviour: BaseEngine.cpp:814-873), decided once for all shards by the rule the one-device engine uses
+// (QuizzesToLetGo, hip_engine_kb.cpp) over the usage times kept here.
 Error ShardedEngine::ClearOldQuizzes(int64_t maxCount, double maxAgeSec) {
   if (maxCount < 0)
     return Error::MakeP(ErrCode::NegativeCount, "count=" + std::to_string(maxCount), "The number of quizzes to keep cannot be less than 0.");
   std::lock_guard<std::mutex> lk(_mu);
   if (!_sh[0]->IsRegularMode()) return Error();   // quizzes are not expected to exist in maintenance / shutdown mode
-  struct QuizAge { int64_t iQuiz; double ageSec; bool operator<(const QuizAge &o) const { return ageSec < o.ageSec; } };
-  std::vector<int64_t> ids;
-  for (const auto &kv : _usage) ids.push_back(kv.first);
-  std::sort(ids.begin(), ids.end());   // (registry order, as the reference walks it)
-  std::vector<QuizAge> ages;
-  std::vector<int64_t> evict;
-  const time_t callTime = time(nullptr);
-  for (int64_t id : ids) {
-    const double ageSec = difftime(callTime, _usage[id]);
-    if (ageSec > maxAgeSec) evict.push_back(id); else ages.push_back(QuizAge{id, ageSec});
-  }
-  if ((int64_t)ages.size() > maxCount) {
-    std::make_heap(ages.begin(), ages.end());
-    while ((int64_t)ages.size() > maxCount) {
-      evict.push_back(ages.front().iQuiz);
-      std::pop_heap(ages.begin(), ages.end());
-      ages.pop_back();
-    }
-  }
+  std::vector<QuizUsage> inUse;
+  for (const auto &kv : _usage) inUse.push_back(QuizUsage{kv.first, kv.second});
+  std::sort(inUse.begin(), inUse.end(), [](const QuizUsage &x, const QuizUsage &y) { return x.id < y.id; });   // registry order
   Error first;
-  for (int64_t id : evict) {
+  for (int64_t id : QuizzesToLetGo(inUse, time(nullptr), maxCount, maxAgeSec)) {
     _lastOwner.erase(id);
     _usage.erase(id);
     for (auto &s : _sh) { Error e = s->ReleaseQuiz(id); if (!e.ok() && first.ok()) first = e; }
@@ -678,7 +672,7 @@ Error ShardedEngine::RemoveQuestions(int64_t n, const int64_t *pQIds) {   // Bas
     if (bad) return Error::MakeP(ErrCode::AbsentId, "id=" + std::to_string(iq), "Question index is not in KB.");
   }
   for (auto &s : _sh) { e = s->SetQuestionGaps(n, pQIds); if (!e.ok()) return e; }
-  for (int64_t i = 0; i < n; i++) { _qGapList.push_back(pQIds[i]); _pimQuestions.RemoveComp(pQIds[i]); }
+  for (int64_t i = 0; i < n; i++) { _qGapList.push_back(pQIds[i]); _questionIds.Vacate(pQIds[i]); }
   return Error();
 }
 
@@ -695,7 +689,7 @@ Error ShardedEngine::RemoveTargets(int64_t n, const int64_t *pTIds) {   // BaseE
 // (a gap, or an id that fillQ / fillT initialise).  The registries that are not data -- gaps, id maps, options, mode -- are
 // carried over.  On failure nothing has changed.
 Error ShardedEngine::Rebuild(int64_t newQ, int64_t newT, const std::vector<int64_t> &srcQ, const std::vector<int64_t> &srcT,
-                             const std::vector<int64_t> &qGaps, const std::vector<int64_t> &tGaps, const PermIdMgr &pimT,
+                             const std::vector<int64_t> &qGaps, const std::vector<int64_t> &tGaps, const IdLedger &targetIds,
                              const std::vector<int64_t> &fillT, const std::vector<double> &fillTInit, const std::vector<int64_t> &fillQ,
                              const std::vector<double> &fillQInit) {
   const int64_t N = (int64_t)_sh.size();
@@ -739,8 +733,8 @@ Error ShardedEngine::Rebuild(int64_t newQ, int64_t newT, const std::vector<int64
     err = e->SetQuestionGaps((int64_t)qGaps.size(), qGaps.data());
     if (err.ok()) err = e->SetTargetGaps((int64_t)tGaps.size(), tGaps.data());
     if (!err.ok()) return err;
-    e->SetTargetPim(pimT);
-    e->SetQuizPim(_sh[(size_t)s]->QuizPim());
+    e->SetTargetIds(targetIds);
+    e->SetQuizIds(_sh[(size_t)s]->QuizIds());
     Error ae;
     e->SetQuestionsAsked(s == 0 ? s0.GetTotalQuestionsAsked(ae) : 0);
     for (const char *opt : {"select", "workers", "eval_subtasks", "eval_variant", "bug_compat", "top_cache", "speculate", "host_sampled",
@@ -790,16 +784,16 @@ Error ShardedEngine::AddQsTs(int64_t nQuestions, CiAddQorTParam *pAqps, int64_t 
   for (int64_t t = 0; t < _T; t++) srcT[(size_t)t] = t;
   for (int64_t id : qIds) if (id < _Q) srcQ[(size_t)id] = -1;   // re-initialised below
   std::vector<int64_t> qGaps(_qGapList.begin(), _qGapList.end() - nQReuse), tGaps(tGapList.begin(), tGapList.end() - nTReuse);
-  PermIdMgr pimT = _sh[0]->TargetPim();
-  for (int64_t i = 0; i < nTReuse; i++) pimT.RenewComp(tIds[(size_t)i]);
-  pimT.GrowTo(newT);                                           // :541-542
-  PermIdMgr pimQ = _pimQuestions;
-  for (int64_t i = 0; i < nQReuse; i++) pimQ.RenewComp(qIds[(size_t)i]);
-  pimQ.GrowTo(newQ);
+  IdLedger targetIds = _sh[0]->TargetIds();
+  for (int64_t i = 0; i < nTReuse; i++) targetIds.Reissue(tIds[(size_t)i]);
+  targetIds.Extend(newT);                                           // :541-542
+  IdLedger questionIds = _questionIds;
+  for (int64_t i = 0; i < nQReuse; i++) questionIds.Reissue(qIds[(size_t)i]);
+  questionIds.Extend(newQ);
   // (the rebuilt shards mark their remaining gaps themselves: their own id maps are over local ids and are not consulted)
-  e = Rebuild(newQ, newT, srcQ, srcT, qGaps, tGaps, pimT, tIds, tInit, qIds, qInit);
+  e = Rebuild(newQ, newT, srcQ, srcT, qGaps, tGaps, targetIds, tIds, tInit, qIds, qInit);
   if (!e.ok()) return e;
-  _pimQuestions = pimQ;
+  _questionIds = questionIds;
   for (int64_t i = 0; i < nQuestions; i++) pAqps[i]._index = qIds[(size_t)i];
   for (int64_t j = 0; j < nTargets; j++) pAtps[j]._index = tIds[(size_t)j];
   return Error();
@@ -839,12 +833,12 @@ Error ShardedEngine::Compact(int64_t *pnQuestions, const int64_t **ppOldQuestion
   }
   oldQ.resize((size_t)nQ);
   oldT.resize((size_t)nT);
-  PermIdMgr pimT = _sh[0]->TargetPim(), pimQ = _pimQuestions;
-  pimT.OnCompact(nT, oldT.data());
-  pimQ.OnCompact(nQ, oldQ.data());
-  e = Rebuild(nQ, nT, oldQ, oldT, {}, {}, pimT, {}, {}, {}, {});
+  IdLedger targetIds = _sh[0]->TargetIds(), questionIds = _questionIds;
+  targetIds.Repack(nT, oldT.data());
+  questionIds.Repack(nQ, oldQ.data());
+  e = Rebuild(nQ, nT, oldQ, oldT, {}, {}, targetIds, {}, {}, {}, {});
   if (!e.ok()) return e;
-  _pimQuestions = pimQ;
+  _questionIds = questionIds;
   int64_t *outQ = (int64_t *)std::malloc(sizeof(int64_t) * (size_t)std::max<int64_t>(nQ, 1));
   int64_t *outT = (int64_t *)std::malloc(sizeof(int64_t) * (size_t)std::max<int64_t>(nT, 1));
   std::copy(oldQ.begin(), oldQ.end(), outQ);
@@ -892,7 +886,7 @@ Error ShardedEngine::SaveKB(const char *filePath, bool doubleBuffer) {
   };
   if (!writeGaps(qGaps) || !writeGaps(tGaps)) return KbFileErr(filePath, "Can't write the gaps.");
   // (the live quiz map with empty = true keeps its next permanent id, as BaseEngine.cpp:379 and HipEngine::SaveKB write it)
-  if (!_pimQuestions.Save(fg.f) || !s0.TargetPim().Save(fg.f) || !s0.QuizPim().Save(fg.f, true))
+  if (!_questionIds.Write(fg.f) || !s0.TargetIds().Write(fg.f) || !s0.QuizIds().Write(fg.f, true))
     return KbFileErr(filePath, "Can't write the permanent-compact ID mappings.");
   if (std::fflush(fg.f) != 0) return KbFileErr(filePath, "Failed in hard flushing the KB.");
   FILE *f = fg.f;
@@ -948,9 +942,9 @@ ShardedEngine *ShardedEngine::Load(Error &err, const char *filePath, const std::
     if (e.ok()) e = s->SetTargetGaps((int64_t)tGaps.size(), tGaps.data());
     if (!e.ok()) return fail(std::move(e));
   }
-  PermIdMgr pimT, pimZ;
-  if (!eng->_pimQuestions.Load(fg.f) || !pimT.Load(fg.f) || !pimZ.Load(fg.f)) return fail(KbFileErr(filePath, "Can't read the permanent-compact ID mappings."));
-  for (auto &s : eng->_sh) { s->SetTargetPim(pimT); s->SetQuizPim(pimZ); }
+  IdLedger targetIds, quizIds;
+  if (!eng->_questionIds.Read(fg.f) || !targetIds.Read(fg.f) || !quizIds.Read(fg.f)) return fail(KbFileErr(filePath, "Can't read the permanent-compact ID mappings."));
+  for (auto &s : eng->_sh) { s->SetTargetIds(targetIds); s->SetQuizIds(quizIds); }
   err = Error();
   return eng.release();
 }

@@ -145,6 +145,7 @@ HIP_EXPORTS = {
     "PqaHip_RecordAnswerRemote": (_vp, [_vp, _i64, _i64]),
     "PqaEngine_RecordAnswerBatch": (_vp, [_vp, _i64, _pi64, _pi64]),
     "PqaEngine_StartQuizBatch": (_vp, [_vp, _i64, _pi64]),
+    "PqaHip_HostLogicProbe": (_i64, [ctypes.c_char_p, _pi64, _i64, _pi64, _i64]),
 }
 
 _lib = None
