@@ -37,7 +37,9 @@ static inline uint64_t mix64(uint64_t z) {
 }
 
 // nThreads learner threads share nQuizzes quizzes (a common counter hands them out); quiz i guesses target
-// mix64(seed + i) % nTargets.  train != 0: RecordQuizTarget at the end of every quiz, as the reference's learner does.
+// mix64(seed + i) % nTargets.  train: bit 0 = RecordQuizTarget at the end of every quiz, as the reference's learner does; bit 1 = a
+// client that does not look at the targets between its questions (no ListTopTargets: RecordAnswer is followed by NextQuestion
+// directly, every quiz runs to maxQuestions).
 __attribute__((visibility("default"))) int64_t PqaClient_RunLearners(void *pvEngine, int64_t nThreads, int64_t nQuizzes, int64_t maxQuestions,
                                                                      uint64_t seed, int64_t train, PqaClientStats *pStats) {
   if (!pvEngine || !pStats || nThreads < 1 || nQuizzes < 0 || maxQuestions < 1) return -1;
@@ -88,15 +90,18 @@ __attribute__((visibility("default"))) int64_t PqaClient_RunLearners(void *pvEng
         if (e1) { failed(e1, "RecordAnswer"); break; }
         CiRatedTarget best;
         best._iTarget = -1;
-        t0 = now();
-        const int64_t n = PqaEngine_ListTopTargets(pvEngine, &err, quiz, 1, &best);
-        spent(3, t0);
-        if (err) { failed(err, "ListTopTargets"); err = nullptr; break; }
+        int64_t n = 0;
+        if (!(train & 2)) {
+          t0 = now();
+          n = PqaEngine_ListTopTargets(pvEngine, &err, quiz, 1, &best);
+          spent(3, t0);
+          if (err) { failed(err, "ListTopTargets"); err = nullptr; break; }
+        }
         h = mix64(h ^ mix64((uint64_t)q * 31 + (uint64_t)a) ^ (uint64_t)(n > 0 ? best._iTarget : -1));
         top = n > 0 && best._iTarget == guess;
       }
       if (top) onTop++;
-      if (train) {
+      if (train & 1) {
         t0 = now();
         void *e2 = PqaEngine_RecordQuizTarget(pvEngine, quiz, guess, 1.0);
         spent(4, t0);

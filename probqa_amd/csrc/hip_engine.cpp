@@ -759,14 +759,24 @@ Error HipEngine::ReleaseQuiz(int64_t iQuiz) {
   std::unique_lock<EngineMutex> lk(_mu, std::defer_lock);
   if (_optCombine) lk = std::unique_lock<EngineMutex>(_mu, std::adopt_lock);
   else lk.lock();
-  return ReleaseQuizLocked(iQuiz);
+  return ReleaseQuizLocked(iQuiz, true);
 }
 
-Error HipEngine::ReleaseQuizLocked(int64_t iQuiz) {
+Error HipEngine::ReleaseQuizLocked(int64_t iQuiz, bool mayWait) {
   Error err = CheckRegular("release quiz");
   if (!err.ok()) return err;
   Quiz *q = UseQuiz(err, iQuiz);
   if (!q) return err;
+  // A NextQuestion of this quiz is selecting on another thread (a combined sweep's client, outside the lock): concurrent calls on
+  // one quiz are the caller's error (IPqaEngine.h:44).  A direct call waits it out, briefly; a posted one cannot -- the thread
+  // that runs the drain may be the very leader whose CollectBatch ends the selection -- and is refused.
+  if (q->inSelection.load(std::memory_order_acquire)) {
+    const auto t0 = std::chrono::steady_clock::now();
+    while (mayWait && q->inSelection.load(std::memory_order_acquire) && std::chrono::steady_clock::now() - t0 < std::chrono::seconds(2)) _mm_pause();
+    if (q->inSelection.load(std::memory_order_acquire))
+      return Error::MakeP(ErrCode::Internal, "quizId=" + std::to_string(iQuiz),
+                          "The quiz is inside a NextQuestion call on another thread: it cannot be released now (no concurrent calls on one quiz).");
+  }
   hipSetDevice(_device);
   UnassignQuiz(iQuiz);
   DestroyQuiz(q);  // the buffers go to the pool; their next user is ordered behind pending work on the engine's stream
@@ -1159,6 +1169,7 @@ Error HipEngine::ServerWait(volatile uint64_t *flag, uint64_t value, const char 
 // Post one selection request for quiz `q`; the finisher writes {priority, index + outBase} to `out` and then flagValue to
 // `flag` (host-coherent memory).  Starts the kernel if none is resident.
 Error HipEngine::ServerPost(Quiz *q, SelectResult *out, uint64_t *flag, uint64_t flagValue, int64_t outBase) {
+  { Error fe = FlushUpdates(); if (!fe.ok()) return fe; }   // (a deferred RecordAnswer of this quiz -- posterior and asked bit -- is what the request reads)
   // the resident kernel is not ordered behind the engine's stream: wait for what that stream still runs
   if (_pendingRecordOp != 0 && _pendingRecordFlag != nullptr && !_mu.wasBusy) {
     Error e = WaitFlag(_pendingRecordFlag, _pendingRecordOp, "ServerPost");
@@ -1735,7 +1746,7 @@ void HipEngine::DrainPosted() {
   for (PostedOp *op = ordered; op != nullptr; op = op->next) {
     _postedOps++;
     if (op->kind == 1) { op->err = RecordAnswerLocked(op->iQuiz, op->arg, op->remote, false); continue; }
-    if (op->kind == 5) { op->err = ReleaseQuizLocked(op->iQuiz); continue; }
+    if (op->kind == 5) { op->err = ReleaseQuizLocked(op->iQuiz, false); continue; }
     if (op->kind == 6) { nTrains++; continue; }
     if (op->kind == 4) { nStarts++; continue; }
     if (op->kind == 3) continue;
@@ -1748,8 +1759,9 @@ void HipEngine::DrainPosted() {
   }
   Error flushErr;
   if (needFlush) flushErr = FlushUpdates();
-  if (nTrains > 0) TrainPosted(ordered);
+  if (nTrains > 0) { TrainPosted(ordered); MarkStreamBusy(); }
   if (nStarts > 0) {
+    MarkStreamBusy();
     // the StartQuiz calls of this drain: ONE launch sets all their priors (as StartQuizBatch; chunks of kStartInline)
     hipSetDevice(_device);
     static thread_local StartBatchInline batch;   // (4 KB of pointers: not on a client thread's stack)
@@ -1812,6 +1824,9 @@ void HipEngine::DrainPosted() {
     if (word->exchange(1, std::memory_order_acq_rel) == 2) _postedWake.push_back(word);
     op = next;
   }
+  // The drain runs on the holder's way out -- possibly after a selection path declared the stream idle -- and may have launched
+  // updates, trainings, quiz starts and listings: whoever takes the lock next finds the stream marked busy.
+  MarkStreamBusy();
 }
 
 // The RecordQuizTarget calls of a drain (kind 6), in the order they were posted: calls with different targets touch disjoint cells
@@ -2352,6 +2367,15 @@ Error HipEngine::RecordAnswerLocked(int64_t iQuiz, int64_t iAnswer, bool remote,
   return Error();
 }
 
+// Work has been put on the engine's stream that no completion flag covers: the next request to the resident sweep -- in this hold
+// of the lock or a later one -- synchronises the stream first (ServerPost reads wasBusy of the CURRENT hold, busy becomes the next
+// hold's wasBusy).
+void HipEngine::MarkStreamBusy() {
+  _mu.busy = _mu.wasBusy = true;
+  _pendingRecordOp = 0;
+  _pendingRecordFlag = nullptr;
+}
+
 // The deferred RecordAnswers, on the engine's stream: one launch, no copy, no synchronisation -- the kernel also sets the
 // question's bit in the quiz's device bitmap and lists the new posterior's best targets into the quiz's own pinned lines (as
 // many as ListTopTargets has been asking for lately; every listed target is a round of the kernel's selection, `top_cache` at
@@ -2362,27 +2386,44 @@ Error HipEngine::FlushUpdates() {
   ups.swap(_pendingUpdates);
   _pendingCount.store(0, std::memory_order_relaxed);
   for (PendingUpdate &u : ups) u.q->updatePending = false;
+  // A launch that fails leaves its updates (and those behind them) deferred: the host's bookkeeping has advanced and the calls
+  // that recorded them have returned, so whoever next needs one of those posteriors gets the error instead of a stale posterior.
+  auto requeue = [&](size_t from, hipError_t he, const char *what) {
+    (void)hipGetLastError();
+    for (size_t i = from; i < ups.size(); i++) ups[i].q->updatePending = true;
+    _pendingUpdates.insert(_pendingUpdates.begin(), ups.begin() + (std::ptrdiff_t)from, ups.end());
+    _pendingCount.store(_pendingUpdates.size(), std::memory_order_relaxed);
+    MarkStreamBusy();
+    return HipErr(he, what);
+  };
   hipSetDevice(_device);
   ServerQuiesce();
   // NLooseWorkers = max(1, hw - 1): reference PqaCore/CEQuiz.h:98, PqaCore/BaseCpuEngine.cpp:22
   const int64_t nLoose = std::max<int64_t>(1, _optWorkers - 1);
   const int64_t topCount = _T <= 16384 ? std::min<int64_t>(std::min<int64_t>(std::min<int64_t>(_optTopCache, _topWantRecent), kQuizTop), _T) : 0;
-  _flushes++;
-  _flushedUpdates += ups.size();
-  _flushedSinceSweep.fetch_add((int64_t)ups.size(), std::memory_order_relaxed);
-  if (ups.size() > _maxFlush) _maxFlush = ups.size();
   auto listed = [&](Quiz *q, uint64_t op) { q->topOp = op; q->topVersion = q->priorVersion; q->topCount = topCount; };
+  auto counted = [&](size_t n) {
+    _flushes++;
+    _flushedUpdates += n;
+    _flushedSinceSweep.fetch_add((int64_t)n, std::memory_order_relaxed);
+    if (n > _maxFlush) _maxFlush = n;
+  };
   if (ups.size() == 1) {
     const PendingUpdate &u = ups[0];
-    const uint64_t op = ++_opSeq;
-    HIP_TRY(LaunchRecordAnswer(View(), u.q->dPrior, u.q->dAsked, u.qLocal, u.iAnswer, nLoose, u.q->pin->top, &u.q->pin->nOut,
-                               &u.q->pin->topFlag, op, topCount, _stream));
+    const uint64_t op = _opSeq + 1;
+    const hipError_t he = LaunchRecordAnswer(View(), u.q->dPrior, u.q->dAsked, u.qLocal, u.iAnswer, nLoose, u.q->pin->top, &u.q->pin->nOut,
+                                             &u.q->pin->topFlag, op, topCount, _stream);
+    if (he != hipSuccess) return requeue(0, he, "LaunchRecordAnswer");
+    _opSeq = op;
+    counted(1);
     listed(u.q, op);
     if (topCount > 0) {
       // the kernel stores `op` last: whoever sees it knows that everything enqueued on the stream so far has finished
       _pendingRecordOp = op;
       _pendingRecordFlag = &u.q->pin->topFlag;
       _mu.busy = _mu.wasBusy;   // (busy only if it was before this call: `op` covers this call's launch)
+    } else {
+      MarkStreamBusy();         // (no flag of this launch to wait for)
     }
     return Error();
   }
@@ -2395,14 +2436,17 @@ Error HipEngine::FlushUpdates() {
     b.topCount = (int32_t)topCount;
     for (int32_t i = 0; i < b.n; i++) {
       const PendingUpdate &u = ups[first + (size_t)i];
-      const uint64_t op = ++_opSeq;
-      b.s[i] = RecordSlot{u.q->dPrior, u.q->dAsked, u.q->pin, (int32_t)u.qLocal, (int32_t)u.iAnswer, op};
-      listed(u.q, op);
+      b.s[i] = RecordSlot{u.q->dPrior, u.q->dAsked, u.q->pin, (int32_t)u.qLocal, (int32_t)u.iAnswer, _opSeq + 1 + (uint64_t)i};
     }
-    HIP_TRY(LaunchRecordAnswerBatch(kb, b, nLoose, _stream));
+    const hipError_t he = LaunchRecordAnswerBatch(kb, b, nLoose, _stream);
+    if (he != hipSuccess) return requeue(first, he, "LaunchRecordAnswerBatch");
+    for (int32_t i = 0; i < b.n; i++) listed(ups[first + (size_t)i].q, _opSeq + 1 + (uint64_t)i);
+    _opSeq += (uint64_t)b.n;
+    counted((size_t)b.n);
   }
-  _pendingRecordOp = 0;   // (the workgroups of a batched launch finish in any order: no one flag says that the stream is idle)
-  _pendingRecordFlag = nullptr;
+  // the workgroups of a batched launch finish in any order: no one flag says that the stream is idle -- whoever needs it idle
+  // (the resident sweep's request, ServerPost) synchronises the stream, in this hold of the lock as well as in the next
+  MarkStreamBusy();
   return Error();
 }
 

@@ -381,6 +381,7 @@ class HipEngine : public IEngine {
   struct PendingUpdate { Quiz *q; int64_t qLocal, iAnswer; };
   std::vector<PendingUpdate> _pendingUpdates;
   Error FlushUpdates();                       // the caller holds _mu
+  void MarkStreamBusy();
   uint64_t _flushes = 0, _flushedUpdates = 0, _maxFlush = 0;
   std::atomic<int> _activeCallers{0};         // client threads inside quiz-level calls right now
   struct CallScope {
@@ -458,7 +459,7 @@ class HipEngine : public IEngine {
   void DrainPosted();                              // (the engine's lock held)
   void TrainPosted(PostedOp *ordered);             // the drain's RecordQuizTarget calls
   uint64_t _trainBatches = 0, _trainBatchCalls = 0;
-  Error ReleaseQuizLocked(int64_t iQuiz);
+  Error ReleaseQuizLocked(int64_t iQuiz, bool mayWait);
   Error RecordQuizTargetLocked(int64_t iQuiz, int64_t iTarget, double amount);
   void RunPosted(PostedOp &op);                    // post, and return when somebody has run it
   void ServeQueue(SelRequest *own);

@@ -180,10 +180,12 @@ CLIENT_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libP
 _client = None
 
 
-def run_learners(engine: "PqaEngine", n_threads: int, n_quizzes: int, max_questions: int = 30, seed: int = 1, train: bool = True) -> dict:
+def run_learners(engine: "PqaEngine", n_threads: int, n_quizzes: int, max_questions: int = 30, seed: int = 1, train: bool = True,
+                 list_targets: bool = True) -> dict:
     """The reference's learner client (PqaClient/PqaClient.cpp:150-245) as native threads on ONE engine, through the C ABI only:
     `n_threads` threads share `n_quizzes` quizzes (StartQuiz, NextQuestion / RecordAnswer / ListTopTargets(1) until the guess is
-    on top or `max_questions` were asked, RecordQuizTarget if `train`, ReleaseQuiz)."""
+    on top or `max_questions` were asked, RecordQuizTarget if `train`, ReleaseQuiz).  `list_targets=False`: clients that go from
+    RecordAnswer straight to the next NextQuestion."""
     global _client
     load_library()
     if _client is None:
@@ -193,7 +195,7 @@ def run_learners(engine: "PqaEngine", n_threads: int, n_quizzes: int, max_questi
         _client.PqaClient_RunLearners.restype = ctypes.c_int64
         _client.PqaClient_RunLearners.argtypes = [_vp, _i64, _i64, _i64, ctypes.c_uint64, _i64, ctypes.POINTER(PqaClientStats)]
     st = PqaClientStats()
-    rc = _client.PqaClient_RunLearners(engine.c_engine, n_threads, n_quizzes, max_questions, seed, 1 if train else 0, ctypes.byref(st))
+    rc = _client.PqaClient_RunLearners(engine.c_engine, n_threads, n_quizzes, max_questions, seed, (1 if train else 0) | (0 if list_targets else 2), ctypes.byref(st))
     if rc != 0:
         raise PqaException("PqaClient_RunLearners refused its arguments")
     return {"quizzes": st.nQuizzes, "questions": st.nQuestions, "guessed_on_top": st.nGuessedOnTop, "errors": st.nErrors,

@@ -108,6 +108,59 @@ def test_native_learners_under_every_selection_path(option, factory):
     eng.close()
 
 
+@pytest.mark.parametrize("option", [("server", 1), ("speculate", 0), ("top_cache", 0)], ids=lambda o: "%s=%d" % o)
+def test_clients_that_never_list_targets(option, factory):
+    """clients that go RecordAnswer -> NextQuestion with no ListTopTargets in between.  The deferred updates
+    are then launched by the selection itself (FlushUpdates' batched launch right ahead of the request to the resident sweep, or by
+    the drain on a holder's way out); the resident sweep is not ordered behind the engine's stream and must not read a posterior
+    that such a launch is still writing.  Digest of all transcripts: 32 threads = one thread; repeated, since a race shows up
+    now and then."""
+    eng = _engine(factory, 5, 300, 1000, 8, 1)
+    eng.set_option(*option)
+    one = interop.run_learners(eng, 1, 64, 10, seed=6, train=False, list_targets=False)
+    assert one["errors"] == 0 and one["questions"] == 640
+    for rep in range(4):
+        many = interop.run_learners(eng, 32, 64, 10, seed=6, train=False, list_targets=False)
+        assert many["errors"] == 0
+        assert (many["questions"], many["transcript_hash"]) == (one["questions"], one["transcript_hash"]), rep
+    assert eng.get_option("update_max_flush") > 1
+    eng.close()
+
+
+def test_release_of_a_quiz_inside_a_selection_is_refused_not_waited_for(factory):
+    """ReleaseQuiz of a quiz whose NextQuestion is in flight on another thread (the caller's error, IPqaEngine.h:44) must
+    not hang the engine -- the posted form is refused or succeeds, whichever the timing gives; the engine serves on."""
+    eng = _engine(factory, 5, 300, 1000, 8, 1)
+    quizzes = [eng.start_quiz() for _ in range(24)]
+    stop = threading.Event()
+    errors = []
+
+    def asker(z):
+        try:
+            for _ in range(6):
+                eng.next_question(z)
+                eng.record_answer(z, 1)
+        except interop.PqaException as e:      # (its quiz was released under it: absent id)
+            errors.append(str(e))
+
+    def releaser():
+        for z in quizzes[:6]:
+            try:
+                eng.release_quiz(z)
+            except interop.PqaException as e:
+                errors.append(str(e))
+
+    ts = [threading.Thread(target=asker, args=(z,)) for z in quizzes] + [threading.Thread(target=releaser)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=60)
+    assert not any(t.is_alive() for t in ts), "the engine hangs"
+    z = eng.start_quiz()
+    assert eng.next_question(z) >= 0
+    eng.close()
+
+
 def test_posted_operations_equal_direct_calls(factory):
     """RecordAnswer and ListTopTargets in their posted form (what a call does that finds the engine taken: hip_engine.h, posted
     operations) against the direct form: the same transcripts, top lists and errors.  Option post_always forces the form."""
