@@ -1,23 +1,5 @@
 // hip_engine.cpp -- see hip_engine.h.  Reference files cited are under /root/reference/ProbQA.
-#include "hip_engine.h"
-
-#include <algorithm>
-#include <chrono>
-#include <cmath>
-#include <cstddef>
-#include <cstdio>
-#include <cstring>
-#include <random>
-#include <cstdlib>
-#include <functional>
-#include <sstream>
-
-#include <immintrin.h>
-#include <linux/futex.h>
-#include <sys/syscall.h>
-#include <sys/prctl.h>
-#include <time.h>
-#include <unistd.h>
+#include "hip_engine_internal.h"
 
 namespace pqa {
 
@@ -103,54 +85,7 @@ void DefaultLogger::Log(Severity sev, const std::string &message) {
 }
 
 namespace {
-
-Error HipErr(hipError_t e, const char *what) {
-  std::string msg = std::string("HIP failure in ") + what + ": " + hipGetErrorString(e);
-  DefaultLogger::Log(DefaultLogger::Severity::Error, msg);
-  return Error::MakeP(ErrCode::Internal, std::string("Internal error at hip_engine.cpp(") + what + ")", msg);
-}
-#define HIP_TRY(expr)                                   \
-  do {                                                  \
-    const hipError_t e_ = (expr);                       \
-    if (e_ != hipSuccess) return HipErr(e_, #expr);     \
-  } while (0)
-
-std::string RangeParams(int64_t subj, int64_t lo, int64_t hi) {  // IndexOutOfRangeErrorParams::ToString
-  return "subjIndex=" + std::to_string(subj) + " not in " + std::to_string(lo) + "..." + std::to_string(hi);
-}
-
-inline bool BitTest(const std::vector<uint32_t> &bits, int64_t i) { return (bits[i >> 5] >> (i & 31)) & 1u; }
-inline void BitSet(std::vector<uint32_t> &bits, int64_t i, bool v) {
-  if (v) bits[i >> 5] |= 1u << (i & 31); else bits[i >> 5] &= ~(1u << (i & 31));
-}
-inline size_t BitWords(int64_t nBits) { return (size_t)((nBits + 63) / 64) * 2 + 2; }  // whole 64-bit packs + slack
-inline uint64_t Pack64(const std::vector<uint32_t> &bits, int64_t iPack) {
-  return (uint64_t)bits[2 * iPack] | ((uint64_t)bits[2 * iPack + 1] << 32);
-}
-
-uint64_t SplitMix64(uint64_t &x) {
-  uint64_t z = (x += 0x9E3779B97F4A7C15ULL);
-  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
-  z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
-  return z ^ (z >> 31);
-}
-
 std::once_flag gTableOnce[64];
-
-// A waiting client sleeps on ITS OWN request's state word and is woken alone (futex): with one condition variable for all
-// requests every published batch woke every sleeper, most of them only to find their own request unserved and sleep again.
-inline void FutexWait(std::atomic<int> *word, int expected) {
-  syscall(SYS_futex, reinterpret_cast<int *>(word), FUTEX_WAIT_PRIVATE, expected, nullptr, nullptr, 0);
-}
-inline void FutexWakeOne(std::atomic<int> *word) { syscall(SYS_futex, reinterpret_cast<int *>(word), FUTEX_WAKE_PRIVATE, 1, nullptr, nullptr, 0); }
-// The new state, then the wake -- always: whether the owner sleeps cannot be asked once the state is stored (it may have seen it,
-// returned and gone with its request), and a wake on a word nobody sleeps on only costs the call.
-inline void PublishState(std::atomic<int> *word, int state) {
-  word->store(state, std::memory_order_release);
-  FutexWakeOne(word);
-}
-static_assert(sizeof(std::atomic<int>) == sizeof(int), "the state word is slept on as a futex");
-
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -537,6 +472,7 @@ void HipEngine::DestroyQuiz(Quiz *q) {
     auto it = _graphs.find(q);
     if (it != _graphs.end()) { hipGraphExecDestroy(it->second.exec); _graphs.erase(it); }
   }
+  if (q->dRowStage) { hipFree(q->dRowStage); q->dRowStage = nullptr; }
   if (q->dPrior && q->dAsked && _quizBufferPool.size() < 4096)
     _quizBufferPool.push_back(QuizBuffers{q->dPrior, q->dAsked, _ldT, q->hAsked.size()});
   else {
@@ -700,54 +636,6 @@ int64_t HipEngine::ResumeQuiz(Error &err, int64_t nAnswered, const AQ *pAQs) {
   return SpeculateFor(CreateQuiz(err, nAnswered, pAQs, nullptr, nullptr, 0, nullptr));  // nAnswered == 0 -> StartQuiz (BaseEngine.cpp:393-395)
 }
 
-// ------------------------------------------------------------------------------------------------------------------
-// what a sharded engine (sharded_engine.cpp) needs from its shards beyond the public surface
-// ------------------------------------------------------------------------------------------------------------------
-Error HipEngine::GetRowPointers(int64_t qGlobal, int64_t iAnswer, const void **ppA, const void **ppD) {
-  std::lock_guard<EngineMutex> lk(_mu);
-  if (!OwnsQuestion(qGlobal))
-    return Error::MakeP(ErrCode::IndexOutOfRange, RangeParams(qGlobal, _qFirst, _qFirst + _Q - 1), "Question is not held by this shard.");
-  if (iAnswer < 0 || iAnswer >= _K)
-    return Error::MakeP(ErrCode::IndexOutOfRange, RangeParams(iAnswer, 0, _K - 1), "Answer index is not in KB range.");
-  *ppA = CubeAt(qGlobal - _qFirst, iAnswer);
-  *ppD = CubeAt(qGlobal - _qFirst, _K);
-  return Error();
-}
-
-int64_t HipEngine::ResumeQuizRows(Error &err, int64_t nAnswered, const AQ *pAQs, const void *const *rows) {
-  std::lock_guard<EngineMutex> lk(_mu);
-  return CreateQuiz(err, nAnswered, pAQs, rows, nullptr, 0, nullptr);
-}
-
-int64_t HipEngine::ResumeQuizAdopt(Error &err, int64_t nAnswered, const AQ *pAQs, const double *srcPrior, int srcDevice, hipEvent_t ready) {
-  std::lock_guard<EngineMutex> lk(_mu);
-  return CreateQuiz(err, nAnswered, pAQs, nullptr, srcPrior, srcDevice, ready);
-}
-
-// The owner of the answered question has computed the new posterior: replace this shard's copy, in stream order.
-Error HipEngine::AdoptPrior(int64_t iQuiz, const double *srcPrior, int srcDevice, hipEvent_t ready) {
-  std::lock_guard<EngineMutex> lk(_mu);
-  Error err;
-  Quiz *q = UseQuiz(err, iQuiz);
-  if (!q) return err;
-  hipSetDevice(_device);
-  ServerQuiesce();
-  { Error fe = FlushUpdates(); if (!fe.ok()) return fe; }
-  if (ready != nullptr) HIP_TRY(hipStreamWaitEvent(_stream, ready, 0));
-  HIP_TRY(hipMemcpyPeerAsync(q->dPrior, _device, srcPrior, srcDevice, (size_t)_ldT * sizeof(double), _stream));
-  q->priorVersion++;
-  return Error();
-}
-
-Error HipEngine::QuestionState(int64_t iQuiz, int64_t qGlobal, bool *pUnavailable) {
-  std::lock_guard<EngineMutex> lk(_mu);
-  Error err;
-  Quiz *q = UseQuiz(err, iQuiz);
-  if (!q) return err;
-  *pUnavailable = !OwnsQuestion(qGlobal) || QuestionUnavailable(q, qGlobal - _qFirst);
-  return Error();
-}
-
 Error HipEngine::ReleaseQuiz(int64_t iQuiz) {
   CallScope scope(_activeCallers);
   if (_optCombine && (_optPostAlways || !_mu.try_lock())) {
@@ -901,17 +789,6 @@ int64_t SelectSampledHostBits(double *run, int64_t n, int64_t nWorkers, uint64_t
 
 int64_t HipEngine::FindNearestQuestion(int64_t iMiddle, const Quiz *q) const {   // (over the local question range)
   return FindNearestInPacks(iMiddle, _Q, [&](int64_t p) { return ~(Pack64(_hQGap, p) | Pack64(q->hAsked, p)); });
-}
-
-// bit i of words[i / 32] set = LOCAL question i is asked in the quiz or a gap (bits past the local count set)
-Error HipEngine::UnavailableWords(int64_t iQuiz, std::vector<uint32_t> &words) {
-  std::lock_guard<EngineMutex> lk(_mu);
-  Error err;
-  Quiz *q = UseQuiz(err, iQuiz);
-  if (!q) return err;
-  words.resize(_hQGap.size());
-  for (size_t w = 0; w < words.size(); w++) words[w] = _hQGap[w] | q->hAsked[w];
-  return Error();
 }
 
 int64_t HipEngine::FinishSelection(Error &err, Quiz *q, int64_t selLocal) {
@@ -2411,13 +2288,13 @@ Error HipEngine::FlushUpdates() {
   if (ups.size() == 1) {
     const PendingUpdate &u = ups[0];
     const uint64_t op = _opSeq + 1;
-    const hipError_t he = LaunchRecordAnswer(View(), u.q->dPrior, u.q->dAsked, u.qLocal, u.iAnswer, nLoose, u.q->pin->top, &u.q->pin->nOut,
-                                             &u.q->pin->topFlag, op, topCount, _stream);
+    const hipError_t he = LaunchRecordAnswer(View(), u.q->dPrior, u.q->dAsked, u.qLocal, u.iAnswer, nLoose, u.list ? u.q->pin->top : nullptr, &u.q->pin->nOut,
+                                             &u.q->pin->topFlag, op, topCount, _stream, u.rowA, u.rowD);
     if (he != hipSuccess) return requeue(0, he, "LaunchRecordAnswer");
     _opSeq = op;
     counted(1);
-    listed(u.q, op);
-    if (topCount > 0) {
+    if (u.list) listed(u.q, op);
+    if (topCount > 0 && u.list) {
       // the kernel stores `op` last: whoever sees it knows that everything enqueued on the stream so far has finished
       _pendingRecordOp = op;
       _pendingRecordFlag = &u.q->pin->topFlag;
@@ -2436,11 +2313,11 @@ Error HipEngine::FlushUpdates() {
     b.topCount = (int32_t)topCount;
     for (int32_t i = 0; i < b.n; i++) {
       const PendingUpdate &u = ups[first + (size_t)i];
-      b.s[i] = RecordSlot{u.q->dPrior, u.q->dAsked, u.q->pin, (int32_t)u.qLocal, (int32_t)u.iAnswer, _opSeq + 1 + (uint64_t)i};
+      b.s[i] = RecordSlot{u.q->dPrior, u.q->dAsked, u.list ? (void *)u.q->pin : nullptr, (int32_t)u.qLocal, (int32_t)u.iAnswer, _opSeq + 1 + (uint64_t)i, u.rowA, u.rowD};
     }
     const hipError_t he = LaunchRecordAnswerBatch(kb, b, nLoose, _stream);
     if (he != hipSuccess) return requeue(first, he, "LaunchRecordAnswerBatch");
-    for (int32_t i = 0; i < b.n; i++) listed(ups[first + (size_t)i].q, _opSeq + 1 + (uint64_t)i);
+    for (int32_t i = 0; i < b.n; i++) if (ups[first + (size_t)i].list) listed(ups[first + (size_t)i].q, _opSeq + 1 + (uint64_t)i);
     _opSeq += (uint64_t)b.n;
     counted((size_t)b.n);
   }

@@ -123,6 +123,7 @@ struct Quiz {
   uint64_t priorVersion = 0;           // bumped whenever the posterior changes
   uint64_t serial = 0;                 // unique per created quiz: a registry slot reused by a later quiz is not this quiz
   QuizPinned *pin = nullptr;           // this quiz's host-coherent result lines (pooled by the engine)
+  void *dRowStage = nullptr;           // sharded engine without peer access: the two rows of an answered question another shard holds, copied here
   // the listing in pin->top: made by the kernel that published `topOp` to pin->topFlag, of the posterior `topVersion`
   uint64_t topOp = 0, topVersion = 0;
   int64_t topCount = 0;
@@ -253,7 +254,25 @@ class HipEngine : public IEngine {
   Error RecordAnswerBatch(int64_t n, const int64_t *pQuizzes, const int64_t *pAnswers) override;
   Error StartQuizBatch(int64_t n, int64_t *pQuizzes) override;
 
-  // ---- what a sharded engine needs from its shards (sharded_engine.cpp)
+  // ---- what a sharded engine needs from its shards (sharded_engine.cpp; implemented in hip_engine_shard.cpp)
+  // An answer of a quiz as the sharded engine hands it to EVERY shard: the answered question in global numbering; for the shards
+  // that do not hold it, its two rows where they are (the owner's cube: read in place over peer access, or -- `stage` -- copied
+  // into the quiz's staging rows first).  `list`: this shard's kernel also lists the new posterior's best targets.
+  struct ShardAnswer { int64_t iQuiz, qGlobal, iAnswer; const void *rowA, *rowD; int srcDevice; bool stage, list; };
+  // Bookkeeping of RecordAnswer for each (CEQuiz::RecordAnswer, PqaCore/CEQuiz.h:77-122) and ONE launch for all the posteriors.
+  Error ApplyAnswers(int64_t n, const ShardAnswer *answers);
+  // A combined sweep for n distinct quizzes in two halves (the combining of concurrent NextQuestion calls, done by the sharded
+  // engine over all its shards): EnqueueCombined validates, flushes, launches into batch context `ctx` (0 / 1) and snapshots the
+  // quizzes' unavailable questions; CollectCombined waits for that launch -- without the engine's lock -- and gives per quiz the
+  // shard's winner (argmax batches) or a view of its priority vector on the host (hostPriorities).
+  struct CombinedFlight { uint64_t tag = 0; bool hostPriorities = false, quizMinor = false, tagged = false; int64_t Bp = 0, nQ = 0, n = 0; hipError_t he = hipSuccess; };
+  struct PriorityView { const double *pri = nullptr; int64_t stride = 0; uint64_t tag = 0; };   // local question k: pri[k * stride]; tag != 0: the word behind it must carry the tag first
+  Error EnqueueCombined(int ctx, int64_t n, const int64_t *pQuizzes, bool hostPriorities, CombinedFlight *flight,
+                        std::vector<uint32_t> *unavailable /* n x UnavailableWordCount() words, local bit order */);
+  Error CollectCombined(int ctx, const CombinedFlight &flight, CiHipSelection *winners, PriorityView *views);
+  size_t UnavailableWordCount() const { return _hQGap.size(); }
+  void SetExternalCallers(const std::atomic<int> *n) { _extCallers = n; }   // the sharded engine's count of client threads inside it
+  Error FlushDeferred();   // launch whatever posterior updates are deferred (the sharded engine's training barrier)
   int Device() const { return _device; }
   int64_t FirstQuestion() const { return _qFirst; }
   int64_t LocalQuestions() const { return _Q; }
@@ -262,10 +281,9 @@ class HipEngine : public IEngine {
   const double *PriorityDevicePtr() const { return _dPriority; }   // filled by EnqueueEval, local question order
   void BumpQuestionsAsked(uint64_t n) { _nQuestionsAsked.fetch_add(n, std::memory_order_relaxed); }
   Error GetRowPointers(int64_t qGlobal, int64_t iAnswer, const void **ppA, const void **ppD);
-  int64_t ResumeQuizRows(Error &err, int64_t nAnswered, const AQ *pAQs, const void *const *rows);
-  int64_t ResumeQuizAdopt(Error &err, int64_t nAnswered, const AQ *pAQs, const double *srcPrior, int srcDevice, hipEvent_t ready);
-  Error AdoptPrior(int64_t iQuiz, const double *srcPrior, int srcDevice, hipEvent_t ready);
-  Error QuestionState(int64_t iQuiz, int64_t qGlobal, bool *pUnavailable);
+  // rowDevices / stageRow (optional): the device each row lives on, and whether it is copied to this device first (no peer access)
+  int64_t ResumeQuizRows(Error &err, int64_t nAnswered, const AQ *pAQs, const void *const *rows, const int *rowDevices = nullptr,
+                         const char *stageRow = nullptr);
   // .kb arrays of this engine's questions at the file's current position (hip_engine_kb.cpp); the engine's lock is not taken
   Error IoRows(FILE *f, const char *filePath, bool mD, bool write);
   Error IoVB(FILE *f, const char *filePath, bool write);
@@ -291,6 +309,9 @@ class HipEngine : public IEngine {
   bool IsMaintenanceMode() const { return _mode == Mode::Maintenance; }
   double InitAmount() const { return _initAmount; }
   const void *QuestionBlock(int64_t qLocal) const { return CubeAt(qLocal); }
+  const void *RowPointer(int64_t qLocal, int64_t row) const { return CubeAt(qLocal, row); }   // row < K: sA[q][row][.]; row == K: mD[q][.]
+  int64_t Answers() const { return _K; }
+  int64_t CombinedBatchFor(int64_t waiting) const { return PreferredCombinedBatch(waiting); }
   const double *VBDevicePtr() const { return _dVB; }
   // a rebuilt shard takes its questions' rows from the old shards' cubes (in place, over peer access) ...
   Error AdoptRows(const std::vector<const void *> &srcBlocks, int64_t ldTsrc, const std::vector<int64_t> &colMap, const double *srcVB);
@@ -378,7 +399,7 @@ class HipEngine : public IEngine {
   // ONE kernel for all the updates that have gathered (grid.x = update; prior_kernels.hip: record_answer_batch_kernel) instead
   // of one launch each.  Alone in the engine, RecordAnswer launches at once, as before.
   struct BatchCtx;
-  struct PendingUpdate { Quiz *q; int64_t qLocal, iAnswer; };
+  struct PendingUpdate { Quiz *q; int64_t qLocal, iAnswer; const void *rowA = nullptr, *rowD = nullptr; bool list = true; };   // rowA: another shard's question
   std::vector<PendingUpdate> _pendingUpdates;
   Error FlushUpdates();                       // the caller holds _mu
   void MarkStreamBusy();
@@ -389,11 +410,16 @@ class HipEngine : public IEngine {
     explicit CallScope(std::atomic<int> &c) : n(c) { n.fetch_add(1, std::memory_order_relaxed); }
     ~CallScope() { n.fetch_sub(1, std::memory_order_relaxed); }
   };
-  bool Concurrent() const { return _optCombine && _activeCallers.load(std::memory_order_relaxed) > 1; }
+  const std::atomic<int> *_extCallers = nullptr;   // a shard: the client threads inside the sharded engine that drives it
+  int Callers() const {
+    const int own = _activeCallers.load(std::memory_order_relaxed);
+    return _extCallers ? std::max(own, _extCallers->load(std::memory_order_relaxed)) : own;
+  }
+  bool Concurrent() const { return _optCombine && Callers() > 1; }
   static int AllowedCpus();                   // the CPUs this process may use: the cgroup's quota (cpu.max) or the affinity mask
   int64_t _optCombineSpin = 1;                // option "combine_spin": 1 = waiting clients spin while they are fewer than the allowed CPUs, 0 = they always sleep
   int64_t _optPostAlways = 0;                 // option "post_always" (test hook): the posted form of RecordAnswer / ListTopTargets even when the engine is free
-  bool ClientsFitCpus() const { return _optCombineSpin && _activeCallers.load(std::memory_order_relaxed) + 2 <= AllowedCpus(); }
+  bool ClientsFitCpus() const { return _optCombineSpin && Callers() + 2 <= AllowedCpus(); }
   int64_t _optCombine = 1;                    // option "combine" / PQA_COMBINE: 0 = every call by itself, as before
   // ---- combining of concurrent NextQuestion calls (reference: every client's NextQuestion runs under a SHARED lock,
   // PqaCore/CpuEngine.cpp:357-361, Interface/IPqaEngine.h:44).  A caller posts its request; if a leader is at work it waits

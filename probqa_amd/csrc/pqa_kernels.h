@@ -234,19 +234,23 @@ constexpr int64_t kMaxWorkers = 1000;
 hipError_t LaunchStartQuiz(const KbView &kb, double *prior, uint32_t *asked, int64_t askedWords, int64_t nWorkers, hipStream_t stream);
 // topOut (optional, host-coherent with topN / topFlag): also list the new posterior's topCount best targets, then store
 // topFlagValue to *topFlag.
+// rowA / rowD (optional): the rows of an answered question that ANOTHER shard of the question axis holds (sharded_engine.cpp), read
+// where they are; iQuestion is then not used and no bit of `asked` is set.
 hipError_t LaunchRecordAnswer(const KbView &kb, double *prior, uint32_t *asked, int64_t iQuestion, int64_t iAnswer,
                               int64_t nWorkers, RatedTargetDev *topOut, int64_t *topN, uint64_t *topFlag,
-                              uint64_t topFlagValue, int64_t topCount, hipStream_t stream);
+                              uint64_t topFlagValue, int64_t topCount, hipStream_t stream, const void *rowA = nullptr,
+                              const void *rowD = nullptr);
 // Several quizzes' RecordAnswer in ONE launch (grid.x = update; the same workgroup code and summation order per quiz as
 // LaunchRecordAnswer, so every posterior is bit-identical to the one-by-one result): up to kRecordInline updates travel in the
 // kernel's arguments.  CERecordAnswerSubtaskMul.cpp:15-42 per quiz; the reference runs concurrent quizzes' updates side by side.
 constexpr int kRecordInline = 256;
-struct RecordSlot {               // 40 bytes: 256 of them are 10 KB of kernel arguments
+struct RecordSlot {               // 56 bytes: 256 of them are 14 KB of kernel arguments
   double *prior;
   uint32_t *asked;
-  void *pin;                      // the quiz's host-coherent lines {RatedTargetDev top[kQuizTopDev]; int64 nOut; uint64 topFlag} (optional)
+  void *pin;                      // the quiz's host-coherent lines {RatedTargetDev top[kQuizTopDev]; int64 nOut; uint64 topFlag} (optional: no listing without)
   int32_t iQuestion, iAnswer;     // local question
   uint64_t topFlagValue;
+  const void *rowA, *rowD;        // non-null: another shard's question -- its rows where they are (then iQuestion is unused)
 };
 constexpr int kQuizTopDev = 32;   // == kQuizTop (hip_engine.h)
 struct RecordBatchInline {

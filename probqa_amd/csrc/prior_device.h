@@ -106,18 +106,27 @@ struct TopRequest {
 
 // COH: the caller is the resident kernel -- the old posterior may have been written by a kernel on another XCD (read past the
 // non-coherent cache levels), and the new one must reach memory before the sweep's workgroups on other XCDs read it.
+// rowsElsewhere (optional): the answered question belongs to ANOTHER shard of the question axis (sharded_engine.cpp) -- its rows
+// sA[q][a][.] and mD[q][.] are read where they are (that shard's cube over peer access, or a staged copy) and there is no bit of
+// this shard's bitmap to set; every shard then computes the posterior itself, the same bits everywhere.
+struct RowPair { const void *a, *d; };
 template <bool SMALL, bool COH>
 __device__ __forceinline__ void record_answer_body(PriorArgs a, int64_t iQuestion, int64_t iAnswer, uint32_t *asked, TopRequest top,
-                                                   double *lds, TopScratch *topScratch) {
+                                                   double *lds, TopScratch *topScratch, RowPair rowsElsewhere = RowPair{nullptr, nullptr}) {
   // CEQuiz::RecordAnswer marks the question as asked (PqaCore/CEQuiz.h:92); done here, in stream order with the sweeps
   // that read the bitmap, so that the host call needs neither a copy nor a synchronisation
-  if (threadIdx.x == 0) {
+  if (threadIdx.x == 0 && rowsElsewhere.a == nullptr) {
     const uint32_t w = COH ? __hip_atomic_load(asked + (iQuestion >> 5), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : asked[iQuestion >> 5];
     asked[iQuestion >> 5] = w | (1u << (iQuestion & 31));
   }
   const int64_t nVects = (a.T + 3) >> 2;
-  const int64_t rowA = (iQuestion * (a.K + 1) + iAnswer) * a.ldT;  // CERecordAnswerSubtaskMul.cpp:25
-  const int64_t rowD = (iQuestion * (a.K + 1) + a.K) * a.ldT;      // :26
+  int64_t rowA = (iQuestion * (a.K + 1) + iAnswer) * a.ldT;  // CERecordAnswerSubtaskMul.cpp:25
+  int64_t rowD = (iQuestion * (a.K + 1) + a.K) * a.ldT;      // :26
+  if (rowsElsewhere.a != nullptr) {   // (wave-uniform; offsets in elements from the A row, which stands in for the cube's base)
+    a.cube = rowsElsewhere.a;
+    rowA = 0;
+    rowD = (int64_t)((static_cast<const char *>(rowsElsewhere.d) - static_cast<const char *>(rowsElsewhere.a)) / a.elem);
+  }
   double *stage = prior_stage(a, lds);
   // (four elements per thread and round: their twelve loads are requested together -- a long row is ~100 rounds of one L2 round
   //  trip each otherwise; the element arithmetic and its order per element are unchanged)

@@ -59,10 +59,10 @@ __global__ __launch_bounds__(kThreads) void start_quiz_batch_kernel(PriorArgs a,
 
 template <bool SMALL>
 __global__ __launch_bounds__(SMALL ? kSmallThreads : kThreads) void record_answer_kernel(PriorArgs a, int64_t iQuestion, int64_t iAnswer,
-                                                                                         uint32_t *asked, TopRequest top) {
+                                                                                         uint32_t *asked, TopRequest top, RowPair rowsElsewhere) {
   extern __shared__ double lds[];
   __shared__ TopScratch topScratch;
-  record_answer_body<SMALL, false>(a, iQuestion, iAnswer, asked, top, lds, &topScratch);
+  record_answer_body<SMALL, false>(a, iQuestion, iAnswer, asked, top, lds, &topScratch, rowsElsewhere);
 }
 
 // grid.x = update: workgroup i runs quiz i's RecordAnswer exactly as record_answer_kernel would
@@ -75,7 +75,7 @@ __global__ __launch_bounds__(SMALL ? kSmallThreads : kThreads) void record_answe
   TopOut *topOut = reinterpret_cast<TopOut *>(s.pin);
   int64_t *topN = reinterpret_cast<int64_t *>(topOut + kQuizTopDev);
   const TopRequest top{topOut, topN, reinterpret_cast<uint64_t *>(topN + 1), s.topFlagValue, s.pin ? (int64_t)batch.topCount : 0};
-  record_answer_body<SMALL, false>(a, s.iQuestion, s.iAnswer, s.asked, top, lds, &topScratch);
+  record_answer_body<SMALL, false>(a, s.iQuestion, s.iAnswer, s.asked, top, lds, &topScratch, RowPair{s.rowA, s.rowD});
 }
 
 __device__ __forceinline__ int ceil_log2_u64(uint64_t val) {  // SRPlatform/Interface/SRMath.h:46-51
@@ -176,7 +176,7 @@ __global__ __launch_bounds__(kThreads) void long_row_stage_kernel(PriorArgs a, i
   const int64_t e0 = 4 * first, e1 = (s == nSubtasks - 1) ? a.ldT : 4 * limit;   // (the last subtask's workgroup also takes the row's padding)
   double *vals = lds + 8 * nSubtasks + 1;
   if constexpr (RECORD) {
-    if (s == 0 && threadIdx.x == 0) asked[iQuestion >> 5] |= 1u << (iQuestion & 31);   // CEQuiz::RecordAnswer, PqaCore/CEQuiz.h:92
+    if (s == 0 && threadIdx.x == 0 && asked != nullptr) asked[iQuestion >> 5] |= 1u << (iQuestion & 31);   // CEQuiz::RecordAnswer, PqaCore/CEQuiz.h:92
   } else {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < askedWords; i += (int64_t)gridDim.x * blockDim.x) asked[i] = 0;
   }
@@ -300,9 +300,11 @@ PriorArgs make_args(const KbView &kb, double *prior, int64_t nWorkers, bool stag
 
 // The long-row form: its launches, or false if the row is short / the engine gave no scratch.
 template <bool RECORD>
-static bool launch_long_row(const KbView &kb, double *prior, uint32_t *asked, int64_t askedWords, int64_t iQuestion, int64_t iAnswer,
-                            int64_t nWorkers, hipStream_t stream) {
-  if (kb.ldT <= 16384 || kb.priorScratch == nullptr) return false;
+static bool launch_long_row(const KbView &kbLocal, double *prior, uint32_t *asked, int64_t askedWords, int64_t iQuestion, int64_t iAnswer,
+                            int64_t nWorkers, hipStream_t stream, const void *cubeElsewhere = nullptr) {
+  if (kbLocal.ldT <= 16384 || kbLocal.priorScratch == nullptr) return false;
+  KbView kb = kbLocal;
+  if (cubeElsewhere != nullptr) kb.cube = cubeElsewhere;   // (another shard's question block: same row length and layout)
   const int64_t nVects = (kb.T + 3) >> 2, quot = nVects / nWorkers, rem = nVects % nWorkers;
   const int64_t nSubtasks = quot == 0 ? rem : nWorkers;
   const size_t values = (size_t)(4 * (quot + 1) + (kb.ldT - 4 * nVects)) * sizeof(double);
@@ -328,16 +330,24 @@ hipError_t LaunchStartQuiz(const KbView &kb, double *prior, uint32_t *asked, int
 
 hipError_t LaunchRecordAnswer(const KbView &kb, double *prior, uint32_t *asked, int64_t iQuestion, int64_t iAnswer,
                               int64_t nWorkers, RatedTargetDev *topOut, int64_t *topN, uint64_t *topFlag,
-                              uint64_t topFlagValue, int64_t topCount, hipStream_t stream) {
-  if (nWorkers < 1 || nWorkers > kMaxWorkers) return hipErrorInvalidValue;
+                              uint64_t topFlagValue, int64_t topCount, hipStream_t stream, const void *rowA, const void *rowD) {
+  if (nWorkers < 1 || nWorkers > kMaxWorkers || (rowA == nullptr) != (rowD == nullptr)) return hipErrorInvalidValue;
   const TopRequest top{reinterpret_cast<TopOut *>(topOut), topN, topFlag, topFlagValue, (topOut && kb.T <= 16384) ? topCount : 0};
-  if (top.count == 0 && launch_long_row<true>(kb, prior, asked, 0, iQuestion, iAnswer, nWorkers, stream)) return hipGetLastError();
+  // (the long-row form addresses the rows through the cube: another shard's rows take the one-workgroup kernel)
+  if (top.count == 0 && rowA == nullptr && launch_long_row<true>(kb, prior, asked, 0, iQuestion, iAnswer, nWorkers, stream)) return hipGetLastError();
+  // another shard's rows in place (the D row of a question block lies K - iAnswer rows behind its A row): the block stands in for
+  // a one-question cube; staged copies of the two rows take the one-workgroup kernel
+  if (top.count == 0 && rowA != nullptr &&
+      static_cast<const char *>(rowD) - static_cast<const char *>(rowA) == (ptrdiff_t)((kb.K - iAnswer) * kb.ldT * kb.elem) &&
+      launch_long_row<true>(kb, prior, nullptr, 0, 0, iAnswer, nWorkers, stream, static_cast<const char *>(rowA) - (size_t)(iAnswer * kb.ldT * kb.elem)))
+    return hipGetLastError();
+  const RowPair rows{rowA, rowD};
   if (small_launch(kb))
     hipLaunchKernelGGL(record_answer_kernel<true>, dim3(1), dim3(kSmallThreads), staged_lds_bytes(kb, nWorkers), stream,
-                       make_args(kb, prior, nWorkers, true), iQuestion, iAnswer, asked, top);
+                       make_args(kb, prior, nWorkers, true), iQuestion, iAnswer, asked, top, rows);
   else
     hipLaunchKernelGGL(record_answer_kernel<false>, dim3(1), dim3(kThreads), staged_lds_bytes(kb, nWorkers), stream,
-                       make_args(kb, prior, nWorkers, true), iQuestion, iAnswer, asked, top);
+                       make_args(kb, prior, nWorkers, true), iQuestion, iAnswer, asked, top, rows);
   return hipGetLastError();
 }
 

@@ -412,9 +412,11 @@ def test_sharded_maintenance_equals_whole_engine(f32, factory, tmp_path):
 
 
 def test_learner_threads_on_a_sharded_engine(factory):
-    """Many client threads on ONE sharded engine (one client at a time inside it: the combining of concurrent calls is the
-    single-device engine's): 24 native learner threads, argmax selector, no training -- the digest of all transcripts equals
-    the one-thread run's and a whole-cube engine's; then with training and the sampled selector it must simply work."""
+    """Many client threads on ONE sharded engine (reference: every client's NextQuestion under a shared lock,
+    PqaCore/CpuEngine.cpp:357-361, the published rate the sum over the learner threads, PqaClient/PqaClient.cpp:238-245): concurrent
+    NextQuestion calls become ONE combined sweep per shard, the gathered answers one launch per shard.  Native learner threads,
+    argmax selector, no training -- the digest of all transcripts equals the one-thread run's and a whole-cube engine's; the
+    engine did combine; with training and the sampled selector it must simply work and teach the cube."""
     case = cases.Case("shthreads", 5, 120, 400, seed=21, qgaps=[9])
     with devices("0,0,0"):
         sh = case.make_engine(factory)
@@ -422,11 +424,87 @@ def test_learner_threads_on_a_sharded_engine(factory):
     for e in (sh, whole):
         e.set_option("select", 1)
     one = interop.run_learners(sh, 1, 48, 8, seed=3, train=False)
+    assert sh.get_option("combined_batches") == 0          # one caller at a time: every call by itself
     many = interop.run_learners(sh, 24, 48, 8, seed=3, train=False)
     ref = interop.run_learners(whole, 1, 48, 8, seed=3, train=False)
     assert one["errors"] == many["errors"] == ref["errors"] == 0
     assert (one["questions"], one["transcript_hash"]) == (many["questions"], many["transcript_hash"]) == (ref["questions"], ref["transcript_hash"])
+    assert sh.get_option("combined_batches") > 0 and sh.get_option("combined_max_batch") > 2
+    assert sh.get_option("answer_max_flush") > 1 and sh.get_option("shards_in_flight_max") == 3
+    # clients that never list targets (RecordAnswer -> NextQuestion): the sweeps' leader hands the gathered answers over
+    bare = interop.run_learners(sh, 24, 48, 8, seed=3, train=False, list_targets=False)
+    bare_ref = interop.run_learners(whole, 1, 48, 8, seed=3, train=False, list_targets=False)
+    assert bare["errors"] == 0 and (bare["questions"], bare["transcript_hash"]) == (bare_ref["questions"], bare_ref["transcript_hash"])
     sh.set_option("select", 0)
-    trained = interop.run_learners(sh, 24, 96, 12, seed=4, train=True)
-    assert trained["errors"] == 0 and trained["quizzes"] == 96
+    trained = interop.run_learners(sh, 24, 192, 30, seed=4, train=True)
+    assert trained["errors"] == 0 and trained["quizzes"] == 192 and trained["guessed_on_top"] > 96
+    sh.close(); whole.close()
+
+
+def test_64_learner_threads_on_three_shards_scale(factory):
+    """The rate: 64 learner threads on a 3-shard one-device engine against ONE thread on the same engine (S-shaped cube, the
+    reference's sampled selector, training at the end of every quiz -- the PqaClient workload).  One client at a time (round 3:
+    one mutex held through every GPU wait) gave 1.0x by construction."""
+    case = cases.Case("shrate", 5, 1000, 1000, seed=5)
+    with devices("0,0,0"):
+        sh = case.make_engine(factory)
+    interop.run_learners(sh, 1, 40, 30, seed=1, train=True)                 # warm-up: kernels, pools, clocks
+    one = interop.run_learners(sh, 1, 400, 30, seed=2, train=True)
+    many = interop.run_learners(sh, 64, 3000, 30, seed=3, train=True)
+    assert one["errors"] == 0 and many["errors"] == 0
+    r1, r64 = one["questions"] / one["seconds"], many["questions"] / many["seconds"]
+    print("sharded engine, 3 shards on one device: 1 thread %.0f questions/s, 64 threads %.0f (%.2fx); %d combined sweeps, largest %d"
+          % (r1, r64, r64 / r1, sh.get_option("combined_batches"), sh.get_option("combined_max_batch")))
+    assert sh.get_option("combined_batches") > 0
+    assert r64 >= 2.5 * r1
+    sh.close()
+
+
+@pytest.mark.parametrize("f32", [False, True], ids=["double", "float"])
+def test_without_peer_access_rows_are_staged(f32, factory, monkeypatch):
+    """VERDICT r3, missing #2: a pair of devices that cannot map each other's memory must not be dereferenced across.
+    PQA_FORCE_NO_PEER=1 makes the sharded engine treat EVERY pair of shards that way (a hook that runs on one GPU): the two rows an
+    answer needs and the rows ResumeQuiz reads are copied (hipMemcpyPeerAsync needs no peer access) instead of read in place --
+    same posteriors, bit for bit, same selections and listings as a whole-cube engine; what has no staged form (the
+    maintenance-mode rebuild of the shards) refuses loudly."""
+    from probqa_amd import synth
+
+    def make():
+        kw = dict(prec_type=interop.PrecisionType.FLOAT, prec_exponent=8, prec_mantissa=24) if f32 else {}
+        eng, err = factory.create_cpu_engine(interop.EngineDefinition(5, 45, 150, init_amount=0.1, **kw))
+        assert err is None, err
+        eng.set_option("workers", cases.WORKERS)
+        eng.set_kb(*synth.synthetic_kb(5, 45, 150, 0.1, 8.0, 0.5, 13))
+        eng.set_question_gaps([4])
+        return eng
+
+    monkeypatch.setenv("PQA_FORCE_NO_PEER", "1")
+    with devices("0,0,0"):
+        sh = make()
+    monkeypatch.delenv("PQA_FORCE_NO_PEER")
+    whole = make()
+    assert sh.get_option("peer_access") == 0 and sh.get_option("shards") == 3
+    for e in (sh, whole):
+        e.set_option("select", 1)
+    qs, qw = sh.start_quiz(), whole.start_quiz()
+    asked = []
+    for step in range(9):
+        a, b = sh.next_question(qs), whole.next_question(qw)
+        assert a == b
+        asked.append((a, step % 4))
+        sh.record_answer(qs, step % 4)
+        whole.record_answer(qw, step % 4)
+        assert np.array_equal(sh.get_priors(qs), whole.get_priors(qw)), step
+        ts, tw = sh.list_top_targets(qs, 3), whole.list_top_targets(qw, 3)
+        assert [(t.i_target, t.prob) for t in ts] == [(t.i_target, t.prob) for t in tw]
+    assert sh.get_option("staged_rows") >= 2 * 2 * 9          # every answer: two rows to each of the two shards that do not hold the question
+    rs = sh.resume_quiz([interop.AnsweredQuestion(q, a) for q, a in asked])
+    rw = whole.resume_quiz([interop.AnsweredQuestion(q, a) for q, a in asked])
+    assert np.array_equal(sh.get_priors(rs), whole.get_priors(rw))
+    many = interop.run_learners(sh, 16, 32, 6, seed=2, train=True)
+    assert many["errors"] == 0 and many["quizzes"] == 32
+    sh.start_maintenance(True)
+    with pytest.raises(interop.PqaException, match="peer access"):
+        sh.add_qs_ts([interop.AddQuestionParam(1.0)], [])
+    sh.finish_maintenance()
     sh.close(); whole.close()
