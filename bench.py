@@ -186,15 +186,27 @@ def main():
         (server_idle_us) inside the timed region: 2 ms, i.e. 5.5x the 20 timed steps of the driver's run in round 1."""
         e = e or eng
         r = None
+        # One rank: every step is a synchronous call -- when it has returned there is nothing of it left on the device, and the
+        # bracket only has to say so (PqaHip_Quiesce: the engine's stream drained, the resident kernel idle but STILL THERE).
+        # Sending the resident kernel away on both sides (PqaHip_Synchronize, what a device-wide synchronisation needs) put its
+        # relaunch and two synchronisations inside 20 timed steps: 23.1 us per step where the same call's median was 21.3
+        # (VERDICT r3, weak #4).  Several ranks: the barrier and the full synchronisation, as before.
+        # (the device-wide torch.cuda.synchronize() of the several-rank bracket would sit out the idle resident kernel's time-out --
+        #  0.5 ms -- inside the timed region; PqaHip_Quiesce synchronises the stream ALL of this engine's work is on)
+        def bracket():
+            if world == 1:
+                e.quiesce()
+            else:
+                e.synchronize()
+                barrier()
+
         for _ in range(warmup):
             r = fn()
-        e.synchronize()
-        barrier()
+        bracket()
         t0 = time.perf_counter()
         for _ in range(steps):
             r = fn()
-        e.synchronize()
-        barrier()
+        bracket()
         return ctl.max_float(time.perf_counter() - t0), r
 
     def kernel_ms_of(e, qz, n_k):
@@ -414,6 +426,25 @@ def main():
                     d1 = time.perf_counter() - t1
                     one_process[key] = {"selections_per_sec": n_steps / d1, "us_per_step": 1e6 * d1 / n_steps, "shards": e1.get_option("shards"),
                                         "selected_question": int(p1)}
+                    if c is CONFIGS["S"] and not args.no_quiz_loop:
+                        # the learner loop from many client threads on the ONE sharded engine (sampled selector, training at the end
+                        # of every quiz): concurrent NextQuestion calls share one batched sweep per shard, all shards in flight
+                        e1.set_option("select", 0)
+                        e1.set_option("seed", SEED)
+                        e1.release_quiz(qz1)
+                        qlt = {}
+                        for nt in (1, 16, 64):
+                            b0 = (e1.get_option("combined_batches"), e1.get_option("combined_requests"))
+                            r = interop.run_learners(e1, nt, 300 if nt == 1 else 1500, 30, seed=SEED + nt, train=True)
+                            b1 = (e1.get_option("combined_batches"), e1.get_option("combined_requests"))
+                            qlt[str(nt)] = {"questions_per_sec": r["questions"] / r["seconds"], "quizzes": r["quizzes"], "errors": r["errors"],
+                                            "guessed_on_top": r["guessed_on_top"],
+                                            "next_questions_per_combined_sweep": (b1[1] - b0[1]) / max(1, b1[0] - b0[0])}
+                        for v in qlt.values():
+                            v["vs_one_thread"] = v["questions_per_sec"] / qlt["1"]["questions_per_sec"]
+                        qlt["shards_in_flight_max"] = e1.get_option("shards_in_flight_max")
+                        qlt["peer_access"] = e1.get_option("peer_access")
+                        one_process[key]["quiz_loop_threads"] = qlt
                     e1.close()
                 if "L1" in want:
                     # BASELINE configs[4] as ONE engine: world x 12500 questions x 100000 targets fp32, 256 quizzes per batched call;
@@ -525,6 +556,8 @@ def main():
         },
         "question_evals_per_sec": value * Q,
         "step_latency_us": latency_us,
+        # what a synchronous step spends outside the sweep: the request's way to the kernel, the answer's way back, the wrapper
+        "host_overhead_us": (1e6 * elapsed / args.steps - server_step_us["mean"]) if server_step_us else None,
         "launch_per_selection": launch_rate,
         "pipelined_selections_per_sec": pipelined,
         "batched": batched,

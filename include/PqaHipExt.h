@@ -119,6 +119,10 @@ PQACORE_API void *PqaHip_GetPriors(void *pvEngine, const int64_t iQuiz, double *
 PQACORE_API void *PqaHip_GetStream(void *pvEngine);                 /* hipStream_t */
 PQACORE_API void *PqaHip_SetStream(void *pvEngine, void *hipStream); /* run on the caller's stream, NULL = own */
 PQACORE_API void *PqaHip_Synchronize(void *pvEngine);
+/* Everything the engine has put on the device has finished, and its resident sweep kernel -- if one is serving the selections
+   (option "server") -- STAYS, idle: the bracket of a timed region of synchronous calls (PqaHip_Synchronize sends the kernel away,
+   for a caller about to synchronise the whole device). */
+PQACORE_API void *PqaHip_Quiesce(void *pvEngine);
 /* Enqueue sweep + local argmax; the 16-byte CiHipSelection is written to pOut (device or pinned host pointer). */
 PQACORE_API void *PqaHip_EnqueueSelectArgmax(void *pvEngine, const int64_t iQuiz, void *pOut);
 /* ---- exchange of the shards' winners through host memory shared by the ranks of a node (probqa_amd/dist.py).

@@ -447,6 +447,10 @@ PQACORE_API void *PqaHip_Synchronize(void *pvEngine) {
   ENGINE_OR_RETURN_ERROR;
   return ReturnErr(pEng->Synchronize());
 }
+PQACORE_API void *PqaHip_Quiesce(void *pvEngine) {
+  ENGINE_OR_RETURN_ERROR;
+  return ReturnErr(pEng->Quiesce());
+}
 PQACORE_API void *PqaHip_EnqueueSelectArgmaxFlag(void *pvEngine, const int64_t iQuiz, void *pOut, void *pFlag,
                                                  const uint64_t flagValue) {
   ENGINE_OR_RETURN_ERROR;

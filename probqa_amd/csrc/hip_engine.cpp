@@ -1771,6 +1771,14 @@ int64_t HipEngine::Combine(Error &err, int64_t iQuiz, int kind, uint64_t rnd) {
     std::lock_guard<EngineMutex> lk(_mu);
     return kind == 0 ? NextQuestionArgmaxLocked(err, iQuiz) : NextQuestionSampledLocked(err, iQuiz, rnd);
   }
+  // Nobody else is inside a quiz-level call (the usual case of the reference's wrappers: one quiz loop on one thread): straight to
+  // the single-quiz path -- no request to queue, no batch context, no flight.  Racing with a client that arrives just now is
+  // harmless: each is served by itself, under the engine's lock, as with combining switched off.
+  if (_activeCallers.load(std::memory_order_relaxed) == 1 && _extCallers == nullptr && _mu.try_lock()) {
+    std::lock_guard<EngineMutex> lk(_mu, std::adopt_lock);
+    _flushedSinceSweep.store(0, std::memory_order_relaxed);
+    return kind == 0 ? NextQuestionArgmaxLocked(err, iQuiz) : NextQuestionSampledLocked(err, iQuiz, rnd);
+  }
   SelRequest r;
   r.iQuiz = iQuiz; r.kind = kind; r.rnd = rnd;
   bool lead;
@@ -2812,6 +2820,21 @@ Error HipEngine::Synchronize() {
   hipSetDevice(_device);
   StopServer();
   HIP_TRY(hipStreamSynchronize(_stream));
+  _mu.busy = false;
+  _pendingRecordOp = 0;
+  return Error();
+}
+
+// The same guarantee without sending the resident kernel away: the engine's stream is drained and the resident sweep has finished
+// the step it was given (it stays, polling for the next request).  What brackets a timed region of synchronous selections: every
+// one of them has returned its result, nothing of theirs is left on the device -- and the next selection finds the kernel it would
+// have found, not a relaunch.
+Error HipEngine::Quiesce() {
+  std::lock_guard<EngineMutex> lk(_mu);
+  hipSetDevice(_device);
+  { Error fe = FlushUpdates(); if (!fe.ok()) return fe; }
+  HIP_TRY(hipStreamSynchronize(_stream));
+  ServerQuiesce();
   _mu.busy = false;
   _pendingRecordOp = 0;
   return Error();

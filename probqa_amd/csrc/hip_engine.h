@@ -183,6 +183,7 @@ class IEngine {
   virtual hipStream_t GetStream() const = 0;
   virtual Error SetStream(hipStream_t s) = 0;
   virtual Error Synchronize() = 0;
+  virtual Error Quiesce() = 0;
   virtual Error EnqueueSelectArgmax(int64_t iQuiz, void *pOut) = 0;
   virtual Error EnqueueSelectArgmaxFlag(int64_t iQuiz, void *pOut, void *pFlag, uint64_t flagValue) = 0;
   virtual Error EnqueueEval(int64_t iQuiz) = 0;
@@ -246,6 +247,7 @@ class HipEngine : public IEngine {
   hipStream_t GetStream() const override { return _stream; }
   Error SetStream(hipStream_t s) override;
   Error Synchronize() override;
+  Error Quiesce() override;
   Error EnqueueSelectArgmax(int64_t iQuiz, void *pOut) override;
   Error EnqueueSelectArgmaxFlag(int64_t iQuiz, void *pOut, void *pFlag, uint64_t flagValue) override;
   Error EnqueueEval(int64_t iQuiz) override;

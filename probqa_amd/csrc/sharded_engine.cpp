@@ -197,6 +197,12 @@ class ShardedEngine final : public IEngine {
     if (!e.ok()) return e;
     return AllLocked([&](HipEngine &sh) { return sh.Synchronize(); });
   }
+  Error Quiesce() override {
+    std::lock_guard<OpMutex> lk(_opMu);
+    Error e = FlushAnswers();
+    if (!e.ok()) return e;
+    return AllLocked([&](HipEngine &sh) { return sh.Quiesce(); });
+  }
   Error EnqueueSelectArgmax(int64_t, void *) override { return NotSharded("EnqueueSelectArgmax"); }
   Error EnqueueSelectArgmaxFlag(int64_t, void *, void *, uint64_t) override { return NotSharded("EnqueueSelectArgmaxFlag"); }
   Error EnqueueEval(int64_t iQuiz) override {

@@ -134,6 +134,7 @@ HIP_EXPORTS = {
     "PqaHip_GetStream": (_vp, [_vp]),
     "PqaHip_SetStream": (_vp, [_vp, _vp]),
     "PqaHip_Synchronize": (_vp, [_vp]),
+    "PqaHip_Quiesce": (_vp, [_vp]),
     "PqaHip_EnqueueSelectArgmax": (_vp, [_vp, _i64, _vp]),
     "PqaHip_EnqueueSelectArgmaxFlag": (_vp, [_vp, _i64, _vp, _vp, ctypes.c_uint64]),
     "PqaHip_HostRegister": (_vp, [_vp, _i64, _pvp]),
@@ -309,6 +310,18 @@ class PqaError:
             _lib.CiReleaseString(p)
 
 
+class _ErrSlot(__import__("threading").local):
+    """The `void **ppError` argument of the value-returning calls, one per thread (ctypes releases the GIL inside a call): allocating
+    a fresh c_void_p and its reference for every NextQuestion is a quarter of a microsecond of a 21 us step."""
+
+    def __init__(self):
+        self.err = ctypes.c_void_p()
+        self.ref = ctypes.byref(self.err)
+
+
+_err_slot = _ErrSlot()
+
+
 def _check(c_err, throw: bool = True) -> Optional[PqaError]:
     if not c_err:       # (the common case of every call: nothing to wrap)
         return None
@@ -420,9 +433,10 @@ class PqaEngine:
         return i_quiz
 
     def next_question(self, i_quiz: int) -> int:
-        c_err = ctypes.c_void_p()
-        q = _lib.PqaEngine_NextQuestion(self.c_engine, ctypes.byref(c_err), i_quiz)
-        _check(c_err.value)
+        slot = _err_slot
+        q = _lib.PqaEngine_NextQuestion(self.c_engine, slot.ref, i_quiz)
+        if slot.err.value:
+            _check(slot.err.value)
         return q
 
     def record_answer(self, i_quiz: int, i_answer: int, throw: bool = True) -> Optional[PqaError]:
@@ -544,9 +558,10 @@ class PqaEngine:
         return out
 
     def next_question_argmax(self, i_quiz: int) -> int:
-        c_err = ctypes.c_void_p()
-        q = _lib.PqaEngine_NextQuestionArgmax(self.c_engine, ctypes.byref(c_err), i_quiz)
-        _check(c_err.value)
+        slot = _err_slot
+        q = _lib.PqaEngine_NextQuestionArgmax(self.c_engine, slot.ref, i_quiz)
+        if slot.err.value:
+            _check(slot.err.value)
         return q
 
     def next_question_argmax_batch(self, quizzes) -> List[int]:
@@ -612,6 +627,10 @@ class PqaEngine:
 
     def synchronize(self):
         _check(_lib.PqaHip_Synchronize(self.c_engine))
+
+    def quiesce(self):
+        """Everything this engine put on the device has finished; a resident sweep kernel stays (include/PqaHipExt.h)."""
+        _check(_lib.PqaHip_Quiesce(self.c_engine))
 
     def enqueue_select_argmax(self, i_quiz: int, out_ptr: int = 0):
         _check(_lib.PqaHip_EnqueueSelectArgmax(self.c_engine, i_quiz, ctypes.c_void_p(out_ptr)))
