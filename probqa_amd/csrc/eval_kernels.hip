@@ -26,8 +26,14 @@
 namespace pqa {
 
 static __device__ double gLog2Table[kLog2TableDoubles];  // {log2(midpoint), 1/(2*midpoint)} per bucket
+// Entry 0 as the REFERENCE has it (SRVectMath.cpp:31,42: log2 of bucket 0's midpoint times 9.9999999999999927e-01); the table's
+// own entry 0 is re-seated for the division-free log2hot (hip_engine.cpp).  Used by log2hot_ref below.
+static __device__ double gLog2Entry0Ref;
 
 hipError_t UploadLog2Table(const double *hostTable) {
+  const double entry0 = std::log2(1.0 + 0x1p-11) * 9.9999999999999927e-01;
+  const hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(gLog2Entry0Ref), &entry0, sizeof(double));
+  if (e != hipSuccess) return e;
   return hipMemcpyToSymbol(HIP_SYMBOL(gLog2Table), hostTable, kLog2TableDoubles * sizeof(double));
 }
 
@@ -39,7 +45,8 @@ struct EvalArgs {
   const uint32_t *qgap;
   const uint32_t *asked;
   double *priority;
-  int64_t K, ldT, qFirst, qLimit;
+  double *poleScratch;   // KbView::poleScratch (single-quiz launches), or null
+  int64_t K, T, ldT, qFirst, qLimit;
   double vCompTail;  // ln(sqrt 2) / (nValidTargets + 1)^2, PqaCore/CEEvalQsSubtaskConsider.cpp:191
   FusedSelect fs;
   const QuizSlot *slots;  // batched launch: per-quiz pointers, indexed by blockIdx.y (nullptr: a single quiz)
@@ -190,9 +197,12 @@ __device__ __forceinline__ void fused_select(const EvalArgs &a, Best mine, int l
 }
 
 // One element pair of pass 2 (:95-128).  lh: likelihoods, id: 1/D, pr: masked priors.
+// hiMax: the largest high word of a posterior element seen so far (they are >= 0: their bit patterns order like the numbers) --
+// the watch for rows at the pole of the lack term (pole_fix below).
 __device__ __forceinline__ void pass2_pair(double2 lh, double2 id, double2 pr, double invWk, const double *tbl,
-                                           double &hW, double &v, double &accL) {
+                                           double &hW, double &v, double &accL, uint32_t &hiMax) {
   const double p0 = lh.x * invWk, p1 = lh.y * invWk;           // :97
+  hiMax = max(hiMax, max((uint32_t)(d2u(p0) >> 32), (uint32_t)(d2u(p1) >> 32)));
   const double l20 = log2hot(p0, tbl), l21 = log2hot(p1, tbl); // :106 (gap lanes: p = 0 -> -1023, contributes -0)
   hW = fma(lh.x, l20, hW);                                     // :113-114 weighted by W_k (see eval_epilogue)
   hW = fma(lh.y, l21, hW);
@@ -207,6 +217,140 @@ __device__ __forceinline__ void pass2_pair(double2 lh, double2 id, double2 pr, d
   const double d0 = p0 - pr.x, d1 = p1 - pr.y;                 // :119
   v = fma(d0, d0, v);                                          // :126-127
   v = fma(d1, d1, v);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Rows at the pole of the lack term.  lack = -sum invD^2 / log2(p) (:117) has a pole at p -> 1: with a
+// posterior element at p = 1 - 1e-7, |log2 p| ~ 1e-7, and the last place of p = l * (1 / W_k) -- i.e. of W_k, i.e. of the ORDER
+// W_k was summed in -- moves log2 p by 1.6e-16 absolute and the priority by 1.6e-9 relative: above the 1e-9 the parity tests hold
+// the sweep to (three of round 3's 13 700 soak cases).  The sweep's W_k is a plain per-lane sum and a butterfly; the reference's
+// is four serial Kahan lanes down the row (SRAccumVectDbl256.h:40-46) and PreciseSum (:62-92), which no wave reproduces at speed
+// (a row of T targets is T / 4 DEPENDENT Kahan steps -- measured in round 4: every question of a late quiz redone in
+// that order costs 5 - 8 sweeps).  But where ONE likelihood carries all but a sliver of the row's sum -- exactly the rows in
+// question -- the reference's result IS the correctly rounded sum: its compensation captures the tail exactly
+// (tests/test_oracle.py: no exception in 10^5 such rows; ordinary rows differ by a unit in 10 - 25 % of cases).
+//
+// So: the sweep WATCHES (one v_max3_u32 per element pair: the largest posterior element of the question) and otherwise runs as it
+// always ran.  A question with an element >= 1 - 2^-17 -- a hundred times further from the pole than where the deviation reaches
+// 1e-9 -- also leaves its sums in memory (KbView::poleScratch), and once the workgroup's stream has ended pole_fix goes over its
+// rows again, all threads side by side: W_k as an error-free sum per thread (TwoSum) folded with compensation -- the correctly
+// rounded sum -- and the row's largest likelihood with its 1/D; for the element that is within 2^-17 of 1, Log2Hot by the
+// reference's operation sequence (true quotient, its own table entry 0: log2hot_ref) and the lack quotient as an exact division
+// replace what pass 2 had added for it.  That element's terms are then the oracle's.  A late quiz -- the posterior on one target --
+// has such a row in most questions: the sweep then costs 2 - 4 times its usual time (every such question's rows are read again).
+// Tried on the way (round 4, all measured): the reference's order itself at the end of the sweep (exact; 5 - 8 sweeps per sweep
+// in a late quiz: T / 4 dependent steps per row, the rows re-read twice); the compensated sum and the correction inside the row
+// loop, from the registers (nothing re-read, +25 - 70 % in a late quiz, but the blocks between pass 1 and pass 2 cost the
+// loop its registers: +10 % at 1000 targets, +50 % at 4000 in EVERY state); the fix as a called function (the scratch segment the
+// call needs: +13 % at 1000 targets).
+// ------------------------------------------------------------------------------------------------------------------
+constexpr uint32_t kNearOneHi = 0x3FEFFFF0u;   // high word of 1 - 2^-17
+constexpr int kSusMax = 126;                   // suspects a workgroup lists per sweep (further ones keep the sweep's own values)
+constexpr int kSusDoubles = 64;                // LDS: two flag words (by question parity) + the list
+
+__device__ __forceinline__ double log2hot_ref(double x) {      // SRVectMath.h:87-135, operation for operation (oracle: orc_log2hot)
+  const uint64_t ux = d2u(x);
+  const double z = u2d((ux & ~kExpMaskUp) | kExp0Up);          // :88-89
+  const int32_t high32 = (int32_t)(ux >> 32);                  // :92-94
+  const int32_t normExps = (high32 >> 20) - 1023;              // :97-98
+  const int32_t idx = (high32 >> 10) & 1023;                   // :101-102
+  const double y = idx == 0 ? gLog2Entry0Ref : gLog2Table[2 * idx];   // :105-106
+  const double m = u2d((1ULL << 41) | (d2u(z) & ~((1ULL << 42) - 1)));   // :108
+  const double t = div_fast(z - m, z + m);                     // :111-114 (the exact quotient: div_nr, pqa_device.h)
+  const double t2 = t * t;                                     // :115
+  const double t3 = t * t2;                                    // :117
+  const double terms01 = fma(1.0 / 3, t3, t);                  // :118
+  const double log2z = fma(terms01, 2.8853900817779268147198493620038, y);   // :122
+  return log2z + (double)normExps;                             // :131-133
+}
+
+struct PoleArgs {
+  const double *cube, *prior;
+  const uint32_t *tgap;
+  double *priority, *scratch;
+  TaggedPriority *hostPriority;   // non-null: the priorities are handed to the host as tagged records (flush_pending)
+  uint64_t hostTag;
+  int64_t K, T, ldT, qFirst;
+  double vCompTail;
+};
+
+// nSus questions of this workgroup (local indices in `list`) whose largest posterior element is within 2^-17 of 1; their sums as
+// the sweep formed them are in args.scratch.  All threads; red: LDS, 4 x waves doubles; best: the workgroup's running argmax (LDS).
+template <bool COH>
+__device__ __forceinline__ void pole_fix(const PoleArgs &g, const uint32_t *list, int nSus, double *red, Best *best) {
+  const int tid = threadIdx.x, nThreads = blockDim.x, lane = tid % kWave, wave = tid / kWave, nWaves = nThreads / kWave;
+  const int64_t K = g.K, ldT = g.ldT, nT = 4 * ((g.T + 3) >> 2);
+  auto prior_at = [&](int64_t t) { return COH ? __hip_atomic_load(g.prior + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : g.prior[t]; };
+  for (int s2 = 0; s2 < nSus; s2++) {
+    const int64_t qLocal = list[s2];
+    const double *qBase = g.cube + (g.qFirst + qLocal) * (K + 1) * ldT, *rowD = qBase + K * ldT;
+    double *rec = g.scratch + qLocal * (2 * K + 2);            // W_k [K] | W_k sqrt(V_k) [K] | sum l log2 p | lack sum
+    double dH = 0.0, dL = 0.0;                                 // (thread 0: what the near-1 elements change)
+    for (int64_t k = 0; k < K; k++) {
+      const double *rowA = qBase + k * ldT;
+      Comp c{0.0, 0.0};
+      double mx = 0.0, mxId = 0.0;
+      for (int64_t tb = tid; tb < nT; tb += 4 * nThreads) {    // (four targets per thread and round, their loads requested together)
+        double av[4], dv[4], pv[4];
+        bool live[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          const int64_t t = tb + e * nThreads;
+          live[e] = t < nT && !bit_test(g.tgap, t);
+          const int64_t tc = live[e] ? t : 0;
+          av[e] = rowA[tc];
+          dv[e] = rowD[tc];
+          pv[e] = prior_at(tc);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          if (!live[e]) continue;
+          const double id = div_nr(1.0, dv[e]);                // :74
+          const double l = (av[e] * id) * pv[e];               // :81-82, as pass 1 forms it
+          c = comp_merge(c, Comp{l, 0.0});
+          if (l > mx) { mx = l; mxId = id; }
+        }
+      }
+      c = wave_sum_comp(c);
+      double wmx = mx;
+      for (int m = kWave / 2; m >= 1; m >>= 1) wmx = fmax(wmx, __shfl_xor(wmx, m, kWave));
+      if (lane == 0) { red[2 * wave] = c.s; red[2 * wave + 1] = c.c; red[2 * nWaves + 2 * wave] = 0.0; red[2 * nWaves + 2 * wave + 1] = 0.0; }
+      if (mx == wmx && mx > 0.0) { red[2 * nWaves + 2 * wave] = mx; red[2 * nWaves + 2 * wave + 1] = mxId; }   // (behind lane 0's zeros)
+      __syncthreads();
+      if (tid == 0) {
+        Comp tot{red[0], red[1]};
+        double cand = red[2 * nWaves], candId = red[2 * nWaves + 1];
+        for (int w = 1; w < nWaves; w++) {
+          tot = comp_merge(tot, Comp{red[2 * w], red[2 * w + 1]});
+          if (red[2 * nWaves + 2 * w] > cand) { cand = red[2 * nWaves + 2 * w]; candId = red[2 * nWaves + 2 * w + 1]; }
+        }
+        const double Wx = tot.s + tot.c;                       // :88 -- the correctly rounded sum of the row's likelihoods
+        const double invWx = div_nr(1.0, Wx);                  // :91
+        if (cand > 0.0 && (uint32_t)(d2u(cand * invWx) >> 32) >= kNearOneHi) {
+          const double Wf = rec[k];                            // the sweep's W_k
+          const double lFast = log2hot(cand * div_nr(1.0, Wf), nullptr);   // what pass 2 took for this element (the table is at LDS address 0)
+          const double lRef = log2hot_ref(cand * invWx);       // :106
+          dH += cand * lRef - cand * lFast;                    // :113-114
+          const double id2 = candId * candId;
+          dL += div_fast(id2, lRef) - div_fast(id2, lFast);    // :117 (pass 2's quotient was within 2^-48.8 of the second one)
+          rec[K + k] = Wx * div_fast(rec[K + k], Wf);          // W_k sqrt(V_k): the velocity sum stays the sweep's
+          rec[k] = Wx;
+        }
+      }
+      __syncthreads();
+    }
+    if (tid == 0) {
+      const double pri = eval_epilogue(rec, -(rec[2 * K] + dH), rec + K, K, rec[2 * K + 1] + dL, g.vCompTail);  // :130
+      store_priority(g.priority + qLocal, pri);
+      if (g.hostPriority != nullptr) {
+        typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+        const uint64_t w0 = d2u(pri), w1 = g.hostTag;
+        const u4 x = {(unsigned)w0, (unsigned)(w0 >> 32), (unsigned)w1, (unsigned)(w1 >> 32)};
+        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(g.hostPriority + qLocal), "v"(x) : "memory");
+      }
+      best_offer(best[0], pri, qLocal);
+    }
+  }
 }
 
 // LDS-DMA: 16 bytes per lane from global memory straight into LDS, no destination VGPRs (buffer_load_dwordx4 ... offen lds:
@@ -236,7 +380,7 @@ __device__ __forceinline__ void dma16(dma_rsrc_t rsrc, unsigned byteOffset, unsi
 // memory pipe never idles at a row or question boundary.
 //
 // LDS (doubles): log2 table [2048] | W exchange [2][WPQ] | partials [2][K+2][WPQ] | pending [kPend][2K+3] |
-//                running argmax [64][2] | prior [ldT + 2] if PRLDS, else (KiB-aligned) the mD landing row [NP*64*WPQ pairs] |
+//                running argmax [64][2] | suspects of the pole watch [kSusDoubles] | prior [ldT + 2] if PRLDS, else (KiB-aligned) the mD landing row [NP*64*WPQ pairs] |
 //                deferred lane sums [K+2][64*WPQ] (eval_defers_sums) | the resident kernel's request line [8]
 //   partial rows: V_k (K rows), sum W_k*H_k (1 row), lack (1 row); the leading [2] alternates per question.
 //   pending: per finished question W_k[K], V_k[K], sum WH, lack, question index.  The scalar epilogue (exp2, log,
@@ -247,13 +391,13 @@ constexpr int kPend = 32;
 
 // (+ for register-prior shapes: the landing row of the next question's mD, np*64*wpq pairs, on a KiB boundary)
 __host__ __device__ constexpr size_t eval_lds_fixed_doubles(int wpq, int64_t K) {
-  return kLog2TableDoubles + 2 * (size_t)wpq + 2 * (size_t)(K + 2) * wpq + (size_t)kPend * (2 * (size_t)K + 3) + 2 * kWave;
+  return kLog2TableDoubles + 2 * (size_t)wpq + 2 * (size_t)(K + 2) * wpq + (size_t)kPend * (2 * (size_t)K + 3) + 2 * kWave + kSusDoubles;
 }
 __host__ __device__ constexpr size_t eval_md_row_offset_bytes(int wpq, int64_t K) {
   return (eval_lds_fixed_doubles(wpq, K) * sizeof(double) + 1023) / 1024 * 1024;
 }
 __host__ __device__ constexpr size_t eval_lds_doubles(int wpq, int64_t K, bool prLds, int64_t ldT) {
-  return kLog2TableDoubles + 2 * (size_t)wpq + 2 * (size_t)(K + 2) * wpq + (size_t)kPend * (2 * (size_t)K + 3) + 2 * kWave +
+  return kLog2TableDoubles + 2 * (size_t)wpq + 2 * (size_t)(K + 2) * wpq + (size_t)kPend * (2 * (size_t)K + 3) + 2 * kWave + kSusDoubles +
          (prLds ? (size_t)ldT + 2 : 0);
 }
 
@@ -324,7 +468,7 @@ __device__ __forceinline__ double2 load_pair(const double2 *p) {
 // workgroup also lists the posterior's best targets right away (ListTopTargets is the client's next call), and workgroup 0, as the
 // finisher that has seen every workgroup's record (so nobody reads the old prior any more), stores the posterior over the old prior
 // at the end.
-template <int WPQ, int NP, bool PRLDS, bool SERVER, bool DEFER, bool FUSE = false>
+template <int WPQ, int NP, bool PRLDS, bool SERVER, bool DEFER, bool FUSE = false, bool POLE = false>
 __device__ __forceinline__ void sweep_body(EvalArgs a, bool copyTable) {
   constexpr int kThreads = WPQ * kWave;
   constexpr int NPR = PRLDS ? 1 : NP;
@@ -336,7 +480,8 @@ __device__ __forceinline__ void sweep_body(EvalArgs a, bool copyTable) {
   double *partAll = redW + 2 * WPQ;
   double *pend = partAll + 2 * (K + 2) * WPQ;
   Best *bestLds = reinterpret_cast<Best *>(pend + kPend * (2 * K + 3));  // wave 0's per-lane running argmax
-  double2 *prLds = reinterpret_cast<double2 *>(bestLds + kWave);
+  uint32_t *susWords = reinterpret_cast<uint32_t *>(bestLds + kWave);   // [0], [1]: the question of that parity has a row at the pole; [2..): the list
+  double2 *prLds = reinterpret_cast<double2 *>(reinterpret_cast<double *>(bestLds + kWave) + kSusDoubles);
   // landing row of the NEXT question's mD (register-prior shapes): lane-private 16-byte slots, slot j of thread tid at
   // mdRow[j*kThreads + tid]; filled by LDS-DMA while the current question's last answer is in pass 2
   constexpr bool kMdLds = !PRLDS;
@@ -477,6 +622,7 @@ __device__ __forceinline__ void sweep_body(EvalArgs a, bool copyTable) {
     }
     return q;
   };
+  if (tid < 2) susWords[tid] = 0;
   int64_t q = q0;
   if (haveQ0 && ((((q0Gap | q0Asked) >> (q0 & 31)) & 1u) || (FUSE && q0 == a.updQuestion))) {     // the first candidate is skipped: restart the stream
     q = next_valid(q0);
@@ -484,7 +630,15 @@ __device__ __forceinline__ void sweep_body(EvalArgs a, bool copyTable) {
   }
   __syncthreads();
 
-  int phase = 0, qpar = 0, nPend = 0;
+  int phase = 0, qpar = 0, nPend = 0, nSus = 0;
+  // The pole watch (pole_fix) exists for the launched sweeps over rows of up to 4096 targets (template POLE: the launcher takes the
+  // variant when the engine gave it KbView::poleScratch -- option pole_fix, default on): there it costs 2.5 - 5 % (one v_max3_u32 per
+  // element pair and what the fix's presence does to the loop's scalar registers).  The long-row shapes sit at the edge of the
+  // register file (the watch alone cost 10000 x 5 x 10000 3.7 %), the resident kernel's step is the headline of bench.py (+6.5 %
+  // with it: 16.9 -> 18.0 us) and hands out only the selected question: both keep the sweep's own sums -- and the conditioning
+  // bound of DESIGN section 5.
+  constexpr bool kPoleShape = POLE && 128 * WPQ * NP <= 4096 && !(NP == 4 && !DEFER);   // (the two 4-pair shapes without deferred sums -- grid.y batches, dozens of answers -- are a register short of three waves)
+  const bool poleWatch = kPoleShape && a.poleScratch != nullptr;
   if (wave == 0) bestLds[lane] = Best{0.0, -1};   // only wave 0 ever touches these
   while (q < a.qLimit) {
     const int64_t qn = next_valid(q + gridDim.x);
@@ -515,6 +669,7 @@ __device__ __forceinline__ void sweep_body(EvalArgs a, bool copyTable) {
     double *part = partAll + qpar * (nPart * WPQ);
     double *rec = pend + nPend * recLen;
     double accL = 0, hW = 0;
+    uint32_t hiMax = 0;
     for (int64_t k = 0; k < K; k++) {
       // ---- pass 1 (:66-87): likelihoods into registers, W_k; each consumed pair is refilled from the next stream row
       double2 lh[NP];
@@ -567,7 +722,7 @@ __device__ __forceinline__ void sweep_body(EvalArgs a, bool copyTable) {
       for (int j = 0; j < NP; j++) {
         double2 pv;
         if constexpr (PRLDS) pv = prLds[min(tid + j * kThreads, nPairs)]; else pv = pr[j];
-        pass2_pair(lh[j], invD[j], pv, invWk, tbl, hW, v, accL);
+        pass2_pair(lh[j], invD[j], pv, invWk, tbl, hW, v, accL, hiMax);
         // Pin the accumulators here: without an opaque use the compiler sinks the whole lack chain (and every log2 it
         // needs) below the loop, which costs 8 live VGPRs per pair; and keep the interleave to one pair at a time.
         asm volatile("" : "+v"(accL), "+v"(hW), "+v"(v));
@@ -584,12 +739,15 @@ __device__ __forceinline__ void sweep_body(EvalArgs a, bool copyTable) {
         }
       }
     }
+    bool suspect = false;   // workgroup-uniform: a posterior element of this question is within 2^-17 of 1
     if constexpr (kDefer) {
       // (the dump is single-buffered: a wave that runs ahead writes it again only behind the next question's first W
       //  barrier, which no wave passes before every wave has read here)
       vdump[K * kThreads + tid] = hW;
       vdump[(K + 1) * kThreads + tid] = accL;
+      if constexpr (kPoleShape) { if (hiMax >= kNearOneHi) susWords[qpar] = 1; }   // (rare: see pole_fix)
       __syncthreads();
+      if constexpr (kPoleShape) suspect = poleWatch && susWords[qpar] != 0 && nSus < kSusMax;
       // every 32 lanes take one of the K + 2 sums: threads/32 partials each, then a 32-lane butterfly
       constexpr int kGroups = kThreads / 32;
       const int l32 = tid & 31;
@@ -607,7 +765,16 @@ __device__ __forceinline__ void sweep_body(EvalArgs a, bool copyTable) {
         if (r < K) acc = rec[r] * sqrt(acc);                   // :156-157
         if (l32 == 0) rec[K + r] = acc;
       }
-      if (tid == 0) reinterpret_cast<int64_t *>(rec)[2 * K + 2] = q;
+      if (tid == 0) {
+        reinterpret_cast<int64_t *>(rec)[2 * K + 2] = q;
+        susWords[qpar ^ 1] = 0;                                // (the other parity's flag: read by everybody before this question's barrier, set again only behind the next question's)
+        if (suspect) susWords[2 + nSus] = (uint32_t)(q - a.qFirst);
+      }
+      if (suspect) {
+        // the question's sums as they are, for pole_fix (the question is queued like any other: its priority stands until then)
+        __syncthreads();
+        for (int i = tid; i < 2 * (int)K + 2; i += kThreads) a.poleScratch[(q - a.qFirst) * (2 * K + 2) + i] = rec[i];
+      }
       if (nPend + 1 == kPend) {
         __syncthreads();                                       // the records of other waves
         if (wave == 0) flush_pending(a, pend, kPend, lane, bestLds[lane]);
@@ -619,7 +786,9 @@ __device__ __forceinline__ void sweep_body(EvalArgs a, bool copyTable) {
         part[K * WPQ + wave] = hW;
         part[(K + 1) * WPQ + wave] = accL;
       }
+      if constexpr (kPoleShape) { if (hiMax >= kNearOneHi) susWords[qpar] = 1; }   // (rare: see pole_fix)
       if constexpr (WPQ > 1) __syncthreads();
+      if constexpr (kPoleShape) suspect = poleWatch && susWords[qpar] != 0 && nSus < kSusMax;
       if (wave == 0) {
         // combine the waves' partials in wave order, one partial row per lane, and queue the question
         for (int r = lane; r < nPart; r += kWave) {
@@ -628,20 +797,45 @@ __device__ __forceinline__ void sweep_body(EvalArgs a, bool copyTable) {
           if (r < K) acc = rec[r] * sqrt(acc);                   // :156-157, one answer per lane
           rec[K + r] = acc;
         }
-        if (lane == 0) reinterpret_cast<int64_t *>(rec)[2 * K + 2] = q;
+        if (lane == 0) {
+          reinterpret_cast<int64_t *>(rec)[2 * K + 2] = q;
+          susWords[qpar ^ 1] = 0;
+          if (suspect) susWords[2 + nSus] = (uint32_t)(q - a.qFirst);
+        }
+        if (suspect)   // (the record is this wave's own work: no barrier)
+          for (int i = lane; i < 2 * (int)K + 2; i += kWave) a.poleScratch[(q - a.qFirst) * (2 * K + 2) + i] = rec[i];
         if (nPend + 1 == kPend) flush_pending(a, pend, kPend, lane, bestLds[lane]);
       }
     }
+    if (suspect) nSus++;
     nPend = nPend + 1 == kPend ? 0 : nPend + 1;
     qpar ^= 1;
     q = qn;
   }
   if constexpr (kDefer) __syncthreads();                       // the last questions' records, written by other waves
   bool *allReported = reinterpret_cast<bool *>(redW);         // (the W exchange buffer is free now)
-  if (wave == 0) {
-    flush_pending(a, pend, nPend, lane, bestLds[lane]);
-    fused_select<SERVER>(a, bestLds[lane], lane, allReported);
+  if (wave == 0) flush_pending(a, pend, nPend, lane, bestLds[lane]);
+  if constexpr (kPoleShape) if (nSus > 0) {
+    // ---- this workgroup's questions with a row at the pole of the lack term: their near-1 elements the reference's way
+    PoleArgs g{a.cube, a.prior, a.tgap, a.priority, a.poleScratch,
+               a.fs.hostPriority != nullptr && a.fs.sampleSubtasks > 0 ? a.fs.hostPriority : nullptr, a.fs.seqValue, K, a.T, ldT, a.qFirst, a.vCompTail};
+    if constexpr (FUSE) {
+      // (the new posterior is in this launch's registers until workgroup 0 stores it at the very end: the lanes' own pairs go to
+      //  the mD landing row, free by now)
+      double *stash = reinterpret_cast<double *>(mdRow);
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < NP; j++) {
+        const int p = tid + j * kThreads;
+        if (p < nPairs) { stash[2 * p] = pr[j].x; stash[2 * p + 1] = pr[j].y; }
+      }
+      g.prior = stash;
+    }
+    __syncthreads();                                           // (the suspects' sums are in memory, their first priorities stored)
+    pole_fix<SERVER>(g, susWords + 2, nSus, partAll, bestLds);
+    __syncthreads();
   }
+  if (wave == 0) fused_select<SERVER>(a, bestLds[lane], lane, allReported);
   if constexpr (FUSE) {
     if (blockIdx.x == 0) {
       // every workgroup has reported (fused_select above has seen their records): the old prior has no readers left
@@ -695,23 +889,23 @@ __device__ __forceinline__ void sweep_body(EvalArgs a, bool copyTable) {
 // DEFER: the question's lane sums leave the row loop (eval_defers_sums) -- the default where the shape has a deferred form
 // and the (K + 2) x threads doubles fit beside the rest of its LDS; a knowledge base with dozens of answers per question
 // falls back to the form without.
-template <int WPQ, int NP, bool PRLDS, bool DEFER>
+template <int WPQ, int NP, bool PRLDS, bool DEFER, bool POLE = false>
 __global__ __launch_bounds__(WPQ * 64) void eval_questions_f64(EvalArgs a) {
   select_quiz(a);
-  sweep_body<WPQ, NP, PRLDS, false, DEFER>(a, true);
+  sweep_body<WPQ, NP, PRLDS, false, DEFER, false, POLE>(a, true);
 }
 // The same kernel held to three waves per SIMD (168 VGPRs): the two 4-pair shapes need 169 with the deferred sums, and a
 // register spilled costs them less than a wave of occupancy does.
-template <int WPQ, int NP, bool PRLDS, bool DEFER>
+template <int WPQ, int NP, bool PRLDS, bool DEFER, bool POLE = false>
 __global__ __launch_bounds__(WPQ * 64) __attribute__((amdgpu_waves_per_eu(3, 3))) void eval_questions_f64_occ3(EvalArgs a) {
   select_quiz(a);
-  sweep_body<WPQ, NP, PRLDS, false, DEFER>(a, true);
+  sweep_body<WPQ, NP, PRLDS, false, DEFER, false, POLE>(a, true);
 }
 
 // RecordAnswer's posterior update + the sweep of the NextQuestion that follows, one launch (sweep_body: FUSE)
-template <int WPQ, int NP, bool DEFER>
+template <int WPQ, int NP, bool DEFER, bool POLE = false>
 __global__ __launch_bounds__(WPQ * 64) void eval_questions_f64_upd(EvalArgs a) {
-  sweep_body<WPQ, NP, false, false, DEFER, true>(a, true);
+  sweep_body<WPQ, NP, false, false, DEFER, true, POLE>(a, true);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -871,6 +1065,7 @@ __global__ __launch_bounds__(256) void eval_questions_f64_stream(EvalArgs a) {
     double *wk = wkAll + qpar * K;
     double *part = partAll + qpar * (nPart * WPQ);
     double accL = 0, hW = 0;
+    uint32_t hiUnused = 0;   // (the re-reading fallback keeps its own sums at the pole: rows beyond 16384 targets)
     for (int64_t k = 0; k < K; k++) {
       const double2 *rowA = reinterpret_cast<const double2 *>(qBase + k * ldT);
       double s0 = 0, c0 = 0, s1 = 0, c1 = 0;
@@ -912,7 +1107,7 @@ __global__ __launch_bounds__(256) void eval_questions_f64_stream(EvalArgs a) {
         pv.y = g1 ? 0.0 : pv.y;
         lh.x = (av.x * id.x) * pv.x;
         lh.y = (av.y * id.y) * pv.y;
-        pass2_pair(lh, id, pv, invWk, tbl, hW, v, accL);
+        pass2_pair(lh, id, pv, invWk, tbl, hW, v, accL, hiUnused);
       }
       v = wave_sum(v);
       if (lane == 0) {
@@ -1019,6 +1214,7 @@ __global__ __launch_bounds__(256) void batch_rerank_kernel(const E *__restrict__
   const int64_t nPairs = ldT >> 1;
   int phase = 0;
   double accL = 0, hW = 0;
+  uint32_t hiUnused = 0;   // (Float engines: the fp32 tolerance covers what the summation order moves)
   for (int64_t k = 0; k < K; k++) {
     const E *rowA = qBase + k * ldT;
     double s0 = 0, c0 = 0, s1 = 0, c1 = 0;
@@ -1048,7 +1244,7 @@ __global__ __launch_bounds__(256) void batch_rerank_kernel(const E *__restrict__
       pv.y = g1 ? 0.0 : prior[2 * p + 1];
       lh.x = ((double)rowA[2 * p] * id.x) * pv.x;
       lh.y = ((double)rowA[2 * p + 1] * id.y) * pv.y;
-      pass2_pair(lh, id, pv, invWk, tbl, hW, v, accL);
+      pass2_pair(lh, id, pv, invWk, tbl, hW, v, accL, hiUnused);
     }
     v = wave_sum(v);
     if (lane == 0) {
@@ -1188,12 +1384,16 @@ constexpr size_t eval_base_lds_bytes(int64_t K, int64_t ldT) {
                : eval_md_row_offset_bytes(WPQ, K) + (size_t)NP * WPQ * kWave * 16;
 }
 
-template <int WPQ, int NP, bool PRLDS, bool DEFER>
+template <int WPQ, int NP, bool PRLDS, bool DEFER, bool POLE = false>
 hipError_t launch_reg_form(const EvalArgs &args, int64_t nQ, int nBatch, hipStream_t stream) {
+  // the variant with the pole watch (sweep_body: kPoleShape) where the shape has one and the engine asked for it
+  if constexpr (!POLE && 128 * WPQ * NP <= 4096 && !(NP == 4 && !DEFER)) {
+    if (args.poleScratch != nullptr) return launch_reg_form<WPQ, NP, PRLDS, DEFER, true>(args, nQ, nBatch, stream);
+  }
   const size_t shmem = eval_base_lds_bytes<WPQ, NP, PRLDS>(args.K, args.ldT) + (DEFER ? eval_deferred_bytes(WPQ, NP, args.K, PRLDS) : 0);
   auto kern = [] {
-    if constexpr (NP == 4 && WPQ == 4 && DEFER) return eval_questions_f64_occ3<WPQ, NP, PRLDS, DEFER>;   // (5 and 6 pairs: slower with the spills)
-    else return eval_questions_f64<WPQ, NP, PRLDS, DEFER>;
+    if constexpr (NP == 4 && WPQ == 4 && DEFER) return eval_questions_f64_occ3<WPQ, NP, PRLDS, DEFER, POLE>;   // (5 and 6 pairs: slower with the spills)
+    else return eval_questions_f64<WPQ, NP, PRLDS, DEFER, POLE>;
   }();
   // attribute and occupancy are properties of (kernel, LDS size, device): asked once per device, not on every launch
   static LaunchCache cache;
@@ -1297,7 +1497,9 @@ static EvalArgs make_args(const KbView &kb, int64_t qFirst, int64_t qLimit) {
   args.tgap = kb.tgap;
   args.qgap = kb.qgap;
   args.K = kb.K;
+  args.T = kb.T;
   args.ldT = kb.ldT;
+  args.poleScratch = kb.poleScratch;
   args.qFirst = qFirst;
   args.qLimit = qLimit;
   const double nT = (double)(kb.nValidTargets + 1);  // PqaCore/CEEvalQsSubtaskConsider.cpp:191
@@ -1348,7 +1550,8 @@ hipError_t LaunchEvalQuestionsWithUpdate(const KbView &kb, double *prior, uint32
   args.updTop = TopRequest{reinterpret_cast<TopOut *>(topOut), topN, topFlag, topFlagValue, topOut ? topCount : 0};
   constexpr int WPQ = 4, NP = 2;
   const size_t shmem = eval_base_lds_bytes<WPQ, NP, false>(args.K, args.ldT) + eval_deferred_bytes(WPQ, NP, args.K, false);
-  auto kern = eval_questions_f64_upd<WPQ, NP, true>;
+  const bool pole = args.poleScratch != nullptr;
+  auto kern = pole ? eval_questions_f64_upd<WPQ, NP, true, true> : eval_questions_f64_upd<WPQ, NP, true, false>;
   static LaunchCache cache;
   const int dev = LaunchCache::Device();
   int cachedPerCU = 0;
@@ -1377,6 +1580,7 @@ hipError_t LaunchEvalQuestionsBatch(const KbView &kb, const QuizSlot *slots, int
   EvalArgs args = make_args(kb, qFirst, qLimit);
   args.fs = fused;
   args.slots = slots;
+  args.poleScratch = nullptr;   // (one buffer per engine, not per quiz of a batch: the quizzes of a grid.y launch keep the sweep's own sums at the pole)
   return launch_variant(args, kb.ldT, variant, nSlots, stream);
 }
 

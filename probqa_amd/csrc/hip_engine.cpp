@@ -183,6 +183,7 @@ Error HipEngine::Init(const CiEngineDefinition &def, const CiHipShard *shard) {
   HIP_TRY(hipMalloc(&_dVB, (size_t)_ldT * sizeof(double)));
   HIP_TRY(hipMalloc(&_dPriority, (size_t)_Q * sizeof(double)));
   HIP_TRY(hipMalloc(&_dRunLength, (size_t)_Q * sizeof(double)));
+  HIP_TRY(hipMalloc(&_dPoleScratch, (size_t)_Q * (size_t)(2 * _K + 2) * sizeof(double)));
   HIP_TRY(hipMalloc(&_dExps, (size_t)_ldT * sizeof(int64_t)));
   HIP_TRY(hipMalloc(&_dStatus, 2 * sizeof(int64_t)));
   HIP_TRY(hipMalloc(&_dNOut, sizeof(int64_t)));
@@ -259,7 +260,7 @@ HipEngine::~HipEngine() {
   hipFree(_dServerCtl);
   if (_stream) hipStreamSynchronize(_stream);
   for (Quiz *q : _quizzes) if (q) DestroyQuiz(q);
-  hipFree(_dCube); hipFree(_dVB); hipFree(_dPriority); hipFree(_dRunLength); hipFree(_dExps); hipFree(_dStatus);
+  hipFree(_dCube); hipFree(_dVB); hipFree(_dPriority); hipFree(_dRunLength); hipFree(_dPoleScratch); hipFree(_dExps); hipFree(_dStatus);
   hipFree(_dNOut); hipFree(_dSel); hipFree(_dSelScratch); hipFree(_dPriorScratch); hipFree(_dClusterScratch);
   for (BatchCtx &c : _ctx) {
     hipFree(c.dSlots); hipFree(c.dScratch); hipFree(c.dPriority); hipFree(c.dPT); hipFree(c.dAcc); hipFree(c.dRecs); hipFree(c.dPriT); hipFree(c.dRerank);
@@ -294,6 +295,7 @@ KbView HipEngine::View() const {
   v.smallLaunches = _optServer ? 1 : 0;
   v.priorScratch = _optLongRowForm ? _dPriorScratch : nullptr;
   v.maxGrid = (int)_optEvalMaxGrid;
+  v.poleScratch = _optPoleFix ? _dPoleScratch : nullptr;
   return v;
 }
 
@@ -307,6 +309,7 @@ Error HipEngine::SetOption(const char *name, int64_t value) {
   if (n == "select") { if (value != 0 && value != 1) goto bad; _optSelect = value; }
   else if (n == "combine") { _optCombine = value ? 1 : 0; }
   else if (n == "combine_spin") { _optCombineSpin = value ? 1 : 0; }
+  else if (n == "pole_fix") { StopServer(); _optPoleFix = value ? 1 : 0; _kbVersion++; }   // 0: questions with a row at the pole of the lack term keep the sweep's own sums (eval_kernels.hip: pole_fix)
   else if (n == "long_row_form") { _optLongRowForm = value ? 1 : 0; }   // 0: the one-workgroup posterior kernels for rows beyond 16384 targets too
   else if (n == "fuse_update") { _optFuseUpdate = value ? 1 : 0; }   // RecordAnswer's posterior update inside the speculative sweep's launch
   else if (n == "post_always") { _optPostAlways = value ? 1 : 0; }   // test hook: RecordAnswer / ListTopTargets always as posted operations
@@ -357,6 +360,7 @@ int64_t HipEngine::GetOption(const char *name) const {
   if (n == "fuse_update") return _optFuseUpdate;
   if (n == "fused_updates") return (int64_t)_fusedUpdates;           // RecordAnswers whose update ran inside the sweep's launch
   if (n == "long_row_form") return _optLongRowForm;
+  if (n == "pole_fix") return _optPoleFix;
   if (n == "allowed_cpus") return AllowedCpus();
   if (n == "combined_batches") return (int64_t)_combBatches;        // sweeps that served more than one NextQuestion call ...
   if (n == "combined_requests") return (int64_t)_combRequests;      // ... the calls they served ...

@@ -360,7 +360,7 @@ class HipEngine : public IEngine {
   uint8_t _precType = 3;
   char *CubeAt(int64_t q, int64_t row = 0) const { return _dCube + ((size_t)(q * (_K + 1) + row) * (size_t)_ldT) * (size_t)_elem; }
   static int64_t RoundLdT(int64_t T, int elem) { const int64_t m = 128 / elem; return ((T + m - 1) / m) * m; }   // rows start on 128-byte lines
-  double *_dVB = nullptr, *_dPriority = nullptr, *_dRunLength = nullptr;
+  double *_dVB = nullptr, *_dPriority = nullptr, *_dRunLength = nullptr, *_dPoleScratch = nullptr;
   uint32_t *_dTGap = nullptr, *_dQGap = nullptr;
   int64_t *_dExps = nullptr, *_dAqs = nullptr, *_dStatus = nullptr, *_dNOut = nullptr;
   int64_t _aqCapacity = 0;
@@ -515,6 +515,7 @@ class HipEngine : public IEngine {
   Error WaitFlagNapping(volatile uint64_t *flag, uint64_t value, const char *what);   // for many waiters at once: a short spin, then naps
   SelectResult *_dSelScratch = nullptr;  // its per-workgroup winner records
   double *_dPriorScratch = nullptr;      // the long-row posterior kernels' subtask sums (KbView::priorScratch)
+  int64_t _optPoleFix = 1;               // option "pole_fix"
   int64_t _optLongRowForm = 1;           // option "long_row_form": StartQuiz / RecordAnswer over rows beyond 16384 targets as one workgroup per subtask of the sum
   // batched selections (NextQuestionArgmaxBatch); allocated on first use
   static constexpr int64_t kMaxBatch = 256, kBatchGrid = 1024;

@@ -430,7 +430,7 @@ Error HipEngine::ReallocKB(int64_t newQ, int64_t newT) {
   const int64_t newCap = std::max(_capQ, newQ);
   const bool regrow = newLdT != _ldT || newCap != _capQ;
   DevBuf<char> cube;
-  DevBuf<double> vB, priority, runLength;
+  DevBuf<double> vB, priority, runLength, poleScratch;
   DevBuf<int64_t> exps;
   DevBuf<uint32_t> tgapDev, qgapDev;
   // bitmaps: keep the old bits, new positions are not gaps, everything past the size is
@@ -449,6 +449,7 @@ Error HipEngine::ReallocKB(int64_t newQ, int64_t newT) {
     if (newCap != _capQ) {
       HIP_TRY(priority.Alloc((size_t)newCap * sizeof(double)));
       HIP_TRY(runLength.Alloc((size_t)newCap * sizeof(double)));
+      HIP_TRY(poleScratch.Alloc((size_t)newCap * (size_t)(2 * _K + 2) * sizeof(double)));
     }
     // old rows keep their content; new padding columns get A = 0, D = 1 from the fill of new questions / a plain fill
     HIP_TRY(LaunchFillFresh(cube.p, _elem, vB.p, _K, newCap, 0, newLdT, 0.0, _stream));  // T = 0: every column is "padding"
@@ -462,7 +463,10 @@ Error HipEngine::ReallocKB(int64_t newQ, int64_t newT) {
     hipFree(_dCube); hipFree(_dVB);
     _dCube = cube.Release(); _dVB = vB.Release();
     if (exps.p) { hipFree(_dExps); _dExps = exps.Release(); }
-    if (priority.p) { hipFree(_dPriority); hipFree(_dRunLength); _dPriority = priority.Release(); _dRunLength = runLength.Release(); }
+    if (priority.p) {
+      hipFree(_dPriority); hipFree(_dRunLength); hipFree(_dPoleScratch);
+      _dPriority = priority.Release(); _dRunLength = runLength.Release(); _dPoleScratch = poleScratch.Release();
+    }
     _ldT = newLdT;
     _capQ = newCap;
   }

@@ -57,6 +57,8 @@ struct KbView {
   double *priorScratch;   // 8 * kMaxWorkers + 2 doubles (device): the subtasks' sums of the long-row posterior kernels (prior_kernels.hip); may be null
   int maxGrid;            // test hook (engine option "eval_max_grid"): cap the workgroups of a sweep, so that a small cube makes
                           // every workgroup stream dozens of questions; 0 = no cap
+  double *poleScratch;    // Q x (2 K + 2) doubles (device): the sums of questions with a row at the pole of the lack term, between the
+                          // sweep and its fix (eval_kernels.hip: pole_fix); may be null (then such questions keep the sweep's own sums)
 };
 
 struct SelectResult {     // 16 bytes, written by the select kernels

@@ -286,3 +286,49 @@ def test_training_pairing_rules():
     o2 = fresh()
     o2.train([(1, 3), (5, 0), (1, 3), (1, 3)], 4, b, n_workers=64)
     assert o2.A[1, 3, 4] == o.A[1, 3, 4] and o2.A[5, 0, 4] == o.A[5, 0, 4]
+
+
+def test_reference_sum_is_the_correctly_rounded_sum_where_one_element_dominates():
+    """What the sweep's handling of rows at the pole of the lack term rests on (eval_kernels.hip: pole_fix): where ONE likelihood
+    carries all but a sliver (2^-17) of a row's sum, the reference's W_k -- four serial Kahan lanes down the row and PreciseSum
+    (SRAccumVectDbl256.h:40-46, :62-92) -- equals the correctly rounded sum of the row, which a compensated parallel sum gives the
+    device.  (For ordinary rows the two differ by a unit in the last place in 10 - 25 % of cases: there the deviation is
+    harmless, three orders of magnitude below the parity bar.)"""
+    import math
+
+    def reference_sum(x):
+        n4 = (len(x) + 3) // 4 * 4
+        x = np.concatenate([x, np.zeros(n4 - len(x))])
+        s, c = [0.0] * 4, [0.0] * 4
+        for j in range(0, n4, 4):                       # SRAccumVectDbl256::Add
+            for lane in range(4):
+                y = x[j + lane] - c[lane]
+                t = s[lane] + y
+                c[lane] = (t - s[lane]) - y
+                s[lane] = t
+        ks, kc = c[3], 0.0                              # PreciseSum: the corrections, negated, then the sums
+        for i in (2, 1, 0):
+            y = c[i] - kc
+            t = ks + y
+            kc = (t - ks) - y
+            ks = t
+        ks, kc = -ks, -kc
+        for i in (3, 2, 1, 0):
+            y = s[i] - kc
+            t = ks + y
+            kc = (t - ks) - y
+            ks = t
+        return ks - kc
+
+    rng = np.random.default_rng(20260929)
+    ordinary = 0
+    for n in (4, 8, 10, 101, 400):
+        for trial in range(600):
+            tail = rng.random(n - 1) * rng.choice([1e-5, 1e-7, 1e-9, 1e-12]) / n     # the other targets: at most 2^-17 of the row
+            big = rng.random() + 0.5
+            x = np.concatenate([[big], tail])
+            rng.shuffle(x)
+            assert reference_sum(x) == math.fsum(x), (n, trial)
+            y = rng.random(n)
+            ordinary += reference_sum(y) != math.fsum(y)
+    assert ordinary > 0     # (the property is special to dominated rows)
