@@ -226,17 +226,17 @@ __device__ __forceinline__ void pass2_pair(double2 lh, double2 id, double2 pr, d
 // the sweep to (three of round 3's 13 700 soak cases).  The sweep's W_k is a plain per-lane sum and a butterfly; the reference's
 // is four serial Kahan lanes down the row (SRAccumVectDbl256.h:40-46) and PreciseSum (:62-92), which no wave reproduces at speed
 // (a row of T targets is T / 4 DEPENDENT Kahan steps -- measured in round 4: every question of a late quiz redone in
-// that order costs 5 - 8 sweeps).  But where ONE likelihood carries all but a sliver of the row's sum -- exactly the rows in
-// question -- the reference's result IS the correctly rounded sum: its compensation captures the tail exactly
-// (tests/test_oracle.py: no exception in 10^5 such rows; ordinary rows differ by a unit in 10 - 25 % of cases).
+// that order costs 5 - 8 sweeps).  Only the rows AT the pole need it, though, and of those a late quiz has one in most questions,
+// not five.
 //
 // So: the sweep WATCHES (one v_max3_u32 per element pair: the largest posterior element of the question) and otherwise runs as it
 // always ran.  A question with an element >= 1 - 2^-17 -- a hundred times further from the pole than where the deviation reaches
 // 1e-9 -- also leaves its sums in memory (KbView::poleScratch), and once the workgroup's stream has ended pole_fix goes over its
-// rows again, all threads side by side: W_k as an error-free sum per thread (TwoSum) folded with compensation -- the correctly
-// rounded sum -- and the row's largest likelihood with its 1/D; for the element that is within 2^-17 of 1, Log2Hot by the
-// reference's operation sequence (true quotient, its own table entry 0: log2hot_ref) and the lack quotient as an exact division
-// replace what pass 2 had added for it.  That element's terms are then the oracle's.  A late quiz -- the posterior on one target --
+// rows again, all threads side by side: a compensated sum of the row (TwoSum per thread, compensated folds) and its largest
+// likelihood with its 1/D say whether THIS row is at the pole; if so its likelihoods are staged in LDS and four lanes sum them in
+// the reference's order (T / 4 dependent steps: 4.5 us at 1000 targets), and for the element that is within 2^-17 of 1, Log2Hot
+// by the reference's operation sequence (true quotient, its own table entry 0: log2hot_ref) and the lack quotient as an exact
+// division replace what pass 2 had added for it.  That element's terms are then the oracle's.  A late quiz -- the posterior on one target --
 // has such a row in most questions: the sweep then costs 2 - 4 times its usual time (every such question's rows are read again).
 // Tried on the way (round 4, all measured): the reference's order itself at the end of the sweep (exact; 5 - 8 sweeps per sweep
 // in a late quiz: T / 4 dependent steps per row, the rows re-read twice); the compensated sum and the correction inside the row
@@ -275,9 +275,10 @@ struct PoleArgs {
 };
 
 // nSus questions of this workgroup (local indices in `list`) whose largest posterior element is within 2^-17 of 1; their sums as
-// the sweep formed them are in args.scratch.  All threads; red: LDS, 4 x waves doubles; best: the workgroup's running argmax (LDS).
+// the sweep formed them are in args.scratch.  All threads; red: LDS, 4 x waves (at least 8) doubles; stage: LDS, a row's worth of
+// doubles; best: the workgroup's running argmax (LDS).
 template <bool COH>
-__device__ __forceinline__ void pole_fix(const PoleArgs &g, const uint32_t *list, int nSus, double *red, Best *best) {
+__device__ __forceinline__ void pole_fix(const PoleArgs &g, const uint32_t *list, int nSus, double *red, double *stage, Best *best) {
   const int tid = threadIdx.x, nThreads = blockDim.x, lane = tid % kWave, wave = tid / kWave, nWaves = nThreads / kWave;
   const int64_t K = g.K, ldT = g.ldT, nT = 4 * ((g.T + 3) >> 2);
   auto prior_at = [&](int64_t t) { return COH ? __hip_atomic_load(g.prior + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : g.prior[t]; };
@@ -317,27 +318,81 @@ __device__ __forceinline__ void pole_fix(const PoleArgs &g, const uint32_t *list
       if (lane == 0) { red[2 * wave] = c.s; red[2 * wave + 1] = c.c; red[2 * nWaves + 2 * wave] = 0.0; red[2 * nWaves + 2 * wave + 1] = 0.0; }
       if (mx == wmx && mx > 0.0) { red[2 * nWaves + 2 * wave] = mx; red[2 * nWaves + 2 * wave + 1] = mxId; }   // (behind lane 0's zeros)
       __syncthreads();
-      if (tid == 0) {
-        Comp tot{red[0], red[1]};
-        double cand = red[2 * nWaves], candId = red[2 * nWaves + 1];
-        for (int w = 1; w < nWaves; w++) {
-          tot = comp_merge(tot, Comp{red[2 * w], red[2 * w + 1]});
-          if (red[2 * nWaves + 2 * w] > cand) { cand = red[2 * nWaves + 2 * w]; candId = red[2 * nWaves + 2 * w + 1]; }
-        }
-        const double Wx = tot.s + tot.c;                       // :88 -- the correctly rounded sum of the row's likelihoods
-        const double invWx = div_nr(1.0, Wx);                  // :91
-        if (cand > 0.0 && (uint32_t)(d2u(cand * invWx) >> 32) >= kNearOneHi) {
-          const double Wf = rec[k];                            // the sweep's W_k
-          const double lFast = log2hot(cand * div_nr(1.0, Wf), nullptr);   // what pass 2 took for this element (the table is at LDS address 0)
-          const double lRef = log2hot_ref(cand * invWx);       // :106
-          dH += cand * lRef - cand * lFast;                    // :113-114
-          const double id2 = candId * candId;
-          dL += div_fast(id2, lRef) - div_fast(id2, lFast);    // :117 (pass 2's quotient was within 2^-48.8 of the second one)
-          rec[K + k] = Wx * div_fast(rec[K + k], Wf);          // W_k sqrt(V_k): the velocity sum stays the sweep's
-          rec[k] = Wx;
-        }
+      // is THIS row at the pole?  (every thread decides, from the same numbers)
+      Comp tot{red[0], red[1]};
+      double cand = red[2 * nWaves], candId = red[2 * nWaves + 1];
+      for (int w = 1; w < nWaves; w++) {
+        tot = comp_merge(tot, Comp{red[2 * w], red[2 * w + 1]});
+        if (red[2 * nWaves + 2 * w] > cand) { cand = red[2 * nWaves + 2 * w]; candId = red[2 * nWaves + 2 * w + 1]; }
       }
-      __syncthreads();
+      const double Wc = tot.s + tot.c;                         // the row's sum to the last place or one short of the reference's
+      const bool atPole = cand > 0.0 && (uint32_t)(d2u(cand * div_nr(1.0, Wc)) >> 32) >= kNearOneHi - 1;
+      __syncthreads();                                         // (red is written again below)
+      if (atPole) {
+        // W_k in the REFERENCE'S ORDER (:66-88): the row's likelihoods into LDS, every thread its share; then one lane per Kahan
+        // lane c takes the targets 4j + c in order (SRAccumVectDbl256.h:40-46) and PreciseSum (:62-92) folds the four.  The
+        // correctly rounded sum would do in 70 - 90 % of such rows (tests/test_oracle.py), not in all: the compensation of a lane
+        // that meets the large element after smaller ones is itself rounded.
+        for (int64_t tb = tid; tb < nT; tb += 4 * nThreads) {
+          double av[4], dv[4], pv[4];
+          bool in[4], gap[4];
+#pragma unroll
+          for (int e = 0; e < 4; e++) {
+            const int64_t t = tb + e * nThreads;
+            in[e] = t < nT;
+            const int64_t tc = in[e] ? t : 0;
+            gap[e] = bit_test(g.tgap, tc);
+            av[e] = rowA[tc];
+            dv[e] = rowD[tc];
+            pv[e] = prior_at(tc);
+          }
+#pragma unroll
+          for (int e = 0; e < 4; e++)
+            if (in[e]) stage[tb + e * nThreads] = gap[e] ? 0.0 : (av[e] * div_nr(1.0, dv[e])) * pv[e];   // :72-82
+        }
+        __syncthreads();
+        if (tid < 4) {
+          double sum = 0.0, corr = 0.0;
+          const double *src = stage + tid;
+          int64_t j = 0;
+          for (; j + 8 <= nT / 4; j += 8) {                    // (eight elements requested at once, added in order)
+            double x[8];
+#pragma unroll
+            for (int e = 0; e < 8; e++) x[e] = src[4 * (j + e)];
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+              const double y = x[e] - corr;
+              const double u = sum + y;
+              corr = (u - sum) - y;
+              sum = u;
+            }
+          }
+          for (; j < nT / 4; j++) {
+            const double y = src[4 * j] - corr;
+            const double u = sum + y;
+            corr = (u - sum) - y;
+            sum = u;
+          }
+          red[tid] = sum;
+          red[4 + tid] = corr;
+        }
+        __syncthreads();
+        if (tid == 0) {
+          const double Wx = precise_sum4(red, red + 4);        // :88
+          const double invWx = div_nr(1.0, Wx);                // :91
+          if ((uint32_t)(d2u(cand * invWx) >> 32) >= kNearOneHi) {
+            const double Wf = rec[k];                          // the sweep's W_k
+            const double lFast = log2hot(cand * div_nr(1.0, Wf), nullptr);   // what pass 2 took for this element (the table is at LDS address 0)
+            const double lRef = log2hot_ref(cand * invWx);     // :106
+            dH += cand * lRef - cand * lFast;                  // :113-114
+            const double id2 = candId * candId;
+            dL += div_fast(id2, lRef) - div_fast(id2, lFast);  // :117 (pass 2's quotient was within 2^-48.8 of the second one)
+            rec[K + k] = Wx * div_fast(rec[K + k], Wf);        // W_k sqrt(V_k): the velocity sum stays the sweep's
+            rec[k] = Wx;
+          }
+        }
+        __syncthreads();
+      }
     }
     if (tid == 0) {
       const double pri = eval_epilogue(rec, -(rec[2 * K] + dH), rec + K, K, rec[2 * K + 1] + dL, g.vCompTail);  // :130
@@ -817,12 +872,15 @@ __device__ __forceinline__ void sweep_body(EvalArgs a, bool copyTable) {
   if (wave == 0) flush_pending(a, pend, nPend, lane, bestLds[lane]);
   if constexpr (kPoleShape) if (nSus > 0) {
     // ---- this workgroup's questions with a row at the pole of the lack term: their near-1 elements the reference's way
+    double *poleStage = PRLDS ? reinterpret_cast<double *>(prLds) : reinterpret_cast<double *>(mdRow);   // (a row's worth either way, free by now)
     PoleArgs g{a.cube, a.prior, a.tgap, a.priority, a.poleScratch,
                a.fs.hostPriority != nullptr && a.fs.sampleSubtasks > 0 ? a.fs.hostPriority : nullptr, a.fs.seqValue, K, a.T, ldT, a.qFirst, a.vCompTail};
     if constexpr (FUSE) {
       // (the new posterior is in this launch's registers until workgroup 0 stores it at the very end: the lanes' own pairs go to
       //  the mD landing row, free by now)
       double *stash = reinterpret_cast<double *>(mdRow);
+      poleStage = vdump;                                       // (the deferred sums' LDS: (K + 2) x 256 doubles for rows of up to 1024 targets)
+      static_assert(!FUSE || DEFER, "the fused update's shapes defer their sums");
       __syncthreads();
 #pragma unroll
       for (int j = 0; j < NP; j++) {
@@ -832,7 +890,7 @@ __device__ __forceinline__ void sweep_body(EvalArgs a, bool copyTable) {
       g.prior = stash;
     }
     __syncthreads();                                           // (the suspects' sums are in memory, their first priorities stored)
-    pole_fix<SERVER>(g, susWords + 2, nSus, partAll, bestLds);
+    pole_fix<SERVER>(g, susWords + 2, nSus, partAll, poleStage, bestLds);
     __syncthreads();
   }
   if (wave == 0) fused_select<SERVER>(a, bestLds[lane], lane, allReported);

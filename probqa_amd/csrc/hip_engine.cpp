@@ -222,6 +222,7 @@ Error HipEngine::Init(const CiEngineDefinition &def, const CiHipShard *shard) {
 //   PQA_WORKERS=n              emulated thread-pool size (summation order of the posterior updates, training buckets)
 //   PQA_SEED=n                 seed of the selector's generator (the reference's cannot be seeded)
 //   PQA_COMBINE=0|1            concurrent NextQuestion calls of different quizzes share one sweep, RecordAnswer's kernels are gathered (1, default)
+//   PQA_POLE_FIX=0|1           launched sweeps re-evaluate rows at the pole of the lack term in the reference's order (1, default; eval_kernels.hip: pole_fix)
 //   PQA_DEVICES=i[,j,...]      device ordinal(s): read by the factory (c_abi.cpp), which builds one shard per listed device
 void HipEngine::ApplyEnvironment() {
   auto num = [](const char *name, int64_t lo, int64_t hi, int64_t &out) {
@@ -247,6 +248,7 @@ void HipEngine::ApplyEnvironment() {
   if (num("PQA_BUG_COMPAT", 0, 1, x)) _optBugCompat = x;
   if (num("PQA_SPECULATE", 0, 1, x)) _optSpeculate = x;
   if (num("PQA_COMBINE", 0, 1, x)) _optCombine = x;
+  if (num("PQA_POLE_FIX", 0, 1, x)) _optPoleFix = x;
   if (num("PQA_WORKERS", 1, kMaxWorkers, x)) _optWorkers = x;
   if (num("PQA_SEED", INT64_MIN, INT64_MAX, x)) { uint64_t s = (uint64_t)x; _rng[0] = SplitMix64(s); _rng[1] = SplitMix64(s); }
 }

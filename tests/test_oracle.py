@@ -288,12 +288,12 @@ def test_training_pairing_rules():
     assert o2.A[1, 3, 4] == o.A[1, 3, 4] and o2.A[5, 0, 4] == o.A[5, 0, 4]
 
 
-def test_reference_sum_is_the_correctly_rounded_sum_where_one_element_dominates():
-    """What the sweep's handling of rows at the pole of the lack term rests on (eval_kernels.hip: pole_fix): where ONE likelihood
-    carries all but a sliver (2^-17) of a row's sum, the reference's W_k -- four serial Kahan lanes down the row and PreciseSum
-    (SRAccumVectDbl256.h:40-46, :62-92) -- equals the correctly rounded sum of the row, which a compensated parallel sum gives the
-    device.  (For ordinary rows the two differ by a unit in the last place in 10 - 25 % of cases: there the deviation is
-    harmless, three orders of magnitude below the parity bar.)"""
+def test_reference_sum_is_not_the_correctly_rounded_sum():
+    """Why the sweep's handling of rows at the pole of the lack term (eval_kernels.hip: pole_fix) walks the row in the
+    REFERENCE'S ORDER instead of summing it well: the reference's W_k -- four serial Kahan lanes down the row and PreciseSum
+    (SRAccumVectDbl256.h:40-46, :62-92) -- differs from the correctly rounded sum by a unit in the last place in 10 - 30 % of rows,
+    also where one likelihood carries all but a sliver of the sum (a lane that meets the large element after smaller ones rounds
+    its own compensation).  A better sum on the device would therefore still miss the reference's last place that often."""
     import math
 
     def reference_sum(x):
@@ -321,14 +321,14 @@ def test_reference_sum_is_the_correctly_rounded_sum_where_one_element_dominates(
         return ks - kc
 
     rng = np.random.default_rng(20260929)
-    ordinary = 0
-    for n in (4, 8, 10, 101, 400):
-        for trial in range(600):
-            tail = rng.random(n - 1) * rng.choice([1e-5, 1e-7, 1e-9, 1e-12]) / n     # the other targets: at most 2^-17 of the row
-            big = rng.random() + 0.5
-            x = np.concatenate([[big], tail])
+    dominated = ordinary = 0
+    for n in (4, 10, 101):
+        for trial in range(300):
+            x = np.concatenate([[rng.random() + 0.5], rng.random(n - 1) * 1e-7 / n])     # the other targets: far below 2^-17 of the row
             rng.shuffle(x)
-            assert reference_sum(x) == math.fsum(x), (n, trial)
+            r, e = reference_sum(x), math.fsum(x)
+            assert abs(r - e) <= np.spacing(e)
+            dominated += r != e
             y = rng.random(n)
             ordinary += reference_sum(y) != math.fsum(y)
-    assert ordinary > 0     # (the property is special to dominated rows)
+    assert dominated > 30 and ordinary > 30
