@@ -33,6 +33,7 @@
 #include <algorithm>
 
 #include "eval_device.h"
+#include "pole_device.h"
 #include "pqa_device.h"
 #include "pqa_kernels.h"
 
@@ -131,7 +132,13 @@ struct BatchArgs {
   double *acc;               // fp64 totals, [grid][threads][QB][2K+2]: W_k (K), V_k (K), sum W_k H_k, lack
   BatchRecord *recs;         // [grid][Bp]: every workgroup's best question per quiz
   double *priorityT;         // optional [Q][Bp]: the priorities themselves (tests, EvalPrioritiesBatch)
+  // rows at the pole of the lack term (pole_device.h; Double engines, rows of up to 4096 targets): a row's worth of LDS for the
+  // reference-order sum (0: none, such questions keep the sweep's own sums), the row length, log2hot_ref's table entry 0
+  int poleDoubles;
+  int64_t T;
+  double log2Entry0Ref;
 };
+constexpr int kPoleMax = 128;   // (question, quiz) pairs a workgroup re-evaluates per block of questions
 
 // Tile in LDS: R tile[TC][QB][KG + 1]; entry [tc][qi][k < KG] = A[q][kg + k][t] * invD[q][t], entry [tc][qi][KG] = invD^2.
 // Gap targets hold zeros in both (:74, :79 andnot masks; the reference masks the lack term instead, :117).
@@ -184,8 +191,12 @@ __global__ __launch_bounds__(256) void eval_batch_kernel(BatchArgs a) {
   double bestP = 0.0;
   int64_t bestQ = -1;
   const int64_t nBlocks = (a.Q + QB - 1) / QB;
+  constexpr bool kPoleWatch = Num<R>::kTable;                  // (Double engines: the fp32 tolerance covers what the summation order moves)
   for (int64_t blk = blockIdx.x; blk < nBlocks; blk += gridDim.x) {
     const int64_t q0 = blk * QB;
+    uint32_t hiMax[QB];                                        // the largest posterior element's high word, per question (pole_device.h)
+#pragma unroll
+    for (int qi = 0; qi < QB; qi++) hiMax[qi] = 0;
     bool staged = false;                                       // single-tile rows, single answer group: pass 2 reuses pass 1's tile
     for (int64_t kg = 0; kg < K; kg += KG) {
       const int kN = EXACT ? KG : (int)(K - kg < KG ? K - kg : KG);
@@ -263,6 +274,7 @@ __global__ __launch_bounds__(256) void eval_batch_kernel(BatchArgs a) {
               const R lh = cv[qi][k] * pi;
               const R p = lh * invW[qi][k];
               const R l2 = Num<R>::log2p(p, tbl);
+              if constexpr (kPoleWatch) hiMax[qi] = max(hiMax[qi], (uint32_t)(d2u((double)p) >> 32));
               hW[qi] = fma(lh, l2, hW[qi]);
               const R d = p - pi;
               v[qi][k] = fma(d, d, v[qi][k]);
@@ -323,6 +335,46 @@ __global__ __launch_bounds__(256) void eval_batch_kernel(BatchArgs a) {
           const double cand = pri != pri ? -__builtin_huge_val() : pri;   // NaN never wins over a number
           if (bestQ < 0 || cand > bestP) { bestP = cand; bestQ = q; }     // (questions ascend: the lowest index wins a tie)
         }
+      }
+    }
+    if constexpr (kPoleWatch) {
+      if (a.poleDoubles > 0) {
+        // ---- (question, quiz) pairs with a posterior element within 2^-17 of 1: their rows at the pole of the lack term again,
+        // the reference's way, the whole workgroup on one pair at a time (pole_device.h; the single-quiz sweep: pole_fix).  The
+        // tile's LDS is free here: reduction scratch | a row of likelihoods | the list | the corrected priorities.
+        double *red = reinterpret_cast<double *>(tile), *stage = red + 32;
+        uint32_t *plist = reinterpret_cast<uint32_t *>(stage + a.poleDoubles), *pcount = plist + 2 * kPoleMax;
+        double *fixedPri = reinterpret_cast<double *>(plist + 2 * kPoleMax + 2);
+        __syncthreads();                                       // (everybody is done with the tile)
+        if (tid == 0) *pcount = 0;
+        __syncthreads();
+#pragma unroll
+        for (int qi = 0; qi < QB; qi++) {
+          const int64_t q = q0 + qi;
+          if (live && q < a.Q && hiMax[qi] >= kNearOneHi && !(bit_test(a.qgap, q) || ((asked[q >> 5] >> (q & 31)) & 1u))) {
+            const uint32_t at = atomicAdd(pcount, 1u);
+            if (at < (uint32_t)kPoleMax) { plist[2 * at] = (uint32_t)b; plist[2 * at + 1] = (uint32_t)qi; }
+          }
+        }
+        __syncthreads();
+        const int nPole = (int)min(*pcount, (uint32_t)kPoleMax);
+        for (int e = 0; e < nPole; e++) {
+          const int b2 = (int)plist[2 * e], qi2 = (int)plist[2 * e + 1];
+          double *rec = a.acc + ((size_t)blockIdx.x * nThreads + b2) * (size_t)(QB * nAcc) + (size_t)qi2 * nAcc;   // (W_k sqrt(V_k) in place of V_k by now)
+          const PoleRows rows{static_cast<const double *>(a.cube), a.slots[b2].prior, a.tgap, K, a.T, ldT, gLog2TableB, a.log2Entry0Ref};
+          double dH = 0.0, dL = 0.0;
+          pole_fix_question<false>(rows, q0 + qi2, rec, true, red, stage, dH, dL);
+          if (tid == 0) fixedPri[e] = eval_epilogue(rec, -(rec[2 * K] + dH), rec + K, K, rec[2 * K + 1] + dL, a.vCompTail);
+        }
+        __syncthreads();
+        for (int e = 0; e < nPole; e++)
+          if ((int)plist[2 * e] == b) {
+            const int64_t q = q0 + (int64_t)plist[2 * e + 1];
+            const double pri = fixedPri[e];
+            if (a.priorityT) a.priorityT[q * Bp + b] = pri;
+            const double cand = pri != pri ? -__builtin_huge_val() : pri;
+            if (bestQ < 0 || cand > bestP || (cand == bestP && q < bestQ)) { bestP = cand; bestQ = q; }
+          }
       }
     }
   }
@@ -681,7 +733,10 @@ template <typename R, int QB, int KG, bool EXACT>
 hipError_t launch_batch(const BatchArgs &args0, int nThreads, size_t *accBytesNeeded, int *gridOut, bool queryOnly, hipStream_t stream) {
   BatchArgs args = args0;
   auto kern = eval_batch_kernel<R, QB, KG, EXACT>;
-  const size_t shmem = (Num<R>::kTable ? kLog2TableDoubles * sizeof(double) : 0) + (size_t)args.TC * QB * (KG + 1) * sizeof(R);
+  size_t tileBytes = (size_t)args.TC * QB * (KG + 1) * sizeof(R);
+  if (Num<R>::kTable && args.poleDoubles > 0)   // (the pole fix's LDS takes the tile's place: pole_device.h)
+    tileBytes = std::max(tileBytes, (size_t)(32 + args.poleDoubles + 128) * sizeof(double) + (size_t)(2 * kPoleMax + 2) * sizeof(uint32_t));
+  const size_t shmem = (Num<R>::kTable ? kLog2TableDoubles * sizeof(double) : 0) + tileBytes;
   if (shmem > 160 * 1024) return hipErrorInvalidValue;
   static LaunchCache cache;   // (per instantiation and device; the occupancy also depends on the thread count: part of the key)
   const int devSlot = LaunchCache::Device();
@@ -728,6 +783,9 @@ hipError_t LaunchEvalBatch(const KbView &kb, const QuizSlot *slots, int nSlots, 
   const double nT = (double)(kb.nValidTargets + 1);            // PqaCore/CEEvalQsSubtaskConsider.cpp:191
   a.vCompTail = 0.34657359027997265470861606072909 / (nT * nT);
   a.acc = acc; a.recs = recs; a.priorityT = priorityT;
+  a.T = kb.T;
+  a.poleDoubles = (!f32 && kb.poleScratch != nullptr && kb.ldT <= 4096) ? (int)(4 * ((kb.T + 3) / 4)) : 0;   // (the engine's option pole_fix: KbView::poleScratch)
+  a.log2Entry0Ref = std::log2(1.0 + 0x1p-11) * 9.9999999999999927e-01;   // SRVectMath.cpp:31,42
   plan->ptBytes = (size_t)kb.ldT * Bp * (f32 ? 4 : 8);
   plan->Bp = Bp;
   hipError_t e;
