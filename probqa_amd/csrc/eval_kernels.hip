@@ -204,6 +204,7 @@ __device__ __forceinline__ void pass2_pair(double2 lh, double2 id, double2 pr, d
                                            double &hW, double &v, double &accL, uint32_t &hiMax) {
   const double p0 = lh.x * invWk, p1 = lh.y * invWk;           // :97
   hiMax = max(hiMax, max((uint32_t)(d2u(p0) >> 32), (uint32_t)(d2u(p1) >> 32)));
+  const double d0 = p0 - pr.x, d1 = p1 - pr.y;                 // :119 (first: log2hot may then rework p's registers in place)
   const double l20 = log2hot(p0, tbl), l21 = log2hot(p1, tbl); // :106 (gap lanes: p = 0 -> -1023, contributes -0)
   hW = fma(lh.x, l20, hW);                                     // :113-114 weighted by W_k (see eval_epilogue)
   hW = fma(lh.y, l21, hW);
@@ -215,7 +216,6 @@ __device__ __forceinline__ void pass2_pair(double2 lh, double2 id, double2 pr, d
   r = fma(r, fma(-prod, r, 1.0), r);
   const double num = fma(id.y * l20, id.y, (id.x * l21) * id.x);
   accL = fma(num, r, accL);
-  const double d0 = p0 - pr.x, d1 = p1 - pr.y;                 // :119
   v = fma(d0, d0, v);                                          // :126-127
   v = fma(d1, d1, v);
 }

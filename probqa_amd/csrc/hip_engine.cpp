@@ -149,7 +149,7 @@ Error HipEngine::Init(const CiEngineDefinition &def, const CiHipShard *shard) {
         double zp;
         std::memcpy(&zp, &iZp, 8);
         tbl[2 * i] = std::log2(zp);
-        tbl[2 * i + 1] = 1.0 / (2.0 * zp);
+        tbl[2 * i + 1] = (double)(2.8853900817779268147198493620038L / (2.0L * (long double)zp));   // (2/ln 2)/(2m): pqa_device.h
       }
       tbl[0] *= 9.9999999999999927e-01;
       // The reference scales entry 0 so that Log2Hot(1) is (just) negative, -1.08e-19: lack = -sum invD^2 / log2(p)
@@ -158,13 +158,11 @@ Error HipEngine::Init(const CiEngineDefinition &def, const CiHipShard *shard) {
       // 0 on the device's own arithmetic (the same IEEE operations, replayed here): the largest table value for which
       // the device's Log2Hot(1) is negative.  Every other argument of bucket 0 moves by the same < 3e-18.
       {
-        const double m = 1.0 + 0x1p-11, c = tbl[1];
-        const double u = (1.0 - m) * c;
-        double pc = std::fma(u, -2.0, 4.0 / 3);
-        pc = std::fma(u, pc, -1.0);
-        pc = std::fma(u, pc, 1.0);
-        const double terms01 = u * pc;
-        auto at1 = [&](double y0) { return std::fma(terms01, 2.8853900817779268147198493620038, y0) + 0.0; };
+        const double m = 1.0 + 0x1p-11, w = (1.0 - m) * tbl[1];
+        double pc = std::fma(w, -0x1.55046a143789p-4, 0x1.47fd3ffac83b4p-3);
+        pc = std::fma(w, pc, -0x1.62e42fefa39efp-2);
+        pc = std::fma(w, pc, 1.0);
+        auto at1 = [&](double y0) { return std::fma(w, pc, y0) + 0.0; };
         double y0 = tbl[0];
         while (at1(y0) >= 0) y0 = std::nextafter(y0, 0.0);
         while (at1(std::nextafter(y0, 1.0)) < 0) y0 = std::nextafter(y0, 1.0);

@@ -82,12 +82,12 @@ __device__ __forceinline__ double2 row_load(RowRsrc rs, uint32_t byteOffset) {
 // Reference: SRPlatform/Interface/SRVectMath.h:87-135 with the 1024-entry table of SRPlatform/SRVectMath.cpp:30-44 (log2 of
 // the bucket midpoint m, entry 0 scaled by 9.9999999999999927e-01 so that log2(1) < 0).  The table is built on the host
 // with std::log2 and uploaded once (UploadLog2Table), so the kernels see exactly the host libm's values, like the
-// reference's CPU code; each entry carries a second double, 1/(2m).
+// reference's CPU code; each entry carries a second double, (2/ln 2)/(2m).
 // log2hot() follows the reference operation for operation -- exponent / mantissa split, bucket midpoint, t = (z-m)/(z+m),
 // the two explicit FMAs, + exponent -- except for how the quotient t is formed: the reference divides; here
-// z+m = 2m(1+u), u = (z-m)/(2m), so t = u/(1+u) = u - u^2 + u^3 - u^4 ..., and the series t + t^3/3 of :118 is evaluated as one
-// degree-4 polynomial in u (next term 3 u^5, |u| <= 2^-12): 4 fp64 operations instead of a 37-cycle exact division and three
-// more.  The truncation reaches the result below 8e-18 absolute: the value is the reference's Log2Hot(x) except where that
+// z+m = 2m(1+u), u = (z-m)/(2m), so t = u/(1+u) = u - u^2 + u^3 - u^4 ..., and the series t + t^3/3 of :118 with its scaling by
+// 2/ln 2 (:122) is evaluated as one degree-4 polynomial (next term 3 u^5, |u| <= 2^-12): 5 fp64 operations instead of a 37-cycle
+// exact division and four more.  The truncation reaches the result below 1.1e-17 absolute: the value is the reference's Log2Hot(x) except where that
 // perturbation crosses a rounding boundary of the last two operations (a fraction of a percent of arguments, by one
 // rounding unit; tools/log2hot_stats.py).  The host
 // re-seats table entry 0 so that Log2Hot(1) stays negative under this arithmetic (hip_engine.cpp).  The priority vector
@@ -100,12 +100,24 @@ __device__ __forceinline__ bool lds_table_at_zero(const double *tbl) {
   return (uint32_t)(uintptr_t)tbl == 0;
 }
 
+// The three bit patterns of the mantissa surgery, in registers: the two field masks in SGPRs and the fill pattern in a VGPR, so
+// that each of the two results is ONE v_bfi_b32 (a VOP3 takes no literal on gfx9 and one SGPR; as literals the compiler spends
+// v_and + v_or on each).  Plain asm without inputs: hoisted out of every loop and shared by all the call sites of a kernel.
+struct Log2Bits { uint32_t keepZ, keepM, fill; };
+__device__ __forceinline__ Log2Bits log2_bits() {
+  Log2Bits k;
+  asm("s_mov_b32 %0, 0x800fffff" : "=s"(k.keepZ));            // sign and mantissa: the rest <- exponent 0
+  asm("s_mov_b32 %0, 0x800ffc00" : "=s"(k.keepM));            // sign and the top 10 mantissa bits: the rest <- exponent 0, 100...0
+  asm("v_mov_b32 %0, 0x3ff00200" : "=v"(k.fill));
+  return k;
+}
+
 __device__ __forceinline__ double log2hot(double x, const double *__restrict__ tbl) {
-  // the bit surgery is done on the high word only (the low mantissa word passes through)
+  // the bit surgery is done on the high word only (the low mantissa word passes through): 5 integer instructions per element
+  // (two shifts, a mask, two bit-field inserts), of the ~26 the element costs at all
+  const Log2Bits k = log2_bits();
   const uint32_t lo = (uint32_t)d2u(x);
   const uint32_t hi = (uint32_t)(d2u(x) >> 32);
-  const uint32_t zhi = (hi & 0x800FFFFFu) | 0x3FF00000u;       // mantissa (and sign) with exponent 0: z in [1,2)
-  const double z = u2d(((uint64_t)zhi << 32) | lo);
   // exponent as a double (:96-98, :131; x >= 0 assumed): (2^52 + E) - (2^52 + 1023) with E the biased exponent field
   // planted in the low word of 2^52 -- exact, and an integer shift + one fp64 add instead of shift, add and a
   // quarter-rate v_cvt_f64_i32
@@ -118,17 +130,20 @@ __device__ __forceinline__ double log2hot(double x, const double *__restrict__ t
   (void)tbl;
   typedef double f64x2_t __attribute__((ext_vector_type(2)));
   const f64x2_t yc = *reinterpret_cast<const __attribute__((address_space(3))) f64x2_t *>((uintptr_t)tblByte);
-  const uint32_t mhi = (zhi & 0xFFFFFC00u) | 0x200u;           // bucket midpoint (:108): low 42 bits <- 100...0
+  const uint32_t mhi = (hi & k.keepM) | (k.fill & ~k.keepM);   // bucket midpoint (:108): low 42 bits <- 100...0
+  const uint32_t zhi = (hi & k.keepZ) | (k.fill & ~k.keepZ);   // mantissa (and sign) with exponent 0: z in [1,2)
   const double m = u2d((uint64_t)mhi << 32);
-  const double u = (z - m) * yc.y;                             // z - m is exact (same binade, |z-m| < 2^-10)
-  // :111-118 t = (z-m)/(z+m) = u/(1+u), terms01 = t + t^3/3 -- as ONE polynomial in u: with t = u - u^2 + u^3 - u^4 + ... and
-  // t^3 = u^3 - 3u^4 + ..., terms01 = u - u^2 + (4/3) u^3 - 2 u^4 (next term 3 u^5 <= 3 * 2^-60: 7.5e-18 on the result).
-  // Four operations for what the quotient (4) and the two-term series (3) took.
-  double c = fma(u, -2.0, 4.0 / 3);
-  c = fma(u, c, -1.0);
-  c = fma(u, c, 1.0);
-  const double terms01 = u * c;
-  const double log2z = fma(terms01, 2.8853900817779268147198493620038, yc.x);  // :122
+  const double z = u2d(((uint64_t)zhi << 32) | lo);
+  const double w = (z - m) * yc.y;                             // z - m is exact (same binade, |z-m| < 2^-10); w = C u, u = (z-m)/(2m)
+  // :111-122 t = (z-m)/(z+m) = u/(1+u), terms01 = t + t^3/3, log2 z = C * terms01 + y with C = 2/ln 2 -- as ONE polynomial: with
+  // t = u - u^2 + u^3 - u^4 + ... and t^3 = u^3 - 3u^4 + ..., terms01 = u - u^2 + (4/3) u^3 - 2 u^4 (next term 3 u^5 <= 3 * 2^-60:
+  // 1.1e-17 on the result), and in w = C u (the table's second double is C/(2m)):
+  // C * terms01 = w (1 - w/C + (4/3) w^2/C^2 - 2 w^3/C^3).  Five operations for what the quotient (4), the two-term series (3) and
+  // the scaling (1) took; the roundings of w and of the bracket reach the result below 3e-19.
+  double c = fma(w, -0x1.55046a143789p-4, 0x1.47fd3ffac83b4p-3);   // -(ln 2)^3 / 4, (ln 2)^2 / 3
+  c = fma(w, c, -0x1.62e42fefa39efp-2);                        // -(ln 2) / 2
+  c = fma(w, c, 1.0);
+  const double log2z = fma(w, c, yc.x);                        // :122
   return log2z + de;                                           // :131-133
 }
 
