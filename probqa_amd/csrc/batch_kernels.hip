@@ -386,7 +386,7 @@ __global__ __launch_bounds__(256) void eval_batch_kernel(BatchArgs a) {
 // (lanes over targets: a wave reduction per row and quiz, the cube re-read per quiz -- 11-14 us per quiz at 1000 x 5 x 1000) and
 // the row-sharing sweep above (a lane is a quiz: no reductions, but 64 quizzes per wave or its lanes idle, and a lane walks the
 // whole row serially: it needs ~200 quizzes to fill the chip) there was nothing for the batches a server with dozens of client
-// threads produces (hip_engine.cpp: Combine -- 5 to 60 quizzes per combined sweep).  Here a lane is a (quiz, chunk of the
+// threads produces (hip_engine_combine.cpp: Combine -- 5 to 60 quizzes per combined sweep).  Here a lane is a (quiz, chunk of the
 // row): QS quiz slots x 64 / QS chunks per wave, four waves per workgroup, one QUESTION per workgroup at a time --
 //   * the workgroup stages the question's whole row block in LDS once: c = A * (1/D) for every answer and 1/D^2 (the divisions
 //     and the cube's bytes shared by all quizzes of the launch);

@@ -370,7 +370,7 @@ __device__ __forceinline__ void flush_pending(const EvalArgs &a, const double *p
 // What changes between two steps of the resident kernel without a kernel boundary in between: the quiz's posterior and its
 // asked bits (rewritten by RecordAnswer's kernel, possibly on another XCD, whose L2 is not coherent with this one's).  The
 // resident kernel reads exactly these with agent-scope (sc1) loads, which are served past the non-coherent cache levels.
-// The cube and the gap bitmaps change only in operations that stop the resident kernel first (hip_engine.cpp: StopServer).
+// The cube and the gap bitmaps change only in operations that stop the resident kernel first (hip_engine_server.cpp: StopServer).
 // Tried instead: an acquire fence in every wave at the start of a step (what a kernel boundary does) -- correct, 44 us per
 // step against 22; per-XCD copies made by one leader workgroup per XCD and read with workgroup-scope (sc0) loads -- no
 // faster (the step is bound by pulling the 48 MB cube through the L2s, ~13 us, not by these 8 KB) and not coherent.

@@ -603,7 +603,7 @@ class HipEngine : public IEngine {
       m.lock(); wasBusy = busy; busy = true;
     }
     void lock_urgent() { lock(); }
-    void unlock();   // (runs the posted operations first: hip_engine.cpp)
+    void unlock();   // (runs the posted operations first: hip_engine_combine.cpp)
   };
   struct UrgentLock {   // (RAII for lock_urgent, re-lockable like std::unique_lock)
     EngineMutex &mu;

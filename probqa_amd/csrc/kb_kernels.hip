@@ -70,7 +70,7 @@ __global__ __launch_bounds__(256) void fill_synth_kernel(void *__restrict__ cube
 }
 
 // Training (reference PqaCore/CETrainOperation.cpp:15-83).  The host turns the call's answered questions into steps in the
-// reference's own pairing order (hip_engine.cpp: BuildTrainSteps) and groups the steps by question: steps on different
+// reference's own pairing order (hip_engine_update.cpp: BuildTrainSteps) and groups the steps by question: steps on different
 // questions touch different cells and run in parallel, one thread per question; a question's steps run in order.
 //   kind 1  Perform1 (:28-30, and either half of a Perform2 over two different questions, :56-82): a = sqrt(A); A, D += 2ab + b^2
 //   kind 2  Perform2, same question and answer (:34-35): ONE step of 2b -- A, D += 4ab + 4b^2 (_inc4B, _incSquare2B)
@@ -305,7 +305,7 @@ hipError_t LaunchTrainBatchInline(void *cube, int elem, double *vB, int64_t K, i
 
 hipError_t LaunchTopTargets(const KbView &kb, const double *prior, int64_t maxCount, RatedTargetDev *out,
                             int64_t *nOut, uint64_t *flag, uint64_t flagValue, hipStream_t stream) {
-  if (kb.T > 16384) return hipErrorInvalidValue;  // the host-side listing takes over (hip_engine.cpp)
+  if (kb.T > 16384) return hipErrorInvalidValue;  // the host-side listing takes over (hip_engine_update.cpp)
   if (kb.smallLaunches && kb.T <= 1024)   // beside the resident sweep (prior_kernels.hip: kSmallThreads)
     hipLaunchKernelGGL(top_targets_kernel<true>, dim3(1), dim3(256), 0, stream, prior, kb.tgap, kb.T, maxCount, out, nOut, flag,
                        flagValue);

@@ -299,7 +299,7 @@ hipError_t LaunchTrainStepsInline(void *cube, int elem, double *vB, int64_t K, i
                                   int64_t iTarget, double amount, hipStream_t stream);
 // Several training calls -- each with its own target and amount, DIFFERENT targets (their cells are disjoint then) -- in one launch:
 // workgroup c runs call c's chains exactly as train_steps_inline_kernel would.  What a server's clients' RecordQuizTarget calls
-// become when they arrive together (hip_engine.cpp: DrainPosted).
+// become when they arrive together (hip_engine_combine.cpp: DrainPosted).
 constexpr int kTrainBatchCalls = 24, kTrainBatchSteps = 192;
 struct TrainBatchStep { int32_t q; uint8_t kind, a1, a2, pad; };
 struct TrainBatchCall { int64_t iTarget; double amount; int32_t firstChain, nChains; };

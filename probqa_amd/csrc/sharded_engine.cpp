@@ -28,7 +28,7 @@
 //                          engine's file: a KB saved sharded loads unsharded and vice versa).
 // One lock (_opMu) orders what must happen in the same order on every shard -- quiz registry changes, trainings, the launch of a
 // combined sweep; it is never held while the GPU is waited for, and calls that find it taken post their operation and are served
-// by its holder on the way out (as hip_engine.cpp's posted operations).  Maintenance-mode edits of the dimensions rebuild the
+// by its holder on the way out (as hip_engine_combine.cpp's posted operations).  Maintenance-mode edits of the dimensions rebuild the
 // shards (Rebuild below).  Not sharded (NotImplemented on this engine): SetStream and the stream-ordered single-shard entry points.
 #include "hip_engine_internal.h"
 
@@ -356,7 +356,7 @@ class ShardedEngine final : public IEngine {
     return _rng[1] + s0;
   }
 
-  // ---- concurrent NextQuestion calls: combined (as hip_engine.cpp's Combine / ServeQueue / LaunchBatch / CollectBatch) --------
+  // ---- concurrent NextQuestion calls: combined (as hip_engine_combine.cpp's Combine / ServeQueue / LaunchBatch / CollectBatch) --------
   struct SelRequest {
     int64_t iQuiz = -1;
     int kind = 0;                      // 0 argmax, 1 sampled (rnd)

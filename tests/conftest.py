@@ -9,6 +9,17 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
         sys.path.insert(0, p)
 
 
+def pytest_addoption(parser):
+    parser.addoption("--soak", type=int, default=0,
+                     help="tests/test_gpu_soak.py: run N more random cases (and N // 50 more concurrency rounds) than the suite's own few")
+    parser.addoption("--soak-first", type=int, default=120, help="first seed of the --soak range (the suite's fixed seeds end below 120)")
+
+
+@pytest.fixture(scope="session")
+def soak(request):
+    return request.config.getoption("--soak"), request.config.getoption("--soak-first")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

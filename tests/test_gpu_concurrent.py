@@ -1,7 +1,7 @@
 """Many client threads on ONE engine behind the plain ABI (missing #1).  The reference serves every client's
 NextQuestion under a shared lock (PqaCore/CpuEngine.cpp:357-361; contract Interface/IPqaEngine.h:44: no concurrent calls on the
 SAME quiz); here concurrent NextQuestion calls of different quizzes are combined into one batched sweep, concurrent RecordAnswers
-into one launch (hip_engine.cpp: Combine / FlushUpdates).  Whatever the threads' interleaving, every quiz's transcript must be
+into one launch (hip_engine_combine.cpp: Combine, hip_engine_update.cpp: FlushUpdates).  Whatever the threads' interleaving, every quiz's transcript must be
 the one the same script produces alone -- questions, listed targets and the final posterior bit for bit."""
 import threading
 
