@@ -61,7 +61,8 @@ def main():
     ap.add_argument("--config", choices=sorted(CONFIGS), default="S")
     ap.add_argument("--variant", type=int, default=0, help="force an eval kernel shape (0 = auto)")
     ap.add_argument("--batch", type=int, default=-1,
-                    help="quizzes per launch of the batched-selection extra (0 = skip; default 64, or 8 for cubes over 1 GB)")
+                    help="quizzes per launch of the batched-selection extra (0 = skip; default 64, or 8 for cubes over 1 GB); "
+                         "with a batched config (L1, ...): the batch size of the run instead of the config's own")
     ap.add_argument("--force-collective", action="store_true",
                     help="use the sharded selector even on one GPU: exercises the N>1 path")
     ap.add_argument("--exchange", choices=("shm", "rccl"), default="shm",
@@ -113,6 +114,8 @@ def main():
     cfg = CONFIGS[args.config]
     Q, K, T = cfg["Q"], cfg["K"], cfg["T"]
     if "quizzes" in cfg:
+        if args.batch > 0 and args.batch != cfg["quizzes"]:
+            cfg = dict(cfg, quizzes=args.batch, traffic_key="%s_b%d" % (args.config, args.batch))   # (--config L1 --batch 32: the small-batch point)
         out = run_batched(args, cfg, np, torch, interop, pdist, ctl, rank, dev_index, device)
         if rank == 0:
             os.write(result_fd, (json.dumps(out) + "\n").encode())
@@ -897,14 +900,14 @@ def run_batched(args, cfg, np, torch, interop, pdist, ctl, rank, dev_index, devi
             "peak": peak,
             "unit": "TFLOP/s",
             "frac": tf / peak,
-            "traffic": pmc_traffic(args.config, world),
+            "traffic": pmc_traffic(cfg.get("traffic_key", args.config), world),
             "kernel": "eval_batch_kernel",
             "kernel_us": kernel_ms * 1e3,
             "kernel_us_source": "HIP events on the engine's stream around the timed steps (sweep + prep + pick kernels; the sweep "
                                 "is > 99.9 % of it at this size)",
             "algorithmic_flops_per_launch": alg_flops,
             "flops_per_element": FLOPS_PER_ELEMENT,
-            "pmc": pmc_valu(args.config, world),
+            "pmc": pmc_valu(cfg.get("traffic_key", args.config), world),
             "note": "flops = B Q K T x 45 (the reference's operation count per element, SURVEY 8(d)); peak = the %s vector peak"
                     % ("fp32" if f32 else "fp64"),
         },
@@ -1027,7 +1030,7 @@ def pmc_traffic(config, world):
         return None
 
 
-KERNEL_HEADERS = ("pqa_device.h", "eval_device.h", "prior_device.h", "pqa_kernels.h")   # (what the kernels include; hip_engine.h is the host's)
+KERNEL_HEADERS = ("pqa_device.h", "eval_device.h", "prior_device.h", "pole_device.h", "pqa_kernels.h")   # (what the kernels include; hip_engine.h is the host's)
 
 
 def kernel_sources_sha16():

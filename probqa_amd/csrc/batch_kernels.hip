@@ -126,8 +126,9 @@ struct BatchArgs {
   const uint32_t *tgap, *qgap;
   const QuizSlot *slots;
   int nSlots, Bp;
+  int Bq;                    // lanes per question group: lane = (group g = tid / Bq, quiz b = tid % Bq); Bq <= Bp, Bq divides the threads
   int64_t K, Q, ldT;
-  int TC;                    // targets per tile, a multiple of the workgroup's threads
+  int TC;                    // targets per tile (even)
   double vCompTail;          // ln(sqrt 2) / (nValidTargets + 1)^2 (:191)
   double *acc;               // fp64 totals, [grid][threads][QB][2K+2]: W_k (K), V_k (K), sum W_k H_k, lack
   BatchRecord *recs;         // [grid][Bp]: every workgroup's best question per quiz
@@ -140,22 +141,26 @@ struct BatchArgs {
 };
 constexpr int kPoleMax = 128;   // (question, quiz) pairs a workgroup re-evaluates per block of questions
 
-// Tile in LDS: R tile[TC][QB][KG + 1]; entry [tc][qi][k < KG] = A[q][kg + k][t] * invD[q][t], entry [tc][qi][KG] = invD^2.
+// Tile in LDS: R tile[TC][G * QB][KG + 1] (G question groups of QB questions each -- see eval_batch_kernel); entry [tc][qi][k < KG] =
+// A[q][kg + k][t] * invD[q][t], entry [tc][qi][KG] = invD^2.
 // Gap targets hold zeros in both (:74, :79 andnot masks; the reference masks the lack term instead, :117).
 template <typename R, int QB, int KG>
-__device__ __forceinline__ void stage_tile(const BatchArgs &a, R *tile, int64_t q0, int64_t kg, int kN, int64_t t0, int tcN) {
+__device__ __forceinline__ void stage_tile(const BatchArgs &a, R *tile, int G, int64_t q0, int64_t kg, int kN, int64_t t0, int tcN) {
   const R *cube = static_cast<const R *>(a.cube);
   const int64_t ldT = a.ldT, K = a.K;
-  for (int tc = threadIdx.x; tc < tcN; tc += blockDim.x) {
+  const int QT = G * QB;
+  for (int idx = threadIdx.x; idx < tcN * G; idx += blockDim.x) {
+    const int gg = G == 1 ? 0 : idx / tcN, tc = idx - gg * tcN;   // (neighbouring threads: neighbouring targets of one question group)
     const int64_t t = t0 + tc;
     const bool gap = bit_test(a.tgap, t);
 #pragma unroll
     for (int qi = 0; qi < QB; qi++) {
-      const int64_t q = q0 + qi < a.Q ? q0 + qi : a.Q - 1;    // (beyond the last question: a copy whose results are dropped)
+      const int64_t qq = q0 + gg * QB + qi;
+      const int64_t q = qq < a.Q ? qq : a.Q - 1;              // (beyond the last question: a copy whose results are dropped)
       const R *qb = cube + q * (K + 1) * ldT;
       const R d = qb[K * ldT + t];
       const R invD = gap ? (R)0 : Num<R>::inv(d);             // :74
-      R *dst = tile + ((size_t)tc * QB + qi) * (KG + 1);
+      R *dst = tile + ((size_t)tc * QT + gg * QB + qi) * (KG + 1);
 #pragma unroll
       for (int k = 0; k < KG; k++) dst[k] = k < kN ? qb[(kg + k) * ldT + t] * invD : (R)0;   // :81 (A * invD)
       dst[KG] = invD * invD;                                   // :117
@@ -163,8 +168,12 @@ __device__ __forceinline__ void stage_tile(const BatchArgs &a, R *tile, int64_t 
   }
 }
 
-// One workgroup: NW = blockDim / 64 waves, lane (w, l) <-> quiz b = 64 w + l.  Questions in blocks of QB consecutive local
-// indices, answers in groups of KG (K <= KG: one group).
+// One workgroup: lane tid <-> (question group g = tid / Bq, quiz b = tid % Bq).  A full batch (Bq = 256 lanes) has one group: a
+// lane is a quiz.  A smaller batch would leave the workgroup with one or two waves and the chip with a fraction of its waves (32
+// quizzes on 12500 x 5 x 100000, fp32: 379 ms per sweep where 256 quizzes take 552): the freed lanes take further questions --
+// G = threads / Bq groups side by side, each with its own QB questions of the block's G * QB; the tile holds all of them, a lane
+// reads its group's entries (one LDS address per group and wave), the lanes of a quiz read the same prior.
+// Questions in blocks of G * QB consecutive local indices, answers in groups of KG (K <= KG: one group).
 // EXACT: K == KG, so the one answer group is full and nothing in the element loops depends on a run-time answer count.
 template <typename R, int QB, int KG, bool EXACT>
 __global__ __launch_bounds__(256) void eval_batch_kernel(BatchArgs a) {
@@ -176,10 +185,14 @@ __global__ __launch_bounds__(256) void eval_batch_kernel(BatchArgs a) {
     for (int i = threadIdx.x; i < kLog2TableDoubles; i += blockDim.x) smem[i] = gLog2TableB[i];
   }
   const int tid = threadIdx.x, nThreads = blockDim.x;
-  const int b = tid;                                           // quiz of this lane
+  const int Bq = a.Bq, G = nThreads / Bq;
+  const int g = G == 1 ? 0 : tid / Bq, b = tid - g * Bq;       // question group and quiz of this lane
   const bool live = b < a.nSlots;
   const int64_t K = a.K, ldT = a.ldT;
   const int Bp = a.Bp, TC = a.TC;
+  const int QT = G * QB;
+  const R *tileLane = tile + (size_t)g * QB * (KG + 1);        // the lane's group within a target's entries
+  const size_t tileStride = (size_t)QT * (KG + 1);
   const int nChunks = (int)((ldT + TC - 1) / TC);
   const R *pt = static_cast<const R *>(a.PT) + b;
   const uint32_t *asked = live ? a.slots[b].asked : a.qgap;   // (idle lanes: any valid words)
@@ -190,10 +203,10 @@ __global__ __launch_bounds__(256) void eval_batch_kernel(BatchArgs a) {
   double *acc = a.acc + ((size_t)blockIdx.x * nThreads + tid) * (size_t)(QB * nAcc);
   double bestP = 0.0;
   int64_t bestQ = -1;
-  const int64_t nBlocks = (a.Q + QB - 1) / QB;
+  const int64_t nBlocks = (a.Q + QT - 1) / QT;
   constexpr bool kPoleWatch = Num<R>::kTable;                  // (Double engines: the fp32 tolerance covers what the summation order moves)
   for (int64_t blk = blockIdx.x; blk < nBlocks; blk += gridDim.x) {
-    const int64_t q0 = blk * QB;
+    const int64_t qBlk = blk * QT, q0 = qBlk + (int64_t)g * QB;   // the block's first question; this lane's first question
     uint32_t hiMax[QB];                                        // the largest posterior element's high word, per question (pole_device.h)
 #pragma unroll
     for (int qi = 0; qi < QB; qi++) hiMax[qi] = 0;
@@ -210,7 +223,7 @@ __global__ __launch_bounds__(256) void eval_batch_kernel(BatchArgs a) {
         const int64_t t0 = (int64_t)ch * TC;
         const int tcN = (int)(ldT - t0 < TC ? ldT - t0 : TC);
         __syncthreads();                                       // everybody is done with the previous tile
-        stage_tile<R, QB, KG>(a, tile, q0, kg, kN, t0, tcN);
+        stage_tile<R, QB, KG>(a, tile, G, qBlk, kg, kN, t0, tcN);
         __syncthreads();
         R W[QB][KG];
 #pragma unroll
@@ -218,7 +231,7 @@ __global__ __launch_bounds__(256) void eval_batch_kernel(BatchArgs a) {
 #pragma unroll
           for (int k = 0; k < KG; k++) W[qi][k] = (R)0;
         walk_targets<R>(pt + t0 * Bp, Bp, tcN, [&](int tc, R pi) __attribute__((always_inline)) {
-          const R *c = tile + (size_t)tc * QB * (KG + 1);
+          const R *c = tileLane + (size_t)tc * tileStride;
 #pragma unroll
           for (int qi = 0; qi < QB; qi++)
 #pragma unroll
@@ -245,7 +258,7 @@ __global__ __launch_bounds__(256) void eval_batch_kernel(BatchArgs a) {
         const int tcN = (int)(ldT - t0 < TC ? ldT - t0 : TC);
         if (!staged) {
           __syncthreads();
-          stage_tile<R, QB, KG>(a, tile, q0, kg, kN, t0, tcN);
+          stage_tile<R, QB, KG>(a, tile, G, qBlk, kg, kN, t0, tcN);
           __syncthreads();
         }
         R v[QB][KG], hW[QB], accL[QB];
@@ -258,7 +271,7 @@ __global__ __launch_bounds__(256) void eval_batch_kernel(BatchArgs a) {
         walk_targets<R>(pt + t0 * Bp, Bp, tcN, [&](int tc, R pi) __attribute__((always_inline)) {
           // the target's tile values -- QB x (KG + 1) wave-uniform numbers -- are all requested before the first of them is used:
           // behind the scheduling barrier of each question group they would be fetched group by group, an LDS round trip each
-          const R *c = tile + (size_t)tc * QB * (KG + 1);
+          const R *c = tileLane + (size_t)tc * tileStride;
           R cv[QB][KG + 1];
 #pragma unroll
           for (int qi = 0; qi < QB; qi++)
@@ -353,22 +366,22 @@ __global__ __launch_bounds__(256) void eval_batch_kernel(BatchArgs a) {
           const int64_t q = q0 + qi;
           if (live && q < a.Q && hiMax[qi] >= kNearOneHi && !(bit_test(a.qgap, q) || ((asked[q >> 5] >> (q & 31)) & 1u))) {
             const uint32_t at = atomicAdd(pcount, 1u);
-            if (at < (uint32_t)kPoleMax) { plist[2 * at] = (uint32_t)b; plist[2 * at + 1] = (uint32_t)qi; }
+            if (at < (uint32_t)kPoleMax) { plist[2 * at] = (uint32_t)tid; plist[2 * at + 1] = (uint32_t)qi; }
           }
         }
         __syncthreads();
         const int nPole = (int)min(*pcount, (uint32_t)kPoleMax);
         for (int e = 0; e < nPole; e++) {
-          const int b2 = (int)plist[2 * e], qi2 = (int)plist[2 * e + 1];
-          double *rec = a.acc + ((size_t)blockIdx.x * nThreads + b2) * (size_t)(QB * nAcc) + (size_t)qi2 * nAcc;   // (W_k sqrt(V_k) in place of V_k by now)
+          const int tid2 = (int)plist[2 * e], qi2 = (int)plist[2 * e + 1], g2 = tid2 / Bq, b2 = tid2 - g2 * Bq;   // (the lane that listed the pair)
+          double *rec = a.acc + ((size_t)blockIdx.x * nThreads + tid2) * (size_t)(QB * nAcc) + (size_t)qi2 * nAcc;   // (W_k sqrt(V_k) in place of V_k by now)
           const PoleRows rows{static_cast<const double *>(a.cube), a.slots[b2].prior, a.tgap, K, a.T, ldT, gLog2TableB, a.log2Entry0Ref};
           double dH = 0.0, dL = 0.0;
-          pole_fix_question<false>(rows, q0 + qi2, rec, true, red, stage, dH, dL);
+          pole_fix_question<false>(rows, qBlk + (int64_t)g2 * QB + qi2, rec, true, red, stage, dH, dL);
           if (tid == 0) fixedPri[e] = eval_epilogue(rec, -(rec[2 * K] + dH), rec + K, K, rec[2 * K + 1] + dL, a.vCompTail);
         }
         __syncthreads();
         for (int e = 0; e < nPole; e++)
-          if ((int)plist[2 * e] == b) {
+          if ((int)plist[2 * e] == tid) {
             const int64_t q = q0 + (int64_t)plist[2 * e + 1];
             const double pri = fixedPri[e];
             if (a.priorityT) a.priorityT[q * Bp + b] = pri;
@@ -378,7 +391,7 @@ __global__ __launch_bounds__(256) void eval_batch_kernel(BatchArgs a) {
       }
     }
   }
-  a.recs[(size_t)blockIdx.x * Bp + b] = BatchRecord{bestP, bestQ};
+  a.recs[((size_t)blockIdx.x * G + g) * Bp + b] = BatchRecord{bestP, bestQ};   // (a record strip per workgroup and question group)
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -733,7 +746,8 @@ template <typename R, int QB, int KG, bool EXACT>
 hipError_t launch_batch(const BatchArgs &args0, int nThreads, size_t *accBytesNeeded, int *gridOut, bool queryOnly, hipStream_t stream) {
   BatchArgs args = args0;
   auto kern = eval_batch_kernel<R, QB, KG, EXACT>;
-  size_t tileBytes = (size_t)args.TC * QB * (KG + 1) * sizeof(R);
+  const int G = nThreads / args.Bq;   // question groups side by side (eval_batch_kernel)
+  size_t tileBytes = (size_t)args.TC * G * QB * (KG + 1) * sizeof(R);
   if (Num<R>::kTable && args.poleDoubles > 0)   // (the pole fix's LDS takes the tile's place: pole_device.h)
     tileBytes = std::max(tileBytes, (size_t)(32 + args.poleDoubles + 128) * sizeof(double) + (size_t)(2 * kPoleMax + 2) * sizeof(uint32_t));
   const size_t shmem = (Num<R>::kTable ? kLog2TableDoubles * sizeof(double) : 0) + tileBytes;
@@ -751,7 +765,7 @@ hipError_t launch_batch(const BatchArgs &args0, int nThreads, size_t *accBytesNe
     cache.Put(devSlot, key, perCU);
   }
   const int nCU = cache.NumCUs(devSlot);
-  const int64_t nBlocks = (args.Q + QB - 1) / QB;
+  const int64_t nBlocks = (args.Q + G * QB - 1) / (G * QB);
   int64_t grid = (int64_t)nCU * perCU;
   if (grid > nBlocks) grid = nBlocks;
   if (grid > kBatchMaxGrid) grid = kBatchMaxGrid;
@@ -771,14 +785,28 @@ hipError_t LaunchEvalBatch(const KbView &kb, const QuizSlot *slots, int nSlots, 
                            bool skipPick) {
   if (nSlots <= 0 || nSlots > 256 || plan == nullptr) return hipErrorInvalidValue;
   const bool f32 = kb.elem == 4;
-  const int nThreads = ((nSlots + 63) / 64) * 64, Bp = nThreads;
+  // lanes: Bq per question group (the batch rounded up to 32, 64, 128 or whole waves), 256 / Bq groups per workgroup where that
+  // is a whole number -- a lane is a quiz, and lanes a small batch leaves over take further questions (eval_batch_kernel)
+  const int Bp = ((nSlots + 63) / 64) * 64;
+  const int Bq = nSlots <= 32 ? 32 : Bp;
+  // questions per block: the more, the fewer prior loads and tile reads per element -- and the more registers
+  const int qb = plan->questionsPerBlock > 0 ? plan->questionsPerBlock : (f32 ? 4 : 2);
+  // groups: as many as the lanes allow while every CU still gets a workgroup (a small cube keeps its waves apart instead)
+  static LaunchCache devInfo;
+  const int nCUs = devInfo.NumCUs(LaunchCache::Device());
+  int G = 256 % Bq == 0 ? 256 / Bq : 1;
+  if (plan->questionGroups > 0) G = std::min(G, 1 << (31 - __builtin_clz((unsigned)plan->questionGroups)));
+  else while (G > 1 && (kb.Q + (int64_t)G * qb - 1) / ((int64_t)G * qb) < (f32 ? nCUs : nCUs * 3 / 4)) G >>= 1;   // (measured: tools/batch_bench.py)
+  const int nThreads = G * Bq;
   BatchArgs a{};
-  a.cube = kb.cube; a.PT = PT; a.tgap = kb.tgap; a.qgap = kb.qgap; a.slots = slots; a.nSlots = nSlots; a.Bp = Bp;
+  a.cube = kb.cube; a.PT = PT; a.tgap = kb.tgap; a.qgap = kb.qgap; a.slots = slots; a.nSlots = nSlots; a.Bp = Bp; a.Bq = Bq;
   a.K = kb.K; a.Q = kb.Q; a.ldT = kb.ldT;
   // default tile (measured, 256 quizzes): fp64 256 targets; fp32 512 (2000 x 5 x 100000: 91.2 ms against 93.6 at 256 and 129.8 at
   // 1024), and a row of up to 1024 targets whole -- staged once for both passes (1000 x 5 x 1000: 341 k selections/s against 324 k)
+  // (the tile holds G groups' questions: the targets per tile shrink by G, its bytes stay)
   int tc = plan->tileTargets > 0 ? plan->tileTargets : !f32 ? 256 : kb.ldT <= 1024 ? 1024 : 512;
-  tc = ((tc + nThreads - 1) / nThreads) * nThreads;
+  tc = std::max(64, ((tc / G + 63) / 64) * 64);
+  if ((int64_t)tc > kb.ldT) tc = (int)kb.ldT;                  // (ldT is a multiple of 32)
   a.TC = tc;
   const double nT = (double)(kb.nValidTargets + 1);            // PqaCore/CEEvalQsSubtaskConsider.cpp:191
   a.vCompTail = 0.34657359027997265470861606072909 / (nT * nT);
@@ -791,8 +819,6 @@ hipError_t LaunchEvalBatch(const KbView &kb, const QuizSlot *slots, int nSlots, 
   hipError_t e;
   int grid = 0;
   const bool k5 = kb.K == 5;
-  // questions per block: the more, the fewer prior loads and tile reads per element -- and the more registers
-  const int qb = plan->questionsPerBlock > 0 ? plan->questionsPerBlock : (f32 ? 4 : 2);
   auto run = [&](bool query, size_t *accBytes) -> hipError_t {
     if (f32) {
       if (k5) return qb >= 4 ? launch_batch<float, 4, 5, true>(a, nThreads, accBytes, &grid, query, stream)
@@ -808,7 +834,7 @@ hipError_t LaunchEvalBatch(const KbView &kb, const QuizSlot *slots, int nSlots, 
   e = run(true, &plan->accBytes);
   if (e != hipSuccess) return e;
   plan->grid = grid;
-  plan->recBytes = (size_t)grid * Bp * sizeof(BatchRecord);
+  plan->recBytes = (size_t)grid * G * Bp * sizeof(BatchRecord);
   if (queryOnly) return hipSuccess;
   if (PT == nullptr || acc == nullptr || recs == nullptr) return hipErrorInvalidValue;
   const dim3 pgrid((unsigned)((kb.ldT + 63) / 64), (unsigned)(Bp / 64));
@@ -819,7 +845,7 @@ hipError_t LaunchEvalBatch(const KbView &kb, const QuizSlot *slots, int nSlots, 
   size_t dummy = 0;
   e = run(false, &dummy);
   if (e != hipSuccess || skipPick) return e;
-  hipLaunchKernelGGL(batch_pick_kernel, dim3((unsigned)nSlots), dim3(64), 0, stream, recs, grid, Bp, slots, nSlots,
+  hipLaunchKernelGGL(batch_pick_kernel, dim3((unsigned)nSlots), dim3(64), 0, stream, recs, grid * G, Bp, slots, nSlots,
                      outBase, flagValue);
   return hipGetLastError();
 }

@@ -336,6 +336,7 @@ Error HipEngine::SetOption(const char *name, int64_t value) {
   else if (n == "batch_form") { if (value < 0 || value > 3) goto bad; _optBatchForm = value; }
   else if (n == "batch_qb") { if (value < 0 || value > 4) goto bad; _optBatchQb = value; }
   else if (n == "batch_tile") { if (value < 0 || value > 8192) goto bad; _optBatchTile = value; }
+  else if (n == "batch_groups") { if (value < 0 || value > 8) goto bad; _optBatchGroups = value; }
   else if (n == "server_vram_mailbox") { if (_serverStream) goto bad; _optServerVramMailbox = value ? 1 : 0; }
   else if (n == "server_idle_us") { if (value < 10 || value > 1000000) goto bad; StopServer(); _optServerIdleUs = value; }
   else if (n == "seed") { uint64_t s = (uint64_t)value; _rng[0] = SplitMix64(s); _rng[1] = SplitMix64(s); }
@@ -393,6 +394,7 @@ int64_t HipEngine::GetOption(const char *name) const {
   if (n == "rerank") return _optRerank;
   if (n == "batch_form") return _optBatchForm;
   if (n == "batch_tile") return _optBatchTile;
+  if (n == "batch_groups") return _optBatchGroups;
   if (n == "batch_qb") return _optBatchQb;
   if (n == "precision") return _precType;
   if (n == "server_vram_mailbox") return _serverStream ? (_serverRequestInVram ? 1 : 0) : _optServerVramMailbox;

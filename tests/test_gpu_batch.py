@@ -140,6 +140,40 @@ def test_fp64_batched_sweep_against_oracle_and_single(case, n_quizzes, tile, fac
     eng.close()
 
 
+@pytest.mark.parametrize("prec", ["f64", "f32"])
+@pytest.mark.parametrize("n_quizzes,groups,tile", [(5, 8, 0), (20, 8, 64), (32, 4, 0), (33, 4, 128), (64, 2, 0), (100, 2, 64), (128, 0, 0)],
+                         ids=lambda v: str(v))
+def test_small_batches_share_a_workgroup_between_question_groups(prec, n_quizzes, groups, tile, factory):
+    """Batches of up to 128 quizzes: the lanes a small batch leaves over take further questions (batch_kernels.hip:
+    eval_batch_kernel, lane = (question group, quiz)).  The automatic rule takes the grouped form only on cubes with hundreds of
+    questions per CU-full of workgroups; here it is forced (option batch_groups) on cubes whose question counts leave the last
+    block ragged, over several LDS tiles, gaps included: every quiz's priorities against the oracle, the picks its argmaxes."""
+    case = cases.Case("groups_%s" % prec, 5, 117, 700, seed=5, qgaps=[0, 31, 116], tgaps=[3, 698])
+    rng = np.random.default_rng(4242)
+    if prec == "f64":
+        eng, orc = case.make_engine(factory), case.make_oracle()
+    else:
+        eng, orc = float_engine(case, factory)
+    eng.set_option("batch_min", 1)
+    eng.set_option("batch_form", 2)
+    eng.set_option("batch_groups", groups)
+    eng.set_option("batch_tile", tile)
+    quizzes = scripted_quizzes(case, eng, n_quizzes, rng)
+    ids = [q for q, _ in quizzes]
+    pri_b = eng.eval_priorities_batch(ids, case.Q)
+    picks = eng.next_question_argmax_batch(ids)
+    for i, (quiz, hist) in enumerate(quizzes):
+        opri, opriors = oracle_priorities(orc, hist)
+        assert np.array_equal(eng.get_priors(quiz), opriors)
+        tol = PRIORITY_RTOL if prec == "f64" else f32_tolerance(orc, case)
+        r = rel_vec(pri_b[i], opri)
+        assert (r < tol).all(), f"quiz {i} ({hist}): {r.max():g}"
+        top = np.sort(opri)[::-1]
+        if top[0] > 0 and (top[0] - top[1]) / top[0] > 10 * np.max(tol):
+            assert picks[i] == orc.select_argmax(opri), f"quiz {i}: argmax"
+    eng.close()
+
+
 def float_engine(case, factory):
     eng, err = factory.create_cpu_engine(interop.EngineDefinition(case.K, case.Q, case.T, init_amount=case.init,
                                                                   prec_type=interop.PrecisionType.FLOAT, prec_exponent=8,

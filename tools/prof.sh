@@ -13,6 +13,7 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 case $CFG in
   custom:*) KERNEL=${CFG#custom:}; shift 2; CMD="$*"; CFG=$KERNEL ;;
+  L1_b*) CMD="python $PWD/bench.py --config L1 --batch ${CFG#L1_b} --steps $STEPS --warmup 1 --no-cpu-baseline"; KERNEL=eval_batch_kernel ;;
   L1|LS|SB) CMD="python $PWD/bench.py --config $CFG --steps $STEPS --warmup 1 --no-cpu-baseline"; KERNEL=eval_batch_kernel ;;
   *) CMD="python $PWD/bench.py --config $CFG --variant $VAR --steps $STEPS --warmup 5 --no-cpu-baseline --batch 0 --no-server --no-quiz-loop --no-points"; KERNEL=eval_questions ;;
 esac
@@ -43,7 +44,7 @@ for d in sorted(glob.glob(out+"/pmc_*/")):
         for k,(n,s) in acc.items():
             print("pmc %-24s per-launch avg of %s: %.6g (n=%d)"%(k,kern,s/n,n)); vals[k]=s/n
 import hashlib
-src=hashlib.sha256(b"".join(open(os.path.join("$PWD","probqa_amd","csrc",f),"rb").read() for f in sorted(os.listdir(os.path.join("$PWD","probqa_amd","csrc"))) if f.endswith(".hip") or f in ("pqa_device.h","eval_device.h","prior_device.h","pqa_kernels.h"))).hexdigest()[:16]
+src=hashlib.sha256(b"".join(open(os.path.join("$PWD","probqa_amd","csrc",f),"rb").read() for f in sorted(os.listdir(os.path.join("$PWD","probqa_amd","csrc"))) if f.endswith(".hip") or f in ("pqa_device.h","eval_device.h","prior_device.h","pole_device.h","pqa_kernels.h"))).hexdigest()[:16]
 rec={"command": "$CMD", "kernel": kern, "kernel_sources_sha16": src}
 if "FETCH_SIZE" in vals:
     rec.update({"bytes_per_launch": vals["FETCH_SIZE"]*1024*2, "fetch_size_kb_raw": vals["FETCH_SIZE"],
