@@ -41,6 +41,8 @@ namespace {
 
 constexpr int kClusterThreads = 512;
 constexpr int kMaxK = 16;
+constexpr int kExchangeDoubles = 1024;   // LDS: xch[C][K + 2] doubles -- clusters of up to 1024 / (K + 2) members
+constexpr bool kClusterAheadByDefault = true;
 
 template <typename R> struct Vec;
 template <> struct Vec<float> { typedef float4 type; static constexpr int N = 4; };
@@ -342,6 +344,277 @@ __global__ __launch_bounds__(kClusterThreads, 4) void eval_cluster_kernel(Cluste
   if (qPrev >= 0 && (int)((round - 1) % (unsigned long long)C) == m) fold(qPrev, round - 1, wTot);
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// The same sweep with the exchange of question i under the work of its neighbours (round 4).  In the form above a
+// member's question is a chain -- pass 1, publish, wait for everybody's partials (a write-through, a read past the L2s and the skew
+// of ~100 members: 2.7 of a question's 8.1 us), pass 2 -- and only the CU's second workgroup fills the wait.  Here a member runs pass
+// 1 of the NEXT question before it asks for the current one's partials: the likelihoods of question i + 1 wait in REGISTERS (one
+// 16-byte unit per thread and answer) while pass 2 of question i still owns the LDS copy, and move there when it is done -- the LDS
+// and the slices stay what they are (two workgroups per CU), no second LDS copy (which would halve the slices and double the members
+// and the records of every exchange, or cost the second workgroup).  By the time a member polls for question i its partials have been
+// on their way for a whole pass 2 + pass 1.
+//   iteration i:  pass 1 (q[i+1]) from the arrived rows -> its likelihoods in registers, publish its partial W   |  request the rows of q[i+2]
+//                 gather W (q[i])  ->  the turn-taker folds q[i-2]  ->  pass 2 (q[i]) from LDS, publish its sums  |  likelihoods of q[i+1] -> LDS
+// Records: a member is now up to two questions ahead of another (it publishes W of q[i+1] when it has seen everybody's W of q[i-1]),
+// so the record buffers have FOUR slots (question count mod 4) instead of two, and the fold lags two questions (everybody published
+// the sums of q[i-2] before its W of q[i], which have all been seen).  One unit per thread (NU = 1): rows of up to 512 units per member.
+template <typename R>
+__global__ __launch_bounds__(kClusterThreads, 4) void eval_cluster_ahead_kernel(ClusterArgs a) {
+  typedef typename Vec<R>::type V;
+  constexpr int VN = Vec<R>::N;
+  constexpr int NW = kClusterThreads / kWave;
+  constexpr int kRows = 5;                                      // answer rows requested ahead (further ones are fetched on the spot)
+  extern __shared__ double smem[];
+  const double *tbl = smem;
+  V *lhL = reinterpret_cast<V *>(smem + (NumC<R>::kTable ? kLog2TableDoubles : 0));
+  double (*red)[NW] = reinterpret_cast<double (*)[NW]>(lhL + (size_t)a.K * a.sliceUnits);
+  double *wTot = &red[kMaxK + 2][0];
+  double *xch = wTot + kMaxK + NW / 2;                          // [C][K + 2]: the members' partials of one question
+  double *wHist = xch + kExchangeDoubles;                       // [4][kMaxK]: W_k of the last four questions (the fold lags two)
+  double *wInv = wHist + 4 * kMaxK;                             // [kMaxK]: 1 / W_k of the question in pass 2
+  if constexpr (NumC<R>::kTable) {
+    if (!lds_table_at_zero(tbl)) __builtin_trap();            // log2hot addresses the table absolutely
+    for (int i = threadIdx.x; i < kLog2TableDoubles; i += kClusterThreads) smem[i] = gLog2TableC[i];
+  }
+  const int tid = threadIdx.x, lane = tid % kWave, wave = tid / kWave;
+  const int64_t K = a.K, ldT = a.ldT;
+  const int C = a.C, g = blockIdx.x / C, m = blockIdx.x % C;   // cluster, member (= slice)
+  const int nUnits = (int)(ldT / VN), SU = a.sliceUnits;
+  const int u0 = m * SU;
+  const int nMine = u0 >= nUnits ? 0 : (nUnits - u0 < SU ? nUnits - u0 : SU);
+  const R *cube = static_cast<const R *>(a.cube);
+  const int64_t qStride = (K + 1) * ldT;
+  const bool in = tid < nMine, inSlice = tid < SU;
+  const int ui = in ? u0 + tid : (nUnits - 1);                  // unit index within the row (clamped; units beyond the slice are masked)
+  const int64_t t0 = (int64_t)ui * VN;
+  const uint32_t gapBits = in ? (a.tgap[t0 >> 5] >> (t0 & 31)) & ((1u << VN) - 1) : (1u << VN) - 1;   // (bits past T are set)
+  V pr;
+#pragma unroll
+  for (int e = 0; e < VN; e++) at<R>(pr, e) = ((gapBits >> e) & 1) ? (R)0 : (R)a.prior[t0 + e];      // :103
+  ExRec *recW = a.recW + (size_t)g * 4 * C * kMaxK, *recS = a.recS + (size_t)g * 4 * C * (kMaxK + 2);
+  const unsigned long long tagBase = a.tagBase;
+
+  auto gather = [&](const ExRec *recs, int stride, int n, unsigned long long tag) {   // (as eval_cluster_kernel's)
+    const int total = C * n;
+    const RowRsrc rs = row_rsrc(recs, (int64_t)C * stride * (int64_t)sizeof(ExRec));
+    constexpr int kAuxSc1 = 16;
+    uint32_t off[2];
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+      const int r = tid + u * kClusterThreads;
+      const int rc = r < total ? r : 0;
+      const int mm = rc / n, kk = rc - mm * n;
+      off[u] = (uint32_t)((mm * stride + kk) * (int)sizeof(ExRec));
+    }
+    unsigned spins = 0;
+    for (;;) {
+      u32x4_t x[2];
+#pragma unroll
+      for (int u = 0; u < 2; u++)
+        if (u == 0 || total > kClusterThreads) x[u] = __builtin_amdgcn_raw_buffer_load_b128(rs, off[u], 0, kAuxSc1);
+      int ok = 1;
+#pragma unroll
+      for (int u = 0; u < 2; u++) {
+        const int r = tid + u * kClusterThreads;
+        if ((u == 0 || total > kClusterThreads) && r < total) {
+          const unsigned long long t = (unsigned long long)x[u][2] | ((unsigned long long)x[u][3] << 32);
+          if (t == tag) xch[r] = u2d((unsigned long long)x[u][0] | ((unsigned long long)x[u][1] << 32)); else ok = 0;
+        }
+      }
+      if (__all(ok)) break;
+      __builtin_amdgcn_s_sleep(1);
+      if (++spins > (1u << 26)) __builtin_trap();               // (minutes: a member died -- no silent hang)
+    }
+    __syncthreads();
+  };
+  auto sum_members = [&](int n, double *out) {
+    for (int col = wave; col < n; col += NW) {
+      double s = 0.0;
+      for (int i = lane; i < C; i += kWave) s += xch[i * n + col];
+      s = wave_sum(s);
+      if (lane == 0) out[col] = s;
+    }
+  };
+  auto fold = [&](int64_t qq, unsigned long long cnt) {
+    gather(recS + (size_t)(cnt & 3) * C * (kMaxK + 2), kMaxK + 2, (int)K + 2, tagBase + cnt + 1);
+    sum_members((int)K + 2, red[0]);
+    __syncthreads();
+    if (tid < K + 2) {
+      const double s = red[0][tid];
+      double *tot = a.totals + (size_t)qq * (2 * kMaxK + 2);
+      if (tid < K) { tot[tid] = wHist[(cnt & 3) * kMaxK + tid]; tot[kMaxK + tid] = s; }
+      else tot[2 * kMaxK + (tid - K)] = s;
+    }
+    __syncthreads();
+  };
+  auto next_valid = [&](int64_t q) {    // :54
+    while (q < a.Q && (bit_test(a.qgap, q) || bit_test(a.asked, q))) {
+      if (m == 0 && tid == 0) a.priority[q] = 0.0;
+      q += a.nClusters;
+    }
+    return q;
+  };
+  V dN, rows[kRows];
+  auto request_question = [&](int64_t qq) __attribute__((always_inline)) {
+    const R *base = cube + qq * qStride;
+    dN = reinterpret_cast<const V *>(base + K * ldT)[ui];
+#pragma unroll
+    for (int k = 0; k < kRows; k++)
+      if (k < K) rows[k] = reinterpret_cast<const V *>(base + k * ldT)[ui];
+  };
+  // pass 1 of question qq (count cnt) on the rows that have arrived: 1/D and the likelihoods of the first kRows answers into idOut /
+  // lhOut (registers), further answers' likelihoods straight into LDS when `direct` (the first question) or not at all here -- they
+  // are formed again when the registers move to LDS (store_question); the partial W_k published.
+  auto pass1 = [&](int64_t qq, unsigned long long cnt, V &idOut, V (&lhOut)[kRows]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int e = 0; e < VN; e++) at<R>(idOut, e) = ((gapBits >> e) & 1) ? (R)0 : NumC<R>::inv(at<R>(dN, e));   // :74
+    auto row_sum = [&](int64_t k, const V &row, V &lh) __attribute__((always_inline)) {
+      R sum = (R)0;
+#pragma unroll
+      for (int e = 0; e < VN; e++) {
+        at<R>(lh, e) = (at<R>(row, e) * at<R>(idOut, e)) * at<R>(pr, e);   // :81-82
+        sum += at<R>(lh, e);
+      }
+      const double sw = wave_sum_d((double)sum);
+      if (lane == 0) red[k][wave] = sw;
+    };
+#pragma unroll
+    for (int k = 0; k < kRows; k++)
+      if (k < K) row_sum(k, rows[k], lhOut[k]);
+    for (int64_t k = kRows; k < K; k++) {                       // (more than kRows answers: summed here, formed again for LDS later)
+      const V late = reinterpret_cast<const V *>(cube + qq * qStride + k * ldT)[ui];
+      V lh;
+      row_sum(k, late, lh);
+    }
+    __syncthreads();
+    if (tid < K) {
+      double w = 0.0;
+      for (int i = 0; i < NW; i++) w += red[tid][i];
+      put_record(recW + ((size_t)(cnt & 3) * C + m) * kMaxK + tid, w, tagBase + cnt + 1);
+    }
+  };
+  // the likelihoods of question qq into LDS (pass 2 of the question before it is done with the copy: the caller's barrier)
+  auto store_question = [&](int64_t qq, const V &idOf, const V (&lhOf)[kRows]) __attribute__((always_inline)) {
+    if (inSlice) {
+#pragma unroll
+      for (int k = 0; k < kRows; k++)
+        if (k < K) lhL[k * SU + tid] = lhOf[k];
+      for (int64_t k = kRows; k < K; k++) {
+        const V late = reinterpret_cast<const V *>(cube + qq * qStride + k * ldT)[ui];
+        V lh;
+#pragma unroll
+        for (int e = 0; e < VN; e++) at<R>(lh, e) = (at<R>(late, e) * at<R>(idOf, e)) * at<R>(pr, e);
+        lhL[k * SU + tid] = lh;
+      }
+    }
+  };
+
+  if constexpr (NumC<R>::kTable) __syncthreads();
+  unsigned long long round = 0;                                 // count of the question in pass 2 (the cluster's questions so far)
+  int64_t q = next_valid(g), qPrev = -1, qPrev2 = -1;
+  V id, idNext, lhNext[kRows];
+  if (q < a.Q) {
+    request_question(q);
+    pass1(q, 0, idNext, lhNext);                                // (the first question: nothing to hide behind)
+    store_question(q, idNext, lhNext);
+    id = idNext;
+  }
+  int64_t qNext = q < a.Q ? next_valid(q + a.nClusters) : a.Q;
+  if (qNext < a.Q) request_question(qNext);
+  while (q < a.Q) {
+    // ---- pass 1 of the NEXT question; then its successor's rows are requested into the registers that are free again
+    const int64_t qNext2 = qNext < a.Q ? next_valid(qNext + a.nClusters) : a.Q;
+    if (qNext < a.Q) {
+      pass1(qNext, round + 1, idNext, lhNext);
+      if (qNext2 < a.Q) request_question(qNext2);
+    }
+    // ---- everybody's partial W of THIS question (published an iteration ago), in slice order
+    gather(recW + (size_t)(round & 3) * C * kMaxK, kMaxK, (int)K, tagBase + round + 1);
+    sum_members((int)K, red[8]);
+    __syncthreads();                                            // (xch is read)
+    // the turn-taker folds the question before the previous one: every member published its sums before it published its W of this
+    // question, which have all just been seen
+    if (qPrev2 >= 0 && (int)((round - 2) % (unsigned long long)C) == m) fold(qPrev2, round - 2);
+    if (tid < K) {
+      const double w = red[8][tid];
+      wTot[tid] = w;
+      wInv[tid] = div_fast(1.0, w);                     // :91, once per workgroup (every thread formed it: a fifth of pass 2's instructions)
+      wHist[(round & 3) * kMaxK + tid] = w;
+    }
+    __syncthreads();
+    // ---- pass 2 (:95-128) from LDS, answer by answer.  The lanes' sums are not reduced wave by wave (K + 2 butterflies of six DPP
+    // steps each were a quarter of the iteration's instructions): a lane parks its K + 2 sums in the LDS slots of its own unit --
+    // 16 bytes per answer row, dead once the row's likelihoods have been read -- and sixteen groups of 32 lanes add one column each.
+    double *slot = reinterpret_cast<double *>(lhL);             // unit u of row k: slot[(k * SU + u) * 2 + {0, 1}]
+    V accN, accD;
+    R hW = (R)0, accL = (R)0;
+    for (int64_t k = 0; k < K; k++) {
+      const R invWk = (R)wInv[k];                               // :91 (formed once per workgroup, above)
+      R vk = (R)0;
+      if (inSlice) {
+        const V lh = lhL[k * SU + tid];
+#pragma unroll
+        for (int e = 0; e < VN; e++) {
+          const R l = at<R>(lh, e), pi = at<R>(pr, e);
+          const R p = l * invWk;                                // :97
+          const R l2 = NumC<R>::log2p(p, tbl);                  // :106
+          hW = fma(l, l2, hW);                                  // :113-114 weighted by W_k (eval_epilogue)
+          const R dd = p - pi;                                  // :119
+          vk = fma(dd, dd, vk);                                 // :126-127
+          if (k == 0) { at<R>(accN, e) = (R)1; at<R>(accD, e) = l2; }   // :117 sum_k 1 / log2 p_k = N / D, answer by answer
+          else { at<R>(accN, e) = fma(at<R>(accN, e), l2, at<R>(accD, e)); at<R>(accD, e) = at<R>(accD, e) * l2; }
+        }
+        slot[(k * SU + tid) * 2] = (double)vk;
+      }
+    }
+    if (inSlice) {
+#pragma unroll
+      for (int e = 0; e < VN; e++) {
+        const R i1 = at<R>(id, e);
+        accL = fma((i1 * at<R>(accN, e)) * i1, NumC<R>::rcp(at<R>(accD, e)), accL);
+      }
+      slot[tid * 2 + 1] = (double)hW;                           // (row 0's second double)
+      if (K > 1) slot[(SU + tid) * 2 + 1] = (double)accL;       // (row 1's)
+    }
+    if (K == 1) {                                               // (one answer: one row of slots -- the lack sum the old way)
+      const double s2 = wave_sum_d((double)accL);
+      if (lane == 0) red[0][wave] = s2;
+    }
+    __syncthreads();                                            // (the slots are complete)
+    {
+      const int grp = tid >> 5, l32 = tid & 31;                 // column grp of the K + 2: V_k (k < K) | sum l log2 p | lack
+      if (grp < K + 2) {
+        const double *src = grp < K ? slot + (size_t)grp * SU * 2 : grp == K ? slot + 1 : slot + (size_t)SU * 2 + 1;
+        double acc = 0.0;
+        if (grp == K + 1 && K == 1) {
+          if (l32 < NW) acc = red[0][l32];
+        } else {
+          for (int u = l32; u < SU; u += 32) acc += src[(size_t)u * 2];
+        }
+        acc += mov_dpp<kDppXor1>(acc);
+        acc += mov_dpp<kDppXor2>(acc);
+        acc += mov_dpp<kDppHalfMirror>(acc);
+        acc += mov_dpp<kDppMirror>(acc);
+        const Pair pq = swap16(acc);
+        acc = pq.a + pq.b;
+        if (l32 == 0) put_record(recS + ((size_t)(round & 3) * C + m) * (kMaxK + 2) + grp, acc, tagBase + round + 1);
+      }
+    }
+    __syncthreads();                                            // (the slots are read: the LDS copy is free)
+    // ---- the next question's likelihoods move from the registers to LDS
+    if (qNext < a.Q) { store_question(qNext, idNext, lhNext); id = idNext; }
+    qPrev2 = qPrev;
+    qPrev = q;
+    round++;
+    q = qNext;
+    qNext = qNext2;
+    __syncthreads();                                            // red[] is free again, the LDS copy is the new question's
+  }
+  // the last two questions' sums: their turn-takers wait for them
+  if (qPrev2 >= 0 && (int)((round - 2) % (unsigned long long)C) == m) fold(qPrev2, round - 2);
+  if (qPrev >= 0 && (int)((round - 1) % (unsigned long long)C) == m) fold(qPrev, round - 1);
+}
+
 // :134-207, one thread per question
 __global__ __launch_bounds__(256) void cluster_epilogue_kernel(const double *__restrict__ totals, const uint32_t *__restrict__ qgap,
                                                                const uint32_t *__restrict__ asked, double *__restrict__ priority,
@@ -355,18 +628,21 @@ __global__ __launch_bounds__(256) void cluster_epilogue_kernel(const double *__r
 }
 
 constexpr size_t kFixedLdsBytes = ((size_t)(kMaxK + 2) * (kClusterThreads / kWave) + kMaxK + kClusterThreads / kWave / 2) * sizeof(double);   // red[][] + wTot[] + votes[]
-constexpr size_t kExchangeLdsBytes = 8 * 1024;   // xch[C][K + 2] doubles: clusters of up to 1024 / (K + 2) members
-struct ClusterShape { int C, nClusters, sliceUnits, nu; size_t shmem; };
+constexpr size_t kExchangeLdsBytes = kExchangeDoubles * sizeof(double);
+constexpr size_t kAheadLdsBytes = 5 * kMaxK * sizeof(double);   // eval_cluster_ahead_kernel: wHist, wInv
+struct ClusterShape { int C, nClusters, sliceUnits, nu; size_t shmem; bool ahead; };
 
-template <typename R, int NU>
+template <typename R, int NU>   // NU == 0: eval_cluster_ahead_kernel
 bool occupancy_two(size_t shmem) {
   static LaunchCache cache;   // (per instantiation and device)
   const int dev = LaunchCache::Device();
   int perCU = 0;
   if (cache.Get(dev, shmem, &perCU)) return perCU >= 2;
-  auto kern = eval_cluster_kernel<R, NU>;
+  const void *kern;
+  if constexpr (NU == 0) kern = reinterpret_cast<const void *>(eval_cluster_ahead_kernel<R>);
+  else kern = reinterpret_cast<const void *>(eval_cluster_kernel<R, NU>);
   hipError_t e = hipSuccess;
-  if (shmem > 64 * 1024) e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+  if (shmem > 64 * 1024) e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
   if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, kern, kClusterThreads, shmem);
   if (e != hipSuccess) { perCU = 0; (void)hipGetLastError(); }   // (not this launch's error: the caller falls back to the streaming form)
   cache.Put(dev, shmem, perCU);
@@ -375,17 +651,18 @@ bool occupancy_two(size_t shmem) {
 
 // Slices as long as two workgroups' LDS per CU allow (72 KB each, the fp64 table included): the fewer members a cluster has, the
 // fewer partials every member adds per question.
+// ahead: the form that runs pass 1 a question ahead (eval_cluster_ahead_kernel: one unit per thread).
 template <typename R>
-bool cluster_shape(const KbView &kb, int nCU, ClusterShape *out) {
+bool cluster_shape_of(const KbView &kb, int nCU, bool ahead, ClusterShape *out) {
   constexpr int VN = Vec<R>::N;
   if (kb.K > kMaxK || kb.K < 1) return false;
   const int64_t nUnits = kb.ldT / VN;
   const size_t tableBytes = NumC<R>::kTable ? kLog2TableDoubles * sizeof(double) : 0;
-  const size_t budget = 72 * 1024 - tableBytes - kFixedLdsBytes - kExchangeLdsBytes;
+  const size_t budget = 72 * 1024 - tableBytes - kFixedLdsBytes - kExchangeLdsBytes - (ahead ? kAheadLdsBytes : 0);
   int64_t maxUnits = (int64_t)(budget / ((size_t)kb.K * 16));
   // fp32: up to two units per thread (fewer members per cluster: 1797 vs 2018 us at 2000 x 5 x 100000); fp64: one -- with two the
   // next question's rows do not fit the 128 registers beside pass 2 and spill (6160 vs 4459 us)
-  maxUnits = std::min<int64_t>(maxUnits, (NumC<R>::kTable ? 1 : 2) * kClusterThreads);
+  maxUnits = std::min<int64_t>(maxUnits, (NumC<R>::kTable || ahead ? 1 : 2) * kClusterThreads);
   maxUnits = maxUnits / kWave * kWave;
   if (maxUnits < kWave) return false;
   const int64_t C = (nUnits + maxUnits - 1) / maxUnits;
@@ -401,8 +678,17 @@ bool cluster_shape(const KbView &kb, int nCU, ClusterShape *out) {
   out->nClusters = (int)std::max<int64_t>(1, std::min<int64_t>(capacity / C, kb.Q));
   out->sliceUnits = (int)su;
   out->nu = su <= kClusterThreads ? 1 : 2;
-  out->shmem = tableBytes + (size_t)kb.K * su * 16 + kFixedLdsBytes + kExchangeLdsBytes;
+  out->ahead = ahead;
+  out->shmem = tableBytes + (size_t)kb.K * su * 16 + kFixedLdsBytes + kExchangeLdsBytes + (ahead ? kAheadLdsBytes : 0);
+  if (ahead) return occupancy_two<R, 0>(out->shmem);
   return out->nu == 1 ? occupancy_two<R, 1>(out->shmem) : occupancy_two<R, 2>(out->shmem);
+}
+// KbView::clusterForm (engine option cluster_form): 0 = the default below, 1 = the question-by-question form, 2 = pass 1 a question ahead
+template <typename R>
+bool cluster_shape(const KbView &kb, int nCU, ClusterShape *out) {
+  const bool ahead = kb.clusterForm == 0 ? kClusterAheadByDefault : kb.clusterForm == 2;
+  if (ahead && cluster_shape_of<R>(kb, nCU, true, out)) return true;
+  return cluster_shape_of<R>(kb, nCU, false, out);
 }
 
 int device_cus() {
@@ -425,7 +711,7 @@ const char *EvalClusterKernelName(const KbView &kb) {
   ClusterShape s{};
   const bool ok = kb.elem == 4 ? cluster_shape<float>(kb, device_cus(), &s) : cluster_shape<double>(kb, device_cus(), &s);
   if (!ok) return "stream";
-  std::snprintf(name, sizeof(name), "%s_cluster%d_x%d", kb.elem == 4 ? "f32" : "f64", s.C, s.nClusters);
+  std::snprintf(name, sizeof(name), "%s_cluster%d_x%d%s", kb.elem == 4 ? "f32" : "f64", s.C, s.nClusters, s.ahead ? "_ahead" : "");
   return name;
 }
 
@@ -434,7 +720,7 @@ size_t EvalClusterScratchBytes(const KbView &kb) {
   ClusterShape s{};
   const bool ok = kb.elem == 4 ? cluster_shape<float>(kb, device_cus(), &s) : cluster_shape<double>(kb, device_cus(), &s);
   if (!ok) return 0;
-  const size_t perCluster = (size_t)2 * s.C * (2 * kMaxK + 2) * sizeof(ExRec);
+  const size_t perCluster = (size_t)4 * s.C * (2 * kMaxK + 2) * sizeof(ExRec);   // (four record slots: the form that runs ahead; the other uses two)
   return (size_t)s.nClusters * perCluster + (size_t)kb.Q * (2 * kMaxK + 2) * sizeof(double) + 256;
 }
 
@@ -448,14 +734,17 @@ hipError_t LaunchEvalCluster(const KbView &kb, const double *prior, const uint32
   a.cube = kb.cube; a.prior = prior; a.tgap = kb.tgap; a.qgap = kb.qgap; a.asked = asked;
   a.K = kb.K; a.Q = kb.Q; a.ldT = kb.ldT; a.C = s.C; a.nClusters = s.nClusters; a.sliceUnits = s.sliceUnits;
   a.recW = reinterpret_cast<ExRec *>(p);
-  a.recS = a.recW + (size_t)s.nClusters * 2 * s.C * kMaxK;
-  a.totals = reinterpret_cast<double *>(a.recS + (size_t)s.nClusters * 2 * s.C * (kMaxK + 2));
+  a.recS = a.recW + (size_t)s.nClusters * 4 * s.C * kMaxK;
+  a.totals = reinterpret_cast<double *>(a.recS + (size_t)s.nClusters * 4 * s.C * (kMaxK + 2));
   a.priority = priority;
   static std::atomic<unsigned long long> launches{0};
   a.tagBase = (launches.fetch_add(1) + 1) << 32;
   hipError_t e = hipSuccess;
   const dim3 grid((unsigned)(s.C * s.nClusters));
-  if (f32) {
+  if (s.ahead) {
+    if (f32) hipLaunchKernelGGL((eval_cluster_ahead_kernel<float>), grid, dim3(kClusterThreads), s.shmem, stream, a);
+    else hipLaunchKernelGGL((eval_cluster_ahead_kernel<double>), grid, dim3(kClusterThreads), s.shmem, stream, a);
+  } else if (f32) {
     if (s.nu == 1) hipLaunchKernelGGL((eval_cluster_kernel<float, 1>), grid, dim3(kClusterThreads), s.shmem, stream, a);
     else hipLaunchKernelGGL((eval_cluster_kernel<float, 2>), grid, dim3(kClusterThreads), s.shmem, stream, a);
   } else {

@@ -57,6 +57,7 @@ struct KbView {
   double *priorScratch;   // 8 * kMaxWorkers + 2 doubles (device): the subtasks' sums of the long-row posterior kernels (prior_kernels.hip); may be null
   int maxGrid;            // test hook (engine option "eval_max_grid"): cap the workgroups of a sweep, so that a small cube makes
                           // every workgroup stream dozens of questions; 0 = no cap
+  int clusterForm;        // long rows (cluster_kernels.hip): 0 = default, 1 = question by question, 2 = pass 1 a question ahead (option cluster_form)
   double *poleScratch;    // Q x (2 K + 2) doubles (device): the sums of questions with a row at the pole of the lack term, between the
                           // sweep and its fix (eval_kernels.hip: pole_fix); may be null (then such questions keep the sweep's own sums)
 };

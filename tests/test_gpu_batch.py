@@ -296,7 +296,8 @@ def test_batched_sweep_mid_size_fp64_and_fp32(factory):
                                      (16384, 5, "f32_wg1024_nq4"), (20000, 5, "f32_cluster7_x14"), (70000, 3, "f32_cluster18_x14"),
                                      (900, 17, "f32_stream")],
                          ids=lambda v: str(v))
-def test_float_single_quiz_register_shapes(T, K, name, factory):
+@pytest.mark.parametrize("cluster_form", [1, 2], ids=["by_question", "ahead"])
+def test_float_single_quiz_register_shapes(T, K, name, cluster_form, factory):
     """The single-quiz sweep of a Float engine, every register shape (eval_f32_kernels.hip), the cluster form for long rows
     (cluster_kernels.hip) and the streaming form behind them:
     against the fp64 oracle on the rounded cube at the fp32 tolerance, after StartQuiz and after three answers, with target and
@@ -307,8 +308,14 @@ def test_float_single_quiz_register_shapes(T, K, name, factory):
     tgaps = sorted(rng.choice(T, 7, replace=False).tolist()) + [T - 1]
     case = cases.Case("f32shape_%d" % T, K, Q, T, seed=T, tgaps=sorted(set(tgaps)), qgaps=[3],
                       answers=[(5, 1), (0, K - 1), (13, 0)])
+    if cluster_form == 2 and "cluster" not in name:
+        pytest.skip("the two forms of the cluster sweep are for rows beyond the register shapes")
     eng, orc = float_engine(case, factory)
-    assert eng.eval_kernel_name() == name
+    eng.set_option("cluster_form", cluster_form)
+    if cluster_form == 2:       # (one unit per thread: more members than the question-by-question form's two)
+        assert eng.eval_kernel_name().startswith("f32_cluster") and eng.eval_kernel_name().endswith("_ahead")
+    else:
+        assert eng.eval_kernel_name() == name
     quiz = eng.start_quiz()
     tol = f32_tolerance(orc, case)
     worst = 0.0
@@ -342,7 +349,8 @@ def test_float_single_quiz_register_shapes(T, K, name, factory):
 
 @pytest.mark.parametrize("T,K,name", [(20000, 5, "f64_cluster20_x14"), (40000, 2, "f64_cluster40_x12"), (16500, 9, "f64_cluster26_x14")],
                          ids=lambda v: str(v))
-def test_double_long_rows_cluster_sweep(T, K, name, factory):
+@pytest.mark.parametrize("cluster_form", [1, 2], ids=["by_question", "ahead"])
+def test_double_long_rows_cluster_sweep(T, K, name, cluster_form, factory):
     """Rows beyond the register shapes on a Double engine: the question split over a cluster of workgroups (cluster_kernels.hip).
     Against the oracle at the stated bar, after StartQuiz and after three answers, with gaps; the streaming form (variant 99) on
     the same states; argmax and the sampled selector's pick as the oracle's."""
@@ -351,7 +359,8 @@ def test_double_long_rows_cluster_sweep(T, K, name, factory):
     tgaps = sorted(set(rng.choice(T, 9, replace=False).tolist() + [T - 1, 0]))
     case = cases.Case("f64long_%d" % T, K, Q, T, seed=T + 1, tgaps=tgaps, qgaps=[7], answers=[(5, 1), (0, K - 1), (13, 0)])
     eng, orc = case.make_engine(factory), case.make_oracle()
-    assert eng.eval_kernel_name() == name
+    eng.set_option("cluster_form", cluster_form)
+    assert eng.eval_kernel_name() == name + ("_ahead" if cluster_form == 2 else "")
     quiz = eng.start_quiz()
     worst = 0.0
     for step in range(len(case.answers) + 1):
