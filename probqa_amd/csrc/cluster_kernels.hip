@@ -372,6 +372,8 @@ __global__ __launch_bounds__(kClusterThreads, 4) void eval_cluster_ahead_kernel(
   double *xch = wTot + kMaxK + NW / 2;                          // [C][K + 2]: the members' partials of one question
   double *wHist = xch + kExchangeDoubles;                       // [4][kMaxK]: W_k of the last four questions (the fold lags two)
   double *wInv = wHist + 4 * kMaxK;                             // [kMaxK]: 1 / W_k of the question in pass 2
+  float *park = reinterpret_cast<float *>(wInv + kMaxK);        // fp32: [K][threads] -- the lanes' pass-1 sums, added by column (kParkPass1)
+  constexpr bool kParkPass1 = !NumC<R>::kTable;                 // (Float engines have the Log2Hot table's 16 KB of LDS to spare)
   if constexpr (NumC<R>::kTable) {
     if (!lds_table_at_zero(tbl)) __builtin_trap();            // log2hot addresses the table absolutely
     for (int i = threadIdx.x; i < kLog2TableDoubles; i += kClusterThreads) smem[i] = gLog2TableC[i];
@@ -475,8 +477,12 @@ __global__ __launch_bounds__(kClusterThreads, 4) void eval_cluster_ahead_kernel(
         at<R>(lh, e) = (at<R>(row, e) * at<R>(idOut, e)) * at<R>(pr, e);   // :81-82
         sum += at<R>(lh, e);
       }
-      const double sw = wave_sum_d((double)sum);
-      if (lane == 0) red[k][wave] = sw;
+      if constexpr (kParkPass1) {
+        park[k * kClusterThreads + tid] = (float)sum;           // (a butterfly of six DPP steps per answer otherwise: a sixth of the iteration's instructions)
+      } else {
+        const double sw = wave_sum_d((double)sum);
+        if (lane == 0) red[k][wave] = sw;
+      }
     };
 #pragma unroll
     for (int k = 0; k < kRows; k++)
@@ -487,10 +493,27 @@ __global__ __launch_bounds__(kClusterThreads, 4) void eval_cluster_ahead_kernel(
       row_sum(k, late, lh);
     }
     __syncthreads();
-    if (tid < K) {
-      double w = 0.0;
-      for (int i = 0; i < NW; i++) w += red[tid][i];
-      put_record(recW + ((size_t)(cnt & 3) * C + m) * kMaxK + tid, w, tagBase + cnt + 1);
+    if constexpr (kParkPass1) {
+      const int grp = tid >> 5, l32 = tid & 31;                 // sixteen groups of 32 lanes, a column (answer) each
+      for (int col = grp; col < K; col += kClusterThreads / 32) {
+        const float *src = park + col * kClusterThreads + l32;
+        double acc = 0.0;
+#pragma unroll
+        for (int i = 0; i < kClusterThreads / 32; i++) acc += (double)src[32 * i];
+        acc += mov_dpp<kDppXor1>(acc);
+        acc += mov_dpp<kDppXor2>(acc);
+        acc += mov_dpp<kDppHalfMirror>(acc);
+        acc += mov_dpp<kDppMirror>(acc);
+        const Pair pq = swap16(acc);
+        acc = pq.a + pq.b;
+        if (l32 == 0) put_record(recW + ((size_t)(cnt & 3) * C + m) * kMaxK + col, acc, tagBase + cnt + 1);
+      }
+    } else {
+      if (tid < K) {
+        double w = 0.0;
+        for (int i = 0; i < NW; i++) w += red[tid][i];
+        put_record(recW + ((size_t)(cnt & 3) * C + m) * kMaxK + tid, w, tagBase + cnt + 1);
+      }
     }
   };
   // the likelihoods of question qq into LDS (pass 2 of the question before it is done with the copy: the caller's barrier)
@@ -530,18 +553,35 @@ __global__ __launch_bounds__(kClusterThreads, 4) void eval_cluster_ahead_kernel(
     }
     // ---- everybody's partial W of THIS question (published an iteration ago), in slice order
     gather(recW + (size_t)(round & 3) * C * kMaxK, kMaxK, (int)K, tagBase + round + 1);
-    sum_members((int)K, red[8]);
-    __syncthreads();                                            // (xch is read)
+    // (two forms of the same sums, each kept where it measured faster on one box at 2000 x 5 x 100000: the sums written straight to
+    //  where pass 2 and the fold look, one barrier less -- fp32 1517 -> 1489 us, fp64 3206 -> 3262 us)
+    constexpr bool kDirectSums = !NumC<R>::kTable;
+    if constexpr (kDirectSums) {
+      for (int col = wave; col < K; col += NW) {
+        double w = 0.0;
+        for (int i = lane; i < C; i += kWave) w += xch[i * (int)K + col];
+        w = wave_sum(w);
+        if (lane == 0) {
+          wInv[col] = div_fast(1.0, w);                         // :91, once per workgroup (every thread formed it: a fifth of pass 2's instructions)
+          wHist[(round & 3) * kMaxK + col] = w;
+        }
+      }
+      __syncthreads();                                          // (xch is read, W is there)
+    } else {
+      sum_members((int)K, red[8]);
+      __syncthreads();                                          // (xch is read)
+    }
     // the turn-taker folds the question before the previous one: every member published its sums before it published its W of this
     // question, which have all just been seen
     if (qPrev2 >= 0 && (int)((round - 2) % (unsigned long long)C) == m) fold(qPrev2, round - 2);
-    if (tid < K) {
-      const double w = red[8][tid];
-      wTot[tid] = w;
-      wInv[tid] = div_fast(1.0, w);                     // :91, once per workgroup (every thread formed it: a fifth of pass 2's instructions)
-      wHist[(round & 3) * kMaxK + tid] = w;
+    if constexpr (!kDirectSums) {
+      if (tid < K) {
+        const double w = red[8][tid];
+        wInv[tid] = div_fast(1.0, w);                           // :91, once per workgroup
+        wHist[(round & 3) * kMaxK + tid] = w;
+      }
+      __syncthreads();
     }
-    __syncthreads();
     // ---- pass 2 (:95-128) from LDS, answer by answer.  The lanes' sums are not reduced wave by wave (K + 2 butterflies of six DPP
     // steps each were a quarter of the iteration's instructions): a lane parks its K + 2 sums in the LDS slots of its own unit --
     // 16 bytes per answer row, dead once the row's likelihoods have been read -- and sixteen groups of 32 lanes add one column each.
@@ -608,8 +648,9 @@ __global__ __launch_bounds__(kClusterThreads, 4) void eval_cluster_ahead_kernel(
     round++;
     q = qNext;
     qNext = qNext2;
-    __syncthreads();                                            // red[] is free again, the LDS copy is the new question's
+    if constexpr (!kDirectSums) __syncthreads();                // (not needed for the data: the next reader of the LDS copy is pass 2, behind pass 1's and the exchange's barriers)
   }
+  __syncthreads();
   // the last two questions' sums: their turn-takers wait for them
   if (qPrev2 >= 0 && (int)((round - 2) % (unsigned long long)C) == m) fold(qPrev2, round - 2);
   if (qPrev >= 0 && (int)((round - 1) % (unsigned long long)C) == m) fold(qPrev, round - 1);
@@ -629,7 +670,7 @@ __global__ __launch_bounds__(256) void cluster_epilogue_kernel(const double *__r
 
 constexpr size_t kFixedLdsBytes = ((size_t)(kMaxK + 2) * (kClusterThreads / kWave) + kMaxK + kClusterThreads / kWave / 2) * sizeof(double);   // red[][] + wTot[] + votes[]
 constexpr size_t kExchangeLdsBytes = kExchangeDoubles * sizeof(double);
-constexpr size_t kAheadLdsBytes = 5 * kMaxK * sizeof(double);   // eval_cluster_ahead_kernel: wHist, wInv
+constexpr size_t kAheadLdsBytes = 5 * kMaxK * sizeof(double);   // eval_cluster_ahead_kernel: wHist, wInv (+ fp32: K x threads floats, park)
 struct ClusterShape { int C, nClusters, sliceUnits, nu; size_t shmem; bool ahead; };
 
 template <typename R, int NU>   // NU == 0: eval_cluster_ahead_kernel
@@ -658,7 +699,9 @@ bool cluster_shape_of(const KbView &kb, int nCU, bool ahead, ClusterShape *out) 
   if (kb.K > kMaxK || kb.K < 1) return false;
   const int64_t nUnits = kb.ldT / VN;
   const size_t tableBytes = NumC<R>::kTable ? kLog2TableDoubles * sizeof(double) : 0;
-  const size_t budget = 72 * 1024 - tableBytes - kFixedLdsBytes - kExchangeLdsBytes - (ahead ? kAheadLdsBytes : 0);
+  const size_t parkBytes = ahead && !NumC<R>::kTable ? (size_t)kb.K * kClusterThreads * sizeof(float) : 0;
+  if (72 * 1024 < tableBytes + kFixedLdsBytes + kExchangeLdsBytes + kAheadLdsBytes + parkBytes + 64 * 16 * (size_t)kb.K) return false;
+  const size_t budget = 72 * 1024 - tableBytes - kFixedLdsBytes - kExchangeLdsBytes - (ahead ? kAheadLdsBytes + parkBytes : 0);
   int64_t maxUnits = (int64_t)(budget / ((size_t)kb.K * 16));
   // fp32: up to two units per thread (fewer members per cluster: 1797 vs 2018 us at 2000 x 5 x 100000); fp64: one -- with two the
   // next question's rows do not fit the 128 registers beside pass 2 and spill (6160 vs 4459 us)
@@ -679,7 +722,7 @@ bool cluster_shape_of(const KbView &kb, int nCU, bool ahead, ClusterShape *out) 
   out->sliceUnits = (int)su;
   out->nu = su <= kClusterThreads ? 1 : 2;
   out->ahead = ahead;
-  out->shmem = tableBytes + (size_t)kb.K * su * 16 + kFixedLdsBytes + kExchangeLdsBytes + (ahead ? kAheadLdsBytes : 0);
+  out->shmem = tableBytes + (size_t)kb.K * su * 16 + kFixedLdsBytes + kExchangeLdsBytes + (ahead ? kAheadLdsBytes + parkBytes : 0);
   if (ahead) return occupancy_two<R, 0>(out->shmem);
   return out->nu == 1 ? occupancy_two<R, 1>(out->shmem) : occupancy_two<R, 2>(out->shmem);
 }
