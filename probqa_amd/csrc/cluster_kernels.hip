@@ -67,6 +67,11 @@ template <> struct NumC<float> {
   static __device__ __forceinline__ float inv(float x) { const float r = __builtin_amdgcn_rcpf(x); return fmaf(r, fmaf(-x, r, 1.0f), r); }
 };
 
+// a 16-byte unit of a cube row, with the hint that it will not be read again (the cube streams: pqa_device.h, row_load)
+template <typename V> __device__ __forceinline__ V load_unit(const V *p) {
+  typedef unsigned int u4n __attribute__((ext_vector_type(4)));
+  return __builtin_bit_cast(V, __builtin_nontemporal_load(reinterpret_cast<const u4n *>(p)));
+}
 template <typename R> __device__ __forceinline__ R &at(typename Vec<R>::type &v, int e) { return reinterpret_cast<R *>(&v)[e]; }
 template <typename R> __device__ __forceinline__ R at(const typename Vec<R>::type &v, int e) { return reinterpret_cast<const R *>(&v)[e]; }
 
@@ -217,7 +222,7 @@ __global__ __launch_bounds__(kClusterThreads, 4) void eval_cluster_kernel(Cluste
   };
   auto load_units = [&](const R *rowPtr, V (&dst)[NU]) __attribute__((always_inline)) {
 #pragma unroll
-    for (int j = 0; j < NU; j++) dst[j] = reinterpret_cast<const V *>(rowPtr)[ui[j]];
+    for (int j = 0; j < NU; j++) dst[j] = load_unit(reinterpret_cast<const V *>(rowPtr) + ui[j]);
   };
   if constexpr (NumC<R>::kTable) __syncthreads();
   int64_t q = next_valid(g);
@@ -459,10 +464,10 @@ __global__ __launch_bounds__(kClusterThreads, 4) void eval_cluster_ahead_kernel(
   V dN, rows[kRows];
   auto request_question = [&](int64_t qq) __attribute__((always_inline)) {
     const R *base = cube + qq * qStride;
-    dN = reinterpret_cast<const V *>(base + K * ldT)[ui];
+    dN = load_unit(reinterpret_cast<const V *>(base + K * ldT) + ui);
 #pragma unroll
     for (int k = 0; k < kRows; k++)
-      if (k < K) rows[k] = reinterpret_cast<const V *>(base + k * ldT)[ui];
+      if (k < K) rows[k] = load_unit(reinterpret_cast<const V *>(base + k * ldT) + ui);
   };
   // pass 1 of question qq (count cnt) on the rows that have arrived: 1/D and the likelihoods of the first kRows answers into idOut /
   // lhOut (registers), further answers' likelihoods straight into LDS when `direct` (the first question) or not at all here -- they
@@ -488,7 +493,7 @@ __global__ __launch_bounds__(kClusterThreads, 4) void eval_cluster_ahead_kernel(
     for (int k = 0; k < kRows; k++)
       if (k < K) row_sum(k, rows[k], lhOut[k]);
     for (int64_t k = kRows; k < K; k++) {                       // (more than kRows answers: summed here, formed again for LDS later)
-      const V late = reinterpret_cast<const V *>(cube + qq * qStride + k * ldT)[ui];
+      const V late = load_unit(reinterpret_cast<const V *>(cube + qq * qStride + k * ldT) + ui);
       V lh;
       row_sum(k, late, lh);
     }
@@ -523,7 +528,7 @@ __global__ __launch_bounds__(kClusterThreads, 4) void eval_cluster_ahead_kernel(
       for (int k = 0; k < kRows; k++)
         if (k < K) lhL[k * SU + tid] = lhOf[k];
       for (int64_t k = kRows; k < K; k++) {
-        const V late = reinterpret_cast<const V *>(cube + qq * qStride + k * ldT)[ui];
+        const V late = load_unit(reinterpret_cast<const V *>(cube + qq * qStride + k * ldT) + ui);
         V lh;
 #pragma unroll
         for (int e = 0; e < VN; e++) at<R>(lh, e) = (at<R>(late, e) * at<R>(idOf, e)) * at<R>(pr, e);

@@ -105,7 +105,10 @@ __global__ __launch_bounds__(1024) void eval_questions_f32_reg(F32Args a) {
     if (p.q >= a.Q) return;             // (past the end of the stream)
     const float4 *row = reinterpret_cast<const float4 *>(a.cube + p.q * qStride + p.r * ldT);
 #pragma unroll
-    for (int j = 0; j < NQ; j++) dst[j] = row[qi[j]];
+    for (int j = 0; j < NQ; j++) {      // (non-temporal: the cube streams -- pqa_device.h, row_load)
+      typedef unsigned int u4n __attribute__((ext_vector_type(4)));
+      dst[j] = __builtin_bit_cast(float4, __builtin_nontemporal_load(reinterpret_cast<const u4n *>(row + qi[j])));
+    }
   };
   int nPend = 0;
   auto flush = [&](int n) {           // wave 0: one queued question per lane (:130-207)

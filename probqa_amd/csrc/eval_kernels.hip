@@ -403,6 +403,7 @@ template <int WPQ, int NP, bool PRLDS, bool SERVER, bool DEFER, bool FUSE = fals
 __device__ __forceinline__ void sweep_body(EvalArgs a, bool copyTable) {
   constexpr int kThreads = WPQ * kWave;
   constexpr int NPR = PRLDS ? 1 : NP;
+  constexpr bool kStreamHint = !SERVER && WPQ >= 8;            // the shapes for rows beyond 4096 targets: see row_load
   extern __shared__ double smem[];
   const int64_t ldT = a.ldT, K = a.K;
   double *tbl = smem;
@@ -457,13 +458,13 @@ __device__ __forceinline__ void sweep_body(EvalArgs a, bool copyTable) {
       const dma_rsrc_t md = dma_rsrc(a.cube + qq * qStride + K * ldT, rowBytes);
 #pragma unroll
       for (int j = 0; j < NP; j++) {
-        ring[j] = row_load(rowA, poff[j]);
+        ring[j] = row_load<kStreamHint>(rowA, poff[j]);
         dma16(md, poff[j], mdRowWaveAddr + (unsigned)j * (kThreads * 16u));
       }
     } else {
       const RowRsrc rowD = row_rsrc(a.cube + qq * qStride + K * ldT, rowBytes);
 #pragma unroll
-      for (int j = 0; j < NP; j++) ring[j] = row_load(rowD, poff[j]);
+      for (int j = 0; j < NP; j++) ring[j] = row_load<kStreamHint>(rowD, poff[j]);
     }
   };
   if (haveQ0) head_of_stream(q0);
@@ -488,7 +489,7 @@ __device__ __forceinline__ void sweep_body(EvalArgs a, bool copyTable) {
     double2 av[NP], dv[NP];
     const RowRsrc ra = row_rsrc(a.updRowA, rowBytes), rd = row_rsrc(a.updRowD, rowBytes);
 #pragma unroll
-    for (int j = 0; j < NP; j++) { av[j] = row_load(ra, poff[j]); dv[j] = row_load(rd, poff[j]); }
+    for (int j = 0; j < NP; j++) { av[j] = row_load(ra, poff[j]); dv[j] = row_load(rd, poff[j]); }   // (every workgroup reads these two rows: no streaming hint)
 #pragma unroll
     for (int j = 0; j < NP; j++) {
       const int p = tid + j * kThreads;
@@ -593,7 +594,7 @@ __device__ __forceinline__ void sweep_body(EvalArgs a, bool copyTable) {
       for (int j = 0; j < NP; j++) {
         invD[j].x = ((gapBits >> (2 * j)) & 1) ? 0.0 : div_nr(1.0, ring[j].x);      // :74 andnot(gapMask, 1/D)
         invD[j].y = ((gapBits >> (2 * j + 1)) & 1) ? 0.0 : div_nr(1.0, ring[j].y);
-        ring[j] = row_load(rowA, poff[j]);
+        ring[j] = row_load<kStreamHint>(rowA, poff[j]);
         __builtin_amdgcn_sched_barrier(0);
       }
     }
@@ -627,7 +628,7 @@ __device__ __forceinline__ void sweep_body(EvalArgs a, bool copyTable) {
 #ifdef PQA_ABLATE_REFILL   // measurement only (wrong values): the stream's rows are not loaded -- what the sweep costs without its memory
         asm volatile("" : "+v"(ring[j].x), "+v"(ring[j].y));
 #else
-        ring[j] = row_load(rowN, poff[j]);
+        ring[j] = row_load<kStreamHint>(rowN, poff[j]);
 #endif
         __builtin_amdgcn_sched_barrier(0);
       }

@@ -74,8 +74,14 @@ __device__ __forceinline__ RowRsrc row_rsrc(const void *row, int64_t bytes) {
   return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>((uintptr_t)pu), (short)0,
                                            __builtin_amdgcn_readfirstlane((int)bytes), 0x00020000);
 }
+// NT: with the hint that the bytes will not be read again (aux 2 = nt).  The cube streams -- a row is read once per sweep and by one
+// workgroup -- and on a cube that lives in HBM the hint saves the L2s the allocation: round 4, two boxes, back to back, 10000^2
+// 876 -> 853 and 893 -> 870 us, 8000^2 589 -> 578 and 598 -> 590 us.  A cube that fits the Infinity Cache is better off without it
+// (1000^2: the resident step 15.3 -> 15.6 us), so the sweep gives the hint for rows beyond 4096 targets only (the same hint on the
+// mD row's LDS-DMA loads changes nothing either way).
+template <bool NT = false>
 __device__ __forceinline__ double2 row_load(RowRsrc rs, uint32_t byteOffset) {
-  return __builtin_bit_cast(double2, __builtin_amdgcn_raw_buffer_load_b128(rs, byteOffset, 0, 0));
+  return __builtin_bit_cast(double2, __builtin_amdgcn_raw_buffer_load_b128(rs, byteOffset, 0, NT ? 2 : 0));
 }
 
 // ---- SRVectMath::Log2Hot ---------------------------------------------------------------------------------------------
