@@ -158,11 +158,14 @@ __device__ __forceinline__ void stage_tile(const BatchArgs &a, R *tile, int G, i
       const int64_t qq = q0 + gg * QB + qi;
       const int64_t q = qq < a.Q ? qq : a.Q - 1;              // (beyond the last question: a copy whose results are dropped)
       const R *qb = cube + q * (K + 1) * ldT;
-      const R d = qb[K * ldT + t];
+      // (non-temporal: the cube streams through a workgroup once per pass.  12500 x 5 x 100000 fp32, 256 quizzes, same box: 556.7 ->
+      //  545.4 ms per sweep; the L2s then keep less of what misses them -- FETCH_SIZE 168 -> 189 GB per sweep, served by the
+      //  Infinity Cache, which holds the quizzes' 102 MB of priors whole)
+      const R d = __builtin_nontemporal_load(qb + K * ldT + t);
       const R invD = gap ? (R)0 : Num<R>::inv(d);             // :74
       R *dst = tile + ((size_t)tc * QT + gg * QB + qi) * (KG + 1);
 #pragma unroll
-      for (int k = 0; k < KG; k++) dst[k] = k < kN ? qb[(kg + k) * ldT + t] * invD : (R)0;   // :81 (A * invD)
+      for (int k = 0; k < KG; k++) dst[k] = k < kN ? __builtin_nontemporal_load(qb + (kg + k) * ldT + t) * invD : (R)0;   // :81 (A * invD)
       dst[KG] = invD * invD;                                   // :117
     }
   }
