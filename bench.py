@@ -908,8 +908,9 @@ def run_batched(args, cfg, np, torch, interop, pdist, ctl, rank, dev_index, devi
             "algorithmic_flops_per_launch": alg_flops,
             "flops_per_element": FLOPS_PER_ELEMENT,
             "pmc": pmc_valu(cfg.get("traffic_key", args.config), world),
-            "note": "flops = B Q K T x 45 (the reference's operation count per element, SURVEY 8(d)); peak = the %s vector peak"
-                    % ("fp32" if f32 else "fp64"),
+            "note": "flops = B Q K T x 45 (the reference's operation count per element, SURVEY 8(d)); peak = the %s vector peak -- the "
+                    "contract's fraction.  The physical one is pmc.valu_pipe_busy: the kernel issues ~7.7 VALU instructions per "
+                    "element (packed ones carry two elements), two of them quarter-rate transcendentals" % ("fp32" if f32 else "fp64"),
         },
         "roofline_hbm": {
             "bound": "hbm",
@@ -1059,9 +1060,15 @@ def pmc_valu(config, world):
         return None
     try:
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
-            return json.load(f).get(config, {}).get("valu")
+            v = json.load(f).get(config, {}).get("valu")
     except (OSError, ValueError):
         return None
+    if v and v.get("SQ_WAVE_CYCLES") and v.get("SQ_WAVES"):
+        # the physical figure beside the contract's flops fraction: the share of the launch in which a SIMD's VALU has an
+        # instruction executing = (VALU-active share of a wave's resident cycles) x (waves per SIMD; the sweeps are persistent
+        # grids, every wave resident for the whole launch; MI355X: 256 CUs x 4 SIMDs)
+        v = dict(v, valu_pipe_busy=min(1.0, v["SQ_ACTIVE_INST_VALU"] / v["SQ_WAVE_CYCLES"] * v["SQ_WAVES"] / 1024.0))
+    return v
 
 
 def cpu_baseline(np, cfg, seconds):
