@@ -476,6 +476,8 @@ def main():
                             "shards_in_flight_max": e1.get_option("shards_in_flight_max"), "quizzes_per_batch": len(qzs),
                             "selected_question_of_quiz_0": int(p1[0])}
                         e1.close()
+            except Exception as ex:  # noqa: BLE001 -- an extra must not take the line (and the other ranks, at the barrier) with it
+                one_process["error"] = repr(ex)[:500]
             finally:
                 os.environ.pop("PQA_DEVICES", None)
         barrier()
