@@ -64,7 +64,14 @@ PQACORE_API void *PqaEngineFactory_CreateHipEngineSharded(void *pvFactory, void 
  * plus a division launch; default 1), "post_always" (test hook: the posted form of the quiz-level calls even when the engine is free),
  * "eval_max_grid" (test hook: cap the workgroups of a sweep so that each streams many questions; 0 = no cap).
  * "batch_min" (PqaEngine_NextQuestionArgmaxBatch: batches of at least this many quizzes take the row-sharing sweep, which
- * reads the cube once per batch; default 0 = decided by how many waves the batch gives that sweep; Float engines always take it), "batch_tile" (targets per LDS tile of that sweep, 0 = default).
+ * reads the cube once per batch; default 0 = decided by how many waves the batch gives that sweep; Float engines always take it), "batch_tile" (targets per LDS tile of that sweep, 0 = default),
+ * "batch_groups" (that sweep for batches of up to 128 quizzes: question groups side by side in a workgroup, so that the lanes a small
+ * batch leaves over take further questions; 0 = as many as leave every CU a workgroup [default], else at most this many),
+ * "pole_fix" (sweeps over rows of up to 4096 targets re-evaluate a row with a posterior element within 2^-17 of 1 in the reference's
+ * own summation order -- SRAccumVectDbl256.h:40-46, :62-92 -- so that late quiz states stay within 1e-9 of the reference's
+ * priorities; default 1, also PQA_POLE_FIX),
+ * "cluster_form" (the single-quiz sweep over rows beyond 16384 targets: 0 = default, 1 = question by question, 2 = pass 1 a question
+ * ahead of the exchange),
  * Read-only: "server_last_step_ns" (device-side duration of the newest finished step of the resident sweep: request in hand
  * to answer published, from the kernel's own 100 MHz clock; -1 if there is none), "precision" (TPqaPrecisionType of the engine: 1 = Float, 3 = Double), "server_active",
  * "ldT", "device". */
