@@ -140,6 +140,7 @@ struct BatchArgs {
   double log2Entry0Ref;
 };
 constexpr int kPoleMax = 128;   // (question, quiz) pairs a workgroup re-evaluates per block of questions
+constexpr int kPoleRed = 256;   // doubles of reduction scratch of pole_fix_question (partials, the rows' largest elements, 16 chains' results)
 
 // Tile in LDS: R tile[TC][G * QB][KG + 1] (G question groups of QB questions each -- see eval_batch_kernel); entry [tc][qi][k < KG] =
 // A[q][kg + k][t] * invD[q][t], entry [tc][qi][KG] = invD^2.
@@ -358,7 +359,7 @@ __global__ __launch_bounds__(256) void eval_batch_kernel(BatchArgs a) {
         // ---- (question, quiz) pairs with a posterior element within 2^-17 of 1: their rows at the pole of the lack term again,
         // the reference's way, the whole workgroup on one pair at a time (pole_device.h; the single-quiz sweep: pole_fix).  The
         // tile's LDS is free here: reduction scratch | a row of likelihoods | the list | the corrected priorities.
-        double *red = reinterpret_cast<double *>(tile), *stage = red + 32;
+        double *red = reinterpret_cast<double *>(tile), *stage = red + kPoleRed;
         uint32_t *plist = reinterpret_cast<uint32_t *>(stage + a.poleDoubles), *pcount = plist + 2 * kPoleMax;
         double *fixedPri = reinterpret_cast<double *>(plist + 2 * kPoleMax + 2);
         __syncthreads();                                       // (everybody is done with the tile)
@@ -379,7 +380,7 @@ __global__ __launch_bounds__(256) void eval_batch_kernel(BatchArgs a) {
           double *rec = a.acc + ((size_t)blockIdx.x * nThreads + tid2) * (size_t)(QB * nAcc) + (size_t)qi2 * nAcc;   // (W_k sqrt(V_k) in place of V_k by now)
           const PoleRows rows{static_cast<const double *>(a.cube), a.slots[b2].prior, a.tgap, K, a.T, ldT, gLog2TableB, a.log2Entry0Ref};
           double dH = 0.0, dL = 0.0;
-          pole_fix_question<false>(rows, qBlk + (int64_t)g2 * QB + qi2, rec, true, red, stage, dH, dL);
+          pole_fix_question<false>(rows, qBlk + (int64_t)g2 * QB + qi2, rec, true, 0u, red, kPoleRed, stage, a.poleDoubles, dH, dL);
           if (tid == 0) fixedPri[e] = eval_epilogue(rec, -(rec[2 * K] + dH), rec + K, K, rec[2 * K + 1] + dL, a.vCompTail);
         }
         __syncthreads();
@@ -752,7 +753,7 @@ hipError_t launch_batch(const BatchArgs &args0, int nThreads, size_t *accBytesNe
   const int G = nThreads / args.Bq;   // question groups side by side (eval_batch_kernel)
   size_t tileBytes = (size_t)args.TC * G * QB * (KG + 1) * sizeof(R);
   if (Num<R>::kTable && args.poleDoubles > 0)   // (the pole fix's LDS takes the tile's place: pole_device.h)
-    tileBytes = std::max(tileBytes, (size_t)(32 + args.poleDoubles + 128) * sizeof(double) + (size_t)(2 * kPoleMax + 2) * sizeof(uint32_t));
+    tileBytes = std::max(tileBytes, (size_t)(kPoleRed + args.poleDoubles + kPoleMax) * sizeof(double) + (size_t)(2 * kPoleMax + 2) * sizeof(uint32_t));
   const size_t shmem = (Num<R>::kTable ? kLog2TableDoubles * sizeof(double) : 0) + tileBytes;
   if (shmem > 160 * 1024) return hipErrorInvalidValue;
   static LaunchCache cache;   // (per instantiation and device; the occupancy also depends on the thread count: part of the key)
@@ -815,7 +816,13 @@ hipError_t LaunchEvalBatch(const KbView &kb, const QuizSlot *slots, int nSlots, 
   a.vCompTail = 0.34657359027997265470861606072909 / (nT * nT);
   a.acc = acc; a.recs = recs; a.priorityT = priorityT;
   a.T = kb.T;
-  a.poleDoubles = (!f32 && kb.poleScratch != nullptr && kb.ldT <= 4096) ? (int)(4 * ((kb.T + 3) / 4)) : 0;   // (the engine's option pole_fix: KbView::poleScratch)
+  // (the engine's option pole_fix: KbView::poleScratch; room for the rows of a question side by side -- pole_fix_question -- as far as
+  //  40 KB go: with the table and the rest two workgroups per CU still fit)
+  a.poleDoubles = 0;
+  if (!f32 && kb.poleScratch != nullptr && kb.ldT <= 4096) {
+    const int nT = (int)(4 * ((kb.T + 3) / 4));
+    a.poleDoubles = nT * (int)std::max<int64_t>(1, std::min<int64_t>(kb.K, 5120 / nT));
+  }
   a.log2Entry0Ref = std::log2(1.0 + 0x1p-11) * 9.9999999999999927e-01;   // SRVectMath.cpp:31,42
   plan->ptBytes = (size_t)kb.ldT * Bp * (f32 ? 4 : 8);
   plan->Bp = Bp;

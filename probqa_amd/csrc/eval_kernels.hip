@@ -227,26 +227,27 @@ __device__ __forceinline__ void pass2_pair(double2 lh, double2 id, double2 pr, d
 // the sweep to (three of round 3's 13 700 soak cases).  The sweep's W_k is a plain per-lane sum and a butterfly; the reference's
 // is four serial Kahan lanes down the row (SRAccumVectDbl256.h:40-46) and PreciseSum (:62-92), which no wave reproduces at speed
 // (a row of T targets is T / 4 DEPENDENT Kahan steps -- measured in round 4: every question of a late quiz redone in
-// that order costs 5 - 8 sweeps).  Only the rows AT the pole need it, though, and of those a late quiz has one in most questions,
-// not five.
+// that order costs 5 - 8 sweeps).  Only the rows AT the pole need it, though.
 //
-// So: the sweep WATCHES (one v_max3_u32 per element pair: the largest posterior element of the question) and otherwise runs as it
-// always ran.  A question with an element >= 1 - 2^-17 -- a hundred times further from the pole than where the deviation reaches
-// 1e-9 -- also leaves its sums in memory (KbView::poleScratch), and once the workgroup's stream has ended pole_fix goes over its
-// rows again, all threads side by side: a compensated sum of the row (TwoSum per thread, compensated folds) and its largest
-// likelihood with its 1/D say whether THIS row is at the pole; if so its likelihoods are staged in LDS and four lanes sum them in
-// the reference's order (T / 4 dependent steps: 4.5 us at 1000 targets), and for the element that is within 2^-17 of 1, Log2Hot
-// by the reference's operation sequence (true quotient, its own table entry 0: log2hot_ref) and the lack quotient as an exact
-// division replace what pass 2 had added for it.  That element's terms are then the oracle's.  A late quiz -- the posterior on one target --
-// has such a row in most questions: the sweep then costs 2 - 4 times its usual time (every such question's rows are read again).
+// So: the sweep WATCHES (one v_max3_u32 per element pair, a compare and a wave-uniform branch per row: the answer rows in which a
+// posterior element came within 2^-17 of 1 -- a hundred times further from the pole than where the deviation reaches 1e-9) and
+// otherwise runs as it always ran.  A question with such a row also leaves its sums in memory (KbView::poleScratch), and once the
+// workgroup's stream has ended pole_fix (pole_device.h: pole_fix_question) goes over those rows again, all threads side by side:
+// the rows' likelihoods are staged in the LDS the stream has left -- the mD landing row and the deferred sums' dump behind it: as
+// many rows as fit, side by side -- four lanes per row sum them in the reference's order (T / 4 dependent steps: 4.5 us at 1000
+// targets, for all the staged rows at once), and for the element that is within 2^-17 of 1, Log2Hot by the reference's operation
+// sequence (true quotient, its own table entry 0: log2hot_ref) and the lack quotient as an exact division replace what pass 2 had
+// added for it.  That element's terms are then the oracle's.  A late quiz -- the posterior on one target -- has EVERY row of nearly
+// every question at the pole (that target's likelihood is all of W_k whatever the answer): the sweep then costs 4.5 - 6.5 times
+// its usual time (the rows are read again, the chains are serial).
 // Tried on the way (round 4, all measured): the reference's order itself at the end of the sweep (exact; 5 - 8 sweeps per sweep
 // in a late quiz: T / 4 dependent steps per row, the rows re-read twice); the compensated sum and the correction inside the row
 // loop, from the registers (nothing re-read, +25 - 70 % in a late quiz, but the blocks between pass 1 and pass 2 cost the
 // loop its registers: +10 % at 1000 targets, +50 % at 4000 in EVERY state); the fix as a called function (the scratch segment the
 // call needs: +13 % at 1000 targets).
 // ------------------------------------------------------------------------------------------------------------------
-constexpr int kSusMax = 126;                   // suspects a workgroup lists per sweep (further ones keep the sweep's own values)
-constexpr int kSusDoubles = 64;                // LDS: two flag words (by question parity) + the list
+constexpr int kSusMax = 62;                    // suspects a workgroup lists per sweep (further ones keep the sweep's own values)
+constexpr int kSusDoubles = 64;                // LDS: two words (by question parity: the answer rows at the pole, a bit each) + the list of {question, rows}
 
 struct PoleArgs {
   const double *cube, *prior;
@@ -262,13 +263,15 @@ struct PoleArgs {
 // the sweep formed them are in args.scratch.  All threads; red: LDS, 4 x waves (at least 8) doubles; stage: LDS, a row's worth of
 // doubles; best: the workgroup's running argmax (LDS).
 template <bool COH>
-__device__ __forceinline__ void pole_fix(const PoleArgs &g, const uint32_t *list, int nSus, double *red, double *stage, Best *best) {
+__device__ __forceinline__ void pole_fix(const PoleArgs &g, const uint32_t *list, int nSus, double *red, int redDoubles, double *stage,
+                                         int stageDoubles, Best *best) {
   const PoleRows rows{g.cube, g.prior, g.tgap, g.K, g.T, g.ldT, gLog2Table, gLog2Entry0Ref};
   for (int s2 = 0; s2 < nSus; s2++) {
-    const int64_t qLocal = list[s2];
+    const int64_t qLocal = list[2 * s2];
+    const uint32_t rowMask = list[2 * s2 + 1];                 // the answer rows in which the sweep saw an element within 2^-17 of 1
     double *rec = g.scratch + qLocal * (2 * g.K + 2);          // W_k [K] | W_k sqrt(V_k) [K] | sum l log2 p | lack sum
     double dH = 0.0, dL = 0.0;                                 // (thread 0: what the near-1 elements change)
-    pole_fix_question<COH>(rows, g.qFirst + qLocal, rec, true, red, stage, dH, dL);
+    pole_fix_question<COH>(rows, g.qFirst + qLocal, rec, true, rowMask, red, redDoubles, stage, stageDoubles, dH, dL);
     if (threadIdx.x == 0) {
       const int64_t K = g.K;
       const double pri = eval_epilogue(rec, -(rec[2 * K] + dH), rec + K, K, rec[2 * K + 1] + dL, g.vCompTail);  // :130
@@ -601,7 +604,7 @@ __device__ __forceinline__ void sweep_body(EvalArgs a, bool copyTable) {
     double *part = partAll + qpar * (nPart * WPQ);
     double *rec = pend + nPend * recLen;
     double accL = 0, hW = 0;
-    uint32_t hiMax = 0;
+    uint32_t hiMax = 0, poleRows = 0;                          // (pole watch: the row's largest posterior high word; the rows that had one near 1)
     for (int64_t k = 0; k < K; k++) {
       // ---- pass 1 (:66-87): likelihoods into registers, W_k; each consumed pair is refilled from the next stream row
       double2 lh[NP];
@@ -660,6 +663,12 @@ __device__ __forceinline__ void sweep_body(EvalArgs a, bool copyTable) {
         asm volatile("" : "+v"(accL), "+v"(hW), "+v"(v));
         __builtin_amdgcn_sched_barrier(0);
       }
+      if constexpr (kPoleShape) {                              // (the pole watch by ROW: pole_fix then knows which rows to redo)
+        if (__any(hiMax >= kNearOneHi)) {                      // (a compare and a scalar branch per row; rare outside late quiz states)
+          if (hiMax >= kNearOneHi) poleRows |= 1u << (k < 31 ? (int)k : 31);
+          hiMax = 0;                                           // (below the threshold it may stand: only crossing it matters)
+        }
+      }
       if constexpr (kDefer) {
         vdump[k * kThreads + tid] = v;                         // :132, reduced with the question's other sums below
         if (tid == 0) rec[k] = Wk;                             // :90
@@ -677,7 +686,7 @@ __device__ __forceinline__ void sweep_body(EvalArgs a, bool copyTable) {
       //  barrier, which no wave passes before every wave has read here)
       vdump[K * kThreads + tid] = hW;
       vdump[(K + 1) * kThreads + tid] = accL;
-      if constexpr (kPoleShape) { if (hiMax >= kNearOneHi) susWords[qpar] = 1; }   // (rare: see pole_fix)
+      if constexpr (kPoleShape) { if (poleRows != 0) atomicOr(&susWords[qpar], poleRows); }   // (rare: see pole_fix)
       __syncthreads();
       if constexpr (kPoleShape) suspect = poleWatch && susWords[qpar] != 0 && nSus < kSusMax;
       // every 32 lanes take one of the K + 2 sums: threads/32 partials each, then a 32-lane butterfly
@@ -700,7 +709,7 @@ __device__ __forceinline__ void sweep_body(EvalArgs a, bool copyTable) {
       if (tid == 0) {
         reinterpret_cast<int64_t *>(rec)[2 * K + 2] = q;
         susWords[qpar ^ 1] = 0;                                // (the other parity's flag: read by everybody before this question's barrier, set again only behind the next question's)
-        if (suspect) susWords[2 + nSus] = (uint32_t)(q - a.qFirst);
+        if (suspect) { susWords[2 + 2 * nSus] = (uint32_t)(q - a.qFirst); susWords[3 + 2 * nSus] = K <= 31 ? susWords[qpar] : 0u; }
       }
       if (suspect) {
         // the question's sums as they are, for pole_fix (the question is queued like any other: its priority stands until then)
@@ -718,7 +727,7 @@ __device__ __forceinline__ void sweep_body(EvalArgs a, bool copyTable) {
         part[K * WPQ + wave] = hW;
         part[(K + 1) * WPQ + wave] = accL;
       }
-      if constexpr (kPoleShape) { if (hiMax >= kNearOneHi) susWords[qpar] = 1; }   // (rare: see pole_fix)
+      if constexpr (kPoleShape) { if (poleRows != 0) atomicOr(&susWords[qpar], poleRows); }   // (rare: see pole_fix)
       if constexpr (WPQ > 1) __syncthreads();
       if constexpr (kPoleShape) suspect = poleWatch && susWords[qpar] != 0 && nSus < kSusMax;
       if (wave == 0) {
@@ -732,7 +741,7 @@ __device__ __forceinline__ void sweep_body(EvalArgs a, bool copyTable) {
         if (lane == 0) {
           reinterpret_cast<int64_t *>(rec)[2 * K + 2] = q;
           susWords[qpar ^ 1] = 0;
-          if (suspect) susWords[2 + nSus] = (uint32_t)(q - a.qFirst);
+          if (suspect) { susWords[2 + 2 * nSus] = (uint32_t)(q - a.qFirst); susWords[3 + 2 * nSus] = K <= 31 ? susWords[qpar] : 0u; }
         }
         if (suspect)   // (the record is this wave's own work: no barrier)
           for (int i = lane; i < 2 * (int)K + 2; i += kWave) a.poleScratch[(q - a.qFirst) * (2 * K + 2) + i] = rec[i];
@@ -749,7 +758,11 @@ __device__ __forceinline__ void sweep_body(EvalArgs a, bool copyTable) {
   if (wave == 0) flush_pending(a, pend, nPend, lane, bestLds[lane]);
   if constexpr (kPoleShape) if (nSus > 0) {
     // ---- this workgroup's questions with a row at the pole of the lack term: their near-1 elements the reference's way
-    double *poleStage = PRLDS ? reinterpret_cast<double *>(prLds) : reinterpret_cast<double *>(mdRow);   // (a row's worth either way, free by now)
+    // (LDS that is free by now: the prior row, or the mD landing row and -- contiguous behind it -- the deferred sums' dump: 1 + (K + 2) / 2
+    //  rows' worth, so that the rows of a question at the pole are summed side by side; red: the partials and the queue of records)
+    double *poleStage = PRLDS ? reinterpret_cast<double *>(prLds) : reinterpret_cast<double *>(mdRow);
+    int poleStageDoubles = PRLDS ? (int)ldT : NP * kThreads * 2 + (kDefer ? (int)(K + 2) * kThreads : 0);
+    const int poleRedDoubles = 2 * nPart * WPQ + kPend * recLen;
     PoleArgs g{a.cube, a.prior, a.tgap, a.priority, a.poleScratch,
                a.fs.hostPriority != nullptr && a.fs.sampleSubtasks > 0 ? a.fs.hostPriority : nullptr, a.fs.seqValue, K, a.T, ldT, a.qFirst, a.vCompTail};
     if constexpr (FUSE) {
@@ -757,6 +770,7 @@ __device__ __forceinline__ void sweep_body(EvalArgs a, bool copyTable) {
       //  the mD landing row, free by now)
       double *stash = reinterpret_cast<double *>(mdRow);
       poleStage = vdump;                                       // (the deferred sums' LDS: (K + 2) x 256 doubles for rows of up to 1024 targets)
+      poleStageDoubles = (int)(K + 2) * kThreads;
       static_assert(!FUSE || DEFER, "the fused update's shapes defer their sums");
       __syncthreads();
 #pragma unroll
@@ -767,7 +781,7 @@ __device__ __forceinline__ void sweep_body(EvalArgs a, bool copyTable) {
       g.prior = stash;
     }
     __syncthreads();                                           // (the suspects' sums are in memory, their first priorities stored)
-    pole_fix<SERVER>(g, susWords + 2, nSus, partAll, poleStage, bestLds);
+    pole_fix<SERVER>(g, susWords + 2, nSus, partAll, poleRedDoubles, poleStage, poleStageDoubles, bestLds);
     __syncthreads();
   }
   if (wave == 0) fused_select<SERVER>(a, bestLds[lane], lane, allReported);

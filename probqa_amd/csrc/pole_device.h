@@ -29,6 +29,18 @@ __device__ __forceinline__ double log2hot_ref(double x, const double *tbl, doubl
   return log2z + (double)normExps;                             // :131-133
 }
 
+// the wave's maximum in every lane (the DPP / permlane steps of wave_sum: six ds_bpermute round trips otherwise)
+__device__ __forceinline__ double wave_max_d(double v) {
+  v = fmax(v, mov_dpp<kDppXor1>(v));
+  v = fmax(v, mov_dpp<kDppXor2>(v));
+  v = fmax(v, mov_dpp<kDppHalfMirror>(v));
+  v = fmax(v, mov_dpp<kDppMirror>(v));
+  Pair p = swap16(v);
+  v = fmax(p.a, p.b);
+  p = swap32(v);
+  return fmax(p.a, p.b);
+}
+
 struct PoleRows {
   const double *cube, *prior;    // [Q][K+1][ldT]; the quiz's posterior (gap targets are masked here)
   const uint32_t *tgap;
@@ -38,63 +50,39 @@ struct PoleRows {
 };
 
 // One question (index q of the cube) whose largest posterior element is within 2^-17 of 1.  rec: its sums as the sweep formed them
-// -- W_k [K] | W_k sqrt(V_k) or V_k [K] (secondIsWV) | sum l log2 p | lack sum.  All threads of the workgroup; the Log2Hot table
-// must be at LDS address 0 (log2hot); red: LDS, 4 x waves (at least 8) doubles; stage: LDS, 4 ceil(T / 4) doubles.  Thread 0 puts
-// the reference-order W_k of the rows at the pole into rec and returns in dH / dL what their near-1 elements change in the
-// entropy and lack sums.
+// -- W_k [K] | W_k sqrt(V_k) or V_k [K] (secondIsWV) | sum l log2 p | lack sum.  rowMask: the answer rows in which the sweep saw such
+// an element (bit k), or 0: not known -- then every row is looked at first (a compensated sum and its largest likelihood).  All
+// threads of the workgroup; the Log2Hot table must be at LDS address 0 (log2hot); red: LDS, redDoubles >= 6 x waves + 8 doubles;
+// stage: LDS, stageDoubles >= 4 ceil(T / 4).  Thread 0 puts the reference-order W_k of the rows at the pole into rec and returns in
+// dH / dL what their near-1 elements change in the entropy and lack sums.
+// In a late quiz -- the posterior on one target -- EVERY answer row of a question is at the pole (the target's likelihood is all of
+// W_k whatever the answer), and a row's reference-order sum is T / 4 DEPENDENT Kahan steps on four lanes: so the rows at the pole
+// are staged side by side -- as many as stage and red have room for -- and their chains run at the same time, four lanes each, in
+// one wave: five rows cost one chain's time, not five.
 template <bool COH>
-__device__ __forceinline__ void pole_fix_question(const PoleRows &g, int64_t q, double *rec, bool secondIsWV, double *red, double *stage,
-                                                  double &dH, double &dL) {
+__device__ __forceinline__ void pole_fix_question(const PoleRows &g, int64_t q, double *rec, bool secondIsWV, uint32_t rowMask, double *red,
+                                                  int redDoubles, double *stage, int stageDoubles, double &dH, double &dL) {
   const int tid = threadIdx.x, nThreads = blockDim.x, lane = tid % kWave, wave = tid / kWave, nWaves = nThreads / kWave;
   const int64_t K = g.K, ldT = g.ldT, nT = 4 * ((g.T + 3) >> 2);
   auto prior_at = [&](int64_t t) { return COH ? __hip_atomic_load(g.prior + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : g.prior[t]; };
   const double *qBase = g.cube + q * (K + 1) * ldT, *rowD = qBase + K * ldT;
-  for (int64_t k = 0; k < K; k++) {
-    const double *rowA = qBase + k * ldT;
-    Comp c{0.0, 0.0};
-    double mx = 0.0, mxId = 0.0;
-    for (int64_t tb = tid; tb < nT; tb += 4 * nThreads) {    // (four targets per thread and round, their loads requested together)
-      double av[4], dv[4], pv[4];
-      bool live[4];
-#pragma unroll
-      for (int e = 0; e < 4; e++) {
-        const int64_t t = tb + e * nThreads;
-        live[e] = t < nT && !bit_test(g.tgap, t);
-        const int64_t tc = live[e] ? t : 0;
-        av[e] = rowA[tc];
-        dv[e] = rowD[tc];
-        pv[e] = prior_at(tc);
-      }
-#pragma unroll
-      for (int e = 0; e < 4; e++) {
-        if (!live[e]) continue;
-        const double id = div_nr(1.0, dv[e]);                // :74
-        const double l = (av[e] * id) * pv[e];               // :81-82, as pass 1 forms it
-        c = comp_merge(c, Comp{l, 0.0});
-        if (l > mx) { mx = l; mxId = id; }
-      }
-    }
-    c = wave_sum_comp(c);
-    double wmx = mx;
-    for (int m = kWave / 2; m >= 1; m >>= 1) wmx = fmax(wmx, __shfl_xor(wmx, m, kWave));
-    if (lane == 0) { red[2 * wave] = c.s; red[2 * wave + 1] = c.c; red[2 * nWaves + 2 * wave] = 0.0; red[2 * nWaves + 2 * wave + 1] = 0.0; }
-    if (mx == wmx && mx > 0.0) { red[2 * nWaves + 2 * wave] = mx; red[2 * nWaves + 2 * wave + 1] = mxId; }   // (behind lane 0's zeros)
-    __syncthreads();
-    // is THIS row at the pole?  (every thread decides, from the same numbers)
-    Comp tot{red[0], red[1]};
-    double cand = red[2 * nWaves], candId = red[2 * nWaves + 1];
-    for (int w = 1; w < nWaves; w++) {
-      tot = comp_merge(tot, Comp{red[2 * w], red[2 * w + 1]});
-      if (red[2 * nWaves + 2 * w] > cand) { cand = red[2 * nWaves + 2 * w]; candId = red[2 * nWaves + 2 * w + 1]; }
-    }
-    const double Wc = tot.s + tot.c;                         // the row's sum to the last place or one short of the reference's
-    const bool atPole = cand > 0.0 && (uint32_t)(d2u(cand * div_nr(1.0, Wc)) >> 32) >= kNearOneHi - 1;
-    __syncthreads();                                         // (red is written again below)
-    if (atPole) {
-      // W_k in the REFERENCE'S ORDER (:66-88): the row's likelihoods into LDS, every thread its share; then one lane per Kahan
-      // lane c takes the targets 4j + c in order (SRAccumVectDbl256.h:40-46) and PreciseSum (:62-92) folds the four.  The
-      // correctly rounded sum would do in 70 - 90 % of such rows (tests/test_oracle.py), not in all: the compensation of a lane
-      // that meets the large element after smaller ones is itself rounded.
+  // red: per row of a batch the waves' largest likelihood and its 1/D [2 x waves] and the chains' results [8]
+  const int perRow = 2 * nWaves + 8;
+  int maxRows = (int)min((int64_t)(stageDoubles / nT), (int64_t)(redDoubles / perRow));
+  maxRows = maxRows > 16 ? 16 : maxRows;                     // (the chains of a batch: four lanes each, one wave)
+  if (maxRows < 1 || redDoubles < 4 * nWaves) return;        // (no room: the sweep's own sums stand)
+  // W_k of a batch of rows in the REFERENCE'S ORDER (:66-88): the rows' likelihoods into LDS, every thread its share (and the
+  // largest of them with its 1/D: the element whose terms are replaced); then four lanes per row take the targets 4j + c in order
+  // (SRAccumVectDbl256.h:40-46) and PreciseSum (:62-92) folds the four.  The correctly rounded sum would do in 70 - 90 % of such
+  // rows (tests/test_oracle.py), not in all: the compensation of a lane that meets the large element after smaller ones is itself
+  // rounded.
+  auto run_batch = [&](int64_t base, uint32_t batch, int nb) __attribute__((always_inline)) {   // rows base + (the bits of batch)
+    int r = 0;
+    for (uint32_t rest = batch; rest != 0; rest &= rest - 1, r++) {
+      const int64_t k = base + __builtin_ctz(rest);
+      const double *rowA = qBase + k * ldT;
+      double *dst = stage + (int64_t)r * nT;
+      double mx = 0.0, mxId = 0.0;
       for (int64_t tb = tid; tb < nT; tb += 4 * nThreads) {
         double av[4], dv[4], pv[4];
         bool in[4], gap[4];
@@ -110,39 +98,57 @@ __device__ __forceinline__ void pole_fix_question(const PoleRows &g, int64_t q, 
         }
 #pragma unroll
         for (int e = 0; e < 4; e++)
-          if (in[e]) stage[tb + e * nThreads] = gap[e] ? 0.0 : (av[e] * div_nr(1.0, dv[e])) * pv[e];   // :72-82
-      }
-      __syncthreads();
-      if (tid < 4) {
-        double sum = 0.0, corr = 0.0;
-        const double *src = stage + tid;
-        int64_t j = 0;
-        for (; j + 8 <= nT / 4; j += 8) {                    // (eight elements requested at once, added in order)
-          double x[8];
-#pragma unroll
-          for (int e = 0; e < 8; e++) x[e] = src[4 * (j + e)];
-#pragma unroll
-          for (int e = 0; e < 8; e++) {
-            const double y = x[e] - corr;
-            const double u = sum + y;
-            corr = (u - sum) - y;
-            sum = u;
+          if (in[e]) {
+            const double id = div_nr(1.0, dv[e]);            // :74
+            const double l = gap[e] ? 0.0 : (av[e] * id) * pv[e];   // :72-82, as pass 1 forms it
+            dst[tb + e * nThreads] = l;
+            if (l > mx) { mx = l; mxId = id; }
           }
-        }
-        for (; j < nT / 4; j++) {
-          const double y = src[4 * j] - corr;
+      }
+      const double wmx = wave_max_d(mx);
+      double *cw = red + r * perRow + 2 * wave;
+      if (lane == 0) { cw[0] = 0.0; cw[1] = 0.0; }
+      if (mx == wmx && mx > 0.0) { cw[0] = mx; cw[1] = mxId; }   // (behind lane 0's zeros; lanes that tie hold the same element's values or an equal one's)
+    }
+    __syncthreads();
+    if (tid < 4 * nb) {
+      double sum = 0.0, corr = 0.0;
+      const double *src = stage + (int64_t)(tid >> 2) * nT + (tid & 3);
+      int64_t j = 0;
+      for (; j + 8 <= nT / 4; j += 8) {                      // (eight elements requested at once, added in order)
+        double x[8];
+#pragma unroll
+        for (int e = 0; e < 8; e++) x[e] = src[4 * (j + e)];
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+          const double y = x[e] - corr;
           const double u = sum + y;
           corr = (u - sum) - y;
           sum = u;
         }
-        red[tid] = sum;
-        red[4 + tid] = corr;
       }
-      __syncthreads();
-      if (tid == 0) {
-        const double Wx = precise_sum4(red, red + 4);        // :88
+      for (; j < nT / 4; j++) {
+        const double y = src[4 * j] - corr;
+        const double u = sum + y;
+        corr = (u - sum) - y;
+        sum = u;
+      }
+      double *out = red + (tid >> 2) * perRow + 2 * nWaves;
+      out[tid & 3] = sum;
+      out[4 + (tid & 3)] = corr;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      int rr = 0;
+      for (uint32_t rest = batch; rest != 0; rest &= rest - 1, rr++) {
+        const int64_t k = base + __builtin_ctz(rest);
+        const double *cw = red + rr * perRow;
+        double cand = cw[0], candId = cw[1];
+        for (int w = 1; w < nWaves; w++)
+          if (cw[2 * w] > cand) { cand = cw[2 * w]; candId = cw[2 * w + 1]; }
+        const double Wx = precise_sum4(cw + 2 * nWaves, cw + 2 * nWaves + 4);   // :88
         const double invWx = div_nr(1.0, Wx);                // :91
-        if ((uint32_t)(d2u(cand * invWx) >> 32) >= kNearOneHi) {
+        if (cand > 0.0 && (uint32_t)(d2u(cand * invWx) >> 32) >= kNearOneHi) {
           const double Wf = rec[k];                          // the sweep's W_k
           const double lFast = log2hot(cand * div_nr(1.0, Wf), nullptr);   // what pass 2 took for this element (the table is at LDS address 0)
           const double lRef = log2hot_ref(cand * invWx, g.tblGlobal, g.entry0Ref);     // :106
@@ -153,8 +159,61 @@ __device__ __forceinline__ void pole_fix_question(const PoleRows &g, int64_t q, 
           rec[k] = Wx;
         }
       }
-      __syncthreads();
     }
+    __syncthreads();
+  };
+  uint32_t poleMask = K <= 31 ? rowMask : 0u;
+  if (poleMask == 0) {
+    // ---- which rows are at the pole is not known: a compensated sum of every row and its largest likelihood say
+    for (int64_t k = 0; k < K; k++) {
+      const double *rowA = qBase + k * ldT;
+      Comp c{0.0, 0.0};
+      double mx = 0.0;
+      for (int64_t tb = tid; tb < nT; tb += 4 * nThreads) {  // (four targets per thread and round, their loads requested together)
+        double av[4], dv[4], pv[4];
+        bool live[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          const int64_t t = tb + e * nThreads;
+          live[e] = t < nT && !bit_test(g.tgap, t);
+          const int64_t tc = live[e] ? t : 0;
+          av[e] = rowA[tc];
+          dv[e] = rowD[tc];
+          pv[e] = prior_at(tc);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          if (!live[e]) continue;
+          const double l = (av[e] * div_nr(1.0, dv[e])) * pv[e];   // :74, :81-82
+          c = comp_merge(c, Comp{l, 0.0});
+          mx = fmax(mx, l);
+        }
+      }
+      c = wave_sum_comp(c);
+      const double wmx = wave_max_d(mx);
+      if (lane == 0) { red[3 * wave] = c.s; red[3 * wave + 1] = c.c; red[3 * wave + 2] = wmx; }
+      __syncthreads();
+      Comp tot{red[0], red[1]};                              // (every thread decides, from the same numbers)
+      double cand = red[2];
+      for (int w = 1; w < nWaves; w++) {
+        tot = comp_merge(tot, Comp{red[3 * w], red[3 * w + 1]});
+        cand = fmax(cand, red[3 * w + 2]);
+      }
+      const double Wc = tot.s + tot.c;                       // the row's sum to the last place or one short of the reference's
+      const bool atPole = cand > 0.0 && (uint32_t)(d2u(cand * div_nr(1.0, Wc)) >> 32) >= kNearOneHi - 1;
+      __syncthreads();                                       // (red is written again)
+      if (atPole) {
+        if (maxRows == 1 || K > 31) run_batch(k, 1u, 1);     // (one row's room: now, while its cache lines are warm; dozens of answers: no mask of them)
+        else poleMask |= 1u << k;
+      }
+    }
+  }
+  while (poleMask != 0) {
+    uint32_t batch = 0;
+    int nb = 0;
+    for (uint32_t rest = poleMask; rest != 0 && nb < maxRows; rest &= rest - 1, nb++) batch |= rest & (0u - rest);
+    poleMask &= ~batch;
+    run_batch(0, batch, nb);
   }
 }
 
