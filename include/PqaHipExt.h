@@ -67,6 +67,8 @@ PQACORE_API void *PqaEngineFactory_CreateHipEngineSharded(void *pvFactory, void 
  * reads the cube once per batch; default 0 = decided by how many waves the batch gives that sweep; Float engines always take it), "batch_tile" (targets per LDS tile of that sweep, 0 = default),
  * "batch_groups" (that sweep for batches of up to 128 quizzes: question groups side by side in a workgroup, so that the lanes a small
  * batch leaves over take further questions; 0 = as many as leave every CU a workgroup [default], else at most this many),
+ * "batch_tail" (that sweep's last, partial round of question blocks as a second launch of a shape with fewer questions per group, where
+ * exactly one full round precedes it; default 1),
  * "pole_fix" (sweeps over rows of up to 4096 targets re-evaluate a row with a posterior element within 2^-17 of 1 in the reference's
  * own summation order -- SRAccumVectDbl256.h:40-46, :62-92 -- so that late quiz states stay within 1e-9 of the reference's
  * priorities; default 1, also PQA_POLE_FIX),

@@ -128,6 +128,7 @@ struct BatchArgs {
   int nSlots, Bp;
   int Bq;                    // lanes per question group: lane = (group g = tid / Bq, quiz b = tid % Bq); Bq <= Bp, Bq divides the threads
   int64_t K, Q, ldT;
+  int64_t qBegin, qEnd;      // the questions of THIS launch (a sweep is one launch, or a main launch and one for the last questions: LaunchEvalBatch)
   int TC;                    // targets per tile (even)
   double vCompTail;          // ln(sqrt 2) / (nValidTargets + 1)^2 (:191)
   double *acc;               // fp64 totals, [grid][threads][QB][2K+2]: W_k (K), V_k (K), sum W_k H_k, lack
@@ -157,7 +158,7 @@ __device__ __forceinline__ void stage_tile(const BatchArgs &a, R *tile, int G, i
 #pragma unroll
     for (int qi = 0; qi < QB; qi++) {
       const int64_t qq = q0 + gg * QB + qi;
-      const int64_t q = qq < a.Q ? qq : a.Q - 1;              // (beyond the last question: a copy whose results are dropped)
+      const int64_t q = qq < a.qEnd ? qq : a.qEnd - 1;        // (beyond the last question: a copy whose results are dropped)
       const R *qb = cube + q * (K + 1) * ldT;
       // (non-temporal: the cube streams through a workgroup once per pass.  12500 x 5 x 100000 fp32, 256 quizzes, same box: 556.7 ->
       //  545.4 ms per sweep; the L2s then keep less of what misses them -- FETCH_SIZE 168 -> 189 GB per sweep, served by the
@@ -207,10 +208,10 @@ __global__ __launch_bounds__(256) void eval_batch_kernel(BatchArgs a) {
   double *acc = a.acc + ((size_t)blockIdx.x * nThreads + tid) * (size_t)(QB * nAcc);
   double bestP = 0.0;
   int64_t bestQ = -1;
-  const int64_t nBlocks = (a.Q + QT - 1) / QT;
+  const int64_t nBlocks = (a.qEnd - a.qBegin + QT - 1) / QT;
   constexpr bool kPoleWatch = Num<R>::kTable;                  // (Double engines: the fp32 tolerance covers what the summation order moves)
   for (int64_t blk = blockIdx.x; blk < nBlocks; blk += gridDim.x) {
-    const int64_t qBlk = blk * QT, q0 = qBlk + (int64_t)g * QB;   // the block's first question; this lane's first question
+    const int64_t qBlk = a.qBegin + blk * QT, q0 = qBlk + (int64_t)g * QB;   // the block's first question; this lane's first question
     uint32_t hiMax[QB];                                        // the largest posterior element's high word, per question (pole_device.h)
 #pragma unroll
     for (int qi = 0; qi < QB; qi++) hiMax[qi] = 0;
@@ -337,7 +338,7 @@ __global__ __launch_bounds__(256) void eval_batch_kernel(BatchArgs a) {
 #pragma unroll 1
     for (int qi = 0; qi < QB; qi++) {
       const int64_t q = q0 + qi;
-      if (q >= a.Q) break;
+      if (q >= a.qEnd) break;
       const bool skip = bit_test(a.qgap, q) || ((asked[q >> 5] >> (q & 31)) & 1u);   // :54
       double pri = 0.0;
       if (!skip) {
@@ -368,7 +369,7 @@ __global__ __launch_bounds__(256) void eval_batch_kernel(BatchArgs a) {
 #pragma unroll
         for (int qi = 0; qi < QB; qi++) {
           const int64_t q = q0 + qi;
-          if (live && q < a.Q && hiMax[qi] >= kNearOneHi && !(bit_test(a.qgap, q) || ((asked[q >> 5] >> (q & 31)) & 1u))) {
+          if (live && q < a.qEnd && hiMax[qi] >= kNearOneHi && !(bit_test(a.qgap, q) || ((asked[q >> 5] >> (q & 31)) & 1u))) {
             const uint32_t at = atomicAdd(pcount, 1u);
             if (at < (uint32_t)kPoleMax) { plist[2 * at] = (uint32_t)tid; plist[2 * at + 1] = (uint32_t)qi; }
           }
@@ -747,7 +748,8 @@ __global__ __launch_bounds__(NT) void eval_questions_f32_stream(const float *__r
 }
 
 template <typename R, int QB, int KG, bool EXACT>
-hipError_t launch_batch(const BatchArgs &args0, int nThreads, size_t *accBytesNeeded, int *gridOut, bool queryOnly, hipStream_t stream) {
+hipError_t launch_batch(const BatchArgs &args0, int nThreads, size_t *accBytesNeeded, int *gridOut, int *capacityOut, bool queryOnly,
+                        hipStream_t stream) {
   BatchArgs args = args0;
   auto kern = eval_batch_kernel<R, QB, KG, EXACT>;
   const int G = nThreads / args.Bq;   // question groups side by side (eval_batch_kernel)
@@ -769,10 +771,11 @@ hipError_t launch_batch(const BatchArgs &args0, int nThreads, size_t *accBytesNe
     cache.Put(devSlot, key, perCU);
   }
   const int nCU = cache.NumCUs(devSlot);
-  const int64_t nBlocks = (args.Q + G * QB - 1) / (G * QB);
+  const int64_t nBlocks = (args.qEnd - args.qBegin + G * QB - 1) / (G * QB);
   int64_t grid = (int64_t)nCU * perCU;
-  if (grid > nBlocks) grid = nBlocks;
   if (grid > kBatchMaxGrid) grid = kBatchMaxGrid;
+  if (capacityOut) *capacityOut = (int)grid;                  // (workgroups the device holds at once: LaunchEvalBatch plans the last round by it)
+  if (grid > nBlocks) grid = nBlocks;
   *gridOut = (int)grid;
   *accBytesNeeded = (size_t)grid * QB * (2 * args.K + 2) * nThreads * sizeof(double);
   if (queryOnly) return hipSuccess;
@@ -827,24 +830,66 @@ hipError_t LaunchEvalBatch(const KbView &kb, const QuizSlot *slots, int nSlots, 
   plan->ptBytes = (size_t)kb.ldT * Bp * (f32 ? 4 : 8);
   plan->Bp = Bp;
   hipError_t e;
-  int grid = 0;
   const bool k5 = kb.K == 5;
-  auto run = [&](bool query, size_t *accBytes) -> hipError_t {
+  // one launch of the shape with `qbSel` questions per group over the questions [a.qBegin, a.qEnd)
+  auto run = [&](int qbSel, bool query, size_t *accBytes, int *grid, int *capacity) -> hipError_t {
     if (f32) {
-      if (k5) return qb >= 4 ? launch_batch<float, 4, 5, true>(a, nThreads, accBytes, &grid, query, stream)
-                             : launch_batch<float, 2, 5, true>(a, nThreads, accBytes, &grid, query, stream);
-      return qb >= 4 ? launch_batch<float, 4, 4, false>(a, nThreads, accBytes, &grid, query, stream)
-                     : launch_batch<float, 2, 4, false>(a, nThreads, accBytes, &grid, query, stream);
+      if (k5) return qbSel >= 4   ? launch_batch<float, 4, 5, true>(a, nThreads, accBytes, grid, capacity, query, stream)
+                     : qbSel >= 2 ? launch_batch<float, 2, 5, true>(a, nThreads, accBytes, grid, capacity, query, stream)
+                                  : launch_batch<float, 1, 5, true>(a, nThreads, accBytes, grid, capacity, query, stream);
+      return qbSel >= 4   ? launch_batch<float, 4, 4, false>(a, nThreads, accBytes, grid, capacity, query, stream)
+             : qbSel >= 2 ? launch_batch<float, 2, 4, false>(a, nThreads, accBytes, grid, capacity, query, stream)
+                          : launch_batch<float, 1, 4, false>(a, nThreads, accBytes, grid, capacity, query, stream);
     }
-    if (k5) return qb >= 2 ? launch_batch<double, 2, 5, true>(a, nThreads, accBytes, &grid, query, stream)
-                           : launch_batch<double, 1, 5, true>(a, nThreads, accBytes, &grid, query, stream);
-    return qb >= 2 ? launch_batch<double, 2, 4, false>(a, nThreads, accBytes, &grid, query, stream)
-                   : launch_batch<double, 1, 4, false>(a, nThreads, accBytes, &grid, query, stream);
+    if (k5) return qbSel >= 2 ? launch_batch<double, 2, 5, true>(a, nThreads, accBytes, grid, capacity, query, stream)
+                              : launch_batch<double, 1, 5, true>(a, nThreads, accBytes, grid, capacity, query, stream);
+    return qbSel >= 2 ? launch_batch<double, 2, 4, false>(a, nThreads, accBytes, grid, capacity, query, stream)
+                      : launch_batch<double, 1, 4, false>(a, nThreads, accBytes, grid, capacity, query, stream);
   };
-  e = run(true, &plan->accBytes);
+  // The sweep is a persistent grid striding over blocks of G * qb questions: with nBlocks = rounds * grid + rest, `rest` workgroups
+  // make one more round while the others idle.  Where that last round is a large part of the sweep -- ONE full round and a rest
+  // (12500 questions, 64 quizzes: 782 blocks of 16 questions on 512 workgroups) -- the full round is one launch and the last
+  // questions another, of the largest shape with fewer questions per group that fits the device in one round: 205 -> 182 ms.
+  // Not beyond that: after several rounds the few workgroups of the last one have the chip to themselves and run faster than a
+  // second launch of smaller blocks, whose time shrinks less than their questions (256 quizzes, six rounds + 53 blocks: 540 ms
+  // as one launch, 545 - 554 ms split; 128 quizzes, three rounds: 293 against 311 ms).
+  const int qbMain = f32 ? (qb >= 4 ? 4 : qb >= 2 ? 2 : 1) : (qb >= 2 ? 2 : 1);
+  int gridMain = 0, capMain = 0, gridTail = 0, qbTail = 0;
+  int64_t qSplit = kb.Q;
+  a.qBegin = 0;
+  a.qEnd = kb.Q;
+  e = run(qbMain, true, &plan->accBytes, &gridMain, &capMain);
   if (e != hipSuccess) return e;
-  plan->grid = grid;
-  plan->recBytes = (size_t)grid * G * Bp * sizeof(BatchRecord);
+  {
+    const int64_t QT = (int64_t)G * qbMain, nBlocks = (kb.Q + QT - 1) / QT, rounds = nBlocks / std::max(1, gridMain), rest = nBlocks % std::max(1, gridMain);
+    if (plan->splitTail && gridMain == capMain && rounds == 1 && rest > 0 && qbMain > 1) {
+      const int64_t tailQ = kb.Q - rounds * gridMain * QT;
+      for (int cand = qbMain / 2; cand >= 1; cand /= 2) {      // (the largest smaller shape that still fits: a block's time shrinks less than its questions)
+        a.qBegin = kb.Q - tailQ;
+        a.qEnd = kb.Q;
+        size_t accT = 0;
+        int gT = 0, capT = 0;
+        if (run(cand, true, &accT, &gT, &capT) != hipSuccess) continue;
+        if ((tailQ + (int64_t)G * cand - 1) / ((int64_t)G * cand) <= capT) {   // (one round of the smaller shape)
+          qbTail = cand;
+          gridTail = gT;
+          qSplit = kb.Q - tailQ;
+          plan->accBytes = std::max(plan->accBytes, accT);
+          break;
+        }
+      }
+      if (qbTail != 0) {   // (the main launch covers whole rounds only)
+        a.qBegin = 0;
+        a.qEnd = qSplit;
+        size_t accM = 0;
+        e = run(qbMain, true, &accM, &gridMain, &capMain);
+        if (e != hipSuccess) return e;
+        plan->accBytes = std::max(plan->accBytes, accM);
+      }
+    }
+  }
+  plan->grid = gridMain + gridTail;
+  plan->recBytes = (size_t)(gridMain + gridTail) * G * Bp * sizeof(BatchRecord);
   if (queryOnly) return hipSuccess;
   if (PT == nullptr || acc == nullptr || recs == nullptr) return hipErrorInvalidValue;
   const dim3 pgrid((unsigned)((kb.ldT + 63) / 64), (unsigned)(Bp / 64));
@@ -853,9 +898,21 @@ hipError_t LaunchEvalBatch(const KbView &kb, const QuizSlot *slots, int nSlots, 
   e = hipGetLastError();
   if (e != hipSuccess) return e;
   size_t dummy = 0;
-  e = run(false, &dummy);
-  if (e != hipSuccess || skipPick) return e;
-  hipLaunchKernelGGL(batch_pick_kernel, dim3((unsigned)nSlots), dim3(64), 0, stream, recs, grid * G, Bp, slots, nSlots,
+  int gDummy = 0;
+  a.qBegin = 0;
+  a.qEnd = qSplit;
+  a.recs = recs;
+  e = run(qbMain, false, &dummy, &gDummy, nullptr);
+  if (e != hipSuccess) return e;
+  if (qbTail != 0) {
+    a.qBegin = qSplit;
+    a.qEnd = kb.Q;
+    a.recs = recs + (size_t)gridMain * G * Bp;
+    e = run(qbTail, false, &dummy, &gDummy, nullptr);
+    if (e != hipSuccess) return e;
+  }
+  if (skipPick) return hipSuccess;
+  hipLaunchKernelGGL(batch_pick_kernel, dim3((unsigned)nSlots), dim3(64), 0, stream, recs, (gridMain + gridTail) * G, Bp, slots, nSlots,
                      outBase, flagValue);
   return hipGetLastError();
 }

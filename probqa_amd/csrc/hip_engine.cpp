@@ -338,6 +338,7 @@ Error HipEngine::SetOption(const char *name, int64_t value) {
   else if (n == "batch_qb") { if (value < 0 || value > 4) goto bad; _optBatchQb = value; }
   else if (n == "batch_tile") { if (value < 0 || value > 8192) goto bad; _optBatchTile = value; }
   else if (n == "cluster_form") { if (value < 0 || value > 2) goto bad; _optClusterForm = value; }
+  else if (n == "batch_tail") { _optBatchTail = value ? 1 : 0; }
   else if (n == "batch_groups") { if (value < 0 || value > 8) goto bad; _optBatchGroups = value; }
   else if (n == "server_vram_mailbox") { if (_serverStream) goto bad; _optServerVramMailbox = value ? 1 : 0; }
   else if (n == "server_idle_us") { if (value < 10 || value > 1000000) goto bad; StopServer(); _optServerIdleUs = value; }
@@ -397,6 +398,7 @@ int64_t HipEngine::GetOption(const char *name) const {
   if (n == "batch_form") return _optBatchForm;
   if (n == "batch_tile") return _optBatchTile;
   if (n == "batch_groups") return _optBatchGroups;
+  if (n == "batch_tail") return _optBatchTail;
   if (n == "cluster_form") return _optClusterForm;
   if (n == "batch_qb") return _optBatchQb;
   if (n == "precision") return _precType;

@@ -637,6 +637,7 @@ class HipEngine : public IEngine {
   int64_t _optBatchQb = 0;        // questions per block of that sweep (0 = default)
   int64_t _optBatchTile = 0;      // targets per LDS tile of that sweep (0 = default)
   int64_t _optClusterForm = 0;    // long rows, one quiz (cluster_kernels.hip): 0 = default, 1 = question by question, 2 = pass 1 a question ahead
+  int64_t _optBatchTail = 1;      // that sweep's last, partial round as a launch of its own with fewer questions per group (LaunchEvalBatch)
   int64_t _optBatchGroups = 0;    // question groups per workgroup of that sweep for batches under 129 quizzes (0 = automatic)
   // ---- the next sweep ahead of its request (option "speculate"): RecordAnswer enqueues, right behind its posterior kernel, the
   // sweep the NextQuestion that normally follows would launch -- the client's time between the two calls (the wrapper's own

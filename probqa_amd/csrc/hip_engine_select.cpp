@@ -453,6 +453,7 @@ Error HipEngine::BatchSweep(BatchCtx &c, int64_t n, const int64_t *pQuizzes, std
   plan.tileTargets = (int)_optBatchTile;
   plan.questionsPerBlock = (int)_optBatchQb;
   plan.questionGroups = (int)_optBatchGroups;
+  plan.splitTail = (int)_optBatchTail;
   HIP_TRY(LaunchEvalBatch(kb, c.dSlots, (int)n, &plan, nullptr, nullptr, nullptr, nullptr, 0, tag, true, _stream));
   HIP_TRY(grow(&c.dPT, c.ptBytes, plan.ptBytes));
   HIP_TRY(grow((void **)&c.dAcc, c.accBytes, plan.accBytes));

@@ -128,6 +128,7 @@ struct BatchRecord { double priority; int64_t index; };   // a workgroup's best 
 struct BatchPlan {
   int tileTargets;        // in: targets per LDS tile (0 = default)
   int questionsPerBlock;  // in: questions staged together (0 = default: 4 fp32, 2 fp64; else the largest built shape <= this)
+  int splitTail;          // in: 1 = the questions of the last, partial round of the persistent grid go to a second launch with fewer questions per group (LaunchEvalBatch)
   int questionGroups;     // in: question groups side by side in a workgroup of a small batch (0 = automatic; see eval_batch_kernel)
   int grid, Bp;           // out: workgroups of the sweep; quizzes rounded up to whole waves
   size_t ptBytes, accBytes, recBytes;   // out: sizes of the scratch buffers PT / acc / recs the caller provides

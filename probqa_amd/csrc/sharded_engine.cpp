@@ -1465,7 +1465,7 @@ Error ShardedEngine::Rebuild(int64_t newQ, int64_t newT, const std::vector<int64
     Error ae;
     e->SetQuestionsAsked(s == 0 ? s0.GetTotalQuestionsAsked(ae) : 0);
     for (const char *opt : {"select", "workers", "eval_subtasks", "eval_variant", "bug_compat", "top_cache", "speculate", "host_sampled",
-                            "fused_sampled", "batch_min", "batch_qb", "batch_tile", "batch_groups", "cluster_form", "rerank", "combine", "server", "use_graph"}) {
+                            "fused_sampled", "batch_min", "batch_qb", "batch_tile", "batch_groups", "batch_tail", "cluster_form", "rerank", "combine", "server", "use_graph"}) {
       const int64_t v = _sh[(size_t)s]->GetOption(opt);
       if (v >= 0) (void)e->SetOption(opt, std::string(opt) == "eval_subtasks" && v == 8 * _sh[(size_t)s]->GetOption("workers") ? 0 : v);
     }
