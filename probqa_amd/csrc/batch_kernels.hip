@@ -157,14 +157,11 @@ struct BatchArgs {
   double *acc;               // fp64 totals, [grid][threads][QB][2K+2]: W_k (K), V_k (K), sum W_k H_k, lack
   BatchRecord *recs;         // [grid][Bp]: every workgroup's best question per quiz
   double *priorityT;         // optional [Q][Bp]: the priorities themselves (tests, EvalPrioritiesBatch)
-  // rows at the pole of the lack term (pole_device.h; Double engines, rows of up to 4096 targets): a row's worth of LDS for the
-  // reference-order sum (0: none, such questions keep the sweep's own sums), the row length, log2hot_ref's table entry 0
-  int poleDoubles;
-  int64_t T;
-  double log2Entry0Ref;
+  // the pole watch (Double engines; pole_kernels.hip redoes the listed (question, quiz) pairs behind the sweep): the list, and
+  // per entry the pair's sums as the epilogue left them -- W_k | W_k sqrt(V_k) | sum l log2 p | lack; null: no watch
+  PoleHeader *poleList;
+  double *poleSums;
 };
-constexpr int kPoleMax = 128;   // (question, quiz) pairs a workgroup re-evaluates per block of questions
-constexpr int kPoleRed = 256;   // doubles of reduction scratch of pole_fix_question (partials, the rows' largest elements, 16 chains' results)
 
 // Tile in LDS: R tile[TC][G * QB][KG + 1] (G question groups of QB questions each -- see eval_batch_kernel); entry [tc][qi][k < KG] =
 // A[q][kg + k][t] * invD[q][t], entry [tc][qi][KG] = invD^2.
@@ -379,43 +376,19 @@ __global__ __launch_bounds__(256) void eval_batch_kernel(BatchArgs a) {
       }
     }
     if constexpr (kPoleWatch) {
-      if (a.poleDoubles > 0) {
-        // ---- (question, quiz) pairs with a posterior element within 2^-17 of 1: their rows at the pole of the lack term again,
-        // the reference's way, the whole workgroup on one pair at a time (pole_device.h; the single-quiz sweep: pole_fix).  The
-        // tile's LDS is free here: reduction scratch | a row of likelihoods | the list | the corrected priorities.
-        double *red = reinterpret_cast<double *>(tile), *stage = red + kPoleRed;
-        uint32_t *plist = reinterpret_cast<uint32_t *>(stage + a.poleDoubles), *pcount = plist + 2 * kPoleMax;
-        double *fixedPri = reinterpret_cast<double *>(plist + 2 * kPoleMax + 2);
-        __syncthreads();                                       // (everybody is done with the tile)
-        if (tid == 0) *pcount = 0;
-        __syncthreads();
+      if (a.poleList != nullptr) {
+        // ---- (question, quiz) pairs with a posterior element within 2^-10 of 1: listed, with their sums, for the fix behind the
+        // sweep (every row of such a pair is redone: the watch keeps one maximum per question, not per row)
 #pragma unroll
         for (int qi = 0; qi < QB; qi++) {
           const int64_t q = q0 + qi;
           if (live && q < a.qEnd && hiMax[qi] >= kNearOneHi && !(bit_test(a.qgap, q) || ((asked[q >> 5] >> (q & 31)) & 1u))) {
-            const uint32_t at = atomicAdd(pcount, 1u);
-            if (at < (uint32_t)kPoleMax) { plist[2 * at] = (uint32_t)tid; plist[2 * at + 1] = (uint32_t)qi; }
+            const uint32_t at = pole_list_append(a.poleList, (uint32_t)q, 0u, (uint32_t)b);
+            const double *rec = acc + (size_t)qi * nAcc;       // (W_k sqrt(V_k) in place of V_k by now)
+            double *dst = a.poleSums + (size_t)at * nAcc;
+            for (int i = 0; i < nAcc; i++) dst[i] = rec[i];
           }
         }
-        __syncthreads();
-        const int nPole = (int)min(*pcount, (uint32_t)kPoleMax);
-        for (int e = 0; e < nPole; e++) {
-          const int tid2 = (int)plist[2 * e], qi2 = (int)plist[2 * e + 1], g2 = tid2 / Bq, b2 = tid2 - g2 * Bq;   // (the lane that listed the pair)
-          double *rec = a.acc + ((size_t)blockIdx.x * nThreads + tid2) * (size_t)(QB * nAcc) + (size_t)qi2 * nAcc;   // (W_k sqrt(V_k) in place of V_k by now)
-          const PoleRows rows{static_cast<const double *>(a.cube), a.slots[b2].prior, a.tgap, K, a.T, ldT, gLog2TableB, a.log2Entry0Ref};
-          double dH = 0.0, dL = 0.0;
-          pole_fix_question<false>(rows, qBlk + (int64_t)g2 * QB + qi2, rec, true, 0u, red, kPoleRed, stage, a.poleDoubles, dH, dL);
-          if (tid == 0) fixedPri[e] = eval_epilogue(rec, -(rec[2 * K] + dH), rec + K, K, rec[2 * K + 1] + dL, a.vCompTail);
-        }
-        __syncthreads();
-        for (int e = 0; e < nPole; e++)
-          if ((int)plist[2 * e] == tid) {
-            const int64_t q = q0 + (int64_t)plist[2 * e + 1];
-            const double pri = fixedPri[e];
-            if (a.priorityT) a.priorityT[q * Bp + b] = pri;
-            const double cand = pri != pri ? -__builtin_huge_val() : pri;
-            if (bestQ < 0 || cand > bestP || (cand == bestP && q < bestQ)) { bestP = cand; bestQ = q; }
-          }
       }
     }
   }
@@ -456,6 +429,8 @@ struct MidArgs {
   BatchRecord *recs;         // [grid.x][Bp]
   double *priorityT;         // optional [Q][Bp]
   uint64_t tag;              // launch tag of the host hand-over records
+  PoleHeader *poleList;      // the pole watch (as BatchArgs'): the list and the listed pairs' sums; null: no watch
+  double *poleSums;
 };
 
 template <int QS> __device__ __forceinline__ double chunk_fold(double v) {   // sum over the lanes of one quiz slot within a wave
@@ -504,7 +479,9 @@ __global__ __launch_bounds__(kMidThreads) void eval_midbatch_kernel(MidArgs a) {
   if (!lds_table_at_zero(tbl)) __builtin_trap();            // log2hot addresses the table absolutely
   double *tile = smem + kLog2TableDoubles;                  // [ldT][K + 1]
   double *red = tile + (size_t)a.ldT * (K + 1);             // [NW][K + 2][QS]
+  uint32_t *watchW = reinterpret_cast<uint32_t *>(red + (size_t)NW * (K + 2) * QS);   // [QS]: the rows of this question that passed the pole watch, per quiz slot
   for (int i = threadIdx.x; i < kLog2TableDoubles; i += kMidThreads) smem[i] = gLog2TableB[i];
+  if (threadIdx.x < QS) watchW[threadIdx.x] = 0;
   const int tid = threadIdx.x, lane = tid % kWave, wave = tid / kWave;
   const int slot = lane % QS, chunk = wave * NSUB + lane / QS;
   const int b = blockIdx.y * QS + slot;                     // this lane's quiz
@@ -540,13 +517,16 @@ __global__ __launch_bounds__(kMidThreads) void eval_midbatch_kernel(MidArgs a) {
 #pragma unroll
       for (int k = 0; k < K; k++) W[k] = fma(c[k], pi, W[k]);                             // :81-82, :85
     });
+    double Wlane[K];                                        // (the pole watch: this lane's share of W_k)
 #pragma unroll
     for (int k = 0; k < K; k++) {
+      Wlane[k] = W[k];
       W[k] = chunk_fold<QS>(W[k]);
       if (lane < QS) red[(wave * (K + 2) + k) * QS + slot] = W[k];
     }
     __syncthreads();
     double invW[K];
+    uint32_t poleRows = 0;
 #pragma unroll
     for (int k = 0; k < K; k++) {
       double w = 0.0;
@@ -554,7 +534,10 @@ __global__ __launch_bounds__(kMidThreads) void eval_midbatch_kernel(MidArgs a) {
       for (int w2 = 0; w2 < NW; w2++) w += red[(w2 * (K + 2) + k) * QS + slot];
       W[k] = w;                                                                           // :88-90 (the same bits in every lane of the quiz)
       invW[k] = (EXACT || k < kN) ? div_fast(1.0, w) : 0.0;                               // :91
+      // an element within 2^-10 of 1 is nearly all of W_k: so is the serial sum of the lane that holds it (eval_kernels.hip: the watch)
+      if ((EXACT || k < kN) && Wlane[k] >= w * (1.0 - 0x1p-9) && Wlane[k] > 0.0) poleRows |= 1u << k;
     }
+    if (poleRows != 0 && a.poleList != nullptr) atomicOr(&watchW[slot], poleRows);           // (rare; read by the quiz's head lane behind the next barriers)
     __syncthreads();                                        // (the exchange buffer is used again below)
     // ---- pass 2 (:95-128)
     double v[K], hW = 0.0, accL = 0.0;
@@ -608,7 +591,18 @@ __global__ __launch_bounds__(kMidThreads) void eval_midbatch_kernel(MidArgs a) {
           else sums[r - K] = s2;
         }
         pri = eval_epilogue(mW, -sums[0], mWV, kN, sums[1], a.vCompTail);
+        if (live && watchW[slot] != 0) {
+          // the pair's sums as they are, for the fix behind the sweep (pole_kernels.hip)
+          const uint32_t at = pole_list_append(a.poleList, (uint32_t)q, watchW[slot], (uint32_t)b);
+          double *dst = a.poleSums + (size_t)at * (2 * kN + 2);
+#pragma unroll
+          for (int r = 0; r < K; r++)
+            if (EXACT || r < kN) { dst[r] = mW[r]; dst[kN + r] = mWV[r]; }
+          dst[2 * kN] = sums[0];
+          dst[2 * kN + 1] = sums[1];
+        }
       }
+      watchW[slot] = 0;                                       // (set again only behind the next question's barriers)
       if (live) {
         if (a.priorityT) a.priorityT[q * Bp + b] = pri;
         if (!skip) {
@@ -631,13 +625,26 @@ __global__ __launch_bounds__(kMidThreads) void eval_midbatch_kernel(MidArgs a) {
 // One wave per quiz: lane l merges records l, l + 64, ... (each a workgroup's best for this quiz), then the lanes' bests are merged
 // by shuffles.  (Until round 3 one THREAD per quiz walked all ~500 records, a dependent load each: 150 us behind every batched
 // sweep -- a tenth of the 256-quiz sweep at 1000 x 5 x 1000, more than the whole sweep for the batches of a few dozen quizzes.)
+// dirty (optional, [nSlots]): quizzes with a priority the fix behind the sweep has changed (pole_kernels.hip) -- their workgroups'
+// records are stale, the winner comes out of the quiz's column of the priority matrix; the mark is cleared for the next launch.
 __global__ __launch_bounds__(64) void batch_pick_kernel(const BatchRecord *__restrict__ recs, int nRecs, int Bp,
                                                         const QuizSlot *__restrict__ slots, int nSlots, int64_t outBase,
-                                                        uint64_t flagValue) {
+                                                        uint64_t flagValue, uint32_t *dirty, const double *__restrict__ priorityT,
+                                                        int64_t Q, const uint32_t *__restrict__ qgap) {
   const int b = blockIdx.x, lane = threadIdx.x;
   if (b >= nSlots) return;
   double bp = 0.0;
   int64_t bq = -1;
+  if (dirty != nullptr && dirty[b] != 0) {
+    const uint32_t *asked = slots[b].asked;
+    for (int64_t q = lane; q < Q; q += 64) {
+      if (bit_test(qgap, q) || bit_test(asked, q)) continue;
+      double p = priorityT[(size_t)q * Bp + b];
+      if (p != p) p = -__builtin_huge_val();                  // NaN never wins over a number
+      if (bq < 0 || p > bp) { bp = p; bq = q; }               // (q ascending: the first of equal values stays)
+    }
+    if (lane == 0) dirty[b] = 0;
+  } else
   for (int g = lane; g < nRecs; g += 64) {
     const BatchRecord r = recs[(size_t)g * Bp + b];
     if (r.index >= 0 && (bq < 0 || r.priority > bp || (r.priority == bp && r.index < bq))) { bp = r.priority; bq = r.index; }
@@ -776,9 +783,7 @@ hipError_t launch_batch(const BatchArgs &args0, int nThreads, size_t *accBytesNe
   BatchArgs args = args0;
   auto kern = eval_batch_kernel<R, QB, KG, EXACT>;
   const int G = nThreads / args.Bq;   // question groups side by side (eval_batch_kernel)
-  size_t tileBytes = (size_t)args.TC * G * QB * (KG + 1) * sizeof(R);
-  if (Num<R>::kTable && args.poleDoubles > 0)   // (the pole fix's LDS takes the tile's place: pole_device.h)
-    tileBytes = std::max(tileBytes, (size_t)(kPoleRed + args.poleDoubles + kPoleMax) * sizeof(double) + (size_t)(2 * kPoleMax + 2) * sizeof(uint32_t));
+  const size_t tileBytes = (size_t)args.TC * G * QB * (KG + 1) * sizeof(R);
   const size_t shmem = (Num<R>::kTable ? kLog2TableDoubles * sizeof(double) : 0) + tileBytes;
   if (shmem > 160 * 1024) return hipErrorInvalidValue;
   static LaunchCache cache;   // (per instantiation and device; the occupancy also depends on the thread count: part of the key)
@@ -804,6 +809,33 @@ hipError_t launch_batch(const BatchArgs &args0, int nThreads, size_t *accBytesNe
   if (queryOnly) return hipSuccess;
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(nThreads), shmem, stream, args);
   return hipGetLastError();
+}
+
+// The pole scratch of a batched sweep (BatchPlan::pole): marks of the quizzes the fix changed [256] | list header | entries [Q x Bp]
+// | the listed pairs' sums [Q x Bp][2 K + 2].  The caller clears the first kBatchPoleClear bytes once; every launch leaves them cleared.
+static_assert(kBatchPoleClear == 256 * sizeof(uint32_t) + sizeof(PoleHeader), "marks and list header");
+size_t batch_pole_bytes(const KbView &kb, int Bp) {
+  const size_t cap = (size_t)kb.Q * (size_t)Bp;
+  return kBatchPoleClear + cap * sizeof(PoleEntry) + cap * (size_t)(2 * kb.K + 2) * sizeof(double);
+}
+struct BatchPole { PoleHeader *list; uint32_t *dirty; double *sums; };
+BatchPole batch_pole(const KbView &kb, int Bp, void *pole) {
+  char *p = static_cast<char *>(pole);
+  const size_t cap = (size_t)kb.Q * (size_t)Bp;
+  return BatchPole{reinterpret_cast<PoleHeader *>(p + 256 * sizeof(uint32_t)), reinterpret_cast<uint32_t *>(p),
+                   reinterpret_cast<double *>(p + kBatchPoleClear + cap * sizeof(PoleEntry))};
+}
+// the fix between a batched sweep and its pick: the listed pairs, corrected in the priority matrix (and in the host's records)
+hipError_t launch_batch_fixup(const KbView &kb, const QuizSlot *slots, int nSlots, int Bp, const BatchPole &bp, double *priorityT,
+                              uint64_t hostTag, double vCompTail, hipStream_t stream) {
+  PoleFix f{};
+  f.cube = static_cast<const double *>(kb.cube); f.tgap = kb.tgap; f.qgap = kb.qgap; f.slots = slots;
+  f.list = bp.list; f.dirty = bp.dirty; f.sums = bp.sums; f.sumsStride = 2 * kb.K + 2; f.bySlot = 1;
+  f.wOff = 0; f.vOff = (int)kb.K; f.hOff = (int)(2 * kb.K); f.lOff = (int)(2 * kb.K + 1); f.secondIsWV = 1;
+  f.priorityT = priorityT; f.Bp = Bp; f.hostTag = hostTag;
+  f.K = kb.K; f.T = kb.T; f.ldT = kb.ldT; f.qFirst = 0; f.nQ = kb.Q; f.capacity = kb.Q * (int64_t)nSlots;
+  f.vCompTail = vCompTail;
+  return LaunchPoleFixup(f, stream);
 }
 
 }  // namespace
@@ -841,15 +873,17 @@ hipError_t LaunchEvalBatch(const KbView &kb, const QuizSlot *slots, int nSlots, 
   const double nT = (double)(kb.nValidTargets + 1);            // PqaCore/CEEvalQsSubtaskConsider.cpp:191
   a.vCompTail = 0.34657359027997265470861606072909 / (nT * nT);
   a.acc = acc; a.recs = recs; a.priorityT = priorityT;
-  a.T = kb.T;
-  // (the engine's option pole_fix: KbView::poleScratch; room for the rows of a question side by side -- pole_fix_question -- as far as
-  //  40 KB go: with the table and the rest two workgroups per CU still fit)
-  a.poleDoubles = 0;
-  if (!f32 && kb.poleScratch != nullptr && kb.ldT <= 4096) {
-    const int nT = (int)(4 * ((kb.T + 3) / 4));
-    a.poleDoubles = nT * (int)std::max<int64_t>(1, std::min<int64_t>(kb.K, 5120 / nT));
+  // the engine's option pole_fix (KbView::poleList), Double engines: the sweep lists the (question, quiz) pairs at the pole of the
+  // lack term, pole_kernels.hip redoes them in the priority matrix -- which the caller then provides -- before the pick
+  const bool watch = !f32 && kb.poleList != nullptr && !skipPick;
+  plan->poleBytes = watch ? batch_pole_bytes(kb, Bp) : 0;
+  BatchPole bpole{};
+  if (watch && !queryOnly) {
+    if (plan->pole == nullptr || priorityT == nullptr) return hipErrorInvalidValue;
+    bpole = batch_pole(kb, Bp, plan->pole);
+    a.poleList = bpole.list;
+    a.poleSums = bpole.sums;
   }
-  a.log2Entry0Ref = std::log2(1.0 + 0x1p-11) * 9.9999999999999927e-01;   // SRVectMath.cpp:31,42
   plan->ptBytes = (size_t)kb.ldT * Bp * (f32 ? 4 : 8);
   plan->Bp = Bp;
   hipError_t e;
@@ -935,8 +969,12 @@ hipError_t LaunchEvalBatch(const KbView &kb, const QuizSlot *slots, int nSlots, 
     if (e != hipSuccess) return e;
   }
   if (skipPick) return hipSuccess;
+  if (watch) {
+    e = launch_batch_fixup(kb, slots, nSlots, Bp, bpole, priorityT, 0, a.vCompTail, stream);
+    if (e != hipSuccess) return e;
+  }
   hipLaunchKernelGGL(batch_pick_kernel, dim3((unsigned)nSlots), dim3(64), 0, stream, recs, (gridMain + gridTail) * G, Bp, slots, nSlots,
-                     outBase, flagValue);
+                     outBase, flagValue, watch ? bpole.dirty : nullptr, priorityT, kb.Q, kb.qgap);
   return hipGetLastError();
 }
 
@@ -944,7 +982,7 @@ hipError_t LaunchEvalBatch(const KbView &kb, const QuizSlot *slots, int nSlots, 
 bool EvalMidBatchSupported(const KbView &kb) {
   const int64_t km = kb.K == 5 ? 5 : kMidMaxK;
   return kb.elem == 8 && kb.K >= 2 && kb.K <= kMidMaxK &&
-         (size_t)(kLog2TableDoubles + kb.ldT * (km + 1) + (kMidThreads / kWave) * (km + 2) * 64) * sizeof(double) <= 160 * 1024;
+         (size_t)(kLog2TableDoubles + kb.ldT * (km + 1) + (kMidThreads / kWave) * (km + 2) * 64 + 32) * sizeof(double) <= 160 * 1024;
 }
 
 // plan: out grid / Bp / ptBytes / recBytes (queryOnly), as LaunchEvalBatch; PT and recs from the caller.  Every quiz's winner goes to
@@ -960,7 +998,7 @@ hipError_t LaunchEvalMidBatch(const KbView &kb, const QuizSlot *slots, int nSlot
   const int devSlot = LaunchCache::Device();
   const int nCU = cache.NumCUs(devSlot);
   const int KM = kb.K == 5 ? 5 : kMidMaxK;
-  const size_t shmem = (size_t)(kLog2TableDoubles + kb.ldT * (KM + 1) + (kMidThreads / kWave) * (KM + 2) * QS) * sizeof(double);
+  const size_t shmem = (size_t)(kLog2TableDoubles + kb.ldT * (KM + 1) + (kMidThreads / kWave) * (KM + 2) * QS + 32) * sizeof(double);   // (+ the watch words)
   if (shmem > 160 * 1024) return hipErrorInvalidValue;
   const int perCU = (int)std::max<size_t>(1, std::min<size_t>(3, (160 * 1024) / shmem));
   int64_t grid = std::min<int64_t>(kb.Q, std::max<int64_t>(1, (int64_t)nCU * perCU / groups));
@@ -971,8 +1009,12 @@ hipError_t LaunchEvalMidBatch(const KbView &kb, const QuizSlot *slots, int nSlot
   plan->ptBytes = (size_t)kb.ldT * Bp * sizeof(double);
   plan->accBytes = 0;
   plan->recBytes = (size_t)grid * Bp * sizeof(BatchRecord);
+  const bool watch = kb.poleList != nullptr;                  // (as LaunchEvalBatch)
+  plan->poleBytes = watch ? batch_pole_bytes(kb, Bp) : 0;
   if (queryOnly) return hipSuccess;
   if (PT == nullptr || recs == nullptr) return hipErrorInvalidValue;
+  if (watch && (plan->pole == nullptr || priorityT == nullptr)) return hipErrorInvalidValue;
+  const BatchPole bpole = watch ? batch_pole(kb, Bp, plan->pole) : BatchPole{};
   // the instantiation: quiz slots per wave x (five answers exactly | up to eight)
   void (*kern)(MidArgs) = nullptr;
   if (KM == 5) kern = QS == 8 ? eval_midbatch_kernel<8, 5, true> : QS == 16 ? eval_midbatch_kernel<16, 5, true> : QS == 32 ? eval_midbatch_kernel<32, 5, true> : eval_midbatch_kernel<64, 5, true>;
@@ -992,12 +1034,17 @@ hipError_t LaunchEvalMidBatch(const KbView &kb, const QuizSlot *slots, int nSlot
   const double nT = (double)(kb.nValidTargets + 1);            // PqaCore/CEEvalQsSubtaskConsider.cpp:191
   a.vCompTail = 0.34657359027997265470861606072909 / (nT * nT);
   a.recs = recs; a.priorityT = priorityT; a.tag = flagValue;
+  a.poleList = bpole.list; a.poleSums = bpole.sums;
   const dim3 g((unsigned)grid, (unsigned)groups);
   hipLaunchKernelGGL(kern, g, dim3(kMidThreads), shmem, stream, a);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
+  if (watch) {
+    e = launch_batch_fixup(kb, slots, nSlots, Bp, bpole, priorityT, flagValue, a.vCompTail, stream);
+    if (e != hipSuccess) return e;
+  }
   hipLaunchKernelGGL(batch_pick_kernel, dim3((unsigned)nSlots), dim3(64), 0, stream, recs, (int)grid, Bp, slots, nSlots,
-                     outBase, flagValue);
+                     outBase, flagValue, watch ? bpole.dirty : nullptr, priorityT, kb.Q, kb.qgap);
   return hipGetLastError();
 }
 

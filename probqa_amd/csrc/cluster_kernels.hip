@@ -26,6 +26,7 @@
 #include <cstdlib>
 
 #include "eval_device.h"
+#include "pole_device.h"
 #include "pqa_device.h"
 #include "pqa_kernels.h"
 
@@ -91,7 +92,15 @@ struct ClusterArgs {
   unsigned long long tagBase;  // launch number << 32: records of earlier launches never match
   double *totals;             // [Q][2 kMaxK + 2]: W_k | V_k | sum W_k H_k | lack
   double *priority;           // skipped questions get their 0 here
+  // the pole watch (Double engines; pole_kernels.hip redoes the listed questions between this sweep and its epilogues): the list,
+  // and per question the rows in which a member saw a posterior element within 2^-10 of 1 (several members may)
+  PoleHeader *poleList;
+  uint32_t *poleMask;
 };
+// a member's rows of one question that passed the watch (one thread of the member)
+__device__ __forceinline__ void cluster_watch_report(const ClusterArgs &a, int64_t q, uint32_t rows) {
+  if (atomicOr(&a.poleMask[q], rows) == 0u) pole_list_append(a.poleList, (uint32_t)q, 0u, 0u);
+}
 
 // The members of a cluster run on different XCDs, whose L2s are not coherent with each other: records are written through (sc1)
 // and read past the L2s (sc1), 16 bytes at a time -- value and tag travel together (as the sweep's winner records do,
@@ -294,9 +303,11 @@ __global__ __launch_bounds__(kClusterThreads, 4) void eval_cluster_kernel(Cluste
     // ---- pass 2 (:95-128) from LDS, answer by answer; the lack term's N / D pairs (batch_kernels.hip) run across the answers
     V accN[NU], accD[NU];
     R hW = (R)0, accL = (R)0;
+    uint32_t poleRows = 0;                                      // (the pole watch: wave-uniform)
     for (int64_t k = 0; k < K; k++) {
       const R invWk = (R)div_fast(1.0, wTot[k]);                // :91
       R vk = (R)0;
+      [[maybe_unused]] uint32_t hiMax = 0;
 #pragma unroll
       for (int j = 0; j < NU; j++) {
         const int sl = tid + j * kClusterThreads;
@@ -306,6 +317,7 @@ __global__ __launch_bounds__(kClusterThreads, 4) void eval_cluster_kernel(Cluste
           for (int e = 0; e < VN; e++) {
             const R l = at<R>(lh, e), pi = at<R>(pr[j], e);
             const R p = l * invWk;                              // :97
+            if constexpr (NumC<R>::kTable) hiMax = max(hiMax, (uint32_t)(d2u((double)p) >> 32));
             const R l2 = NumC<R>::log2p(p, tbl);                // :106
             hW = fma(l, l2, hW);                                // :113-114 weighted by W_k (eval_epilogue)
             const R dd = p - pi;                                // :119
@@ -318,6 +330,7 @@ __global__ __launch_bounds__(kClusterThreads, 4) void eval_cluster_kernel(Cluste
       }
       const double s = wave_sum_d((double)vk);
       if (lane == 0) red[k][wave] = s;
+      if constexpr (NumC<R>::kTable) { if (a.poleList != nullptr && __any(hiMax >= kNearOneHi)) poleRows |= 1u << (k < 31 ? (int)k : 31); }
     }
 #pragma unroll
     for (int j = 0; j < NU; j++) {
@@ -334,6 +347,7 @@ __global__ __launch_bounds__(kClusterThreads, 4) void eval_cluster_kernel(Cluste
       const double s1 = wave_sum_d((double)hW), s2 = wave_sum_d((double)accL);
       if (lane == 0) { red[K][wave] = s1; red[K + 1][wave] = s2; }
     }
+    if (poleRows != 0 && lane == 0) cluster_watch_report(a, q, poleRows);   // (rare)
     __syncthreads();
     if (tid < K + 2) {
       double s = 0.0;
@@ -593,15 +607,18 @@ __global__ __launch_bounds__(kClusterThreads, 4) void eval_cluster_ahead_kernel(
     double *slot = reinterpret_cast<double *>(lhL);             // unit u of row k: slot[(k * SU + u) * 2 + {0, 1}]
     V accN, accD;
     R hW = (R)0, accL = (R)0;
+    uint32_t poleRows = 0;                                      // (the pole watch: wave-uniform)
     for (int64_t k = 0; k < K; k++) {
       const R invWk = (R)wInv[k];                               // :91 (formed once per workgroup, above)
       R vk = (R)0;
+      [[maybe_unused]] uint32_t hiMax = 0;
       if (inSlice) {
         const V lh = lhL[k * SU + tid];
 #pragma unroll
         for (int e = 0; e < VN; e++) {
           const R l = at<R>(lh, e), pi = at<R>(pr, e);
           const R p = l * invWk;                                // :97
+          if constexpr (NumC<R>::kTable) hiMax = max(hiMax, (uint32_t)(d2u((double)p) >> 32));
           const R l2 = NumC<R>::log2p(p, tbl);                  // :106
           hW = fma(l, l2, hW);                                  // :113-114 weighted by W_k (eval_epilogue)
           const R dd = p - pi;                                  // :119
@@ -611,7 +628,9 @@ __global__ __launch_bounds__(kClusterThreads, 4) void eval_cluster_ahead_kernel(
         }
         slot[(k * SU + tid) * 2] = (double)vk;
       }
+      if constexpr (NumC<R>::kTable) { if (a.poleList != nullptr && __any(hiMax >= kNearOneHi)) poleRows |= 1u << (k < 31 ? (int)k : 31); }
     }
+    if (poleRows != 0 && lane == 0) cluster_watch_report(a, q, poleRows);   // (rare)
     if (inSlice) {
 #pragma unroll
       for (int e = 0; e < VN; e++) {
@@ -769,7 +788,7 @@ size_t EvalClusterScratchBytes(const KbView &kb) {
   const bool ok = kb.elem == 4 ? cluster_shape<float>(kb, device_cus(), &s) : cluster_shape<double>(kb, device_cus(), &s);
   if (!ok) return 0;
   const size_t perCluster = (size_t)4 * s.C * (2 * kMaxK + 2) * sizeof(ExRec);   // (four record slots: the form that runs ahead; the other uses two)
-  return (size_t)s.nClusters * perCluster + (size_t)kb.Q * (2 * kMaxK + 2) * sizeof(double) + 256;
+  return (size_t)s.nClusters * perCluster + (size_t)kb.Q * (2 * kMaxK + 2) * sizeof(double) + 256 + (size_t)kb.Q * sizeof(uint32_t);
 }
 
 hipError_t LaunchEvalCluster(const KbView &kb, const double *prior, const uint32_t *asked, double *priority, void *scratch, hipStream_t stream) {
@@ -785,6 +804,10 @@ hipError_t LaunchEvalCluster(const KbView &kb, const double *prior, const uint32
   a.recS = a.recW + (size_t)s.nClusters * 4 * s.C * kMaxK;
   a.totals = reinterpret_cast<double *>(a.recS + (size_t)s.nClusters * 4 * s.C * (kMaxK + 2));
   a.priority = priority;
+  // (the rows' mask words: behind the totals; the caller cleared the scratch once, the fix leaves them cleared)
+  const bool watch = !f32 && kb.poleList != nullptr && kb.poleScratch != nullptr;
+  a.poleList = watch ? kb.poleList : nullptr;
+  a.poleMask = watch ? reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(a.totals) + (size_t)kb.Q * (2 * kMaxK + 2) * sizeof(double) + 256) : nullptr;
   static std::atomic<unsigned long long> launches{0};
   a.tagBase = (launches.fetch_add(1) + 1) << 32;
   hipError_t e = hipSuccess;
@@ -801,6 +824,17 @@ hipError_t LaunchEvalCluster(const KbView &kb, const double *prior, const uint32
   }
   e = hipGetLastError();
   if (e != hipSuccess) return e;
+  if (watch) {
+    // the questions on the list, redone in the reference's order where their totals lie (W_k | V_k | sum l log2 p | lack); the
+    // epilogues below then see the corrected totals
+    PoleFix f{};
+    f.cube = static_cast<const double *>(kb.cube); f.tgap = kb.tgap; f.qgap = kb.qgap; f.asked = asked; f.prior = prior;
+    f.list = a.poleList; f.maskDense = a.poleMask; f.sums = a.totals; f.sumsStride = 2 * kMaxK + 2;
+    f.wOff = 0; f.vOff = kMaxK; f.hOff = 2 * kMaxK; f.lOff = 2 * kMaxK + 1; f.secondIsWV = 0;
+    f.K = kb.K; f.T = kb.T; f.ldT = kb.ldT; f.qFirst = 0; f.nQ = kb.Q; f.capacity = kb.Q;
+    e = LaunchPoleFixup(f, stream);
+    if (e != hipSuccess) return e;
+  }
   const double nT = (double)(kb.nValidTargets + 1);             // PqaCore/CEEvalQsSubtaskConsider.cpp:191
   hipLaunchKernelGGL(cluster_epilogue_kernel, dim3((unsigned)((kb.Q + 255) / 256)), dim3(256), 0, stream, a.totals, kb.qgap, asked,
                      priority, kb.K, kb.Q, 0.34657359027997265470861606072909 / (nT * nT));

@@ -46,7 +46,8 @@ struct EvalArgs {
   const uint32_t *qgap;
   const uint32_t *asked;
   double *priority;
-  double *poleScratch;   // KbView::poleScratch (single-quiz launches), or null
+  double *poleScratch;   // KbView::poleScratch (single-quiz launches), or null: the sums of questions that passed the pole watch, [question][2 K + 2]
+  PoleHeader *poleList;  // KbView::poleList: ... and their entries (pole_kernels.hip is launched behind the sweep); null: no watch
   int64_t K, T, ldT, qFirst, qLimit;
   double vCompTail;  // ln(sqrt 2) / (nValidTargets + 1)^2, PqaCore/CEEvalQsSubtaskConsider.cpp:191
   FusedSelect fs;
@@ -178,10 +179,15 @@ __device__ __forceinline__ void fused_select(const EvalArgs &a, Best mine, int l
       }
   }
   b = wave_best(b);
-  if (sampled) {           // the selection follows (sweep_body); only whether the sweep is complete is handed on
-    if (allReported != nullptr && (UNI || lane == 0)) *allReported = complete;
+  // questions that passed the pole watch (any workgroup's: their entries were in the list before their workgroups reported): the
+  // fix launched behind this sweep publishes the result -- pole_kernels.hip
+  bool deferred = false;
+  if (a.poleList != nullptr && complete) deferred = __hip_atomic_load(&a.poleList->count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+  if (sampled) {           // the selection follows (sweep_body); only whether the sweep is complete (and whether it publishes) is handed on
+    if (allReported != nullptr && (UNI || lane == 0)) { allReported[0] = complete; allReported[1] = deferred; }
     return;
   }
+  if (deferred) return;
   if (UNI || lane == 0) {
     a.fs.out->priority = b.i < 0 ? 0.0 : b.p;
     a.fs.out->index = !complete ? -3 : b.i < 0 ? -1 : b.i + a.fs.outBase;
@@ -198,12 +204,9 @@ __device__ __forceinline__ void fused_select(const EvalArgs &a, Best mine, int l
 }
 
 // One element pair of pass 2 (:95-128).  lh: likelihoods, id: 1/D, pr: masked priors.
-// hiMax: the largest high word of a posterior element seen so far (they are >= 0: their bit patterns order like the numbers) --
-// the watch for rows at the pole of the lack term (pole_fix below).
 __device__ __forceinline__ void pass2_pair(double2 lh, double2 id, double2 pr, double invWk, const double *tbl,
-                                           double &hW, double &v, double &accL, uint32_t &hiMax) {
+                                           double &hW, double &v, double &accL) {
   const double p0 = lh.x * invWk, p1 = lh.y * invWk;           // :97
-  hiMax = max(hiMax, max((uint32_t)(d2u(p0) >> 32), (uint32_t)(d2u(p1) >> 32)));
   const double d0 = p0 - pr.x, d1 = p1 - pr.y;                 // :119 (first: log2hot may then rework p's registers in place)
   const double l20 = log2hot(p0, tbl), l21 = log2hot(p1, tbl); // :106 (gap lanes: p = 0 -> -1023, contributes -0)
   hW = fma(lh.x, l20, hW);                                     // :113-114 weighted by W_k (see eval_epilogue)
@@ -221,71 +224,24 @@ __device__ __forceinline__ void pass2_pair(double2 lh, double2 id, double2 pr, d
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// Rows at the pole of the lack term.  lack = -sum invD^2 / log2(p) (:117) has a pole at p -> 1: with a
-// posterior element at p = 1 - 1e-7, |log2 p| ~ 1e-7, and the last place of p = l * (1 / W_k) -- i.e. of W_k, i.e. of the ORDER
-// W_k was summed in -- moves log2 p by 1.6e-16 absolute and the priority by 1.6e-9 relative: above the 1e-9 the parity tests hold
-// the sweep to (three of round 3's 13 700 soak cases).  The sweep's W_k is a plain per-lane sum and a butterfly; the reference's
-// is four serial Kahan lanes down the row (SRAccumVectDbl256.h:40-46) and PreciseSum (:62-92), which no wave reproduces at speed
-// (a row of T targets is T / 4 DEPENDENT Kahan steps -- measured in round 4: every question of a late quiz redone in
-// that order costs 5 - 8 sweeps).  Only the rows AT the pole need it, though.
-//
-// So: the sweep WATCHES (one v_max3_u32 per element pair, a compare and a wave-uniform branch per row: the answer rows in which a
-// posterior element came within 2^-17 of 1 -- a hundred times further from the pole than where the deviation reaches 1e-9) and
-// otherwise runs as it always ran.  A question with such a row also leaves its sums in memory (KbView::poleScratch), and once the
-// workgroup's stream has ended pole_fix (pole_device.h: pole_fix_question) goes over those rows again, all threads side by side:
-// the rows' likelihoods are staged in the LDS the stream has left -- the mD landing row and the deferred sums' dump behind it: as
-// many rows as fit, side by side -- four lanes per row sum them in the reference's order (T / 4 dependent steps: 4.5 us at 1000
-// targets, for all the staged rows at once), and for the element that is within 2^-17 of 1, Log2Hot by the reference's operation
-// sequence (true quotient, its own table entry 0: log2hot_ref) and the lack quotient as an exact division replace what pass 2 had
-// added for it.  That element's terms are then the oracle's.  A late quiz -- the posterior on one target -- has EVERY row of nearly
-// every question at the pole (that target's likelihood is all of W_k whatever the answer): the sweep then costs 4.5 - 6.5 times
-// its usual time (the rows are read again, the chains are serial).
-// Tried on the way (round 4, all measured): the reference's order itself at the end of the sweep (exact; 5 - 8 sweeps per sweep
-// in a late quiz: T / 4 dependent steps per row, the rows re-read twice); the compensated sum and the correction inside the row
-// loop, from the registers (nothing re-read, +25 - 70 % in a late quiz, but the blocks between pass 1 and pass 2 cost the
-// loop its registers: +10 % at 1000 targets, +50 % at 4000 in EVERY state); the fix as a called function (the scratch segment the
-// call needs: +13 % at 1000 targets).
+// Rows at the pole of the lack term.  lack = -sum invD^2 / log2(p) (:117) has a pole at p -> 1: with a posterior element at
+// p = 1 - 1e-7 the last place of p = l * (1 / W_k) -- i.e. the ORDER W_k was summed in -- moves the priority by 1.6e-9 relative,
+// and by more the closer to 1 (a quiz's last states).  The sweep's W_k is a plain per-lane sum and a butterfly; the reference's is
+// four serial Kahan lanes down the row (SRAccumVectDbl256.h:40-46) and PreciseSum (:62-92), which no wave reproduces at speed
+// (SURVEY F4).  Only the rows AT the pole need it, so the sweep only WATCHES, and what it finds is redone behind it by
+// pole_kernels.hip (the whole story is told there).
+// The watch costs a multiplication and a compare per ROW: an element within 2^-10 of 1 is nearly all of W_k, so the lane that holds
+// it has a pass-1 sum of at least (1 - 2^-9) of its wave's sum (all terms are >= 0, sums of them only grow), and its wave's sum is
+// at least that share of W_k.  Both tests are wave-uniform (a vote; a scalar compare) and false most of the time; a row that passes
+// sets its bit in the question's row mask.  (A lane whose several elements together hold the row's mass passes too: the fix looks
+// at the row's largest element before it changes anything.)  Round 4 watched every element PAIR (one v_max3_u32 each and a register
+// for the running maximum: +2 - 5 % on the short-row shapes, 3.7 % at 10000 targets) and fixed rows of up to 4096 targets inside
+// the sweep, lists of 62 suspects per workgroup; measured on the way there and dropped: the reference's order for every row at the
+// end of the sweep (5 - 8 sweeps per sweep in a late quiz), the correction inside the row loop from the registers (+10 - 50 % in
+// EVERY state: the blocks between pass 1 and pass 2 cost the loop its registers), the fix as a called function (+13 %: scratch).
 // ------------------------------------------------------------------------------------------------------------------
-constexpr int kSusMax = 62;                    // suspects a workgroup lists per sweep (further ones keep the sweep's own values)
-constexpr int kSusDoubles = 64;                // LDS: two words (by question parity: the answer rows at the pole, a bit each) + the list of {question, rows}
-
-struct PoleArgs {
-  const double *cube, *prior;
-  const uint32_t *tgap;
-  double *priority, *scratch;
-  TaggedPriority *hostPriority;   // non-null: the priorities are handed to the host as tagged records (flush_pending)
-  uint64_t hostTag;
-  int64_t K, T, ldT, qFirst;
-  double vCompTail;
-};
-
-// nSus questions of this workgroup (local indices in `list`) whose largest posterior element is within 2^-17 of 1; their sums as
-// the sweep formed them are in args.scratch.  All threads; red: LDS, 4 x waves (at least 8) doubles; stage: LDS, a row's worth of
-// doubles; best: the workgroup's running argmax (LDS).
-template <bool COH>
-__device__ __forceinline__ void pole_fix(const PoleArgs &g, const uint32_t *list, int nSus, double *red, int redDoubles, double *stage,
-                                         int stageDoubles, Best *best) {
-  const PoleRows rows{g.cube, g.prior, g.tgap, g.K, g.T, g.ldT, gLog2Table, gLog2Entry0Ref};
-  for (int s2 = 0; s2 < nSus; s2++) {
-    const int64_t qLocal = list[2 * s2];
-    const uint32_t rowMask = list[2 * s2 + 1];                 // the answer rows in which the sweep saw an element within 2^-17 of 1
-    double *rec = g.scratch + qLocal * (2 * g.K + 2);          // W_k [K] | W_k sqrt(V_k) [K] | sum l log2 p | lack sum
-    double dH = 0.0, dL = 0.0;                                 // (thread 0: what the near-1 elements change)
-    pole_fix_question<COH>(rows, g.qFirst + qLocal, rec, true, rowMask, red, redDoubles, stage, stageDoubles, dH, dL);
-    if (threadIdx.x == 0) {
-      const int64_t K = g.K;
-      const double pri = eval_epilogue(rec, -(rec[2 * K] + dH), rec + K, K, rec[2 * K + 1] + dL, g.vCompTail);  // :130
-      store_priority(g.priority + qLocal, pri);
-      if (g.hostPriority != nullptr) {
-        typedef unsigned int u4 __attribute__((ext_vector_type(4)));
-        const uint64_t w0 = d2u(pri), w1 = g.hostTag;
-        const u4 x = {(unsigned)w0, (unsigned)(w0 >> 32), (unsigned)w1, (unsigned)(w1 >> 32)};
-        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(g.hostPriority + qLocal), "v"(x) : "memory");
-      }
-      best_offer(best[0], pri, qLocal);
-    }
-  }
-}
+constexpr double kNearOneShare = 1.0 - 0x1p-9;   // (of the wave's sum, of W_k: see above; the bar is pole_device.h: kNearOneHi)
+constexpr int kSusDoubles = 2;                 // LDS: two words (by question parity: the answer rows that passed the watch, a bit each) + a slot
 
 // LDS-DMA: 16 bytes per lane from global memory straight into LDS, no destination VGPRs (buffer_load_dwordx4 ... offen lds:
 // row base in an SGPR descriptor, the lane's 32-bit byte offset in a VGPR -- no 64-bit address pairs either); completion is
@@ -377,6 +333,11 @@ __device__ __forceinline__ void flush_pending(const EvalArgs &a, const double *p
 // Tried instead: an acquire fence in every wave at the start of a step (what a kernel boundary does) -- correct, 44 us per
 // step against 22; per-XCD copies made by one leader workgroup per XCD and read with workgroup-scope (sc0) loads -- no
 // faster (the step is bound by pulling the 48 MB cube through the L2s, ~13 us, not by these 8 KB) and not coherent.
+__device__ __forceinline__ double uniform_double(double x) {   // a wave-uniform value, into scalar registers
+  const uint64_t u = d2u(x);
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)u), hi = __builtin_amdgcn_readfirstlane((uint32_t)(u >> 32));
+  return u2d(((uint64_t)hi << 32) | lo);
+}
 template <bool COH>
 __device__ __forceinline__ uint32_t load_word(const uint32_t *p) {
   if constexpr (COH) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -415,7 +376,7 @@ __device__ __forceinline__ void sweep_body(EvalArgs a, bool copyTable) {
   double *partAll = redW + 2 * WPQ;
   double *pend = partAll + 2 * (K + 2) * WPQ;
   Best *bestLds = reinterpret_cast<Best *>(pend + kPend * (2 * K + 3));  // wave 0's per-lane running argmax
-  uint32_t *susWords = reinterpret_cast<uint32_t *>(bestLds + kWave);   // [0], [1]: the question of that parity has a row at the pole; [2..): the list
+  uint32_t *susWords = reinterpret_cast<uint32_t *>(bestLds + kWave);   // [0], [1]: the rows of the question of that parity that passed the pole watch
   double2 *prLds = reinterpret_cast<double2 *>(reinterpret_cast<double *>(bestLds + kWave) + kSusDoubles);
   // landing row of the NEXT question's mD (register-prior shapes): lane-private 16-byte slots, slot j of thread tid at
   // mdRow[j*kThreads + tid]; filled by LDS-DMA while the current question's last answer is in pass 2
@@ -565,15 +526,11 @@ __device__ __forceinline__ void sweep_body(EvalArgs a, bool copyTable) {
   }
   __syncthreads();
 
-  int phase = 0, qpar = 0, nPend = 0, nSus = 0;
-  // The pole watch (pole_fix) exists for the launched sweeps over rows of up to 4096 targets (template POLE: the launcher takes the
-  // variant when the engine gave it KbView::poleScratch -- option pole_fix, default on): there it costs 2.5 - 5 % (one v_max3_u32 per
-  // element pair and what the fix's presence does to the loop's scalar registers).  The long-row shapes sit at the edge of the
-  // register file (the watch alone cost 10000 x 5 x 10000 3.7 %), the resident kernel's step is the headline of bench.py (+6.5 %
-  // with it: 16.9 -> 18.0 us) and hands out only the selected question: both keep the sweep's own sums -- and the conditioning
-  // bound of DESIGN section 5.
-  constexpr bool kPoleShape = POLE && 128 * WPQ * NP <= 4096 && !(NP == 4 && !DEFER);   // (the two 4-pair shapes without deferred sums -- grid.y batches, dozens of answers -- are a register short of three waves)
-  const bool poleWatch = kPoleShape && a.poleScratch != nullptr;
+  int phase = 0, qpar = 0, nPend = 0;
+  // The pole watch (see above; template POLE: the launcher takes the variant when the engine gave it KbView::poleList -- option
+  // pole_fix, default on).  The resident kernel -- its step is the headline of bench.py, and nothing can be launched behind a step --
+  // keeps the sweep's own sums and the conditioning bound of DESIGN section 5.
+  constexpr bool kWatch = POLE && !SERVER;
   if (wave == 0) bestLds[lane] = Best{0.0, -1};   // only wave 0 ever touches these
   while (q < a.qLimit) {
     const int64_t qn = next_valid(q + gridDim.x);
@@ -604,7 +561,7 @@ __device__ __forceinline__ void sweep_body(EvalArgs a, bool copyTable) {
     double *part = partAll + qpar * (nPart * WPQ);
     double *rec = pend + nPend * recLen;
     double accL = 0, hW = 0;
-    uint32_t hiMax = 0, poleRows = 0;                          // (pole watch: the row's largest posterior high word; the rows that had one near 1)
+    uint32_t poleRows = 0;                                     // (pole watch: the rows that passed, wave-uniform)
     for (int64_t k = 0; k < K; k++) {
       // ---- pass 1 (:66-87): likelihoods into registers, W_k; each consumed pair is refilled from the next stream row
       double2 lh[NP];
@@ -642,13 +599,23 @@ __device__ __forceinline__ void sweep_body(EvalArgs a, bool copyTable) {
 #pragma unroll
         for (int j = 0; j < NP; j++) dma16(mdNext, poff[j], mdRowWaveAddr + (unsigned)j * (kThreads * 16u));
       }
-      double Wk = wave_sum(s0 + s1);                           // :88
+      const double sLane = s0 + s1;
+      double Wk = wave_sum(sLane);                             // :88
+      bool watchHit = false;                                   // (wave-uniform: a lane of this wave holds nearly all of the wave's sum)
+      double waveW = 0.0;
+      if constexpr (kWatch) {
+        watchHit = __any(sLane >= Wk * kNearOneShare && sLane > 0.0);
+        if (watchHit) waveW = uniform_double(Wk);                // (in scalar registers across the exchange)
+      }
       if constexpr (WPQ > 1) {
         double *buf = redW + phase * WPQ;
         if (lane == 0) buf[wave] = Wk;
         __syncthreads();
         Wk = row_sum<WPQ>(buf[lane % WPQ]);
         phase ^= 1;
+      }
+      if constexpr (kWatch) {
+        if (watchHit && __any(waveW >= Wk * kNearOneShare)) poleRows |= 1u << (k < 31 ? (int)k : 31);   // (rare outside late quiz states)
       }
       const double invWk = div_nr(1.0, Wk);                    // :91
       // ---- pass 2 (:95-128)
@@ -657,17 +624,11 @@ __device__ __forceinline__ void sweep_body(EvalArgs a, bool copyTable) {
       for (int j = 0; j < NP; j++) {
         double2 pv;
         if constexpr (PRLDS) pv = prLds[min(tid + j * kThreads, nPairs)]; else pv = pr[j];
-        pass2_pair(lh[j], invD[j], pv, invWk, tbl, hW, v, accL, hiMax);
+        pass2_pair(lh[j], invD[j], pv, invWk, tbl, hW, v, accL);
         // Pin the accumulators here: without an opaque use the compiler sinks the whole lack chain (and every log2 it
         // needs) below the loop, which costs 8 live VGPRs per pair; and keep the interleave to one pair at a time.
         asm volatile("" : "+v"(accL), "+v"(hW), "+v"(v));
         __builtin_amdgcn_sched_barrier(0);
-      }
-      if constexpr (kPoleShape) {                              // (the pole watch by ROW: pole_fix then knows which rows to redo)
-        if (__any(hiMax >= kNearOneHi)) {                      // (a compare and a scalar branch per row; rare outside late quiz states)
-          if (hiMax >= kNearOneHi) poleRows |= 1u << (k < 31 ? (int)k : 31);
-          hiMax = 0;                                           // (below the threshold it may stand: only crossing it matters)
-        }
       }
       if constexpr (kDefer) {
         vdump[k * kThreads + tid] = v;                         // :132, reduced with the question's other sums below
@@ -680,15 +641,15 @@ __device__ __forceinline__ void sweep_body(EvalArgs a, bool copyTable) {
         }
       }
     }
-    bool suspect = false;   // workgroup-uniform: a posterior element of this question is within 2^-17 of 1
+    bool suspect = false;   // workgroup-uniform: a row of this question passed the pole watch
     if constexpr (kDefer) {
       // (the dump is single-buffered: a wave that runs ahead writes it again only behind the next question's first W
       //  barrier, which no wave passes before every wave has read here)
       vdump[K * kThreads + tid] = hW;
       vdump[(K + 1) * kThreads + tid] = accL;
-      if constexpr (kPoleShape) { if (poleRows != 0) atomicOr(&susWords[qpar], poleRows); }   // (rare: see pole_fix)
+      if constexpr (kWatch) { if (poleRows != 0 && lane == 0) atomicOr(&susWords[qpar], poleRows); }   // (rare)
       __syncthreads();
-      if constexpr (kPoleShape) suspect = poleWatch && susWords[qpar] != 0 && nSus < kSusMax;
+      if constexpr (kWatch) suspect = a.poleList != nullptr && susWords[qpar] != 0;
       // every 32 lanes take one of the K + 2 sums: threads/32 partials each, then a 32-lane butterfly
       constexpr int kGroups = kThreads / 32;
       const int l32 = tid & 31;
@@ -709,10 +670,10 @@ __device__ __forceinline__ void sweep_body(EvalArgs a, bool copyTable) {
       if (tid == 0) {
         reinterpret_cast<int64_t *>(rec)[2 * K + 2] = q;
         susWords[qpar ^ 1] = 0;                                // (the other parity's flag: read by everybody before this question's barrier, set again only behind the next question's)
-        if (suspect) { susWords[2 + 2 * nSus] = (uint32_t)(q - a.qFirst); susWords[3 + 2 * nSus] = K <= 31 ? susWords[qpar] : 0u; }
+        if (suspect) pole_list_append(a.poleList, (uint32_t)(q - a.qFirst), K <= 31 ? susWords[qpar] : 0u, 0u);
       }
       if (suspect) {
-        // the question's sums as they are, for pole_fix (the question is queued like any other: its priority stands until then)
+        // the question's sums as they are, for the fix behind the sweep (the question is queued like any other: its priority stands until then)
         __syncthreads();
         for (int i = tid; i < 2 * (int)K + 2; i += kThreads) a.poleScratch[(q - a.qFirst) * (2 * K + 2) + i] = rec[i];
       }
@@ -727,9 +688,9 @@ __device__ __forceinline__ void sweep_body(EvalArgs a, bool copyTable) {
         part[K * WPQ + wave] = hW;
         part[(K + 1) * WPQ + wave] = accL;
       }
-      if constexpr (kPoleShape) { if (poleRows != 0) atomicOr(&susWords[qpar], poleRows); }   // (rare: see pole_fix)
+      if constexpr (kWatch) { if (poleRows != 0 && lane == 0) atomicOr(&susWords[qpar], poleRows); }   // (rare)
       if constexpr (WPQ > 1) __syncthreads();
-      if constexpr (kPoleShape) suspect = poleWatch && susWords[qpar] != 0 && nSus < kSusMax;
+      if constexpr (kWatch) suspect = a.poleList != nullptr && susWords[qpar] != 0;
       if (wave == 0) {
         // combine the waves' partials in wave order, one partial row per lane, and queue the question
         for (int r = lane; r < nPart; r += kWave) {
@@ -741,14 +702,13 @@ __device__ __forceinline__ void sweep_body(EvalArgs a, bool copyTable) {
         if (lane == 0) {
           reinterpret_cast<int64_t *>(rec)[2 * K + 2] = q;
           susWords[qpar ^ 1] = 0;
-          if (suspect) { susWords[2 + 2 * nSus] = (uint32_t)(q - a.qFirst); susWords[3 + 2 * nSus] = K <= 31 ? susWords[qpar] : 0u; }
+          if (suspect) pole_list_append(a.poleList, (uint32_t)(q - a.qFirst), K <= 31 ? susWords[qpar] : 0u, 0u);
         }
         if (suspect)   // (the record is this wave's own work: no barrier)
           for (int i = lane; i < 2 * (int)K + 2; i += kWave) a.poleScratch[(q - a.qFirst) * (2 * K + 2) + i] = rec[i];
         if (nPend + 1 == kPend) flush_pending(a, pend, kPend, lane, bestLds[lane]);
       }
     }
-    if (suspect) nSus++;
     nPend = nPend + 1 == kPend ? 0 : nPend + 1;
     qpar ^= 1;
     q = qn;
@@ -756,34 +716,6 @@ __device__ __forceinline__ void sweep_body(EvalArgs a, bool copyTable) {
   if constexpr (kDefer) __syncthreads();                       // the last questions' records, written by other waves
   bool *allReported = reinterpret_cast<bool *>(redW);         // (the W exchange buffer is free now)
   if (wave == 0) flush_pending(a, pend, nPend, lane, bestLds[lane]);
-  if constexpr (kPoleShape) if (nSus > 0) {
-    // ---- this workgroup's questions with a row at the pole of the lack term: their near-1 elements the reference's way
-    // (LDS that is free by now: the prior row, or the mD landing row and -- contiguous behind it -- the deferred sums' dump: 1 + (K + 2) / 2
-    //  rows' worth, so that the rows of a question at the pole are summed side by side; red: the partials and the queue of records)
-    double *poleStage = PRLDS ? reinterpret_cast<double *>(prLds) : reinterpret_cast<double *>(mdRow);
-    int poleStageDoubles = PRLDS ? (int)ldT : NP * kThreads * 2 + (kDefer ? (int)(K + 2) * kThreads : 0);
-    const int poleRedDoubles = 2 * nPart * WPQ + kPend * recLen;
-    PoleArgs g{a.cube, a.prior, a.tgap, a.priority, a.poleScratch,
-               a.fs.hostPriority != nullptr && a.fs.sampleSubtasks > 0 ? a.fs.hostPriority : nullptr, a.fs.seqValue, K, a.T, ldT, a.qFirst, a.vCompTail};
-    if constexpr (FUSE) {
-      // (the new posterior is in this launch's registers until workgroup 0 stores it at the very end: the lanes' own pairs go to
-      //  the mD landing row, free by now)
-      double *stash = reinterpret_cast<double *>(mdRow);
-      poleStage = vdump;                                       // (the deferred sums' LDS: (K + 2) x 256 doubles for rows of up to 1024 targets)
-      poleStageDoubles = (int)(K + 2) * kThreads;
-      static_assert(!FUSE || DEFER, "the fused update's shapes defer their sums");
-      __syncthreads();
-#pragma unroll
-      for (int j = 0; j < NP; j++) {
-        const int p = tid + j * kThreads;
-        if (p < nPairs) { stash[2 * p] = pr[j].x; stash[2 * p + 1] = pr[j].y; }
-      }
-      g.prior = stash;
-    }
-    __syncthreads();                                           // (the suspects' sums are in memory, their first priorities stored)
-    pole_fix<SERVER>(g, susWords + 2, nSus, partAll, poleRedDoubles, poleStage, poleStageDoubles, bestLds);
-    __syncthreads();
-  }
   if (wave == 0) fused_select<SERVER>(a, bestLds[lane], lane, allReported);
   if constexpr (FUSE) {
     if (blockIdx.x == 0) {
@@ -803,8 +735,8 @@ __device__ __forceinline__ void sweep_body(EvalArgs a, bool copyTable) {
     // entry: the selector skips them by the bitmaps.
     if (blockIdx.x == 0) {
       __syncthreads();
-      const bool complete = *allReported;
-      if (SERVER ? wave == 0 : tid == 0) {
+      const bool complete = allReported[0], deferred = allReported[1];
+      if (!deferred && (SERVER ? wave == 0 : tid == 0)) {
         a.fs.out->priority = 0.0;
         a.fs.out->index = complete ? 0 : -3;
         if (a.fs.seq != nullptr) {
@@ -820,7 +752,8 @@ __device__ __forceinline__ void sweep_body(EvalArgs a, bool copyTable) {
       // ---- the reference's selector, by this workgroup, over what every workgroup has written (fused_select above made
       // sure they all have); the Log2Hot table's LDS holds the subtask totals
       __syncthreads();
-      const bool complete = *allReported;
+      const bool complete = allReported[0];
+      if (allReported[1]) return;                              // (deferred to the fix behind the sweep: fused_select)
       const SampledPick r = select_sampled_wg_lds<true>(a.priority, a.qgap, a.asked, a.qFirst, a.qLimit - a.qFirst,
                                                         a.fs.sampleSubtasks, a.fs.sampleRnd, tbl);
       if (tid == 0) {
@@ -996,12 +929,15 @@ __global__ __launch_bounds__(256) void eval_questions_f64_stream(EvalArgs a) {
   double *wkAll = redW + 2 * WPQ;
   double *partAll = wkAll + 2 * K;
   const int nPart = (int)(K + 2);
+  uint32_t *watchWords = reinterpret_cast<uint32_t *>(partAll + 2 * nPart * WPQ);   // by question parity: the rows that passed the pole watch
   const int tid = threadIdx.x, lane = tid % kWave, wave = tid / kWave;
   for (int i = tid; i < kLog2TableDoubles; i += kThreads) tbl[i] = gLog2Table[i];
+  if (tid < 2) watchWords[tid] = 0;
   __syncthreads();
   const int64_t qStride = (K + 1) * ldT;
   const int64_t nPairs = ldT >> 1;
   int phase = 0, qpar = 0;
+  const bool watch = a.poleList != nullptr && a.slots == nullptr;
   Best best{0.0, -1};
   for (int64_t q = a.qFirst + blockIdx.x; q < a.qLimit; q += gridDim.x) {
     if (bit_test(a.qgap, q) || bit_test(a.asked, q)) {
@@ -1014,7 +950,7 @@ __global__ __launch_bounds__(256) void eval_questions_f64_stream(EvalArgs a) {
     double *wk = wkAll + qpar * K;
     double *part = partAll + qpar * (nPart * WPQ);
     double accL = 0, hW = 0;
-    uint32_t hiUnused = 0;   // (the re-reading fallback keeps its own sums at the pole: rows beyond 16384 targets)
+    uint32_t poleRows = 0;
     for (int64_t k = 0; k < K; k++) {
       const double2 *rowA = reinterpret_cast<const double2 *>(qBase + k * ldT);
       double s0 = 0, c0 = 0, s1 = 0, c1 = 0;
@@ -1036,7 +972,8 @@ __global__ __launch_bounds__(256) void eval_questions_f64_stream(EvalArgs a) {
           s1 = t;
         }
       }
-      double Wk = wave_sum((s0 - c0) + (s1 - c1));
+      const double sLane = (s0 - c0) + (s1 - c1);
+      double Wk = wave_sum(sLane);
       {
         double *buf = redW + phase * WPQ;
         if (lane == 0) buf[wave] = Wk;
@@ -1044,6 +981,8 @@ __global__ __launch_bounds__(256) void eval_questions_f64_stream(EvalArgs a) {
         Wk = row_sum<WPQ>(buf[lane % WPQ]);
         phase ^= 1;
       }
+      // the pole watch (see sweep_body): a lane that holds nearly all of W_k
+      if (watch && __any(sLane >= Wk * kNearOneShare && sLane > 0.0)) poleRows |= 1u << (k < 31 ? (int)k : 31);
       const double invWk = div_nr(1.0, Wk);
       double v = 0;
       for (int64_t p = tid; p < nPairs; p += kThreads) {
@@ -1056,7 +995,7 @@ __global__ __launch_bounds__(256) void eval_questions_f64_stream(EvalArgs a) {
         pv.y = g1 ? 0.0 : pv.y;
         lh.x = (av.x * id.x) * pv.x;
         lh.y = (av.y * id.y) * pv.y;
-        pass2_pair(lh, id, pv, invWk, tbl, hW, v, accL, hiUnused);
+        pass2_pair(lh, id, pv, invWk, tbl, hW, v, accL);
       }
       v = wave_sum(v);
       if (lane == 0) {
@@ -1069,6 +1008,7 @@ __global__ __launch_bounds__(256) void eval_questions_f64_stream(EvalArgs a) {
     if (lane == 0) {
       part[K * WPQ + wave] = hW;
       part[(K + 1) * WPQ + wave] = accL;
+      if (poleRows != 0) atomicOr(&watchWords[qpar], poleRows);
     }
     __syncthreads();
     if (tid == 0) {
@@ -1080,6 +1020,15 @@ __global__ __launch_bounds__(256) void eval_questions_f64_stream(EvalArgs a) {
       const double pri = eval_epilogue(wk, -part[K], part, K, part[K + 1], a.vCompTail);
       store_priority(a.priority + (q - a.qFirst), pri);
       best_offer(best, pri, q - a.qFirst);
+      watchWords[qpar ^ 1] = 0;                                // (set again only behind the next question's barriers)
+      if (watch && watchWords[qpar] != 0) {
+        // the question's sums as they are, for the fix behind the sweep (pole_kernels.hip)
+        double *ps = a.poleScratch + (q - a.qFirst) * (2 * K + 2);
+        for (int r = 0; r < K; r++) { ps[r] = wk[r]; ps[K + r] = part[r]; }
+        ps[2 * K] = part[K];
+        ps[2 * K + 1] = part[K + 1];
+        pole_list_append(a.poleList, (uint32_t)(q - a.qFirst), K <= 31 ? watchWords[qpar] : 0u, 0u);
+      }
     }
     qpar ^= 1;
   }
@@ -1163,7 +1112,6 @@ __global__ __launch_bounds__(256) void batch_rerank_kernel(const E *__restrict__
   const int64_t nPairs = ldT >> 1;
   int phase = 0;
   double accL = 0, hW = 0;
-  uint32_t hiUnused = 0;   // (Float engines: the fp32 tolerance covers what the summation order moves)
   for (int64_t k = 0; k < K; k++) {
     const E *rowA = qBase + k * ldT;
     double s0 = 0, c0 = 0, s1 = 0, c1 = 0;
@@ -1193,7 +1141,7 @@ __global__ __launch_bounds__(256) void batch_rerank_kernel(const E *__restrict__
       pv.y = g1 ? 0.0 : prior[2 * p + 1];
       lh.x = ((double)rowA[2 * p] * id.x) * pv.x;
       lh.y = ((double)rowA[2 * p + 1] * id.y) * pv.y;
-      pass2_pair(lh, id, pv, invWk, tbl, hW, v, accL, hiUnused);
+      pass2_pair(lh, id, pv, invWk, tbl, hW, v, accL);
     }
     v = wave_sum(v);
     if (lane == 0) {
@@ -1333,15 +1281,31 @@ constexpr size_t eval_base_lds_bytes(int64_t K, int64_t ldT) {
                : eval_md_row_offset_bytes(WPQ, K) + (size_t)NP * WPQ * kWave * 16;
 }
 
+// The fix behind a watching single-quiz sweep (pole_kernels.hip): the questions in the launch's suspect list, their sums in
+// poleScratch as the sweep left them -- W_k [K] | W_k sqrt(V_k) [K] | sum l log2 p | lack sum.
+hipError_t launch_pole_fixup(const EvalArgs &args, hipStream_t stream) {
+  PoleFix f{};
+  f.cube = args.cube; f.tgap = args.tgap; f.qgap = args.qgap; f.asked = args.asked; f.prior = args.prior;
+  f.list = args.poleList; f.sums = args.poleScratch; f.sumsStride = 2 * args.K + 2;
+  f.wOff = 0; f.vOff = (int)args.K; f.hOff = (int)(2 * args.K); f.lOff = (int)(2 * args.K + 1); f.secondIsWV = 1;
+  f.priority = args.priority;
+  f.K = args.K; f.T = args.T; f.ldT = args.ldT; f.qFirst = args.qFirst; f.nQ = args.qLimit - args.qFirst;
+  f.capacity = f.nQ;
+  f.vCompTail = args.vCompTail;
+  f.fs = args.fs;
+  if (args.fs.scratch != nullptr && args.fs.sampleSubtasks > 0 && args.fs.hostPriority != nullptr) { f.hostPriority = args.fs.hostPriority; f.hostTag = args.fs.seqValue; }
+  return LaunchPoleFixup(f, stream);
+}
+
 template <int WPQ, int NP, bool PRLDS, bool DEFER, bool POLE = false>
 hipError_t launch_reg_form(const EvalArgs &args, int64_t nQ, int nBatch, hipStream_t stream) {
-  // the variant with the pole watch (sweep_body: kPoleShape) where the shape has one and the engine asked for it
-  if constexpr (!POLE && 128 * WPQ * NP <= 4096 && !(NP == 4 && !DEFER)) {
-    if (args.poleScratch != nullptr) return launch_reg_form<WPQ, NP, PRLDS, DEFER, true>(args, nQ, nBatch, stream);
+  // the variant with the pole watch where the engine asked for it (single-quiz launches)
+  if constexpr (!POLE) {
+    if (args.poleList != nullptr) return launch_reg_form<WPQ, NP, PRLDS, DEFER, true>(args, nQ, nBatch, stream);
   }
   const size_t shmem = eval_base_lds_bytes<WPQ, NP, PRLDS>(args.K, args.ldT) + (DEFER ? eval_deferred_bytes(WPQ, NP, args.K, PRLDS) : 0);
   auto kern = [] {
-    if constexpr (NP == 4 && WPQ == 4 && DEFER) return eval_questions_f64_occ3<WPQ, NP, PRLDS, DEFER, POLE>;   // (5 and 6 pairs: slower with the spills)
+    if constexpr (NP == 4 && WPQ == 4 && (DEFER || POLE)) return eval_questions_f64_occ3<WPQ, NP, PRLDS, DEFER, POLE>;   // (5 and 6 pairs: slower with the spills)
     else return eval_questions_f64<WPQ, NP, PRLDS, DEFER, POLE>;
   }();
   // attribute and occupancy are properties of (kernel, LDS size, device): asked once per device, not on every launch
@@ -1369,7 +1333,9 @@ hipError_t launch_reg_form(const EvalArgs &args, int64_t nQ, int nBatch, hipStre
   if (args.fs.scratch != nullptr && resGrid > maxRecords) resGrid = maxRecords;  // one winner record per workgroup
   if (args.maxGrid > 0 && resGrid > args.maxGrid) resGrid = args.maxGrid;   // (test hook: KbView::maxGrid)
   hipLaunchKernelGGL(kern, dim3((unsigned)resGrid, (unsigned)nBatch), dim3(WPQ * 64), shmem, stream, args);
-  return hipGetLastError();
+  const hipError_t le = hipGetLastError();
+  if constexpr (POLE) { if (le == hipSuccess) return launch_pole_fixup(args, stream); }
+  return le;
 }
 
 template <int WPQ, int NP, bool PRLDS>
@@ -1425,7 +1391,9 @@ hipError_t launch_variant(const EvalArgs &args, int64_t ldT, int variant, int nB
       if (args.maxGrid > 0 && maxBlocks > args.maxGrid) maxBlocks = args.maxGrid;
       const unsigned grid = (unsigned)(nQ < maxBlocks ? nQ : maxBlocks);
       hipLaunchKernelGGL(eval_questions_f64_stream, dim3(grid, (unsigned)nBatch), dim3(256), shmem, stream, args);
-      return hipGetLastError();
+      const hipError_t le = hipGetLastError();
+      if (le == hipSuccess && args.poleList != nullptr && args.slots == nullptr) return launch_pole_fixup(args, stream);
+      return le;
     }
     default: return hipErrorInvalidValue;
   }
@@ -1449,6 +1417,7 @@ static EvalArgs make_args(const KbView &kb, int64_t qFirst, int64_t qLimit) {
   args.T = kb.T;
   args.ldT = kb.ldT;
   args.poleScratch = kb.poleScratch;
+  args.poleList = kb.poleScratch != nullptr ? kb.poleList : nullptr;
   args.qFirst = qFirst;
   args.qLimit = qLimit;
   const double nT = (double)(kb.nValidTargets + 1);  // PqaCore/CEEvalQsSubtaskConsider.cpp:191
@@ -1499,7 +1468,7 @@ hipError_t LaunchEvalQuestionsWithUpdate(const KbView &kb, double *prior, uint32
   args.updTop = TopRequest{reinterpret_cast<TopOut *>(topOut), topN, topFlag, topFlagValue, topOut ? topCount : 0};
   constexpr int WPQ = 4, NP = 2;
   const size_t shmem = eval_base_lds_bytes<WPQ, NP, false>(args.K, args.ldT) + eval_deferred_bytes(WPQ, NP, args.K, false);
-  const bool pole = args.poleScratch != nullptr;
+  const bool pole = args.poleList != nullptr;
   auto kern = pole ? eval_questions_f64_upd<WPQ, NP, true, true> : eval_questions_f64_upd<WPQ, NP, true, false>;
   static LaunchCache cache;
   const int dev = LaunchCache::Device();
@@ -1519,7 +1488,9 @@ hipError_t LaunchEvalQuestionsWithUpdate(const KbView &kb, double *prior, uint32
   int64_t grid = kb.Q < resident ? kb.Q : resident;
   if (grid > kFusedMaxGrid) grid = kFusedMaxGrid;
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(WPQ * 64), shmem, stream, args);
-  return hipGetLastError();
+  const hipError_t le = hipGetLastError();
+  if (pole && le == hipSuccess) return launch_pole_fixup(args, stream);
+  return le;
 }
 
 hipError_t LaunchEvalQuestionsBatch(const KbView &kb, const QuizSlot *slots, int nSlots, int64_t qFirst, int64_t qLimit,
@@ -1530,6 +1501,7 @@ hipError_t LaunchEvalQuestionsBatch(const KbView &kb, const QuizSlot *slots, int
   args.fs = fused;
   args.slots = slots;
   args.poleScratch = nullptr;   // (one buffer per engine, not per quiz of a batch: the quizzes of a grid.y launch keep the sweep's own sums at the pole)
+  args.poleList = nullptr;
   return launch_variant(args, kb.ldT, variant, nSlots, stream);
 }
 
@@ -1588,6 +1560,8 @@ hipError_t LaunchEvalServer(const KbView &kb, int64_t qFirst, int64_t qLimit, do
   if (qLimit <= qFirst || scratch == nullptr || mailbox == nullptr || requestLine == nullptr || ctl == nullptr)
     return hipErrorInvalidValue;
   EvalArgs args = make_args(kb, qFirst, qLimit);
+  args.poleScratch = nullptr;   // (nothing can be launched behind a step of the resident kernel: it keeps the sweep's own sums)
+  args.poleList = nullptr;
   args.priority = priority;
   args.fs.scratch = scratch;
   args.fs.hostPriority = hostPriority;

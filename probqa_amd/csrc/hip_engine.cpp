@@ -177,6 +177,7 @@ Error HipEngine::Init(const CiEngineDefinition &def, const CiHipShard *shard) {
       tblErr = UploadLog2Table(tbl.data());
       if (tblErr == hipSuccess) tblErr = UploadLog2TableBatch(tbl.data());
       if (tblErr == hipSuccess) tblErr = UploadLog2TableCluster(tbl.data());
+      if (tblErr == hipSuccess) tblErr = UploadLog2TablePole(tbl.data());
     });
     HIP_TRY(tblErr);
   }
@@ -187,7 +188,9 @@ Error HipEngine::Init(const CiEngineDefinition &def, const CiHipShard *shard) {
   HIP_TRY(hipMalloc(&_dVB, (size_t)_ldT * sizeof(double)));
   HIP_TRY(hipMalloc(&_dPriority, (size_t)_Q * sizeof(double)));
   HIP_TRY(hipMalloc(&_dRunLength, (size_t)_Q * sizeof(double)));
-  HIP_TRY(hipMalloc(&_dPoleScratch, (size_t)_Q * (size_t)(2 * _K + 2) * sizeof(double)));
+  // the sums of the questions that pass a sweep's pole watch, and behind them their list (pole_kernels.hip; every launch leaves it empty)
+  HIP_TRY(hipMalloc(&_dPoleScratch, PoleScratchBytes(_Q)));
+  HIP_TRY(hipMemset(_dPoleScratch, 0, PoleScratchBytes(_Q)));
   HIP_TRY(hipMalloc(&_dExps, (size_t)_ldT * sizeof(int64_t)));
   HIP_TRY(hipMalloc(&_dStatus, 2 * sizeof(int64_t)));
   HIP_TRY(hipMalloc(&_dNOut, sizeof(int64_t)));
@@ -269,7 +272,7 @@ HipEngine::~HipEngine() {
   hipFree(_dCube); hipFree(_dVB); hipFree(_dPriority); hipFree(_dRunLength); hipFree(_dPoleScratch); hipFree(_dExps); hipFree(_dStatus);
   hipFree(_dNOut); hipFree(_dSel); hipFree(_dSelScratch); hipFree(_dPriorScratch); hipFree(_dClusterScratch);
   for (BatchCtx &c : _ctx) {
-    hipFree(c.dSlots); hipFree(c.dScratch); hipFree(c.dPriority); hipFree(c.dPT); hipFree(c.dAcc); hipFree(c.dRecs); hipFree(c.dPriT); hipFree(c.dRerank);
+    hipFree(c.dSlots); hipFree(c.dScratch); hipFree(c.dPriority); hipFree(c.dPT); hipFree(c.dAcc); hipFree(c.dRecs); hipFree(c.dPriT); hipFree(c.dRerank); hipFree(c.dPole);
     if (c.hPri) hipHostFree(c.hPri);
     if (c.event) hipEventDestroy(c.event);
     if (c.h) hipHostFree(c.h);
@@ -303,6 +306,7 @@ KbView HipEngine::View() const {
   v.maxGrid = (int)_optEvalMaxGrid;
   v.clusterForm = (int)_optClusterForm;
   v.poleScratch = _optPoleFix ? _dPoleScratch : nullptr;
+  v.poleList = _optPoleFix ? reinterpret_cast<PoleHeader *>(_dPoleScratch + (size_t)_capQ * (size_t)(2 * _K + 2)) : nullptr;
   return v;
 }
 

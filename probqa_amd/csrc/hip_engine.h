@@ -361,6 +361,7 @@ class HipEngine : public IEngine {
   char *CubeAt(int64_t q, int64_t row = 0) const { return _dCube + ((size_t)(q * (_K + 1) + row) * (size_t)_ldT) * (size_t)_elem; }
   static int64_t RoundLdT(int64_t T, int elem) { const int64_t m = 128 / elem; return ((T + m - 1) / m) * m; }   // rows start on 128-byte lines
   double *_dVB = nullptr, *_dPriority = nullptr, *_dRunLength = nullptr, *_dPoleScratch = nullptr;
+  size_t PoleScratchBytes(int64_t capQ) const { return (size_t)capQ * (size_t)(2 * _K + 2) * sizeof(double) + PoleListBytes(capQ); }
   uint32_t *_dTGap = nullptr, *_dQGap = nullptr;
   int64_t *_dExps = nullptr, *_dAqs = nullptr, *_dStatus = nullptr, *_dNOut = nullptr;
   int64_t _aqCapacity = 0;
@@ -534,6 +535,8 @@ class HipEngine : public IEngine {
     void *dPT = nullptr; double *dAcc = nullptr; BatchRecord *dRecs = nullptr; double *dPriT = nullptr;
     size_t ptBytes = 0, accBytes = 0, recBytes = 0, priTBytes = 0, rerankBytes = 0;
     void *dRerank = nullptr;             // Float engines: the candidates of the fp64 re-rank and their priorities
+    void *dPole = nullptr;               // Double engines: the batched sweeps' pole scratch (BatchPlan::pole)
+    size_t poleBytes = 0;
     int lastBp = 0;
     double *hPri = nullptr;              // pinned: the batch's priority vectors for the host-side selector -- copied there behind the
     size_t hPriDoubles = 0;              // row-sharing sweep, or written there by the grid.y = quiz sweep itself as {priority, launch tag} records

@@ -449,7 +449,8 @@ Error HipEngine::ReallocKB(int64_t newQ, int64_t newT) {
     if (newCap != _capQ) {
       HIP_TRY(priority.Alloc((size_t)newCap * sizeof(double)));
       HIP_TRY(runLength.Alloc((size_t)newCap * sizeof(double)));
-      HIP_TRY(poleScratch.Alloc((size_t)newCap * (size_t)(2 * _K + 2) * sizeof(double)));
+      HIP_TRY(poleScratch.Alloc(PoleScratchBytes(newCap)));
+      HIP_TRY(hipMemsetAsync(poleScratch.p, 0, PoleScratchBytes(newCap), _stream));
     }
     // old rows keep their content; new padding columns get A = 0, D = 1 from the fill of new questions / a plain fill
     HIP_TRY(LaunchFillFresh(cube.p, _elem, vB.p, _K, newCap, 0, newLdT, 0.0, _stream));  // T = 0: every column is "padding"

@@ -430,14 +430,29 @@ Error HipEngine::BatchSweep(BatchCtx &c, int64_t n, const int64_t *pQuizzes, std
     if (e == hipSuccess) have = need;
     return e;
   };
+  // the batched sweeps' pole scratch (pole_kernels.hip): grown with the batch, its head cleared once
+  auto growPole = [&](BatchPlan &plan) -> hipError_t {
+    plan.pole = nullptr;
+    if (plan.poleBytes == 0) return hipSuccess;
+    if (plan.poleBytes > c.poleBytes) {
+      const hipError_t e = grow(&c.dPole, c.poleBytes, plan.poleBytes);
+      if (e != hipSuccess) return e;
+      const hipError_t me = hipMemsetAsync(c.dPole, 0, kBatchPoleClear, _stream);
+      if (me != hipSuccess) return me;
+    }
+    plan.pole = c.dPole;
+    return hipSuccess;
+  };
   if (mid) {
     const KbView kb = View();
     BatchPlan plan{};
     HIP_TRY(LaunchEvalMidBatch(kb, c.dSlots, (int)n, &plan, nullptr, nullptr, nullptr, 0, tag, true, _stream));
     HIP_TRY(grow(&c.dPT, c.ptBytes, plan.ptBytes));
     HIP_TRY(grow((void **)&c.dRecs, c.recBytes, plan.recBytes));
-    if (wantPriorities) HIP_TRY(grow((void **)&c.dPriT, c.priTBytes, (size_t)_Q * (size_t)plan.Bp * sizeof(double)));
-    HIP_TRY(LaunchEvalMidBatch(kb, c.dSlots, (int)n, &plan, c.dPT, c.dRecs, wantPriorities ? c.dPriT : nullptr, 0, tag, false, _stream));
+    HIP_TRY(growPole(plan));
+    const bool matrix = wantPriorities || plan.poleBytes > 0;   // (the fix corrects the priority matrix, the pick reads it)
+    if (matrix) HIP_TRY(grow((void **)&c.dPriT, c.priTBytes, (size_t)_Q * (size_t)plan.Bp * sizeof(double)));
+    HIP_TRY(LaunchEvalMidBatch(kb, c.dSlots, (int)n, &plan, c.dPT, c.dRecs, matrix ? c.dPriT : nullptr, 0, tag, false, _stream));
     c.lastBp = plan.Bp;
     return Error();
   }
@@ -460,9 +475,11 @@ Error HipEngine::BatchSweep(BatchCtx &c, int64_t n, const int64_t *pQuizzes, std
   HIP_TRY(grow((void **)&c.dRecs, c.recBytes, plan.recBytes));
   // Float engines: the fp32 sweep nominates every quiz's best questions, fp64 decides among them (option "rerank", default on)
   const bool rerank = _elem == 4 && _optRerank != 0;
-  if (wantPriorities || rerank) HIP_TRY(grow((void **)&c.dPriT, c.priTBytes, (size_t)_Q * (size_t)plan.Bp * sizeof(double)));
+  HIP_TRY(growPole(plan));
+  const bool matrix = wantPriorities || rerank || plan.poleBytes > 0;   // (the fix corrects the priority matrix, the pick reads it)
+  if (matrix) HIP_TRY(grow((void **)&c.dPriT, c.priTBytes, (size_t)_Q * (size_t)plan.Bp * sizeof(double)));
   if (rerank) HIP_TRY(grow(&c.dRerank, c.rerankBytes, BatchRerankScratchBytes()));
-  HIP_TRY(LaunchEvalBatch(kb, c.dSlots, (int)n, &plan, c.dPT, c.dAcc, c.dRecs, (wantPriorities || rerank) ? c.dPriT : nullptr, 0, tag,
+  HIP_TRY(LaunchEvalBatch(kb, c.dSlots, (int)n, &plan, c.dPT, c.dAcc, c.dRecs, matrix ? c.dPriT : nullptr, 0, tag,
                           false, _stream, rerank));
   if (rerank) HIP_TRY(LaunchBatchRerank(kb, c.dSlots, (int)n, plan.Bp, c.dPriT, c.dRerank, 0, tag, _stream));
   c.lastBp = plan.Bp;

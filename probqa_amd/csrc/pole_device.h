@@ -5,10 +5,24 @@
 #pragma once
 #include "pqa_device.h"
 #include "eval_device.h"
+#include "pqa_kernels.h"
 
 namespace pqa {
 
-constexpr uint32_t kNearOneHi = 0x3FEFFFF0u;   // high word of 1 - 2^-17
+// A row is redone in the reference's order when its largest posterior element is at least 1 - 2^-10.  Two mechanisms set the bar.
+// The lack term's pole: the summation order of W_k moves the priority by ~1e-16 / (1 - p): 1e-9 at p = 1 - 1e-7.  The velocity
+// term reaches further out: (p - prior)^2 of a target that holds nearly all the mass BEFORE and AFTER the answer is the square of
+// a difference of two numbers next to 1 -- |p - prior| ~ (1 - p) x (how much the answer tells this target from the rest) -- and
+// p's last place (1.1e-16) is 1e-8 of it at p = 1 - 4e-5, where the likeliest answer's velocity is a sixth of the question's:
+// 1.3e-9 of the priority (tests/test_gpu_late.py: the first cases that found it).  At 1 - 2^-10 both are below 1e-11.
+constexpr uint32_t kNearOneHi = 0x3FEFF800u;   // high word of 1 - 2^-10
+
+// a sweep's entry for a question that passed its watch (pqa_kernels.h: PoleHeader; one thread)
+__device__ __forceinline__ uint32_t pole_list_append(PoleHeader *list, uint32_t q, uint32_t rowMask, uint32_t b) {
+  const uint32_t at = atomicAdd(&list->count, 1u);
+  reinterpret_cast<PoleEntry *>(list + 1)[at] = PoleEntry{q, rowMask, b, 0u};
+  return at;
+}
 
 // SRVectMath.h:87-135, operation for operation (oracle: orc_log2hot).  tbl: the Log2Hot table in global memory ({log2 midpoint,
 // 1 / (2 midpoint)} per bucket), entry0: its entry 0 as the REFERENCE has it (SRVectMath.cpp:31,42 -- the table's own is re-seated

@@ -59,8 +59,21 @@ struct KbView {
                           // every workgroup stream dozens of questions; 0 = no cap
   int clusterForm;        // long rows (cluster_kernels.hip): 0 = default, 1 = question by question, 2 = pass 1 a question ahead (option cluster_form)
   double *poleScratch;    // Q x (2 K + 2) doubles (device): the sums of questions with a row at the pole of the lack term, between the
-                          // sweep and its fix (eval_kernels.hip: pole_fix); may be null (then such questions keep the sweep's own sums)
+                          // sweep and the fix launched behind it (pole_kernels.hip); may be null (then such questions keep the sweep's own sums)
+  struct PoleHeader *poleList;   // ... and the list of those questions: PoleListBytes(Q) bytes, zeroed once (every launch leaves it empty)
 };
+
+// ---- questions with a row at the pole of the lack term: listed by the sweeps, redone in the reference's order behind them
+// (pole_kernels.hip).  A list is a header and `capacity` entries; a sweep appends at most one entry per question (and quiz).
+struct PoleHeader { uint32_t count, arrived, pad[2]; };
+struct PoleEntry {
+  uint32_t q;             // position in the priority vector (question qFirst + q of the cube)
+  uint32_t rowMask;       // the answer rows that passed the sweep's watch, a bit each (0: not known -- every row is redone)
+  uint32_t b;             // the quiz (batched sweeps; 0 otherwise)
+  uint32_t pad;
+};
+size_t PoleListBytes(int64_t capacity);
+hipError_t UploadLog2TablePole(const double *hostTable);
 
 struct SelectResult {     // 16 bytes, written by the select kernels
   double priority;        // argmax: winning priority; sampled: grand total of priorities
@@ -117,6 +130,32 @@ struct QuizSlot {
 hipError_t LaunchEvalQuestions(const KbView &kb, const double *prior, const uint32_t *asked, int64_t qFirst,
                                int64_t qLimit, double *priority, int variant, const FusedSelect *fused,
                                hipStream_t stream);
+// The fix behind a watching sweep.  A record of sums is `sumsStride` doubles: W_k [K] at wOff, W_k sqrt(V_k) (secondIsWV) or V_k [K]
+// at vOff, sum l log2 p at hOff, the lack sum at lOff; record of entry e: e itself (bySlot) or its question.  priority (or priorityT
+// [q][Bp], or the quizzes' own vectors: slots) receives the corrected priorities -- all null: the records are corrected in place
+// and the caller's epilogue follows.  fs: the sweep's own fused selection; when the list is not empty the sweep's finisher has left
+// its publication to this launch.
+struct PoleFix {
+  const double *cube;
+  const uint32_t *tgap, *qgap, *asked;
+  const double *prior;            // single quiz
+  const QuizSlot *slots;          // batched sweeps: entry.b selects the quiz
+  PoleHeader *list;
+  uint32_t *maskDense;            // optional [nQ]: the rows per question where several workgroups watch one question (cleared here)
+  uint32_t *dirty;                // optional [quizzes]: set to 1 for every quiz with a corrected priority (batched sweeps: the pick reads it)
+  double *sums;
+  int64_t sumsStride;
+  int bySlot, wOff, vOff, hOff, lOff, secondIsWV;
+  double *priority, *priorityT;
+  int Bp;
+  TaggedPriority *hostPriority;   // optional: the corrected priorities also go to the host as {priority, hostTag} records
+  uint64_t hostTag;
+  int64_t K, T, ldT, qFirst, nQ, capacity;
+  double vCompTail;
+  FusedSelect fs;
+  int rows;                       // (set by the launcher)
+};
+hipError_t LaunchPoleFixup(const PoleFix &fix, hipStream_t stream);
 // The same sweep for nSlots quizzes in one launch (grid.y = quiz): `slots` is a DEVICE array; fused->scratch holds
 // nSlots * fused->scratchStride records; fused->out / seq are ignored (each slot has its own).
 hipError_t LaunchEvalQuestionsBatch(const KbView &kb, const QuizSlot *slots, int nSlots, int64_t qFirst, int64_t qLimit,
@@ -132,7 +171,11 @@ struct BatchPlan {
   int questionGroups;     // in: question groups side by side in a workgroup of a small batch (0 = automatic; see eval_batch_kernel)
   int grid, Bp;           // out: workgroups of the sweep; quizzes rounded up to whole waves
   size_t ptBytes, accBytes, recBytes;   // out: sizes of the scratch buffers PT / acc / recs the caller provides
+  size_t poleBytes;       // out: ... and of `pole` (0: the sweep does not watch for rows at the pole of the lack term -- pole_kernels.hip)
+  void *pole;             // in: poleBytes of device memory whose first kBatchPoleClear bytes were cleared once after allocation; the
+                          //     caller then also provides priorityT (the fix corrects the priority matrix, the pick reads it)
 };
+constexpr size_t kBatchPoleClear = 1024 + 16;
 // queryOnly: only fill `plan`.  Otherwise: transposed masked priors -> PT, the sweep, and every quiz's winner {priority,
 // local index + outBase} to its slot's `out`, then flagValue to its `seq` (host-coherent).  priorityT (optional):
 // [Q][plan->Bp] priorities, quiz-minor.

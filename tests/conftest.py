@@ -12,12 +12,19 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
 def pytest_addoption(parser):
     parser.addoption("--soak", type=int, default=0,
                      help="tests/test_gpu_soak.py: run N more random cases (and N // 50 more concurrency rounds) than the suite's own few")
+    parser.addoption("--late", type=int, default=0, help="tests/test_gpu_late.py: run N more late-quiz-state cases than the suite's own")
+    parser.addoption("--late-first", type=int, default=1000, help="first seed of the --late range")
     parser.addoption("--soak-first", type=int, default=120, help="first seed of the --soak range (the suite's fixed seeds end below 120)")
 
 
 @pytest.fixture(scope="session")
 def soak(request):
     return request.config.getoption("--soak"), request.config.getoption("--soak-first")
+
+
+@pytest.fixture(scope="session")
+def late(request):
+    return request.config.getoption("--late"), request.config.getoption("--late-first")
 
 
 def pytest_configure(config):

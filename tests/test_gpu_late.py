@@ -1,0 +1,182 @@
+"""Late quiz states on every kernel form: a posterior element at 1 - 1e-4 ... 1 - 1e-16 (and exactly 1), where the reference's
+lack term -sum invD^2 / log2(p) (PqaCore/CEEvalQsSubtaskConsider.cpp:117) has its pole and the ORDER in which W_k was summed
+(SRPlatform/Interface/SRAccumVectDbl256.h:40-46, :62-92) decides the ninth digit of the priority -- or, a few answers later, its
+first.  That is where real quizzes end (a handful of consistent answers), and the random cases of tests/test_gpu_fuzz.py hardly
+ever get there: their answers are random, their rows short.
+
+The cases here are dichotomy quizzes as the reference's own DichotomyTest plays them (PqaCoreTests/DichotomyTest.cpp:50-64): a
+window of the synthetic cube with one question per target around a hidden target (probqa_amd/synth.py with q_total = T), answered
+consistently 4 - 8 questions deep -- "it is the target" / "just below" / "just above" -- so that the posterior collapses onto the
+hidden target by a factor of a few hundred per answer.  Legs: every register shape for rows beyond 4096 targets (the defaults by
+row length and the forced ones), the short-row shapes with one or two workgroups streaming more questions than the in-kernel fix
+lists, the streaming fallback, both cluster forms (rows of 20000 / 50000 targets), the (quiz, chunk) and row-sharing batched
+sweeps, the quiz-per-grid.y launches and the resident sweep (picks).  Every step of every case is held to 1e-9 against the oracle;
+the posterior stays bit-identical; the argmax and the reference's sampled selector pick the oracle's questions.
+
+`pytest -m gpu tests/test_gpu_late.py --late N [--late-first SEED]` runs N more cases than the suite's own."""
+import numpy as np
+import pytest
+
+import cases
+import test_gpu_batch as tb
+from probqa_amd import synth
+from test_gpu_parity import run_script
+
+pytestmark = pytest.mark.gpu
+
+
+class LateCase(cases.Case):
+    """A window of Q questions of the T-question dichotomy cube around `hidden` (question q asks about target q_offset + q)."""
+
+    def __init__(self, name, K, Q, T, seed, hidden, q_offset, **kw):
+        super().__init__(name, K, Q, T, seed, **kw)
+        self.hidden, self.q_offset = hidden, q_offset
+
+    def kb(self):
+        return synth.synthetic_kb(self.K, self.Q, self.T, self.init, self.n_train, self.noise, self.seed,
+                                  q_offset=self.q_offset, q_total=self.T)
+
+
+# (leg, row lengths, engine options)
+REG_DEFAULT = [4608, 5120, 6144, 7168, 8192, 9216, 10000, 10240, 16384, 12000]
+REG_FORCED = [(8000, 5), (10000, 6), (5000, 9), (10000, 11), (10000, 12), (5000, 21), (3000, 22), (4000, 23), (4500, 24), (5000, 20),
+              (900, 1), (1000, 8), (2000, 3), (4096, 4)]
+LEGS = ["reg", "reg", "forced", "stream", "cluster", "overflow", "short", "mid", "rowshare", "gridy", "server", "reg"]
+
+
+def late_case(i):
+    rng = np.random.default_rng(770000 + i)
+    leg = LEGS[i % len(LEGS)]
+    options, K = [], 5
+    if leg == "reg":
+        T = int(rng.choice(REG_DEFAULT)) if rng.random() < 0.7 else int(rng.integers(4097, 16385))
+        Q = int(rng.integers(12, 40))
+        if rng.random() < 0.3:
+            options.append(("eval_max_grid", int(rng.integers(1, 4))))
+    elif leg == "forced":
+        T, v = REG_FORCED[int(rng.integers(len(REG_FORCED)))]
+        T -= int(rng.integers(0, 40))
+        Q = int(rng.integers(12, 40))
+        options.append(("eval_variant", v))
+        if rng.random() < 0.3:
+            options.append(("eval_max_grid", 2))
+    elif leg == "stream":
+        T, Q = int(rng.integers(300, 9000)), int(rng.integers(8, 30))
+        options.append(("eval_variant", 99))
+    elif leg == "cluster":
+        T, Q = int(rng.choice([20000, 50000, 17000, 33000])), int(rng.integers(8, 20))
+        options.append(("cluster_form", int(rng.choice([1, 2]))))
+    elif leg == "overflow":   # more suspects per workgroup than the in-kernel fix lists (kSusMax = 62)
+        T, Q = int(rng.integers(64, 1500)), int(rng.integers(70, 200))
+        options.append(("eval_max_grid", 1))
+    elif leg == "short":
+        T, Q = int(rng.integers(40, 4097)), int(rng.integers(10, 60))
+    elif leg == "mid":
+        T, Q = int(rng.integers(100, 2400)), int(rng.integers(10, 40))
+    elif leg == "rowshare":
+        T, Q = int(rng.choice([4608, 6000, 10000, 2000, 700])), int(rng.integers(8, 24))
+    elif leg == "gridy":
+        T, Q = int(rng.choice([1000, 3000, 5000, 10000])), int(rng.integers(8, 24))
+    else:   # server
+        T, Q = int(rng.integers(100, 1025)), int(rng.integers(10, 60))
+        options.append(("server", 1))
+    if leg in ("reg", "forced", "stream", "short", "overflow", "rowshare") and rng.random() < 0.35:
+        K = int(rng.integers(3, 9))
+    Q = min(Q, T)
+    hidden = int(rng.integers(Q, T - Q)) if T > 3 * Q else T // 2
+    q_offset = min(max(hidden - Q // 2, 0), T - Q)
+    depth = int(rng.integers(4, 9))
+    # the dichotomy's answers around the hidden target: the question about it, then alternately the ones just above / just below
+    order = [0] + [s * d for d in range(1, Q) for s in (1, -1)]
+    answers = []
+    for off in order:
+        x = hidden + off
+        q = x - q_offset
+        if 0 <= q < Q and len(answers) < depth:
+            answers.append((q, min(synth.dichotomy_answer(x, hidden, max(1, (32 * T) // 1000)), K - 1)))
+    if rng.random() < 0.5:
+        rng.shuffle(answers)
+    answers = [(int(q), int(a)) for q, a in answers]
+    n_tg = int(rng.integers(0, 6)) if rng.random() < 0.3 else 0
+    tgaps = sorted(int(t) for t in rng.choice([t for t in range(T) if t != hidden], n_tg, replace=False)) if n_tg else []
+    name = "late%04d_%s_%dx%dx%d" % (i, leg, Q, K, T)
+    case = LateCase(name, K, Q, T, seed=3000 + i, hidden=hidden, q_offset=q_offset, init=float(rng.choice([0.1, 0.5])),
+                    n_train=float(rng.choice([4.0, 8.0])), noise=float(rng.choice([0.1, 0.5])), tgaps=tgaps, answers=answers)
+    return leg, case, options
+
+
+def batched_states(case, factory, form, n_extra):
+    """One quiz per prefix of the answer script (plus copies) through a batched sweep; returns the worst step."""
+    eng, orc = case.make_engine(factory), case.make_oracle()
+    eng.set_option("batch_form", form)
+    eng.set_option("batch_min", 1)
+    quizzes, hists = [], []
+    n = len(case.answers) + 1 + n_extra
+    for j in range(n):
+        quiz = eng.start_quiz()
+        hist = case.answers[: j % (len(case.answers) + 1)]
+        for q, a in hist:
+            eng.set_active_question(quiz, q)
+            eng.record_answer(quiz, a)
+        quizzes.append(quiz)
+        hists.append(hist)
+    pri = eng.eval_priorities_batch(quizzes, case.Q) if form != 1 else None
+    picks = eng.next_question_argmax_batch(quizzes)
+    worst, seen = 0.0, {}
+    for j in range(n):
+        key = len(hists[j])
+        if key not in seen:
+            opri, opriors = tb.oracle_priorities(orc, hists[j])
+            seen[key] = (opri, opriors, orc.select_argmax(opri))
+        opri, opriors, want = seen[key]
+        assert np.array_equal(eng.get_priors(quizzes[j]), opriors), (case.name, j)
+        if pri is not None:
+            rel = tb.rel_vec(pri[j], opri)
+            worst = max(worst, float(rel.max()))
+            assert (rel < 1e-9).all(), (case.name, j, key, float(rel.max()), int(rel.argmax()))
+        top = np.sort(opri)[::-1]
+        margin = (top[0] - top[1]) / top[0] if len(top) > 1 and top[0] > 0 else 1.0
+        if want < 0:
+            assert picks[j] == -1
+        elif margin > 1e-8:
+            assert picks[j] == want, (case.name, j, key, picks[j], want, margin)
+    eng.close()
+    return worst
+
+
+def run_late_case(i, factory):
+    leg, case, options = late_case(i)
+    if leg == "mid":
+        return leg, case, batched_states(case, factory, 3, int(i % 23))
+    if leg == "rowshare":
+        return leg, case, batched_states(case, factory, 2, int(i % 70))
+    if leg == "gridy":
+        return leg, case, batched_states(case, factory, 1, int(i % 5))
+    return leg, case, max(run_script(case, factory, options))
+
+
+@pytest.mark.parametrize("i", range(60))
+def test_late_state(i, factory):
+    leg, case, worst = run_late_case(i, factory)
+    assert worst < 1e-9, (case.name, worst)
+
+
+def test_late_soak(factory, late):
+    """--late N further cases; prints the worst step per leg."""
+    n, first = late
+    if n <= 0:
+        pytest.skip("no --late N given")
+    worst, bad = {}, []
+    for i in range(first, first + n):
+        try:
+            leg, case, w = run_late_case(i, factory)
+            worst[leg] = max(worst.get(leg, 0.0), w)
+        except BaseException as ex:  # noqa: BLE001
+            if isinstance(ex, KeyboardInterrupt):
+                raise
+            leg, case, _ = late_case(i)
+            bad.append((i, case.name, repr(ex)[:240]))
+            print("FAIL", bad[-1])
+    print("late-state soak: %d cases from seed %d, worst relative deviation per leg: %s" % (
+        n, first, {k: "%.2e" % v for k, v in sorted(worst.items())}))
+    assert not bad, (len(bad), bad[:8])
