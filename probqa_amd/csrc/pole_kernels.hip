@@ -46,11 +46,13 @@ hipError_t UploadLog2TablePole(const double *hostTable) {
 
 namespace {
 
-constexpr int kFixThreads = 256;
-constexpr int kFixStagers = kFixThreads - kWave;   // waves 1 - 3
-constexpr int kFixChunk = 2 * kFixStagers;         // targets of a row per LDS chunk: one 16-byte pair per stager
-constexpr int kFixRows = 8;                        // rows of a question side by side (four chain lanes each, in wave 0)
-constexpr int kFixRed = 24;                        // doubles of reduction scratch per row
+#ifndef PQA_FIX_WAVES
+#define PQA_FIX_WAVES 4
+#endif
+constexpr int kFixThreads = 256;                   // four waves, each by itself
+constexpr int kFixChunk = 2 * kWave;               // targets of a row per LDS chunk: one 16-byte pair per lane
+constexpr int kFixRowStride = kFixChunk + 4;       // doubles between the rows of a chunk (the rows' chain lanes on different banks)
+constexpr int kFixRed = 12;                        // doubles of scratch per row
 
 // log2hot (pqa_device.h) with the table in global memory: the same operations on the same table entries, so the same bits -- what
 // pass 2 of the sweep took for an element.  (This kernel's LDS is the rows' chunks; one lane per row needs the function.)
@@ -80,79 +82,110 @@ __device__ __forceinline__ void best_merge(Best &b, double op, int64_t oi) {
   if (oi >= 0 && (b.i < 0 || op > b.p || (op == b.p && oi < b.i))) { b.p = op; b.i = oi; }
 }
 
-__global__ __launch_bounds__(kFixThreads) void pole_fixup_kernel(PoleFix a) {
+// One WAVE per suspect, no workgroup barriers: every lane stages a pair of targets of the listed rows per chunk (the loads of the next
+// chunk in flight while this one is worked on), then four lanes per row run the rows' reference-order sums over the chunk -- T / 4
+// dependent Kahan steps per row in all, the only serial part -- while a SIMD's other waves fill the gaps of the chain with their own
+// suspects' work.  LDS per wave: one chunk of the rows (RMAX KB) and a few dozen doubles: a CU holds twenty suspects at once.
+// (Round 5's first form gave a suspect a workgroup -- three staging waves, one chain wave, a barrier per chunk: 30 us per suspect
+// whatever the row length, three suspects per CU.)
+// RMAX: rows of a question side by side (the launcher takes the smallest of 2 / 5 / 8 / 16 that holds the answers).
+template <int RMAX>
+__global__ __launch_bounds__(kFixThreads) __attribute__((amdgpu_waves_per_eu(PQA_FIX_WAVES, PQA_FIX_WAVES))) void pole_fixup_kernel(PoleFix a) {
   extern __shared__ double smem[];
   const uint32_t n = a.list->count;   // (written by the sweep: a kernel boundary ago)
   if (n == 0) return;
-  const int tid = threadIdx.x, lane = tid % kWave, wave = tid / kWave;
+  const int tid = threadIdx.x, lane = tid % kWave;
+  const int wave = (int)__builtin_amdgcn_readfirstlane(tid / kWave);
   const int64_t K = a.K, ldT = a.ldT, nT = 4 * ((a.T + 3) >> 2);
-  const int R = a.rows;                                        // rows side by side: min(K, kFixRows)
-  double *buf = smem;                                          // [2][R][kFixChunk]
-  double *red = buf + 2 * (size_t)R * kFixChunk;               // [R][kFixRed]
-  double *misc = red + (size_t)R * kFixRed;                    // dH, dL of the question; the last-workgroup flag
+  constexpr int R = RMAX;
+  // this wave's LDS: the rows' chunk [R][kFixRowStride] | per row {four lanes' sums, corrections, largest element, its place, dH, dL} [R][kFixRed] | the suspect's record [2 K + 2]
+  double *buf = smem + (size_t)wave * a.waveLds;
+  double *red = buf + (size_t)R * kFixRowStride;
+  double *rec = red + (size_t)R * kFixRed;
+  double *recW = rec, *recV = rec + K;
   const PoleEntry *entries = reinterpret_cast<const PoleEntry *>(a.list + 1);
   const int nChunks = (int)((nT + kFixChunk - 1) / kFixChunk);
-  for (uint32_t e = blockIdx.x; e < n; e += gridDim.x) {
-    const PoleEntry en = entries[e];
+  const uint32_t nWaves = gridDim.x * (kFixThreads / kWave);
+  for (uint32_t e = blockIdx.x * (kFixThreads / kWave) + wave; e < n; e += nWaves) {
+    // (the entry is the same for every lane: said once, so that everything derived from it -- the row and record pointers --
+    //  lives in scalar registers)
+    PoleEntry en = entries[e];
+    en.q = __builtin_amdgcn_readfirstlane(en.q);
+    en.b = __builtin_amdgcn_readfirstlane(en.b);
+    en.rowMask = __builtin_amdgcn_readfirstlane(en.rowMask);
     const int64_t qLocal = en.q;                               // position in the priority vector; the cube's question is qFirst + it
-    const double *prior = a.slots != nullptr ? a.slots[en.b].prior : a.prior;
+    const double *prior = a.prior;
+    if (a.slots != nullptr) {
+      const uint64_t pp = (uint64_t)(uintptr_t)a.slots[en.b].prior;
+      prior = reinterpret_cast<const double *>((uintptr_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(pp >> 32)) << 32) |
+                                                              (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)pp)));
+    }
     uint32_t rowMask = en.rowMask;
-    if (a.maskDense != nullptr) rowMask = a.maskDense[qLocal];
+    if (a.maskDense != nullptr) rowMask = __builtin_amdgcn_readfirstlane(a.maskDense[qLocal]);
     if (K > 31 || rowMask == 0) rowMask = K >= 32 ? 0xFFFFFFFFu : (1u << K) - 1u;   // (not known, or dozens of answers: every row)
-    double *rec = a.sums + (size_t)(a.bySlot ? (int64_t)e : qLocal) * a.sumsStride;
-    double *recW = rec + a.wOff, *recV = rec + a.vOff;
+    // the suspect's record of sums, in LDS while it is worked on: W_k | second | sum l log2 p | lack
+    double *recG = a.sums + (size_t)(a.bySlot ? (int64_t)e : qLocal) * a.sumsStride;
+    for (int i = lane; i < 2 * (int)K + 2; i += kWave)
+      rec[i] = recG[i < K ? a.wOff + i : i < 2 * K ? a.vOff + (i - (int)K) : i == 2 * K ? a.hOff : a.lOff];
     const double *qBase = a.cube + (a.qFirst + qLocal) * (K + 1) * ldT;
-    const double2 *rowD2 = reinterpret_cast<const double2 *>(qBase + K * ldT);
-    const double2 *prior2 = reinterpret_cast<const double2 *>(prior);
-    if (tid == 0) { misc[0] = 0.0; misc[1] = 0.0; }
+    const double *rowD = qBase + K * ldT;
+    double dHsum = 0.0, dLsum = 0.0;                           // (lane 0: what the near-1 elements change in the entropy and lack sums)
     for (int64_t kBase = 0; kBase < K; kBase += 32) {          // (more than 32 answers: every row, 32 at a time)
       uint32_t rest = K > 31 ? (K - kBase >= 32 ? 0xFFFFFFFFu : (1u << (K - kBase)) - 1u) : rowMask;
       while (rest != 0) {
         // ---- a batch of up to R listed rows
-        int rowOf[kFixRows], nb = 0;
+        uint32_t rowOff[R];                                    // (element offset of the row within the question's block)
+        int nb = 0;
 #pragma unroll
-        for (int r = 0; r < kFixRows; r++) {
-          rowOf[r] = 0;
-          if (r < R && rest != 0) { rowOf[r] = (int)kBase + __builtin_ctz(rest); rest &= rest - 1; nb = r + 1; }
+        for (int r = 0; r < R; r++) {
+          rowOff[r] = 0;
+          if (rest != 0) { rowOff[r] = (uint32_t)(((int)kBase + __builtin_ctz(rest)) * ldT); rest &= rest - 1; nb = r + 1; }
         }
-        double mx[kFixRows], mxId[kFixRows];
-        int mxT[kFixRows];
+        // lane 4 r + cc: lane cc of row r's accumulator (SRAccumVectDbl256.h:40-46); every lane: the largest likelihood it has formed
+        // per row, and where (chunk and element of its pair)
+        double sum = 0.0, corr = 0.0;
+        double mx[R];
+        int mxAt[R];
 #pragma unroll
-        for (int r = 0; r < kFixRows; r++) { mx[r] = 0.0; mxId[r] = 0.0; mxT[r] = 0; }
-        double sum = 0.0, corr = 0.0;                          // (wave 0, lane 4 r + c: lane c of row r's accumulator, SRAccumVectDbl256.h:40-46)
-        __syncthreads();                                       // (the previous batch's red[] has been read)
-        for (int c = 0; c <= nChunks; c++) {
-          if (wave != 0) {
-            if (c < nChunks) {
-              // ---- chunk c of the rows' likelihoods (:72-82, as pass 1 forms them), a pair of targets per thread
-              const int s = tid - kWave;
-              const int64_t t0 = (int64_t)c * kFixChunk + 2 * s;
-              if (t0 < nT) {
-                const double2 dv = rowD2[t0 >> 1], pv = prior2[t0 >> 1];
-                const uint32_t gw = a.tgap[t0 >> 5] >> (t0 & 31);
-                double2 av[kFixRows];
+        for (int r = 0; r < R; r++) { mx[r] = 0.0; mxAt[r] = 0; }
+        struct Chunk { double2 dv, pv, av[R]; uint32_t gw; };
+        // the loads of chunk c (:72-82's operands), a pair of targets per lane
+        auto request = [&](Chunk &ch, int c) __attribute__((always_inline)) {
+          const int64_t t0 = (int64_t)c * kFixChunk + 2 * lane;
+          const int64_t tc = t0 < nT ? t0 : 0;                 // (beyond the row: any valid pair, not used)
+          ch.dv = *reinterpret_cast<const double2 *>(rowD + tc);
+          ch.pv = *reinterpret_cast<const double2 *>(prior + tc);
+          ch.gw = a.tgap[tc >> 5] >> (tc & 31);
 #pragma unroll
-                for (int r = 0; r < kFixRows; r++)
-                  if (r < nb) av[r] = reinterpret_cast<const double2 *>(qBase + (int64_t)rowOf[r] * ldT)[t0 >> 1];
-                const bool g0 = gw & 1u, g1 = gw & 2u;
-                const double id0 = g0 ? 0.0 : div_nr(1.0, dv.x), id1 = g1 ? 0.0 : div_nr(1.0, dv.y);   // :74
-                const double p0 = g0 ? 0.0 : pv.x, p1 = g1 ? 0.0 : pv.y;                                  // :103
-                double *dst = buf + ((size_t)(c & 1) * R) * kFixChunk + 2 * s;
+          for (int r = 0; r < R; r++)
+            if (r < nb) ch.av[r] = *reinterpret_cast<const double2 *>(qBase + rowOff[r] + tc);
+        };
+        // chunk c: the rows' likelihoods as pass 1 forms them, into LDS
+        auto stage = [&](const Chunk &ch, int c) __attribute__((always_inline)) {
+          const int64_t t0 = (int64_t)c * kFixChunk + 2 * lane;
+          if (t0 < nT) {
+            const bool g0 = ch.gw & 1u, g1 = ch.gw & 2u;
+            const double id0 = g0 ? 0.0 : div_nr(1.0, ch.dv.x), id1 = g1 ? 0.0 : div_nr(1.0, ch.dv.y);   // :74
+            const double p0 = g0 ? 0.0 : ch.pv.x, p1 = g1 ? 0.0 : ch.pv.y;                                // :103
 #pragma unroll
-                for (int r = 0; r < kFixRows; r++)
-                  if (r < nb) {
-                    const double l0 = (av[r].x * id0) * p0, l1 = (av[r].y * id1) * p1;                    // :81-82
-                    dst[(size_t)r * kFixChunk] = l0;
-                    dst[(size_t)r * kFixChunk + 1] = l1;
-                    if (l0 > mx[r]) { mx[r] = l0; mxId[r] = id0; mxT[r] = (int)t0; }
-                    if (l1 > mx[r]) { mx[r] = l1; mxId[r] = id1; mxT[r] = (int)t0 + 1; }
-                  }
+            for (int r = 0; r < R; r++)
+              if (r < nb) {
+                const double l0 = (ch.av[r].x * id0) * p0, l1 = (ch.av[r].y * id1) * p1;                  // :81-82
+                *reinterpret_cast<double2 *>(buf + (size_t)r * kFixRowStride + 2 * lane) = make_double2(l0, l1);
+                const double lm = l1 > l0 ? l1 : l0;
+                if (lm > mx[r]) { mx[r] = lm; mxAt[r] = 2 * c + (l1 > l0 ? 1 : 0); }
               }
-            }
-          } else if (c > 0 && lane < 4 * nb) {
-            // ---- the reference-order sums over chunk c - 1: lane 4 r + cc takes the targets 4 j + cc of row r, in order
-            const double *src = buf + ((size_t)((c - 1) & 1) * R + (lane >> 2)) * kFixChunk + (lane & 3);
-            const int64_t left = nT / 4 - (int64_t)(c - 1) * (kFixChunk / 4);
+          }
+        };
+        Chunk ch;
+        request(ch, 0);
+        for (int c = 0; c < nChunks; c++) {
+          stage(ch, c);
+          if (c + 1 < nChunks) request(ch, c + 1);             // (in flight during the chains below, and the other waves' work)
+          __builtin_amdgcn_wave_barrier();                     // (one wave, LDS in order: the chains read what the lanes wrote)
+          if (lane < 4 * nb) {
+            const double *src = buf + (size_t)(lane >> 2) * kFixRowStride + (lane & 3);
+            const int64_t left = nT / 4 - (int64_t)c * (kFixChunk / 4);
             const int steps = (int)(left < kFixChunk / 4 ? left : kFixChunk / 4);
             int j = 0;
             for (; j + 8 <= steps; j += 8) {                   // (eight elements requested at once, added in order)
@@ -174,47 +207,49 @@ __global__ __launch_bounds__(kFixThreads) void pole_fixup_kernel(PoleFix a) {
               sum = t;
             }
           }
-          __syncthreads();
+          __builtin_amdgcn_wave_barrier();                     // (... and the next chunk is written behind these reads)
         }
-        // ---- per row: the stagers' largest element, the chains' results
-        if (wave != 0) {
-#pragma unroll
-          for (int r = 0; r < kFixRows; r++)
-            if (r < nb) {
-              const double wmx = wave_max_d(mx[r]);
-              double *cw = red + (size_t)r * kFixRed + 3 * (wave - 1);
-              if (lane == 0) { cw[0] = 0.0; cw[1] = 0.0; cw[2] = 0.0; }
-              if (mx[r] == wmx && mx[r] > 0.0) { cw[0] = mx[r]; cw[1] = mxId[r]; cw[2] = (double)mxT[r]; }   // (behind lane 0's zeros; lanes that tie hold equal values: any one's index serves)
-            }
-        } else if (lane < 4 * nb) {
-          double *out = red + (size_t)(lane >> 2) * kFixRed + 9;
+        // ---- per row: the four lanes' results, the largest element and its place
+        if (lane < 4 * nb) {
+          double *out = red + (size_t)(lane >> 2) * kFixRed;
           out[lane & 3] = sum;
           out[4 + (lane & 3)] = corr;
         }
-        __syncthreads();
-        if (tid < nb) {
-          const int k = rowOf[0];                              // (rowOf[tid] without a dynamic register index)
-          int kk = k;
 #pragma unroll
-          for (int r = 1; r < kFixRows; r++) kk = tid == r ? rowOf[r] : kk;
-          double *rr = red + (size_t)tid * kFixRed;
-          double cand = rr[0], candId = rr[1], candT = rr[2];
-          for (int w = 1; w < 3; w++)
-            if (rr[3 * w] > cand) { cand = rr[3 * w]; candId = rr[3 * w + 1]; candT = rr[3 * w + 2]; }
-          const double Wx = precise_sum4(rr + 9, rr + 13);     // :88
+        for (int r = 0; r < R; r++)
+          if (r < nb) {
+            const double wmx = wave_max_d(mx[r]);
+            double *cw = red + (size_t)r * kFixRed + 8;
+            if (lane == 0) { cw[0] = 0.0; cw[1] = 0.0; }
+            if (mx[r] == wmx && mx[r] > 0.0) {                 // (behind lane 0's zeros; lanes that tie hold equal values: any one's place serves)
+              cw[0] = mx[r];
+              cw[1] = (double)((mxAt[r] >> 1) * kFixChunk + 2 * lane + (mxAt[r] & 1));
+            }
+          }
+        __builtin_amdgcn_wave_barrier();
+        if (lane < nb) {
+          uint32_t off = rowOff[0];                            // (rowOff[lane] without a dynamic register index)
+#pragma unroll
+          for (int r = 1; r < R; r++) off = lane == r ? rowOff[r] : off;
+          const int kk = (int)(off / (uint32_t)ldT);
+          double *rr = red + (size_t)lane * kFixRed;
+          const double cand = rr[8];
+          const int candT = (int)rr[9];
+          const double Wx = precise_sum4(rr, rr + 4);          // :88
           const double invWx = div_nr(1.0, Wx);                // :91
           const double pRef = cand * invWx;                    // :97
           double dH = 0.0, dL = 0.0;
           if (cand > 0.0 && (uint32_t)(d2u(pRef) >> 32) >= kNearOneHi) {
+            const double dAt = rowD[candT], prh = prior[candT];   // (one round trip for both)
             const double Wf = recW[kk];                        // the sweep's W_k
             const double pFast = cand * div_nr(1.0, Wf);       // what pass 2 took for this element
             const double lFast = log2hot_global(pFast, gLog2TableP);
             const double lRef = log2hot_ref(pRef, gLog2TableP, gLog2Entry0RefP);   // :106
             dH = cand * lRef - cand * lFast;                   // :113-114 (weighted by W_k: eval_epilogue)
+            const double candId = div_nr(1.0, dAt);            // :74 (not a gap: its likelihood is positive)
             const double id2 = candId * candId;
             dL = div_fast(id2, lRef) - div_fast(id2, lFast);   // :117 (pass 2's quotient was within 2^-48.8 of the second one)
             // :119-127 the element's velocity term: a difference of two numbers next to 1
-            const double prh = prior[(int64_t)candT];
             const double dF = pFast - prh, dR = pRef - prh;
             const double vOld = a.secondIsWV ? [&] { const double sv = div_fast(recV[kk], Wf); return sv * sv; }() : recV[kk];
             double vNew = (vOld - dF * dF) + dR * dR;
@@ -222,19 +257,20 @@ __global__ __launch_bounds__(kFixThreads) void pole_fixup_kernel(PoleFix a) {
             recV[kk] = a.secondIsWV ? Wx * sqrt(vNew) : vNew;  // :156-157
             recW[kk] = Wx;                                     // :90
           }
-          rr[17] = dH;
-          rr[18] = dL;
+          rr[10] = dH;
+          rr[11] = dL;
         }
-        __syncthreads();
-        if (tid == 0)
-          for (int r = 0; r < nb; r++) { misc[0] += red[(size_t)r * kFixRed + 17]; misc[1] += red[(size_t)r * kFixRed + 18]; }
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0)
+          for (int r = 0; r < nb; r++) { dHsum += red[(size_t)r * kFixRed + 10]; dLsum += red[(size_t)r * kFixRed + 11]; }
+        __builtin_amdgcn_wave_barrier();                       // (red[] is written again by the next batch)
       }
     }
-    if (tid == 0) {
-      if (a.priority != nullptr || a.priorityT != nullptr) {
-        const double pri = eval_epilogue(recW, -(rec[a.hOff] + misc[0]), recV, K, rec[a.lOff] + misc[1], a.vCompTail);   // :130-207
-        double *dst = a.slots != nullptr && a.priorityT == nullptr ? a.slots[en.b].priority + qLocal
-                      : a.priorityT != nullptr ? a.priorityT + (size_t)qLocal * a.Bp + en.b : a.priority + qLocal;
+    if (lane == 0) {
+      if (a.priority != nullptr || a.priorityT != nullptr || a.slots != nullptr) {
+        const double pri = eval_epilogue(recW, -(rec[2 * K] + dHsum), recV, K, rec[2 * K + 1] + dLsum, a.vCompTail);   // :130-207
+        double *dst = a.priorityT != nullptr ? a.priorityT + (size_t)qLocal * a.Bp + en.b
+                      : a.slots != nullptr ? a.slots[en.b].priority + qLocal : a.priority + qLocal;
         __hip_atomic_store(dst, pri, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         TaggedPriority *hp = a.slots != nullptr ? a.slots[en.b].hostPriority : a.hostPriority;
         if (hp != nullptr) {
@@ -244,16 +280,19 @@ __global__ __launch_bounds__(kFixThreads) void pole_fixup_kernel(PoleFix a) {
           asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(hp + qLocal), "v"(x) : "memory");
         }
       } else {                                                 // (the caller's epilogue kernel follows: cluster_kernels.hip)
-        rec[a.hOff] += misc[0];
-        rec[a.lOff] += misc[1];
+        for (int k = 0; k < K; k++) { recG[a.wOff + k] = recW[k]; recG[a.vOff + k] = recV[k]; }
+        recG[a.hOff] = rec[2 * K] + dHsum;
+        recG[a.lOff] = rec[2 * K + 1] + dLsum;
       }
       if (a.maskDense != nullptr) a.maskDense[qLocal] = 0;
       if (a.dirty != nullptr) a.dirty[en.b] = 1u;
     }
-    __syncthreads();
+    __builtin_amdgcn_wave_barrier();                           // (rec[] is the next suspect's)
   }
+  double *misc = smem, *pub = smem + 8;                        // (the waves' LDS is free by the barrier below)
   // ---- the last workgroup to get here publishes what the sweep's finisher left to this kernel, and empties the list
-  __threadfence_system();                                      // (the corrected priorities, the host's records among them)
+  if (a.hostPriority != nullptr || a.slots != nullptr) __threadfence_system();   // (the host's records among the corrected priorities)
+  else __threadfence();
   __syncthreads();
   if (tid == 0) {
     const uint32_t arrived = atomicAdd(&a.list->arrived, 1u);
@@ -284,7 +323,7 @@ __global__ __launch_bounds__(kFixThreads) void pole_fixup_kernel(PoleFix a) {
         const int64_t oi = __shfl_xor(b.i, m, kWave);
         best_merge(b, op, oi);
       }
-      Best *wb = reinterpret_cast<Best *>(buf);
+      Best *wb = reinterpret_cast<Best *>(pub);
       if (lane == 0) wb[wave] = b;
       __syncthreads();
       if (tid == 0) {
@@ -294,7 +333,7 @@ __global__ __launch_bounds__(kFixThreads) void pole_fixup_kernel(PoleFix a) {
       }
     } else if (a.fs.hostPriority == nullptr) {
       // the reference's selector over the corrected vector (the sweep's own workgroup 0 would have run it)
-      const SampledPick r = select_sampled_wg_lds<true>(a.priority, a.qgap, a.asked, a.qFirst, nQ, a.fs.sampleSubtasks, a.fs.sampleRnd, buf);
+      const SampledPick r = select_sampled_wg_lds<true>(a.priority, a.qgap, a.asked, a.qFirst, nQ, a.fs.sampleSubtasks, a.fs.sampleRnd, pub);
       outP = r.priority;
       outI = r.index + a.fs.outBase;
     }
@@ -327,29 +366,32 @@ size_t PoleListBytes(int64_t capacity) { return sizeof(PoleHeader) + (size_t)cap
 hipError_t LaunchPoleFixup(const PoleFix &fix, hipStream_t stream) {
   if (fix.list == nullptr || fix.sums == nullptr) return hipErrorInvalidValue;
   PoleFix a = fix;
-  a.rows = (int)(a.K < kFixRows ? a.K : kFixRows);
-  size_t shmem = ((size_t)2 * a.rows * kFixChunk + (size_t)a.rows * kFixRed + 8) * sizeof(double);
+  a.rows = a.K <= 2 ? 2 : a.K <= 5 ? 5 : a.K <= 8 ? 8 : 16;
+  void (*kern)(PoleFix) = a.rows == 2 ? pole_fixup_kernel<2> : a.rows == 5 ? pole_fixup_kernel<5> : a.rows == 8 ? pole_fixup_kernel<8> : pole_fixup_kernel<16>;
+  a.waveLds = (int)(((size_t)a.rows * kFixRowStride + (size_t)a.rows * kFixRed + 2 * (size_t)a.K + 2 + 1) / 2 * 2);
+  size_t shmem = (size_t)(kFixThreads / kWave) * a.waveLds * sizeof(double);
+  if (shmem < 512) shmem = 512;
   if (a.fs.scratch != nullptr && a.fs.sampleSubtasks > 0 && a.fs.hostPriority == nullptr) {
-    const size_t need = (size_t)select_sampled_lds_doubles(a.nQ, a.fs.sampleSubtasks) * sizeof(double);
+    const size_t need = ((size_t)select_sampled_lds_doubles(a.nQ, a.fs.sampleSubtasks) + 8) * sizeof(double);
     if (need > shmem) shmem = need;
   }
   if (shmem > 160 * 1024) return hipErrorInvalidValue;
-  static LaunchCache cache;
+  static LaunchCache cache;   // (the shape is a function of the LDS size, up to selections with very many subtasks)
   const int dev = LaunchCache::Device();
   int perCU = 0;
   if (!cache.Get(dev, shmem, &perCU)) {
     if (shmem > 64 * 1024) {
-      const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(pole_fixup_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+      const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
       if (e != hipSuccess) return e;
     }
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, pole_fixup_kernel, kFixThreads, shmem) != hipSuccess || perCU < 1) perCU = 1;
-    if (perCU > 4) perCU = 4;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, kern, kFixThreads, shmem) != hipSuccess || perCU < 1) perCU = 1;
     cache.Put(dev, shmem, perCU);
   }
   int64_t grid = (int64_t)cache.NumCUs(dev) * perCU;
-  if (fix.capacity > 0 && grid > fix.capacity) grid = fix.capacity;
+  const int64_t wgs = (fix.capacity + kFixThreads / kWave - 1) / (kFixThreads / kWave);   // (a wave per suspect)
+  if (fix.capacity > 0 && grid > wgs) grid = wgs;
   if (grid < 1) grid = 1;
-  hipLaunchKernelGGL(pole_fixup_kernel, dim3((unsigned)grid), dim3(kFixThreads), shmem, stream, a);
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(kFixThreads), shmem, stream, a);
   return hipGetLastError();
 }
 

@@ -153,7 +153,7 @@ struct PoleFix {
   int64_t K, T, ldT, qFirst, nQ, capacity;
   double vCompTail;
   FusedSelect fs;
-  int rows;                       // (set by the launcher)
+  int rows, waveLds;              // (set by the launcher)
 };
 hipError_t LaunchPoleFixup(const PoleFix &fix, hipStream_t stream);
 // The same sweep for nSlots quizzes in one launch (grid.y = quiz): `slots` is a DEVICE array; fused->scratch holds

@@ -170,7 +170,8 @@ def test_late_soak(factory, late):
     for i in range(first, first + n):
         try:
             leg, case, w = run_late_case(i, factory)
-            worst[leg] = max(worst.get(leg, 0.0), w)
+            if w >= worst.get(leg, (-1.0, ""))[0]:
+                worst[leg] = (w, case.name)
         except BaseException as ex:  # noqa: BLE001
             if isinstance(ex, KeyboardInterrupt):
                 raise
@@ -178,5 +179,5 @@ def test_late_soak(factory, late):
             bad.append((i, case.name, repr(ex)[:240]))
             print("FAIL", bad[-1])
     print("late-state soak: %d cases from seed %d, worst relative deviation per leg: %s" % (
-        n, first, {k: "%.2e" % v for k, v in sorted(worst.items())}))
+        n, first, {k: "%.2e %s" % v for k, v in sorted(worst.items())}))
     assert not bad, (len(bad), bad[:8])

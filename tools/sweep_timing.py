@@ -1,16 +1,19 @@
 """Launched sweep time (HIP events, back-to-back) for a list of cube shapes, the resident step at S, and a late quiz state's sweep:
-sweep_timing.py [QxKxT ...]"""
+sweep_timing.py [QxKxT ...] [option=value ...]   (engine options, e.g. pole_fix=0)"""
 import os, sys, time
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, root)
 import torch
 from probqa_amd import interop
 f = interop.PqaEngineFactory()
-shapes = [tuple(int(x) for x in a.split("x")) for a in sys.argv[1:]] or [(1000, 5, 1000), (2000, 5, 2000), (4000, 5, 4000), (8000, 5, 8000), (10000, 5, 10000)]
+opts = [(a.split("=")[0], int(a.split("=")[1])) for a in sys.argv[1:] if "=" in a]
+shapes = [tuple(int(x) for x in a.split("x")) for a in sys.argv[1:] if "=" not in a] or [(1000, 5, 1000), (2000, 5, 2000), (4000, 5, 4000), (8000, 5, 8000), (10000, 5, 10000)]
 st = torch.cuda.Stream()
 for Q, K, T in shapes:
     e = f.create_hip_engine(interop.EngineDefinition(K, Q, T, init_amount=0.1), 0, Q, 0)
     e.set_option("select", 1)
+    for name, value in opts:
+        e.set_option(name, value)
     e.fill_synthetic(8.0, 0.5, 20260928)
     e.set_stream(st.cuda_stream)
     q = e.start_quiz()
