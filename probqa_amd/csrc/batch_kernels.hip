@@ -354,6 +354,21 @@ __global__ __launch_bounds__(256) void eval_batch_kernel(BatchArgs a) {
         }
       }
     }
+    // the pole watch's verdict per question: every row if an element came within 2^-10 of 1; the rows whose velocity sum all but
+    // vanishes if one holds a quarter of the mass (pole_device.h)
+    [[maybe_unused]] uint32_t listRows[QB];
+    if constexpr (kPoleWatch) {
+#pragma unroll
+      for (int qi = 0; qi < QB; qi++) {
+        listRows[qi] = 0;
+        if (a.poleList != nullptr && hiMax[qi] >= kQuarterHi) {
+          if (hiMax[qi] >= kNearOneHi) listRows[qi] = K >= 32 ? 0xFFFFFFFFu : (1u << K) - 1u;
+          else
+            for (int64_t k = 0; k < K; k++)
+              if (acc[qi * nAcc + (int)(K + k)] <= kSmallV) listRows[qi] |= 1u << (k < 31 ? (int)k : 31);
+        }
+      }
+    }
     // ---- epilogue (:134-207), one per (question, quiz), fp64
 #pragma unroll 1
     for (int qi = 0; qi < QB; qi++) {
@@ -377,13 +392,12 @@ __global__ __launch_bounds__(256) void eval_batch_kernel(BatchArgs a) {
     }
     if constexpr (kPoleWatch) {
       if (a.poleList != nullptr) {
-        // ---- (question, quiz) pairs with a posterior element within 2^-10 of 1: listed, with their sums, for the fix behind the
-        // sweep (every row of such a pair is redone: the watch keeps one maximum per question, not per row)
+        // ---- the (question, quiz) pairs the watch has named: listed, with their sums, for the fix behind the sweep
 #pragma unroll
         for (int qi = 0; qi < QB; qi++) {
           const int64_t q = q0 + qi;
-          if (live && q < a.qEnd && hiMax[qi] >= kNearOneHi && !(bit_test(a.qgap, q) || ((asked[q >> 5] >> (q & 31)) & 1u))) {
-            const uint32_t at = pole_list_append(a.poleList, (uint32_t)q, 0u, (uint32_t)b);
+          if (live && q < a.qEnd && listRows[qi] != 0 && !(bit_test(a.qgap, q) || ((asked[q >> 5] >> (q & 31)) & 1u))) {
+            const uint32_t at = pole_list_append(a.poleList, (uint32_t)q, K <= 31 ? listRows[qi] : 0u, (uint32_t)b);
             const double *rec = acc + (size_t)qi * nAcc;       // (W_k sqrt(V_k) in place of V_k by now)
             double *dst = a.poleSums + (size_t)at * nAcc;
             for (int i = 0; i < nAcc; i++) dst[i] = rec[i];
@@ -479,9 +493,9 @@ __global__ __launch_bounds__(kMidThreads) void eval_midbatch_kernel(MidArgs a) {
   if (!lds_table_at_zero(tbl)) __builtin_trap();            // log2hot addresses the table absolutely
   double *tile = smem + kLog2TableDoubles;                  // [ldT][K + 1]
   double *red = tile + (size_t)a.ldT * (K + 1);             // [NW][K + 2][QS]
-  uint32_t *watchW = reinterpret_cast<uint32_t *>(red + (size_t)NW * (K + 2) * QS);   // [QS]: the rows of this question that passed the pole watch, per quiz slot
+  uint32_t *watchW = reinterpret_cast<uint32_t *>(red + (size_t)NW * (K + 2) * QS);   // [2][QS]: the rows of this question that passed the pole watch -- an element next to 1 | an element of a quarter -- per quiz slot
   for (int i = threadIdx.x; i < kLog2TableDoubles; i += kMidThreads) smem[i] = gLog2TableB[i];
-  if (threadIdx.x < QS) watchW[threadIdx.x] = 0;
+  if (threadIdx.x < 2 * QS) watchW[threadIdx.x] = 0;
   const int tid = threadIdx.x, lane = tid % kWave, wave = tid / kWave;
   const int slot = lane % QS, chunk = wave * NSUB + lane / QS;
   const int b = blockIdx.y * QS + slot;                     // this lane's quiz
@@ -526,7 +540,7 @@ __global__ __launch_bounds__(kMidThreads) void eval_midbatch_kernel(MidArgs a) {
     }
     __syncthreads();
     double invW[K];
-    uint32_t poleRows = 0;
+    uint32_t poleRows = 0, quarterRows = 0;
 #pragma unroll
     for (int k = 0; k < K; k++) {
       double w = 0.0;
@@ -534,10 +548,17 @@ __global__ __launch_bounds__(kMidThreads) void eval_midbatch_kernel(MidArgs a) {
       for (int w2 = 0; w2 < NW; w2++) w += red[(w2 * (K + 2) + k) * QS + slot];
       W[k] = w;                                                                           // :88-90 (the same bits in every lane of the quiz)
       invW[k] = (EXACT || k < kN) ? div_fast(1.0, w) : 0.0;                               // :91
-      // an element within 2^-10 of 1 is nearly all of W_k: so is the serial sum of the lane that holds it (eval_kernels.hip: the watch)
-      if ((EXACT || k < kN) && Wlane[k] >= w * (1.0 - 0x1p-9) && Wlane[k] > 0.0) poleRows |= 1u << k;
+      // an element within 2^-10 of 1 is nearly all of W_k, and so is the serial sum of the lane that holds it; likewise an element
+      // of a quarter (eval_kernels.hip: the watch)
+      if ((EXACT || k < kN) && Wlane[k] >= w * 0.25 && Wlane[k] > 0.0) {
+        quarterRows |= 1u << k;
+        if (Wlane[k] >= w * (1.0 - 0x1p-9)) poleRows |= 1u << k;
+      }
     }
-    if (poleRows != 0 && a.poleList != nullptr) atomicOr(&watchW[slot], poleRows);           // (rare; read by the quiz's head lane behind the next barriers)
+    if (quarterRows != 0 && a.poleList != nullptr) {                                        // (rare; read by the quiz's head lane behind the next barriers)
+      atomicOr(&watchW[QS + slot], quarterRows);
+      if (poleRows != 0) atomicOr(&watchW[slot], poleRows);
+    }
     __syncthreads();                                        // (the exchange buffer is used again below)
     // ---- pass 2 (:95-128)
     double v[K], hW = 0.0, accL = 0.0;
@@ -591,9 +612,16 @@ __global__ __launch_bounds__(kMidThreads) void eval_midbatch_kernel(MidArgs a) {
           else sums[r - K] = s2;
         }
         pri = eval_epilogue(mW, -sums[0], mWV, kN, sums[1], a.vCompTail);
-        if (live && watchW[slot] != 0) {
+        uint32_t listRows = watchW[slot];
+        if (watchW[QS + slot] != 0) {
+          // (rows with an element of a quarter whose velocity sum all but vanishes: mWV = W sqrt(V))
+#pragma unroll
+          for (int r = 0; r < K; r++)
+            if ((EXACT || r < kN) && ((watchW[QS + slot] >> r) & 1u) && mWV[r] * mWV[r] <= kSmallV * (mW[r] * mW[r])) listRows |= 1u << r;
+        }
+        if (live && listRows != 0) {
           // the pair's sums as they are, for the fix behind the sweep (pole_kernels.hip)
-          const uint32_t at = pole_list_append(a.poleList, (uint32_t)q, watchW[slot], (uint32_t)b);
+          const uint32_t at = pole_list_append(a.poleList, (uint32_t)q, listRows, (uint32_t)b);
           double *dst = a.poleSums + (size_t)at * (2 * kN + 2);
 #pragma unroll
           for (int r = 0; r < K; r++)
@@ -603,6 +631,7 @@ __global__ __launch_bounds__(kMidThreads) void eval_midbatch_kernel(MidArgs a) {
         }
       }
       watchW[slot] = 0;                                       // (set again only behind the next question's barriers)
+      watchW[QS + slot] = 0;
       if (live) {
         if (a.priorityT) a.priorityT[q * Bp + b] = pri;
         if (!skip) {
@@ -982,7 +1011,7 @@ hipError_t LaunchEvalBatch(const KbView &kb, const QuizSlot *slots, int nSlots, 
 bool EvalMidBatchSupported(const KbView &kb) {
   const int64_t km = kb.K == 5 ? 5 : kMidMaxK;
   return kb.elem == 8 && kb.K >= 2 && kb.K <= kMidMaxK &&
-         (size_t)(kLog2TableDoubles + kb.ldT * (km + 1) + (kMidThreads / kWave) * (km + 2) * 64 + 32) * sizeof(double) <= 160 * 1024;
+         (size_t)(kLog2TableDoubles + kb.ldT * (km + 1) + (kMidThreads / kWave) * (km + 2) * 64 + 64) * sizeof(double) <= 160 * 1024;
 }
 
 // plan: out grid / Bp / ptBytes / recBytes (queryOnly), as LaunchEvalBatch; PT and recs from the caller.  Every quiz's winner goes to
@@ -998,7 +1027,7 @@ hipError_t LaunchEvalMidBatch(const KbView &kb, const QuizSlot *slots, int nSlot
   const int devSlot = LaunchCache::Device();
   const int nCU = cache.NumCUs(devSlot);
   const int KM = kb.K == 5 ? 5 : kMidMaxK;
-  const size_t shmem = (size_t)(kLog2TableDoubles + kb.ldT * (KM + 1) + (kMidThreads / kWave) * (KM + 2) * QS + 32) * sizeof(double);   // (+ the watch words)
+  const size_t shmem = (size_t)(kLog2TableDoubles + kb.ldT * (KM + 1) + (kMidThreads / kWave) * (KM + 2) * QS + 64) * sizeof(double);   // (+ the watch words)
   if (shmem > 160 * 1024) return hipErrorInvalidValue;
   const int perCU = (int)std::max<size_t>(1, std::min<size_t>(3, (160 * 1024) / shmem));
   int64_t grid = std::min<int64_t>(kb.Q, std::max<int64_t>(1, (int64_t)nCU * perCU / groups));

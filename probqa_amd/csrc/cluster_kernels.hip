@@ -96,10 +96,17 @@ struct ClusterArgs {
   // and per question the rows in which a member saw a posterior element within 2^-10 of 1 (several members may)
   PoleHeader *poleList;
   uint32_t *poleMask;
+  uint32_t *wideMask;         // ... and the rows with an element of a quarter: listed by the member that folds the question, if their velocity sum all but vanishes (pole_device.h: kSmallV)
 };
 // a member's rows of one question that passed the watch (one thread of the member)
 __device__ __forceinline__ void cluster_watch_report(const ClusterArgs &a, int64_t q, uint32_t rows) {
   if (atomicOr(&a.poleMask[q], rows) == 0u) pole_list_append(a.poleList, (uint32_t)q, 0u, 0u);
+}
+// the folding member, thread k < K with the question's velocity sum of answer k: the wider watch's verdict
+__device__ __forceinline__ void cluster_watch_fold(const ClusterArgs &a, int64_t q, int k, double vSum) {
+  if (a.poleList == nullptr) return;
+  const uint32_t wide = __hip_atomic_load(&a.wideMask[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (((wide >> (k < 31 ? k : 31)) & 1u) && vSum <= kSmallV) cluster_watch_report(a, q, 1u << (k < 31 ? k : 31));
 }
 
 // The members of a cluster run on different XCDs, whose L2s are not coherent with each other: records are written through (sc1)
@@ -216,10 +223,11 @@ __global__ __launch_bounds__(kClusterThreads, 4) void eval_cluster_kernel(Cluste
     if (tid < K + 2) {
       const double s = red[0][tid];
       double *tot = a.totals + (size_t)qq * (2 * kMaxK + 2);
-      if (tid < K) { tot[tid] = wOfQ[tid]; tot[kMaxK + tid] = s; }
+      if (tid < K) { tot[tid] = wOfQ[tid]; tot[kMaxK + tid] = s; if constexpr (NumC<R>::kTable) cluster_watch_fold(a, qq, tid, s); }
       else tot[2 * kMaxK + (tid - K)] = s;
     }
     __syncthreads();
+    if constexpr (NumC<R>::kTable) { if (tid == 0 && a.wideMask != nullptr) a.wideMask[qq] = 0; }   // (read above; the next launch finds it cleared)
   };
 
   auto next_valid = [&](int64_t q) {    // :54 gap / asked questions get priority 0 and are skipped (the same decision in every member)
@@ -303,7 +311,7 @@ __global__ __launch_bounds__(kClusterThreads, 4) void eval_cluster_kernel(Cluste
     // ---- pass 2 (:95-128) from LDS, answer by answer; the lack term's N / D pairs (batch_kernels.hip) run across the answers
     V accN[NU], accD[NU];
     R hW = (R)0, accL = (R)0;
-    uint32_t poleRows = 0;                                      // (the pole watch: wave-uniform)
+    uint32_t poleRows = 0, quarterRows = 0;                     // (the pole watch: wave-uniform)
     for (int64_t k = 0; k < K; k++) {
       const R invWk = (R)div_fast(1.0, wTot[k]);                // :91
       R vk = (R)0;
@@ -330,7 +338,12 @@ __global__ __launch_bounds__(kClusterThreads, 4) void eval_cluster_kernel(Cluste
       }
       const double s = wave_sum_d((double)vk);
       if (lane == 0) red[k][wave] = s;
-      if constexpr (NumC<R>::kTable) { if (a.poleList != nullptr && __any(hiMax >= kNearOneHi)) poleRows |= 1u << (k < 31 ? (int)k : 31); }
+      if constexpr (NumC<R>::kTable) {
+        if (a.poleList != nullptr && __any(hiMax >= kQuarterHi)) {
+          quarterRows |= 1u << (k < 31 ? (int)k : 31);
+          if (__any(hiMax >= kNearOneHi)) poleRows |= 1u << (k < 31 ? (int)k : 31);
+        }
+      }
     }
 #pragma unroll
     for (int j = 0; j < NU; j++) {
@@ -347,7 +360,10 @@ __global__ __launch_bounds__(kClusterThreads, 4) void eval_cluster_kernel(Cluste
       const double s1 = wave_sum_d((double)hW), s2 = wave_sum_d((double)accL);
       if (lane == 0) { red[K][wave] = s1; red[K + 1][wave] = s2; }
     }
-    if (poleRows != 0 && lane == 0) cluster_watch_report(a, q, poleRows);   // (rare)
+    if (quarterRows != 0 && lane == 0) {                        // (rare)
+      atomicOr(&a.wideMask[q], quarterRows);
+      if (poleRows != 0) cluster_watch_report(a, q, poleRows);
+    }
     __syncthreads();
     if (tid < K + 2) {
       double s = 0.0;
@@ -463,10 +479,11 @@ __global__ __launch_bounds__(kClusterThreads, 4) void eval_cluster_ahead_kernel(
     if (tid < K + 2) {
       const double s = red[0][tid];
       double *tot = a.totals + (size_t)qq * (2 * kMaxK + 2);
-      if (tid < K) { tot[tid] = wHist[(cnt & 3) * kMaxK + tid]; tot[kMaxK + tid] = s; }
+      if (tid < K) { tot[tid] = wHist[(cnt & 3) * kMaxK + tid]; tot[kMaxK + tid] = s; if constexpr (NumC<R>::kTable) cluster_watch_fold(a, qq, tid, s); }
       else tot[2 * kMaxK + (tid - K)] = s;
     }
     __syncthreads();
+    if constexpr (NumC<R>::kTable) { if (tid == 0 && a.wideMask != nullptr) a.wideMask[qq] = 0; }   // (read above; the next launch finds it cleared)
   };
   auto next_valid = [&](int64_t q) {    // :54
     while (q < a.Q && (bit_test(a.qgap, q) || bit_test(a.asked, q))) {
@@ -607,7 +624,7 @@ __global__ __launch_bounds__(kClusterThreads, 4) void eval_cluster_ahead_kernel(
     double *slot = reinterpret_cast<double *>(lhL);             // unit u of row k: slot[(k * SU + u) * 2 + {0, 1}]
     V accN, accD;
     R hW = (R)0, accL = (R)0;
-    uint32_t poleRows = 0;                                      // (the pole watch: wave-uniform)
+    uint32_t poleRows = 0, quarterRows = 0;                     // (the pole watch: wave-uniform)
     for (int64_t k = 0; k < K; k++) {
       const R invWk = (R)wInv[k];                               // :91 (formed once per workgroup, above)
       R vk = (R)0;
@@ -628,9 +645,17 @@ __global__ __launch_bounds__(kClusterThreads, 4) void eval_cluster_ahead_kernel(
         }
         slot[(k * SU + tid) * 2] = (double)vk;
       }
-      if constexpr (NumC<R>::kTable) { if (a.poleList != nullptr && __any(hiMax >= kNearOneHi)) poleRows |= 1u << (k < 31 ? (int)k : 31); }
+      if constexpr (NumC<R>::kTable) {
+        if (a.poleList != nullptr && __any(hiMax >= kQuarterHi)) {
+          quarterRows |= 1u << (k < 31 ? (int)k : 31);
+          if (__any(hiMax >= kNearOneHi)) poleRows |= 1u << (k < 31 ? (int)k : 31);
+        }
+      }
     }
-    if (poleRows != 0 && lane == 0) cluster_watch_report(a, q, poleRows);   // (rare)
+    if (quarterRows != 0 && lane == 0) {                        // (rare)
+      atomicOr(&a.wideMask[q], quarterRows);
+      if (poleRows != 0) cluster_watch_report(a, q, poleRows);
+    }
     if (inSlice) {
 #pragma unroll
       for (int e = 0; e < VN; e++) {
@@ -788,7 +813,7 @@ size_t EvalClusterScratchBytes(const KbView &kb) {
   const bool ok = kb.elem == 4 ? cluster_shape<float>(kb, device_cus(), &s) : cluster_shape<double>(kb, device_cus(), &s);
   if (!ok) return 0;
   const size_t perCluster = (size_t)4 * s.C * (2 * kMaxK + 2) * sizeof(ExRec);   // (four record slots: the form that runs ahead; the other uses two)
-  return (size_t)s.nClusters * perCluster + (size_t)kb.Q * (2 * kMaxK + 2) * sizeof(double) + 256 + (size_t)kb.Q * sizeof(uint32_t);
+  return (size_t)s.nClusters * perCluster + (size_t)kb.Q * (2 * kMaxK + 2) * sizeof(double) + 256 + 2 * (size_t)kb.Q * sizeof(uint32_t);
 }
 
 hipError_t LaunchEvalCluster(const KbView &kb, const double *prior, const uint32_t *asked, double *priority, void *scratch, hipStream_t stream) {
@@ -808,6 +833,7 @@ hipError_t LaunchEvalCluster(const KbView &kb, const double *prior, const uint32
   const bool watch = !f32 && kb.poleList != nullptr && kb.poleScratch != nullptr;
   a.poleList = watch ? kb.poleList : nullptr;
   a.poleMask = watch ? reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(a.totals) + (size_t)kb.Q * (2 * kMaxK + 2) * sizeof(double) + 256) : nullptr;
+  a.wideMask = watch ? a.poleMask + kb.Q : nullptr;
   static std::atomic<unsigned long long> launches{0};
   a.tagBase = (launches.fetch_add(1) + 1) << 32;
   hipError_t e = hipSuccess;

@@ -241,6 +241,7 @@ __device__ __forceinline__ void pass2_pair(double2 lh, double2 id, double2 pr, d
 // EVERY state: the blocks between pass 1 and pass 2 cost the loop its registers), the fix as a called function (+13 %: scratch).
 // ------------------------------------------------------------------------------------------------------------------
 constexpr double kNearOneShare = 1.0 - 0x1p-9;   // (of the wave's sum, of W_k: see above; the bar is pole_device.h: kNearOneHi)
+constexpr double kQuarterShare = 0.25;           // ... and the wider watch for rows with a vanishing velocity sum (pole_device.h: kSmallV)
 constexpr int kSusDoubles = 2;                 // LDS: two words (by question parity: the answer rows that passed the watch, a bit each) + a slot
 
 // LDS-DMA: 16 bytes per lane from global memory straight into LDS, no destination VGPRs (buffer_load_dwordx4 ... offen lds:
@@ -376,7 +377,7 @@ __device__ __forceinline__ void sweep_body(EvalArgs a, bool copyTable) {
   double *partAll = redW + 2 * WPQ;
   double *pend = partAll + 2 * (K + 2) * WPQ;
   Best *bestLds = reinterpret_cast<Best *>(pend + kPend * (2 * K + 3));  // wave 0's per-lane running argmax
-  uint32_t *susWords = reinterpret_cast<uint32_t *>(bestLds + kWave);   // [0], [1]: the rows of the question of that parity that passed the pole watch
+  uint32_t *susWords = reinterpret_cast<uint32_t *>(bestLds + kWave);   // [0], [1]: the rows of the question of that parity that passed the pole watch; [2], [3]: its wider form (kQuarterShare)
   double2 *prLds = reinterpret_cast<double2 *>(reinterpret_cast<double *>(bestLds + kWave) + kSusDoubles);
   // landing row of the NEXT question's mD (register-prior shapes): lane-private 16-byte slots, slot j of thread tid at
   // mdRow[j*kThreads + tid]; filled by LDS-DMA while the current question's last answer is in pass 2
@@ -518,7 +519,7 @@ __device__ __forceinline__ void sweep_body(EvalArgs a, bool copyTable) {
     }
     return q;
   };
-  if (tid < 2) susWords[tid] = 0;
+  if (tid < 4) susWords[tid] = 0;
   int64_t q = q0;
   if (haveQ0 && ((((q0Gap | q0Asked) >> (q0 & 31)) & 1u) || (FUSE && q0 == a.updQuestion))) {     // the first candidate is skipped: restart the stream
     q = next_valid(q0);
@@ -561,7 +562,7 @@ __device__ __forceinline__ void sweep_body(EvalArgs a, bool copyTable) {
     double *part = partAll + qpar * (nPart * WPQ);
     double *rec = pend + nPend * recLen;
     double accL = 0, hW = 0;
-    uint32_t poleRows = 0;                                     // (pole watch: the rows that passed, wave-uniform)
+    uint32_t poleRows = 0, quarterRows = 0;                    // (pole watch: the rows that passed -- an element next to 1; an element of a quarter -- wave-uniform)
     for (int64_t k = 0; k < K; k++) {
       // ---- pass 1 (:66-87): likelihoods into registers, W_k; each consumed pair is refilled from the next stream row
       double2 lh[NP];
@@ -601,11 +602,14 @@ __device__ __forceinline__ void sweep_body(EvalArgs a, bool copyTable) {
       }
       const double sLane = s0 + s1;
       double Wk = wave_sum(sLane);                             // :88
-      bool watchHit = false;                                   // (wave-uniform: a lane of this wave holds nearly all of the wave's sum)
+      bool watchHit = false, watchNear = false;               // (wave-uniform: a lane of this wave holds a quarter / nearly all of the wave's sum)
       double waveW = 0.0;
       if constexpr (kWatch) {
-        watchHit = __any(sLane >= Wk * kNearOneShare && sLane > 0.0);
-        if (watchHit) waveW = uniform_double(Wk);                // (in scalar registers across the exchange)
+        watchHit = __any(sLane >= Wk * kQuarterShare && sLane > 0.0);
+        if (watchHit) {
+          waveW = uniform_double(Wk);                            // (in scalar registers across the exchange)
+          watchNear = __any(sLane >= Wk * kNearOneShare);
+        }
       }
       if constexpr (WPQ > 1) {
         double *buf = redW + phase * WPQ;
@@ -615,7 +619,10 @@ __device__ __forceinline__ void sweep_body(EvalArgs a, bool copyTable) {
         phase ^= 1;
       }
       if constexpr (kWatch) {
-        if (watchHit && __any(waveW >= Wk * kNearOneShare)) poleRows |= 1u << (k < 31 ? (int)k : 31);   // (rare outside late quiz states)
+        if (watchHit && __any(waveW >= Wk * kQuarterShare)) {     // (rare before a quiz's last third)
+          quarterRows |= 1u << (k < 31 ? (int)k : 31);
+          if (watchNear && __any(waveW >= Wk * kNearOneShare)) poleRows |= 1u << (k < 31 ? (int)k : 31);
+        }
       }
       const double invWk = div_nr(1.0, Wk);                    // :91
       // ---- pass 2 (:95-128)
@@ -647,9 +654,15 @@ __device__ __forceinline__ void sweep_body(EvalArgs a, bool copyTable) {
       //  barrier, which no wave passes before every wave has read here)
       vdump[K * kThreads + tid] = hW;
       vdump[(K + 1) * kThreads + tid] = accL;
-      if constexpr (kWatch) { if (poleRows != 0 && lane == 0) atomicOr(&susWords[qpar], poleRows); }   // (rare)
+      if constexpr (kWatch) {                                   // (rare)
+        if (quarterRows != 0 && lane == 0) { atomicOr(&susWords[2 + qpar], quarterRows); if (poleRows != 0) atomicOr(&susWords[qpar], poleRows); }
+      }
       __syncthreads();
-      if constexpr (kWatch) suspect = a.poleList != nullptr && susWords[qpar] != 0;
+      uint32_t wideRows = 0;                                     // workgroup-uniform: the rows with an element of a quarter
+      if constexpr (kWatch) {
+        suspect = a.poleList != nullptr && susWords[qpar] != 0;
+        wideRows = a.poleList != nullptr ? susWords[2 + qpar] : 0u;
+      }
       // every 32 lanes take one of the K + 2 sums: threads/32 partials each, then a 32-lane butterfly
       constexpr int kGroups = kThreads / 32;
       const int l32 = tid & 31;
@@ -664,12 +677,19 @@ __device__ __forceinline__ void sweep_body(EvalArgs a, bool copyTable) {
         acc += mov_dpp<kDppMirror>(acc);
         const Pair p = swap16(acc);
         acc = p.a + p.b;
+        if constexpr (kWatch) {                                  // (a row whose velocity sum all but vanishes, with an element of a quarter: pole_device.h)
+          if (l32 == 0 && r < K && acc <= kSmallV && ((wideRows >> (r < 31 ? r : 31)) & 1u)) atomicOr(&susWords[qpar], 1u << (r < 31 ? r : 31));
+        }
         if (r < K) acc = rec[r] * sqrt(acc);                   // :156-157
         if (l32 == 0) rec[K + r] = acc;
       }
+      if constexpr (kWatch) {
+        if (wideRows != 0) { __syncthreads(); suspect = susWords[qpar] != 0; }   // (the bits the other waves' lanes have just set)
+      }
       if (tid == 0) {
         reinterpret_cast<int64_t *>(rec)[2 * K + 2] = q;
-        susWords[qpar ^ 1] = 0;                                // (the other parity's flag: read by everybody before this question's barrier, set again only behind the next question's)
+        susWords[qpar ^ 1] = 0;                                // (the other parity's flags: read by everybody before this question's barrier, set again only behind the next question's)
+        susWords[2 + (qpar ^ 1)] = 0;
         if (suspect) pole_list_append(a.poleList, (uint32_t)(q - a.qFirst), K <= 31 ? susWords[qpar] : 0u, 0u);
       }
       if (suspect) {
@@ -688,20 +708,31 @@ __device__ __forceinline__ void sweep_body(EvalArgs a, bool copyTable) {
         part[K * WPQ + wave] = hW;
         part[(K + 1) * WPQ + wave] = accL;
       }
-      if constexpr (kWatch) { if (poleRows != 0 && lane == 0) atomicOr(&susWords[qpar], poleRows); }   // (rare)
+      if constexpr (kWatch) {                                   // (rare)
+        if (quarterRows != 0 && lane == 0) { atomicOr(&susWords[2 + qpar], quarterRows); if (poleRows != 0) atomicOr(&susWords[qpar], poleRows); }
+      }
       if constexpr (WPQ > 1) __syncthreads();
-      if constexpr (kWatch) suspect = a.poleList != nullptr && susWords[qpar] != 0;
+      uint32_t wideRows = 0;
+      if constexpr (kWatch) {
+        suspect = a.poleList != nullptr && susWords[qpar] != 0;
+        wideRows = a.poleList != nullptr ? susWords[2 + qpar] : 0u;
+      }
       if (wave == 0) {
         // combine the waves' partials in wave order, one partial row per lane, and queue the question
         for (int r = lane; r < nPart; r += kWave) {
           double acc = part[r * WPQ];
           for (int w2 = 1; w2 < WPQ; w2++) acc += part[r * WPQ + w2];
+          if constexpr (kWatch) {                                // (a row whose velocity sum all but vanishes, with an element of a quarter)
+            if (r < K && acc <= kSmallV && ((wideRows >> (r < 31 ? r : 31)) & 1u)) atomicOr(&susWords[qpar], 1u << (r < 31 ? r : 31));
+          }
           if (r < K) acc = rec[r] * sqrt(acc);                   // :156-157, one answer per lane
           rec[K + r] = acc;
         }
+        if constexpr (kWatch) { if (wideRows != 0) suspect = susWords[qpar] != 0; }   // (this wave's own atomics: in order)
         if (lane == 0) {
           reinterpret_cast<int64_t *>(rec)[2 * K + 2] = q;
           susWords[qpar ^ 1] = 0;
+          susWords[2 + (qpar ^ 1)] = 0;
           if (suspect) pole_list_append(a.poleList, (uint32_t)(q - a.qFirst), K <= 31 ? susWords[qpar] : 0u, 0u);
         }
         if (suspect)   // (the record is this wave's own work: no barrier)
@@ -929,10 +960,10 @@ __global__ __launch_bounds__(256) void eval_questions_f64_stream(EvalArgs a) {
   double *wkAll = redW + 2 * WPQ;
   double *partAll = wkAll + 2 * K;
   const int nPart = (int)(K + 2);
-  uint32_t *watchWords = reinterpret_cast<uint32_t *>(partAll + 2 * nPart * WPQ);   // by question parity: the rows that passed the pole watch
+  uint32_t *watchWords = reinterpret_cast<uint32_t *>(partAll + 2 * nPart * WPQ);   // by question parity: the rows that passed the pole watch [0], [1], its wider form [2], [3]
   const int tid = threadIdx.x, lane = tid % kWave, wave = tid / kWave;
   for (int i = tid; i < kLog2TableDoubles; i += kThreads) tbl[i] = gLog2Table[i];
-  if (tid < 2) watchWords[tid] = 0;
+  if (tid < 4) watchWords[tid] = 0;
   __syncthreads();
   const int64_t qStride = (K + 1) * ldT;
   const int64_t nPairs = ldT >> 1;
@@ -950,7 +981,7 @@ __global__ __launch_bounds__(256) void eval_questions_f64_stream(EvalArgs a) {
     double *wk = wkAll + qpar * K;
     double *part = partAll + qpar * (nPart * WPQ);
     double accL = 0, hW = 0;
-    uint32_t poleRows = 0;
+    uint32_t poleRows = 0, quarterRows = 0;
     for (int64_t k = 0; k < K; k++) {
       const double2 *rowA = reinterpret_cast<const double2 *>(qBase + k * ldT);
       double s0 = 0, c0 = 0, s1 = 0, c1 = 0;
@@ -981,8 +1012,11 @@ __global__ __launch_bounds__(256) void eval_questions_f64_stream(EvalArgs a) {
         Wk = row_sum<WPQ>(buf[lane % WPQ]);
         phase ^= 1;
       }
-      // the pole watch (see sweep_body): a lane that holds nearly all of W_k
-      if (watch && __any(sLane >= Wk * kNearOneShare && sLane > 0.0)) poleRows |= 1u << (k < 31 ? (int)k : 31);
+      // the pole watch (see sweep_body): a lane that holds a quarter / nearly all of W_k
+      if (watch && __any(sLane >= Wk * kQuarterShare && sLane > 0.0)) {
+        quarterRows |= 1u << (k < 31 ? (int)k : 31);
+        if (__any(sLane >= Wk * kNearOneShare)) poleRows |= 1u << (k < 31 ? (int)k : 31);
+      }
       const double invWk = div_nr(1.0, Wk);
       double v = 0;
       for (int64_t p = tid; p < nPairs; p += kThreads) {
@@ -1008,19 +1042,21 @@ __global__ __launch_bounds__(256) void eval_questions_f64_stream(EvalArgs a) {
     if (lane == 0) {
       part[K * WPQ + wave] = hW;
       part[(K + 1) * WPQ + wave] = accL;
-      if (poleRows != 0) atomicOr(&watchWords[qpar], poleRows);
+      if (quarterRows != 0) { atomicOr(&watchWords[2 + qpar], quarterRows); if (poleRows != 0) atomicOr(&watchWords[qpar], poleRows); }
     }
     __syncthreads();
     if (tid == 0) {
       for (int r = 0; r < nPart; r++) {
         double acc = part[r * WPQ];
         for (int w2 = 1; w2 < WPQ; w2++) acc += part[r * WPQ + w2];
+        if (r < K && acc <= kSmallV && ((watchWords[2 + qpar] >> (r < 31 ? r : 31)) & 1u)) watchWords[qpar] |= 1u << (r < 31 ? r : 31);   // (a vanishing velocity sum: pole_device.h)
         part[r] = r < K ? wk[r] * sqrt(acc) : acc;
       }
       const double pri = eval_epilogue(wk, -part[K], part, K, part[K + 1], a.vCompTail);
       store_priority(a.priority + (q - a.qFirst), pri);
       best_offer(best, pri, q - a.qFirst);
       watchWords[qpar ^ 1] = 0;                                // (set again only behind the next question's barriers)
+      watchWords[2 + (qpar ^ 1)] = 0;
       if (watch && watchWords[qpar] != 0) {
         // the question's sums as they are, for the fix behind the sweep (pole_kernels.hip)
         double *ps = a.poleScratch + (q - a.qFirst) * (2 * K + 2);

@@ -16,6 +16,13 @@ namespace pqa {
 // p's last place (1.1e-16) is 1e-8 of it at p = 1 - 4e-5, where the likeliest answer's velocity is a sixth of the question's:
 // 1.3e-9 of the priority (tests/test_gpu_late.py: the first cases that found it).  At 1 - 2^-10 both are below 1e-11.
 constexpr uint32_t kNearOneHi = 0x3FEFF800u;   // high word of 1 - 2^-10
+// The velocity term again, further out still: an answer that tells a question's targets apart by less than one part in 10^5 -- the
+// near-certain answer of a late quiz, or of a question with few answers -- leaves the posterior where the prior was, and the
+// row's velocity sum V_k = sum (p - prior)^2 is then the square of ONE difference |d| ~ sqrt(V_k) carrying p's last place:
+// 2.2e-16 / sqrt(V_k) relative.  Rows with V_k <= kSmallV whose largest element holds at least a quarter of the mass (below that no
+// single difference makes up the sum) are redone as well: what is left is below 1.1e-11 of a row's velocity.
+constexpr double kSmallV = 4e-10;
+constexpr uint32_t kQuarterHi = 0x3FCE0000u;   // high word of 0.234: the element of a listed row whose terms are corrected
 
 // a sweep's entry for a question that passed its watch (pqa_kernels.h: PoleHeader; one thread)
 __device__ __forceinline__ uint32_t pole_list_append(PoleHeader *list, uint32_t q, uint32_t rowMask, uint32_t b) {

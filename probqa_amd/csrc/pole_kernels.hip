@@ -239,7 +239,7 @@ __global__ __launch_bounds__(kFixThreads) __attribute__((amdgpu_waves_per_eu(PQA
           const double invWx = div_nr(1.0, Wx);                // :91
           const double pRef = cand * invWx;                    // :97
           double dH = 0.0, dL = 0.0;
-          if (cand > 0.0 && (uint32_t)(d2u(pRef) >> 32) >= kNearOneHi) {
+          if (cand > 0.0 && (uint32_t)(d2u(pRef) >> 32) >= kQuarterHi) {     // (the row is listed: next to 1, or a quarter and a vanishing velocity sum)
             const double dAt = rowD[candT], prh = prior[candT];   // (one round trip for both)
             const double Wf = recW[kk];                        // the sweep's W_k
             const double pFast = cand * div_nr(1.0, Wf);       // what pass 2 took for this element
