@@ -241,8 +241,8 @@ __device__ __forceinline__ void pass2_pair(double2 lh, double2 id, double2 pr, d
 // EVERY state: the blocks between pass 1 and pass 2 cost the loop its registers), the fix as a called function (+13 %: scratch).
 // ------------------------------------------------------------------------------------------------------------------
 constexpr double kNearOneShare = 1.0 - 0x1p-9;   // (of the wave's sum, of W_k: see above; the bar is pole_device.h: kNearOneHi)
-constexpr double kQuarterShare = 0.25;           // ... and the wider watch for rows with a vanishing velocity sum (pole_device.h: kSmallV)
-constexpr int kSusDoubles = 2;                 // LDS: two words (by question parity: the answer rows that passed the watch, a bit each) + a slot
+constexpr double kQuarterShare = 0.2499;         // ... and the wider watch (a strict compare: a wave of padding lanes, all sums 0, does not pass) for rows with a vanishing velocity sum (pole_device.h: kSmallV)
+constexpr int kSusDoubles = 3;                 // LDS: two words (by question parity: the answer rows that passed the watch, a bit each) + a slot
 
 // LDS-DMA: 16 bytes per lane from global memory straight into LDS, no destination VGPRs (buffer_load_dwordx4 ... offen lds:
 // row base in an SGPR descriptor, the lane's 32-bit byte offset in a VGPR -- no 64-bit address pairs either); completion is
@@ -605,7 +605,7 @@ __device__ __forceinline__ void sweep_body(EvalArgs a, bool copyTable) {
       bool watchHit = false, watchNear = false;               // (wave-uniform: a lane of this wave holds a quarter / nearly all of the wave's sum)
       double waveW = 0.0;
       if constexpr (kWatch) {
-        watchHit = __any(sLane >= Wk * kQuarterShare && sLane > 0.0);
+        watchHit = __any(sLane > Wk * kQuarterShare);
         if (watchHit) {
           waveW = uniform_double(Wk);                            // (in scalar registers across the exchange)
           watchNear = __any(sLane >= Wk * kNearOneShare);
@@ -690,12 +690,14 @@ __device__ __forceinline__ void sweep_body(EvalArgs a, bool copyTable) {
         reinterpret_cast<int64_t *>(rec)[2 * K + 2] = q;
         susWords[qpar ^ 1] = 0;                                // (the other parity's flags: read by everybody before this question's barrier, set again only behind the next question's)
         susWords[2 + (qpar ^ 1)] = 0;
-        if (suspect) pole_list_append(a.poleList, (uint32_t)(q - a.qFirst), K <= 31 ? susWords[qpar] : 0u, 0u);
+        if (suspect) susWords[4] = pole_list_append(a.poleList, (uint32_t)(q - a.qFirst), K <= 31 ? susWords[qpar] : 0u, a.slots != nullptr ? blockIdx.y : 0u);
       }
       if (suspect) {
-        // the question's sums as they are, for the fix behind the sweep (the question is queued like any other: its priority stands until then)
+        // the question's sums as they are, for the fix behind the sweep (the question is queued like any other: its priority stands until
+        // then): by question, or -- the quizzes of a grid.y launch share the buffer -- by its entry in the list
         __syncthreads();
-        for (int i = tid; i < 2 * (int)K + 2; i += kThreads) a.poleScratch[(q - a.qFirst) * (2 * K + 2) + i] = rec[i];
+        const int64_t at = a.slots != nullptr ? (int64_t)susWords[4] : q - a.qFirst;
+        for (int i = tid; i < 2 * (int)K + 2; i += kThreads) a.poleScratch[at * (2 * K + 2) + i] = rec[i];
       }
       if (nPend + 1 == kPend) {
         __syncthreads();                                       // the records of other waves
@@ -733,10 +735,12 @@ __device__ __forceinline__ void sweep_body(EvalArgs a, bool copyTable) {
           reinterpret_cast<int64_t *>(rec)[2 * K + 2] = q;
           susWords[qpar ^ 1] = 0;
           susWords[2 + (qpar ^ 1)] = 0;
-          if (suspect) pole_list_append(a.poleList, (uint32_t)(q - a.qFirst), K <= 31 ? susWords[qpar] : 0u, 0u);
+          if (suspect) susWords[4] = pole_list_append(a.poleList, (uint32_t)(q - a.qFirst), K <= 31 ? susWords[qpar] : 0u, a.slots != nullptr ? blockIdx.y : 0u);
         }
-        if (suspect)   // (the record is this wave's own work: no barrier)
-          for (int i = lane; i < 2 * (int)K + 2; i += kWave) a.poleScratch[(q - a.qFirst) * (2 * K + 2) + i] = rec[i];
+        if (suspect) {   // (the record is this wave's own work: no barrier)
+          const int64_t at = a.slots != nullptr ? (int64_t)susWords[4] : q - a.qFirst;
+          for (int i = lane; i < 2 * (int)K + 2; i += kWave) a.poleScratch[at * (2 * K + 2) + i] = rec[i];
+        }
         if (nPend + 1 == kPend) flush_pending(a, pend, kPend, lane, bestLds[lane]);
       }
     }
@@ -968,7 +972,7 @@ __global__ __launch_bounds__(256) void eval_questions_f64_stream(EvalArgs a) {
   const int64_t qStride = (K + 1) * ldT;
   const int64_t nPairs = ldT >> 1;
   int phase = 0, qpar = 0;
-  const bool watch = a.poleList != nullptr && a.slots == nullptr;
+  const bool watch = a.poleList != nullptr;
   Best best{0.0, -1};
   for (int64_t q = a.qFirst + blockIdx.x; q < a.qLimit; q += gridDim.x) {
     if (bit_test(a.qgap, q) || bit_test(a.asked, q)) {
@@ -1013,7 +1017,7 @@ __global__ __launch_bounds__(256) void eval_questions_f64_stream(EvalArgs a) {
         phase ^= 1;
       }
       // the pole watch (see sweep_body): a lane that holds a quarter / nearly all of W_k
-      if (watch && __any(sLane >= Wk * kQuarterShare && sLane > 0.0)) {
+      if (watch && __any(sLane > Wk * kQuarterShare)) {
         quarterRows |= 1u << (k < 31 ? (int)k : 31);
         if (__any(sLane >= Wk * kNearOneShare)) poleRows |= 1u << (k < 31 ? (int)k : 31);
       }
@@ -1059,11 +1063,11 @@ __global__ __launch_bounds__(256) void eval_questions_f64_stream(EvalArgs a) {
       watchWords[2 + (qpar ^ 1)] = 0;
       if (watch && watchWords[qpar] != 0) {
         // the question's sums as they are, for the fix behind the sweep (pole_kernels.hip)
-        double *ps = a.poleScratch + (q - a.qFirst) * (2 * K + 2);
+        const uint32_t at = pole_list_append(a.poleList, (uint32_t)(q - a.qFirst), K <= 31 ? watchWords[qpar] : 0u, a.slots != nullptr ? blockIdx.y : 0u);
+        double *ps = a.poleScratch + (a.slots != nullptr ? (int64_t)at : q - a.qFirst) * (2 * K + 2);
         for (int r = 0; r < K; r++) { ps[r] = wk[r]; ps[K + r] = part[r]; }
         ps[2 * K] = part[K];
         ps[2 * K + 1] = part[K + 1];
-        pole_list_append(a.poleList, (uint32_t)(q - a.qFirst), K <= 31 ? watchWords[qpar] : 0u, 0u);
       }
     }
     qpar ^= 1;
@@ -1319,7 +1323,7 @@ constexpr size_t eval_base_lds_bytes(int64_t K, int64_t ldT) {
 
 // The fix behind a watching single-quiz sweep (pole_kernels.hip): the questions in the launch's suspect list, their sums in
 // poleScratch as the sweep left them -- W_k [K] | W_k sqrt(V_k) [K] | sum l log2 p | lack sum.
-hipError_t launch_pole_fixup(const EvalArgs &args, hipStream_t stream) {
+hipError_t launch_pole_fixup(const EvalArgs &args, hipStream_t stream, int nBatch = 1) {
   PoleFix f{};
   f.cube = args.cube; f.tgap = args.tgap; f.qgap = args.qgap; f.asked = args.asked; f.prior = args.prior;
   f.list = args.poleList; f.sums = args.poleScratch; f.sumsStride = 2 * args.K + 2;
@@ -1330,6 +1334,11 @@ hipError_t launch_pole_fixup(const EvalArgs &args, hipStream_t stream) {
   f.vCompTail = args.vCompTail;
   f.fs = args.fs;
   if (args.fs.scratch != nullptr && args.fs.sampleSubtasks > 0 && args.fs.hostPriority != nullptr) { f.hostPriority = args.fs.hostPriority; f.hostTag = args.fs.seqValue; }
+  if (args.slots != nullptr) {   // a grid.y = quiz launch: the records by entry, every quiz's own vectors, and every quiz's publication
+    f.slots = args.slots; f.nSlots = nBatch; f.bySlot = 1; f.prior = nullptr; f.asked = nullptr; f.priority = nullptr;
+    f.capacity = f.nQ * (int64_t)nBatch;
+    f.hostTag = args.fs.seqValue;
+  }
   return LaunchPoleFixup(f, stream);
 }
 
@@ -1370,7 +1379,7 @@ hipError_t launch_reg_form(const EvalArgs &args, int64_t nQ, int nBatch, hipStre
   if (args.maxGrid > 0 && resGrid > args.maxGrid) resGrid = args.maxGrid;   // (test hook: KbView::maxGrid)
   hipLaunchKernelGGL(kern, dim3((unsigned)resGrid, (unsigned)nBatch), dim3(WPQ * 64), shmem, stream, args);
   const hipError_t le = hipGetLastError();
-  if constexpr (POLE) { if (le == hipSuccess) return launch_pole_fixup(args, stream); }
+  if constexpr (POLE) { if (le == hipSuccess) return launch_pole_fixup(args, stream, nBatch); }
   return le;
 }
 
@@ -1428,7 +1437,7 @@ hipError_t launch_variant(const EvalArgs &args, int64_t ldT, int variant, int nB
       const unsigned grid = (unsigned)(nQ < maxBlocks ? nQ : maxBlocks);
       hipLaunchKernelGGL(eval_questions_f64_stream, dim3(grid, (unsigned)nBatch), dim3(256), shmem, stream, args);
       const hipError_t le = hipGetLastError();
-      if (le == hipSuccess && args.poleList != nullptr && args.slots == nullptr) return launch_pole_fixup(args, stream);
+      if (le == hipSuccess && args.poleList != nullptr) return launch_pole_fixup(args, stream, nBatch);
       return le;
     }
     default: return hipErrorInvalidValue;
@@ -1529,15 +1538,28 @@ hipError_t LaunchEvalQuestionsWithUpdate(const KbView &kb, double *prior, uint32
   return le;
 }
 
+size_t EvalBatchPoleBytes(const KbView &kb, int nSlots) {
+  if (kb.elem != 8 || kb.poleList == nullptr) return 0;
+  const size_t cap = (size_t)kb.Q * (size_t)nSlots;
+  return kBatchPoleClear + cap * sizeof(PoleEntry) + cap * (size_t)(2 * kb.K + 2) * sizeof(double);
+}
+
 hipError_t LaunchEvalQuestionsBatch(const KbView &kb, const QuizSlot *slots, int nSlots, int64_t qFirst, int64_t qLimit,
-                                    int variant, const FusedSelect &fused, hipStream_t stream) {
+                                    int variant, const FusedSelect &fused, hipStream_t stream, void *pole) {
   if (qLimit <= qFirst || nSlots <= 0) return hipSuccess;
   if (slots == nullptr || fused.scratch == nullptr || fused.scratchStride <= 0) return hipErrorInvalidValue;
   EvalArgs args = make_args(kb, qFirst, qLimit);
   args.fs = fused;
   args.slots = slots;
-  args.poleScratch = nullptr;   // (one buffer per engine, not per quiz of a batch: the quizzes of a grid.y launch keep the sweep's own sums at the pole)
+  // the pole watch of a grid.y launch: one list for the batch's quizzes (an entry names its quiz), the records by entry; without the
+  // caller's buffer the quizzes keep the sweep's own sums
+  args.poleScratch = nullptr;
   args.poleList = nullptr;
+  if (pole != nullptr && kb.poleList != nullptr && qFirst == 0 && qLimit == kb.Q) {
+    char *p = static_cast<char *>(pole);
+    args.poleList = reinterpret_cast<PoleHeader *>(p + 256 * sizeof(uint32_t));
+    args.poleScratch = reinterpret_cast<double *>(p + kBatchPoleClear + (size_t)kb.Q * (size_t)nSlots * sizeof(PoleEntry));
+  }
   return launch_variant(args, kb.ldT, variant, nSlots, stream);
 }
 

@@ -356,7 +356,7 @@ Error HipEngine::BatchSweep(BatchCtx &c, int64_t n, const int64_t *pQuizzes, std
   // to 8 / 16 / 32 quizzes (its lanes come in 8, 16 or 32 quiz slots) and 6.2 us per slot of 64 beyond: it wins at 7 and 8 quizzes and from
   // 11 on, except 17 and 18.
   bool mid = EvalMidBatchSupported(View()) && ((_optBatchForm == 0 && !rowSharing && (n == 7 || n == 8 || (n >= 11 && n <= 16) || n >= 19)) || _optBatchForm == 3);
-  if (_optBatchForm == 1 && _elem == 8 && !wantPriorities) { rowSharing = false; mid = false; }
+  if (_optBatchForm == 1 && _elem == 8) { rowSharing = false; mid = false; }   // (with priorities wanted too: the quizzes' own vectors, CollectBatchPriorities)
   if (_optBatchForm == 2) { rowSharing = true; mid = false; }
   if (mid) rowSharing = false;
   if (hostPriorities) {
@@ -456,10 +456,16 @@ Error HipEngine::BatchSweep(BatchCtx &c, int64_t n, const int64_t *pQuizzes, std
     c.lastBp = plan.Bp;
     return Error();
   }
+  c.lastBp = 0;   // (0: the quizzes' priorities are their own vectors in dPriority, not a matrix)
   if (!rowSharing) {
     const FusedSelect fs{c.dScratch, nullptr, nullptr, tag, 0, kBatchGrid, tag, nullptr, tagged ? 1 : 0, 0, nullptr,
                          tagged ? reinterpret_cast<TaggedPriority *>(c.hPri) : nullptr};
-    HIP_TRY(LaunchEvalQuestionsBatch(View(), c.dSlots, (int)n, 0, _Q, (int)_optEvalVariant, fs, _stream));
+    // (the batch's suspect list and records -- pole_kernels.hip: grown with the batch, the head cleared once)
+    const KbView kbv = View();
+    BatchPlan pp{};
+    pp.poleBytes = EvalBatchPoleBytes(kbv, (int)n);
+    HIP_TRY(growPole(pp));
+    HIP_TRY(LaunchEvalQuestionsBatch(kbv, c.dSlots, (int)n, 0, _Q, (int)_optEvalVariant, fs, _stream, pp.pole));
     if (hostPriorities && !tagged) return copyToHost(c.dPriority, (size_t)n * (size_t)_Q);
     return Error();
   }
@@ -545,6 +551,11 @@ Error HipEngine::CollectBatchPrioritiesLocked(int64_t n, double *pOut) {
   if (!pOut) return Error::Make(ErrCode::NullArgument, "Nullptr is passed in place of a batch buffer.");
   hipSetDevice(_device);
   BatchCtx &c = _ctx[0];
+  if (c.lastBp == 0) {   // grid.y = quiz: every quiz's own vector
+    HIP_TRY(hipMemcpyAsync(pOut, c.dPriority, (size_t)n * (size_t)_Q * sizeof(double), hipMemcpyDeviceToHost, _stream));
+    HIP_TRY(hipStreamSynchronize(_stream));
+    return Error();
+  }
   std::vector<double> host((size_t)_Q * (size_t)c.lastBp);
   HIP_TRY(hipMemcpyAsync(host.data(), c.dPriT, host.size() * sizeof(double), hipMemcpyDeviceToHost, _stream));
   HIP_TRY(hipStreamSynchronize(_stream));

@@ -351,6 +351,36 @@ __global__ __launch_bounds__(kFixThreads) __attribute__((amdgpu_waves_per_eu(PQA
       }
     }
   }
+  if (a.fs.scratch != nullptr && a.slots != nullptr && a.nSlots > 0) {
+    // a grid.y = quiz launch: every quiz's result (the finishers that saw the list empty have published theirs already -- the same)
+    const bool handOver = a.fs.sampleSubtasks > 0;            // (the priorities went to the host as tagged records: the flags only)
+    for (int b = wave; b < a.nSlots; b += kFixThreads / kWave) {
+      const QuizSlot qs = a.slots[b];
+      Best best{0.0, -1};
+      if (!handOver) {
+        for (int64_t j = lane; j < a.nQ; j += kWave) {
+          const int64_t q = a.qFirst + j;
+          if (bit_test(a.qgap, q) || bit_test(qs.asked, q)) continue;
+          double p = __hip_atomic_load(qs.priority + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (p != p) p = -__builtin_huge_val();
+          best_merge(best, p, j);
+        }
+        for (int m = kWave / 2; m >= 1; m >>= 1) {
+          const double op = __shfl_xor(best.p, m, kWave);
+          const int64_t oi = __shfl_xor(best.i, m, kWave);
+          best_merge(best, op, oi);
+        }
+      }
+      if (lane == 0) {
+        qs.out->priority = handOver || best.i < 0 ? 0.0 : best.p;
+        qs.out->index = handOver ? 0 : best.i < 0 ? -1 : best.i + a.fs.outBase;
+        if (qs.seq != nullptr) {
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+          __hip_atomic_store(qs.seq, a.fs.flagValue, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+      }
+    }
+  }
   if (tid == 0) {
     a.list->arrived = 0;
     __hip_atomic_store(&a.list->count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

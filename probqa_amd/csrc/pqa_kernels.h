@@ -140,6 +140,7 @@ struct PoleFix {
   const uint32_t *tgap, *qgap, *asked;
   const double *prior;            // single quiz
   const QuizSlot *slots;          // batched sweeps: entry.b selects the quiz
+  int nSlots;                     // ... of a grid.y = quiz launch (fs set): this launch publishes every quiz's result when it has work
   PoleHeader *list;
   uint32_t *maskDense;            // optional [nQ]: the rows per question where several workgroups watch one question (cleared here)
   uint32_t *dirty;                // optional [quizzes]: set to 1 for every quiz with a corrected priority (batched sweeps: the pick reads it)
@@ -158,8 +159,11 @@ struct PoleFix {
 hipError_t LaunchPoleFixup(const PoleFix &fix, hipStream_t stream);
 // The same sweep for nSlots quizzes in one launch (grid.y = quiz): `slots` is a DEVICE array; fused->scratch holds
 // nSlots * fused->scratchStride records; fused->out / seq are ignored (each slot has its own).
+// pole (optional): EvalBatchPoleBytes(kb, nSlots) bytes of device memory, the first kBatchPoleClear cleared once after allocation -- the
+// batch's suspect list and records (pole_kernels.hip); without it the quizzes of the launch keep the sweep's own sums at the pole.
+size_t EvalBatchPoleBytes(const KbView &kb, int nSlots);
 hipError_t LaunchEvalQuestionsBatch(const KbView &kb, const QuizSlot *slots, int nSlots, int64_t qFirst, int64_t qLimit,
-                                    int variant, const FusedSelect &fused, hipStream_t stream);
+                                    int variant, const FusedSelect &fused, hipStream_t stream, void *pole = nullptr);
 // ---- many quizzes per sweep, one cube read per batch (batch_kernels.hip): lane = quiz, the cube tile staged in LDS is shared by
 // all quizzes of the batch.  Double and Float engines.  nSlots <= 256.
 constexpr int kBatchMaxGrid = 2048;

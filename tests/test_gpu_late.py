@@ -10,7 +10,7 @@ consistently 4 - 8 questions deep -- "it is the target" / "just below" / "just a
 hidden target by a factor of a few hundred per answer.  Legs: every register shape for rows beyond 4096 targets (the defaults by
 row length and the forced ones), the short-row shapes with one or two workgroups streaming more questions than the in-kernel fix
 lists, the streaming fallback, both cluster forms (rows of 20000 / 50000 targets), the (quiz, chunk) and row-sharing batched
-sweeps, the quiz-per-grid.y launches and the resident sweep (picks).  Every step of every case is held to 1e-9 against the oracle;
+sweeps, the quiz-per-grid.y launches, and the resident sweep (picks).  Every step of every case is held to 1e-9 against the oracle;
 the posterior stays bit-identical; the argmax and the reference's sampled selector pick the oracle's questions.
 
 `pytest -m gpu tests/test_gpu_late.py --late N [--late-first SEED]` runs N more cases than the suite's own."""
@@ -120,7 +120,7 @@ def batched_states(case, factory, form, n_extra):
             eng.record_answer(quiz, a)
         quizzes.append(quiz)
         hists.append(hist)
-    pri = eng.eval_priorities_batch(quizzes, case.Q) if form != 1 else None
+    pri = eng.eval_priorities_batch(quizzes, case.Q)
     picks = eng.next_question_argmax_batch(quizzes)
     worst, seen = 0.0, {}
     for j in range(n):
