@@ -2,6 +2,7 @@
 // Shims follow reference ProbQA/PqaCore/PqaCInterop.cpp:45-408 (AssignPqaError / ReturnPqaError and its three null-handle
 // conventions: return an error object, set *ppError, or log and return 0); declarations are in include/PqaCInterop.h and
 // include/PqaHipExt.h.
+#include <sched.h>
 #include <atomic>
 #include <chrono>
 #include <cmath>
@@ -480,10 +481,11 @@ PQACORE_API void *PqaHip_PickWhenAll(const void *pSlots, const int64_t world, co
   for (int64_t r = 0; r < world; r++) {
     const volatile uint64_t *flag = (const volatile uint64_t *)(base + r * strideBytes + 16);
     uint64_t spins = 0;
-    while (*flag != flagValue) {
-      if ((++spins & 0x3FFF) == 0 &&
-          std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeoutSec)
+    while (*flag != flagValue) {   // (a pure spin while the answer is a kernel's time away, then the core is offered between looks)
+      if (++spins < 1500) { __builtin_ia32_pause(); continue; }
+      if ((spins & 0xFF) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeoutSec)
         return ReturnErr(Error::MakeP(ErrCode::StdException, "rank=" + std::to_string(r), "Timed out waiting for a shard's selection."));
+      sched_yield();
     }
   }
   std::atomic_thread_fence(std::memory_order_acquire);

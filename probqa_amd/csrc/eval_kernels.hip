@@ -27,14 +27,7 @@
 namespace pqa {
 
 static __device__ double gLog2Table[kLog2TableDoubles];  // {log2(midpoint), 1/(2*midpoint)} per bucket
-// Entry 0 as the REFERENCE has it (SRVectMath.cpp:31,42: log2 of bucket 0's midpoint times 9.9999999999999927e-01); the table's
-// own entry 0 is re-seated for the division-free log2hot (hip_engine.cpp).  Used by log2hot_ref below.
-static __device__ double gLog2Entry0Ref;
-
 hipError_t UploadLog2Table(const double *hostTable) {
-  const double entry0 = std::log2(1.0 + 0x1p-11) * 9.9999999999999927e-01;
-  const hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(gLog2Entry0Ref), &entry0, sizeof(double));
-  if (e != hipSuccess) return e;
   return hipMemcpyToSymbol(HIP_SYMBOL(gLog2Table), hostTable, kLog2TableDoubles * sizeof(double));
 }
 

@@ -320,7 +320,7 @@ Error HipEngine::SetOption(const char *name, int64_t value) {
   if (n == "select") { if (value != 0 && value != 1) goto bad; _optSelect = value; }
   else if (n == "combine") { _optCombine = value ? 1 : 0; }
   else if (n == "combine_spin") { _optCombineSpin = value ? 1 : 0; }
-  else if (n == "pole_fix") { StopServer(); _optPoleFix = value ? 1 : 0; _kbVersion++; }   // 0: questions with a row at the pole of the lack term keep the sweep's own sums (eval_kernels.hip: pole_fix)
+  else if (n == "pole_fix") { StopServer(); _optPoleFix = value ? 1 : 0; _kbVersion++; }   // 0: questions with a row at the pole of the lack term keep the sweep's own sums (pole_kernels.hip)
   else if (n == "long_row_form") { _optLongRowForm = value ? 1 : 0; }   // 0: the one-workgroup posterior kernels for rows beyond 16384 targets too
   else if (n == "fuse_update") { _optFuseUpdate = value ? 1 : 0; }   // RecordAnswer's posterior update inside the speculative sweep's launch
   else if (n == "post_always") { _optPostAlways = value ? 1 : 0; }   // test hook: RecordAnswer / ListTopTargets always as posted operations
@@ -482,7 +482,17 @@ void HipEngine::DestroyQuiz(Quiz *q) {
   ServerQuiesce();
   if (!q) return;
   while (q->inSelection.load(std::memory_order_acquire)) _mm_pause();   // (a NextQuestion of this quiz is selecting on another thread: a client's error, waited out)
-  if (q->updatePending) (void)FlushUpdates();   // (its kernel works on the buffers that go back to the pool)
+  if (q->updatePending) {   // (its kernel works on the buffers that go back to the pool)
+    (void)FlushUpdates();
+    // a launch that failed has put the updates back (hip_engine_update.cpp: requeue): this quiz's entries name buffers that are
+    // about to be freed or pooled -- they go, whatever happens to the others
+    if (q->updatePending) {
+      _pendingUpdates.erase(std::remove_if(_pendingUpdates.begin(), _pendingUpdates.end(), [q](const PendingUpdate &u) { return u.q == q; }),
+                            _pendingUpdates.end());
+      _pendingCount.store(_pendingUpdates.size(), std::memory_order_relaxed);
+      q->updatePending = false;
+    }
+  }
   if (q->pin != nullptr) {
     if (_pendingRecordFlag == &q->pin->topFlag) { _pendingRecordOp = 0; _pendingRecordFlag = nullptr; _mu.busy = true; }
     _pinFree.push_back(q->pin);

@@ -316,12 +316,12 @@ int64_t HipEngine::SelectFromPriorities(SelRequest *r) {
     // (the quiz's flag said that every workgroup had reported, not that every one of its stores had landed: an entry is taken
     //  once it carries the launch's tag -- it almost always does by now)
     const volatile double *rec = r->pri;
-    const auto t0 = std::chrono::steady_clock::now();
+    SpinWait w;
     for (int64_t k = 0; k < nQ; k++) {
       if (skip(k)) { run[(size_t)k] = 0.0; continue; }
       const volatile uint64_t *tagWord = reinterpret_cast<const volatile uint64_t *>(rec + 2 * k + 1);
-      for (uint64_t spins = 0; *tagWord != r->priTag;)
-        if ((++spins & 0xFFFF) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(30)) {
+      while (*tagWord != r->priTag)
+        if (!w.Tick(std::chrono::seconds(30))) {
           r->err = HipErr(hipErrorNotReady, "priority vector hand-over (combined sweep)");
           q->inSelection.store(false, std::memory_order_release);
           return r->result = -1;

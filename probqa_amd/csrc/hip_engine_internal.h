@@ -5,6 +5,7 @@
 
 #include <immintrin.h>
 #include <linux/futex.h>
+#include <sched.h>
 #include <sys/prctl.h>
 #include <sys/syscall.h>
 #include <time.h>
@@ -70,6 +71,21 @@ inline void PublishState(std::atomic<int> *word, int state) {
   FutexWakeOne(word);
 }
 static_assert(sizeof(std::atomic<int>) == sizeof(int), "the state word is slept on as a futex");
+
+// A wait for a word the GPU writes: a pure spin while the answer is a kernel's time away (the first ~50 us), then the core is
+// offered to whoever else wants it between looks (sched_yield) -- a process whose clients outnumber its CPUs otherwise burns its
+// allowance on waiting -- and the clock is read only every so often.  Tick() returns false once `limit` has passed.
+struct SpinWait {
+  uint64_t spins = 0;
+  std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+  bool Tick(std::chrono::seconds limit) {
+    if (++spins < 1500) { _mm_pause(); return true; }
+    if ((spins & 0xFF) == 0 && std::chrono::steady_clock::now() - t0 > limit) return false;
+    sched_yield();
+    return true;
+  }
+  bool Due() const { return (spins & 0xFFF) == 0; }   // (for the occasional look at something else while waiting)
+};
 
 
 }  // namespace

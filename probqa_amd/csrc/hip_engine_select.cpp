@@ -232,13 +232,11 @@ hipError_t HipEngine::EnsureHostPriority() {
 Error HipEngine::CollectHostPriority(uint64_t tag, const Quiz *q) {
   _hostRun.resize((size_t)_Q);
   const volatile TaggedPriority *rec = _hHostPriority;
-  const auto t0 = std::chrono::steady_clock::now();
+  SpinWait w;
   for (int64_t i = 0; i < _Q; i++) {
     if (BitTest(_hQGap, i) || BitTest(q->hAsked, i)) { _hostRun[(size_t)i] = 0.0; continue; }
-    uint64_t spins = 0;
     while (rec[i].tag != tag)
-      if ((++spins & 0xFFFF) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(30))
-        return HipErr(hipErrorNotReady, "priority vector hand-over");
+      if (!w.Tick(std::chrono::seconds(30))) return HipErr(hipErrorNotReady, "priority vector hand-over");
     std::atomic_thread_fence(std::memory_order_acquire);
     _hostRun[(size_t)i] = rec[i].priority;
   }
@@ -273,15 +271,12 @@ Error HipEngine::WaitFlagNapping(volatile uint64_t *flag, uint64_t value, const 
 }
 
 Error HipEngine::WaitFlag(volatile uint64_t *flag, uint64_t value, const char *what) {
-  const auto t0 = std::chrono::steady_clock::now();
-  uint64_t spins = 0;
+  SpinWait w;
   while (*flag != value) {
-    if ((++spins & 0xFFF) == 0) {
-      if (hipStreamQuery(_stream) == hipSuccess && *flag != value) {  // the kernel retired without publishing
-        const hipError_t he = hipStreamSynchronize(_stream);
-        if (he != hipSuccess || *flag != value) return HipErr(he == hipSuccess ? hipErrorUnknown : he, what);
-      }
-      if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(30)) return HipErr(hipErrorNotReady, what);
+    if (!w.Tick(std::chrono::seconds(30))) return HipErr(hipErrorNotReady, what);
+    if (w.Due() && hipStreamQuery(_stream) == hipSuccess && *flag != value) {  // the kernel retired without publishing
+      const hipError_t he = hipStreamSynchronize(_stream);
+      if (he != hipSuccess || *flag != value) return HipErr(he == hipSuccess ? hipErrorUnknown : he, what);
     }
   }
   std::atomic_thread_fence(std::memory_order_acquire);
@@ -595,18 +590,14 @@ Error HipEngine::SelectArgmaxBatch(int64_t n, const int64_t *pQuizzes, CiHipSele
 }
 
 Error HipEngine::WaitBatchFlags(BatchCtx &c, int64_t n, uint64_t tag) {
-  const auto t0 = std::chrono::steady_clock::now();
+  SpinWait w;
   for (int64_t i = 0; i < n; i++) {
     volatile uint64_t *flag = &c.h->seq[i];
-    uint64_t spins = 0;
     while (*flag != tag) {
-      if ((++spins & 0xFFF) == 0) {
-        if (hipStreamQuery(_stream) == hipSuccess && *flag != tag) {  // the kernel retired without publishing
-          const hipError_t he = hipStreamSynchronize(_stream);
-          if (he != hipSuccess || *flag != tag) return HipErr(he == hipSuccess ? hipErrorUnknown : he, "batched selection (result flag)");
-        }
-        if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(600))
-          return HipErr(hipErrorNotReady, "batched selection (timeout)");
+      if (!w.Tick(std::chrono::seconds(600))) return HipErr(hipErrorNotReady, "batched selection (timeout)");
+      if (w.Due() && hipStreamQuery(_stream) == hipSuccess && *flag != tag) {  // the kernel retired without publishing
+        const hipError_t he = hipStreamSynchronize(_stream);
+        if (he != hipSuccess || *flag != tag) return HipErr(he == hipSuccess ? hipErrorUnknown : he, "batched selection (result flag)");
       }
     }
   }

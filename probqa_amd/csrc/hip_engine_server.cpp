@@ -24,21 +24,17 @@ void HipEngine::StopServer() {
 void HipEngine::ServerQuiesce() {
   if (!_serverLaunched || _serverPosted == 0) return;
   volatile ServerMailbox *mb = _hMailbox;
-  const auto t0 = std::chrono::steady_clock::now();
-  uint64_t spins = 0;
+  SpinWait w;
   while (mb->done != _serverPosted && mb->state != kServerExited)
-    if ((++spins & 0xFFF) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(30)) return;
+    if (!w.Tick(std::chrono::seconds(30))) return;
 }
 
 Error HipEngine::ServerWait(volatile uint64_t *flag, uint64_t value, const char *what) {
-  const auto t0 = std::chrono::steady_clock::now();
-  uint64_t spins = 0;
+  SpinWait w;
   volatile ServerMailbox *mb = _hMailbox;
   while (*flag != value) {
-    if ((++spins & 0xFFF) == 0) {
-      if (mb->state == kServerExited && mb->taken != _serverPosted && *flag != value) return HipErr(hipErrorUnknown, what);
-      if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(30)) return HipErr(hipErrorNotReady, what);
-    }
+    if (!w.Tick(std::chrono::seconds(30))) return HipErr(hipErrorNotReady, what);
+    if (w.Due() && mb->state == kServerExited && mb->taken != _serverPosted && *flag != value) return HipErr(hipErrorUnknown, what);
   }
   std::atomic_thread_fence(std::memory_order_acquire);
   return Error();
@@ -86,13 +82,10 @@ Error HipEngine::ServerPost(Quiz *q, SelectResult *out, uint64_t *flag, uint64_t
   volatile ServerMailbox *mb = _hMailbox;
   // the previous request's fields must have been read before they are overwritten
   if (_serverLaunched && _serverPosted != 0) {
-    const auto t0 = std::chrono::steady_clock::now();
-    uint64_t spins = 0;
+    SpinWait w;
     // (every workgroup reads the line itself when it is in device memory: then not before the step is done)
-    while ((_serverRequestInVram ? mb->done : mb->taken) != _serverPosted && mb->state != kServerExited) {
-      if ((++spins & 0xFFF) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(30))
-        return HipErr(hipErrorNotReady, "ServerPost (previous request never taken)");
-    }
+    while ((_serverRequestInVram ? mb->done : mb->taken) != _serverPosted && mb->state != kServerExited)
+      if (!w.Tick(std::chrono::seconds(30))) return HipErr(hipErrorNotReady, "ServerPost (previous request never taken)");
   }
   const uint64_t prev = _serverReqSeq;
   const uint64_t seq = NextLaunchTag();
@@ -114,8 +107,7 @@ Error HipEngine::ServerPost(Quiz *q, SelectResult *out, uint64_t *flag, uint64_t
     // one.  (With the line in host memory "write mine, then read yours" on both sides would decide this without waiting:
     // PCIe keeps the kernel's read behind its write.  A line in device memory is written by the host with a posted write
     // that may still be in flight when the host looks at `state`, so the acknowledgement is what is relied on.)
-    const auto t0 = std::chrono::steady_clock::now();
-    uint64_t spins = 0;
+    SpinWait w;
     for (;;) {
       if (mb->taken == seq) return Error();
       if (mb->state == kServerExited) {
@@ -123,8 +115,7 @@ Error HipEngine::ServerPost(Quiz *q, SelectResult *out, uint64_t *flag, uint64_t
         if (mb->taken == seq) return Error();
         break;
       }
-      if ((++spins & 0xFFF) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(30))
-        return HipErr(hipErrorNotReady, "ServerPost (request neither taken nor refused)");
+      if (!w.Tick(std::chrono::seconds(30))) return HipErr(hipErrorNotReady, "ServerPost (request neither taken nor refused)");
     }
     _serverLaunched = false;   // it left without this request
   }
@@ -140,11 +131,5 @@ Error HipEngine::ServerPost(Quiz *q, SelectResult *out, uint64_t *flag, uint64_t
   _serverVariant = _optEvalVariant;
   return Error();
 }
-
-// Argmax selections for several quizzes at once.  pOut[i] = the selected GLOBAL question of pQuizzes[i], or -1 when that quiz
-// has run out of questions (not an error of the call).  Two forms:
-//   * the row-sharing sweep (batch_kernels.hip; batches of at least `batch_min` quizzes, and every batch of a Float engine):
-//     a lane is a quiz, the cube tile staged in LDS serves all quizzes of the batch -- the cube is read once per batch;
-//   * grid.y = quiz over the single-quiz kernel (small batches of Double engines): one launch, but one cube read per quiz.
 
 }  // namespace pqa

@@ -142,6 +142,7 @@ class ShardedEngine final : public IEngine {
   const char *EvalKernelName() const override { return _sh[0]->EvalKernelName(); }
   Error SetKB(const double *pA, const double *pD, const double *pB) override {
     std::lock_guard<OpMutex> lk(_opMu);
+    { Error fe = FlushAnswers(); if (!fe.ok()) return fe; }   // (the gathered answers read the cube as it was when they were given)
     for (auto &s : _sh) {
       const size_t q0 = (size_t)s->FirstQuestion();
       Error e = s->SetKB(pA + q0 * (size_t)_K * (size_t)_T, pD + q0 * (size_t)_T, pB);
@@ -151,6 +152,7 @@ class ShardedEngine final : public IEngine {
   }
   Error GetKB(double *pA, double *pD, double *pB) override {
     std::lock_guard<OpMutex> lk(_opMu);
+    { Error fe = FlushAnswers(); if (!fe.ok()) return fe; }
     for (auto &s : _sh) {
       const size_t q0 = (size_t)s->FirstQuestion();
       Error e = s->GetKB(pA ? pA + q0 * (size_t)_K * (size_t)_T : nullptr, pD ? pD + q0 * (size_t)_T : nullptr, s == _sh[0] ? pB : nullptr);
@@ -162,6 +164,7 @@ class ShardedEngine final : public IEngine {
   Error SetTargetGaps(int64_t n, const int64_t *ids) override { return All([&](HipEngine &e) { return e.SetTargetGaps(n, ids); }); }
   Error SetQuestionGaps(int64_t n, const int64_t *ids) override {
     std::lock_guard<OpMutex> lk(_opMu);
+    { Error fe = FlushAnswers(); if (!fe.ok()) return fe; }
     Error e = AllLocked([&](HipEngine &eng) { return eng.SetQuestionGaps(n, ids); });
     if (e.ok())
       for (int64_t i = 0; i < n; i++)
@@ -267,7 +270,11 @@ class ShardedEngine final : public IEngine {
   void Execute(Op *ordered);
 
   template <typename F>
-  Error All(F &&f) { std::lock_guard<OpMutex> lk(_opMu); return AllLocked(f); }
+  Error All(F &&f) {   // (the gathered answers first: what follows reads or changes what they read)
+    std::lock_guard<OpMutex> lk(_opMu);
+    Error fe = FlushAnswers();
+    return fe.ok() ? AllLocked(f) : fe;
+  }
   template <typename F>
   Error AllLocked(F &&f) { for (auto &s : _sh) { Error e = f(*s); if (!e.ok()) return e; } return Error(); }
   int OwnerOf(int64_t qGlobal) const {
@@ -279,7 +286,9 @@ class ShardedEngine final : public IEngine {
   // BaseEngine.cpp:417 -- ClearOldQuizzes is decided once for all shards), the active question (CEQuiz::_activeQuestion) and
   // whether an answer of the quiz is still among the gathered ones.  Read and written by the quiz's own client without a lock
   // (no concurrent calls on one quiz, IPqaEngine.h:44): a table of chunks that only grows, under _opMu.
-  struct QuizRow { std::atomic<int64_t> lastUse{0}, active{-1}; std::atomic<int> pending{0}; };
+  // failed: a hand-over of this quiz's answer did not reach every shard (FlushAnswers): the posterior replicas may differ, and every
+  // later call on the quiz says so instead of selecting from one of them; released like any other quiz
+  struct QuizRow { std::atomic<int64_t> lastUse{0}, active{-1}; std::atomic<int> pending{0}, failed{0}; };
   static constexpr int64_t kRowsPerChunk = 4096, kRowChunks = 8192;
   std::atomic<QuizRow *> _rows[kRowChunks] = {};
   std::atomic<int64_t> _registrySize{0};       // ids below this have been handed out at some time
@@ -298,10 +307,10 @@ class ShardedEngine final : public IEngine {
   }
   void Touch(int64_t iQuiz) { if (QuizRow *r = LiveRow(iQuiz)) r->lastUse.store((int64_t)NowStamp(), std::memory_order_relaxed); }
   static int64_t NowStamp() { const time_t t = time(nullptr); return t == 0 ? 1 : (int64_t)t; }
-  void NewQuiz(int64_t id) { QuizRow *r = EnsureRow(id); if (r) { r->active.store(-1); r->pending.store(0); r->lastUse.store(NowStamp()); } }
+  void NewQuiz(int64_t id) { QuizRow *r = EnsureRow(id); if (r) { r->active.store(-1); r->pending.store(0); r->failed.store(0); r->lastUse.store(NowStamp()); } }
   void ForgetQuizzes() {
     { std::lock_guard<std::mutex> lk(_pendMu); _pending.clear(); _pendingCount.store(0); }
-    for (int64_t id = 0; id < _registrySize.load(); id++) if (QuizRow *r = Row(id)) { r->lastUse.store(0); r->active.store(-1); r->pending.store(0); }
+    for (int64_t id = 0; id < _registrySize.load(); id++) if (QuizRow *r = Row(id)) { r->lastUse.store(0); r->active.store(-1); r->pending.store(0); r->failed.store(0); }
   }
   // The error a call on quiz `iQuiz` gets when the quiz is not there or the mode is wrong: the shards' own (BaseEngine::UseQuiz,
   // BaseEngine.cpp:399-419; the MaintenanceSwitch gate), asked of shard 0 by a call that changes nothing.
@@ -323,9 +332,16 @@ class ShardedEngine final : public IEngine {
   }
   // Before anything reads quiz `iQuiz`'s posterior on a shard: its answer -- if one is among the gathered ones, or in a hand-over
   // another thread is making right now (the quiz's flag falls only after the last shard has it) -- has reached the shards.
+  Error FailedQuiz(int64_t iQuiz) const {
+    QuizRow *r = LiveRow(iQuiz);
+    if (r && r->failed.load(std::memory_order_acquire))
+      return Error::MakeP(ErrCode::Internal, "quizId=" + std::to_string(iQuiz), "An answer of this quiz did not reach every shard: its posteriors may differ. Release the quiz.");
+    return Error();
+  }
   Error EnsureApplied(int64_t iQuiz) {
     QuizRow *r = LiveRow(iQuiz);
-    return r && r->pending.load(std::memory_order_acquire) ? FlushNow() : Error();
+    Error e = r && r->pending.load(std::memory_order_acquire) ? FlushNow() : Error();
+    return e.ok() ? FailedQuiz(iQuiz) : e;
   }
   std::vector<char> _qGapBit;           // per global question: a gap (mirror of _qGapList for RecordAnswer's check)
   void RefreshGapBits() { _qGapBit.assign((size_t)_Q, 0); for (int64_t g : _qGapList) if (g >= 0 && g < _Q) _qGapBit[(size_t)g] = 1; }
@@ -400,6 +416,8 @@ class ShardedEngine final : public IEngine {
   bool CollectBatch(int ctx, std::vector<SelRequest *> &batch, Flight &f, SelRequest *own);
   int64_t SelectFromViews(SelRequest *r);
   void ServeAlone(SelRequest *r) {     // (_opMu held)
+    r->err = FailedQuiz(r->iQuiz);
+    if (!r->err.ok()) { r->result = -1; return; }
     r->result = r->kind == 0 ? SelectArgmaxAlone(r->err, r->iQuiz) : SelectSampledLocked(r->err, r->iQuiz, r->rnd);
   }
   int64_t SelectArgmaxAlone(Error &err, int64_t iQuiz) {
@@ -525,8 +543,23 @@ void ShardedEngine::Execute(Op *ordered) {
     if (op->kind == 3) { nTrains++; continue; }
     if (op->kind == 2) {   // ReleaseQuiz: every shard releases (a shard that has not got the quiz says so): the registries stay in step
       Error first;
-      for (auto &s : _sh) { Error e = s->ReleaseQuiz(op->iQuiz); if (!e.ok() && first.ok()) first = e; }
-      if (first.ok()) if (QuizRow *r = Row(op->iQuiz)) { r->lastUse.store(0); r->active.store(-1); r->pending.store(0); }
+      size_t released = 0;
+      for (auto &s : _sh) { Error e = s->ReleaseQuiz(op->iQuiz); if (e.ok()) released++; else if (first.ok()) first = e; }
+      // (some shards released and one refused -- a NextQuestion of the quiz selecting on another thread, the client's own error: the
+      //  refusing shards are asked again until they agree, so that every shard's registry holds the same quizzes)
+      for (int tries = 0; !first.ok() && released > 0 && released < _sh.size() && tries < 2000; tries++) {
+        first = Error();
+        released = 0;
+        for (auto &s : _sh) {
+          Error qe;
+          (void)s->GetActiveQuestionId(qe, op->iQuiz);
+          if (!qe.ok()) { released++; continue; }              // (this shard has let it go already)
+          Error e = s->ReleaseQuiz(op->iQuiz);
+          if (e.ok()) released++; else if (first.ok()) first = e;
+        }
+        if (!first.ok()) { struct timespec ts{0, 50000}; nanosleep(&ts, nullptr); }
+      }
+      if (first.ok()) if (QuizRow *r = Row(op->iQuiz)) { r->lastUse.store(0); r->active.store(-1); r->pending.store(0); r->failed.store(0); }
       op->err = first;
     }
   }
@@ -846,6 +879,7 @@ Error ShardedEngine::RecordAnswerDeferred(int64_t iQuiz, int64_t iAnswer) {
     return Error::MakeP(ErrCode::IndexOutOfRange, RangeParams(iAnswer, 0, _K - 1), "Answer index is not in the answer range.");
   QuizRow *r = LiveRow(iQuiz);
   if (!r) { Error e = QuizError(iQuiz); return e.ok() ? Error::Make(ErrCode::Internal, "The quiz tables have diverged.") : e; }
+  { Error fe = FailedQuiz(iQuiz); if (!fe.ok()) return fe; }
   r->lastUse.store(NowStamp(), std::memory_order_relaxed);
   const int64_t aq = r->active.load(std::memory_order_relaxed);
   if (aq == -1)
@@ -912,7 +946,13 @@ Error ShardedEngine::FlushAnswers() {
     Error e = _sh[s]->ApplyAnswers((int64_t)forShard.size(), forShard.data());
     if (!e.ok() && first.ok()) first = e;
   }
-  for (const PendingAnswer &p : taken) if (QuizRow *r = Row(p.iQuiz)) r->pending.store(0, std::memory_order_release);
+  // (a failure on any shard: which of the batch's answers that shard still applied is not known here -- every quiz of the batch is
+  //  marked, and says so from now on)
+  for (const PendingAnswer &p : taken)
+    if (QuizRow *r = Row(p.iQuiz)) {
+      if (!first.ok()) r->failed.store(1, std::memory_order_release);
+      r->pending.store(0, std::memory_order_release);
+    }
   return first;
 }
 
@@ -975,12 +1015,11 @@ int64_t ShardedEngine::SelectArgmaxLocked(Error &err, int64_t iQuiz, double *pPr
     if (!err.ok()) return -1;
   }
   Touch(iQuiz);
-  const auto t0 = std::chrono::steady_clock::now();
+  SpinWait w;
   for (size_t s = 0; s < _sh.size(); s++) {
     volatile uint64_t *flag = &_slots[s].flag;
-    uint64_t spins = 0;
     while (*flag != step)
-      if ((++spins & 0x3FFF) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(60)) {
+      if (!w.Tick(std::chrono::seconds(60))) {
         err = Error::MakeP(ErrCode::Internal, "shard=" + std::to_string(s), "Timed out waiting for a shard's selection.");
         return -1;
       }
@@ -1162,6 +1201,7 @@ void ShardedEngine::LaunchBatchLocked(int ctx, std::vector<SelRequest *> &batch,
   const bool regular = _sh[0]->IsRegularMode();
   for (SelRequest *r : batch) {
     if (!regular || LiveRow(r->iQuiz) == nullptr) { r->err = QuizError(r->iQuiz); r->result = -1; if (r->err.ok()) r->err = Error::Make(ErrCode::Internal, "The quiz tables have diverged."); continue; }
+    { Error fe = FailedQuiz(r->iQuiz); if (!fe.ok()) { r->err = fe; r->result = -1; continue; } }
     live.push_back(r);
     ids.push_back(r->iQuiz);
     f.anySampled = f.anySampled || r->kind == 1;
@@ -1264,7 +1304,7 @@ int64_t ShardedEngine::SelectFromViews(SelRequest *r) {
   const int64_t nQ = _Q;
   auto skipped = [&](int64_t q) { return ((r->skip[(size_t)(q >> 6)] >> (q & 63)) & 1ULL) != 0; };
   std::vector<double> run((size_t)nQ);
-  const auto t0 = std::chrono::steady_clock::now();
+  SpinWait w;
   for (size_t s = 0; s < _sh.size(); s++) {
     const HipEngine::PriorityView &v = r->views[s];
     const int64_t q0 = _sh[s]->FirstQuestion(), nLocal = _sh[s]->LocalQuestions();
@@ -1275,8 +1315,8 @@ int64_t ShardedEngine::SelectFromViews(SelRequest *r) {
         // (the quiz's flag said that every workgroup had reported, not that every one of its stores had landed: an entry is taken
         //  once it carries the launch's tag -- it almost always does by now)
         const volatile uint64_t *tagWord = reinterpret_cast<const volatile uint64_t *>(rec + 1);
-        for (uint64_t spins = 0; *tagWord != v.tag;)
-          if ((++spins & 0xFFFF) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(30)) {
+        while (*tagWord != v.tag)
+          if (!w.Tick(std::chrono::seconds(30))) {
             r->err = Error::Make(ErrCode::Internal, "Timed out waiting for a shard's priority vector.");
             return r->result = -1;
           }
@@ -1465,7 +1505,8 @@ Error ShardedEngine::Rebuild(int64_t newQ, int64_t newT, const std::vector<int64
     Error ae;
     e->SetQuestionsAsked(s == 0 ? s0.GetTotalQuestionsAsked(ae) : 0);
     for (const char *opt : {"select", "workers", "eval_subtasks", "eval_variant", "bug_compat", "top_cache", "speculate", "host_sampled",
-                            "fused_sampled", "batch_min", "batch_qb", "batch_tile", "batch_groups", "batch_tail", "cluster_form", "rerank", "combine", "server", "use_graph"}) {
+                            "fused_sampled", "batch_min", "batch_qb", "batch_tile", "batch_groups", "batch_tail", "batch_form", "cluster_form", "rerank", "combine", "server", "use_graph",
+                            "pole_fix", "long_row_form", "fuse_update", "combine_spin", "combine_linger_us", "post_always", "server_idle_us"}) {
       const int64_t v = _sh[(size_t)s]->GetOption(opt);
       if (v >= 0) (void)e->SetOption(opt, std::string(opt) == "eval_subtasks" && v == 8 * _sh[(size_t)s]->GetOption("workers") ? 0 : v);
     }
