@@ -332,3 +332,32 @@ def test_reference_sum_is_not_the_correctly_rounded_sum():
             y = rng.random(n)
             ordinary += reference_sum(y) != math.fsum(y)
     assert dominated > 30 and ordinary > 30
+
+
+@pytest.mark.parametrize("name", ["tiny_8x3x12", "gaps_37x5x101", "ragged_50x4x67"])
+def test_independent_restatement(name):
+    """The committed priorities (tests/golden/*.npz, from oracle/pqa_oracle.c) against a SECOND restatement of
+    CEEvalQsSubtaskConsider.cpp:59-207 written from the reference's sources in plain Python (tests/golden/independent_a1.py:
+    lane-emulating Kahan accumulators, Log2Hot with exactly rounded fused multiply-adds): BIT FOR BIT, every question, every
+    step.  The fixtures are then not single-sourced: a misreading of the reference would have to be made twice."""
+    import json
+    import os
+    import sys
+
+    gdir = os.path.join(os.path.dirname(__file__), "golden")
+    sys.path.insert(0, gdir)
+    import independent_a1
+    import make_golden
+
+    meta = json.load(open(os.path.join(gdir, name + ".json")))
+    gold = np.load(os.path.join(gdir, name + ".npz"))
+    case = make_golden.case_from_meta(meta)
+    A, D, _ = case.kb()
+    asked = []
+    for step in range(len(case.answers) + 1):
+        mine = independent_a1.priorities(A, D, gold[f"priors_{step}"], case.tgaps, case.qgaps, asked, case.K, case.Q, case.T)
+        want = gold[f"priority_{step}"]
+        bad = [q for q in range(case.Q) if np.float64(mine[q]).tobytes() != np.float64(want[q]).tobytes()]
+        assert not bad, (name, step, bad[:5], [(mine[q], want[q]) for q in bad[:3]])
+        if step < len(case.answers):
+            asked.append(case.answers[step][0])
