@@ -378,6 +378,7 @@ def main():
         return res
 
     exchanges_s, sharded_m, sharded_l1 = None, None, None
+    ranks_seen = ctl.rccl_ranks_seen()          # (every rank takes part)
     want = set(x for x in args.sharded_configs.split(",") if x)
     if sharded and args.config == "S":
         if "S" in want:
@@ -569,6 +570,16 @@ def main():
         "hip_graph_replay": graph_rate,
         "quiz_loop": quiz_loop,
         "quiz_loop_threads": quiz_loop_threads,
+        # what a scaling run is read by: which exchange `value` used, how many ranks an RCCL collective reached, the node's peer
+        # access, and the rate of BOTH exchanges where the run is sharded (one launch per selection on both)
+        "multi_gpu": {
+            "n_gpus": world,
+            "exchange": args.exchange if selector is not None else None,
+            "rccl_ranks_seen": ranks_seen,
+            "peer_access_matrix": ctl.peer_access_matrix(),
+            "selections_per_sec": {k: v.get("selections_per_sec") for k, v in exchanges_s.items() if isinstance(v, dict)} if exchanges_s else
+            {"single_gpu_no_exchange": value},
+        },
         "exchange_1000x5x1000": exchanges_s,
         "sharded_10000x5x10000": sharded_m,
         "sharded_12500x5x100000_per_gpu": sharded_l1,
@@ -707,6 +718,23 @@ class Ctl:
             h = t.cpu()
             self.dist.broadcast(h, src=owner)
             t.copy_(h)
+
+    def rccl_ranks_seen(self):
+        """How many ranks one RCCL all-gather reaches (every rank contributes its rank number): the world size if the
+        collective spans the job, None without RCCL (one rank and no --force-collective, or the gloo dry run)."""
+        if not self.rccl:
+            return None
+        mine = self.torch.tensor([int(os.environ.get("RANK", "0"))], dtype=self.torch.int64, device=self.device)
+        parts = [self.torch.empty_like(mine) for _ in range(max(1, self.world))]
+        self.dist.all_gather(parts, mine)
+        self.torch.cuda.synchronize()
+        return len(set(int(p.item()) for p in parts))
+
+    def peer_access_matrix(self):
+        """[i][j] = 1 if device i of this node maps device j's memory (hipDeviceCanAccessPeer): what the shards' reads of each
+        other's rows go over (xGMI where 1, a staged copy where 0)."""
+        n = self.torch.cuda.device_count()
+        return [[1 if i == j or self.torch.cuda.can_device_access_peer(i, j) else 0 for j in range(n)] for i in range(n)]
 
     def close(self):
         if self.dist is not None:

@@ -35,3 +35,31 @@ def test_bench_gpus_2_self_spawns():
     assert one["1000x5x1000"]["shards"] == 2
     l1 = [v for k, v in one.items() if k.endswith("_per_shard")][0]
     assert l1["shards"] == 2 and l1["shards_in_flight_max"] == 2
+
+
+def _bench(extra):
+    env = dict(os.environ)
+    env.pop("RANK", None)
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2000", "--warmup", "300", "--no-quiz-loop",
+                        "--no-points", "--no-cpu-baseline", "--batch", "0", "--no-server"] + extra,
+                       capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_force_collective_agrees_with_plain_run():
+    """N = 1 through the sharded selector (--force-collective: a world of one, both exchanges -- the RCCL all-gather really runs)
+    against the plain run: the same question, and a rate within 10 % (a SCALE file's N = 1 point must agree with the BENCH file's).
+    Both launch one kernel per selection (--no-server: the sharded path has no resident form)."""
+    plain = _bench([])
+    forced = _bench(["--force-collective", "--sharded-configs", "S"])
+    assert forced["config"]["selected_question"] == plain["config"]["selected_question"]
+    mg = forced["multi_gpu"]
+    assert mg["n_gpus"] == 1 and mg["rccl_ranks_seen"] == 1 and mg["peer_access_matrix"][0][0] == 1
+    assert mg["exchange"] == "shm" and mg["selections_per_sec"]["shm"] > 0 and mg["selections_per_sec"]["rccl"] > 0
+    assert plain["multi_gpu"]["exchange"] is None and plain["multi_gpu"]["rccl_ranks_seen"] is None
+    ratio = forced["value"] / plain["value"]
+    assert 0.9 < ratio < 1.1, (forced["value"], plain["value"])
