@@ -213,7 +213,15 @@ def main():
         return ctl.max_float(time.perf_counter() - t0), r
 
     def kernel_ms_of(e, qz, n_k):
-        """dominant kernel: live HIP-event timing on the engine's stream, back-to-back launches"""
+        """dominant kernel: live HIP-event timing on the engine's stream, back-to-back launches of the sweep kernel -- by itself:
+        the (empty, in this quiz state) fix that is launched behind every watching sweep is left out (option pole_follow)"""
+        e.set_option("pole_follow", 0)
+        try:
+            return kernel_ms_with(e, qz, n_k)
+        finally:
+            e.set_option("pole_follow", 1)
+
+    def kernel_ms_with(e, qz, n_k):
         for _ in range(5):
             e.enqueue_eval(qz)
         torch.cuda.synchronize()
@@ -259,11 +267,25 @@ def main():
             server_step_us = {"mean": sum(ticks) / len(ticks), "p10": ticks[len(ticks) // 10], "p50": ticks[len(ticks) // 2],
                               "p90": ticks[(9 * len(ticks)) // 10], "n": len(ticks)}
 
+    # ---- the same synchronous call made by native code (libPqaClient.so: n x PqaEngine_NextQuestion, no Python between the calls):
+    # what of a step is the wrapper's
+    native = None
+    if selector is None:
+        n_nat = max(500, min(args.steps, 5000))
+        dt_n, sel_n = interop.time_selections_native(eng, quiz, 200, n_nat)
+        native = {"resident" if resident else "launched": {"selections_per_sec": n_nat / dt_n, "us_per_step": 1e6 * dt_n / n_nat,
+                                                            "agrees": int(sel_n) == int(sel)}}
+        if server_step_us:
+            native["resident"]["host_overhead_us"] = 1e6 * dt_n / n_nat - server_step_us["mean"]
     launch_rate = None
     if resident:
         eng.set_option("server", 0)   # everything below launches kernels that would wait for the resident one to leave
         dt_l, sel_l = timed(step, min(args.warmup, 500), max(200, args.steps // 2))
         launch_rate = {"selections_per_sec": max(200, args.steps // 2) / dt_l, "agrees_with_resident": int(sel_l) == int(sel)}
+        if native is not None:
+            n_nat = max(500, min(args.steps, 5000))
+            dt_n, sel_n = interop.time_selections_native(eng, quiz, 200, n_nat)
+            native["launched"] = {"selections_per_sec": n_nat / dt_n, "us_per_step": 1e6 * dt_n / n_nat, "agrees": int(sel_n) == int(sel)}
     kernel_ms = kernel_ms_of(eng, quiz, max(20, min(args.steps, 200)))
     alg_bytes = q_local * (K + 1) * T * 8  # one read of every sA row and the mD row, fp64
     alg_flops = q_local * K * T * FLOPS_PER_ELEMENT   # ~45 fp64 operations per (question, answer, target)
@@ -565,6 +587,7 @@ def main():
         # what a synchronous step spends outside the sweep: the request's way to the kernel, the answer's way back, the wrapper
         "host_overhead_us": (1e6 * elapsed / args.steps - server_step_us["mean"]) if server_step_us else None,
         "launch_per_selection": launch_rate,
+        "native_caller": native,
         "pipelined_selections_per_sec": pipelined,
         "batched": batched,
         "hip_graph_replay": graph_rate,

@@ -137,4 +137,26 @@ __attribute__((visibility("default"))) int64_t PqaClient_RunLearners(void *pvEng
   return 0;
 }
 
+// The synchronous selection step from a NATIVE caller: n x PqaEngine_NextQuestion on one quiz (the engine's selector as its options
+// say), timed here -- what bench.py's step costs without the Python wrapper around every call.  Returns the seconds, < 0 on an error;
+// pLast: the last selected question.
+__attribute__((visibility("default"))) double PqaClient_TimeSelections(void *pvEngine, int64_t iQuiz, int64_t nWarm, int64_t n, int64_t *pLast) {
+  if (!pvEngine || n < 1) return -1.0;
+  int64_t last = -1;
+  for (int64_t i = 0; i < nWarm; i++) {
+    void *e = nullptr;
+    last = PqaEngine_NextQuestion(pvEngine, &e, iQuiz);
+    if (e) { CiReleasePqaError(e); return -1.0; }
+  }
+  const auto t0 = std::chrono::steady_clock::now();
+  for (int64_t i = 0; i < n; i++) {
+    void *e = nullptr;
+    last = PqaEngine_NextQuestion(pvEngine, &e, iQuiz);
+    if (e) { CiReleasePqaError(e); return -1.0; }
+  }
+  const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  if (pLast) *pLast = last;
+  return dt;
+}
+
 }  // extern "C"

@@ -46,6 +46,7 @@ struct EvalArgs {
   FusedSelect fs;
   const QuizSlot *slots;  // batched launch: per-quiz pointers, indexed by blockIdx.y (nullptr: a single quiz)
   int maxGrid;            // host side only: KbView::maxGrid
+  int poleNoFollow;       // host side only: KbView::poleNoFollow
   // eval_questions_f64_upd only: the answer whose posterior update runs in the sweep's prologue (sweep_body, FUSE)
   const double *updRowA, *updRowD;   // sA[q][a][.], mD[q][.] of the answered question
   int64_t updQuestion;               // its index (local): asked from this sweep on
@@ -1372,7 +1373,7 @@ hipError_t launch_reg_form(const EvalArgs &args, int64_t nQ, int nBatch, hipStre
   if (args.maxGrid > 0 && resGrid > args.maxGrid) resGrid = args.maxGrid;   // (test hook: KbView::maxGrid)
   hipLaunchKernelGGL(kern, dim3((unsigned)resGrid, (unsigned)nBatch), dim3(WPQ * 64), shmem, stream, args);
   const hipError_t le = hipGetLastError();
-  if constexpr (POLE) { if (le == hipSuccess) return launch_pole_fixup(args, stream, nBatch); }
+  if constexpr (POLE) { if (le == hipSuccess && !args.poleNoFollow) return launch_pole_fixup(args, stream, nBatch); }
   return le;
 }
 
@@ -1463,6 +1464,7 @@ static EvalArgs make_args(const KbView &kb, int64_t qFirst, int64_t qLimit) {
   args.fs = FusedSelect{nullptr, nullptr, nullptr, 0, 0, 0, 0, nullptr, 0, 0, nullptr, nullptr};
   args.slots = nullptr;
   args.maxGrid = kb.maxGrid;
+  args.poleNoFollow = kb.poleNoFollow;
   return args;
 }
 

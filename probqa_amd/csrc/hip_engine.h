@@ -517,6 +517,7 @@ class HipEngine : public IEngine {
   SelectResult *_dSelScratch = nullptr;  // its per-workgroup winner records
   double *_dPriorScratch = nullptr;      // the long-row posterior kernels' subtask sums (KbView::priorScratch)
   int64_t _optPoleFix = 1;               // option "pole_fix"
+  int64_t _optPoleFollow = 1;            // option "pole_follow" (measurement hook)
   int64_t _optLongRowForm = 1;           // option "long_row_form": StartQuiz / RecordAnswer over rows beyond 16384 targets as one workgroup per subtask of the sum
   // batched selections (NextQuestionArgmaxBatch); allocated on first use
   static constexpr int64_t kMaxBatch = 256, kBatchGrid = 1024;

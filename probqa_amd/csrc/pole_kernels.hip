@@ -49,10 +49,47 @@ namespace {
 #ifndef PQA_FIX_WAVES
 #define PQA_FIX_WAVES 4
 #endif
+#ifndef PQA_FIX_DEPTH
+#define PQA_FIX_DEPTH 2
+#endif
 constexpr int kFixThreads = 256;                   // four waves, each by itself
 constexpr int kFixChunk = 2 * kWave;               // targets of a row per LDS chunk: one 16-byte pair per lane
 constexpr int kFixRowStride = kFixChunk + 4;       // doubles between the rows of a chunk (the rows' chain lanes on different banks)
 constexpr int kFixRed = 12;                        // doubles of scratch per row
+constexpr int kFixDepth = PQA_FIX_DEPTH;           // chunks whose operands are in flight (LDS-DMA) ahead of the one worked on
+
+// LDS-DMA (eval_kernels.hip: dma16): 16 (4) bytes per lane from global memory straight into LDS -- the row base in an SGPR descriptor,
+// the lane's byte offset in a VGPR, M0 = the wave-uniform LDS byte address; lane i lands at M0 + 16 i (4 i).  Counted by vmcnt,
+// invisible to the compiler's own bookkeeping: waited for explicitly (wait_vmcnt).  Reads beyond the descriptor's range return 0.
+typedef unsigned int dma_rsrc_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ dma_rsrc_t dma_rsrc(const void *row, int64_t bytes) {
+  const uint64_t base = (uint64_t)(uintptr_t)row;
+  return dma_rsrc_t{(unsigned)__builtin_amdgcn_readfirstlane((unsigned)base),
+                    (unsigned)__builtin_amdgcn_readfirstlane((unsigned)(base >> 32)) & 0xFFFFu,
+                    (unsigned)__builtin_amdgcn_readfirstlane((unsigned)bytes), 0x00020000u};
+}
+__device__ __forceinline__ void dma16(dma_rsrc_t rsrc, unsigned byteOffset, unsigned ldsDst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(byteOffset), "s"(rsrc), "s"(__builtin_amdgcn_readfirstlane(ldsDst)) : "memory");
+}
+__device__ __forceinline__ void dma4(dma_rsrc_t rsrc, unsigned byteOffset, unsigned ldsDst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dword %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(byteOffset), "s"(rsrc), "s"(__builtin_amdgcn_readfirstlane(ldsDst)) : "memory");
+}
+// s_waitcnt vmcnt(n) for a wave-uniform n (the instruction takes an immediate; fewer than asked for is always safe)
+__device__ __forceinline__ void wait_vmcnt(int n) {
+#define PQA_VM(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
+  switch (n) {
+    PQA_VM(0) PQA_VM(1) PQA_VM(2) PQA_VM(3) PQA_VM(4) PQA_VM(5) PQA_VM(6) PQA_VM(7) PQA_VM(8) PQA_VM(9) PQA_VM(10) PQA_VM(11) PQA_VM(12)
+    PQA_VM(13) PQA_VM(14) PQA_VM(15) PQA_VM(16) PQA_VM(17) PQA_VM(18) PQA_VM(19) PQA_VM(20) PQA_VM(21) PQA_VM(22) PQA_VM(23) PQA_VM(24)
+    PQA_VM(25) PQA_VM(26) PQA_VM(27) PQA_VM(28) PQA_VM(29) PQA_VM(30) PQA_VM(31) PQA_VM(32) PQA_VM(33) PQA_VM(34) PQA_VM(35) PQA_VM(36)
+    PQA_VM(37) PQA_VM(38) PQA_VM(39) PQA_VM(40) PQA_VM(41) PQA_VM(42) PQA_VM(43) PQA_VM(44) PQA_VM(45) PQA_VM(46) PQA_VM(47) PQA_VM(48)
+    default: asm volatile("s_waitcnt vmcnt(48)" ::: "memory"); break;
+  }
+#undef PQA_VM
+}
 
 // log2hot (pqa_device.h) with the table in global memory: the same operations on the same table entries, so the same bits -- what
 // pass 2 of the sweep took for an element.  (This kernel's LDS is the rows' chunks; one lane per row needs the function.)
@@ -98,15 +135,18 @@ __global__ __launch_bounds__(kFixThreads) __attribute__((amdgpu_waves_per_eu(PQA
   const int wave = (int)__builtin_amdgcn_readfirstlane(tid / kWave);
   const int64_t K = a.K, ldT = a.ldT, nT = 4 * ((a.T + 3) >> 2);
   constexpr int R = RMAX;
-  // this wave's LDS: the rows' chunk [R][kFixRowStride] | per row {four lanes' sums, corrections, largest element, its place, dH, dL} [R][kFixRed] | the suspect's record [2 K + 2]
-  double *buf = smem + (size_t)wave * a.waveLds;
+  constexpr unsigned kFixSlotBytes = (R + 2) * 1024u + 16u;
+  // this wave's LDS: the DMA ring | the rows' likelihoods of one chunk [R][kFixRowStride] | per row {four lanes' sums, corrections, largest element, its place, dH, dL} [R][kFixRed] | the suspect's record [2 K + 2]
+  double *ring = smem + (size_t)wave * a.waveLds;              // [kFixDepth] slots of {R answer rows, mD, prior: a KB each; four gap words}
+  double *buf = ring + (size_t)kFixDepth * (kFixSlotBytes / 8);
   double *red = buf + (size_t)R * kFixRowStride;
   double *rec = red + (size_t)R * kFixRed;
   double *recW = rec, *recV = rec + K;
   const PoleEntry *entries = reinterpret_cast<const PoleEntry *>(a.list + 1);
   const int nChunks = (int)((nT + kFixChunk - 1) / kFixChunk);
-  const uint32_t nWaves = gridDim.x * (kFixThreads / kWave);
-  for (uint32_t e = blockIdx.x * (kFixThreads / kWave) + wave; e < n; e += nWaves) {
+  const int wgWaves = (int)(blockDim.x / kWave);               // (four; fewer where dozens of rows side by side take the LDS)
+  const uint32_t nWaves = gridDim.x * (uint32_t)wgWaves;
+  for (uint32_t e = blockIdx.x * (uint32_t)wgWaves + wave; e < n; e += nWaves) {
     // (the entry is the same for every lane: said once, so that everything derived from it -- the row and record pointers --
     //  lives in scalar registers)
     PoleEntry en = entries[e];
@@ -148,40 +188,51 @@ __global__ __launch_bounds__(kFixThreads) __attribute__((amdgpu_waves_per_eu(PQA
         int mxAt[R];
 #pragma unroll
         for (int r = 0; r < R; r++) { mx[r] = 0.0; mxAt[r] = 0; }
-        struct Chunk { double2 dv, pv, av[R]; uint32_t gw; };
-        // the loads of chunk c (:72-82's operands), a pair of targets per lane
-        auto request = [&](Chunk &ch, int c) __attribute__((always_inline)) {
-          const int64_t t0 = (int64_t)c * kFixChunk + 2 * lane;
-          const int64_t tc = t0 < nT ? t0 : 0;                 // (beyond the row: any valid pair, not used)
-          ch.dv = *reinterpret_cast<const double2 *>(rowD + tc);
-          ch.pv = *reinterpret_cast<const double2 *>(prior + tc);
-          ch.gw = a.tgap[tc >> 5] >> (tc & 31);
+        // The operands of the rows' likelihoods (:72-82) arrive by LDS-DMA -- global memory straight into this wave's ring in LDS, no
+        // registers held while they fly -- kFixDepth chunks ahead of the chunk being worked on: per chunk the mD row, the prior, the
+        // listed answer rows (16 bytes per lane each) and the chunk's four gap words.  A lane's pair of chunk c lies at byte
+        // 16 lane of the row's KB in slot c % kFixDepth.
+        const unsigned ringAddr = (unsigned)(uintptr_t)ring;
+        const int G = nb + 3;                                  // loads per chunk
+        dma_rsrc_t rsA[R];
+#pragma unroll
+        for (int r = 0; r < R; r++) rsA[r] = dma_rsrc(qBase + rowOff[r], ldT * 8);
+        const dma_rsrc_t rsD = dma_rsrc(rowD, ldT * 8), rsP = dma_rsrc(prior, ldT * 8), rsG = dma_rsrc(a.tgap, ((nT + 31) >> 5) * 4);
+        auto request = [&](int c) __attribute__((always_inline)) {
+          const unsigned slotAddr = ringAddr + (unsigned)(c % kFixDepth) * kFixSlotBytes;
+          const unsigned off = (unsigned)c * (kFixChunk * 8u) + 16u * (unsigned)lane;
 #pragma unroll
           for (int r = 0; r < R; r++)
-            if (r < nb) ch.av[r] = *reinterpret_cast<const double2 *>(qBase + rowOff[r] + tc);
+            if (r < nb) dma16(rsA[r], off, slotAddr + (unsigned)r * 1024u);
+          dma16(rsD, off, slotAddr + (unsigned)R * 1024u);
+          dma16(rsP, off, slotAddr + (unsigned)(R + 1) * 1024u);
+          if (lane < 4) dma4(rsG, (unsigned)c * 16u + 4u * (unsigned)lane, slotAddr + (unsigned)(R + 2) * 1024u);
         };
-        // chunk c: the rows' likelihoods as pass 1 forms them, into LDS
-        auto stage = [&](const Chunk &ch, int c) __attribute__((always_inline)) {
+        for (int c = 0; c < kFixDepth && c < nChunks; c++) request(c);
+        for (int c = 0; c < nChunks; c++) {
+          const int later = nChunks - 1 - c < kFixDepth - 1 ? nChunks - 1 - c : kFixDepth - 1;   // chunks requested behind this one
+          wait_vmcnt(later * G);
+          const char *slot = reinterpret_cast<const char *>(ring) + (size_t)(c % kFixDepth) * kFixSlotBytes;
           const int64_t t0 = (int64_t)c * kFixChunk + 2 * lane;
           if (t0 < nT) {
-            const bool g0 = ch.gw & 1u, g1 = ch.gw & 2u;
-            const double id0 = g0 ? 0.0 : div_nr(1.0, ch.dv.x), id1 = g1 ? 0.0 : div_nr(1.0, ch.dv.y);   // :74
-            const double p0 = g0 ? 0.0 : ch.pv.x, p1 = g1 ? 0.0 : ch.pv.y;                                // :103
+            const double2 dv = *reinterpret_cast<const double2 *>(slot + R * 1024 + 16 * lane);
+            const double2 pv = *reinterpret_cast<const double2 *>(slot + (R + 1) * 1024 + 16 * lane);
+            const uint32_t gw = reinterpret_cast<const uint32_t *>(slot + (R + 2) * 1024)[lane >> 4] >> ((2 * lane) & 31);
+            const bool g0 = gw & 1u, g1 = gw & 2u;
+            const double id0 = g0 ? 0.0 : div_nr(1.0, dv.x), id1 = g1 ? 0.0 : div_nr(1.0, dv.y);   // :74
+            const double p0 = g0 ? 0.0 : pv.x, p1 = g1 ? 0.0 : pv.y;                                  // :103
 #pragma unroll
             for (int r = 0; r < R; r++)
               if (r < nb) {
-                const double l0 = (ch.av[r].x * id0) * p0, l1 = (ch.av[r].y * id1) * p1;                  // :81-82
+                const double2 av = *reinterpret_cast<const double2 *>(slot + r * 1024 + 16 * lane);
+                const double l0 = (av.x * id0) * p0, l1 = (av.y * id1) * p1;                          // :81-82
                 *reinterpret_cast<double2 *>(buf + (size_t)r * kFixRowStride + 2 * lane) = make_double2(l0, l1);
                 const double lm = l1 > l0 ? l1 : l0;
                 if (lm > mx[r]) { mx[r] = lm; mxAt[r] = 2 * c + (l1 > l0 ? 1 : 0); }
               }
           }
-        };
-        Chunk ch;
-        request(ch, 0);
-        for (int c = 0; c < nChunks; c++) {
-          stage(ch, c);
-          if (c + 1 < nChunks) request(ch, c + 1);             // (in flight during the chains below, and the other waves' work)
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (the slot has been read: its next chunk may land)
+          if (c + kFixDepth < nChunks) request(c + kFixDepth);
           __builtin_amdgcn_wave_barrier();                     // (one wave, LDS in order: the chains read what the lanes wrote)
           if (lane < 4 * nb) {
             const double *src = buf + (size_t)(lane >> 2) * kFixRowStride + (lane & 3);
@@ -311,7 +362,7 @@ __global__ __launch_bounds__(kFixThreads) __attribute__((amdgpu_waves_per_eu(PQA
     if (!sampled) {
       // the argmax over every evaluated question (maximum priority, lowest index on ties, NaN never wins: eval_kernels.hip)
       Best b{0.0, -1};
-      for (int64_t j = tid; j < nQ; j += kFixThreads) {
+      for (int64_t j = tid; j < nQ; j += blockDim.x) {
         const int64_t q = a.qFirst + j;
         if (bit_test(a.qgap, q) || bit_test(a.asked, q)) continue;
         double p = __hip_atomic_load(a.priority + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -327,7 +378,7 @@ __global__ __launch_bounds__(kFixThreads) __attribute__((amdgpu_waves_per_eu(PQA
       if (lane == 0) wb[wave] = b;
       __syncthreads();
       if (tid == 0) {
-        for (int w = 1; w < kFixThreads / kWave; w++) best_merge(b, wb[w].p, wb[w].i);
+        for (int w = 1; w < wgWaves; w++) best_merge(b, wb[w].p, wb[w].i);
         outP = b.i < 0 ? 0.0 : b.p;
         outI = b.i < 0 ? -1 : b.i + a.fs.outBase;
       }
@@ -354,7 +405,7 @@ __global__ __launch_bounds__(kFixThreads) __attribute__((amdgpu_waves_per_eu(PQA
   if (a.fs.scratch != nullptr && a.slots != nullptr && a.nSlots > 0) {
     // a grid.y = quiz launch: every quiz's result (the finishers that saw the list empty have published theirs already -- the same)
     const bool handOver = a.fs.sampleSubtasks > 0;            // (the priorities went to the host as tagged records: the flags only)
-    for (int b = wave; b < a.nSlots; b += kFixThreads / kWave) {
+    for (int b = wave; b < a.nSlots; b += wgWaves) {
       const QuizSlot qs = a.slots[b];
       Best best{0.0, -1};
       if (!handOver) {
@@ -398,8 +449,10 @@ hipError_t LaunchPoleFixup(const PoleFix &fix, hipStream_t stream) {
   PoleFix a = fix;
   a.rows = a.K <= 2 ? 2 : a.K <= 5 ? 5 : a.K <= 8 ? 8 : 16;
   void (*kern)(PoleFix) = a.rows == 2 ? pole_fixup_kernel<2> : a.rows == 5 ? pole_fixup_kernel<5> : a.rows == 8 ? pole_fixup_kernel<8> : pole_fixup_kernel<16>;
-  a.waveLds = (int)(((size_t)a.rows * kFixRowStride + (size_t)a.rows * kFixRed + 2 * (size_t)a.K + 2 + 1) / 2 * 2);
-  size_t shmem = (size_t)(kFixThreads / kWave) * a.waveLds * sizeof(double);
+  a.waveLds = (int)(((size_t)kFixDepth * (((size_t)a.rows + 2) * 1024 + 16) / 8 + (size_t)a.rows * kFixRowStride + (size_t)a.rows * kFixRed + 2 * (size_t)a.K + 2 + 1) / 2 * 2);
+  int wgWaves = kFixThreads / kWave;
+  while (wgWaves > 1 && (size_t)wgWaves * a.waveLds * sizeof(double) > 150 * 1024) wgWaves--;   // (sixteen rows side by side: two waves)
+  size_t shmem = (size_t)wgWaves * a.waveLds * sizeof(double);
   if (shmem < 512) shmem = 512;
   if (a.fs.scratch != nullptr && a.fs.sampleSubtasks > 0 && a.fs.hostPriority == nullptr) {
     const size_t need = ((size_t)select_sampled_lds_doubles(a.nQ, a.fs.sampleSubtasks) + 8) * sizeof(double);
@@ -414,14 +467,14 @@ hipError_t LaunchPoleFixup(const PoleFix &fix, hipStream_t stream) {
       const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
       if (e != hipSuccess) return e;
     }
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, kern, kFixThreads, shmem) != hipSuccess || perCU < 1) perCU = 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, kern, wgWaves * kWave, shmem) != hipSuccess || perCU < 1) perCU = 1;
     cache.Put(dev, shmem, perCU);
   }
   int64_t grid = (int64_t)cache.NumCUs(dev) * perCU;
-  const int64_t wgs = (fix.capacity + kFixThreads / kWave - 1) / (kFixThreads / kWave);   // (a wave per suspect)
+  const int64_t wgs = (fix.capacity + wgWaves - 1) / wgWaves;   // (a wave per suspect)
   if (fix.capacity > 0 && grid > wgs) grid = wgs;
   if (grid < 1) grid = 1;
-  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(kFixThreads), shmem, stream, a);
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3((unsigned)(wgWaves * kWave)), shmem, stream, a);
   return hipGetLastError();
 }
 

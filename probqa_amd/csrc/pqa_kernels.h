@@ -61,6 +61,8 @@ struct KbView {
   double *poleScratch;    // Q x (2 K + 2) doubles (device): the sums of questions with a row at the pole of the lack term, between the
                           // sweep and the fix launched behind it (pole_kernels.hip); may be null (then such questions keep the sweep's own sums)
   struct PoleHeader *poleList;   // ... and the list of those questions: PoleListBytes(Q) bytes, zeroed once (every launch leaves it empty)
+  int poleNoFollow;       // measurement hook (engine option "pole_follow" = 0): the watching sweep WITHOUT the launch behind it -- for timing the sweep
+                          // kernel by itself in a quiz state that lists nothing; anything listed would stay listed
 };
 
 // ---- questions with a row at the pole of the lack term: listed by the sweeps, redone in the reference's order behind them

@@ -203,6 +203,24 @@ def run_learners(engine: "PqaEngine", n_threads: int, n_quizzes: int, max_questi
             "seconds": st.seconds, "transcript_hash": st.transcriptHash, "threads": n_threads}
 
 
+def time_selections_native(engine: "PqaEngine", i_quiz: int, n_warm: int, n: int):
+    """(seconds, last selected question) of n synchronous PqaEngine_NextQuestion calls made by native code (libPqaClient.so): the
+    step of bench.py without the Python wrapper around every call."""
+    global _client
+    load_library()
+    if _client is None:
+        _client = ctypes.CDLL(CLIENT_LIB_PATH)
+        _client.PqaClient_RunLearners.restype = ctypes.c_int64
+        _client.PqaClient_RunLearners.argtypes = [_vp, _i64, _i64, _i64, ctypes.c_uint64, _i64, ctypes.POINTER(PqaClientStats)]
+    _client.PqaClient_TimeSelections.restype = ctypes.c_double
+    _client.PqaClient_TimeSelections.argtypes = [_vp, _i64, _i64, _i64, ctypes.POINTER(_i64)]
+    last = _i64(-1)
+    dt = _client.PqaClient_TimeSelections(engine.c_engine, i_quiz, n_warm, n, ctypes.byref(last))
+    if dt < 0:
+        raise PqaException("PqaClient_TimeSelections: a call of the ABI failed")
+    return dt, int(last.value)
+
+
 class PqaException(Exception):  # reference ProbQA.py:300-302
     pass
 
