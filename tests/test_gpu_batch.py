@@ -291,7 +291,7 @@ def test_batched_sweep_mid_size_fp64_and_fp32(factory):
 
 @pytest.mark.parametrize("T,K,name", [(900, 5, "f32_wg256_nq1"), (1500, 3, "f32_wg256_nq2"), (2500, 5, "f32_wg256_nq3"),
                                      (4000, 5, "f32_wg256_nq4"), (4500, 5, "f32_wg320_nq4"), (6000, 2, "f32_wg384_nq4"),
-                                     (8000, 5, "f32_wg512_nq4"), (10000, 5, "f32_wg640_nq4"),
+                                     (8000, 5, "f32_wg512_nq4"), (9000, 7, "f32_wg512_nq5"), (10000, 5, "f32_wg512_nq5"),
                                      (11000, 16, "f32_wg704_nq4"), (12000, 5, "f32_wg768_nq4"),
                                      (16384, 5, "f32_wg1024_nq4"), (20000, 5, "f32_cluster7_x14"), (70000, 3, "f32_cluster18_x14"),
                                      (900, 17, "f32_stream")],
