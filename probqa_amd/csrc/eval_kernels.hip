@@ -41,6 +41,9 @@ struct EvalArgs {
   double *priority;
   double *poleScratch;   // KbView::poleScratch (single-quiz launches), or null: the sums of questions that passed the pole watch, [question][2 K + 2]
   PoleHeader *poleList;  // KbView::poleList: ... and their entries (pole_kernels.hip is launched behind the sweep); null: no watch
+  bool serverWatch;          // the resident kernel watches too (nothing can be launched behind a step: a step that found a row says so --
+                             // index -4 -- and the host takes the launched path)
+  bool serverNoWatch;        // ... not reported for this request (ServerMailbox: kServerNoWatch)
   int64_t K, T, ldT, qFirst, qLimit;
   double vCompTail;  // ln(sqrt 2) / (nValidTargets + 1)^2, PqaCore/CEEvalQsSubtaskConsider.cpp:191
   FusedSelect fs;
@@ -111,7 +114,7 @@ __device__ __forceinline__ Best wave_best(Best b) {       // every lane ends up 
 // structurizer behind the loop exit of its wave while the other lanes run on to the next step's barrier: a deadlock
 // (tools/server_rt.hip reproduces it).
 template <bool UNI = false>
-__device__ __forceinline__ void fused_select(const EvalArgs &a, Best mine, int lane, bool *allReported = nullptr) {
+__device__ __forceinline__ void fused_select(const EvalArgs &a, Best mine, int lane, bool *allReported = nullptr, bool wgSuspect = false) {
   if (a.fs.scratch == nullptr) return;
   const bool sampled = a.fs.sampleSubtasks > 0;
   // sampled: the finisher's workgroup reads every workgroup's priorities afterwards -- they must be visible before the record
@@ -126,7 +129,8 @@ __device__ __forceinline__ void fused_select(const EvalArgs &a, Best mine, int l
   SelectResult *rec = a.fs.scratch;
   if (UNI || lane == 0) {
     typedef unsigned int u4 __attribute__((ext_vector_type(4)));
-    const uint64_t w0 = d2u(wg.p), w1 = tag | (uint32_t)(wg.i < 0 ? 0xFFFFFFFFu : (uint32_t)wg.i);
+    // (bit 31 of the index word: a question of this workgroup passed the pole watch -- the finisher learns it with the record)
+    const uint64_t w0 = d2u(wg.p), w1 = tag | (uint32_t)(wg.i < 0 ? 0x7FFFFFFFu : (uint32_t)wg.i) | (wgSuspect ? 0x80000000u : 0u);
     const u4 v = {(unsigned)w0, (unsigned)(w0 >> 32), (unsigned)w1, (unsigned)(w1 >> 32)};
     asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(rec + blockIdx.x), "v"(v) : "memory");
   }
@@ -137,6 +141,7 @@ __device__ __forceinline__ void fused_select(const EvalArgs &a, Best mine, int l
   // bounded (~20 s): a record can only stay stale if a workgroup of this launch died; then the host gets index -3
   typedef unsigned int u4 __attribute__((ext_vector_type(4)));
   bool complete = true;
+  uint32_t anySuspect = 0;
   Best b{0.0, -1};
   for (unsigned chunk = 0; chunk < grid && complete; chunk += 16 * kWave) {
     const SelectResult *p0 = rec + chunk + lane, *p1 = p0 + 4 * kWave, *p2 = p0 + 8 * kWave, *p3 = p0 + 12 * kWave;
@@ -169,22 +174,25 @@ __device__ __forceinline__ void fused_select(const EvalArgs &a, Best mine, int l
     for (int u = 0; u < 16; u++)
       if (chunk + lane + u * kWave < grid) {
         const uint64_t pw = (uint64_t)r[u][0] | ((uint64_t)r[u][1] << 32);
-        best_merge(b, u2d(pw), r[u][2] == 0xFFFFFFFFu ? -1 : (int64_t)r[u][2]);
+        anySuspect |= r[u][2] >> 31;
+        best_merge(b, u2d(pw), (r[u][2] & 0x7FFFFFFFu) == 0x7FFFFFFFu ? -1 : (int64_t)(r[u][2] & 0x7FFFFFFFu));
       }
   }
   b = wave_best(b);
   // questions that passed the pole watch (any workgroup's: their entries were in the list before their workgroups reported): the
   // fix launched behind this sweep publishes the result -- pole_kernels.hip
-  bool deferred = false;
-  if (a.poleList != nullptr && complete) deferred = __hip_atomic_load(&a.poleList->count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+  // A workgroup's question passed the pole watch: the fix launched behind this sweep publishes the result (pole_kernels.hip) -- or,
+  // the resident kernel, behind which nothing can be launched: the step's answer says so (index -4; the caller takes the launched path)
+  const bool suspects = __any(anySuspect != 0);
+  const bool deferred = !UNI && suspects && complete && a.poleList != nullptr, redo = UNI && suspects && !a.serverNoWatch;
   if (sampled) {           // the selection follows (sweep_body); only whether the sweep is complete (and whether it publishes) is handed on
-    if (allReported != nullptr && (UNI || lane == 0)) { allReported[0] = complete; allReported[1] = deferred; }
+    if (allReported != nullptr && (UNI || lane == 0)) { allReported[0] = complete; allReported[1] = deferred; allReported[2] = redo; }
     return;
   }
   if (deferred) return;
   if (UNI || lane == 0) {
     a.fs.out->priority = b.i < 0 ? 0.0 : b.p;
-    a.fs.out->index = !complete ? -3 : b.i < 0 ? -1 : b.i + a.fs.outBase;
+    a.fs.out->index = !complete ? -3 : redo ? -4 : b.i < 0 ? -1 : b.i + a.fs.outBase;
     if (a.fs.seq != nullptr) {
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");  // system scope: the record is visible to the host before the flag
       __hip_atomic_store(a.fs.seq, flagValue, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -371,7 +379,7 @@ __device__ __forceinline__ void sweep_body(EvalArgs a, bool copyTable) {
   double *partAll = redW + 2 * WPQ;
   double *pend = partAll + 2 * (K + 2) * WPQ;
   Best *bestLds = reinterpret_cast<Best *>(pend + kPend * (2 * K + 3));  // wave 0's per-lane running argmax
-  uint32_t *susWords = reinterpret_cast<uint32_t *>(bestLds + kWave);   // [0], [1]: the rows of the question of that parity that passed the pole watch; [2], [3]: its wider form (kQuarterShare)
+  uint32_t *susWords = reinterpret_cast<uint32_t *>(bestLds + kWave);   // [0], [1] by question parity: the listed rows (low half) and the rows with an element of a quarter (high half); [4]: the entry's place in the list
   double2 *prLds = reinterpret_cast<double2 *>(reinterpret_cast<double *>(bestLds + kWave) + kSusDoubles);
   // landing row of the NEXT question's mD (register-prior shapes): lane-private 16-byte slots, slot j of thread tid at
   // mdRow[j*kThreads + tid]; filled by LDS-DMA while the current question's last answer is in pass 2
@@ -525,7 +533,9 @@ __device__ __forceinline__ void sweep_body(EvalArgs a, bool copyTable) {
   // The pole watch (see above; template POLE: the launcher takes the variant when the engine gave it KbView::poleList -- option
   // pole_fix, default on).  The resident kernel -- its step is the headline of bench.py, and nothing can be launched behind a step --
   // keeps the sweep's own sums and the conditioning bound of DESIGN section 5.
-  constexpr bool kWatch = POLE && !SERVER;
+  constexpr bool kWatch = POLE;
+  const bool watchOn = SERVER ? a.serverWatch : a.poleList != nullptr;
+  bool wgSuspect = false;                                     // (a question of this workgroup has passed: into its record)
   if (wave == 0) bestLds[lane] = Best{0.0, -1};   // only wave 0 ever touches these
   while (q < a.qLimit) {
     const int64_t qn = next_valid(q + gridDim.x);
@@ -599,10 +609,16 @@ __device__ __forceinline__ void sweep_body(EvalArgs a, bool copyTable) {
       bool watchHit = false, watchNear = false;               // (wave-uniform: a lane of this wave holds a quarter / nearly all of the wave's sum)
       double waveW = 0.0;
       if constexpr (kWatch) {
-        watchHit = __any(sLane > Wk * kQuarterShare);
-        if (watchHit) {
-          waveW = uniform_double(Wk);                            // (in scalar registers across the exchange)
-          watchNear = __any(sLane >= Wk * kNearOneShare);
+        // (first by the high words -- two integer instructions: 4 x sLane >= Wk only if its high word, two up in the exponent,
+        //  reaches Wk's; the exact tests behind the vote, and pinned there: hoisted, their multiplications ran for every row)
+        if (__any((uint32_t)(d2u(sLane) >> 32) + 0x00200000u >= (uint32_t)(d2u(Wk) >> 32))) {
+          double wq = Wk;
+          asm volatile("" : "+v"(wq));
+          watchHit = __any(sLane > wq * kQuarterShare);
+          if (watchHit) {
+            waveW = uniform_double(Wk);                          // (in scalar registers across the exchange)
+            watchNear = __any(sLane >= wq * kNearOneShare);
+          }
         }
       }
       if constexpr (WPQ > 1) {
@@ -613,9 +629,13 @@ __device__ __forceinline__ void sweep_body(EvalArgs a, bool copyTable) {
         phase ^= 1;
       }
       if constexpr (kWatch) {
-        if (watchHit && __any(waveW >= Wk * kQuarterShare)) {     // (rare before a quiz's last third)
-          quarterRows |= 1u << (k < 31 ? (int)k : 31);
-          if (watchNear && __any(waveW >= Wk * kNearOneShare)) poleRows |= 1u << (k < 31 ? (int)k : 31);
+        if (watchHit) {                                          // (rare before a quiz's last third)
+          double wq = Wk;
+          asm volatile("" : "+v"(wq));
+          if (__any(waveW >= wq * kQuarterShare)) {
+            quarterRows |= 0x10000u << (k < 15 ? (int)k : 15);   // (one word per question: the rows with an element of a quarter above, the listed rows below)
+            if (watchNear && __any(waveW >= wq * kNearOneShare)) poleRows |= 1u << (k < 15 ? (int)k : 15);
+          }
         }
       }
       const double invWk = div_nr(1.0, Wk);                    // :91
@@ -649,13 +669,14 @@ __device__ __forceinline__ void sweep_body(EvalArgs a, bool copyTable) {
       vdump[K * kThreads + tid] = hW;
       vdump[(K + 1) * kThreads + tid] = accL;
       if constexpr (kWatch) {                                   // (rare)
-        if (quarterRows != 0 && lane == 0) { atomicOr(&susWords[2 + qpar], quarterRows); if (poleRows != 0) atomicOr(&susWords[qpar], poleRows); }
+        if (quarterRows != 0 && lane == 0) atomicOr(&susWords[qpar], quarterRows | poleRows);
       }
       __syncthreads();
       uint32_t wideRows = 0;                                     // workgroup-uniform: the rows with an element of a quarter
       if constexpr (kWatch) {
-        suspect = a.poleList != nullptr && susWords[qpar] != 0;
-        wideRows = a.poleList != nullptr ? susWords[2 + qpar] : 0u;
+        const uint32_t w = watchOn ? susWords[qpar] : 0u;
+        suspect = (w & 0xFFFFu) != 0;
+        wideRows = w >> 16;
       }
       // every 32 lanes take one of the K + 2 sums: threads/32 partials each, then a 32-lane butterfly
       constexpr int kGroups = kThreads / 32;
@@ -672,21 +693,23 @@ __device__ __forceinline__ void sweep_body(EvalArgs a, bool copyTable) {
         const Pair p = swap16(acc);
         acc = p.a + p.b;
         if constexpr (kWatch) {                                  // (a row whose velocity sum all but vanishes, with an element of a quarter: pole_device.h)
-          if (l32 == 0 && r < K && acc <= kSmallV && ((wideRows >> (r < 31 ? r : 31)) & 1u)) atomicOr(&susWords[qpar], 1u << (r < 31 ? r : 31));
+          if (l32 == 0 && r < K && acc <= kSmallV && ((wideRows >> (r < 15 ? r : 15)) & 1u)) atomicOr(&susWords[qpar], 1u << (r < 15 ? r : 15));
         }
         if (r < K) acc = rec[r] * sqrt(acc);                   // :156-157
         if (l32 == 0) rec[K + r] = acc;
       }
       if constexpr (kWatch) {
-        if (wideRows != 0) { __syncthreads(); suspect = susWords[qpar] != 0; }   // (the bits the other waves' lanes have just set)
+        if (wideRows != 0) { __syncthreads(); suspect = (susWords[qpar] & 0xFFFFu) != 0; }   // (the bits the other waves' lanes have just set)
       }
       if (tid == 0) {
         reinterpret_cast<int64_t *>(rec)[2 * K + 2] = q;
         susWords[qpar ^ 1] = 0;                                // (the other parity's flags: read by everybody before this question's barrier, set again only behind the next question's)
-        susWords[2 + (qpar ^ 1)] = 0;
-        if (suspect) susWords[4] = pole_list_append(a.poleList, (uint32_t)(q - a.qFirst), K <= 31 ? susWords[qpar] : 0u, a.slots != nullptr ? blockIdx.y : 0u);
+        if constexpr (!SERVER) {
+          if (suspect) susWords[4] = pole_list_append(a.poleList, (uint32_t)(q - a.qFirst), K <= 15 ? susWords[qpar] & 0xFFFFu : 0u, a.slots != nullptr ? blockIdx.y : 0u);
+        }
       }
-      if (suspect) {
+      wgSuspect = wgSuspect || suspect;
+      if (!SERVER && suspect) {
         // the question's sums as they are, for the fix behind the sweep (the question is queued like any other: its priority stands until
         // then): by question, or -- the quizzes of a grid.y launch share the buffer -- by its entry in the list
         __syncthreads();
@@ -705,13 +728,14 @@ __device__ __forceinline__ void sweep_body(EvalArgs a, bool copyTable) {
         part[(K + 1) * WPQ + wave] = accL;
       }
       if constexpr (kWatch) {                                   // (rare)
-        if (quarterRows != 0 && lane == 0) { atomicOr(&susWords[2 + qpar], quarterRows); if (poleRows != 0) atomicOr(&susWords[qpar], poleRows); }
+        if (quarterRows != 0 && lane == 0) atomicOr(&susWords[qpar], quarterRows | poleRows);
       }
       if constexpr (WPQ > 1) __syncthreads();
       uint32_t wideRows = 0;
       if constexpr (kWatch) {
-        suspect = a.poleList != nullptr && susWords[qpar] != 0;
-        wideRows = a.poleList != nullptr ? susWords[2 + qpar] : 0u;
+        const uint32_t w = watchOn ? susWords[qpar] : 0u;
+        suspect = (w & 0xFFFFu) != 0;
+        wideRows = w >> 16;
       }
       if (wave == 0) {
         // combine the waves' partials in wave order, one partial row per lane, and queue the question
@@ -719,19 +743,21 @@ __device__ __forceinline__ void sweep_body(EvalArgs a, bool copyTable) {
           double acc = part[r * WPQ];
           for (int w2 = 1; w2 < WPQ; w2++) acc += part[r * WPQ + w2];
           if constexpr (kWatch) {                                // (a row whose velocity sum all but vanishes, with an element of a quarter)
-            if (r < K && acc <= kSmallV && ((wideRows >> (r < 31 ? r : 31)) & 1u)) atomicOr(&susWords[qpar], 1u << (r < 31 ? r : 31));
+            if (r < K && acc <= kSmallV && ((wideRows >> (r < 15 ? r : 15)) & 1u)) atomicOr(&susWords[qpar], 1u << (r < 15 ? r : 15));
           }
           if (r < K) acc = rec[r] * sqrt(acc);                   // :156-157, one answer per lane
           rec[K + r] = acc;
         }
-        if constexpr (kWatch) { if (wideRows != 0) suspect = susWords[qpar] != 0; }   // (this wave's own atomics: in order)
+        if constexpr (kWatch) { if (wideRows != 0) suspect = (susWords[qpar] & 0xFFFFu) != 0; }   // (this wave's own atomics: in order)
         if (lane == 0) {
           reinterpret_cast<int64_t *>(rec)[2 * K + 2] = q;
           susWords[qpar ^ 1] = 0;
-          susWords[2 + (qpar ^ 1)] = 0;
-          if (suspect) susWords[4] = pole_list_append(a.poleList, (uint32_t)(q - a.qFirst), K <= 31 ? susWords[qpar] : 0u, a.slots != nullptr ? blockIdx.y : 0u);
+          if constexpr (!SERVER) {
+            if (suspect) susWords[4] = pole_list_append(a.poleList, (uint32_t)(q - a.qFirst), K <= 15 ? susWords[qpar] & 0xFFFFu : 0u, a.slots != nullptr ? blockIdx.y : 0u);
+          }
         }
-        if (suspect) {   // (the record is this wave's own work: no barrier)
+        wgSuspect = wgSuspect || suspect;
+        if (!SERVER && suspect) {   // (the record is this wave's own work: no barrier)
           const int64_t at = a.slots != nullptr ? (int64_t)susWords[4] : q - a.qFirst;
           for (int i = lane; i < 2 * (int)K + 2; i += kWave) a.poleScratch[at * (2 * K + 2) + i] = rec[i];
         }
@@ -745,7 +771,7 @@ __device__ __forceinline__ void sweep_body(EvalArgs a, bool copyTable) {
   if constexpr (kDefer) __syncthreads();                       // the last questions' records, written by other waves
   bool *allReported = reinterpret_cast<bool *>(redW);         // (the W exchange buffer is free now)
   if (wave == 0) flush_pending(a, pend, nPend, lane, bestLds[lane]);
-  if (wave == 0) fused_select<SERVER>(a, bestLds[lane], lane, allReported);
+  if (wave == 0) fused_select<SERVER>(a, bestLds[lane], lane, allReported, wgSuspect);
   if constexpr (FUSE) {
     if (blockIdx.x == 0) {
       // every workgroup has reported (fused_select above has seen their records): the old prior has no readers left
@@ -764,10 +790,10 @@ __device__ __forceinline__ void sweep_body(EvalArgs a, bool copyTable) {
     // entry: the selector skips them by the bitmaps.
     if (blockIdx.x == 0) {
       __syncthreads();
-      const bool complete = allReported[0], deferred = allReported[1];
+      const bool complete = allReported[0], deferred = allReported[1], redo = allReported[2];
       if (!deferred && (SERVER ? wave == 0 : tid == 0)) {
         a.fs.out->priority = 0.0;
-        a.fs.out->index = complete ? 0 : -3;
+        a.fs.out->index = !complete ? -3 : redo ? -4 : 0;
         if (a.fs.seq != nullptr) {
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
           __hip_atomic_store(a.fs.seq, a.fs.flagValue, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -919,7 +945,8 @@ void eval_server_f64(EvalArgs a, ServerMailbox *mb, uint32_t *requestLine, int e
     b.fs.seq = reinterpret_cast<uint64_t *>(uniform64(reinterpret_cast<const uint64_t *>(step)[4]));
     b.fs.flagValue = uniform64(reinterpret_cast<const uint64_t *>(step)[5]);
     const uint64_t ob = uniform64(reinterpret_cast<const uint64_t *>(step)[6]);
-    b.fs.outBase = (int64_t)(ob & ~kServerHandOver);
+    b.fs.outBase = (int64_t)(ob & ~(kServerHandOver | kServerNoWatch));
+    b.serverNoWatch = (ob & kServerNoWatch) != 0;
     b.fs.sampleSubtasks = (ob & kServerHandOver) ? 1 : 0;   // the priority vector goes to the host (FusedSelect::hostPriority), no argmax
     b.fs.seqValue = go;
     // (as with the thread index: nothing derived from the launch constants may be hoisted out of the step loop)
@@ -927,7 +954,7 @@ void eval_server_f64(EvalArgs a, ServerMailbox *mb, uint32_t *requestLine, int e
                  "+s"(b.qFirst), "+s"(b.qLimit));
     __syncthreads();   // the step block may be rewritten only after everybody has read it
     const uint64_t tA = wall_clock64();   // 100 MHz
-    sweep_body<WPQ, NP, false, true, DEFER>(b, copyTable);
+    sweep_body<WPQ, NP, false, true, DEFER, false, true>(b, copyTable);
     copyTable = false;
     last = go;
     if (first && wave == 0) {
@@ -967,6 +994,7 @@ __global__ __launch_bounds__(256) void eval_questions_f64_stream(EvalArgs a) {
   const int64_t nPairs = ldT >> 1;
   int phase = 0, qpar = 0;
   const bool watch = a.poleList != nullptr;
+  bool wgSuspect = false;                                     // (thread 0's: a question of this workgroup passed the watch)
   Best best{0.0, -1};
   for (int64_t q = a.qFirst + blockIdx.x; q < a.qLimit; q += gridDim.x) {
     if (bit_test(a.qgap, q) || bit_test(a.asked, q)) {
@@ -1056,6 +1084,7 @@ __global__ __launch_bounds__(256) void eval_questions_f64_stream(EvalArgs a) {
       watchWords[qpar ^ 1] = 0;                                // (set again only behind the next question's barriers)
       watchWords[2 + (qpar ^ 1)] = 0;
       if (watch && watchWords[qpar] != 0) {
+        wgSuspect = true;
         // the question's sums as they are, for the fix behind the sweep (pole_kernels.hip)
         const uint32_t at = pole_list_append(a.poleList, (uint32_t)(q - a.qFirst), K <= 31 ? watchWords[qpar] : 0u, a.slots != nullptr ? blockIdx.y : 0u);
         double *ps = a.poleScratch + (a.slots != nullptr ? (int64_t)at : q - a.qFirst) * (2 * K + 2);
@@ -1066,7 +1095,7 @@ __global__ __launch_bounds__(256) void eval_questions_f64_stream(EvalArgs a) {
     }
     qpar ^= 1;
   }
-  if (wave == 0) fused_select(a, best, lane);   // lane 0 carries the workgroup's best, the other lanes none
+  if (wave == 0) fused_select(a, best, lane, nullptr, wgSuspect);   // lane 0 carries the workgroup's best, the other lanes none
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -1609,12 +1638,14 @@ bool EvalServerSupported(const KbView &kb, int variant) { return server_variant(
 
 hipError_t LaunchEvalServer(const KbView &kb, int64_t qFirst, int64_t qLimit, double *priority, int variant,
                             SelectResult *scratch, ServerMailbox *mailbox, void *requestLine, bool everyonePolls,
-                            ServerCtl *ctl, uint64_t lastSeq, uint64_t idleTicks, TaggedPriority *hostPriority, hipStream_t stream) {
+                            ServerCtl *ctl, uint64_t lastSeq, uint64_t idleTicks, TaggedPriority *hostPriority, hipStream_t stream,
+                            bool watch) {
   if (qLimit <= qFirst || scratch == nullptr || mailbox == nullptr || requestLine == nullptr || ctl == nullptr)
     return hipErrorInvalidValue;
   EvalArgs args = make_args(kb, qFirst, qLimit);
-  args.poleScratch = nullptr;   // (nothing can be launched behind a step of the resident kernel: it keeps the sweep's own sums)
+  args.poleScratch = nullptr;   // (nothing can be launched behind a step of the resident kernel: it only says that the step wants redoing)
   args.poleList = nullptr;
+  args.serverWatch = watch;
   args.priority = priority;
   args.fs.scratch = scratch;
   args.fs.hostPriority = hostPriority;

@@ -122,6 +122,8 @@ struct Quiz {
   int64_t activeQuestion = -1;         // global id (reference CEQuiz::_activeQuestion)
   uint64_t priorVersion = 0;           // bumped whenever the posterior changes
   uint64_t serial = 0;                 // unique per created quiz: a registry slot reused by a later quiz is not this quiz
+  bool noServer = false;               // the resident sweep has answered a step of this quiz with -4 (a row at the pole of the lack term:
+                                       // pole_kernels.hip) -- from here on its selections are launched, with the fix behind them
   QuizPinned *pin = nullptr;           // this quiz's host-coherent result lines (pooled by the engine)
   void *dRowStage = nullptr;           // sharded engine without peer access: the two rows of an answered question another shard holds, copied here
   // the listing in pin->top: made by the kernel that published `topOp` to pin->topFlag, of the posterior `topVersion`

@@ -207,7 +207,7 @@ Error HipEngine::EnqueueSelectArgmaxFlag(int64_t iQuiz, void *pOut, void *pFlag,
   if (!q) return err;
   if (!pOut || !pFlag) return Error::Make(ErrCode::NullArgument, "Nullptr is passed in place of the record or the flag.");
   hipSetDevice(_device);
-  if (_optServer && ServerUsable()) return ServerPost(q, (SelectResult *)pOut, (uint64_t *)pFlag, flagValue, _qFirst);
+  if (_optServer && ServerUsable()) return ServerPost(q, (SelectResult *)pOut, (uint64_t *)pFlag, flagValue, _qFirst | (int64_t)kServerNoWatch);   // (the record goes to another process: no -4 there)
   const FusedSelect fs{_dSelScratch, (SelectResult *)pOut, (uint64_t *)pFlag, NextLaunchTag(), _qFirst, 0, flagValue, nullptr, 0, 0, nullptr, nullptr};
   StopServer();   // a launched sweep has no room beside the resident one and would wait for it to idle out
   return LaunchSingleSweep(q, &fs);
@@ -295,7 +295,7 @@ int64_t HipEngine::NextQuestionArgmaxLocked(Error &err, int64_t iQuiz) {
   err = FlushUpdates();
   if (!err.ok()) return -1;
   if (_optUseGraph && _elem == 8) return NextQuestionArgmaxGraph(err, q);
-  if (_optServer && ServerUsable()) {
+  if (_optServer && !q->noServer && ServerUsable()) {
     // resident sweep: post the request, poll the answer -- no launch on the critical path
     const uint64_t value = kServerFlagBase | ++_opSeq;   // (its own range: see kGraphFlagBase)
     err = ServerPost(q, &_hPinned->sel, &_hPinned->seq, value, 0);
@@ -305,8 +305,11 @@ int64_t HipEngine::NextQuestionArgmaxLocked(Error &err, int64_t iQuiz) {
       err = HipErr(hipErrorLaunchFailure, "NextQuestionArgmax (incomplete sweep)");
       return -1;
     }
-    CheckPriority(_hPinned->sel.priority, _hPinned->sel.index);
-  return FinishSelection(err, q, _hPinned->sel.index);
+    if (_hPinned->sel.index != -4) {
+      CheckPriority(_hPinned->sel.priority, _hPinned->sel.index);
+      return FinishSelection(err, q, _hPinned->sel.index);
+    }
+    q->noServer = true;   // (a row at the pole of the lack term: this quiz's selections are launched from here on, the fix behind them)
   }
   // One launch; the last workgroup writes the winner and then a sequence number straight into host-coherent pinned
   // memory, which this thread polls: no D2H copy, no stream synchronisation on the critical path.
@@ -676,17 +679,20 @@ int64_t HipEngine::NextQuestionSampledLocked(Error &err, int64_t iQuiz, uint64_t
   if (!err.ok()) return -1;
   const KbView kb = View();
   const int64_t nSub = _optEvalSubtasks ? _optEvalSubtasks : 8 * _optWorkers;  // reference PqaCore/CpuEngine.cpp:339
-  if (_optServer && _optHostSampled && !_optFusedSampled && ServerUsable()) {
+  if (_optServer && !q->noServer && _optHostSampled && !_optFusedSampled && ServerUsable()) {
     // resident sweep: post the request with the hand-over mark, poll the flag, select on the host -- no launch on the path
     const uint64_t value = kServerFlagBase | ++_opSeq;   // (its own range: see kGraphFlagBase)
     err = ServerPost(q, &_hPinned->sel, &_hPinned->seq, value, (int64_t)kServerHandOver);
     if (err.ok()) err = ServerWait(&_hPinned->seq, value, "NextQuestionSampled");
     if (!err.ok()) return -1;
     if (_hPinned->sel.index == -3) { err = HipErr(hipErrorLaunchFailure, "NextQuestionSampled (incomplete sweep)"); return -1; }
-    err = CollectHostPriority(_serverPosted, q);
-    if (!err.ok()) return -1;
-    const int64_t sel = SelectSampledHostBits(_hostRun.data(), _Q, nSub, rnd, _hQGap.data(), q->hAsked.data());
-    return FinishSelection(err, q, sel);
+    if (_hPinned->sel.index != -4) {
+      err = CollectHostPriority(_serverPosted, q);
+      if (!err.ok()) return -1;
+      const int64_t sel = SelectSampledHostBits(_hostRun.data(), _Q, nSub, rnd, _hQGap.data(), q->hAsked.data());
+      return FinishSelection(err, q, sel);
+    }
+    q->noServer = true;   // (as NextQuestionArgmaxLocked)
   }
   uint64_t specTag = 0;
   const int took = TakeSpeculation(q, (1 << 2) | (1 << 3), &specTag);   // 2 / 3: RecordAnswer has launched the sweep already

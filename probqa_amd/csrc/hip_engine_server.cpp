@@ -125,7 +125,8 @@ Error HipEngine::ServerPost(Quiz *q, SelectResult *out, uint64_t *flag, uint64_t
   std::atomic_thread_fence(std::memory_order_seq_cst);
   HIP_TRY(EnsureHostPriority());   // (a launch argument of the resident kernel: requests may ask for the priority vector)
   HIP_TRY(LaunchEvalServer(View(), 0, _Q, _dPriority, (int)_optEvalVariant, _dSelScratch, _hMailbox, (void *)_serverRequest, _serverRequestInVram, _dServerCtl, prev,
-                           (uint64_t)_optServerIdleUs * 100, _hHostPriority, _serverStream));   // 100 MHz ticks
+                           (uint64_t)_optServerIdleUs * 100, _hHostPriority, _serverStream,
+                           _optPoleFix != 0));   // 100 MHz ticks
   _serverLaunched = true;
   _serverKb = _kbVersion;
   _serverVariant = _optEvalVariant;

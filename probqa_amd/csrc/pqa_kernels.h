@@ -256,9 +256,14 @@ struct ServerCtl {                // device memory, one line; zeroed before each
 // hostPriority (optional, host-coherent, qLimit - qFirst doubles): a request whose outBase carries kServerHandOver is answered
 // with the priority vector itself (for the host's sampled selector) instead of the argmax.
 constexpr uint64_t kServerHandOver = 1ull << 62;
+// watch: the resident sweep watches for rows at the pole of the lack term (pole_kernels.hip) and answers
+// a step that found one with index -4 -- the caller then takes the launched path, behind which the fix can run; a request whose outBase
+// carries kServerNoWatch is answered as if nothing had been found.
+constexpr uint64_t kServerNoWatch = 1ull << 61;
 hipError_t LaunchEvalServer(const KbView &kb, int64_t qFirst, int64_t qLimit, double *priority, int variant,
                             SelectResult *scratch, ServerMailbox *mailbox, void *requestLine, bool everyonePolls,
-                            ServerCtl *ctl, uint64_t lastSeq, uint64_t idleTicks, TaggedPriority *hostPriority, hipStream_t stream);
+                            ServerCtl *ctl, uint64_t lastSeq, uint64_t idleTicks, TaggedPriority *hostPriority, hipStream_t stream,
+                            bool watch = false);
 bool EvalServerSupported(const KbView &kb, int variant);
 
 
