@@ -69,9 +69,12 @@ PQACORE_API void *PqaEngineFactory_CreateHipEngineSharded(void *pvFactory, void 
  * batch leaves over take further questions; 0 = as many as leave every CU a workgroup [default], else at most this many),
  * "batch_tail" (that sweep's last, partial round of question blocks as a second launch of a shape with fewer questions per group, where
  * exactly one full round precedes it; default 1),
- * "pole_fix" (sweeps over rows of up to 4096 targets re-evaluate a row with a posterior element within 2^-17 of 1 in the reference's
- * own summation order -- SRAccumVectDbl256.h:40-46, :62-92 -- so that late quiz states stay within 1e-9 of the reference's
- * priorities; default 1, also PQA_POLE_FIX),
+ * "pole_fix" (every fp64 sweep watches, row by row, for a posterior element that holds nearly all -- or a quarter, while the answer
+ * hardly moves the posterior -- of the row; such questions are listed and a kernel launched behind the sweep re-evaluates them in the
+ * reference's own summation order -- SRAccumVectDbl256.h:40-46, :62-92 -- so that late quiz states stay within 1e-9 of the
+ * reference's priorities on every kernel form; a resident sweep that finds such a row hands the quiz to the launched path; default 1,
+ * also PQA_POLE_FIX), "pole_follow" (measurement hook: 0 = the watching sweep WITHOUT the launch behind it, for timing the sweep
+ * kernel by itself in a quiz state that lists nothing; default 1),
  * "cluster_form" (the single-quiz sweep over rows beyond 16384 targets: 0 = default, 1 = question by question, 2 = pass 1 a question
  * ahead of the exchange),
  * Read-only: "server_last_step_ns" (device-side duration of the newest finished step of the resident sweep: request in hand

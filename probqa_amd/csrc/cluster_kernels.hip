@@ -96,17 +96,26 @@ struct ClusterArgs {
   // and per question the rows in which a member saw a posterior element within 2^-10 of 1 (several members may)
   PoleHeader *poleList;
   uint32_t *poleMask;
-  uint32_t *wideMask;         // ... and the rows with an element of a quarter: listed by the member that folds the question, if their velocity sum all but vanishes (pole_device.h: kSmallV)
+  unsigned long long *candSum;   // [Q][kMaxK]: the bits of the largest THREAD sum of likelihoods in each answer row, where some thread held a quarter of its wave's
+                              // (cluster_watch_kernel, behind the sweep, compares it with W_k and lists the question's rows)
 };
-// a member's rows of one question that passed the watch (one thread of the member)
-__device__ __forceinline__ void cluster_watch_report(const ClusterArgs &a, int64_t q, uint32_t rows) {
-  if (atomicOr(&a.poleMask[q], rows) == 0u) pole_list_append(a.poleList, (uint32_t)q, 0u, 0u);
+// The pole watch of the long-row sweeps (fp64; pole_kernels.hip redoes what it lists) leaves pass 2 -- at the edge of its 128
+// registers -- alone.  Pass 1 votes, answer row by answer row: does a thread's sum of likelihoods (two elements) reach a quarter of
+// its WAVE's sum?  That is necessary for one of its elements to hold a quarter of W_k, and never true on a fresh quiz's rows.  The
+// votes of a question's rows are OR-ed as masks (no branch per row: the rows' butterflies overlap); where any was cast (rare, until
+// the posterior has settled) the waves put the largest thread sum of every row into candSum[q][k] (an atomic max of the bits).
+// Behind the sweep cluster_watch_kernel holds those against W_k as the sweeps of eval_kernels.hip do their lanes' sums: a share of
+// 1 - 2^-9 lists the row, a quarter lists it if its velocity sum all but vanishes (pole_device.h: kSmallV).
+// (Measured on the way at 2000 x 5 x 100000, fp64, form that runs ahead, 3.16 ms without any watch: the largest element tracked
+//  inside pass 2 -- one integer max per element -- 4.12 ms, the scalar registers it pushed out going through VGPR lanes inside the
+//  loop; the second stage as a rarely taken loop over the LDS copy in front of pass 2 3.37 ms, 3.29 of it for the code's mere presence.)
+// the vote on the high words: four times the thread's sum, and a little (2^-9 ... 2^-8) more, reaches the wave's; all sums 0 does not pass
+__device__ __forceinline__ unsigned long long cluster_cand_vote(double sum, double waveSum) {
+  return __ballot((uint32_t)(d2u(sum) >> 32) >= (uint32_t)(d2u(waveSum) >> 32) - 0x00201000u);
 }
-// the folding member, thread k < K with the question's velocity sum of answer k: the wider watch's verdict
-__device__ __forceinline__ void cluster_watch_fold(const ClusterArgs &a, int64_t q, int k, double vSum) {
-  if (a.poleList == nullptr) return;
-  const uint32_t wide = __hip_atomic_load(&a.wideMask[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  if (((wide >> (k < 31 ? k : 31)) & 1u) && vSum <= kSmallV) cluster_watch_report(a, q, 1u << (k < 31 ? k : 31));
+__device__ __forceinline__ void cluster_cand_publish(unsigned long long *candSum, int64_t q, int64_t k, double sum, int lane) {
+  const double mx = wave_max_d(sum);
+  if (lane == 0) atomicMax(&candSum[q * kMaxK + k], d2u(mx));
 }
 
 // The members of a cluster run on different XCDs, whose L2s are not coherent with each other: records are written through (sc1)
@@ -223,11 +232,10 @@ __global__ __launch_bounds__(kClusterThreads, 4) void eval_cluster_kernel(Cluste
     if (tid < K + 2) {
       const double s = red[0][tid];
       double *tot = a.totals + (size_t)qq * (2 * kMaxK + 2);
-      if (tid < K) { tot[tid] = wOfQ[tid]; tot[kMaxK + tid] = s; if constexpr (NumC<R>::kTable) cluster_watch_fold(a, qq, tid, s); }
+      if (tid < K) { tot[tid] = wOfQ[tid]; tot[kMaxK + tid] = s; }
       else tot[2 * kMaxK + (tid - K)] = s;
     }
     __syncthreads();
-    if constexpr (NumC<R>::kTable) { if (tid == 0 && a.wideMask != nullptr) a.wideMask[qq] = 0; }   // (read above; the next launch finds it cleared)
   };
 
   auto next_valid = [&](int64_t q) {    // :54 gap / asked questions get priority 0 and are skipped (the same decision in every member)
@@ -267,6 +275,7 @@ __global__ __launch_bounds__(kClusterThreads, 4) void eval_cluster_kernel(Cluste
     for (int j = 0; j < NU; j++)
 #pragma unroll
       for (int e = 0; e < VN; e++) at<R>(id[j], e) = ((gapBits[j] >> e) & 1) ? (R)0 : NumC<R>::inv(at<R>(dN[j], e));   // :74
+    [[maybe_unused]] unsigned long long candVotes = 0;
     auto pass1_row = [&](int64_t k, const V (&row)[NU]) __attribute__((always_inline)) {
       R s = (R)0;
 #pragma unroll
@@ -282,6 +291,7 @@ __global__ __launch_bounds__(kClusterThreads, 4) void eval_cluster_kernel(Cluste
       }
       const double sw = wave_sum_d((double)s);
       if (lane == 0) red[k][wave] = sw;
+      if constexpr (NumC<R>::kTable) candVotes |= cluster_cand_vote((double)s, sw);   // (the pole watch)
     };
 #pragma unroll
     for (int k = 0; k < kRowsAhead; k++)
@@ -290,6 +300,23 @@ __global__ __launch_bounds__(kClusterThreads, 4) void eval_cluster_kernel(Cluste
       V late[NU];
       load_units(qb + k * ldT, late);
       pass1_row(k, late);
+    }
+    if constexpr (NumC<R>::kTable) {
+      if (candVotes != 0 && a.candSum != nullptr) {             // (rare: the rows' thread sums again, from the LDS copy this thread wrote)
+        for (int64_t k = 0; k < K; k++) {
+          R sk = (R)0;
+#pragma unroll
+          for (int j = 0; j < NU; j++) {
+            const int sl = tid + j * kClusterThreads;
+            if (sl < SU) {
+              const V lh = lhL[k * SU + sl];
+#pragma unroll
+              for (int e = 0; e < VN; e++) sk += at<R>(lh, e);
+            }
+          }
+          cluster_cand_publish(a.candSum, q, k, (double)sk, lane);
+        }
+      }
     }
     __syncthreads();
     if (tid < K) {
@@ -311,11 +338,9 @@ __global__ __launch_bounds__(kClusterThreads, 4) void eval_cluster_kernel(Cluste
     // ---- pass 2 (:95-128) from LDS, answer by answer; the lack term's N / D pairs (batch_kernels.hip) run across the answers
     V accN[NU], accD[NU];
     R hW = (R)0, accL = (R)0;
-    uint32_t poleRows = 0, quarterRows = 0;                     // (the pole watch: wave-uniform)
     for (int64_t k = 0; k < K; k++) {
       const R invWk = (R)div_fast(1.0, wTot[k]);                // :91
       R vk = (R)0;
-      [[maybe_unused]] uint32_t hiMax = 0;
 #pragma unroll
       for (int j = 0; j < NU; j++) {
         const int sl = tid + j * kClusterThreads;
@@ -325,7 +350,6 @@ __global__ __launch_bounds__(kClusterThreads, 4) void eval_cluster_kernel(Cluste
           for (int e = 0; e < VN; e++) {
             const R l = at<R>(lh, e), pi = at<R>(pr[j], e);
             const R p = l * invWk;                              // :97
-            if constexpr (NumC<R>::kTable) hiMax = max(hiMax, (uint32_t)(d2u((double)p) >> 32));
             const R l2 = NumC<R>::log2p(p, tbl);                // :106
             hW = fma(l, l2, hW);                                // :113-114 weighted by W_k (eval_epilogue)
             const R dd = p - pi;                                // :119
@@ -338,12 +362,6 @@ __global__ __launch_bounds__(kClusterThreads, 4) void eval_cluster_kernel(Cluste
       }
       const double s = wave_sum_d((double)vk);
       if (lane == 0) red[k][wave] = s;
-      if constexpr (NumC<R>::kTable) {
-        if (a.poleList != nullptr && __any(hiMax >= kQuarterHi)) {
-          quarterRows |= 1u << (k < 31 ? (int)k : 31);
-          if (__any(hiMax >= kNearOneHi)) poleRows |= 1u << (k < 31 ? (int)k : 31);
-        }
-      }
     }
 #pragma unroll
     for (int j = 0; j < NU; j++) {
@@ -359,10 +377,6 @@ __global__ __launch_bounds__(kClusterThreads, 4) void eval_cluster_kernel(Cluste
     {
       const double s1 = wave_sum_d((double)hW), s2 = wave_sum_d((double)accL);
       if (lane == 0) { red[K][wave] = s1; red[K + 1][wave] = s2; }
-    }
-    if (quarterRows != 0 && lane == 0) {                        // (rare)
-      atomicOr(&a.wideMask[q], quarterRows);
-      if (poleRows != 0) cluster_watch_report(a, q, poleRows);
     }
     __syncthreads();
     if (tid < K + 2) {
@@ -479,11 +493,10 @@ __global__ __launch_bounds__(kClusterThreads, 4) void eval_cluster_ahead_kernel(
     if (tid < K + 2) {
       const double s = red[0][tid];
       double *tot = a.totals + (size_t)qq * (2 * kMaxK + 2);
-      if (tid < K) { tot[tid] = wHist[(cnt & 3) * kMaxK + tid]; tot[kMaxK + tid] = s; if constexpr (NumC<R>::kTable) cluster_watch_fold(a, qq, tid, s); }
+      if (tid < K) { tot[tid] = wHist[(cnt & 3) * kMaxK + tid]; tot[kMaxK + tid] = s; }
       else tot[2 * kMaxK + (tid - K)] = s;
     }
     __syncthreads();
-    if constexpr (NumC<R>::kTable) { if (tid == 0 && a.wideMask != nullptr) a.wideMask[qq] = 0; }   // (read above; the next launch finds it cleared)
   };
   auto next_valid = [&](int64_t q) {    // :54
     while (q < a.Q && (bit_test(a.qgap, q) || bit_test(a.asked, q))) {
@@ -506,7 +519,8 @@ __global__ __launch_bounds__(kClusterThreads, 4) void eval_cluster_ahead_kernel(
   auto pass1 = [&](int64_t qq, unsigned long long cnt, V &idOut, V (&lhOut)[kRows]) __attribute__((always_inline)) {
 #pragma unroll
     for (int e = 0; e < VN; e++) at<R>(idOut, e) = ((gapBits >> e) & 1) ? (R)0 : NumC<R>::inv(at<R>(dN, e));   // :74
-    auto row_sum = [&](int64_t k, const V &row, V &lh) __attribute__((always_inline)) {
+    [[maybe_unused]] unsigned long long candVotes = 0;
+    auto row_sum = [&](int64_t k, const V &row, V &lh, bool late) __attribute__((always_inline)) {
       R sum = (R)0;
 #pragma unroll
       for (int e = 0; e < VN; e++) {
@@ -518,15 +532,28 @@ __global__ __launch_bounds__(kClusterThreads, 4) void eval_cluster_ahead_kernel(
       } else {
         const double sw = wave_sum_d((double)sum);
         if (lane == 0) red[k][wave] = sw;
+        if constexpr (NumC<R>::kTable) { const unsigned long long vote = cluster_cand_vote((double)sum, sw); candVotes |= vote; if (late && vote != 0 && a.candSum != nullptr) cluster_cand_publish(a.candSum, qq, k, (double)sum, lane); }   // (the pole watch)
       }
     };
 #pragma unroll
     for (int k = 0; k < kRows; k++)
-      if (k < K) row_sum(k, rows[k], lhOut[k]);
+      if (k < K) row_sum(k, rows[k], lhOut[k], false);
     for (int64_t k = kRows; k < K; k++) {                       // (more than kRows answers: summed here, formed again for LDS later)
       const V late = load_unit(reinterpret_cast<const V *>(cube + qq * qStride + k * ldT) + ui);
       V lh;
-      row_sum(k, late, lh);
+      row_sum(k, late, lh, true);
+    }
+    if constexpr (NumC<R>::kTable) {
+      if (candVotes != 0 && a.candSum != nullptr) {             // (rare: the rows' thread sums again, from the registers; rows beyond kRows published theirs)
+#pragma unroll
+        for (int k = 0; k < kRows; k++)
+          if (k < K) {
+            R sk = (R)0;
+#pragma unroll
+            for (int e = 0; e < VN; e++) sk += at<R>(lhOut[k], e);
+            cluster_cand_publish(a.candSum, qq, k, (double)sk, lane);
+          }
+      }
     }
     __syncthreads();
     if constexpr (kParkPass1) {
@@ -624,18 +651,15 @@ __global__ __launch_bounds__(kClusterThreads, 4) void eval_cluster_ahead_kernel(
     double *slot = reinterpret_cast<double *>(lhL);             // unit u of row k: slot[(k * SU + u) * 2 + {0, 1}]
     V accN, accD;
     R hW = (R)0, accL = (R)0;
-    uint32_t poleRows = 0, quarterRows = 0;                     // (the pole watch: wave-uniform)
     for (int64_t k = 0; k < K; k++) {
       const R invWk = (R)wInv[k];                               // :91 (formed once per workgroup, above)
       R vk = (R)0;
-      [[maybe_unused]] uint32_t hiMax = 0;
       if (inSlice) {
         const V lh = lhL[k * SU + tid];
 #pragma unroll
         for (int e = 0; e < VN; e++) {
           const R l = at<R>(lh, e), pi = at<R>(pr, e);
           const R p = l * invWk;                                // :97
-          if constexpr (NumC<R>::kTable) hiMax = max(hiMax, (uint32_t)(d2u((double)p) >> 32));
           const R l2 = NumC<R>::log2p(p, tbl);                  // :106
           hW = fma(l, l2, hW);                                  // :113-114 weighted by W_k (eval_epilogue)
           const R dd = p - pi;                                  // :119
@@ -645,16 +669,6 @@ __global__ __launch_bounds__(kClusterThreads, 4) void eval_cluster_ahead_kernel(
         }
         slot[(k * SU + tid) * 2] = (double)vk;
       }
-      if constexpr (NumC<R>::kTable) {
-        if (a.poleList != nullptr && __any(hiMax >= kQuarterHi)) {
-          quarterRows |= 1u << (k < 31 ? (int)k : 31);
-          if (__any(hiMax >= kNearOneHi)) poleRows |= 1u << (k < 31 ? (int)k : 31);
-        }
-      }
-    }
-    if (quarterRows != 0 && lane == 0) {                        // (rare)
-      atomicOr(&a.wideMask[q], quarterRows);
-      if (poleRows != 0) cluster_watch_report(a, q, poleRows);
     }
     if (inSlice) {
 #pragma unroll
@@ -703,6 +717,23 @@ __global__ __launch_bounds__(kClusterThreads, 4) void eval_cluster_ahead_kernel(
   // the last two questions' sums: their turn-takers wait for them
   if (qPrev2 >= 0 && (int)((round - 2) % (unsigned long long)C) == m) fold(qPrev2, round - 2);
   if (qPrev >= 0 && (int)((round - 1) % (unsigned long long)C) == m) fold(qPrev, round - 1);
+}
+
+// The pole watch's verdict, behind the sweep (a thread per question and answer row; nearly all of them read one zero word and leave):
+// the largest thread sum a wave reported for the row against W_k -- the bars of the sweeps in eval_kernels.hip (kNearOneShare,
+// kQuarterShare there; the shares are of two elements' sum here, of a lane's there: bounds for the largest element both).
+__global__ __launch_bounds__(256) void cluster_watch_kernel(const double *__restrict__ totals, unsigned long long *__restrict__ candSum,
+                                                            uint32_t *__restrict__ poleMask, PoleHeader *list, int64_t K, int64_t Q) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  const int64_t q = i / kMaxK, k = i % kMaxK;
+  if (q >= Q || k >= K) return;
+  const unsigned long long bits = candSum[i];
+  if (bits == 0ull) return;
+  candSum[i] = 0ull;                                            // (the next launch finds it cleared)
+  const double *tot = totals + (size_t)q * (2 * kMaxK + 2);
+  const double top = __longlong_as_double((long long)bits), w = tot[k];
+  const bool list1 = top >= w * (1.0 - 0x1p-9) || (top > w * 0.2499 && tot[kMaxK + k] <= kSmallV);
+  if (list1 && atomicOr(&poleMask[q], 1u << k) == 0u) pole_list_append(list, (uint32_t)q, 0u, 0u);
 }
 
 // :134-207, one thread per question
@@ -813,7 +844,7 @@ size_t EvalClusterScratchBytes(const KbView &kb) {
   const bool ok = kb.elem == 4 ? cluster_shape<float>(kb, device_cus(), &s) : cluster_shape<double>(kb, device_cus(), &s);
   if (!ok) return 0;
   const size_t perCluster = (size_t)4 * s.C * (2 * kMaxK + 2) * sizeof(ExRec);   // (four record slots: the form that runs ahead; the other uses two)
-  return (size_t)s.nClusters * perCluster + (size_t)kb.Q * (2 * kMaxK + 2) * sizeof(double) + 256 + 2 * (size_t)kb.Q * sizeof(uint32_t);
+  return (size_t)s.nClusters * perCluster + (size_t)kb.Q * (2 * kMaxK + 2) * sizeof(double) + 256 + ((size_t)kb.Q + 2) * sizeof(uint32_t) + (size_t)kb.Q * kMaxK * sizeof(unsigned long long);
 }
 
 hipError_t LaunchEvalCluster(const KbView &kb, const double *prior, const uint32_t *asked, double *priority, void *scratch, hipStream_t stream) {
@@ -833,7 +864,7 @@ hipError_t LaunchEvalCluster(const KbView &kb, const double *prior, const uint32
   const bool watch = !f32 && kb.poleList != nullptr && kb.poleScratch != nullptr;
   a.poleList = watch ? kb.poleList : nullptr;
   a.poleMask = watch ? reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(a.totals) + (size_t)kb.Q * (2 * kMaxK + 2) * sizeof(double) + 256) : nullptr;
-  a.wideMask = watch ? a.poleMask + kb.Q : nullptr;
+  a.candSum = watch ? reinterpret_cast<unsigned long long *>(a.poleMask + ((kb.Q + 1) & ~(int64_t)1)) : nullptr;
   static std::atomic<unsigned long long> launches{0};
   a.tagBase = (launches.fetch_add(1) + 1) << 32;
   hipError_t e = hipSuccess;
@@ -851,6 +882,8 @@ hipError_t LaunchEvalCluster(const KbView &kb, const double *prior, const uint32
   e = hipGetLastError();
   if (e != hipSuccess) return e;
   if (watch) {
+    hipLaunchKernelGGL(cluster_watch_kernel, dim3((unsigned)((kb.Q * kMaxK + 255) / 256)), dim3(256), 0, stream, a.totals, a.candSum, a.poleMask,
+                       a.poleList, kb.K, kb.Q);
     // the questions on the list, redone in the reference's order where their totals lie (W_k | V_k | sum l log2 p | lack); the
     // epilogues below then see the corrected totals
     PoleFix f{};

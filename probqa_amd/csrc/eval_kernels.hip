@@ -244,7 +244,7 @@ __device__ __forceinline__ void pass2_pair(double2 lh, double2 id, double2 pr, d
 // ------------------------------------------------------------------------------------------------------------------
 constexpr double kNearOneShare = 1.0 - 0x1p-9;   // (of the wave's sum, of W_k: see above; the bar is pole_device.h: kNearOneHi)
 constexpr double kQuarterShare = 0.2499;         // ... and the wider watch (a strict compare: a wave of padding lanes, all sums 0, does not pass) for rows with a vanishing velocity sum (pole_device.h: kSmallV)
-constexpr int kSusDoubles = 3;                 // LDS: two words (by question parity: the answer rows that passed the watch, a bit each) + a slot
+constexpr int kSusDoubles = 4;                 // LDS: words [0], [1] by question parity (the answer rows that passed the watch, a bit each), [4] the list slot -- an EVEN count of doubles: the LDS priors behind it are read as 16-byte pairs
 
 // LDS-DMA: 16 bytes per lane from global memory straight into LDS, no destination VGPRs (buffer_load_dwordx4 ... offen lds:
 // row base in an SGPR descriptor, the lane's 32-bit byte offset in a VGPR -- no 64-bit address pairs either); completion is
@@ -286,6 +286,8 @@ constexpr int kPend = 32;
 __host__ __device__ constexpr size_t eval_lds_fixed_doubles(int wpq, int64_t K) {
   return kLog2TableDoubles + 2 * (size_t)wpq + 2 * (size_t)(K + 2) * wpq + (size_t)kPend * (2 * (size_t)K + 3) + 2 * kWave + kSusDoubles;
 }
+static_assert(kSusDoubles % 2 == 0 && kLog2TableDoubles % 2 == 0 && (kPend * 3) % 2 == 0,
+              "the LDS priors behind the fixed part are read as 16-byte pairs: an odd count of doubles in front of them halves their rate (10000 x 5 x 10000: 906 -> 1250 us)");
 __host__ __device__ constexpr size_t eval_md_row_offset_bytes(int wpq, int64_t K) {
   return (eval_lds_fixed_doubles(wpq, K) * sizeof(double) + 1023) / 1024 * 1024;
 }

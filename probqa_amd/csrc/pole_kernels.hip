@@ -10,21 +10,23 @@
 //  -- but only the rows AT the pole need it.
 //
 // So every sweep only WATCHES (a compare per row; eval_kernels.hip, cluster_kernels.hip, batch_kernels.hip): a question with a row
-// whose largest posterior element is within 2^-10 of 1 (pole_device.h: kNearOneHi -- why there) leaves its sums in memory and an entry in the suspect list, and the sweep's finisher, seeing a non-empty list, leaves
-// the publication of the result to this kernel, which is launched behind every watching sweep (an empty list: a few hundred
-// threads read one word and leave).  Here a workgroup takes one suspect at a time:
-//   * waves 1 - 3 form the likelihoods (A * invD) * prior of the listed rows again, chunk by chunk, into LDS -- bit for bit the
-//     sweep's and the reference's (:72-82) -- and keep each row's largest element;
-//   * wave 0 runs the rows' reference-order sums side by side, four lanes per row (the chunks double-buffered against the
-//     stagers), PreciseSum folds the four;
-//   * for the element within 2^-10 of 1: Log2Hot by the reference's own operation sequence (SRVectMath.h:87-135) on
+// whose largest posterior element is within 2^-10 of 1, or holds a quarter of the row while the answer hardly moves the posterior
+// (pole_device.h: kNearOneHi, kQuarterHi, kSmallV -- why there), leaves its sums in memory and an entry in the suspect list, and
+// the sweep's finisher, seeing suspects, leaves the publication of the result to this kernel, which is launched behind every
+// watching sweep (an empty list: a few hundred threads read one word and leave).  Here a WAVE takes one suspect at a time:
+//   * the operands of the listed rows -- the answer rows, mD, the priors, the gap words -- come in chunk by chunk by LDS-DMA,
+//     kFixDepth chunks ahead of the one worked on (no register is held across the wait);
+//   * the lanes form the likelihoods (A * invD) * prior again in place -- bit for bit the sweep's and the reference's (:72-82) --
+//     and keep each row's largest element;
+//   * four lanes per row run the reference-order sums, all rows of the question side by side; PreciseSum folds the four;
+//   * for the row's largest element: Log2Hot by the reference's own operation sequence (SRVectMath.h:87-135) on
 //     p = l * (1 / W_k) with the reference-order W_k, and its entropy, lack and velocity terms replace what pass 2 had added;
 //   * the epilogue (:134-207) again, the priority stored (and handed to the host where the sweep hands priorities over).
 // The last workgroup to finish then does what the sweep's finisher left undone: the argmax / the reference's selector / the
 // flag of the hand-over, and empties the list.
 // In a late quiz EVERY question has such rows (the target's likelihood is all of W_k whatever the answer): the fix then re-reads
-// the cube once and runs T / 4 dependent steps per question, a few questions per CU at a time -- about one more sweep's time,
-// whatever the row length; the in-kernel fix of round 4 (rows of up to 4096 targets only, lists of 62 / 128 suspects) cost 4.5 - 6.5.
+// the cube once and runs T / 4 dependent steps per question, four questions per CU and SIMD at a time -- one to two more sweeps'
+// time; the in-kernel fix of round 4 (rows of up to 4096 targets only, lists of 62 / 128 suspects) cost 4.5 - 6.5.
 #include <cmath>
 
 #include "eval_device.h"
@@ -459,7 +461,8 @@ hipError_t LaunchPoleFixup(const PoleFix &fix, hipStream_t stream) {
     if (need > shmem) shmem = need;
   }
   if (shmem > 160 * 1024) return hipErrorInvalidValue;
-  static LaunchCache cache;   // (the shape is a function of the LDS size, up to selections with very many subtasks)
+  static LaunchCache caches[4];   // (per kernel: the shape is a function of the LDS size, up to selections with very many subtasks)
+  LaunchCache &cache = caches[a.rows == 2 ? 0 : a.rows == 5 ? 1 : a.rows == 8 ? 2 : 3];
   const int dev = LaunchCache::Device();
   int perCU = 0;
   if (!cache.Get(dev, shmem, &perCU)) {
