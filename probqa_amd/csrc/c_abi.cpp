@@ -481,8 +481,14 @@ PQACORE_API void *PqaHip_PickWhenAll(const void *pSlots, const int64_t world, co
   for (int64_t r = 0; r < world; r++) {
     const volatile uint64_t *flag = (const volatile uint64_t *)(base + r * strideBytes + 16);
     uint64_t spins = 0;
-    while (*flag != flagValue) {   // (a pure spin while the answer is a kernel's time away, then the core is offered between looks)
-      if (++spins < 1500) { __builtin_ia32_pause(); continue; }
+    bool yielding = false;
+    while (*flag != flagValue) {   // (a pure spin for the first 200 us -- the answer is a kernel's time away --, then the core is offered between looks)
+      ++spins;
+      if (!yielding) {
+        __builtin_ia32_pause();
+        if ((spins & 63) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(200)) yielding = true;
+        continue;
+      }
       if ((spins & 0xFF) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeoutSec)
         return ReturnErr(Error::MakeP(ErrCode::StdException, "rank=" + std::to_string(r), "Timed out waiting for a shard's selection."));
       sched_yield();

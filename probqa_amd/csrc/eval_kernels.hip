@@ -568,7 +568,7 @@ __device__ __forceinline__ void sweep_body(EvalArgs a, bool copyTable) {
     double *part = partAll + qpar * (nPart * WPQ);
     double *rec = pend + nPend * recLen;
     double accL = 0, hW = 0;
-    uint32_t poleRows = 0, quarterRows = 0;                    // (pole watch: the rows that passed -- an element next to 1; an element of a quarter -- wave-uniform)
+    [[maybe_unused]] uint32_t watchRows = 0;                   // (pole watch, per lane: the rows in which this lane's sum is nearly all of W_k below, a quarter of it above)
     for (int64_t k = 0; k < K; k++) {
       // ---- pass 1 (:66-87): likelihoods into registers, W_k; each consumed pair is refilled from the next stream row
       double2 lh[NP];
@@ -608,21 +608,6 @@ __device__ __forceinline__ void sweep_body(EvalArgs a, bool copyTable) {
       }
       const double sLane = s0 + s1;
       double Wk = wave_sum(sLane);                             // :88
-      bool watchHit = false, watchNear = false;               // (wave-uniform: a lane of this wave holds a quarter / nearly all of the wave's sum)
-      double waveW = 0.0;
-      if constexpr (kWatch) {
-        // (first by the high words -- two integer instructions: 4 x sLane >= Wk only if its high word, two up in the exponent,
-        //  reaches Wk's; the exact tests behind the vote, and pinned there: hoisted, their multiplications ran for every row)
-        if (__any((uint32_t)(d2u(sLane) >> 32) + 0x00200000u >= (uint32_t)(d2u(Wk) >> 32))) {
-          double wq = Wk;
-          asm volatile("" : "+v"(wq));
-          watchHit = __any(sLane > wq * kQuarterShare);
-          if (watchHit) {
-            waveW = uniform_double(Wk);                          // (in scalar registers across the exchange)
-            watchNear = __any(sLane >= wq * kNearOneShare);
-          }
-        }
-      }
       if constexpr (WPQ > 1) {
         double *buf = redW + phase * WPQ;
         if (lane == 0) buf[wave] = Wk;
@@ -631,14 +616,14 @@ __device__ __forceinline__ void sweep_body(EvalArgs a, bool copyTable) {
         phase ^= 1;
       }
       if constexpr (kWatch) {
-        if (watchHit) {                                          // (rare before a quiz's last third)
-          double wq = Wk;
-          asm volatile("" : "+v"(wq));
-          if (__any(waveW >= wq * kQuarterShare)) {
-            quarterRows |= 0x10000u << (k < 15 ? (int)k : 15);   // (one word per question: the rows with an element of a quarter above, the listed rows below)
-            if (watchNear && __any(waveW >= wq * kNearOneShare)) poleRows |= 1u << (k < 15 ? (int)k : 15);
-          }
-        }
+        // Does this lane's sum reach a quarter of W_k / nearly all of it (a share of 1 - 2^-9)?  On the high words -- an integer add
+        // and compare each, the bars a little (2^-9 ... 2^-8) on the generous side; lanes of padding, sum 0, do not pass -- per lane and
+        // without a branch: a bit per row in one word per question (the rows with an element of a quarter above, the rows to list
+        // below), OR-ed into LDS at the question's end by the lanes that have any.  (A vote and a branch per row in front of the
+        // exchange cost the launched 1000-target sweep 6 - 8 %; this form nothing measurable there, ~0.5 us of the resident step's 16.)
+        const uint32_t hs = (uint32_t)(d2u(sLane) >> 32), hw = (uint32_t)(d2u(Wk) >> 32);
+        const uint32_t kb = (uint32_t)(k < 15 ? k : 15);
+        watchRows |= (hs + 0x00201000u >= hw ? 0x10000u << kb : 0u) | (hs + 0x00001000u >= hw ? 1u << kb : 0u);   // (per lane: no vote, no scalar result to wait for)
       }
       const double invWk = div_nr(1.0, Wk);                    // :91
       // ---- pass 2 (:95-128)
@@ -671,7 +656,7 @@ __device__ __forceinline__ void sweep_body(EvalArgs a, bool copyTable) {
       vdump[K * kThreads + tid] = hW;
       vdump[(K + 1) * kThreads + tid] = accL;
       if constexpr (kWatch) {                                   // (rare)
-        if (quarterRows != 0 && lane == 0) atomicOr(&susWords[qpar], quarterRows | poleRows);
+        if (watchRows != 0) atomicOr(&susWords[qpar], watchRows);   // (the lanes that hold such a sum: one or two of a late quiz's wave)
       }
       __syncthreads();
       uint32_t wideRows = 0;                                     // workgroup-uniform: the rows with an element of a quarter
@@ -730,7 +715,7 @@ __device__ __forceinline__ void sweep_body(EvalArgs a, bool copyTable) {
         part[(K + 1) * WPQ + wave] = accL;
       }
       if constexpr (kWatch) {                                   // (rare)
-        if (quarterRows != 0 && lane == 0) atomicOr(&susWords[qpar], quarterRows | poleRows);
+        if (watchRows != 0) atomicOr(&susWords[qpar], watchRows);   // (the lanes that hold such a sum: one or two of a late quiz's wave)
       }
       if constexpr (WPQ > 1) __syncthreads();
       uint32_t wideRows = 0;

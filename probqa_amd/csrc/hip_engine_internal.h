@@ -77,9 +77,17 @@ static_assert(sizeof(std::atomic<int>) == sizeof(int), "the state word is slept 
 // allowance on waiting -- and the clock is read only every so often.  Tick() returns false once `limit` has passed.
 struct SpinWait {
   uint64_t spins = 0;
+  bool yielding = false;
   std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+  // (by TIME, not by count: a pause is 15 - 40 ns on the hosts met so far, and a count that ran out just before a 20 us step's answer
+  //  put a system call -- a microsecond -- into every selection)
   bool Tick(std::chrono::seconds limit) {
-    if (++spins < 1500) { _mm_pause(); return true; }
+    ++spins;
+    if (!yielding) {
+      _mm_pause();
+      if ((spins & 63) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(200)) yielding = true;
+      return true;
+    }
     if ((spins & 0xFF) == 0 && std::chrono::steady_clock::now() - t0 > limit) return false;
     sched_yield();
     return true;

@@ -26,6 +26,15 @@ def test_sweep_timing_tool():
     assert re.search(r"300x5x700 wg256_np\d+: sweep [\d.]+ us after StartQuiz; [\d.]+ us after", out), out
 
 
+def test_pole_cost_and_late_tools():
+    out = run_tool("pole_cost.py", "300x5x700", "late", 5)
+    assert re.search(r"300x5x700 \S+ late .*: [\d.]+ us per sweep back to back", out), out
+    out = run_tool("late_run.py", 0, 4)
+    assert len(re.findall(r"worst relative deviation [\d.e+-]+", out)) == 2, out
+    out = run_tool("late_probe.py", 6)
+    assert "late0006" in out, out
+
+
 def test_batch_bench_tool_same_pick_by_every_group_count():
     picks = set()
     for groups in (1, 4, 0):
