@@ -184,7 +184,8 @@ __device__ __forceinline__ void fused_select(const EvalArgs &a, Best mine, int l
   // A workgroup's question passed the pole watch: the fix launched behind this sweep publishes the result (pole_kernels.hip) -- or,
   // the resident kernel, behind which nothing can be launched: the step's answer says so (index -4; the caller takes the launched path)
   const bool suspects = __any(anySuspect != 0);
-  const bool deferred = !UNI && suspects && complete && a.poleList != nullptr, redo = UNI && suspects && !a.serverNoWatch;
+  const bool listed = !UNI && suspects && complete && a.poleList != nullptr, lazy = a.fs.lazyFix != 0;   // (lazy: the caller launches the fix when told to -- index -4, as the resident kernel's)
+  const bool deferred = listed && !lazy, redo = (UNI && suspects && !a.serverNoWatch) || (listed && lazy);
   if (sampled) {           // the selection follows (sweep_body); only whether the sweep is complete (and whether it publishes) is handed on
     if (allReported != nullptr && (UNI || lane == 0)) { allReported[0] = complete; allReported[1] = deferred; allReported[2] = redo; }
     return;
@@ -1389,7 +1390,7 @@ hipError_t launch_reg_form(const EvalArgs &args, int64_t nQ, int nBatch, hipStre
   if (args.maxGrid > 0 && resGrid > args.maxGrid) resGrid = args.maxGrid;   // (test hook: KbView::maxGrid)
   hipLaunchKernelGGL(kern, dim3((unsigned)resGrid, (unsigned)nBatch), dim3(WPQ * 64), shmem, stream, args);
   const hipError_t le = hipGetLastError();
-  if constexpr (POLE) { if (le == hipSuccess && !args.poleNoFollow) return launch_pole_fixup(args, stream, nBatch); }
+  if constexpr (POLE) { if (le == hipSuccess && !args.poleNoFollow && !args.fs.lazyFix) return launch_pole_fixup(args, stream, nBatch); }
   return le;
 }
 
@@ -1447,7 +1448,7 @@ hipError_t launch_variant(const EvalArgs &args, int64_t ldT, int variant, int nB
       const unsigned grid = (unsigned)(nQ < maxBlocks ? nQ : maxBlocks);
       hipLaunchKernelGGL(eval_questions_f64_stream, dim3(grid, (unsigned)nBatch), dim3(256), shmem, stream, args);
       const hipError_t le = hipGetLastError();
-      if (le == hipSuccess && args.poleList != nullptr) return launch_pole_fixup(args, stream, nBatch);
+      if (le == hipSuccess && args.poleList != nullptr && !args.fs.lazyFix) return launch_pole_fixup(args, stream, nBatch);
       return le;
     }
     default: return hipErrorInvalidValue;
@@ -1494,6 +1495,17 @@ hipError_t LaunchEvalQuestions(const KbView &kb, const double *prior, const uint
   args.priority = priority;
   if (fused) args.fs = *fused;
   return launch_variant(args, kb.ldT, variant, 1, stream);
+}
+
+hipError_t LaunchEvalPoleFixup(const KbView &kb, const double *prior, const uint32_t *asked, double *priority, const FusedSelect &fused,
+                               hipStream_t stream) {
+  EvalArgs args = make_args(kb, 0, kb.Q);
+  if (args.poleList == nullptr) return hipErrorInvalidValue;
+  args.prior = prior;
+  args.asked = asked;
+  args.priority = priority;
+  args.fs = fused;
+  return launch_pole_fixup(args, stream, 1);
 }
 
 // ---- the posterior update of one answer + the sweep over the new posterior (eval_questions_f64_upd).  Whole-cube Double engines,

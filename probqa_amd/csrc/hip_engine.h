@@ -520,6 +520,7 @@ class HipEngine : public IEngine {
   double *_dPriorScratch = nullptr;      // the long-row posterior kernels' subtask sums (KbView::priorScratch)
   int64_t _optPoleFix = 1;               // option "pole_fix"
   int64_t _optPoleFollow = 1;            // option "pole_follow" (measurement hook)
+  int64_t _optPoleLazy = 1;              // option "pole_lazy": synchronous single-quiz selections launch the fix only when the sweep listed something (FusedSelect::lazyFix)
   int64_t _optLongRowForm = 1;           // option "long_row_form": StartQuiz / RecordAnswer over rows beyond 16384 targets as one workgroup per subtask of the sum
   // batched selections (NextQuestionArgmaxBatch); allocated on first use
   static constexpr int64_t kMaxBatch = 256, kBatchGrid = 1024;
@@ -562,7 +563,9 @@ class HipEngine : public IEngine {
   void *_dClusterScratch = nullptr;   // exchange buffers of the long-row sweep (cluster_kernels.hip), grown on demand
   size_t _clusterScratchBytes = 0;
   bool UseClusterSweep() const;       // rows beyond the register shapes, automatic variant, shape supported
-  Error LaunchSingleSweep(Quiz *q, const FusedSelect *fused);   // the single-quiz sweep of this engine's precision, on _stream
+  Error LaunchSingleSweep(Quiz *q, const FusedSelect *fused);
+  bool LazyFix() const;
+  Error RunLazyFix(Quiz *q, const FusedSelect &swept, const char *what);   // the single-quiz sweep of this engine's precision, on _stream
   uint64_t _selSeq = 0;
   // Tag of the next fused launch: consecutive launches differ in the low 32 bits, and those are never 0 (the state of
   // freshly cleared records)

@@ -285,6 +285,21 @@ Error HipEngine::WaitFlag(volatile uint64_t *flag, uint64_t value, const char *w
 
 int64_t HipEngine::NextQuestionArgmax(Error &err, int64_t iQuiz) { return Combine(err, iQuiz, 0, 0); }
 
+// Synchronous single-quiz selections of a Double engine through a register shape (whose finisher knows whether anything was listed):
+// the fix of pole_kernels.hip is launched only when the sweep says so (FusedSelect::lazyFix) -- one launch per selection of a fresh quiz.
+bool HipEngine::LazyFix() const {
+  return _optPoleFix && _optPoleLazy && _optPoleFollow && _elem == 8 && !UseClusterSweep() && EvalVariantHasFinisherWorkgroup(View(), (int)_optEvalVariant);
+}
+Error HipEngine::RunLazyFix(Quiz *q, const FusedSelect &swept, const char *what) {
+  FusedSelect fs = swept;
+  fs.lazyFix = 0;
+  fs.flagValue = NextLaunchTag();   // (the records of a hand-over keep the sweep's tag, seqValue)
+  HIP_TRY(LaunchEvalPoleFixup(View(), q->dPrior, q->dAsked, _dPriority, fs, _stream));
+  Error err = WaitFlag(fs.seq, fs.flagValue, what);
+  std::atomic_thread_fence(std::memory_order_acquire);
+  return err;
+}
+
 // One quiz, by itself (the caller holds _mu)
 int64_t HipEngine::NextQuestionArgmaxLocked(Error &err, int64_t iQuiz) {
   err = CheckRegular("compute next question");
@@ -314,9 +329,10 @@ int64_t HipEngine::NextQuestionArgmaxLocked(Error &err, int64_t iQuiz) {
   // One launch; the last workgroup writes the winner and then a sequence number straight into host-coherent pinned
   // memory, which this thread polls: no D2H copy, no stream synchronisation on the critical path.
   uint64_t seq;
+  FusedSelect fs{};
   if (TakeSpeculation(q, 1 << 1, &seq) == 0) {   // (else: RecordAnswer has launched this very sweep already)
     seq = NextLaunchTag();
-    const FusedSelect fs{_dSelScratch, &_hPinned->sel, &_hPinned->seq, seq, 0, 0, seq, nullptr, 0, 0, nullptr, nullptr};
+    fs = FusedSelect{_dSelScratch, &_hPinned->sel, &_hPinned->seq, seq, 0, 0, seq, nullptr, 0, 0, nullptr, nullptr, LazyFix() ? 1 : 0};
     StopServer();   // a launched sweep has no room beside the resident one and would wait for it to idle out
     err = LaunchSingleSweep(q, &fs);
     if (!err.ok()) return -1;
@@ -324,6 +340,10 @@ int64_t HipEngine::NextQuestionArgmaxLocked(Error &err, int64_t iQuiz) {
   err = WaitFlag(&_hPinned->seq, seq, "NextQuestionArgmax");
   if (!err.ok()) return -1;
   std::atomic_thread_fence(std::memory_order_acquire);
+  if (_hPinned->sel.index == -4 && fs.lazyFix) {   // the sweep listed rows at the pole of the lack term: the fix now, and its answer
+    err = RunLazyFix(q, fs, "NextQuestionArgmax");
+    if (!err.ok()) return -1;
+  }
   if (_hPinned->sel.index == -3) {  // the sweep's finisher gave up: some workgroup of the launch never reported
     err = HipErr(hipErrorLaunchFailure, "NextQuestionArgmax (incomplete sweep)");
     return -1;
@@ -705,14 +725,19 @@ int64_t HipEngine::NextQuestionSampledLocked(Error &err, int64_t iQuiz, uint64_t
     const hipError_t ae = EnsureHostPriority();
     if (ae != hipSuccess) { err = HipErr(ae, "host priority buffer"); return -1; }
     uint64_t seq = specTag;
+    FusedSelect fs{};
     if (!speculated) {
       seq = NextLaunchTag();
-      const FusedSelect fs{_dSelScratch, &_hPinned->sel, &_hPinned->seq, seq, 0, 0, seq, nullptr, 1, 0, nullptr, _hHostPriority};
+      fs = FusedSelect{_dSelScratch, &_hPinned->sel, &_hPinned->seq, seq, 0, 0, seq, nullptr, 1, 0, nullptr, _hHostPriority, LazyFix() ? 1 : 0};
       const hipError_t he = LaunchEvalQuestions(kb, q->dPrior, q->dAsked, 0, _Q, _dPriority, (int)_optEvalVariant, &fs, _stream);
       if (he != hipSuccess) { err = HipErr(he, "NextQuestionSampled"); return -1; }
     }
     err = WaitFlag(&_hPinned->seq, seq, "NextQuestionSampled");
     if (!err.ok()) return -1;
+    if (_hPinned->sel.index == -4 && fs.lazyFix) {   // (as NextQuestionArgmaxLocked: the corrected entries carry the sweep's tag)
+      err = RunLazyFix(q, fs, "NextQuestionSampled");
+      if (!err.ok()) return -1;
+    }
     if (_hPinned->sel.index == -3) { err = HipErr(hipErrorLaunchFailure, "NextQuestionSampled (incomplete sweep)"); return -1; }
     err = CollectHostPriority(seq, q);
     if (!err.ok()) return -1;

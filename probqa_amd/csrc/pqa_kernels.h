@@ -118,6 +118,11 @@ struct FusedSelect {
   // finisher raises the flag once it has seen every workgroup's record; the host takes an entry when it carries the launch's tag
   // (it almost always does by then; a straggling store is waited for there, not by two thousand waves on the device).
   TaggedPriority *hostPriority;
+  // A synchronous caller that waits on `seq` right behind its launch may ask for the fix of pole_kernels.hip only when the sweep
+  // has listed something (lazyFix != 0; argmax and hostPriority forms): nothing is launched behind the sweep, and a finisher
+  // that saw suspects publishes index -4 instead of leaving the publication to the fix; the caller then launches
+  // LaunchEvalPoleFixup (same arguments, a new flagValue) and waits again.  A fresh quiz's selections so cost one launch, not two.
+  int64_t lazyFix;
 };
 // One quiz of a batched sweep (blockIdx.y selects it): everything that differs between the quizzes of one launch.
 struct QuizSlot {
@@ -131,6 +136,9 @@ struct QuizSlot {
 };
 hipError_t LaunchEvalQuestions(const KbView &kb, const double *prior, const uint32_t *asked, int64_t qFirst,
                                int64_t qLimit, double *priority, int variant, const FusedSelect *fused,
+                               hipStream_t stream);
+// the fix behind a sweep launched with FusedSelect::lazyFix whose answer was -4 (the sweep's own arguments; fused.flagValue: what the caller waits for now)
+hipError_t LaunchEvalPoleFixup(const KbView &kb, const double *prior, const uint32_t *asked, double *priority, const FusedSelect &fused,
                                hipStream_t stream);
 // The fix behind a watching sweep.  A record of sums is `sumsStride` doubles: W_k [K] at wOff, W_k sqrt(V_k) (secondIsWV) or V_k [K]
 // at vOff, sum l log2 p at hOff, the lack sum at lOff; record of entry e: e itself (bySlot) or its question.  priority (or priorityT

@@ -161,6 +161,35 @@ def test_late_state(i, factory):
     assert worst < 1e-9, (case.name, worst)
 
 
+@pytest.mark.parametrize("i", [0, 2, 6, 10, 12, 26, 30])
+def test_lazy_and_eager_fix_agree(i, factory):
+    """Synchronous single-quiz selections launch the fix of pole_kernels.hip only when the sweep has listed something (engine option
+    pole_lazy, default on: FusedSelect::lazyFix); with pole_lazy = 0 it is launched behind every sweep.  Same picks by the argmax
+    and by the reference's selector (host hand-over form) on every step of late-state cases."""
+    leg, case, options = late_case(i)
+    if leg in ("mid", "rowshare", "gridy", "cluster"):
+        pytest.skip("single-quiz register shapes only")
+    picks = []
+    for lazy in (1, 0):
+        eng = case.make_engine(factory)
+        for n, v in options:
+            eng.set_option(n, v)
+        eng.set_option("speculate", 0)
+        eng.set_option("pole_lazy", lazy)
+        assert eng.get_option("pole_lazy") == lazy
+        quiz = eng.start_quiz()
+        got = []
+        for step in range(len(case.answers) + 1):
+            got.append((eng.next_question_argmax(quiz), eng.next_question_sampled(quiz, 0x9E3779B97F4A7C15 * (step + 1) % 2**64)))
+            if step < len(case.answers):
+                q, a = case.answers[step]
+                eng.set_active_question(quiz, q)
+                eng.record_answer(quiz, a)
+        eng.close()
+        picks.append(got)
+    assert picks[0] == picks[1], (case.name, picks)
+
+
 def test_late_soak(factory, late):
     """--late N further cases; prints the worst step per leg."""
     n, first = late
