@@ -1557,7 +1557,7 @@ hipError_t LaunchEvalQuestionsWithUpdate(const KbView &kb, double *prior, uint32
   if (grid > kFusedMaxGrid) grid = kFusedMaxGrid;
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(WPQ * 64), shmem, stream, args);
   const hipError_t le = hipGetLastError();
-  if (pole && le == hipSuccess) return launch_pole_fixup(args, stream);
+  if (pole && le == hipSuccess && !args.fs.lazyFix) return launch_pole_fixup(args, stream);
   return le;
 }
 

@@ -659,7 +659,13 @@ class HipEngine : public IEngine {
     int kind = 0;            // 1: argmax record in _hPinned->sel; 2: priority vector in _hHostPriority; 3: priorities in _dPriority
     int64_t variant = 0;
     hipStream_t stream = nullptr;
+    FusedSelect fs{};        // the launch's own arguments: a speculative sweep is launched WITHOUT the pole fix-up behind it (lazyFix) --
+                             // most of a quiz's last speculations are never used, and their fix-ups were the longest kernels of the loop
   } _spec;
+  // A sweep launched with lazyFix whose answer nobody has looked at yet may have left entries in the engine's suspect list: the next
+  // launch that uses the list empties it first (and the speculation that left them is dropped: its fix-up would find nothing)
+  bool _poleListPending = false;
+  Error SettlePoleList();
   int64_t _optSpeculate = 1;
   int _specScore = 0;        // +1 per speculation used, -1 per speculation dropped: below -4 only every 32nd RecordAnswer speculates
   uint64_t _specProbe = 0, _specHits = 0, _specDropped = 0;

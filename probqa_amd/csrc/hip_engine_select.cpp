@@ -152,6 +152,7 @@ Error HipEngine::EnqueueEval(int64_t iQuiz) {
 bool HipEngine::UseClusterSweep() const { return _optEvalVariant == 0 && _ldT > 16384 && EvalClusterSupported(View()); }
 
 Error HipEngine::LaunchSingleSweep(Quiz *q, const FusedSelect *fused) {
+  { Error se = SettlePoleList(); if (!se.ok()) return se; }
   if (UseClusterSweep()) {
     // long rows, either precision: the question split over a cluster of workgroups, then the epilogues, then (where a selection
     // is asked for) the argmax kernel
@@ -290,6 +291,14 @@ int64_t HipEngine::NextQuestionArgmax(Error &err, int64_t iQuiz) { return Combin
 bool HipEngine::LazyFix() const {
   return _optPoleFix && _optPoleLazy && _optPoleFollow && _elem == 8 && !UseClusterSweep() && EvalVariantHasFinisherWorkgroup(View(), (int)_optEvalVariant);
 }
+Error HipEngine::SettlePoleList() {
+  if (!_poleListPending) return Error();
+  _poleListPending = false;
+  DropSpeculation();
+  const KbView kb = View();
+  if (kb.poleList != nullptr) HIP_TRY(hipMemsetAsync(kb.poleList, 0, sizeof(PoleHeader), _stream));   // (stream order: behind the sweep that wrote it)
+  return Error();
+}
 Error HipEngine::RunLazyFix(Quiz *q, const FusedSelect &swept, const char *what) {
   FusedSelect fs = swept;
   fs.lazyFix = 0;
@@ -297,6 +306,7 @@ Error HipEngine::RunLazyFix(Quiz *q, const FusedSelect &swept, const char *what)
   HIP_TRY(LaunchEvalPoleFixup(View(), q->dPrior, q->dAsked, _dPriority, fs, _stream));
   Error err = WaitFlag(fs.seq, fs.flagValue, what);
   std::atomic_thread_fence(std::memory_order_acquire);
+  _poleListPending = false;   // (the fix-up has emptied the list)
   return err;
 }
 
@@ -330,7 +340,8 @@ int64_t HipEngine::NextQuestionArgmaxLocked(Error &err, int64_t iQuiz) {
   // memory, which this thread polls: no D2H copy, no stream synchronisation on the critical path.
   uint64_t seq;
   FusedSelect fs{};
-  if (TakeSpeculation(q, 1 << 1, &seq) == 0) {   // (else: RecordAnswer has launched this very sweep already)
+  if (TakeSpeculation(q, 1 << 1, &seq) != 0) fs = _spec.fs;   // (RecordAnswer has launched this very sweep already)
+  else {
     seq = NextLaunchTag();
     fs = FusedSelect{_dSelScratch, &_hPinned->sel, &_hPinned->seq, seq, 0, 0, seq, nullptr, 0, 0, nullptr, nullptr, LazyFix() ? 1 : 0};
     StopServer();   // a launched sweep has no room beside the resident one and would wait for it to idle out
@@ -340,9 +351,12 @@ int64_t HipEngine::NextQuestionArgmaxLocked(Error &err, int64_t iQuiz) {
   err = WaitFlag(&_hPinned->seq, seq, "NextQuestionArgmax");
   if (!err.ok()) return -1;
   std::atomic_thread_fence(std::memory_order_acquire);
-  if (_hPinned->sel.index == -4 && fs.lazyFix) {   // the sweep listed rows at the pole of the lack term: the fix now, and its answer
-    err = RunLazyFix(q, fs, "NextQuestionArgmax");
-    if (!err.ok()) return -1;
+  if (fs.lazyFix) {
+    if (_hPinned->sel.index == -4) {   // the sweep listed rows at the pole of the lack term: the fix now, and its answer
+      err = RunLazyFix(q, fs, "NextQuestionArgmax");
+      if (!err.ok()) return -1;
+    }
+    _poleListPending = false;
   }
   if (_hPinned->sel.index == -3) {  // the sweep's finisher gave up: some workgroup of the launch never reported
     err = HipErr(hipErrorLaunchFailure, "NextQuestionArgmax (incomplete sweep)");
@@ -675,6 +689,8 @@ int64_t HipEngine::NextQuestionArgmaxGraph(Error &err, Quiz *q) {
   }
   const uint64_t expect = _graphTag;
   StopServer();   // a launched sweep has no room beside the resident one and would wait for it to idle out
+  err = SettlePoleList();
+  if (!err.ok()) return -1;
   const hipError_t he = hipGraphLaunch(it->second.exec, _stream);
   if (he != hipSuccess) { err = HipErr(he, "hipGraphLaunch"); return -1; }
   uint64_t next = _graphTag + 1;                     // the finisher's own rule (fused_select)
@@ -726,7 +742,9 @@ int64_t HipEngine::NextQuestionSampledLocked(Error &err, int64_t iQuiz, uint64_t
     if (ae != hipSuccess) { err = HipErr(ae, "host priority buffer"); return -1; }
     uint64_t seq = specTag;
     FusedSelect fs{};
-    if (!speculated) {
+    if (speculated) fs = _spec.fs;
+    else {
+      { Error se = SettlePoleList(); if (!se.ok()) { err = se; return -1; } }
       seq = NextLaunchTag();
       fs = FusedSelect{_dSelScratch, &_hPinned->sel, &_hPinned->seq, seq, 0, 0, seq, nullptr, 1, 0, nullptr, _hHostPriority, LazyFix() ? 1 : 0};
       const hipError_t he = LaunchEvalQuestions(kb, q->dPrior, q->dAsked, 0, _Q, _dPriority, (int)_optEvalVariant, &fs, _stream);
@@ -734,9 +752,12 @@ int64_t HipEngine::NextQuestionSampledLocked(Error &err, int64_t iQuiz, uint64_t
     }
     err = WaitFlag(&_hPinned->seq, seq, "NextQuestionSampled");
     if (!err.ok()) return -1;
-    if (_hPinned->sel.index == -4 && fs.lazyFix) {   // (as NextQuestionArgmaxLocked: the corrected entries carry the sweep's tag)
-      err = RunLazyFix(q, fs, "NextQuestionSampled");
-      if (!err.ok()) return -1;
+    if (fs.lazyFix) {
+      if (_hPinned->sel.index == -4) {   // (as NextQuestionArgmaxLocked: the corrected entries carry the sweep's tag)
+        err = RunLazyFix(q, fs, "NextQuestionSampled");
+        if (!err.ok()) return -1;
+      }
+      _poleListPending = false;
     }
     if (_hPinned->sel.index == -3) { err = HipErr(hipErrorLaunchFailure, "NextQuestionSampled (incomplete sweep)"); return -1; }
     err = CollectHostPriority(seq, q);
@@ -746,6 +767,7 @@ int64_t HipEngine::NextQuestionSampledLocked(Error &err, int64_t iQuiz, uint64_t
   }
   if (took != 3 && _optFusedSampled && _elem == 8 && EvalVariantFusesSampled(kb, (int)_optEvalVariant, nSub)) {
     // ONE launch: the sweep's finisher workgroup runs the reference's selector once every workgroup has reported
+    { Error se = SettlePoleList(); if (!se.ok()) { err = se; return -1; } }
     const uint64_t seq = NextLaunchTag();
     const FusedSelect fs{_dSelScratch, &_hPinned->sel, &_hPinned->seq, seq, 0, 0, seq, nullptr, nSub, rnd, _dRunLength, nullptr};
     const hipError_t he = LaunchEvalQuestions(kb, q->dPrior, q->dAsked, 0, _Q, _dPriority, (int)_optEvalVariant, &fs, _stream);

@@ -228,8 +228,9 @@ bool HipEngine::Speculate(Quiz *q, int64_t updQuestion, int64_t updAnswer) {
   if (kind == 2 && EnsureHostPriority() != hipSuccess) return false;
   if (withUpdate) DropSpeculation();
   const uint64_t seq = NextLaunchTag();
+  if (!SettlePoleList().ok()) return false;
   const FusedSelect fs{_dSelScratch, &_hPinned->sel, &_hPinned->seq, seq, 0, 0, seq, nullptr, kind == 2 ? 1 : 0, 0, nullptr,
-                       kind == 2 ? _hHostPriority : nullptr};
+                       kind == 2 ? _hHostPriority : nullptr, (kind == 1 || kind == 2) && LazyFix() ? 1 : 0};
   if (withUpdate) {
     const int64_t topCount = std::min<int64_t>(std::min<int64_t>(std::min<int64_t>(_optTopCache, _topWantRecent), kQuizTop), _T);
     const uint64_t op = _opSeq + 1;
@@ -248,7 +249,8 @@ bool HipEngine::Speculate(Quiz *q, int64_t updQuestion, int64_t updAnswer) {
     (void)hipGetLastError();   // NextQuestion will launch for itself and report
     return false;
   }
-  _spec.quiz = q; _spec.priorVersion = q->priorVersion; _spec.tag = seq; _spec.kind = kind;
+  _spec.quiz = q; _spec.priorVersion = q->priorVersion; _spec.tag = seq; _spec.kind = kind; _spec.fs = fs;
+  if (fs.lazyFix) _poleListPending = true;
   _spec.variant = _optEvalVariant; _spec.stream = _stream;
   _pendingRecordOp = 0;   // the posterior kernel's flag no longer says that the stream is idle
   _pendingRecordFlag = nullptr;
