@@ -233,17 +233,20 @@ __device__ __forceinline__ void pass2_pair(double2 lh, double2 id, double2 pr, d
 // four serial Kahan lanes down the row (SRAccumVectDbl256.h:40-46) and PreciseSum (:62-92), which no wave reproduces at speed
 // (SURVEY F4).  Only the rows AT the pole need it, so the sweep only WATCHES, and what it finds is redone behind it by
 // pole_kernels.hip (the whole story is told there).
-// The watch costs a multiplication and a compare per ROW: an element within 2^-10 of 1 is nearly all of W_k, so the lane that holds
-// it has a pass-1 sum of at least (1 - 2^-9) of its wave's sum (all terms are >= 0, sums of them only grow), and its wave's sum is
-// at least that share of W_k.  Both tests are wave-uniform (a vote; a scalar compare) and false most of the time; a row that passes
-// sets its bit in the question's row mask.  (A lane whose several elements together hold the row's mass passes too: the fix looks
-// at the row's largest element before it changes anything.)  Round 4 watched every element PAIR (one v_max3_u32 each and a register
-// for the running maximum: +2 - 5 % on the short-row shapes, 3.7 % at 10000 targets) and fixed rows of up to 4096 targets inside
-// the sweep, lists of 62 suspects per workgroup; measured on the way there and dropped: the reference's order for every row at the
-// end of the sweep (5 - 8 sweeps per sweep in a late quiz), the correction inside the row loop from the registers (+10 - 50 % in
-// EVERY state: the blocks between pass 1 and pass 2 cost the loop its registers), the fix as a called function (+13 %: scratch).
+// The watch costs an integer add and compare per ROW and bar: an element within 2^-10 of 1 is nearly all of W_k, so the lane that
+// holds it has a pass-1 sum of at least (1 - 2^-9) of W_k (all terms are >= 0, sums of them only grow); the wider bar -- a quarter of
+// W_k -- is for rows whose velocity sum all but vanishes (pole_device.h: kSmallV).  Per lane, on the high words of the two sums, no
+// vote and no branch: a row that passes sets its bit in the lane's word of the question, and the lanes that have any OR them into
+// LDS at the question's end (sweep_body; the streaming kernel below still votes per row: its rows are long).  (A lane whose several
+// elements together hold the row's mass passes too: the fix looks at the row's largest element before it changes anything.)
+// Round 4 watched every element PAIR (one v_max3_u32 each and a register for the running maximum: +2 - 5 % on the short-row
+// shapes, 3.7 % at 10000 targets) and fixed rows of up to 4096 targets inside the sweep, lists of 62 suspects per workgroup;
+// round 5's first form voted per row in front of the W exchange (a branch there: +6 - 8 % at 1000 targets).  Measured on the way and
+// dropped: the reference's order for every row at the end of the sweep (5 - 8 sweeps per sweep in a late quiz), the correction
+// inside the row loop from the registers (+10 - 50 % in EVERY state: the blocks between pass 1 and pass 2 cost the loop its
+// registers), the fix as a called function (+13 %: scratch).
 // ------------------------------------------------------------------------------------------------------------------
-constexpr double kNearOneShare = 1.0 - 0x1p-9;   // (of the wave's sum, of W_k: see above; the bar is pole_device.h: kNearOneHi)
+constexpr double kNearOneShare = 1.0 - 0x1p-9;   // (of W_k, in the streaming kernel's votes: see above; the bar is pole_device.h: kNearOneHi)
 constexpr double kQuarterShare = 0.2499;         // ... and the wider watch (a strict compare: a wave of padding lanes, all sums 0, does not pass) for rows with a vanishing velocity sum (pole_device.h: kSmallV)
 constexpr int kSusDoubles = 4;                 // LDS: words [0], [1] by question parity (the answer rows that passed the watch, a bit each), [4] the list slot -- an EVEN count of doubles: the LDS priors behind it are read as 16-byte pairs
 

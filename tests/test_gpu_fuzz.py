@@ -52,10 +52,10 @@ def test_ill_conditioned_states(i, factory):
     """The offenders of round 3's soak beyond the suite's seeds (tools/fuzz_more.py 120..3770 and 5000..8000: these three of 13700
     runs): knowledge bases of 4 - 10 targets after several answers, a posterior element at p = 1 - 1e-7, where the reference's lack
     term -sum invD^2 / log2(p) has its pole and the last place of W_k -- its summation ORDER -- moves the priority by 1.3 - 2.7e-9.
-    Round 4: the sweep detects such questions (a posterior element >= 1 - 2^-17) and re-evaluates them in the reference's exact
-    order -- four serial Kahan lanes and PreciseSum for W_k, IEEE divisions, Log2Hot operation for operation
-    (eval_kernels.hip: exact_questions).  They are held to 1e-9 like every other state, with the launched sweep, two workgroups
-    streaming all questions, and the resident sweep."""
+    The sweeps watch for such rows and a kernel behind them (pole_kernels.hip) redoes the listed questions in the reference's exact
+    order -- four serial Kahan lanes and PreciseSum for W_k, Log2Hot operation for operation on the row's largest element.  They are
+    held to 1e-9 like every other state, with the launched sweep, two workgroups streaming all questions, and the resident sweep
+    (which answers "redo" and hands the quiz to the launched path).  The late states of real quizzes are tests/test_gpu_late.py."""
     case = random_case(i)
     for options in ([], [("eval_max_grid", 2)], [("server", 1)]):
         steps = run_script(case, factory, options)
