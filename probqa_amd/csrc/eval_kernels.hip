@@ -537,8 +537,8 @@ __device__ __forceinline__ void sweep_body(EvalArgs a, bool copyTable) {
 
   int phase = 0, qpar = 0, nPend = 0;
   // The pole watch (see above; template POLE: the launcher takes the variant when the engine gave it KbView::poleList -- option
-  // pole_fix, default on).  The resident kernel -- its step is the headline of bench.py, and nothing can be launched behind a step --
-  // keeps the sweep's own sums and the conditioning bound of DESIGN section 5.
+  // pole_fix, default on).  The resident kernel watches too (EvalArgs::serverWatch); nothing can be launched behind a step, so a
+  // step that met such a row answers "redo" (index -4, fused_select) and the host launches that quiz's selections from there on.
   constexpr bool kWatch = POLE;
   const bool watchOn = SERVER ? a.serverWatch : a.poleList != nullptr;
   bool wgSuspect = false;                                     // (a question of this workgroup has passed: into its record)

@@ -66,7 +66,7 @@ def late_case(i):
     elif leg == "cluster":
         T, Q = int(rng.choice([20000, 50000, 17000, 33000])), int(rng.integers(8, 20))
         options.append(("cluster_form", int(rng.choice([1, 2]))))
-    elif leg == "overflow":   # more suspects per workgroup than the in-kernel fix lists (kSusMax = 62)
+    elif leg == "overflow":   # hundreds of suspects per workgroup (round 4's in-kernel fix listed 62 and let the rest be)
         T, Q = int(rng.integers(64, 1500)), int(rng.integers(70, 200))
         options.append(("eval_max_grid", 1))
     elif leg == "short":
