@@ -540,6 +540,12 @@ __device__ __forceinline__ void sweep_body(EvalArgs a, bool copyTable) {
   // pole_fix, default on).  The resident kernel watches too (EvalArgs::serverWatch); nothing can be launched behind a step, so a
   // step that met such a row answers "redo" (index -4, fused_select) and the host launches that quiz's selections from there on.
   constexpr bool kWatch = POLE;
+  // (the resident kernel only has to know WHETHER a step met such a row, so its lanes decide for themselves and keep one bit over the
+  //  whole step: a lane's sum of nearly all of W_k, or of a quarter of it while the lane's OWN share of the row's velocity sum is
+  //  within kSmallV -- if the row's sum is, so is the share of the lane that holds the element: every row the launched sweeps would
+  //  list passes, few others do -- and the workgroup asks once, at the step's end; the per-question bookkeeping below cost its step 0.5 us)
+  constexpr bool kListWatch = kWatch && !SERVER;
+  [[maybe_unused]] uint32_t stepBits = 0;
   const bool watchOn = SERVER ? a.serverWatch : a.poleList != nullptr;
   bool wgSuspect = false;                                     // (a question of this workgroup has passed: into its record)
   if (wave == 0) bestLds[lane] = Best{0.0, -1};   // only wave 0 ever touches these
@@ -572,6 +578,7 @@ __device__ __forceinline__ void sweep_body(EvalArgs a, bool copyTable) {
     double *part = partAll + qpar * (nPart * WPQ);
     double *rec = pend + nPend * recLen;
     double accL = 0, hW = 0;
+    [[maybe_unused]] uint32_t rowBits = 0;
     [[maybe_unused]] uint32_t watchRows = 0;                   // (pole watch, per lane: the rows in which this lane's sum is nearly all of W_k below, a quarter of it above)
     for (int64_t k = 0; k < K; k++) {
       // ---- pass 1 (:66-87): likelihoods into registers, W_k; each consumed pair is refilled from the next stream row
@@ -626,8 +633,12 @@ __device__ __forceinline__ void sweep_body(EvalArgs a, bool copyTable) {
         // below), OR-ed into LDS at the question's end by the lanes that have any.  (A vote and a branch per row in front of the
         // exchange cost the launched 1000-target sweep 6 - 8 %; this form nothing measurable there, ~0.5 us of the resident step's 16.)
         const uint32_t hs = (uint32_t)(d2u(sLane) >> 32), hw = (uint32_t)(d2u(Wk) >> 32);
-        const uint32_t kb = (uint32_t)(k < 15 ? k : 15);
-        watchRows |= (hs + 0x00201000u >= hw ? 0x10000u << kb : 0u) | (hs + 0x00001000u >= hw ? 1u << kb : 0u);   // (per lane: no vote, no scalar result to wait for)
+        if constexpr (SERVER) {
+          rowBits = (hs + 0x00201000u >= hw ? 2u : 0u) | (hs + 0x00001000u >= hw ? 1u : 0u);   // (the quarter's verdict waits for the lane's velocity sum: below)
+        } else {
+          const uint32_t kb = (uint32_t)(k < 15 ? k : 15);
+          watchRows |= (hs + 0x00201000u >= hw ? 0x10000u << kb : 0u) | (hs + 0x00001000u >= hw ? 1u << kb : 0u);   // (per lane: no vote, no scalar result to wait for)
+        }
       }
       const double invWk = div_nr(1.0, Wk);                    // :91
       // ---- pass 2 (:95-128)
@@ -642,6 +653,7 @@ __device__ __forceinline__ void sweep_body(EvalArgs a, bool copyTable) {
         asm volatile("" : "+v"(accL), "+v"(hW), "+v"(v));
         __builtin_amdgcn_sched_barrier(0);
       }
+      if constexpr (kWatch && SERVER) stepBits |= (rowBits & 1u) | ((rowBits >> 1) & (v <= kSmallV ? 1u : 0u));
       if constexpr (kDefer) {
         vdump[k * kThreads + tid] = v;                         // :132, reduced with the question's other sums below
         if (tid == 0) rec[k] = Wk;                             // :90
@@ -659,12 +671,12 @@ __device__ __forceinline__ void sweep_body(EvalArgs a, bool copyTable) {
       //  barrier, which no wave passes before every wave has read here)
       vdump[K * kThreads + tid] = hW;
       vdump[(K + 1) * kThreads + tid] = accL;
-      if constexpr (kWatch) {                                   // (rare)
+      if constexpr (kListWatch) {                                   // (rare)
         if (watchRows != 0) atomicOr(&susWords[qpar], watchRows);   // (the lanes that hold such a sum: one or two of a late quiz's wave)
       }
       __syncthreads();
       uint32_t wideRows = 0;                                     // workgroup-uniform: the rows with an element of a quarter
-      if constexpr (kWatch) {
+      if constexpr (kListWatch) {
         const uint32_t w = watchOn ? susWords[qpar] : 0u;
         suspect = (w & 0xFFFFu) != 0;
         wideRows = w >> 16;
@@ -683,18 +695,18 @@ __device__ __forceinline__ void sweep_body(EvalArgs a, bool copyTable) {
         acc += mov_dpp<kDppMirror>(acc);
         const Pair p = swap16(acc);
         acc = p.a + p.b;
-        if constexpr (kWatch) {                                  // (a row whose velocity sum all but vanishes, with an element of a quarter: pole_device.h)
+        if constexpr (kListWatch) {                                  // (a row whose velocity sum all but vanishes, with an element of a quarter: pole_device.h)
           if (l32 == 0 && r < K && acc <= kSmallV && ((wideRows >> (r < 15 ? r : 15)) & 1u)) atomicOr(&susWords[qpar], 1u << (r < 15 ? r : 15));
         }
         if (r < K) acc = rec[r] * sqrt(acc);                   // :156-157
         if (l32 == 0) rec[K + r] = acc;
       }
-      if constexpr (kWatch) {
+      if constexpr (kListWatch) {
         if (wideRows != 0) { __syncthreads(); suspect = (susWords[qpar] & 0xFFFFu) != 0; }   // (the bits the other waves' lanes have just set)
       }
       if (tid == 0) {
         reinterpret_cast<int64_t *>(rec)[2 * K + 2] = q;
-        susWords[qpar ^ 1] = 0;                                // (the other parity's flags: read by everybody before this question's barrier, set again only behind the next question's)
+        if constexpr (kListWatch) susWords[qpar ^ 1] = 0;      // (the other parity's flags: read by everybody before this question's barrier, set again only behind the next question's)
         if constexpr (!SERVER) {
           if (suspect) susWords[4] = pole_list_append(a.poleList, (uint32_t)(q - a.qFirst), K <= 15 ? susWords[qpar] & 0xFFFFu : 0u, a.slots != nullptr ? blockIdx.y : 0u);
         }
@@ -718,12 +730,12 @@ __device__ __forceinline__ void sweep_body(EvalArgs a, bool copyTable) {
         part[K * WPQ + wave] = hW;
         part[(K + 1) * WPQ + wave] = accL;
       }
-      if constexpr (kWatch) {                                   // (rare)
+      if constexpr (kListWatch) {                                   // (rare)
         if (watchRows != 0) atomicOr(&susWords[qpar], watchRows);   // (the lanes that hold such a sum: one or two of a late quiz's wave)
       }
       if constexpr (WPQ > 1) __syncthreads();
       uint32_t wideRows = 0;
-      if constexpr (kWatch) {
+      if constexpr (kListWatch) {
         const uint32_t w = watchOn ? susWords[qpar] : 0u;
         suspect = (w & 0xFFFFu) != 0;
         wideRows = w >> 16;
@@ -733,16 +745,16 @@ __device__ __forceinline__ void sweep_body(EvalArgs a, bool copyTable) {
         for (int r = lane; r < nPart; r += kWave) {
           double acc = part[r * WPQ];
           for (int w2 = 1; w2 < WPQ; w2++) acc += part[r * WPQ + w2];
-          if constexpr (kWatch) {                                // (a row whose velocity sum all but vanishes, with an element of a quarter)
+          if constexpr (kListWatch) {                                // (a row whose velocity sum all but vanishes, with an element of a quarter)
             if (r < K && acc <= kSmallV && ((wideRows >> (r < 15 ? r : 15)) & 1u)) atomicOr(&susWords[qpar], 1u << (r < 15 ? r : 15));
           }
           if (r < K) acc = rec[r] * sqrt(acc);                   // :156-157, one answer per lane
           rec[K + r] = acc;
         }
-        if constexpr (kWatch) { if (wideRows != 0) suspect = (susWords[qpar] & 0xFFFFu) != 0; }   // (this wave's own atomics: in order)
+        if constexpr (kListWatch) { if (wideRows != 0) suspect = (susWords[qpar] & 0xFFFFu) != 0; }   // (this wave's own atomics: in order)
         if (lane == 0) {
           reinterpret_cast<int64_t *>(rec)[2 * K + 2] = q;
-          susWords[qpar ^ 1] = 0;
+          if constexpr (kListWatch) susWords[qpar ^ 1] = 0;
           if constexpr (!SERVER) {
             if (suspect) susWords[4] = pole_list_append(a.poleList, (uint32_t)(q - a.qFirst), K <= 15 ? susWords[qpar] & 0xFFFFu : 0u, a.slots != nullptr ? blockIdx.y : 0u);
           }
@@ -759,7 +771,11 @@ __device__ __forceinline__ void sweep_body(EvalArgs a, bool copyTable) {
     qpar ^= 1;
     q = qn;
   }
-  if constexpr (kDefer) __syncthreads();                       // the last questions' records, written by other waves
+  if constexpr (kWatch && SERVER) { if (stepBits != 0) susWords[0] = 1u; }   // (rare; any lane of any wave)
+  if constexpr (kDefer || (kWatch && SERVER)) __syncthreads();   // the last questions' records, written by other waves
+  if constexpr (kWatch && SERVER) {
+    if (wave == 0) { wgSuspect = watchOn && susWords[0] != 0u; if (lane == 0) susWords[0] = 0u; }   // (the next step's lanes write behind its rows' barriers)
+  }
   bool *allReported = reinterpret_cast<bool *>(redW);         // (the W exchange buffer is free now)
   if (wave == 0) flush_pending(a, pend, nPend, lane, bestLds[lane]);
   if (wave == 0) fused_select<SERVER>(a, bestLds[lane], lane, allReported, wgSuspect);

@@ -213,7 +213,8 @@ Error HipEngine::FlushUpdates() {
 bool HipEngine::Speculate(Quiz *q, int64_t updQuestion, int64_t updAnswer) {
   const bool withUpdate = updQuestion >= 0;
   if (!withUpdate) DropSpeculation();   // (one at a time: the hand-over buffers are the engine's)
-  if (!_optSpeculate || _optServer || _optUseGraph || _qTotal != _Q || _Q <= 0) return false;
+  if (!_optSpeculate || (_optServer && !q->noServer) || _optUseGraph || _qTotal != _Q || _Q <= 0) return false;   // (a quiz the resident sweep has handed over -- rows at the pole of the lack term -- is served as if there were none)
+  if (_optServer && _serverLaunched) return false;   // (a launched sweep has no room beside the resident one: this quiz's last selection has sent it away, unless another quiz called it back)
   if (Concurrent()) return false;   // (several clients: their NextQuestions are served together, by a batched sweep)
   if (withUpdate && (!_optFuseUpdate || _specScore < -4)) return false;
   if (_specScore < -4 && (++_specProbe & 31) != 0) return false;   // the client does not follow RecordAnswer with NextQuestion: probe now and then
@@ -264,7 +265,7 @@ bool HipEngine::Speculate(Quiz *q, int64_t updQuestion, int64_t updAnswer) {
 int HipEngine::TakeSpeculation(Quiz *q, int kindMask, uint64_t *pTag) {
   if (_spec.quiz == nullptr) return 0;
   const bool match = _spec.quiz == q && ((kindMask >> _spec.kind) & 1) && _spec.priorVersion == q->priorVersion && _spec.tag == _selSeq &&
-                     _spec.variant == _optEvalVariant && _spec.stream == _stream && !_optServer && !_optUseGraph;
+                     _spec.variant == _optEvalVariant && _spec.stream == _stream && (!_optServer || q->noServer) && !_optUseGraph;
   if (!match) { DropSpeculation(); return 0; }
   _spec.quiz = nullptr;
   _specHits++;
