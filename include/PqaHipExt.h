@@ -74,7 +74,9 @@ PQACORE_API void *PqaEngineFactory_CreateHipEngineSharded(void *pvFactory, void 
  * reference's own summation order -- SRAccumVectDbl256.h:40-46, :62-92 -- so that late quiz states stay within 1e-9 of the
  * reference's priorities on every kernel form; a resident sweep that finds such a row hands the quiz to the launched path; default 1,
  * also PQA_POLE_FIX), "pole_lazy" (a synchronous single-quiz selection launches that kernel only when its sweep has listed something
- * -- one launch per selection of a fresh quiz instead of two; default 1; 0 = behind every sweep), "pole_follow" (measurement hook: 0 = the watching sweep WITHOUT the launch behind it, for timing the sweep
+ * -- one launch per selection of a fresh quiz instead of two; default 1; 0 = behind every sweep), "late_eager" (after this many
+ * selections of a quiz in a row that needed the fix, RecordAnswer's speculative sweep has it launched right behind it again: it runs
+ * while the client is elsewhere; default 3 -- long quizzes in late states +4 %, the learner loop unchanged), "pole_follow" (measurement hook: 0 = the watching sweep WITHOUT the launch behind it, for timing the sweep
  * kernel by itself in a quiz state that lists nothing; default 1),
  * "cluster_form" (the single-quiz sweep over rows beyond 16384 targets: 0 = default, 1 = question by question, 2 = pass 1 a question
  * ahead of the exchange),

@@ -322,6 +322,7 @@ Error HipEngine::SetOption(const char *name, int64_t value) {
   else if (n == "combine") { _optCombine = value ? 1 : 0; }
   else if (n == "combine_spin") { _optCombineSpin = value ? 1 : 0; }
   else if (n == "pole_fix") { StopServer(); _optPoleFix = value ? 1 : 0; _kbVersion++; }   // 0: questions with a row at the pole of the lack term keep the sweep's own sums (pole_kernels.hip)
+  else if (n == "late_eager") { if (value < 0 || value > 1000000) goto bad; _optLateEager = value; }
   else if (n == "pole_lazy") { _optPoleLazy = value ? 1 : 0; }
   else if (n == "pole_follow") { _optPoleFollow = value ? 1 : 0; }   // measurement hook: 0 = the watching sweeps without the fix launched behind them (KbView::poleNoFollow)
   else if (n == "long_row_form") { _optLongRowForm = value ? 1 : 0; }   // 0: the one-workgroup posterior kernels for rows beyond 16384 targets too
@@ -378,6 +379,7 @@ int64_t HipEngine::GetOption(const char *name) const {
   if (n == "fused_updates") return (int64_t)_fusedUpdates;           // RecordAnswers whose update ran inside the sweep's launch
   if (n == "long_row_form") return _optLongRowForm;
   if (n == "pole_fix") return _optPoleFix;
+  if (n == "late_eager") return _optLateEager;
   if (n == "pole_lazy") return _optPoleLazy;
   if (n == "pole_follow") return _optPoleFollow;
   if (n == "allowed_cpus") return AllowedCpus();

@@ -122,6 +122,8 @@ struct Quiz {
   int64_t activeQuestion = -1;         // global id (reference CEQuiz::_activeQuestion)
   uint64_t priorVersion = 0;           // bumped whenever the posterior changes
   uint64_t serial = 0;                 // unique per created quiz: a registry slot reused by a later quiz is not this quiz
+  int lateStreak = 0;                  // selections in a row whose (lazily fixed) sweep had listed rows at the pole: from the third on, RecordAnswer's
+                                       // speculative sweep gets its fix-up launched right behind it again (it will be needed, and runs while the client is elsewhere)
   bool noServer = false;               // the resident sweep has answered a step of this quiz with -4 (a row at the pole of the lack term:
                                        // pole_kernels.hip) -- from here on its selections are launched, with the fix behind them
   QuizPinned *pin = nullptr;           // this quiz's host-coherent result lines (pooled by the engine)
@@ -520,6 +522,7 @@ class HipEngine : public IEngine {
   double *_dPriorScratch = nullptr;      // the long-row posterior kernels' subtask sums (KbView::priorScratch)
   int64_t _optPoleFix = 1;               // option "pole_fix"
   int64_t _optPoleFollow = 1;            // option "pole_follow" (measurement hook)
+  int64_t _optLateEager = 3;             // option "late_eager": see Quiz::lateStreak (0: speculative sweeps always with the fix-up behind them)
   int64_t _optPoleLazy = 1;              // option "pole_lazy": synchronous single-quiz selections launch the fix only when the sweep listed something (FusedSelect::lazyFix)
   int64_t _optLongRowForm = 1;           // option "long_row_form": StartQuiz / RecordAnswer over rows beyond 16384 targets as one workgroup per subtask of the sum
   // batched selections (NextQuestionArgmaxBatch); allocated on first use

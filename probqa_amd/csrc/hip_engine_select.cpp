@@ -355,7 +355,8 @@ int64_t HipEngine::NextQuestionArgmaxLocked(Error &err, int64_t iQuiz) {
     if (_hPinned->sel.index == -4) {   // the sweep listed rows at the pole of the lack term: the fix now, and its answer
       err = RunLazyFix(q, fs, "NextQuestionArgmax");
       if (!err.ok()) return -1;
-    }
+      q->lateStreak++;
+    } else q->lateStreak = 0;
     _poleListPending = false;
   }
   if (_hPinned->sel.index == -3) {  // the sweep's finisher gave up: some workgroup of the launch never reported
@@ -756,7 +757,8 @@ int64_t HipEngine::NextQuestionSampledLocked(Error &err, int64_t iQuiz, uint64_t
       if (_hPinned->sel.index == -4) {   // (as NextQuestionArgmaxLocked: the corrected entries carry the sweep's tag)
         err = RunLazyFix(q, fs, "NextQuestionSampled");
         if (!err.ok()) return -1;
-      }
+        q->lateStreak++;
+      } else q->lateStreak = 0;
       _poleListPending = false;
     }
     if (_hPinned->sel.index == -3) { err = HipErr(hipErrorLaunchFailure, "NextQuestionSampled (incomplete sweep)"); return -1; }

@@ -231,7 +231,7 @@ bool HipEngine::Speculate(Quiz *q, int64_t updQuestion, int64_t updAnswer) {
   const uint64_t seq = NextLaunchTag();
   if (!SettlePoleList().ok()) return false;
   const FusedSelect fs{_dSelScratch, &_hPinned->sel, &_hPinned->seq, seq, 0, 0, seq, nullptr, kind == 2 ? 1 : 0, 0, nullptr,
-                       kind == 2 ? _hHostPriority : nullptr, (kind == 1 || kind == 2) && LazyFix() ? 1 : 0};
+                       kind == 2 ? _hHostPriority : nullptr, (kind == 1 || kind == 2) && LazyFix() && q->lateStreak < _optLateEager ? 1 : 0};
   if (withUpdate) {
     const int64_t topCount = std::min<int64_t>(std::min<int64_t>(std::min<int64_t>(_optTopCache, _topWantRecent), kQuizTop), _T);
     const uint64_t op = _opSeq + 1;
