@@ -146,6 +146,12 @@ PQACORE_API void *PqaHip_EnqueueSelectArgmax(void *pvEngine, const int64_t iQuiz
  * soon as all flags carry the step's value.  No collective launch, no copy, no stream synchronisation. */
 PQACORE_API void *PqaHip_EnqueueSelectArgmaxFlag(void *pvEngine, const int64_t iQuiz, void *pOut, void *pFlag,
                                                  const uint64_t flagValue);
+/* ... or through ONE RCCL collective on the engine's stream, for a process-per-GPU host that owns a communicator (pNcclComm: its
+ * ncclComm_t; world: its size): the shards' 16-byte winners are all-gathered and every rank returns the same exact pick (max
+ * priority, lowest GLOBAL index on ties, -1 if none).  librccl.so is loaded at the first call; libPqaCore.so does not link it.
+ * (probqa_amd/dist.py does the same through torch.distributed, where the communicator is PyTorch's.) */
+PQACORE_API void *PqaHip_SelectArgmaxRccl(void *pvEngine, const int64_t iQuiz, void *pNcclComm, const int64_t world, double *pPriority,
+                                          int64_t *pIndex);
 PQACORE_API void *PqaHip_HostRegister(void *pHost, const int64_t nBytes, void **ppDevice);
 PQACORE_API void *PqaHip_HostUnregister(void *pHost);
 /* Slots of strideBytes each, starting with {double priority; int64 index; uint64 flag}: wait until all `world` flags

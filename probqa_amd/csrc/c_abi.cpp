@@ -2,6 +2,7 @@
 // Shims follow reference ProbQA/PqaCore/PqaCInterop.cpp:45-408 (AssignPqaError / ReturnPqaError and its three null-handle
 // conventions: return an error object, set *ppError, or log and return 0); declarations are in include/PqaCInterop.h and
 // include/PqaHipExt.h.
+#include <dlfcn.h>
 #include <sched.h>
 #include <atomic>
 #include <chrono>
@@ -10,7 +11,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <mutex>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "hip_engine.h"
@@ -523,6 +526,69 @@ PQACORE_API void *PqaHip_SelectThroughSlots(void *pvEngine, const int64_t iQuiz,
   Error e = pEng->EnqueueSelectArgmaxFlag(iQuiz, mine, mine + 16, flagValue);
   if (!e.ok()) return ReturnErr(std::move(e));
   return PqaHip_PickWhenAll(pSlots, world, strideBytes, flagValue, timeoutSec, pPriority, pIndex);
+}
+// The shards' 16-byte winners gathered by ONE RCCL collective on the engine's stream, for a process-per-GPU host that owns an RCCL
+// communicator and is not Python (probqa_amd/dist.py does the same through torch.distributed; north_star: "a single RCCL
+// all-reduce" -- an all-gather of {priority, GLOBAL index} and the exact pick on every rank, so that ties break by the lowest
+// index as in the reference's argmax).  RCCL is looked up at the first call (dlopen: libPqaCore.so itself does not link it).
+namespace {
+struct RcclBufs { void *dSend = nullptr, *dRecv = nullptr, *hRecv = nullptr; int64_t world = 0; };
+std::mutex gRcclMu;
+std::unordered_map<void *, RcclBufs> gRcclBufs;
+typedef int (*NcclAllGatherFn)(const void *, void *, size_t, int, void *, hipStream_t);
+NcclAllGatherFn RcclAllGather() {
+  static NcclAllGatherFn fn = [] {
+    void *h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    return h ? reinterpret_cast<NcclAllGatherFn>(dlsym(h, "ncclAllGather")) : nullptr;
+  }();
+  return fn;
+}
+}  // namespace
+PQACORE_API void *PqaHip_SelectArgmaxRccl(void *pvEngine, const int64_t iQuiz, void *pNcclComm, const int64_t world, double *pPriority,
+                                          int64_t *pIndex) {
+  ENGINE_OR_RETURN_ERROR;
+  if (!pNcclComm || !pPriority || !pIndex || world < 1 || world > 4096)
+    return ReturnErr(Error::Make(ErrCode::NullArgument, "Bad arguments to PqaHip_SelectArgmaxRccl."));
+  const NcclAllGatherFn allGather = RcclAllGather();
+  if (allGather == nullptr) return ReturnErr(Error::Make(ErrCode::StdException, "librccl.so (ncclAllGather) could not be loaded."));
+  RcclBufs b;
+  {
+    std::lock_guard<std::mutex> lk(gRcclMu);
+    RcclBufs &slot = gRcclBufs[pvEngine];
+    if (slot.world != world) {   // (first call, or another communicator size: the 16 (world + 1) device bytes and their pinned mirror)
+      if (slot.dSend) { hipFree(slot.dSend); hipHostFree(slot.hRecv); slot = RcclBufs{}; }
+      void *d = nullptr, *h = nullptr;
+      if (hipMalloc(&d, (size_t)(world + 1) * 16) != hipSuccess || hipHostMalloc(&h, (size_t)world * 16, hipHostMallocDefault) != hipSuccess) {
+        if (d) hipFree(d);
+        return ReturnErr(Error::Make(ErrCode::StdException, "PqaHip_SelectArgmaxRccl: no memory for the exchange buffers."));
+      }
+      slot.dSend = d; slot.dRecv = static_cast<char *>(d) + 16; slot.hRecv = h; slot.world = world;
+    }
+    b = slot;
+  }
+  Error e = pEng->EnqueueSelectArgmax(iQuiz, b.dSend);   // {priority, GLOBAL index} of this shard's winner, in stream order
+  if (!e.ok()) return ReturnErr(std::move(e));
+  const hipStream_t stream = pEng->GetStream();
+  const int rc = allGather(b.dSend, b.dRecv, 16, /* ncclUint8 */ 1, pNcclComm, stream);
+  if (rc != 0) return ReturnErr(Error::MakeP(ErrCode::StdException, "ncclResult=" + std::to_string(rc), "ncclAllGather failed."));
+  hipError_t he = hipMemcpyAsync(b.hRecv, b.dRecv, (size_t)world * 16, hipMemcpyDeviceToHost, stream);
+  if (he == hipSuccess) he = hipStreamSynchronize(stream);
+  if (he != hipSuccess) return ReturnErr(Error::MakeP(ErrCode::StdException, hipGetErrorString(he), "PqaHip_SelectArgmaxRccl: the gathered winners did not arrive."));
+  double bestP = 0;
+  int64_t bestI = -1;
+  for (int64_t r = 0; r < world; r++) {   // (as PqaHip_PickWhenAll: max priority, lowest index on ties, NaN never wins, -1 if none)
+    double p;
+    int64_t i;
+    std::memcpy(&p, static_cast<const char *>(b.hRecv) + r * 16, 8);
+    std::memcpy(&i, static_cast<const char *>(b.hRecv) + r * 16 + 8, 8);
+    if (i < 0) continue;
+    if (p != p) p = -HUGE_VAL;
+    if (bestI < 0 || p > bestP || (p == bestP && i < bestI)) { bestP = p; bestI = i; }
+  }
+  *pPriority = bestP;
+  *pIndex = bestI;
+  return nullptr;
 }
 PQACORE_API void *PqaHip_EnqueueSelectArgmax(void *pvEngine, const int64_t iQuiz, void *pOut) {
   ENGINE_OR_RETURN_ERROR;

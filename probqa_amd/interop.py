@@ -141,6 +141,7 @@ HIP_EXPORTS = {
     "PqaHip_HostUnregister": (_vp, [_vp]),
     "PqaHip_PickWhenAll": (_vp, [_vp, _i64, _i64, ctypes.c_uint64, ctypes.c_double, _pdbl, _pi64]),
     "PqaHip_SelectThroughSlots": (_vp, [_vp, _i64, _vp, _vp, _i64, _i64, _i64, ctypes.c_uint64, ctypes.c_double, _pdbl, _pi64]),
+    "PqaHip_SelectArgmaxRccl": (_vp, [_vp, _i64, _vp, _i64, _pdbl, _pi64]),
     "PqaHip_EnqueueEval": (_vp, [_vp, _i64]),
     "PqaHip_GetPriorDevicePtr": (_vp, [_vp, _i64, _pvp, _pi64]),
     "PqaHip_RecordAnswerRemote": (_vp, [_vp, _i64, _i64]),
@@ -617,6 +618,12 @@ class PqaEngine:
         pri, idx = ctypes.c_double(), ctypes.c_int64()
         _check(_lib.PqaHip_SelectThroughSlots(self.c_engine, i_quiz, ctypes.c_void_p(slots_host), ctypes.c_void_p(slots_dev),
                                               rank, world, stride, flag_value, timeout_s, ctypes.byref(pri), ctypes.byref(idx)))
+        return pri.value, idx.value
+
+    def select_argmax_rccl(self, i_quiz: int, nccl_comm: int, world: int):
+        """This shard's winner all-gathered over the caller's RCCL communicator (an ncclComm_t as an integer) -> (priority, index)."""
+        pri, idx = ctypes.c_double(), ctypes.c_int64()
+        _check(_lib.PqaHip_SelectArgmaxRccl(self.c_engine, i_quiz, ctypes.c_void_p(nccl_comm), world, ctypes.byref(pri), ctypes.byref(idx)))
         return pri.value, idx.value
 
     def log2hot(self, x: np.ndarray) -> np.ndarray:
