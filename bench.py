@@ -508,11 +508,15 @@ def main():
     # ---- extras (not `value`), one GPU, default config: the two other measured points of the path in the line the driver runs --
     # the HBM-bound point M (BASELINE configs[2]: 10000x5x10000 fp64, one quiz) and the VALU-bound point L1 (configs[4]'s
     # per-GPU shard: 12500x5x100000 fp32, 256 quizzes per batched sweep), each with a bounded parity sample against the CPU port.
-    hbm_point_m, valu_point_l1 = None, None
+    hbm_point_m, valu_point_l1, late_state = None, None, None
     if not sharded and args.config == "S" and not args.no_points:
         free_b = torch.cuda.mem_get_info(device)[0]
         if free_b > 12e9:
             hbm_point_m = point_m(args, np, torch, interop, factory, stream, kernel_ms_of)
+        try:
+            late_state = late_state_point(args, np, torch, interop, factory, stream, kernel_ms_with)
+        except Exception as ex:  # noqa: BLE001 -- an extra must not take the line with it
+            late_state = {"error": repr(ex)[:300]}
         if free_b > 80e9:
             valu_point_l1 = run_batched(args, CONFIGS["L1"], np, torch, interop, pdist, ctl, rank, dev_index, device, compact=True)
 
@@ -608,6 +612,7 @@ def main():
         "sharded_12500x5x100000_per_gpu": sharded_l1,
         "one_process_sharded_engine": one_process,
         "hbm_point_M": hbm_point_m,
+        "late_state_S": late_state,
         "valu_point_L1": valu_point_l1,
         "roofline": {
             "bound": "hbm",
@@ -763,6 +768,65 @@ class Ctl:
         if self.dist is not None:
             self.dist.destroy_process_group()
             self.dist = None
+
+
+def late_state_point(args, np, torch, interop, factory, stream, kernel_ms_with):
+    """The default cube in a LATE quiz state -- consistent answers until the posterior sits on one target, where every question has
+    an answer row at the pole of the lack term: the sweep with the reference-order fix-up behind it (pole_kernels.hip) against the
+    sweep alone, by HIP events; the synchronous selection a caller sees; parity of that state's priorities against the CPU port."""
+    c = CONFIGS["S"]
+    Q, K, T = c["Q"], c["K"], c["T"]
+    e = factory.create_hip_engine(interop.EngineDefinition(K, Q, T, init_amount=0.1), 0, Q, torch.cuda.current_device())
+    e.set_option("select", 1)
+    e.fill_synthetic(8.0, 0.5, SEED)
+    e.set_stream(stream.cuda_stream)
+    qz = e.start_quiz()
+    guess, width, top, answers, hist = int(0.37 * T), max(1, 32 * T // 1000), None, 0, []
+    for _ in range(40):
+        qq = e.next_question_argmax(qz)
+        x = qq * T // Q
+        ans = 0 if guess < x - width else 1 if guess < x else 2 if guess == x else 3 if guess <= x + width else 4
+        e.record_answer(qz, ans)
+        hist.append((int(qq), ans))
+        answers += 1
+        top = e.list_top_targets(qz, 1)
+        if top and top[0].prob > 1 - 1e-6:
+            break
+    with_fix = kernel_ms_with(e, qz, 100)
+    for _ in range(5):
+        pick = e.next_question_argmax(qz)
+    n = 300
+    t0 = time.perf_counter()
+    for _ in range(n):
+        pick = e.next_question_argmax(qz)
+    sync_us = 1e6 * (time.perf_counter() - t0) / n
+    out = {"workload": c["name"] + " fp64, one quiz after %d consistent answers (top posterior 1 - %.1e): every question listed" % (answers, 1 - top[0].prob if top else float("nan")),
+           "sweep_plus_fixup_us": 1e3 * with_fix, "synchronous_selection_us": sync_us, "selected_question": int(pick)}
+    if not args.no_cpu_baseline:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import orclib
+        from probqa_amd import synth
+
+        pri = e.eval_priorities(qz, Q)
+        orc = orclib.Oracle(K, Q, T, 0.1)
+        orc.set_kb(*synth.synthetic_kb(K, Q, T, 0.1, 8.0, 0.5, SEED))
+        orc.start_quiz(16)
+        for qa in hist:
+            orc.record_answer(qa[0], qa[1], 15)
+        _, opri = orc.eval_avx2(min(os.cpu_count() or 1, 16))
+        live = opri > 0
+        rel = np.abs(pri[live] - opri[live]) / opri[live]
+        out["parity"] = {"questions": int(live.sum()), "max_rel_err": float(rel.max()),
+                         "posterior_bit_identical": bool(np.array_equal(e.get_priors(qz), orc.priors())),
+                         "argmax_matches_cpu": int(pick) == int(orc.select_argmax(opri)),
+                         "note": "all priorities of this state against the fp64 CPU port replaying the same answers"}
+    e.set_option("pole_fix", 0)
+    out["sweep_alone_us"] = 1e3 * kernel_ms_with(e, qz, 100)
+    if "parity" in out:
+        pri0 = e.eval_priorities(qz, Q)
+        out["parity"]["max_rel_err_without_the_fixup"] = float((np.abs(pri0[live] - opri[live]) / opri[live]).max())
+    e.close()
+    return out
 
 
 def point_m(args, np, torch, interop, factory, stream, kernel_ms_of):

@@ -343,7 +343,7 @@ int64_t HipEngine::NextQuestionArgmaxLocked(Error &err, int64_t iQuiz) {
   if (TakeSpeculation(q, 1 << 1, &seq) != 0) fs = _spec.fs;   // (RecordAnswer has launched this very sweep already)
   else {
     seq = NextLaunchTag();
-    fs = FusedSelect{_dSelScratch, &_hPinned->sel, &_hPinned->seq, seq, 0, 0, seq, nullptr, 0, 0, nullptr, nullptr, LazyFix() ? 1 : 0};
+    fs = FusedSelect{_dSelScratch, &_hPinned->sel, &_hPinned->seq, seq, 0, 0, seq, nullptr, 0, 0, nullptr, nullptr, LazyFix() && q->lateStreak < _optLateEager ? 1 : 0};   // (a quiz whose last selections all needed the fix: launched behind the sweep again)
     StopServer();   // a launched sweep has no room beside the resident one and would wait for it to idle out
     err = LaunchSingleSweep(q, &fs);
     if (!err.ok()) return -1;
@@ -747,7 +747,7 @@ int64_t HipEngine::NextQuestionSampledLocked(Error &err, int64_t iQuiz, uint64_t
     else {
       { Error se = SettlePoleList(); if (!se.ok()) { err = se; return -1; } }
       seq = NextLaunchTag();
-      fs = FusedSelect{_dSelScratch, &_hPinned->sel, &_hPinned->seq, seq, 0, 0, seq, nullptr, 1, 0, nullptr, _hHostPriority, LazyFix() ? 1 : 0};
+      fs = FusedSelect{_dSelScratch, &_hPinned->sel, &_hPinned->seq, seq, 0, 0, seq, nullptr, 1, 0, nullptr, _hHostPriority, LazyFix() && q->lateStreak < _optLateEager ? 1 : 0};   // (a quiz whose last selections all needed the fix: launched behind the sweep again)
       const hipError_t he = LaunchEvalQuestions(kb, q->dPrior, q->dAsked, 0, _Q, _dPriority, (int)_optEvalVariant, &fs, _stream);
       if (he != hipSuccess) { err = HipErr(he, "NextQuestionSampled"); return -1; }
     }
