@@ -869,6 +869,44 @@ def point_m(args, np, torch, interop, factory, stream, kernel_ms_of):
         out["sample_parity"] = {"questions": n_q, "max_rel_err": float(rel.max()),
                                 "argmax_of_sample_matches_cpu": int(np.argmax(pri[:n_q])) == int(orc.select_argmax(opri)),
                                 "note": "GPU priorities of the first %d questions against the fp64 CPU port on the generator's rows" % n_q}
+    # ... and the same cube in a LATE quiz state (consistent answers until the posterior sits on one target): sweep + fix-up
+    try:
+        guess, width, top, hist = int(0.37 * T), max(1, 32 * T // 1000), None, 0
+        for _ in range(40):
+            qq = e.next_question_argmax(qz)
+            x = qq * T // Q
+            e.record_answer(qz, 0 if guess < x - width else 1 if guess < x else 2 if guess == x else 3 if guess <= x + width else 4)
+            hist += 1
+            top = e.list_top_targets(qz, 1)
+            if top and top[0].prob > 1 - 1e-6:
+                break
+        e.set_option("pole_follow", 1)
+        for _ in range(2):
+            e.enqueue_eval(qz)
+        torch.cuda.synchronize()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record(stream)
+        for _ in range(10):
+            e.enqueue_eval(qz)
+        ev1.record(stream)
+        torch.cuda.synchronize()
+        late = {"answers": hist, "top_posterior_one_minus": (1 - top[0].prob) if top else None, "sweep_plus_fixup_us": 1e3 * ev0.elapsed_time(ev1) / 10}
+        if not args.no_cpu_baseline:
+            n_q = 200
+            pri = e.eval_priorities(qz, Q)
+            orc = orclib.Oracle(K, n_q, T, 0.1)
+            orc.set_kb(*synth.synthetic_kb(K, n_q, T, 0.1, 8.0, 0.5, SEED, q_offset=0, q_total=Q))
+            orc.mants[:T] = e.get_priors(qz)
+            _, opri = orc.eval_avx2(min(os.cpu_count() or 1, 16))
+            live = pri[:n_q] > 0                                   # (asked questions among the sample: priority 0 on the device)
+            late["sample_parity"] = {"questions": int(live.sum()),
+                                     "max_rel_err": float((np.abs(pri[:n_q][live] - opri[live]) / opri[live]).max())}
+            e.set_option("pole_fix", 0)
+            pri0 = e.eval_priorities(qz, Q)
+            late["sample_parity"]["max_rel_err_without_the_fixup"] = float((np.abs(pri0[:n_q][live] - opri[live]) / opri[live]).max())
+        out["late_state"] = late
+    except Exception as ex:  # noqa: BLE001 -- an extra of an extra
+        out["late_state"] = {"error": repr(ex)[:300]}
     e.close()
     return out
 
