@@ -545,7 +545,7 @@ __device__ __forceinline__ void sweep_body(EvalArgs a, bool copyTable) {
   //  within kSmallV -- if the row's sum is, so is the share of the lane that holds the element: every row the launched sweeps would
   //  list passes, few others do -- and the workgroup asks once, at the step's end; the per-question bookkeeping below cost its step 0.5 us)
   constexpr bool kListWatch = kWatch && !SERVER;
-  [[maybe_unused]] uint32_t stepBits = 0;
+  [[maybe_unused]] int32_t stepNear = INT32_MIN, stepSmall = INT32_MIN;   // (the largest hi(lane's sum) - hi(W_k) of the step: over all rows / over the rows with the lane's velocity share within kSmallV)
   const bool watchOn = SERVER ? a.serverWatch : a.poleList != nullptr;
   bool wgSuspect = false;                                     // (a question of this workgroup has passed: into its record)
   if (wave == 0) bestLds[lane] = Best{0.0, -1};   // only wave 0 ever touches these
@@ -578,7 +578,7 @@ __device__ __forceinline__ void sweep_body(EvalArgs a, bool copyTable) {
     double *part = partAll + qpar * (nPart * WPQ);
     double *rec = pend + nPend * recLen;
     double accL = 0, hW = 0;
-    [[maybe_unused]] uint32_t rowBits = 0;
+    [[maybe_unused]] int32_t rowGap = INT32_MIN;
     [[maybe_unused]] uint32_t watchRows = 0;                   // (pole watch, per lane: the rows in which this lane's sum is nearly all of W_k below, a quarter of it above)
     for (int64_t k = 0; k < K; k++) {
       // ---- pass 1 (:66-87): likelihoods into registers, W_k; each consumed pair is refilled from the next stream row
@@ -634,7 +634,8 @@ __device__ __forceinline__ void sweep_body(EvalArgs a, bool copyTable) {
         // exchange cost the launched 1000-target sweep 6 - 8 %; this form nothing measurable there, ~0.5 us of the resident step's 16.)
         const uint32_t hs = (uint32_t)(d2u(sLane) >> 32), hw = (uint32_t)(d2u(Wk) >> 32);
         if constexpr (SERVER) {
-          rowBits = (hs + 0x00201000u >= hw ? 2u : 0u) | (hs + 0x00001000u >= hw ? 1u : 0u);   // (the quarter's verdict waits for the lane's velocity sum: below)
+          rowGap = (int32_t)(hs - hw);                         // (high words of positive doubles: no overflow; both bars are looked at once, at the step's end)
+          stepNear = max(stepNear, rowGap);
         } else {
           const uint32_t kb = (uint32_t)(k < 15 ? k : 15);
           watchRows |= (hs + 0x00201000u >= hw ? 0x10000u << kb : 0u) | (hs + 0x00001000u >= hw ? 1u << kb : 0u);   // (per lane: no vote, no scalar result to wait for)
@@ -653,7 +654,7 @@ __device__ __forceinline__ void sweep_body(EvalArgs a, bool copyTable) {
         asm volatile("" : "+v"(accL), "+v"(hW), "+v"(v));
         __builtin_amdgcn_sched_barrier(0);
       }
-      if constexpr (kWatch && SERVER) stepBits |= (rowBits & 1u) | ((rowBits >> 1) & (v <= kSmallV ? 1u : 0u));
+      if constexpr (kWatch && SERVER) stepSmall = max(stepSmall, v <= kSmallV ? rowGap : INT32_MIN);
       if constexpr (kDefer) {
         vdump[k * kThreads + tid] = v;                         // :132, reduced with the question's other sums below
         if (tid == 0) rec[k] = Wk;                             // :90
@@ -771,7 +772,7 @@ __device__ __forceinline__ void sweep_body(EvalArgs a, bool copyTable) {
     qpar ^= 1;
     q = qn;
   }
-  if constexpr (kWatch && SERVER) { if (stepBits != 0) susWords[0] = 1u; }   // (rare; any lane of any wave)
+  if constexpr (kWatch && SERVER) { if (stepNear >= -0x00001000 || stepSmall >= -0x00201000) susWords[0] = 1u; }   // (rare; any lane of any wave: the bars of the launched sweeps' watch)
   if constexpr (kDefer || (kWatch && SERVER)) __syncthreads();   // the last questions' records, written by other waves
   if constexpr (kWatch && SERVER) {
     if (wave == 0) { wgSuspect = watchOn && susWords[0] != 0u; if (lane == 0) susWords[0] = 0u; }   // (the next step's lanes write behind its rows' barriers)
