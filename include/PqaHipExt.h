@@ -79,7 +79,8 @@ PQACORE_API void *PqaEngineFactory_CreateHipEngineSharded(void *pvFactory, void 
  * while the client is elsewhere; default 3 -- long quizzes in late states +4 %, the learner loop unchanged), "pole_follow" (measurement hook: 0 = the watching sweep WITHOUT the launch behind it, for timing the sweep
  * kernel by itself in a quiz state that lists nothing; default 1),
  * "cluster_form" (the single-quiz sweep over rows beyond 16384 targets: 0 = default, 1 = question by question, 2 = pass 1 a question
- * ahead of the exchange),
+ * ahead of the exchange), "cluster_shape" (threads x 16-byte units per thread of the form that runs ahead: 0 = default, 1 = 512 x 1, 2 = 256 x 2;
+ * two workgroups per CU both),
  * Read-only: "server_last_step_ns" (device-side duration of the newest finished step of the resident sweep: request in hand
  * to answer published, from the kernel's own 100 MHz clock; -1 if there is none), "precision" (TPqaPrecisionType of the engine: 1 = Float, 3 = Double), "server_active",
  * "ldT", "device". */

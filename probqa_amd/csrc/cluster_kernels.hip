@@ -41,6 +41,7 @@ hipError_t UploadLog2TableCluster(const double *hostTable) {
 namespace {
 
 constexpr int kClusterThreads = 512;
+constexpr int kMaxWaves = kClusterThreads / kWave;
 constexpr int kMaxK = 16;
 constexpr int kExchangeDoubles = 1024;   // LDS: xch[C][K + 2] doubles -- clusters of up to 1024 / (K + 2) members
 constexpr bool kClusterAheadByDefault = true;
@@ -126,6 +127,37 @@ __device__ __forceinline__ void put_record(ExRec *p, double v, unsigned long lon
   const unsigned long long w0 = d2u(v);
   const u4 x = {(unsigned)w0, (unsigned)(w0 >> 32), (unsigned)tag, (unsigned)(tag >> 32)};
   asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(x) : "memory");
+}
+// A record read past the L2s WITHOUT the compiler's wait accounting: the compiler drains the vector-memory counter wherever control
+// flow has merged (s_waitcnt vmcnt(0) in front of the first use of a polled record, of pass 2's first LDS read, ...), i.e. it waits
+// there for the next-but-one question's ROWS, requested a moment earlier and not needed for a whole iteration -- an HBM round trip
+// (~2900 cycles of an iteration's 19 900, by the kernel's own clock) in series with everything else.  Loads issued here are waited
+// for by wait_records<N>: "at most N younger vector-memory operations outstanding", N = the row loads issued behind them (loads
+// return in order, so the records are in; a smaller N only waits longer).
+__device__ __forceinline__ u4 get_record_async(const ExRec *p) {
+  u4 x;
+  asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(x) : "v"(p));
+  return x;
+}
+// ... and the rows themselves, requested a whole iteration before pass 1 takes them: issued here (a streaming 16-byte load, as
+// load_unit's) and waited for by rows_arrived at the top of pass 1 -- the compiler sees no vector-memory load inside the loop and
+// puts no wait of its own there.
+template <typename V> __device__ __forceinline__ u4 load_unit_async(const V *p) {
+  u4 x;
+  asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(x) : "v"(p));
+  return x;
+}
+template <int NU, int NR> __device__ __forceinline__ void rows_arrived(u4 (&d)[NU], u4 (&rows)[NR][NU]) {
+  static_assert(NR == 5, "five answer rows ahead");
+  asm volatile("s_waitcnt vmcnt(0)");
+#pragma unroll
+  for (int j = 0; j < NU; j++)   // (the uses stand behind these empty statements, which stand behind the wait)
+    asm volatile("" : "+v"(d[j]), "+v"(rows[0][j]), "+v"(rows[1][j]), "+v"(rows[2][j]), "+v"(rows[3][j]), "+v"(rows[4][j]));
+}
+template <int N, int M> __device__ __forceinline__ void wait_records(u4 (&x)[M]) {
+  static_assert(M == 2 || M == 4, "records per thread");
+  if constexpr (M == 2) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(x[0]), "+v"(x[1]) : "n"(N));
+  else asm volatile("s_waitcnt vmcnt(%4)" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]) : "n"(N));
 }
 template <typename R, int NU>   // NU: 16-byte units of a slice per thread; two workgroups per CU (<= 128 registers)
 __global__ __launch_bounds__(kClusterThreads, 4) void eval_cluster_kernel(ClusterArgs a) {
@@ -719,6 +751,384 @@ __global__ __launch_bounds__(kClusterThreads, 4) void eval_cluster_ahead_kernel(
   if (qPrev >= 0 && (int)((round - 1) % (unsigned long long)C) == m) fold(qPrev, round - 1);
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// The form that runs ahead for questions of exactly FIVE answers -- every configuration of BASELINE.json -- in round 5: TPB threads of
+// NU 16-byte units each (WPE waves per SIMD resident: the register budget), and the loop's loads issued and waited for by hand
+// (get_record_async), so that the next-but-one question's rows stay in flight from their request to the pass 1 that takes them.
+//   * 256 threads x 2 units: the reductions, the exchange and the barriers are per wave, two units per thread amortise them over
+//     twice the elements (same slices, same LDS, two workgroups per CU; 2 waves per SIMD with up to 256 registers);
+//   * by the kernel's own clock (s_memtime around the phases, 2000 x 5 x 100000 fp64, 512 x 1) an iteration of 19 900 cycles was:
+//     pass 1 of the next question 6550, the wait for the members' records 2700, their sums and the fold 1700, pass 2 -- the only part
+//     that is the sweep's arithmetic -- 3800, barrier 950, the column sums 2400, the likelihoods' move to LDS 1800.  The 2700 were not
+//     the records: the compiler's s_waitcnt vmcnt(0) in front of the first use of a polled record also waited for the rows requested
+//     a moment earlier, and so did one in front of pass 2's first prior (loop-carried "maybe pending" from loads before the loop).
+// With the answer count a constant the loops over the answers have no trip-count registers and no on-the-spot loads; other answer
+// counts keep eval_cluster_ahead_kernel above (the hand-made waits measured there too, as one kernel with a switch: 3000 x 3 x 60000
+// fp64 +8 %, 2000 x 8 x 50000 fp32 +3 % against it).
+template <typename R, int TPB, int NU, int WPE>
+__global__ __launch_bounds__(TPB, WPE) void eval_cluster_five_kernel(ClusterArgs a) {
+  typedef typename Vec<R>::type V;
+  constexpr int VN = Vec<R>::N;
+  constexpr int NW = TPB / kWave;
+  constexpr int NG = TPB / 32;                                  // groups of 32 lanes: the column sums
+  constexpr int kRows = 5;                                      // answer rows requested ahead (further ones are fetched on the spot)
+  extern __shared__ double smem[];
+  const double *tbl = smem;
+  V *lhL = reinterpret_cast<V *>(smem + (NumC<R>::kTable ? kLog2TableDoubles : 0));
+  double (*red)[kMaxWaves] = reinterpret_cast<double (*)[kMaxWaves]>(lhL + (size_t)a.K * a.sliceUnits);
+  double *wTot = &red[kMaxK + 2][0];
+  double *xch = wTot + kMaxK + kMaxWaves / 2;                   // [C][K + 2]: the members' partials of one question
+  double *wHist = xch + kExchangeDoubles;                       // [4][kMaxK]: W_k of the last four questions (the fold lags two)
+  double *wInv = wHist + 4 * kMaxK;                             // [kMaxK]: 1 / W_k of the question in pass 2
+  float *park = reinterpret_cast<float *>(wInv + kMaxK);        // fp32: [K][threads] -- the threads' pass-1 sums, added by column (kParkPass1)
+  constexpr bool kParkPass1 = !NumC<R>::kTable;                 // (Float engines have the Log2Hot table's 16 KB of LDS to spare)
+  if constexpr (NumC<R>::kTable) {
+    if (!lds_table_at_zero(tbl)) __builtin_trap();            // log2hot addresses the table absolutely
+    for (int i = threadIdx.x; i < kLog2TableDoubles; i += TPB) smem[i] = gLog2TableC[i];
+  }
+  const int tid = threadIdx.x, lane = tid % kWave, wave = tid / kWave;
+  constexpr int64_t K = 5;                                      // (the launcher sends nothing else here)
+  const int64_t ldT = a.ldT;
+  const int C = a.C, g = blockIdx.x / C, m = blockIdx.x % C;   // cluster, member (= slice)
+  const int nUnits = (int)(ldT / VN), SU = a.sliceUnits;
+  const int u0 = m * SU;
+  const int nMine = u0 >= nUnits ? 0 : (nUnits - u0 < SU ? nUnits - u0 : SU);
+  const R *cube = static_cast<const R *>(a.cube);
+  const int64_t qStride = (K + 1) * ldT;
+  // the thread's units of the slice: tid, tid + TPB, ... (clamped; units beyond the slice are masked), gap bits, masked priors (:103)
+  int ui[NU];
+  uint32_t gapBits[NU];
+  V pr[NU];
+#pragma unroll
+  for (int j = 0; j < NU; j++) {
+    const int s = tid + j * TPB;
+    const bool in = s < nMine;
+    ui[j] = in ? u0 + s : (nUnits - 1);
+    const int64_t t0 = (int64_t)ui[j] * VN;
+    gapBits[j] = in ? (a.tgap[t0 >> 5] >> (t0 & 31)) & ((1u << VN) - 1) : (1u << VN) - 1;   // (bits past T are set)
+#pragma unroll
+    for (int e = 0; e < VN; e++) at<R>(pr[j], e) = ((gapBits[j] >> e) & 1) ? (R)0 : (R)a.prior[t0 + e];
+  }
+  // (what was loaded up to here is USED here, on every path: otherwise the compiler, which cannot tell whether these loads were waited
+  //  for on the way into the loop, puts s_waitcnt vmcnt(0) in front of pass 2's first use of a prior -- and waits there for the rows)
+#pragma unroll
+  for (int j = 0; j < NU; j++) {
+    asm volatile("" : "+v"(gapBits[j]));
+#pragma unroll
+    for (int e = 0; e < VN; e++) asm volatile("" : "+v"(at<R>(pr[j], e)));
+  }
+  const bool inSlice0 = tid < SU;                               // (a thread whose first unit lies beyond the slice has none in it)
+  const int nSlots = SU < TPB ? SU : TPB;                       // pass 2 parks a thread's sums in the slots of its FIRST unit
+  ExRec *recW = a.recW + (size_t)g * 4 * C * kMaxK, *recS = a.recS + (size_t)g * 4 * C * (kMaxK + 2);
+  const unsigned long long tagBase = a.tagBase;
+
+  // All C x n records of one exchange (eval_cluster_kernel's gather), in two halves: the loads are ISSUED in front of the request for
+  // the next-but-one question's rows and looked at behind it, with a wait that leaves those rows in flight (get_record_async)
+  constexpr int kRounds = 2 * kClusterThreads / TPB;            // records per thread: C x n <= 1024
+  struct Polled { u4 x[kRounds]; };
+  auto gather_issue = [&](const ExRec *recs, int stride, int n, Polled &px) __attribute__((always_inline)) {
+    const int total = C * n;
+#pragma unroll
+    for (int u = 0; u < kRounds; u++) {
+      const int r = tid + u * TPB;
+      const int rc = r < total ? r : 0;
+      const int mm = rc / n, kk = rc - mm * n;
+      px.x[u] = get_record_async(recs + (mm * stride + kk));
+    }
+  };
+  // rowsBehind: the loads of request_question ((kRows + 1) x NU of them) stand behind the records'
+  auto gather_finish = [&](const ExRec *recs, int stride, int n, unsigned long long tag, Polled &px, bool rowsBehind) __attribute__((always_inline)) {
+    const int total = C * n;
+    unsigned spins = 0;
+    if (rowsBehind) wait_records<(kRows + 1) * NU>(px.x); else wait_records<0>(px.x);   // (the wait's count is an immediate)
+    for (;;) {
+      int ok = 1;
+#pragma unroll
+      for (int u = 0; u < kRounds; u++) {
+        const int r = tid + u * TPB;
+        if (r < total) {
+          const unsigned long long t = (unsigned long long)px.x[u][2] | ((unsigned long long)px.x[u][3] << 32);
+          if (t == tag) xch[r] = u2d((unsigned long long)px.x[u][0] | ((unsigned long long)px.x[u][1] << 32)); else ok = 0;
+        }
+      }
+      if (__all(ok)) break;
+      __builtin_amdgcn_s_sleep(1);
+      if (++spins > (1u << 26)) __builtin_trap();               // (minutes: a member died -- no silent hang)
+      gather_issue(recs, stride, n, px);
+      wait_records<0>(px.x);
+    }
+    __syncthreads();
+  };
+  auto gather = [&](const ExRec *recs, int stride, int n, unsigned long long tag) {
+    Polled px;
+    gather_issue(recs, stride, n, px);
+    gather_finish(recs, stride, n, tag, px, false);
+  };
+  auto sum_members = [&](int n, double *out) {
+    for (int col = wave; col < n; col += NW) {
+      double s = 0.0;
+      for (int i = lane; i < C; i += kWave) s += xch[i * n + col];
+      s = wave_sum(s);
+      if (lane == 0) out[col] = s;
+    }
+  };
+  auto fold = [&](int64_t qq, unsigned long long cnt) {
+    gather(recS + (size_t)(cnt & 3) * C * (kMaxK + 2), kMaxK + 2, (int)K + 2, tagBase + cnt + 1);
+    sum_members((int)K + 2, red[0]);
+    __syncthreads();
+    if (tid < K + 2) {
+      const double s = red[0][tid];
+      double *tot = a.totals + (size_t)qq * (2 * kMaxK + 2);
+      if (tid < K) { tot[tid] = wHist[(cnt & 3) * kMaxK + tid]; tot[kMaxK + tid] = s; }
+      else tot[2 * kMaxK + (tid - K)] = s;
+    }
+    __syncthreads();
+  };
+  auto next_valid = [&](int64_t q) {    // :54
+    while (q < a.Q && (bit_test(a.qgap, q) || bit_test(a.asked, q))) {
+      if (m == 0 && tid == 0) a.priority[q] = 0.0;
+      q += a.nClusters;
+    }
+    return q;
+  };
+  u4 dN[NU], rows[kRows][NU];                                  // (raw: the loads are inline assembly, get_record_async's comment)
+  auto request_question = [&](int64_t qq) __attribute__((always_inline)) {
+    const R *base = cube + qq * qStride;
+#pragma unroll
+    for (int j = 0; j < NU; j++) dN[j] = load_unit_async(reinterpret_cast<const V *>(base + K * ldT) + ui[j]);
+#pragma unroll
+    for (int k = 0; k < kRows; k++)
+#pragma unroll
+      for (int j = 0; j < NU; j++) rows[k][j] = load_unit_async(reinterpret_cast<const V *>(base + k * ldT) + ui[j]);
+  };
+  // pass 1 of question qq (count cnt) once its rows have arrived: 1/D and the likelihoods into idOut / lhOut (registers); the partial
+  // W_k published.
+  auto pass1 = [&](int64_t qq, unsigned long long cnt, V (&idOut)[NU], V (&lhOut)[kRows][NU]) __attribute__((always_inline)) {
+    rows_arrived(dN, rows);
+#pragma unroll
+    for (int j = 0; j < NU; j++)
+#pragma unroll
+      for (int e = 0; e < VN; e++) at<R>(idOut[j], e) = ((gapBits[j] >> e) & 1) ? (R)0 : NumC<R>::inv(at<R>(__builtin_bit_cast(V, dN[j]), e));   // :74
+    [[maybe_unused]] unsigned long long candVotes = 0;
+    auto row_sum = [&](int k, const V (&row)[NU], V (&lh)[NU]) __attribute__((always_inline)) {
+      R sum = (R)0;
+#pragma unroll
+      for (int j = 0; j < NU; j++)
+#pragma unroll
+        for (int e = 0; e < VN; e++) {
+          at<R>(lh[j], e) = (at<R>(row[j], e) * at<R>(idOut[j], e)) * at<R>(pr[j], e);   // :81-82
+          sum += at<R>(lh[j], e);
+        }
+      if constexpr (kParkPass1) {
+        park[k * TPB + tid] = (float)sum;                       // (a butterfly of six DPP steps per answer otherwise: a sixth of the iteration's instructions)
+      } else {
+        const double sw = wave_sum_d((double)sum);
+        if (lane == 0) red[k][wave] = sw;
+        if constexpr (NumC<R>::kTable) candVotes |= cluster_cand_vote((double)sum, sw);   // (the pole watch)
+      }
+    };
+#pragma unroll
+    for (int k = 0; k < kRows; k++) {
+      V row[NU];
+#pragma unroll
+      for (int j = 0; j < NU; j++) row[j] = __builtin_bit_cast(V, rows[k][j]);
+      row_sum(k, row, lhOut[k]);
+    }
+    if constexpr (NumC<R>::kTable) {
+      if (candVotes != 0 && a.candSum != nullptr) {             // (rare: the rows' thread sums again, from the registers)
+#pragma unroll
+        for (int k = 0; k < kRows; k++) {
+          R sk = (R)0;
+#pragma unroll
+          for (int j = 0; j < NU; j++)
+#pragma unroll
+            for (int e = 0; e < VN; e++) sk += at<R>(lhOut[k][j], e);
+          cluster_cand_publish(a.candSum, qq, k, (double)sk, lane);
+        }
+      }
+    }
+    __syncthreads();
+    if constexpr (kParkPass1) {
+      const int grp = tid >> 5, l32 = tid & 31;                 // groups of 32 lanes, a column (answer) each
+      for (int col = grp; col < K; col += NG) {
+        const float *src = park + col * TPB + l32;
+        double acc = 0.0;
+#pragma unroll
+        for (int i = 0; i < NG; i++) acc += (double)src[32 * i];
+        acc += mov_dpp<kDppXor1>(acc);
+        acc += mov_dpp<kDppXor2>(acc);
+        acc += mov_dpp<kDppHalfMirror>(acc);
+        acc += mov_dpp<kDppMirror>(acc);
+        const Pair pq = swap16(acc);
+        acc = pq.a + pq.b;
+        if (l32 == 0) put_record(recW + ((size_t)(cnt & 3) * C + m) * kMaxK + col, acc, tagBase + cnt + 1);
+      }
+    } else {
+      if (tid < K) {
+        double w = 0.0;
+        for (int i = 0; i < NW; i++) w += red[tid][i];
+        put_record(recW + ((size_t)(cnt & 3) * C + m) * kMaxK + tid, w, tagBase + cnt + 1);
+      }
+    }
+  };
+  // the likelihoods of question qq into LDS (pass 2 of the question before it is done with the copy: the caller's barrier)
+  auto store_question = [&](int64_t qq, const V (&idOf)[NU], const V (&lhOf)[kRows][NU]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < NU; j++) {
+      const int s = tid + j * TPB;
+      if (s < SU) {
+#pragma unroll
+        for (int k = 0; k < kRows; k++)
+          lhL[k * SU + s] = lhOf[k][j];
+      }
+    }
+  };
+
+  if constexpr (NumC<R>::kTable) __syncthreads();
+  unsigned long long round = 0;                                 // count of the question in pass 2 (the cluster's questions so far)
+  int64_t q = next_valid(g), qPrev = -1, qPrev2 = -1;
+  V id[NU], idNext[NU], lhNext[kRows][NU];
+  if (q < a.Q) {
+    request_question(q);
+    pass1(q, 0, idNext, lhNext);                                // (the first question: nothing to hide behind)
+    store_question(q, idNext, lhNext);
+#pragma unroll
+    for (int j = 0; j < NU; j++) id[j] = idNext[j];
+  }
+  int64_t qNext = q < a.Q ? next_valid(q + a.nClusters) : a.Q;
+  if (qNext < a.Q) request_question(qNext);
+  while (q < a.Q) {
+    // ---- pass 1 of the NEXT question; then its successor's rows are requested into the registers that are free again
+    const int64_t qNext2 = qNext < a.Q ? next_valid(qNext + a.nClusters) : a.Q;
+    bool rowsBehind = false;
+    Polled pw;
+    if (qNext < a.Q) pass1(qNext, round + 1, idNext, lhNext);
+    // ---- everybody's partial W of THIS question (published an iteration ago), in slice order; the next-but-one question's rows are
+    // requested into the registers pass 1 has just freed, BEHIND the records' loads, whose wait leaves them in flight
+    gather_issue(recW + (size_t)(round & 3) * C * kMaxK, kMaxK, (int)K, pw);
+    if (qNext2 < a.Q) { request_question(qNext2); rowsBehind = true; }
+    gather_finish(recW + (size_t)(round & 3) * C * kMaxK, kMaxK, (int)K, tagBase + round + 1, pw, rowsBehind);
+    // (two forms of the same sums, each kept where it measured faster on one box at 2000 x 5 x 100000: the sums written straight to
+    //  where pass 2 and the fold look, one barrier less -- fp32 1517 -> 1489 us, fp64 3206 -> 3262 us)
+    constexpr bool kDirectSums = !NumC<R>::kTable;
+    if constexpr (kDirectSums) {
+      for (int col = wave; col < K; col += NW) {
+        double w = 0.0;
+        for (int i = lane; i < C; i += kWave) w += xch[i * (int)K + col];
+        w = wave_sum(w);
+        if (lane == 0) {
+          wInv[col] = div_fast(1.0, w);                         // :91, once per workgroup (every thread formed it: a fifth of pass 2's instructions)
+          wHist[(round & 3) * kMaxK + col] = w;
+        }
+      }
+      __syncthreads();                                          // (xch is read, W is there)
+    } else {
+      sum_members((int)K, red[8]);
+      __syncthreads();                                          // (xch is read)
+    }
+    // the turn-taker folds the question before the previous one: every member published its sums before it published its W of this
+    // question, which have all just been seen
+    if (qPrev2 >= 0 && (int)((round - 2) % (unsigned long long)C) == m) fold(qPrev2, round - 2);
+    if constexpr (!kDirectSums) {
+      if (tid < K) {
+        const double w = red[8][tid];
+        wInv[tid] = div_fast(1.0, w);                           // :91, once per workgroup
+        wHist[(round & 3) * kMaxK + tid] = w;
+      }
+      __syncthreads();
+    }
+    // ---- pass 2 (:95-128) from LDS, answer by answer.  The threads' sums are not reduced wave by wave (K + 2 butterflies of six DPP
+    // steps each were a quarter of the iteration's instructions): a thread parks its K + 2 sums in the LDS slots of its first unit --
+    // 16 bytes per answer row, dead once the row's likelihoods have been read -- and groups of 32 lanes add one column each.
+    double *slot = reinterpret_cast<double *>(lhL);             // unit u of row k: slot[(k * SU + u) * 2 + {0, 1}]
+    V accN[NU], accD[NU];
+    R hW = (R)0, accL = (R)0;
+#pragma unroll 1
+    for (int64_t k = 0; k < K; k++) {
+      const R invWk = (R)wInv[k];                               // :91 (formed once per workgroup, above)
+      R vk = (R)0;
+      V lh[NU];
+#pragma unroll
+      for (int j = 0; j < NU; j++) {
+        const int s = tid + j * TPB;
+        lh[j] = lhL[k * SU + (s < SU ? s : 0)];
+      }
+#pragma unroll
+      for (int j = 0; j < NU; j++) {
+        if (tid + j * TPB < SU) {
+#pragma unroll
+          for (int e = 0; e < VN; e++) {
+            const R l = at<R>(lh[j], e), pi = at<R>(pr[j], e);
+            const R p = l * invWk;                              // :97
+            const R l2 = NumC<R>::log2p(p, tbl);                // :106
+            hW = fma(l, l2, hW);                                // :113-114 weighted by W_k (eval_epilogue)
+            const R dd = p - pi;                                // :119
+            vk = fma(dd, dd, vk);                               // :126-127
+            if (k == 0) { at<R>(accN[j], e) = (R)1; at<R>(accD[j], e) = l2; }   // :117 sum_k 1 / log2 p_k = N / D, answer by answer
+            else { at<R>(accN[j], e) = fma(at<R>(accN[j], e), l2, at<R>(accD[j], e)); at<R>(accD[j], e) = at<R>(accD[j], e) * l2; }
+          }
+        }
+      }
+      if (inSlice0) slot[(k * SU + tid) * 2] = (double)vk;
+    }
+#pragma unroll
+    for (int j = 0; j < NU; j++) {
+      if (tid + j * TPB < SU) {
+#pragma unroll
+        for (int e = 0; e < VN; e++) {
+          const R i1 = at<R>(id[j], e);
+          accL = fma((i1 * at<R>(accN[j], e)) * i1, NumC<R>::rcp(at<R>(accD[j], e)), accL);
+        }
+      }
+    }
+    if (inSlice0) {
+      slot[tid * 2 + 1] = (double)hW;                           // (row 0's second double)
+      if (K > 1) slot[(SU + tid) * 2 + 1] = (double)accL;       // (row 1's)
+    }
+    if (K == 1) {                                               // (one answer: one row of slots -- the lack sum the old way)
+      const double s2 = wave_sum_d((double)accL);
+      if (lane == 0) red[0][wave] = s2;
+    }
+    __syncthreads();                                            // (the slots are complete)
+    {
+      const int grp = tid >> 5, l32 = tid & 31;                 // column c of the K + 2: V_k (k < K) | sum l log2 p | lack
+      for (int col = grp; col < K + 2; col += NG) {
+        const double *src = col < K ? slot + (size_t)col * SU * 2 : col == K ? slot + 1 : slot + (size_t)SU * 2 + 1;
+        double acc = 0.0;
+        if (col == K + 1 && K == 1) {
+          if (l32 < NW) acc = red[0][l32];
+        } else {
+          for (int u = l32; u < nSlots; u += 32) acc += src[(size_t)u * 2];
+        }
+        acc += mov_dpp<kDppXor1>(acc);
+        acc += mov_dpp<kDppXor2>(acc);
+        acc += mov_dpp<kDppHalfMirror>(acc);
+        acc += mov_dpp<kDppMirror>(acc);
+        const Pair pq = swap16(acc);
+        acc = pq.a + pq.b;
+        if (l32 == 0) put_record(recS + ((size_t)(round & 3) * C + m) * (kMaxK + 2) + col, acc, tagBase + round + 1);
+      }
+    }
+    __syncthreads();                                            // (the slots are read: the LDS copy is free)
+    // ---- the next question's likelihoods move from the registers to LDS
+    if (qNext < a.Q) {
+      store_question(qNext, idNext, lhNext);
+#pragma unroll
+      for (int j = 0; j < NU; j++) id[j] = idNext[j];
+    }
+    qPrev2 = qPrev;
+    qPrev = q;
+    round++;
+    q = qNext;
+    qNext = qNext2;
+    if constexpr (!kDirectSums) __syncthreads();                // (not needed for the data: the next reader of the LDS copy is pass 2, behind pass 1's and the exchange's barriers)
+  }
+  __syncthreads();
+  // the last two questions' sums: their turn-takers wait for them
+  if (qPrev2 >= 0 && (int)((round - 2) % (unsigned long long)C) == m) fold(qPrev2, round - 2);
+  if (qPrev >= 0 && (int)((round - 1) % (unsigned long long)C) == m) fold(qPrev, round - 1);
+}
+
 // The pole watch's verdict, behind the sweep (a thread per question and answer row; nearly all of them read one zero word and leave):
 // the largest thread sum a wave reported for the row against W_k -- the bars of the sweeps in eval_kernels.hip (kNearOneShare,
 // kQuarterShare there; the shares are of two elements' sum here, of a lane's there: bounds for the largest element both).
@@ -751,45 +1161,75 @@ __global__ __launch_bounds__(256) void cluster_epilogue_kernel(const double *__r
 constexpr size_t kFixedLdsBytes = ((size_t)(kMaxK + 2) * (kClusterThreads / kWave) + kMaxK + kClusterThreads / kWave / 2) * sizeof(double);   // red[][] + wTot[] + votes[]
 constexpr size_t kExchangeLdsBytes = kExchangeDoubles * sizeof(double);
 constexpr size_t kAheadLdsBytes = 5 * kMaxK * sizeof(double);   // eval_cluster_ahead_kernel: wHist, wInv (+ fp32: K x threads floats, park)
-struct ClusterShape { int C, nClusters, sliceUnits, nu; size_t shmem; bool ahead; };
+struct ClusterShape { int C, nClusters, sliceUnits, nu, tpb, perCU; size_t shmem; bool ahead; };
 
-template <typename R, int NU>   // NU == 0: eval_cluster_ahead_kernel
-bool occupancy_two(size_t shmem) {
-  static LaunchCache cache;   // (per instantiation and device)
-  const int dev = LaunchCache::Device();
-  int perCU = 0;
-  if (cache.Get(dev, shmem, &perCU)) return perCU >= 2;
-  const void *kern;
-  if constexpr (NU == 0) kern = reinterpret_cast<const void *>(eval_cluster_ahead_kernel<R>);
-  else kern = reinterpret_cast<const void *>(eval_cluster_kernel<R, NU>);
-  hipError_t e = hipSuccess;
-  if (shmem > 64 * 1024) e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-  if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, kern, kClusterThreads, shmem);
-  if (e != hipSuccess) { perCU = 0; (void)hipGetLastError(); }   // (not this launch's error: the caller falls back to the streaming form)
-  cache.Put(dev, shmem, perCU);
-  return perCU >= 2;
+// The shapes of the form that runs ahead (engine option cluster_shape; KbView::clusterShape): threads x units per thread, and how
+// many workgroups share a CU.  Reductions, exchanges and barriers are per WAVE: two units per thread amortise them over twice the
+// elements (at half the waves per SIMD and twice the registers per thread).
+struct AheadVariant { int tpb, nu, perCU; };
+constexpr AheadVariant kAheadVariants[] = {
+    {512, 1, 2},   // 1: round 4's shape -- four waves per SIMD, 128 registers
+    {256, 2, 2},   // 2: the same slices and LDS, half the waves, two units per thread
+    // (measured and taken out in round 5: one workgroup of 512 x 2 or 512 x 3 per CU, slices two and three times as long, half and a
+    //  third of the members -- 2000 x 5 x 100000: fp64 3.74 / 3.93 ms against 3.48, fp32 1.67 / 1.61 against 1.31)
+};
+constexpr int kAheadVariantCount = (int)(sizeof(kAheadVariants) / sizeof(kAheadVariants[0]));
+constexpr int kAheadDefaultF64 = 2, kAheadDefaultF32 = 2;     // (where the shape is not built -- other than five answers -- shape 1)
+
+template <typename R>
+const void *ahead_kernel_of(int variant, bool five) {   // five: exactly five answers
+  if (variant == 2) return reinterpret_cast<const void *>(eval_cluster_five_kernel<R, 256, 2, 2>);   // (five answers only: cluster_shape_of)
+  return five ? reinterpret_cast<const void *>(eval_cluster_five_kernel<R, 512, 1, 4>) : reinterpret_cast<const void *>(eval_cluster_ahead_kernel<R>);
 }
 
-// Slices as long as two workgroups' LDS per CU allow (72 KB each, the fp64 table included): the fewer members a cluster has, the
-// fewer partials every member adds per question.
-// ahead: the form that runs pass 1 a question ahead (eval_cluster_ahead_kernel: one unit per thread).
+// does the device hold `perCU` workgroups of the kernel per CU with this much LDS?  (cached per kernel, device and LDS size)
+bool occupancy_reaches(LaunchCache &cache, const void *kern, int threads, size_t shmem, int perCU) {
+  const int dev = LaunchCache::Device();
+  int got = 0;
+  if (cache.Get(dev, shmem, &got)) return got >= perCU;
+  hipError_t e = hipSuccess;
+  if (shmem > 64 * 1024) e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+  if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&got, kern, threads, shmem);
+  if (e != hipSuccess) { got = 0; (void)hipGetLastError(); }   // (not this launch's error: the caller falls back to another form)
+  cache.Put(dev, shmem, got);
+  return got >= perCU;
+}
+template <typename R, int NU>
+bool occupancy_two(size_t shmem) {
+  static LaunchCache cache;   // (per instantiation and device)
+  return occupancy_reaches(cache, reinterpret_cast<const void *>(eval_cluster_kernel<R, NU>), kClusterThreads, shmem, 2);
+}
 template <typename R>
-bool cluster_shape_of(const KbView &kb, int nCU, bool ahead, ClusterShape *out) {
+bool occupancy_ahead(int variant, bool five, size_t shmem) {
+  static LaunchCache cache[2 * (kAheadVariantCount + 1)];
+  const AheadVariant &v = kAheadVariants[variant - 1];
+  return occupancy_reaches(cache[2 * variant + (five ? 1 : 0)], ahead_kernel_of<R>(variant, five), v.tpb, shmem, v.perCU);
+}
+
+// Slices as long as the workgroups' LDS allows (72 KB each where two share a CU, the fp64 table included): the fewer members a
+// cluster has, the fewer partials every member adds per question.
+// variant: 0 = the question-by-question form (eval_cluster_kernel), 1.. = kAheadVariants[variant - 1] of the form that runs ahead.
+template <typename R>
+bool cluster_shape_of(const KbView &kb, int nCU, int variant, ClusterShape *out) {
   constexpr int VN = Vec<R>::N;
-  if (kb.K > kMaxK || kb.K < 1) return false;
+  const bool ahead = variant > 0;
+  if (kb.K > kMaxK || kb.K < 1 || variant > kAheadVariantCount) return false;
+  if (variant == 2 && kb.K != 5) return false;                  // (256 x 2 is built for questions of five answers)
+  const AheadVariant v = ahead ? kAheadVariants[variant - 1] : AheadVariant{kClusterThreads, NumC<R>::kTable ? 1 : 2, 2};
   const int64_t nUnits = kb.ldT / VN;
+  const size_t ldsPerWg = v.perCU == 2 ? 72 * 1024 : 144 * 1024;
   const size_t tableBytes = NumC<R>::kTable ? kLog2TableDoubles * sizeof(double) : 0;
   const size_t parkBytes = ahead && !NumC<R>::kTable ? (size_t)kb.K * kClusterThreads * sizeof(float) : 0;
-  if (72 * 1024 < tableBytes + kFixedLdsBytes + kExchangeLdsBytes + kAheadLdsBytes + parkBytes + 64 * 16 * (size_t)kb.K) return false;
-  const size_t budget = 72 * 1024 - tableBytes - kFixedLdsBytes - kExchangeLdsBytes - (ahead ? kAheadLdsBytes + parkBytes : 0);
+  if (ldsPerWg < tableBytes + kFixedLdsBytes + kExchangeLdsBytes + kAheadLdsBytes + parkBytes + 64 * 16 * (size_t)kb.K) return false;
+  const size_t budget = ldsPerWg - tableBytes - kFixedLdsBytes - kExchangeLdsBytes - (ahead ? kAheadLdsBytes + parkBytes : 0);
   int64_t maxUnits = (int64_t)(budget / ((size_t)kb.K * 16));
-  // fp32: up to two units per thread (fewer members per cluster: 1797 vs 2018 us at 2000 x 5 x 100000); fp64: one -- with two the
-  // next question's rows do not fit the 128 registers beside pass 2 and spill (6160 vs 4459 us)
-  maxUnits = std::min<int64_t>(maxUnits, (NumC<R>::kTable || ahead ? 1 : 2) * kClusterThreads);
+  // question by question: fp32 up to two units per thread (fewer members per cluster: 1797 vs 2018 us at 2000 x 5 x 100000), fp64 one --
+  // with two the next question's rows do not fit the 128 registers beside pass 2 and spill (6160 vs 4459 us)
+  maxUnits = std::min<int64_t>(maxUnits, (int64_t)v.nu * v.tpb);
   maxUnits = maxUnits / kWave * kWave;
   if (maxUnits < kWave) return false;
   const int64_t C = (nUnits + maxUnits - 1) / maxUnits;
-  const int capacity = 2 * nCU;
+  const int capacity = v.perCU * nCU;
   // A cluster's members wait for each other, so they must become resident together.  Workgroups of a launch are dispatched in
   // order: at any time a launch has at most ONE incomplete cluster on the device (its frontier), every other resident cluster is
   // complete and finishes its questions whatever else happens -- so even several such launches in flight at once (shards of one
@@ -800,19 +1240,28 @@ bool cluster_shape_of(const KbView &kb, int nCU, bool ahead, ClusterShape *out) 
   out->C = (int)C;
   out->nClusters = (int)std::max<int64_t>(1, std::min<int64_t>(capacity / C, kb.Q));
   out->sliceUnits = (int)su;
-  out->nu = su <= kClusterThreads ? 1 : 2;
+  out->tpb = v.tpb;
+  out->perCU = v.perCU;
+  out->nu = ahead ? v.nu : (su <= kClusterThreads ? 1 : 2);
   out->ahead = ahead;
   out->shmem = tableBytes + (size_t)kb.K * su * 16 + kFixedLdsBytes + kExchangeLdsBytes + (ahead ? kAheadLdsBytes + parkBytes : 0);
-  if (ahead) return occupancy_two<R, 0>(out->shmem);
+  if (ahead) return occupancy_ahead<R>(variant, kb.K == 5, out->shmem);
   return out->nu == 1 ? occupancy_two<R, 1>(out->shmem) : occupancy_two<R, 2>(out->shmem);
 }
-// KbView::clusterForm (engine option cluster_form): 0 = the default below, 1 = the question-by-question form, 2 = pass 1 a question ahead
+// KbView::clusterForm (engine option cluster_form): 0 = the default below, 1 = the question-by-question form, 2 = pass 1 a question
+// ahead; KbView::clusterShape (option cluster_shape): which of kAheadVariants the form that runs ahead takes, 0 = the default
 template <typename R>
-bool cluster_shape(const KbView &kb, int nCU, ClusterShape *out) {
+int cluster_variant(const KbView &kb, int nCU, ClusterShape *out) {   // -1: not supported; 0: question by question; 1..: kAheadVariants
   const bool ahead = kb.clusterForm == 0 ? kClusterAheadByDefault : kb.clusterForm == 2;
-  if (ahead && cluster_shape_of<R>(kb, nCU, true, out)) return true;
-  return cluster_shape_of<R>(kb, nCU, false, out);
+  if (ahead) {
+    const int want = kb.clusterShape > 0 ? kb.clusterShape : (NumC<R>::kTable ? kAheadDefaultF64 : kAheadDefaultF32);
+    if (cluster_shape_of<R>(kb, nCU, want, out)) return want;
+    if (want != 1 && cluster_shape_of<R>(kb, nCU, 1, out)) return 1;
+  }
+  return cluster_shape_of<R>(kb, nCU, 0, out) ? 0 : -1;
 }
+template <typename R>
+bool cluster_shape(const KbView &kb, int nCU, ClusterShape *out) { return cluster_variant<R>(kb, nCU, out) >= 0; }
 
 int device_cus() {
   int dev = 0, nCU = 0;
@@ -834,7 +1283,9 @@ const char *EvalClusterKernelName(const KbView &kb) {
   ClusterShape s{};
   const bool ok = kb.elem == 4 ? cluster_shape<float>(kb, device_cus(), &s) : cluster_shape<double>(kb, device_cus(), &s);
   if (!ok) return "stream";
-  std::snprintf(name, sizeof(name), "%s_cluster%d_x%d%s", kb.elem == 4 ? "f32" : "f64", s.C, s.nClusters, s.ahead ? "_ahead" : "");
+  char shape[16] = "";
+  if (s.ahead && !(s.tpb == 512 && s.nu == 1)) std::snprintf(shape, sizeof(shape), "_%dx%d", s.tpb, s.nu);
+  std::snprintf(name, sizeof(name), "%s_cluster%d_x%d%s%s", kb.elem == 4 ? "f32" : "f64", s.C, s.nClusters, s.ahead ? "_ahead" : "", shape);
   return name;
 }
 
@@ -850,8 +1301,8 @@ size_t EvalClusterScratchBytes(const KbView &kb) {
 hipError_t LaunchEvalCluster(const KbView &kb, const double *prior, const uint32_t *asked, double *priority, void *scratch, hipStream_t stream) {
   ClusterShape s{};
   const bool f32 = kb.elem == 4;
-  const bool ok = f32 ? cluster_shape<float>(kb, device_cus(), &s) : cluster_shape<double>(kb, device_cus(), &s);
-  if (!ok || scratch == nullptr) return hipErrorInvalidValue;
+  const int variant = f32 ? cluster_variant<float>(kb, device_cus(), &s) : cluster_variant<double>(kb, device_cus(), &s);
+  if (variant < 0 || scratch == nullptr) return hipErrorInvalidValue;
   char *p = static_cast<char *>(scratch);
   ClusterArgs a{};
   a.cube = kb.cube; a.prior = prior; a.tgap = kb.tgap; a.qgap = kb.qgap; a.asked = asked;
@@ -869,9 +1320,10 @@ hipError_t LaunchEvalCluster(const KbView &kb, const double *prior, const uint32
   a.tagBase = (launches.fetch_add(1) + 1) << 32;
   hipError_t e = hipSuccess;
   const dim3 grid((unsigned)(s.C * s.nClusters));
-  if (s.ahead) {
-    if (f32) hipLaunchKernelGGL((eval_cluster_ahead_kernel<float>), grid, dim3(kClusterThreads), s.shmem, stream, a);
-    else hipLaunchKernelGGL((eval_cluster_ahead_kernel<double>), grid, dim3(kClusterThreads), s.shmem, stream, a);
+  if (variant > 0) {
+    void *params[] = {&a};
+    e = hipLaunchKernel(f32 ? ahead_kernel_of<float>(variant, kb.K == 5) : ahead_kernel_of<double>(variant, kb.K == 5), grid, dim3((unsigned)s.tpb), params, s.shmem, stream);
+    if (e != hipSuccess) return e;
   } else if (f32) {
     if (s.nu == 1) hipLaunchKernelGGL((eval_cluster_kernel<float, 1>), grid, dim3(kClusterThreads), s.shmem, stream, a);
     else hipLaunchKernelGGL((eval_cluster_kernel<float, 2>), grid, dim3(kClusterThreads), s.shmem, stream, a);

@@ -648,6 +648,7 @@ class HipEngine : public IEngine {
   int64_t _optRerank = 1;         // Float engines' batched argmax: the fp32 sweep's best 8 questions per quiz re-ranked in fp64
   int64_t _optBatchQb = 0;        // questions per block of that sweep (0 = default)
   int64_t _optBatchTile = 0;      // targets per LDS tile of that sweep (0 = default)
+  int64_t _optClusterShape = 0;   // ... the shape of the form that runs ahead (cluster_kernels.hip: kAheadVariants), 0 = default
   int64_t _optClusterForm = 0;    // long rows, one quiz (cluster_kernels.hip): 0 = default, 1 = question by question, 2 = pass 1 a question ahead
   int64_t _optBatchTail = 1;      // that sweep's last, partial round as a launch of its own with fewer questions per group (LaunchEvalBatch)
   int64_t _optBatchGroups = 0;    // question groups per workgroup of that sweep for batches under 129 quizzes (0 = automatic)

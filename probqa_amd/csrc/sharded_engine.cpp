@@ -1505,7 +1505,7 @@ Error ShardedEngine::Rebuild(int64_t newQ, int64_t newT, const std::vector<int64
     Error ae;
     e->SetQuestionsAsked(s == 0 ? s0.GetTotalQuestionsAsked(ae) : 0);
     for (const char *opt : {"select", "workers", "eval_subtasks", "eval_variant", "bug_compat", "top_cache", "speculate", "host_sampled",
-                            "fused_sampled", "batch_min", "batch_qb", "batch_tile", "batch_groups", "batch_tail", "batch_form", "cluster_form", "rerank", "combine", "server", "use_graph",
+                            "fused_sampled", "batch_min", "batch_qb", "batch_tile", "batch_groups", "batch_tail", "batch_form", "cluster_form", "cluster_shape", "rerank", "combine", "server", "use_graph",
                             "pole_fix", "pole_lazy", "late_eager", "long_row_form", "fuse_update", "combine_spin", "combine_linger_us", "post_always", "server_idle_us"}) {
       const int64_t v = _sh[(size_t)s]->GetOption(opt);
       if (v >= 0) (void)e->SetOption(opt, std::string(opt) == "eval_subtasks" && v == 8 * _sh[(size_t)s]->GetOption("workers") ? 0 : v);

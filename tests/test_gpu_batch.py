@@ -31,6 +31,13 @@ PRIORITY_RTOL = 1e-9
 F32_RTOL = 5e-4
 F32_AMPLIFY = 6.0
 
+# the long-row sweep's forms (option cluster_form) and, for the form that runs ahead, its shapes (option cluster_shape:
+# cluster_kernels.hip kAheadVariants)
+CLUSTER_FORMS = [(1, 0), (2, 1), (2, 2)]
+CLUSTER_FORM_IDS = ["by_question", "ahead", "ahead_256x2"]
+CLUSTER_SHAPE_SUFFIX = {0: "", 1: "", 2: "_256x2"}
+
+
 
 def scripted_quizzes(case, eng, n_quizzes, rng):
     """n_quizzes quizzes with different answer histories (0..3 answers); returns [(quiz id, [(q, a), ...])]."""
@@ -296,8 +303,8 @@ def test_batched_sweep_mid_size_fp64_and_fp32(factory):
                                      (16384, 5, "f32_wg1024_nq4"), (20000, 5, "f32_cluster7_x14"), (70000, 3, "f32_cluster18_x14"),
                                      (900, 17, "f32_stream")],
                          ids=lambda v: str(v))
-@pytest.mark.parametrize("cluster_form", [1, 2], ids=["by_question", "ahead"])
-def test_float_single_quiz_register_shapes(T, K, name, cluster_form, factory):
+@pytest.mark.parametrize("cluster_form,cluster_shape", CLUSTER_FORMS, ids=CLUSTER_FORM_IDS)
+def test_float_single_quiz_register_shapes(T, K, name, cluster_form, cluster_shape, factory):
     """The single-quiz sweep of a Float engine, every register shape (eval_f32_kernels.hip), the cluster form for long rows
     (cluster_kernels.hip) and the streaming form behind them:
     against the fp64 oracle on the rounded cube at the fp32 tolerance, after StartQuiz and after three answers, with target and
@@ -312,8 +319,9 @@ def test_float_single_quiz_register_shapes(T, K, name, cluster_form, factory):
         pytest.skip("the two forms of the cluster sweep are for rows beyond the register shapes")
     eng, orc = float_engine(case, factory)
     eng.set_option("cluster_form", cluster_form)
-    if cluster_form == 2:       # (one unit per thread: more members than the question-by-question form's two)
-        assert eng.eval_kernel_name().startswith("f32_cluster") and eng.eval_kernel_name().endswith("_ahead")
+    eng.set_option("cluster_shape", cluster_shape)
+    if cluster_form == 2:       # (slices by the shape: threads x units per thread, one or two workgroups per CU)
+        assert eng.eval_kernel_name().startswith("f32_cluster") and eng.eval_kernel_name().endswith("_ahead" + (CLUSTER_SHAPE_SUFFIX[cluster_shape] if K == 5 else ""))
     else:
         assert eng.eval_kernel_name() == name
     quiz = eng.start_quiz()
@@ -349,8 +357,8 @@ def test_float_single_quiz_register_shapes(T, K, name, cluster_form, factory):
 
 @pytest.mark.parametrize("T,K,name", [(20000, 5, "f64_cluster20_x14"), (40000, 2, "f64_cluster40_x12"), (16500, 9, "f64_cluster26_x14")],
                          ids=lambda v: str(v))
-@pytest.mark.parametrize("cluster_form", [1, 2], ids=["by_question", "ahead"])
-def test_double_long_rows_cluster_sweep(T, K, name, cluster_form, factory):
+@pytest.mark.parametrize("cluster_form,cluster_shape", CLUSTER_FORMS, ids=CLUSTER_FORM_IDS)
+def test_double_long_rows_cluster_sweep(T, K, name, cluster_form, cluster_shape, factory):
     """Rows beyond the register shapes on a Double engine: the question split over a cluster of workgroups (cluster_kernels.hip).
     Against the oracle at the stated bar, after StartQuiz and after three answers, with gaps; the streaming form (variant 99) on
     the same states; argmax and the sampled selector's pick as the oracle's."""
@@ -360,7 +368,11 @@ def test_double_long_rows_cluster_sweep(T, K, name, cluster_form, factory):
     case = cases.Case("f64long_%d" % T, K, Q, T, seed=T + 1, tgaps=tgaps, qgaps=[7], answers=[(5, 1), (0, K - 1), (13, 0)])
     eng, orc = case.make_engine(factory), case.make_oracle()
     eng.set_option("cluster_form", cluster_form)
-    assert eng.eval_kernel_name() == name + ("_ahead" if cluster_form == 2 else "")
+    eng.set_option("cluster_shape", cluster_shape)
+    if cluster_shape <= 1:
+        assert eng.eval_kernel_name() == name + ("_ahead" if cluster_form == 2 else "")
+    else:
+        assert eng.eval_kernel_name().startswith("f64_cluster") and eng.eval_kernel_name().endswith("_ahead" + (CLUSTER_SHAPE_SUFFIX[cluster_shape] if K == 5 else ""))   # (256 x 2 is built for five answers)
     quiz = eng.start_quiz()
     worst = 0.0
     for step in range(len(case.answers) + 1):

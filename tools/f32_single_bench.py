@@ -1,4 +1,4 @@
-"""Timing of the single-quiz sweep of a Float engine and of a Double engine (tools): f32_single_bench.py Q K T [steps] [variant] [cluster_form]"""
+"""Timing of the single-quiz sweep of a Float engine and of a Double engine (tools): f32_single_bench.py Q K T [steps] [variant] [cluster_form] [cluster_shape]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from probqa_amd import interop
@@ -6,6 +6,7 @@ Q, K, T = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
 steps = int(sys.argv[4]) if len(sys.argv) > 4 else 200
 variant = int(sys.argv[5]) if len(sys.argv) > 5 else 0
 cluster_form = int(sys.argv[6]) if len(sys.argv) > 6 else 0
+cluster_shape = int(sys.argv[7]) if len(sys.argv) > 7 else 0
 f = interop.PqaEngineFactory()
 for prec in ("f32", "f64"):
     kw = dict(prec_type=interop.PrecisionType.FLOAT, prec_exponent=8, prec_mantissa=24) if prec == "f32" else {}
@@ -15,6 +16,7 @@ for prec in ("f32", "f64"):
     if prec == "f32":
         e.set_option("eval_variant", variant)
     e.set_option("cluster_form", cluster_form)
+    e.set_option("cluster_shape", cluster_shape)
     e.fill_synthetic(8.0, 0.5, 20260928)
     qz = e.start_quiz()
     for _ in range(10):
