@@ -134,6 +134,11 @@ __device__ __forceinline__ void put_record(ExRec *p, double v, unsigned long lon
 // (~2900 cycles of an iteration's 19 900, by the kernel's own clock) in series with everything else.  Loads issued here are waited
 // for by wait_records<N>: "at most N younger vector-memory operations outstanding", N = the row loads issued behind them (loads
 // return in order, so the records are in; a smaller N only waits longer).
+// THE PRICE: between such a load and its wait the compiler believes the destination registers hold the value.  Were it to spill or
+// copy them in that window (live-range splitting under register pressure) it would save stale contents and hand the registers to
+// something else, which the landing load then overwrites -- seen in round 5 as a memory fault of a 512-thread form of the kernel
+// below, built at the edge of its 128 registers.  Kernels that use these loads are therefore built with registers to spare, and
+// tests/test_build_lint.py holds their compiled form to it: no scratch, no AGPR copies, at least 16 VGPRs unused.
 __device__ __forceinline__ u4 get_record_async(const ExRec *p) {
   u4 x;
   asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(x) : "v"(p));
@@ -1003,48 +1008,43 @@ __global__ __launch_bounds__(TPB, WPE) void eval_cluster_five_kernel(ClusterArgs
     bool rowsBehind = false;
     Polled pw;
     if (qNext < a.Q) pass1(qNext, round + 1, idNext, lhNext);
-    // ---- everybody's partial W of THIS question (published an iteration ago), in slice order; the next-but-one question's rows are
-    // requested into the registers pass 1 has just freed, BEHIND the records' loads, whose wait leaves them in flight
+    // ---- everybody's partial W of THIS question (published an iteration ago), in slice order: the records are asked for BEFORE the
+    // next-but-one question's rows are requested (into the registers pass 1 has just freed), so that their wait leaves those in flight.
+    // (Asked for already in front of pass 1's arithmetic, 16 registers held across it: 2921 against 2910 us -- no gain, not kept.)
     gather_issue(recW + (size_t)(round & 3) * C * kMaxK, kMaxK, (int)K, pw);
     if (qNext2 < a.Q) { request_question(qNext2); rowsBehind = true; }
     gather_finish(recW + (size_t)(round & 3) * C * kMaxK, kMaxK, (int)K, tagBase + round + 1, pw, rowsBehind);
-    // (two forms of the same sums, each kept where it measured faster on one box at 2000 x 5 x 100000: the sums written straight to
-    //  where pass 2 and the fold look, one barrier less -- fp32 1517 -> 1489 us, fp64 3206 -> 3262 us)
-    constexpr bool kDirectSums = !NumC<R>::kTable;
-    if constexpr (kDirectSums) {
-      for (int col = wave; col < K; col += NW) {
+    // W_k over the members, a column per group of 32 lanes (the five in one round), written straight to where pass 2 and the fold look;
+    // 1 / W_k (:91) once per workgroup (every thread formed it: a fifth of pass 2's instructions)
+    {
+      const int grp = tid >> 5, l32 = tid & 31;
+      for (int col = grp; col < K; col += NG) {
         double w = 0.0;
-        for (int i = lane; i < C; i += kWave) w += xch[i * (int)K + col];
-        w = wave_sum(w);
-        if (lane == 0) {
-          wInv[col] = div_fast(1.0, w);                         // :91, once per workgroup (every thread formed it: a fifth of pass 2's instructions)
+        for (int i = l32; i < C; i += 32) w += xch[i * (int)K + col];
+        w += mov_dpp<kDppXor1>(w);
+        w += mov_dpp<kDppXor2>(w);
+        w += mov_dpp<kDppHalfMirror>(w);
+        w += mov_dpp<kDppMirror>(w);
+        const Pair pq = swap16(w);
+        w = pq.a + pq.b;
+        if (l32 == 0) {
+          wInv[col] = div_fast(1.0, w);
           wHist[(round & 3) * kMaxK + col] = w;
         }
       }
-      __syncthreads();                                          // (xch is read, W is there)
-    } else {
-      sum_members((int)K, red[8]);
-      __syncthreads();                                          // (xch is read)
     }
+    __syncthreads();                                            // (xch is read, W is there)
     // the turn-taker folds the question before the previous one: every member published its sums before it published its W of this
     // question, which have all just been seen
     if (qPrev2 >= 0 && (int)((round - 2) % (unsigned long long)C) == m) fold(qPrev2, round - 2);
-    if constexpr (!kDirectSums) {
-      if (tid < K) {
-        const double w = red[8][tid];
-        wInv[tid] = div_fast(1.0, w);                           // :91, once per workgroup
-        wHist[(round & 3) * kMaxK + tid] = w;
-      }
-      __syncthreads();
-    }
     // ---- pass 2 (:95-128) from LDS, answer by answer.  The threads' sums are not reduced wave by wave (K + 2 butterflies of six DPP
     // steps each were a quarter of the iteration's instructions): a thread parks its K + 2 sums in the LDS slots of its first unit --
     // 16 bytes per answer row, dead once the row's likelihoods have been read -- and groups of 32 lanes add one column each.
     double *slot = reinterpret_cast<double *>(lhL);             // unit u of row k: slot[(k * SU + u) * 2 + {0, 1}]
     V accN[NU], accD[NU];
     R hW = (R)0, accL = (R)0;
-#pragma unroll 1
-    for (int64_t k = 0; k < K; k++) {
+#pragma unroll                                                 // (the five answers in one stretch: -6 % against a loop)
+    for (int k = 0; k < (int)K; k++) {
       const R invWk = (R)wInv[k];                               // :91 (formed once per workgroup, above)
       R vk = (R)0;
       V lh[NU];
@@ -1098,7 +1098,11 @@ __global__ __launch_bounds__(TPB, WPE) void eval_cluster_five_kernel(ClusterArgs
         if (col == K + 1 && K == 1) {
           if (l32 < NW) acc = red[0][l32];
         } else {
-          for (int u = l32; u < nSlots; u += 32) acc += src[(size_t)u * 2];
+          double acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;             // (four chains: nSlots / 32 dependent additions were the phase)
+          int u = l32;
+          for (; u + 96 < nSlots; u += 128) { acc += src[(size_t)u * 2]; acc1 += src[(size_t)(u + 32) * 2]; acc2 += src[(size_t)(u + 64) * 2]; acc3 += src[(size_t)(u + 96) * 2]; }
+          for (; u < nSlots; u += 32) acc += src[(size_t)u * 2];
+          acc = (acc + acc1) + (acc2 + acc3);
         }
         acc += mov_dpp<kDppXor1>(acc);
         acc += mov_dpp<kDppXor2>(acc);
@@ -1121,7 +1125,6 @@ __global__ __launch_bounds__(TPB, WPE) void eval_cluster_five_kernel(ClusterArgs
     round++;
     q = qNext;
     qNext = qNext2;
-    if constexpr (!kDirectSums) __syncthreads();                // (not needed for the data: the next reader of the LDS copy is pass 2, behind pass 1's and the exchange's barriers)
   }
   __syncthreads();
   // the last two questions' sums: their turn-takers wait for them
@@ -1168,8 +1171,8 @@ struct ClusterShape { int C, nClusters, sliceUnits, nu, tpb, perCU; size_t shmem
 // elements (at half the waves per SIMD and twice the registers per thread).
 struct AheadVariant { int tpb, nu, perCU; };
 constexpr AheadVariant kAheadVariants[] = {
-    {512, 1, 2},   // 1: round 4's shape -- four waves per SIMD, 128 registers
-    {256, 2, 2},   // 2: the same slices and LDS, half the waves, two units per thread
+    {512, 1, 2},   // 1: round 4's kernel (eval_cluster_ahead_kernel) -- four waves per SIMD, 128 registers, any number of answers
+    {256, 2, 2},   // 2: eval_cluster_five_kernel -- the same slices and LDS, half the waves, two units per thread; five answers
     // (measured and taken out in round 5: one workgroup of 512 x 2 or 512 x 3 per CU, slices two and three times as long, half and a
     //  third of the members -- 2000 x 5 x 100000: fp64 3.74 / 3.93 ms against 3.48, fp32 1.67 / 1.61 against 1.31)
 };
@@ -1177,9 +1180,9 @@ constexpr int kAheadVariantCount = (int)(sizeof(kAheadVariants) / sizeof(kAheadV
 constexpr int kAheadDefaultF64 = 2, kAheadDefaultF32 = 2;     // (where the shape is not built -- other than five answers -- shape 1)
 
 template <typename R>
-const void *ahead_kernel_of(int variant, bool five) {   // five: exactly five answers
+const void *ahead_kernel_of(int variant) {
   if (variant == 2) return reinterpret_cast<const void *>(eval_cluster_five_kernel<R, 256, 2, 2>);   // (five answers only: cluster_shape_of)
-  return five ? reinterpret_cast<const void *>(eval_cluster_five_kernel<R, 512, 1, 4>) : reinterpret_cast<const void *>(eval_cluster_ahead_kernel<R>);
+  return reinterpret_cast<const void *>(eval_cluster_ahead_kernel<R>);
 }
 
 // does the device hold `perCU` workgroups of the kernel per CU with this much LDS?  (cached per kernel, device and LDS size)
@@ -1200,10 +1203,10 @@ bool occupancy_two(size_t shmem) {
   return occupancy_reaches(cache, reinterpret_cast<const void *>(eval_cluster_kernel<R, NU>), kClusterThreads, shmem, 2);
 }
 template <typename R>
-bool occupancy_ahead(int variant, bool five, size_t shmem) {
-  static LaunchCache cache[2 * (kAheadVariantCount + 1)];
+bool occupancy_ahead(int variant, size_t shmem) {
+  static LaunchCache cache[kAheadVariantCount + 1];
   const AheadVariant &v = kAheadVariants[variant - 1];
-  return occupancy_reaches(cache[2 * variant + (five ? 1 : 0)], ahead_kernel_of<R>(variant, five), v.tpb, shmem, v.perCU);
+  return occupancy_reaches(cache[variant], ahead_kernel_of<R>(variant), v.tpb, shmem, v.perCU);
 }
 
 // Slices as long as the workgroups' LDS allows (72 KB each where two share a CU, the fp64 table included): the fewer members a
@@ -1245,7 +1248,7 @@ bool cluster_shape_of(const KbView &kb, int nCU, int variant, ClusterShape *out)
   out->nu = ahead ? v.nu : (su <= kClusterThreads ? 1 : 2);
   out->ahead = ahead;
   out->shmem = tableBytes + (size_t)kb.K * su * 16 + kFixedLdsBytes + kExchangeLdsBytes + (ahead ? kAheadLdsBytes + parkBytes : 0);
-  if (ahead) return occupancy_ahead<R>(variant, kb.K == 5, out->shmem);
+  if (ahead) return occupancy_ahead<R>(variant, out->shmem);
   return out->nu == 1 ? occupancy_two<R, 1>(out->shmem) : occupancy_two<R, 2>(out->shmem);
 }
 // KbView::clusterForm (engine option cluster_form): 0 = the default below, 1 = the question-by-question form, 2 = pass 1 a question
@@ -1322,7 +1325,7 @@ hipError_t LaunchEvalCluster(const KbView &kb, const double *prior, const uint32
   const dim3 grid((unsigned)(s.C * s.nClusters));
   if (variant > 0) {
     void *params[] = {&a};
-    e = hipLaunchKernel(f32 ? ahead_kernel_of<float>(variant, kb.K == 5) : ahead_kernel_of<double>(variant, kb.K == 5), grid, dim3((unsigned)s.tpb), params, s.shmem, stream);
+    e = hipLaunchKernel(f32 ? ahead_kernel_of<float>(variant) : ahead_kernel_of<double>(variant), grid, dim3((unsigned)s.tpb), params, s.shmem, stream);
     if (e != hipSuccess) return e;
   } else if (f32) {
     if (s.nu == 1) hipLaunchKernelGGL((eval_cluster_kernel<float, 1>), grid, dim3(kClusterThreads), s.shmem, stream, a);
