@@ -1011,6 +1011,8 @@ __global__ __launch_bounds__(TPB, WPE) void eval_cluster_five_kernel(ClusterArgs
     // ---- everybody's partial W of THIS question (published an iteration ago), in slice order: the records are asked for BEFORE the
     // next-but-one question's rows are requested (into the registers pass 1 has just freed), so that their wait leaves those in flight.
     // (Asked for already in front of pass 1's arithmetic, 16 registers held across it: 2921 against 2910 us -- no gain, not kept.)
+    // (Each answer's group of 32 lanes reading ITS records itself, no staging in LDS and a barrier less: the reads are 256 bytes apart
+    //  instead of one coalesced round -- fp64 2670 -> 2757 us, fp32 1110 -> 1170-1220; not kept.)
     gather_issue(recW + (size_t)(round & 3) * C * kMaxK, kMaxK, (int)K, pw);
     if (qNext2 < a.Q) { request_question(qNext2); rowsBehind = true; }
     gather_finish(recW + (size_t)(round & 3) * C * kMaxK, kMaxK, (int)K, tagBase + round + 1, pw, rowsBehind);

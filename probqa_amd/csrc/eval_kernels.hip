@@ -372,13 +372,13 @@ __device__ __forceinline__ double2 load_pair(const double2 *p) {
 // workgroup also lists the posterior's best targets right away (ListTopTargets is the client's next call), and workgroup 0, as the
 // finisher that has seen every workgroup's record (so nobody reads the old prior any more), stores the posterior over the old prior
 // at the end.
-template <int WPQ, int NP, bool PRLDS, bool SERVER, bool DEFER, bool FUSE = false, bool POLE = false>
+template <int WPQ, int NP, bool PRLDS, bool SERVER, bool DEFER, bool FUSE = false, bool POLE = false, int KC = 0>
 __device__ __forceinline__ void sweep_body(EvalArgs a, bool copyTable) {
   constexpr int kThreads = WPQ * kWave;
   constexpr int NPR = PRLDS ? 1 : NP;
   constexpr bool kStreamHint = !SERVER && WPQ >= 8;            // the shapes for rows beyond 4096 targets: see row_load
   extern __shared__ double smem[];
-  const int64_t ldT = a.ldT, K = a.K;
+  const int64_t ldT = a.ldT, K = KC > 0 ? KC : a.K;             // (KC: the answer count as a constant)
   double *tbl = smem;
   if (!lds_table_at_zero(tbl)) __builtin_trap();  // log2hot addresses the table absolutely
   double *redW = tbl + kLog2TableDoubles;
@@ -580,6 +580,7 @@ __device__ __forceinline__ void sweep_body(EvalArgs a, bool copyTable) {
     double accL = 0, hW = 0;
     [[maybe_unused]] int32_t rowGap = INT32_MIN;
     [[maybe_unused]] uint32_t watchRows = 0;                   // (pole watch, per lane: the rows in which this lane's sum is nearly all of W_k below, a quarter of it above)
+#pragma unroll KC > 0 ? KC : 1
     for (int64_t k = 0; k < K; k++) {
       // ---- pass 1 (:66-87): likelihoods into registers, W_k; each consumed pair is refilled from the next stream row
       double2 lh[NP];
@@ -834,10 +835,13 @@ __device__ __forceinline__ void sweep_body(EvalArgs a, bool copyTable) {
 // DEFER: the question's lane sums leave the row loop (eval_defers_sums) -- the default where the shape has a deferred form
 // and the (K + 2) x threads doubles fit beside the rest of its LDS; a knowledge base with dozens of answers per question
 // falls back to the form without.
-template <int WPQ, int NP, bool PRLDS, bool DEFER, bool POLE = false>
+// KC (here and in the kernels below): the answer count as a constant -- five, where the caller's cube has five answers per question
+// (every configuration of BASELINE.json) and the shape is the short rows' (four waves of two pairs): the loop over the answers has
+// no trip-count registers and is unrolled (round 5: the resident step's selections 48.0 -> 50.7 k per second on one box).
+template <int WPQ, int NP, bool PRLDS, bool DEFER, bool POLE = false, int KC = 0>
 __global__ __launch_bounds__(WPQ * 64) void eval_questions_f64(EvalArgs a) {
   select_quiz(a);
-  sweep_body<WPQ, NP, PRLDS, false, DEFER, false, POLE>(a, true);
+  sweep_body<WPQ, NP, PRLDS, false, DEFER, false, POLE, KC>(a, true);
 }
 // The same kernel held to three waves per SIMD (168 VGPRs): the two 4-pair shapes need 169 with the deferred sums, and a
 // register spilled costs them less than a wave of occupancy does.
@@ -848,9 +852,9 @@ __global__ __launch_bounds__(WPQ * 64) __attribute__((amdgpu_waves_per_eu(3, 3))
 }
 
 // RecordAnswer's posterior update + the sweep of the NextQuestion that follows, one launch (sweep_body: FUSE)
-template <int WPQ, int NP, bool DEFER, bool POLE = false>
+template <int WPQ, int NP, bool DEFER, bool POLE = false, int KC = 0>
 __global__ __launch_bounds__(WPQ * 64) void eval_questions_f64_upd(EvalArgs a) {
-  sweep_body<WPQ, NP, false, false, DEFER, true, POLE>(a, true);
+  sweep_body<WPQ, NP, false, false, DEFER, true, POLE, KC>(a, true);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -873,7 +877,7 @@ __device__ __forceinline__ uint64_t line_u64(uint32_t v, int i) {   // qword i o
          ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)v, 2 * i + 1) << 32);
 }
 
-template <int WPQ, int NP, bool DEFER>
+template <int WPQ, int NP, bool DEFER, int KC>
 // Three workgroups per CU with the 154 registers the kernel wants (3 x 160 of the 512 per SIMD lane).  Capped at 128 (waves_per_eu
 // (4, 4), until round 3) it spilled 17 registers and a step took 19.0 us instead of 17.0.  The 32 registers left per lane are what the
 // 256-thread posterior kernels that must run beside the resident sweep fit into (prior_kernels.hip: kSmallThreads; 24 - 30 each).
@@ -962,7 +966,7 @@ void eval_server_f64(EvalArgs a, ServerMailbox *mb, uint32_t *requestLine, int e
                  "+s"(b.qFirst), "+s"(b.qLimit));
     __syncthreads();   // the step block may be rewritten only after everybody has read it
     const uint64_t tA = wall_clock64();   // 100 MHz
-    sweep_body<WPQ, NP, false, true, DEFER, false, true>(b, copyTable);
+    sweep_body<WPQ, NP, false, true, DEFER, false, true, KC>(b, copyTable);
     copyTable = false;
     last = go;
     if (first && wave == 0) {
@@ -1373,16 +1377,19 @@ hipError_t launch_pole_fixup(const EvalArgs &args, hipStream_t stream, int nBatc
   return LaunchPoleFixup(f, stream);
 }
 
-template <int WPQ, int NP, bool PRLDS, bool DEFER, bool POLE = false>
+template <int WPQ, int NP, bool PRLDS, bool DEFER, bool POLE = false, int KC = 0>
 hipError_t launch_reg_form(const EvalArgs &args, int64_t nQ, int nBatch, hipStream_t stream) {
   // the variant with the pole watch where the engine asked for it (single-quiz launches)
   if constexpr (!POLE) {
-    if (args.poleList != nullptr) return launch_reg_form<WPQ, NP, PRLDS, DEFER, true>(args, nQ, nBatch, stream);
+    if (args.poleList != nullptr) return launch_reg_form<WPQ, NP, PRLDS, DEFER, true, KC>(args, nQ, nBatch, stream);
+  }
+  if constexpr (KC == 0 && WPQ == 4 && NP == 2 && !PRLDS && DEFER) {   // (five answers as a constant: eval_questions_f64's comment)
+    if (args.K == 5) return launch_reg_form<WPQ, NP, PRLDS, DEFER, POLE, 5>(args, nQ, nBatch, stream);
   }
   const size_t shmem = eval_base_lds_bytes<WPQ, NP, PRLDS>(args.K, args.ldT) + (DEFER ? eval_deferred_bytes(WPQ, NP, args.K, PRLDS) : 0);
   auto kern = [] {
     if constexpr (NP == 4 && WPQ == 4 && (DEFER || POLE)) return eval_questions_f64_occ3<WPQ, NP, PRLDS, DEFER, POLE>;   // (5 and 6 pairs: slower with the spills)
-    else return eval_questions_f64<WPQ, NP, PRLDS, DEFER, POLE>;
+    else return eval_questions_f64<WPQ, NP, PRLDS, DEFER, POLE, KC>;
   }();
   // attribute and occupancy are properties of (kernel, LDS size, device): asked once per device, not on every launch
   static LaunchCache cache;
@@ -1557,7 +1564,8 @@ hipError_t LaunchEvalQuestionsWithUpdate(const KbView &kb, double *prior, uint32
   constexpr int WPQ = 4, NP = 2;
   const size_t shmem = eval_base_lds_bytes<WPQ, NP, false>(args.K, args.ldT) + eval_deferred_bytes(WPQ, NP, args.K, false);
   const bool pole = args.poleList != nullptr;
-  auto kern = pole ? eval_questions_f64_upd<WPQ, NP, true, true> : eval_questions_f64_upd<WPQ, NP, true, false>;
+  auto kern = args.K == 5 ? (pole ? eval_questions_f64_upd<WPQ, NP, true, true, 5> : eval_questions_f64_upd<WPQ, NP, true, false, 5>)
+                          : (pole ? eval_questions_f64_upd<WPQ, NP, true, true> : eval_questions_f64_upd<WPQ, NP, true, false>);
   static LaunchCache cache;
   const int dev = LaunchCache::Device();
   int cachedPerCU = 0;
@@ -1606,12 +1614,12 @@ hipError_t LaunchEvalQuestionsBatch(const KbView &kb, const QuizSlot *slots, int
   return launch_variant(args, kb.ldT, variant, nSlots, stream);
 }
 
-template <int WPQ, int NP, bool DEFER>
+template <int WPQ, int NP, bool DEFER, int KC>
 static hipError_t launch_server_form(const EvalArgs &args, ServerMailbox *mb, void *requestLine, bool everyonePolls, ServerCtl *ctl,
                                 uint64_t lastSeq, uint64_t idleTicks, hipStream_t stream) {
   const size_t stepOffset = eval_base_lds_bytes<WPQ, NP, false>(args.K, args.ldT) + (DEFER ? eval_deferred_bytes(WPQ, NP, args.K, false) : 0);
   const size_t shmem = stepOffset + 64;
-  auto kern = eval_server_f64<WPQ, NP, DEFER>;
+  auto kern = eval_server_f64<WPQ, NP, DEFER, KC>;
   static LaunchCache cache;
   const int dev = LaunchCache::Device();
   int cachedPerCU = 0;
@@ -1641,8 +1649,9 @@ template <int WPQ, int NP>
 static hipError_t launch_server(const EvalArgs &args, ServerMailbox *mb, void *requestLine, bool everyonePolls, ServerCtl *ctl,
                                 uint64_t lastSeq, uint64_t idleTicks, hipStream_t stream) {
   if (eval_defers_sums(WPQ, NP, false) && eval_base_lds_bytes<WPQ, NP, false>(args.K, args.ldT) + eval_deferred_bytes(WPQ, NP, args.K, false) + 64 <= kLdsPerCU)
-    return launch_server_form<WPQ, NP, true>(args, mb, requestLine, everyonePolls, ctl, lastSeq, idleTicks, stream);
-  return launch_server_form<WPQ, NP, false>(args, mb, requestLine, everyonePolls, ctl, lastSeq, idleTicks, stream);
+    return args.K == 5 && WPQ == 4 && NP == 2 ? launch_server_form<WPQ, NP, true, (WPQ == 4 && NP == 2 ? 5 : 0)>(args, mb, requestLine, everyonePolls, ctl, lastSeq, idleTicks, stream)
+                       : launch_server_form<WPQ, NP, true, 0>(args, mb, requestLine, everyonePolls, ctl, lastSeq, idleTicks, stream);
+  return launch_server_form<WPQ, NP, false, 0>(args, mb, requestLine, everyonePolls, ctl, lastSeq, idleTicks, stream);
 }
 
 static int server_variant(const KbView &kb, int variant) {
