@@ -836,8 +836,9 @@ __device__ __forceinline__ void sweep_body(EvalArgs a, bool copyTable) {
 // and the (K + 2) x threads doubles fit beside the rest of its LDS; a knowledge base with dozens of answers per question
 // falls back to the form without.
 // KC (here and in the kernels below): the answer count as a constant -- five, where the caller's cube has five answers per question
-// (every configuration of BASELINE.json) and the shape is the short rows' (four waves of two pairs): the loop over the answers has
-// no trip-count registers and is unrolled (round 5: the resident step's selections 48.0 -> 50.7 k per second on one box).
+// (every configuration of BASELINE.json): the loop over the answers has no trip-count registers and is unrolled.  Round 5, same box,
+// launched sweep: 1000 targets (four waves of two pairs) 14.1 -> 13.2 us (the resident step 16.3-16.7 -> 15.1-15.6), 1500 29.1 -> 27.3,
+// 3000 108 -> 96, 4000 179 -> 158, 6000 388 -> 328, 8000 653 -> 556 us (-15 %); the shapes with the priors in LDS -1 % or nothing.
 template <int WPQ, int NP, bool PRLDS, bool DEFER, bool POLE = false, int KC = 0>
 __global__ __launch_bounds__(WPQ * 64) void eval_questions_f64(EvalArgs a) {
   select_quiz(a);
@@ -1383,7 +1384,10 @@ hipError_t launch_reg_form(const EvalArgs &args, int64_t nQ, int nBatch, hipStre
   if constexpr (!POLE) {
     if (args.poleList != nullptr) return launch_reg_form<WPQ, NP, PRLDS, DEFER, true, KC>(args, nQ, nBatch, stream);
   }
-  if constexpr (KC == 0 && WPQ == 4 && NP == 2 && !PRLDS && DEFER) {   // (five answers as a constant: eval_questions_f64's comment)
+  // five answers as a constant (eval_questions_f64's comment): the shapes with the priors in registers, and the 10000-target shape
+  // (the other LDS-prior shapes measured within 1 %: not built)
+  // (four pairs per lane: 2000 targets 39.3 -> 41.5 us with it -- the shape sits at its register cap, eval_questions_f64_occ3 -- left out)
+  if constexpr (KC == 0 && DEFER && NP != 4 && (!PRLDS || (WPQ == 8 && NP == 10))) {
     if (args.K == 5) return launch_reg_form<WPQ, NP, PRLDS, DEFER, POLE, 5>(args, nQ, nBatch, stream);
   }
   const size_t shmem = eval_base_lds_bytes<WPQ, NP, PRLDS>(args.K, args.ldT) + (DEFER ? eval_deferred_bytes(WPQ, NP, args.K, PRLDS) : 0);
