@@ -20,6 +20,9 @@
 // The cube is read ONCE.  Two workgroups of different clusters share a CU, so that one streams while the other waits for its
 // cluster.  The grid is exactly the number of workgroups the device holds at once (they wait for each other).
 // Slices, partial sums and their order are fixed by (ldT, K, C) alone: results do not depend on timing.
+// Three kernels: eval_cluster_kernel (question by question, as above), eval_cluster_ahead_kernel (round 4: pass 1 a question ahead of
+// the exchange; any number of answers), eval_cluster_five_kernel (round 5: that form for questions of five answers -- 256 threads of
+// two units, the loop's loads issued and waited for by hand; the default where it applies).  Options cluster_form / cluster_shape.
 #include <algorithm>
 #include <atomic>
 #include <cstdio>
