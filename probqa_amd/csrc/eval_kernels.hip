@@ -882,6 +882,8 @@ template <int WPQ, int NP, bool DEFER, int KC>
 // Three workgroups per CU with the 154 registers the kernel wants (3 x 160 of the 512 per SIMD lane).  Capped at 128 (waves_per_eu
 // (4, 4), until round 3) it spilled 17 registers and a step took 19.0 us instead of 17.0.  The 32 registers left per lane are what the
 // 256-thread posterior kernels that must run beside the resident sweep fit into (prior_kernels.hip: kSmallThreads; 24 - 30 each).
+// (KC = 5, round 5: 162 registers, 168 allocated.  A quiz through the resident sweep -- NextQuestion and RecordAnswer in turn, 1000 x 5 x
+//  1000 -- took 73.4 us per pair before and 73.5 after on one box: measured, because the margin above is gone.)
 __global__ __launch_bounds__(WPQ * 64) __attribute__((amdgpu_waves_per_eu(3, 3)))
 void eval_server_f64(EvalArgs a, ServerMailbox *mb, uint32_t *requestLine, int everyonePolls, ServerCtl *ctl, uint64_t lastSeq,
                      uint64_t idleTicks, unsigned stepOffsetBytes) {
