@@ -116,6 +116,13 @@ PQACORE_API void *PqaEngine_NextQuestionArgmaxBatch(void *pvEngine, const int64_
  * same batched launch by the engine itself (option "combine"). */
 PQACORE_API void *PqaEngine_RecordAnswerBatch(void *pvEngine, const int64_t nQuizzes, const int64_t *pQuizzes, const int64_t *pAnswers);
 PQACORE_API void *PqaEngine_StartQuizBatch(void *pvEngine, const int64_t nQuizzes, int64_t *pQuizzes);
+/* ListTopTargets for nQuizzes quizzes (any number; 256 per launch sequence) without copying a posterior to the host: pDest[i * maxCount + j],
+ * j < pCounts[i], is the listing PqaEngine_ListTopTargets(pQuizzes[i], maxCount) returns -- descending probability, gaps and
+ * probabilities <= 0 dropped (reference PqaCore/CEHeapifyPriorsSubtaskMake.cpp:42-52), equal probabilities by ascending target.
+ * Rows of any length: 4096-target chunks list their own best maxCount on the device and merge there; what crosses to the host is
+ * nQuizzes x maxCount records (the reference's GPU engine copies all nTargets posteriors per quiz: PqaCore/CudaEngine.cpp:251-289). */
+PQACORE_API void *PqaEngine_ListTopTargetsBatch(void *pvEngine, const int64_t nQuizzes, const int64_t *pQuizzes, const int64_t maxCount,
+                                                CiRatedTarget *pDest, int64_t *pCounts);
 /* The priority vectors of nQuizzes <= 256 distinct quizzes from ONE sweep that reads the cube once for the whole batch
  * (batch_kernels.hip): pOut[i * nLocalQuestions + q] = priority of local question q for pQuizzes[i], 0 for gap / asked
  * questions.  The deterministic output behind PqaEngine_NextQuestionArgmaxBatch's row-sharing form. */

@@ -637,3 +637,156 @@ int orc_resume_quiz(const OrcKB *kb, OrcQuiz *quiz, int64_t nAnswered, const Orc
   free(bounds); free(sums);
   return ORC_OK;
 }
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * f2: ListTopTargets.  CpuEngine::ListTopTargetsSpec (PqaCore/CpuEngine.cpp:417-440),
+ * CEListTopTargetsAlgorithm::RunHeapifyBased (PqaCore/CEListTopTargetsAlgorithm.cpp:30-95),
+ * CEHeapifyPriorsSubtaskMake (PqaCore/CEHeapifyPriorsSubtaskMake.cpp:42-52 Regard, :56-88 Run),
+ * SRHeapHelper::Down (SRPlatform/Interface/SRHeap.h:16-39), RatedTarget / RatingsHeapItem order by probability only
+ * (PqaCore/Interface/PqaCommon.h:58-60, PqaCore/RatingsHeap.h:18-20).
+ *
+ * std::make_heap / std::pop_heap are the C++ library's: the reference binary carries MSVC's.  Restated below is the
+ * algorithm MSVC's <algorithm> (_Make_heap_unchecked / _Pop_heap_hole_by_index / _Push_heap_by_index), libstdc++'s
+ * (__make_heap / __adjust_heap / __push_heap) and libc++'s pre-Floyd versions share: the hole sinks to a leaf taking the
+ * right child unless it is less than the left one (a last lone left child is taken too), then the lifted value climbs
+ * while its parent is less.  With distinct probabilities the listing does not depend on it; the order of EQUAL
+ * probabilities does.  tests/test_oracle.py pins this restatement to libstdc++'s own std::make_heap / std::pop_heap
+ * (a checker compiled there with g++); against MSVC's it is "parity unpinned" (no MSVC here) beyond that shared algorithm.
+ *
+ * The radix-sort branch (CEListTopTargetsAlgorithm.cpp:97-173, CERadixSortRatingsSubtaskSort.cpp:61-140), which the cost model
+ * of CpuEngine.cpp:423-434 picks for long lists (orc_list_top_targets_takes_radix), is not restated: its scatter passes
+ * never advance the bucket offsets (CERadixSortRatingsSubtaskSort.cpp:111,126 store to pOffsets[bucket] without ++), so all
+ * but one slot per bucket keep whatever the memory pool held -- its output is not a function of its inputs.  Both branches
+ * filter the same way: gaps and prob <= 0 are dropped (CEHeapifyPriorsSubtaskMake.cpp:43-49,
+ * CERadixSortRatingsSubtaskSort.cpp:78-84).
+ * ---------------------------------------------------------------------------------------------------------------- */
+typedef struct { double prob; int64_t id; } HeapItem;   /* RatedTarget (id = iTarget) or RatingsHeapItem (id = iSource) */
+
+static void heap_push_by_index(HeapItem *first, int64_t hole, int64_t top, HeapItem val) {
+  for (int64_t idx = (hole - 1) >> 1; top < hole && first[idx].prob < val.prob; idx = (hole - 1) >> 1) {
+    first[hole] = first[idx];
+    hole = idx;
+  }
+  first[hole] = val;
+}
+static void heap_adjust(HeapItem *first, int64_t hole, int64_t bottom, HeapItem val) {
+  const int64_t top = hole;
+  int64_t idx = hole;
+  const int64_t maxNonLeaf = (bottom - 1) >> 1;
+  while (idx < maxNonLeaf) {                         /* the hole moves down to the larger child */
+    idx = 2 * idx + 2;
+    if (first[idx].prob < first[idx - 1].prob) --idx;
+    first[hole] = first[idx];
+    hole = idx;
+  }
+  if (idx == maxNonLeaf && bottom % 2 == 0) {        /* an only child at the bottom */
+    first[hole] = first[bottom - 1];
+    hole = bottom - 1;
+  }
+  heap_push_by_index(first, hole, top, val);
+}
+static void heap_make(HeapItem *first, int64_t n) {                             /* std::make_heap */
+  for (int64_t hole = n >> 1; hole > 0;) {
+    --hole;
+    heap_adjust(first, hole, n, first[hole]);
+  }
+}
+static void heap_pop(HeapItem *first, int64_t n) {                              /* std::pop_heap: the top goes to first[n-1] */
+  if (n < 2) return;
+  const HeapItem val = first[n - 1];
+  first[n - 1] = first[0];
+  heap_adjust(first, 0, n - 1, val);
+}
+static void heap_down(HeapItem *first, int64_t n) {                             /* SRHeapHelper::Down, SRHeap.h:16-39 */
+  int64_t cur = 0;
+  for (;;) {
+    const int64_t child1 = 2 * cur + 1;
+    if (child1 >= n) return;                                                    /* :21-23 */
+    const int64_t child2 = child1 + 1;
+    if (child2 >= n) {                                                          /* :25-30 */
+      if (first[cur].prob < first[child1].prob) { const HeapItem t = first[cur]; first[cur] = first[child1]; first[child1] = t; }
+      return;
+    }
+    const int64_t higher = (first[child2].prob < first[child1].prob) ? child1 : child2;   /* :31 */
+    if (!(first[cur].prob < first[higher].prob)) return;                        /* :32-34 */
+    { const HeapItem t = first[cur]; first[cur] = first[higher]; first[higher] = t; }   /* :35 */
+    cur = higher;                                                               /* :36 */
+  }
+}
+
+/* test access to the three heap steps above (tests/test_oracle.py holds them to libstdc++'s) */
+void orc_heap_make(double *prob, int64_t *id, int64_t n) {
+  HeapItem *h = (HeapItem *)malloc((size_t)(n > 0 ? n : 1) * sizeof(HeapItem));
+  for (int64_t i = 0; i < n; i++) { h[i].prob = prob[i]; h[i].id = id[i]; }
+  heap_make(h, n);
+  for (int64_t i = 0; i < n; i++) { prob[i] = h[i].prob; id[i] = h[i].id; }
+  free(h);
+}
+void orc_heap_pop(double *prob, int64_t *id, int64_t n) {
+  HeapItem *h = (HeapItem *)malloc((size_t)(n > 0 ? n : 1) * sizeof(HeapItem));
+  for (int64_t i = 0; i < n; i++) { h[i].prob = prob[i]; h[i].id = id[i]; }
+  heap_pop(h, n);
+  for (int64_t i = 0; i < n; i++) { prob[i] = h[i].prob; id[i] = h[i].id; }
+  free(h);
+}
+
+int orc_list_top_targets_takes_radix(int64_t nTargets, int64_t nWorkers, int64_t maxCount) {   /* CpuEngine.cpp:423-434 */
+  const uint64_t nTargPerThread = ((uint64_t)nTargets + (uint64_t)nWorkers - 1) / (uint64_t)nWorkers;   /* :423 PosDivideRoundUp */
+  const uint64_t logW = (uint64_t)ceil_log2_u64((uint64_t)nWorkers), logT = (uint64_t)ceil_log2_u64((uint64_t)nTargets);
+  const uint64_t nRadixSortOps = 9 * (nTargPerThread > 256 ? nTargPerThread : 256) + (uint64_t)maxCount * (logW > 1 ? logW : 1);   /* :426-427 */
+  const uint64_t nHeapifyOps = 3 * nTargPerThread + (uint64_t)maxCount * logT;                          /* :428 */
+  return nRadixSortOps < nHeapifyOps;                                                                   /* :431 */
+}
+
+int64_t orc_list_top_targets(const OrcKB *kb, const OrcQuiz *quiz, int64_t maxCount, int64_t nWorkers, OrcRatedTarget *dest) {
+  const int64_t T = kb->nTargets;
+  int64_t *bounds = (int64_t *)malloc((size_t)nWorkers * sizeof(int64_t));
+  int64_t *pieceLimits = (int64_t *)malloc((size_t)nWorkers * sizeof(int64_t));
+  HeapItem *headHeap = (HeapItem *)malloc((size_t)nWorkers * sizeof(HeapItem));
+  HeapItem *ratings = (HeapItem *)malloc((size_t)(T > 0 ? T : 1) * sizeof(HeapItem));
+  const int64_t nSub = orc_calc_split(T, nWorkers, bounds);                     /* CEListTopTargetsAlgorithm.cpp:46 */
+  for (int64_t s = 0; s < nSub; s++) {                                          /* CEHeapifyPriorsSubtaskMake::Run, one per piece */
+    const int64_t iFirst = s == 0 ? 0 : bounds[s - 1], iLimit = bounds[s];
+    int64_t iSelLim = iFirst;                                                   /* CEHeapifyPriorsSubtaskMake.cpp:31 */
+    for (int64_t t = iFirst; t < iLimit; t++) {                                 /* :66-83 (the unrolling changes no order) */
+      if (bit_test(kb->targetGaps, t)) continue;                                /* :43-45 */
+      const double prob = quiz->mants[t];                                       /* :46 */
+      if (prob <= 0) continue;                                                  /* :47-49 */
+      ratings[iSelLim].prob = prob;                                             /* :50-52 */
+      ratings[iSelLim].id = t;
+      iSelLim++;
+    }
+    pieceLimits[s] = iSelLim;                                                   /* :86 */
+    heap_make(ratings + iFirst, iSelLim - iFirst);                              /* :87 */
+  }
+  /* RecalcToStarts (SRPoolRunner.h:71-77): pStarts[i] = start of piece i */
+  int64_t nHh = 0;
+  for (int64_t i = 0; i < nSub; i++) {                                          /* CEListTopTargetsAlgorithm.cpp:58-66 */
+    const int64_t curFirst = i == 0 ? 0 : bounds[i - 1];
+    if (pieceLimits[i] == curFirst) continue;
+    headHeap[nHh].id = i;
+    headHeap[nHh].prob = ratings[curFirst].prob;
+    nHh++;
+  }
+  heap_make(headHeap, nHh);                                                     /* :67 */
+  int64_t listed = maxCount;
+  for (int64_t i = 0; i < maxCount; i++) {                                      /* :69-92 */
+    if (nHh == 0) { listed = i; break; }                                        /* :71-73 */
+    dest[i].prob = headHeap[0].prob;                                            /* :74 */
+    const int64_t curPiece = headHeap[0].id;
+    const int64_t pieceStart = curPiece == 0 ? 0 : bounds[curPiece - 1];
+    dest[i].iTarget = ratings[pieceStart].id;                                   /* :77 */
+    const int64_t pieceLim = pieceLimits[curPiece];
+    if (pieceStart + 1 == pieceLim) {                                           /* :81-88 the piece is exhausted */
+      heap_pop(headHeap, nHh);
+      nHh--;
+      continue;
+    }
+    heap_pop(ratings + pieceStart, pieceLim - pieceStart);                      /* :90 */
+    pieceLimits[curPiece]--;                                                    /* :91 */
+    headHeap[0].prob = ratings[pieceStart].prob;                                /* :93 */
+    heap_down(headHeap, nHh);                                                   /* :94 */
+  }
+  free(bounds); free(pieceLimits); free(headHeap); free(ratings);
+  return listed;                                                                /* :73 / :97 */
+}

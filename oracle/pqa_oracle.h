@@ -119,6 +119,18 @@ void orc_record_answer(const OrcKB *kb, OrcQuiz *quiz, int64_t iQuestion, int64_
 int orc_resume_quiz(const OrcKB *kb, OrcQuiz *quiz, int64_t nAnswered, const OrcAQ *aqs, int64_t nWorkers,
                     int bugCompat);
 
+/* ---- f2: ListTopTargets -- CEListTopTargetsAlgorithm::RunHeapifyBased (PqaCore/CEListTopTargetsAlgorithm.cpp:30-95) over the
+ * pieces of CEHeapifyPriorsSubtaskMake (PqaCore/CEHeapifyPriorsSubtaskMake.cpp:42-88): gaps and prob <= 0 dropped, descending;
+ * equal probabilities in the order the per-piece heaps and the head heap of an nWorkers-thread pool give.  Returns the number
+ * listed (<= maxCount).  orc_list_top_targets_takes_radix: 1 where the reference's cost model (PqaCore/CpuEngine.cpp:423-434)
+ * would take its radix-sort branch instead, which is not restated (pqa_oracle.c says why). */
+typedef struct { int64_t iTarget; double prob; } OrcRatedTarget;               /* RatedTarget, PqaCore/Interface/PqaCommon.h:54-61 */
+int64_t orc_list_top_targets(const OrcKB *kb, const OrcQuiz *quiz, int64_t maxCount, int64_t nWorkers, OrcRatedTarget *dest);
+int     orc_list_top_targets_takes_radix(int64_t nTargets, int64_t nWorkers, int64_t maxCount);
+/* the restated std::make_heap / std::pop_heap over (prob, id) records ordered by prob, for the test that holds them to libstdc++'s */
+void    orc_heap_make(double *prob, int64_t *id, int64_t n);
+void    orc_heap_pop(double *prob, int64_t *id, int64_t n);
+
 /* ---- AVX2 + pthreads restatement of a1 for the timed CPU baseline (pqa_oracle_avx2.c).  Bit-identical to
  * orc_eval_all (checked in tests).  nThreads worker threads, nSubtasks = 8*nThreads as PqaCore/CpuEngine.cpp:339. */
 void orc_eval_all_avx2_mt(const OrcKB *kb, const OrcQuiz *quiz, int64_t nThreads, int64_t nSubtasks,

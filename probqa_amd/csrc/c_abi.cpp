@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <unordered_map>
@@ -188,7 +189,11 @@ PQACORE_API void *PqaError_ToString(void *pvError, const uint8_t withParams) {
   return DupString(pErr->ToString(withParams != 0));
 }
 
-PQACORE_API void CiReleasePqaEngine(void *pvEngine) { delete static_cast<pqa::IEngine *>(pvEngine); }
+static void ReleaseEngineSideTables(void *pvEngine);   // (what c_abi.cpp keeps per engine handle: the RCCL exchange buffers)
+PQACORE_API void CiReleasePqaEngine(void *pvEngine) {
+  if (pvEngine) ReleaseEngineSideTables(pvEngine);
+  delete static_cast<pqa::IEngine *>(pvEngine);
+}
 
 PQACORE_API void *PqaEngine_Train(void *pvEngine, int64_t nQuestions, const CiAnsweredQuestion *const pAQs,
                                   const int64_t iTarget, const double amount) {
@@ -427,6 +432,11 @@ PQACORE_API void *PqaEngine_StartQuizBatch(void *pvEngine, const int64_t nQuizze
   ENGINE_OR_RETURN_ERROR;
   return ReturnErr(pEng->StartQuizBatch(nQuizzes, pQuizzes));
 }
+PQACORE_API void *PqaEngine_ListTopTargetsBatch(void *pvEngine, const int64_t nQuizzes, const int64_t *pQuizzes, const int64_t maxCount,
+                                                CiRatedTarget *pDest, int64_t *pCounts) {
+  ENGINE_OR_RETURN_ERROR;
+  return ReturnErr(pEng->ListTopTargetsBatch(nQuizzes, pQuizzes, maxCount, pDest, pCounts));
+}
 PQACORE_API void *PqaHip_SelectArgmaxBatch(void *pvEngine, const int64_t nQuizzes, const int64_t *pQuizzes, CiHipSelection *pOut) {
   ENGINE_OR_RETURN_ERROR;
   return ReturnErr(pEng->SelectArgmaxBatch(nQuizzes, pQuizzes, pOut));
@@ -532,9 +542,35 @@ PQACORE_API void *PqaHip_SelectThroughSlots(void *pvEngine, const int64_t iQuiz,
 // all-reduce" -- an all-gather of {priority, GLOBAL index} and the exact pick on every rank, so that ties break by the lowest
 // index as in the reference's argmax).  RCCL is looked up at the first call (dlopen: libPqaCore.so itself does not link it).
 namespace {
-struct RcclBufs { void *dSend = nullptr, *dRecv = nullptr, *hRecv = nullptr; int64_t world = 0; };
+// The exchange buffers of one engine: 16 (world + 1) bytes on the ENGINE's device and their pinned mirror.  They live as long as the
+// engine (ReleaseRcclBufs at CiReleasePqaEngine: an engine at a recycled address never meets an earlier engine's buffers), and `mu`
+// is held over enqueue, all-gather, copy and pick, so that concurrent calls on one engine do not share them mid-flight.
+struct RcclBufs {
+  std::mutex mu;
+  void *dSend = nullptr, *dRecv = nullptr, *hRecv = nullptr;
+  int64_t world = 0;
+  int device = -1;
+  void Free() {
+    if (dSend) { hipSetDevice(device); hipFree(dSend); }
+    if (hRecv) hipHostFree(hRecv);
+    dSend = dRecv = hRecv = nullptr;
+    world = 0;
+  }
+};
 std::mutex gRcclMu;
-std::unordered_map<void *, RcclBufs> gRcclBufs;
+std::unordered_map<void *, std::shared_ptr<RcclBufs>> gRcclBufs;
+void ReleaseRcclBufs(void *pvEngine) {
+  std::shared_ptr<RcclBufs> b;
+  {
+    std::lock_guard<std::mutex> lk(gRcclMu);
+    auto it = gRcclBufs.find(pvEngine);
+    if (it == gRcclBufs.end()) return;
+    b = std::move(it->second);
+    gRcclBufs.erase(it);
+  }
+  std::lock_guard<std::mutex> lk(b->mu);   // (a call still inside finishes first)
+  b->Free();
+}
 typedef int (*NcclAllGatherFn)(const void *, void *, size_t, int, void *, hipStream_t);
 NcclAllGatherFn RcclAllGather() {
   static NcclAllGatherFn fn = [] {
@@ -552,20 +588,28 @@ PQACORE_API void *PqaHip_SelectArgmaxRccl(void *pvEngine, const int64_t iQuiz, v
     return ReturnErr(Error::Make(ErrCode::NullArgument, "Bad arguments to PqaHip_SelectArgmaxRccl."));
   const NcclAllGatherFn allGather = RcclAllGather();
   if (allGather == nullptr) return ReturnErr(Error::Make(ErrCode::StdException, "librccl.so (ncclAllGather) could not be loaded."));
-  RcclBufs b;
+  std::shared_ptr<RcclBufs> bufs;
   {
     std::lock_guard<std::mutex> lk(gRcclMu);
-    RcclBufs &slot = gRcclBufs[pvEngine];
-    if (slot.world != world) {   // (first call, or another communicator size: the 16 (world + 1) device bytes and their pinned mirror)
-      if (slot.dSend) { hipFree(slot.dSend); hipHostFree(slot.hRecv); slot = RcclBufs{}; }
-      void *d = nullptr, *h = nullptr;
-      if (hipMalloc(&d, (size_t)(world + 1) * 16) != hipSuccess || hipHostMalloc(&h, (size_t)world * 16, hipHostMallocDefault) != hipSuccess) {
-        if (d) hipFree(d);
-        return ReturnErr(Error::Make(ErrCode::StdException, "PqaHip_SelectArgmaxRccl: no memory for the exchange buffers."));
-      }
-      slot.dSend = d; slot.dRecv = static_cast<char *>(d) + 16; slot.hRecv = h; slot.world = world;
+    std::shared_ptr<RcclBufs> &slot = gRcclBufs[pvEngine];
+    if (!slot) slot = std::make_shared<RcclBufs>();
+    bufs = slot;
+  }
+  RcclBufs &b = *bufs;
+  std::lock_guard<std::mutex> held(b.mu);
+  const int device = (int)pEng->GetOption("device");
+  if (device < 0 || pEng->GetOption("shards") > 0) return ReturnErr(Error::Make(ErrCode::StdException, "PqaHip_SelectArgmaxRccl is for an engine on ONE device (a shard of a process-per-GPU host)."));
+  if (hipSetDevice(device) != hipSuccess) return ReturnErr(Error::Make(ErrCode::StdException, "PqaHip_SelectArgmaxRccl: the engine's device cannot be selected."));
+  if (b.world != world || b.device != device) {   // (first call, or another communicator size: allocated on the engine's device, whatever the calling thread's was)
+    b.Free();
+    b.device = device;
+    void *d = nullptr, *h = nullptr;
+    if (hipMalloc(&d, (size_t)(world + 1) * 16) != hipSuccess || hipHostMalloc(&h, (size_t)world * 16, hipHostMallocDefault) != hipSuccess) {
+      if (d) hipFree(d);
+      (void)hipGetLastError();
+      return ReturnErr(Error::Make(ErrCode::StdException, "PqaHip_SelectArgmaxRccl: no memory for the exchange buffers."));
     }
-    b = slot;
+    b.dSend = d; b.dRecv = static_cast<char *>(d) + 16; b.hRecv = h; b.world = world;
   }
   Error e = pEng->EnqueueSelectArgmax(iQuiz, b.dSend);   // {priority, GLOBAL index} of this shard's winner, in stream order
   if (!e.ok()) return ReturnErr(std::move(e));
@@ -590,6 +634,7 @@ PQACORE_API void *PqaHip_SelectArgmaxRccl(void *pvEngine, const int64_t iQuiz, v
   *pIndex = bestI;
   return nullptr;
 }
+static void ReleaseEngineSideTables(void *pvEngine) { ReleaseRcclBufs(pvEngine); }
 PQACORE_API void *PqaHip_EnqueueSelectArgmax(void *pvEngine, const int64_t iQuiz, void *pOut) {
   ENGINE_OR_RETURN_ERROR;
   return ReturnErr(pEng->EnqueueSelectArgmax(iQuiz, pOut));

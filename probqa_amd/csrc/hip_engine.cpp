@@ -281,7 +281,8 @@ HipEngine::~HipEngine() {
   for (auto &g : _graphs) hipGraphExecDestroy(g.second.exec);
   hipFree(_dGraphScratch); hipFree(_dTagCell);
   for (QuizPinned *slab : _pinSlabs) hipHostFree(slab);
-  hipFree(_dTGap); hipFree(_dQGap); hipFree(_dAqs); hipFree(_dTop);
+  hipFree(_dTGap); hipFree(_dQGap); hipFree(_dAqs); hipFree(_dTopScratch[0]); hipFree(_dTopScratch[1]);
+  if (_hTopBatch) hipHostFree(_hTopBatch);
   if (_hPinned) hipHostFree(_hPinned);
   if (_hHostPriority) hipHostFree(_hHostPriority);
   if (_ownStream) hipStreamDestroy(_ownStream);
@@ -290,6 +291,7 @@ HipEngine::~HipEngine() {
 Error HipEngine::UploadGaps() {
   StopServer();  // its launch arguments hold the old view
   _kbVersion++;  // every change of the KB's shape or gaps passes through here: captured graphs hold the old view
+  for (Quiz *q : _quizzes) if (q) q->topOp = 0;   // ... and a listing made ahead of ListTopTargets names targets by the old gaps
   HIP_TRY(hipMemcpyAsync(_dTGap, _hTGap.data(), _hTGap.size() * sizeof(uint32_t), hipMemcpyHostToDevice, _stream));
   HIP_TRY(hipMemcpyAsync(_dQGap, _hQGap.data(), _hQGap.size() * sizeof(uint32_t), hipMemcpyHostToDevice, _stream));
   HIP_TRY(hipStreamSynchronize(_stream));

@@ -195,6 +195,7 @@ class IEngine {
   virtual Error RecordAnswerRemote(int64_t iQuiz, int64_t iAnswer) = 0;
   virtual Error RecordAnswerBatch(int64_t n, const int64_t *pQuizzes, const int64_t *pAnswers) = 0;
   virtual Error StartQuizBatch(int64_t n, int64_t *pQuizzes) = 0;
+  virtual Error ListTopTargetsBatch(int64_t n, const int64_t *pQuizzes, int64_t maxCount, CiRatedTarget *pDest, int64_t *pCounts) = 0;
 };
 
 class HipEngine : public IEngine {
@@ -259,6 +260,7 @@ class HipEngine : public IEngine {
   Error RecordAnswerRemote(int64_t iQuiz, int64_t iAnswer) override;
   Error RecordAnswerBatch(int64_t n, const int64_t *pQuizzes, const int64_t *pAnswers) override;
   Error StartQuizBatch(int64_t n, int64_t *pQuizzes) override;
+  Error ListTopTargetsBatch(int64_t n, const int64_t *pQuizzes, int64_t maxCount, CiRatedTarget *pDest, int64_t *pCounts) override;
 
   // ---- what a sharded engine needs from its shards (sharded_engine.cpp; implemented in hip_engine_shard.cpp)
   // An answer of a quiz as the sharded engine hands it to EVERY shard: the answered question in global numbering; for the shards
@@ -369,8 +371,14 @@ class HipEngine : public IEngine {
   uint32_t *_dTGap = nullptr, *_dQGap = nullptr;
   int64_t *_dExps = nullptr, *_dAqs = nullptr, *_dStatus = nullptr, *_dNOut = nullptr;
   int64_t _aqCapacity = 0;
-  RatedTargetDev *_dTop = nullptr;
-  int64_t _topCapacity = 0;
+  // ListTopTargets over rows of more than 16384 targets / for many quizzes at once (kb_kernels.hip: LaunchTopTargetsBatch): the two
+  // buffers of candidate lists on the device, and the host-coherent lines a batch's results arrive in (records, then the counts)
+  RatedTargetDev *_dTopScratch[2] = {nullptr, nullptr};
+  int64_t _topScratchRecords = 0;
+  RatedTargetDev *_hTopBatch = nullptr;
+  int64_t _hTopBatchRecords = 0;
+  Error EnsureTopScratch(int64_t nQuizzes, int64_t want);
+  int64_t ListTopTargetsOnHost(Error &err, Quiz *q, int64_t want, CiRatedTarget *pDest);
   // Released quizzes' device buffers, reused by the next StartQuiz / ResumeQuiz of the same dimensions: hipMalloc / hipFree
   // cost tens of microseconds and hipFree synchronises the device.  Reuse is ordered by the engine's stream.
   struct QuizBuffers { double *dPrior; uint32_t *dAsked; int64_t ldT; size_t askedWords; };

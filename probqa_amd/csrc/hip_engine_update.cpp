@@ -435,19 +435,114 @@ int64_t HipEngine::ListTopTargets(Error &err, int64_t iQuiz, int64_t maxCount, C
     std::memcpy(pDest, _hPinned->top, (size_t)n * sizeof(RatedTargetDev));
     return n;
   }
-  // large lists: sort on the host (the listing is O(T log T) on 8T bytes, not a cube operation)
+  if (want <= 256) {   // rows beyond one workgroup's registers: chunk lists and their merge (kb_kernels.hip), the engine's own lines
+    err = EnsureTopScratch(1, want);
+    if (!err.ok()) return -1;
+    TopBatchPriors pr;
+    pr.prior[0] = q->dPrior;
+    const uint64_t op = ++_opSeq;
+    const hipError_t he = LaunchTopTargetsBatch(View(), pr, 1, want, _dTopScratch[0], _dTopScratch[1], _hPinned->top, &_hPinned->nOut, &_hPinned->topFlag, op, _stream);
+    if (he != hipSuccess) { err = HipErr(he, "ListTopTargets"); return -1; }
+    err = WaitFlag(&_hPinned->topFlag, op, "ListTopTargets");
+    if (!err.ok()) return -1;
+    _mu.busy = false;   // (this call's own launches were the newest work on the stream)
+    _pendingRecordOp = 0;
+    const int64_t n = std::min<int64_t>(_hPinned->nOut, want);
+    std::memcpy(pDest, _hPinned->top, (size_t)n * sizeof(RatedTargetDev));
+    return n;
+  }
+  return ListTopTargetsOnHost(err, q, want, pDest);
+}
+
+// Lists of more than 256 targets: sort on the host (a listing of that length is the caller's bulk export, not a quiz step).
+int64_t HipEngine::ListTopTargetsOnHost(Error &err, Quiz *q, int64_t want, CiRatedTarget *pDest) {
   std::vector<double> pri((size_t)_T);
   hipError_t he = hipMemcpyAsync(pri.data(), q->dPrior, (size_t)_T * sizeof(double), hipMemcpyDeviceToHost, _stream);
   if (he == hipSuccess) he = hipStreamSynchronize(_stream);
   if (he != hipSuccess) { err = HipErr(he, "ListTopTargets"); return -1; }
+  _mu.busy = false;
+  _pendingRecordOp = 0;
   std::vector<int64_t> idx;
   idx.reserve((size_t)_T);
-  for (int64_t t = 0; t < _T; t++) if (!BitTest(_hTGap, t)) idx.push_back(t);
+  // gaps and probabilities <= 0 are no candidates (reference PqaCore/CEHeapifyPriorsSubtaskMake.cpp:43-49)
+  for (int64_t t = 0; t < _T; t++) if (!BitTest(_hTGap, t) && pri[(size_t)t] > 0.0) idx.push_back(t);
   const int64_t n = std::min<int64_t>(want, (int64_t)idx.size());
   std::partial_sort(idx.begin(), idx.begin() + n, idx.end(),
                     [&](int64_t a, int64_t b) { return pri[a] > pri[b] || (pri[a] == pri[b] && a < b); });
   for (int64_t i = 0; i < n; i++) { pDest[i]._iTarget = idx[i]; pDest[i]._prob = pri[idx[i]]; }
   return n;
+}
+
+// The device scratch of the chunked listing (two buffers of candidate lists) for nQuizzes quizzes at once.
+Error HipEngine::EnsureTopScratch(int64_t nQuizzes, int64_t want) {
+  const int64_t need = nQuizzes * TopBatchScratchRecords(_T, want);
+  if (need <= _topScratchRecords) return Error();
+  HIP_TRY(hipStreamSynchronize(_stream));   // (nothing in flight reads the buffers about to go)
+  for (int i = 0; i < 2; i++) { if (_dTopScratch[i]) hipFree(_dTopScratch[i]); _dTopScratch[i] = nullptr; }
+  _topScratchRecords = 0;
+  for (int i = 0; i < 2; i++) HIP_TRY(hipMalloc((void **)&_dTopScratch[i], (size_t)need * sizeof(RatedTargetDev)));
+  _topScratchRecords = need;
+  return Error();
+}
+
+// ListTopTargets for n quizzes with one launch sequence per 256 of them: pDest[i * maxCount + j], j < pCounts[i], is quiz
+// pQuizzes[i]'s listing -- record for record what PqaEngine_ListTopTargets(pQuizzes[i], maxCount) returns.  What comes back from the
+// device is n x maxCount records; no posterior is copied (the reference's GPU engine: all T of them per quiz,
+// PqaCore/CudaEngine.cpp:251-289).
+Error HipEngine::ListTopTargetsBatch(int64_t n, const int64_t *pQuizzes, int64_t maxCount, CiRatedTarget *pDest, int64_t *pCounts) {
+  if (n < 0) return Error::MakeP(ErrCode::NegativeCount, "count=" + std::to_string(n), "|nQuizzes| must be non-negative.");
+  if (maxCount < 0) return Error::MakeP(ErrCode::NegativeCount, "count=" + std::to_string(maxCount), "|maxCount| must be non-negative.");
+  if (n > 0 && (!pQuizzes || !pCounts || (maxCount > 0 && !pDest))) return Error::Make(ErrCode::NullArgument, "Nullptr is passed in place of a batch buffer.");
+  CallScope scope(_activeCallers);
+  std::lock_guard<EngineMutex> lk(_mu);
+  Error err = CheckRegular("list top targets");
+  if (!err.ok()) return err;
+  std::vector<Quiz *> quizzes((size_t)n);
+  for (int64_t i = 0; i < n; i++) {
+    quizzes[(size_t)i] = UseQuiz(err, pQuizzes[i]);
+    if (!quizzes[(size_t)i]) return err;
+  }
+  for (int64_t i = 0; i < n; i++) pCounts[i] = 0;
+  if (n == 0 || maxCount == 0) return Error();
+  hipSetDevice(_device);
+  err = FlushUpdates();
+  if (!err.ok()) return err;
+  const int64_t want = std::min<int64_t>(maxCount, _T);
+  if (want > 256) {
+    for (int64_t i = 0; i < n; i++) {
+      pCounts[i] = ListTopTargetsOnHost(err, quizzes[(size_t)i], want, pDest + i * maxCount);
+      if (pCounts[i] < 0) { pCounts[i] = 0; return err; }
+    }
+    return Error();
+  }
+  const int64_t group = std::min<int64_t>(n, kTopBatchQuizzes);
+  err = EnsureTopScratch(group, want);
+  if (!err.ok()) return err;
+  // the results' lines: host-coherent, written by the last level's workgroups
+  const int64_t needRecords = group * want;
+  if (needRecords > _hTopBatchRecords) {
+    HIP_TRY(hipStreamSynchronize(_stream));
+    if (_hTopBatch) hipHostFree(_hTopBatch);
+    _hTopBatch = nullptr; _hTopBatchRecords = 0;
+    HIP_TRY(hipHostMalloc((void **)&_hTopBatch, (size_t)needRecords * sizeof(RatedTargetDev) + (size_t)kTopBatchQuizzes * sizeof(int64_t), hipHostMallocDefault));
+    _hTopBatchRecords = needRecords;
+  }
+  int64_t *hCounts = reinterpret_cast<int64_t *>(_hTopBatch + _hTopBatchRecords);
+  for (int64_t first = 0; first < n; first += group) {
+    const int64_t m = std::min<int64_t>(group, n - first);
+    TopBatchPriors pr;
+    for (int64_t i = 0; i < m; i++) pr.prior[i] = quizzes[(size_t)(first + i)]->dPrior;
+    HIP_TRY(LaunchTopTargetsBatch(View(), pr, m, want, _dTopScratch[0], _dTopScratch[1], _hTopBatch, hCounts, nullptr, 0, _stream));
+    HIP_TRY(hipStreamSynchronize(_stream));
+    for (int64_t i = 0; i < m; i++) {
+      const int64_t c = std::min<int64_t>(hCounts[i], want);
+      pCounts[first + i] = c;
+      std::memcpy(pDest + (first + i) * maxCount, _hTopBatch + i * want, (size_t)c * sizeof(RatedTargetDev));
+    }
+  }
+  _mu.busy = false;   // (the stream has just been synchronised)
+  _pendingRecordOp = 0;
+  return Error();
 }
 
 // ------------------------------------------------------------------------------------------------------------------

@@ -305,13 +305,124 @@ hipError_t LaunchTrainBatchInline(void *cube, int elem, double *vB, int64_t K, i
 
 hipError_t LaunchTopTargets(const KbView &kb, const double *prior, int64_t maxCount, RatedTargetDev *out,
                             int64_t *nOut, uint64_t *flag, uint64_t flagValue, hipStream_t stream) {
-  if (kb.T > 16384) return hipErrorInvalidValue;  // the host-side listing takes over (hip_engine_update.cpp)
+  if (kb.T > 16384) return hipErrorInvalidValue;  // LaunchTopTargetsBatch takes over (hip_engine_update.cpp)
   if (kb.smallLaunches && kb.T <= 1024)   // beside the resident sweep (prior_kernels.hip: kSmallThreads)
     hipLaunchKernelGGL(top_targets_kernel<true>, dim3(1), dim3(256), 0, stream, prior, kb.tgap, kb.T, maxCount, out, nOut, flag,
                        flagValue);
   else
     hipLaunchKernelGGL(top_targets_kernel<false>, dim3(1), dim3(1024), 0, stream, prior, kb.tgap, kb.T, maxCount, out, nOut, flag,
                        flagValue);
+  return hipGetLastError();
+}
+
+// ---- ListTopTargets over rows of any length, for many quizzes at once ----------------------------------------------------
+// Level 0: every WAVE holds 1024 targets of a quiz's posterior in registers (16 per lane) and lists ITS best maxCount by itself -- no
+// LDS, no barrier: a round is two wave all-reduces, and the lane that held the winner looks at its 16 again.  The best maxCount of the
+// whole row under the order (probability descending, target ascending) are among the waves' bests under the same order.  Then merges
+// of up to 16384 / maxCount candidate lists per workgroup until one list per quiz is left; the last level writes the caller's records
+// and counts.  What crosses to the host is nQuizzes x maxCount records -- the reference's GPU engine copies all T posteriors per quiz
+// and heapifies on the host (PqaCore/CudaEngine.cpp:251-289).
+namespace {
+constexpr int kTopChunkThreads = 256, kTopWaveTargets = 16 * kWave;
+static_assert(kTopChunkThreads / kWave * kTopWaveTargets == kTopChunkTargets, "four waves of 1024 targets per workgroup");
+
+__global__ __launch_bounds__(kTopChunkThreads) void top_chunks_kernel(TopBatchPriors priors, const uint32_t *__restrict__ tgap, int64_t T,
+                                                                      int64_t maxCount, TopOut *lists) {
+  const int lane = threadIdx.x % kWave, wave = threadIdx.x / kWave;
+  const int64_t quiz = blockIdx.y, nLists = (int64_t)gridDim.x * (kTopChunkThreads / kWave);
+  const int64_t list = (int64_t)blockIdx.x * (kTopChunkThreads / kWave) + wave;
+  const int64_t tFirst = list * kTopWaveTargets;
+  const double *prior = priors.prior[quiz];
+  double p[16];
+  int t[16];
+#pragma unroll
+  for (int e = 0; e < 16; e++) {
+    const int64_t tt = tFirst + lane + e * kWave;
+    const bool ok = tt < T && !bit_test(tgap, tt);
+    p[e] = ok ? prior[tt] : -1.0;
+    if (!(p[e] > 0.0)) p[e] = -1.0;       // gaps and probabilities <= 0 are no candidates (pqa_device.h)
+    t[e] = (int)tt;
+  }
+  TopOut *mine = lists + (quiz * nLists + list) * maxCount;
+  const int64_t listed = top_rounds_wave<16>(p, t, maxCount, mine);
+  for (int64_t i = listed + lane; i < maxCount; i += kWave) mine[i] = TopOut{-1, -1.0};   // the rest of the list says "no candidate"
+}
+
+__device__ __forceinline__ void top_scratch_init(TopScratch *scratch) {
+  if (threadIdx.x < 32) {   // waves that do not exist never win a round
+    scratch->sp[threadIdx.x >> 4][threadIdx.x & 15] = -1.0;
+    scratch->st[threadIdx.x >> 4][threadIdx.x & 15] = kTopNone;
+  }
+  __syncthreads();
+}
+template <int E>
+__device__ __forceinline__ int64_t top_merge_rounds(const TopOut *cand, int64_t n, int64_t maxCount, TopScratch *scratch) {
+  double p[E];
+  int t[E];
+#pragma unroll
+  for (int e = 0; e < E; e++) {
+    const int64_t i = threadIdx.x + (int64_t)e * blockDim.x;
+    const TopOut c = i < n ? cand[i] : TopOut{-1, -1.0};
+    p[e] = c.prob > 0.0 ? c.prob : -1.0;
+    t[e] = (int)c.iTarget;
+  }
+  return top_rounds<E>(p, t, maxCount, scratch->staged, scratch->sp, scratch->st);
+}
+// workgroup (group, quiz): lists [group * fanIn, ...) of the quiz's nLists lists of maxCount records -> list `group` of the next level
+// (256 threads for up to 4096 candidates, 1024 beyond: a round costs every wave its all-reduces, whatever it holds).  The winners are
+// staged in LDS and leave in one burst: the last level's list goes to host-coherent memory, where a store per round would cost more
+// than the round.
+__global__ __launch_bounds__(1024) void top_merge_kernel(const TopOut *__restrict__ lists, int64_t nLists, int64_t fanIn, int64_t maxCount,
+                                                         TopOut *outLists, int64_t *nOut, uint64_t *flag, uint64_t flagValue) {
+  __shared__ TopScratch scratch;
+  top_scratch_init(&scratch);
+  const int64_t group = blockIdx.x, quiz = blockIdx.y;
+  const int64_t first = group * fanIn, limit = first + fanIn < nLists ? first + fanIn : nLists;
+  const TopOut *cand = lists + (quiz * nLists + first) * maxCount;
+  const int64_t n = (limit - first) * maxCount;
+  int64_t listed;
+  if (n <= blockDim.x) listed = top_merge_rounds<1>(cand, n, maxCount, &scratch);
+  else if (n <= 4 * (int64_t)blockDim.x) listed = top_merge_rounds<4>(cand, n, maxCount, &scratch);
+  else listed = top_merge_rounds<16>(cand, n, maxCount, &scratch);
+  __syncthreads();
+  TopOut *list = outLists + (quiz * gridDim.x + group) * maxCount;
+  for (int64_t i = threadIdx.x; i < maxCount; i += blockDim.x) list[i] = i < listed ? scratch.staged[i] : TopOut{-1, -1.0};
+  if (nOut != nullptr || flag != nullptr) {   // (the last level)
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      if (nOut != nullptr) nOut[quiz] = listed;
+      if (flag != nullptr) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+        __hip_atomic_store(flag, flagValue, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
+  }
+}
+}  // namespace
+
+static int64_t TopBatchLists(int64_t T) { return (T <= 0 ? 1 : (T + kTopChunkTargets - 1) / kTopChunkTargets) * (kTopChunkThreads / kWave); }
+static int64_t TopFanIn(int64_t maxCount) { const int64_t f = kTopMergeCapacity / maxCount; return f < 2 ? 2 : f; }
+// records per quiz each of the two scratch buffers must hold
+int64_t TopBatchScratchRecords(int64_t T, int64_t maxCount) { return TopBatchLists(T) * maxCount; }
+hipError_t LaunchTopTargetsBatch(const KbView &kb, const TopBatchPriors &priors, int64_t nQuizzes, int64_t maxCount, RatedTargetDev *scratchA,
+                                 RatedTargetDev *scratchB, RatedTargetDev *out, int64_t *nOut, uint64_t *flag, uint64_t flagValue,
+                                 hipStream_t stream) {
+  if (nQuizzes <= 0 || nQuizzes > kTopBatchQuizzes || maxCount <= 0 || maxCount > 256 || (flag != nullptr && nQuizzes != 1)) return hipErrorInvalidValue;
+  int64_t nLists = TopBatchLists(kb.T);
+  hipLaunchKernelGGL(top_chunks_kernel, dim3((unsigned)(nLists / (kTopChunkThreads / kWave)), (unsigned)nQuizzes), dim3(kTopChunkThreads), 0, stream, priors,
+                     kb.tgap, kb.T, maxCount, reinterpret_cast<TopOut *>(scratchA));
+  const int64_t fanIn = TopFanIn(maxCount);
+  RatedTargetDev *src = scratchA, *dst = scratchB;
+  for (;;) {
+    const int64_t nGroups = (nLists + fanIn - 1) / fanIn;
+    const bool last = nGroups == 1;
+    const int threads = (nLists < fanIn ? nLists : fanIn) * maxCount <= 4096 ? 256 : 1024;
+    hipLaunchKernelGGL(top_merge_kernel, dim3((unsigned)nGroups, (unsigned)nQuizzes), dim3(threads), 0, stream, reinterpret_cast<const TopOut *>(src), nLists,
+                       fanIn, maxCount, reinterpret_cast<TopOut *>(last ? out : dst), last ? nOut : nullptr, last ? flag : nullptr, flagValue);
+    if (last) break;
+    nLists = nGroups;
+    RatedTargetDev *t = src; src = dst; dst = t;
+  }
   return hipGetLastError();
 }
 

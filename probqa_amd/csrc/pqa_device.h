@@ -468,7 +468,10 @@ __device__ __forceinline__ SampledPick select_sampled_wg_lds(const double *prior
 __host__ __device__ constexpr int64_t select_sampled_lds_doubles(int64_t n, int64_t nWorkers) { return n + nWorkers + n / 64 + 2; }
 
 // ---- top-maxCount targets by probability -------------------------------------------------------------------------------
-// Descending probability, lower index first on ties, gaps never listed (reference PqaCore/CEListTopTargetsAlgorithm.cpp).
+// Descending probability, lower index first on ties, gaps and probabilities <= 0 never listed (reference
+// PqaCore/CEListTopTargetsAlgorithm.cpp:30-95 over CEHeapifyPriorsSubtaskMake.cpp:42-52).  Ties: the reference lists equal
+// probabilities in the order its per-thread heaps leave them -- a function of the machine's thread count --; here they come by
+// ascending target index.
 // For a workgroup of up to 1024 threads: every thread holds its E targets (t = tid + e*blockDim) in registers; a round is one wave
 // argmax by DPP / permlane swaps, one LDS exchange and ONE barrier (the per-wave results alternate between two LDS rows by
 // round parity), one 16-lane row argmax over the 16 waves' results, after which every thread knows the round's winner and
@@ -482,21 +485,27 @@ struct TopOut {
 // first version carried {probability, index} pairs through one butterfly with a four-way comparison per step -- ten
 // steps of ~25 dependent instructions, 2.7 us per listed target, three quarters of RecordAnswer's kernel.
 // Listed: valid targets by descending probability, lower index first on ties; retired and invalid ones hold -1.
+// (v_max_f64 as written: the compiler's fmax quiets signalling NaNs first -- a second v_max_f64 per operand; no NaN reaches these)
+__device__ __forceinline__ double max_raw(double a, double b) {
+  double r;
+  asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
 __device__ __forceinline__ double wave_max(double v) {
-  v = __builtin_fmax(v, mov_dpp<kDppXor1>(v));
-  v = __builtin_fmax(v, mov_dpp<kDppXor2>(v));
-  v = __builtin_fmax(v, mov_dpp<kDppHalfMirror>(v));
-  v = __builtin_fmax(v, mov_dpp<kDppMirror>(v));
+  v = max_raw(v, mov_dpp<kDppXor1>(v));
+  v = max_raw(v, mov_dpp<kDppXor2>(v));
+  v = max_raw(v, mov_dpp<kDppHalfMirror>(v));
+  v = max_raw(v, mov_dpp<kDppMirror>(v));
   Pair p = swap16(v);
-  v = __builtin_fmax(p.a, p.b);
+  v = max_raw(p.a, p.b);
   p = swap32(v);
-  return __builtin_fmax(p.a, p.b);
+  return max_raw(p.a, p.b);
 }
 __device__ __forceinline__ double row_max(double v) {   // over the 16 lanes of a row
-  v = __builtin_fmax(v, mov_dpp<kDppXor1>(v));
-  v = __builtin_fmax(v, mov_dpp<kDppXor2>(v));
-  v = __builtin_fmax(v, mov_dpp<kDppHalfMirror>(v));
-  return __builtin_fmax(v, mov_dpp<kDppMirror>(v));
+  v = max_raw(v, mov_dpp<kDppXor1>(v));
+  v = max_raw(v, mov_dpp<kDppXor2>(v));
+  v = max_raw(v, mov_dpp<kDppHalfMirror>(v));
+  return max_raw(v, mov_dpp<kDppMirror>(v));
 }
 template <int CTRL>
 __device__ __forceinline__ int min_dpp(int v) {
@@ -517,48 +526,93 @@ __device__ __forceinline__ int wave_min(int v) {
   return (int)t[0] < (int)t[1] ? (int)t[0] : (int)t[1];
 }
 constexpr int kTopNone = 0x7FFFFFFF;
+// The lane's own best candidate: the highest probability it holds, the lowest target among equals.  A lane's targets ascend with e
+// wherever its probabilities tie (t = base + tid + e * blockDim over a posterior; position in a sequence of lists that are each
+// ascending among equals and cover ascending target ranges), so the first e that holds the maximum is the one.
 template <int E>
-__device__ __forceinline__ int64_t top_targets_rounds(const double *prior, const uint32_t *tgap, int64_t T, int64_t maxCount,
-                                                      TopOut *out, double (*sp)[16], int (*st)[16]) {
-  double p[E];
-  int t[E];
+__device__ __forceinline__ void lane_best(const double (&p)[E], const int (&t)[E], double &bp, int &bt) {
+  bp = p[0];
 #pragma unroll
-  for (int e = 0; e < E; e++) {
-    const int64_t tt = threadIdx.x + (int64_t)e * blockDim.x;
-    const bool ok = tt < T && !bit_test(tgap, tt);
-    p[e] = ok ? prior[tt] : -1.0;
-    if (!(p[e] >= 0.0)) p[e] = -1.0;       // (a NaN is never listed)
-    t[e] = (int)tt;
-  }
+  for (int e = 1; e < E; e++) bp = max_raw(bp, p[e]);
+  bt = t[E - 1];
+#pragma unroll
+  for (int e = E - 2; e >= 0; e--) bt = p[e] == bp ? t[e] : bt;
+}
+// The rounds over what the threads of a WORKGROUP hold: p[e] > 0 for a candidate (anything else, -1, is never listed), t[e] its target.
+// Every lane carries its own best from round to round; a round is the all-reduce of those, and only the lane that held the winner --
+// one lane of one wave -- looks at its E candidates again.
+template <int E>
+__device__ __forceinline__ int64_t top_rounds(double (&p)[E], int (&t)[E], int64_t maxCount, TopOut *out, double (*sp)[16], int (*st)[16]) {
   const int lane = threadIdx.x % kWave, wave = threadIdx.x / kWave;
   int64_t listed = 0;
+  double bp;
+  int bt;
+  lane_best<E>(p, t, bp, bt);
   for (int64_t r = 0; r < maxCount; r++) {
-    double bp = p[0];
-#pragma unroll
-    for (int e = 1; e < E; e++) bp = __builtin_fmax(bp, p[e]);
     const double wm = wave_max(bp);
-    int bt = kTopNone;
-#pragma unroll
-    for (int e = 0; e < E; e++) bt = (p[e] == wm && t[e] < bt) ? t[e] : bt;
-    bt = wave_min(bt);
+    const int wt = wave_min(bp == wm ? bt : kTopNone);
     const int par = (int)(r & 1);
     if (lane == 0) {
       sp[par][wave] = wm;
-      st[par][wave] = bt;
+      st[par][wave] = wt;
     }
     __syncthreads();
     const double mp = sp[par][lane % 16];     // up to 16 waves -> one 16-lane row (absent waves hold -1)
     const int mt = st[par][lane % 16];
     const double gm = row_max(mp);
-    if (!(gm >= 0.0)) break;                  // nothing left; the same for every thread
+    if (!(gm > 0.0)) break;                   // nothing left; the same for every thread
     const int gt = row_min(mp == gm ? mt : kTopNone);
-    if (threadIdx.x == 0) out[r] = TopOut{gt, gm};   // `out`: LDS staging (top_targets_publish)
+    if (threadIdx.x == 0) out[r] = TopOut{gt, gm};   // `out`: LDS staging (top_targets_publish, the batched listing's kernels)
+    if (bt == gt) {                           // (targets are unique: this lane held the winner)
 #pragma unroll
-    for (int e = 0; e < E; e++)
-      if (t[e] == gt) p[e] = -1.0;
+      for (int e = 0; e < E; e++)
+        if (t[e] == gt) p[e] = -1.0;
+      lane_best<E>(p, t, bp, bt);
+    }
     listed++;
   }
   return listed;
+}
+// The same for ONE WAVE by itself (no LDS, no barrier): its lanes' candidates only; every lane learns every round's winner.
+template <int E>
+__device__ __forceinline__ int64_t top_rounds_wave(double (&p)[E], int (&t)[E], int64_t maxCount, TopOut *out) {
+  const int lane = threadIdx.x % kWave;
+  int64_t listed = 0;
+  double bp;
+  int bt;
+  lane_best<E>(p, t, bp, bt);
+  for (int64_t r = 0; r < maxCount; r++) {
+    const double gm = wave_max(bp);
+    if (!(gm > 0.0)) break;
+    const int gt = wave_min(bp == gm ? bt : kTopNone);
+    if (lane == 0) out[r] = TopOut{gt, gm};
+    if (bt == gt) {
+#pragma unroll
+      for (int e = 0; e < E; e++)
+        if (t[e] == gt) p[e] = -1.0;
+      lane_best<E>(p, t, bp, bt);
+    }
+    listed++;
+  }
+  return listed;
+}
+// A target is listed if it is no gap and its probability is > 0: the reference drops `prob <= 0` (PqaCore/CEHeapifyPriorsSubtaskMake.cpp:43-49,
+// PqaCore/CERadixSortRatingsSubtaskSort.cpp:78-84) -- a posterior element that underflowed to exactly 0, or that NormalizePriors flushed
+// (PqaCore/CENormPriorsSubtaskCorrSum.cpp:32-36), is no candidate.  (A NaN is never listed here.)
+template <int E>
+__device__ __forceinline__ int64_t top_targets_rounds(const double *prior, const uint32_t *tgap, int64_t tFirst, int64_t tLimit, int64_t maxCount,
+                                                      TopOut *out, double (*sp)[16], int (*st)[16]) {
+  double p[E];
+  int t[E];
+#pragma unroll
+  for (int e = 0; e < E; e++) {
+    const int64_t tt = tFirst + threadIdx.x + (int64_t)e * blockDim.x;
+    const bool ok = tt < tLimit && !bit_test(tgap, tt);
+    p[e] = ok ? prior[tt] : -1.0;
+    if (!(p[e] > 0.0)) p[e] = -1.0;
+    t[e] = (int)tt;
+  }
+  return top_rounds<E>(p, t, maxCount, out, sp, st);
 }
 // the list, its length and then a flag, into host-coherent memory (T <= 16384, maxCount <= 256).  The winners are staged
 // in LDS and leave in one coalesced burst at the end: a store to host memory per round costs more than the round.
@@ -585,9 +639,9 @@ __device__ __forceinline__ void top_targets_publish(const double *prior, const u
   __syncthreads();
   const int64_t perThread = (T + blockDim.x - 1) / blockDim.x;
   int64_t listed;
-  if (perThread <= 1) listed = top_targets_rounds<1>(prior, tgap, T, maxCount, staged, sp, st);
-  else if (SMALL || perThread <= 4) listed = top_targets_rounds<4>(prior, tgap, T, maxCount, staged, sp, st);
-  else listed = top_targets_rounds<16>(prior, tgap, T, maxCount, staged, sp, st);
+  if (perThread <= 1) listed = top_targets_rounds<1>(prior, tgap, 0, T, maxCount, staged, sp, st);
+  else if (SMALL || perThread <= 4) listed = top_targets_rounds<4>(prior, tgap, 0, T, maxCount, staged, sp, st);
+  else listed = top_targets_rounds<16>(prior, tgap, 0, T, maxCount, staged, sp, st);
   __syncthreads();
   if ((int64_t)threadIdx.x < listed) out[threadIdx.x] = staged[threadIdx.x];
   __syncthreads();

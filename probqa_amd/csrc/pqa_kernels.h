@@ -392,5 +392,15 @@ hipError_t LaunchMoveTargets(void *cube, int elem, double *vB, int64_t K, int64_
 // (flag != nullptr: out / nOut / flag are host-coherent; the kernel stores flagValue to *flag after its results)
 hipError_t LaunchTopTargets(const KbView &kb, const double *prior, int64_t maxCount, RatedTargetDev *out,
                             int64_t *nOut, uint64_t *flag, uint64_t flagValue, hipStream_t stream);
+// ... over rows of any length and for up to kTopBatchQuizzes quizzes per launch (maxCount <= 256): a list per wave of 1024 targets,
+// then merges; out[quiz][maxCount] records (unused ones {-1, -1}) and nOut[quiz], device or host-coherent; `flag` only with ONE quiz.
+// The two scratch buffers hold nQuizzes * TopBatchScratchRecords(T, maxCount) records each.
+constexpr int kTopBatchQuizzes = 256;
+constexpr int64_t kTopChunkTargets = 4096, kTopMergeCapacity = 16384;
+struct TopBatchPriors { const double *prior[kTopBatchQuizzes]; };
+int64_t TopBatchScratchRecords(int64_t T, int64_t maxCount);
+hipError_t LaunchTopTargetsBatch(const KbView &kb, const TopBatchPriors &priors, int64_t nQuizzes, int64_t maxCount, RatedTargetDev *scratchA,
+                                 RatedTargetDev *scratchB, RatedTargetDev *out, int64_t *nOut, uint64_t *flag, uint64_t flagValue,
+                                 hipStream_t stream);
 
 }  // namespace pqa

@@ -225,6 +225,12 @@ class ShardedEngine final : public IEngine {
     for (int64_t i = 0; i < n; i++) { Error e = RecordAnswerDeferred(pQuizzes[i], pAnswers[i]); if (!e.ok()) return e; }
     return FlushNow();
   }
+  Error ListTopTargetsBatch(int64_t n, const int64_t *pQuizzes, int64_t maxCount, CiRatedTarget *pDest, int64_t *pCounts) override {
+    // every shard holds every quiz's whole posterior: the gathered answers reach the shards, then one of them lists
+    Error e = FlushNow();
+    if (!e.ok()) return e;
+    return _sh[0]->ListTopTargetsBatch(n, pQuizzes, maxCount, pDest, pCounts);
+  }
   Error StartQuizBatch(int64_t n, int64_t *pQuizzes) override {
     if (n > 0 && !pQuizzes) return Error::Make(ErrCode::NullArgument, "Nullptr is passed in place of a batch buffer.");
     for (int64_t i = 0; i < n; i++) {

@@ -147,6 +147,7 @@ HIP_EXPORTS = {
     "PqaHip_RecordAnswerRemote": (_vp, [_vp, _i64, _i64]),
     "PqaEngine_RecordAnswerBatch": (_vp, [_vp, _i64, _pi64, _pi64]),
     "PqaEngine_StartQuizBatch": (_vp, [_vp, _i64, _pi64]),
+    "PqaEngine_ListTopTargetsBatch": (_vp, [_vp, _i64, _pi64, _i64, ctypes.POINTER(CiRatedTarget), _pi64]),
     "PqaHip_HostLogicProbe": (_i64, [ctypes.c_char_p, _pi64, _i64, _pi64, _i64]),
 }
 
@@ -681,6 +682,15 @@ class PqaEngine:
         out = (ctypes.c_int64 * max(n, 1))()
         _check(_lib.PqaEngine_StartQuizBatch(self.c_engine, n, out))
         return list(out[:n])
+
+    def list_top_targets_batch(self, quizzes, max_count: int) -> List[List[RatedTarget]]:
+        """ListTopTargets of several quizzes with one launch sequence; no posterior leaves the device."""
+        n = len(quizzes)
+        qs = (ctypes.c_int64 * max(n, 1))(*quizzes)
+        counts = (ctypes.c_int64 * max(n, 1))()
+        arr = (CiRatedTarget * max(n * max_count, 1))()
+        _check(_lib.PqaEngine_ListTopTargetsBatch(self.c_engine, n, qs, max_count, arr, counts))
+        return [[RatedTarget(arr[i * max_count + j].iTarget, arr[i * max_count + j].prob) for j in range(counts[i])] for i in range(n)]
 
     def record_answer_remote(self, i_quiz: int, i_answer: int):
         _check(_lib.PqaHip_RecordAnswerRemote(self.c_engine, i_quiz, i_answer))

@@ -29,6 +29,10 @@ class OrcAQ(ctypes.Structure):
     _fields_ = [("iQuestion", ctypes.c_int64), ("iAnswer", ctypes.c_int64)]
 
 
+class OrcRatedTarget(ctypes.Structure):
+    _fields_ = [("iTarget", ctypes.c_int64), ("prob", ctypes.c_double)]
+
+
 class OrcKahan4(ctypes.Structure):
     _fields_ = [("sum", ctypes.c_double * 4), ("corr", ctypes.c_double * 4)]
 
@@ -77,6 +81,10 @@ def lib() -> ctypes.CDLL:
         "orc_resume_quiz": (ctypes.c_int, [pKB, pQz, i64, ctypes.POINTER(OrcAQ), i64, ctypes.c_int]),
         "orc_eval_all_avx2_mt": (None, [pKB, pQz, i64, i64, pd, pd]),
         "orc_have_avx2": (ctypes.c_int, []),
+        "orc_list_top_targets": (i64, [pKB, pQz, i64, i64, ctypes.POINTER(OrcRatedTarget)]),
+        "orc_list_top_targets_takes_radix": (ctypes.c_int, [i64, i64, i64]),
+        "orc_heap_make": (None, [pd, ctypes.POINTER(i64), i64]),
+        "orc_heap_pop": (None, [pd, ctypes.POINTER(i64), i64]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)
@@ -173,6 +181,12 @@ class Oracle:
 
     def select_argmax(self, pri: np.ndarray) -> int:
         return self.L.orc_select_argmax(self.kb, self.quiz, _dp(pri))
+
+    def list_top_targets(self, max_count: int, n_workers: int = 16):
+        """CpuEngine::ListTopTargetsSpec's heapify branch for a pool of n_workers threads: [(target, prob)], descending."""
+        dest = (OrcRatedTarget * max(max_count, 1))()
+        n = self.L.orc_list_top_targets(self.kb, self.quiz, max_count, n_workers, dest)
+        return [(dest[i].iTarget, dest[i].prob) for i in range(n)]
 
     def find_nearest(self, q: int) -> int:
         return self.L.orc_find_nearest_question(self.kb, self.quiz, q)

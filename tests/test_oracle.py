@@ -361,3 +361,143 @@ def test_independent_restatement(name):
         assert not bad, (name, step, bad[:5], [(mine[q], want[q]) for q in bad[:3]])
         if step < len(case.answers):
             asked.append(case.answers[step][0])
+
+
+# ---- f2: ListTopTargets (PqaCore/CEListTopTargetsAlgorithm.cpp:30-95, CEHeapifyPriorsSubtaskMake.cpp:42-88) ------------
+@pytest.fixture(scope="module")
+def std_heap(tmp_path_factory):
+    """libstdc++'s std::make_heap / std::pop_heap behind a C ABI (tests/std_heap_check.cpp, compiled here)."""
+    import subprocess
+
+    so = tmp_path_factory.mktemp("stdheap") / "libstdheap.so"
+    subprocess.check_call(["g++", "-O1", "-shared", "-fPIC", "-o", str(so), os.path.join(os.path.dirname(__file__), "std_heap_check.cpp")])
+    L = ctypes.CDLL(str(so))
+    for name in ("std_heap_make", "std_heap_pop"):
+        getattr(L, name).restype = None
+        getattr(L, name).argtypes = [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64), ctypes.c_int64]
+    return L
+
+
+def _heap_call(fn, prob, ids):
+    p, i = np.array(prob, dtype=np.float64), np.array(ids, dtype=np.int64)
+    fn(p.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), i.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)), len(p))
+    return p, i
+
+
+def test_restated_heap_steps_equal_libstdcxx(oracle_lib, std_heap):
+    """The oracle's make_heap / pop_heap move every record exactly as the C++ library's do, ties included (few distinct values)."""
+    rng = np.random.default_rng(11)
+    for n in list(range(0, 40)) + [63, 64, 65, 127, 128, 1000, 6250]:
+        for distinct in (1, 2, 3, 7, 10**9):
+            prob = rng.integers(1, distinct + 1, size=n).astype(np.float64) / 8.0
+            ids = np.arange(n, dtype=np.int64)
+            mine = _heap_call(oracle_lib.orc_heap_make, prob, ids)
+            std = _heap_call(std_heap.std_heap_make, prob, ids)
+            assert np.array_equal(mine[0], std[0]) and np.array_equal(mine[1], std[1]), (n, distinct)
+            p, i = mine
+            for m in range(n, max(n - 12, 0), -1):           # a dozen pops of the heap just made
+                a = _heap_call(oracle_lib.orc_heap_pop, p[:m], i[:m])
+                b = _heap_call(std_heap.std_heap_pop, p[:m], i[:m])
+                assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]), (n, distinct, m)
+                p[:m], i[:m] = a
+
+
+def _listing_by_definition(orc, max_count, n_workers, std_heap):
+    """RunHeapifyBased restated a second time, in Python over libstdc++'s heap calls (not over the oracle's)."""
+    T = orc.T
+    gaps = np.unpackbits(np.ctypeslib.as_array(orc.kb.contents.targetGaps, shape=((orc.ldT + 7) // 8,)), bitorder="little")
+    bounds = (ctypes.c_int64 * n_workers)()
+    n_sub = orc.L.orc_calc_split(T, n_workers, bounds)
+    pieces = []
+    for s in range(n_sub):
+        first, limit = (0 if s == 0 else bounds[s - 1]), bounds[s]
+        sel = [(orc.mants[t], t) for t in range(first, limit) if not gaps[t] and not (orc.mants[t] <= 0)]
+        p, i = _heap_call(std_heap.std_heap_make, [x[0] for x in sel], [x[1] for x in sel])
+        pieces.append([list(p), list(i)])
+    head = [(pieces[s][0][0], s) for s in range(n_sub) if pieces[s][0]]
+    hp, hs = _heap_call(std_heap.std_heap_make, [h[0] for h in head], [h[1] for h in head])
+    hp, hs = list(hp), list(hs)
+    out = []
+    for _ in range(max_count):
+        if not hp:
+            break
+        s = int(hs[0])
+        p, i = pieces[s]
+        out.append((int(i[0]), hp[0]))
+        if len(p) == 1:
+            a, b = _heap_call(std_heap.std_heap_pop, hp, hs)
+            hp, hs = list(a[:-1]), list(b[:-1])
+            continue
+        a, b = _heap_call(std_heap.std_heap_pop, p, i)
+        pieces[s] = [list(a[:-1]), list(b[:-1])]
+        hp[0] = pieces[s][0][0]
+        cur = 0                                              # SRHeapHelper::Down, SRPlatform/Interface/SRHeap.h:16-39
+        while True:
+            c1 = 2 * cur + 1
+            if c1 >= len(hp):
+                break
+            c2 = c1 + 1
+            if c2 >= len(hp):
+                if hp[cur] < hp[c1]:
+                    hp[cur], hp[c1], hs[cur], hs[c1] = hp[c1], hp[cur], hs[c1], hs[cur]
+                break
+            hi = c1 if hp[c2] < hp[c1] else c2
+            if not (hp[cur] < hp[hi]):
+                break
+            hp[cur], hp[hi], hs[cur], hs[hi] = hp[hi], hp[cur], hs[hi], hs[cur]
+            cur = hi
+    return out
+
+
+def test_list_top_targets_drops_gaps_and_nonpositive_and_orders_descending(std_heap):
+    K, Q, T = 3, 4, 203
+    orc = orclib.Oracle(K, Q, T, 1.0)
+    rng = np.random.default_rng(5)
+    orc.set_target_gaps([0, 17, 202])
+    orc.start_quiz(16)
+    orc.mants[:T] = rng.random(T)
+    orc.mants[[5, 6, 100]] = 0.0              # exact zeros: never listed (CEHeapifyPriorsSubtaskMake.cpp:47)
+    orc.mants[7] = -0.25                      # (cannot arise; the filter is `prob <= 0`)
+    live = [t for t in range(T) if t not in (0, 17, 202, 5, 6, 100, 7)]
+    want = sorted(live, key=lambda t: -orc.mants[t])
+    for n_workers in (1, 2, 7, 16, 64, 300):
+        for mc in (1, 3, 10, len(live), T + 5):
+            got = orc.list_top_targets(mc, n_workers)
+            assert [t for t, _ in got] == want[:mc], (n_workers, mc)             # distinct values: the order is the sort's
+            assert [p for _, p in got] == [orc.mants[t] for t in want[:mc]]
+            assert got == _listing_by_definition(orc, mc, n_workers, std_heap)
+    # nothing positive: an empty listing
+    orc.mants[:T] = 0.0
+    assert orc.list_top_targets(10, 16) == []
+    orc.close()
+
+
+def test_list_top_targets_tie_order_is_the_heaps(std_heap):
+    """Equal probabilities come out in the order the piece heaps and the head heap give: a function of the pool size, not of
+    the target index -- the second restatement (over libstdc++'s heap calls) agrees record for record."""
+    K, Q, T = 2, 3, 157
+    orc = orclib.Oracle(K, Q, T, 0.5)
+    orc.set_target_gaps([3, 80])
+    orc.start_quiz(16)                        # a fresh KB: every live target holds the same probability
+    orders = {}
+    for n_workers in (1, 4, 16):
+        got = orc.list_top_targets(12, n_workers)
+        assert len(got) == 12 and len({p for _, p in got}) == 1 and len({t for t, _ in got}) == 12
+        assert got == _listing_by_definition(orc, 12, n_workers, std_heap)
+        orders[n_workers] = [t for t, _ in got]
+    assert orders[1] != orders[16] and orders[1] != sorted(orders[1])           # neither index order nor pool-independent
+    rng = np.random.default_rng(9)            # a few distinct values, many ties each
+    orc.mants[:T] = rng.integers(0, 5, size=T) / 16.0
+    for n_workers in (1, 3, 16, 40):
+        for mc in (1, 5, 40, 200):
+            got = orc.list_top_targets(mc, n_workers)
+            assert got == _listing_by_definition(orc, mc, n_workers, std_heap), (n_workers, mc)
+            assert [p for _, p in got] == sorted((p for _, p in got), reverse=True) and all(p > 0 for _, p in got)
+    orc.close()
+
+
+def test_list_top_targets_cost_model_switch(oracle_lib):
+    """CpuEngine.cpp:423-434: the radix branch only for lists of hundreds (never for the quiz loop's 1..10)."""
+    f = oracle_lib.orc_list_top_targets_takes_radix
+    assert not f(1000, 16, 10) and not f(1000, 16, 300) and f(1000, 16, 400)
+    assert not f(100000, 16, 10) and not f(100000, 16, 256) and f(100000, 16, 3000)
