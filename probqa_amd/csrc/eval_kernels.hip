@@ -49,7 +49,7 @@ struct EvalArgs {
   FusedSelect fs;
   const QuizSlot *slots;  // batched launch: per-quiz pointers, indexed by blockIdx.y (nullptr: a single quiz)
   int maxGrid;            // host side only: KbView::maxGrid
-  int poleNoFollow;       // host side only: KbView::poleNoFollow
+  int poleNoFollow;       // KbView::poleNoFollow (measurement hook): the register-form sweep watches but lists and defers nothing, and no fix is launched behind it
   // eval_questions_f64_upd only: the answer whose posterior update runs in the sweep's prologue (sweep_body, FUSE)
   const double *updRowA, *updRowD;   // sA[q][a][.], mD[q][.] of the answered question
   int64_t updQuestion;               // its index (local): asked from this sweep on
@@ -705,6 +705,7 @@ __device__ __forceinline__ void sweep_body(EvalArgs a, bool copyTable) {
       }
       if constexpr (kListWatch) {
         if (wideRows != 0) { __syncthreads(); suspect = (susWords[qpar] & 0xFFFFu) != 0; }   // (the bits the other waves' lanes have just set)
+        if constexpr (!SERVER) { if (a.poleNoFollow) suspect = false; }   // (measurement hook: the watch runs, nothing is listed or deferred -- no fix follows)
       }
       if (tid == 0) {
         reinterpret_cast<int64_t *>(rec)[2 * K + 2] = q;
@@ -754,6 +755,7 @@ __device__ __forceinline__ void sweep_body(EvalArgs a, bool copyTable) {
           rec[K + r] = acc;
         }
         if constexpr (kListWatch) { if (wideRows != 0) suspect = (susWords[qpar] & 0xFFFFu) != 0; }   // (this wave's own atomics: in order)
+        if constexpr (kListWatch && !SERVER) { if (a.poleNoFollow) suspect = false; }   // (measurement hook, as above)
         if (lane == 0) {
           reinterpret_cast<int64_t *>(rec)[2 * K + 2] = q;
           if constexpr (kListWatch) susWords[qpar ^ 1] = 0;

@@ -324,10 +324,10 @@ Error HipEngine::SetOption(const char *name, int64_t value) {
   if (n == "select") { if (value != 0 && value != 1) goto bad; _optSelect = value; }
   else if (n == "combine") { _optCombine = value ? 1 : 0; }
   else if (n == "combine_spin") { _optCombineSpin = value ? 1 : 0; }
-  else if (n == "pole_fix") { StopServer(); _optPoleFix = value ? 1 : 0; _kbVersion++; }   // 0: questions with a row at the pole of the lack term keep the sweep's own sums (pole_kernels.hip)
+  else if (n == "pole_fix") { StopServer(); (void)SettlePoleList(); _optPoleFix = value ? 1 : 0; _kbVersion++; }   // (settled while the list is still in view)   // 0: questions with a row at the pole of the lack term keep the sweep's own sums (pole_kernels.hip)
   else if (n == "late_eager") { if (value < 0 || value > 1000000) goto bad; _optLateEager = value; }
-  else if (n == "pole_lazy") { _optPoleLazy = value ? 1 : 0; }
-  else if (n == "pole_follow") { _optPoleFollow = value ? 1 : 0; }   // measurement hook: 0 = the watching sweeps without the fix launched behind them (KbView::poleNoFollow)
+  else if (n == "pole_lazy") { StopServer(); (void)SettlePoleList(); _optPoleLazy = value ? 1 : 0; }
+  else if (n == "pole_follow") { StopServer(); (void)SettlePoleList(); _optPoleFollow = value ? 1 : 0; }   // measurement hook: 0 = the watching sweeps without the fix launched behind them (KbView::poleNoFollow)
   else if (n == "long_row_form") { _optLongRowForm = value ? 1 : 0; }   // 0: the one-workgroup posterior kernels for rows beyond 16384 targets too
   else if (n == "fuse_update") { _optFuseUpdate = value ? 1 : 0; }   // RecordAnswer's posterior update inside the speculative sweep's launch
   else if (n == "post_always") { _optPostAlways = value ? 1 : 0; }   // test hook: RecordAnswer / ListTopTargets always as posted operations
@@ -769,8 +769,9 @@ Error HipEngine::Shutdown(const char *saveFilePath) {
 
 Error HipEngine::SetStream(hipStream_t s) {
   std::lock_guard<EngineMutex> lk(_mu);
-  StopServer();
+  StopServer();   // (drops a speculative sweep ...)
   hipSetDevice(_device);
+  { Error se = SettlePoleList(); if (!se.ok()) return se; }   // (... whose listed rows are emptied on the stream that wrote them, before it is left)
   HIP_TRY(hipStreamSynchronize(_stream));
   _stream = s ? s : _ownStream;
   return Error();

@@ -208,7 +208,10 @@ Error HipEngine::EnqueueSelectArgmaxFlag(int64_t iQuiz, void *pOut, void *pFlag,
   if (!q) return err;
   if (!pOut || !pFlag) return Error::Make(ErrCode::NullArgument, "Nullptr is passed in place of the record or the flag.");
   hipSetDevice(_device);
-  if (_optServer && ServerUsable()) return ServerPost(q, (SelectResult *)pOut, (uint64_t *)pFlag, flagValue, _qFirst | (int64_t)kServerNoWatch);   // (the record goes to another process: no -4 there)
+  // The resident sweep cannot hand a quiz over to the fix of pole_kernels.hip here -- its record goes to another process, where a "-4,
+  // take the launched path" means nothing -- so while that fix is on (the default) this selection is always launched, with the fix
+  // behind it: a late quiz state gets the reference-order sums on the sharded path as on the single-engine one.
+  if (_optServer && !_optPoleFix && ServerUsable()) return ServerPost(q, (SelectResult *)pOut, (uint64_t *)pFlag, flagValue, _qFirst | (int64_t)kServerNoWatch);
   const FusedSelect fs{_dSelScratch, (SelectResult *)pOut, (uint64_t *)pFlag, NextLaunchTag(), _qFirst, 0, flagValue, nullptr, 0, 0, nullptr, nullptr};
   StopServer();   // a launched sweep has no room beside the resident one and would wait for it to idle out
   return LaunchSingleSweep(q, &fs);
@@ -306,7 +309,7 @@ Error HipEngine::RunLazyFix(Quiz *q, const FusedSelect &swept, const char *what)
   HIP_TRY(LaunchEvalPoleFixup(View(), q->dPrior, q->dAsked, _dPriority, fs, _stream));
   Error err = WaitFlag(fs.seq, fs.flagValue, what);
   std::atomic_thread_fence(std::memory_order_acquire);
-  _poleListPending = false;   // (the fix-up has emptied the list)
+  if (err.ok()) _poleListPending = false;   // (the fix-up has emptied the list)
   return err;
 }
 
@@ -347,17 +350,20 @@ int64_t HipEngine::NextQuestionArgmaxLocked(Error &err, int64_t iQuiz) {
     StopServer();   // a launched sweep has no room beside the resident one and would wait for it to idle out
     err = LaunchSingleSweep(q, &fs);
     if (!err.ok()) return -1;
+    if (fs.lazyFix) _poleListPending = true;   // (whatever it lists stays listed until the fix has run or the sweep has said "nothing": a wait that fails leaves it for SettlePoleList)
   }
   err = WaitFlag(&_hPinned->seq, seq, "NextQuestionArgmax");
   if (!err.ok()) return -1;
   std::atomic_thread_fence(std::memory_order_acquire);
   if (fs.lazyFix) {
     if (_hPinned->sel.index == -4) {   // the sweep listed rows at the pole of the lack term: the fix now, and its answer
-      err = RunLazyFix(q, fs, "NextQuestionArgmax");
+      err = RunLazyFix(q, fs, "NextQuestionArgmax");   // (clears the mark once the fix has emptied the list)
       if (!err.ok()) return -1;
       q->lateStreak++;
-    } else q->lateStreak = 0;
-    _poleListPending = false;
+    } else {
+      q->lateStreak = 0;
+      if (_hPinned->sel.index != -3) _poleListPending = false;   // (a complete sweep that listed nothing)
+    }
   }
   if (_hPinned->sel.index == -3) {  // the sweep's finisher gave up: some workgroup of the launch never reported
     err = HipErr(hipErrorLaunchFailure, "NextQuestionArgmax (incomplete sweep)");
@@ -750,6 +756,7 @@ int64_t HipEngine::NextQuestionSampledLocked(Error &err, int64_t iQuiz, uint64_t
       fs = FusedSelect{_dSelScratch, &_hPinned->sel, &_hPinned->seq, seq, 0, 0, seq, nullptr, 1, 0, nullptr, _hHostPriority, LazyFix() && q->lateStreak < _optLateEager ? 1 : 0};   // (a quiz whose last selections all needed the fix: launched behind the sweep again)
       const hipError_t he = LaunchEvalQuestions(kb, q->dPrior, q->dAsked, 0, _Q, _dPriority, (int)_optEvalVariant, &fs, _stream);
       if (he != hipSuccess) { err = HipErr(he, "NextQuestionSampled"); return -1; }
+      if (fs.lazyFix) _poleListPending = true;   // (as NextQuestionArgmaxLocked)
     }
     err = WaitFlag(&_hPinned->seq, seq, "NextQuestionSampled");
     if (!err.ok()) return -1;
@@ -758,8 +765,10 @@ int64_t HipEngine::NextQuestionSampledLocked(Error &err, int64_t iQuiz, uint64_t
         err = RunLazyFix(q, fs, "NextQuestionSampled");
         if (!err.ok()) return -1;
         q->lateStreak++;
-      } else q->lateStreak = 0;
-      _poleListPending = false;
+      } else {
+        q->lateStreak = 0;
+        if (_hPinned->sel.index != -3) _poleListPending = false;
+      }
     }
     if (_hPinned->sel.index == -3) { err = HipErr(hipErrorLaunchFailure, "NextQuestionSampled (incomplete sweep)"); return -1; }
     err = CollectHostPriority(seq, q);

@@ -190,6 +190,44 @@ def test_lazy_and_eager_fix_agree(i, factory):
     assert picks[0] == picks[1], (case.name, picks)
 
 
+@pytest.mark.parametrize("i", [5, 6, 12, 17])
+def test_measurement_hook_without_the_fix_is_harmless(i, factory):
+    """Option pole_follow = 0 (bench.py times the watching sweep by itself with it): in a late state the sweep then lists nothing and
+    defers nothing -- a fused selection answers at once with the sweep's own sums instead of waiting for a fix that never comes --,
+    however often it runs; back at 1 the next selection is the reference-order one again."""
+    import time
+
+    leg, case, options = late_case(i)
+    assert leg in ("short", "overflow", "reg", "forced"), leg
+    eng, orc = case.make_engine(factory), case.make_oracle()
+    for n, v in options:
+        eng.set_option(n, v)
+    quiz = eng.start_quiz()
+    orc.start_quiz(cases.WORKERS)
+    for q, a in case.answers:
+        eng.set_active_question(quiz, q)
+        eng.record_answer(quiz, a)
+        orc.record_answer(q, a, cases.WORKERS - 1)
+    _, opri = orc.eval(8 * cases.WORKERS)
+    for lazy in (1, 0):
+        eng.set_option("pole_lazy", lazy)
+        eng.set_option("pole_follow", 0)
+        t0 = time.perf_counter()
+        for _ in range(300):                     # (more sweeps than the list has entries: nothing accumulates)
+            eng.enqueue_eval(quiz)
+        picks = {eng.next_question_argmax(quiz) for _ in range(20)}
+        eng.synchronize()
+        assert time.perf_counter() - t0 < 10.0 and len(picks) == 1
+        eng.set_option("pole_follow", 1)
+        pri = eng.eval_priorities(quiz)
+        live = opri != 0
+        assert cases.rel_err(pri[live], opri[live]).max() < 1e-9
+        top = np.sort(opri)[::-1]
+        if top[0] > 0 and (top[0] - top[1]) / top[0] > 1e-8:
+            assert eng.next_question_argmax(quiz) == orc.select_argmax(opri)
+    eng.close()
+
+
 def test_late_soak(factory, late):
     """--late N further cases; prints the worst step per leg."""
     n, first = late
