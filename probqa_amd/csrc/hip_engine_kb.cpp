@@ -260,25 +260,82 @@ Error HipEngine::ClearOldQuizzes(int64_t maxCount, double maxAgeSec) {  // behav
 // host staging buffer.  The same code serves a whole-cube engine and every shard of a sharded one (the file orders its rows
 // by question, so the shards' blocks follow each other).
 // ------------------------------------------------------------------------------------------------------------------
+// Two pinned staging buffers in turn: the file's read of one batch runs while the other batch's rows are on their way to the
+// device (and a save's write while the next batch comes back), so a large knowledge base moves at the slower of the two rates, not
+// at their sum (reference: PqaCore/BaseEngine.cpp:323-385 writes row by row; PqaCore/CudaPersistence.cpp:15-43 stages through one
+// pageable buffer).  The mD rows of a batch are ONE strided copy (a row per question, (K + 1) ldT elements apart); a question's K sA
+// rows are one.
 Error HipEngine::IoRows(FILE *f, const char *filePath, bool mD, bool write) {   // sA rows [q][a] of T elements, or mD rows [q]
   hipSetDevice(_device);
   const size_t rowB = (size_t)_T * (size_t)_elem, ldB = (size_t)_ldT * (size_t)_elem;
   const int64_t rowsPerQ = mD ? 1 : _K;
   const int64_t batch = std::max<int64_t>(1, (int64_t)((64u << 20) / (rowB * (size_t)rowsPerQ)));
-  std::vector<char> host((size_t)std::min(batch, _Q) * (size_t)rowsPerQ * rowB);
+  const size_t bufBytes = (size_t)std::min(batch, _Q) * (size_t)rowsPerQ * rowB;
+  struct Staging {
+    char *buf[2] = {nullptr, nullptr};
+    hipEvent_t done[2] = {nullptr, nullptr};
+    bool pinned = false;
+    std::vector<char> pageable[2];
+    ~Staging() {
+      for (int i = 0; i < 2; i++) {
+        if (pinned && buf[i]) hipHostFree(buf[i]);
+        if (done[i]) hipEventDestroy(done[i]);
+      }
+    }
+  } st;
+  const int nBuf = _Q > batch ? 2 : 1;
+  st.pinned = true;
+  for (int i = 0; i < nBuf && st.pinned; i++)
+    if (hipHostMalloc((void **)&st.buf[i], bufBytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); st.pinned = false; }
+  if (!st.pinned) {   // (no pinned memory to be had: pageable staging, the copies then synchronise by themselves)
+    for (int i = 0; i < 2; i++) { if (st.buf[i]) hipHostFree(st.buf[i]); st.buf[i] = nullptr; }
+    for (int i = 0; i < nBuf; i++) { st.pageable[i].resize(bufBytes); st.buf[i] = st.pageable[i].data(); }
+  }
+  for (int i = 0; i < nBuf; i++) HIP_TRY(hipEventCreateWithFlags(&st.done[i], hipEventDisableTiming));
   const char *what = mD ? "the target dimension of _mD weights." : "the target dimension of _sA weights.";
-  for (int64_t q0 = 0; q0 < _Q; q0 += batch) {
+  auto copyBatch = [&](char *host, int64_t q0, int64_t nq) -> hipError_t {
+    if (mD) {   // one row per question, (K + 1) ldT elements apart
+      return write ? hipMemcpy2DAsync(host, rowB, CubeAt(q0, _K), ldB * (size_t)(_K + 1), rowB, (size_t)nq, hipMemcpyDeviceToHost, _stream)
+                   : hipMemcpy2DAsync(CubeAt(q0, _K), ldB * (size_t)(_K + 1), host, rowB, rowB, (size_t)nq, hipMemcpyHostToDevice, _stream);
+    }
+    for (int64_t q = 0; q < nq; q++) {
+      char *h = host + (size_t)q * (size_t)rowsPerQ * rowB;
+      char *d = CubeAt(q0 + q, 0);
+      const hipError_t he = write ? hipMemcpy2DAsync(h, rowB, d, ldB, rowB, (size_t)rowsPerQ, hipMemcpyDeviceToHost, _stream)
+                                  : hipMemcpy2DAsync(d, ldB, h, rowB, rowB, (size_t)rowsPerQ, hipMemcpyHostToDevice, _stream);
+      if (he != hipSuccess) return he;
+    }
+    return hipSuccess;
+  };
+  int64_t prevQ0 = -1, prevNq = 0;   // a save: the batch whose rows are on their way into the other buffer
+  int turn = 0;
+  for (int64_t q0 = 0; q0 < _Q; q0 += batch, turn ^= (nBuf - 1)) {
     const int64_t nq = std::min(batch, _Q - q0);
     const size_t nRows = (size_t)(nq * rowsPerQ);
-    if (!write && std::fread(host.data(), rowB, nRows, f) != nRows) return FileErr(filePath, (std::string("Can't read ") + what).c_str());
-    for (int64_t q = 0; q < nq; q++) {
-      char *h = host.data() + (size_t)q * (size_t)rowsPerQ * rowB;
-      char *d = CubeAt(q0 + q, mD ? _K : 0);
-      if (write) HIP_TRY(hipMemcpy2DAsync(h, rowB, d, ldB, rowB, (size_t)rowsPerQ, hipMemcpyDeviceToHost, _stream));
-      else HIP_TRY(hipMemcpy2DAsync(d, ldB, h, rowB, rowB, (size_t)rowsPerQ, hipMemcpyHostToDevice, _stream));
+    char *host = st.buf[turn];
+    HIP_TRY(hipEventSynchronize(st.done[turn]));   // (whatever used this buffer two batches ago has finished; a fresh event is complete)
+    if (!write) {
+      if (std::fread(host, rowB, nRows, f) != nRows) { (void)hipStreamSynchronize(_stream); return FileErr(filePath, (std::string("Can't read ") + what).c_str()); }
+      HIP_TRY(copyBatch(host, q0, nq));
+      HIP_TRY(hipEventRecord(st.done[turn], _stream));
+    } else {
+      HIP_TRY(copyBatch(host, q0, nq));
+      HIP_TRY(hipEventRecord(st.done[turn], _stream));
+      if (prevQ0 >= 0) {   // while this batch comes back, the previous one goes to the file
+        const int other = turn ^ (nBuf - 1);
+        HIP_TRY(hipEventSynchronize(st.done[other]));
+        if (std::fwrite(st.buf[other], rowB, (size_t)(prevNq * rowsPerQ), f) != (size_t)(prevNq * rowsPerQ)) { (void)hipStreamSynchronize(_stream); return FileErr(filePath, (std::string("Can't write ") + what).c_str()); }
+      }
+      if (nBuf == 1) {   // (a single batch: written right away)
+        HIP_TRY(hipEventSynchronize(st.done[turn]));
+        if (std::fwrite(host, rowB, nRows, f) != nRows) return FileErr(filePath, (std::string("Can't write ") + what).c_str());
+      } else { prevQ0 = q0; prevNq = nq; }
     }
-    HIP_TRY(hipStreamSynchronize(_stream));
-    if (write && std::fwrite(host.data(), rowB, nRows, f) != nRows) return FileErr(filePath, (std::string("Can't write ") + what).c_str());
+  }
+  HIP_TRY(hipStreamSynchronize(_stream));
+  if (write && nBuf == 2 && prevQ0 >= 0) {   // the last batch of a save
+    const int last = turn ^ 1;
+    if (std::fwrite(st.buf[last], rowB, (size_t)(prevNq * rowsPerQ), f) != (size_t)(prevNq * rowsPerQ)) return FileErr(filePath, (std::string("Can't write ") + what).c_str());
   }
   return Error();
 }
