@@ -78,7 +78,8 @@ PQACORE_API void *PqaEngineFactory_CreateHipEngineSharded(void *pvFactory, void 
  * selections of a quiz in a row that needed the fix, RecordAnswer's speculative sweep has it launched right behind it again: it runs
  * while the client is elsewhere; default 3 -- long quizzes in late states +4 %, the learner loop unchanged), "pole_follow" (measurement hook: 0 = the watching sweep WITHOUT the launch behind it, for timing the sweep
  * kernel by itself in a quiz state that lists nothing; default 1),
- * "cluster_form" (the single-quiz sweep over rows beyond 16384 targets: 0 = default, 1 = question by question, 2 = pass 1 a question
+ * "cluster_from" (rows of more than this many elements -- 1024..16384, default 10240: what the register shapes hold without spilling -- take the
+ * cluster sweep, a question over a cluster of workgroups), "cluster_form" (that sweep: 0 = default, 1 = question by question, 2 = pass 1 a question
  * ahead of the exchange), "cluster_shape" (threads x 16-byte units per thread of the form that runs ahead: 0 = default, 1 = 512 x 1, 2 = 256 x 2;
  * two workgroups per CU both),
  * Read-only: "server_last_step_ns" (device-side duration of the newest finished step of the resident sweep: request in hand

@@ -1281,7 +1281,7 @@ int device_cus() {
 
 // Rows longer than the register shapes take (ldT > 16384), up to 16 answers, two workgroups per CU resident.
 bool EvalClusterSupported(const KbView &kb) {
-  if (kb.ldT <= 16384) return false;
+  if (kb.ldT <= kb.clusterFrom) return false;
   ClusterShape s;
   return kb.elem == 4 ? cluster_shape<float>(kb, device_cus(), &s) : cluster_shape<double>(kb, device_cus(), &s);
 }

@@ -308,6 +308,7 @@ KbView HipEngine::View() const {
   v.maxGrid = (int)_optEvalMaxGrid;
   v.clusterForm = (int)_optClusterForm;
   v.clusterShape = (int)_optClusterShape;
+  v.clusterFrom = ClusterFrom();
   v.poleScratch = _optPoleFix ? _dPoleScratch : nullptr;
   v.poleNoFollow = _optPoleFollow ? 0 : 1;
   v.poleList = _optPoleFix ? reinterpret_cast<PoleHeader *>(_dPoleScratch + (size_t)_capQ * (size_t)(2 * _K + 2)) : nullptr;
@@ -350,6 +351,7 @@ Error HipEngine::SetOption(const char *name, int64_t value) {
   else if (n == "batch_tile") { if (value < 0 || value > 8192) goto bad; _optBatchTile = value; }
   else if (n == "cluster_shape") { if (value < 0 || value > 2) goto bad; _optClusterShape = value; }
   else if (n == "cluster_form") { if (value < 0 || value > 2) goto bad; _optClusterForm = value; }
+  else if (n == "cluster_from") { if (value < 1024 || value > 16384) goto bad; StopServer(); _optClusterFrom = value; }   // rows longer than this take the cluster sweep
   else if (n == "batch_tail") { _optBatchTail = value ? 1 : 0; }
   else if (n == "batch_groups") { if (value < 0 || value > 8) goto bad; _optBatchGroups = value; }
   else if (n == "server_vram_mailbox") { if (_serverStream) goto bad; _optServerVramMailbox = value ? 1 : 0; }
@@ -415,6 +417,7 @@ int64_t HipEngine::GetOption(const char *name) const {
   if (n == "batch_groups") return _optBatchGroups;
   if (n == "batch_tail") return _optBatchTail;
   if (n == "cluster_form") return _optClusterForm;
+  if (n == "cluster_from") return _optClusterFrom;
   if (n == "cluster_shape") return _optClusterShape;
   if (n == "batch_qb") return _optBatchQb;
   if (n == "precision") return _precType;

@@ -657,6 +657,11 @@ class HipEngine : public IEngine {
   int64_t _optBatchQb = 0;        // questions per block of that sweep (0 = default)
   int64_t _optBatchTile = 0;      // targets per LDS tile of that sweep (0 = default)
   int64_t _optClusterShape = 0;   // ... the shape of the form that runs ahead (cluster_kernels.hip: kAheadVariants), 0 = default
+  // Rows longer than this many elements take the cluster sweep (option cluster_from, 1024..16384).  10240: what the register shapes hold
+  // without spilling -- the 16-wave shapes behind them (128 registers a lane) ran 10500^2 at 2552 us against the cluster's 1597, 12000^2
+  // at 3004 against 1974, 16000^2 at 4230 against 3430 (round 6, one box); they stay selectable (eval_variant 6, 7, 11).
+  int64_t _optClusterFrom = 10240;
+  int64_t ClusterFrom() const { return _elem == 8 ? _optClusterFrom : 16384; }   // (Float engines: their register shapes hold 16384 elements; not re-measured)
   int64_t _optClusterForm = 0;    // long rows, one quiz (cluster_kernels.hip): 0 = default, 1 = question by question, 2 = pass 1 a question ahead
   int64_t _optBatchTail = 1;      // that sweep's last, partial round as a launch of its own with fewer questions per group (LaunchEvalBatch)
   int64_t _optBatchGroups = 0;    // question groups per workgroup of that sweep for batches under 129 quizzes (0 = automatic)

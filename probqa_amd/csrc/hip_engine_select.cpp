@@ -149,7 +149,7 @@ Error HipEngine::EnqueueEval(int64_t iQuiz) {
 // The single-quiz sweep of this engine's precision on the engine's stream: the register-resident fp64 shapes with the fused
 // argmax (eval_kernels.hip) for Double engines; for Float engines the fp32 streaming sweep and, where a selection is asked
 // for, the argmax kernel behind it (batch_kernels.hip, select_kernels.hip).
-bool HipEngine::UseClusterSweep() const { return _optEvalVariant == 0 && _ldT > 16384 && EvalClusterSupported(View()); }
+bool HipEngine::UseClusterSweep() const { return _optEvalVariant == 0 && _ldT > ClusterFrom() && EvalClusterSupported(View()); }
 
 Error HipEngine::LaunchSingleSweep(Quiz *q, const FusedSelect *fused) {
   { Error se = SettlePoleList(); if (!se.ok()) return se; }

@@ -59,6 +59,7 @@ struct KbView {
                           // every workgroup stream dozens of questions; 0 = no cap
   int clusterForm;        // long rows (cluster_kernels.hip): 0 = default, 1 = question by question, 2 = pass 1 a question ahead (option cluster_form)
   int clusterShape;       // ... the shape of the form that runs ahead: 0 = default, 1 = 512 threads x 1 unit, 2 = 256 x 2 (option cluster_shape)
+  int64_t clusterFrom;    // rows LONGER than this many elements take the cluster sweep (engine option cluster_from)
   double *poleScratch;    // Q x (2 K + 2) doubles (device): the sums of questions with a row at the pole of the lack term, between the
                           // sweep and the fix launched behind it (pole_kernels.hip); may be null (then such questions keep the sweep's own sums)
   struct PoleHeader *poleList;   // ... and the list of those questions: PoleListBytes(Q) bytes, zeroed once (every launch leaves it empty)

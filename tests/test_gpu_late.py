@@ -40,7 +40,7 @@ class LateCase(cases.Case):
 # (leg, row lengths, engine options)
 REG_DEFAULT = [4608, 5120, 6144, 7168, 8192, 9216, 10000, 10240, 16384, 12000]
 REG_FORCED = [(8000, 5), (10000, 6), (5000, 9), (10000, 11), (10000, 12), (5000, 21), (3000, 22), (4000, 23), (4500, 24), (5000, 20),
-              (900, 1), (1000, 8), (2000, 3), (4096, 4)]
+              (900, 1), (1000, 8), (2000, 3), (4096, 4), (16384, 7), (12000, 7)]   # (7: the 16-wave shape, selectable; rows beyond 10240 targets take the cluster sweep by default)
 LEGS = ["reg", "reg", "forced", "stream", "cluster", "overflow", "short", "mid", "rowshare", "gridy", "server", "reg"]
 
 

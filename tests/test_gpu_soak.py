@@ -1,4 +1,4 @@
-"""The two soaks that found every late offender of rounds 3 and 4, as seeded tests: 200 cases and ten concurrency rounds in every run of the suite, as
+"""The two soaks that found every late offender of rounds 3 and 4, as seeded tests: 200 cases and fifty concurrency rounds in every run of the suite, as
 many more as asked for with `pytest -m gpu tests/test_gpu_soak.py --soak N [--soak-first SEED]` (round 4: --soak 13700 is clean,
 390 s on one MI355X).  tools/fuzz_more.py and tools/concurrency_soak.py are the same loops from the command line."""
 import random
@@ -75,5 +75,5 @@ def test_fuzz_soak(factory, soak):
 
 def test_concurrency_soak(factory, soak):
     n, first = soak
-    bad = concurrency_rounds(10 if n <= 0 else max(10, n // 50), factory, seed=20260929 + (first if n > 0 else 0))
+    bad = concurrency_rounds(50 if n <= 0 else max(50, n // 50), factory, seed=20260929 + (first if n > 0 else 0))
     assert not bad, bad
