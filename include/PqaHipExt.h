@@ -73,7 +73,11 @@ PQACORE_API void *PqaEngineFactory_CreateHipEngineSharded(void *pvFactory, void 
  * hardly moves the posterior -- of the row; such questions are listed and a kernel launched behind the sweep re-evaluates them in the
  * reference's own summation order -- SRAccumVectDbl256.h:40-46, :62-92 -- so that late quiz states stay within 1e-9 of the
  * reference's priorities on every kernel form; a resident sweep that finds such a row hands the quiz to the launched path; default 1,
- * also PQA_POLE_FIX), "pole_lazy" (a synchronous single-quiz selection launches that kernel only when its sweep has listed something
+ * also PQA_POLE_FIX), "pole_gate" (where only the selected question leaves the engine -- NextQuestion with the argmax selector, one quiz -- that kernel
+ * redoes only the listed questions whose priority can still be the maximum: per listed question the sweep hands over how close to 1 its
+ * largest posterior element can be, a kernel ahead of the fix bounds how far the fix can move the priority, and questions whose upper bound
+ * stays below the best lower bound keep the sweep's value; PqaEngine_EvalPriorities and the sampled selector always get every listed
+ * question redone; default 1), "pole_lazy" (a synchronous single-quiz selection launches that kernel only when its sweep has listed something
  * -- one launch per selection of a fresh quiz instead of two; default 1; 0 = behind every sweep), "late_eager" (after this many
  * selections of a quiz in a row that needed the fix, RecordAnswer's speculative sweep has it launched right behind it again: it runs
  * while the client is elsewhere; default 3 -- long quizzes in late states +4 %, the learner loop unchanged), "pole_follow" (measurement hook: 0 = the watching sweep WITHOUT the launch behind it, for timing the sweep

@@ -50,6 +50,7 @@ struct EvalArgs {
   const QuizSlot *slots;  // batched launch: per-quiz pointers, indexed by blockIdx.y (nullptr: a single quiz)
   int maxGrid;            // host side only: KbView::maxGrid
   int poleNoFollow;       // KbView::poleNoFollow (measurement hook): the register-form sweep watches but lists and defers nothing, and no fix is launched behind it
+  int poleGate;           // the launch is a fused argmax of one quiz and KbView::poleGate is on: the watch also tracks the listed questions' gaps (PoleEntry::gap)
   // eval_questions_f64_upd only: the answer whose posterior update runs in the sweep's prologue (sweep_body, FUSE)
   const double *updRowA, *updRowD;   // sA[q][a][.], mD[q][.] of the answered question
   int64_t updQuestion;               // its index (local): asked from this sweep on
@@ -527,7 +528,7 @@ __device__ __forceinline__ void sweep_body(EvalArgs a, bool copyTable) {
     }
     return q;
   };
-  if (tid < 4) susWords[tid] = 0;
+  if (tid < 4) susWords[tid] = tid < 2 ? 0u : kGapNoneBits;   // ([2], [3]: the smallest gap of the question's listed rows, by parity -- EvalArgs::poleGate)
   int64_t q = q0;
   if (haveQ0 && ((((q0Gap | q0Asked) >> (q0 & 31)) & 1u) || (FUSE && q0 == a.updQuestion))) {     // the first candidate is skipped: restart the stream
     q = next_valid(q0);
@@ -580,6 +581,7 @@ __device__ __forceinline__ void sweep_body(EvalArgs a, bool copyTable) {
     double accL = 0, hW = 0;
     [[maybe_unused]] int32_t rowGap = INT32_MIN;
     [[maybe_unused]] uint32_t watchRows = 0;                   // (pole watch, per lane: the rows in which this lane's sum is nearly all of W_k below, a quarter of it above)
+    [[maybe_unused]] double gapMin = 0x1p-10;                  // (... and, where the fix is gated: the smallest 1 - (lane sum) / W_k over the rows in which it is nearly all)
 #pragma unroll KC > 0 ? KC : 1
     for (int64_t k = 0; k < K; k++) {
       // ---- pass 1 (:66-87): likelihoods into registers, W_k; each consumed pair is refilled from the next stream row
@@ -643,6 +645,15 @@ __device__ __forceinline__ void sweep_body(EvalArgs a, bool copyTable) {
         }
       }
       const double invWk = div_nr(1.0, Wk);                    // :91
+      if constexpr (kListWatch) {
+        // Gated fix (pole_kernels.hip): the row's largest element is at most this lane's sum, so 1 - p >= (W_k - sum) / W_k -- an exact
+        // difference where it matters.  A wave-uniform branch: launches that do not gate skip it.
+        if (a.poleGate) {
+          const double gRel = (Wk - sLane) * invWk;
+          const bool nearOne = (uint32_t)(d2u(sLane) >> 32) + 0x00001000u >= (uint32_t)(d2u(Wk) >> 32);
+          gapMin = nearOne && gRel < gapMin ? gRel : gapMin;
+        }
+      }
       // ---- pass 2 (:95-128)
       double v = 0;
 #pragma unroll
@@ -674,7 +685,10 @@ __device__ __forceinline__ void sweep_body(EvalArgs a, bool copyTable) {
       vdump[K * kThreads + tid] = hW;
       vdump[(K + 1) * kThreads + tid] = accL;
       if constexpr (kListWatch) {                                   // (rare)
-        if (watchRows != 0) atomicOr(&susWords[qpar], watchRows);   // (the lanes that hold such a sum: one or two of a late quiz's wave)
+        if (watchRows != 0) {                                       // (the lanes that hold such a sum: one or two of a late quiz's wave)
+          atomicOr(&susWords[qpar], watchRows);
+          if (a.poleGate && gapMin < 0x1p-10) atomicMin(&susWords[2 + qpar], pole_gap_bits(gapMin));
+        }
       }
       __syncthreads();
       uint32_t wideRows = 0;                                     // workgroup-uniform: the rows with an element of a quarter
@@ -709,9 +723,10 @@ __device__ __forceinline__ void sweep_body(EvalArgs a, bool copyTable) {
       }
       if (tid == 0) {
         reinterpret_cast<int64_t *>(rec)[2 * K + 2] = q;
-        if constexpr (kListWatch) susWords[qpar ^ 1] = 0;      // (the other parity's flags: read by everybody before this question's barrier, set again only behind the next question's)
+        if constexpr (kListWatch) { susWords[qpar ^ 1] = 0; susWords[2 + (qpar ^ 1)] = kGapNoneBits; }   // (the other parity's flags: read by everybody before this question's barrier, set again only behind the next question's)
         if constexpr (!SERVER) {
-          if (suspect) susWords[4] = pole_list_append(a.poleList, (uint32_t)(q - a.qFirst), K <= 15 ? susWords[qpar] & 0xFFFFu : 0u, a.slots != nullptr ? blockIdx.y : 0u);
+          if (suspect) susWords[4] = pole_list_append(a.poleList, (uint32_t)(q - a.qFirst), K <= 15 ? susWords[qpar] & 0xFFFFu : 0u, a.slots != nullptr ? blockIdx.y : 0u,
+                                                      a.poleGate ? susWords[2 + qpar] : 0u);
         }
       }
       wgSuspect = wgSuspect || suspect;
@@ -734,7 +749,10 @@ __device__ __forceinline__ void sweep_body(EvalArgs a, bool copyTable) {
         part[(K + 1) * WPQ + wave] = accL;
       }
       if constexpr (kListWatch) {                                   // (rare)
-        if (watchRows != 0) atomicOr(&susWords[qpar], watchRows);   // (the lanes that hold such a sum: one or two of a late quiz's wave)
+        if (watchRows != 0) {                                       // (the lanes that hold such a sum: one or two of a late quiz's wave)
+          atomicOr(&susWords[qpar], watchRows);
+          if (a.poleGate && gapMin < 0x1p-10) atomicMin(&susWords[2 + qpar], pole_gap_bits(gapMin));
+        }
       }
       if constexpr (WPQ > 1) __syncthreads();
       uint32_t wideRows = 0;
@@ -758,9 +776,10 @@ __device__ __forceinline__ void sweep_body(EvalArgs a, bool copyTable) {
         if constexpr (kListWatch && !SERVER) { if (a.poleNoFollow) suspect = false; }   // (measurement hook, as above)
         if (lane == 0) {
           reinterpret_cast<int64_t *>(rec)[2 * K + 2] = q;
-          if constexpr (kListWatch) susWords[qpar ^ 1] = 0;
+          if constexpr (kListWatch) { susWords[qpar ^ 1] = 0; susWords[2 + (qpar ^ 1)] = kGapNoneBits; }
           if constexpr (!SERVER) {
-            if (suspect) susWords[4] = pole_list_append(a.poleList, (uint32_t)(q - a.qFirst), K <= 15 ? susWords[qpar] & 0xFFFFu : 0u, a.slots != nullptr ? blockIdx.y : 0u);
+            if (suspect) susWords[4] = pole_list_append(a.poleList, (uint32_t)(q - a.qFirst), K <= 15 ? susWords[qpar] & 0xFFFFu : 0u, a.slots != nullptr ? blockIdx.y : 0u,
+                                                        a.poleGate ? susWords[2 + qpar] : 0u);
           }
         }
         wgSuspect = wgSuspect || suspect;
@@ -1363,6 +1382,15 @@ constexpr size_t eval_base_lds_bytes(int64_t K, int64_t ldT) {
 
 // The fix behind a watching single-quiz sweep (pole_kernels.hip): the questions in the launch's suspect list, their sums in
 // poleScratch as the sweep left them -- W_k [K] | W_k sqrt(V_k) [K] | sum l log2 p | lack sum.
+// Where only the argmax leaves the engine -- a fused argmax of ONE quiz -- the fix is gated (PoleFix::gate); the sweep of such a launch tracks
+// the gaps the gate needs (EvalArgs::poleGate is set from this by the launch wrappers: sweep and fix always agree).
+static bool eval_gates(const EvalArgs &args) {
+  // (rows of up to 1024 targets: a question's fix is latency there -- ~20 us whatever the number of questions redone -- and the kernel
+  //  that bounds them one launch more: 71.3 vs 71.9 us per late selection at 1000 x 5 x 1000, 60.8 vs 55.0 half-way; from 1500 targets on
+  //  the gate pays: 86 vs 95, 116 vs 123 (2000), 181 vs 262 (3000), 245 vs 377 (4000), 988 vs 1771 us (10000) -- tools/gate_probe.py)
+  return args.poleGate && args.poleList != nullptr && args.slots == nullptr && args.fs.scratch != nullptr && args.fs.sampleSubtasks == 0 &&
+         args.fs.hostPriority == nullptr && !args.poleNoFollow && args.ldT > 1024;
+}
 hipError_t launch_pole_fixup(const EvalArgs &args, hipStream_t stream, int nBatch = 1) {
   PoleFix f{};
   f.cube = args.cube; f.tgap = args.tgap; f.qgap = args.qgap; f.asked = args.asked; f.prior = args.prior;
@@ -1374,6 +1402,7 @@ hipError_t launch_pole_fixup(const EvalArgs &args, hipStream_t stream, int nBatc
   f.vCompTail = args.vCompTail;
   f.fs = args.fs;
   if (args.fs.scratch != nullptr && args.fs.sampleSubtasks > 0 && args.fs.hostPriority != nullptr) { f.hostPriority = args.fs.hostPriority; f.hostTag = args.fs.seqValue; }
+  f.gate = eval_gates(args) ? 1 : 0;
   if (args.slots != nullptr) {   // a grid.y = quiz launch: the records by entry, every quiz's own vectors, and every quiz's publication
     f.slots = args.slots; f.nSlots = nBatch; f.bySlot = 1; f.prior = nullptr; f.asked = nullptr; f.priority = nullptr;
     f.capacity = f.nQ * (int64_t)nBatch;
@@ -1517,8 +1546,11 @@ static EvalArgs make_args(const KbView &kb, int64_t qFirst, int64_t qLimit) {
   args.slots = nullptr;
   args.maxGrid = kb.maxGrid;
   args.poleNoFollow = kb.poleNoFollow;
+  args.poleGate = kb.poleGate;   // (the engine's option; the launch wrappers clear it where the launch is no fused single-quiz argmax: finish_args)
   return args;
 }
+// once a launch's selection fields are set: the sweep tracks gaps only where its fix will be gated
+static void finish_args(EvalArgs &args) { args.poleGate = eval_gates(args) ? 1 : 0; }
 
 hipError_t LaunchEvalQuestions(const KbView &kb, const double *prior, const uint32_t *asked, int64_t qFirst,
                                int64_t qLimit, double *priority, int variant, const FusedSelect *fused,
@@ -1529,6 +1561,7 @@ hipError_t LaunchEvalQuestions(const KbView &kb, const double *prior, const uint
   args.asked = asked;
   args.priority = priority;
   if (fused) args.fs = *fused;
+  finish_args(args);
   return launch_variant(args, kb.ldT, variant, 1, stream);
 }
 
@@ -1540,6 +1573,7 @@ hipError_t LaunchEvalPoleFixup(const KbView &kb, const double *prior, const uint
   args.asked = asked;
   args.priority = priority;
   args.fs = fused;
+  finish_args(args);
   return launch_pole_fixup(args, stream, 1);
 }
 
@@ -1569,6 +1603,7 @@ hipError_t LaunchEvalQuestionsWithUpdate(const KbView &kb, double *prior, uint32
   args.updWorkers = nWorkers;
   args.updT = kb.T;
   args.updTop = TopRequest{reinterpret_cast<TopOut *>(topOut), topN, topFlag, topFlagValue, topOut ? topCount : 0};
+  finish_args(args);
   constexpr int WPQ = 4, NP = 2;
   const size_t shmem = eval_base_lds_bytes<WPQ, NP, false>(args.K, args.ldT) + eval_deferred_bytes(WPQ, NP, args.K, false);
   const bool pole = args.poleList != nullptr;
@@ -1619,6 +1654,7 @@ hipError_t LaunchEvalQuestionsBatch(const KbView &kb, const QuizSlot *slots, int
     args.poleList = reinterpret_cast<PoleHeader *>(p + 256 * sizeof(uint32_t));
     args.poleScratch = reinterpret_cast<double *>(p + kBatchPoleClear + (size_t)kb.Q * (size_t)nSlots * sizeof(PoleEntry));
   }
+  finish_args(args);   // (a grid.y = quiz launch: never gated)
   return launch_variant(args, kb.ldT, variant, nSlots, stream);
 }
 
@@ -1685,6 +1721,7 @@ hipError_t LaunchEvalServer(const KbView &kb, int64_t qFirst, int64_t qLimit, do
   args.priority = priority;
   args.fs.scratch = scratch;
   args.fs.hostPriority = hostPriority;
+  args.poleGate = 0;
   switch (server_variant(kb, variant)) {
     case 2: return launch_server<4, 2>(args, mailbox, requestLine, everyonePolls, ctl, lastSeq, idleTicks, stream);
     case 8: return launch_server<2, 4>(args, mailbox, requestLine, everyonePolls, ctl, lastSeq, idleTicks, stream);

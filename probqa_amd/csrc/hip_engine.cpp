@@ -311,6 +311,7 @@ KbView HipEngine::View() const {
   v.clusterFrom = ClusterFrom();
   v.poleScratch = _optPoleFix ? _dPoleScratch : nullptr;
   v.poleNoFollow = _optPoleFollow ? 0 : 1;
+  v.poleGate = _optPoleFix && _optPoleGate ? 1 : 0;
   v.poleList = _optPoleFix ? reinterpret_cast<PoleHeader *>(_dPoleScratch + (size_t)_capQ * (size_t)(2 * _K + 2)) : nullptr;
   return v;
 }
@@ -327,6 +328,7 @@ Error HipEngine::SetOption(const char *name, int64_t value) {
   else if (n == "combine_spin") { _optCombineSpin = value ? 1 : 0; }
   else if (n == "pole_fix") { StopServer(); (void)SettlePoleList(); _optPoleFix = value ? 1 : 0; _kbVersion++; }   // (settled while the list is still in view)   // 0: questions with a row at the pole of the lack term keep the sweep's own sums (pole_kernels.hip)
   else if (n == "late_eager") { if (value < 0 || value > 1000000) goto bad; _optLateEager = value; }
+  else if (n == "pole_gate") { StopServer(); (void)SettlePoleList(); _optPoleGate = value ? 1 : 0; }   // 0: a fused argmax's fix redoes every listed question
   else if (n == "pole_lazy") { StopServer(); (void)SettlePoleList(); _optPoleLazy = value ? 1 : 0; }
   else if (n == "pole_follow") { StopServer(); (void)SettlePoleList(); _optPoleFollow = value ? 1 : 0; }   // measurement hook: 0 = the watching sweeps without the fix launched behind them (KbView::poleNoFollow)
   else if (n == "long_row_form") { _optLongRowForm = value ? 1 : 0; }   // 0: the one-workgroup posterior kernels for rows beyond 16384 targets too
@@ -387,6 +389,7 @@ int64_t HipEngine::GetOption(const char *name) const {
   if (n == "pole_fix") return _optPoleFix;
   if (n == "late_eager") return _optLateEager;
   if (n == "pole_lazy") return _optPoleLazy;
+  if (n == "pole_gate") return _optPoleGate;
   if (n == "pole_follow") return _optPoleFollow;
   if (n == "allowed_cpus") return AllowedCpus();
   if (n == "combined_batches") return (int64_t)_combBatches;        // sweeps that served more than one NextQuestion call ...

@@ -26,10 +26,18 @@ constexpr double kSmallV = 2e-12;
 constexpr uint32_t kQuarterHi = 0x3FCE0000u;   // high word of 0.234: the element of a listed row whose terms are corrected
 
 // a sweep's entry for a question that passed its watch (pqa_kernels.h: PoleHeader; one thread)
-__device__ __forceinline__ uint32_t pole_list_append(PoleHeader *list, uint32_t q, uint32_t rowMask, uint32_t b) {
+__device__ __forceinline__ uint32_t pole_list_append(PoleHeader *list, uint32_t q, uint32_t rowMask, uint32_t b, uint32_t gap = 0u) {
   const uint32_t at = atomicAdd(&list->count, 1u);
-  reinterpret_cast<PoleEntry *>(list + 1)[at] = PoleEntry{q, rowMask, b, 0u};
+  reinterpret_cast<PoleEntry *>(list + 1)[at] = PoleEntry{q, rowMask, b, gap};
   return at;
+}
+// The gap a sweep that tracks it (KbView::poleGate) hands over with an entry: a lower bound of 1 - p for the largest element of the
+// question's listed rows, as float bits rounded down (positive floats order as their bit patterns: an LDS atomicMin gathers the lanes').
+// A row whose lane sums all stay 2^-8 below W_k -- not "near one" for the watch -- has no element above 1 - 2^-9: kGapNoneBits.
+constexpr uint32_t kGapNoneBits = 0x3A7FF000u;   // just below 2^-10
+__device__ __forceinline__ uint32_t pole_gap_bits(double gap) {
+  const float f = (float)(gap * 0.99999);        // (below the double whatever the rounding of the conversion)
+  return f > 0.0f ? __float_as_uint(f) : 0u;     // (0, denormal-flushed or negative: not known -- such a question is always redone)
 }
 
 // SRVectMath.h:87-135, operation for operation (oracle: orc_log2hot).  tbl: the Log2Hot table in global memory ({log2 midpoint,

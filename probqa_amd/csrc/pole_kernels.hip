@@ -121,6 +121,65 @@ __device__ __forceinline__ void best_merge(Best &b, double op, int64_t oi) {
   if (oi >= 0 && (b.i < 0 || op > b.p || (op == b.p && oi < b.i))) { b.p = op; b.i = oi; }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// The gate (PoleFix::gate): where only the ARGMAX leaves the engine, a listed question needs the fix only if it can still win.
+// What the fix changes in a question's sums is bounded by how far the two sums of a row can differ and how close to 1 the row's
+// largest posterior element is.  With d the relative difference of the reference-order W_k and the sweep's -- the sweep's is a
+// pairwise tree over lane sums of at most 2 x 10 terms, depth <= 30 additions of non-negative terms: within 30 u of the exact sum,
+// the reference's Kahan lanes within 2 u + O(n u^2); d <= 33 u, taken as kGateD = 4e-15 -- and g a lower bound of 1 - p for that
+// element (PoleEntry::gap, from the sweep's watch):
+//   * lack (:117): the element's term id^2 / log2 p moves by |log2 pFast - log2 pRef| / |log2 pRef| of itself, and itself is at most the
+//     whole (one-signed) lack sum: |log2 pRef| >= (g - 2 d) / ln 2, the difference <= 1.01 d / ln 2 + 3e-17 (the two Log2Hot forms) --
+//     per listed row (1.1 d + 3e-17) / (g - 2 d) of the lack sum, hence of the priority (:207);
+//   * entropy (:113-114, :175-181): the element's term moves by at most W_k (1.5 d + 2e-17), sum W_k by d of itself: avgH by at most 21.5 d
+//     (|avgH| <= log2 of the targets <= 20), 2^(-2 avgH) by 30 d;
+//   * velocity (:119-127, :156-177): |sqrt V_new - sqrt V_old| <= |pRef - pFast| (both roots are at least the element's own difference),
+//     so W_k sqrt V_k moves by at most 2.6 d W_k, avgV by 4.1 d, ln avgV by 4.1 d / avgV, vComp^9 (:191, :207) by 38 d vComp / avgV.
+// The bound of a question is twice the sum (kGateSafety) plus 2e-9 (what the fixed priorities themselves are held to); a question
+// whose gap is not known (other sweeps than the register shapes', an element that rounds to 1) has none and is always redone.
+// pole_bounds_kernel computes it per entry from the sums the sweep left -- the epilogue's averages again, a thread per entry -- stores
+// it in the entry and raises PoleHeader::floorBits to the best LOWER bound priority x (1 - bound) over the listed questions (positive
+// doubles order as their bit patterns).  The fix then skips every entry whose UPPER bound priority x (1 + bound) is below that floor:
+// the question that is the reference's maximum is never skipped (its upper bound is at least its reference priority, which is at
+// least every other question's, which is at least the floor), and what the final argmax compares are fixed priorities of the
+// questions that could win and untouched ones that could not.
+// ------------------------------------------------------------------------------------------------------------------
+constexpr double kGateD = 4e-15, kGateSafety = 2.0, kGateSlack = 2e-9;
+
+__global__ __launch_bounds__(256) void pole_bounds_kernel(PoleFix a) {
+  const uint32_t n = a.list->count;
+  PoleEntry *entries = reinterpret_cast<PoleEntry *>(a.list + 1);
+  const int64_t K = a.K;
+  double lo = 0.0;
+  for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) {
+    const PoleEntry en = entries[e];
+    const float g = __uint_as_float(en.gap);
+    const double *rec = a.sums + (size_t)en.q * a.sumsStride;
+    double bound = __builtin_huge_val();
+    const double pri = a.priority[en.q];
+    if (en.gap != 0u && g > 4.0 * kGateD && K <= 31) {
+      double totW = 0.0, wv = 0.0;
+      for (int64_t k = 0; k < K; k++) { totW += rec[a.wOff + k]; wv += rec[a.vOff + k]; }   // (a.secondIsWV: W_k sqrt V_k)
+      const double avgV = wv / totW;
+      if (avgV > 1e-100 && totW > 0.0) {
+        const double lnV = log_pos(avgV);
+        const double vComp = 1.0 / (0.34657359027997265470861606072909 - lnV + a.vCompTail);
+        const int rows = en.rowMask != 0u ? __popc(en.rowMask) : (int)K;
+        const double lack = rows * (1.1 * kGateD + 3e-17) / ((double)g - 2.0 * kGateD);
+        const double vel = 38.0 * kGateD * vComp / avgV;
+        bound = kGateSafety * (lack + 30.0 * kGateD + vel) + kGateSlack;
+      }
+    }
+    if (!(bound < 0.25)) bound = __builtin_huge_val();         // (nothing to gain: redone)
+    float bf = (float)bound;
+    if ((double)bf < bound) bf = __uint_as_float(__float_as_uint(bf) + 1u);   // (rounded up)
+    entries[e].gap = __float_as_uint(bf);
+    if (bound < 0.25 && pri > 0.0) { const double l = pri * (1.0 - bound); lo = l > lo ? l : lo; }
+  }
+  lo = wave_max_d(lo);
+  if (threadIdx.x % kWave == 0 && lo > 0.0) atomicMax(&a.list->floorBits, (unsigned long long)d2u(lo));
+}
+
 // One WAVE per suspect, no workgroup barriers: every lane stages a pair of targets of the listed rows per chunk (the loads of the next
 // chunk in flight while this one is worked on), then four lanes per row run the rows' reference-order sums over the chunk -- T / 4
 // dependent Kahan steps per row in all, the only serial part -- while a SIMD's other waves fill the gaps of the chain with their own
@@ -161,6 +220,11 @@ __global__ __launch_bounds__(kFixThreads) __attribute__((amdgpu_waves_per_eu(PQA
       const uint64_t pp = (uint64_t)(uintptr_t)a.slots[en.b].prior;
       prior = reinterpret_cast<const double *>((uintptr_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(pp >> 32)) << 32) |
                                                               (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)pp)));
+    }
+    if (a.gate) {   // (the bound pole_bounds_kernel left in the entry: a question that cannot be the maximum keeps the sweep's priority)
+      const float bf = __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)en.gap));
+      const double pri = a.priority[qLocal], floorP = u2d(__hip_atomic_load(&a.list->floorBits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+      if (bf < 0.25f && pri * (1.0 + (double)bf) < floorP) continue;
     }
     uint32_t rowMask = en.rowMask;
     if (a.maskDense != nullptr) rowMask = __builtin_amdgcn_readfirstlane(a.maskDense[qLocal]);
@@ -436,6 +500,7 @@ __global__ __launch_bounds__(kFixThreads) __attribute__((amdgpu_waves_per_eu(PQA
   }
   if (tid == 0) {
     a.list->arrived = 0;
+    a.list->floorBits = 0ull;
     __hip_atomic_store(&a.list->count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
@@ -477,6 +542,11 @@ hipError_t LaunchPoleFixup(const PoleFix &fix, hipStream_t stream) {
   const int64_t wgs = (fix.capacity + wgWaves - 1) / wgWaves;   // (a wave per suspect)
   if (fix.capacity > 0 && grid > wgs) grid = wgs;
   if (grid < 1) grid = 1;
+  if (a.gate) {
+    if (a.priority == nullptr || a.slots != nullptr || a.bySlot || !a.secondIsWV) a.gate = 0;   // (what pole_bounds_kernel reads)
+    else hipLaunchKernelGGL(pole_bounds_kernel, dim3((unsigned)((fix.capacity + 255) / 256 < 1 ? 1 : (fix.capacity + 255) / 256 > 64 ? 64 : (fix.capacity + 255) / 256)),
+                            dim3(256), 0, stream, a);
+  }
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3((unsigned)(wgWaves * kWave)), shmem, stream, a);
   return hipGetLastError();
 }

@@ -65,17 +65,23 @@ struct KbView {
   struct PoleHeader *poleList;   // ... and the list of those questions: PoleListBytes(Q) bytes, zeroed once (every launch leaves it empty)
   int poleNoFollow;       // measurement hook (engine option "pole_follow" = 0): the watching sweep WITHOUT the launch behind it -- for timing the sweep
                           // kernel by itself in a quiz state that lists nothing; anything listed would stay listed
+  int poleGate;           // engine option "pole_gate" (default 1): where only the ARGMAX leaves the engine (a fused single-quiz argmax), the fix
+                          // redoes only the listed questions that can still win (pole_kernels.hip: pole_bounds_kernel) -- the register-shape
+                          // sweeps then track, per listed question, how close to 1 its largest posterior element can be
 };
 
 // ---- questions with a row at the pole of the lack term: listed by the sweeps, redone in the reference's order behind them
 // (pole_kernels.hip).  A list is a header and `capacity` entries; a sweep appends at most one entry per question (and quiz).
-struct PoleHeader { uint32_t count, arrived, pad[2]; };
+struct PoleHeader { uint32_t count, arrived; unsigned long long floorBits; };   // floorBits: see PoleFix::gate
 struct PoleEntry {
   uint32_t q;             // position in the priority vector (question qFirst + q of the cube)
   uint32_t rowMask;       // the answer rows that passed the sweep's watch, a bit each (0: not known -- every row is redone)
   uint32_t b;             // the quiz (batched sweeps; 0 otherwise)
-  uint32_t pad;
+  uint32_t gap;           // float bits.  From a sweep that tracks it (KbView::poleGate): a lower bound of 1 - p for the largest posterior
+                          // element of the question's listed rows (0: not known); then, from pole_bounds_kernel: how far the fix can move
+                          // the question's priority, relative (+inf: not known)
 };
+static_assert(sizeof(PoleHeader) == 16, "header and entries are 16 bytes each");
 size_t PoleListBytes(int64_t capacity);
 hipError_t UploadLog2TablePole(const double *hostTable);
 
@@ -167,6 +173,10 @@ struct PoleFix {
   double vCompTail;
   FusedSelect fs;
   int rows, waveLds;              // (set by the launcher)
+  // gate: only the argmax leaves the engine (fs names a fused argmax of ONE quiz, `priority` holds the sweep's vector, the entries carry
+  // the sweep's gaps): a kernel ahead of the fix bounds, per listed question, how far the fix can move its priority, and the fix skips
+  // the questions whose upper bound stays below the best lower bound (PoleHeader::floorBits) -- they cannot be the maximum.
+  int gate;
 };
 hipError_t LaunchPoleFixup(const PoleFix &fix, hipStream_t stream);
 // The same sweep for nSlots quizzes in one launch (grid.y = quiz): `slots` is a DEVICE array; fused->scratch holds

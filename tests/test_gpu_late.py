@@ -228,6 +228,43 @@ def test_measurement_hook_without_the_fix_is_harmless(i, factory):
     eng.close()
 
 
+@pytest.mark.parametrize("i", [0, 1, 2, 5, 6, 11, 12, 13, 14, 17, 18, 23, 26, 29, 30, 35, 38, 42, 47, 50, 54, 59])
+def test_gated_fix_picks_what_the_full_fix_picks(i, factory):
+    """Engine option pole_gate (default on): NextQuestion with the argmax selector has only the listed questions redone that can still
+    be the maximum (pole_kernels.hip: pole_bounds_kernel).  Every step of late-state cases, register shapes: the same question as with
+    every listed question redone, and the oracle's where its two best are told apart."""
+    leg, case, options = late_case(i)
+    if leg in ("mid", "rowshare", "gridy", "cluster", "server"):
+        pytest.skip("single-quiz launched register shapes")
+    eng, orc = case.make_engine(factory), case.make_oracle()
+    for n, v in options:
+        eng.set_option(n, v)
+    eng.set_option("speculate", 0)
+    quiz = eng.start_quiz()
+    orc.start_quiz(cases.WORKERS)
+    for step in range(len(case.answers) + 1):
+        picks = []
+        for gate, lazy in ((1, 1), (0, 1), (1, 0), (0, 0)):
+            eng.set_option("pole_gate", gate)
+            eng.set_option("pole_lazy", lazy)
+            picks.append(eng.next_question_argmax(quiz))
+        assert len(set(picks)) == 1, (case.name, step, picks)
+        _, opri = orc.eval(8 * cases.WORKERS)
+        top = np.sort(opri)[::-1]
+        if top[0] > 0 and (top[0] - top[1]) / top[0] > 1e-8:
+            assert picks[0] == orc.select_argmax(opri), (case.name, step)
+        eng.set_option("pole_gate", 1)
+        pri = eng.eval_priorities(quiz)                      # (every listed question redone, whatever the gate)
+        live = opri != 0
+        assert cases.rel_err(pri[live], opri[live]).max() < 1e-9, (case.name, step)
+        if step < len(case.answers):
+            q, a = case.answers[step]
+            eng.set_active_question(quiz, q)
+            eng.record_answer(quiz, a)
+            orc.record_answer(q, a, cases.WORKERS - 1)
+    eng.close()
+
+
 def test_late_soak(factory, late):
     """--late N further cases; prints the worst step per leg."""
     n, first = late
