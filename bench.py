@@ -4,7 +4,9 @@
 A "step" is one complete NextQuestion of one quiz: the priority sweep over every unasked question of the
 sA[question][answer][target] cube (eval kernel) + the argmax selection + delivery of the selected question id to
 the host.  The cube is resident in HBM before the timed region.  Workload at N=1: BASELINE.json configs[1]
-(1000Q x 5A x 1000T fp64, single in-flight quiz).  N>1: the question axis of the same cube is sharded over the ranks
+(1000Q x 5A x 1000T fp64, single in-flight quiz).  `value` goes through the library's DEFAULT path -- one kernel launch per
+selection, what an unchanged caller of PqaEngine_NextQuestion gets; the opt-in resident sweep (engine option server = 1) is
+measured beside it (`resident_sweep`), and `--server` takes `value` through it instead.  N>1: the question axis of the same cube is sharded over the ranks
 (one process per GPU), each rank sweeps its shard and the ranks' 16-byte winners meet in host shared memory written by
 the sweeps themselves (--exchange rccl: one RCCL all-gather instead), every rank picks the same global argmax
 ("strong" scaling, as north_star states it).  --config M runs configs[2] (10000x5x10000, the HBM-bound point); sharded
@@ -68,7 +70,11 @@ def main():
     ap.add_argument("--exchange", choices=("shm", "rccl"), default="shm",
                     help="how the shards' 16-byte winners meet: host shared memory written by the sweep itself "
                          "(default), or an RCCL all-gather + D2H copy")
-    ap.add_argument("--no-server", action="store_true", help="launch one kernel per selection even where a resident sweep exists")
+    ap.add_argument("--server", action="store_true",
+                    help="take `value` through the resident sweep kernel (engine option server=1, opt-in in the library too) instead of the "
+                         "library's default path, one kernel launch per selection; without it the resident rate is reported beside `value` "
+                         "(resident_sweep)")
+    ap.add_argument("--no-server", action="store_true", help="do not measure the resident sweep at all")
     ap.add_argument("--no-quiz-loop", action="store_true", help="skip the quiz-loop extra")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-points", action="store_true", help="one GPU, default config: skip the M and L1 points (hbm_point_M, valu_point_L1)")
@@ -236,9 +242,15 @@ def main():
     # The resident sweep (engine option "server": one launch serves many selections, csrc/eval_kernels.hip) where the
     # engine has one for the cube's shape; the launch-per-selection rate of the same call is reported beside it.
     uses_collective = selector is not None and args.exchange == "rccl"   # (that path enqueues launches on the stream)
-    if not args.no_server and not uses_collective:
+    if args.server and not args.no_server and not uses_collective:
         eng.set_option("server", 1)
     resident = bool(eng.get_option("server_active") == 1) and not uses_collective
+    # set-up, not measurement: the device's clocks ramp up over the first tenths of a second of work, and a run of W = 5 warm-up steps
+    # and K = 20 timed ones (the driver's command: 0.6 ms of device work in all) would time the ramp -- a third of a second of the same
+    # call first, then the W untimed and K timed steps of the contract
+    t_settle = time.perf_counter() + 0.3
+    while time.perf_counter() < t_settle:
+        step()
     elapsed, sel = timed(step, args.warmup, args.steps)
     value = args.steps / elapsed
 
@@ -286,6 +298,30 @@ def main():
             n_nat = max(500, min(args.steps, 5000))
             dt_n, sel_n = interop.time_selections_native(eng, quiz, 200, n_nat)
             native["launched"] = {"selections_per_sec": n_nat / dt_n, "us_per_step": 1e6 * dt_n / n_nat, "agrees": int(sel_n) == int(sel)}
+    # ---- extra (not `value`): the same synchronous call through the resident sweep kernel (engine option server = 1: opt-in -- it keeps
+    # every CU polling for up to server_idle_us after a selection), where the engine has one for the cube's shape
+    resident_extra = None
+    if not resident and selector is None and not args.no_server and not uses_collective:
+        eng.set_option("server", 1)
+        if eng.get_option("server_active") == 1:
+            n_r = max(200, args.steps)
+            dt_r, sel_r = timed(step, min(args.warmup, 2000), n_r)
+            ticks = []
+            for _ in range(max(50, min(args.steps, 500))):
+                step()
+                ns = eng.get_option("server_last_step_ns")
+                if ns > 0:
+                    ticks.append(ns * 1e-3)
+            ticks.sort()
+            step_us = {"mean": sum(ticks) / len(ticks), "p10": ticks[len(ticks) // 10], "p50": ticks[len(ticks) // 2],
+                       "p90": ticks[(9 * len(ticks)) // 10], "n": len(ticks)} if ticks else None
+            resident_extra = {"selections_per_sec": n_r / dt_r, "us_per_step": 1e6 * dt_r / n_r, "agrees_with_launches": int(sel_r) == int(sel),
+                              "resident_step_us": step_us,
+                              "host_overhead_us": (1e6 * dt_r / n_r - step_us["mean"]) if step_us else None,
+                              "note": "engine option server = 1 (opt-in; `bench.py --server` takes `value` through it): one launch of eval_server_f64 serves "
+                                      "the selections, request and answer through pinned / BAR-mapped memory; resident_step_us is the kernel's own 100 MHz "
+                                      "clock per step, request in hand to answer published"}
+        eng.set_option("server", 0)
     kernel_ms = kernel_ms_of(eng, quiz, max(20, min(args.steps, 200)))
     alg_bytes = q_local * (K + 1) * T * 8  # one read of every sA row and the mD row, fp64
     alg_flops = q_local * K * T * FLOPS_PER_ELEMENT   # ~45 fp64 operations per (question, answer, target)
@@ -577,8 +613,8 @@ def main():
         "config": {
             "workload": "%s fp64 cube resident in HBM, single in-flight quiz; step = priority sweep + argmax + "
                         "question id on host, synchronous call through the C ABI" % cfg["name"],
-            "selection_path": "resident sweep kernel (engine option server=1): request and answer through pinned memory"
-            if resident else "one kernel launch per selection",
+            "selection_path": "resident sweep kernel (engine option server=1, opt-in: bench.py --server): request and answer through pinned memory"
+            if resident else "one kernel launch per selection (the library's default path)",
             "questions_per_gpu": q_local,
             "parallelism": ("question-axis shards x%d, winners exchanged through %s" % (
             world, "host shared memory written by the sweep" if args.exchange == "shm" else "an RCCL all-gather"))
@@ -589,8 +625,9 @@ def main():
         "question_evals_per_sec": value * Q,
         "step_latency_us": latency_us,
         # what a synchronous step spends outside the sweep: the request's way to the kernel, the answer's way back, the wrapper
-        "host_overhead_us": (1e6 * elapsed / args.steps - server_step_us["mean"]) if server_step_us else None,
-        "launch_per_selection": launch_rate,
+        "host_overhead_us": (1e6 * elapsed / args.steps - server_step_us["mean"]) if server_step_us else (1e6 * elapsed / args.steps - launched_us),
+        "launch_per_selection": launch_rate if launch_rate is not None else ({"selections_per_sec": value, "note": "this is `value`"} if selector is None else None),
+        "resident_sweep": resident_extra,
         "native_caller": native,
         "pipelined_selections_per_sec": pipelined,
         "batched": batched,
