@@ -581,7 +581,6 @@ __device__ __forceinline__ void sweep_body(EvalArgs a, bool copyTable) {
     double accL = 0, hW = 0;
     [[maybe_unused]] int32_t rowGap = INT32_MIN;
     [[maybe_unused]] uint32_t watchRows = 0;                   // (pole watch, per lane: the rows in which this lane's sum is nearly all of W_k below, a quarter of it above)
-    [[maybe_unused]] double gapMin = 0x1p-10;                  // (... and, where the fix is gated: the smallest 1 - (lane sum) / W_k over the rows in which it is nearly all)
 #pragma unroll KC > 0 ? KC : 1
     for (int64_t k = 0; k < K; k++) {
       // ---- pass 1 (:66-87): likelihoods into registers, W_k; each consumed pair is refilled from the next stream row
@@ -647,11 +646,12 @@ __device__ __forceinline__ void sweep_body(EvalArgs a, bool copyTable) {
       const double invWk = div_nr(1.0, Wk);                    // :91
       if constexpr (kListWatch) {
         // Gated fix (pole_kernels.hip): the row's largest element is at most this lane's sum, so 1 - p >= (W_k - sum) / W_k -- an exact
-        // difference where it matters.  A wave-uniform branch: launches that do not gate skip it.
+        // difference where it matters.  A wave-uniform branch (launches that do not gate skip it) around a rare divergent one: the lane
+        // whose sum is nearly all of W_k lowers the question's word right here -- nothing is carried over the rows.  (Behind the row's
+        // exchange barrier: the word was reset for this question before any wave passed it.)
         if (a.poleGate) {
-          const double gRel = (Wk - sLane) * invWk;
-          const bool nearOne = (uint32_t)(d2u(sLane) >> 32) + 0x00001000u >= (uint32_t)(d2u(Wk) >> 32);
-          gapMin = nearOne && gRel < gapMin ? gRel : gapMin;
+          if ((uint32_t)(d2u(sLane) >> 32) + 0x00001000u >= (uint32_t)(d2u(Wk) >> 32))
+            atomicMin(&susWords[2 + qpar], pole_gap_bits((Wk - sLane) * invWk));
         }
       }
       // ---- pass 2 (:95-128)
@@ -685,10 +685,7 @@ __device__ __forceinline__ void sweep_body(EvalArgs a, bool copyTable) {
       vdump[K * kThreads + tid] = hW;
       vdump[(K + 1) * kThreads + tid] = accL;
       if constexpr (kListWatch) {                                   // (rare)
-        if (watchRows != 0) {                                       // (the lanes that hold such a sum: one or two of a late quiz's wave)
-          atomicOr(&susWords[qpar], watchRows);
-          if (a.poleGate && gapMin < 0x1p-10) atomicMin(&susWords[2 + qpar], pole_gap_bits(gapMin));
-        }
+        if (watchRows != 0) atomicOr(&susWords[qpar], watchRows);   // (the lanes that hold such a sum: one or two of a late quiz's wave)
       }
       __syncthreads();
       uint32_t wideRows = 0;                                     // workgroup-uniform: the rows with an element of a quarter
@@ -749,10 +746,7 @@ __device__ __forceinline__ void sweep_body(EvalArgs a, bool copyTable) {
         part[(K + 1) * WPQ + wave] = accL;
       }
       if constexpr (kListWatch) {                                   // (rare)
-        if (watchRows != 0) {                                       // (the lanes that hold such a sum: one or two of a late quiz's wave)
-          atomicOr(&susWords[qpar], watchRows);
-          if (a.poleGate && gapMin < 0x1p-10) atomicMin(&susWords[2 + qpar], pole_gap_bits(gapMin));
-        }
+        if (watchRows != 0) atomicOr(&susWords[qpar], watchRows);   // (the lanes that hold such a sum: one or two of a late quiz's wave)
       }
       if constexpr (WPQ > 1) __syncthreads();
       uint32_t wideRows = 0;

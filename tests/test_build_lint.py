@@ -55,7 +55,7 @@ ON_REQUEST = [
 ]
 # KNOWN: dispatched by default and touching scratch -- each with what was measured; the list may only shrink.
 KNOWN = {
-    r"eval_questions_f64<8, 9, false, true, true, 5>": 28,    # six spilled registers, and still 733 vs 819 us at 9000 x 5 x 9000 against the form without the constant K (round 6, same box)
+    r"eval_questions_f64<8, 9, false, true, true, 5>": 20,    # four spilled registers (six before the round-6 watch), and still 733 vs 819 us at 9000 x 5 x 9000 against the form without the constant K (round 6, same box)
     r"eval_cluster_ahead_kernel<double>": 16,                 # long rows, answer counts other than five
     r"eval_cluster_kernel<float, 2>": 20,                     # Float engines, long rows, question by question
     r"eval_questions_f32_dma<6, 2>": 80,                      # Float engines, one quiz, rows of 7681..9216 / 9217..12288 elements
