@@ -927,7 +927,25 @@ def point_m(args, np, torch, interop, factory, stream, kernel_ms_of):
             e.enqueue_eval(qz)
         ev1.record(stream)
         torch.cuda.synchronize()
-        late = {"answers": hist, "top_posterior_one_minus": (1 - top[0].prob) if top else None, "sweep_plus_fixup_us": 1e3 * ev0.elapsed_time(ev1) / 10}
+        late = {"answers": hist, "top_posterior_one_minus": (1 - top[0].prob) if top else None, "sweep_plus_fixup_us": 1e3 * ev0.elapsed_time(ev1) / 10,
+                "sweep_plus_fixup_note": "the priority VECTOR of the late state (what PqaEngine_EvalPriorities and the sampled selector get): every listed question redone"}
+        # ... and what a NextQuestion with the argmax selector costs there: only the selected question leaves the engine, so only the listed
+        # questions that can still win are redone (engine option pole_gate; pole_kernels.hip: pole_bounds_kernel)
+        e.set_option("speculate", 0)
+        sel_us = {}
+        for gate in (0, 1):
+            e.set_option("pole_gate", gate)
+            for _ in range(3):
+                pick_l = e.next_question_argmax(qz)
+            t1 = time.perf_counter()
+            for _ in range(10):
+                pick_l = e.next_question_argmax(qz)
+            sel_us[gate] = (1e5 * (time.perf_counter() - t1), int(pick_l))
+        e.set_option("speculate", 1)
+        late["synchronous_argmax_selection_us"] = sel_us[1][0]
+        late["synchronous_argmax_selection_us_with_every_listed_question_redone"] = sel_us[0][0]
+        late["selected_question"] = sel_us[1][1]
+        late["gated_and_full_fix_select_the_same_question"] = sel_us[0][1] == sel_us[1][1]
         if not args.no_cpu_baseline:
             n_q = 200
             pri = e.eval_priorities(qz, Q)

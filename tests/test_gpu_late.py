@@ -265,6 +265,19 @@ def test_gated_fix_picks_what_the_full_fix_picks(i, factory):
     eng.close()
 
 
+@pytest.mark.parametrize("i", [11, 24])
+def test_rerouted_rows_again_and_again(i, factory):
+    """Rows of 10241..16384 targets take the cluster sweep since round 6 -- clusters of 11..16 members, shorter slices than the rows
+    that sweep was built for.  The same late case thirty times over (three answers / five answers per question): a race between the
+    members shows as a rare wrong priority, not as a wrong one every time (round 6: the five-answer kernel's schedule instantiated for
+    two to four answers failed 10 of 150 such runs by up to 10^4 x and was taken out again; these two forms: 0 of 400)."""
+    leg, case, options = late_case(i)
+    assert case.T > 10240 and leg == "reg"
+    for rep in range(30):
+        worst = max(run_script(case, factory, options))
+        assert worst < 1e-9, (case.name, rep, worst)
+
+
 def test_late_soak(factory, late):
     """--late N further cases; prints the worst step per leg."""
     n, first = late
