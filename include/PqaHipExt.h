@@ -73,7 +73,9 @@ PQACORE_API void *PqaEngineFactory_CreateHipEngineSharded(void *pvFactory, void 
  * hardly moves the posterior -- of the row; such questions are listed and a kernel launched behind the sweep re-evaluates them in the
  * reference's own summation order -- SRAccumVectDbl256.h:40-46, :62-92 -- so that late quiz states stay within 1e-9 of the
  * reference's priorities on every kernel form; a resident sweep that finds such a row hands the quiz to the launched path; default 1,
- * also PQA_POLE_FIX), "pole_gate" (where only the selected question leaves the engine -- NextQuestion with the argmax selector, one quiz -- that kernel
+ * also PQA_POLE_FIX), "top_exact" (ListTopTargets where probabilities tie among the listed targets or at the list's end: 1 [default] = the
+ * reference's order among equals -- CEListTopTargetsAlgorithm::RunHeapifyBased's per-worker heaps and head heap reproduced on the device for
+ * the emulated worker count --, 0 = by ascending target; read-only "top_exact_listings" counts the listings that took the heaps), "pole_gate" (where only the selected question leaves the engine -- NextQuestion with the argmax selector, one quiz -- that kernel
  * redoes only the listed questions whose priority can still be the maximum: per listed question the sweep hands over how close to 1 its
  * largest posterior element can be, a kernel ahead of the fix bounds how far the fix can move the priority, and questions whose upper bound
  * stays below the best lower bound keep the sweep's value; PqaEngine_EvalPriorities and the sampled selector always get every listed
@@ -123,7 +125,8 @@ PQACORE_API void *PqaEngine_RecordAnswerBatch(void *pvEngine, const int64_t nQui
 PQACORE_API void *PqaEngine_StartQuizBatch(void *pvEngine, const int64_t nQuizzes, int64_t *pQuizzes);
 /* ListTopTargets for nQuizzes quizzes (any number; 256 per launch sequence) without copying a posterior to the host: pDest[i * maxCount + j],
  * j < pCounts[i], is the listing PqaEngine_ListTopTargets(pQuizzes[i], maxCount) returns -- descending probability, gaps and
- * probabilities <= 0 dropped (reference PqaCore/CEHeapifyPriorsSubtaskMake.cpp:42-52), equal probabilities by ascending target.
+ * probabilities <= 0 dropped (reference PqaCore/CEHeapifyPriorsSubtaskMake.cpp:42-52), equal probabilities in the order the reference's
+ * per-worker heaps leave them (option "workers" = its thread count; option "top_exact" 0: by ascending target instead).
  * Rows of any length: 4096-target chunks list their own best maxCount on the device and merge there; what crosses to the host is
  * nQuizzes x maxCount records (the reference's GPU engine copies all nTargets posteriors per quiz: PqaCore/CudaEngine.cpp:251-289). */
 PQACORE_API void *PqaEngine_ListTopTargetsBatch(void *pvEngine, const int64_t nQuizzes, const int64_t *pQuizzes, const int64_t maxCount,

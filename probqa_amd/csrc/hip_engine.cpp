@@ -283,6 +283,7 @@ HipEngine::~HipEngine() {
   for (QuizPinned *slab : _pinSlabs) hipHostFree(slab);
   hipFree(_dTGap); hipFree(_dQGap); hipFree(_dAqs); hipFree(_dTopScratch[0]); hipFree(_dTopScratch[1]);
   if (_hTopBatch) hipHostFree(_hTopBatch);
+  hipFree(_dTopExact);
   if (_hPinned) hipHostFree(_hPinned);
   if (_hHostPriority) hipHostFree(_hHostPriority);
   if (_ownStream) hipStreamDestroy(_ownStream);
@@ -328,6 +329,7 @@ Error HipEngine::SetOption(const char *name, int64_t value) {
   else if (n == "combine_spin") { _optCombineSpin = value ? 1 : 0; }
   else if (n == "pole_fix") { StopServer(); (void)SettlePoleList(); _optPoleFix = value ? 1 : 0; _kbVersion++; }   // (settled while the list is still in view)   // 0: questions with a row at the pole of the lack term keep the sweep's own sums (pole_kernels.hip)
   else if (n == "late_eager") { if (value < 0 || value > 1000000) goto bad; _optLateEager = value; }
+  else if (n == "top_exact") { _optTopExact = value ? 1 : 0; }   // 0: equal probabilities always by ascending target (the fast listing alone)
   else if (n == "pole_gate") { StopServer(); (void)SettlePoleList(); _optPoleGate = value ? 1 : 0; }   // 0: a fused argmax's fix redoes every listed question
   else if (n == "pole_lazy") { StopServer(); (void)SettlePoleList(); _optPoleLazy = value ? 1 : 0; }
   else if (n == "pole_follow") { StopServer(); (void)SettlePoleList(); _optPoleFollow = value ? 1 : 0; }   // measurement hook: 0 = the watching sweeps without the fix launched behind them (KbView::poleNoFollow)
@@ -390,6 +392,8 @@ int64_t HipEngine::GetOption(const char *name) const {
   if (n == "late_eager") return _optLateEager;
   if (n == "pole_lazy") return _optPoleLazy;
   if (n == "pole_gate") return _optPoleGate;
+  if (n == "top_exact") return _optTopExact;
+  if (n == "top_exact_listings") return _topExactListings;
   if (n == "pole_follow") return _optPoleFollow;
   if (n == "allowed_cpus") return AllowedCpus();
   if (n == "combined_batches") return (int64_t)_combBatches;        // sweeps that served more than one NextQuestion call ...

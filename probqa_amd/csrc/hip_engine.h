@@ -378,7 +378,16 @@ class HipEngine : public IEngine {
   RatedTargetDev *_hTopBatch = nullptr;
   int64_t _hTopBatchRecords = 0;
   Error EnsureTopScratch(int64_t nQuizzes, int64_t want);
-  int64_t ListTopTargetsOnHost(Error &err, Quiz *q, int64_t want, CiRatedTarget *pDest);
+  int64_t ListTopTargetsOnHost(Error &err, Quiz *q, int64_t want, CiRatedTarget *pDest, bool referenceOrder = false);
+  // ListTopTargets = the fast listing with one entry more than asked for; where it shows equal probabilities, the reference's own
+  // order among them (its per-worker heaps, reproduced on the device: kb_kernels.hip LaunchTopTargetsExact) -- option "top_exact"
+  int64_t ListTopTargetsFast(Error &err, int64_t iQuiz, int64_t maxCount, CiRatedTarget *pDest);
+  int64_t ListTopTargetsExact(Error &err, int64_t iQuiz, int64_t maxCount, CiRatedTarget *pDest);
+  Error EnsureTopExactScratch(int64_t nQuizzes, int64_t want);
+  void *_dTopExact = nullptr;
+  size_t _topExactBytes = 0;
+  int64_t _optTopExact = 1;
+  int64_t _topExactListings = 0;   // read-only option "top_exact_listings": listings that took the heaps' path
   // Released quizzes' device buffers, reused by the next StartQuiz / ResumeQuiz of the same dimensions: hipMalloc / hipFree
   // cost tens of microseconds and hipFree synchronises the device.  Reuse is ordered by the engine's stream.
   struct QuizBuffers { double *dPrior; uint32_t *dAsked; int64_t ldT; size_t askedWords; };

@@ -339,7 +339,77 @@ Error HipEngine::GetPriorDevicePtr(int64_t iQuiz, void **ppDev, int64_t *pLdT) {
   return Error();
 }
 
+// Where the listed probabilities (and the next one below the list) are all different, the listing is the reference's whatever the order
+// among equals: the fast listing -- by (probability descending, target ascending) -- with one entry more than asked for says so.  Where
+// they tie, the reference's order is its heaps' (CEListTopTargetsAlgorithm.cpp:30-95), and ListTopTargetsExact reproduces them.
+static bool ListingHasTies(const CiRatedTarget *got, int64_t nGot, int64_t maxCount, int64_t probed) {
+  // (fewer than probed came back: every candidate is listed -- only ties among them matter)
+  (void)probed;
+  for (int64_t i = 0; i + 1 < nGot; i++)
+    if (got[i]._prob == got[i + 1]._prob && i < maxCount) return true;
+  return false;
+}
+
 int64_t HipEngine::ListTopTargets(Error &err, int64_t iQuiz, int64_t maxCount, CiRatedTarget *pDest) {
+  if (maxCount <= 0 || pDest == nullptr || !_optTopExact) return ListTopTargetsFast(err, iQuiz, maxCount, pDest);
+  const int64_t probed = std::min<int64_t>(maxCount, _T) + 1;   // (one beyond the list: the boundary)
+  CiRatedTarget small[kQuizTop + 1];
+  std::vector<CiRatedTarget> large;
+  CiRatedTarget *tmp = small;
+  if (probed > kQuizTop + 1) { large.resize((size_t)probed); tmp = large.data(); }
+  const int64_t n = ListTopTargetsFast(err, iQuiz, probed, tmp);
+  if (n < 0) return n;
+  if (!ListingHasTies(tmp, n, maxCount, probed)) {
+    const int64_t take = std::min(n, maxCount);
+    std::memcpy(pDest, tmp, (size_t)take * sizeof(CiRatedTarget));
+    return take;
+  }
+  return ListTopTargetsExact(err, iQuiz, maxCount, pDest);
+}
+
+// The reference's listing where probabilities tie: on the device for lists of up to 256 targets (kb_kernels.hip: LaunchTopTargetsExact),
+// on the host beyond (the posterior copied: a bulk export, as ListTopTargetsOnHost).
+int64_t HipEngine::ListTopTargetsExact(Error &err, int64_t iQuiz, int64_t maxCount, CiRatedTarget *pDest) {
+  CallScope scope(_activeCallers);
+  std::lock_guard<EngineMutex> lk(_mu);
+  err = CheckRegular("list top targets");
+  if (!err.ok()) return -1;
+  Quiz *q = UseQuiz(err, iQuiz);
+  if (!q) return -1;
+  hipSetDevice(_device);
+  err = FlushUpdates();
+  if (!err.ok()) return -1;
+  const int64_t want = std::min<int64_t>(maxCount, _T);
+  if (want > 256) return ListTopTargetsOnHost(err, q, want, pDest, true);
+  err = EnsureTopExactScratch(1, want);
+  if (!err.ok()) return -1;
+  TopBatchPriors pr;
+  pr.prior[0] = q->dPrior;
+  const uint64_t op = ++_opSeq;
+  const hipError_t he = LaunchTopTargetsExact(View(), pr, 1, _optWorkers, want, _dTopExact, _hPinned->top, &_hPinned->nOut, &_hPinned->topFlag, op, _stream);
+  if (he != hipSuccess) { err = HipErr(he, "ListTopTargets"); return -1; }
+  err = WaitFlag(&_hPinned->topFlag, op, "ListTopTargets");
+  if (!err.ok()) return -1;
+  _mu.busy = false;
+  _pendingRecordOp = 0;
+  _topExactListings++;
+  const int64_t n = std::min<int64_t>(_hPinned->nOut, want);
+  std::memcpy(pDest, _hPinned->top, (size_t)n * sizeof(RatedTargetDev));
+  return n;
+}
+
+Error HipEngine::EnsureTopExactScratch(int64_t nQuizzes, int64_t want) {
+  const size_t need = TopExactScratchBytes(_T, _optWorkers, want, nQuizzes);
+  if (need <= _topExactBytes) return Error();
+  HIP_TRY(hipStreamSynchronize(_stream));
+  if (_dTopExact) hipFree(_dTopExact);
+  _dTopExact = nullptr; _topExactBytes = 0;
+  HIP_TRY(hipMalloc(&_dTopExact, need));
+  _topExactBytes = need;
+  return Error();
+}
+
+int64_t HipEngine::ListTopTargetsFast(Error &err, int64_t iQuiz, int64_t maxCount, CiRatedTarget *pDest) {
   CallScope scope(_activeCallers);
   std::unique_lock<EngineMutex> lk(_mu, std::defer_lock);
   if (!_optCombine || maxCount <= 0 || pDest == nullptr) lk.lock();
@@ -455,13 +525,54 @@ int64_t HipEngine::ListTopTargets(Error &err, int64_t iQuiz, int64_t maxCount, C
 }
 
 // Lists of more than 256 targets: sort on the host (a listing of that length is the caller's bulk export, not a quiz step).
-int64_t HipEngine::ListTopTargetsOnHost(Error &err, Quiz *q, int64_t want, CiRatedTarget *pDest) {
+int64_t HipEngine::ListTopTargetsOnHost(Error &err, Quiz *q, int64_t want, CiRatedTarget *pDest, bool referenceOrder) {
   std::vector<double> pri((size_t)_T);
   hipError_t he = hipMemcpyAsync(pri.data(), q->dPrior, (size_t)_T * sizeof(double), hipMemcpyDeviceToHost, _stream);
   if (he == hipSuccess) he = hipStreamSynchronize(_stream);
   if (he != hipSuccess) { err = HipErr(he, "ListTopTargets"); return -1; }
   _mu.busy = false;
   _pendingRecordOp = 0;
+  if (referenceOrder) {
+    // CEListTopTargetsAlgorithm::RunHeapifyBased (CEListTopTargetsAlgorithm.cpp:30-95) as written, with the C++ library's own heap calls
+    struct Rated { int64_t t; double p; bool operator<(const Rated &o) const { return p < o.p; } };
+    struct Head { double p; int64_t piece; bool operator<(const Head &o) const { return p < o.p; } };
+    const int64_t W = _optWorkers, quot = _T / W, rem = _T % W, nSub = quot == 0 ? rem : W;
+    std::vector<Rated> ratings((size_t)_T);
+    std::vector<int64_t> start((size_t)nSub), lim((size_t)nSub);
+    for (int64_t i = 0; i < nSub; i++) {
+      const int64_t first = i * quot + std::min(i, rem), limit = first + quot + (i < rem ? 1 : 0);
+      int64_t sel = first;
+      for (int64_t t = first; t < limit; t++)
+        if (!BitTest(_hTGap, t) && pri[(size_t)t] > 0.0) ratings[(size_t)sel++] = Rated{t, pri[(size_t)t]};   // CEHeapifyPriorsSubtaskMake.cpp:42-52
+      start[(size_t)i] = first; lim[(size_t)i] = sel;
+      std::make_heap(ratings.begin() + first, ratings.begin() + sel);                                        // :87
+    }
+    std::vector<Head> head;
+    for (int64_t i = 0; i < nSub; i++) if (lim[(size_t)i] != start[(size_t)i]) head.push_back(Head{ratings[(size_t)start[(size_t)i]].p, i});
+    std::make_heap(head.begin(), head.end());
+    int64_t listed = 0;
+    for (; listed < want && !head.empty(); listed++) {
+      const int64_t piece = head.front().piece, ps = start[(size_t)piece];
+      pDest[listed]._iTarget = ratings[(size_t)ps].t; pDest[listed]._prob = head.front().p;
+      if (ps + 1 == lim[(size_t)piece]) { std::pop_heap(head.begin(), head.end()); head.pop_back(); continue; }
+      std::pop_heap(ratings.begin() + ps, ratings.begin() + lim[(size_t)piece]);
+      lim[(size_t)piece]--;
+      head.front().p = ratings[(size_t)ps].p;
+      // SRHeapHelper::Down (SRHeap.h:16-39)
+      size_t cur = 0;
+      for (;;) {
+        const size_t c1 = 2 * cur + 1;
+        if (c1 >= head.size()) break;
+        const size_t c2 = c1 + 1;
+        if (c2 >= head.size()) { if (head[cur] < head[c1]) std::swap(head[cur], head[c1]); break; }
+        const size_t hi = head[c2] < head[c1] ? c1 : c2;
+        if (!(head[cur] < head[hi])) break;
+        std::swap(head[cur], head[hi]);
+        cur = hi;
+      }
+    }
+    return listed;
+  }
   std::vector<int64_t> idx;
   idx.reserve((size_t)_T);
   // gaps and probabilities <= 0 are no candidates (reference PqaCore/CEHeapifyPriorsSubtaskMake.cpp:43-49)
@@ -508,18 +619,23 @@ Error HipEngine::ListTopTargetsBatch(int64_t n, const int64_t *pQuizzes, int64_t
   err = FlushUpdates();
   if (!err.ok()) return err;
   const int64_t want = std::min<int64_t>(maxCount, _T);
+  const bool exact = _optTopExact != 0;
   if (want > 256) {
     for (int64_t i = 0; i < n; i++) {
-      pCounts[i] = ListTopTargetsOnHost(err, quizzes[(size_t)i], want, pDest + i * maxCount);
+      // (bulk exports: on the host, in the reference's order right away)
+      pCounts[i] = ListTopTargetsOnHost(err, quizzes[(size_t)i], want, pDest + i * maxCount, exact);
       if (pCounts[i] < 0) { pCounts[i] = 0; return err; }
     }
     return Error();
   }
+  // the fast listing with one entry beyond the list where that fits (the boundary); a quiz whose listing shows equal probabilities
+  // -- or whose boundary cannot be seen -- is listed again in the reference's own order among them (LaunchTopTargetsExact)
+  const int64_t probe = exact && want + 1 <= 256 && want + 1 <= _T ? want + 1 : want;
   const int64_t group = std::min<int64_t>(n, kTopBatchQuizzes);
-  err = EnsureTopScratch(group, want);
+  err = EnsureTopScratch(group, probe);
   if (!err.ok()) return err;
   // the results' lines: host-coherent, written by the last level's workgroups
-  const int64_t needRecords = group * want;
+  const int64_t needRecords = group * probe;
   if (needRecords > _hTopBatchRecords) {
     HIP_TRY(hipStreamSynchronize(_stream));
     if (_hTopBatch) hipHostFree(_hTopBatch);
@@ -528,20 +644,40 @@ Error HipEngine::ListTopTargetsBatch(int64_t n, const int64_t *pQuizzes, int64_t
     _hTopBatchRecords = needRecords;
   }
   int64_t *hCounts = reinterpret_cast<int64_t *>(_hTopBatch + _hTopBatchRecords);
+  std::vector<int64_t> tied;   // positions in the batch
   for (int64_t first = 0; first < n; first += group) {
     const int64_t m = std::min<int64_t>(group, n - first);
     TopBatchPriors pr;
     for (int64_t i = 0; i < m; i++) pr.prior[i] = quizzes[(size_t)(first + i)]->dPrior;
-    HIP_TRY(LaunchTopTargetsBatch(View(), pr, m, want, _dTopScratch[0], _dTopScratch[1], _hTopBatch, hCounts, nullptr, 0, _stream));
+    HIP_TRY(LaunchTopTargetsBatch(View(), pr, m, probe, _dTopScratch[0], _dTopScratch[1], _hTopBatch, hCounts, nullptr, 0, _stream));
     HIP_TRY(hipStreamSynchronize(_stream));
     for (int64_t i = 0; i < m; i++) {
-      const int64_t c = std::min<int64_t>(hCounts[i], want);
+      const int64_t got = std::min<int64_t>(hCounts[i], probe), c = std::min(got, want);
+      const CiRatedTarget *rec = reinterpret_cast<const CiRatedTarget *>(_hTopBatch + i * probe);
       pCounts[first + i] = c;
-      std::memcpy(pDest + (first + i) * maxCount, _hTopBatch + i * want, (size_t)c * sizeof(RatedTargetDev));
+      std::memcpy(pDest + (first + i) * maxCount, rec, (size_t)c * sizeof(RatedTargetDev));
+      if (exact && ((probe == want && got == want && want < _T) || ListingHasTies(rec, got, want, probe))) tied.push_back(first + i);
     }
   }
   _mu.busy = false;   // (the stream has just been synchronised)
   _pendingRecordOp = 0;
+  if (tied.empty()) return Error();
+  const int64_t tgroup = std::min<int64_t>((int64_t)tied.size(), kTopBatchQuizzes);
+  err = EnsureTopExactScratch(tgroup, want);
+  if (!err.ok()) return err;
+  for (size_t first = 0; first < tied.size(); first += (size_t)tgroup) {
+    const int64_t m = std::min<int64_t>(tgroup, (int64_t)(tied.size() - first));
+    TopBatchPriors pr;
+    for (int64_t i = 0; i < m; i++) pr.prior[i] = quizzes[(size_t)tied[first + (size_t)i]]->dPrior;
+    HIP_TRY(LaunchTopTargetsExact(View(), pr, m, _optWorkers, want, _dTopExact, _hTopBatch, hCounts, nullptr, 0, _stream));   // (want <= probe: the lines hold it)
+    HIP_TRY(hipStreamSynchronize(_stream));
+    for (int64_t i = 0; i < m; i++) {
+      const int64_t at = tied[first + (size_t)i], c = std::min<int64_t>(hCounts[i], want);
+      pCounts[at] = c;
+      std::memcpy(pDest + at * maxCount, _hTopBatch + i * want, (size_t)c * sizeof(RatedTargetDev));
+    }
+    _topExactListings += m;
+  }
   return Error();
 }
 

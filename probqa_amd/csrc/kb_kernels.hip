@@ -400,6 +400,209 @@ __global__ __launch_bounds__(1024) void top_merge_kernel(const TopOut *__restric
 }
 }  // namespace
 
+// ---- ListTopTargets in the REFERENCE'S order among equal probabilities (round 6) --------------------------------------------------
+// Where the listing above shows equal probabilities among the listed targets, or between the last listed and the next, what the
+// reference returns is decided by its heaps (PqaCore/CEListTopTargetsAlgorithm.cpp:30-95): the target axis in one piece per worker
+// thread (CalcSplit), every piece's candidates -- no gaps, prob > 0 -- in index order made a heap (std::make_heap,
+// CEHeapifyPriorsSubtaskMake.cpp:56-88), then a head heap over the pieces' tops that pops maxCount times.  Reproduced step for step:
+//   * top_pieces_kernel, a workgroup per (piece, quiz): the candidates compacted in index order into LDS (a piece of more than 8192
+//     candidates: into global scratch); std::make_heap level by level -- the library sifts the holes n/2 - 1 ... 0 in turn, deeper
+//     levels before shallower ones, and the subtrees of one level are disjoint: a level's holes sift side by side, a barrier between
+//     levels, the same heap --; then ONE thread pops the piece's first maxCount tops, which are what the piece yields whatever the
+//     other pieces do (a piece's heap changes only when its own top is taken);
+//   * top_heads_kernel, a thread per quiz: the head heap over the pieces' first tops (std::make_heap), maxCount times the top, the
+//     piece's next key and SRHeapHelper::Down (SRPlatform/Interface/SRHeap.h:16-39) -- or std::pop_heap when the piece is exhausted.
+// The heap steps are the algorithm MSVC's and libstdc++'s libraries share (the oracle's restatement is held to libstdc++'s).
+namespace {
+struct HeapRec { double prob; int64_t id; };
+__device__ __forceinline__ void heap_push_by_index(HeapRec *first, int64_t hole, int64_t top, HeapRec val) {
+  for (int64_t idx = (hole - 1) >> 1; top < hole && first[idx].prob < val.prob; idx = (hole - 1) >> 1) {
+    first[hole] = first[idx];
+    hole = idx;
+  }
+  first[hole] = val;
+}
+__device__ __forceinline__ void heap_adjust(HeapRec *first, int64_t hole, int64_t bottom, HeapRec val) {
+  const int64_t top = hole;
+  int64_t idx = hole;
+  const int64_t maxNonLeaf = (bottom - 1) >> 1;
+  while (idx < maxNonLeaf) {                         // the hole moves down to the larger child (the right one unless it is less)
+    idx = 2 * idx + 2;
+    if (first[idx].prob < first[idx - 1].prob) --idx;
+    first[hole] = first[idx];
+    hole = idx;
+  }
+  if (idx == maxNonLeaf && bottom % 2 == 0) {        // an only child at the bottom
+    first[hole] = first[bottom - 1];
+    hole = bottom - 1;
+  }
+  heap_push_by_index(first, hole, top, val);
+}
+__device__ __forceinline__ void heap_pop(HeapRec *first, int64_t n) {   // std::pop_heap: the top goes to first[n - 1]
+  if (n < 2) return;
+  const HeapRec val = first[n - 1];
+  first[n - 1] = first[0];
+  heap_adjust(first, 0, n - 1, val);
+}
+__device__ __forceinline__ void heap_down(HeapRec *first, int64_t n) {  // SRHeapHelper::Down
+  int64_t cur = 0;
+  for (;;) {
+    const int64_t c1 = 2 * cur + 1;
+    if (c1 >= n) return;
+    const int64_t c2 = c1 + 1;
+    if (c2 >= n) {
+      if (first[cur].prob < first[c1].prob) { const HeapRec t = first[cur]; first[cur] = first[c1]; first[c1] = t; }
+      return;
+    }
+    const int64_t hi = first[c2].prob < first[c1].prob ? c1 : c2;
+    if (!(first[cur].prob < first[hi].prob)) return;
+    const HeapRec t = first[cur]; first[cur] = first[hi]; first[hi] = t;
+    cur = hi;
+  }
+}
+
+constexpr int kTopPieceThreads = 256;
+constexpr int64_t kTopPieceLds = 8192;               // candidates of a piece held in LDS (128 KB)
+struct TopExactArgs {
+  TopBatchPriors priors;
+  const uint32_t *tgap;
+  int64_t T, quot, rem, nSub, maxCount;              // CalcSplit(T, nWorkers): piece i = [i quot + min(i, rem), ...) of quot + (i < rem) targets
+  HeapRec *heaps;                                    // [quiz][T]: the pieces that do not fit LDS (null: all fit)
+  TopOut *lists;                                     // [quiz][nSub][maxCount]: a piece's first tops, in the order it yields them
+  int32_t *counts;                                   // [quiz][nSub]: min(candidates of the piece, maxCount + 1)
+  TopOut *out;                                       // [quiz][maxCount]
+  int64_t *nOut;                                     // [quiz]
+  uint64_t *flag;                                    // (one quiz) set to flagValue behind the results
+  uint64_t flagValue;
+};
+
+__global__ __launch_bounds__(kTopPieceThreads) void top_pieces_kernel(TopExactArgs a) {
+  extern __shared__ double smem[];
+  __shared__ int64_t waveCount[kTopPieceThreads / kWave];
+  const int tid = threadIdx.x, lane = tid % kWave, wave = tid / kWave;
+  const int64_t piece = blockIdx.x, quiz = blockIdx.y;
+  const int64_t first = piece * a.quot + (piece < a.rem ? piece : a.rem), size = a.quot + (piece < a.rem ? 1 : 0), limit = first + size;
+  const double *prior = a.priors.prior[quiz];
+  HeapRec *h = size <= kTopPieceLds ? reinterpret_cast<HeapRec *>(smem) : a.heaps + quiz * a.T + first;
+  // ---- the candidates, in index order (CEHeapifyPriorsSubtaskMake.cpp:42-52, :66-83)
+  int64_t m = 0;
+  for (int64_t base = first; base < limit; base += kTopPieceThreads) {
+    const int64_t t = base + tid;
+    double p = 0.0;
+    bool ok = t < limit && !bit_test(a.tgap, t);
+    if (ok) { p = prior[t]; ok = p > 0.0; }
+    const unsigned long long mask = __ballot(ok);
+    const int rank = __popcll(mask & ((1ull << lane) - 1ull));
+    if (lane == 0) waveCount[wave] = __popcll(mask);
+    __syncthreads();
+    int64_t off = m;
+    for (int w = 0; w < wave; w++) off += waveCount[w];
+    if (ok) h[off + rank] = HeapRec{p, t};
+    int64_t all = 0;
+    for (int w = 0; w < kTopPieceThreads / kWave; w++) all += waveCount[w];
+    m += all;
+    __syncthreads();
+  }
+  // ---- std::make_heap (:87), level by level
+  if (m >= 2) {
+    const int64_t lastInternal = m / 2 - 1;
+    int L = 0;
+    while (((int64_t)2 << L) - 1 <= lastInternal) L++;          // the deepest level with an internal node: 2^L - 1 <= lastInternal
+    for (; L >= 0; L--) {
+      const int64_t lo = ((int64_t)1 << L) - 1, hiNode = ((int64_t)2 << L) - 2 < lastInternal ? ((int64_t)2 << L) - 2 : lastInternal;
+      for (int64_t j = lo + tid; j <= hiNode; j += kTopPieceThreads) heap_adjust(h, j, m, h[j]);
+      __syncthreads();
+    }
+  }
+  // ---- what the piece yields, in turn: its top, then std::pop_heap (CEListTopTargetsAlgorithm.cpp:74-91)
+  if (tid == 0) {
+    const int64_t cnt = m < a.maxCount ? m : a.maxCount;
+    TopOut *mine = a.lists + (quiz * a.nSub + piece) * a.maxCount;
+    int64_t n = m;
+    for (int64_t r = 0; r < cnt; r++) {
+      mine[r] = TopOut{h[0].id, h[0].prob};
+      if (r + 1 < cnt) { heap_pop(h, n); n--; }
+    }
+    a.counts[quiz * a.nSub + piece] = (int32_t)(m < a.maxCount + 1 ? m : a.maxCount + 1);
+  }
+}
+
+__global__ __launch_bounds__(kWave) void top_heads_kernel(TopExactArgs a) {
+  extern __shared__ double smem[];
+  HeapRec *head = reinterpret_cast<HeapRec *>(smem);           // [nSub]
+  int32_t *taken = reinterpret_cast<int32_t *>(head + a.nSub); // [nSub]
+  const int64_t quiz = blockIdx.x;
+  if (threadIdx.x != 0) return;
+  const TopOut *lists = a.lists + quiz * a.nSub * a.maxCount;
+  const int32_t *counts = a.counts + quiz * a.nSub;
+  int64_t nHh = 0;
+  for (int64_t i = 0; i < a.nSub; i++) {                        // :58-66: the pieces that have a candidate, in piece order
+    taken[i] = 0;
+    if (counts[i] == 0) continue;
+    head[nHh++] = HeapRec{lists[i * a.maxCount].prob, i};
+  }
+  for (int64_t hole = nHh >> 1; hole > 0;) { --hole; heap_adjust(head, hole, nHh, head[hole]); }   // std::make_heap :67
+  TopOut *out = a.out + quiz * a.maxCount;
+  int64_t listed = a.maxCount;
+  for (int64_t i = 0; i < a.maxCount; i++) {                    // :69-95
+    if (nHh == 0) { listed = i; break; }
+    const int64_t piece = head[0].id;
+    out[i] = lists[piece * a.maxCount + taken[piece]];
+    taken[piece]++;
+    if (taken[piece] == counts[piece]) {                        // the piece is exhausted (:81-88)
+      heap_pop(head, nHh);
+      nHh--;
+      continue;
+    }
+    if (i + 1 == a.maxCount) break;                             // (the key behind the last listed target is never looked at)
+    head[0].prob = lists[piece * a.maxCount + taken[piece]].prob;   // :93
+    heap_down(head, nHh);                                       // :94
+  }
+  for (int64_t i = listed; i < a.maxCount; i++) out[i] = TopOut{-1, -1.0};
+  a.nOut[quiz] = listed;
+  if (a.flag != nullptr) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+    __hip_atomic_store(a.flag, a.flagValue, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+}  // namespace
+
+// scratch of the exact listing for nQuizzes quizzes: bytes of {the pieces' lists, their counts, the heaps of pieces beyond LDS}
+size_t TopExactScratchBytes(int64_t T, int64_t nWorkers, int64_t maxCount, int64_t nQuizzes) {
+  const int64_t quot = T / nWorkers, rem = T % nWorkers, nSub = quot == 0 ? rem : nWorkers;
+  const bool big = quot + (rem ? 1 : 0) > kTopPieceLds;
+  return (size_t)nQuizzes * ((size_t)nSub * (size_t)maxCount * sizeof(TopOut) + (size_t)nSub * sizeof(int32_t) + 16 + (big ? (size_t)T * sizeof(HeapRec) : 0));
+}
+hipError_t LaunchTopTargetsExact(const KbView &kb, const TopBatchPriors &priors, int64_t nQuizzes, int64_t nWorkers, int64_t maxCount, void *scratch,
+                                 RatedTargetDev *out, int64_t *nOut, uint64_t *flag, uint64_t flagValue, hipStream_t stream) {
+  if (nQuizzes <= 0 || nQuizzes > kTopBatchQuizzes || maxCount <= 0 || nWorkers < 1 || scratch == nullptr || (flag != nullptr && nQuizzes != 1)) return hipErrorInvalidValue;
+  TopExactArgs a{};
+  a.priors = priors; a.tgap = kb.tgap; a.T = kb.T; a.maxCount = maxCount;
+  a.quot = kb.T / nWorkers; a.rem = kb.T % nWorkers; a.nSub = a.quot == 0 ? a.rem : nWorkers;   // SRPoolRunner::CalcSplit, SRPoolRunner.h:96-110
+  const int64_t pieceMax = a.quot + (a.rem ? 1 : 0);
+  const bool big = pieceMax > kTopPieceLds;
+  char *p = static_cast<char *>(scratch);
+  a.lists = reinterpret_cast<TopOut *>(p);
+  p += (size_t)nQuizzes * a.nSub * maxCount * sizeof(TopOut);
+  a.heaps = big ? reinterpret_cast<HeapRec *>(p) : nullptr;
+  if (big) p += (size_t)nQuizzes * kb.T * sizeof(HeapRec);
+  a.counts = reinterpret_cast<int32_t *>(p);
+  a.out = reinterpret_cast<TopOut *>(out); a.nOut = nOut; a.flag = flag; a.flagValue = flagValue;
+  const size_t shPieces = big ? 16 : (size_t)pieceMax * sizeof(HeapRec);
+  static LaunchCache cache;
+  const int dev = LaunchCache::Device();
+  int dummy = 0;
+  if (shPieces > 64 * 1024 && !cache.Get(dev, 1, &dummy)) {   // (the opt-in to more than 64 KiB of dynamic LDS: once per device, for the largest size)
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(top_pieces_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kTopPieceLds * sizeof(HeapRec)));
+    if (e != hipSuccess) return e;
+    cache.Put(dev, 1, 1);
+  }
+  hipLaunchKernelGGL(top_pieces_kernel, dim3((unsigned)a.nSub, (unsigned)nQuizzes), dim3(kTopPieceThreads), shPieces, stream, a);
+  const size_t shHeads = (size_t)a.nSub * (sizeof(HeapRec) + sizeof(int32_t)) + 16;
+  hipLaunchKernelGGL(top_heads_kernel, dim3((unsigned)nQuizzes), dim3(kWave), shHeads, stream, a);
+  return hipGetLastError();
+}
+
 static int64_t TopBatchLists(int64_t T) { return (T <= 0 ? 1 : (T + kTopChunkTargets - 1) / kTopChunkTargets) * (kTopChunkThreads / kWave); }
 static int64_t TopFanIn(int64_t maxCount) { const int64_t f = kTopMergeCapacity / maxCount; return f < 2 ? 2 : f; }
 // records per quiz each of the two scratch buffers must hold

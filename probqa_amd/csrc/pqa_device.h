@@ -470,8 +470,9 @@ __host__ __device__ constexpr int64_t select_sampled_lds_doubles(int64_t n, int6
 // ---- top-maxCount targets by probability -------------------------------------------------------------------------------
 // Descending probability, lower index first on ties, gaps and probabilities <= 0 never listed (reference
 // PqaCore/CEListTopTargetsAlgorithm.cpp:30-95 over CEHeapifyPriorsSubtaskMake.cpp:42-52).  Ties: the reference lists equal
-// probabilities in the order its per-thread heaps leave them -- a function of the machine's thread count --; here they come by
-// ascending target index.
+// probabilities in the order its per-thread heaps leave them -- a function of the machine's thread count.  These rounds list them by
+// ascending target index; the engine asks for one entry more than its caller, and where that listing shows a tie it is made again
+// by the heaps themselves (kb_kernels.hip: LaunchTopTargetsExact).
 // For a workgroup of up to 1024 threads: every thread holds its E targets (t = tid + e*blockDim) in registers; a round is one wave
 // argmax by DPP / permlane swaps, one LDS exchange and ONE barrier (the per-wave results alternate between two LDS rows by
 // round parity), one 16-lane row argmax over the 16 waves' results, after which every thread knows the round's winner and

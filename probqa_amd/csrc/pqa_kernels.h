@@ -410,6 +410,11 @@ constexpr int kTopBatchQuizzes = 256;
 constexpr int64_t kTopChunkTargets = 4096, kTopMergeCapacity = 16384;
 struct TopBatchPriors { const double *prior[kTopBatchQuizzes]; };
 int64_t TopBatchScratchRecords(int64_t T, int64_t maxCount);
+// ... and in the reference's order among EQUAL probabilities (its per-worker heaps and head heap, reproduced step for step; nWorkers:
+// the emulated thread count): what ListTopTargets returns where the listing above shows a tie.  `scratch`: TopExactScratchBytes bytes.
+size_t TopExactScratchBytes(int64_t T, int64_t nWorkers, int64_t maxCount, int64_t nQuizzes);
+hipError_t LaunchTopTargetsExact(const KbView &kb, const TopBatchPriors &priors, int64_t nQuizzes, int64_t nWorkers, int64_t maxCount, void *scratch,
+                                 RatedTargetDev *out, int64_t *nOut, uint64_t *flag, uint64_t flagValue, hipStream_t stream);
 hipError_t LaunchTopTargetsBatch(const KbView &kb, const TopBatchPriors &priors, int64_t nQuizzes, int64_t maxCount, RatedTargetDev *scratchA,
                                  RatedTargetDev *scratchB, RatedTargetDev *out, int64_t *nOut, uint64_t *flag, uint64_t flagValue,
                                  hipStream_t stream);

@@ -61,6 +61,7 @@ KNOWN = {
     r"eval_questions_f32_dma<6, 2>": 80,                      # Float engines, one quiz, rows of 7681..9216 / 9217..12288 elements
     r"eval_questions_f32_dma<6, 3>": 80,
     r"eval_questions_f32_reg<4>": 32,                         # Float engines, one quiz, rows of 12289..16384 elements
+    r"top_heads_kernel": 40,                                  # ListTopTargets where probabilities tie: one thread per quiz walks the head heap (40 bytes of stack, no spill)
     r"pole_fixup_kernel<16>": 92,                             # the fix-up behind a sweep over rows of 8193..16384 targets (late quiz states only)
 }
 

@@ -266,8 +266,8 @@ def test_batched_argmax_equals_one_by_one(factory):
 
 def test_top_targets_cache_behind_record_answer(factory):
     """RecordAnswer's kernel lists the new posterior's best targets ahead of the ListTopTargets that follows it; whatever
-    path serves the list (that cache, or a launch), it is the descending-probability, lower-index-first listing of the
-    quiz's CURRENT posterior without gaps."""
+    path serves the list (that cache, or a launch), it is the descending-probability listing of the quiz's CURRENT posterior without
+    gaps (the noisy cube's posteriors are all distinct: the order is the sort's; equal probabilities -- tests/test_gpu_top_targets.py)."""
     K, Q, T = 4, 30, 500
     eng, *_ = make(factory, K, Q, T, seed=8)
     eng.set_target_gaps([3, 250, 499])

@@ -64,6 +64,22 @@ if ONLY:
 for n in sorted({1, N, 32, 256}):
     w, d = timed(lambda: e.list_top_targets(quizzes[0], n))
     print("single : top-%d over %d targets: call %.0f us (events: %.0f us)" % (n, T, w, d))
+# ... and where every probability ties (quizzes just started on a knowledge base with equal target counts): the reference's order among
+# equals is its heaps' -- reproduced on the device (LaunchTopTargetsExact) behind the fast listing that found the tie
+fresh, err = f.create_cpu_engine(interop.EngineDefinition(K, Q, T, init_amount=0.1, prec_type=interop.PrecisionType.FLOAT, prec_exponent=8, prec_mantissa=24))
+assert err is None, err
+fresh.set_stream(st.cuda_stream)
+fq = fresh.start_quiz_batch(NQ)
+c_fq = (ctypes.c_int64 * NQ)(*fq)
+for n in sorted({1, N}):
+    c_dest = (interop.CiRatedTarget * (NQ * n))()
+    before = fresh.get_option("top_exact_listings")
+    w, d = timed(lambda: interop._check(interop._lib.PqaEngine_ListTopTargetsBatch(fresh.c_engine, NQ, c_fq, n, c_dest, c_counts)))
+    assert fresh.get_option("top_exact_listings") > before
+    print("all equal: %d quizzes x top-%d over %d targets: C-ABI call %.0f us (the fast listing, then the heaps' order on the device)" % (NQ, n, T, w))
+    w1, d1 = timed(lambda: fresh.list_top_targets(fq[0], n))
+    print("all equal: one quiz, top-%d: call %.0f us" % (n, w1))
+fresh.close()
 w, d = timed(lambda: e.list_top_targets(quizzes[0], 300), reps=5)
 print("single : top-300 (host path: the posterior is copied): call %.0f us" % w)
 e.close()
