@@ -483,7 +483,7 @@ __global__ __launch_bounds__(kTopPieceThreads) void top_pieces_kernel(TopExactAr
   const int64_t piece = blockIdx.x, quiz = blockIdx.y;
   const int64_t first = piece * a.quot + (piece < a.rem ? piece : a.rem), size = a.quot + (piece < a.rem ? 1 : 0), limit = first + size;
   const double *prior = a.priors.prior[quiz];
-  HeapRec *h = size <= kTopPieceLds ? reinterpret_cast<HeapRec *>(smem) : a.heaps + quiz * a.T + first;
+  HeapRec *h = a.heaps == nullptr ? reinterpret_cast<HeapRec *>(smem) : a.heaps + quiz * a.T + first;   // (the launcher's choice, by the largest piece)
   // ---- the candidates, in index order (CEHeapifyPriorsSubtaskMake.cpp:42-52, :66-83)
   int64_t m = 0;
   for (int64_t base = first; base < limit; base += kTopPieceThreads) {

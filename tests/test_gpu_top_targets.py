@@ -185,7 +185,8 @@ def test_few_distinct_values_many_ties(factory):
     """Posteriors of a cube trained without noise: a handful of distinct values, hundreds of targets each -- ties inside the list, at
     its boundary, across pieces.  Single listings, batches, long rows; against the oracle record for record."""
     # (the last two: pieces of more than 8192 candidates -- their heaps live in global memory, not LDS)
-    for (K, Q, T, workers) in ((5, 40, 1000, 16), (5, 12, 5000, 7), (4, 6, 40000, 16), (3, 4, 20000, 3), (4, 5, 40000, 3), (2, 3, 100000, 1)):
+    for (K, Q, T, workers) in ((5, 40, 1000, 16), (5, 12, 5000, 7), (4, 6, 40000, 16), (3, 4, 20000, 3), (4, 5, 40000, 3), (2, 3, 100000, 1),
+                               (2, 3, 24577, 3)):     # (pieces of 8193 / 8192 / 8192: the largest decides for all of them)
         eng, orc = make(factory, K, Q, T, seed=3, noise=0.0)
         eng.set_option("workers", workers)
         gaps = [1, T // 2]
