@@ -323,6 +323,22 @@ def main():
                                       "clock per step, request in hand to answer published"}
         eng.set_option("server", 0)
     kernel_ms = kernel_ms_of(eng, quiz, max(20, min(args.steps, 200)))
+    # ... and the sweep's launch INSIDE the synchronous call `value` times: HIP events recorded by the engine on its stream right
+    # around the launch (option time_sweeps), dispatch to retirement -- what a kernel trace of this command shows per launch
+    # (profiles/): a launch onto an idle device does not overlap its ramp with the previous one's tail as back-to-back launches do
+    sync_kernel_us = None
+    if selector is None and not resident:
+        eng.set_option("time_sweeps", 1)
+        ts = []
+        for _ in range(max(50, min(args.steps, 500))):
+            step()
+            ns = eng.get_option("last_sweep_ns")
+            if ns > 0:
+                ts.append(ns * 1e-3)
+        eng.set_option("time_sweeps", 0)
+        if ts:
+            ts.sort()
+            sync_kernel_us = {"mean": sum(ts) / len(ts), "p10": ts[len(ts) // 10], "p50": ts[len(ts) // 2], "p90": ts[(9 * len(ts)) // 10], "n": len(ts)}
     alg_bytes = q_local * (K + 1) * T * 8  # one read of every sA row and the mD row, fp64
     alg_flops = q_local * K * T * FLOPS_PER_ELEMENT   # ~45 fp64 operations per (question, answer, target)
     launched_us = kernel_ms * 1e3
@@ -665,6 +681,11 @@ def main():
             "kernel_us_source": ("the resident kernel's own 100 MHz clock per step, request in hand to answer published "
                                  "(mean of %d steps; p10/p50/p90 in resident_step_us)" % server_step_us["n"]) if server_step_us
             else "HIP events on the engine's stream around back-to-back launches (mean)",
+            # the same kernel launched onto an IDLE device, as every synchronous call of the timed region launches it: the engine's own
+            # HIP events right around the launch (option time_sweeps; the two event markers included), dispatch to retirement.  A launch
+            # by itself does not overlap its ramp with the previous kernel's tail: rocprofv3's per-launch average over the profiled
+            # command (profiles/r06_S_*: mostly such launches) lies between this and kernel_us
+            "synchronous_launch_us": sync_kernel_us,
             "resident_step_us": server_step_us,
             "launched_kernel": {"kernel": "eval_questions_f64 (%s)" % eng.eval_kernel_name(), "kernel_us": launched_us,
                                 "achieved": alg_bytes / (launched_us * 1e-6) / 1e9,

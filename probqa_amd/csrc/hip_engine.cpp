@@ -284,6 +284,7 @@ HipEngine::~HipEngine() {
   hipFree(_dTGap); hipFree(_dQGap); hipFree(_dAqs); hipFree(_dTopScratch[0]); hipFree(_dTopScratch[1]);
   if (_hTopBatch) hipHostFree(_hTopBatch);
   hipFree(_dTopExact);
+  if (_evSweep[0]) { hipEventDestroy(_evSweep[0]); hipEventDestroy(_evSweep[1]); }
   if (_hPinned) hipHostFree(_hPinned);
   if (_hHostPriority) hipHostFree(_hHostPriority);
   if (_ownStream) hipStreamDestroy(_ownStream);
@@ -330,6 +331,7 @@ Error HipEngine::SetOption(const char *name, int64_t value) {
   else if (n == "pole_fix") { StopServer(); (void)SettlePoleList(); _optPoleFix = value ? 1 : 0; _kbVersion++; }   // (settled while the list is still in view)   // 0: questions with a row at the pole of the lack term keep the sweep's own sums (pole_kernels.hip)
   else if (n == "late_eager") { if (value < 0 || value > 1000000) goto bad; _optLateEager = value; }
   else if (n == "top_exact") { _optTopExact = value ? 1 : 0; }   // 0: equal probabilities always by ascending target (the fast listing alone)
+  else if (n == "time_sweeps") { _optTimeSweeps = value ? 1 : 0; }   // measurement hook (hip_engine_select.cpp: LaunchSingleSweep)
   else if (n == "pole_gate") { StopServer(); (void)SettlePoleList(); _optPoleGate = value ? 1 : 0; }   // 0: a fused argmax's fix redoes every listed question
   else if (n == "pole_lazy") { StopServer(); (void)SettlePoleList(); _optPoleLazy = value ? 1 : 0; }
   else if (n == "pole_follow") { StopServer(); (void)SettlePoleList(); _optPoleFollow = value ? 1 : 0; }   // measurement hook: 0 = the watching sweeps without the fix launched behind them (KbView::poleNoFollow)
@@ -392,6 +394,13 @@ int64_t HipEngine::GetOption(const char *name) const {
   if (n == "late_eager") return _optLateEager;
   if (n == "pole_lazy") return _optPoleLazy;
   if (n == "pole_gate") return _optPoleGate;
+  if (n == "time_sweeps") return _optTimeSweeps;
+  if (n == "last_sweep_ns") {   // the newest timed sweep's launch, dispatch to retirement (-1: none)
+    if (!_sweepTimed || !_evSweep[1]) return -1;
+    float ms = 0;
+    if (hipEventSynchronize(_evSweep[1]) != hipSuccess || hipEventElapsedTime(&ms, _evSweep[0], _evSweep[1]) != hipSuccess) { (void)hipGetLastError(); return -1; }
+    return (int64_t)(ms * 1e6);
+  }
   if (n == "top_exact") return _optTopExact;
   if (n == "top_exact_listings") return _topExactListings;
   if (n == "pole_follow") return _optPoleFollow;

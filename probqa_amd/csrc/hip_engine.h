@@ -540,6 +540,9 @@ class HipEngine : public IEngine {
   int64_t _optPoleFix = 1;               // option "pole_fix"
   int64_t _optPoleFollow = 1;            // option "pole_follow" (measurement hook)
   int64_t _optLateEager = 3;             // option "late_eager": see Quiz::lateStreak (0: speculative sweeps always with the fix-up behind them)
+  int64_t _optTimeSweeps = 0;            // option "time_sweeps" (measurement hook): events around every launched fp64 sweep; read-only "last_sweep_ns"
+  hipEvent_t _evSweep[2] = {nullptr, nullptr};
+  mutable bool _sweepTimed = false;
   int64_t _optPoleGate = 1;              // option "pole_gate": a fused single-quiz ARGMAX has only the listed questions redone that can still win (pole_kernels.hip: pole_bounds_kernel)
   int64_t _optPoleLazy = 1;              // option "pole_lazy": synchronous single-quiz selections launch the fix only when the sweep listed something (FusedSelect::lazyFix)
   int64_t _optLongRowForm = 1;           // option "long_row_form": StartQuiz / RecordAnswer over rows beyond 16384 targets as one workgroup per subtask of the sum

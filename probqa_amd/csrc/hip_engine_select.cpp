@@ -172,7 +172,15 @@ Error HipEngine::LaunchSingleSweep(Quiz *q, const FusedSelect *fused) {
     return Error();
   }
   if (_elem == 8) {
+    // (measurement hook, option "time_sweeps": HIP events on the engine's stream right around this launch -- what the launch of a
+    //  SYNCHRONOUS selection takes on the device, dispatch to retirement, as a profiler's kernel trace sees it; back-to-back launches,
+    //  whose ramps overlap, are shorter)
+    if (_optTimeSweeps) {
+      if (!_evSweep[0]) { HIP_TRY(hipEventCreate(&_evSweep[0])); HIP_TRY(hipEventCreate(&_evSweep[1])); }
+      HIP_TRY(hipEventRecord(_evSweep[0], _stream));
+    }
     HIP_TRY(LaunchEvalQuestions(View(), q->dPrior, q->dAsked, 0, _Q, _dPriority, (int)_optEvalVariant, fused, _stream));
+    if (_optTimeSweeps) { HIP_TRY(hipEventRecord(_evSweep[1], _stream)); _sweepTimed = true; }
     return Error();
   }
   if (_optEvalVariant != 99 && EvalF32RegisterShape(View(), (int)_optEvalVariant))   // (variant 99: the streaming form, as for Double engines)
