@@ -276,7 +276,9 @@ Error HipEngine::IoRows(FILE *f, const char *filePath, bool mD, bool write) {   
     hipEvent_t done[2] = {nullptr, nullptr};
     bool pinned = false;
     std::vector<char> pageable[2];
+    hipStream_t stream = nullptr;
     ~Staging() {
+      (void)hipStreamSynchronize(stream);   // (an early return -- a failed read, a failed copy -- leaves copies in flight: not under buffers about to go)
       for (int i = 0; i < 2; i++) {
         if (pinned && buf[i]) hipHostFree(buf[i]);
         if (done[i]) hipEventDestroy(done[i]);
@@ -284,6 +286,7 @@ Error HipEngine::IoRows(FILE *f, const char *filePath, bool mD, bool write) {   
     }
   } st;
   const int nBuf = _Q > batch ? 2 : 1;
+  st.stream = _stream;
   st.pinned = true;
   for (int i = 0; i < nBuf && st.pinned; i++)
     if (hipHostMalloc((void **)&st.buf[i], bufBytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); st.pinned = false; }

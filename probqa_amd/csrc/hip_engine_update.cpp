@@ -381,6 +381,7 @@ int64_t HipEngine::ListTopTargetsExact(Error &err, int64_t iQuiz, int64_t maxCou
   if (!err.ok()) return -1;
   const int64_t want = std::min<int64_t>(maxCount, _T);
   if (want > 256) return ListTopTargetsOnHost(err, q, want, pDest, true);
+  StopServer();   // (workgroups of up to 128 KB of LDS: no room beside a resident sweep, they would wait for it to idle out)
   err = EnsureTopExactScratch(1, want);
   if (!err.ok()) return -1;
   TopBatchPriors pr;
@@ -632,6 +633,7 @@ Error HipEngine::ListTopTargetsBatch(int64_t n, const int64_t *pQuizzes, int64_t
   // -- or whose boundary cannot be seen -- is listed again in the reference's own order among them (LaunchTopTargetsExact)
   const int64_t probe = exact && want + 1 <= 256 && want + 1 <= _T ? want + 1 : want;
   const int64_t group = std::min<int64_t>(n, kTopBatchQuizzes);
+  StopServer();   // (thousands of workgroups: they would wait for a resident sweep to idle out)
   err = EnsureTopScratch(group, probe);
   if (!err.ok()) return err;
   // the results' lines: host-coherent, written by the last level's workgroups

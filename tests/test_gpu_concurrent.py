@@ -79,6 +79,47 @@ def test_native_learner_threads_same_transcripts_and_combined(factory):
     eng.close()
 
 
+def test_tied_listings_from_many_threads(factory):
+    """A cube trained without noise: the posteriors tie, so most ListTopTargets calls of the learner threads take the reference's heaps
+    on the device (hip_engine_update.cpp: ListTopTargetsExact) -- from 1 and from 32 threads the same transcripts; and Python threads
+    listing three targets each step get, quiz by quiz, what the same script gets alone."""
+    K, Q, T = 5, 200, 1000
+    eng, err = factory.create_cpu_engine(interop.EngineDefinition(K, Q, T, init_amount=0.1))
+    assert err is None
+    eng.set_option("workers", cases.WORKERS)
+    eng.set_option("select", 1)
+    eng.fill_synthetic(8.0, 0.0, 11)
+    one = interop.run_learners(eng, 1, 64, 10, seed=4, train=False)
+    before = eng.get_option("top_exact_listings")
+    many = interop.run_learners(eng, 32, 64, 10, seed=4, train=False)
+    assert one["errors"] == 0 and many["errors"] == 0
+    assert (many["questions"], many["guessed_on_top"], many["transcript_hash"]) == (one["questions"], one["guessed_on_top"], one["transcript_hash"])
+    assert eng.get_option("top_exact_listings") > before        # (ties were met)
+
+    def script(seed, out):
+        rng = np.random.default_rng(seed)
+        quiz = eng.start_quiz()
+        log = []
+        for _ in range(6):
+            q = eng.next_question(quiz)
+            a = int(rng.integers(0, K))
+            eng.record_answer(quiz, a)
+            log.append((q, a, tuple((t.i_target, t.prob) for t in eng.list_top_targets(quiz, 3))))
+        eng.release_quiz(quiz)
+        out.append((seed, log))
+
+    alone, together = [], []
+    for seed in range(24):
+        script(seed, alone)
+    threads = [threading.Thread(target=script, args=(seed, together)) for seed in range(24)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert sorted(together) == sorted(alone)
+    eng.close()
+
+
 def test_combining_can_be_switched_off(factory):
     eng = _engine(factory, 5, 40, 100, 3, 1)
     eng.set_option("combine", 0)
