@@ -155,17 +155,34 @@ template <typename V> __device__ __forceinline__ u4 load_unit_async(const V *p) 
   asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(x) : "v"(p));
   return x;
 }
+// (The registers are named behind the wait, unit by unit.  Nothing in the language keeps the compiler from copying one of them between
+//  the wait and the statement that names it -- tools/vmem_hazards.py reads the BUILT kernel and fails the build lint if it did.  One
+//  statement that holds the wait and all twelve registers was measured: 1.5-4 % slower, the allocator has them all tied at once.)
 template <int NU, int NR> __device__ __forceinline__ void rows_arrived(u4 (&d)[NU], u4 (&rows)[NR][NU]) {
-  static_assert(NR == 5, "five answer rows ahead");
   asm volatile("s_waitcnt vmcnt(0)");
 #pragma unroll
-  for (int j = 0; j < NU; j++)   // (the uses stand behind these empty statements, which stand behind the wait)
-    asm volatile("" : "+v"(d[j]), "+v"(rows[0][j]), "+v"(rows[1][j]), "+v"(rows[2][j]), "+v"(rows[3][j]), "+v"(rows[4][j]));
+  for (int j = 0; j < NU; j++) {   // (the uses stand behind these empty statements, which stand behind the wait)
+    asm volatile("" : "+v"(d[j]));
+#pragma unroll
+    for (int k = 0; k < NR; k++) asm volatile("" : "+v"(rows[k][j]));
+  }
 }
 template <int N, int M> __device__ __forceinline__ void wait_records(u4 (&x)[M]) {
   static_assert(M == 2 || M == 4, "records per thread");
   if constexpr (M == 2) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(x[0]), "+v"(x[1]) : "n"(N));
   else asm volatile("s_waitcnt vmcnt(%4)" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]) : "n"(N));
+}
+// records asked for and waited for in ONE statement: there is no stretch of code in which the compiler believes the registers loaded
+// while they are not (the retry rounds of a poll; the wait also drains whatever else is in flight -- retries are rare)
+template <int M> __device__ __forceinline__ void get_records_now(const ExRec *(&p)[M], u4 (&x)[M]) {
+  static_assert(M == 2 || M == 4, "records per thread");
+  if constexpr (M == 2)
+    asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %3, off sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(x[0]), "=&v"(x[1]) : "v"(p[0]), "v"(p[1]) : "memory");
+  else
+    asm volatile("global_load_dwordx4 %0, %4, off sc1\n\tglobal_load_dwordx4 %1, %5, off sc1\n\tglobal_load_dwordx4 %2, %6, off sc1\n\t"
+                 "global_load_dwordx4 %3, %7, off sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(x[0]), "=&v"(x[1]), "=&v"(x[2]), "=&v"(x[3]) : "v"(p[0]), "v"(p[1]), "v"(p[2]), "v"(p[3]) : "memory");
 }
 template <typename R, int NU>   // NU: 16-byte units of a slice per thread; two workgroups per CU (<= 128 registers)
 __global__ __launch_bounds__(kClusterThreads, 4) void eval_cluster_kernel(ClusterArgs a) {
@@ -773,13 +790,13 @@ __global__ __launch_bounds__(kClusterThreads, 4) void eval_cluster_ahead_kernel(
 // With the answer count a constant the loops over the answers have no trip-count registers and no on-the-spot loads; other answer
 // counts keep eval_cluster_ahead_kernel above (the hand-made waits measured there too, as one kernel with a switch: 3000 x 3 x 60000
 // fp64 +8 %, 2000 x 8 x 50000 fp32 +3 % against it).
-template <typename R, int TPB, int NU, int WPE>
+template <typename R, int TPB, int NU, int WPE, int KC>
 __global__ __launch_bounds__(TPB, WPE) void eval_cluster_five_kernel(ClusterArgs a) {
   typedef typename Vec<R>::type V;
   constexpr int VN = Vec<R>::N;
   constexpr int NW = TPB / kWave;
   constexpr int NG = TPB / 32;                                  // groups of 32 lanes: the column sums
-  constexpr int kRows = 5;                                      // answer rows requested ahead (further ones are fetched on the spot)
+  constexpr int kRows = KC;                                     // answer rows requested ahead: all of the question's
   extern __shared__ double smem[];
   const double *tbl = smem;
   V *lhL = reinterpret_cast<V *>(smem + (NumC<R>::kTable ? kLog2TableDoubles : 0));
@@ -795,7 +812,7 @@ __global__ __launch_bounds__(TPB, WPE) void eval_cluster_five_kernel(ClusterArgs
     for (int i = threadIdx.x; i < kLog2TableDoubles; i += TPB) smem[i] = gLog2TableC[i];
   }
   const int tid = threadIdx.x, lane = tid % kWave, wave = tid / kWave;
-  constexpr int64_t K = 5;                                      // (the launcher sends nothing else here)
+  constexpr int64_t K = KC;                                     // (the launcher sends nothing else here)
   const int64_t ldT = a.ldT;
   const int C = a.C, g = blockIdx.x / C, m = blockIdx.x % C;   // cluster, member (= slice)
   const int nUnits = (int)(ldT / VN), SU = a.sliceUnits;
@@ -834,43 +851,48 @@ __global__ __launch_bounds__(TPB, WPE) void eval_cluster_five_kernel(ClusterArgs
   // the next-but-one question's rows and looked at behind it, with a wait that leaves those rows in flight (get_record_async)
   constexpr int kRounds = 2 * kClusterThreads / TPB;            // records per thread: C x n <= 1024
   struct Polled { u4 x[kRounds]; };
+  auto record_of = [&](const ExRec *recs, int stride, int n, int u) __attribute__((always_inline)) {
+    const int r = tid + u * TPB;
+    const int rc = r < C * n ? r : 0;
+    const int mm = rc / n, kk = rc - mm * n;
+    return recs + (mm * stride + kk);
+  };
   auto gather_issue = [&](const ExRec *recs, int stride, int n, Polled &px) __attribute__((always_inline)) {
-    const int total = C * n;
+#pragma unroll
+    for (int u = 0; u < kRounds; u++) px.x[u] = get_record_async(record_of(recs, stride, n, u));
+  };
+  // one look at the thread's polled records: those that carry the tag go to xch; 1 if all of them did
+  auto take_records = [&](int total, unsigned long long tag, const Polled &px) __attribute__((always_inline)) {
+    int ok = 1;
 #pragma unroll
     for (int u = 0; u < kRounds; u++) {
       const int r = tid + u * TPB;
-      const int rc = r < total ? r : 0;
-      const int mm = rc / n, kk = rc - mm * n;
-      px.x[u] = get_record_async(recs + (mm * stride + kk));
+      if (r < total) {
+        const unsigned long long t = (unsigned long long)px.x[u][2] | ((unsigned long long)px.x[u][3] << 32);
+        if (t == tag) xch[r] = u2d((unsigned long long)px.x[u][0] | ((unsigned long long)px.x[u][1] << 32)); else ok = 0;
+      }
     }
+    return ok;
   };
-  // rowsBehind: the loads of request_question ((kRows + 1) x NU of them) stand behind the records'
-  auto gather_finish = [&](const ExRec *recs, int stride, int n, unsigned long long tag, Polled &px, bool rowsBehind) __attribute__((always_inline)) {
+  // ... and again until every record is there: each round's loads are issued AND waited for in one statement (get_records_now), so
+  // that no register is believed loaded before it is -- and the first look's registers never meet these in a phi
+  auto poll_records = [&](const ExRec *recs, int stride, int n, unsigned long long tag) {
     const int total = C * n;
     unsigned spins = 0;
-    if (rowsBehind) wait_records<(kRows + 1) * NU>(px.x); else wait_records<0>(px.x);   // (the wait's count is an immediate)
     for (;;) {
-      int ok = 1;
+      Polled px;
+      const ExRec *at[kRounds];
 #pragma unroll
-      for (int u = 0; u < kRounds; u++) {
-        const int r = tid + u * TPB;
-        if (r < total) {
-          const unsigned long long t = (unsigned long long)px.x[u][2] | ((unsigned long long)px.x[u][3] << 32);
-          if (t == tag) xch[r] = u2d((unsigned long long)px.x[u][0] | ((unsigned long long)px.x[u][1] << 32)); else ok = 0;
-        }
-      }
-      if (__all(ok)) break;
+      for (int u = 0; u < kRounds; u++) at[u] = record_of(recs, stride, n, u);
+      get_records_now(at, px.x);
+      if (__all(take_records(total, tag, px))) break;
       __builtin_amdgcn_s_sleep(1);
       if (++spins > (1u << 26)) __builtin_trap();               // (minutes: a member died -- no silent hang)
-      gather_issue(recs, stride, n, px);
-      wait_records<0>(px.x);
     }
-    __syncthreads();
   };
   auto gather = [&](const ExRec *recs, int stride, int n, unsigned long long tag) {
-    Polled px;
-    gather_issue(recs, stride, n, px);
-    gather_finish(recs, stride, n, tag, px, false);
+    poll_records(recs, stride, n, tag);
+    __syncthreads();
   };
   auto sum_members = [&](int n, double *out) {
     for (int col = wave; col < n; col += NW) {
@@ -909,10 +931,9 @@ __global__ __launch_bounds__(TPB, WPE) void eval_cluster_five_kernel(ClusterArgs
 #pragma unroll
       for (int j = 0; j < NU; j++) rows[k][j] = load_unit_async(reinterpret_cast<const V *>(base + k * ldT) + ui[j]);
   };
-  // pass 1 of question qq (count cnt) once its rows have arrived: 1/D and the likelihoods into idOut / lhOut (registers); the partial
-  // W_k published.
+  // pass 1 of question qq (count cnt), its rows having arrived (rows_arrived, the caller): 1/D and the likelihoods into idOut / lhOut
+  // (registers); the partial W_k published.
   auto pass1 = [&](int64_t qq, unsigned long long cnt, V (&idOut)[NU], V (&lhOut)[kRows][NU]) __attribute__((always_inline)) {
-    rows_arrived(dN, rows);
 #pragma unroll
     for (int j = 0; j < NU; j++)
 #pragma unroll
@@ -998,6 +1019,7 @@ __global__ __launch_bounds__(TPB, WPE) void eval_cluster_five_kernel(ClusterArgs
   V id[NU], idNext[NU], lhNext[kRows][NU];
   if (q < a.Q) {
     request_question(q);
+    rows_arrived(dN, rows);
     pass1(q, 0, idNext, lhNext);                                // (the first question: nothing to hide behind)
     store_question(q, idNext, lhNext);
 #pragma unroll
@@ -1008,17 +1030,33 @@ __global__ __launch_bounds__(TPB, WPE) void eval_cluster_five_kernel(ClusterArgs
   while (q < a.Q) {
     // ---- pass 1 of the NEXT question; then its successor's rows are requested into the registers that are free again
     const int64_t qNext2 = qNext < a.Q ? next_valid(qNext + a.nClusters) : a.Q;
-    bool rowsBehind = false;
     Polled pw;
+    rows_arrived(dN, rows);                                     // (whether or not there is a next question: no path carries a request past here)
     if (qNext < a.Q) pass1(qNext, round + 1, idNext, lhNext);
     // ---- everybody's partial W of THIS question (published an iteration ago), in slice order: the records are asked for BEFORE the
     // next-but-one question's rows are requested (into the registers pass 1 has just freed), so that their wait leaves those in flight.
     // (Asked for already in front of pass 1's arithmetic, 16 registers held across it: 2921 against 2910 us -- no gain, not kept.)
     // (Each answer's group of 32 lanes reading ITS records itself, no staging in LDS and a barrier less: the reads are 256 bytes apart
     //  instead of one coalesced round -- fp64 2670 -> 2757 us, fp32 1110 -> 1170-1220; not kept.)
-    gather_issue(recW + (size_t)(round & 3) * C * kMaxK, kMaxK, (int)K, pw);
-    if (qNext2 < a.Q) { request_question(qNext2); rowsBehind = true; }
-    gather_finish(recW + (size_t)(round & 3) * C * kMaxK, kMaxK, (int)K, tagBase + round + 1, pw, rowsBehind);
+    // (the request, its wait and the look at the records stand TOGETHER in one branch: the wait's count is an immediate, and a wait
+    //  behind a merge would be a second test of the same condition -- tools/vmem_hazards.py follows the built code's paths without
+    //  knowing that two branches test the same thing.  Without a request behind them the records are asked for and waited for in
+    //  one statement: a tied wait there had the compiler copy the registers to where the other branch leaves them BEFORE the wait.)
+    int seen;
+    if (qNext2 < a.Q) {
+      gather_issue(recW + (size_t)(round & 3) * C * kMaxK, kMaxK, (int)K, pw);
+      request_question(qNext2);
+      wait_records<(kRows + 1) * NU>(pw.x);                     // (the rows just requested stay in flight)
+      seen = take_records(C * (int)K, tagBase + round + 1, pw);
+    } else {
+      const ExRec *at[kRounds];
+#pragma unroll
+      for (int u = 0; u < kRounds; u++) at[u] = record_of(recW + (size_t)(round & 3) * C * kMaxK, kMaxK, (int)K, u);
+      get_records_now(at, pw.x);
+      seen = take_records(C * (int)K, tagBase + round + 1, pw);
+    }
+    if (!__all(seen)) poll_records(recW + (size_t)(round & 3) * C * kMaxK, kMaxK, (int)K, tagBase + round + 1);
+    __syncthreads();
     // W_k over the members, a column per group of 32 lanes (the five in one round), written straight to where pass 2 and the fold look;
     // 1 / W_k (:91) once per workgroup (every thread formed it: a fifth of pass 2's instructions)
     {
@@ -1131,6 +1169,7 @@ __global__ __launch_bounds__(TPB, WPE) void eval_cluster_five_kernel(ClusterArgs
     q = qNext;
     qNext = qNext2;
   }
+  rows_arrived(dN, rows);                                       // (nothing is in flight here -- said where the checker of the built code sees it)
   __syncthreads();
   // the last two questions' sums: their turn-takers wait for them
   if (qPrev2 >= 0 && (int)((round - 2) % (unsigned long long)C) == m) fold(qPrev2, round - 2);
@@ -1184,9 +1223,17 @@ constexpr AheadVariant kAheadVariants[] = {
 constexpr int kAheadVariantCount = (int)(sizeof(kAheadVariants) / sizeof(kAheadVariants[0]));
 constexpr int kAheadDefaultF64 = 2, kAheadDefaultF32 = 2;     // (where the shape is not built -- other than five answers -- shape 1)
 
+constexpr int kFiveMinK = 2, kFiveMaxK = 5;                   // answer counts eval_cluster_five_kernel is built for (six: 254 registers, eight: spills)
 template <typename R>
-const void *ahead_kernel_of(int variant) {
-  if (variant == 2) return reinterpret_cast<const void *>(eval_cluster_five_kernel<R, 256, 2, 2>);   // (five answers only: cluster_shape_of)
+const void *ahead_kernel_of(int variant, int64_t K) {
+  if (variant == 2) {                                           // (two to five answers only: cluster_shape_of)
+    switch (K) {
+      case 2: return reinterpret_cast<const void *>(eval_cluster_five_kernel<R, 256, 2, 2, 2>);
+      case 3: return reinterpret_cast<const void *>(eval_cluster_five_kernel<R, 256, 2, 2, 3>);
+      case 4: return reinterpret_cast<const void *>(eval_cluster_five_kernel<R, 256, 2, 2, 4>);
+      default: return reinterpret_cast<const void *>(eval_cluster_five_kernel<R, 256, 2, 2, 5>);
+    }
+  }
   return reinterpret_cast<const void *>(eval_cluster_ahead_kernel<R>);
 }
 
@@ -1208,10 +1255,10 @@ bool occupancy_two(size_t shmem) {
   return occupancy_reaches(cache, reinterpret_cast<const void *>(eval_cluster_kernel<R, NU>), kClusterThreads, shmem, 2);
 }
 template <typename R>
-bool occupancy_ahead(int variant, size_t shmem) {
-  static LaunchCache cache[kAheadVariantCount + 1];
+bool occupancy_ahead(int variant, int64_t K, size_t shmem) {
+  static LaunchCache cache[kAheadVariantCount + 1][kFiveMaxK + 1];   // (per kernel: the 256 x 2 shape is one per answer count)
   const AheadVariant &v = kAheadVariants[variant - 1];
-  return occupancy_reaches(cache[variant], ahead_kernel_of<R>(variant), v.tpb, shmem, v.perCU);
+  return occupancy_reaches(cache[variant][variant == 2 ? (int)K : 0], ahead_kernel_of<R>(variant, K), v.tpb, shmem, v.perCU);
 }
 
 // Slices as long as the workgroups' LDS allows (72 KB each where two share a CU, the fp64 table included): the fewer members a
@@ -1222,7 +1269,7 @@ bool cluster_shape_of(const KbView &kb, int nCU, int variant, ClusterShape *out)
   constexpr int VN = Vec<R>::N;
   const bool ahead = variant > 0;
   if (kb.K > kMaxK || kb.K < 1 || variant > kAheadVariantCount) return false;
-  if (variant == 2 && kb.K != 5) return false;                  // (256 x 2 is built for questions of five answers)
+  if (variant == 2 && (kb.K < kFiveMinK || kb.K > kFiveMaxK)) return false;   // (256 x 2 is built for questions of two to five answers)
   const AheadVariant v = ahead ? kAheadVariants[variant - 1] : AheadVariant{kClusterThreads, NumC<R>::kTable ? 1 : 2, 2};
   const int64_t nUnits = kb.ldT / VN;
   const size_t ldsPerWg = v.perCU == 2 ? 72 * 1024 : 144 * 1024;
@@ -1253,7 +1300,7 @@ bool cluster_shape_of(const KbView &kb, int nCU, int variant, ClusterShape *out)
   out->nu = ahead ? v.nu : (su <= kClusterThreads ? 1 : 2);
   out->ahead = ahead;
   out->shmem = tableBytes + (size_t)kb.K * su * 16 + kFixedLdsBytes + kExchangeLdsBytes + (ahead ? kAheadLdsBytes + parkBytes : 0);
-  if (ahead) return occupancy_ahead<R>(variant, out->shmem);
+  if (ahead) return occupancy_ahead<R>(variant, kb.K, out->shmem);
   return out->nu == 1 ? occupancy_two<R, 1>(out->shmem) : occupancy_two<R, 2>(out->shmem);
 }
 // KbView::clusterForm (engine option cluster_form): 0 = the default below, 1 = the question-by-question form, 2 = pass 1 a question
@@ -1330,7 +1377,7 @@ hipError_t LaunchEvalCluster(const KbView &kb, const double *prior, const uint32
   const dim3 grid((unsigned)(s.C * s.nClusters));
   if (variant > 0) {
     void *params[] = {&a};
-    e = hipLaunchKernel(f32 ? ahead_kernel_of<float>(variant) : ahead_kernel_of<double>(variant), grid, dim3((unsigned)s.tpb), params, s.shmem, stream);
+    e = hipLaunchKernel(f32 ? ahead_kernel_of<float>(variant, kb.K) : ahead_kernel_of<double>(variant, kb.K), grid, dim3((unsigned)s.tpb), params, s.shmem, stream);
     if (e != hipSuccess) return e;
   } else if (f32) {
     if (s.nu == 1) hipLaunchKernelGGL((eval_cluster_kernel<float, 1>), grid, dim3(kClusterThreads), s.shmem, stream, a);

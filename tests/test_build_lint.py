@@ -2,7 +2,11 @@
 (probqa_amd/csrc/cluster_kernels.hip: get_record_async / load_unit_async, waited for by hand).  Between such a load and its wait
 the compiler believes the destination registers hold the value; spilling or copying them in that window would save stale contents
 and free registers a landing load then overwrites.  The kernels are therefore built with registers to spare, and this test holds
-the build to it: no scratch, no AGPRs, at least 16 of the 256 VGPRs of their occupancy unused.  (hipcc cross-compiles without a GPU.)"""
+the build to it: no scratch, no AGPRs, at least 16 of the 256 VGPRs of their occupancy unused -- and, on the BUILT library,
+tools/vmem_hazards.py walks every kernel's code along its branches: no instruction may name a register while a load into it can
+still be outstanding (round 6: the five-answer long-row kernel of round 5 had eight copies of polled records in front of their
+wait on the path of a cluster's last two questions -- harmless only because a stale record's tag does not match and is polled
+again).  (hipcc cross-compiles without a GPU.)"""
 import os
 import re
 import shutil
@@ -37,7 +41,7 @@ def test_kernels_with_hand_waited_loads_have_registers_to_spare():
         if m and name:
             usage[name][m.group(1)] = int(m.group(2))
     five = {n: u for n, u in usage.items() if "eval_cluster_five_kernel" in n}
-    assert len(five) == 2, sorted(usage)      # Float and Double engines
+    assert len(five) == 8, sorted(usage)      # Float and Double engines, two to five answers
     for n, u in five.items():
         assert u["ScratchSize [bytes/lane]"] == 0 and u["VGPRs Spill"] == 0, (n, u)
         assert u["AGPRs"] == 0, (n, u)
@@ -90,3 +94,44 @@ def test_default_kernels_do_not_touch_scratch():
     # ... and the allowances are not stale: every KNOWN entry still names a kernel that spills
     for p in KNOWN:
         assert any(p in n and r["scratch"] > 0 for n, r in ks.items()), p
+
+
+def test_no_register_is_named_while_a_load_into_it_is_outstanding():
+    import sys
+
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import kernel_resources
+    import vmem_hazards
+
+    if not os.path.exists(kernel_resources.LIB):
+        pytest.skip("libPqaCore.so is not built")
+    kernels = vmem_hazards.disassemble(".")
+    assert len(kernels) > 150, len(kernels)
+    hand_waited = [n for n, ins in kernels.items() if any(op == "global_load_dwordx4" and re.search(r"\b(nt|sc1)\b", args) for _, op, args, _ in ins)]
+    assert sum("eval_cluster_five_kernel" in n for n in hand_waited) == 8, hand_waited
+    bad = {n: vmem_hazards.hazards(ins)[:5] for n, ins in kernels.items()}
+    bad = {n: h for n, h in bad.items() if h}
+    assert not bad, bad
+
+
+def test_the_hazard_walk_sees_a_copy_in_front_of_its_wait():
+    """the checker on a hand-made listing: a polled record copied before the wait that covers it (what round 5's build did), and the same
+    copy behind the wait"""
+    import sys
+
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import vmem_hazards
+
+    def listing(*lines):
+        return [(4 * i, ln.split(None, 1)[0], ln.split(None, 1)[1] if " " in ln else "", None) for i, ln in enumerate(lines)]
+
+    early = listing("global_load_dwordx4 v[98:101], v[190:191], off sc1", "global_load_dwordx4 v[2:5], v[2:3], off nt",
+                    "v_mov_b64_e32 v[120:121], v[100:101]", "s_waitcnt vmcnt(1)", "v_cmp_eq_u64_e32 vcc, s[56:57], v[120:121]", "s_endpgm")
+    late = listing("global_load_dwordx4 v[98:101], v[190:191], off sc1", "global_load_dwordx4 v[2:5], v[2:3], off nt",
+                   "s_waitcnt vmcnt(1)", "v_mov_b64_e32 v[120:121], v[100:101]", "s_waitcnt vmcnt(0)", "v_add_u32_e32 v2, v2, v3", "s_endpgm")
+    assert [h[0] for h in vmem_hazards.hazards(early)] == [8]
+    assert vmem_hazards.hazards(late) == []
+    # a store counts and completes in order; a load into LDS names only its address
+    mixed = listing("global_load_dword v1, v[6:7], off", "global_store_dword v[8:9], v10, off", "s_waitcnt vmcnt(1)", "v_add_u32_e32 v1, v1, v1",
+                    "buffer_load_dword v50, s[4:7], 0 offen lds", "v_add_u32_e32 v50, 4, v50", "s_endpgm")
+    assert vmem_hazards.hazards(mixed) == []
