@@ -550,6 +550,27 @@ __device__ __forceinline__ void sweep_body(EvalArgs a, bool copyTable) {
   const bool watchOn = SERVER ? a.serverWatch : a.poleList != nullptr;
   bool wgSuspect = false;                                     // (a question of this workgroup has passed: into its record)
   if (wave == 0) bestLds[lane] = Best{0.0, -1};   // only wave 0 ever touches these
+  // mD in the ring (the shapes with the priors in LDS: no room for a landing row): 1/D pair by pair, each consumed pair refilled from
+  // the question's first answer row.  At the head of a question that row's whole latency stands between 1/D and pass 1 -- so, with
+  // the answer count a constant (the rows' loop unrolled: no branch in the pairs' loop, the ring no phi), every question but a
+  // workgroup's first has it done inside the LAST answer's pass 2 of the question before it (kHeadInTail): behind pair j's pass 2
+  // the old 1/D of the pair is dead and the next question's mD pair, requested during that answer's pass 1, has long arrived; the
+  // first answer row then has the rest of that pass 2 and the question's reduction to arrive in.
+  constexpr bool kHeadInTail = !kMdLds && KC > 0;
+  [[maybe_unused]] bool firstOfStream = true;
+  auto head_pair = [&](const RowRsrc &rowA, int j) __attribute__((always_inline)) {
+    invD[j].x = ((gapBits >> (2 * j)) & 1) ? 0.0 : div_nr(1.0, ring[j].x);      // :74 andnot(gapMask, 1/D)
+    invD[j].y = ((gapBits >> (2 * j + 1)) & 1) ? 0.0 : div_nr(1.0, ring[j].y);
+    ring[j] = row_load<kStreamHint>(rowA, poff[j]);
+  };
+  auto head_from_ring = [&](const double *qBase) __attribute__((always_inline)) {
+    const RowRsrc rowA = row_rsrc(qBase, rowBytes);
+#pragma unroll
+    for (int j = 0; j < NP; j++) {
+      head_pair(rowA, j);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
   while (q < a.qLimit) {
     const int64_t qn = next_valid(q + gridDim.x);
     const double *qBase = a.cube + q * qStride;
@@ -566,15 +587,9 @@ __device__ __forceinline__ void sweep_body(EvalArgs a, bool copyTable) {
         invD[j].y = ((gapBits >> (2 * j + 1)) & 1) ? 0.0 : div_nr(1.0, dv.y);
         __builtin_amdgcn_sched_barrier(0);
       }
-    } else {
-      const RowRsrc rowA = row_rsrc(qBase, rowBytes);
-#pragma unroll
-      for (int j = 0; j < NP; j++) {
-        invD[j].x = ((gapBits >> (2 * j)) & 1) ? 0.0 : div_nr(1.0, ring[j].x);      // :74 andnot(gapMask, 1/D)
-        invD[j].y = ((gapBits >> (2 * j + 1)) & 1) ? 0.0 : div_nr(1.0, ring[j].y);
-        ring[j] = row_load<kStreamHint>(rowA, poff[j]);
-        __builtin_amdgcn_sched_barrier(0);
-      }
+    } else if (!kHeadInTail || firstOfStream) {
+      head_from_ring(qBase);
+      firstOfStream = false;
     }
     double *part = partAll + qpar * (nPart * WPQ);
     double *rec = pend + nPend * recLen;
@@ -656,6 +671,9 @@ __device__ __forceinline__ void sweep_body(EvalArgs a, bool copyTable) {
       }
       // ---- pass 2 (:95-128)
       double v = 0;
+      // (kHeadInTail, the last answer: the next question's 1/D and the request for its first answer row, pair by pair behind this
+      //  pass 2 -- where no question follows, the prior vector stands in for both rows, as it does for the refill above)
+      [[maybe_unused]] const RowRsrc rowHead = row_rsrc(moreQuestions ? a.cube + qn * qStride : a.prior, rowBytes);
 #pragma unroll
       for (int j = 0; j < NP; j++) {
         double2 pv;
@@ -664,6 +682,7 @@ __device__ __forceinline__ void sweep_body(EvalArgs a, bool copyTable) {
         // Pin the accumulators here: without an opaque use the compiler sinks the whole lack chain (and every log2 it
         // needs) below the loop, which costs 8 live VGPRs per pair; and keep the interleave to one pair at a time.
         asm volatile("" : "+v"(accL), "+v"(hW), "+v"(v));
+        if constexpr (kHeadInTail) { if (lastRow) head_pair(rowHead, j); }
         __builtin_amdgcn_sched_barrier(0);
       }
       if constexpr (kWatch && SERVER) stepSmall = max(stepSmall, v <= kSmallV ? rowGap : INT32_MIN);
