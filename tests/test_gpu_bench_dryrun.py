@@ -21,7 +21,10 @@ def test_bench_gpus_2_self_spawns():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "50", "--warmup", "20", "--no-quiz-loop",
                         "--sharded-configs", "S,L1", "--l1-config", "LS", "--batch", "0"],
                        capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
-    assert r.returncode == 0, r.stderr[-3000:]
+    if r.returncode != 0:   # (the ranks' own tracebacks stand far above the launcher's summary)
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        open(os.path.join(ROOT, "gpurun_out", "dryrun_stderr.txt"), "w").write(r.stderr)
+    assert r.returncode == 0, r.stderr[-12000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
     out = json.loads(lines[0])

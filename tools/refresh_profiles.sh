@@ -34,6 +34,9 @@ bash tools/pole_cost.sh > gpurun_out/r6_pole_fixup_stats.txt 2>&1
 # round 6: the gated fix (late argmax selections), ListTopTargets on the device, the re-routed 10241..16384-target rows, .kb I/O
 python tools/gate_probe.py 1000x5x1000 2000x5x2000 4000x5x4000 10000x5x10000 > gpurun_out/r6_gated_fix_stats.txt 2>&1
 python tools/top_targets_bench.py > gpurun_out/r6_top_targets_stats.txt 2>&1
-{ for t in 10500 12000 14000 16000; do python tools/sweep_timing.py ${t}x5x${t} | tail -1; python tools/sweep_timing.py ${t}x5x${t} cluster_from=16384 | tail -1; done; } > gpurun_out/r6_rows_10241_16384_stats.txt 2>&1
+set +x
+{ for t in 10500 12000 14000 16000; do python tools/sweep_timing.py ${t}x5x${t} 2>/dev/null | tail -1; python tools/sweep_timing.py ${t}x5x${t} cluster_from=16384 2>/dev/null | tail -1; done; } > gpurun_out/r6_rows_10241_16384_stats.txt
 { python tools/kb_io_bench.py 10000x5x10000; python tools/kb_io_bench.py 3000x5x100000 f32; } > gpurun_out/r6_kb_io_stats.txt 2>&1
+# long rows by answer count (two to five: eval_cluster_five_kernel; six: round 4's kernel); each twice, the engine of the first run of a process being the coldest
+{ for k in 2 3 4 5 6; do python tools/f32_single_bench.py 2000 $k 100000 20 2>/dev/null; python tools/f32_single_bench.py 2000 $k 100000 20 2>/dev/null; done; } > gpurun_out/r6_long_rows_by_answers_stats.txt
 echo refresh r6 done
