@@ -636,11 +636,6 @@ __device__ __forceinline__ void sweep_body(EvalArgs a, bool copyTable) {
       }
       const double sLane = s0 + s1;
       double Wk = wave_sum(sLane);                             // :88
-#if defined(PQA_ABLATE_EXCHANGE)   // measurement only (wrong values): the row's W_k is the wave's own sum
-      Wk *= (double)WPQ;
-#elif defined(PQA_ABLATE_EXCHANGE_KEEP_BARRIER)
-      if constexpr (WPQ > 1) { __syncthreads(); Wk *= (double)WPQ; }
-#else
       if constexpr (WPQ > 1) {
         double *buf = redW + phase * WPQ;
         if (lane == 0) buf[wave] = Wk;
@@ -648,7 +643,6 @@ __device__ __forceinline__ void sweep_body(EvalArgs a, bool copyTable) {
         Wk = row_sum<WPQ>(buf[lane % WPQ]);
         phase ^= 1;
       }
-#endif
       if constexpr (kWatch) {
         // Does this lane's sum reach a quarter of W_k / nearly all of it (a share of 1 - 2^-9)?  On the high words -- an integer add
         // and compare each, the bars a little (2^-9 ... 2^-8) on the generous side; lanes of padding, sum 0, do not pass -- per lane and
