@@ -87,7 +87,7 @@ PQACORE_API void *PqaEngineFactory_CreateHipEngineSharded(void *pvFactory, void 
  * "cluster_from" (rows of more than this many elements -- 1024..16384, default 10240: what the register shapes hold without spilling -- take the
  * cluster sweep, a question over a cluster of workgroups), "cluster_form" (that sweep: 0 = default, 1 = question by question, 2 = pass 1 a question
  * ahead of the exchange), "cluster_shape" (threads x 16-byte units per thread of the form that runs ahead: 0 = default, 1 = 512 x 1, 2 = 256 x 2;
- * two workgroups per CU both),
+ * two workgroups per CU both; 256 x 2 is built for questions of two to five answers, other answer counts take 512 x 1),
  * Read-only: "server_last_step_ns" (device-side duration of the newest finished step of the resident sweep: request in hand
  * to answer published, from the kernel's own 100 MHz clock; -1 if there is none), "precision" (TPqaPrecisionType of the engine: 1 = Float, 3 = Double), "server_active",
  * "ldT", "device". */
