@@ -880,13 +880,19 @@ hipError_t LaunchEvalBatch(const KbView &kb, const QuizSlot *slots, int nSlots, 
   // is a whole number -- a lane is a quiz, and lanes a small batch leaves over take further questions (eval_batch_kernel)
   const int Bp = ((nSlots + 63) / 64) * 64;
   const int Bq = nSlots <= 32 ? 32 : Bp;
-  // questions per block: the more, the fewer prior loads and tile reads per element -- and the more registers
-  const int qb = plan->questionsPerBlock > 0 ? plan->questionsPerBlock : (f32 ? 4 : 2);
+  // questions per lane and block: the more, the fewer prior loads and tile reads per element -- and the more registers, the fewer
+  // and longer lane-tasks.  Measured over batch sizes and cubes in round 6 (tools/batch_bench.py, one box per table): fp64 is
+  // better off with ONE at every batch size (1000 x 5 x 1000: 32 quizzes 0.94 -> 0.60 ms, 256: 1.33 -> 1.16; 10000 x 5 x 10000, 256:
+  // 117.6 -> 108.9 ms; 2000 x 5 x 100000: 32 quizzes 95.5 -> 56.3 ms, 256: 233 -> 199), fp32 with one up to 32 quizzes
+  // (12500 x 5 x 100000: 125.5 -> 102.7 ms; 2000 x 5 x 100000: 74.1 -> 39.8), two up to 128 (64: 178.6 -> 150.6, 128: 287 -> 270)
+  // and four beyond -- what rounds 3-5 had for every size was tuned at 256 quizzes of fp32
+  const int qb = plan->questionsPerBlock > 0 ? plan->questionsPerBlock : !f32 ? 1 : nSlots <= 32 ? 1 : nSlots <= 128 ? 2 : 4;
   // groups: as many as the lanes allow while every CU still gets a workgroup (a small cube keeps its waves apart instead)
   static LaunchCache devInfo;
   const int nCUs = devInfo.NumCUs(LaunchCache::Device());
   int G = 256 % Bq == 0 ? 256 / Bq : 1;
   if (plan->questionGroups > 0) G = std::min(G, 1 << (31 - __builtin_clz((unsigned)plan->questionGroups)));
+  else if (f32 && G >= 4) G >>= 1;   // (fp32, same tables: half the groups the lanes allow -- 32 quizzes 110.7 -> 102.7 ms with four instead of eight, 64: 161.4 -> 150.6 with two)
   else while (G > 1 && (kb.Q + (int64_t)G * qb - 1) / ((int64_t)G * qb) < (f32 ? nCUs : nCUs * 3 / 4)) G >>= 1;   // (measured: tools/batch_bench.py)
   const int nThreads = G * Bq;
   BatchArgs a{};
