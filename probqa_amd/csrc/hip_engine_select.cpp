@@ -395,8 +395,14 @@ Error HipEngine::BatchSweep(BatchCtx &c, int64_t n, const int64_t *pQuizzes, std
   // leaves most of the chip's 1024 SIMDs without a wave (1000 x 5 x 1000, 64 quizzes: 500 waves, 40 k selections/s against
   // 92 k for grid.y = quiz, whose 48 MB cube is re-read from the Infinity Cache), while 256 quizzes fill it (133 k vs 95 k).
   // batch_min = 0 (default) decides by the wave count; an explicit value decides by the batch size alone.
+  // (the count is in waves of TWO questions per lane, what the fp64 sweep had when the bar was measured; with one per lane since
+  //  round 6 the bars were measured again -- tools/batch_bench.py, row-sharing against grid.y, ms per batch: 1000 x 5 x 1000 64 quizzes
+  //  0.61 / 0.41, 128: 0.77 / 0.76, 192: 1.29 / 1.15, 256: 1.21 / 1.47 -- as before; 2000 x 5 x 2000 32: 1.24 / 1.10, 48: 1.55 / 2.00,
+  //  64: 1.53 / 1.99, 128: 2.35 / 3.84 -- the row-sharing sweep from 33 quizzes on where rows are longer than 1024 targets and it has a
+  //  thousand such waves; 4000 x 5 x 4000 and 10000 x 5 x 10000: from 32 quizzes, as before)
   const int64_t qb = _optBatchQb > 0 ? _optBatchQb : (_elem == 4 ? 4 : 2), wavesRowSharing = ((n + 63) / 64) * ((_Q + qb - 1) / qb);
-  bool rowSharing = _elem == 4 || wantPriorities || (_optBatchMin > 0 ? n >= _optBatchMin : (n >= 32 && wavesRowSharing >= 1536));
+  bool rowSharing = _elem == 4 || wantPriorities ||
+                    (_optBatchMin > 0 ? n >= _optBatchMin : (n >= 32 && (wavesRowSharing >= 1536 || (n > 32 && _ldT > 1024 && wavesRowSharing >= 1000))));
   // ... and between the two, for a few dozen quizzes over short rows (a server's combined sweeps): a lane is a (quiz, chunk of the
   // row) -- batch_kernels.hip: eval_midbatch_kernel.  Option batch_form: 0 = by these rules, 1 grid.y = quiz, 2 row-sharing, 3 this one.
   // By the measured costs at 1000 x 5 x 1000 (tools/midbatch_bench.py): grid.y ~11.3 us per quiz + 25; this form 87 / 138 / 229 us for up
