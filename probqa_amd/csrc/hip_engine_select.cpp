@@ -406,9 +406,10 @@ Error HipEngine::BatchSweep(BatchCtx &c, int64_t n, const int64_t *pQuizzes, std
   // ... and between the two, for a few dozen quizzes over short rows (a server's combined sweeps): a lane is a (quiz, chunk of the
   // row) -- batch_kernels.hip: eval_midbatch_kernel.  Option batch_form: 0 = by these rules, 1 grid.y = quiz, 2 row-sharing, 3 this one.
   // By the measured costs at 1000 x 5 x 1000 (tools/midbatch_bench.py): grid.y ~11.3 us per quiz + 25; this form 87 / 138 / 229 us for up
-  // to 8 / 16 / 32 quizzes (its lanes come in 8, 16 or 32 quiz slots) and 6.2 us per slot of 64 beyond: it wins at 7 and 8 quizzes and from
-  // 11 on, except 17 and 18.
-  bool mid = EvalMidBatchSupported(View()) && ((_optBatchForm == 0 && !rowSharing && (n == 7 || n == 8 || (n >= 11 && n <= 16) || n >= 19)) || _optBatchForm == 3);
+  // to 8 / 16 / 32 quizzes (its lanes come in 8, 16 or 32 quiz slots) and 6.2 us per slot of 64 beyond: it won at 7 and 8 quizzes and from
+  // 11 on, except 17 and 18.  Round 6, measured again (grid.y / this form, us per batch): 6: 91 / 91, 7: 103 / 92, 9: 145 / 133, 10: 157 / 134,
+  // 12: 182 / 131, 17: 248 / 213, 18: 260 / 211, 24: 339 / 214, 32: 443 / 221 -- from seven quizzes on.
+  bool mid = EvalMidBatchSupported(View()) && ((_optBatchForm == 0 && !rowSharing && n >= 7) || _optBatchForm == 3);
   if (_optBatchForm == 1 && _elem == 8) { rowSharing = false; mid = false; }   // (with priorities wanted too: the quizzes' own vectors, CollectBatchPriorities)
   if (_optBatchForm == 2) { rowSharing = true; mid = false; }
   if (mid) rowSharing = false;
